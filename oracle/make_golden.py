@@ -1,0 +1,264 @@
+"""Generate tests/golden/*.npz from the upstream reference (dev container only).
+
+TEST INFRASTRUCTURE.  Imports /root/reference through oracle/ref_import.py,
+loads numpy-seeded weights (oracle/weights.py) into the reference modules,
+runs them with explicit noise, records inputs/outputs, and cross-checks the
+oracle restatement (oracle/oracle.py) against the reference on every case.
+
+    python oracle/make_golden.py            # regenerate everything
+
+Nothing from /root/reference is copied: the fixtures hold only tensors.
+"""
+import contextlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from oracle import ref_import, weights as Wt  # noqa: E402
+
+GOLD = Wt.GOLDEN_DIR
+torch.set_grad_enabled(False)
+
+
+@contextlib.contextmanager
+def patched_randn(noises):
+    """torch.randn pops from `noises` (spec_denoiser.py:180, diffusion_utils.py:65-68)."""
+    queue = list(noises)
+    real = torch.randn
+
+    def fake(*shape, **kw):
+        t = queue.pop(0)
+        shp = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else shape
+        assert tuple(t.shape) == tuple(shp), (t.shape, shp)
+        return t.clone()
+
+    torch.randn = fake
+    try:
+        yield queue
+    finally:
+        torch.randn = real
+
+
+def build_ref_model(hp, timesteps, overrides=None):
+    hp["timesteps"] = timesteps
+    for k, v in (overrides or {}).items():
+        hp[k] = v
+    from modules.speech_editing.spec_denoiser import spec_denoiser as SD
+    from modules.speech_editing.spec_denoiser.diffnet import DiffNet
+    SD.tqdm = lambda it, **kw: it
+    m = SD.GaussianDiffusion(list(range(80)), 80, DiffNet(80), timesteps=timesteps, time_scale=1,
+                             loss_type="l1", spec_min=[], spec_max=[])
+    m.eval()
+    return m
+
+
+def manifest_of(module):
+    return [(k, list(v.shape)) for k, v in module.state_dict().items()]
+
+
+def load_seeded(module, seed):
+    man = [(k, tuple(s)) for k, s in manifest_of(module)]
+    W = Wt.seeded_weights(man, seed)
+    missing, unexpected = module.load_state_dict(W, strict=False)
+    assert not unexpected, unexpected
+    assert all(Wt.is_buffer(k) for k in missing), missing
+    return W
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+def infer_case(hp, name, B, T, T_txt, steps, wseed, iseed, pad_tail=False, overrides=None,
+               trace_layers=(), flags=None, keep_steps=None):
+    flags = flags or {}
+    model = build_ref_model(hp, steps, overrides)
+    W = load_seeded(model, wseed)
+    inp = Wt.synthetic_inputs(B, T, T_txt, seed=iseed, pad_tail=pad_tail)
+    noises = Wt.synthetic_noises(B, T, steps, seed=iseed + 1)
+    rec = {"x0": [], "x": [], "layers": {}}
+    hooks = []
+    step_ctr = {"n": 0}
+
+    def dn_hook(mod, args, out):
+        rec["x0"].append(out.clone())
+        step_ctr["n"] += 1
+
+    hooks.append(model.denoise_fn.register_forward_hook(dn_hook))
+    for li in trace_layers:
+        def mk(li):
+            def h(mod, args, out):
+                if step_ctr["n"] == 0:  # first executed step only
+                    rec["layers"][li] = (out[0].clone(), out[1].clone())
+            return h
+        hooks.append(model.denoise_fn.residual_layers[li].register_forward_hook(mk(li)))
+    orig_qps = model.q_posterior_sample
+
+    def qps(x_start, x_t, t, repeat_noise=False):
+        r = orig_qps(x_start=x_start, x_t=x_t, t=t, repeat_noise=repeat_noise)
+        rec["x"].append(r.clone())
+        return r
+
+    model.q_posterior_sample = qps
+    with patched_randn(noises) as q:
+        ret = model(inp["txt_tokens"], inp["time_mel_masks"].clone(), inp["mel2ph"].clone(), inp["spk_embed"],
+                    inp["ref_mels"], inp["f0"].clone(), inp["uv"].clone(), infer=True, **flags)
+        assert len(q) == 0
+    for h in hooks:
+        h.remove()
+    # ---- oracle cross-check
+    dcl = hp["dilation_cycle_length"]
+    otrace = []
+    oret = O.gaussian_diffusion_infer(W, steps, inp, noises, dilation_cycle_length=dcl, trace=otrace, **flags)
+    d_mel = maxdiff(oret["mel_out"], ret["mel_out"])
+    d_cond = maxdiff(oret["decoder_inp"], ret["decoder_inp"])
+    d_dur = maxdiff(oret["dur"], ret["dur"])
+    d_pp = maxdiff(oret["pitch_pred"], ret["pitch_pred"])
+    assert torch.equal(oret["mel2ph"], ret["mel2ph"])
+    print("  [%s] oracle vs reference: mel %.2e cond %.2e dur %.2e pitch_pred %.2e" % (name, d_mel, d_cond, d_dur, d_pp))
+    assert max(d_mel, d_cond, d_dur, d_pp) < 2e-5, "oracle restatement deviates from the reference"
+    for k in range(steps):
+        assert maxdiff(otrace[k][0], rec["x0"][k]) < 2e-5 and maxdiff(otrace[k][1], rec["x"][k]) < 2e-5
+    # integer intermediates from the oracle (the reference does not expose them) --
+    # they are validated indirectly: decoder_inp embeds them, so any bin mismatch shows up in d_cond.
+    out = dict(
+        meta=np.array(json.dumps(dict(B=B, T=T, T_txt=T_txt, steps=steps, wseed=wseed, iseed=iseed,
+                                      pad_tail=pad_tail, overrides=overrides or {}, flags=flags,
+                                      trace_layers=list(trace_layers)))),
+        mel_out=ret["mel_out"], decoder_inp=ret["decoder_inp"], dur=ret["dur"], mel2ph=ret["mel2ph"],
+        pitch_pred=ret["pitch_pred"], f0_denorm=ret["f0_denorm"], f0_denorm_pred=ret["f0_denorm_pred"],
+        masked_dur=oret["masked_dur"], masked_pitch=oret["masked_pitch"], pitch=oret["pitch"],
+    )
+    ks = range(steps) if keep_steps is None else keep_steps
+    for k in ks:
+        out["x0_step%d" % k] = rec["x0"][k]
+        out["x_step%d" % k] = rec["x"][k]
+    for li, (xl, sl) in rec["layers"].items():
+        out["layer%d_x" % li] = xl
+        out["layer%d_skip" % li] = sl
+    npz(name, **out)
+    return model
+
+
+def train_case(hp, name, B, T, T_txt, steps, wseed, iseed):
+    model = build_ref_model(hp, steps)
+    W = load_seeded(model, wseed)
+    inp = Wt.synthetic_inputs(B, T, T_txt, seed=iseed, pad_tail=True)
+    rng = np.random.default_rng(iseed + 7)
+    t = torch.from_numpy(rng.integers(0, steps + 1, size=(B,), dtype=np.int64))
+    eps = torch.from_numpy(rng.standard_normal(size=(B, 1, 80, T), dtype=np.float32))
+    real_randint, real_rl = torch.randint, torch.randn_like
+    torch.randint = lambda *a, **k: t.clone()
+    torch.randn_like = lambda x, **k: eps.clone()
+    try:
+        ret = model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"],
+                    inp["ref_mels"], inp["f0"].clone(), inp["uv"].clone(), infer=False)
+    finally:
+        torch.randint, torch.randn_like = real_randint, real_rl
+    oret = O.gaussian_diffusion_train(W, steps, inp, t, eps)
+    d = maxdiff(oret["mel_out"], ret["mel_out"])
+    print("  [%s] oracle vs reference (train branch): mel %.2e" % (name, d))
+    assert d < 2e-5
+    npz(name, meta=np.array(json.dumps(dict(B=B, T=T, T_txt=T_txt, steps=steps, wseed=wseed, iseed=iseed,
+                                            pad_tail=True))),
+        t=t, eps=eps, mel_out=ret["mel_out"], x_t=oret["x_t"], decoder_inp=ret["decoder_inp"])
+
+
+def schedule_case(hp):
+    out = {}
+    for steps in (4, 8, 100):
+        m = build_ref_model(hp, steps)
+        tab, tab64 = O.diffusion_tables(steps)
+        for k in tab:
+            ref = getattr(m, k)
+            assert torch.equal(ref, tab[k]), (steps, k)
+            out["s%d_%s" % (steps, k)] = ref
+        out["s%d_betas64" % steps] = tab64["betas"]
+    npz("schedule", **out)
+
+
+def length_regulator_case():
+    from modules.commons.nar_tts_modules import LengthRegulator
+    rng = np.random.default_rng(99)
+    dur = torch.from_numpy(rng.uniform(0, 6, size=(3, 12)).astype(np.float32))
+    pad = torch.zeros(3, 12, dtype=torch.bool)
+    pad[1, 9:] = True
+    pad[2, 5:] = True
+    ref = LengthRegulator()(dur, pad)
+    mine = O.length_regulator(dur, pad)
+    assert torch.equal(ref, mine)
+    npz("length_regulator", dur=dur, pad=pad, mel2ph=ref)
+
+
+def hifigan_case(name, h, B, T, wseed, iseed):
+    from modules.vocoder.hifigan.hifigan import HifiGanGenerator
+    g = HifiGanGenerator(h).eval()
+    man = manifest_of(g)
+    W = Wt.seeded_weights([(k, tuple(s)) for k, s in man], wseed)
+    g.load_state_dict(W, strict=True)
+    with open(os.path.join(GOLD, "manifest_%s.json" % name), "w") as f:
+        json.dump(man, f)
+    rng = np.random.default_rng(iseed)
+    mel = torch.from_numpy(np.clip(rng.normal(-3.0, 1.5, size=(B, 80, T)), -6.0, 1.5).astype(np.float32))
+    wav = g(mel)
+    mine = O.hifigan_forward(W, h, mel)
+    d = maxdiff(wav, mine)
+    print("  [%s] oracle vs reference: wav %.2e (|wav| max %.3f)" % (name, d, float(wav.abs().max())))
+    assert d < 2e-5
+    npz(name, meta=np.array(json.dumps(dict(h=h, B=B, T=T, wseed=wseed, iseed=iseed))), mel=mel, wav=wav)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    hp = ref_import.install(timesteps=4)
+    base = dict(residual_layers=20, residual_channels=256, dilation_cycle_length=1)
+    schedule_case(hp)
+    m = build_ref_model(hp, 4, base)
+    with open(os.path.join(GOLD, "manifest_spec_denoiser.json"), "w") as f:
+        json.dump(manifest_of(m), f)
+    infer_case(hp, "infer_tiny", B=2, T=64, T_txt=16, steps=4, wseed=11, iseed=101, overrides=base,
+               trace_layers=(0, 1, 19))
+    infer_case(hp, "infer_pad", B=3, T=96, T_txt=24, steps=8, wseed=12, iseed=102, pad_tail=True, overrides=base,
+               keep_steps=(0, 7))
+    infer_case(hp, "infer_drift100", B=1, T=64, T_txt=16, steps=100, wseed=13, iseed=103, overrides=base,
+               keep_steps=(0, 99))
+    infer_case(hp, "infer_predpitch", B=2, T=64, T_txt=16, steps=2, wseed=14, iseed=104, overrides=base,
+               flags=dict(use_pred_pitch=True), keep_steps=(1,))
+    ov = dict(residual_layers=6, residual_channels=256, dilation_cycle_length=4)
+    m = build_ref_model(hp, 2, ov)
+    with open(os.path.join(GOLD, "manifest_spec_denoiser_dil.json"), "w") as f:
+        json.dump(manifest_of(m), f)
+    infer_case(hp, "infer_dil", B=1, T=80, T_txt=20, steps=2, wseed=15, iseed=105, overrides=ov,
+               trace_layers=(2, 3), keep_steps=(0, 1))
+    ov = dict(residual_layers=3, residual_channels=64, dilation_cycle_length=2)
+    m = build_ref_model(hp, 2, ov)
+    with open(os.path.join(GOLD, "manifest_spec_denoiser_c64.json"), "w") as f:
+        json.dump(manifest_of(m), f)
+    infer_case(hp, "infer_c64", B=2, T=48, T_txt=12, steps=2, wseed=16, iseed=106, overrides=ov, keep_steps=(1,))
+    hp.update(base)
+    train_case(hp, "train_tiny", B=2, T=64, T_txt=16, steps=8, wseed=17, iseed=107)
+    length_regulator_case()
+    hifigan_case("hifigan_tiny", Wt.HIFIGAN_TINY, B=2, T=24, wseed=21, iseed=201)
+    hifigan_case("hifigan_tiny_rb2", Wt.HIFIGAN_TINY_RB2, B=1, T=20, wseed=22, iseed=202)
+    hifigan_case("hifigan_v1", Wt.HIFIGAN_V1, B=1, T=12, wseed=23, iseed=203)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,428 @@
+"""CPU oracle for the FluentSpeech spec_denoiser hot path + HiFi-GAN generator.
+
+TEST INFRASTRUCTURE.  This file is the *checker*, never the product:
+only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may
+import it.  The product path (speech-editing-toolkit_amd/) never imports
+anything under oracle/ and fails loudly when the HIP library is missing.
+
+It is a functional restatement (plain torch CPU ops over a flat
+{state_dict key -> tensor} weight dict) of the reference algorithm, written
+from the equations in SURVEY.md section 8a; each function cites the reference
+file:line it follows (paths relative to the upstream repo root).
+
+Pinning: the reference has no tests and no golden vectors,
+so this oracle is pinned against outputs of the reference itself, imported in
+the development container by oracle/make_golden.py; the resulting vectors are
+committed under tests/golden/ and re-checked by tests/test_oracle_golden.py.
+Third-party arithmetic is torch (CPU, mkldnn); no reference test pins results
+at that boundary, so beyond those fixtures parity is unpinned.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# a1/a2: noise schedule + diffusion tables
+# --------------------------------------------------------------------------
+def vpsde_betas(timesteps_plus_1, min_beta=0.1, max_beta=40.0):
+    """modules/speech_editing/spec_denoiser/diffusion_utils.py:16-18,36-38.
+
+    beta_t = 1 - exp(-min/T' - 0.5 (max-min) (2t-1)/T'^2), t = 1..T' (fp64)."""
+    Tp = int(timesteps_plus_1)
+    t = np.arange(1, Tp + 1, dtype=np.float64)
+    return 1.0 - np.exp(-min_beta / Tp - 0.5 * (max_beta - min_beta) * (2.0 * t - 1.0) / (Tp ** 2))
+
+
+def diffusion_tables(timesteps, betas=None):
+    """spec_denoiser.py:26-69: fp64 cumprod tables -> fp32 buffers.
+
+    NB the schedule has timesteps+1 entries (spec_denoiser.py:31) while
+    num_timesteps = int(timesteps) (spec_denoiser.py:42)."""
+    if betas is None:
+        betas = vpsde_betas(int(timesteps) + 1)
+    betas = np.asarray(betas, dtype=np.float64)
+    alphas = 1.0 - betas
+    ac = np.cumprod(alphas, axis=0)
+    ac_prev = np.append(1.0, ac[:-1])
+    pv = betas * (1.0 - ac_prev) / (1.0 - ac)
+    tab64 = {
+        "betas": betas,
+        "alphas_cumprod": ac,
+        "alphas_cumprod_prev": ac_prev,
+        "sqrt_alphas_cumprod": np.sqrt(ac),
+        "sqrt_one_minus_alphas_cumprod": np.sqrt(1.0 - ac),
+        "log_one_minus_alphas_cumprod": np.log(1.0 - ac),
+        "sqrt_recip_alphas_cumprod": np.sqrt(1.0 / ac),
+        "sqrt_recipm1_alphas_cumprod": np.sqrt(1.0 / ac - 1.0),
+        "posterior_variance": pv,
+        "posterior_log_variance_clipped": np.log(np.maximum(pv, 1e-20)),
+        "posterior_mean_coef1": betas * np.sqrt(ac_prev) / (1.0 - ac),
+        "posterior_mean_coef2": (1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac),
+    }
+    return {k: torch.tensor(v, dtype=torch.float32) for k, v in tab64.items()}, tab64
+
+
+# --------------------------------------------------------------------------
+# a8-a10: DiffNet
+# --------------------------------------------------------------------------
+def sinusoidal_pos_emb(t, dim):
+    """diffnet.py:34-46 (always fp32; t int64[B])."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    freq = torch.exp(torch.arange(half) * -e)
+    ang = t[:, None] * freq[None, :]
+    return torch.cat((ang.sin(), ang.cos()), dim=-1)
+
+
+def mish(x):
+    """diffnet.py:14-16."""
+    return x * torch.tanh(F.softplus(x))
+
+
+def step_embedding(W, t, prefix="denoise_fn."):
+    """diffnet.py:121-122,97-101: sinusoid -> Linear -> Mish -> Linear. [B,C]"""
+    C = W[prefix + "mlp.2.weight"].shape[0]
+    e = sinusoidal_pos_emb(t, C).to(W[prefix + "mlp.0.weight"].dtype)
+    h = F.linear(e, W[prefix + "mlp.0.weight"], W[prefix + "mlp.0.bias"])
+    return F.linear(mish(h), W[prefix + "mlp.2.weight"], W[prefix + "mlp.2.bias"])
+
+
+def residual_block(W, p, x, cond, dstep, dilation):
+    """diffnet.py:60-81 (one DiffNet layer).  x[B,C,T], cond[B,H,T], dstep[B,C]."""
+    d = F.linear(dstep, W[p + "diffusion_projection.weight"], W[p + "diffusion_projection.bias"])[:, :, None]
+    c = F.conv1d(cond, W[p + "conditioner_projection.weight"], W[p + "conditioner_projection.bias"])
+    y = F.conv1d(x + d, W[p + "dilated_conv.weight"], W[p + "dilated_conv.bias"],
+                 padding=dilation, dilation=dilation) + c
+    gate, filt = torch.chunk(y, 2, dim=1)
+    y = torch.sigmoid(gate) * torch.tanh(filt)
+    y = F.conv1d(y, W[p + "output_projection.weight"], W[p + "output_projection.bias"])
+    res, skip = torch.chunk(y, 2, dim=1)
+    return (x + res) / math.sqrt(2.0), skip
+
+
+def diffnet_forward(W, spec, t, cond, dilation_cycle_length=1, prefix="denoise_fn.", trace=None):
+    """diffnet.py:110-132.  spec[B,1,M,T], t int64[B], cond[B,H,T] -> [B,1,M,T]."""
+    x = F.relu(F.conv1d(spec[:, 0], W[prefix + "input_projection.weight"], W[prefix + "input_projection.bias"]))
+    dstep = step_embedding(W, t, prefix)
+    n_layers = 0
+    while (prefix + "residual_layers.%d.dilated_conv.weight" % n_layers) in W:
+        n_layers += 1
+    skip = None
+    for i in range(n_layers):
+        dil = 2 ** (i % dilation_cycle_length)  # diffnet.py:102-105
+        x, s = residual_block(W, prefix + "residual_layers.%d." % i, x, cond, dstep, dil)
+        skip = s if skip is None else skip + s  # == torch.sum(torch.stack(skip), 0), diffnet.py:128
+        if trace is not None:
+            trace.append((x.clone(), s.clone()))
+    x = skip / math.sqrt(n_layers)
+    x = F.relu(F.conv1d(x, W[prefix + "skip_projection.weight"], W[prefix + "skip_projection.bias"]))
+    x = F.conv1d(x, W[prefix + "output_projection.weight"], W[prefix + "output_projection.bias"])
+    return x[:, None]
+
+
+# --------------------------------------------------------------------------
+# a3-a6: posterior / forward diffusion
+# --------------------------------------------------------------------------
+def extract(a, t, ndim):
+    """diffusion_utils.py:59-62."""
+    return a.gather(-1, t).reshape(t.shape[0], *((1,) * (ndim - 1)))
+
+
+def q_posterior_sample(tab, x0, x_t, t, noise):
+    """spec_denoiser.py:86-101.  noise is drawn even at t == 0 (masked out)."""
+    mean = extract(tab["posterior_mean_coef1"], t, x_t.dim()) * x0 + \
+        extract(tab["posterior_mean_coef2"], t, x_t.dim()) * x_t
+    logvar = extract(tab["posterior_log_variance_clipped"], t, x_t.dim())
+    nonzero = (1 - (t == 0).float()).reshape(t.shape[0], *((1,) * (x_t.dim() - 1)))
+    return mean + nonzero * (0.5 * logvar).exp() * noise
+
+
+def q_sample(tab, x_start, t, noise):
+    """spec_denoiser.py:126-132."""
+    return extract(tab["sqrt_alphas_cumprod"], t, x_start.dim()) * x_start + \
+        extract(tab["sqrt_one_minus_alphas_cumprod"], t, x_start.dim()) * noise
+
+
+def p_sample_loop(W, tab, cond, noises, timesteps, dilation_cycle_length=1, trace=None):
+    """spec_denoiser.py:178-184.  noises[0] = x_T, noises[1+k] = eps of the k-th
+    executed step (i = timesteps-1-k).  Returns x [B,1,M,T]."""
+    x = noises[0]
+    B = x.shape[0]
+    for k, i in enumerate(reversed(range(0, timesteps))):
+        t = torch.full((B,), i, dtype=torch.long)
+        x0 = diffnet_forward(W, x, t, cond, dilation_cycle_length)
+        x = q_posterior_sample(tab, x0, x, t, noises[1 + k])
+        if trace is not None:
+            trace.append((x0.clone(), x.clone()))
+    return x
+
+
+# --------------------------------------------------------------------------
+# a11-a16: conditioner (FastSpeech-style encoder, predictors, MelEncoder)
+# --------------------------------------------------------------------------
+def layer_norm_ch(x, w, b, eps=1e-5):
+    """modules/commons/layers.py:5-24 with dim=1: LN over channels of [B,C,T]."""
+    return F.layer_norm(x.transpose(1, -1), (x.shape[1],), w, b, eps).transpose(1, -1)
+
+
+def conv_blocks(W, p, x, n_blocks=4, layers_in_block=2, kernel_size=5, dilations=None, post_k=3):
+    """modules/commons/conv.py:24-116 (ConvBlocks.forward, is_BTC=True, norm 'ln').
+    x [B,T,H] -> [B,T,out]."""
+    dilations = dilations or [1] * n_blocks
+    x = x.transpose(1, 2)
+    nonpadding = (x.abs().sum(1) > 0).float()[:, None, :]  # conv.py:108
+    for bi in range(n_blocks):
+        d = dilations[bi]
+        np_b = (x.abs().sum(1) > 0).float()[:, None, :]  # conv.py:58
+        for li in range(layers_in_block):
+            q = "%sres_blocks.%d.blocks.%d." % (p, bi, li)
+            h = layer_norm_ch(x, W[q + "0.weight"], W[q + "0.bias"])
+            h = F.conv1d(h, W[q + "1.weight"], W[q + "1.bias"], dilation=d,
+                         padding=(d * (kernel_size - 1)) // 2)
+            h = h * kernel_size ** -0.5
+            h = F.gelu(h)
+            h = F.conv1d(h, W[q + "4.weight"], W[q + "4.bias"])
+            x = (x + h) * np_b
+    x = x * nonpadding
+    x = layer_norm_ch(x, W[p + "last_norm.weight"], W[p + "last_norm.bias"]) * nonpadding
+    x = F.conv1d(x, W[p + "post_net1.weight"], W[p + "post_net1.bias"], padding=post_k // 2) * nonpadding
+    return x.transpose(1, 2)
+
+
+def text_encoder(W, txt_tokens, p="fs.encoder."):
+    """conv.py:119-139: sqrt(H) * Embedding -> ConvBlocks."""
+    emb = W[p + "embed_tokens.weight"]
+    x = math.sqrt(emb.shape[1]) * F.embedding(txt_tokens, emb, padding_idx=0)
+    return conv_blocks(W, p, x)
+
+
+def mel2token_to_dur(mel2token, T_txt):
+    """utils/audio/align.py:71-90 (scatter_add count, drop slot 0)."""
+    B = mel2token.shape[0]
+    dur = mel2token.new_zeros(B, T_txt + 1).scatter_add(1, mel2token, torch.ones_like(mel2token))
+    return dur[:, 1:]
+
+
+def predictor_stack(W, p, x, n_layers, k, padding_mask=None):
+    """nar_tts_modules.py:8-34 / 75-100: n x (conv k -> ReLU -> LN(ch) -> dropout[eval])."""
+    x = x.transpose(1, -1)
+    for i in range(n_layers):
+        q = "%sconv.%d." % (p, i)
+        x = F.conv1d(x, W[q + "0.weight"], W[q + "0.bias"], padding=k // 2)
+        x = F.relu(x)
+        x = layer_norm_ch(x, W[q + "2.weight"], W[q + "2.bias"])
+        if padding_mask is not None:
+            x = x * (1 - padding_mask.float())[:, None, :]
+    return x.transpose(1, -1)
+
+
+def duration_predictor(W, x, x_padding, p="fs.dur_predictor.", n_layers=3, k=5):
+    """nar_tts_modules.py:24-34."""
+    h = predictor_stack(W, p, x, n_layers, k, x_padding)
+    h = F.softplus(F.linear(h, W[p + "linear.0.weight"], W[p + "linear.0.bias"]))
+    h = h * (1 - x_padding.float())[:, :, None]
+    return h[..., 0]
+
+
+def length_regulator(dur, dur_padding):
+    """nar_tts_modules.py:42-72 (alpha = 1)."""
+    dur = torch.round(dur.float()).long()
+    dur = dur * (1 - dur_padding.long())
+    token_idx = torch.arange(1, dur.shape[1] + 1)[None, :, None]
+    cs = torch.cumsum(dur, 1)
+    cs_prev = F.pad(cs, [1, -1])
+    pos = torch.arange(int(dur.sum(-1).max()))[None, None]
+    mask = (pos >= cs_prev[:, :, None]) & (pos < cs[:, :, None])
+    return (token_idx * mask.long()).sum(1)
+
+
+def denorm_f0(f0, uv, pitch_padding=None, fmin=50, fmax=900):
+    """utils/audio/pitch/utils.py:71-82 (pitch_norm='log'); returns a new tensor."""
+    f0 = (2 ** f0).clamp(min=fmin, max=fmax)
+    if uv is not None:
+        f0 = torch.where(uv > 0, torch.zeros_like(f0), f0)
+    if pitch_padding is not None:
+        f0 = torch.where(pitch_padding, torch.zeros_like(f0), f0)
+    return f0
+
+
+def f0_to_coarse(f0, f0_bin=256, f0_max=900.0, f0_min=50.0):
+    """utils/audio/pitch/utils.py:17-28 -> int64 bins 1..255."""
+    mel_min = 1127 * np.log(1 + f0_min / 700)
+    mel_max = 1127 * np.log(1 + f0_max / 700)
+    m = 1127 * (1 + f0 / 700).log()
+    m = torch.where(m > 0, (m - mel_min) * (f0_bin - 2) / (mel_max - mel_min) + 1, m)
+    m = torch.where(m <= 1, torch.ones_like(m), m)
+    m = torch.where(m > f0_bin - 1, torch.full_like(m, f0_bin - 1), m)
+    return (m + 0.5).long()
+
+
+def expand_states(h, mel2token):
+    """modules/tts/commons/align_ops.py:21-25: index 0 -> zero row."""
+    h = F.pad(h, [0, 0, 1, 0])
+    idx = mel2token[..., None].repeat([1, 1, h.shape[-1]])
+    return torch.gather(h, 1, idx)
+
+
+def mel_encoder(W, x, p="mel_encoder."):
+    """modules/speech_editing/commons/mel_encoder.py:15-19."""
+    h = F.relu(F.linear(x, W[p + "encoder.0.weight"], W[p + "encoder.0.bias"]))
+    h = F.relu(F.linear(h, W[p + "encoder.2.weight"], W[p + "encoder.2.bias"]))
+    return F.linear(h, W[p + "fc_out.weight"], W[p + "fc_out.bias"])
+
+
+def fastspeech_forward(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv,
+                       use_pred_mel2ph=False, use_pred_pitch=False, p="fs."):
+    """fs.py:83-189 with skip_decoder=True, use_spk_embed, use_pitch_embed,
+    pitch_type 'frame', use_uv (egs/spec_denoiser.yaml).  Eval mode (no dropout).
+    Returns the ret dict incl. integer intermediates."""
+    ret = {}
+    enc = text_encoder(W, txt_tokens, p + "encoder.")
+    src_nonpad = (txt_tokens > 0).float()[:, :, None]
+    style = F.linear(spk_embed, W[p + "spk_embed_proj.weight"], W[p + "spk_embed_proj.bias"])[:, None, :]
+    # -- duration (fs.py:123-151)
+    dur_inp = (enc + style) * src_nonpad
+    T_txt = txt_tokens.shape[1]
+    nonpad = (txt_tokens != 0).float()
+    masked_dur = mel2token_to_dur(mel2ph * (1 - time_mel_masks).squeeze(-1).long(), T_txt) * nonpad
+    ret["masked_dur"] = masked_dur.long()
+    dur_inp = dur_inp + F.embedding(masked_dur.long(), W[p + "dur_embed.weight"], padding_idx=0)
+    src_padding = txt_tokens == 0
+    dur = duration_predictor(W, dur_inp, src_padding, p + "dur_predictor.")
+    ret["dur"] = dur
+    if use_pred_mel2ph:
+        mel2ph = length_regulator(dur, src_padding)
+    ret["mel2ph"] = mel2ph
+    tgt_nonpad = (mel2ph > 0).float()[:, :, None]
+    dec_inp = expand_states(enc, mel2ph)
+    # -- pitch (fs.py:153-189)
+    pitch_inp = (dec_inp + style) * tgt_nonpad
+    pitch_padding = mel2ph == 0
+    m = time_mel_masks.squeeze(-1)
+    masked_f0 = f0 * (1 - m)
+    masked_uv = uv * (1 - m)
+    masked_pitch = f0_to_coarse(denorm_f0(masked_f0, masked_uv, pitch_padding))
+    ret["masked_pitch"] = masked_pitch
+    pp_inp = pitch_inp + F.embedding(masked_pitch, W[p + "pitch_embed.weight"], padding_idx=0)
+    h = predictor_stack(W, p + "pitch_predictor.", pp_inp, 5, 5)
+    pitch_pred = F.linear(h, W[p + "pitch_predictor.linear.weight"], W[p + "pitch_predictor.linear.bias"])
+    ret["pitch_pred"] = pitch_pred
+    if use_pred_pitch:
+        pitch_padding = None
+        pred_f0 = pitch_pred[:, :, 0]
+        pred_uv = pitch_pred[:, :, 1] > 0
+        res_f0 = f0 * (1 - m) + pred_f0 * m
+        res_uv = uv * (1 - m) + pred_uv * m
+    else:
+        res_f0, res_uv = f0, uv
+    f0_denorm = denorm_f0(res_f0, res_uv, pitch_padding)
+    pitch = f0_to_coarse(f0_denorm)
+    ret["pitch"] = pitch
+    ret["f0_denorm"] = f0_denorm
+    ret["f0_denorm_pred"] = denorm_f0(pitch_pred[:, :, 0], pitch_pred[:, :, 1] > 0, pitch_padding)
+    dec_inp = dec_inp + F.embedding(pitch, W[p + "pitch_embed.weight"], padding_idx=0)
+    ret["decoder_inp"] = (dec_inp + style) * tgt_nonpad
+    return ret
+
+
+def conditioner(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv,
+                use_pred_mel2ph=False, use_pred_pitch=False):
+    """spec_denoiser.py:159-167: fs(...) + mel_encoder(ref*(1-mask))*nonpad.
+    Returns (ret, cond[B,H,T])."""
+    ret = fastspeech_forward(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv,
+                             use_pred_mel2ph, use_pred_pitch)
+    tgt_nonpad = (ret["mel2ph"] > 0).float()[:, :, None]
+    dec = ret["decoder_inp"] + mel_encoder(W, ref_mels * (1 - time_mel_masks)) * tgt_nonpad
+    ret["decoder_inp"] = dec
+    return ret, dec.transpose(1, 2)
+
+
+def gaussian_diffusion_infer(W, timesteps, inputs, noises, dilation_cycle_length=1, trace=None, **flags):
+    """spec_denoiser.py:154-185 with infer=True and explicit noise tensors."""
+    tab, _ = diffusion_tables(timesteps)
+    ret, cond = conditioner(W, inputs["txt_tokens"], inputs["time_mel_masks"], inputs["mel2ph"],
+                            inputs["spk_embed"], inputs["ref_mels"], inputs["f0"], inputs["uv"], **flags)
+    x = p_sample_loop(W, tab, cond, noises, timesteps, dilation_cycle_length, trace)
+    ret["mel_out"] = x[:, 0].transpose(1, 2)
+    ret["cond"] = cond
+    return ret
+
+
+def gaussian_diffusion_train(W, timesteps, inputs, t, noise, dilation_cycle_length=1):
+    """spec_denoiser.py:168-176 (infer=False) with explicit t and eps; eval-mode predictors."""
+    tab, _ = diffusion_tables(timesteps)
+    ret, cond = conditioner(W, inputs["txt_tokens"], inputs["time_mel_masks"], inputs["mel2ph"],
+                            inputs["spk_embed"], inputs["ref_mels"], inputs["f0"], inputs["uv"])
+    nonpadding = (inputs["mel2ph"] != 0).float().unsqueeze(1).unsqueeze(1)
+    x_start = inputs["ref_mels"].transpose(1, 2)[:, None]
+    x_t = q_sample(tab, x_start, t, noise) * nonpadding
+    x0 = diffnet_forward(W, x_t, t, cond, dilation_cycle_length) * nonpadding
+    ret["mel_out"] = x0[:, 0].transpose(1, 2)
+    ret["x_t"] = x_t
+    return ret
+
+
+# --------------------------------------------------------------------------
+# a17: HiFi-GAN generator forward
+# --------------------------------------------------------------------------
+def weight_norm_fold(g, v):
+    """torch.nn.utils.weight_norm (dim=0): w = g * v / ||v||, norm over all dims but 0."""
+    n = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))
+    return v * (g / n)
+
+
+def _wn(W, p):
+    if (p + "weight") in W:
+        return W[p + "weight"]
+    return weight_norm_fold(W[p + "weight_g"], W[p + "weight_v"])
+
+
+def hifigan_forward(W, h, x, prefix=""):
+    """modules/vocoder/hifigan/hifigan.py:126-142 (+ ResBlock1 :51-58, ResBlock2 :79-84).
+    x [B,80,T] -> [B,1,T*prod(upsample_rates)]."""
+    p = prefix
+    x = F.conv1d(x, _wn(W, p + "conv_pre."), W[p + "conv_pre.bias"], padding=3)
+    nk = len(h["resblock_kernel_sizes"])
+    for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+        x = F.leaky_relu(x, 0.1)
+        x = F.conv_transpose1d(x, _wn(W, p + "ups.%d." % i), W[p + "ups.%d.bias" % i],
+                               stride=u, padding=(k - u) // 2)
+        xs = None
+        for j, (rk, rd) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
+            q = p + "resblocks.%d." % (i * nk + j)
+            y = x
+            if str(h["resblock"]) == "1":
+                for m, d in enumerate(rd):
+                    t = F.leaky_relu(y, 0.1)
+                    t = F.conv1d(t, _wn(W, q + "convs1.%d." % m), W[q + "convs1.%d.bias" % m],
+                                 dilation=d, padding=(rk * d - d) // 2)
+                    t = F.leaky_relu(t, 0.1)
+                    t = F.conv1d(t, _wn(W, q + "convs2.%d." % m), W[q + "convs2.%d.bias" % m],
+                                 padding=(rk - 1) // 2)
+                    y = t + y
+            else:
+                for m, d in enumerate(rd):
+                    t = F.leaky_relu(y, 0.1)
+                    t = F.conv1d(t, _wn(W, q + "convs.%d." % m), W[q + "convs.%d.bias" % m],
+                                 dilation=d, padding=(rk * d - d) // 2)
+                    y = t + y
+            xs = y if xs is None else xs + y
+        x = xs / nk
+    x = F.leaky_relu(x)  # default slope 0.01, hifigan.py:138
+    x = F.conv1d(x, _wn(W, p + "conv_post."), W[p + "conv_post.bias"], padding=3)
+    return torch.tanh(x)
+
+
+# --------------------------------------------------------------------------
+# metric: mel-level MCD (utils/eval/mcd.py:13-31,89-95,103-144 restated)
+# --------------------------------------------------------------------------
+def mel_mcd(mel_a, mel_b, n_mfcc=39):
+    """DCT-II (unnormalised) over the mel axis of log10-mels [T,M], keep c1..c_n,
+    /2, mean per-frame L2 of the difference."""
+    from scipy.fft import dct
+    a = dct(np.asarray(mel_a, dtype=np.float64), type=2, axis=-1, norm=None)[..., 1:n_mfcc + 1] / 2.0
+    b = dct(np.asarray(mel_b, dtype=np.float64), type=2, axis=-1, norm=None)[..., 1:n_mfcc + 1] / 2.0
+    return float(np.sqrt(((a - b) ** 2).sum(-1)).mean())
