@@ -1,0 +1,257 @@
+/*
+ * set_amd.h -- C ABI of libset_amd.so: the MI355X (gfx950) implementation of the
+ * Speech-Editing-Toolkit acoustic hot path (FluentSpeech spec_denoiser diffusion
+ * loop + HiFi-GAN generator forward).
+ *
+ * The reference (Zain-Jiang/Speech-Editing-Toolkit) is pure Python/PyTorch and has
+ * NO native/FFI boundary of its own; its extension points
+ * are Python registries.  This header is therefore the boundary a maintainer of
+ * the reference would bind with ctypes.  Every entry point
+ * cites the reference code whose arithmetic it replaces (paths relative to the
+ * upstream repo root).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (hipMalloc'd / torch CUDA tensors) unless
+ *     a parameter is documented as host;
+ *   - activations are fp32, channel-major: [B][C][T] with T contiguous (the
+ *     layout nn.Conv1d uses in the reference); index tensors are int64;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*);
+ *     the caller keeps all buffers alive until it synchronises the stream;
+ *   - return value: 0 = ok, negative = SET_E_* error code; nothing throws;
+ *   - no global mutable state; thread-compatible (one caller thread per stream).
+ */
+#ifndef SET_AMD_H
+#define SET_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SET_AMD_ABI_VERSION 1
+
+/* error codes */
+#define SET_OK 0
+#define SET_E_INVALID (-1)     /* bad argument (null pointer, shape out of range) */
+#define SET_E_UNSUPPORTED (-2) /* shape not supported by the requested implementation */
+#define SET_E_LAUNCH (-3)      /* hipLaunch / hip runtime error */
+
+/* activation codes (epilogue `act`) */
+#define SET_ACT_NONE 0
+#define SET_ACT_RELU 1
+#define SET_ACT_GELU 2     /* exact erf GELU (nn.GELU default) */
+#define SET_ACT_TANH 3
+#define SET_ACT_SOFTPLUS 4 /* beta=1, threshold=20 (nn.Softplus default) */
+#define SET_ACT_MISH 5     /* x*tanh(softplus(x)), diffnet.py:14-16 */
+#define SET_ACT_LRELU 6    /* leaky_relu(x, act_param) */
+
+/* input prologue codes (`pro`) applied to every in-range input sample */
+#define SET_PRO_NONE 0
+#define SET_PRO_LRELU 1 /* leaky_relu(x, pro_param)   (hifigan.py:53,55,129,138) */
+#define SET_PRO_DIV 2   /* x / pro_param              (diffnet.py:128, / sqrt(L)) */
+
+/* implementation selector for set_conv1d (0 is treated as NAIVE) */
+#define SET_IMPL_NAIVE 1 /* one thread per output sample; any shape; device-side cross-check */
+#define SET_IMPL_MFMA 2  /* implicit-GEMM on v_mfma_f32_32x32x2_f32; needs packed weights */
+
+int set_abi_version(void);
+/* last hip error string of the calling thread's most recent failing call (host pointer, static storage) */
+const char *set_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Generic 1-D convolution, stride 1, with fused prologue/epilogue.  Replaces every
+ * F.conv1d / nn.Conv1d / nn.Linear / nn.ConvTranspose1d (as u polyphase convs) call on the path:
+ * modules/commons/conv.py:45-49,94 ; nar_tts_modules.py:17,22,83,88 ; mel_encoder.py:7-13 ;
+ * diffnet.py:49-52,94,106-107 ; hifigan.py:108,114-115,122 and ResBlock1/2 (:31-48,71-76).
+ *
+ *   for t in [0, T_iter):  n = t*out_stride + out_off   (skipped unless 0 <= n < T_out)
+ *     acc  = sum_{ci,tap} W[co][ci][tap] * P(in[b][ci][t + tap*dil - pad])   (0 outside [0,T_in))
+ *            where P(x) = pro(x + in_chan_add[b][ci])      (in_chan_add optional)
+ *     v    = act((acc + bias[co]) * alpha)
+ *     v    = v + res[b][co][n]                              (res optional)
+ *     v    = v * mask[b][n]                                 (mask optional, [B][T_out])
+ *     out[b][co][n] = accumulate ? out[b][co][n] + v : v
+ *
+ * `dil` may be negative (ConvTranspose polyphase taps read in[q - j]).
+ * Weights: impl NAIVE reads w[w_base + co*w_sco + ci*w_sci + tap*w_stap];
+ *          impl MFMA reads `w` as the packed image written by set_pack_conv_weight.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct SetConv1dArgs {
+    const float *in;          /* [B][Cin][T_in], batch stride in_bs, channel stride in_cs */
+    const float *w;           /* see above */
+    const float *bias;        /* [Cout] or NULL */
+    const float *res;         /* optional residual, batch stride res_bs, channel stride res_cs */
+    const float *mask;        /* optional [B][T_out] */
+    const float *in_chan_add; /* optional [B][Cin] (batch stride Cin) */
+    float *out;               /* [B][Cout][T_out], batch stride out_bs, channel stride out_cs */
+    int64_t in_bs, in_cs, out_bs, out_cs, res_bs, res_cs;
+    int64_t w_base, w_sco, w_sci, w_stap; /* NAIVE weight addressing */
+    int32_t B, Cin, Cout, K, dil, pad;
+    int32_t T_in, T_iter, T_out, out_stride, out_off;
+    int32_t pro, act, accumulate, impl;
+    float pro_param, act_param, alpha;
+} SetConv1dArgs;
+
+int set_conv1d(const SetConv1dArgs *args, void *stream);
+
+/* number of floats of the packed image for (Cout, Cin, K) */
+int64_t set_packed_conv_weight_size(int32_t Cout, int32_t Cin, int32_t K);
+/* pack w[w_base + co*w_sco + ci*w_sci + tap*w_stap] into MFMA A-fragment order:
+ * wp[rb][tap][cp][lane] = W[32*rb + (lane&31)][2*cp + (lane>>5)][tap], zero padded
+ * (rb < ceil(Cout/32), cp < CinP/2, CinP = Cin rounded up to 16). */
+int set_pack_conv_weight(const float *w, float *wp, int32_t Cout, int32_t Cin, int32_t K,
+                         int64_t w_base, int64_t w_sco, int64_t w_sci, int64_t w_stap, void *stream);
+
+/* weight-norm fold  w[i][...] = g[i] * v[i][...] / ||v[i][...]||_2   (torch.nn.utils.weight_norm, dim=0;
+ * hifigan.py:32-47,108,114,122).  v,w: [n0][inner]; g: [n0]. */
+int set_weight_norm_fold(const float *g, const float *v, float *w, int32_t n0, int64_t inner, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Conditioner glue kernels (FastSpeech-style encoder path; all tiny)
+ * ------------------------------------------------------------------------------------------------ */
+/* LayerNorm over the channel dim of [B][C][T] (modules/commons/layers.py:5-24 with dim=1),
+ * then optional * mask[b][t].  */
+int set_layernorm_ch(const float *x, const float *gamma, const float *beta, const float *mask, float *out,
+                     int32_t B, int32_t C, int32_t T, float eps, void *stream);
+/* out[b][c][t] (+)= scale * table[idx[b][t]][c]     (layers.py:45-50, conv.py:138, fs.py:138,164,188) */
+int set_embedding_bct(const int64_t *idx, const float *table, float *out, int32_t B, int32_t T, int32_t C,
+                      int32_t n_rows, float scale, int32_t accumulate, void *stream);
+/* mask[b][t] = (sum_c |x[b][c][t]|) > 0 ? 1 : 0     (conv.py:58,108) */
+int set_abs_sum_mask(const float *x, float *mask, int32_t B, int32_t C, int32_t T, void *stream);
+/* mask[i] = idx[i] > 0 ? 1 : 0                       (fs.py:87,93 ; spec_denoiser.py:163,166) */
+int set_index_mask(const int64_t *idx, float *mask, int64_t n, void *stream);
+/* out[b][c][t] = mel2ph[b][t] > 0 ? enc[b][c][mel2ph[b][t]-1] : 0   (align_ops.py:21-25) */
+int set_expand_states(const float *enc, const int64_t *mel2ph, float *out, int32_t B, int32_t C,
+                      int32_t T_txt, int32_t T, void *stream);
+/* out[b][c][t] = (x[b][c][t] + (add ? add[b][c] : 0)) * (mask ? mask[b][t] : 1)   (fs.py:91,98,102) */
+int set_add_chan_mask(const float *x, const float *add, const float *mask, float *out, int32_t B, int32_t C,
+                      int32_t T, void *stream);
+/* masked_dur[b][j] = #{t : mel2ph[b][t]*(1-(int)tmask[b][t]) == j+1} * (txt[b][j] != 0)
+ * (fs.py:136-137, utils/audio/align.py:71-90).  int64 out [B][T_txt]. */
+int set_masked_dur(const int64_t *mel2ph, const float *tmask, const int64_t *txt, int64_t *out, int32_t B,
+                   int32_t T, int32_t T_txt, void *stream);
+/* pitch bins: f = clamp(2^f0,50,900); f = 0 where uv>0 or pad; mel-scale -> bin 1..255
+ * (utils/audio/pitch/utils.py:17-28,71-82 ; fs.py:160-163,182-183).
+ * f0_in/uv_in [B][T]; tmask optional: inputs are first multiplied by (1-tmask) (fs.py:160-161);
+ * uv_from_logit: treat uv_in as logits (uv = uv_in > 0, fs.py:186); pad optional int64 mel2ph (pad where == 0);
+ * outputs optional: f0_denorm fp32 [B][T], coarse int64 [B][T]. */
+int set_pitch_coarse(const float *f0_in, const float *uv_in, const float *tmask, const int64_t *mel2ph_pad,
+                     int32_t uv_from_logit, float *f0_denorm, int64_t *coarse, int64_t n, void *stream);
+/* [B][T][C] <-> [B][C][T] */
+int set_transpose_btc_to_bct(const float *in, float *out, int32_t B, int32_t T, int32_t C, void *stream);
+int set_transpose_bct_to_btc(const float *in, float *out, int32_t B, int32_t C, int32_t T, void *stream);
+/* out = (a + b + c) / div  (b, c optional)           (hifigan.py:131-137 MRF mean `xs / num_kernels`) */
+int set_sum_scale(const float *a, const float *b, const float *c, float *out, float div, int64_t n, void *stream);
+/* out[i] = a[i]*(1-m[i]) + b[i]*m[i] ; m broadcast over `inner` trailing elements
+ * (fs.py:176-177 ; tasks/speech_editing/spec_denoiser.py:53) */
+int set_blend_mask(const float *a, const float *b, const float *m, float *out, int64_t n, int64_t inner, void *stream);
+/* out[i] = x[i] * (1 - m[i / inner])                 (spec_denoiser.py:164 ref_mels*(1-mask)) */
+int set_mul_one_minus_mask(const float *x, const float *m, float *out, int64_t n, int64_t inner, void *stream);
+/* LengthRegulator: mel2ph[b][p] = sum_j (j+1) * [cs_prev_j <= p < cs_j], dur = round(dur)*(1-pad)
+ * (nar_tts_modules.py:42-72).  Two calls: set_dur_total writes total[b] (int64) = sum_j dur_j;
+ * the host reads max(total) to size the output (the reference sizes a tensor the same way, :69). */
+int set_dur_total(const float *dur, const int64_t *txt, int64_t *total, int32_t B, int32_t T_txt, void *stream);
+int set_length_regulate(const float *dur, const int64_t *txt, int64_t *mel2ph, int32_t B, int32_t T_txt,
+                        int32_t T_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DiffNet + diffusion loop
+ * ------------------------------------------------------------------------------------------------ */
+/* out[j][n] = sin(t[n]*w_j) (j < dim/2), cos(t[n]*w_{j-dim/2}) (j >= dim/2), w_j = exp(-j ln(1e4)/(dim/2-1))
+ * (diffnet.py:34-46).  t: fp32 [n] (host fills it with the integer step ids).  out: [dim][n]. */
+int set_sinusoid_embed(const float *t, float *out, int32_t dim, int32_t n, void *stream);
+
+/* z = sigmoid(y[:, :C]) * tanh(y[:, C:])   y [B][2C][T] -> z [B][C][T]    (diffnet.py:76-77) */
+int set_gate(const float *y, float *z, int32_t B, int32_t C, int32_t T, void *stream);
+/* x_out = (x_in + o[:, :C]) / sqrt(2) ; skip (+)= o[:, C:]               (diffnet.py:80-81,128) */
+int set_res_skip(const float *x_in, const float *o, float *x_out, float *skip, int32_t B, int32_t C, int32_t T,
+                 int32_t first, void *stream);
+
+/* One fused DiffNet residual layer (diffnet.py:60-81) for residual_channels == 256:
+ *   y   = W_dil (*) (x_in + d) + b_dil + condproj      k=3, dilation `dil`, zero padded
+ *   z   = sigmoid(y[:256]) * tanh(y[256:])
+ *   o   = W_out z + b_out
+ *   x_out = (x_in + o[:256]) / sqrt(2);  skip = first ? o[256:] : skip + o[256:]
+ * x_in/x_out/skip: [B][256][T] (must not alias); condproj: [B][512][T] slab with batch stride cp_bs
+ * (= conditioner_projection(cond) + its bias, hoisted out of the step loop: it does not depend on t);
+ * d[b][c] = dstep[b*d_bs + c*d_cs]  (diffusion_projection(mlp(emb(t)))[b][c]);
+ * w1p / w2p: images written by set_pack_diffnet_layer. */
+typedef struct SetDiffnetLayerArgs {
+    const float *x_in;
+    const float *condproj;
+    const float *dstep;
+    const float *w1p;
+    const float *b_dil;
+    const float *w2p;
+    const float *b_out;
+    float *x_out;
+    float *skip;
+    int64_t cp_bs, d_bs, d_cs;
+    int32_t B, T, dil, first;
+} SetDiffnetLayerArgs;
+int set_diffnet_layer(const SetDiffnetLayerArgs *args, void *stream);
+/* floats needed for w1p (512x768) and w2p (512x256) */
+int64_t set_diffnet_w1p_size(void);
+int64_t set_diffnet_w2p_size(void);
+/* pack dilated_conv.weight [512][256][3] and output_projection.weight [512][256][1] (diffnet.py:63,66) */
+int set_pack_diffnet_layer(const float *w_dil, const float *w_out, float *w1p, float *w2p, void *stream);
+
+/* posterior step (spec_denoiser.py:86-101):  x_prev = c1*x0 + c2*x_t + (t != 0) * exp(0.5*logvar) * eps
+ * per-batch scalars coef4[b*coef_bs + {0,1,2,3}] = {c1, c2, logvar, nonzero} (coef_bs = 0: shared by the
+ * batch); eps == NULL -> counter-based Philox4x32-10 + Box-Muller noise keyed by (seed, offset + i/4).
+ * x_prev may alias x_t. */
+int set_posterior_step(const float *x0, const float *x_t, const float *eps, const float *coef4, int64_t coef_bs,
+                       float *x_prev, int32_t B, int64_t per_batch, uint64_t seed, uint64_t offset, void *stream);
+/* x_t = a[b]*x_start + s[b]*eps   (q_sample, spec_denoiser.py:126-132); ab2[b] = {a, s}; optional * nonpad[b][t] */
+int set_q_sample(const float *x_start, const float *eps, const float *ab2, const float *nonpad, float *x_t,
+                 int32_t B, int32_t M, int32_t T, void *stream);
+/* fill with N(0,1): Philox4x32-10 + Box-Muller (throughput runs; spec_denoiser.py:180) */
+int set_randn(float *out, int64_t n, uint64_t seed, uint64_t offset, void *stream);
+
+/* Whole reverse loop (spec_denoiser.py:178-184 + p_sample :103-108 + DiffNet.forward diffnet.py:110-132)
+ * for residual_channels == 256.  All weights pre-packed by the caller; workspaces provided by the caller. */
+typedef struct SetDiffLoopArgs {
+    /* problem */
+    int32_t B, T, M, L, steps, dilation_cycle_length;
+    /* state */
+    float *x;              /* [B][M][T]  in: x_T, out: x_0 */
+    const float *noise;    /* optional explicit eps: [steps][B][M][T] in execution order (i = steps-1..0); NULL -> Philox */
+    uint64_t seed;
+    const float *condproj; /* [B][L*512][T]  hoisted conditioner projections (+bias) */
+    const float *dstep;    /* [L*256][steps] : column s = diffusion_projection_l(mlp(emb(s))) */
+    const float *coef4;    /* [steps][4] host-computed {c1, c2, logvar, nonzero} per step id, DEVICE pointer */
+    /* packed weights */
+    const float *w_in_p;   /* input_projection packed (Cout 256, Cin M, K 1) */
+    const float *b_in;
+    const float *const *w1p; /* HOST array of L device pointers */
+    const float *const *w2p; /* HOST array of L device pointers */
+    const float *const *b_dil;
+    const float *const *b_out;
+    const float *w_skip_p; /* skip_projection packed */
+    const float *b_skip;
+    const float *w_outp_p; /* output_projection packed (Cout M, Cin 256) */
+    const float *b_outp;
+    /* workspaces, each [B][256][T] floats */
+    float *ws_x0, *ws_x1, *ws_skip, *ws_h;
+    float *ws_x0pred; /* [B][M][T] */
+    /* optional: HOST array [steps] receiving the wall time in ms of the 20-layer span of each step
+     * (hipEvent pairs on `stream`; the call then synchronises the stream before returning) */
+    float *layer_span_ms;
+} SetDiffLoopArgs;
+int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream);
+
+/* MFMA fragment-layout self test: runs a 32x32xK product through v_mfma_f32_32x32x2_f32 with the layout
+ * this library assumes and returns the max abs error vs an in-kernel scalar reference via *max_err (HOST).
+ * Synchronises.  Used by tests to pin the hardware layout assumption. */
+int set_selftest_mfma(float *max_err_host, void *stream);
+
+/* sizeof() of the argument structs, so a foreign-language binding can verify its mirror of the layout */
+int64_t set_sizeof_conv1d_args(void);
+int64_t set_sizeof_diffnet_layer_args(void);
+int64_t set_sizeof_diff_loop_args(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SET_AMD_H */

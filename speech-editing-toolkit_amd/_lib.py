@@ -1,0 +1,171 @@
+"""ctypes binding of libset_amd.so (include/set_amd.h) + the in-tree hipcc build.
+
+The library is built in-tree (speech-editing-toolkit_amd/libset_amd.so) with
+`hipcc --offload-arch=gfx950`; hipcc cross-compiles without a GPU.  The product
+path fails loudly (RuntimeError) when the library cannot be loaded -- there is
+no fallback implementation.
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+CSRC = os.path.join(_PKG, "csrc")
+INCLUDE = os.path.join(_ROOT, "include")
+LIB_PATH = os.path.join(_PKG, "libset_amd.so")
+SOURCES = ["conv1d.hip", "glue.hip", "diffnet.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+
+# constants mirrored from set_amd.h
+OK, E_INVALID, E_UNSUPPORTED, E_LAUNCH = 0, -1, -2, -3
+ACT = dict(none=0, relu=1, gelu=2, tanh=3, softplus=4, mish=5, lrelu=6)
+PRO = dict(none=0, lrelu=1, div=2)
+IMPL_NAIVE, IMPL_MFMA = 1, 2
+
+c_f32p = C.POINTER(C.c_float)
+c_i64p = C.POINTER(C.c_int64)
+
+
+class SetConv1dArgs(C.Structure):
+    _fields_ = [
+        ("inp", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+        ("mask", C.c_void_p), ("in_chan_add", C.c_void_p), ("out", C.c_void_p),
+        ("in_bs", C.c_int64), ("in_cs", C.c_int64), ("out_bs", C.c_int64), ("out_cs", C.c_int64),
+        ("res_bs", C.c_int64), ("res_cs", C.c_int64),
+        ("w_base", C.c_int64), ("w_sco", C.c_int64), ("w_sci", C.c_int64), ("w_stap", C.c_int64),
+        ("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("K", C.c_int32), ("dil", C.c_int32),
+        ("pad", C.c_int32),
+        ("T_in", C.c_int32), ("T_iter", C.c_int32), ("T_out", C.c_int32), ("out_stride", C.c_int32),
+        ("out_off", C.c_int32),
+        ("pro", C.c_int32), ("act", C.c_int32), ("accumulate", C.c_int32), ("impl", C.c_int32),
+        ("pro_param", C.c_float), ("act_param", C.c_float), ("alpha", C.c_float),
+    ]
+
+
+class SetDiffnetLayerArgs(C.Structure):
+    _fields_ = [
+        ("x_in", C.c_void_p), ("condproj", C.c_void_p), ("dstep", C.c_void_p), ("w1p", C.c_void_p),
+        ("b_dil", C.c_void_p), ("w2p", C.c_void_p), ("b_out", C.c_void_p), ("x_out", C.c_void_p),
+        ("skip", C.c_void_p),
+        ("cp_bs", C.c_int64), ("d_bs", C.c_int64), ("d_cs", C.c_int64),
+        ("B", C.c_int32), ("T", C.c_int32), ("dil", C.c_int32), ("first", C.c_int32),
+    ]
+
+
+class SetDiffLoopArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int32), ("M", C.c_int32), ("L", C.c_int32), ("steps", C.c_int32),
+        ("dilation_cycle_length", C.c_int32),
+        ("x", C.c_void_p), ("noise", C.c_void_p), ("seed", C.c_uint64),
+        ("condproj", C.c_void_p), ("dstep", C.c_void_p), ("coef4", C.c_void_p),
+        ("w_in_p", C.c_void_p), ("b_in", C.c_void_p),
+        ("w1p", C.POINTER(C.c_void_p)), ("w2p", C.POINTER(C.c_void_p)),
+        ("b_dil", C.POINTER(C.c_void_p)), ("b_out", C.POINTER(C.c_void_p)),
+        ("w_skip_p", C.c_void_p), ("b_skip", C.c_void_p), ("w_outp_p", C.c_void_p), ("b_outp", C.c_void_p),
+        ("ws_x0", C.c_void_p), ("ws_x1", C.c_void_p), ("ws_skip", C.c_void_p), ("ws_h", C.c_void_p),
+        ("ws_x0pred", C.c_void_p),
+        ("layer_span_ms", C.POINTER(C.c_float)),
+    ]
+
+
+_V, _I32, _I64, _U64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+
+# name -> (restype, argtypes); every symbol include/set_amd.h declares
+SIGNATURES = {
+    "set_abi_version": (C.c_int, []),
+    "set_last_error": (C.c_char_p, []),
+    "set_conv1d": (C.c_int, [C.POINTER(SetConv1dArgs), _V]),
+    "set_packed_conv_weight_size": (_I64, [_I32, _I32, _I32]),
+    "set_pack_conv_weight": (C.c_int, [_V, _V, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _V]),
+    "set_weight_norm_fold": (C.c_int, [_V, _V, _V, _I32, _I64, _V]),
+    "set_layernorm_ch": (C.c_int, [_V, _V, _V, _V, _V, _I32, _I32, _I32, _F, _V]),
+    "set_embedding_bct": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _I32, _F, _I32, _V]),
+    "set_abs_sum_mask": (C.c_int, [_V, _V, _I32, _I32, _I32, _V]),
+    "set_index_mask": (C.c_int, [_V, _V, _I64, _V]),
+    "set_expand_states": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _I32, _V]),
+    "set_add_chan_mask": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _V]),
+    "set_masked_dur": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _V]),
+    "set_pitch_coarse": (C.c_int, [_V, _V, _V, _V, _I32, _V, _V, _I64, _V]),
+    "set_transpose_btc_to_bct": (C.c_int, [_V, _V, _I32, _I32, _I32, _V]),
+    "set_transpose_bct_to_btc": (C.c_int, [_V, _V, _I32, _I32, _I32, _V]),
+    "set_sum_scale": (C.c_int, [_V, _V, _V, _V, _F, _I64, _V]),
+    "set_blend_mask": (C.c_int, [_V, _V, _V, _V, _I64, _I64, _V]),
+    "set_mul_one_minus_mask": (C.c_int, [_V, _V, _V, _I64, _I64, _V]),
+    "set_dur_total": (C.c_int, [_V, _V, _V, _I32, _I32, _V]),
+    "set_length_regulate": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _V]),
+    "set_sinusoid_embed": (C.c_int, [_V, _V, _I32, _I32, _V]),
+    "set_gate": (C.c_int, [_V, _V, _I32, _I32, _I32, _V]),
+    "set_res_skip": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _V]),
+    "set_diffnet_layer": (C.c_int, [C.POINTER(SetDiffnetLayerArgs), _V]),
+    "set_diffnet_w1p_size": (_I64, []),
+    "set_diffnet_w2p_size": (_I64, []),
+    "set_pack_diffnet_layer": (C.c_int, [_V, _V, _V, _V, _V]),
+    "set_posterior_step": (C.c_int, [_V, _V, _V, _V, _I64, _V, _I32, _I64, _U64, _U64, _V]),
+    "set_q_sample": (C.c_int, [_V, _V, _V, _V, _V, _I32, _I32, _I32, _V]),
+    "set_randn": (C.c_int, [_V, _I64, _U64, _U64, _V]),
+    "set_diffusion_loop": (C.c_int, [C.POINTER(SetDiffLoopArgs), _V]),
+    "set_selftest_mfma": (C.c_int, [C.POINTER(C.c_float), _V]),
+    "set_sizeof_conv1d_args": (_I64, []),
+    "set_sizeof_diffnet_layer_args": (_I64, []),
+    "set_sizeof_diff_loop_args": (_I64, []),
+}
+
+_lib = None
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h"]] + [os.path.join(INCLUDE, "set_amd.h")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    """Compile libset_amd.so for gfx950 in-tree (no GPU needed)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found; cannot build libset_amd.so")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libset_amd.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "There is no CPU/eager fallback for this path." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    assert L.set_sizeof_conv1d_args() == C.sizeof(SetConv1dArgs), "SetConv1dArgs ABI mismatch"
+    assert L.set_sizeof_diffnet_layer_args() == C.sizeof(SetDiffnetLayerArgs), "SetDiffnetLayerArgs ABI mismatch"
+    assert L.set_sizeof_diff_loop_args() == C.sizeof(SetDiffLoopArgs), "SetDiffLoopArgs ABI mismatch"
+    _lib = L
+    return L
+
+
+class SetAmdError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != OK:
+        msg = lib().set_last_error()
+        raise SetAmdError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))

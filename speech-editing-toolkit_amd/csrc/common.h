@@ -1,0 +1,66 @@
+// Shared device helpers for libset_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "set_amd.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- host-side error plumbing -------------------------------------------------------------
+extern thread_local char g_set_err[512];
+
+static inline int set_fail(int code, const char *what, const char *detail) {
+    snprintf(g_set_err, sizeof(g_set_err), "%s: %s", what, detail ? detail : "");
+    return code;
+}
+static inline int set_check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_fail(SET_E_LAUNCH, what, hipGetErrorString(e));
+    return SET_OK;
+}
+#define SET_REQUIRE(cond, what)                                        \
+    do {                                                               \
+        if (!(cond)) return set_fail(SET_E_INVALID, what, #cond);      \
+    } while (0)
+#define SET_HIP(call, what)                                                        \
+    do {                                                                           \
+        hipError_t e__ = (call);                                                   \
+        if (e__ != hipSuccess) return set_fail(SET_E_LAUNCH, what, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline unsigned set_blocks(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// ---- activations (match torch CPU fp32 semantics) -----------------------------------------
+__device__ __forceinline__ float dev_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float dev_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float dev_act(float v, int act, float p) {
+    switch (act) {
+        case SET_ACT_RELU: return v > 0.0f ? v : 0.0f;
+        case SET_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case SET_ACT_TANH: return tanhf(v);
+        case SET_ACT_SOFTPLUS: return dev_softplus(v);
+        case SET_ACT_MISH: return v * tanhf(dev_softplus(v));
+        case SET_ACT_LRELU: return v > 0.0f ? v : v * p;
+        default: return v;
+    }
+}
+__device__ __forceinline__ float dev_pro(float v, int pro, float p) {
+    switch (pro) {
+        case SET_PRO_LRELU: return v > 0.0f ? v : v * p;
+        case SET_PRO_DIV: return v / p;
+        default: return v;
+    }
+}
+
+// ---- MFMA f32 32x32x2 fragment maps (cdna_hip_programming.md section 3) --------------------
+//   A operand: lane l holds A[i = l & 31][k = l >> 5]
+//   B operand: lane l holds B[k = l >> 5][j = l & 31]
+//   C/D      : reg r of lane l is D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31]
+__device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}

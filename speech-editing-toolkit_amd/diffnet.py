@@ -1,0 +1,151 @@
+"""DiffNet denoiser (`DIFF_DECODERS['wavenet']`) on the HIP kernels.
+
+Same constructor contract, `forward(spec, diffusion_step, cond)` signature and state_dict keys as the
+reference's modules/speech_editing/spec_denoiser/diffnet.py:84-132, so reference checkpoints load unchanged.
+nn.Conv1d / nn.Linear modules are used as parameter containers only; no torch arithmetic runs in forward.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+from .hparams import hparams as _global_hparams
+
+
+def _kaiming_conv1d(cin, cout, k, **kw):
+    layer = nn.Conv1d(cin, cout, k, **kw)  # diffnet.py:49-52
+    nn.init.kaiming_normal_(layer.weight)
+    return layer
+
+
+class ResidualBlock(nn.Module):
+    """Parameter container for one residual layer (diffnet.py:60-66)."""
+
+    def __init__(self, encoder_hidden, residual_channels, dilation):
+        super().__init__()
+        C = residual_channels
+        self.dilation = dilation
+        self.dilated_conv = _kaiming_conv1d(C, 2 * C, 3, padding=dilation, dilation=dilation)
+        self.diffusion_projection = nn.Linear(C, C)
+        self.conditioner_projection = _kaiming_conv1d(encoder_hidden, 2 * C, 1)
+        self.output_projection = _kaiming_conv1d(C, 2 * C, 1)
+        H = encoder_hidden
+        self._w_dil = ops.ConvWeight(lambda: self.dilated_conv.weight.data, 2 * C, C, 3)
+        self._w_dproj = ops.ConvWeight(lambda: self.diffusion_projection.weight.data, C, C, 1)
+        self._w_cond = ops.ConvWeight(lambda: self.conditioner_projection.weight.data, 2 * C, H, 1)
+        self._w_out = ops.ConvWeight(lambda: self.output_projection.weight.data, 2 * C, C, 1)
+        self._fused = None
+        self._fused_key = None
+
+    def fused_weights(self):
+        wd, wo = self.dilated_conv.weight.data, self.output_projection.weight.data
+        key = (wd.data_ptr(), wd._version, wo.data_ptr(), wo._version)
+        if self._fused is None or key != self._fused_key:
+            self._fused = ops.pack_diffnet_layer(wd, wo)
+            self._fused_key = key
+        return self._fused
+
+
+class DiffNet(nn.Module):
+    FUSED_CHANNELS = 256  # residual_channels the fused layer kernel is specialised for
+    FUSED_MAX_DIL = 8
+
+    def __init__(self, in_dims=80, hp=None):
+        super().__init__()
+        hp = hp if hp is not None else _global_hparams
+        self.in_dims = in_dims
+        self.encoder_hidden = hp["hidden_size"]
+        self.n_layers = hp["residual_layers"]
+        self.C = C = hp["residual_channels"]
+        self.dilation_cycle_length = hp["dilation_cycle_length"]
+        self.input_projection = _kaiming_conv1d(in_dims, C, 1)
+        self.mlp = nn.Sequential(nn.Linear(C, C * 4), nn.Identity(), nn.Linear(C * 4, C))  # [1] is Mish (no params)
+        self.residual_layers = nn.ModuleList([
+            ResidualBlock(self.encoder_hidden, C, 2 ** (i % self.dilation_cycle_length))
+            for i in range(self.n_layers)])
+        self.skip_projection = _kaiming_conv1d(C, C, 1)
+        self.output_projection = _kaiming_conv1d(C, in_dims, 1)
+        nn.init.zeros_(self.output_projection.weight)
+        self._w_in = ops.ConvWeight(lambda: self.input_projection.weight.data, C, in_dims, 1)
+        self._w_mlp0 = ops.ConvWeight(lambda: self.mlp[0].weight.data, 4 * C, C, 1)
+        self._w_mlp2 = ops.ConvWeight(lambda: self.mlp[2].weight.data, C, 4 * C, 1)
+        self._w_skip = ops.ConvWeight(lambda: self.skip_projection.weight.data, C, C, 1)
+        self._w_outp = ops.ConvWeight(lambda: self.output_projection.weight.data, in_dims, C, 1)
+        self.impl = "auto"  # auto | fused | unfused  (unfused = generic kernels; device-side cross-check)
+
+    # ---- helpers -------------------------------------------------------------------------------------
+    def can_fuse(self):
+        return self.C == self.FUSED_CHANNELS and 2 ** (self.dilation_cycle_length - 1) <= self.FUSED_MAX_DIL
+
+    def use_fused(self):
+        if self.impl == "unfused":
+            return False
+        if self.impl == "fused" and not self.can_fuse():
+            raise RuntimeError("fused DiffNet layer kernel needs residual_channels == 256 and dilation <= 8")
+        return self.can_fuse()
+
+    def step_table(self, t_values):
+        """d[l][c][n] = diffusion_projection_l(mlp(sinusoid(t_n)))[c]  ->  tensor [L*C, n]
+        (diffnet.py:121-122 and :69).  t_values: float tensor [n]; depends on t only, so the reverse
+        loop computes it once for all steps."""
+        C, L = self.C, self.n_layers
+        n = t_values.numel()
+        emb = ops.sinusoid_embed(t_values, C).view(1, C, n)
+        h = ops.conv1d(emb, self._w_mlp0, self.mlp[0].bias.data, act="mish")
+        h = ops.conv1d(h, self._w_mlp2, self.mlp[2].bias.data)
+        out = torch.empty(1, L * C, n, dtype=torch.float32, device=h.device)
+        for l, layer in enumerate(self.residual_layers):
+            ops.conv1d(h, layer._w_dproj, layer.diffusion_projection.bias.data, out=out[:, l * C:(l + 1) * C, :])
+        return out.view(L * C, n)
+
+    def cond_projections(self, cond):
+        """conditioner_projection_l(cond) for every layer -> [B, L*2C, T].  It does not depend on the
+        diffusion step, so the reverse loop hoists it (the reference recomputes it every step, diffnet.py:70)."""
+        B, H, T = cond.shape
+        C, L = self.C, self.n_layers
+        out = torch.empty(B, L * 2 * C, T, dtype=torch.float32, device=cond.device)
+        for l, layer in enumerate(self.residual_layers):
+            ops.conv1d(cond, layer._w_cond, layer.conditioner_projection.bias.data,
+                       out=out[:, l * 2 * C:(l + 1) * 2 * C, :])
+        return out
+
+    def denoise(self, x, condproj, dtab, col, batch_cols):
+        """One DiffNet pass.  x [B,M,T]; condproj [B,L*2C,T]; dtab [L*C,n];
+        column of batch b is `col + b` if batch_cols else `col`.  Returns x0 [B,M,T]."""
+        B, M, T = x.shape
+        C, L = self.C, self.n_layers
+        n = dtab.shape[1]
+        fused = self.use_fused()
+        h = ops.conv1d(x, self._w_in, self.input_projection.bias.data, act="relu")
+        skip = torch.empty(B, C, T, dtype=torch.float32, device=x.device)
+        nxt = torch.empty_like(h)
+        for l, layer in enumerate(self.residual_layers):
+            cp = condproj[:, l * 2 * C:(l + 1) * 2 * C, :]
+            if fused:
+                w1p, w2p = layer.fused_weights()
+                dptr = dtab.data_ptr() + 4 * (l * C * n + col)
+                ops.diffnet_layer(h, cp.data_ptr(), condproj.stride(0), dptr, 1 if batch_cols else 0, n,
+                                  w1p, layer.dilated_conv.bias.data, w2p, layer.output_projection.bias.data,
+                                  nxt, skip, layer.dilation, l == 0)
+                h, nxt = nxt, h
+            else:
+                d = dtab.view(L, C, n)[l]  # [C, n]
+                d = d[:, col:col + B].t().contiguous() if batch_cols else d[:, col].reshape(1, C).expand(B, C).contiguous()
+                y = ops.conv1d(h, layer._w_dil, layer.dilated_conv.bias.data, dil=layer.dilation,
+                               pad=layer.dilation, in_chan_add=d, res=cp)
+                z = ops.gate(y)
+                o = ops.conv1d(z, layer._w_out, layer.output_projection.bias.data)
+                h = ops.res_skip(h, o, skip, l == 0)
+        hs = ops.conv1d(skip, self._w_skip, self.skip_projection.bias.data, pro="div", pro_param=math.sqrt(L),
+                        act="relu")
+        return ops.conv1d(hs, self._w_outp, self.output_projection.bias.data)
+
+    # ---- reference signature ---------------------------------------------------------------------------
+    def forward(self, spec, diffusion_step, cond):
+        """spec [B,1,M,T] fp32, diffusion_step int64 [B], cond [B,H,T] -> [B,1,M,T]  (diffnet.py:110-132)."""
+        x = spec[:, 0].contiguous()
+        dtab = self.step_table(diffusion_step.to(torch.float32).contiguous())
+        condproj = self.cond_projections(cond.contiguous())
+        x0 = self.denoise(x, condproj, dtab, 0, True)
+        return x0[:, None, :, :]

@@ -1,0 +1,273 @@
+"""FastSpeech-style conditioner of FluentSpeech on the HIP kernels (conv encoder, duration / pitch
+predictors, alignment gather) + MelEncoder.
+
+Module tree and parameter names equal the reference's (modules/speech_editing/spec_denoiser/fs.py:49-81,
+modules/commons/conv.py:24-139, modules/commons/nar_tts_modules.py:8-100,
+modules/speech_editing/commons/mel_encoder.py:3-19) so `state_dict()` keys match and reference
+checkpoints load with strict=True.  Only the configuration the spec_denoiser yaml selects is implemented
+(encoder_type/decoder_type 'conv', enc_dec_norm 'ln', use_spk_embed, use_pitch_embed, pitch_type 'frame',
+use_uv); anything else raises NotImplementedError.  Internally every activation is [B, C, T].
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+def _embedding(n, dim, padding_idx=None):
+    m = nn.Embedding(n, dim, padding_idx=padding_idx)  # layers.py:45-50
+    nn.init.normal_(m.weight, mean=0, std=dim ** -0.5)
+    if padding_idx is not None:
+        nn.init.constant_(m.weight[padding_idx], 0)
+    return m
+
+
+def _cw(conv_or_linear):
+    """ConvWeight over an nn.Conv1d / nn.Linear parameter container."""
+    w = conv_or_linear.weight
+    if w.dim() == 3:
+        cout, cin, k = w.shape
+    else:
+        (cout, cin), k = w.shape, 1
+    return ops.ConvWeight(lambda: conv_or_linear.weight.data, cout, cin, k)
+
+
+class ResidualBlock(nn.Module):
+    """n x [LN(ch) -> conv k (C->2C) -> *k^-0.5 -> GELU -> conv 1x1 (2C->C)] + residual, x nonpadding
+    (modules/commons/conv.py:24-65)."""
+
+    def __init__(self, channels, kernel_size, dilation, n=2, c_multiple=2, ln_eps=1e-5):
+        super().__init__()
+        self.kernel_size, self.dilation, self.ln_eps = kernel_size, dilation, ln_eps
+        self.blocks = nn.ModuleList([
+            nn.Sequential(
+                nn.LayerNorm(channels, eps=ln_eps),
+                nn.Conv1d(channels, c_multiple * channels, kernel_size, dilation=dilation,
+                          padding=(dilation * (kernel_size - 1)) // 2),
+                nn.Identity(), nn.Identity(),  # [2] = scale lambda, [3] = GELU in the reference (no params)
+                nn.Conv1d(c_multiple * channels, channels, 1, dilation=dilation),
+            ) for _ in range(n)])
+        self._cw = [(_cw(b[1]), _cw(b[4])) for b in self.blocks]
+
+    def run(self, x):
+        k, d = self.kernel_size, self.dilation
+        nonpad = ops.abs_sum_mask(x)  # conv.py:58
+        for b, (w1, w2) in zip(self.blocks, self._cw):
+            h = ops.layernorm_ch(x, b[0].weight.data, b[0].bias.data, eps=self.ln_eps)
+            h = ops.conv1d(h, w1, b[1].bias.data, dil=d, pad=(d * (k - 1)) // 2, alpha=k ** -0.5, act="gelu")
+            x = ops.conv1d(h, w2, b[4].bias.data, res=x, mask=nonpad)  # (x + x_) * nonpadding
+        return x
+
+
+class ConvBlocks(nn.Module):
+    """modules/commons/conv.py:68-116 (norm 'ln', is_BTC handled by the caller: this works on [B,C,T])."""
+
+    def __init__(self, hidden_size, out_dims, dilations, kernel_size, layers_in_block=2, c_multiple=2,
+                 ln_eps=1e-5, post_net_kernel=3, norm_type="ln"):
+        super().__init__()
+        if norm_type != "ln":
+            raise NotImplementedError("enc_dec_norm=%r (spec_denoiser.yaml uses 'ln')" % norm_type)
+        self.res_blocks = nn.Sequential(*[
+            ResidualBlock(hidden_size, kernel_size, d, n=layers_in_block, c_multiple=c_multiple, ln_eps=ln_eps)
+            for d in dilations])
+        self.last_norm = nn.LayerNorm(hidden_size, eps=ln_eps)
+        self.post_net1 = nn.Conv1d(hidden_size, out_dims, kernel_size=post_net_kernel, padding=post_net_kernel // 2)
+        self.post_net_kernel = post_net_kernel
+        self.ln_eps = ln_eps
+        for m in self.modules():  # init_weights_func, conv.py:18-21
+            if isinstance(m, nn.Conv1d):
+                nn.init.xavier_uniform_(m.weight)
+        self._w_post = _cw(self.post_net1)
+
+    def run(self, x):
+        nonpad = ops.abs_sum_mask(x)  # conv.py:108
+        for rb in self.res_blocks:
+            x = rb.run(x)
+        x = ops.add_chan_mask(x, None, nonpad)
+        x = ops.layernorm_ch(x, self.last_norm.weight.data, self.last_norm.bias.data, mask=nonpad, eps=self.ln_eps)
+        return ops.conv1d(x, self._w_post, self.post_net1.bias.data, pad=self.post_net_kernel // 2, mask=nonpad)
+
+
+class TextConvEncoder(ConvBlocks):
+    """modules/commons/conv.py:119-139."""
+
+    def __init__(self, dict_size, hidden_size, out_dims, dilations, kernel_size, layers_in_block=2,
+                 post_net_kernel=3, norm_type="ln"):
+        super().__init__(hidden_size, out_dims, dilations, kernel_size, layers_in_block=layers_in_block,
+                         post_net_kernel=post_net_kernel, norm_type=norm_type)
+        self.embed_tokens = _embedding(dict_size, hidden_size, 0)
+        self.embed_scale = math.sqrt(hidden_size)
+
+    def run_tokens(self, txt_tokens):
+        x = ops.embedding_bct(txt_tokens, self.embed_tokens.weight.data, scale=self.embed_scale)
+        return self.run(x)
+
+
+class _PredictorStack(nn.Module):
+    def __init__(self, idim, n_layers, n_chans, kernel_size):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.conv = nn.ModuleList()
+        for idx in range(n_layers):
+            cin = idim if idx == 0 else n_chans
+            self.conv.append(nn.Sequential(
+                nn.Conv1d(cin, n_chans, kernel_size, stride=1, padding=kernel_size // 2),
+                nn.Identity(),  # ReLU
+                nn.LayerNorm(n_chans),
+                nn.Identity(),  # Dropout (eval)
+            ))
+        self._cws = [_cw(f[0]) for f in self.conv]
+
+    def run_stack(self, x, nonpad=None):
+        k = self.kernel_size
+        for f, w in zip(self.conv, self._cws):
+            x = ops.conv1d(x, w, f[0].bias.data, pad=k // 2, act="relu")
+            x = ops.layernorm_ch(x, f[2].weight.data, f[2].bias.data, mask=nonpad)
+        return x
+
+
+class DurationPredictor(_PredictorStack):
+    """modules/commons/nar_tts_modules.py:8-34 (inference / eval: dropout is identity)."""
+
+    def __init__(self, idim, n_layers=2, n_chans=384, kernel_size=3, dropout_rate=0.1):
+        super().__init__(idim, n_layers, n_chans, kernel_size)
+        self.linear = nn.Sequential(nn.Linear(n_chans, 1), nn.Identity())  # [1] = Softplus
+        self._w_lin = _cw(self.linear[0])
+
+    def run(self, x, src_nonpad):
+        x = self.run_stack(x, src_nonpad)
+        d = ops.conv1d(x, self._w_lin, self.linear[0].bias.data, act="softplus", mask=src_nonpad)
+        return d.view(d.shape[0], d.shape[2])
+
+
+class PitchPredictor(_PredictorStack):
+    """modules/commons/nar_tts_modules.py:75-100."""
+
+    def __init__(self, idim, n_layers=5, n_chans=384, odim=2, kernel_size=5, dropout_rate=0.1):
+        super().__init__(idim, n_layers, n_chans, kernel_size)
+        self.linear = nn.Linear(n_chans, odim)
+        self._w_lin = _cw(self.linear)
+
+    def run(self, x):
+        x = self.run_stack(x, None)
+        return ops.conv1d(x, self._w_lin, self.linear.bias.data)  # [B, odim, T]
+
+
+class LengthRegulator(nn.Module):
+    """modules/commons/nar_tts_modules.py:37-72 (alpha = 1; padding given by txt_tokens == 0)."""
+
+    def forward(self, dur, txt_tokens):
+        return ops.length_regulate(dur.contiguous(), txt_tokens)
+
+
+class MelEncoder(nn.Module):
+    """modules/speech_editing/commons/mel_encoder.py:3-19."""
+
+    def __init__(self, input_dim=80, hidden_size=192):
+        super().__init__()
+        self.encoder = nn.Sequential(nn.Linear(input_dim, hidden_size), nn.Identity(),
+                                     nn.Linear(hidden_size, hidden_size), nn.Identity())
+        self.fc_out = nn.Linear(hidden_size, hidden_size)
+        self._w0, self._w2, self._w_out = _cw(self.encoder[0]), _cw(self.encoder[2]), _cw(self.fc_out)
+
+    def run(self, x_bct, res=None, mask=None):
+        """x [B,80,T] -> fc_out(...) (+ res) (* mask), all fused in the last conv's epilogue."""
+        h = ops.conv1d(x_bct, self._w0, self.encoder[0].bias.data, act="relu")
+        h = ops.conv1d(h, self._w2, self.encoder[2].bias.data, act="relu")
+        return ops.conv1d(h, self._w_out, self.fc_out.bias.data, res=res, mask=mask)
+
+
+class FastSpeech(nn.Module):
+    """modules/speech_editing/spec_denoiser/fs.py:49-189 with skip_decoder=True (the only way
+    GaussianDiffusion calls it, spec_denoiser.py:159-161).  `decoder` / `mel_out` exist as parameters
+    (checkpoint compatibility) but are never run, exactly as in the reference."""
+
+    def __init__(self, dict_size, hp, out_dims=None):
+        super().__init__()
+        self.hparams = dict(hp)
+        H = self.hidden_size = hp["hidden_size"]
+        if hp["encoder_type"] != "conv" or hp["decoder_type"] != "conv":
+            raise NotImplementedError("only encoder_type/decoder_type 'conv' (spec_denoiser.yaml)")
+        self.encoder = TextConvEncoder(dict_size, H, H, hp["enc_dilations"], hp["enc_kernel_size"],
+                                       layers_in_block=hp["layers_in_block"], norm_type=hp["enc_dec_norm"],
+                                       post_net_kernel=hp.get("enc_post_net_kernel", 3))
+        self.decoder = ConvBlocks(H, H, hp["dec_dilations"], hp["dec_kernel_size"],
+                                  layers_in_block=hp["layers_in_block"], norm_type=hp["enc_dec_norm"],
+                                  post_net_kernel=hp.get("dec_post_net_kernel", 3))
+        self.out_dims = hp["audio_num_mel_bins"] if out_dims is None else out_dims
+        self.mel_out = nn.Linear(H, self.out_dims, bias=True)
+        if hp["use_spk_id"]:
+            raise NotImplementedError("use_spk_id (spec_denoiser.yaml uses use_spk_embed)")
+        if not hp["use_spk_embed"] or not hp["use_pitch_embed"]:
+            raise NotImplementedError("spec_denoiser.yaml sets use_spk_embed and use_pitch_embed")
+        if hp.get("dec_inp_add_noise"):
+            raise NotImplementedError("dec_inp_add_noise")
+        self.spk_embed_proj = nn.Linear(256, H, bias=True)
+        ph = hp["predictor_hidden"] if hp["predictor_hidden"] > 0 else H
+        self.dur_embed = _embedding(2000, H, 0)
+        self.dur_predictor = DurationPredictor(H, n_chans=ph, n_layers=hp["dur_predictor_layers"],
+                                               dropout_rate=hp["predictor_dropout"],
+                                               kernel_size=hp["dur_predictor_kernel"])
+        self.length_regulator = LengthRegulator()
+        self.pitch_embed = _embedding(300, H, 0)
+        self.pitch_predictor = PitchPredictor(H, n_chans=ph, n_layers=5, dropout_rate=0.2, odim=2,
+                                              kernel_size=hp["predictor_kernel"])
+        self._w_spk = _cw(self.spk_embed_proj)
+
+    def forward(self, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv, spk_id=None, skip_decoder=True,
+                infer=False, use_pred_mel2ph=False, use_pred_pitch=False, **kwargs):
+        """Returns ret with `decoder_inp_bct` [B,H,T] (internal layout) next to the reference's keys
+        (`dur`, `mel2ph`, `pitch_pred`, `f0_denorm`, `f0_denorm_pred`); the caller finishes `decoder_inp`."""
+        if not skip_decoder:
+            raise NotImplementedError("FluentSpeech always calls fs(..., skip_decoder=True)")
+        hp = self.hparams
+        if not (hp["pitch_type"] == "frame" and hp["use_uv"]):
+            raise NotImplementedError("pitch_type 'frame' + use_uv only")
+        ret = {}
+        B, T_txt = txt_tokens.shape
+        tmask = time_mel_masks.reshape(B, -1).contiguous()  # [B,T]
+        enc = self.encoder.run_tokens(txt_tokens)  # [B,H,T_txt]
+        src_nonpad = ops.index_mask(txt_tokens)
+        style = ops.conv1d(spk_embed.reshape(B, 256, 1).contiguous(), self._w_spk, self.spk_embed_proj.bias.data)
+        style = style.view(B, self.hidden_size)  # fs.py:114-121
+        # ---- duration (fs.py:123-151)
+        dur_inp = ops.add_chan_mask(enc, style, src_nonpad)
+        mdur = ops.masked_dur(mel2ph, tmask, txt_tokens)
+        ret["masked_dur"] = mdur
+        ops.embedding_bct(mdur, self.dur_embed.weight.data, out=dur_inp, accumulate=True)
+        ret["dur"] = dur = self.dur_predictor.run(dur_inp, src_nonpad)
+        if use_pred_mel2ph:
+            mel2ph = self.length_regulator(dur, txt_tokens)
+        fm = hp["frames_multiple"]
+        if fm != 1:
+            mel2ph = mel2ph[:, :mel2ph.shape[1] // fm * fm].contiguous()  # align_ops.py:15-18
+        ret["mel2ph"] = mel2ph
+        tgt_nonpad = ops.index_mask(mel2ph)
+        dec = ops.expand_states(enc, mel2ph)  # align_ops.py:21-25
+        # ---- pitch (fs.py:153-189)
+        pitch_inp = ops.add_chan_mask(dec, style, tgt_nonpad)
+        _, masked_pitch = ops.pitch_coarse(f0, uv, tmask=tmask, mel2ph_pad=mel2ph, want_denorm=False)
+        ret["masked_pitch"] = masked_pitch
+        ops.embedding_bct(masked_pitch, self.pitch_embed.weight.data, out=pitch_inp, accumulate=True)
+        pp = self.pitch_predictor.run(pitch_inp)  # [B,2,T]
+        ret["pitch_pred"] = ops.bct_to_btc(pp)
+        pad_idx = mel2ph
+        if use_pred_pitch:
+            pad_idx = None  # fs.py:172
+            pred_f0 = pp[:, 0, :].contiguous()
+            pred_uv = (pp[:, 1, :] > 0).to(torch.float32).contiguous()
+            res_f0 = ops.blend_mask(f0, pred_f0, tmask, 1)
+            res_uv = ops.blend_mask(uv, pred_uv, tmask, 1)
+        else:
+            res_f0, res_uv = f0, uv
+        f0_denorm, pitch = ops.pitch_coarse(res_f0, res_uv, mel2ph_pad=pad_idx)
+        ret["pitch"] = pitch
+        ret["f0_denorm"] = f0_denorm
+        ret["f0_denorm_pred"], _ = ops.pitch_coarse(pp[:, 0, :].contiguous(), pp[:, 1, :].contiguous(),
+                                                    mel2ph_pad=pad_idx, uv_from_logit=True, want_coarse=False)
+        ops.embedding_bct(pitch, self.pitch_embed.weight.data, out=dec, accumulate=True)
+        ret["decoder_inp_bct"] = ops.add_chan_mask(dec, style, tgt_nonpad)
+        ret["tgt_nonpad"] = tgt_nonpad
+        return ret

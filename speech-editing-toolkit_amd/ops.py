@@ -1,0 +1,415 @@
+"""Tensor-level wrappers over the C ABI (include/set_amd.h).
+
+torch is used for device memory, the current HIP stream and parameter storage
+only; every arithmetic op below is a kernel in libset_amd.so.  All tensors must
+be fp32 (or int64 for indices), contiguous, on a HIP device.  Nothing here has a
+CPU implementation: calling an op without the library / without a GPU raises.
+"""
+import ctypes as C
+import math
+import os
+
+import torch
+
+from . import _lib
+from ._lib import ACT, PRO, IMPL_MFMA, IMPL_NAIVE, SetConv1dArgs, SetDiffnetLayerArgs, SetDiffLoopArgs, check
+
+_DEFAULT_IMPL = os.environ.get("SET_AMD_CONV_IMPL", "auto")  # auto | naive | mfma
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype=torch.float32, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU: the set_amd path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+
+
+def _f(t, name="tensor"):
+    _chk(t, torch.float32, name)
+    return t
+
+
+def _fv(t, name="tensor"):
+    """fp32 GPU tensor that may be a [B,C,T] view: only the last stride must be 1."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU: the set_amd path has no CPU fallback" % name)
+    if t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1:
+        raise ValueError("%s must be an fp32 [B,C,T] tensor/view with unit last stride" % name)
+    return t
+
+
+def _i(t, name="index"):
+    _chk(t, torch.int64, name)
+    return t
+
+
+# --------------------------------------------------------------------------
+# weights: raw parameter + lazily packed MFMA image, re-packed when the parameter changes
+# --------------------------------------------------------------------------
+class ConvWeight:
+    """Weight operand of set_conv1d.
+
+    `w` is the raw tensor; (base, sco, sci, stap) address W[co][ci][tap] inside it, so the same class serves
+    nn.Conv1d [Cout,Cin,K], nn.Linear [Cout,Cin] (K=1) and one polyphase branch of nn.ConvTranspose1d
+    [Cin,Cout,k] (base=p, sco=k, sci=Cout*k, stap=u)."""
+
+    def __init__(self, getter, Cout, Cin, K, base=0, sco=None, sci=None, stap=1):
+        self._getter = getter if callable(getter) else (lambda: getter)
+        self.Cout, self.Cin, self.K = int(Cout), int(Cin), int(K)
+        self.base = int(base)
+        self.sco = int(sco if sco is not None else Cin * K)
+        self.sci = int(sci if sci is not None else K)
+        self.stap = int(stap)
+        self._packed = None
+        self._key = None
+
+    def raw(self):
+        return _f(self._getter(), "weight")
+
+    def packed(self):
+        w = self.raw()
+        key = (w.data_ptr(), w._version, w.device)
+        if self._packed is None or self._key != key:
+            n = _lib.lib().set_packed_conv_weight_size(self.Cout, self.Cin, self.K)
+            wp = torch.empty(n, dtype=torch.float32, device=w.device)
+            check(_lib.lib().set_pack_conv_weight(_p(w), _p(wp), self.Cout, self.Cin, self.K, self.base, self.sco,
+                                                  self.sci, self.stap, _stream()), "set_pack_conv_weight")
+            self._packed, self._key = wp, key
+        return self._packed
+
+
+def _pick_impl(impl, T_iter):
+    impl = impl or _DEFAULT_IMPL
+    if impl == "auto":
+        return "mfma" if T_iter >= 16 else "naive"
+    return impl
+
+
+def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act="none", act_param=0.0, alpha=1.0,
+           res=None, mask=None, in_chan_add=None, out=None, accumulate=False, impl=None,
+           T_iter=None, T_out=None, out_stride=1, out_off=0):
+    """Generic fused conv (see SetConv1dArgs in set_amd.h).  x [B,Cin,T_in] -> out [B,Cout,T_out]."""
+    _f(x, "x")
+    assert isinstance(weight, ConvWeight)
+    B, Cin, T_in = x.shape
+    assert Cin == weight.Cin, (Cin, weight.Cin)
+    if T_out is None:
+        T_out = T_in + 2 * pad - dil * (weight.K - 1) if dil > 0 else T_in
+    if T_iter is None:
+        T_iter = T_out
+    if out is None:
+        out = torch.empty(B, weight.Cout, T_out, dtype=torch.float32, device=x.device)
+    _fv(out, "out")
+    impl = _pick_impl(impl, T_iter)
+    a = SetConv1dArgs()
+    a.inp = x.data_ptr()
+    a.w = (weight.packed() if impl == "mfma" else weight.raw()).data_ptr()
+    a.bias = _f(bias, "bias").data_ptr() if bias is not None else None
+    a.res = _fv(res, "res").data_ptr() if res is not None else None
+    a.mask = _f(mask, "mask").data_ptr() if mask is not None else None
+    a.in_chan_add = _f(in_chan_add, "in_chan_add").data_ptr() if in_chan_add is not None else None
+    a.out = out.data_ptr()
+    a.in_bs, a.in_cs = Cin * T_in, T_in
+    a.out_bs, a.out_cs = out.stride(0), out.stride(1)
+    if res is not None:
+        a.res_bs, a.res_cs = res.stride(0), res.stride(1)
+    a.w_base, a.w_sco, a.w_sci, a.w_stap = weight.base, weight.sco, weight.sci, weight.stap
+    a.B, a.Cin, a.Cout, a.K, a.dil, a.pad = B, Cin, weight.Cout, weight.K, dil, pad
+    a.T_in, a.T_iter, a.T_out, a.out_stride, a.out_off = T_in, T_iter, T_out, out_stride, out_off
+    a.pro, a.act, a.accumulate = PRO[pro], ACT[act], int(bool(accumulate))
+    a.impl = IMPL_MFMA if impl == "mfma" else IMPL_NAIVE
+    a.pro_param, a.act_param, a.alpha = float(pro_param), float(act_param), float(alpha)
+    check(_lib.lib().set_conv1d(C.byref(a), _stream()), "set_conv1d")
+    return out
+
+
+def conv_transpose1d(x, w_getter, bias, Cin, Cout, k, stride, padding, *, pro="none", pro_param=0.0, impl=None,
+                     cache=None):
+    """nn.ConvTranspose1d as `stride` polyphase stride-1 convolutions (hifigan.py:114-115).
+    out[co][n] = sum_ci sum_j Wt[ci][co][u*j+p] * in[ci][q-j],  n + P = u*q + p."""
+    B, _, T_in = x.shape
+    u, P = int(stride), int(padding)
+    T_out = (T_in - 1) * u - 2 * P + k
+    out = torch.empty(B, Cout, T_out, dtype=torch.float32, device=x.device)
+    phases = cache if cache is not None else {}
+    for p in range(u):
+        J = (k - p + u - 1) // u
+        if J <= 0:
+            continue
+        if p not in phases:
+            phases[p] = ConvWeight(w_getter, Cout, Cin, J, base=p, sco=k, sci=Cout * k, stap=u)
+        conv1d(x, phases[p], bias, dil=-1, pad=0, pro=pro, pro_param=pro_param, out=out, impl=impl,
+               T_iter=T_in + J - 1, T_out=T_out, out_stride=u, out_off=p - P)
+    if k < u:  # output samples no tap reaches still carry the bias
+        raise NotImplementedError("kernel_size < stride")
+    return out
+
+
+def weight_norm_fold(g, v):
+    _f(g), _f(v)
+    w = torch.empty_like(v)
+    n0 = v.shape[0]
+    check(_lib.lib().set_weight_norm_fold(_p(g), _p(v), _p(w), n0, v.numel() // n0, _stream()), "set_weight_norm_fold")
+    return w
+
+
+# --------------------------------------------------------------------------
+# conditioner glue
+# --------------------------------------------------------------------------
+def layernorm_ch(x, gamma, beta, mask=None, eps=1e-5, out=None):
+    _f(x), _f(gamma), _f(beta), _f(mask)
+    B, Cc, T = x.shape
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.lib().set_layernorm_ch(_p(x), _p(gamma), _p(beta), _p(mask), _p(out), B, Cc, T, float(eps), _stream()),
+          "set_layernorm_ch")
+    return out
+
+
+def embedding_bct(idx, table, scale=1.0, out=None, accumulate=False):
+    _i(idx), _f(table)
+    B, T = idx.shape
+    n_rows, Cc = table.shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty(B, Cc, T, dtype=torch.float32, device=table.device)
+    check(_lib.lib().set_embedding_bct(_p(idx), _p(table), _p(_f(out)), B, T, Cc, n_rows, float(scale),
+                                       int(bool(accumulate)), _stream()), "set_embedding_bct")
+    return out
+
+
+def abs_sum_mask(x):
+    _f(x)
+    B, Cc, T = x.shape
+    m = torch.empty(B, T, dtype=torch.float32, device=x.device)
+    check(_lib.lib().set_abs_sum_mask(_p(x), _p(m), B, Cc, T, _stream()), "set_abs_sum_mask")
+    return m
+
+
+def index_mask(idx):
+    _i(idx)
+    m = torch.empty(idx.shape, dtype=torch.float32, device=idx.device)
+    check(_lib.lib().set_index_mask(_p(idx), _p(m), idx.numel(), _stream()), "set_index_mask")
+    return m
+
+
+def expand_states(enc_bct, mel2ph):
+    _f(enc_bct), _i(mel2ph)
+    B, Cc, T_txt = enc_bct.shape
+    T = mel2ph.shape[1]
+    out = torch.empty(B, Cc, T, dtype=torch.float32, device=enc_bct.device)
+    check(_lib.lib().set_expand_states(_p(enc_bct), _p(mel2ph), _p(out), B, Cc, T_txt, T, _stream()),
+          "set_expand_states")
+    return out
+
+
+def add_chan_mask(x, add=None, mask=None, out=None):
+    _f(x), _f(add), _f(mask)
+    B, Cc, T = x.shape
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.lib().set_add_chan_mask(_p(x), _p(add), _p(mask), _p(out), B, Cc, T, _stream()), "set_add_chan_mask")
+    return out
+
+
+def masked_dur(mel2ph, tmask_bt, txt_tokens):
+    _i(mel2ph), _f(tmask_bt), _i(txt_tokens)
+    B, T = mel2ph.shape
+    T_txt = txt_tokens.shape[1]
+    out = torch.empty(B, T_txt, dtype=torch.int64, device=mel2ph.device)
+    check(_lib.lib().set_masked_dur(_p(mel2ph), _p(tmask_bt), _p(txt_tokens), _p(out), B, T, T_txt, _stream()),
+          "set_masked_dur")
+    return out
+
+
+def pitch_coarse(f0, uv, tmask=None, mel2ph_pad=None, uv_from_logit=False, want_denorm=True, want_coarse=True):
+    _f(f0), _f(uv), _f(tmask), _i(mel2ph_pad)
+    n = f0.numel()
+    den = torch.empty_like(f0) if want_denorm else None
+    co = torch.empty(f0.shape, dtype=torch.int64, device=f0.device) if want_coarse else None
+    check(_lib.lib().set_pitch_coarse(_p(f0), _p(uv), _p(tmask), _p(mel2ph_pad), int(bool(uv_from_logit)), _p(den),
+                                      _p(co), n, _stream()), "set_pitch_coarse")
+    return den, co
+
+
+def btc_to_bct(x):
+    _f(x)
+    B, T, Cc = x.shape
+    out = torch.empty(B, Cc, T, dtype=torch.float32, device=x.device)
+    check(_lib.lib().set_transpose_btc_to_bct(_p(x), _p(out), B, T, Cc, _stream()), "set_transpose_btc_to_bct")
+    return out
+
+
+def bct_to_btc(x):
+    _f(x)
+    B, Cc, T = x.shape
+    out = torch.empty(B, T, Cc, dtype=torch.float32, device=x.device)
+    check(_lib.lib().set_transpose_bct_to_btc(_p(x), _p(out), B, Cc, T, _stream()), "set_transpose_bct_to_btc")
+    return out
+
+
+def sum_div(a, b=None, c=None, div=1.0, out=None):
+    _f(a), _f(b), _f(c)
+    out = torch.empty_like(a) if out is None else out
+    check(_lib.lib().set_sum_scale(_p(a), _p(b), _p(c), _p(out), float(div), a.numel(), _stream()), "set_sum_scale")
+    return out
+
+
+def blend_mask(a, b, m, inner):
+    """a*(1-m) + b*m with m broadcast over `inner` trailing elements."""
+    _f(a), _f(b), _f(m)
+    out = torch.empty_like(a)
+    check(_lib.lib().set_blend_mask(_p(a), _p(b), _p(m), _p(out), a.numel(), int(inner), _stream()), "set_blend_mask")
+    return out
+
+
+def mul_one_minus_mask(x, m, inner):
+    _f(x), _f(m)
+    out = torch.empty_like(x)
+    check(_lib.lib().set_mul_one_minus_mask(_p(x), _p(m), _p(out), x.numel(), int(inner), _stream()),
+          "set_mul_one_minus_mask")
+    return out
+
+
+def length_regulate(dur, txt_tokens):
+    """nar_tts_modules.py:42-72.  Host reads max total length (the reference sizes a tensor the same way)."""
+    _f(dur), _i(txt_tokens)
+    B, T_txt = dur.shape
+    total = torch.empty(B, dtype=torch.int64, device=dur.device)
+    check(_lib.lib().set_dur_total(_p(dur), _p(txt_tokens), _p(total), B, T_txt, _stream()), "set_dur_total")
+    T_out = int(total.max().item())
+    out = torch.empty(B, max(T_out, 0), dtype=torch.int64, device=dur.device)
+    if T_out > 0:
+        check(_lib.lib().set_length_regulate(_p(dur), _p(txt_tokens), _p(out), B, T_txt, T_out, _stream()),
+              "set_length_regulate")
+    return out
+
+
+# --------------------------------------------------------------------------
+# DiffNet pieces
+# --------------------------------------------------------------------------
+def sinusoid_embed(t_float, dim):
+    """-> [dim][n]"""
+    _f(t_float)
+    n = t_float.numel()
+    out = torch.empty(dim, n, dtype=torch.float32, device=t_float.device)
+    check(_lib.lib().set_sinusoid_embed(_p(t_float), _p(out), dim, n, _stream()), "set_sinusoid_embed")
+    return out
+
+
+def gate(y):
+    _f(y)
+    B, C2, T = y.shape
+    z = torch.empty(B, C2 // 2, T, dtype=torch.float32, device=y.device)
+    check(_lib.lib().set_gate(_p(y), _p(z), B, C2 // 2, T, _stream()), "set_gate")
+    return z
+
+
+def res_skip(x_in, o, skip, first):
+    _f(x_in), _f(o), _f(skip)
+    B, Cc, T = x_in.shape
+    x_out = torch.empty_like(x_in)
+    check(_lib.lib().set_res_skip(_p(x_in), _p(o), _p(x_out), _p(skip), B, Cc, T, int(bool(first)), _stream()),
+          "set_res_skip")
+    return x_out
+
+
+def pack_diffnet_layer(w_dil, w_out):
+    _f(w_dil), _f(w_out)
+    L = _lib.lib()
+    w1p = torch.empty(L.set_diffnet_w1p_size(), dtype=torch.float32, device=w_dil.device)
+    w2p = torch.empty(L.set_diffnet_w2p_size(), dtype=torch.float32, device=w_dil.device)
+    check(L.set_pack_diffnet_layer(_p(w_dil), _p(w_out), _p(w1p), _p(w2p), _stream()), "set_pack_diffnet_layer")
+    return w1p, w2p
+
+
+def diffnet_layer(x_in, condproj, cp_bs, dstep, d_bs, d_cs, w1p, b_dil, w2p, b_out, x_out, skip, dil, first):
+    _f(x_in), _f(x_out), _f(skip)
+    B, Cc, T = x_in.shape
+    assert Cc == 256
+    a = SetDiffnetLayerArgs()
+    a.x_in, a.condproj, a.dstep = x_in.data_ptr(), condproj, dstep
+    a.w1p, a.b_dil, a.w2p, a.b_out = w1p.data_ptr(), b_dil.data_ptr(), w2p.data_ptr(), b_out.data_ptr()
+    a.x_out, a.skip = x_out.data_ptr(), skip.data_ptr()
+    a.cp_bs, a.d_bs, a.d_cs = int(cp_bs), int(d_bs), int(d_cs)
+    a.B, a.T, a.dil, a.first = B, T, int(dil), int(bool(first))
+    check(_lib.lib().set_diffnet_layer(C.byref(a), _stream()), "set_diffnet_layer")
+
+
+def posterior_step(x0, x_t, coef4, eps=None, out=None, seed=0, offset=0):
+    """coef4 [B,4] (or [1,4] shared by the batch)."""
+    _f(x0), _f(x_t), _f(coef4), _f(eps)
+    B = x0.shape[0]
+    per_batch = x0.numel() // B
+    out = x_t if out is None else out
+    assert coef4.shape[0] in (1, B) and coef4.shape[-1] == 4
+    coef_bs = 0 if coef4.shape[0] == 1 else 4
+    check(_lib.lib().set_posterior_step(_p(x0), _p(x_t), _p(eps), _p(coef4), coef_bs, _p(out), B, per_batch, int(seed),
+                                        int(offset), _stream()), "set_posterior_step")
+    return out
+
+
+def q_sample(x_start, eps, ab2, nonpad=None):
+    _f(x_start), _f(eps), _f(ab2), _f(nonpad)
+    B, M, T = x_start.shape[0], x_start.shape[-2], x_start.shape[-1]
+    out = torch.empty_like(x_start)
+    check(_lib.lib().set_q_sample(_p(x_start), _p(eps), _p(ab2), _p(nonpad), _p(out), B, M, T, _stream()),
+          "set_q_sample")
+    return out
+
+
+def randn(shape, device, seed=0, offset=0):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(_lib.lib().set_randn(_p(out), out.numel(), int(seed), int(offset), _stream()), "set_randn")
+    return out
+
+
+def selftest_mfma():
+    err = C.c_float(-1.0)
+    check(_lib.lib().set_selftest_mfma(C.byref(err), _stream()), "set_selftest_mfma")
+    return float(err.value)
+
+
+def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, w1p, w2p, b_dil, b_out, w_skip, b_skip,
+                   w_outp, b_outp, L, steps, dilation_cycle_length, want_layer_spans=False):
+    """Enqueue the whole reverse loop (set_diffusion_loop).  x [B,M,T] is updated in place."""
+    _f(x), _f(noise), _f(condproj), _f(dstep), _f(coef4)
+    B, M, T = x.shape
+    dev = x.device
+    ws = [torch.empty(B, 256, T, dtype=torch.float32, device=dev) for _ in range(4)]
+    ws_x0pred = torch.empty(B, M, T, dtype=torch.float32, device=dev)
+    a = SetDiffLoopArgs()
+    a.B, a.T, a.M, a.L, a.steps, a.dilation_cycle_length = B, T, M, L, steps, dilation_cycle_length
+    a.x = x.data_ptr()
+    a.noise = noise.data_ptr() if noise is not None else None
+    a.seed = int(seed)
+    a.condproj, a.dstep, a.coef4 = condproj.data_ptr(), dstep.data_ptr(), coef4.data_ptr()
+    a.w_in_p, a.b_in = w_in.packed().data_ptr(), b_in.data_ptr()
+    arr = C.c_void_p * L
+    keep = [arr(*[t.data_ptr() for t in lst]) for lst in (w1p, w2p, b_dil, b_out)]
+    a.w1p, a.w2p, a.b_dil, a.b_out = (C.cast(k, C.POINTER(C.c_void_p)) for k in keep)
+    a.w_skip_p, a.b_skip = w_skip.packed().data_ptr(), b_skip.data_ptr()
+    a.w_outp_p, a.b_outp = w_outp.packed().data_ptr(), b_outp.data_ptr()
+    a.ws_x0, a.ws_x1, a.ws_skip, a.ws_h = (w.data_ptr() for w in ws)
+    a.ws_x0pred = ws_x0pred.data_ptr()
+    spans = None
+    if want_layer_spans:
+        spans = (C.c_float * steps)()
+        a.layer_span_ms = C.cast(spans, C.POINTER(C.c_float))
+    check(_lib.lib().set_diffusion_loop(C.byref(a), _stream()), "set_diffusion_loop")
+    # workspaces must outlive the enqueued kernels: record them on the stream
+    for w in ws + [ws_x0pred]:
+        w.record_stream(torch.cuda.current_stream())
+    return list(spans) if spans is not None else None

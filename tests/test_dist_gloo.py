@@ -1,0 +1,59 @@
+"""world_size-2 gloo test of the multi-GPU path: utterance sharding (no data-path collective) and the
+barrier + max-over-ranks timing reduction bench.py uses.  Runs on CPU."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import set_amd  # noqa: F401
+    from set_amd import parallel
+    r, w, _ = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    sample = {"mels": torch.arange(6 * 4 * 2, dtype=torch.float32).reshape(6, 4, 2), "mel2ph": torch.arange(24).reshape(6, 4),
+              "nsamples": 6}
+    sh = parallel.shard_batch(sample, r, w)
+    parallel.barrier()
+    tmax = parallel.max_over_ranks(1.0 + rank)
+    tot = parallel.sum_over_ranks(float(sh["mels"].shape[0]))
+    q.put((rank, sh["mels"][:, 0, 0].tolist(), sh["mel2ph"].shape[0], sh["nsamples"], tmax, tot))
+    dist.destroy_process_group()
+
+
+def test_shard_and_reduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, m0, n0, ns0, t0, tot0), (r1, m1, n1, ns1, t1, tot1) = res
+    assert m0 == [0.0, 16.0, 32.0] and m1 == [8.0, 24.0, 40.0]  # utterances 0,2,4 / 1,3,5
+    assert n0 == n1 == 3 and ns0 == 6
+    assert t0 == t1 == 2.0 and tot0 == tot1 == 6.0
+
+
+def test_single_process_is_identity():
+    import set_amd  # noqa: F401
+    from set_amd import parallel
+    s = {"a": torch.ones(3, 2)}
+    assert parallel.shard_batch(s, 0, 1) is s
+    assert parallel.max_over_ranks(3.5) == 3.5

@@ -1,0 +1,85 @@
+"""The oracle (oracle/oracle.py) against the golden vectors generated from the reference itself
+(oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import oracle as O
+from oracle import weights as Wt
+
+torch.set_grad_enabled(False)
+TOL = 2e-5
+
+INFER = [("infer_tiny", "spec_denoiser"), ("infer_pad", "spec_denoiser"), ("infer_predpitch", "spec_denoiser"),
+         ("infer_dil", "spec_denoiser_dil"), ("infer_c64", "spec_denoiser_c64"), ("infer_drift100", "spec_denoiser")]
+
+
+def _run_infer(case, manifest):
+    g = load_golden(case)
+    m = g["meta"]
+    W = Wt.seeded_weights(Wt.load_manifest(manifest), m["wseed"])
+    inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=m["pad_tail"])
+    noises = Wt.synthetic_noises(m["B"], m["T"], m["steps"], seed=m["iseed"] + 1)
+    dcl = m["overrides"].get("dilation_cycle_length", 1)
+    ret = O.gaussian_diffusion_infer(W, m["steps"], inp, noises, dilation_cycle_length=dcl, **m["flags"])
+    return g, ret
+
+
+@pytest.mark.parametrize("case,manifest", INFER)
+def test_oracle_infer_matches_reference(case, manifest):
+    g, ret = _run_infer(case, manifest)
+    assert np.abs(ret["mel_out"].numpy() - g["mel_out"]).max() < TOL
+    assert np.abs(ret["decoder_inp"].numpy() - g["decoder_inp"]).max() < TOL
+    assert np.abs(ret["dur"].numpy() - g["dur"]).max() < TOL
+    assert np.abs(ret["pitch_pred"].numpy() - g["pitch_pred"]).max() < TOL
+    assert np.array_equal(ret["mel2ph"].numpy(), g["mel2ph"])
+    assert np.array_equal(ret["masked_dur"].numpy(), g["masked_dur"])
+    assert np.array_equal(ret["pitch"].numpy(), g["pitch"])
+
+
+def test_oracle_train_branch():
+    g = load_golden("train_tiny")
+    m = g["meta"]
+    W = Wt.seeded_weights(Wt.load_manifest("spec_denoiser"), m["wseed"])
+    inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=True)
+    ret = O.gaussian_diffusion_train(W, m["steps"], inp, torch.from_numpy(g["t"]), torch.from_numpy(g["eps"]))
+    assert np.abs(ret["mel_out"].numpy() - g["mel_out"]).max() < TOL
+
+
+def test_schedule_known_answers():
+    # SURVEY.md 8a rows a1/a2
+    b8 = O.vpsde_betas(9)
+    assert abs(b8[0] - 0.2269467980000719) < 1e-15 and abs(b8[8] - 0.9849766278643581) < 1e-15
+    b100 = O.vpsde_betas(101)
+    assert abs(b100[0] - 0.0029414550474994305) < 1e-15 and abs(b100[100] - 0.32570252868784266) < 1e-15
+    g = load_golden("schedule")
+    for steps in (4, 8, 100):
+        tab, _ = O.diffusion_tables(steps)
+        for k, v in tab.items():
+            assert np.array_equal(v.numpy(), g["s%d_%s" % (steps, k)]), (steps, k)
+    tab, t64 = O.diffusion_tables(100)
+    assert t64["posterior_mean_coef1"][0] == 1.0 and t64["posterior_mean_coef2"][0] == 0.0
+    assert abs(t64["posterior_mean_coef1"][99] - 2.1172884940200542e-05) < 1e-18
+
+
+def test_length_regulator():
+    g = load_golden("length_regulator")
+    out = O.length_regulator(torch.from_numpy(g["dur"]), torch.from_numpy(g["pad"]))
+    assert np.array_equal(out.numpy(), g["mel2ph"])
+
+
+@pytest.mark.parametrize("name,h", [("hifigan_tiny", Wt.HIFIGAN_TINY), ("hifigan_tiny_rb2", Wt.HIFIGAN_TINY_RB2),
+                                    ("hifigan_v1", Wt.HIFIGAN_V1)])
+def test_oracle_hifigan(name, h):
+    g = load_golden(name)
+    W = Wt.seeded_weights(Wt.load_manifest(name), g["meta"]["wseed"])
+    wav = O.hifigan_forward(W, h, torch.from_numpy(g["mel"]))
+    assert np.abs(wav.numpy() - g["wav"]).max() < TOL
+
+
+def test_mel_mcd_zero_and_scale():
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(50, 80))
+    assert O.mel_mcd(a, a) == 0.0
+    assert O.mel_mcd(a, a + 1e-4) < 1e-2
