@@ -1,0 +1,448 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): every HIP kernel and the whole path, through the
+C ABI, against the CPU oracle on the same seeded inputs and against the committed golden vectors.
+
+Bars: bit-exact for integer/index tensors; fp32 tolerances written next to each check
+(north_star: |dmel| < 1e-4 on the final mel)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import base_hparams, load_golden
+from oracle import oracle as O
+from oracle import weights as Wt
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev(built_lib):
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _maxdiff(a, b):
+    a = a.detach().cpu().double() if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a)).double()
+    b = b.detach().cpu().double() if isinstance(b, torch.Tensor) else torch.from_numpy(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max())
+
+
+def test_mfma_fragment_layout(dev):
+    from set_amd import ops
+    assert ops.selftest_mfma() == 0.0  # exact: small integers/8ths in fp32
+
+
+# ----------------------------------------------------------------------------------------------------
+# generic conv: naive and MFMA vs torch CPU
+# ----------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B, Cin, Cout, K, dil, T, extras
+    (2, 80, 256, 1, 1, 64, dict(act="relu")),
+    (2, 256, 80, 1, 1, 70, dict()),
+    (1, 256, 256, 1, 1, 33, dict(pro="div", pro_param=math.sqrt(20.0), act="relu")),
+    (2, 192, 384, 5, 1, 50, dict(alpha=5 ** -0.5, act="gelu")),
+    (2, 384, 192, 1, 1, 50, dict(res=True, mask=True)),
+    (1, 192, 192, 3, 1, 16, dict(mask=True)),
+    (3, 7, 33, 3, 2, 29, dict(chan_add=True, res=True)),
+    (2, 192, 1, 1, 1, 40, dict(act="softplus", mask=True)),
+    (2, 192, 2, 1, 1, 300, dict()),
+    (1, 32, 32, 11, 5, 257, dict(pro="lrelu", pro_param=0.1, res=True)),
+    (1, 64, 1, 7, 1, 130, dict(pro="lrelu", pro_param=0.01, act="tanh")),
+    (2, 256, 1024, 1, 1, 5, dict(act="mish")),
+    (1, 256, 512, 3, 4, 90, dict(chan_add=True, res=True)),
+    (2, 16, 48, 3, 1, 64, dict(accumulate=True)),
+]
+
+
+def _conv_ref(x, w, b, K, dil, ex, res, mask, add, prev):
+    xin = x
+    if add is not None:
+        xin = xin + add[:, :, None]
+    if ex.get("pro") == "lrelu":
+        xin = F.leaky_relu(xin, ex["pro_param"])
+    elif ex.get("pro") == "div":
+        xin = xin / ex["pro_param"]
+    pad = dil * (K - 1) // 2
+    # the bias / chan_add must not leak into the zero padding: pad AFTER the prologue
+    y = F.conv1d(F.pad(xin, (pad, pad)), w, b, dilation=dil)
+    y = y * ex.get("alpha", 1.0)
+    act = ex.get("act", "none")
+    y = {"none": lambda v: v, "relu": F.relu, "gelu": F.gelu, "tanh": torch.tanh, "softplus": F.softplus,
+         "mish": O.mish}[act](y)
+    if res is not None:
+        y = y + res
+    if mask is not None:
+        y = y * mask[:, None, :]
+    if prev is not None:
+        y = prev + y
+    return y
+
+
+@pytest.mark.parametrize("impl", ["naive", "mfma"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv1d_vs_torch(dev, impl, case):
+    from set_amd import ops
+    B, Cin, Cout, K, dil, T, ex = case
+    g = torch.Generator().manual_seed(1000 + Cin * 7 + Cout + K)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / math.sqrt(Cin * K)
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(B, Cout, T, generator=g) if ex.get("res") else None
+    mask = (torch.rand(B, T, generator=g) > 0.3).float() if ex.get("mask") else None
+    add = torch.randn(B, Cin, generator=g) if ex.get("chan_add") else None
+    prev = torch.randn(B, Cout, T, generator=g) if ex.get("accumulate") else None
+    ref = _conv_ref(x, w, b, K, dil, ex, res, mask, add, prev)
+    wd = w.to(dev)
+    cw = ops.ConvWeight(lambda: wd, Cout, Cin, K)
+    out = prev.clone().to(dev) if prev is not None else None
+    kw = {k: ex[k] for k in ("pro", "pro_param", "act", "alpha") if k in ex}
+    y = ops.conv1d(x.to(dev), cw, b.to(dev), dil=dil, pad=dil * (K - 1) // 2, res=None if res is None else res.to(dev),
+                   mask=None if mask is None else mask.to(dev), in_chan_add=None if add is None else add.to(dev),
+                   out=out, accumulate=prev is not None, impl=impl, **kw)
+    torch.cuda.synchronize()
+    assert _maxdiff(y, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("impl", ["naive", "mfma"])
+@pytest.mark.parametrize("cfg", [(2, 64, 32, 8, 4, 24), (1, 32, 16, 4, 2, 37), (1, 512, 256, 16, 8, 12),
+                                 (2, 16, 8, 7, 3, 10)])
+def test_conv_transpose_polyphase(dev, impl, cfg):
+    from set_amd import ops
+    B, Cin, Cout, k, u, T = cfg
+    g = torch.Generator().manual_seed(77 + k)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cin, Cout, k, generator=g) / math.sqrt(Cin * k / u)
+    b = torch.randn(Cout, generator=g) * 0.1
+    P = (k - u) // 2
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=u, padding=P)
+    wd = w.to(dev)
+    y = ops.conv_transpose1d(x.to(dev), lambda: wd, b.to(dev), Cin, Cout, k, u, P, pro="lrelu", pro_param=0.1,
+                             impl=impl)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert _maxdiff(y, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+# ----------------------------------------------------------------------------------------------------
+# glue kernels
+# ----------------------------------------------------------------------------------------------------
+def test_glue_kernels(dev):
+    from set_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, C, T, Tt = 3, 192, 70, 21
+    x = torch.randn(B, C, T, generator=g)
+    gam, bet = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    mask = (torch.rand(B, T, generator=g) > 0.2).float()
+    ref = O.layer_norm_ch(x, gam, bet) * mask[:, None, :]
+    assert _maxdiff(ops.layernorm_ch(x.to(dev), gam.to(dev), bet.to(dev), mask.to(dev)), ref) < 1e-5
+    idx = torch.randint(0, 50, (B, T), generator=g)
+    tab = torch.randn(50, C, generator=g)
+    e = ops.embedding_bct(idx.to(dev), tab.to(dev), scale=math.sqrt(C))
+    assert _maxdiff(e, (math.sqrt(C) * F.embedding(idx, tab)).transpose(1, 2)) == 0.0
+    e2 = ops.embedding_bct(idx.to(dev), tab.to(dev), out=x.to(dev).clone(), accumulate=True)
+    assert _maxdiff(e2, x + F.embedding(idx, tab).transpose(1, 2)) == 0.0
+    xz = x.clone()
+    xz[:, :, 5:9] = 0
+    assert _maxdiff(ops.abs_sum_mask(xz.to(dev)), (xz.abs().sum(1) > 0).float()) == 0.0
+    assert _maxdiff(ops.index_mask(idx.to(dev)), (idx > 0).float()) == 0.0
+    enc = torch.randn(B, C, Tt, generator=g)
+    m2p = torch.sort(torch.randint(0, Tt + 1, (B, T), generator=g), dim=1).values
+    ref = O.expand_states(enc.transpose(1, 2), m2p).transpose(1, 2)
+    assert _maxdiff(ops.expand_states(enc.to(dev), m2p.to(dev)), ref) == 0.0
+    add = torch.randn(B, C, generator=g)
+    assert _maxdiff(ops.add_chan_mask(x.to(dev), add.to(dev), mask.to(dev)), (x + add[:, :, None]) * mask[:, None]) == 0.0
+    bt = torch.randn(B, T, 80, generator=g)
+    assert _maxdiff(ops.btc_to_bct(bt.to(dev)), bt.transpose(1, 2)) == 0.0
+    assert _maxdiff(ops.bct_to_btc(x.to(dev)), x.transpose(1, 2)) == 0.0
+    a, b_, c = (torch.randn(1000, generator=g) for _ in range(3))
+    assert _maxdiff(ops.sum_div(a.to(dev), b_.to(dev), c.to(dev), 3.0), ((a + b_) + c) / 3.0) == 0.0
+    m1 = (torch.rand(B, T, generator=g) > 0.5).float()
+    assert _maxdiff(ops.mul_one_minus_mask(bt.to(dev), m1.to(dev), 80), bt * (1 - m1[:, :, None])) == 0.0
+    bt2 = torch.randn(B, T, 80, generator=g)
+    assert _maxdiff(ops.blend_mask(bt.to(dev), bt2.to(dev), m1.to(dev), 80),
+                    bt * (1 - m1[:, :, None]) + bt2 * m1[:, :, None]) == 0.0
+
+
+def test_integer_bookkeeping_bit_exact(dev):
+    from set_amd import ops
+    inp = Wt.synthetic_inputs(4, 120, 30, seed=9, pad_tail=True)
+    tm = inp["time_mel_masks"].squeeze(-1)
+    ref_md = (O.mel2token_to_dur(inp["mel2ph"] * (1 - inp["time_mel_masks"]).squeeze(-1).long(), 30)
+              * (inp["txt_tokens"] != 0).float()).long()
+    md = ops.masked_dur(inp["mel2ph"].to(dev), tm.contiguous().to(dev), inp["txt_tokens"].to(dev))
+    assert torch.equal(md.cpu(), ref_md)
+    pad = inp["mel2ph"] == 0
+    ref_den = O.denorm_f0(inp["f0"] * (1 - tm), inp["uv"] * (1 - tm), pad)
+    ref_bins = O.f0_to_coarse(ref_den)
+    den, bins = ops.pitch_coarse(inp["f0"].to(dev), inp["uv"].to(dev), tmask=tm.contiguous().to(dev),
+                                 mel2ph_pad=inp["mel2ph"].to(dev))
+    assert torch.equal(bins.cpu(), ref_bins)
+    assert _maxdiff(den, ref_den) < 1e-3  # Hz; exp2f vs torch pow(2, x)
+    # dense sweep of the bin function over the whole f0 range
+    f = torch.linspace(5.0, 10.5, 20001)
+    ref_bins = O.f0_to_coarse(O.denorm_f0(f, None))
+    _, bins = ops.pitch_coarse(f.to(dev), None)
+    mism = int((bins.cpu() != ref_bins).sum())
+    assert mism <= 2, mism  # bin edges: exp2f vs pow rounding can flip a sample sitting exactly on an edge
+    g = load_golden("length_regulator")
+    txt = torch.from_numpy((~g["pad"]).astype(np.int64))
+    out = ops.length_regulate(torch.from_numpy(g["dur"]).to(dev), txt.to(dev))
+    assert torch.equal(out.cpu(), torch.from_numpy(g["mel2ph"]))
+
+
+def test_posterior_qsample_randn(dev):
+    from set_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, M, T = 3, 80, 37
+    tab, _ = O.diffusion_tables(8)
+    x0, xt, eps = (torch.randn(B, 1, M, T, generator=g) for _ in range(3))
+    t = torch.tensor([0, 3, 7])
+    ref = O.q_posterior_sample(tab, x0, xt, t, eps)
+    coef = torch.stack([tab["posterior_mean_coef1"][t], tab["posterior_mean_coef2"][t],
+                        tab["posterior_log_variance_clipped"][t], (t != 0).float()], -1).contiguous()
+    out = torch.empty(B, 1, M, T, device=dev)
+    ops.posterior_step(x0.to(dev), xt.to(dev), coef.to(dev), eps=eps.to(dev), out=out)
+    assert _maxdiff(out, ref) < 1e-6
+    ab = torch.stack([tab["sqrt_alphas_cumprod"][t], tab["sqrt_one_minus_alphas_cumprod"][t]], -1).contiguous()
+    assert _maxdiff(ops.q_sample(x0.to(dev), eps.to(dev), ab.to(dev)), O.q_sample(tab, x0, t, eps)) < 1e-6
+    z = ops.randn((1 << 20,), dev, seed=7)
+    z2 = ops.randn((1 << 20,), dev, seed=7)
+    assert torch.equal(z, z2) and not torch.equal(z, ops.randn((1 << 20,), dev, seed=8))
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.05
+
+
+# ----------------------------------------------------------------------------------------------------
+# DiffNet: fused layer kernel vs unfused kernels vs golden layer traces
+# ----------------------------------------------------------------------------------------------------
+def _build_model(dev, manifest, wseed, steps, **over):
+    from set_amd.diffnet import DiffNet
+    from set_amd.spec_denoiser import GaussianDiffusion
+    hp = base_hparams(timesteps=steps, **over)
+    m = GaussianDiffusion(list(range(80)), 80, DiffNet(80, hp), timesteps=steps, time_scale=1, loss_type="l1",
+                          spec_min=[], spec_max=[], hp=hp)
+    W = Wt.seeded_weights(Wt.load_manifest(manifest), wseed)
+    missing, unexpected = m.load_state_dict(W, strict=False)
+    assert not unexpected and all(Wt.is_buffer(k) for k in missing)
+    return m.to(dev).eval(), W
+
+
+def _case_inputs(g, dev):
+    m = g["meta"]
+    inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=m["pad_tail"])
+    noises = torch.stack(Wt.synthetic_noises(m["B"], m["T"], m["steps"], seed=m["iseed"] + 1))
+    return {k: v.to(dev) for k, v in inp.items()}, noises.to(dev)
+
+
+def test_diffnet_single_pass_fused_vs_unfused_vs_oracle(dev):
+    g = load_golden("infer_tiny")
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"])
+    dn = model.denoise_fn
+    gen = torch.Generator().manual_seed(11)
+    B, T = 2, 100  # T not a multiple of the 64-frame tile
+    spec = torch.randn(B, 1, 80, T, generator=gen)
+    cond = torch.randn(B, 192, T, generator=gen)
+    t = torch.tensor([3, 0])
+    ref = O.diffnet_forward(W, spec, t, cond)
+    dn.impl = "fused"
+    y_f = dn(spec.to(dev), t.to(dev), cond.to(dev))
+    dn.impl = "unfused"
+    y_u = dn(spec.to(dev), t.to(dev), cond.to(dev))
+    torch.cuda.synchronize()
+    assert _maxdiff(y_u, ref) < 2e-5
+    assert _maxdiff(y_f, ref) < 2e-5
+    assert _maxdiff(y_f, y_u) < 2e-5
+
+
+def test_fused_layer_matches_golden_layer_trace(dev):
+    """First executed step of infer_tiny: per-layer (x, skip) after layers 0, 1 and 19 from the reference."""
+    from set_amd import ops
+    g = load_golden("infer_tiny")
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"])
+    inp, noises = _case_inputs(g, dev)
+    dn = model.denoise_fn
+    ret, cond = model.conditioner(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"],
+                                  inp["ref_mels"], inp["f0"], inp["uv"])
+    steps = m["steps"]
+    ids = torch.arange(steps, device=dev)
+    dtab = dn.step_table(ids.float())
+    condproj = dn.cond_projections(cond)
+    x = noises[0, :, 0].contiguous()
+    h = ops.conv1d(x, dn._w_in, dn.input_projection.bias.data, act="relu")
+    B, C, T = h.shape
+    skip = torch.empty_like(h)
+    nxt = torch.empty_like(h)
+    sid = steps - 1
+    for l, layer in enumerate(dn.residual_layers):
+        w1p, w2p = layer.fused_weights()
+        ops.diffnet_layer(h, condproj[:, l * 512:(l + 1) * 512].data_ptr(), condproj.stride(0),
+                          dtab.data_ptr() + 4 * (l * C * steps + sid), 0, steps, w1p, layer.dilated_conv.bias.data,
+                          w2p, layer.output_projection.bias.data, nxt, skip, layer.dilation, l == 0)
+        h, nxt = nxt, h
+        if l in (0, 1, 19):
+            torch.cuda.synchronize()
+            assert _maxdiff(h, g["layer%d_x" % l]) < 2e-5, l
+    # golden skip is the per-layer skip output; ours is the running sum -> check the final sum via x0
+    hs = ops.conv1d(skip, dn._w_skip, dn.skip_projection.bias.data, pro="div", pro_param=math.sqrt(20.0), act="relu")
+    x0 = ops.conv1d(hs, dn._w_outp, dn.output_projection.bias.data)
+    assert _maxdiff(x0[:, None], g["x0_step0"]) < 2e-5
+
+
+# ----------------------------------------------------------------------------------------------------
+# whole path vs golden (reference outputs)
+# ----------------------------------------------------------------------------------------------------
+FULL = [("infer_tiny", "spec_denoiser", {}), ("infer_pad", "spec_denoiser", {}),
+        ("infer_predpitch", "spec_denoiser", {}), ("infer_drift100", "spec_denoiser", {}),
+        ("infer_dil", "spec_denoiser_dil", {}), ("infer_c64", "spec_denoiser_c64", {})]
+
+
+@pytest.mark.parametrize("case,manifest,_", FULL)
+def test_full_inference_matches_reference(dev, case, manifest, _):
+    g = load_golden(case)
+    m = g["meta"]
+    model, W = _build_model(dev, manifest, m["wseed"], m["steps"], **m["overrides"])
+    inp, noises = _case_inputs(g, dev)
+    ret = model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"],
+                inp["f0"], inp["uv"], infer=True, noises=noises, **m["flags"])
+    torch.cuda.synchronize()
+    # integer / index tensors: bit exact
+    assert torch.equal(ret["mel2ph"].cpu(), torch.from_numpy(g["mel2ph"]))
+    assert torch.equal(ret["masked_dur"].cpu(), torch.from_numpy(g["masked_dur"]))
+    assert torch.equal(ret["masked_pitch"].cpu(), torch.from_numpy(g["masked_pitch"]))
+    assert torch.equal(ret["pitch"].cpu(), torch.from_numpy(g["pitch"]))
+    # conditioner floats
+    assert _maxdiff(ret["decoder_inp"], g["decoder_inp"]) < 2e-5
+    assert _maxdiff(ret["dur"], g["dur"]) < 2e-5
+    assert _maxdiff(ret["pitch_pred"], g["pitch_pred"]) < 5e-5
+    assert _maxdiff(ret["f0_denorm"], g["f0_denorm"]) < 1e-3
+    # the bar: |dmel| < 1e-4 (fp32) after the whole reverse loop
+    d = _maxdiff(ret["mel_out"], g["mel_out"])
+    mcd = O.mel_mcd(ret["mel_out"].cpu().numpy(), g["mel_out"])
+    print("%s: max|dmel| = %.3e  mel-MCD = %.3e" % (case, d, mcd))
+    assert d < 1e-4
+    assert mcd < 1e-3
+
+
+def test_unfused_loop_matches_fused(dev):
+    g = load_golden("infer_pad")
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"])
+    inp, noises = _case_inputs(g, dev)
+    args = (inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"],
+            inp["uv"])
+    model.denoise_fn.impl = "unfused"
+    r_u = model(*args, infer=True, noises=noises)
+    model.denoise_fn.impl = "fused"
+    r_f = model(*args, infer=True, noises=noises)
+    assert _maxdiff(r_u["mel_out"], g["mel_out"]) < 1e-4
+    assert _maxdiff(r_f["mel_out"], r_u["mel_out"]) < 1e-4
+
+
+def test_train_branch_forward(dev):
+    g = load_golden("train_tiny")
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"])
+    inp = {k: v.to(dev) for k, v in Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=True).items()}
+    ret = model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"],
+                inp["uv"], infer=False, t=torch.from_numpy(g["t"]).to(dev), noises=torch.from_numpy(g["eps"]).to(dev))
+    assert _maxdiff(ret["x_t"][:, None], g["x_t"]) < 1e-6
+    assert _maxdiff(ret["mel_out"], g["mel_out"]) < 5e-5
+
+
+def test_task_run_model_paste(dev):
+    from set_amd import hparams as H
+    from set_amd import tasks
+    g = load_golden("infer_tiny")
+    m = g["meta"]
+    H.hparams.clear()
+    H.hparams.update(base_hparams(timesteps=m["steps"]))
+    task = tasks.SpeechDenoiserTask(build_vocoder=False)
+    task.build_model()
+    W = Wt.seeded_weights(Wt.load_manifest("spec_denoiser"), m["wseed"])
+    task.model.load_state_dict(W, strict=False)
+    task.model.to(dev).eval()
+    inp, noises = _case_inputs(g, dev)
+    sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"],
+                  time_mel_masks=inp["time_mel_masks"].squeeze(-1), spk_embed=inp["spk_embed"])
+    out = task.run_model(sample, infer=True, noises=noises)
+    tm = inp["time_mel_masks"].cpu()
+    ref = torch.from_numpy(g["mel_out"]) * tm + inp["ref_mels"].cpu() * (1 - tm)
+    assert _maxdiff(out["mel_out"], ref) < 1e-4
+    with pytest.raises(NotImplementedError):
+        task.run_model(sample, infer=False)
+
+
+# ----------------------------------------------------------------------------------------------------
+# HiFi-GAN
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,h", [("hifigan_tiny", Wt.HIFIGAN_TINY), ("hifigan_tiny_rb2", Wt.HIFIGAN_TINY_RB2),
+                                    ("hifigan_v1", Wt.HIFIGAN_V1)])
+@pytest.mark.parametrize("impl", ["naive", "mfma"])
+def test_hifigan_matches_reference(dev, name, h, impl, monkeypatch):
+    from set_amd import ops
+    from set_amd.hifigan import HifiGanGenerator
+    monkeypatch.setattr(ops, "_DEFAULT_IMPL", impl)
+    g = load_golden(name)
+    gen = HifiGanGenerator(h)
+    gen.load_state_dict(Wt.seeded_weights(Wt.load_manifest(name), g["meta"]["wseed"]), strict=True)
+    gen.to(dev).eval()
+    wav = gen(torch.from_numpy(g["mel"]).to(dev))
+    torch.cuda.synchronize()
+    assert wav.shape == g["wav"].shape
+    assert _maxdiff(wav, g["wav"]) < 1e-4
+
+
+def test_vocoder_wrapper_spec2wav(dev, tmp_path):
+    import yaml
+    from set_amd import hparams as H
+    from set_amd import vocoder_infer
+    g = load_golden("hifigan_tiny")
+    d = tmp_path / "voc"
+    d.mkdir()
+    yaml.safe_dump(Wt.HIFIGAN_TINY, open(d / "config.yaml", "w"))
+    torch.save({"state_dict": {"model_gen": Wt.seeded_weights(Wt.load_manifest("hifigan_tiny"), g["meta"]["wseed"])}},
+               d / "model_ckpt_steps_0.ckpt")
+    H.hparams.clear()
+    H.hparams.update(base_hparams(vocoder_ckpt=str(d)))
+    voc = vocoder_infer.get_vocoder_cls("HifiGAN")()
+    wav = voc.spec2wav(g["mel"][0].T)  # [T,80] numpy in, numpy out
+    assert wav.dtype == np.float32 and wav.shape == (g["wav"].shape[-1],)
+    assert np.abs(wav - g["wav"][0, 0]).max() < 1e-4
+
+
+# ----------------------------------------------------------------------------------------------------
+# BASELINE size (B=32, T=800): size-independent properties + a 2-step oracle check
+# ----------------------------------------------------------------------------------------------------
+def test_full_size_properties(dev):
+    from set_amd import parallel
+    B, T, Tt, steps = 32, 800, 100, 2
+    model, W = _build_model(dev, "spec_denoiser", 31, steps)
+    inp = Wt.synthetic_inputs(B, T, Tt, seed=1234, pad_tail=True)
+    noises = torch.stack(Wt.synthetic_noises(B, T, steps, seed=77))
+    di = {k: v.to(dev) for k, v in inp.items()}
+
+    def run(d, nz):
+        return model(d["txt_tokens"], d["time_mel_masks"], d["mel2ph"], d["spk_embed"], d["ref_mels"], d["f0"], d["uv"],
+                     infer=True, noises=nz.to(dev))
+
+    full = run(di, noises)
+    again = run(di, noises)
+    assert torch.equal(full["mel_out"], again["mel_out"])  # deterministic
+    assert torch.isfinite(full["mel_out"]).all()
+    # sharding invariance (what the multi-GPU path relies on): rank r of 2 computes rows r::2 bit-identically
+    for r in range(2):
+        sh = parallel.shard_batch(di, r, 2)
+        part = run(sh, noises[:, r::2].contiguous())
+        assert torch.equal(part["mel_out"], full["mel_out"][r::2])
+        assert torch.equal(part["mel2ph"], full["mel2ph"][r::2])
+    # oracle on the first 4 utterances (the CPU finishes this in seconds)
+    sub = {k: v[:4] for k, v in inp.items()}
+    oret = O.gaussian_diffusion_infer(W, steps, sub, [n[:4] for n in noises])
+    assert _maxdiff(full["mel_out"][:4], oret["mel_out"]) < 1e-4
+    assert torch.equal(full["pitch"][:4].cpu(), oret["pitch"])
