@@ -18,7 +18,8 @@
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*);
  *     the caller keeps all buffers alive until it synchronises the stream;
  *   - return value: 0 = ok, negative = SET_E_* error code; nothing throws;
- *   - no global mutable state; thread-compatible (one caller thread per stream).
+ *   - no global mutable state except a lazily created pool of auxiliary HIP streams (set_diffusion_loop
+ *     with n_groups > 1); thread-compatible (one caller thread per stream).
  */
 #ifndef SET_AMD_H
 #define SET_AMD_H
@@ -189,6 +190,9 @@ typedef struct SetDiffnetLayerArgs {
     float *skip;
     int64_t cp_bs, d_bs, d_cs;
     int32_t B, T, dil, first;
+    /* diagnostic, normally NULL: [gridDim.y*gridDim.x][8] uint64 s_memtime stamps written by wave 0 of every
+     * block at the phase boundaries (start, tile staged, GEMM1 done, gate done, z staged, GEMM2 done, end) */
+    uint64_t *dbg_clock;
 } SetDiffnetLayerArgs;
 int set_diffnet_layer(const SetDiffnetLayerArgs *args, void *stream);
 /* floats needed for w1p (512x768) and w2p (512x256) */
@@ -235,9 +239,15 @@ typedef struct SetDiffLoopArgs {
     /* workspaces, each [B][256][T] floats */
     float *ws_x0, *ws_x1, *ws_skip, *ws_h;
     float *ws_x0pred; /* [B][M][T] */
-    /* optional: HOST array [steps] receiving the wall time in ms of the 20-layer span of each step
-     * (hipEvent pairs on `stream`; the call then synchronises the stream before returning) */
+    /* optional: HOST array [steps] receiving the wall time in ms of the L-layer span of each step (hipEvent
+     * pairs on the launching stream; mean over utterance groups); the call then synchronises before returning */
     float *layer_span_ms;
+    /* optional: HOST float receiving the wall time in ms of the whole loop (event pair on `stream`); synchronises */
+    float *loop_ms;
+    /* utterance groups (<= 8; 0/1 = one): the batch is split into n_groups contiguous slices that run as
+     * independent chains on auxiliary HIP streams (forked from / joined to `stream` with events), so the tail of one
+     * group's layer launch overlaps the next layer of another group.  Results are bit-identical for any n_groups. */
+    int32_t n_groups;
 } SetDiffLoopArgs;
 int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream);
 

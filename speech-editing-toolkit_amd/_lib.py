@@ -51,6 +51,7 @@ class SetDiffnetLayerArgs(C.Structure):
         ("skip", C.c_void_p),
         ("cp_bs", C.c_int64), ("d_bs", C.c_int64), ("d_cs", C.c_int64),
         ("B", C.c_int32), ("T", C.c_int32), ("dil", C.c_int32), ("first", C.c_int32),
+        ("dbg_clock", C.c_void_p),
     ]
 
 
@@ -67,6 +68,8 @@ class SetDiffLoopArgs(C.Structure):
         ("ws_x0", C.c_void_p), ("ws_x1", C.c_void_p), ("ws_skip", C.c_void_p), ("ws_h", C.c_void_p),
         ("ws_x0pred", C.c_void_p),
         ("layer_span_ms", C.POINTER(C.c_float)),
+        ("loop_ms", C.POINTER(C.c_float)),
+        ("n_groups", C.c_int32),
     ]
 
 

@@ -25,10 +25,19 @@ constexpr int NT = 64;        // frames per block tile
 constexpr int KS1 = 3 * DC / 2;  // 384 k-steps (K=768) of GEMM 1
 constexpr int KS2 = DC / 2;      // 128 k-steps (K=256) of GEMM 2
 
+// Accumulator register r of the 32x32 block holds row  urow(r) + 4*(lane>>5):  the first term is wave-uniform, so
+// every global access below is  (uniform row pointer, SGPR) + (one per-lane 32-bit offset, VGPR)  -- no per-row
+// 64-bit address registers (those spilled and serialised the epilogue stores behind vmcnt(0) reloads).
+__device__ __forceinline__ int urow16(int r) { return (r & 3) + 8 * (r >> 2); }
+
 __device__ __forceinline__ int layer_row(int w, int rb, int i) {
     // rb 0,1 -> first half rows (gate / residual); rb 2,3 -> second half (filter / skip)
     return (rb < 2 ? 64 * w + 32 * rb : DC + 64 * w + 32 * (rb - 2)) + i;
 }
+
+// fast gate math: v_exp_f32 / v_rcp_f32 (<= 1-2 ulp each); absolute error ~1e-7, far inside the 1e-4 mel bar
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 __global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -42,54 +51,102 @@ __global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerAr
     const int XW = NT + 2 * dil;  // tile width incl. halo
     const int T = a.T;
     const float *xin = a.x_in + (int64_t)b * DC * T;
+    uint64_t *dbg = a.dbg_clock ? a.dbg_clock + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+#define PHASE_STAMP(i) \
+    if (dbg && tid == 0) dbg[i] = __builtin_amdgcn_s_memtime();
+    PHASE_STAMP(0)
 
-    // ---- phase 0: stage (x + d) tile, zero outside [0,T) (conv zero padding applies to x+d) ----
-    for (int i = tid; i < DC * XW; i += 256) {
-        const int c = i / XW, j = i - c * XW;
-        const int t = t0 - dil + j;
-        float v = 0.0f;
-        if (t >= 0 && t < T) v = xin[(int64_t)c * T + t] + a.dstep[(int64_t)b * a.d_bs + (int64_t)c * a.d_cs];
-        smem[i] = v;
+    // NB every global load below is UNCONDITIONAL on a clamped (always in-bounds) address and the validity
+    // select happens afterwards: a `cond ? load : 0` makes hipcc branch around each load and drain vmcnt(0)
+    // per element (128 serialized round trips per lane).
+    const int tc0 = min(t0 + l31, T - 1), tc1 = min(t0 + 32 + l31, T - 1);
+    const bool tv0 = t0 + l31 < T, tv1 = t0 + 32 + l31 < T;
+    const unsigned lo0 = (unsigned)(4 * half * T + tc0), lo1 = (unsigned)(4 * half * T + tc1);  // per-lane offsets
+    const unsigned lb = (unsigned)(4 * half);
+
+    // ---- phase 0a: accumulators of GEMM 1 start at  b_dil + condproj  (so the gate needs no loads later);
+    //      all 128 loads per lane are independent and issued together.
+    f32x16 acc[4][2];
+    {
+        const float *cpb = a.condproj + (int64_t)b * a.cp_bs;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ur = layer_row(w, rb, urow16(r));  // wave-uniform
+                const float bias = (a.b_dil + ur)[lb];
+                const float *cr = cpb + (int64_t)ur * T;
+                acc[rb][0][r] = bias + cr[lo0];
+                acc[rb][1][r] = bias + cr[lo1];
+            }
+    }
+    // ---- phase 0b: stage the (x + d) tile: wave w owns channels [64w, 64w+64); one row = one coalesced
+    //      64-lane load (+ a halo load); 16 rows in flight.  Zero outside [0,T): the conv's zero padding
+    //      applies to x + d (diffnet.py:71,74).
+    {
+        const int tA = t0 - dil + lane;       // columns 0..63
+        const int tB = t0 - dil + 64 + lane;  // columns 64..XW-1 (lanes < 2*dil)
+        const bool vA = tA >= 0 && tA < T;
+        const bool vB = tB >= 0 && tB < T;
+        const unsigned cA = (unsigned)min(max(tA, 0), T - 1), cB = (unsigned)min(max(tB, 0), T - 1);
+        const bool haloLane = lane < 2 * dil;
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+            float xa[16], xb[16], dd[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = 64 * w + r0 + u;
+                const float *row = xin + (int64_t)c * T;
+                xa[u] = row[cA];
+                xb[u] = row[cB];
+                dd[u] = a.dstep[(int64_t)b * a.d_bs + (int64_t)c * a.d_cs];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = 64 * w + r0 + u;
+                smem[c * XW + lane] = vA ? xa[u] + dd[u] : 0.0f;
+                if (haloLane) smem[c * XW + 64 + lane] = vB ? xb[u] + dd[u] : 0.0f;
+            }
+        }
     }
     __syncthreads();
+    PHASE_STAMP(1)
 
-    // ---- phase 1: GEMM 1  y[512 x 64] = Wdil[512 x 768] * im2col(xs) -------------------------------
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) acc[r][c] = (f32x16){0};
-
+    // ---- phase 1: GEMM 1  y[512 x 64] += Wdil[512 x 768] * im2col(xs) ------------------------------------
+    // k-steps are processed in groups of 4 (32 MFMAs = 2048 cycles/SIMD).  The operands of the next group
+    // (A: 4 x dwordx4 from L2, B: 4 x ds_read2) are issued before the current group's MFMAs and pinned there
+    // with sched_barrier so the scheduler cannot sink them next to their use.
     {
-        // Operands of the next 4 k-steps (A: 4 x dwordx4 from L2, B: 8 LDS dwords) are issued before the
-        // 32 MFMAs (2048 cycles/SIMD) of the current 4, and pinned there with sched_barrier so the
-        // scheduler cannot sink them next to their use.
         const f32x4 *wp = reinterpret_cast<const f32x4 *>(a.w1p) + (int64_t)w * KS1 * 64 + lane;
-        const float *bbase = smem + half * XW + l31;
+        const float *bp = smem + half * XW + l31;
+        const int rstep = 2 * XW;  // LDS floats between consecutive k-steps (2 channels)
         f32x4 A[4], nA[4];
         float Bv[4][2], nB[4][2];
-        auto load_ops = [&](f32x4(&dA)[4], float(&dB)[4][2], int ks0) {
+        auto load_ops = [&](f32x4(&dA)[4], float(&dB)[4][2]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int ks = ks0 + u < KS1 ? ks0 + u : KS1 - 1;
-                dA[u] = wp[(int64_t)ks * 64];
-                const float *bp = bbase + (2 * (ks & 127)) * XW + (ks >> 7) * dil;
-                dB[u][0] = bp[0];
-                dB[u][1] = bp[32];
+                dA[u] = wp[u * 64];
+                dB[u][0] = bp[u * rstep];
+                dB[u][1] = bp[u * rstep + 32];
             }
         };
-        load_ops(A, Bv, 0);
-        for (int ks = 0; ks < KS1; ks += 4) {
-            load_ops(nA, nB, ks + 4);
-            __builtin_amdgcn_sched_barrier(0);
+        auto compute = [&](const f32x4(&cA)[4], const float(&cB)[4][2]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    acc[r][0] = mfma32(A[u][r], Bv[u][0], acc[r][0]);
-                    acc[r][1] = mfma32(A[u][r], Bv[u][1], acc[r][1]);
+                    acc[r][0] = mfma32(cA[u][r], cB[u][0], acc[r][0]);
+                    acc[r][1] = mfma32(cA[u][r], cB[u][1], acc[r][1]);
                 }
-            }
+        };
+        constexpr int NG = KS1 / 4;  // 96 groups; group g: tap = g / 32, channel pairs (g % 32) * 4 ..
+        load_ops(A, Bv);
+        for (int g = 0; g < NG - 1; ++g) {
+            wp += 4 * 64;
+            bp += 4 * rstep;
+            if ((g & 31) == 31) bp += dil - 32 * 4 * rstep;  // next tap: back to channel 0, shift by dil columns
+            load_ops(nA, nB);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A, Bv);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -98,30 +155,21 @@ __global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerAr
                 Bv[u][1] = nB[u][1];
             }
         }
+        compute(A, Bv);
     }
+    PHASE_STAMP(2)
 
-    // ---- phase 2: gate (lane-local: acc[rb] pairs with acc[rb+2]) -----------------------------------
-    const float *cpb = a.condproj + (int64_t)b * a.cp_bs;
+    // ---- phase 2: gate, lane-local (acc[rb] pairs with acc[rb+2]); bias + conditioner are already inside -----
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int t = t0 + cb * 32 + l31;
-            const bool tv = t < T;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rg = layer_row(w, rb, mfma32_row(r, lane));
-                const int rf = rg + DC;
-                float z = 0.0f;
-                if (tv) {
-                    const float yg = (acc[rb][cb][r] + a.b_dil[rg]) + cpb[(int64_t)rg * T + t];
-                    const float yf = (acc[rb + 2][cb][r] + a.b_dil[rf]) + cpb[(int64_t)rf * T + t];
-                    z = dev_sigmoid(yg) * tanhf(yf);
-                }
-                acc[rb][cb][r] = z;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const float z0 = fast_sigmoid(acc[rb][0][r]) * fast_tanh(acc[rb + 2][0][r]);
+            const float z1 = fast_sigmoid(acc[rb][1][r]) * fast_tanh(acc[rb + 2][1][r]);
+            acc[rb][0][r] = tv0 ? z0 : 0.0f;
+            acc[rb][1][r] = tv1 ? z1 : 0.0f;
         }
-    }
+    PHASE_STAMP(3)
     __syncthreads();  // every wave is done reading xs
     // z tile zs[256][64] overlays the xs tile
 #pragma unroll
@@ -133,40 +181,60 @@ __global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerAr
                 const int c = 64 * w + 32 * rb + mfma32_row(r, lane);
                 smem[c * NT + cb * 32 + l31] = acc[rb][cb][r];
             }
+    // ---- accumulators of GEMM 2 start at  x_in + b_out  (residual rows) /  skip + b_out  (skip rows): the
+    //      epilogue is then store-only and these 128 loads fly while the other waves finish their z stores.
+    __builtin_amdgcn_sched_barrier(0);  // z registers are dead from here: keep the init loads below the z stores
+    float *skp = a.skip + (int64_t)b * DC * T;
+    const bool first = a.first != 0;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ur = layer_row(w, rb, urow16(r));  // wave-uniform
+            const float bias = (a.b_out + ur)[lb];
+            // residual rows read x_in, skip rows read the running skip sum (ignored by a select when first)
+            const float *src = (rb < 2 ? xin + (int64_t)ur * T : skp + (int64_t)(ur - DC) * T);
+            const float s0 = src[lo0], s1 = src[lo1];
+            acc[rb][0][r] = (rb >= 2 && first) ? bias : bias + s0;
+            acc[rb][1][r] = (rb >= 2 && first) ? bias : bias + s1;
+        }
+        if (rb == 1) __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
+    PHASE_STAMP(4)
 
-    // ---- phase 3: GEMM 2  o[512 x 64] = Wout[512 x 256] * zs ------------------------------------------
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) acc[r][c] = (f32x16){0};
+    // ---- phase 3: GEMM 2  o[512 x 64] += Wout[512 x 256] * zs ------------------------------------------------
     {
         const f32x4 *wp = reinterpret_cast<const f32x4 *>(a.w2p) + (int64_t)w * KS2 * 64 + lane;
-        const float *bbase = smem + half * NT + l31;
+        const float *bp = smem + half * NT + l31;
+        constexpr int rstep = 2 * NT;
         f32x4 A[4], nA[4];
         float Bv[4][2], nB[4][2];
-        auto load_ops = [&](f32x4(&dA)[4], float(&dB)[4][2], int ks0) {
+        auto load_ops = [&](f32x4(&dA)[4], float(&dB)[4][2]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int ks = ks0 + u < KS2 ? ks0 + u : KS2 - 1;
-                dA[u] = wp[(int64_t)ks * 64];
-                const float *bp = bbase + (2 * ks) * NT;
-                dB[u][0] = bp[0];
-                dB[u][1] = bp[32];
+                dA[u] = wp[u * 64];
+                dB[u][0] = bp[u * rstep];
+                dB[u][1] = bp[u * rstep + 32];
             }
         };
-        load_ops(A, Bv, 0);
-        for (int ks = 0; ks < KS2; ks += 4) {
-            load_ops(nA, nB, ks + 4);
-            __builtin_amdgcn_sched_barrier(0);
+        auto compute = [&](const f32x4(&cA)[4], const float(&cB)[4][2]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    acc[r][0] = mfma32(A[u][r], Bv[u][0], acc[r][0]);
-                    acc[r][1] = mfma32(A[u][r], Bv[u][1], acc[r][1]);
+                    acc[r][0] = mfma32(cA[u][r], cB[u][0], acc[r][0]);
+                    acc[r][1] = mfma32(cA[u][r], cB[u][1], acc[r][1]);
                 }
-            }
+        };
+        constexpr int NG = KS2 / 4;
+        load_ops(A, Bv);
+        for (int g = 0; g < NG - 1; ++g) {
+            wp += 4 * 64;
+            bp += 4 * rstep;
+            load_ops(nA, nB);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A, Bv);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -175,31 +243,30 @@ __global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerAr
                 Bv[u][1] = nB[u][1];
             }
         }
+        compute(A, Bv);
     }
+    PHASE_STAMP(5)
 
-    // ---- phase 4: epilogue ------------------------------------------------------------------------------
+    // ---- phase 4: store-only epilogue: x_out = (x + o_res) * 2^-1/2 ; skip = skip + o_skip ----------------------
     float *xout = a.x_out + (int64_t)b * DC * T;
-    float *skp = a.skip + (int64_t)b * DC * T;
+    const unsigned so0 = (unsigned)(4 * half * T + t0 + l31), so1 = so0 + 32u;  // unclamped store offsets
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
+    for (int cb = 0; cb < 2; ++cb) {
+        if (cb == 0 ? tv0 : tv1) {  // one exec-mask region per column block, not one per store
+            const unsigned so = cb == 0 ? so0 : so1;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int t = t0 + cb * 32 + l31;
-            if (t >= T) continue;
+            for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = layer_row(w, rb, mfma32_row(r, lane));
-                const float o = acc[rb][cb][r] + a.b_out[row];
-                if (rb < 2) {
-                    const int64_t off = (int64_t)row * T + t;
-                    xout[off] = (xin[off] + o) / 1.41421356237309504880f;
-                } else {
-                    const int64_t off = (int64_t)(row - DC) * T + t;
-                    skp[off] = a.first ? o : skp[off] + o;
+                for (int r = 0; r < 16; ++r) {
+                    const int ur = layer_row(w, rb, urow16(r));  // wave-uniform
+                    float *dst = (rb < 2 ? xout + (int64_t)ur * T : skp + (int64_t)(ur - DC) * T);
+                    const float sc = rb < 2 ? 0.70710678118654752440f : 1.0f;
+                    dst[so] = acc[rb][cb][r] * sc;
                 }
-            }
         }
     }
+    PHASE_STAMP(6)
+#undef PHASE_STAMP
 }
 
 __global__ void __launch_bounds__(256) pack_diffnet_layer_kernel(const float *w_dil, const float *w_out, float *w1p,
@@ -455,6 +522,65 @@ static SetConv1dArgs conv1x1_args(const float *in, const float *wp, const float 
     return c;
 }
 
+// auxiliary streams for utterance groups (created once, never destroyed)
+static hipStream_t g_aux_streams[8] = {nullptr};
+static int aux_stream(int i, hipStream_t *out) {
+    if (!g_aux_streams[i]) SET_HIP(hipStreamCreateWithFlags(&g_aux_streams[i], hipStreamNonBlocking), "aux stream");
+    *out = g_aux_streams[i];
+    return SET_OK;
+}
+
+// enqueue the chain of one utterance group [b0, b0+Bg) on stream s
+static int diffusion_chain(const SetDiffLoopArgs &a, int b0, int Bg, hipStream_t s, hipEvent_t *ev) {
+    const int T = a.T, M = a.M, L = a.L;
+    const int64_t per_batch = (int64_t)M * T;
+    float *x = a.x + (int64_t)b0 * per_batch;
+    float *ws_x0 = a.ws_x0 + (int64_t)b0 * DC * T, *ws_x1 = a.ws_x1 + (int64_t)b0 * DC * T;
+    float *ws_skip = a.ws_skip + (int64_t)b0 * DC * T, *ws_h = a.ws_h + (int64_t)b0 * DC * T;
+    float *ws_x0pred = a.ws_x0pred + (int64_t)b0 * per_batch;
+    const float *condproj = a.condproj + (int64_t)b0 * L * 512 * T;
+    const uint64_t quads_before = (uint64_t)((int64_t)b0 * per_batch / 4);
+    const uint64_t quads_total = (uint64_t)(((int64_t)a.B * per_batch + 3) / 4);
+    int rc = SET_OK;
+    for (int k = 0; k < a.steps && rc == SET_OK; ++k) {
+        const int sid = a.steps - 1 - k;  // diffusion step id t = steps-1 .. 0 (spec_denoiser.py:181)
+        // input projection + ReLU (diffnet.py:118-120)
+        SetConv1dArgs cin = conv1x1_args(x, a.w_in_p, a.b_in, ws_x0, Bg, M, DC, T);
+        cin.act = SET_ACT_RELU;
+        rc = set_conv1d(&cin, s);
+        if (rc != SET_OK) break;
+        float *cur = ws_x0, *nxt = ws_x1;
+        if (ev) (void)hipEventRecord(ev[2 * k], s);
+        for (int l = 0; l < L && rc == SET_OK; ++l) {
+            SetDiffnetLayerArgs la = {};
+            la.x_in = cur; la.x_out = nxt; la.skip = ws_skip;
+            la.condproj = condproj + (int64_t)l * 512 * T;
+            la.cp_bs = (int64_t)L * 512 * T;
+            la.dstep = a.dstep + (int64_t)l * DC * a.steps + sid;
+            la.d_bs = 0; la.d_cs = a.steps;
+            la.w1p = a.w1p[l]; la.b_dil = a.b_dil[l]; la.w2p = a.w2p[l]; la.b_out = a.b_out[l];
+            la.B = Bg; la.T = T; la.dil = 1 << (l % a.dilation_cycle_length); la.first = (l == 0);
+            rc = set_diffnet_layer(&la, s);
+            float *tmp = cur; cur = nxt; nxt = tmp;
+        }
+        if (ev) (void)hipEventRecord(ev[2 * k + 1], s);
+        if (rc != SET_OK) break;
+        // skip sum / sqrt(L) -> skip_projection -> ReLU -> output_projection (diffnet.py:128-131)
+        SetConv1dArgs cs = conv1x1_args(ws_skip, a.w_skip_p, a.b_skip, ws_h, Bg, DC, DC, T);
+        cs.pro = SET_PRO_DIV; cs.pro_param = sqrtf((float)L); cs.act = SET_ACT_RELU;
+        rc = set_conv1d(&cs, s);
+        if (rc != SET_OK) break;
+        SetConv1dArgs co = conv1x1_args(ws_h, a.w_outp_p, a.b_outp, ws_x0pred, Bg, DC, M, T);
+        rc = set_conv1d(&co, s);
+        if (rc != SET_OK) break;
+        const float *eps = a.noise ? a.noise + (int64_t)k * a.B * per_batch + (int64_t)b0 * per_batch : nullptr;
+        // Philox counters are global element quads, so the noise does not depend on the grouping
+        rc = set_posterior_step(ws_x0pred, x, eps, a.coef4 + 4 * sid, 0, x, Bg, per_batch, a.seed,
+                                (uint64_t)(k + 1) * quads_total + quads_before, s);
+    }
+    return rc;
+}
+
 extern "C" int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream) {
     SET_REQUIRE(args != nullptr, "set_diffusion_loop");
     const SetDiffLoopArgs &a = *args;
@@ -465,62 +591,68 @@ extern "C" int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream) {
                 "set_diffusion_loop");
     SET_REQUIRE(a.ws_x0 && a.ws_x1 && a.ws_skip && a.ws_h && a.ws_x0pred, "set_diffusion_loop");
     hipStream_t s = (hipStream_t)stream;
-    const int B = a.B, T = a.T, M = a.M, L = a.L;
-    const int64_t per_batch = (int64_t)M * T;
+    const int64_t per_batch = (int64_t)a.M * a.T;
+    int G = a.n_groups < 1 ? 1 : (a.n_groups > 8 ? 8 : a.n_groups);
+    if (G > a.B) G = a.B;
+    if (per_batch % 4 != 0) G = 1;  // group slices must start on a Philox quad boundary
+    const bool timing = a.layer_span_ms != nullptr;
     hipEvent_t *ev = nullptr;
-    if (a.layer_span_ms) {
-        ev = new hipEvent_t[2 * a.steps];
-        for (int i = 0; i < 2 * a.steps; ++i) SET_HIP(hipEventCreate(&ev[i]), "set_diffusion_loop(event)");
+    if (timing) {
+        ev = new hipEvent_t[(size_t)2 * a.steps * G];
+        for (int i = 0; i < 2 * a.steps * G; ++i) SET_HIP(hipEventCreate(&ev[i]), "set_diffusion_loop(event)");
+    }
+    hipEvent_t loop_ev[2] = {nullptr, nullptr};
+    if (a.loop_ms) {
+        SET_HIP(hipEventCreate(&loop_ev[0]), "set_diffusion_loop(event)");
+        SET_HIP(hipEventCreate(&loop_ev[1]), "set_diffusion_loop(event)");
+        (void)hipEventRecord(loop_ev[0], s);
     }
     int rc = SET_OK;
-    for (int k = 0; k < a.steps && rc == SET_OK; ++k) {
-        const int sid = a.steps - 1 - k;  // diffusion step id t = steps-1 .. 0 (spec_denoiser.py:181)
-        // input projection + ReLU (diffnet.py:118-120)
-        SetConv1dArgs cin = conv1x1_args(a.x, a.w_in_p, a.b_in, a.ws_x0, B, M, DC, T);
-        cin.act = SET_ACT_RELU;
-        rc = set_conv1d(&cin, s);
-        if (rc != SET_OK) break;
-        float *cur = a.ws_x0, *nxt = a.ws_x1;
-        if (ev) (void)hipEventRecord(ev[2 * k], s);
-        for (int l = 0; l < L && rc == SET_OK; ++l) {
-            SetDiffnetLayerArgs la = {};
-            la.x_in = cur; la.x_out = nxt; la.skip = a.ws_skip;
-            la.condproj = a.condproj + (int64_t)l * 512 * T;
-            la.cp_bs = (int64_t)L * 512 * T;
-            la.dstep = a.dstep + (int64_t)l * DC * a.steps + sid;
-            la.d_bs = 0; la.d_cs = a.steps;
-            la.w1p = a.w1p[l]; la.b_dil = a.b_dil[l]; la.w2p = a.w2p[l]; la.b_out = a.b_out[l];
-            la.B = B; la.T = T; la.dil = 1 << (l % a.dilation_cycle_length); la.first = (l == 0);
-            rc = set_diffnet_layer(&la, s);
-            float *tmp = cur; cur = nxt; nxt = tmp;
+    if (G == 1) {
+        rc = diffusion_chain(a, 0, a.B, s, ev);
+    } else {
+        hipEvent_t fork = nullptr, join[8] = {nullptr};
+        SET_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming), "set_diffusion_loop(fork)");
+        SET_HIP(hipEventRecord(fork, s), "set_diffusion_loop(fork)");
+        for (int g = 0; g < G && rc == SET_OK; ++g) {
+            const int b0 = (int)((int64_t)a.B * g / G), b1 = (int)((int64_t)a.B * (g + 1) / G);
+            hipStream_t sg;
+            rc = aux_stream(g, &sg);
+            if (rc != SET_OK) break;
+            SET_HIP(hipStreamWaitEvent(sg, fork, 0), "set_diffusion_loop(fork wait)");
+            rc = diffusion_chain(a, b0, b1 - b0, sg, ev ? ev + (size_t)2 * a.steps * g : nullptr);
+            SET_HIP(hipEventCreateWithFlags(&join[g], hipEventDisableTiming), "set_diffusion_loop(join)");
+            SET_HIP(hipEventRecord(join[g], sg), "set_diffusion_loop(join)");
+            SET_HIP(hipStreamWaitEvent(s, join[g], 0), "set_diffusion_loop(join wait)");
         }
-        if (ev) (void)hipEventRecord(ev[2 * k + 1], s);
-        if (rc != SET_OK) break;
-        // skip sum / sqrt(L) -> skip_projection -> ReLU -> output_projection (diffnet.py:128-131)
-        SetConv1dArgs cs = conv1x1_args(a.ws_skip, a.w_skip_p, a.b_skip, a.ws_h, B, DC, DC, T);
-        cs.pro = SET_PRO_DIV; cs.pro_param = sqrtf((float)L); cs.act = SET_ACT_RELU;
-        rc = set_conv1d(&cs, s);
-        if (rc != SET_OK) break;
-        SetConv1dArgs co = conv1x1_args(a.ws_h, a.w_outp_p, a.b_outp, a.ws_x0pred, B, DC, M, T);
-        rc = set_conv1d(&co, s);
-        if (rc != SET_OK) break;
-        const float *eps = a.noise ? a.noise + (int64_t)k * B * per_batch : nullptr;
-        rc = set_posterior_step(a.ws_x0pred, a.x, eps, a.coef4 + 4 * sid, 0, a.x, B, per_batch, a.seed,
-                                (uint64_t)(k + 1) * (uint64_t)((B * per_batch + 3) / 4), s);
+        (void)hipEventDestroy(fork);
+        for (int g = 0; g < G; ++g)
+            if (join[g]) (void)hipEventDestroy(join[g]);
     }
-    if (ev) {
+    if (a.loop_ms) (void)hipEventRecord(loop_ev[1], s);
+    if (timing || a.loop_ms) {
         if (rc == SET_OK) {
             hipError_t e = hipStreamSynchronize(s);
             if (e != hipSuccess) rc = set_fail(SET_E_LAUNCH, "set_diffusion_loop(sync)", hipGetErrorString(e));
-            for (int k = 0; k < a.steps && rc == SET_OK; ++k) {
-                float ms = 0.0f;
-                (void)hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]);
-                a.layer_span_ms[k] = ms;
+        }
+        if (rc == SET_OK && timing) {
+            for (int k = 0; k < a.steps; ++k) {
+                float acc_ms = 0.0f;
+                for (int g = 0; g < G; ++g) {
+                    float ms = 0.0f;
+                    (void)hipEventElapsedTime(&ms, ev[(size_t)2 * a.steps * g + 2 * k], ev[(size_t)2 * a.steps * g + 2 * k + 1]);
+                    acc_ms += ms;
+                }
+                a.layer_span_ms[k] = acc_ms / (float)G;
             }
         }
-        for (int i = 0; i < 2 * a.steps; ++i) (void)hipEventDestroy(ev[i]);
+        if (rc == SET_OK && a.loop_ms) (void)hipEventElapsedTime(a.loop_ms, loop_ev[0], loop_ev[1]);
+    }
+    if (ev) {
+        for (int i = 0; i < 2 * a.steps * G; ++i) (void)hipEventDestroy(ev[i]);
         delete[] ev;
     }
+    if (loop_ev[0]) { (void)hipEventDestroy(loop_ev[0]); (void)hipEventDestroy(loop_ev[1]); }
     return rc;
 }
 

@@ -335,7 +335,8 @@ def pack_diffnet_layer(w_dil, w_out):
     return w1p, w2p
 
 
-def diffnet_layer(x_in, condproj, cp_bs, dstep, d_bs, d_cs, w1p, b_dil, w2p, b_out, x_out, skip, dil, first):
+def diffnet_layer(x_in, condproj, cp_bs, dstep, d_bs, d_cs, w1p, b_dil, w2p, b_out, x_out, skip, dil, first,
+                  dbg_clock=None):
     _f(x_in), _f(x_out), _f(skip)
     B, Cc, T = x_in.shape
     assert Cc == 256
@@ -345,6 +346,7 @@ def diffnet_layer(x_in, condproj, cp_bs, dstep, d_bs, d_cs, w1p, b_dil, w2p, b_o
     a.x_out, a.skip = x_out.data_ptr(), skip.data_ptr()
     a.cp_bs, a.d_bs, a.d_cs = int(cp_bs), int(d_bs), int(d_cs)
     a.B, a.T, a.dil, a.first = B, T, int(dil), int(bool(first))
+    a.dbg_clock = dbg_clock.data_ptr() if dbg_clock is not None else None
     check(_lib.lib().set_diffnet_layer(C.byref(a), _stream()), "set_diffnet_layer")
 
 
@@ -383,7 +385,7 @@ def selftest_mfma():
 
 
 def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, w1p, w2p, b_dil, b_out, w_skip, b_skip,
-                   w_outp, b_outp, L, steps, dilation_cycle_length, want_layer_spans=False):
+                   w_outp, b_outp, L, steps, dilation_cycle_length, want_layer_spans=False, n_groups=None):
     """Enqueue the whole reverse loop (set_diffusion_loop).  x [B,M,T] is updated in place."""
     _f(x), _f(noise), _f(condproj), _f(dstep), _f(coef4)
     B, M, T = x.shape
@@ -404,12 +406,23 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, w1p, w
     a.w_outp_p, a.b_outp = w_outp.packed().data_ptr(), b_outp.data_ptr()
     a.ws_x0, a.ws_x1, a.ws_skip, a.ws_h = (w.data_ptr() for w in ws)
     a.ws_x0pred = ws_x0pred.data_ptr()
-    spans = None
+    a.n_groups = default_groups(B, T) if n_groups is None else int(n_groups)
+    spans, loop_ms = None, None
     if want_layer_spans:
         spans = (C.c_float * steps)()
         a.layer_span_ms = C.cast(spans, C.POINTER(C.c_float))
+        loop_ms = C.c_float(0.0)
+        a.loop_ms = C.pointer(loop_ms)
     check(_lib.lib().set_diffusion_loop(C.byref(a), _stream()), "set_diffusion_loop")
-    # workspaces must outlive the enqueued kernels: record them on the stream
-    for w in ws + [ws_x0pred]:
-        w.record_stream(torch.cuda.current_stream())
-    return list(spans) if spans is not None else None
+    # the group chains are joined back into the current stream, so stream-ordered reuse of these buffers is safe
+    if spans is None:
+        return None
+    return {"layer_span_ms": list(spans), "loop_ms": float(loop_ms.value), "n_groups": int(a.n_groups)}
+
+
+def default_groups(B, T):
+    """Utterance groups for the reverse loop (SET_AMD_GROUPS overrides).  Measured on MI355X (profiles/): more than
+    one group is slower -- kernels from different streams are placed on the same CUs first, so the per-CU imbalance
+    of a 416-block launch gets worse, not better -- hence 1.  Grouping never changes results."""
+    env = os.environ.get("SET_AMD_GROUPS")
+    return max(1, int(env)) if env else 1

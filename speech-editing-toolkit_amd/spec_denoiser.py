@@ -106,7 +106,7 @@ class GaussianDiffusion(nn.Module):
     @torch.no_grad()
     def forward(self, txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv, energy=None, infer=False,
                 use_pred_mel2ph=False, use_pred_pitch=False, *, noises=None, t=None, seed=None,
-                want_layer_spans=False):
+                want_layer_spans=False, n_groups=None):
         """Keyword-only extras (not in the reference): `noises` = explicit [steps+1,B,1,M,T] noise stack
         (x_T then one eps per executed step) for parity runs; `t` = explicit training step ids; `seed` for
         the on-device Philox stream; `want_layer_spans` returns per-step layer-span timings in ret."""
@@ -155,9 +155,9 @@ class GaussianDiffusion(nn.Module):
                 w_skip=dn._w_skip, b_skip=dn.skip_projection.bias.data,
                 w_outp=dn._w_outp, b_outp=dn.output_projection.bias.data,
                 L=dn.n_layers, steps=steps, dilation_cycle_length=dn.dilation_cycle_length,
-                want_layer_spans=want_layer_spans)
+                want_layer_spans=want_layer_spans, n_groups=n_groups)
             if spans is not None:
-                ret["layer_span_ms"] = spans
+                ret.update(spans)
         else:
             quads = (B * M * T + 3) // 4
             for k, i in enumerate(reversed(range(steps))):  # spec_denoiser.py:181-182

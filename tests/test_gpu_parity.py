@@ -344,6 +344,24 @@ def test_unfused_loop_matches_fused(dev):
     assert _maxdiff(r_f["mel_out"], r_u["mel_out"]) < 1e-4
 
 
+def test_utterance_groups_do_not_change_results(dev):
+    """set_diffusion_loop(n_groups=g): chains on auxiliary streams, bit-identical output incl. the Philox noise."""
+    g = load_golden("infer_pad")
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"])
+    inp, noises = _case_inputs(g, dev)
+    args = (inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"],
+            inp["uv"])
+    base = model(*args, infer=True, noises=noises, n_groups=1)["mel_out"]
+    assert _maxdiff(base, g["mel_out"]) < 1e-4
+    for ng in (2, 3):
+        assert torch.equal(model(*args, infer=True, noises=noises, n_groups=ng)["mel_out"], base)
+    p1 = model(*args, infer=True, seed=5, n_groups=1)["mel_out"]
+    p3 = model(*args, infer=True, seed=5, n_groups=3, want_layer_spans=True)
+    assert torch.equal(p3["mel_out"], p1) and len(p3["layer_span_ms"]) == m["steps"] and p3["loop_ms"] > 0
+    assert not torch.equal(model(*args, infer=True, seed=6, n_groups=3)["mel_out"], p1)
+
+
 def test_train_branch_forward(dev):
     g = load_golden("train_tiny")
     m = g["meta"]
