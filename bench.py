@@ -128,16 +128,24 @@ def main():
 
     frames = B_PER_GPU * world * T * args.steps
     value = frames / t_max
-    # The reverse loop runs the batch as `groups` utterance groups on separate HIP streams (no effect on results), so
-    # `groups` diffnet_layer_kernel launches of B/groups utterances are in flight together.
-    #   launch_ms        = mean duration of ONE launch (hipEvent pairs on each group's stream, over the timed region)
-    #   achieved         = groups * flop_per_launch / launch_ms  (aggregate rate of the concurrent launches)
-    #   achieved_wall_lb = all layer FLOPs of the loop / wall time of the WHOLE loop (incl. the ~4 % other kernels)
-    layer_ms = sum(spans) / (len(spans) * L)
-    flop_per_launch = FLOP_PER_FRAME_LAYER * (B_PER_GPU / groups) * T
-    ach_tflops = groups * flop_per_launch / (layer_ms * 1e-3) / 1e12
+    # Dominant kernel.  Default path: ONE persistent diffnet_stack_kernel launch per denoise step runs all L residual
+    # layers (task queue over (layer, 32-frame tile)); SET_AMD_PERSISTENT=0: L diffnet_layer_kernel launches per step.
+    #   launch_ms = mean duration of one launch, from hipEvent pairs on the launch stream over the timed region
+    #   achieved  = algorithmic FLOPs of one launch / launch_ms  (x concurrent launches if utterance groups > 1)
+    persistent = bool(ret.get("persistent", 0))
+    layers_per_launch = L if persistent else 1
+    launch_ms = sum(spans) / len(spans) / (L // layers_per_launch)
+    flop_per_launch = FLOP_PER_FRAME_LAYER * (B_PER_GPU / groups) * T * layers_per_launch
+    bytes_per_launch = BYTES_PER_FRAME_LAYER * (B_PER_GPU / groups) * T * layers_per_launch
+    ach_tflops = groups * flop_per_launch / (launch_ms * 1e-3) / 1e12
     ach_wall = FLOP_PER_FRAME_LAYER * B_PER_GPU * T * L * DIFF_STEPS * len(loop_ms) / (sum(loop_ms) * 1e-3) / 1e12
-    ach_gbs = BYTES_PER_FRAME_LAYER * B_PER_GPU * T / (layer_ms * 1e-3) / 1e9
+    ach_gbs = groups * bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic_bytes_per_launch.json")
+    if os.path.exists(tfile):  # HBM bytes per launch from the PMC passes (tools/pmc_traffic.py), same kernel + shape
+        with open(tfile) as f:
+            tj = json.load(f)
+        traffic = tj.get("diffnet_stack_kernel" if persistent else "diffnet_layer_kernel")
     out = {
         "metric": "diffusion mel-frames/s (100-step p_sample, B=32/GPU, T=800)",
         "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -148,10 +156,11 @@ def main():
                                "BASELINE configs[1]); on-device Philox noise",
                    "B_per_gpu": B_PER_GPU, "T": T, "T_txt": T_TXT, "denoise_steps": DIFF_STEPS,
                    "sharding": "utterances r::N, no collective"},
-        "roofline": {"kernel": "diffnet_layer_kernel", "bound": "mfma", "achieved": ach_tflops,
-                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS,
-                     "traffic": None, "launch_ms": layer_ms, "flop_per_launch": flop_per_launch,
-                     "concurrent_launches": groups, "per_launch_achieved": ach_tflops / groups,
+        "roofline": {"kernel": "diffnet_stack_kernel" if persistent else "diffnet_layer_kernel", "bound": "mfma",
+                     "achieved": ach_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "launch_ms": launch_ms,
+                     "flop_per_launch": flop_per_launch, "layers_per_launch": layers_per_launch,
+                     "algorithmic_bytes_per_launch": bytes_per_launch, "concurrent_launches": groups,
                      "achieved_wall_lower_bound": ach_wall, "frac_wall_lower_bound": ach_wall / PEAK_F32_MFMA_TFLOPS,
                      "hbm_algorithmic_GBps": ach_gbs, "hbm_frac": ach_gbs / PEAK_HBM_GBS},
     }

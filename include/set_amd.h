@@ -201,6 +201,29 @@ int64_t set_diffnet_w2p_size(void);
 /* pack dilated_conv.weight [512][256][3] and output_projection.weight [512][256][1] (diffnet.py:63,66) */
 int set_pack_diffnet_layer(const float *w_dil, const float *w_out, float *w1p, float *w2p, void *stream);
 
+/* All L residual layers of one DiffNet pass in ONE persistent launch (residual_channels == 256).
+ * Up to 2 x #CU resident blocks pull (layer, tile) tasks in layer-major order from an atomic queue; a task
+ * (l, i) starts when tiles i-1, i, i+1 of layer l-1 are published (per-tile epoch flags; agent-scope
+ * release/acquire), so no CU idles at layer boundaries (a 416-tile layer does not divide over 256 CUs).
+ * Tiles are 64 frames when a layer has >= 3 x #CU of them, else 32 frames (keeps runnable tasks > workers).
+ * Layer l reads (l even ? xa : xb) and writes the other buffer; skip accumulates in place; results are
+ * bit-identical to L calls of set_diffnet_layer.  sync_ws: >= 4 + B*ceil(T/32) int32, zeroed by the call;
+ * sync_ws[1] != 0 afterwards means a dependency wait timed out (SET_E_LAUNCH is NOT raised asynchronously). */
+typedef struct SetDiffnetStackArgs {
+    float *xa, *xb, *skip;        /* [B][256][T] each */
+    const float *condproj;        /* layer l, batch b slab at condproj + l*cp_ls + b*cp_bs : [512][T] */
+    const float *dstep;           /* d[l][b][c] = dstep[l*d_ls + b*d_bs + c*d_cs] */
+    const float *w1p_all;         /* [L][512*768]  packed (set_pack_diffnet_layer) */
+    const float *w2p_all;         /* [L][512*256] */
+    const float *b_dil_all;       /* [L][512] */
+    const float *b_out_all;       /* [L][512] */
+    int32_t *sync_ws;
+    int64_t cp_bs, cp_ls, d_bs, d_cs, d_ls;
+    int32_t B, T, L, dilation_cycle_length;
+} SetDiffnetStackArgs;
+int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream);
+int64_t set_sizeof_diffnet_stack_args(void);
+
 /* posterior step (spec_denoiser.py:86-101):  x_prev = c1*x0 + c2*x_t + (t != 0) * exp(0.5*logvar) * eps
  * per-batch scalars coef4[b*coef_bs + {0,1,2,3}] = {c1, c2, logvar, nonzero} (coef_bs = 0: shared by the
  * batch); eps == NULL -> counter-based Philox4x32-10 + Box-Muller noise keyed by (seed, offset + i/4).
@@ -228,10 +251,10 @@ typedef struct SetDiffLoopArgs {
     /* packed weights */
     const float *w_in_p;   /* input_projection packed (Cout 256, Cin M, K 1) */
     const float *b_in;
-    const float *const *w1p; /* HOST array of L device pointers */
-    const float *const *w2p; /* HOST array of L device pointers */
-    const float *const *b_dil;
-    const float *const *b_out;
+    const float *w1p_all;  /* [L][512*768] packed dilated-conv weights (set_pack_diffnet_layer) */
+    const float *w2p_all;  /* [L][512*256] packed output-projection weights */
+    const float *b_dil_all; /* [L][512] */
+    const float *b_out_all; /* [L][512] */
     const float *w_skip_p; /* skip_projection packed */
     const float *b_skip;
     const float *w_outp_p; /* output_projection packed (Cout M, Cin 256) */
@@ -248,6 +271,10 @@ typedef struct SetDiffLoopArgs {
      * independent chains on auxiliary HIP streams (forked from / joined to `stream` with events), so the tail of one
      * group's layer launch overlaps the next layer of another group.  Results are bit-identical for any n_groups. */
     int32_t n_groups;
+    /* persistent != 0: run the L layers of every step as one set_diffnet_stack launch (needs sync_ws,
+     * >= 32 + B*ceil(T/32) int32); 0: one set_diffnet_layer launch per layer */
+    int32_t persistent;
+    int32_t *sync_ws;
 } SetDiffLoopArgs;
 int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream);
 

@@ -62,14 +62,25 @@ class SetDiffLoopArgs(C.Structure):
         ("x", C.c_void_p), ("noise", C.c_void_p), ("seed", C.c_uint64),
         ("condproj", C.c_void_p), ("dstep", C.c_void_p), ("coef4", C.c_void_p),
         ("w_in_p", C.c_void_p), ("b_in", C.c_void_p),
-        ("w1p", C.POINTER(C.c_void_p)), ("w2p", C.POINTER(C.c_void_p)),
-        ("b_dil", C.POINTER(C.c_void_p)), ("b_out", C.POINTER(C.c_void_p)),
+        ("w1p_all", C.c_void_p), ("w2p_all", C.c_void_p), ("b_dil_all", C.c_void_p), ("b_out_all", C.c_void_p),
         ("w_skip_p", C.c_void_p), ("b_skip", C.c_void_p), ("w_outp_p", C.c_void_p), ("b_outp", C.c_void_p),
         ("ws_x0", C.c_void_p), ("ws_x1", C.c_void_p), ("ws_skip", C.c_void_p), ("ws_h", C.c_void_p),
         ("ws_x0pred", C.c_void_p),
         ("layer_span_ms", C.POINTER(C.c_float)),
         ("loop_ms", C.POINTER(C.c_float)),
         ("n_groups", C.c_int32),
+        ("persistent", C.c_int32),
+        ("sync_ws", C.c_void_p),
+    ]
+
+
+class SetDiffnetStackArgs(C.Structure):
+    _fields_ = [
+        ("xa", C.c_void_p), ("xb", C.c_void_p), ("skip", C.c_void_p), ("condproj", C.c_void_p), ("dstep", C.c_void_p),
+        ("w1p_all", C.c_void_p), ("w2p_all", C.c_void_p), ("b_dil_all", C.c_void_p), ("b_out_all", C.c_void_p),
+        ("sync_ws", C.c_void_p),
+        ("cp_bs", C.c_int64), ("cp_ls", C.c_int64), ("d_bs", C.c_int64), ("d_cs", C.c_int64), ("d_ls", C.c_int64),
+        ("B", C.c_int32), ("T", C.c_int32), ("L", C.c_int32), ("dilation_cycle_length", C.c_int32),
     ]
 
 
@@ -105,6 +116,8 @@ SIGNATURES = {
     "set_diffnet_w1p_size": (_I64, []),
     "set_diffnet_w2p_size": (_I64, []),
     "set_pack_diffnet_layer": (C.c_int, [_V, _V, _V, _V, _V]),
+    "set_diffnet_stack": (C.c_int, [C.POINTER(SetDiffnetStackArgs), _V]),
+    "set_sizeof_diffnet_stack_args": (_I64, []),
     "set_posterior_step": (C.c_int, [_V, _V, _V, _V, _I64, _V, _I32, _I64, _U64, _U64, _V]),
     "set_q_sample": (C.c_int, [_V, _V, _V, _V, _V, _I32, _I32, _I32, _V]),
     "set_randn": (C.c_int, [_V, _I64, _U64, _U64, _V]),
@@ -160,6 +173,7 @@ def lib():
     assert L.set_sizeof_conv1d_args() == C.sizeof(SetConv1dArgs), "SetConv1dArgs ABI mismatch"
     assert L.set_sizeof_diffnet_layer_args() == C.sizeof(SetDiffnetLayerArgs), "SetDiffnetLayerArgs ABI mismatch"
     assert L.set_sizeof_diff_loop_args() == C.sizeof(SetDiffLoopArgs), "SetDiffLoopArgs ABI mismatch"
+    assert L.set_sizeof_diffnet_stack_args() == C.sizeof(SetDiffnetStackArgs), "SetDiffnetStackArgs ABI mismatch"
     _lib = L
     return L
 

@@ -16,6 +16,8 @@
 //   A operand (weights): pre-packed in fragment order so one k-step of a wave is a single 1 KiB
 //   coalesced global_load_dwordx4 (L2 resident: 2 MiB per layer); prefetched 4 k-steps ahead.
 //   z (gate output) overwrites the xs tile in LDS; x for the residual is re-read from L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -39,19 +41,82 @@ __device__ __forceinline__ int layer_row(int w, int rb, int i) {
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
-__global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// One (layer, 32*NCB-frame tile) unit of work; shared by the per-layer kernel (NCB = 2) and the persistent stack
+// kernel (NCB = 1 or 2).
+struct LayerTile {
+    const float *xin;      // x_in  + b*256*T
+    float *xout;           // x_out + b*256*T
+    float *skp;            // skip  + b*256*T
+    const float *cpb;      // condproj slab of this layer + b*cp_bs
+    const float *dstep;    // d[c] = dstep[c*d_cs]  (already offset by b*d_bs)
+    int64_t d_cs;
+    const float *w1p, *b_dil, *w2p, *b_out;
+    int T, t0, dil, first;
+    uint64_t *dbg;
+};
+
+// operands of GS consecutive k-steps: A = 4 row blocks (one dwordx4 per lane per k-step), B = NCB column blocks
+template <int NCB, int GS>
+struct KOps {
+    f32x4 A[GS];
+    float B[GS][NCB];
+};
+
+// acc[4][NCB] += W[512 x 2*KS] * Bmat, k-steps in groups of GS.  Two operand sets ping-pong (no register copies):
+// while the MFMAs of one group run, the loads of the next group are issued one k-step at a time, each pinned in
+// front of its k-step's MFMAs with sched_barrier (otherwise the scheduler sinks them next to their use).
+// `advance(g)` moves wp / bp from group g to group g+1.
+template <int NCB, int GS, int NG, typename Adv>
+__device__ __forceinline__ void gemm_groups(f32x16 (&acc)[4][NCB], const f32x4 *&wp, const float *&bp, int rstep,
+                                            Adv advance) {
+    static_assert(NG % 2 == 0, "group count must be even");
+    KOps<NCB, GS> P, Q;
+    auto load_step = [&](KOps<NCB, GS> &o, int u) {
+        o.A[u] = wp[u * 64];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) o.B[u][cb] = bp[u * rstep + 32 * cb];
+    };
+    auto mma_step = [&](const KOps<NCB, GS> &o, int u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[r][cb] = mfma32(o.A[u][r], o.B[u][cb], acc[r][cb]);
+    };
+#pragma unroll
+    for (int u = 0; u < GS; ++u) load_step(P, u);
+    for (int g = 0; g < NG; g += 2) {
+        advance(g);  // -> group g+1 (always exists: NG is even)
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+            load_step(Q, u);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(P, u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g + 2 < NG) advance(g + 1);  // last pair: re-load the final group (harmless, in bounds)
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+            load_step(P, u);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(Q, u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int NCB, int GS>
+__device__ __forceinline__ void layer_tile(const LayerTile &a, float *smem) {
+    constexpr int NTt = 32 * NCB;           // frames per tile;  GS = k-steps per operand group
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * NT;
+    const int t0 = a.t0;
     const int dil = a.dil;
-    const int XW = NT + 2 * dil;  // tile width incl. halo
+    const int XW = NTt + 2 * dil;  // tile width incl. halo
     const int T = a.T;
-    const float *xin = a.x_in + (int64_t)b * DC * T;
-    uint64_t *dbg = a.dbg_clock ? a.dbg_clock + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+    const float *xin = a.xin;
+    uint64_t *dbg = a.dbg;
 #define PHASE_STAMP(i) \
     if (dbg && tid == 0) dbg[i] = __builtin_amdgcn_s_memtime();
     PHASE_STAMP(0)
@@ -59,37 +124,39 @@ __global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerAr
     // NB every global load below is UNCONDITIONAL on a clamped (always in-bounds) address and the validity
     // select happens afterwards: a `cond ? load : 0` makes hipcc branch around each load and drain vmcnt(0)
     // per element (128 serialized round trips per lane).
-    const int tc0 = min(t0 + l31, T - 1), tc1 = min(t0 + 32 + l31, T - 1);
-    const bool tv0 = t0 + l31 < T, tv1 = t0 + 32 + l31 < T;
-    const unsigned lo0 = (unsigned)(4 * half * T + tc0), lo1 = (unsigned)(4 * half * T + tc1);  // per-lane offsets
+    unsigned lo[NCB];  // per-lane load offsets (clamped) relative to a wave-uniform row pointer
+    bool tv[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        lo[cb] = (unsigned)(4 * half * T + min(t0 + 32 * cb + l31, T - 1));
+        tv[cb] = t0 + 32 * cb + l31 < T;
+    }
     const unsigned lb = (unsigned)(4 * half);
 
     // ---- phase 0a: accumulators of GEMM 1 start at  b_dil + condproj  (so the gate needs no loads later);
-    //      all 128 loads per lane are independent and issued together.
-    f32x16 acc[4][2];
-    {
-        const float *cpb = a.condproj + (int64_t)b * a.cp_bs;
+    //      all loads are independent and issued together.
+    f32x16 acc[4][NCB];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+    for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ur = layer_row(w, rb, urow16(r));  // wave-uniform
-                const float bias = (a.b_dil + ur)[lb];
-                const float *cr = cpb + (int64_t)ur * T;
-                acc[rb][0][r] = bias + cr[lo0];
-                acc[rb][1][r] = bias + cr[lo1];
-            }
-    }
+        for (int r = 0; r < 16; ++r) {
+            const int ur = layer_row(w, rb, urow16(r));  // wave-uniform
+            const float bias = (a.b_dil + ur)[lb];
+            const float *cr = a.cpb + (int64_t)ur * T;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = bias + cr[lo[cb]];
+        }
     // ---- phase 0b: stage the (x + d) tile: wave w owns channels [64w, 64w+64); one row = one coalesced
-    //      64-lane load (+ a halo load); 16 rows in flight.  Zero outside [0,T): the conv's zero padding
-    //      applies to x + d (diffnet.py:71,74).
+    //      64-lane load (+ a halo load when the row is wider than 64); 16 rows in flight.  Zero outside [0,T):
+    //      the conv's zero padding applies to x + d (diffnet.py:71,74).
     {
         const int tA = t0 - dil + lane;       // columns 0..63
-        const int tB = t0 - dil + 64 + lane;  // columns 64..XW-1 (lanes < 2*dil)
+        const int tB = t0 - dil + 64 + lane;  // columns 64..XW-1
         const bool vA = tA >= 0 && tA < T;
         const bool vB = tB >= 0 && tB < T;
         const unsigned cA = (unsigned)min(max(tA, 0), T - 1), cB = (unsigned)min(max(tB, 0), T - 1);
-        const bool haloLane = lane < 2 * dil;
+        const bool laneA = lane < XW;
+        const bool laneB = 64 + lane < XW;
         for (int r0 = 0; r0 < 64; r0 += 16) {
             float xa[16], xb[16], dd[16];
 #pragma unroll
@@ -97,65 +164,33 @@ __global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerAr
                 const int c = 64 * w + r0 + u;
                 const float *row = xin + (int64_t)c * T;
                 xa[u] = row[cA];
-                xb[u] = row[cB];
-                dd[u] = a.dstep[(int64_t)b * a.d_bs + (int64_t)c * a.d_cs];
+                if constexpr (NCB == 2) xb[u] = row[cB];
+                dd[u] = a.dstep[(int64_t)c * a.d_cs];
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int c = 64 * w + r0 + u;
-                smem[c * XW + lane] = vA ? xa[u] + dd[u] : 0.0f;
-                if (haloLane) smem[c * XW + 64 + lane] = vB ? xb[u] + dd[u] : 0.0f;
+                if (laneA) smem[c * XW + lane] = vA ? xa[u] + dd[u] : 0.0f;
+                if constexpr (NCB == 2) {
+                    if (laneB) smem[c * XW + 64 + lane] = vB ? xb[u] + dd[u] : 0.0f;
+                }
             }
         }
     }
     __syncthreads();
     PHASE_STAMP(1)
 
-    // ---- phase 1: GEMM 1  y[512 x 64] += Wdil[512 x 768] * im2col(xs) ------------------------------------
-    // k-steps are processed in groups of 4 (32 MFMAs = 2048 cycles/SIMD).  The operands of the next group
-    // (A: 4 x dwordx4 from L2, B: 4 x ds_read2) are issued before the current group's MFMAs and pinned there
-    // with sched_barrier so the scheduler cannot sink them next to their use.
+    // ---- phase 1: GEMM 1  y[512 x NTt] += Wdil[512 x 768] * im2col(xs): k-step ks -> tap ks/128, channels 2*(ks%128)+{0,1}
     {
         const f32x4 *wp = reinterpret_cast<const f32x4 *>(a.w1p) + (int64_t)w * KS1 * 64 + lane;
         const float *bp = smem + half * XW + l31;
         const int rstep = 2 * XW;  // LDS floats between consecutive k-steps (2 channels)
-        f32x4 A[4], nA[4];
-        float Bv[4][2], nB[4][2];
-        auto load_ops = [&](f32x4(&dA)[4], float(&dB)[4][2]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                dA[u] = wp[u * 64];
-                dB[u][0] = bp[u * rstep];
-                dB[u][1] = bp[u * rstep + 32];
-            }
-        };
-        auto compute = [&](const f32x4(&cA)[4], const float(&cB)[4][2]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[r][0] = mfma32(cA[u][r], cB[u][0], acc[r][0]);
-                    acc[r][1] = mfma32(cA[u][r], cB[u][1], acc[r][1]);
-                }
-        };
-        constexpr int NG = KS1 / 4;  // 96 groups; group g: tap = g / 32, channel pairs (g % 32) * 4 ..
-        load_ops(A, Bv);
-        for (int g = 0; g < NG - 1; ++g) {
-            wp += 4 * 64;
-            bp += 4 * rstep;
-            if ((g & 31) == 31) bp += dil - 32 * 4 * rstep;  // next tap: back to channel 0, shift by dil columns
-            load_ops(nA, nB);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(A, Bv);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                A[u] = nA[u];
-                Bv[u][0] = nB[u][0];
-                Bv[u][1] = nB[u][1];
-            }
-        }
-        compute(A, Bv);
+        constexpr int GPT = 128 / GS;  // groups per tap
+        gemm_groups<NCB, GS, KS1 / GS>(acc, wp, bp, rstep, [&](int g) {
+            wp += GS * 64;
+            bp += GS * rstep;
+            if ((g % GPT) == GPT - 1) bp += dil - 128 * rstep;  // next tap: back to channel 0, shift by dil columns
+        });
     }
     PHASE_STAMP(2)
 
@@ -163,28 +198,28 @@ __global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerAr
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float z0 = fast_sigmoid(acc[rb][0][r]) * fast_tanh(acc[rb + 2][0][r]);
-            const float z1 = fast_sigmoid(acc[rb][1][r]) * fast_tanh(acc[rb + 2][1][r]);
-            acc[rb][0][r] = tv0 ? z0 : 0.0f;
-            acc[rb][1][r] = tv1 ? z1 : 0.0f;
-        }
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float z = fast_sigmoid(acc[rb][cb][r]) * fast_tanh(acc[rb + 2][cb][r]);
+                acc[rb][cb][r] = tv[cb] ? z : 0.0f;
+            }
     PHASE_STAMP(3)
     __syncthreads();  // every wave is done reading xs
-    // z tile zs[256][64] overlays the xs tile
+    // z tile zs[256][NTt] overlays the xs tile
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = 64 * w + 32 * rb + mfma32_row(r, lane);
-                smem[c * NT + cb * 32 + l31] = acc[rb][cb][r];
+                smem[c * NTt + cb * 32 + l31] = acc[rb][cb][r];
             }
     // ---- accumulators of GEMM 2 start at  x_in + b_out  (residual rows) /  skip + b_out  (skip rows): the
-    //      epilogue is then store-only and these 128 loads fly while the other waves finish their z stores.
+    //      epilogue is then store-only and these loads fly while the other waves finish their z stores.
     __builtin_amdgcn_sched_barrier(0);  // z registers are dead from here: keep the init loads below the z stores
-    float *skp = a.skip + (int64_t)b * DC * T;
+    float *skp = a.skp;
     const bool first = a.first != 0;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
@@ -194,66 +229,35 @@ __global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerAr
             const float bias = (a.b_out + ur)[lb];
             // residual rows read x_in, skip rows read the running skip sum (ignored by a select when first)
             const float *src = (rb < 2 ? xin + (int64_t)ur * T : skp + (int64_t)(ur - DC) * T);
-            const float s0 = src[lo0], s1 = src[lo1];
-            acc[rb][0][r] = (rb >= 2 && first) ? bias : bias + s0;
-            acc[rb][1][r] = (rb >= 2 && first) ? bias : bias + s1;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float sv = src[lo[cb]];
+                acc[rb][cb][r] = (rb >= 2 && first) ? bias : bias + sv;
+            }
         }
         if (rb == 1) __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     PHASE_STAMP(4)
 
-    // ---- phase 3: GEMM 2  o[512 x 64] += Wout[512 x 256] * zs ------------------------------------------------
+    // ---- phase 3: GEMM 2  o[512 x NTt] += Wout[512 x 256] * zs ------------------------------------------------
     {
         const f32x4 *wp = reinterpret_cast<const f32x4 *>(a.w2p) + (int64_t)w * KS2 * 64 + lane;
-        const float *bp = smem + half * NT + l31;
-        constexpr int rstep = 2 * NT;
-        f32x4 A[4], nA[4];
-        float Bv[4][2], nB[4][2];
-        auto load_ops = [&](f32x4(&dA)[4], float(&dB)[4][2]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                dA[u] = wp[u * 64];
-                dB[u][0] = bp[u * rstep];
-                dB[u][1] = bp[u * rstep + 32];
-            }
-        };
-        auto compute = [&](const f32x4(&cA)[4], const float(&cB)[4][2]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[r][0] = mfma32(cA[u][r], cB[u][0], acc[r][0]);
-                    acc[r][1] = mfma32(cA[u][r], cB[u][1], acc[r][1]);
-                }
-        };
-        constexpr int NG = KS2 / 4;
-        load_ops(A, Bv);
-        for (int g = 0; g < NG - 1; ++g) {
-            wp += 4 * 64;
-            bp += 4 * rstep;
-            load_ops(nA, nB);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(A, Bv);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                A[u] = nA[u];
-                Bv[u][0] = nB[u][0];
-                Bv[u][1] = nB[u][1];
-            }
-        }
-        compute(A, Bv);
+        const float *bp = smem + half * NTt + l31;
+        constexpr int rstep = 2 * NTt;
+        gemm_groups<NCB, GS, KS2 / GS>(acc, wp, bp, rstep, [&](int) {
+            wp += GS * 64;
+            bp += GS * rstep;
+        });
     }
     PHASE_STAMP(5)
 
     // ---- phase 4: store-only epilogue: x_out = (x + o_res) * 2^-1/2 ; skip = skip + o_skip ----------------------
-    float *xout = a.x_out + (int64_t)b * DC * T;
-    const unsigned so0 = (unsigned)(4 * half * T + t0 + l31), so1 = so0 + 32u;  // unclamped store offsets
+    float *xout = a.xout;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        if (cb == 0 ? tv0 : tv1) {  // one exec-mask region per column block, not one per store
-            const unsigned so = cb == 0 ? so0 : so1;
+    for (int cb = 0; cb < NCB; ++cb) {
+        if (tv[cb]) {  // one exec-mask region per column block, not one per store
+            const unsigned so = (unsigned)(4 * half * T + t0 + 32 * cb + l31);  // unclamped store offset
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
@@ -267,6 +271,106 @@ __global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerAr
     }
     PHASE_STAMP(6)
 #undef PHASE_STAMP
+}
+
+__global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.y;
+    LayerTile lt;
+    lt.xin = a.x_in + (int64_t)b * DC * a.T;
+    lt.xout = a.x_out + (int64_t)b * DC * a.T;
+    lt.skp = a.skip + (int64_t)b * DC * a.T;
+    lt.cpb = a.condproj + (int64_t)b * a.cp_bs;
+    lt.dstep = a.dstep + (int64_t)b * a.d_bs;
+    lt.d_cs = a.d_cs;
+    lt.w1p = a.w1p; lt.b_dil = a.b_dil; lt.w2p = a.w2p; lt.b_out = a.b_out;
+    lt.T = a.T; lt.t0 = blockIdx.x * NT; lt.dil = a.dil; lt.first = a.first;
+    lt.dbg = a.dbg_clock ? a.dbg_clock + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+    layer_tile<2, 4>(lt, smem);
+}
+
+// ---- persistent layer stack: (layer, tile) task queue + per-tile epoch flags -----------------------------------
+// Inter-workgroup hand-off follows cdna_hip_programming.md Guideline 16: producer = every wave drains vmcnt,
+// __syncthreads, ONE lane agent-scope release fence + asm vmcnt(0) + relaxed agent flag store; consumer = ONE lane
+// polls relaxed, ONE agent-scope acquire, __syncthreads, then plain loads.  Every spin is bounded.
+constexpr unsigned STACK_SPIN_LIMIT = 1u << 22;  // x s_sleep(8) ~ 1 s
+
+__device__ __forceinline__ int ld_agent(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NCB, int GS, int WPS>
+__global__ void __launch_bounds__(256, WPS) diffnet_stack_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles,
+                                                                int ntasks, int task_slot) {
+    constexpr int NTt = 32 * NCB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int *s_task = reinterpret_cast<int *>(smem + task_slot);  // inside the ONE dynamic LDS array
+    int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
+    const int tid = threadIdx.x;
+    uint64_t wait_ticks = 0, fence_ticks = 0;  // diagnostics (lane 0 only): summed into sync_ws[2], sync_ws[3]
+    for (;;) {
+        __syncthreads();  // LDS (tile + task slot) of the previous task is free
+        if (tid == 0) {
+            const uint64_t tw0 = __builtin_amdgcn_s_memtime();
+            int n = atomicAdd(counter, 1);
+            if (n < ntasks && n >= ntiles) {  // layer >= 1: wait for the three producer tiles of layer l-1
+                const int l = n / ntiles, i = n - l * ntiles, j = i % tiles_per_utt;
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = ld_agent(done + i) >= l;
+                    if (j > 0) ok = ok && ld_agent(done + i - 1) >= l;
+                    if (j < tiles_per_utt - 1) ok = ok && ld_agent(done + i + 1) >= l;
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > STACK_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
+                        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        n = ntasks;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            wait_ticks += __builtin_amdgcn_s_memtime() - tw0;
+            *s_task = n;
+        }
+        __syncthreads();
+        const int n = __builtin_amdgcn_readfirstlane(*s_task);
+        if (n >= ntasks) {
+            if (tid == 0) {  // units of 1024 ticks
+                atomicAdd(a.sync_ws + 2, (int)(wait_ticks >> 10));
+                atomicAdd(a.sync_ws + 3, (int)(fence_ticks >> 10));
+            }
+            break;
+        }
+        const int l = n / ntiles, i = n - l * ntiles;
+        const int b = i / tiles_per_utt, j = i - b * tiles_per_utt;
+        LayerTile lt;
+        const float *xi = (l & 1) ? a.xb : a.xa;
+        float *xo = (l & 1) ? a.xa : a.xb;
+        lt.xin = xi + (int64_t)b * DC * a.T;
+        lt.xout = xo + (int64_t)b * DC * a.T;
+        lt.skp = a.skip + (int64_t)b * DC * a.T;
+        lt.cpb = a.condproj + (int64_t)l * a.cp_ls + (int64_t)b * a.cp_bs;
+        lt.dstep = a.dstep + (int64_t)l * a.d_ls + (int64_t)b * a.d_bs;
+        lt.d_cs = a.d_cs;
+        lt.w1p = a.w1p_all + (int64_t)l * (512 * 768);
+        lt.w2p = a.w2p_all + (int64_t)l * (512 * 256);
+        lt.b_dil = a.b_dil_all + (int64_t)l * 512;
+        lt.b_out = a.b_out_all + (int64_t)l * 512;
+        lt.T = a.T; lt.t0 = j * NTt; lt.dil = 1 << (l % a.dilation_cycle_length); lt.first = (l == 0);
+        lt.dbg = nullptr;
+        layer_tile<NCB, GS>(lt, smem);
+        // publish tile i of layer l
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave
+        __syncthreads();
+        if (tid == 0) {
+            const uint64_t tf0 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(done + i, l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fence_ticks += __builtin_amdgcn_s_memtime() - tf0;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) pack_diffnet_layer_kernel(const float *w_dil, const float *w_out, float *w1p,
@@ -320,6 +424,68 @@ extern "C" int set_diffnet_layer(const SetDiffnetLayerArgs *args, void *stream) 
     dim3 grid((a.T + NT - 1) / NT, a.B);
     hipLaunchKernelGGL(diffnet_layer_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
     return set_check_launch("set_diffnet_layer");
+}
+
+extern "C" int64_t set_sizeof_diffnet_stack_args(void) { return (int64_t)sizeof(SetDiffnetStackArgs); }
+
+extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) {
+    SET_REQUIRE(args != nullptr, "set_diffnet_stack");
+    const SetDiffnetStackArgs &a = *args;
+    SET_REQUIRE(a.xa && a.xb && a.skip && a.condproj && a.dstep && a.w1p_all && a.w2p_all && a.b_dil_all &&
+                    a.b_out_all && a.sync_ws,
+                "set_diffnet_stack");
+    SET_REQUIRE(a.B > 0 && a.T > 0 && a.L > 0 && a.dilation_cycle_length >= 1 && a.dilation_cycle_length <= 4,
+                "set_diffnet_stack");
+    hipStream_t s = (hipStream_t)stream;
+    static int n_cu = 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void *fns[3] = {reinterpret_cast<const void *>(diffnet_stack_kernel<1, 8, 2>),
+                              reinterpret_cast<const void *>(diffnet_stack_kernel<1, 4, 3>),
+                              reinterpret_cast<const void *>(diffnet_stack_kernel<2, 4, 2>)};
+        for (const void *f : fns)
+            SET_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                    "set_diffnet_stack(attr)");
+        int dev = 0;
+        SET_HIP(hipGetDevice(&dev), "set_diffnet_stack");
+        SET_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev), "set_diffnet_stack");
+        attr_set = true;
+    }
+    // Tile width: a task (l, i) needs tiles i-1..i+1 of layer l-1, so at most `tiles per layer` tasks are ever
+    // runnable.  Workers (2 per CU) must stay BELOW that or the youngest ones only wait (measured: 36 % wait time
+    // with 512 workers on 416 64-frame tiles).  Use 64-frame tiles when a layer has >= 1.5x the workers, else
+    // 32-frame tiles (B=32, T=800: 800 tiles, no tail waste); the grid is capped at 0.8x the tile count.
+    int ncb = 2;
+    if ((int64_t)a.B * ((a.T + 63) / 64) < 3 * n_cu) ncb = 1;
+    if (const char *e = getenv("SET_AMD_STACK_NCB")) ncb = atoi(e) == 2 ? 2 : 1;
+    const int ntt = 32 * ncb;
+    const int tiles_per_utt = (a.T + ntt - 1) / ntt;
+    const int ntiles = a.B * tiles_per_utt;
+    const int64_t ntasks64 = (int64_t)ntiles * a.L;
+    SET_REQUIRE(ntasks64 < (1ll << 30), "set_diffnet_stack(task count)");
+    const int max_dil = 1 << (a.dilation_cycle_length - 1);
+    const int task_slot = DC * (ntt + 2 * max_dil);  // float index of the task word
+    const size_t lds = (size_t)(task_slot + 4) * sizeof(float);
+    SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
+    int wps = 2;  // resident blocks per CU
+    if (const char *e = getenv("SET_AMD_STACK_WPS")) wps = atoi(e) == 3 ? 3 : 2;
+    if (ncb == 2) wps = 2;
+    int grid = wps * n_cu;
+    if (grid > ntiles * 4 / 5) grid = ntiles * 4 / 5;
+    if (grid < n_cu) grid = n_cu < ntiles ? n_cu : ntiles;
+    if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
+    if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
+    if (grid < 1) grid = 1;
+    if (ncb == 1 && wps == 3)
+        hipLaunchKernelGGL((diffnet_stack_kernel<1, 4, 3>), dim3(grid), dim3(256), lds, s, a, tiles_per_utt, ntiles,
+                           (int)ntasks64, task_slot);
+    else if (ncb == 1)
+        hipLaunchKernelGGL((diffnet_stack_kernel<1, 8, 2>), dim3(grid), dim3(256), lds, s, a, tiles_per_utt, ntiles,
+                           (int)ntasks64, task_slot);
+    else
+        hipLaunchKernelGGL((diffnet_stack_kernel<2, 4, 2>), dim3(grid), dim3(256), lds, s, a, tiles_per_utt, ntiles,
+                           (int)ntasks64, task_slot);
+    return set_check_launch("set_diffnet_stack");
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -531,7 +697,7 @@ static int aux_stream(int i, hipStream_t *out) {
 }
 
 // enqueue the chain of one utterance group [b0, b0+Bg) on stream s
-static int diffusion_chain(const SetDiffLoopArgs &a, int b0, int Bg, hipStream_t s, hipEvent_t *ev) {
+static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipStream_t s, hipEvent_t *ev) {
     const int T = a.T, M = a.M, L = a.L;
     const int64_t per_batch = (int64_t)M * T;
     float *x = a.x + (int64_t)b0 * per_batch;
@@ -539,6 +705,8 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int b0, int Bg, hipStream_t
     float *ws_skip = a.ws_skip + (int64_t)b0 * DC * T, *ws_h = a.ws_h + (int64_t)b0 * DC * T;
     float *ws_x0pred = a.ws_x0pred + (int64_t)b0 * per_batch;
     const float *condproj = a.condproj + (int64_t)b0 * L * 512 * T;
+    const int tiles_per_utt = (T + NT - 1) / NT;
+    int32_t *sync_ws = a.sync_ws ? a.sync_ws + 4 * (int64_t)g + (int64_t)b0 * ((T + 31) / 32) : nullptr;  // per-group slice
     const uint64_t quads_before = (uint64_t)((int64_t)b0 * per_batch / 4);
     const uint64_t quads_total = (uint64_t)(((int64_t)a.B * per_batch + 3) / 4);
     int rc = SET_OK;
@@ -551,14 +719,25 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int b0, int Bg, hipStream_t
         if (rc != SET_OK) break;
         float *cur = ws_x0, *nxt = ws_x1;
         if (ev) (void)hipEventRecord(ev[2 * k], s);
-        for (int l = 0; l < L && rc == SET_OK; ++l) {
+        if (a.persistent) {
+            SetDiffnetStackArgs sa = {};
+            sa.xa = ws_x0; sa.xb = ws_x1; sa.skip = ws_skip;
+            sa.condproj = condproj; sa.cp_bs = (int64_t)L * 512 * T; sa.cp_ls = (int64_t)512 * T;
+            sa.dstep = a.dstep + sid; sa.d_bs = 0; sa.d_cs = a.steps; sa.d_ls = (int64_t)DC * a.steps;
+            sa.w1p_all = a.w1p_all; sa.w2p_all = a.w2p_all; sa.b_dil_all = a.b_dil_all; sa.b_out_all = a.b_out_all;
+            sa.sync_ws = sync_ws;
+            sa.B = Bg; sa.T = T; sa.L = L; sa.dilation_cycle_length = a.dilation_cycle_length;
+            rc = set_diffnet_stack(&sa, s);
+        }
+        for (int l = 0; l < L && rc == SET_OK && !a.persistent; ++l) {
             SetDiffnetLayerArgs la = {};
             la.x_in = cur; la.x_out = nxt; la.skip = ws_skip;
             la.condproj = condproj + (int64_t)l * 512 * T;
             la.cp_bs = (int64_t)L * 512 * T;
             la.dstep = a.dstep + (int64_t)l * DC * a.steps + sid;
             la.d_bs = 0; la.d_cs = a.steps;
-            la.w1p = a.w1p[l]; la.b_dil = a.b_dil[l]; la.w2p = a.w2p[l]; la.b_out = a.b_out[l];
+            la.w1p = a.w1p_all + (int64_t)l * (512 * 768); la.b_dil = a.b_dil_all + (int64_t)l * 512;
+            la.w2p = a.w2p_all + (int64_t)l * (512 * 256); la.b_out = a.b_out_all + (int64_t)l * 512;
             la.B = Bg; la.T = T; la.dil = 1 << (l % a.dilation_cycle_length); la.first = (l == 0);
             rc = set_diffnet_layer(&la, s);
             float *tmp = cur; cur = nxt; nxt = tmp;
@@ -586,9 +765,10 @@ extern "C" int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream) {
     const SetDiffLoopArgs &a = *args;
     SET_REQUIRE(a.B > 0 && a.T > 0 && a.M > 0 && a.L > 0 && a.steps > 0 && a.dilation_cycle_length >= 1,
                 "set_diffusion_loop");
-    SET_REQUIRE(a.x && a.condproj && a.dstep && a.coef4 && a.w_in_p && a.b_in && a.w1p && a.w2p && a.b_dil &&
-                    a.b_out && a.w_skip_p && a.b_skip && a.w_outp_p && a.b_outp,
+    SET_REQUIRE(a.x && a.condproj && a.dstep && a.coef4 && a.w_in_p && a.b_in && a.w1p_all && a.w2p_all &&
+                    a.b_dil_all && a.b_out_all && a.w_skip_p && a.b_skip && a.w_outp_p && a.b_outp,
                 "set_diffusion_loop");
+    SET_REQUIRE(!a.persistent || a.sync_ws, "set_diffusion_loop(persistent needs sync_ws)");
     SET_REQUIRE(a.ws_x0 && a.ws_x1 && a.ws_skip && a.ws_h && a.ws_x0pred, "set_diffusion_loop");
     hipStream_t s = (hipStream_t)stream;
     const int64_t per_batch = (int64_t)a.M * a.T;
@@ -609,7 +789,7 @@ extern "C" int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream) {
     }
     int rc = SET_OK;
     if (G == 1) {
-        rc = diffusion_chain(a, 0, a.B, s, ev);
+        rc = diffusion_chain(a, 0, 0, a.B, s, ev);
     } else {
         hipEvent_t fork = nullptr, join[8] = {nullptr};
         SET_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming), "set_diffusion_loop(fork)");
@@ -620,7 +800,7 @@ extern "C" int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream) {
             rc = aux_stream(g, &sg);
             if (rc != SET_OK) break;
             SET_HIP(hipStreamWaitEvent(sg, fork, 0), "set_diffusion_loop(fork wait)");
-            rc = diffusion_chain(a, b0, b1 - b0, sg, ev ? ev + (size_t)2 * a.steps * g : nullptr);
+            rc = diffusion_chain(a, g, b0, b1 - b0, sg, ev ? ev + (size_t)2 * a.steps * g : nullptr);
             SET_HIP(hipEventCreateWithFlags(&join[g], hipEventDisableTiming), "set_diffusion_loop(join)");
             SET_HIP(hipEventRecord(join[g], sg), "set_diffusion_loop(join)");
             SET_HIP(hipStreamWaitEvent(s, join[g], 0), "set_diffusion_loop(join wait)");

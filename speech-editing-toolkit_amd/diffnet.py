@@ -73,6 +73,7 @@ class DiffNet(nn.Module):
         self._w_skip = ops.ConvWeight(lambda: self.skip_projection.weight.data, C, C, 1)
         self._w_outp = ops.ConvWeight(lambda: self.output_projection.weight.data, in_dims, C, 1)
         self.impl = "auto"  # auto | fused | unfused  (unfused = generic kernels; device-side cross-check)
+        self._packs, self._packs_key = None, None
 
     # ---- helpers -------------------------------------------------------------------------------------
     def can_fuse(self):
@@ -84,6 +85,24 @@ class DiffNet(nn.Module):
         if self.impl == "fused" and not self.can_fuse():
             raise RuntimeError("fused DiffNet layer kernel needs residual_channels == 256 and dilation <= 8")
         return self.can_fuse()
+
+    def fused_packs(self):
+        """Contiguous [L][...] packed weights + biases for the fused layer / persistent stack kernels
+        (re-packed when any layer parameter changes)."""
+        layers = list(self.residual_layers)
+        key = tuple((p.data_ptr(), p._version) for l in layers for p in
+                    (l.dilated_conv.weight, l.output_projection.weight, l.dilated_conv.bias, l.output_projection.bias))
+        if self._packs is None or key != self._packs_key:
+            dev = layers[0].dilated_conv.weight.device
+            L = len(layers)
+            w1 = torch.empty(L, 512 * 768, dtype=torch.float32, device=dev)
+            w2 = torch.empty(L, 512 * 256, dtype=torch.float32, device=dev)
+            for i, l in enumerate(layers):
+                ops.pack_diffnet_layer(l.dilated_conv.weight.data, l.output_projection.weight.data, w1[i], w2[i])
+            bd = torch.stack([l.dilated_conv.bias.data for l in layers]).contiguous()
+            bo = torch.stack([l.output_projection.bias.data for l in layers]).contiguous()
+            self._packs, self._packs_key = (w1, w2, bd, bo), key
+        return self._packs
 
     def step_table(self, t_values):
         """d[l][c][n] = diffusion_projection_l(mlp(sinusoid(t_n)))[c]  ->  tensor [L*C, n]

@@ -12,7 +12,8 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT, PRO, IMPL_MFMA, IMPL_NAIVE, SetConv1dArgs, SetDiffnetLayerArgs, SetDiffLoopArgs, check
+from ._lib import (ACT, PRO, IMPL_MFMA, IMPL_NAIVE, SetConv1dArgs, SetDiffnetLayerArgs, SetDiffLoopArgs,
+                   SetDiffnetStackArgs, check)
 
 _DEFAULT_IMPL = os.environ.get("SET_AMD_CONV_IMPL", "auto")  # auto | naive | mfma
 
@@ -326,13 +327,42 @@ def res_skip(x_in, o, skip, first):
     return x_out
 
 
-def pack_diffnet_layer(w_dil, w_out):
+def pack_diffnet_layer(w_dil, w_out, w1p=None, w2p=None):
+    """Pack one layer; optionally into caller-provided slices of the contiguous [L][...] buffers."""
     _f(w_dil), _f(w_out)
     L = _lib.lib()
-    w1p = torch.empty(L.set_diffnet_w1p_size(), dtype=torch.float32, device=w_dil.device)
-    w2p = torch.empty(L.set_diffnet_w2p_size(), dtype=torch.float32, device=w_dil.device)
-    check(L.set_pack_diffnet_layer(_p(w_dil), _p(w_out), _p(w1p), _p(w2p), _stream()), "set_pack_diffnet_layer")
+    if w1p is None:
+        w1p = torch.empty(L.set_diffnet_w1p_size(), dtype=torch.float32, device=w_dil.device)
+        w2p = torch.empty(L.set_diffnet_w2p_size(), dtype=torch.float32, device=w_dil.device)
+    check(L.set_pack_diffnet_layer(_p(w_dil), _p(w_out), _p(_f(w1p)), _p(_f(w2p)), _stream()), "set_pack_diffnet_layer")
     return w1p, w2p
+
+
+def sync_ws_size(B, T):
+    return 32 + B * ((T + 31) // 32)
+
+
+def diffnet_stack(xa, xb, skip, condproj, dstep_ptr, d_bs, d_cs, d_ls, packs, dilation_cycle_length, sync_ws=None):
+    """All L layers in one persistent launch.  condproj [B, L*512, T]; packs = (w1p_all, w2p_all, b_dil_all, b_out_all).
+    Returns sync_ws (int32; [1] != 0 means a dependency wait timed out)."""
+    _f(xa), _f(xb), _f(skip), _f(condproj)
+    B, Cc, T = xa.shape
+    assert Cc == 256
+    w1p_all, w2p_all, b_dil_all, b_out_all = packs
+    L = b_dil_all.shape[0]
+    if sync_ws is None:
+        sync_ws = torch.empty(sync_ws_size(B, T), dtype=torch.int32, device=xa.device)
+    a = SetDiffnetStackArgs()
+    a.xa, a.xb, a.skip = xa.data_ptr(), xb.data_ptr(), skip.data_ptr()
+    a.condproj, a.dstep = condproj.data_ptr(), dstep_ptr
+    a.w1p_all, a.w2p_all = w1p_all.data_ptr(), w2p_all.data_ptr()
+    a.b_dil_all, a.b_out_all = b_dil_all.data_ptr(), b_out_all.data_ptr()
+    a.sync_ws = sync_ws.data_ptr()
+    a.cp_bs, a.cp_ls = condproj.stride(0), 512 * T
+    a.d_bs, a.d_cs, a.d_ls = int(d_bs), int(d_cs), int(d_ls)
+    a.B, a.T, a.L, a.dilation_cycle_length = B, T, L, int(dilation_cycle_length)
+    check(_lib.lib().set_diffnet_stack(C.byref(a), _stream()), "set_diffnet_stack")
+    return sync_ws
 
 
 def diffnet_layer(x_in, condproj, cp_bs, dstep, d_bs, d_cs, w1p, b_dil, w2p, b_out, x_out, skip, dil, first,
@@ -384,8 +414,9 @@ def selftest_mfma():
     return float(err.value)
 
 
-def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, w1p, w2p, b_dil, b_out, w_skip, b_skip,
-                   w_outp, b_outp, L, steps, dilation_cycle_length, want_layer_spans=False, n_groups=None):
+def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs, w_skip, b_skip,
+                   w_outp, b_outp, L, steps, dilation_cycle_length, want_layer_spans=False, n_groups=None,
+                   persistent=None):
     """Enqueue the whole reverse loop (set_diffusion_loop).  x [B,M,T] is updated in place."""
     _f(x), _f(noise), _f(condproj), _f(dstep), _f(coef4)
     B, M, T = x.shape
@@ -399,9 +430,12 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, w1p, w
     a.seed = int(seed)
     a.condproj, a.dstep, a.coef4 = condproj.data_ptr(), dstep.data_ptr(), coef4.data_ptr()
     a.w_in_p, a.b_in = w_in.packed().data_ptr(), b_in.data_ptr()
-    arr = C.c_void_p * L
-    keep = [arr(*[t.data_ptr() for t in lst]) for lst in (w1p, w2p, b_dil, b_out)]
-    a.w1p, a.w2p, a.b_dil, a.b_out = (C.cast(k, C.POINTER(C.c_void_p)) for k in keep)
+    w1p_all, w2p_all, b_dil_all, b_out_all = packs
+    a.w1p_all, a.w2p_all = w1p_all.data_ptr(), w2p_all.data_ptr()
+    a.b_dil_all, a.b_out_all = b_dil_all.data_ptr(), b_out_all.data_ptr()
+    a.persistent = int(default_persistent() if persistent is None else bool(persistent))
+    sync_ws = torch.empty(sync_ws_size(B, T), dtype=torch.int32, device=dev)
+    a.sync_ws = sync_ws.data_ptr()
     a.w_skip_p, a.b_skip = w_skip.packed().data_ptr(), b_skip.data_ptr()
     a.w_outp_p, a.b_outp = w_outp.packed().data_ptr(), b_outp.data_ptr()
     a.ws_x0, a.ws_x1, a.ws_skip, a.ws_h = (w.data_ptr() for w in ws)
@@ -417,7 +451,13 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, w1p, w
     # the group chains are joined back into the current stream, so stream-ordered reuse of these buffers is safe
     if spans is None:
         return None
-    return {"layer_span_ms": list(spans), "loop_ms": float(loop_ms.value), "n_groups": int(a.n_groups)}
+    return {"layer_span_ms": list(spans), "loop_ms": float(loop_ms.value), "n_groups": int(a.n_groups),
+            "persistent": int(a.persistent)}
+
+
+def default_persistent():
+    """SET_AMD_PERSISTENT=0/1 overrides; default: persistent layer-stack kernel."""
+    return os.environ.get("SET_AMD_PERSISTENT", "1") != "0"
 
 
 def default_groups(B, T):

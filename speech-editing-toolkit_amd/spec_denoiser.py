@@ -106,7 +106,7 @@ class GaussianDiffusion(nn.Module):
     @torch.no_grad()
     def forward(self, txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv, energy=None, infer=False,
                 use_pred_mel2ph=False, use_pred_pitch=False, *, noises=None, t=None, seed=None,
-                want_layer_spans=False, n_groups=None):
+                want_layer_spans=False, n_groups=None, persistent=None):
         """Keyword-only extras (not in the reference): `noises` = explicit [steps+1,B,1,M,T] noise stack
         (x_T then one eps per executed step) for parity runs; `t` = explicit training step ids; `seed` for
         the on-device Philox stream; `want_layer_spans` returns per-step layer-span timings in ret."""
@@ -144,18 +144,14 @@ class GaussianDiffusion(nn.Module):
         dtab = dn.step_table(ids.to(torch.float32))  # [L*C, steps]
         condproj = dn.cond_projections(cond)  # hoisted: independent of the step
         if dn.use_fused():
-            layers = list(dn.residual_layers)
-            packs = [l.fused_weights() for l in layers]
             spans = ops.diffusion_loop(
                 x=x, noise=eps, seed=seed, condproj=condproj, dstep=dtab, coef4=coef4,
                 w_in=dn._w_in, b_in=dn.input_projection.bias.data,
-                w1p=[p[0] for p in packs], w2p=[p[1] for p in packs],
-                b_dil=[l.dilated_conv.bias.data for l in layers],
-                b_out=[l.output_projection.bias.data for l in layers],
+                packs=dn.fused_packs(),
                 w_skip=dn._w_skip, b_skip=dn.skip_projection.bias.data,
                 w_outp=dn._w_outp, b_outp=dn.output_projection.bias.data,
                 L=dn.n_layers, steps=steps, dilation_cycle_length=dn.dilation_cycle_length,
-                want_layer_spans=want_layer_spans, n_groups=n_groups)
+                want_layer_spans=want_layer_spans, n_groups=n_groups, persistent=persistent)
             if spans is not None:
                 ret.update(spans)
         else:

@@ -344,6 +344,58 @@ def test_unfused_loop_matches_fused(dev):
     assert _maxdiff(r_f["mel_out"], r_u["mel_out"]) < 1e-4
 
 
+def test_persistent_stack_bit_identical_to_layer_launches(dev):
+    """set_diffnet_stack (task queue + ready flags across CUs/XCDs) must reproduce L per-layer launches bit for bit,
+    repeatedly, at the full benchmark size (uneven load, L1-warm consumers: every tile re-reads buffers it read two
+    layers earlier) and at ragged sizes; sync_ws[1] (timeout flag) must stay 0."""
+    from set_amd import ops
+    for (B, T, L, dcl, reps) in ((32, 800, 20, 1, 6), (3, 130, 5, 3, 3), (1, 50, 2, 1, 2)):
+        g = torch.Generator().manual_seed(B * 1000 + T)
+        x0 = torch.randn(B, 256, T, generator=g).to(dev)
+        cp = (torch.randn(B, L * 512, T, generator=g) * 0.5).to(dev)
+        dtab = torch.randn(L * 256, 3, generator=g).to(dev)
+        w1 = torch.empty(L, 512 * 768, device=dev)
+        w2 = torch.empty(L, 512 * 256, device=dev)
+        bd = (torch.randn(L, 512, generator=g) * 0.1).to(dev)
+        bo = (torch.randn(L, 512, generator=g) * 0.1).to(dev)
+        for l in range(L):
+            wd = (torch.randn(512, 256, 3, generator=g) / 27.7).to(dev)
+            wo = (torch.randn(512, 256, 1, generator=g) / 16.0).to(dev)
+            ops.pack_diffnet_layer(wd, wo, w1[l], w2[l])
+        col = 1
+        # reference: L launches of the per-layer kernel
+        h, nxt, skip_ref = x0.clone(), torch.empty_like(x0), torch.empty_like(x0)
+        for l in range(L):
+            ops.diffnet_layer(h, cp[:, l * 512:(l + 1) * 512].data_ptr(), cp.stride(0),
+                              dtab.data_ptr() + 4 * (l * 256 * 3 + col), 0, 3, w1[l], bd[l], w2[l], bo[l], nxt, skip_ref,
+                              1 << (l % dcl), l == 0)
+            h, nxt = nxt, h
+        x_ref = h.clone()
+        torch.cuda.synchronize()
+        for rep in range(reps):
+            xa, xb, skip = x0.clone(), torch.full_like(x0, float("nan")), torch.full_like(x0, float("nan"))
+            ws = ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4 * col, 0, 3, 256 * 3, (w1, w2, bd, bo), dcl)
+            torch.cuda.synchronize()
+            assert int(ws[1]) == 0, "dependency wait timed out"
+            assert int(ws[0]) >= L * B * ((T + 63) // 64)
+            assert torch.equal(skip, skip_ref), (B, T, rep)
+            assert torch.equal(xb if L % 2 else xa, x_ref), (B, T, rep)
+
+
+def test_loop_persistent_equals_per_layer_launches(dev):
+    g = load_golden("infer_pad")
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"])
+    inp, noises = _case_inputs(g, dev)
+    args = (inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"],
+            inp["uv"])
+    a = model(*args, infer=True, noises=noises, persistent=False)["mel_out"]
+    b = model(*args, infer=True, noises=noises, persistent=True)["mel_out"]
+    c = model(*args, infer=True, noises=noises, persistent=True, n_groups=2)["mel_out"]
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert _maxdiff(a, g["mel_out"]) < 1e-4
+
+
 def test_utterance_groups_do_not_change_results(dev):
     """set_diffusion_loop(n_groups=g): chains on auxiliary streams, bit-identical output incl. the Philox noise."""
     g = load_golden("infer_pad")

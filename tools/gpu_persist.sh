@@ -1,0 +1,10 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
+timeout 600 python -m pytest tests -q -m gpu -p no:cacheprovider -x -k "persistent or groups or full_size or full_inference or smoke" 2>&1 | tail -8 | tee gpurun_out/pytest_gpu.log
+for p in 0 1; do
+  echo "== persistent $p"
+  SET_AMD_PERSISTENT=$p timeout 300 python bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('value %.0f  ms/step %.1f  launch_ms %.4f  achieved %.1f  wall_lb %.1f persistent %s' % (d['value'], d['ms_per_step'], r['launch_ms'], r['achieved'], r['achieved_wall_lower_bound'], r['persistent_stack']))" | tee -a gpurun_out/persist.log
+done
