@@ -278,6 +278,81 @@ typedef struct SetDiffLoopArgs {
 } SetDiffLoopArgs;
 int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training: backward kernels, losses, optimizer.
+ * Input gradients of a convolution are a set_conv1d call on the output gradient with transposed weight
+ * addressing (w_sco <-> w_sci) and negated dil / pad; the pieces below are what set_conv1d cannot express.
+ * ------------------------------------------------------------------------------------------------ */
+/* dW[co][ci][tap] += sum_{b,t} G[b][co][t] * P(X[b][ci][t + tap*dil - pad]),  P as in set_conv1d
+ * (chan_add, pro).  impl SET_IMPL_MFMA: split-K GEMM on fp32 MFMA with fp32 atomics; else one thread per weight. */
+int set_conv1d_wgrad(const float *g, const float *x, const float *chan_add, float *dw, int32_t B, int32_t Cin,
+                     int32_t Cout, int32_t K, int32_t dil, int32_t pad, int32_t T, int32_t T_in, int32_t pro,
+                     float pro_param, int32_t impl, void *stream);
+/* out[c] += sum_{b,t} x[b][c][t]   (bias gradients) */
+int set_channel_sum(const float *x, float *out, int32_t B, int32_t C, int32_t T, void *stream);
+/* out[row] = scale * sum_t x[row][t] */
+int set_row_sum(const float *x, float *out, int64_t rows, int32_t T, float scale, void *stream);
+/* G = dY * mask[b][t] * alpha * [act == RELU: y > 0]   (epilogue backward of set_conv1d; act NONE or RELU) */
+int set_conv_epilogue_bwd(const float *dy, const float *y, const float *mask, float *g, int32_t B, int32_t C,
+                          int32_t T, int32_t act, float alpha, void *stream);
+/* y = act(z) / dz = dy * act'(z)  for the SET_ACT_* codes */
+int set_act_fwd(const float *z, float *y, int64_t n, int32_t act, float p, void *stream);
+int set_act_bwd(const float *z, const float *dy, float *dz, int64_t n, int32_t act, float p, void *stream);
+/* backward of set_gate: y [B][2C][T] (saved pre-gate), dz [B][C][T] -> dy [B][2C][T] */
+int set_gate_bwd(const float *y, const float *dz, float *dy, int32_t B, int32_t C, int32_t T, void *stream);
+/* backward of set_res_skip: dx = dx_out/sqrt2 ; d_o[:, :C] = dx_out/sqrt2 ; d_o[:, C:] = dskip */
+int set_res_skip_bwd(const float *dx_out, const float *dskip, float *dx, float *d_o, int32_t B, int32_t C, int32_t T,
+                     void *stream);
+/* backward of set_layernorm_ch; dgamma/dbeta are accumulated (+=) */
+int set_layernorm_ch_bwd(const float *x, const float *gamma, const float *mask, const float *dy, float *dx,
+                         float *dgamma, float *dbeta, int32_t B, int32_t C, int32_t T, float eps, void *stream);
+/* dtable[idx[b][t]][c] += scale * dout[b][c][t], except for row `padding_idx` (-1: none), whose gradient stays 0
+ * as with nn.Embedding(padding_idx=...) (modules/commons/layers.py:45-50) */
+int set_embedding_bwd(const int64_t *idx, const float *dout, float *dtable, int32_t B, int32_t T, int32_t C,
+                      int32_t n_rows, float scale, int32_t padding_idx, void *stream);
+/* denc[b][c][mel2ph[b][t]-1] += dout[b][c][t] */
+int set_expand_states_bwd(const int64_t *mel2ph, const float *dout, float *denc, int32_t B, int32_t C, int32_t T_txt,
+                          int32_t T, void *stream);
+/* inverted dropout with a Philox keep-mask keyed by (seed, offset + i/4): y = keep ? x/(1-p) : 0.  Calling it on the
+ * output gradient with the same (seed, offset) is the backward (nar_tts_modules.py:20,86 predictor dropout). */
+int set_dropout(const float *x, float *y, int64_t n, float p, uint64_t seed, uint64_t offset, void *stream);
+/* w[f] = (sum_m |target[f][m]|) != 0    (weights_nonzero_speech, utils/nn/seq_utils.py:33-37) */
+int set_frame_weight(const float *target, float *w, int64_t frames, int32_t M, void *stream);
+/* out[0] += sum_i x[i] * (w ? w[i/inner] : 1) */
+int set_weighted_sum(const float *x, const float *w, float *out, int64_t n, int64_t inner, void *stream);
+/* absd = |pred - target|, sgn = sign(pred - target)  (either may be NULL)   (l1_loss, speech_base.py:223-229) */
+int set_l1_elem(const float *pred, const float *target, float *absd, float *sgn, int64_t n, void *stream);
+/* out[i] = a[i] * (w ? w[i/inner] : 1) * (scale_dev ? scale_dev[0] : 1) * scale */
+int set_scale_bcast(const float *a, const float *w, float *out, int64_t n, int64_t inner, const float *scale_dev,
+                    float scale, void *stream);
+/* SSIM (utils/metrics/ssim.py:12-44) on [B][H][W] images: 11x11 gaussian (sigma 1.5), zero padded.
+ * `bias` (6.0, speech_base.py:247) is added to the in-range pixels of both images.
+ * filter: mu1, mu2, E[x^2], E[y^2], E[xy];  map: 1 - ssim and d ssim / d(mu1, E[x^2], E[xy]);
+ * bwd: dimg1 = F(gm) + 2 img1 F(g11) + img2 F(g12). */
+int set_ssim_filter(const float *img1, const float *img2, float bias, float *mu1, float *mu2, float *s11, float *s22,
+                    float *s12, int32_t B, int32_t H, int32_t W, void *stream);
+int set_ssim_map(const float *mu1, const float *mu2, const float *s11, const float *s22, const float *s12,
+                 float *one_minus, float *d_mu1, float *d_s11, float *d_s12, int64_t n, void *stream);
+int set_ssim_bwd(const float *img1, const float *img2, float bias, const float *gm, const float *g11, const float *g12,
+                 float *dimg1, int32_t B, int32_t H, int32_t W, void *stream);
+/* duration losses (speech_editing_base.py:58-90).  Pass 1 (ddur NULL): sums[0..3] += {sum nonpad*d^2, sum nonpad,
+ * sum wordmask*dw^2, sum wordmask}.  Pass 2 (ddur set): ddur = gscale * d(lam_p*s0/s1 + lam_w*s2/s3)/d dur_pred. */
+int set_dur_loss(const float *dur_pred, const int64_t *mel2ph, const int64_t *txt, const int64_t *word_id, float *sums,
+                 const float *final_sums, float *ddur, int32_t B, int32_t T, int32_t T_txt, int32_t n_words,
+                 float lam_p, float lam_w, float gscale, void *stream);
+/* pitch losses (speech_editing_base.py:92-108) on channel-major pitch_pred [B][2][T] (row 0 f0, row 1 uv logit).
+ * Pass 1: sums += {sum nonpad*bce, sum nonpad, sum nv*|df0|, sum nv};  pass 2: dpp = gradient. */
+int set_pitch_loss(const float *pp, const float *f0, const float *uv, const int64_t *mel2ph, float *sums,
+                   const float *final_sums, float *dpp, int32_t B, int32_t T, float lam_uv, float lam_f0, float gscale,
+                   void *stream);
+/* out[0] += sum g[i]^2 */
+int set_sumsq(const float *g, float *out, int64_t n, void *stream);
+/* torch.optim.AdamW step (speech_base.py:163-170) over flat buffers on the gradient g*grad_scale (grad_scale =
+ * 1/world after a SUM all-reduce), with clip_grad_norm_ folded in (base_task.py:129-133): the gradient is further
+ * scaled by min(1, max_norm / (sqrt(sumsq[0])*grad_scale + 1e-6)) when sumsq != NULL (sumsq = sum g^2). */
+int set_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int32_t step, const float *sumsq, float max_norm, float grad_scale, void *stream);
+
 /* MFMA fragment-layout self test: runs a 32x32xK product through v_mfma_f32_32x32x2_f32 with the layout
  * this library assumes and returns the max abs error vs an in-kernel scalar reference via *max_err (HOST).
  * Synchronises.  Used by tests to pin the hardware layout assumption. */

@@ -181,6 +181,79 @@ def train_case(hp, name, B, T, T_txt, steps, wseed, iseed):
         t=t, eps=eps, mel_out=ret["mel_out"], x_t=oret["x_t"], decoder_inp=ret["decoder_inp"])
 
 
+def train_loss_case(hp, name, B, T, T_txt, steps, wseed, iseed):
+    """Reference forward (infer=False, eval mode) + the reference's own loss functions + autograd."""
+    from tasks.tts.speech_base import SpeechBaseTask
+    from tasks.speech_editing.speech_editing_base import SpeechEditingBaseTask
+
+    class FakeTask:  # the loss methods only touch these attributes of `self`
+        l1_loss = SpeechBaseTask.l1_loss
+        ssim_loss = SpeechBaseTask.ssim_loss
+        add_mel_loss = SpeechBaseTask.add_mel_loss
+        add_dur_loss = SpeechEditingBaseTask.add_dur_loss
+        add_pitch_loss = SpeechEditingBaseTask.add_pitch_loss
+
+    task = FakeTask()
+    task.mel_losses = {"l1": 0.5, "ssim": 0.5}
+    task.sil_ph = [1, 2, 3]
+    task.token_encoder = type("Enc", (), {"encode": staticmethod(lambda p: [p])})()
+    model = build_ref_model(hp, steps)
+    W = load_seeded(model, wseed)
+    inp = Wt.synthetic_inputs(B, T, T_txt, seed=iseed, pad_tail=True)
+    rng = np.random.default_rng(iseed + 7)
+    t = torch.from_numpy(rng.integers(0, steps + 1, size=(B,), dtype=np.int64))
+    eps = torch.from_numpy(rng.standard_normal(size=(B, 1, 80, T), dtype=np.float32))
+    real_randint, real_rl = torch.randint, torch.randn_like
+    torch.randint = lambda *a, **k: t.clone()
+    torch.randn_like = lambda x, **k: eps.clone()
+    try:
+        with torch.enable_grad():
+            out = model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"],
+                        inp["f0"].clone(), inp["uv"].clone(), infer=False)
+            tm = inp["time_mel_masks"]
+            losses = {}
+            task.add_mel_loss(out["mel_out"] * tm, inp["ref_mels"] * tm, losses, postfix="_coarse")
+            task.add_dur_loss(out["dur"], inp["mel2ph"], inp["txt_tokens"], losses=losses)
+            task.add_pitch_loss(out, {"mel2ph": inp["mel2ph"], "f0": inp["f0"], "uv": inp["uv"]}, losses)
+            total = sum(losses.values())
+            total.backward()
+    finally:
+        torch.randint, torch.randn_like = real_randint, real_rl
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    # ---- oracle cross-check (values and every gradient)
+    Wg = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    with torch.enable_grad():
+        olosses, _ = O.training_losses(Wg, steps, inp, t, eps)
+        sum(olosses.values()).backward()
+    for k in losses:
+        assert abs(float(losses[k]) - float(olosses[k])) < 1e-5 * max(1.0, abs(float(losses[k]))), k
+    worst = 0.0
+    for k, g in grads.items():
+        og = Wg[k].grad
+        assert (g is None) == (og is None), k
+        if g is not None:
+            worst = max(worst, float((g - og).abs().max()) / (float(g.abs().max()) + 1e-12))
+    print("  [%s] oracle vs reference: losses ok; worst relative grad deviation %.2e" % (name, worst))
+    assert worst < 1e-3
+    keep = ["denoise_fn.output_projection.bias", "denoise_fn.residual_layers.3.diffusion_projection.bias",
+            "denoise_fn.residual_layers.19.dilated_conv.bias", "denoise_fn.mlp.0.bias",
+            "fs.dur_predictor.linear.0.weight", "fs.pitch_predictor.linear.bias", "fs.encoder.embed_tokens.weight",
+            "fs.spk_embed_proj.weight", "mel_encoder.fc_out.bias", "fs.encoder.res_blocks.0.blocks.0.0.weight",
+            "fs.dur_embed.weight", "fs.pitch_embed.weight"]
+    names = [k for k, _ in model.named_parameters()]
+    norms = np.array([float(grads[k].norm()) if grads[k] is not None else -1.0 for k in names], dtype=np.float64)
+    out_np = dict(meta=np.array(json.dumps(dict(B=B, T=T, T_txt=T_txt, steps=steps, wseed=wseed, iseed=iseed,
+                                                pad_tail=True, sil_ids=[1, 2, 3], param_names=names))),
+                  t=t, eps=eps, grad_norms=norms, total=total.detach(),
+                  **{"loss_" + k: v.detach() for k, v in losses.items()})
+    for k in keep:
+        g = grads[k]
+        if k in ("fs.dur_embed.weight", "fs.pitch_embed.weight"):
+            g = g[:64]
+        out_np["grad::" + k] = g
+    npz(name, **out_np)
+
+
 def schedule_case(hp):
     out = {}
     for steps in (4, 8, 100):
@@ -254,6 +327,7 @@ def main():
     infer_case(hp, "infer_c64", B=2, T=48, T_txt=12, steps=2, wseed=16, iseed=106, overrides=ov, keep_steps=(1,))
     hp.update(base)
     train_case(hp, "train_tiny", B=2, T=64, T_txt=16, steps=8, wseed=17, iseed=107)
+    train_loss_case(hp, "train_losses", B=2, T=64, T_txt=16, steps=8, wseed=18, iseed=108)
     length_regulator_case()
     hifigan_case("hifigan_tiny", Wt.HIFIGAN_TINY, B=2, T=24, wseed=21, iseed=201)
     hifigan_case("hifigan_tiny_rb2", Wt.HIFIGAN_TINY_RB2, B=1, T=20, wseed=22, iseed=202)

@@ -275,7 +275,7 @@ def mel_encoder(W, x, p="mel_encoder."):
 
 
 def fastspeech_forward(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv,
-                       use_pred_mel2ph=False, use_pred_pitch=False, p="fs."):
+                       use_pred_mel2ph=False, use_pred_pitch=False, p="fs.", predictor_grad=0.1):
     """fs.py:83-189 with skip_decoder=True, use_spk_embed, use_pitch_embed,
     pitch_type 'frame', use_uv (egs/spec_denoiser.yaml).  Eval mode (no dropout).
     Returns the ret dict incl. integer intermediates."""
@@ -290,6 +290,7 @@ def fastspeech_forward(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv,
     masked_dur = mel2token_to_dur(mel2ph * (1 - time_mel_masks).squeeze(-1).long(), T_txt) * nonpad
     ret["masked_dur"] = masked_dur.long()
     dur_inp = dur_inp + F.embedding(masked_dur.long(), W[p + "dur_embed.weight"], padding_idx=0)
+    dur_inp = dur_inp.detach() + predictor_grad * (dur_inp - dur_inp.detach())  # fs.py:144-145
     src_padding = txt_tokens == 0
     dur = duration_predictor(W, dur_inp, src_padding, p + "dur_predictor.")
     ret["dur"] = dur
@@ -307,6 +308,7 @@ def fastspeech_forward(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv,
     masked_pitch = f0_to_coarse(denorm_f0(masked_f0, masked_uv, pitch_padding))
     ret["masked_pitch"] = masked_pitch
     pp_inp = pitch_inp + F.embedding(masked_pitch, W[p + "pitch_embed.weight"], padding_idx=0)
+    pp_inp = pp_inp.detach() + predictor_grad * (pp_inp - pp_inp.detach())  # fs.py:167-169
     h = predictor_stack(W, p + "pitch_predictor.", pp_inp, 5, 5)
     pitch_pred = F.linear(h, W[p + "pitch_predictor.linear.weight"], W[p + "pitch_predictor.linear.bias"])
     ret["pitch_pred"] = pitch_pred
@@ -414,6 +416,82 @@ def hifigan_forward(W, h, x, prefix=""):
     x = F.leaky_relu(x)  # default slope 0.01, hifigan.py:138
     x = F.conv1d(x, _wn(W, p + "conv_post."), W[p + "conv_post.bias"], padding=3)
     return torch.tanh(x)
+
+
+# --------------------------------------------------------------------------
+# a20: training losses (tasks/tts/speech_base.py:219-257, tasks/speech_editing/speech_editing_base.py:58-108,
+#      utils/metrics/ssim.py:12-44, utils/nn/seq_utils.py:33-37)
+# --------------------------------------------------------------------------
+def weights_nonzero_speech(target):
+    return target.abs().sum(-1, keepdim=True).ne(0).float().repeat(1, 1, target.size(-1))
+
+
+def l1_loss(pred, target):
+    w = weights_nonzero_speech(target)
+    return (F.l1_loss(pred, target, reduction="none") * w).sum() / w.sum()
+
+
+def _ssim_map(img1, img2, window_size=11, sigma=1.5):
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    g = (g / g.sum()).unsqueeze(1)
+    window = g.mm(g.t()).float()[None, None]
+    p = window_size // 2
+    mu1, mu2 = F.conv2d(img1, window, padding=p), F.conv2d(img2, window, padding=p)
+    mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1 = F.conv2d(img1 * img1, window, padding=p) - mu1_sq
+    s2 = F.conv2d(img2 * img2, window, padding=p) - mu2_sq
+    s12 = F.conv2d(img1 * img2, window, padding=p) - mu12
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return ((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+
+
+def ssim_loss(pred, target, bias=6.0):
+    w = weights_nonzero_speech(target)
+    m = _ssim_map(pred[:, None] + bias, target[:, None] + bias).mean(1)
+    return ((1 - m) * w).sum() / w.sum()
+
+
+def dur_losses(dur_pred, mel2ph, txt_tokens, sil_ids, lam_p, lam_w):
+    B, T = txt_tokens.shape
+    nonpad = (txt_tokens != 0).float()
+    dur_gt = mel2token_to_dur(mel2ph, T).float() * nonpad
+    is_sil = torch.zeros_like(txt_tokens).bool()
+    for i in sil_ids:
+        is_sil = is_sil | (txt_tokens == i)
+    is_sil = is_sil.float()
+    pd = F.mse_loss((dur_pred + 1).log(), (dur_gt + 1).log(), reduction="none")
+    pd = (pd * nonpad).sum() / nonpad.sum() * lam_p
+    word_id = (is_sil.cumsum(-1) * (1 - is_sil)).long()
+    wp = dur_pred.new_zeros([B, int(word_id.max()) + 1]).scatter_add(1, word_id, dur_pred)[:, 1:]
+    wg = dur_gt.new_zeros([B, int(word_id.max()) + 1]).scatter_add(1, word_id, dur_gt)[:, 1:]
+    wl = F.mse_loss((wp + 1).log(), (wg + 1).log(), reduction="none")
+    wm = (wg > 0).float()
+    return pd, (wl * wm).sum() / wm.sum() * lam_w
+
+
+def pitch_losses(pitch_pred, f0, uv, mel2ph, lam_uv, lam_f0):
+    nonpad = (mel2ph != 0).float()
+    uvl = (F.binary_cross_entropy_with_logits(pitch_pred[:, :, 1], uv, reduction="none") * nonpad).sum() \
+        / nonpad.sum() * lam_uv
+    nv = nonpad * (uv == 0).float()
+    f0l = (F.l1_loss(pitch_pred[:, :, 0], f0, reduction="none") * nv).sum() / nv.sum() * lam_f0
+    return uvl, f0l
+
+
+def training_losses(W, timesteps, inputs, t, noise, sil_ids=(1, 2, 3), lambdas=None, dilation_cycle_length=1):
+    """tasks/speech_editing/spec_denoiser.py:39-62 (infer=False) on top of gaussian_diffusion_train; eval-mode
+    predictors (no dropout).  Returns (losses dict, ret)."""
+    lam = dict(l1=0.5, ssim=0.5, ph_dur=0.1, word_dur=1.0, uv=1.0, f0=1.0)
+    lam.update(lambdas or {})
+    ret = gaussian_diffusion_train(W, timesteps, inputs, t, noise, dilation_cycle_length)
+    tm = inputs["time_mel_masks"]
+    pred, target = ret["mel_out"] * tm, inputs["ref_mels"] * tm
+    losses = {"l1_coarse": l1_loss(pred, target) * lam["l1"], "ssim_coarse": ssim_loss(pred, target) * lam["ssim"]}
+    losses["pdur"], losses["wdur"] = dur_losses(ret["dur"], inputs["mel2ph"], inputs["txt_tokens"], sil_ids,
+                                                lam["ph_dur"], lam["word_dur"])
+    losses["uv"], losses["f0"] = pitch_losses(ret["pitch_pred"], inputs["f0"], inputs["uv"], inputs["mel2ph"],
+                                              lam["uv"], lam["f0"])
+    return losses, ret
 
 
 # --------------------------------------------------------------------------

@@ -32,6 +32,11 @@ class _Dummy:
     def __call__(self, *a, **k):
         return None
 
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Dummy()
+
 
 class _StubModule(types.ModuleType):
     def __getattr__(self, name):

@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_PKG, "libset_amd.so")
-SOURCES = ["conv1d.hip", "glue.hip", "diffnet.hip"]
+SOURCES = ["conv1d.hip", "glue.hip", "diffnet.hip", "train.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
 # constants mirrored from set_amd.h
@@ -123,6 +123,29 @@ SIGNATURES = {
     "set_randn": (C.c_int, [_V, _I64, _U64, _U64, _V]),
     "set_diffusion_loop": (C.c_int, [C.POINTER(SetDiffLoopArgs), _V]),
     "set_selftest_mfma": (C.c_int, [C.POINTER(C.c_float), _V]),
+    "set_conv1d_wgrad": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _V]),
+    "set_channel_sum": (C.c_int, [_V, _V, _I32, _I32, _I32, _V]),
+    "set_row_sum": (C.c_int, [_V, _V, _I64, _I32, _F, _V]),
+    "set_conv_epilogue_bwd": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _F, _V]),
+    "set_act_fwd": (C.c_int, [_V, _V, _I64, _I32, _F, _V]),
+    "set_act_bwd": (C.c_int, [_V, _V, _V, _I64, _I32, _F, _V]),
+    "set_gate_bwd": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _V]),
+    "set_res_skip_bwd": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _V]),
+    "set_layernorm_ch_bwd": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _I32, _I32, _I32, _F, _V]),
+    "set_embedding_bwd": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _I32, _F, _I32, _V]),
+    "set_expand_states_bwd": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _I32, _V]),
+    "set_dropout": (C.c_int, [_V, _V, _I64, _F, _U64, _U64, _V]),
+    "set_frame_weight": (C.c_int, [_V, _V, _I64, _I32, _V]),
+    "set_weighted_sum": (C.c_int, [_V, _V, _V, _I64, _I64, _V]),
+    "set_l1_elem": (C.c_int, [_V, _V, _V, _V, _I64, _V]),
+    "set_scale_bcast": (C.c_int, [_V, _V, _V, _I64, _I64, _V, _F, _V]),
+    "set_ssim_filter": (C.c_int, [_V, _V, _F, _V, _V, _V, _V, _V, _I32, _I32, _I32, _V]),
+    "set_ssim_map": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _I64, _V]),
+    "set_ssim_bwd": (C.c_int, [_V, _V, _F, _V, _V, _V, _V, _I32, _I32, _I32, _V]),
+    "set_dur_loss": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _I32, _I32, _I32, _I32, _F, _F, _F, _V]),
+    "set_pitch_loss": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _I32, _I32, _F, _F, _F, _V]),
+    "set_sumsq": (C.c_int, [_V, _V, _I64, _V]),
+    "set_adamw": (C.c_int, [_V, _V, _V, _V, _I64, _F, _F, _F, _F, _F, _I32, _V, _F, _F, _V]),
     "set_sizeof_conv1d_args": (_I64, []),
     "set_sizeof_diffnet_layer_args": (_I64, []),
     "set_sizeof_diff_loop_args": (_I64, []),

@@ -1,0 +1,522 @@
+"""Differentiable versions of the ops in ops.py (same names / signatures), for the training path.
+
+torch.autograd is used as the tape only: every forward AND backward below is a kernel of libset_amd.so
+(include/set_amd.h, "Training" section).  Ops without gradients (masks, integer bookkeeping) are re-exported
+from ops.py unchanged.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from ._lib import ACT, PRO, IMPL_MFMA, IMPL_NAIVE, check
+from .ops import _p, _stream, ConvWeight
+
+# no-gradient ops: identical to the inference path
+abs_sum_mask = ops.abs_sum_mask
+index_mask = ops.index_mask
+masked_dur = ops.masked_dur
+pitch_coarse = ops.pitch_coarse
+mul_one_minus_mask = ops.mul_one_minus_mask
+blend_mask = ops.blend_mask
+sinusoid_embed = ops.sinusoid_embed
+q_sample = ops.q_sample
+randn = ops.randn
+length_regulate = ops.length_regulate
+
+L = _lib.lib
+
+
+def _zeros_like(t):
+    return torch.zeros_like(t, memory_format=torch.contiguous_format)
+
+
+def _wgrad_impl(T):
+    return IMPL_MFMA if T >= 16 else IMPL_NAIVE
+
+
+# --------------------------------------------------------------------------------------------------
+class _Conv1dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, chan_add, res, cw, dil, pad, pro, pro_param, act, alpha, mask, impl):
+        x = x.contiguous()
+        y = ops.conv1d(x, cw, bias, dil=dil, pad=pad, pro=pro, pro_param=pro_param, act=act, alpha=alpha, res=res,
+                       mask=mask, in_chan_add=chan_add, impl=impl)
+        ctx.cw, ctx.cfg = cw, (dil, pad, pro, pro_param, act, alpha, impl)
+        ctx.has = (bias is not None, chan_add is not None, res is not None)
+        ctx.save_for_backward(x, chan_add, mask, y if act == "relu" else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, chan_add, mask, y = ctx.saved_tensors
+        dil, pad, pro, pro_param, act, alpha, impl = ctx.cfg
+        cw = ctx.cw
+        has_bias, has_add, has_res = ctx.has
+        dy = dy.contiguous()
+        B, Cout, T = dy.shape
+        Cin, T_in = x.shape[1], x.shape[2]
+        g = torch.empty_like(dy)
+        check(L().set_conv_epilogue_bwd(_p(dy), _p(y), _p(mask), _p(g), B, Cout, T, ACT[act], float(alpha), _stream()),
+              "set_conv_epilogue_bwd")
+        dres = None
+        if has_res and ctx.needs_input_grad[4]:
+            if act == "none" and alpha == 1.0:
+                dres = g
+            else:
+                dres = torch.empty_like(dy)
+                check(L().set_conv_epilogue_bwd(_p(dy), None, _p(mask), _p(dres), B, Cout, T, 0, 1.0, _stream()),
+                      "set_conv_epilogue_bwd")
+        dx = dadd = None
+        if ctx.needs_input_grad[0] or (has_add and ctx.needs_input_grad[3]):
+            # input gradient = convolution of G with W'[ci][co][tap] = W[co][ci][tap], taps at s + pad - tap*dil
+            dx = ops.conv1d(g, cw.transposed(), None, dil=-dil, pad=-pad, alpha=(1.0 / pro_param) if pro == "div" else 1.0,
+                            T_iter=T_in, T_out=T_in, impl=impl)
+            if has_add and ctx.needs_input_grad[3]:
+                dadd = torch.empty(B, Cin, dtype=torch.float32, device=dy.device)
+                check(L().set_row_sum(_p(dx), _p(dadd), B * Cin, T_in, 1.0, _stream()), "set_row_sum")
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            w = cw.raw()
+            assert cw.base == 0 and cw.stap == 1 and cw.sci == cw.K and cw.sco == cw.Cin * cw.K, "plain conv layout"
+            dw = torch.zeros(w.shape, dtype=torch.float32, device=dy.device)
+            check(L().set_conv1d_wgrad(_p(g), _p(x), _p(chan_add), _p(dw), B, Cin, Cout, cw.K, dil, pad, T, T_in, PRO[pro],
+                                       float(pro_param), _wgrad_impl(T), _stream()), "set_conv1d_wgrad")
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(Cout, dtype=torch.float32, device=dy.device)
+            check(L().set_channel_sum(_p(g), _p(db), B, Cout, T, _stream()), "set_channel_sum")
+        return (dx if ctx.needs_input_grad[0] else None, dw, db, dadd, dres, None, None, None, None, None, None, None,
+                None, None)
+
+
+_SPLIT_ACTS = ("gelu", "mish", "softplus", "tanh")
+
+
+def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act="none", act_param=0.0, alpha=1.0,
+           res=None, mask=None, in_chan_add=None, out=None, accumulate=False, impl=None, T_iter=None, T_out=None,
+           out_stride=1, out_off=0):
+    """Differentiable set_conv1d (stride-1, plain [Cout,Cin,K] weights).  Activations other than ReLU run as a
+    separate kernel so their pre-activation is available to the backward."""
+    assert isinstance(weight, ConvWeight) and out is None and not accumulate and out_stride == 1 and out_off == 0
+    assert pro in ("none", "div")
+    if act in _SPLIT_ACTS:
+        assert res is None
+        z = _Conv1dFn.apply(x, weight.raw(), bias, in_chan_add, None, weight, dil, pad, pro, pro_param, "none", alpha,
+                            None, impl)
+        y = activation(z, act, act_param)
+        return add_chan_mask(y, None, mask) if mask is not None else y
+    return _Conv1dFn.apply(x, weight.raw(), bias, in_chan_add, res, weight, dil, pad, pro, pro_param, act, alpha, mask,
+                           impl)
+
+
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, act, p):
+        z = z.contiguous()
+        y = torch.empty_like(z)
+        check(L().set_act_fwd(_p(z), _p(y), z.numel(), ACT[act], float(p), _stream()), "set_act_fwd")
+        ctx.save_for_backward(z)
+        ctx.cfg = (act, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (z,) = ctx.saved_tensors
+        act, p = ctx.cfg
+        dy = dy.contiguous()
+        dz = torch.empty_like(z)
+        check(L().set_act_bwd(_p(z), _p(dy), _p(dz), z.numel(), ACT[act], float(p), _stream()), "set_act_bwd")
+        return dz, None, None
+
+
+def activation(z, act, p=0.0):
+    return _ActFn.apply(z, act, p)
+
+
+class _LayerNormChFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mask, eps):
+        x = x.contiguous()
+        y = ops.layernorm_ch(x, gamma, beta, mask, eps)
+        ctx.save_for_backward(x, gamma, mask)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mask = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, Cc, T = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(gamma)
+        check(L().set_layernorm_ch_bwd(_p(x), _p(gamma), _p(mask), _p(dy), _p(dx), _p(dg), _p(db), B, Cc, T,
+                                       float(ctx.eps), _stream()), "set_layernorm_ch_bwd")
+        return dx, dg, db, None, None
+
+
+def layernorm_ch(x, gamma, beta, mask=None, eps=1e-5, out=None):
+    return _LayerNormChFn.apply(x, gamma, beta, mask, eps)
+
+
+class _EmbeddingFn(torch.autograd.Function):
+    """out = (base or 0) + scale * table[idx]  written channel-major."""
+
+    @staticmethod
+    def forward(ctx, idx, table, base, scale, padding_idx):
+        ctx.padding_idx = -1 if padding_idx is None else int(padding_idx)
+        if base is None:
+            out = ops.embedding_bct(idx, table, scale=scale)
+        else:
+            out = ops.embedding_bct(idx, table, scale=scale, out=base.detach().clone(), accumulate=True)
+        ctx.save_for_backward(idx)
+        ctx.cfg = (tuple(table.shape), scale, base is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        (n_rows, Cc), scale, has_base = ctx.cfg
+        dout = dout.contiguous()
+        B, T = idx.shape
+        dtab = torch.zeros(n_rows, Cc, dtype=torch.float32, device=dout.device)
+        check(L().set_embedding_bwd(_p(idx), _p(dout), _p(dtab), B, T, Cc, n_rows, float(scale), ctx.padding_idx,
+                                    _stream()), "set_embedding_bwd")
+        return None, dtab, (dout if has_base else None), None, None
+
+
+def embedding_bct(idx, table, scale=1.0, out=None, accumulate=False, padding_idx=None):
+    return _EmbeddingFn.apply(idx, table, out if accumulate else None, scale, padding_idx)
+
+
+class _ExpandStatesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, mel2ph):
+        enc = enc.contiguous()
+        ctx.save_for_backward(mel2ph)
+        ctx.shape = tuple(enc.shape)
+        return ops.expand_states(enc, mel2ph)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (mel2ph,) = ctx.saved_tensors
+        B, Cc, T_txt = ctx.shape
+        dout = dout.contiguous()
+        denc = torch.zeros(B, Cc, T_txt, dtype=torch.float32, device=dout.device)
+        check(L().set_expand_states_bwd(_p(mel2ph), _p(dout), _p(denc), B, Cc, T_txt, mel2ph.shape[1], _stream()),
+              "set_expand_states_bwd")
+        return denc, None
+
+
+def expand_states(enc_bct, mel2ph):
+    return _ExpandStatesFn.apply(enc_bct, mel2ph)
+
+
+class _AddChanMaskFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, add, mask):
+        x = x.contiguous()
+        ctx.save_for_backward(mask)
+        ctx.has_add = add is not None
+        return ops.add_chan_mask(x, add, mask)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (mask,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, Cc, T = dout.shape
+        dx = ops.add_chan_mask(dout, None, mask) if mask is not None else dout
+        dadd = None
+        if ctx.has_add and ctx.needs_input_grad[1]:
+            dadd = torch.empty(B, Cc, dtype=torch.float32, device=dout.device)
+            check(L().set_row_sum(_p(dx), _p(dadd), B * Cc, T, 1.0, _stream()), "set_row_sum")
+        return dx, dadd, None
+
+
+def add_chan_mask(x, add=None, mask=None, out=None):
+    return _AddChanMaskFn.apply(x, add, mask)
+
+
+class _TransposeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, to_bct):
+        ctx.to_bct = to_bct
+        x = x.contiguous()
+        return ops.btc_to_bct(x) if to_bct else ops.bct_to_btc(x)
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        return (ops.bct_to_btc(d) if ctx.to_bct else ops.btc_to_bct(d)), None
+
+
+def btc_to_bct(x):
+    return _TransposeFn.apply(x, True)
+
+
+def bct_to_btc(x):
+    return _TransposeFn.apply(x, False)
+
+
+class _GateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y):
+        y = y.contiguous()
+        ctx.save_for_backward(y)
+        return ops.gate(y)
+
+    @staticmethod
+    def backward(ctx, dz):
+        (y,) = ctx.saved_tensors
+        dz = dz.contiguous()
+        B, C2, T = y.shape
+        dy = torch.empty_like(y)
+        check(L().set_gate_bwd(_p(y), _p(dz), _p(dy), B, C2 // 2, T, _stream()), "set_gate_bwd")
+        return dy
+
+
+def gate(y):
+    return _GateFn.apply(y)
+
+
+class _ResSkipFn(torch.autograd.Function):
+    """(x_out, skip_out) = ((x + o[:, :C]) / sqrt2, skip_in + o[:, C:])   (functional form of set_res_skip)."""
+
+    @staticmethod
+    def forward(ctx, x, o, skip_in):
+        x, o = x.contiguous(), o.contiguous()
+        first = skip_in is None
+        skip = torch.empty_like(x) if first else skip_in.detach().clone()
+        x_out = ops.res_skip(x, o, skip, first)
+        ctx.first = first
+        return x_out, skip
+
+    @staticmethod
+    def backward(ctx, dx_out, dskip):
+        dx_out, dskip = dx_out.contiguous(), dskip.contiguous()
+        B, Cc, T = dx_out.shape
+        dx = torch.empty_like(dx_out)
+        d_o = torch.empty(B, 2 * Cc, T, dtype=torch.float32, device=dx_out.device)
+        check(L().set_res_skip_bwd(_p(dx_out), _p(dskip), _p(dx), _p(d_o), B, Cc, T, _stream()), "set_res_skip_bwd")
+        return dx, d_o, (None if ctx.first else dskip)
+
+
+def res_skip_fn(x, o, skip_in):
+    return _ResSkipFn.apply(x, o, skip_in)
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(L().set_dropout(_p(x), _p(y), x.numel(), float(p), int(seed), int(offset), _stream()), "set_dropout")
+        ctx.cfg = (p, seed, offset)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, offset = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(L().set_dropout(_p(dy), _p(dx), dy.numel(), float(p), int(seed), int(offset), _stream()), "set_dropout")
+        return dx, None, None, None
+
+
+def dropout(x, p, seed, offset=0):
+    return _DropoutFn.apply(x, p, seed, offset) if p > 0 else x
+
+
+class _GradScaleFn(torch.autograd.Function):
+    """x.detach() + s * (x - x.detach())  (fs.py:144-145,167-169): identity forward, gradient scaled by s."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        out = torch.empty_like(d)
+        check(L().set_scale_bcast(_p(d), None, _p(out), d.numel(), 1, None, float(ctx.s), _stream()), "set_scale_bcast")
+        return out, None
+
+
+def grad_scale(x, s):
+    return _GradScaleFn.apply(x, s) if s != 1 else x
+
+
+# --------------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------------
+def frame_weights(target_btm):
+    """weights_nonzero_speech(target)[..., 0]  -> [B*T]"""
+    B, T, M = target_btm.shape
+    w = torch.empty(B * T, dtype=torch.float32, device=target_btm.device)
+    check(L().set_frame_weight(_p(target_btm.contiguous()), _p(w), B * T, M, _stream()), "set_frame_weight")
+    return w
+
+
+def _sum(x, w=None, inner=1):
+    out = torch.zeros(1, dtype=torch.float32, device=x.device)
+    check(L().set_weighted_sum(_p(x), _p(w), _p(out), x.numel(), inner, _stream()), "set_weighted_sum")
+    return out
+
+
+class _MaskedL1Fn(torch.autograd.Function):
+    """(|pred - target| * w).sum() / w_full.sum()   (speech_base.py:223-229; w broadcast over the mel axis)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, w):
+        pred, target = pred.contiguous(), target.contiguous()
+        M = pred.shape[-1]
+        absd = torch.empty_like(pred)
+        check(L().set_l1_elem(_p(pred), _p(target), _p(absd), None, pred.numel(), _stream()), "set_l1_elem")
+        num = _sum(absd, w, M)
+        den = _sum(w) * float(M)
+        ctx.save_for_backward(pred, target, w, den)
+        return (num / den).reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target, w, den = ctx.saved_tensors
+        M = pred.shape[-1]
+        sgn = torch.empty_like(pred)
+        check(L().set_l1_elem(_p(pred), _p(target), None, _p(sgn), pred.numel(), _stream()), "set_l1_elem")
+        scale = (gout.reshape(1) / den).contiguous()
+        d = torch.empty_like(pred)
+        check(L().set_scale_bcast(_p(sgn), _p(w), _p(d), pred.numel(), M, _p(scale), 1.0, _stream()), "set_scale_bcast")
+        return d, None, None
+
+
+def masked_l1(pred, target, w):
+    return _MaskedL1Fn.apply(pred, target, w)
+
+
+class _SSIMLossFn(torch.autograd.Function):
+    """((1 - ssim_map(pred+bias, target+bias)) * w).sum() / w_full.sum()   (speech_base.py:247-257, ssim.py:24-44)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, w, bias):
+        B, T, M = pred.shape
+        dev = pred.device
+        img1, img2 = pred.contiguous(), target.contiguous()
+        maps = [torch.empty(B, T, M, dtype=torch.float32, device=dev) for _ in range(5)]
+        check(L().set_ssim_filter(_p(img1), _p(img2), float(bias), *[_p(m) for m in maps], B, T, M, _stream()), "set_ssim_filter")
+        one_minus = torch.empty_like(pred)
+        d = [torch.empty_like(pred) for _ in range(3)]
+        check(L().set_ssim_map(*[_p(m) for m in maps], _p(one_minus), _p(d[0]), _p(d[1]), _p(d[2]), pred.numel(), _stream()),
+              "set_ssim_map")
+        num = _sum(one_minus, w, M)
+        den = _sum(w) * float(M)
+        ctx.save_for_backward(img1, img2, w, den, *d)
+        ctx.bias = bias
+        return (num / den).reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        img1, img2, w, den, d0, d1, d2 = ctx.saved_tensors
+        B, T, M = img1.shape
+        scale = (-gout.reshape(1) / den).contiguous()  # d loss / d ssim = -w / den
+        g = []
+        for dk in (d0, d1, d2):
+            t = torch.empty_like(dk)
+            check(L().set_scale_bcast(_p(dk), _p(w), _p(t), dk.numel(), M, _p(scale), 1.0, _stream()), "set_scale_bcast")
+            g.append(t)
+        dimg = torch.empty_like(img1)
+        check(L().set_ssim_bwd(_p(img1), _p(img2), float(ctx.bias), _p(g[0]), _p(g[1]), _p(g[2]), _p(dimg), B, T, M, _stream()),
+              "set_ssim_bwd")
+        return dimg, None, None, None
+
+
+def ssim_loss(pred, target, w, bias=6.0):
+    return _SSIMLossFn.apply(pred, target, w, bias)
+
+
+class _DurLossFn(torch.autograd.Function):
+    """returns (pdur, wdur) already multiplied by their lambdas (speech_editing_base.py:58-90)."""
+
+    @staticmethod
+    def forward(ctx, dur_pred, mel2ph, txt, word_id, n_words, lam_p, lam_w):
+        dur_pred = dur_pred.contiguous()
+        B, T_txt = dur_pred.shape
+        T = mel2ph.shape[1]
+        sums = torch.zeros(4, dtype=torch.float32, device=dur_pred.device)
+        check(L().set_dur_loss(_p(dur_pred), _p(mel2ph), _p(txt), _p(word_id), _p(sums), None, None, B, T, T_txt, n_words,
+                               float(lam_p), float(lam_w), 1.0, _stream()), "set_dur_loss")
+        ctx.save_for_backward(dur_pred, mel2ph, txt, word_id, sums)
+        ctx.cfg = (n_words, lam_p, lam_w)
+        pd = sums[0] / sums[1] * lam_p
+        wd = sums[2] / sums[3] * lam_w
+        return pd, wd
+
+    @staticmethod
+    def backward(ctx, gp, gw):
+        dur_pred, mel2ph, txt, word_id, sums = ctx.saved_tensors
+        n_words, lam_p, lam_w = ctx.cfg
+        B, T_txt = dur_pred.shape
+        # both outputs normally receive the same upstream gradient (1.0 from the loss sum); handle them separately
+        d = torch.empty_like(dur_pred)
+        out = None
+        for lam_a, lam_b, gg in ((lam_p, 0.0, gp), (0.0, lam_w, gw)):
+            check(L().set_dur_loss(_p(dur_pred), _p(mel2ph), _p(txt), _p(word_id), None, _p(sums), _p(d), B, mel2ph.shape[1],
+                                   T_txt, n_words, float(lam_a), float(lam_b), 1.0, _stream()), "set_dur_loss")
+            term = torch.empty_like(d)
+            check(L().set_scale_bcast(_p(d), None, _p(term), d.numel(), 1, _p(gg.reshape(1).contiguous()), 1.0, _stream()),
+                  "set_scale_bcast")
+            out = term if out is None else ops.sum_div(out, term, None, 1.0)
+        return out, None, None, None, None, None, None
+
+
+def dur_losses(dur_pred, mel2ph, txt, word_id, n_words, lam_p, lam_w):
+    return _DurLossFn.apply(dur_pred, mel2ph, txt, word_id, n_words, lam_p, lam_w)
+
+
+class _PitchLossFn(torch.autograd.Function):
+    """returns (uv_loss, f0_loss) times their lambdas; pp is channel-major [B,2,T] (speech_editing_base.py:92-108)."""
+
+    @staticmethod
+    def forward(ctx, pp, f0, uv, mel2ph, lam_uv, lam_f0):
+        pp = pp.contiguous()
+        B, _, T = pp.shape
+        sums = torch.zeros(4, dtype=torch.float32, device=pp.device)
+        check(L().set_pitch_loss(_p(pp), _p(f0), _p(uv), _p(mel2ph), _p(sums), None, None, B, T, float(lam_uv),
+                                 float(lam_f0), 1.0, _stream()), "set_pitch_loss")
+        ctx.save_for_backward(pp, f0, uv, mel2ph, sums)
+        ctx.cfg = (lam_uv, lam_f0)
+        return sums[0] / sums[1] * lam_uv, sums[2] / sums[3] * lam_f0
+
+    @staticmethod
+    def backward(ctx, g_uv, g_f0):
+        pp, f0, uv, mel2ph, sums = ctx.saved_tensors
+        lam_uv, lam_f0 = ctx.cfg
+        B, _, T = pp.shape
+        d = torch.empty_like(pp)
+        check(L().set_pitch_loss(_p(pp), _p(f0), _p(uv), _p(mel2ph), None, _p(sums), _p(d), B, T, float(lam_uv),
+                                 float(lam_f0), 1.0, _stream()), "set_pitch_loss")
+        # rows carry independent upstream gradients: row 0 (f0) * g_f0, row 1 (uv) * g_uv
+        gsc = torch.stack([g_f0.reshape(()), g_uv.reshape(())]).reshape(1, 2, 1).expand(B, 2, 1).contiguous().reshape(-1)
+        out = torch.empty_like(d)
+        check(L().set_scale_bcast(_p(d), _p(gsc), _p(out), d.numel(), T, None, 1.0, _stream()), "set_scale_bcast")
+        return out, None, None, None, None, None
+
+
+def pitch_losses(pp_bct, f0, uv, mel2ph, lam_uv, lam_f0):
+    return _PitchLossFn.apply(pp_bct, f0, uv, mel2ph, lam_uv, lam_f0)
+
+
+# --------------------------------------------------------------------------------------------------
+# optimizer
+# --------------------------------------------------------------------------------------------------
+def grad_sumsq(flat_grad):
+    out = torch.zeros(1, dtype=torch.float32, device=flat_grad.device)
+    check(L().set_sumsq(_p(flat_grad), _p(out), flat_grad.numel(), _stream()), "set_sumsq")
+    return out
+
+
+def adamw_step(flat_p, flat_g, m, v, lr, beta1, beta2, eps, weight_decay, step, sumsq=None, max_norm=0.0,
+               grad_scale=1.0):
+    check(L().set_adamw(_p(flat_p), _p(flat_g), _p(m), _p(v), flat_p.numel(), float(lr), float(beta1), float(beta2),
+                        float(eps), float(weight_decay), int(step), _p(sumsq), float(max_norm), float(grad_scale),
+                        _stream()), "set_adamw")

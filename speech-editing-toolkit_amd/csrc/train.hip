@@ -1,0 +1,726 @@
+// Training-side kernels of the hot path: weight-gradient GEMM on fp32 MFMA,
+// reductions, backward of LayerNorm / activations / gate / embedding / alignment gather, the mel / duration /
+// pitch losses of tasks/tts/speech_base.py:219-257 and tasks/speech_editing/speech_editing_base.py:58-108 with
+// their gradients, fused AdamW and the global grad norm.  Input gradients of convolutions reuse set_conv1d
+// (a convolution with transposed weight addressing and negated dilation/padding).
+#include "common.h"
+
+namespace {
+
+// -------------------------------------------------------------------------------------------------------
+// conv weight gradient:  dW[co][ci][tap] += sum_{b,t} G[b][co][t] * P(X[b][ci][t + tap*dil - pad])
+// GEMM M = Cout, N = (tap, ci), reduction over frames; block tile 128 x 64, 32-frame LDS chunks, split over
+// (batch, frame-chunk) slices with fp32 atomics into dW.
+// -------------------------------------------------------------------------------------------------------
+constexpr int WG_KC = 32;       // frames per LDS chunk
+constexpr int WG_LD = WG_KC + 1;  // padded row (conflict-free column reads)
+
+struct WgradArgs {
+    const float *g;    // [B][Cout][T]
+    const float *x;    // [B][Cin][T_in]
+    const float *chan_add;  // optional [B][Cin]
+    float *dw;         // [Cout][Cin][K] (+= )
+    int B, Cin, Cout, K, dil, pad, T, T_in, pro;
+    float pro_param;
+    int chunks_per_slice, n_chunks_t;  // chunk id = b * n_chunks_t + tc
+};
+
+__global__ void __launch_bounds__(256) conv1d_wgrad_mfma_kernel(WgradArgs a) {
+    __shared__ float Gs[128 * WG_LD];
+    __shared__ float Xs[64 * WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ci_tiles = (a.Cin + 63) / 64;
+    const int tap = blockIdx.x / ci_tiles, ci0 = (blockIdx.x % ci_tiles) * 64;
+    const int co0 = blockIdx.y * 128;
+    const int shift = tap * a.dil - a.pad;
+    f32x16 acc0 = {0}, acc1 = {0};
+    const int total_chunks = a.B * a.n_chunks_t;
+    const int c_begin = blockIdx.z * a.chunks_per_slice;
+    const int c_end = min(c_begin + a.chunks_per_slice, total_chunks);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        const int b = ch / a.n_chunks_t, t0 = (ch % a.n_chunks_t) * WG_KC;
+        __syncthreads();
+        for (int i = tid; i < 128 * WG_KC; i += 256) {
+            const int r = i / WG_KC, k = i % WG_KC;
+            const int co = co0 + r, t = t0 + k;
+            float v = 0.0f;
+            if (co < a.Cout && t < a.T) v = a.g[((int64_t)b * a.Cout + co) * a.T + t];
+            Gs[r * WG_LD + k] = v;
+        }
+        for (int i = tid; i < 64 * WG_KC; i += 256) {
+            const int r = i / WG_KC, k = i % WG_KC;
+            const int ci = ci0 + r, t = t0 + k, ti = t + shift;
+            float v = 0.0f;
+            if (ci < a.Cin && t < a.T && ti >= 0 && ti < a.T_in) {
+                v = a.x[((int64_t)b * a.Cin + ci) * a.T_in + ti];
+                if (a.chan_add) v += a.chan_add[(int64_t)b * a.Cin + ci];
+                v = dev_pro(v, a.pro, a.pro_param);
+            }
+            Xs[r * WG_LD + k] = v;
+        }
+        __syncthreads();
+        const float *ap = Gs + (32 * w + l31) * WG_LD + half;
+        const float *bp = Xs + l31 * WG_LD + half;
+#pragma unroll
+        for (int kk = 0; kk < WG_KC; kk += 2) {
+            const float av = ap[kk];
+            acc0 = mfma32(av, bp[kk], acc0);
+            acc1 = mfma32(av, bp[32 * WG_LD + kk], acc1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + 32 * w + mfma32_row(r, lane);
+        if (co >= a.Cout) continue;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int ci = ci0 + 32 * cb + l31;
+            if (ci >= a.Cin) continue;
+            atomicAdd(&a.dw[((int64_t)co * a.Cin + ci) * a.K + tap], cb == 0 ? acc0[r] : acc1[r]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) conv1d_wgrad_naive_kernel(WgradArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.Cout * a.Cin * a.K) return;
+    const int tap = (int)(idx % a.K), ci = (int)((idx / a.K) % a.Cin), co = (int)(idx / ((int64_t)a.K * a.Cin));
+    const int shift = tap * a.dil - a.pad;
+    float s = 0.0f;
+    for (int b = 0; b < a.B; ++b) {
+        const float add = a.chan_add ? a.chan_add[(int64_t)b * a.Cin + ci] : 0.0f;
+        for (int t = 0; t < a.T; ++t) {
+            const int ti = t + shift;
+            if (ti < 0 || ti >= a.T_in) continue;
+            const float xv = dev_pro(a.x[((int64_t)b * a.Cin + ci) * a.T_in + ti] + add, a.pro, a.pro_param);
+            s = fmaf(a.g[((int64_t)b * a.Cout + co) * a.T + t], xv, s);
+        }
+    }
+    a.dw[idx] += s;
+}
+
+// out[c] += sum_{b,t} x[b][c][t]  (bias grads); one block per channel
+__global__ void __launch_bounds__(256) channel_sum_kernel(const float *x, float *out, int B, int C, int T) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float s = 0.0f;
+    for (int64_t i = threadIdx.x; i < (int64_t)B * T; i += 256) {
+        const int b = (int)(i / T), t = (int)(i % T);
+        s += x[((int64_t)b * C + c) * T + t];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] += red[0];
+}
+// out[b][c] = sum_t x[b][c][t] (* 1/div); one wave per (b,c)
+__global__ void __launch_bounds__(256) row_sum_kernel(const float *x, float *out, int64_t rows, int T, float scale) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.0f;
+    for (int t = lane; t < T; t += 64) s += x[row * T + t];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[row] = s * scale;
+}
+
+// G = dY * mask * alpha * [relu: y > 0]      (epilogue backward of set_conv1d; act in {none, relu})
+__global__ void __launch_bounds__(256) conv_epilogue_bwd_kernel(const float *dy, const float *y, const float *mask,
+                                                                float *g, int B, int C, int T, int act, float alpha) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * C * T) return;
+    const int t = (int)(i % T);
+    const int b = (int)(i / ((int64_t)C * T));
+    float v = dy[i];
+    if (mask) v *= mask[(int64_t)b * T + t];
+    if (act == SET_ACT_RELU && !(y[i] > 0.0f)) v = 0.0f;
+    g[i] = v * alpha;
+}
+
+// ---- activations with saved pre-activation z ----------------------------------------------------------------
+__device__ __forceinline__ float dev_act_grad(float z, int act, float p) {
+    switch (act) {
+        case SET_ACT_RELU: return z > 0.0f ? 1.0f : 0.0f;
+        case SET_ACT_GELU: {  // d/dz 0.5 z (1 + erf(z/sqrt2)) = Phi(z) + z phi(z)
+            const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+            return cdf + z * pdf;
+        }
+        case SET_ACT_TANH: { const float th = tanhf(z); return 1.0f - th * th; }
+        case SET_ACT_SOFTPLUS: return z > 20.0f ? 1.0f : dev_sigmoid(z);
+        case SET_ACT_MISH: {
+            const float sp = dev_softplus(z), th = tanhf(sp);
+            const float dsp = z > 20.0f ? 1.0f : dev_sigmoid(z);
+            return th + z * (1.0f - th * th) * dsp;
+        }
+        case SET_ACT_LRELU: return z > 0.0f ? 1.0f : p;
+        default: return 1.0f;
+    }
+}
+__global__ void __launch_bounds__(256) act_fwd_kernel(const float *z, float *y, int64_t n, int act, float p) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = dev_act(z[i], act, p);
+}
+__global__ void __launch_bounds__(256) act_bwd_kernel(const float *z, const float *dy, float *dz, int64_t n, int act,
+                                                      float p) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dz[i] = dy[i] * dev_act_grad(z[i], act, p);
+}
+
+// ---- gate / res-skip backward ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gate_bwd_kernel(const float *y, const float *dz, float *dy, int B, int C,
+                                                       int T) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * C * T) return;
+    const int64_t ct = i % ((int64_t)C * T), b = i / ((int64_t)C * T);
+    const float *yb = y + b * 2 * C * T;
+    float *dyb = dy + b * 2 * C * T;
+    const float s = dev_sigmoid(yb[ct]), th = tanhf(yb[(int64_t)C * T + ct]);
+    const float d = dz[i];
+    dyb[ct] = d * th * s * (1.0f - s);
+    dyb[(int64_t)C * T + ct] = d * s * (1.0f - th * th);
+}
+// forward: x_out = (x + o[:C]) / sqrt2 ; skip_out = skip_in + o[C:]
+// backward: dx = dx_out / sqrt2 ; do[:C] = dx_out / sqrt2 ; do[C:] = dskip_out
+__global__ void __launch_bounds__(256) res_skip_bwd_kernel(const float *dx_out, const float *dskip, float *dx, float *d_o,
+                                                           int B, int C, int T) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * C * T) return;
+    const int64_t ct = i % ((int64_t)C * T), b = i / ((int64_t)C * T);
+    const float v = dx_out[i] / 1.41421356237309504880f;
+    dx[i] = v;
+    float *ob = d_o + b * 2 * C * T;
+    ob[ct] = v;
+    ob[(int64_t)C * T + ct] = dskip[i];
+}
+
+// ---- LayerNorm over channels, backward: one thread per (b,t) column; dgamma/dbeta via wave reduce + atomics ----
+__global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, const float *gamma, const float *mask,
+                                                               const float *dy, float *dx, float *dgamma, float *dbeta,
+                                                               int B, int C, int T, float eps) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = idx < (int64_t)B * T;
+    const int b = valid ? (int)(idx / T) : 0, t = valid ? (int)(idx % T) : 0;
+    const float *xp = x + (int64_t)b * C * T + t;
+    const float *dp = dy + (int64_t)b * C * T + t;
+    float mean = 0.0f, rstd = 0.0f, m = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    if (valid) {
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) s += xp[(int64_t)c * T];
+        mean = s / (float)C;
+        float q = 0.0f;
+        for (int c = 0; c < C; ++c) { const float d = xp[(int64_t)c * T] - mean; q = fmaf(d, d, q); }
+        rstd = 1.0f / sqrtf(q / (float)C + eps);
+        m = mask ? mask[idx] : 1.0f;
+        for (int c = 0; c < C; ++c) {
+            const float xh = (xp[(int64_t)c * T] - mean) * rstd;
+            const float g = dp[(int64_t)c * T] * m * gamma[c];
+            s1 += g;
+            s2 = fmaf(g, xh, s2);
+        }
+        s1 /= (float)C;
+        s2 /= (float)C;
+    }
+    float *op = dx + (int64_t)b * C * T + t;
+    const int lane = threadIdx.x & 63;
+    for (int c = 0; c < C; ++c) {
+        float dg = 0.0f, db = 0.0f;
+        if (valid) {
+            const float xh = (xp[(int64_t)c * T] - mean) * rstd;
+            const float dyc = dp[(int64_t)c * T] * m;
+            op[(int64_t)c * T] = rstd * (dyc * gamma[c] - s1 - xh * s2);
+            dg = dyc * xh;
+            db = dyc;
+        }
+        for (int off = 32; off > 0; off >>= 1) { dg += __shfl_xor(dg, off); db += __shfl_xor(db, off); }
+        if (lane == 0) { atomicAdd(&dgamma[c], dg); atomicAdd(&dbeta[c], db); }
+    }
+}
+
+// ---- embedding / alignment gather backward (scatter-add) ------------------------------------------------------
+__global__ void __launch_bounds__(256) embedding_bwd_kernel(const int64_t *idx, const float *dout, float *dtable, int B,
+                                                            int T, int C, int n_rows, float scale, int padding_idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * C * T) return;
+    const int t = (int)(i % T), c = (int)((i / T) % C), b = (int)(i / ((int64_t)T * C));
+    int64_t row = idx[(int64_t)b * T + t];
+    row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
+    if (row == padding_idx) return;  // nn.Embedding(padding_idx=...) never updates that row (layers.py:45-50)
+    atomicAdd(&dtable[row * C + c], scale * dout[i]);
+}
+__global__ void __launch_bounds__(256) expand_states_bwd_kernel(const int64_t *mel2ph, const float *dout, float *denc,
+                                                                int B, int C, int T_txt, int T) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * C * T) return;
+    const int t = (int)(i % T), c = (int)((i / T) % C), b = (int)(i / ((int64_t)T * C));
+    const int64_t m = mel2ph[(int64_t)b * T + t];
+    if (m > 0 && m <= T_txt) atomicAdd(&denc[((int64_t)b * C + c) * T_txt + (m - 1)], dout[i]);
+}
+
+// ---- dropout: keep mask from Philox(seed, offset + i/4); same kernel for forward and backward ------------------
+__device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__global__ void __launch_bounds__(256) dropout_kernel(const float *x, float *y, int64_t n, float p, uint64_t seed,
+                                                      uint64_t offset) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q * 4 >= n) return;
+    const uint64_t ctr = offset + (uint64_t)q;
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0x5eedu, 0u};
+    philox_round(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float inv = 1.0f / (1.0f - p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = q * 4 + k;
+        if (i >= n) break;
+        const float u = (float)(c[k] >> 8) * (1.0f / 16777216.0f);
+        y[i] = u >= p ? x[i] * inv : 0.0f;
+    }
+}
+
+// ---- losses ------------------------------------------------------------------------------------------------------
+// weights_nonzero_speech (utils/nn/seq_utils.py:33-37): w[b][t] = (sum_m |target[b][t][m]|) != 0
+__global__ void __launch_bounds__(256) frame_weight_kernel(const float *target, float *w, int64_t frames, int M) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= frames) return;
+    float s = 0.0f;
+    for (int m = 0; m < M; ++m) s += fabsf(target[i * M + m]);
+    w[i] = s != 0.0f ? 1.0f : 0.0f;
+}
+// sum-reduce helper: out[0] += sum x[i] (* w[i / inner])
+__global__ void __launch_bounds__(256) weighted_sum_kernel(const float *x, const float *w, float *out, int64_t n,
+                                                           int64_t inner) {
+    __shared__ float red[256];
+    float s = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        s += w ? x[i] * w[i / inner] : x[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+// |pred - target| (forward) / sign(pred - target) (backward), [n]
+__global__ void __launch_bounds__(256) l1_elem_kernel(const float *pred, const float *target, float *absd, float *sgn,
+                                                      int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float d = pred[i] - target[i];
+    if (absd) absd[i] = fabsf(d);
+    if (sgn) sgn[i] = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+}
+// out[i] = a[i] * w[i / inner] * scale   (broadcast multiply used by the loss backward)
+__global__ void __launch_bounds__(256) scale_bcast_kernel(const float *a, const float *w, float *out, int64_t n,
+                                                          int64_t inner, const float *scale_dev, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = a[i] * scale;
+    if (w) v *= w[i / inner];
+    if (scale_dev) v *= scale_dev[0];
+    out[i] = v;
+}
+
+// SSIM (utils/metrics/ssim.py:12-44): 11x11 gaussian (sigma 1.5) zero-padded depthwise filter on [B][H=T][W=M] images
+struct SsimArgs {
+    const float *img1, *img2;  // [B][H][W]; `bias` is added to in-range pixels, the zero padding stays 0
+    float bias;
+    float *mu1, *mu2, *s11, *s22, *s12;  // filtered maps (raw second moments, not centred)
+    int B, H, W;
+};
+__constant__ float c_gauss[11];
+__global__ void __launch_bounds__(256) ssim_filter_kernel(SsimArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)a.B * a.H * a.W) return;
+    const int x = (int)(i % a.W), y = (int)((i / a.W) % a.H), b = (int)(i / ((int64_t)a.W * a.H));
+    const float *p1 = a.img1 + (int64_t)b * a.H * a.W, *p2 = a.img2 + (int64_t)b * a.H * a.W;
+    float m1 = 0, m2 = 0, q11 = 0, q22 = 0, q12 = 0;
+    for (int dy = -5; dy <= 5; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= a.H) continue;
+        for (int dx = -5; dx <= 5; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= a.W) continue;
+            const float wgt = c_gauss[dy + 5] * c_gauss[dx + 5];
+            const float u = p1[(int64_t)yy * a.W + xx] + a.bias, v = p2[(int64_t)yy * a.W + xx] + a.bias;
+            m1 = fmaf(wgt, u, m1); m2 = fmaf(wgt, v, m2);
+            q11 = fmaf(wgt, u * u, q11); q22 = fmaf(wgt, v * v, q22); q12 = fmaf(wgt, u * v, q12);
+        }
+    }
+    a.mu1[i] = m1; a.mu2[i] = m2; a.s11[i] = q11; a.s22[i] = q22; a.s12[i] = q12;
+}
+// per pixel: ssim value (-> one_minus) and the partials of ssim w.r.t. (mu1, E[x^2], E[xy])
+__global__ void __launch_bounds__(256) ssim_map_kernel(const float *mu1, const float *mu2, const float *s11,
+                                                       const float *s22, const float *s12, float *one_minus,
+                                                       float *d_mu1, float *d_s11, float *d_s12, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float C1 = 0.0001f, C2 = 0.0009f;
+    const float m1 = mu1[i], m2 = mu2[i];
+    const float v1 = s11[i] - m1 * m1, v2 = s22[i] - m2 * m2, cv = s12[i] - m1 * m2;
+    const float A1 = 2.0f * m1 * m2 + C1, A2 = 2.0f * cv + C2;
+    const float B1 = m1 * m1 + m2 * m2 + C1, B2 = v1 + v2 + C2;
+    const float s = (A1 * A2) / (B1 * B2);
+    one_minus[i] = 1.0f - s;
+    if (d_mu1) {
+        // ds/dm1 with v1 = q11 - m1^2, cv = q12 - m1 m2 held through q11,q12:
+        const float dA1 = 2.0f * m2, dA2 = -2.0f * m2, dB1 = 2.0f * m1, dB2 = -2.0f * m1;
+        d_mu1[i] = (dA1 * A2 + A1 * dA2) / (B1 * B2) - s * (dB1 / B1 + dB2 / B2);
+        d_s11[i] = -s / B2;             // dB2/dq11 = 1
+        d_s12[i] = 2.0f * A1 / (B1 * B2);  // dA2/dq12 = 2
+    }
+}
+// dimg1 = F(g*d_mu1) + 2 img1 F(g*d_s11) + img2 F(g*d_s12), F = the same (symmetric) gaussian filter, g = upstream
+__global__ void __launch_bounds__(256) ssim_bwd_kernel(const float *img1, const float *img2, const float *gm,
+                                                       const float *g11, const float *g12, float *dimg1, int B, int H,
+                                                       int W, float bias) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * H * W) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((int64_t)W * H));
+    const int64_t base = (int64_t)b * H * W;
+    float a0 = 0, a1 = 0, a2 = 0;
+    for (int dy = -5; dy <= 5; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -5; dx <= 5; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            const float wgt = c_gauss[dy + 5] * c_gauss[dx + 5];
+            const int64_t j = base + (int64_t)yy * W + xx;
+            a0 = fmaf(wgt, gm[j], a0); a1 = fmaf(wgt, g11[j], a1); a2 = fmaf(wgt, g12[j], a2);
+        }
+    }
+    dimg1[i] = a0 + 2.0f * (img1[i] + bias) * a1 + (img2[i] + bias) * a2;
+}
+
+// duration losses (speech_editing_base.py:58-90): one block per utterance.
+// out[0] += sum_j nonpad (log(dp+1) - log(dg+1))^2 ; out[1] += sum nonpad ; out[2] += sum_w wmask (..)^2 ; out[3] += sum wmask
+// ddur (optional): gradient of  lam_p * out0/out1 + lam_w * out2/out3  given the FINAL sums in `sums` (second pass).
+__global__ void __launch_bounds__(256) dur_loss_kernel(const float *dur_pred, const int64_t *mel2ph, const int64_t *txt,
+                                                       const int64_t *word_id, float *sums, const float *final_sums,
+                                                       float *ddur, int T, int T_txt, int n_words, float lam_p,
+                                                       float lam_w, float gscale) {
+    extern __shared__ float sh[];  // dur_gt[T_txt+1] | wp[n_words+1] | wg[n_words+1]
+    float *dg = sh, *wp = sh + (T_txt + 1), *wg = wp + (n_words + 1);
+    const int b = blockIdx.x;
+    for (int j = threadIdx.x; j <= T_txt; j += 256) dg[j] = 0.0f;
+    for (int j = threadIdx.x; j <= n_words; j += 256) { wp[j] = 0.0f; wg[j] = 0.0f; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const int64_t m = mel2ph[(int64_t)b * T + t];
+        if (m >= 0 && m <= T_txt) atomicAdd(&dg[(int)m], 1.0f);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < T_txt; j += 256) {
+        const float np = txt[(int64_t)b * T_txt + j] != 0 ? 1.0f : 0.0f;
+        const int wi = (int)word_id[(int64_t)b * T_txt + j];
+        atomicAdd(&wp[wi], dur_pred[(int64_t)b * T_txt + j]);
+        atomicAdd(&wg[wi], dg[j + 1] * np);
+    }
+    __syncthreads();
+    if (!ddur) {
+        float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (int j = threadIdx.x; j < T_txt; j += 256) {
+            const float np = txt[(int64_t)b * T_txt + j] != 0 ? 1.0f : 0.0f;
+            const float d = logf(dur_pred[(int64_t)b * T_txt + j] + 1.0f) - logf(dg[j + 1] * np + 1.0f);
+            s0 += d * d * np; s1 += np;
+        }
+        for (int wi = 1 + threadIdx.x; wi <= n_words; wi += 256) {
+            const float wm = wg[wi] > 0.0f ? 1.0f : 0.0f;
+            const float d = logf(wp[wi] + 1.0f) - logf(wg[wi] + 1.0f);
+            s2 += d * d * wm; s3 += wm;
+        }
+        atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[2], s2); atomicAdd(&sums[3], s3);
+    } else {
+        for (int j = threadIdx.x; j < T_txt; j += 256) {
+            const float np = txt[(int64_t)b * T_txt + j] != 0 ? 1.0f : 0.0f;
+            const float dp = dur_pred[(int64_t)b * T_txt + j];
+            float g = lam_p * np * 2.0f * (logf(dp + 1.0f) - logf(dg[j + 1] * np + 1.0f)) / (dp + 1.0f) / final_sums[1];
+            const int wi = (int)word_id[(int64_t)b * T_txt + j];
+            if (lam_w > 0.0f && wi > 0 && wg[wi] > 0.0f)
+                g += lam_w * 2.0f * (logf(wp[wi] + 1.0f) - logf(wg[wi] + 1.0f)) / (wp[wi] + 1.0f) / final_sums[3];
+            ddur[(int64_t)b * T_txt + j] = g * gscale;
+        }
+    }
+}
+
+// pitch losses (speech_editing_base.py:92-108) on channel-major pitch_pred [B][2][T]:
+// sums[0] += sum nonpad * bce(logit, uv) ; sums[1] += sum nonpad ; sums[2] += sum nv |f0p - f0| ; sums[3] += sum nv
+// second pass (dpp != NULL): dpp[b][0][t] = lam_f0 * nv * sign / sums[3] ; dpp[b][1][t] = lam_uv * nonpad * (sigmoid - uv) / sums[1]
+__global__ void __launch_bounds__(256) pitch_loss_kernel(const float *pp, const float *f0, const float *uv,
+                                                         const int64_t *mel2ph, float *sums, const float *final_sums,
+                                                         float *dpp, int B, int T, float lam_uv, float lam_f0,
+                                                         float gscale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (i < (int64_t)B * T) {
+        const int b = (int)(i / T), t = (int)(i % T);
+        const float np = mel2ph[i] != 0 ? 1.0f : 0.0f;
+        const float lg = pp[((int64_t)b * 2 + 1) * T + t], fp = pp[((int64_t)b * 2) * T + t];
+        const float u = uv[i];
+        const float nv = np * (u == 0.0f ? 1.0f : 0.0f);
+        if (!dpp) {
+            // bce_with_logits = max(x,0) - x*u + log(1 + exp(-|x|))
+            s0 = np * (fmaxf(lg, 0.0f) - lg * u + log1pf(expf(-fabsf(lg))));
+            s1 = np;
+            s2 = nv * fabsf(fp - f0[i]);
+            s3 = nv;
+        } else {
+            const float d = fp - f0[i];
+            dpp[((int64_t)b * 2) * T + t] = gscale * lam_f0 * nv * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) / final_sums[3];
+            dpp[((int64_t)b * 2 + 1) * T + t] = gscale * lam_uv * np * (dev_sigmoid(lg) - u) / final_sums[1];
+        }
+    }
+    if (!dpp) {
+        for (int off = 32; off > 0; off >>= 1) {
+            s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); s3 += __shfl_xor(s3, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[2], s2); atomicAdd(&sums[3], s3);
+        }
+    }
+}
+
+// ---- optimizer ---------------------------------------------------------------------------------------------------
+// sum of squares of a flat buffer -> out[0] (atomic)
+__global__ void __launch_bounds__(256) sumsq_kernel(const float *g, float *out, int64_t n) {
+    __shared__ float red[256];
+    float s = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = fmaf(g[i], g[i], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+// AdamW (torch.optim.AdamW semantics, amsgrad off) over a flat buffer; grads are first scaled by
+// clip = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))  (torch.nn.utils.clip_grad_norm_), sumsq optional.
+__global__ void __launch_bounds__(256) adamw_kernel(float *p, const float *g, float *m, float *v, int64_t n, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1, float bc2,
+                                                    const float *sumsq, float max_norm, float grad_scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float clip = 1.0f;
+    if (sumsq && max_norm > 0.0f) {
+        const float c = max_norm / (sqrtf(sumsq[0]) * grad_scale + 1e-6f);
+        clip = c < 1.0f ? c : 1.0f;
+    }
+    const float gi = g[i] * grad_scale * clip;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+extern "C" int set_conv1d_wgrad(const float *g, const float *x, const float *chan_add, float *dw, int32_t B, int32_t Cin,
+                                int32_t Cout, int32_t K, int32_t dil, int32_t pad, int32_t T, int32_t T_in, int32_t pro,
+                                float pro_param, int32_t impl, void *stream) {
+    SET_REQUIRE(g && x && dw && B > 0 && Cin > 0 && Cout > 0 && K > 0 && T > 0 && T_in > 0, "set_conv1d_wgrad");
+    WgradArgs a = {g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro, pro_param, 0, 0};
+    hipStream_t s = (hipStream_t)stream;
+    if (impl != SET_IMPL_MFMA) {
+        hipLaunchKernelGGL(conv1d_wgrad_naive_kernel, dim3(set_blocks((int64_t)Cout * Cin * K, 256)), dim3(256), 0, s, a);
+        return set_check_launch("set_conv1d_wgrad(naive)");
+    }
+    a.n_chunks_t = (T + WG_KC - 1) / WG_KC;
+    const int total = B * a.n_chunks_t;
+    const int tiles = K * ((Cin + 63) / 64) * ((Cout + 127) / 128);
+    int slices = (2048 + tiles - 1) / tiles;
+    if (slices > total) slices = total;
+    if (slices < 1) slices = 1;
+    a.chunks_per_slice = (total + slices - 1) / slices;
+    slices = (total + a.chunks_per_slice - 1) / a.chunks_per_slice;
+    dim3 grid(K * ((Cin + 63) / 64), (Cout + 127) / 128, slices);
+    hipLaunchKernelGGL(conv1d_wgrad_mfma_kernel, grid, dim3(256), 0, s, a);
+    return set_check_launch("set_conv1d_wgrad(mfma)");
+}
+
+extern "C" int set_channel_sum(const float *x, float *out, int32_t B, int32_t C, int32_t T, void *stream) {
+    SET_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "set_channel_sum");
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, T);
+    return set_check_launch("set_channel_sum");
+}
+extern "C" int set_row_sum(const float *x, float *out, int64_t rows, int32_t T, float scale, void *stream) {
+    SET_REQUIRE(x && out && rows > 0 && T > 0, "set_row_sum");
+    hipLaunchKernelGGL(row_sum_kernel, dim3(set_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, out, rows, T, scale);
+    return set_check_launch("set_row_sum");
+}
+extern "C" int set_conv_epilogue_bwd(const float *dy, const float *y, const float *mask, float *g, int32_t B, int32_t C,
+                                     int32_t T, int32_t act, float alpha, void *stream) {
+    SET_REQUIRE(dy && g && B > 0 && C > 0 && T > 0 && (act == SET_ACT_NONE || (act == SET_ACT_RELU && y)),
+                "set_conv_epilogue_bwd");
+    hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0,
+                       (hipStream_t)stream, dy, y, mask, g, B, C, T, act, alpha);
+    return set_check_launch("set_conv_epilogue_bwd");
+}
+extern "C" int set_act_fwd(const float *z, float *y, int64_t n, int32_t act, float p, void *stream) {
+    SET_REQUIRE(z && y && n > 0, "set_act_fwd");
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, z, y, n, act, p);
+    return set_check_launch("set_act_fwd");
+}
+extern "C" int set_act_bwd(const float *z, const float *dy, float *dz, int64_t n, int32_t act, float p, void *stream) {
+    SET_REQUIRE(z && dy && dz && n > 0, "set_act_bwd");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, z, dy, dz, n, act, p);
+    return set_check_launch("set_act_bwd");
+}
+extern "C" int set_gate_bwd(const float *y, const float *dz, float *dy, int32_t B, int32_t C, int32_t T, void *stream) {
+    SET_REQUIRE(y && dz && dy && B > 0 && C > 0 && T > 0, "set_gate_bwd");
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0, (hipStream_t)stream, y,
+                       dz, dy, B, C, T);
+    return set_check_launch("set_gate_bwd");
+}
+extern "C" int set_res_skip_bwd(const float *dx_out, const float *dskip, float *dx, float *d_o, int32_t B, int32_t C,
+                                int32_t T, void *stream) {
+    SET_REQUIRE(dx_out && dskip && dx && d_o && B > 0 && C > 0 && T > 0, "set_res_skip_bwd");
+    hipLaunchKernelGGL(res_skip_bwd_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dx_out, dskip, dx, d_o, B, C, T);
+    return set_check_launch("set_res_skip_bwd");
+}
+extern "C" int set_layernorm_ch_bwd(const float *x, const float *gamma, const float *mask, const float *dy, float *dx,
+                                    float *dgamma, float *dbeta, int32_t B, int32_t C, int32_t T, float eps,
+                                    void *stream) {
+    SET_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && B > 0 && C > 0 && T > 0, "set_layernorm_ch_bwd");
+    hipLaunchKernelGGL(layernorm_ch_bwd_kernel, dim3(set_blocks((int64_t)B * T, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, gamma, mask, dy, dx, dgamma, dbeta, B, C, T, eps);
+    return set_check_launch("set_layernorm_ch_bwd");
+}
+extern "C" int set_embedding_bwd(const int64_t *idx, const float *dout, float *dtable, int32_t B, int32_t T, int32_t C,
+                                 int32_t n_rows, float scale, int32_t padding_idx, void *stream) {
+    SET_REQUIRE(idx && dout && dtable && B > 0 && T > 0 && C > 0 && n_rows > 0, "set_embedding_bwd");
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0, (hipStream_t)stream,
+                       idx, dout, dtable, B, T, C, n_rows, scale, padding_idx);
+    return set_check_launch("set_embedding_bwd");
+}
+extern "C" int set_expand_states_bwd(const int64_t *mel2ph, const float *dout, float *denc, int32_t B, int32_t C,
+                                     int32_t T_txt, int32_t T, void *stream) {
+    SET_REQUIRE(mel2ph && dout && denc && B > 0 && C > 0 && T_txt > 0 && T > 0, "set_expand_states_bwd");
+    hipLaunchKernelGGL(expand_states_bwd_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0,
+                       (hipStream_t)stream, mel2ph, dout, denc, B, C, T_txt, T);
+    return set_check_launch("set_expand_states_bwd");
+}
+extern "C" int set_dropout(const float *x, float *y, int64_t n, float p, uint64_t seed, uint64_t offset, void *stream) {
+    SET_REQUIRE(x && y && n > 0 && p >= 0.0f && p < 1.0f, "set_dropout");
+    hipLaunchKernelGGL(dropout_kernel, dim3(set_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, p,
+                       seed, offset);
+    return set_check_launch("set_dropout");
+}
+extern "C" int set_frame_weight(const float *target, float *w, int64_t frames, int32_t M, void *stream) {
+    SET_REQUIRE(target && w && frames > 0 && M > 0, "set_frame_weight");
+    hipLaunchKernelGGL(frame_weight_kernel, dim3(set_blocks(frames, 256)), dim3(256), 0, (hipStream_t)stream, target, w,
+                       frames, M);
+    return set_check_launch("set_frame_weight");
+}
+extern "C" int set_weighted_sum(const float *x, const float *w, float *out, int64_t n, int64_t inner, void *stream) {
+    SET_REQUIRE(x && out && n > 0 && inner > 0, "set_weighted_sum");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, out, n, inner);
+    return set_check_launch("set_weighted_sum");
+}
+extern "C" int set_l1_elem(const float *pred, const float *target, float *absd, float *sgn, int64_t n, void *stream) {
+    SET_REQUIRE(pred && target && (absd || sgn) && n > 0, "set_l1_elem");
+    hipLaunchKernelGGL(l1_elem_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, target, absd, sgn, n);
+    return set_check_launch("set_l1_elem");
+}
+extern "C" int set_scale_bcast(const float *a, const float *w, float *out, int64_t n, int64_t inner,
+                               const float *scale_dev, float scale, void *stream) {
+    SET_REQUIRE(a && out && n > 0 && inner > 0, "set_scale_bcast");
+    hipLaunchKernelGGL(scale_bcast_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, a, w, out, n, inner,
+                       scale_dev, scale);
+    return set_check_launch("set_scale_bcast");
+}
+static int ssim_upload_window() {
+    static bool done = false;
+    if (done) return SET_OK;
+    // utils/metrics/ssim.py:12-14: gaussian(11, 1.5), computed in fp32 like torch.Tensor([...]) / sum
+    float g[11], s = 0.0f;
+    for (int x = 0; x < 11; ++x) { g[x] = (float)exp(-(double)((x - 5) * (x - 5)) / (2.0 * 1.5 * 1.5)); s += g[x]; }
+    for (int x = 0; x < 11; ++x) g[x] /= s;
+    SET_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), g, sizeof(g)), "ssim window");
+    done = true;
+    return SET_OK;
+}
+extern "C" int set_ssim_filter(const float *img1, const float *img2, float bias, float *mu1, float *mu2, float *s11,
+                               float *s22, float *s12, int32_t B, int32_t H, int32_t W, void *stream) {
+    SET_REQUIRE(img1 && img2 && mu1 && mu2 && s11 && s22 && s12 && B > 0 && H > 0 && W > 0, "set_ssim_filter");
+    int rc = ssim_upload_window();
+    if (rc != SET_OK) return rc;
+    SsimArgs a = {img1, img2, bias, mu1, mu2, s11, s22, s12, B, H, W};
+    hipLaunchKernelGGL(ssim_filter_kernel, dim3(set_blocks((int64_t)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return set_check_launch("set_ssim_filter");
+}
+extern "C" int set_ssim_map(const float *mu1, const float *mu2, const float *s11, const float *s22, const float *s12,
+                            float *one_minus, float *d_mu1, float *d_s11, float *d_s12, int64_t n, void *stream) {
+    SET_REQUIRE(mu1 && mu2 && s11 && s22 && s12 && one_minus && n > 0, "set_ssim_map");
+    hipLaunchKernelGGL(ssim_map_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, mu1, mu2, s11, s22, s12,
+                       one_minus, d_mu1, d_s11, d_s12, n);
+    return set_check_launch("set_ssim_map");
+}
+extern "C" int set_ssim_bwd(const float *img1, const float *img2, float bias, const float *gm, const float *g11,
+                            const float *g12, float *dimg1, int32_t B, int32_t H, int32_t W, void *stream) {
+    SET_REQUIRE(img1 && img2 && gm && g11 && g12 && dimg1 && B > 0 && H > 0 && W > 0, "set_ssim_bwd");
+    int rc = ssim_upload_window();
+    if (rc != SET_OK) return rc;
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(set_blocks((int64_t)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, img1,
+                       img2, gm, g11, g12, dimg1, B, H, W, bias);
+    return set_check_launch("set_ssim_bwd");
+}
+extern "C" int set_dur_loss(const float *dur_pred, const int64_t *mel2ph, const int64_t *txt, const int64_t *word_id,
+                            float *sums, const float *final_sums, float *ddur, int32_t B, int32_t T, int32_t T_txt,
+                            int32_t n_words, float lam_p, float lam_w, float gscale, void *stream) {
+    SET_REQUIRE(dur_pred && mel2ph && txt && word_id && B > 0 && T > 0 && T_txt > 0 && n_words >= 0, "set_dur_loss");
+    SET_REQUIRE((ddur && final_sums) || (!ddur && sums), "set_dur_loss");
+    const size_t lds = (size_t)(T_txt + 1 + 2 * (n_words + 1)) * sizeof(float);
+    SET_REQUIRE(lds < 60000, "set_dur_loss(T_txt too large)");
+    hipLaunchKernelGGL(dur_loss_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dur_pred, mel2ph, txt, word_id, sums,
+                       final_sums, ddur, T, T_txt, n_words, lam_p, lam_w, gscale);
+    return set_check_launch("set_dur_loss");
+}
+extern "C" int set_pitch_loss(const float *pp, const float *f0, const float *uv, const int64_t *mel2ph, float *sums,
+                              const float *final_sums, float *dpp, int32_t B, int32_t T, float lam_uv, float lam_f0,
+                              float gscale, void *stream) {
+    SET_REQUIRE(pp && f0 && uv && mel2ph && B > 0 && T > 0, "set_pitch_loss");
+    SET_REQUIRE((dpp && final_sums) || (!dpp && sums), "set_pitch_loss");
+    hipLaunchKernelGGL(pitch_loss_kernel, dim3(set_blocks((int64_t)B * T, 256)), dim3(256), 0, (hipStream_t)stream, pp, f0,
+                       uv, mel2ph, sums, final_sums, dpp, B, T, lam_uv, lam_f0, gscale);
+    return set_check_launch("set_pitch_loss");
+}
+extern "C" int set_sumsq(const float *g, float *out, int64_t n, void *stream) {
+    SET_REQUIRE(g && out && n > 0, "set_sumsq");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, out, n);
+    return set_check_launch("set_sumsq");
+}
+extern "C" int set_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, int32_t step, const float *sumsq, float max_norm,
+                         float grad_scale, void *stream) {
+    SET_REQUIRE(p && g && m && v && n > 0 && step >= 1, "set_adamw");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2, sumsq, max_norm, grad_scale);
+    return set_check_launch("set_adamw");
+}

@@ -9,7 +9,7 @@ import math
 import torch
 from torch import nn
 
-from . import ops
+from . import autograd_ops, ops
 from .hparams import hparams as _global_hparams
 
 
@@ -31,16 +31,16 @@ class ResidualBlock(nn.Module):
         self.conditioner_projection = _kaiming_conv1d(encoder_hidden, 2 * C, 1)
         self.output_projection = _kaiming_conv1d(C, 2 * C, 1)
         H = encoder_hidden
-        self._w_dil = ops.ConvWeight(lambda: self.dilated_conv.weight.data, 2 * C, C, 3)
-        self._w_dproj = ops.ConvWeight(lambda: self.diffusion_projection.weight.data, C, C, 1)
-        self._w_cond = ops.ConvWeight(lambda: self.conditioner_projection.weight.data, 2 * C, H, 1)
-        self._w_out = ops.ConvWeight(lambda: self.output_projection.weight.data, 2 * C, C, 1)
+        self._w_dil = ops.ConvWeight(lambda: self.dilated_conv.weight, 2 * C, C, 3)
+        self._w_dproj = ops.ConvWeight(lambda: self.diffusion_projection.weight, C, C, 1)
+        self._w_cond = ops.ConvWeight(lambda: self.conditioner_projection.weight, 2 * C, H, 1)
+        self._w_out = ops.ConvWeight(lambda: self.output_projection.weight, 2 * C, C, 1)
         self._fused = None
         self._fused_key = None
 
     def fused_weights(self):
-        wd, wo = self.dilated_conv.weight.data, self.output_projection.weight.data
-        key = (wd.data_ptr(), wd._version, wo.data_ptr(), wo._version)
+        wd, wo = self.dilated_conv.weight, self.output_projection.weight
+        key = (wd.data_ptr(), wd._version, wo.data_ptr(), wo._version, ops.weights_epoch())
         if self._fused is None or key != self._fused_key:
             self._fused = ops.pack_diffnet_layer(wd, wo)
             self._fused_key = key
@@ -67,11 +67,11 @@ class DiffNet(nn.Module):
         self.skip_projection = _kaiming_conv1d(C, C, 1)
         self.output_projection = _kaiming_conv1d(C, in_dims, 1)
         nn.init.zeros_(self.output_projection.weight)
-        self._w_in = ops.ConvWeight(lambda: self.input_projection.weight.data, C, in_dims, 1)
-        self._w_mlp0 = ops.ConvWeight(lambda: self.mlp[0].weight.data, 4 * C, C, 1)
-        self._w_mlp2 = ops.ConvWeight(lambda: self.mlp[2].weight.data, C, 4 * C, 1)
-        self._w_skip = ops.ConvWeight(lambda: self.skip_projection.weight.data, C, C, 1)
-        self._w_outp = ops.ConvWeight(lambda: self.output_projection.weight.data, in_dims, C, 1)
+        self._w_in = ops.ConvWeight(lambda: self.input_projection.weight, C, in_dims, 1)
+        self._w_mlp0 = ops.ConvWeight(lambda: self.mlp[0].weight, 4 * C, C, 1)
+        self._w_mlp2 = ops.ConvWeight(lambda: self.mlp[2].weight, C, 4 * C, 1)
+        self._w_skip = ops.ConvWeight(lambda: self.skip_projection.weight, C, C, 1)
+        self._w_outp = ops.ConvWeight(lambda: self.output_projection.weight, in_dims, C, 1)
         self.impl = "auto"  # auto | fused | unfused  (unfused = generic kernels; device-side cross-check)
         self._packs, self._packs_key = None, None
 
@@ -92,15 +92,16 @@ class DiffNet(nn.Module):
         layers = list(self.residual_layers)
         key = tuple((p.data_ptr(), p._version) for l in layers for p in
                     (l.dilated_conv.weight, l.output_projection.weight, l.dilated_conv.bias, l.output_projection.bias))
+        key = key + (ops.weights_epoch(),)
         if self._packs is None or key != self._packs_key:
             dev = layers[0].dilated_conv.weight.device
             L = len(layers)
             w1 = torch.empty(L, 512 * 768, dtype=torch.float32, device=dev)
             w2 = torch.empty(L, 512 * 256, dtype=torch.float32, device=dev)
             for i, l in enumerate(layers):
-                ops.pack_diffnet_layer(l.dilated_conv.weight.data, l.output_projection.weight.data, w1[i], w2[i])
-            bd = torch.stack([l.dilated_conv.bias.data for l in layers]).contiguous()
-            bo = torch.stack([l.output_projection.bias.data for l in layers]).contiguous()
+                ops.pack_diffnet_layer(l.dilated_conv.weight, l.output_projection.weight, w1[i], w2[i])
+            bd = torch.stack([l.dilated_conv.bias for l in layers]).contiguous()
+            bo = torch.stack([l.output_projection.bias for l in layers]).contiguous()
             self._packs, self._packs_key = (w1, w2, bd, bo), key
         return self._packs
 
@@ -111,11 +112,11 @@ class DiffNet(nn.Module):
         C, L = self.C, self.n_layers
         n = t_values.numel()
         emb = ops.sinusoid_embed(t_values, C).view(1, C, n)
-        h = ops.conv1d(emb, self._w_mlp0, self.mlp[0].bias.data, act="mish")
-        h = ops.conv1d(h, self._w_mlp2, self.mlp[2].bias.data)
+        h = ops.conv1d(emb, self._w_mlp0, self.mlp[0].bias, act="mish")
+        h = ops.conv1d(h, self._w_mlp2, self.mlp[2].bias)
         out = torch.empty(1, L * C, n, dtype=torch.float32, device=h.device)
         for l, layer in enumerate(self.residual_layers):
-            ops.conv1d(h, layer._w_dproj, layer.diffusion_projection.bias.data, out=out[:, l * C:(l + 1) * C, :])
+            ops.conv1d(h, layer._w_dproj, layer.diffusion_projection.bias, out=out[:, l * C:(l + 1) * C, :])
         return out.view(L * C, n)
 
     def cond_projections(self, cond):
@@ -125,7 +126,7 @@ class DiffNet(nn.Module):
         C, L = self.C, self.n_layers
         out = torch.empty(B, L * 2 * C, T, dtype=torch.float32, device=cond.device)
         for l, layer in enumerate(self.residual_layers):
-            ops.conv1d(cond, layer._w_cond, layer.conditioner_projection.bias.data,
+            ops.conv1d(cond, layer._w_cond, layer.conditioner_projection.bias,
                        out=out[:, l * 2 * C:(l + 1) * 2 * C, :])
         return out
 
@@ -136,7 +137,7 @@ class DiffNet(nn.Module):
         C, L = self.C, self.n_layers
         n = dtab.shape[1]
         fused = self.use_fused()
-        h = ops.conv1d(x, self._w_in, self.input_projection.bias.data, act="relu")
+        h = ops.conv1d(x, self._w_in, self.input_projection.bias, act="relu")
         skip = torch.empty(B, C, T, dtype=torch.float32, device=x.device)
         nxt = torch.empty_like(h)
         for l, layer in enumerate(self.residual_layers):
@@ -145,24 +146,51 @@ class DiffNet(nn.Module):
                 w1p, w2p = layer.fused_weights()
                 dptr = dtab.data_ptr() + 4 * (l * C * n + col)
                 ops.diffnet_layer(h, cp.data_ptr(), condproj.stride(0), dptr, 1 if batch_cols else 0, n,
-                                  w1p, layer.dilated_conv.bias.data, w2p, layer.output_projection.bias.data,
+                                  w1p, layer.dilated_conv.bias, w2p, layer.output_projection.bias,
                                   nxt, skip, layer.dilation, l == 0)
                 h, nxt = nxt, h
             else:
                 d = dtab.view(L, C, n)[l]  # [C, n]
                 d = d[:, col:col + B].t().contiguous() if batch_cols else d[:, col].reshape(1, C).expand(B, C).contiguous()
-                y = ops.conv1d(h, layer._w_dil, layer.dilated_conv.bias.data, dil=layer.dilation,
+                y = ops.conv1d(h, layer._w_dil, layer.dilated_conv.bias, dil=layer.dilation,
                                pad=layer.dilation, in_chan_add=d, res=cp)
                 z = ops.gate(y)
-                o = ops.conv1d(z, layer._w_out, layer.output_projection.bias.data)
+                o = ops.conv1d(z, layer._w_out, layer.output_projection.bias)
                 h = ops.res_skip(h, o, skip, l == 0)
-        hs = ops.conv1d(skip, self._w_skip, self.skip_projection.bias.data, pro="div", pro_param=math.sqrt(L),
+        hs = ops.conv1d(skip, self._w_skip, self.skip_projection.bias, pro="div", pro_param=math.sqrt(L),
                         act="relu")
-        return ops.conv1d(hs, self._w_outp, self.output_projection.bias.data)
+        return ops.conv1d(hs, self._w_outp, self.output_projection.bias)
+
+    def forward_train(self, spec, diffusion_step, cond):
+        """DiffNet.forward with an autograd tape (training): generic differentiable kernels per op
+        (conv1d dgrad/wgrad on fp32 MFMA, gate / res-skip backward); same math as `forward`."""
+        A = autograd_ops
+        C, L = self.C, self.n_layers
+        x = spec[:, 0].contiguous()
+        n = x.shape[0]
+        emb = ops.sinusoid_embed(diffusion_step.to(torch.float32).contiguous(), C).view(1, C, n)
+        h = A.conv1d(emb, self._w_mlp0, self.mlp[0].bias, act="mish")
+        h = A.conv1d(h, self._w_mlp2, self.mlp[2].bias)
+        hx = A.conv1d(x, self._w_in, self.input_projection.bias, act="relu")
+        cond = cond.contiguous()
+        skip = None
+        for layer in self.residual_layers:
+            d = A.conv1d(h, layer._w_dproj, layer.diffusion_projection.bias)  # [1, C, n]
+            d_bc = d[0].t().contiguous()  # [n, C]: per-utterance channel offsets (layout change only)
+            cp = A.conv1d(cond, layer._w_cond, layer.conditioner_projection.bias)
+            y = A.conv1d(hx, layer._w_dil, layer.dilated_conv.bias, dil=layer.dilation, pad=layer.dilation,
+                         in_chan_add=d_bc, res=cp)
+            z = A.gate(y)
+            o = A.conv1d(z, layer._w_out, layer.output_projection.bias)
+            hx, skip = A.res_skip_fn(hx, o, skip)
+        hs = A.conv1d(skip, self._w_skip, self.skip_projection.bias, pro="div", pro_param=math.sqrt(L), act="relu")
+        return A.conv1d(hs, self._w_outp, self.output_projection.bias)[:, None, :, :]
 
     # ---- reference signature ---------------------------------------------------------------------------
     def forward(self, spec, diffusion_step, cond):
         """spec [B,1,M,T] fp32, diffusion_step int64 [B], cond [B,H,T] -> [B,1,M,T]  (diffnet.py:110-132)."""
+        if torch.is_grad_enabled():
+            return self.forward_train(spec, diffusion_step, cond)
         x = spec[:, 0].contiguous()
         dtab = self.step_table(diffusion_step.to(torch.float32).contiguous())
         condproj = self.cond_projections(cond.contiguous())

@@ -13,7 +13,12 @@ import math
 import torch
 from torch import nn
 
-from . import ops
+from . import autograd_ops, ops
+
+
+def _backend():
+    """Kernels with (training) or without (inference) an autograd tape; same function names either way."""
+    return autograd_ops if torch.is_grad_enabled() else ops
 
 
 def _embedding(n, dim, padding_idx=None):
@@ -31,7 +36,7 @@ def _cw(conv_or_linear):
         cout, cin, k = w.shape
     else:
         (cout, cin), k = w.shape, 1
-    return ops.ConvWeight(lambda: conv_or_linear.weight.data, cout, cin, k)
+    return ops.ConvWeight(lambda: conv_or_linear.weight, cout, cin, k)
 
 
 class ResidualBlock(nn.Module):
@@ -52,12 +57,13 @@ class ResidualBlock(nn.Module):
         self._cw = [(_cw(b[1]), _cw(b[4])) for b in self.blocks]
 
     def run(self, x):
+        F = _backend()
         k, d = self.kernel_size, self.dilation
-        nonpad = ops.abs_sum_mask(x)  # conv.py:58
+        nonpad = F.abs_sum_mask(x.detach())  # conv.py:58
         for b, (w1, w2) in zip(self.blocks, self._cw):
-            h = ops.layernorm_ch(x, b[0].weight.data, b[0].bias.data, eps=self.ln_eps)
-            h = ops.conv1d(h, w1, b[1].bias.data, dil=d, pad=(d * (k - 1)) // 2, alpha=k ** -0.5, act="gelu")
-            x = ops.conv1d(h, w2, b[4].bias.data, res=x, mask=nonpad)  # (x + x_) * nonpadding
+            h = F.layernorm_ch(x, b[0].weight, b[0].bias, eps=self.ln_eps)
+            h = F.conv1d(h, w1, b[1].bias, dil=d, pad=(d * (k - 1)) // 2, alpha=k ** -0.5, act="gelu")
+            x = F.conv1d(h, w2, b[4].bias, res=x, mask=nonpad)  # (x + x_) * nonpadding
         return x
 
 
@@ -82,12 +88,13 @@ class ConvBlocks(nn.Module):
         self._w_post = _cw(self.post_net1)
 
     def run(self, x):
-        nonpad = ops.abs_sum_mask(x)  # conv.py:108
+        F = _backend()
+        nonpad = F.abs_sum_mask(x.detach())  # conv.py:108
         for rb in self.res_blocks:
             x = rb.run(x)
-        x = ops.add_chan_mask(x, None, nonpad)
-        x = ops.layernorm_ch(x, self.last_norm.weight.data, self.last_norm.bias.data, mask=nonpad, eps=self.ln_eps)
-        return ops.conv1d(x, self._w_post, self.post_net1.bias.data, pad=self.post_net_kernel // 2, mask=nonpad)
+        x = F.add_chan_mask(x, None, nonpad)
+        x = F.layernorm_ch(x, self.last_norm.weight, self.last_norm.bias, mask=nonpad, eps=self.ln_eps)
+        return F.conv1d(x, self._w_post, self.post_net1.bias, pad=self.post_net_kernel // 2, mask=nonpad)
 
 
 class TextConvEncoder(ConvBlocks):
@@ -101,14 +108,16 @@ class TextConvEncoder(ConvBlocks):
         self.embed_scale = math.sqrt(hidden_size)
 
     def run_tokens(self, txt_tokens):
-        x = ops.embedding_bct(txt_tokens, self.embed_tokens.weight.data, scale=self.embed_scale)
+        x = _backend().embedding_bct(txt_tokens, self.embed_tokens.weight, scale=self.embed_scale, padding_idx=0)
         return self.run(x)
 
 
 class _PredictorStack(nn.Module):
-    def __init__(self, idim, n_layers, n_chans, kernel_size):
+    def __init__(self, idim, n_layers, n_chans, kernel_size, dropout_rate=0.0):
         super().__init__()
         self.kernel_size = kernel_size
+        self.dropout_rate = dropout_rate
+        self._drop_calls = 0
         self.conv = nn.ModuleList()
         for idx in range(n_layers):
             cin = idim if idx == 0 else n_chans
@@ -120,11 +129,18 @@ class _PredictorStack(nn.Module):
             ))
         self._cws = [_cw(f[0]) for f in self.conv]
 
-    def run_stack(self, x, nonpad=None):
+    def run_stack(self, x, nonpad=None, seed=0):
+        """conv -> ReLU -> LN -> Dropout (-> * nonpadding); dropout only in train() mode with a tape
+        (nar_tts_modules.py:16-21,82-87); mask and inverted-dropout scaling commute, so the mask stays in the LN."""
+        F = _backend()
         k = self.kernel_size
-        for f, w in zip(self.conv, self._cws):
-            x = ops.conv1d(x, w, f[0].bias.data, pad=k // 2, act="relu")
-            x = ops.layernorm_ch(x, f[2].weight.data, f[2].bias.data, mask=nonpad)
+        drop = self.dropout_rate if (self.training and torch.is_grad_enabled()) else 0.0
+        for li, (f, w) in enumerate(zip(self.conv, self._cws)):
+            x = F.conv1d(x, w, f[0].bias, pad=k // 2, act="relu")
+            x = F.layernorm_ch(x, f[2].weight, f[2].bias, mask=nonpad)
+            if drop > 0:
+                self._drop_calls += 1
+                x = F.dropout(x, drop, seed, self._drop_calls * (1 << 28))
         return x
 
 
@@ -132,27 +148,27 @@ class DurationPredictor(_PredictorStack):
     """modules/commons/nar_tts_modules.py:8-34 (inference / eval: dropout is identity)."""
 
     def __init__(self, idim, n_layers=2, n_chans=384, kernel_size=3, dropout_rate=0.1):
-        super().__init__(idim, n_layers, n_chans, kernel_size)
+        super().__init__(idim, n_layers, n_chans, kernel_size, dropout_rate)
         self.linear = nn.Sequential(nn.Linear(n_chans, 1), nn.Identity())  # [1] = Softplus
         self._w_lin = _cw(self.linear[0])
 
-    def run(self, x, src_nonpad):
-        x = self.run_stack(x, src_nonpad)
-        d = ops.conv1d(x, self._w_lin, self.linear[0].bias.data, act="softplus", mask=src_nonpad)
-        return d.view(d.shape[0], d.shape[2])
+    def run(self, x, src_nonpad, seed=0):
+        x = self.run_stack(x, src_nonpad, seed)
+        d = _backend().conv1d(x, self._w_lin, self.linear[0].bias, act="softplus", mask=src_nonpad)
+        return d.reshape(d.shape[0], d.shape[2])
 
 
 class PitchPredictor(_PredictorStack):
     """modules/commons/nar_tts_modules.py:75-100."""
 
     def __init__(self, idim, n_layers=5, n_chans=384, odim=2, kernel_size=5, dropout_rate=0.1):
-        super().__init__(idim, n_layers, n_chans, kernel_size)
+        super().__init__(idim, n_layers, n_chans, kernel_size, dropout_rate)
         self.linear = nn.Linear(n_chans, odim)
         self._w_lin = _cw(self.linear)
 
-    def run(self, x):
-        x = self.run_stack(x, None)
-        return ops.conv1d(x, self._w_lin, self.linear.bias.data)  # [B, odim, T]
+    def run(self, x, seed=0):
+        x = self.run_stack(x, None, seed)
+        return _backend().conv1d(x, self._w_lin, self.linear.bias)  # [B, odim, T]
 
 
 class LengthRegulator(nn.Module):
@@ -174,9 +190,10 @@ class MelEncoder(nn.Module):
 
     def run(self, x_bct, res=None, mask=None):
         """x [B,80,T] -> fc_out(...) (+ res) (* mask), all fused in the last conv's epilogue."""
-        h = ops.conv1d(x_bct, self._w0, self.encoder[0].bias.data, act="relu")
-        h = ops.conv1d(h, self._w2, self.encoder[2].bias.data, act="relu")
-        return ops.conv1d(h, self._w_out, self.fc_out.bias.data, res=res, mask=mask)
+        F = _backend()
+        h = F.conv1d(x_bct, self._w0, self.encoder[0].bias, act="relu")
+        h = F.conv1d(h, self._w2, self.encoder[2].bias, act="relu")
+        return F.conv1d(h, self._w_out, self.fc_out.bias, res=res, mask=mask)
 
 
 class FastSpeech(nn.Module):
@@ -225,49 +242,56 @@ class FastSpeech(nn.Module):
         hp = self.hparams
         if not (hp["pitch_type"] == "frame" and hp["use_uv"]):
             raise NotImplementedError("pitch_type 'frame' + use_uv only")
+        F = _backend()
         ret = {}
         B, T_txt = txt_tokens.shape
+        seed = int(kwargs.get("dropout_seed", 0))
+        pg = hp["predictor_grad"]
         tmask = time_mel_masks.reshape(B, -1).contiguous()  # [B,T]
         enc = self.encoder.run_tokens(txt_tokens)  # [B,H,T_txt]
-        src_nonpad = ops.index_mask(txt_tokens)
-        style = ops.conv1d(spk_embed.reshape(B, 256, 1).contiguous(), self._w_spk, self.spk_embed_proj.bias.data)
-        style = style.view(B, self.hidden_size)  # fs.py:114-121
+        src_nonpad = F.index_mask(txt_tokens)
+        style = F.conv1d(spk_embed.reshape(B, 256, 1).contiguous(), self._w_spk, self.spk_embed_proj.bias)
+        style = style.reshape(B, self.hidden_size)  # fs.py:114-121
         # ---- duration (fs.py:123-151)
-        dur_inp = ops.add_chan_mask(enc, style, src_nonpad)
-        mdur = ops.masked_dur(mel2ph, tmask, txt_tokens)
+        dur_inp = F.add_chan_mask(enc, style, src_nonpad)
+        mdur = F.masked_dur(mel2ph, tmask, txt_tokens)
         ret["masked_dur"] = mdur
-        ops.embedding_bct(mdur, self.dur_embed.weight.data, out=dur_inp, accumulate=True)
-        ret["dur"] = dur = self.dur_predictor.run(dur_inp, src_nonpad)
+        dur_inp = F.embedding_bct(mdur, self.dur_embed.weight, out=dur_inp, accumulate=True, padding_idx=0)
+        dur_inp = F.grad_scale(dur_inp, pg)  # fs.py:144-145
+        ret["dur"] = dur = self.dur_predictor.run(dur_inp, src_nonpad, seed)
         if use_pred_mel2ph:
-            mel2ph = self.length_regulator(dur, txt_tokens)
+            mel2ph = self.length_regulator(dur.detach(), txt_tokens)
         fm = hp["frames_multiple"]
         if fm != 1:
             mel2ph = mel2ph[:, :mel2ph.shape[1] // fm * fm].contiguous()  # align_ops.py:15-18
         ret["mel2ph"] = mel2ph
-        tgt_nonpad = ops.index_mask(mel2ph)
-        dec = ops.expand_states(enc, mel2ph)  # align_ops.py:21-25
+        tgt_nonpad = F.index_mask(mel2ph)
+        dec = F.expand_states(enc, mel2ph)  # align_ops.py:21-25
         # ---- pitch (fs.py:153-189)
-        pitch_inp = ops.add_chan_mask(dec, style, tgt_nonpad)
-        _, masked_pitch = ops.pitch_coarse(f0, uv, tmask=tmask, mel2ph_pad=mel2ph, want_denorm=False)
+        pitch_inp = F.add_chan_mask(dec, style, tgt_nonpad)
+        _, masked_pitch = F.pitch_coarse(f0, uv, tmask=tmask, mel2ph_pad=mel2ph, want_denorm=False)
         ret["masked_pitch"] = masked_pitch
-        ops.embedding_bct(masked_pitch, self.pitch_embed.weight.data, out=pitch_inp, accumulate=True)
-        pp = self.pitch_predictor.run(pitch_inp)  # [B,2,T]
-        ret["pitch_pred"] = ops.bct_to_btc(pp)
+        pitch_inp = F.embedding_bct(masked_pitch, self.pitch_embed.weight, out=pitch_inp, accumulate=True, padding_idx=0)
+        pitch_inp = F.grad_scale(pitch_inp, pg)  # fs.py:167-169
+        pp = self.pitch_predictor.run(pitch_inp, seed + 1)  # [B,2,T]
+        ret["pitch_pred_bct"] = pp
+        ret["pitch_pred"] = F.bct_to_btc(pp)
         pad_idx = mel2ph
+        ppd = pp.detach()
         if use_pred_pitch:
             pad_idx = None  # fs.py:172
-            pred_f0 = pp[:, 0, :].contiguous()
-            pred_uv = (pp[:, 1, :] > 0).to(torch.float32).contiguous()
-            res_f0 = ops.blend_mask(f0, pred_f0, tmask, 1)
-            res_uv = ops.blend_mask(uv, pred_uv, tmask, 1)
+            pred_f0 = ppd[:, 0, :].contiguous()
+            pred_uv = (ppd[:, 1, :] > 0).to(torch.float32).contiguous()
+            res_f0 = F.blend_mask(f0, pred_f0, tmask, 1)
+            res_uv = F.blend_mask(uv, pred_uv, tmask, 1)
         else:
             res_f0, res_uv = f0, uv
-        f0_denorm, pitch = ops.pitch_coarse(res_f0, res_uv, mel2ph_pad=pad_idx)
+        f0_denorm, pitch = F.pitch_coarse(res_f0, res_uv, mel2ph_pad=pad_idx)
         ret["pitch"] = pitch
         ret["f0_denorm"] = f0_denorm
-        ret["f0_denorm_pred"], _ = ops.pitch_coarse(pp[:, 0, :].contiguous(), pp[:, 1, :].contiguous(),
-                                                    mel2ph_pad=pad_idx, uv_from_logit=True, want_coarse=False)
-        ops.embedding_bct(pitch, self.pitch_embed.weight.data, out=dec, accumulate=True)
-        ret["decoder_inp_bct"] = ops.add_chan_mask(dec, style, tgt_nonpad)
+        ret["f0_denorm_pred"], _ = F.pitch_coarse(ppd[:, 0, :].contiguous(), ppd[:, 1, :].contiguous(),
+                                                  mel2ph_pad=pad_idx, uv_from_logit=True, want_coarse=False)
+        dec = F.embedding_bct(pitch, self.pitch_embed.weight, out=dec, accumulate=True, padding_idx=0)
+        ret["decoder_inp_bct"] = F.add_chan_mask(dec, style, tgt_nonpad)
         ret["tgt_nonpad"] = tgt_nonpad
         return ret

@@ -16,6 +16,16 @@ from ._lib import (ACT, PRO, IMPL_MFMA, IMPL_NAIVE, SetConv1dArgs, SetDiffnetLay
                    SetDiffnetStackArgs, check)
 
 _DEFAULT_IMPL = os.environ.get("SET_AMD_CONV_IMPL", "auto")  # auto | naive | mfma
+_WEIGHTS_EPOCH = 0  # bumped by in-place optimizer updates (they do not touch tensor version counters)
+
+
+def bump_weights_epoch():
+    global _WEIGHTS_EPOCH
+    _WEIGHTS_EPOCH += 1
+
+
+def weights_epoch():
+    return _WEIGHTS_EPOCH
 
 
 def _stream():
@@ -81,9 +91,16 @@ class ConvWeight:
     def raw(self):
         return _f(self._getter(), "weight")
 
+    def transposed(self):
+        """W'[ci][co][tap] = W[co][ci][tap]: the weight operand of the input-gradient convolution."""
+        if getattr(self, "_tr", None) is None:
+            assert self.base == 0 and self.stap == 1
+            self._tr = ConvWeight(self._getter, self.Cin, self.Cout, self.K, base=0, sco=self.sci, sci=self.sco, stap=1)
+        return self._tr
+
     def packed(self):
         w = self.raw()
-        key = (w.data_ptr(), w._version, w.device)
+        key = (w.data_ptr(), w._version, w.device, _WEIGHTS_EPOCH)
         if self._packed is None or self._key != key:
             n = _lib.lib().set_packed_conv_weight_size(self.Cout, self.Cin, self.K)
             wp = torch.empty(n, dtype=torch.float32, device=w.device)
@@ -180,7 +197,7 @@ def layernorm_ch(x, gamma, beta, mask=None, eps=1e-5, out=None):
     return out
 
 
-def embedding_bct(idx, table, scale=1.0, out=None, accumulate=False):
+def embedding_bct(idx, table, scale=1.0, out=None, accumulate=False, padding_idx=None):
     _i(idx), _f(table)
     B, T = idx.shape
     n_rows, Cc = table.shape
@@ -406,6 +423,23 @@ def randn(shape, device, seed=0, offset=0):
     out = torch.empty(shape, dtype=torch.float32, device=device)
     check(_lib.lib().set_randn(_p(out), out.numel(), int(seed), int(offset), _stream()), "set_randn")
     return out
+
+
+def grad_scale(x, s):
+    """Inference backend: identity (fs.py:144-145 only rescales gradients)."""
+    return x
+
+
+def dropout(x, p, seed, offset=0):
+    """Inference backend: identity (eval mode)."""
+    return x
+
+
+def res_skip_fn(x, o, skip_in):
+    """Functional form used by the shared layer code: returns (x_out, skip_out); skip_in None on the first layer."""
+    first = skip_in is None
+    skip = torch.empty_like(x) if first else skip_in
+    return res_skip(x, o, skip, first), skip
 
 
 def selftest_mfma():

@@ -55,3 +55,18 @@ def sum_over_ranks(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def bucketed_all_reduce_sum_(flat, bucket_elems):
+    """In-place SUM all-reduce of a flat buffer in a few large buckets (RCCL ring/direct over xGMI is per-link bound,
+    so few large messages beat many small ones).  Returns the world size (the caller folds 1/world into its next
+    kernel).  No-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 1
+    n = flat.numel()
+    works = []
+    for s in range(0, n, bucket_elems):
+        works.append(dist.all_reduce(flat[s:s + bucket_elems], op=dist.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()
+    return dist.get_world_size()

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import ops
+from . import autograd_ops, ops
 from .diffusion_utils import get_noise_schedule_list
 from .fs import FastSpeech, MelEncoder
 from .hparams import hparams as _global_hparams
@@ -91,45 +91,68 @@ class GaussianDiffusion(nn.Module):
 
     # ---- conditioner --------------------------------------------------------------------------------------
     def conditioner(self, txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv, infer=False,
-                    use_pred_mel2ph=False, use_pred_pitch=False):
+                    use_pred_mel2ph=False, use_pred_pitch=False, dropout_seed=0):
         """spec_denoiser.py:159-167.  Returns (ret, cond [B,H,T])."""
+        F = autograd_ops if torch.is_grad_enabled() else ops
         ret = self.fs(txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv, None, skip_decoder=True, infer=infer,
-                      use_pred_mel2ph=use_pred_mel2ph, use_pred_pitch=use_pred_pitch)
+                      use_pred_mel2ph=use_pred_mel2ph, use_pred_pitch=use_pred_pitch, dropout_seed=dropout_seed)
         B, T, M = ref_mels.shape
         tmask = time_mel_masks.reshape(B, T).contiguous()
         masked = ops.mul_one_minus_mask(ref_mels.contiguous(), tmask, M)  # ref_mels*(1-mask)
         cond = self.mel_encoder.run(ops.btc_to_bct(masked), res=ret.pop("decoder_inp_bct"), mask=ret["tgt_nonpad"])
-        ret["decoder_inp"] = ops.bct_to_btc(cond)  # [B,T,H] as in the reference ret dict
+        ret["decoder_inp"] = F.bct_to_btc(cond)  # [B,T,H] as in the reference ret dict
         return ret, cond
 
     # ---- reference forward --------------------------------------------------------------------------------
-    @torch.no_grad()
     def forward(self, txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv, energy=None, infer=False,
                 use_pred_mel2ph=False, use_pred_pitch=False, *, noises=None, t=None, seed=None,
                 want_layer_spans=False, n_groups=None, persistent=None):
         """Keyword-only extras (not in the reference): `noises` = explicit [steps+1,B,1,M,T] noise stack
         (x_T then one eps per executed step) for parity runs; `t` = explicit training step ids; `seed` for
-        the on-device Philox stream; `want_layer_spans` returns per-step layer-span timings in ret."""
-        ret, cond = self.conditioner(txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv, infer,
-                                     use_pred_mel2ph, use_pred_pitch)
+        the on-device Philox stream; `want_layer_spans` returns per-step layer-span timings in ret.
+        infer=True always runs without a tape (the reference's p_sample is @torch.no_grad()); infer=False builds
+        an autograd tape over the differentiable kernels when gradients are enabled."""
+        if infer:
+            with torch.no_grad():
+                return self._forward_infer(txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv,
+                                           use_pred_mel2ph, use_pred_pitch, noises, seed, want_layer_spans, n_groups,
+                                           persistent)
+        return self._forward_train(txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv, noises, t, seed)
+
+    def _forward_train(self, txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv, noises, t, seed):
+        """spec_denoiser.py:168-176: t ~ U{0..steps}, x_t = q_sample(ref) * nonpad, x0 = denoise_fn(x_t, t, cond) * nonpad."""
+        F = autograd_ops if torch.is_grad_enabled() else ops
+        seed = int(seed) if seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        ret, cond = self.conditioner(txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv, False,
+                                     dropout_seed=seed)
         tgt_nonpad = ret.pop("tgt_nonpad")
         B, H, T = cond.shape
         M = self.mel_bins
         dev = cond.device
+        if t is None:
+            t = torch.randint(0, self.num_timesteps + 1, (B,), device=dev).long()
+        x_start = ops.btc_to_bct(ref_mels.contiguous())  # [B,M,T]
+        eps = noises if noises is not None else ops.randn((B, M, T), dev, seed, 1 << 40)
+        ab = torch.stack([self.sqrt_alphas_cumprod[t], self.sqrt_one_minus_alphas_cumprod[t]], -1).contiguous()
+        x_t = ops.q_sample(x_start, eps.reshape(B, M, T).contiguous(), ab, nonpad=tgt_nonpad)
+        x0 = self.denoise_fn(x_t[:, None], t, cond)[:, 0]
+        x0 = F.add_chan_mask(x0.contiguous(), None, tgt_nonpad)
+        ret["mel_out_bct"] = x0
+        ret["mel_out"] = F.bct_to_btc(x0)
+        ret["x_t"] = x_t
+        ret["t"] = t
+        return ret
+
+    def _forward_infer(self, txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv, use_pred_mel2ph,
+                       use_pred_pitch, noises, seed, want_layer_spans, n_groups, persistent):
+        ret, cond = self.conditioner(txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv, True,
+                                     use_pred_mel2ph, use_pred_pitch)
+        ret.pop("tgt_nonpad")
+        ret.pop("pitch_pred_bct", None)
+        B, H, T = cond.shape
+        M = self.mel_bins
+        dev = cond.device
         dn = self.denoise_fn
-        if not infer:
-            # training branch forward (spec_denoiser.py:168-176)
-            if t is None:
-                t = torch.randint(0, self.num_timesteps + 1, (B,), device=dev).long()
-            x_start = ops.btc_to_bct(ref_mels.contiguous())  # [B,M,T]
-            eps = noises if noises is not None else ops.randn((B, M, T), dev, seed or 0)
-            ab = torch.stack([self.sqrt_alphas_cumprod[t], self.sqrt_one_minus_alphas_cumprod[t]], -1).contiguous()
-            x_t = ops.q_sample(x_start, eps.reshape(B, M, T).contiguous(), ab, nonpad=tgt_nonpad)
-            x0 = dn(x_t[:, None], t, cond)[:, 0].contiguous()
-            x0 = ops.add_chan_mask(x0, None, tgt_nonpad)
-            ret["mel_out"] = ops.bct_to_btc(x0)
-            ret["x_t"] = x_t
-            return ret
         steps = self.num_timesteps
         seed = int(seed) if seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         if noises is not None:
@@ -146,10 +169,10 @@ class GaussianDiffusion(nn.Module):
         if dn.use_fused():
             spans = ops.diffusion_loop(
                 x=x, noise=eps, seed=seed, condproj=condproj, dstep=dtab, coef4=coef4,
-                w_in=dn._w_in, b_in=dn.input_projection.bias.data,
+                w_in=dn._w_in, b_in=dn.input_projection.bias,
                 packs=dn.fused_packs(),
-                w_skip=dn._w_skip, b_skip=dn.skip_projection.bias.data,
-                w_outp=dn._w_outp, b_outp=dn.output_projection.bias.data,
+                w_skip=dn._w_skip, b_skip=dn.skip_projection.bias,
+                w_outp=dn._w_outp, b_outp=dn.output_projection.bias,
                 L=dn.n_layers, steps=steps, dilation_cycle_length=dn.dilation_cycle_length,
                 want_layer_spans=want_layer_spans, n_groups=n_groups, persistent=persistent)
             if spans is not None:

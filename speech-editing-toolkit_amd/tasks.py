@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from . import ops
+from . import autograd_ops, ops
 from .diffnet import DiffNet
 from .hparams import hparams, set_hparams
 from .spec_denoiser import GaussianDiffusion
@@ -54,11 +54,63 @@ class SpeechDenoiserTask:
         self.build_tts_model()
         return self.model
 
-    @torch.no_grad()
+    # ---- losses (tasks/tts/speech_base.py:219-257, tasks/speech_editing/speech_editing_base.py:58-108) ----------
+    def word_ids(self, txt_tokens):
+        """word_id = cumsum(is_sil) * (1 - is_sil); silence = tokens listed in hparams['sil_token_ids']
+        (the reference derives them from phone_set.json: phonemes whose first character is not a letter)."""
+        sil = torch.zeros_like(txt_tokens, dtype=torch.bool)
+        for i in hparams.get("sil_token_ids", [1, 2, 3]):
+            sil |= txt_tokens == int(i)
+        sil = sil.long()
+        word_id = (sil.cumsum(-1) * (1 - sil)).contiguous()
+        return word_id, int(word_id.max().item())
+
+    def compute_losses(self, output, sample):
+        """The loss dict of run_model(infer=False): l1_coarse, ssim_coarse, pdur, wdur, uv, f0 (all on the tape)."""
+        A = autograd_ops
+        target = sample["mels"].contiguous()
+        B, T, M = target.shape
+        tm = sample["time_mel_masks"].reshape(B, T).contiguous()
+        pred = A.bct_to_btc(A.add_chan_mask(output["mel_out_bct"], None, tm))          # mel_out * mask
+        target_m = ops.blend_mask(torch.zeros_like(target), target, tm, M)             # target * mask
+        w = A.frame_weights(target_m)
+        losses = {}
+        for item in str(hparams["mel_losses"]).split("|"):
+            name, lam = (item.split(":") + ["1.0"])[:2]
+            if name == "l1":
+                losses["l1_coarse"] = A.masked_l1(pred, target_m, w) * float(lam)
+            elif name == "ssim":
+                losses["ssim_coarse"] = A.ssim_loss(pred, target_m, w) * float(lam)
+            else:
+                raise NotImplementedError("mel loss %r" % name)
+        word_id, n_words = self.word_ids(sample["txt_tokens"])
+        losses["pdur"], losses["wdur"] = A.dur_losses(output["dur"], sample["mel2ph"], sample["txt_tokens"], word_id,
+                                                       n_words, hparams["lambda_ph_dur"], hparams["lambda_word_dur"])
+        if hparams["use_pitch_embed"]:
+            losses["uv"], losses["f0"] = A.pitch_losses(output["pitch_pred_bct"], sample["f0"], sample["uv"],
+                                                        sample["mel2ph"], hparams["lambda_uv"], hparams["lambda_f0"])
+        return losses
+
     def run_model(self, sample, infer=False, **kwargs):
-        """tasks/speech_editing/spec_denoiser.py:39-62 (inference branch)."""
+        """tasks/speech_editing/spec_denoiser.py:39-62.  infer=False returns (losses, output) on an autograd tape
+        whose every node is a kernel of libset_amd.so; infer=True returns the pasted output."""
         if not infer:
-            raise NotImplementedError("training losses / backward are outside the round-1 hot path (SURVEY.md 8f)")
+            target = sample["mels"]
+            tmask = sample["time_mel_masks"][:, :, None]
+            spk = sample.get("spk_embed") if not hparams["use_spk_id"] else sample.get("spk_ids")
+            with torch.enable_grad():
+                output = self.model(sample["txt_tokens"], tmask, mel2ph=sample["mel2ph"], spk_embed=spk,
+                                    ref_mels=target, f0=sample["f0"], uv=sample["uv"], energy=None, infer=False, **kwargs)
+                losses = self.compute_losses(output, sample)
+            with torch.no_grad():
+                B, T, M = target.shape
+                output["mel_out"] = ops.blend_mask(target.contiguous(), output["mel_out"].detach().contiguous(),
+                                                   tmask.reshape(B, T).contiguous(), M)
+            return losses, output
+        return self._run_model_infer(sample, **kwargs)
+
+    @torch.no_grad()
+    def _run_model_infer(self, sample, **kwargs):
         target = sample["mels"]
         tmask = sample["time_mel_masks"][:, :, None]
         spk = sample.get("spk_embed") if not hparams["use_spk_id"] else sample.get("spk_ids")
@@ -69,10 +121,20 @@ class SpeechDenoiserTask:
         output["mel_out"] = ops.blend_mask(target.contiguous(), output["mel_out"], tmask.reshape(B, T).contiguous(), M)
         return output
 
+    def training_step(self, sample, optimizer, **kwargs):
+        """One optimisation step: forward + losses, backward, gradient all-reduce (if distributed), clip + AdamW."""
+        optimizer.zero_grad()
+        losses, _ = self.run_model(sample, infer=False, **kwargs)
+        total = sum(losses.values())
+        total.backward()
+        lr, _ = optimizer.step()
+        return total.detach(), {k: v.detach() for k, v in losses.items()}, lr
+
     @classmethod
     def start(cls):
         if not hparams.get("infer"):
-            raise NotImplementedError("SpeechDenoiserTask.start(): training is outside the round-1 hot path")
+            raise NotImplementedError("SpeechDenoiserTask.start(): the dataset-driven trainer loop is not part of this "
+                                      "path; use training_step() with batches (tools/train_bench.py)")
         raise NotImplementedError("dataset-driven --infer needs the IndexedDataset reader (SURVEY.md 8f rank 3)")
 
 

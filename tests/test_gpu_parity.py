@@ -444,8 +444,6 @@ def test_task_run_model_paste(dev):
     tm = inp["time_mel_masks"].cpu()
     ref = torch.from_numpy(g["mel_out"]) * tm + inp["ref_mels"].cpu() * (1 - tm)
     assert _maxdiff(out["mel_out"], ref) < 1e-4
-    with pytest.raises(NotImplementedError):
-        task.run_model(sample, infer=False)
 
 
 # ----------------------------------------------------------------------------------------------------

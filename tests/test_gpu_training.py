@@ -1,0 +1,332 @@
+"""GPU tests of the training rows: every differentiable op against torch CPU autograd of the
+same op, the whole loss + gradient computation against the oracle / the reference-generated golden, the fused
+clip+AdamW step against torch.optim.AdamW.  fp32 tolerances are written at each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import base_hparams, load_golden
+from oracle import oracle as O
+from oracle import weights as Wt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(built_lib):
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+CONV_BWD = [
+    # B, Cin, Cout, K, dil, T, extras
+    (2, 48, 96, 3, 2, 70, dict(chan_add=True, res=True)),
+    (2, 256, 512, 3, 1, 64, dict(chan_add=True, res=True)),
+    (2, 512, 256, 1, 1, 33, dict()),
+    (1, 256, 256, 1, 1, 40, dict(pro="div", pro_param=math.sqrt(20.0), act="relu")),
+    (2, 192, 384, 5, 1, 50, dict(alpha=5 ** -0.5, act="gelu")),
+    (2, 384, 192, 1, 1, 50, dict(res=True, mask=True)),
+    (3, 192, 2, 1, 1, 90, dict()),
+    (2, 192, 1, 1, 1, 20, dict(act="softplus", mask=True)),
+    (2, 256, 192, 1, 1, 1, dict()),
+    (1, 256, 1024, 1, 1, 5, dict(act="mish")),
+    (2, 80, 256, 1, 1, 100, dict(act="relu")),
+]
+
+
+@pytest.mark.parametrize("case", CONV_BWD)
+def test_conv1d_backward(dev, case):
+    from set_amd import autograd_ops as A, ops
+    B, Cin, Cout, K, dil, T, ex = case
+    g = torch.Generator().manual_seed(Cin + Cout + K + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / math.sqrt(Cin * K)
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(B, Cout, T, generator=g) if ex.get("res") else None
+    mask = (torch.rand(B, T, generator=g) > 0.3).float() if ex.get("mask") else None
+    add = torch.randn(B, Cin, generator=g) if ex.get("chan_add") else None
+    gy = torch.randn(B, Cout, T, generator=g)
+    pad = dil * (K - 1) // 2
+
+    def ref(xr, wr, br, addr, resr):
+        xin = xr if addr is None else xr + addr[:, :, None]
+        if ex.get("pro") == "div":
+            xin = xin / ex["pro_param"]
+        y = F.conv1d(F.pad(xin, (pad, pad)), wr, br, dilation=dil) * ex.get("alpha", 1.0)
+        y = {"none": lambda v: v, "relu": F.relu, "gelu": F.gelu, "softplus": F.softplus, "mish": O.mish}[ex.get("act", "none")](y)
+        if resr is not None:
+            y = y + resr
+        if mask is not None:
+            y = y * mask[:, None, :]
+        return y
+
+    leaves = [t.clone().requires_grad_(True) if t is not None else None for t in (x, w, b, add, res)]
+    with torch.enable_grad():
+        ref(*leaves).backward(gy)
+    d = [t.clone().to(dev).requires_grad_(True) if t is not None else None for t in (x, w, b, add, res)]
+    cw = ops.ConvWeight(lambda: d[1], Cout, Cin, K)
+    kw = {k: ex[k] for k in ("pro", "pro_param", "act", "alpha") if k in ex}
+    with torch.enable_grad():
+        y = A.conv1d(d[0], cw, d[2], dil=dil, pad=pad, in_chan_add=d[3], res=d[4],
+                     mask=None if mask is None else mask.to(dev), **kw)
+        y.backward(gy.to(dev))
+    torch.cuda.synchronize()
+    for name, a, r in zip(("dx", "dw", "db", "dadd", "dres"), d, leaves):
+        if r is not None:
+            assert _rel(a.grad, r.grad) < 2e-5, name
+
+
+def test_small_op_backwards(dev):
+    from set_amd import autograd_ops as A
+    g = torch.Generator().manual_seed(9)
+    B, C, T, Tt = 3, 192, 70, 21
+    # LayerNorm over channels (+ mask)
+    x = torch.randn(B, C, T, generator=g)
+    gam, bet = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    mask = (torch.rand(B, T, generator=g) > 0.2).float()
+    gy = torch.randn(B, C, T, generator=g)
+    lv = [t.clone().requires_grad_(True) for t in (x, gam, bet)]
+    with torch.enable_grad():
+        (O.layer_norm_ch(lv[0], lv[1], lv[2]) * mask[:, None]).backward(gy)
+    dv = [t.clone().to(dev).requires_grad_(True) for t in (x, gam, bet)]
+    with torch.enable_grad():
+        A.layernorm_ch(dv[0], dv[1], dv[2], mask.to(dev)).backward(gy.to(dev))
+    for a, r in zip(dv, lv):
+        assert _rel(a.grad, r.grad) < 2e-5
+    # embedding (+ base), expand_states, add_chan_mask, transposes
+    idx = torch.randint(0, 50, (B, T), generator=g)
+    tab = torch.randn(50, C, generator=g)
+    lt, lb = tab.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    with torch.enable_grad():
+        (lb + 2.0 * F.embedding(idx, lt).transpose(1, 2)).backward(gy)
+    dt, db_ = tab.clone().to(dev).requires_grad_(True), x.clone().to(dev).requires_grad_(True)
+    with torch.enable_grad():
+        A.embedding_bct(idx.to(dev), dt, scale=2.0, out=db_, accumulate=True).backward(gy.to(dev))
+    assert _rel(dt.grad, lt.grad) < 1e-5 and _rel(db_.grad, lb.grad) == 0.0
+    lt2, dt2 = tab.clone().requires_grad_(True), tab.clone().to(dev).requires_grad_(True)
+    with torch.enable_grad():
+        F.embedding(idx, lt2, padding_idx=0).transpose(1, 2).backward(gy)
+        A.embedding_bct(idx.to(dev), dt2, padding_idx=0).backward(gy.to(dev))
+    assert float(dt2.grad[0].abs().max()) == 0.0 and _rel(dt2.grad, lt2.grad) < 1e-5
+    enc = torch.randn(B, C, Tt, generator=g)
+    m2p = torch.sort(torch.randint(0, Tt + 1, (B, T), generator=g), dim=1).values
+    le = enc.clone().requires_grad_(True)
+    with torch.enable_grad():
+        O.expand_states(le.transpose(1, 2), m2p).transpose(1, 2).backward(gy)
+    de = enc.clone().to(dev).requires_grad_(True)
+    with torch.enable_grad():
+        A.expand_states(de, m2p.to(dev)).backward(gy.to(dev))
+    assert _rel(de.grad, le.grad) < 1e-5
+    add = torch.randn(B, C, generator=g)
+    lx, la = x.clone().requires_grad_(True), add.clone().requires_grad_(True)
+    with torch.enable_grad():
+        ((lx + la[:, :, None]) * mask[:, None]).backward(gy)
+    dx, da = x.clone().to(dev).requires_grad_(True), add.clone().to(dev).requires_grad_(True)
+    with torch.enable_grad():
+        A.add_chan_mask(dx, da, mask.to(dev)).backward(gy.to(dev))
+    assert _rel(dx.grad, lx.grad) == 0.0 and _rel(da.grad, la.grad) < 1e-5
+    # activations
+    z = torch.randn(4000, generator=g) * 3
+    for act, fn in (("gelu", F.gelu), ("mish", O.mish), ("softplus", F.softplus), ("tanh", torch.tanh)):
+        lz = z.clone().requires_grad_(True)
+        with torch.enable_grad():
+            fn(lz).backward(torch.ones_like(z))
+        dz = z.clone().to(dev).requires_grad_(True)
+        with torch.enable_grad():
+            yy = A.activation(dz, act)
+            yy.backward(torch.ones_like(dz))
+        assert _rel(yy, fn(z)) < 1e-5 and _rel(dz.grad, lz.grad) < 1e-5, act
+    # gate + res_skip (functional)
+    y2 = torch.randn(B, 2 * C, T, generator=g)
+    ly = y2.clone().requires_grad_(True)
+    with torch.enable_grad():
+        a_, b_ = torch.chunk(ly, 2, dim=1)
+        (torch.sigmoid(a_) * torch.tanh(b_)).backward(gy)
+    dy = y2.clone().to(dev).requires_grad_(True)
+    with torch.enable_grad():
+        A.gate(dy).backward(gy.to(dev))
+    assert _rel(dy.grad, ly.grad) < 1e-5
+    o = torch.randn(B, 2 * C, T, generator=g)
+    sk = torch.randn(B, C, T, generator=g)
+    g2 = torch.randn(B, C, T, generator=g)
+    ls = [t.clone().requires_grad_(True) for t in (x, o, sk)]
+    with torch.enable_grad():
+        r_, s_ = torch.chunk(ls[1], 2, dim=1)
+        (((ls[0] + r_) / math.sqrt(2.0)) * gy + (ls[2] + s_) * g2).sum().backward()
+    ds = [t.clone().to(dev).requires_grad_(True) for t in (x, o, sk)]
+    with torch.enable_grad():
+        xo, so = A.res_skip_fn(ds[0], ds[1], ds[2])
+        (xo * gy.to(dev) + so * g2.to(dev)).sum().backward()
+    for a, r in zip(ds, ls):
+        assert _rel(a.grad, r.grad) < 1e-6
+    # dropout: same mask forward/backward, keep-rate, scaling
+    xd = torch.ones(1 << 18, device=dev, requires_grad=True)
+    with torch.enable_grad():
+        yd = A.dropout(xd, 0.2, seed=3, offset=7)
+        yd.sum().backward()
+    assert torch.equal(yd.detach(), xd.grad) and abs(float((yd > 0).float().mean()) - 0.8) < 5e-3
+    assert abs(float(yd.max()) - 1.25) < 1e-6
+    # grad_scale
+    xs = torch.randn(100, device=dev, requires_grad=True)
+    with torch.enable_grad():
+        A.grad_scale(xs, 0.1).sum().backward()
+    assert _rel(xs.grad, torch.full((100,), 0.1)) < 1e-7
+
+
+def test_losses_forward_backward(dev):
+    from set_amd import autograd_ops as A, ops
+    g = torch.Generator().manual_seed(21)
+    B, T, M, Tt = 3, 60, 80, 14
+    pred = torch.randn(B, T, M, generator=g) * 0.5 - 3.0
+    target = torch.clamp(torch.randn(B, T, M, generator=g) * 1.5 - 3.0, -6, 1.5)
+    target[1, 50:] = 0
+    target[2, 30:] = 0
+    lp = pred.clone().requires_grad_(True)
+    with torch.enable_grad():
+        l1, ss = O.l1_loss(lp, target), O.ssim_loss(lp, target)
+        (l1 * 0.5 + ss * 0.5).backward()
+    dp = pred.clone().to(dev).requires_grad_(True)
+    w = A.frame_weights(target.to(dev))
+    with torch.enable_grad():
+        l1d, ssd = A.masked_l1(dp, target.to(dev), w), A.ssim_loss(dp, target.to(dev), w)
+        (l1d * 0.5 + ssd * 0.5).backward()
+    assert abs(float(l1d) - float(l1)) < 1e-5 and abs(float(ssd) - float(ss)) < 2e-5
+    assert _rel(dp.grad, lp.grad) < 5e-4  # ssim: differences of nearly equal second moments
+    # duration + pitch losses
+    inp = Wt.synthetic_inputs(B, T, Tt, seed=5, pad_tail=True)
+    dur = torch.rand(B, Tt, generator=g) * 5
+    dur[:, -2:] = 0
+    pp = torch.randn(B, T, 2, generator=g)
+    ld, lpp = dur.clone().requires_grad_(True), pp.clone().requires_grad_(True)
+    with torch.enable_grad():
+        pd, wd = O.dur_losses(ld, inp["mel2ph"], inp["txt_tokens"], (1, 2, 3), 0.1, 1.0)
+        uvl, f0l = O.pitch_losses(lpp, inp["f0"], inp["uv"], inp["mel2ph"], 1.0, 1.0)
+        (pd + wd + uvl + f0l).backward()
+    sil = torch.zeros_like(inp["txt_tokens"], dtype=torch.bool)
+    for i in (1, 2, 3):
+        sil |= inp["txt_tokens"] == i
+    sil = sil.long()
+    word_id = (sil.cumsum(-1) * (1 - sil)).contiguous()
+    dd = dur.clone().to(dev).requires_grad_(True)
+    dpp = pp.transpose(1, 2).contiguous().to(dev).requires_grad_(True)
+    with torch.enable_grad():
+        pd2, wd2 = A.dur_losses(dd, inp["mel2ph"].to(dev), inp["txt_tokens"].to(dev), word_id.to(dev),
+                                int(word_id.max()), 0.1, 1.0)
+        uv2, f02 = A.pitch_losses(dpp, inp["f0"].to(dev), inp["uv"].to(dev), inp["mel2ph"].to(dev), 1.0, 1.0)
+        (pd2 + wd2 + uv2 + f02).backward()
+    for a, r in ((pd2, pd), (wd2, wd), (uv2, uvl), (f02, f0l)):
+        assert abs(float(a) - float(r)) < 1e-5 * max(1.0, abs(float(r)))
+    assert _rel(dd.grad, ld.grad) < 1e-5
+    assert _rel(dpp.grad.transpose(1, 2), lpp.grad) < 1e-5
+
+
+def _train_setup(dev, steps, wseed, over=None):
+    from set_amd import hparams as H
+    from set_amd import tasks
+    H.hparams.clear()
+    H.hparams.update(base_hparams(timesteps=steps, **(over or {})))
+    task = tasks.SpeechDenoiserTask(build_vocoder=False)
+    task.build_model()
+    W = Wt.seeded_weights(Wt.load_manifest("spec_denoiser"), wseed)
+    task.model.load_state_dict(W, strict=False)
+    task.model.to(dev).eval()  # eval: predictor dropout off, as in the fixtures
+    return task, W
+
+
+def test_training_losses_and_all_gradients_match_reference(dev):
+    """tests/golden/train_losses.npz: the reference's own model + loss functions + autograd (oracle/make_golden.py)."""
+    g = load_golden("train_losses")
+    m = g["meta"]
+    task, W = _train_setup(dev, m["steps"], m["wseed"])
+    inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=True)
+    sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"],
+                  time_mel_masks=inp["time_mel_masks"].squeeze(-1), spk_embed=inp["spk_embed"])
+    sample = {k: v.to(dev) for k, v in sample.items()}
+    losses, out = task.run_model(sample, infer=False, t=torch.from_numpy(g["t"]).to(dev),
+                                 noises=torch.from_numpy(g["eps"]).to(dev))
+    for k in ("l1_coarse", "ssim_coarse", "pdur", "wdur", "uv", "f0"):
+        ref = float(g["loss_" + k])
+        assert abs(float(losses[k]) - ref) < 2e-5 * max(1.0, abs(ref)), (k, float(losses[k]), ref)
+    total = sum(losses.values())
+    assert abs(float(total) - float(g["total"])) < 1e-4
+    total.backward()
+    torch.cuda.synchronize()
+    params = dict(task.model.named_parameters())
+    norms = dict(zip(m["param_names"], g["grad_norms"]))
+    worst = 0.0
+    for k, p in params.items():
+        ref = norms[k]
+        if ref < 0:  # the reference leaves .grad None (fs.decoder, fs.mel_out never run)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        got = float(p.grad.norm())
+        worst = max(worst, abs(got - ref) / (ref + 1e-12))
+    assert worst < 1e-3, worst
+    for key in [k for k in g if k.startswith("grad::")]:
+        name = key[len("grad::"):]
+        gr = params[name].grad.cpu()
+        ref = torch.from_numpy(g[key])
+        gr = gr[:ref.shape[0]] if gr.shape != ref.shape else gr
+        assert _rel(gr, ref) < 2e-4, name
+
+
+def test_adamw_step_matches_torch(dev):
+    from set_amd import autograd_ops as A
+    g = torch.Generator().manual_seed(4)
+    n = 10000
+    p0 = torch.randn(n, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_p], lr=2e-4, betas=(0.9, 0.98), weight_decay=0.01)
+    dp = p0.clone().to(dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g) * (3.0 if step % 2 else 0.001)
+        ref_p.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        dg = gr.to(dev)
+        A.adamw_step(dp, dg, m, v, 2e-4, 0.9, 0.98, 1e-8, 0.01, step, A.grad_sumsq(dg), 1.0)
+        assert _rel(dp, ref_p) < 1e-6, step
+    # grad_scale = 1/world reproduces the step on the mean gradient
+    dp2, m2, v2 = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    dp3, m3, v3 = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    gs = (torch.randn(n, generator=g) * 4).to(dev)
+    A.adamw_step(dp2, gs, m2, v2, 2e-4, 0.9, 0.98, 1e-8, 0.0, 1, A.grad_sumsq(gs), 1.0, 0.25)
+    gm = (gs * 0.25).contiguous()
+    A.adamw_step(dp3, gm, m3, v3, 2e-4, 0.9, 0.98, 1e-8, 0.0, 1, A.grad_sumsq(gm), 1.0, 1.0)
+    assert _rel(dp2, dp3) < 1e-6
+
+
+def test_training_step_decreases_loss_and_repacks_weights(dev):
+    from set_amd.training import FlatAdamW
+    task, W = _train_setup(dev, 8, 31)
+    task.model.train()  # dropout on (Philox), as in real training
+    opt = FlatAdamW(task.model, lr=1e-3, warmup_updates=1, clip_grad_norm=1.0)
+    inp = Wt.synthetic_inputs(4, 96, 24, seed=77, pad_tail=True)
+    sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"],
+                  time_mel_masks=inp["time_mel_masks"].squeeze(-1), spk_embed=inp["spk_embed"])
+    sample = {k: v.to(dev) for k, v in sample.items()}
+    t = torch.tensor([1, 3, 5, 7], device=dev)
+    eps = torch.randn(4, 80, 96, generator=torch.Generator().manual_seed(1)).to(dev)
+    hist = []
+    for it in range(6):
+        total, parts, lr = task.training_step(sample, opt, t=t, noises=eps, seed=123)
+        hist.append(float(total))
+    assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
+    # parameters are views of the flat buffer and inference after the update sees the new weights (re-packed)
+    p = next(task.model.parameters())
+    assert p.data_ptr() >= opt.flat_p.data_ptr()
+    with torch.no_grad():
+        task.model.eval()
+        out = task.model(sample["txt_tokens"], sample["time_mel_masks"][:, :, None], sample["mel2ph"], sample["spk_embed"],
+                         sample["mels"], sample["f0"], sample["uv"], infer=True, seed=1)
+    assert torch.isfinite(out["mel_out"]).all()
