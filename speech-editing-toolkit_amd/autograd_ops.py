@@ -327,6 +327,30 @@ def dropout(x, p, seed, offset=0):
     return _DropoutFn.apply(x, p, seed, offset) if p > 0 else x
 
 
+class _FanoutFn(torch.autograd.Function):
+    """n uses of one tensor: forward returns n aliases, backward sums the n gradients with set_sum_scale (so the
+    fan-in accumulation is our kernel, not the autograd engine's elementwise add)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g.contiguous() for g in grads if g is not None]
+        acc = gs[0]
+        k = 1
+        while k < len(gs):
+            acc = ops.sum_div(acc, gs[k], gs[k + 1] if k + 1 < len(gs) else None, 1.0)
+            k += 2
+        return acc, None
+
+
+def fanout(x, n):
+    return _FanoutFn.apply(x, n) if n > 1 else (x,)
+
+
 class _GradScaleFn(torch.autograd.Function):
     """x.detach() + s * (x - x.detach())  (fs.py:144-145,167-169): identity forward, gradient scaled by s."""
 

@@ -243,15 +243,28 @@ __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, c
 }
 
 // ---- embedding / alignment gather backward (scatter-add) ------------------------------------------------------
+// one thread per (b, c) walks t and flushes one atomic per RUN of equal indices: masked regions / sorted alignments
+// map long stretches of frames to one row (e.g. every masked frame -> pitch bin 1), which serialises per-frame atomics
 __global__ void __launch_bounds__(256) embedding_bwd_kernel(const int64_t *idx, const float *dout, float *dtable, int B,
                                                             int T, int C, int n_rows, float scale, int padding_idx) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)B * C * T) return;
-    const int t = (int)(i % T), c = (int)((i / T) % C), b = (int)(i / ((int64_t)T * C));
-    int64_t row = idx[(int64_t)b * T + t];
-    row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
-    if (row == padding_idx) return;  // nn.Embedding(padding_idx=...) never updates that row (layers.py:45-50)
-    atomicAdd(&dtable[row * C + c], scale * dout[i]);
+    if (i >= (int64_t)B * C) return;
+    const int c = (int)(i % C), b = (int)(i / C);
+    const int64_t *ib = idx + (int64_t)b * T;
+    const float *dp = dout + ((int64_t)b * C + c) * T;
+    int64_t cur = -1;
+    float acc = 0.0f;
+    for (int t = 0; t < T; ++t) {
+        int64_t row = ib[t];
+        row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
+        if (row != cur) {
+            if (cur >= 0 && cur != padding_idx) atomicAdd(&dtable[cur * C + c], acc);
+            cur = row;
+            acc = 0.0f;
+        }
+        acc = fmaf(scale, dp[t], acc);
+    }
+    if (cur >= 0 && cur != padding_idx) atomicAdd(&dtable[cur * C + c], acc);  // nn.Embedding(padding_idx) row stays 0
 }
 __global__ void __launch_bounds__(256) expand_states_bwd_kernel(const int64_t *mel2ph, const float *dout, float *denc,
                                                                 int B, int C, int T_txt, int T) {
@@ -610,7 +623,7 @@ extern "C" int set_layernorm_ch_bwd(const float *x, const float *gamma, const fl
 extern "C" int set_embedding_bwd(const int64_t *idx, const float *dout, float *dtable, int32_t B, int32_t T, int32_t C,
                                  int32_t n_rows, float scale, int32_t padding_idx, void *stream) {
     SET_REQUIRE(idx && dout && dtable && B > 0 && T > 0 && C > 0 && n_rows > 0, "set_embedding_bwd");
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(set_blocks((int64_t)B * C, 256)), dim3(256), 0, (hipStream_t)stream,
                        idx, dout, dtable, B, T, C, n_rows, scale, padding_idx);
     return set_check_launch("set_embedding_bwd");
 }

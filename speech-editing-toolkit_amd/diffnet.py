@@ -174,7 +174,11 @@ class DiffNet(nn.Module):
         hx = A.conv1d(x, self._w_in, self.input_projection.bias, act="relu")
         cond = cond.contiguous()
         skip = None
-        for layer in self.residual_layers:
+        hs_ = A.fanout(h, L)         # every layer's diffusion_projection reads the step embedding
+        conds = A.fanout(cond, L)    # ... and its conditioner_projection reads cond
+        for li, layer in enumerate(self.residual_layers):
+            h, cond = hs_[li], conds[li]
+            hx, hx_res = A.fanout(hx, 2)  # dilated conv input + residual path
             d = A.conv1d(h, layer._w_dproj, layer.diffusion_projection.bias)  # [1, C, n]
             d_bc = d[0].t().contiguous()  # [n, C]: per-utterance channel offsets (layout change only)
             cp = A.conv1d(cond, layer._w_cond, layer.conditioner_projection.bias)
@@ -182,7 +186,7 @@ class DiffNet(nn.Module):
                          in_chan_add=d_bc, res=cp)
             z = A.gate(y)
             o = A.conv1d(z, layer._w_out, layer.output_projection.bias)
-            hx, skip = A.res_skip_fn(hx, o, skip)
+            hx, skip = A.res_skip_fn(hx_res, o, skip)
         hs = A.conv1d(skip, self._w_skip, self.skip_projection.bias, pro="div", pro_param=math.sqrt(L), act="relu")
         return A.conv1d(hs, self._w_outp, self.output_projection.bias)[:, None, :, :]
 

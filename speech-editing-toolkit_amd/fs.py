@@ -61,9 +61,10 @@ class ResidualBlock(nn.Module):
         k, d = self.kernel_size, self.dilation
         nonpad = F.abs_sum_mask(x.detach())  # conv.py:58
         for b, (w1, w2) in zip(self.blocks, self._cw):
-            h = F.layernorm_ch(x, b[0].weight, b[0].bias, eps=self.ln_eps)
+            x_ln, x_res = F.fanout(x, 2)
+            h = F.layernorm_ch(x_ln, b[0].weight, b[0].bias, eps=self.ln_eps)
             h = F.conv1d(h, w1, b[1].bias, dil=d, pad=(d * (k - 1)) // 2, alpha=k ** -0.5, act="gelu")
-            x = F.conv1d(h, w2, b[4].bias, res=x, mask=nonpad)  # (x + x_) * nonpadding
+            x = F.conv1d(h, w2, b[4].bias, res=x_res, mask=nonpad)  # (x + x_) * nonpadding
         return x
 
 
@@ -252,8 +253,10 @@ class FastSpeech(nn.Module):
         src_nonpad = F.index_mask(txt_tokens)
         style = F.conv1d(spk_embed.reshape(B, 256, 1).contiguous(), self._w_spk, self.spk_embed_proj.bias)
         style = style.reshape(B, self.hidden_size)  # fs.py:114-121
+        enc_d, enc = F.fanout(enc, 2)               # duration branch + alignment gather
+        style_d, style_p, style = F.fanout(style, 3)  # duration / pitch / decoder_inp
         # ---- duration (fs.py:123-151)
-        dur_inp = F.add_chan_mask(enc, style, src_nonpad)
+        dur_inp = F.add_chan_mask(enc_d, style_d, src_nonpad)
         mdur = F.masked_dur(mel2ph, tmask, txt_tokens)
         ret["masked_dur"] = mdur
         dur_inp = F.embedding_bct(mdur, self.dur_embed.weight, out=dur_inp, accumulate=True, padding_idx=0)
@@ -267,8 +270,9 @@ class FastSpeech(nn.Module):
         ret["mel2ph"] = mel2ph
         tgt_nonpad = F.index_mask(mel2ph)
         dec = F.expand_states(enc, mel2ph)  # align_ops.py:21-25
+        dec_p, dec = F.fanout(dec, 2)
         # ---- pitch (fs.py:153-189)
-        pitch_inp = F.add_chan_mask(dec, style, tgt_nonpad)
+        pitch_inp = F.add_chan_mask(dec_p, style_p, tgt_nonpad)
         _, masked_pitch = F.pitch_coarse(f0, uv, tmask=tmask, mel2ph_pad=mel2ph, want_denorm=False)
         ret["masked_pitch"] = masked_pitch
         pitch_inp = F.embedding_bct(masked_pitch, self.pitch_embed.weight, out=pitch_inp, accumulate=True, padding_idx=0)

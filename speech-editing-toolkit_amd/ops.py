@@ -425,6 +425,11 @@ def randn(shape, device, seed=0, offset=0):
     return out
 
 
+def fanout(x, n):
+    """Inference backend: n references to the same tensor."""
+    return (x,) * n
+
+
 def grad_scale(x, s):
     """Inference backend: identity (fs.py:144-145 only rescales gradients)."""
     return x

@@ -125,7 +125,8 @@ class SpeechDenoiserTask:
         """One optimisation step: forward + losses, backward, gradient all-reduce (if distributed), clip + AdamW."""
         optimizer.zero_grad()
         losses, _ = self.run_model(sample, infer=False, **kwargs)
-        total = sum(losses.values())
+        with torch.enable_grad():  # callers may run under a global no_grad
+            total = sum(losses.values())
         total.backward()
         lr, _ = optimizer.step()
         return total.detach(), {k: v.detach() for k, v in losses.items()}, lr

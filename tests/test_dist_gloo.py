@@ -28,6 +28,9 @@ def _worker(rank, world, port, q):
               "nsamples": 6}
     sh = parallel.shard_batch(sample, r, w)
     parallel.barrier()
+    flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    w_ret = parallel.bucketed_all_reduce_sum_(flat, 4)  # 3 buckets: 4 + 4 + 2
+    assert w_ret == world and torch.equal(flat, torch.arange(10, dtype=torch.float32) * 3)
     tmax = parallel.max_over_ranks(1.0 + rank)
     tot = parallel.sum_over_ranks(float(sh["mels"].shape[0]))
     q.put((rank, sh["mels"][:, 0, 0].tolist(), sh["mel2ph"].shape[0], sh["nsamples"], tmax, tot))
@@ -57,3 +60,5 @@ def test_single_process_is_identity():
     s = {"a": torch.ones(3, 2)}
     assert parallel.shard_batch(s, 0, 1) is s
     assert parallel.max_over_ranks(3.5) == 3.5
+    f = torch.ones(5)
+    assert parallel.bucketed_all_reduce_sum_(f, 2) == 1 and torch.equal(f, torch.ones(5))

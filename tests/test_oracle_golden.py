@@ -47,6 +47,30 @@ def test_oracle_train_branch():
     assert np.abs(ret["mel_out"].numpy() - g["mel_out"]).max() < TOL
 
 
+def test_oracle_training_losses_and_grads():
+    """train_losses.npz = reference model + the reference's own loss functions + autograd (oracle/make_golden.py)."""
+    g = load_golden("train_losses")
+    m = g["meta"]
+    W = {k: v.requires_grad_(True) for k, v in Wt.seeded_weights(Wt.load_manifest("spec_denoiser"), m["wseed"]).items()}
+    inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=True)
+    with torch.enable_grad():
+        losses, _ = O.training_losses(W, m["steps"], inp, torch.from_numpy(g["t"]), torch.from_numpy(g["eps"]),
+                                      sil_ids=m["sil_ids"])
+        sum(losses.values()).backward()
+    for k, v in losses.items():
+        assert abs(float(v) - float(g["loss_" + k])) < 1e-5 * max(1.0, abs(float(v))), k
+    norms = dict(zip(m["param_names"], g["grad_norms"]))
+    for k, ref in norms.items():
+        if ref < 0:
+            assert W[k].grad is None, k
+        else:
+            assert abs(float(W[k].grad.norm()) - ref) < 1e-4 * ref + 1e-9, k
+    for key in [k for k in g if k.startswith("grad::")]:
+        gr = W[key[6:]].grad
+        ref = torch.from_numpy(g[key])
+        assert float((gr[:ref.shape[0]] - ref).abs().max()) < 1e-5 * float(ref.abs().max()) + 1e-9, key
+
+
 def test_schedule_known_answers():
     # SURVEY.md 8a rows a1/a2
     b8 = O.vpsde_betas(9)
