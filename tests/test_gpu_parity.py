@@ -514,3 +514,49 @@ def test_full_size_properties(dev):
     oret = O.gaussian_diffusion_infer(W, steps, sub, [n[:4] for n in noises])
     assert _maxdiff(full["mel_out"][:4], oret["mel_out"]) < 1e-4
     assert torch.equal(full["pitch"][:4].cpu(), oret["pitch"])
+
+
+# ----------------------------------------------------------------------------------------------------
+# ragged / extreme shapes vs the oracle (no golden: the oracle itself is pinned by tests/test_oracle_golden.py)
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,T,Tt,steps,pad", [(1, 5, 2, 3, False), (2, 31, 7, 2, True), (1, 33, 9, 2, False),
+                                              (3, 65, 11, 2, True), (1, 1548, 120, 1, True), (5, 200, 40, 2, True)])
+def test_ragged_and_extreme_shapes_vs_oracle(dev, B, T, Tt, steps, pad):
+    """T below / across the 32- and 64-frame tile sizes, B=1, the reference's max_frames (1548), padded tails;
+    persistent and per-layer loops must agree with each other bit for bit and with the oracle to 1e-4."""
+    model, W = _build_model(dev, "spec_denoiser", 40 + T, steps)
+    inp = Wt.synthetic_inputs(B, T, Tt, seed=T, pad_tail=pad)
+    noises = Wt.synthetic_noises(B, T, steps, seed=T + 1)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    nz = torch.stack(noises).to(dev)
+    args = (d["txt_tokens"], d["time_mel_masks"], d["mel2ph"], d["spk_embed"], d["ref_mels"], d["f0"], d["uv"])
+    a = model(*args, infer=True, noises=nz, persistent=True)
+    b = model(*args, infer=True, noises=nz, persistent=False)
+    assert torch.equal(a["mel_out"], b["mel_out"])
+    oret = O.gaussian_diffusion_infer(W, steps, inp, noises)
+    assert torch.equal(a["mel2ph"].cpu(), oret["mel2ph"]) and torch.equal(a["pitch"].cpu(), oret["pitch"])
+    assert torch.equal(a["masked_dur"].cpu(), oret["masked_dur"])
+    assert _maxdiff(a["decoder_inp"], oret["decoder_inp"]) < 2e-5
+    assert _maxdiff(a["mel_out"], oret["mel_out"]) < 1e-4
+
+
+def test_all_padding_and_all_masked_utterances(dev):
+    """Degenerate inputs: one utterance fully padded (mel2ph == 0 everywhere), one fully masked, one unmasked."""
+    steps, B, T, Tt = 2, 3, 48, 10
+    model, W = _build_model(dev, "spec_denoiser", 77, steps)
+    inp = Wt.synthetic_inputs(B, T, Tt, seed=9)
+    inp["mel2ph"][0] = 0
+    inp["ref_mels"][0] = 0
+    inp["f0"][0] = 0
+    inp["uv"][0] = 0
+    inp["time_mel_masks"][0] = 0
+    inp["time_mel_masks"][1] = 1
+    inp["time_mel_masks"][2] = 0
+    noises = Wt.synthetic_noises(B, T, steps, seed=10)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    ret = model(d["txt_tokens"], d["time_mel_masks"], d["mel2ph"], d["spk_embed"], d["ref_mels"], d["f0"], d["uv"],
+                infer=True, noises=torch.stack(noises).to(dev))
+    oret = O.gaussian_diffusion_infer(W, steps, inp, noises)
+    assert torch.isfinite(ret["mel_out"]).all()
+    assert torch.equal(ret["masked_dur"].cpu(), oret["masked_dur"]) and torch.equal(ret["pitch"].cpu(), oret["pitch"])
+    assert _maxdiff(ret["mel_out"], oret["mel_out"]) < 1e-4
