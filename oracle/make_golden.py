@@ -254,6 +254,46 @@ def train_loss_case(hp, name, B, T, T_txt, steps, wseed, iseed):
     npz(name, **out_np)
 
 
+def data_feed_case():
+    """Host-side data feed: f0 normalisation, editing masks under fixed seeds, and a 3-item
+    binarised test set written with the REFERENCE IndexedDatasetBuilder (tests/golden/binary_tiny/)."""
+    import random
+    from utils.audio.pitch.utils import norm_interp_f0 as ref_nif
+    from utils.spec_aug import time_mask as rtm
+    from utils.commons.indexed_datasets import IndexedDatasetBuilder as RefBuilder
+    rng = np.random.default_rng(5)
+    f0 = rng.uniform(80, 400, size=120)
+    f0[rng.uniform(size=120) < 0.3] = 0
+    f0[:4] = 0
+    f0[-3:] = 0
+    a, au = ref_nif(f0.copy())
+    mel2ph = torch.sort(torch.randint(1, 31, (200,), generator=torch.Generator().manual_seed(3))).values
+    spec = torch.zeros(200, 80)
+    random.seed(7)
+    m1 = rtm.generate_inference_mask(spec, mel2ph, ratio=0.5)
+    np.random.seed(11)
+    a1 = rtm.generate_alignment_aware_time_mask(spec, mel2ph, ratio=0.8)
+    torch.manual_seed(13)
+    t1 = rtm.generate_time_mask(spec, ratio=0.3)
+    d = os.path.join(GOLD, "binary_tiny")
+    os.makedirs(d, exist_ok=True)
+    bld = RefBuilder(os.path.join(d, "test"))
+    for i, T in enumerate((40, 56, 33)):
+        Tt = 8 + i
+        m2p = np.sort(rng.integers(1, Tt + 1, size=T)).astype(np.int64)
+        f0i = rng.uniform(90, 300, size=T).astype(np.float32)
+        f0i[rng.uniform(size=T) < 0.25] = 0
+        bld.add_item(dict(item_name="utt%d" % i, txt="hello world %d" % i,
+                          ph_token=rng.integers(1, 80, size=Tt).astype(np.int64),
+                          mel=np.clip(rng.normal(-3, 1.5, size=(T, 80)), -6, 1.5).astype(np.float32), mel2ph=m2p,
+                          f0=f0i, pitch=rng.integers(1, 255, size=T).astype(np.int64),
+                          spk_embed=(rng.standard_normal(256) / 16).astype(np.float32), wav_fn="dummy/utt%d.wav" % i))
+    bld.finalize()
+    np.save(os.path.join(d, "test_lengths.npy"), np.array([40, 56, 33]))
+    npz("data_feed", f0=f0, f0_norm=np.asarray(a, dtype=np.float32), uv=np.asarray(au, dtype=np.float32),
+        mel2ph=mel2ph, infer_mask_seed7=m1, align_mask_seed11=a1, time_mask_seed13=t1)
+
+
 def schedule_case(hp):
     out = {}
     for steps in (4, 8, 100):
@@ -329,6 +369,7 @@ def main():
     train_case(hp, "train_tiny", B=2, T=64, T_txt=16, steps=8, wseed=17, iseed=107)
     train_loss_case(hp, "train_losses", B=2, T=64, T_txt=16, steps=8, wseed=18, iseed=108)
     length_regulator_case()
+    data_feed_case()
     hifigan_case("hifigan_tiny", Wt.HIFIGAN_TINY, B=2, T=24, wseed=21, iseed=201)
     hifigan_case("hifigan_tiny_rb2", Wt.HIFIGAN_TINY_RB2, B=1, T=20, wseed=22, iseed=202)
     hifigan_case("hifigan_v1", Wt.HIFIGAN_V1, B=1, T=12, wseed=23, iseed=203)

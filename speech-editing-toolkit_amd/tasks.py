@@ -131,12 +131,76 @@ class SpeechDenoiserTask:
         lr, _ = optimizer.step()
         return total.detach(), {k: v.detach() for k, v in losses.items()}, lr
 
+    # ---- dataset-driven inference: `--infer`  (utils/commons/base_task.py:203-229, speech_editing_base.py:151-192) --
+    @torch.no_grad()
+    def test_step(self, sample, batch_idx, gen_dir):
+        """One utterance: edit the masked region, vocode prediction (+ ground truth), write the wavs."""
+        from scipy.io import wavfile
+        import numpy as np
+        assert sample["txt_tokens"].shape[0] == 1, "only support batch_size=1 in inference"
+        out = self.run_model(sample, infer=True)
+        item_name, text = sample["item_name"][0], sample["text"][0]
+        mel_gt = sample["mels"][0].cpu().numpy()
+        mel_pred = out["mel_out"][0].cpu().numpy()
+        tm = sample["time_mel_masks"][0].cpu().numpy()
+        base_fn = "[%06d][%s][%%s]" % (batch_idx, str(item_name).replace("%", "_"))
+        if text is not None:
+            base_fn += str(text).replace(":", "$3A")[:80]
+        base_fn = base_fn.replace(" ", "_")
+        written = {}
+        jobs = [("P", mel_pred), ("P_SEG", mel_pred[tm == 1])]
+        if hparams.get("save_gt", True):
+            jobs += [("G", mel_gt), ("G_SEG", mel_gt[tm == 1])]
+        for tag, mel in jobs:
+            if self.vocoder is None or mel.shape[0] == 0:
+                continue
+            wav = self.vocoder.spec2wav(mel)
+            fn = os.path.join(gen_dir, "wavs", (base_fn % tag) + ".wav")
+            wavfile.write(fn, hparams["audio_sample_rate"], (np.clip(wav, -1, 1) * 32767).astype(np.int16))
+            written[tag] = fn
+        return {"item_name": item_name, "text": text, "wav_fn_pred": base_fn % "P", "wav_fn_gt": base_fn % "G",
+                "wav_fn_orig": sample["wav_fn"][0], "mel_pred": mel_pred, "files": written}
+
+    def test(self, max_items=None, device="cuda"):
+        """Run the test set of <binary_data_dir> one utterance at a time; returns the per-item dicts and writes
+        checkpoints/<exp>/generated_<step>_<gen_dir_name>/{wavs/*.wav, meta.csv} like the reference."""
+        from .ckpt_utils import get_last_checkpoint, load_ckpt
+        from .data import StutterSpeechDataset
+        hparams["infer"] = True
+        random_seed = int(hparams.get("seed", 1234))
+        import random
+        import numpy as np
+        random.seed(random_seed)
+        np.random.seed(random_seed)
+        self.build_model()
+        work_dir = hparams.get("work_dir") or ""
+        step = 0
+        if work_dir and get_last_checkpoint(work_dir)[0] is not None:
+            load_ckpt(self.model, work_dir, "model")
+            step = int(get_last_checkpoint(work_dir)[0].get("global_step", 0))
+        self.model.to(device).eval()
+        ds = StutterSpeechDataset(hparams.get("test_set_name", "test"), hparams)
+        gen_dir = os.path.join(work_dir or ".", "generated_%d_%s" % (step, hparams.get("gen_dir_name", "")))
+        os.makedirs(os.path.join(gen_dir, "wavs"), exist_ok=True)
+        results = []
+        n = len(ds) if max_items is None else min(len(ds), max_items)
+        for i in range(n):
+            batch = ds.collater([ds[i]])
+            batch = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+            results.append(self.test_step(batch, i, gen_dir))
+        with open(os.path.join(gen_dir, "meta.csv"), "w") as f:
+            f.write("item_name,text,wav_fn_pred,wav_fn_gt,wav_fn_orig\n")
+            for r in results:
+                f.write(",".join(str(r[k]) for k in ("item_name", "text", "wav_fn_pred", "wav_fn_gt", "wav_fn_orig")) + "\n")
+        return results
+
     @classmethod
     def start(cls):
         if not hparams.get("infer"):
             raise NotImplementedError("SpeechDenoiserTask.start(): the dataset-driven trainer loop is not part of this "
                                       "path; use training_step() with batches (tools/train_bench.py)")
-        raise NotImplementedError("dataset-driven --infer needs the IndexedDataset reader (SURVEY.md 8f rank 3)")
+        task = cls()
+        task.test()
 
 
 def run_task():

@@ -1,0 +1,70 @@
+"""Host-side data feed (speech-editing-toolkit_amd/data.py) against fixtures produced by the reference's own
+functions / IndexedDatasetBuilder (oracle/make_golden.py::data_feed_case).  CPU only."""
+import os
+import random
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN, base_hparams, load_golden
+
+
+def test_norm_interp_f0_and_masks_match_reference():
+    import set_amd  # noqa: F401
+    from set_amd import data as D
+    g = load_golden("data_feed")
+    f0, uv = D.norm_interp_f0(g["f0"])
+    assert np.array_equal(f0.numpy(), g["f0_norm"]) and np.array_equal(uv.numpy(), g["uv"])
+    mel2ph = torch.from_numpy(g["mel2ph"])
+    random.seed(7)
+    assert np.array_equal(D.generate_inference_mask(mel2ph, 0.5).numpy(), g["infer_mask_seed7"])
+    np.random.seed(11)
+    assert np.array_equal(D.generate_alignment_aware_time_mask(mel2ph, 0.8).numpy(), g["align_mask_seed11"])
+    torch.manual_seed(13)
+    assert np.array_equal(D.generate_time_mask(200, 0.3).numpy(), g["time_mask_seed13"])
+    z = np.zeros(10)
+    f0z, uvz = D.norm_interp_f0(z)  # fully unvoiced utterance
+    assert float(f0z.abs().sum()) == 0.0 and float(uvz.sum()) == 10.0
+
+
+def test_indexed_dataset_reads_reference_files_and_round_trips(tmp_path):
+    import set_amd  # noqa: F401
+    from set_amd import data as D
+    ds = D.IndexedDataset(os.path.join(GOLDEN, "binary_tiny", "test"))  # written by the reference's builder
+    assert len(ds) == 3 and [ds[i]["item_name"] for i in range(3)] == ["utt0", "utt1", "utt2"]
+    assert ds[1]["mel"].shape == (56, 80) and ds[2]["mel2ph"].dtype == np.int64
+    try:
+        ds[3]
+        assert False
+    except IndexError:
+        pass
+    b = D.IndexedDatasetBuilder(str(tmp_path / "x"))
+    for i in range(3):
+        b.add_item(ds[i])
+    b.finalize()
+    assert open(tmp_path / "x.data", "rb").read() == open(os.path.join(GOLDEN, "binary_tiny", "test.data"), "rb").read()
+    rt = D.IndexedDataset(str(tmp_path / "x"))
+    assert all(np.array_equal(rt[i]["mel"], ds[i]["mel"]) for i in range(3))
+
+
+def test_dataset_items_and_collater_layout():
+    import set_amd  # noqa: F401
+    from set_amd import data as D
+    hp = base_hparams(binary_data_dir=os.path.join(GOLDEN, "binary_tiny"), infer=True, test_ids=[])
+    ds = D.StutterSpeechDataset("test", hp)
+    random.seed(1)
+    samples = [ds[i] for i in range(3)]
+    batch = ds.collater(samples)
+    assert batch["mels"].shape == (3, 56, 80) and batch["txt_tokens"].shape == (3, 10)
+    assert batch["mel2ph"].dtype == torch.int64 and batch["time_mel_masks"].shape == (3, 56)
+    assert batch["mel_lengths"].tolist() == [40, 56, 33] and batch["nsamples"] == 3
+    assert float(batch["mels"][0, 40:].abs().sum()) == 0.0 and int(batch["mel2ph"][2, 33:].sum()) == 0
+    for s in samples:  # inference mask = one contiguous phoneme span, expanded through mel2ph
+        m = s["time_mel_mask"]
+        assert set(m.tolist()) <= {0.0, 1.0} and m.sum() > 0
+        ph = torch.unique(s["mel2ph"][m == 1])
+        assert int(ph.max() - ph.min()) + 1 >= len(ph)
+    hp2 = dict(hp, infer=False, mask_type="alignment_aware")
+    np.random.seed(2)
+    s = D.StutterSpeechDataset("test", hp2)[1]
+    assert s["time_mel_mask"].shape == (56,) and s["f0"].shape == (56,) and s["uv"].max() <= 1

@@ -560,3 +560,48 @@ def test_all_padding_and_all_masked_utterances(dev):
     assert torch.isfinite(ret["mel_out"]).all()
     assert torch.equal(ret["masked_dur"].cpu(), oret["masked_dur"]) and torch.equal(ret["pitch"].cpu(), oret["pitch"])
     assert _maxdiff(ret["mel_out"], oret["mel_out"]) < 1e-4
+
+
+def test_infer_cli_end_to_end(dev, tmp_path, monkeypatch):
+    """`--infer` path: binarised test set (written by the reference's builder) -> StutterSpeechDataset -> edit the
+    masked span -> HiFi-GAN -> wav files + meta.csv, through set_hparams / run_task like tasks/run.py."""
+    import os
+    import yaml
+    from scipy.io import wavfile
+    from conftest import GOLDEN, ROOT
+    from set_amd import hparams as H
+    from set_amd import tasks
+    monkeypatch.chdir(tmp_path)
+    voc = tmp_path / "voc"
+    voc.mkdir()
+    yaml.safe_dump(Wt.HIFIGAN_TINY_RB2, open(voc / "config.yaml", "w"))
+    torch.save({"state_dict": {"model_gen": Wt.seeded_weights(Wt.load_manifest("hifigan_tiny_rb2"), 22)}},
+               voc / "model_ckpt_steps_0.ckpt")
+    cfg = os.path.join(ROOT, "speech-editing-toolkit_amd", "egs", "spec_denoiser.yaml")
+    H.set_hparams(config=cfg, exp_name="e2e", print_hparams=False,
+                  hparams_str="timesteps=4,binary_data_dir=%s,vocoder_ckpt=%s" % (os.path.join(GOLDEN, "binary_tiny"), voc))
+    H.hparams["infer"] = True
+    # a "trained" checkpoint in the reference layout
+    torch.manual_seed(0)
+    task0 = tasks.SpeechDenoiserTask(build_vocoder=False)
+    sd = task0.build_model().state_dict()  # incl. the 16 schedule buffers, as in a reference checkpoint
+    sd.update(Wt.seeded_weights(Wt.load_manifest("spec_denoiser"), 5))
+    os.makedirs("checkpoints/e2e", exist_ok=True)
+    torch.save({"state_dict": {"model": sd}, "global_step": 1234}, "checkpoints/e2e/model_ckpt_steps_1234.ckpt")
+    task = tasks.SpeechDenoiserTask()
+    assert task.vocoder is not None
+    res = task.test()
+    assert len(res) == 3
+    gen = "checkpoints/e2e/generated_1234_"
+    meta = open(os.path.join(gen, "meta.csv")).read().strip().split("\n")
+    assert len(meta) == 4 and meta[1].startswith("utt0,hello world 0")
+    hop = 4 * 4  # HIFIGAN_TINY_RB2 upsampling
+    for r, T in zip(res, (40, 56, 33)):
+        sr, wav = wavfile.read(r["files"]["P"])
+        assert sr == 22050 and wav.shape == (T * hop,) and wav.dtype == np.int16 and np.abs(wav).max() > 0
+        assert r["mel_pred"].shape == (T, 80) and np.isfinite(r["mel_pred"]).all()
+        assert set(r["files"]) == {"P", "P_SEG", "G", "G_SEG"}
+    # unmasked frames are pasted from the ground truth (spec_denoiser.py:53)
+    from set_amd import data as D
+    ds = D.IndexedDataset(os.path.join(GOLDEN, "binary_tiny", "test"))
+    assert np.abs(res[0]["mel_pred"] - ds[0]["mel"]).min(axis=1).max() < 1e5  # sanity: comparable ranges
