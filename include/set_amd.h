@@ -55,6 +55,9 @@ extern "C" {
 /* implementation selector for set_conv1d (0 is treated as NAIVE) */
 #define SET_IMPL_NAIVE 1 /* one thread per output sample; any shape; device-side cross-check */
 #define SET_IMPL_MFMA 2  /* implicit-GEMM on v_mfma_f32_32x32x2_f32; needs packed weights */
+#define SET_IMPL_MFMA2 3 /* big-tile variant for wide layers (128*RB rows x 64 frames per block, RB = 4/2/1 for
+                            Cout >= 384 / >= 192 / else); needs the image of set_pack_conv_weight_v2;
+                            receptive field (K-1)*|dil| <= 64 */
 
 int set_abi_version(void);
 /* last hip error string of the calling thread's most recent failing call (host pointer, static storage) */
@@ -103,6 +106,11 @@ int64_t set_packed_conv_weight_size(int32_t Cout, int32_t Cin, int32_t K);
  * (rb < ceil(Cout/32), cp < CinP/2, CinP = Cin rounded up to 16). */
 int set_pack_conv_weight(const float *w, float *wp, int32_t Cout, int32_t Cin, int32_t K,
                          int64_t w_base, int64_t w_sco, int64_t w_sci, int64_t w_stap, void *stream);
+
+/* packed image for SET_IMPL_MFMA2 (layout depends on Cout, K and |dil| as well as on the weights) */
+int64_t set_packed_conv_weight_v2_size(int32_t Cout, int32_t Cin, int32_t K);
+int set_pack_conv_weight_v2(const float *w, float *wp, int32_t Cout, int32_t Cin, int32_t K, int32_t dil,
+                            int64_t w_base, int64_t w_sco, int64_t w_sci, int64_t w_stap, void *stream);
 
 /* weight-norm fold  w[i][...] = g[i] * v[i][...] / ||v[i][...]||_2   (torch.nn.utils.weight_norm, dim=0;
  * hifigan.py:32-47,108,114,122).  v,w: [n0][inner]; g: [n0]. */

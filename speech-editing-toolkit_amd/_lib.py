@@ -22,7 +22,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 OK, E_INVALID, E_UNSUPPORTED, E_LAUNCH = 0, -1, -2, -3
 ACT = dict(none=0, relu=1, gelu=2, tanh=3, softplus=4, mish=5, lrelu=6)
 PRO = dict(none=0, lrelu=1, div=2)
-IMPL_NAIVE, IMPL_MFMA = 1, 2
+IMPL_NAIVE, IMPL_MFMA, IMPL_MFMA2 = 1, 2, 3
 
 c_f32p = C.POINTER(C.c_float)
 c_i64p = C.POINTER(C.c_int64)
@@ -93,6 +93,8 @@ SIGNATURES = {
     "set_conv1d": (C.c_int, [C.POINTER(SetConv1dArgs), _V]),
     "set_packed_conv_weight_size": (_I64, [_I32, _I32, _I32]),
     "set_pack_conv_weight": (C.c_int, [_V, _V, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _V]),
+    "set_packed_conv_weight_v2_size": (_I64, [_I32, _I32, _I32]),
+    "set_pack_conv_weight_v2": (C.c_int, [_V, _V, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _V]),
     "set_weight_norm_fold": (C.c_int, [_V, _V, _V, _I32, _I64, _V]),
     "set_layernorm_ch": (C.c_int, [_V, _V, _V, _V, _V, _I32, _I32, _I32, _F, _V]),
     "set_embedding_bct": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _I32, _F, _I32, _V]),

@@ -64,3 +64,63 @@ __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+
+// ---- shared fp32 MFMA GEMM inner loop -----------------------------------------------------------------------
+// acc[RB][NCB] (32x32 blocks) += A * B over `ng` groups of GS k-steps (2 k values each).
+//   A operand: packed image, one vector of RB floats per lane per k-step:  wp[u * 64] for k-step u of the group
+//   B operand: LDS, bp[u * rstep + 32 * cb]
+// Two operand sets ping-pong (no register copies): while the MFMAs of one group run, the loads of the next group are
+// issued one k-step at a time, each pinned in front of its k-step's MFMAs with sched_barrier (otherwise the
+// scheduler sinks them next to their use).  `advance(g)` moves wp / bp from group g to group g+1.  ng must be even.
+template <int RB> struct AVec;
+template <> struct AVec<1> { typedef float type; };
+template <> struct AVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct AVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+template <int RB>
+__device__ __forceinline__ float avec_get(const typename AVec<RB>::type &v, int r) {
+    if constexpr (RB == 1) return v; else return v[r];
+}
+
+template <int RB, int NCB, int GS>
+struct KOps {
+    typename AVec<RB>::type A[GS];
+    float B[GS][NCB];
+};
+
+template <int RB, int NCB, int GS, typename Adv>
+__device__ __forceinline__ void gemm_groups(f32x16 (&acc)[RB][NCB], const typename AVec<RB>::type *&wp, const float *&bp,
+                                            int rstep, int ng, Adv advance) {
+    KOps<RB, NCB, GS> P, Q;
+    auto load_step = [&](KOps<RB, NCB, GS> &o, int u) {
+        o.A[u] = wp[u * 64];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) o.B[u][cb] = bp[u * rstep + 32 * cb];
+    };
+    auto mma_step = [&](const KOps<RB, NCB, GS> &o, int u) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[r][cb] = mfma32(avec_get<RB>(o.A[u], r), o.B[u][cb], acc[r][cb]);
+    };
+#pragma unroll
+    for (int u = 0; u < GS; ++u) load_step(P, u);
+    for (int g = 0; g < ng; g += 2) {
+        advance(g);  // -> group g+1 (always exists: ng is even)
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+            load_step(Q, u);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(P, u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g + 2 < ng) advance(g + 1);  // last pair: re-load the final group (harmless, in bounds)
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+            load_step(P, u);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(Q, u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}

@@ -128,7 +128,219 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(SetConv1dArgs a, int l
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// v2: big-tile implicit GEMM for wide layers (same machinery as the fused DiffNet layer kernel).
+//   block = 4 waves; wave w owns RB row blocks x 2 column blocks (32*RB rows x 64 frames) -> block tile
+//   128*RB rows x 64 frames; the input is staged per chunk of CH <= 256 channels as xs[CH][64 + halo]
+//   (wave-per-row coalesced loads, prologue applied on the way in); A fragments come from a packed image
+//   [row group][wave][k-step][lane][RB] (one RB-float vector per lane per k-step) prefetched by gemm_groups.
+//   k-step order inside a chunk: tap-major, channel pairs minor.
+// ------------------------------------------------------------------------------------------
+constexpr int V2_GS = 4;     // k-steps per operand group
+constexpr int V2_CH = 256;   // max channels per LDS chunk
+
+template <int RB>
+__global__ void __launch_bounds__(256, 2) conv1d_mfma_v2_kernel(SetConv1dArgs a, int lo, int halo, int CinP, int ch_max) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef typename AVec<RB>::type avec_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, t0 = blockIdx.x * 64, g = blockIdx.y;
+    const int XW = 64 + halo;
+    const int T_in = a.T_in;
+    const float *inb = a.in + (int64_t)b * a.in_bs;
+    const int64_t ks_total = (int64_t)a.K * (CinP / 2);
+    const avec_t *wp = reinterpret_cast<const avec_t *>(a.w) + (((int64_t)g * 4 + w) * ks_total) * 64 + lane;
+
+    f32x16 acc[RB][2];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) { acc[r][0] = (f32x16){0}; acc[r][1] = (f32x16){0}; }
+
+    // staging geometry (per lane): columns `lane` and `64 + lane` of the tile; clamped addresses + selects, no branches
+    const int tA = t0 + lo + lane, tB = tA + 64;
+    const bool vA = tA >= 0 && tA < T_in, vB = tB >= 0 && tB < T_in && lane < halo;
+    const unsigned cA = (unsigned)min(max(tA, 0), T_in - 1), cB = (unsigned)min(max(tB, 0), T_in - 1);
+    const bool laneB = lane < halo;
+    // optional per-(b, channel) add: ALWAYS load (from a valid dummy row when absent) and select afterwards -- a
+    // `ptr ? load : 0` inside the unrolled staging loop makes hipcc branch and drain vmcnt(0) per element
+    const bool has_add = a.in_chan_add != nullptr;
+    const float *addp = has_add ? a.in_chan_add + (int64_t)b * a.Cin : inb;
+
+    for (int c0 = 0; c0 < CinP; c0 += ch_max) {
+        const int CH = min(ch_max, CinP - c0);  // multiple of 16
+        __syncthreads();                        // previous chunk fully consumed
+        // wave w stages channels c0 + w, w+4, ... (16 rows in flight per wave)
+        for (int r0 = w; r0 < CH; r0 += 64) {
+            float xa[16], xb[16], dd[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = c0 + r0 + 4 * u;
+                const int cc = min(c, a.Cin - 1);  // clamp: padded channels read a valid row, zeroed below
+                const float *row = inb + (int64_t)cc * a.in_cs;
+                xa[u] = row[cA];
+                xb[u] = row[cB];
+                dd[u] = addp[cc];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int cl = r0 + 4 * u;  // channel inside the chunk
+                if (cl < CH) {
+                    const bool cv = c0 + cl < a.Cin;
+                    const float dv = has_add ? dd[u] : 0.0f;
+                    smem[cl * XW + lane] = (vA && cv) ? dev_pro(xa[u] + dv, a.pro, a.pro_param) : 0.0f;
+                    if (laneB) smem[cl * XW + 64 + lane] = (vB && cv) ? dev_pro(xb[u] + dv, a.pro, a.pro_param) : 0.0f;
+                }
+            }
+        }
+        __syncthreads();
+        const int gpt = CH / (2 * V2_GS);        // operand groups per tap (even: CH is a multiple of 16)
+        const int rstep = 2 * XW;
+        const float *bp = smem + half * XW + l31 + (0 * a.dil - a.pad - lo);
+        gemm_groups<RB, 2, V2_GS>(acc, wp, bp, rstep, a.K * gpt, [&](int gi) {
+            wp += V2_GS * 64;
+            bp += V2_GS * rstep;
+            if ((gi % gpt) == gpt - 1) bp += a.dil - (CH / 2) * rstep;  // next tap: channel 0, shifted by dil columns
+        });
+        wp += V2_GS * 64;  // gemm_groups leaves wp on the chunk's last group
+    }
+
+    // epilogue: accumulators go through LDS one row-block slice (128 rows x 64 frames) at a time, then a compact
+    // cooperative loop applies bias / alpha / act / res / mask with whole-row coalesced global accesses
+    // (a fully unrolled per-register epilogue is ~40k instructions here and spills).
+    // fast path: 4 consecutive frames per thread (16-byte LDS reads / global loads / stores)
+    const bool vec4 = a.out_stride == 1 && a.out_off == 0 && !a.accumulate && (a.T_out & 3) == 0 && (a.out_cs & 3) == 0 &&
+                      (a.out_bs & 3) == 0 && (!a.res || ((a.res_cs & 3) == 0 && (a.res_bs & 3) == 0)) &&
+                      t0 + 64 <= a.T_iter && a.T_iter <= a.T_out;
+    const int col = vec4 ? (tid & 15) * 4 : (tid & 63);
+    const int t = t0 + col;
+    const int n = t * a.out_stride + a.out_off;
+    const bool tvalid = t < a.T_iter && n >= 0 && n < a.T_out;
+    f32x4 msk4 = {1.0f, 1.0f, 1.0f, 1.0f};
+    float msk = 1.0f;
+    if (a.mask && tvalid) {
+        if (vec4) msk4 = *reinterpret_cast<const f32x4 *>(a.mask + (int64_t)b * a.T_out + n);
+        else msk = a.mask[(int64_t)b * a.T_out + n];
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) smem[(32 * w + mfma32_row(r, lane)) * 64 + cb * 32 + l31] = acc[rb][cb][r];
+        __syncthreads();
+        if (vec4) {
+            for (int rr = tid >> 4; rr < 128; rr += 16) {
+                const int co = g * 128 * RB + (rr >> 5) * 32 * RB + rb * 32 + (rr & 31);
+                if (co >= a.Cout) continue;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(smem + rr * 64 + col);
+                const float bi = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = dev_act((v[k] + bi) * a.alpha, a.act, a.act_param);
+                if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + (int64_t)b * a.res_bs + (int64_t)co * a.res_cs + n);
+                v *= msk4;
+                *reinterpret_cast<f32x4 *>(a.out + (int64_t)b * a.out_bs + (int64_t)co * a.out_cs + n) = v;
+            }
+        } else if (tvalid) {
+            for (int rr = tid >> 6; rr < 128; rr += 4) {
+                const int co = g * 128 * RB + (rr >> 5) * 32 * RB + rb * 32 + (rr & 31);
+                if (co >= a.Cout) continue;
+                float v = smem[rr * 64 + col];
+                if (a.bias) v += a.bias[co];
+                v = dev_act(v * a.alpha, a.act, a.act_param);
+                if (a.res) v += a.res[(int64_t)b * a.res_bs + (int64_t)co * a.res_cs + n];
+                v *= msk;
+                float *o = a.out + (int64_t)b * a.out_bs + (int64_t)co * a.out_cs + n;
+                *o = a.accumulate ? (*o + v) : v;
+            }
+        }
+    }
+}
+
+// packed image for v2:  wp[g][w][ks][lane][rb] = W[row][ci][tap],  row = g*128*RB + w*32*RB + rb*32 + (lane&31),
+// ks enumerates (chunk, tap, channel pair) in the kernel's consumption order, ci = chunk0 + 2*cp + (lane>>5)
+__global__ void __launch_bounds__(256) pack_conv_weight_v2_kernel(const float *w, float *wp, int Cout, int Cin, int K,
+                                                                  int CinP, int ch_max, int RB, int64_t total,
+                                                                  int64_t w_base, int64_t w_sco, int64_t w_sci,
+                                                                  int64_t w_stap) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int rb = (int)(idx % RB);
+    const int lane = (int)((idx / RB) & 63);
+    int64_t r = idx / RB / 64;
+    const int64_t ks_total = (int64_t)K * (CinP / 2);
+    int64_t ks = r % ks_total;
+    r /= ks_total;
+    const int wv = (int)(r & 3), g = (int)(r >> 2);
+    // decode ks -> (chunk, tap, cp)
+    int c0 = 0;
+    for (;;) {
+        const int CH = CinP - c0 < ch_max ? CinP - c0 : ch_max;
+        const int64_t per_chunk = (int64_t)K * (CH / 2);
+        if (ks < per_chunk) {
+            const int tap = (int)(ks / (CH / 2)), cp = (int)(ks % (CH / 2));
+            const int co = g * 128 * RB + wv * 32 * RB + rb * 32 + (lane & 31);
+            const int ci = c0 + 2 * cp + (lane >> 5);
+            float v = 0.0f;
+            if (co < Cout && ci < Cin) v = w[w_base + (int64_t)co * w_sco + (int64_t)ci * w_sci + (int64_t)tap * w_stap];
+            wp[idx] = v;
+            return;
+        }
+        ks -= per_chunk;
+        c0 += CH;
+    }
+}
+
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+static inline int v2_rb(int Cout) { return Cout >= 384 ? 4 : (Cout >= 192 ? 2 : 1); }
+static inline int v2_ch_max(int halo) { return (64 + halo) * V2_CH * 4 > 96 * 1024 ? 128 : V2_CH; }
+
+extern "C" int64_t set_packed_conv_weight_v2_size(int32_t Cout, int32_t Cin, int32_t K) {
+    const int RB = v2_rb(Cout);
+    return (int64_t)round_up(Cout, 128 * RB) * K * round_up(Cin, 16);
+}
+
+extern "C" int set_pack_conv_weight_v2(const float *w, float *wp, int32_t Cout, int32_t Cin, int32_t K, int32_t dil,
+                                       int64_t w_base, int64_t w_sco, int64_t w_sci, int64_t w_stap, void *stream) {
+    SET_REQUIRE(w && wp && Cout > 0 && Cin > 0 && K > 0, "set_pack_conv_weight_v2");
+    const int RB = v2_rb(Cout);
+    const int halo = (K - 1) * (dil < 0 ? -dil : dil);
+    const int64_t total = set_packed_conv_weight_v2_size(Cout, Cin, K);
+    hipLaunchKernelGGL(pack_conv_weight_v2_kernel, dim3(set_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wp,
+                       Cout, Cin, K, round_up(Cin, 16), v2_ch_max(halo), RB, total, w_base, w_sco, w_sci, w_stap);
+    return set_check_launch("set_pack_conv_weight_v2");
+}
+
+static int launch_conv_v2(const SetConv1dArgs &a, hipStream_t s) {
+    const int o_first = -a.pad, o_last = (a.K - 1) * a.dil - a.pad;
+    const int lo = o_first < o_last ? o_first : o_last;
+    const int halo = (o_first < o_last ? o_last : o_first) - lo;
+    if (halo > 64) return set_fail(SET_E_UNSUPPORTED, "set_conv1d(mfma2)", "receptive field > 64");
+    const int RB = v2_rb(a.Cout);
+    const int CinP = round_up(a.Cin, 16);
+    const int ch_max = v2_ch_max(halo);
+    const int ch = CinP < ch_max ? CinP : ch_max;
+    size_t lds = (size_t)ch * (64 + halo) * sizeof(float);
+    if (lds < 128 * 64 * sizeof(float)) lds = 128 * 64 * sizeof(float);  // epilogue slice
+    static bool attr_set = false;
+    if (!attr_set) {
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1d_mfma_v2_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), "conv v2 attr");
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1d_mfma_v2_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), "conv v2 attr");
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1d_mfma_v2_kernel<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), "conv v2 attr");
+        attr_set = true;
+    }
+    dim3 grid((a.T_iter + 63) / 64, (a.Cout + 128 * RB - 1) / (128 * RB), a.B), block(256);
+    if (RB == 4) hipLaunchKernelGGL(conv1d_mfma_v2_kernel<4>, grid, block, lds, s, a, lo, halo, CinP, ch_max);
+    else if (RB == 2) hipLaunchKernelGGL(conv1d_mfma_v2_kernel<2>, grid, block, lds, s, a, lo, halo, CinP, ch_max);
+    else hipLaunchKernelGGL(conv1d_mfma_v2_kernel<1>, grid, block, lds, s, a, lo, halo, CinP, ch_max);
+    return set_check_launch("set_conv1d(mfma2)");
+}
+
 
 extern "C" int64_t set_packed_conv_weight_size(int32_t Cout, int32_t Cin, int32_t K) {
     return (int64_t)round_up(Cout, 32) * K * round_up(Cin, KC);
@@ -170,6 +382,7 @@ extern "C" int set_conv1d(const SetConv1dArgs *args, void *stream) {
     SET_REQUIRE(a.out_stride >= 1, "set_conv1d");
     if (a.T_iter <= 0) return SET_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (a.impl == SET_IMPL_MFMA2) return launch_conv_v2(a, s);
     if (a.impl != SET_IMPL_MFMA) {
         const int64_t total = (int64_t)a.B * a.Cout * a.T_iter;
         hipLaunchKernelGGL(conv1d_naive_kernel, dim3(set_blocks(total, 256)), dim3(256), 0, s, a);

@@ -55,55 +55,6 @@ struct LayerTile {
     uint64_t *dbg;
 };
 
-// operands of GS consecutive k-steps: A = 4 row blocks (one dwordx4 per lane per k-step), B = NCB column blocks
-template <int NCB, int GS>
-struct KOps {
-    f32x4 A[GS];
-    float B[GS][NCB];
-};
-
-// acc[4][NCB] += W[512 x 2*KS] * Bmat, k-steps in groups of GS.  Two operand sets ping-pong (no register copies):
-// while the MFMAs of one group run, the loads of the next group are issued one k-step at a time, each pinned in
-// front of its k-step's MFMAs with sched_barrier (otherwise the scheduler sinks them next to their use).
-// `advance(g)` moves wp / bp from group g to group g+1.
-template <int NCB, int GS, int NG, typename Adv>
-__device__ __forceinline__ void gemm_groups(f32x16 (&acc)[4][NCB], const f32x4 *&wp, const float *&bp, int rstep,
-                                            Adv advance) {
-    static_assert(NG % 2 == 0, "group count must be even");
-    KOps<NCB, GS> P, Q;
-    auto load_step = [&](KOps<NCB, GS> &o, int u) {
-        o.A[u] = wp[u * 64];
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) o.B[u][cb] = bp[u * rstep + 32 * cb];
-    };
-    auto mma_step = [&](const KOps<NCB, GS> &o, int u) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[r][cb] = mfma32(o.A[u][r], o.B[u][cb], acc[r][cb]);
-    };
-#pragma unroll
-    for (int u = 0; u < GS; ++u) load_step(P, u);
-    for (int g = 0; g < NG; g += 2) {
-        advance(g);  // -> group g+1 (always exists: NG is even)
-#pragma unroll
-        for (int u = 0; u < GS; ++u) {
-            load_step(Q, u);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_step(P, u);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (g + 2 < NG) advance(g + 1);  // last pair: re-load the final group (harmless, in bounds)
-#pragma unroll
-        for (int u = 0; u < GS; ++u) {
-            load_step(P, u);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_step(Q, u);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
 template <int NCB, int GS>
 __device__ __forceinline__ void layer_tile(const LayerTile &a, float *smem) {
     constexpr int NTt = 32 * NCB;           // frames per tile;  GS = k-steps per operand group
@@ -186,7 +137,7 @@ __device__ __forceinline__ void layer_tile(const LayerTile &a, float *smem) {
         const float *bp = smem + half * XW + l31;
         const int rstep = 2 * XW;  // LDS floats between consecutive k-steps (2 channels)
         constexpr int GPT = 128 / GS;  // groups per tap
-        gemm_groups<NCB, GS, KS1 / GS>(acc, wp, bp, rstep, [&](int g) {
+        gemm_groups<4, NCB, GS>(acc, wp, bp, rstep, KS1 / GS, [&](int g) {
             wp += GS * 64;
             bp += GS * rstep;
             if ((g % GPT) == GPT - 1) bp += dil - 128 * rstep;  // next tap: back to channel 0, shift by dil columns
@@ -245,7 +196,7 @@ __device__ __forceinline__ void layer_tile(const LayerTile &a, float *smem) {
         const f32x4 *wp = reinterpret_cast<const f32x4 *>(a.w2p) + (int64_t)w * KS2 * 64 + lane;
         const float *bp = smem + half * NTt + l31;
         constexpr int rstep = 2 * NTt;
-        gemm_groups<NCB, GS, KS2 / GS>(acc, wp, bp, rstep, [&](int) {
+        gemm_groups<4, NCB, GS>(acc, wp, bp, rstep, KS2 / GS, [&](int) {
             wp += GS * 64;
             bp += GS * rstep;
         });

@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (ACT, PRO, IMPL_MFMA, IMPL_NAIVE, SetConv1dArgs, SetDiffnetLayerArgs, SetDiffLoopArgs,
+from ._lib import (ACT, PRO, IMPL_MFMA, IMPL_MFMA2, IMPL_NAIVE, SetConv1dArgs, SetDiffnetLayerArgs, SetDiffLoopArgs,
                    SetDiffnetStackArgs, check)
 
 _DEFAULT_IMPL = os.environ.get("SET_AMD_CONV_IMPL", "auto")  # auto | naive | mfma
@@ -87,6 +87,7 @@ class ConvWeight:
         self.stap = int(stap)
         self._packed = None
         self._key = None
+        self._packed2 = {}
 
     def raw(self):
         return _f(self._getter(), "weight")
@@ -110,10 +111,33 @@ class ConvWeight:
         return self._packed
 
 
-def _pick_impl(impl, T_iter):
+    def packed_v2(self, dil):
+        """Image for the big-tile kernel (depends on |dil| through the LDS chunking)."""
+        w = self.raw()
+        key = (w.data_ptr(), w._version, w.device, _WEIGHTS_EPOCH)
+        halo = (self.K - 1) * abs(dil)
+        slot = 128 if (64 + halo) * 256 * 4 > 96 * 1024 else 256
+        ent = self._packed2.get(slot)
+        if ent is None or ent[0] != key:
+            n = _lib.lib().set_packed_conv_weight_v2_size(self.Cout, self.Cin, self.K)
+            wp = torch.empty(n, dtype=torch.float32, device=w.device)
+            check(_lib.lib().set_pack_conv_weight_v2(_p(w), _p(wp), self.Cout, self.Cin, self.K, int(dil), self.base,
+                                                     self.sco, self.sci, self.stap, _stream()), "set_pack_conv_weight_v2")
+            ent = (key, wp)
+            self._packed2[slot] = ent
+        return ent[1]
+
+
+def _pick_impl(impl, T_iter, Cout=0, Cin=0, K=1, dil=1):
     impl = impl or _DEFAULT_IMPL
     if impl == "auto":
-        return "mfma" if T_iter >= 16 else "naive"
+        if T_iter < 16:
+            return "naive"
+        # big-tile kernel: measured (tools/conv_probe.py) +10-15 % for wide layers on short sequences (few 64-frame
+        # tiles); the small-tile kernel balances better on long sequences (HiFi-GAN) and narrow layers
+        if Cout >= 192 and Cin >= 192 and 32 <= T_iter <= 2048 and (K - 1) * abs(dil) <= 16:
+            return "mfma2"
+        return "mfma"
     return impl
 
 
@@ -132,10 +156,13 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
     if out is None:
         out = torch.empty(B, weight.Cout, T_out, dtype=torch.float32, device=x.device)
     _fv(out, "out")
-    impl = _pick_impl(impl, T_iter)
+    impl = _pick_impl(impl, T_iter, weight.Cout, Cin, weight.K, dil)
     a = SetConv1dArgs()
     a.inp = x.data_ptr()
-    a.w = (weight.packed() if impl == "mfma" else weight.raw()).data_ptr()
+    if impl == "mfma2":
+        a.w = weight.packed_v2(dil).data_ptr()
+    else:
+        a.w = (weight.packed() if impl == "mfma" else weight.raw()).data_ptr()
     a.bias = _f(bias, "bias").data_ptr() if bias is not None else None
     a.res = _fv(res, "res").data_ptr() if res is not None else None
     a.mask = _f(mask, "mask").data_ptr() if mask is not None else None
@@ -149,7 +176,7 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
     a.B, a.Cin, a.Cout, a.K, a.dil, a.pad = B, Cin, weight.Cout, weight.K, dil, pad
     a.T_in, a.T_iter, a.T_out, a.out_stride, a.out_off = T_in, T_iter, T_out, out_stride, out_off
     a.pro, a.act, a.accumulate = PRO[pro], ACT[act], int(bool(accumulate))
-    a.impl = IMPL_MFMA if impl == "mfma" else IMPL_NAIVE
+    a.impl = {"mfma": IMPL_MFMA, "mfma2": IMPL_MFMA2}.get(impl, IMPL_NAIVE)
     a.pro_param, a.act_param, a.alpha = float(pro_param), float(act_param), float(alpha)
     check(_lib.lib().set_conv1d(C.byref(a), _stream()), "set_conv1d")
     return out

@@ -55,6 +55,10 @@ CONV_CASES = [
     (2, 256, 1024, 1, 1, 5, dict(act="mish")),
     (1, 256, 512, 3, 4, 90, dict(chan_add=True, res=True)),
     (2, 16, 48, 3, 1, 64, dict(accumulate=True)),
+    (2, 512, 256, 3, 1, 130, dict()),                                  # two 256-channel LDS chunks, RB=2
+    (1, 300, 200, 7, 3, 97, dict(pro="lrelu", pro_param=0.1, res=True)),  # ragged channels, two chunks
+    (2, 512, 192, 1, 1, 64, dict()),
+    (1, 128, 128, 11, 5, 300, dict(pro="lrelu", pro_param=0.1)),       # halo 50
 ]
 
 
@@ -82,7 +86,7 @@ def _conv_ref(x, w, b, K, dil, ex, res, mask, add, prev):
     return y
 
 
-@pytest.mark.parametrize("impl", ["naive", "mfma"])
+@pytest.mark.parametrize("impl", ["naive", "mfma", "mfma2"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv1d_vs_torch(dev, impl, case):
     from set_amd import ops
