@@ -133,6 +133,10 @@ def main():
     #   launch_ms = mean duration of one launch, from hipEvent pairs on the launch stream over the timed region
     #   achieved  = algorithmic FLOPs of one launch / launch_ms  (x concurrent launches if utterance groups > 1)
     persistent = bool(ret.get("persistent", 0))
+    variant = _lib.lib().set_diffnet_stack_variant(B_PER_GPU // groups, T, model.denoise_fn.dilation_cycle_length, 1)
+    stack_kernel = "diffnet_stack_wino_kernel" if variant == 2 else "diffnet_stack_kernel"
+    # the Winograd kernel issues 3/4 of the algorithmic MACs (k=3 conv as F(2,3): 4 instead of 6 multiplies per pair)
+    executed_ratio = (4 * 512 * 256 + 512 * 256) / (512 * 768 + 512 * 256) if (persistent and variant == 2) else 1.0
     layers_per_launch = L if persistent else 1
     launch_ms = sum(spans) / len(spans) / (L // layers_per_launch)
     flop_per_launch = FLOP_PER_FRAME_LAYER * (B_PER_GPU / groups) * T * layers_per_launch
@@ -145,7 +149,7 @@ def main():
     if os.path.exists(tfile):  # HBM bytes per launch from the PMC passes (tools/pmc_traffic.py), same kernel + shape
         with open(tfile) as f:
             tj = json.load(f)
-        traffic = tj.get("diffnet_stack_kernel" if persistent else "diffnet_layer_kernel")
+        traffic = tj.get(stack_kernel if persistent else "diffnet_layer_kernel")
     out = {
         "metric": "diffusion mel-frames/s (100-step p_sample, B=32/GPU, T=800)",
         "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -156,10 +160,12 @@ def main():
                                "BASELINE configs[1]); on-device Philox noise",
                    "B_per_gpu": B_PER_GPU, "T": T, "T_txt": T_TXT, "denoise_steps": DIFF_STEPS,
                    "sharding": "utterances r::N, no collective"},
-        "roofline": {"kernel": "diffnet_stack_kernel" if persistent else "diffnet_layer_kernel", "bound": "mfma",
+        "roofline": {"kernel": stack_kernel if persistent else "diffnet_layer_kernel", "bound": "mfma",
                      "achieved": ach_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "launch_ms": launch_ms,
                      "flop_per_launch": flop_per_launch, "layers_per_launch": layers_per_launch,
+                     "executed_mfma_flop_ratio": executed_ratio,
+                     "mfma_issue_frac": executed_ratio * ach_tflops / PEAK_F32_MFMA_TFLOPS,
                      "algorithmic_bytes_per_launch": bytes_per_launch, "concurrent_launches": groups,
                      "achieved_wall_lower_bound": ach_wall, "frac_wall_lower_bound": ach_wall / PEAK_F32_MFMA_TFLOPS,
                      "hbm_algorithmic_GBps": ach_gbs, "hbm_frac": ach_gbs / PEAK_HBM_GBS},

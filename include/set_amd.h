@@ -228,9 +228,21 @@ typedef struct SetDiffnetStackArgs {
     int32_t *sync_ws;
     int64_t cp_bs, cp_ls, d_bs, d_cs, d_ls;
     int32_t B, T, L, dilation_cycle_length;
+    /* optional Winograd F(2,3) images (set_pack_diffnet_layer_wino), [L][512*256*4] and [L][512*256]: when both are
+     * given, every layer has dilation 1 and the batch has more 64-frame tiles than CUs, the k=3 conv runs as four
+     * 512x256 GEMMs over output pairs (2/3 of its MACs); results then agree with the direct kernels to fp32
+     * rounding (a few 1e-6), not bit for bit.  SET_AMD_WINO=0 in the environment disables it. */
+    const float *w1w_all;
+    const float *w2w_all;
 } SetDiffnetStackArgs;
 int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream);
 int64_t set_sizeof_diffnet_stack_args(void);
+
+/* which kernel set_diffnet_stack picks for this shape on the current device: 0 direct/64-frame tiles,
+ * 1 direct/32-frame tiles, 2 Winograd (diagnostics: bench.py names the kernel in its roofline object) */
+int set_diffnet_stack_variant(int B, int T, int dilation_cycle_length, int have_wino_images);
+int64_t set_diffnet_w1w_size(void);
+int set_pack_diffnet_layer_wino(const float *w_dil, const float *w_out, float *w1w, float *w2w, void *stream);
 
 /* posterior step (spec_denoiser.py:86-101):  x_prev = c1*x0 + c2*x_t + (t != 0) * exp(0.5*logvar) * eps
  * per-batch scalars coef4[b*coef_bs + {0,1,2,3}] = {c1, c2, logvar, nonzero} (coef_bs = 0: shared by the
@@ -263,6 +275,8 @@ typedef struct SetDiffLoopArgs {
     const float *w2p_all;  /* [L][512*256] packed output-projection weights */
     const float *b_dil_all; /* [L][512] */
     const float *b_out_all; /* [L][512] */
+    const float *w1w_all;   /* optional Winograd images (see SetDiffnetStackArgs), used by the persistent path */
+    const float *w2w_all;
     const float *w_skip_p; /* skip_projection packed */
     const float *b_skip;
     const float *w_outp_p; /* output_projection packed (Cout M, Cin 256) */

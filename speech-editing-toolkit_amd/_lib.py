@@ -63,6 +63,7 @@ class SetDiffLoopArgs(C.Structure):
         ("condproj", C.c_void_p), ("dstep", C.c_void_p), ("coef4", C.c_void_p),
         ("w_in_p", C.c_void_p), ("b_in", C.c_void_p),
         ("w1p_all", C.c_void_p), ("w2p_all", C.c_void_p), ("b_dil_all", C.c_void_p), ("b_out_all", C.c_void_p),
+        ("w1w_all", C.c_void_p), ("w2w_all", C.c_void_p),
         ("w_skip_p", C.c_void_p), ("b_skip", C.c_void_p), ("w_outp_p", C.c_void_p), ("b_outp", C.c_void_p),
         ("ws_x0", C.c_void_p), ("ws_x1", C.c_void_p), ("ws_skip", C.c_void_p), ("ws_h", C.c_void_p),
         ("ws_x0pred", C.c_void_p),
@@ -81,6 +82,7 @@ class SetDiffnetStackArgs(C.Structure):
         ("sync_ws", C.c_void_p),
         ("cp_bs", C.c_int64), ("cp_ls", C.c_int64), ("d_bs", C.c_int64), ("d_cs", C.c_int64), ("d_ls", C.c_int64),
         ("B", C.c_int32), ("T", C.c_int32), ("L", C.c_int32), ("dilation_cycle_length", C.c_int32),
+        ("w1w_all", C.c_void_p), ("w2w_all", C.c_void_p),
     ]
 
 
@@ -118,6 +120,9 @@ SIGNATURES = {
     "set_diffnet_w1p_size": (_I64, []),
     "set_diffnet_w2p_size": (_I64, []),
     "set_pack_diffnet_layer": (C.c_int, [_V, _V, _V, _V, _V]),
+    "set_diffnet_stack_variant": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "set_diffnet_w1w_size": (_I64, []),
+    "set_pack_diffnet_layer_wino": (C.c_int, [_V, _V, _V, _V, _V]),
     "set_diffnet_stack": (C.c_int, [C.POINTER(SetDiffnetStackArgs), _V]),
     "set_sizeof_diffnet_stack_args": (_I64, []),
     "set_posterior_step": (C.c_int, [_V, _V, _V, _V, _I64, _V, _I32, _I64, _U64, _U64, _V]),

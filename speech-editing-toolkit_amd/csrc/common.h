@@ -65,6 +65,28 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- raw buffer addressing: wave-uniform base (SGPR descriptor) + per-lane byte offset (one VGPR shared by every
+//      row) + wave-uniform byte offset (SGPR).  hipcc otherwise materialises a 64-bit VGPR address per load/store
+//      (v_lshl_add_u64 + 2 VGPRs each), which is what pushes row-looped tile code into spills.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)0x7fffffff, (int)0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f32x4 buf_load4(rsrc_t r, unsigned voff, unsigned soff) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store(float v, rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+// agent-scope write-through store (sc1): complete (vmcnt) = visible to every XCD, no L2 write-back needed later
+__device__ __forceinline__ void buf_store_agent(float v, rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 16);
+}
+
 // ---- shared fp32 MFMA GEMM inner loop -----------------------------------------------------------------------
 // acc[RB][NCB] (32x32 blocks) += A * B over `ng` groups of GS k-steps (2 k values each).
 //   A operand: packed image, one vector of RB floats per lane per k-step:  wp[u * 64] for k-step u of the group
@@ -98,10 +120,12 @@ __device__ __forceinline__ void gemm_groups(f32x16 (&acc)[RB][NCB], const typena
         for (int cb = 0; cb < NCB; ++cb) o.B[u][cb] = bp[u * rstep + 32 * cb];
     };
     auto mma_step = [&](const KOps<RB, NCB, GS> &o, int u) {
+        __builtin_amdgcn_s_setprio(1);  // co-resident blocks run out of phase: favour the wave that is in its MFMA burst (+3 %)
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) acc[r][cb] = mfma32(avec_get<RB>(o.A[u], r), o.B[u][cb], acc[r][cb]);
+        __builtin_amdgcn_s_setprio(0);
     };
 #pragma unroll
     for (int u = 0; u < GS; ++u) load_step(P, u);
@@ -112,7 +136,9 @@ __device__ __forceinline__ void gemm_groups(f32x16 (&acc)[RB][NCB], const typena
             load_step(Q, u);
             __builtin_amdgcn_sched_barrier(0);
             mma_step(P, u);
+#ifndef SET_NO_TRAILING_SB
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         if (g + 2 < ng) advance(g + 1);  // last pair: re-load the final group (harmless, in bounds)
 #pragma unroll
@@ -120,7 +146,9 @@ __device__ __forceinline__ void gemm_groups(f32x16 (&acc)[RB][NCB], const typena
             load_step(P, u);
             __builtin_amdgcn_sched_barrier(0);
             mma_step(Q, u);
+#ifndef SET_NO_TRAILING_SB
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     }
 }

@@ -240,6 +240,224 @@ __global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerAr
     layer_tile<2, 4>(lt, smem);
 }
 
+// ---- Winograd F(2,3) variant of the layer tile (dilation 1) -----------------------------------------------------
+// y[n] = g0 x[n-1] + g1 x[n] + g2 x[n+1].  For an output pair (y0, y1) with inputs d0..d3 = x[n-1..n+2]:
+//   m1 = (d0 - d2) g0          m2 = (d1 + d2) (g0 + g1 + g2)/2
+//   m3 = (d2 - d1) (g0 - g1 + g2)/2      m4 = (d1 - d3) g2          y0 = m1 + m2 + m3,  y1 = m2 - m3 - m4
+// i.e. four 512x256 GEMMs over 32 pair-columns instead of one 512x768 GEMM over 64 frames: 2/3 of the MACs of the
+// k=3 conv, 3/4 of the layer.  512 threads = 8 waves (2 per SIMD, so each hides the other's operand loads), one
+// block per CU, 64-frame tiles.  Wave w owns gate rows [32w,32w+32) and filter rows 256+[32w,32w+32): 2 x 4 planes
+// x 16 = 128 accumulator VGPRs.  The input transform is computed on the fly from the RAW (x + d) tile in LDS (two
+// ds_read_b64 + 4 VALU per k-step); the filter transform is folded into the packed weights; bias + conditioner
+// projection are folded into the M1 / M4 accumulator init.  GEMM 2 and the epilogue are as in layer_tile<2>.
+constexpr int WN_NT = 64;
+constexpr int WN_XW = WN_NT + 2;
+constexpr int WN_KS = DC / 2;  // 128 k-steps (2 channels each) for every GEMM here
+constexpr int WN_GS = 2;       // k-steps per operand group of GEMM 1
+
+// The phases are split so the persistent kernel can order them around its dependency wait:
+//   wino_init   - accumulator init from bias + conditioner projection (does NOT depend on the previous layer)
+//   wino_main   - stage x, GEMM 1, gate, GEMM 2, epilogue
+__device__ __forceinline__ void wino_init(const LayerTile &a, f32x16 (&m)[2][4]) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int T = a.T;
+    const int te = a.t0 + 2 * l31;  // output pair j = l31 -> frames te (even slot), te + 1
+    const unsigned loe = 4u * (unsigned)(4 * half * T + min(te, T - 1)), loo = 4u * (unsigned)(4 * half * T + min(te + 1, T - 1));
+    const unsigned lb = 16u * (unsigned)half;
+    const rsrc_t rcp = make_rsrc(a.cpb), rb = make_rsrc(a.b_dil);
+    // M1 <- b + cp(even), M4 <- -(b + cp(odd)), M2 = M3 = 0
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf) {
+        m[rf][1] = (f32x16){0};
+        m[rf][2] = (f32x16){0};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned ur = (unsigned)(rf * DC + 32 * w + urow16(r));  // wave-uniform
+            const float bias = buf_load(rb, lb, 4u * ur);
+            m[rf][0][r] = bias + buf_load(rcp, loe, 4u * ur * (unsigned)T);
+            m[rf][3][r] = -(bias + buf_load(rcp, loo, 4u * ur * (unsigned)T));
+        }
+    }
+}
+
+// xs = smem[0 .. 256*66), zs = smem + WN_ZS_OFF (own region: no barrier between the last xs read and the zs write)
+constexpr int WN_ZS_OFF = DC * WN_XW;
+
+__device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4], float *smem, uint64_t *ph, int *s_task,
+                                          int claimed) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x;
+#ifdef SET_WINO_PHASES
+#define WPH(k) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - ph[7]; ph[7] = t_; }
+#else
+#define WPH(k)
+#endif
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
+    const int half = lane >> 5, l31 = lane & 31;
+    const int t0 = a.t0, T = a.T;
+    const unsigned T4 = 4u * (unsigned)T;
+    float *zs = smem + WN_ZS_OFF;
+    const bool tve = t0 + 2 * l31 < T, tvo = t0 + 2 * l31 + 1 < T;
+    const rsrc_t rxin = make_rsrc(a.xin), rskp = make_rsrc(a.skp), rxout = make_rsrc(a.xout);
+
+    // ---- stage the raw (x + d) tile xs[256][66], column i <-> frame t0 - 1 + i; wave w owns channels [32w, 32w+32)
+    {
+        const int tA = t0 - 1 + lane, tB = tA + 64;
+        const bool vA = tA >= 0 && tA < T, vB = tB >= 0 && tB < T;
+        const unsigned cA = 4u * (unsigned)min(max(tA, 0), T - 1), cB = 4u * (unsigned)min(max(tB, 0), T - 1);
+        for (int r0 = 0; r0 < 32; r0 += 16) {
+            float xa[16], xb[16], dd[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = 32 * w + r0 + u;
+                xa[u] = buf_load(rxin, cA, (unsigned)c * T4);
+                xb[u] = buf_load(rxin, cB, (unsigned)c * T4);
+                dd[u] = a.dstep[(int64_t)c * a.d_cs];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = 32 * w + r0 + u;
+                smem[c * WN_XW + lane] = vA ? xa[u] + dd[u] : 0.0f;
+                if (lane < 2) smem[c * WN_XW + 64 + lane] = vB ? xb[u] + dd[u] : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    WPH(1)
+
+    // ---- GEMM 1 (Winograd): m[rf][p] += G_p[rows][c] * D_p[c][pair],  k-step = channels (2ks, 2ks+1)
+    {
+        const rsrc_t rw = make_rsrc(a.w1p);
+        const unsigned wv = 32u * (unsigned)lane;                // 8 floats per lane per k-step
+        unsigned ws = (unsigned)w * (WN_KS * 64 * 8 * 4);        // wave-uniform byte offset of the current group
+        const f32x2 *bp = reinterpret_cast<const f32x2 *>(smem + half * WN_XW + 2 * l31);
+        struct Ops { f32x4 A[WN_GS][2]; f32x2 D[WN_GS][2]; };
+        Ops P, Q;
+        auto load_step = [&](Ops &o, int u) {
+            o.A[u][0] = buf_load4(rw, wv, ws + (unsigned)u * 2048u);
+            o.A[u][1] = buf_load4(rw, wv + 16u, ws + (unsigned)u * 2048u);
+            o.D[u][0] = bp[u * WN_XW];      // (d0, d1): row stride 2*WN_XW floats = WN_XW float2
+            o.D[u][1] = bp[u * WN_XW + 1];  // (d2, d3)
+        };
+        auto mma_step = [&](const Ops &o, int u) {
+            const float d0 = o.D[u][0][0], d1 = o.D[u][0][1], d2 = o.D[u][1][0], d3 = o.D[u][1][1];
+            const float D1 = d0 - d2, D2 = d1 + d2, D3 = d2 - d1, D4 = d1 - d3;
+            __builtin_amdgcn_s_setprio(1);
+            m[0][0] = mfma32(o.A[u][0][0], D1, m[0][0]);
+            m[0][1] = mfma32(o.A[u][0][1], D2, m[0][1]);
+            m[0][2] = mfma32(o.A[u][0][2], D3, m[0][2]);
+            m[0][3] = mfma32(o.A[u][0][3], D4, m[0][3]);
+            m[1][0] = mfma32(o.A[u][1][0], D1, m[1][0]);
+            m[1][1] = mfma32(o.A[u][1][1], D2, m[1][1]);
+            m[1][2] = mfma32(o.A[u][1][2], D3, m[1][2]);
+            m[1][3] = mfma32(o.A[u][1][3], D4, m[1][3]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        constexpr int NG = WN_KS / WN_GS;
+#pragma unroll
+        for (int u = 0; u < WN_GS; ++u) load_step(P, u);
+        for (int g = 0; g < NG; g += 2) {
+            ws += WN_GS * 2048u;
+            bp += WN_GS * WN_XW;
+#pragma unroll
+            for (int u = 0; u < WN_GS; ++u) {
+                load_step(Q, u);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_step(P, u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g + 2 < NG) { ws += WN_GS * 2048u; bp += WN_GS * WN_XW; }
+#pragma unroll
+            for (int u = 0; u < WN_GS; ++u) {
+                load_step(P, u);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_step(Q, u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    WPH(2)
+    // ---- output transform + gate (lane-local): even frame y0 = M1 + M2 + M3, odd frame y1 = M2 - M3 - M4
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float g0 = m[0][0][r] + m[0][1][r] + m[0][2][r], g1 = m[0][1][r] - m[0][2][r] - m[0][3][r];
+        const float f0 = m[1][0][r] + m[1][1][r] + m[1][2][r], f1 = m[1][1][r] - m[1][2][r] - m[1][3][r];
+        const float z0 = tve ? fast_sigmoid(g0) * fast_tanh(f0) : 0.0f;
+        const float z1 = tvo ? fast_sigmoid(g1) * fast_tanh(f1) : 0.0f;
+        const int c = 32 * w + mfma32_row(r, lane);
+        *reinterpret_cast<f32x2 *>(zs + c * WN_NT + 2 * l31) = (f32x2){z0, z1};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- put the residual / running-skip tiles in flight (m is dead now); they are consumed after GEMM 2
+    const unsigned lo0 = 4u * (unsigned)(4 * half * T + min(t0 + l31, T - 1)), lo1 = 4u * (unsigned)(4 * half * T + min(t0 + 32 + l31, T - 1));
+    const bool tv0 = t0 + l31 < T, tv1 = t0 + 32 + l31 < T;
+    const bool first = a.first != 0;
+    f32x16 prev[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned ur = (unsigned)(32 * w + urow16(r));  // wave-uniform row of x (rb 0) / skip (rb 1)
+            prev[rb][0][r] = buf_load(rb == 0 ? rxin : rskp, lo0, ur * T4);
+            prev[rb][1][r] = buf_load(rb == 0 ? rxin : rskp, lo1, ur * T4);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- GEMM 2: o[512 x 64] = Wout * zs; wave w owns residual rows [32w, +32) and skip rows 256 + [32w, +32)
+    f32x16 acc[2][2];
+    {
+        const rsrc_t rbo = make_rsrc(a.b_out);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bias = buf_load(rbo, 16u * (unsigned)half, 4u * (unsigned)(rb * DC + 32 * w + urow16(r)));
+                acc[rb][0][r] = bias;
+                acc[rb][1][r] = bias;
+            }
+    }
+    if (tid == 0) s_task[0] = claimed;  // next task of this block, read by everyone after the epilogue
+    __syncthreads();
+    WPH(3)
+    {
+        const AVec<2>::type *wp = reinterpret_cast<const AVec<2>::type *>(a.w2p) + (int64_t)w * WN_KS * 64 + lane;
+        const float *bp = zs + half * WN_NT + l31;
+        constexpr int rstep = 2 * WN_NT;
+        gemm_groups<2, 2, 8>(acc, wp, bp, rstep, WN_KS / 8, [&](int) {
+            wp += 8 * 64;
+            bp += 8 * rstep;
+        });
+    }
+    WPH(4)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        if (cb == 0 ? tv0 : tv1) {
+            const unsigned so = 4u * (unsigned)(4 * half * T + t0 + 32 * cb + l31);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned ur = (unsigned)(32 * w + urow16(r));
+                    const float v = (rb == 1 && first) ? acc[rb][cb][r] : acc[rb][cb][r] + prev[rb][cb][r];
+                    // agent-scope write-through (sc1): once vmcnt drains, the tile is visible to every XCD, so the
+                    // publish needs no L2 write-back (a release fence = buffer_wbl2 of the whole XCD L2: -5 %)
+#ifdef SET_WINO_FENCED
+                    buf_store(v * (rb == 0 ? 0.70710678118654752440f : 1.0f), rb == 0 ? rxout : rskp, so, ur * T4);
+#else
+                    buf_store_agent(v * (rb == 0 ? 0.70710678118654752440f : 1.0f), rb == 0 ? rxout : rskp, so, ur * T4);
+#endif
+                }
+        }
+    }
+    WPH(5)
+#undef WPH
+}
+
 // ---- persistent layer stack: (layer, tile) task queue + per-tile epoch flags -----------------------------------
 // Inter-workgroup hand-off follows cdna_hip_programming.md Guideline 16: producer = every wave drains vmcnt,
 // __syncthreads, ONE lane agent-scope release fence + asm vmcnt(0) + relaxed agent flag store; consumer = ONE lane
@@ -324,6 +542,116 @@ __global__ void __launch_bounds__(256, WPS) diffnet_stack_kernel(SetDiffnetStack
     }
 }
 
+// Winograd flavour of the persistent kernel: 512 threads, one block per CU, 64-frame tiles.  Same queue and flags
+// as above, but each block claims its NEXT task while the current one is in GEMM 2, and issues the next task's
+// producer-independent loads (bias + conditioner projection -> accumulator init) BEFORE it waits for the producer
+// tiles, so that wait, the store drain and the release fence of the previous task overlap with them.  Claiming
+// ahead is deadlock-free: a block finishes its claims in claim order, and a claim only ever waits on earlier ones.
+__global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles,
+                                                                    int ntasks) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int *s_task = reinterpret_cast<int *>(smem + WN_ZS_OFF + DC * WN_NT);
+    int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
+    const int tid = threadIdx.x;
+    uint64_t wait_ticks = 0, fence_ticks = 0;
+    if (tid == 0) s_task[0] = atomicAdd(counter, 1);
+    __syncthreads();
+    int n = __builtin_amdgcn_readfirstlane(s_task[0]);
+    int l = 0, i = 0, j = 0;
+    LayerTile lt;
+    auto decode = [&](int task) {
+        l = task / ntiles;
+        i = task - l * ntiles;
+        const int b = i / tiles_per_utt;
+        j = i - b * tiles_per_utt;
+        const float *xi = (l & 1) ? a.xb : a.xa;
+        float *xo = (l & 1) ? a.xa : a.xb;
+        lt.xin = xi + (int64_t)b * DC * a.T;
+        lt.xout = xo + (int64_t)b * DC * a.T;
+        lt.skp = a.skip + (int64_t)b * DC * a.T;
+        lt.cpb = a.condproj + (int64_t)l * a.cp_ls + (int64_t)b * a.cp_bs;
+        lt.dstep = a.dstep + (int64_t)l * a.d_ls + (int64_t)b * a.d_bs;
+        lt.d_cs = a.d_cs;
+        lt.w1p = a.w1w_all + (int64_t)l * (512 * 256 * 4);
+        lt.w2p = a.w2w_all + (int64_t)l * (512 * 256);
+        lt.b_dil = a.b_dil_all + (int64_t)l * 512;
+        lt.b_out = a.b_out_all + (int64_t)l * 512;
+        lt.T = a.T; lt.t0 = j * WN_NT; lt.dil = 1; lt.first = (l == 0);
+        lt.dbg = nullptr;
+    };
+#ifdef SET_WINO_PHASES
+    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0] init+publish+wait, [1] stage, [2] gemm1, [3] gate.., [4] gemm2, [5] epilogue
+    ph[7] = __builtin_amdgcn_s_memtime();
+#else
+    uint64_t *ph = nullptr;
+#endif
+    int i_done = -1, l_done = 0;  // finished but not yet published tile of this block
+    auto publish = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave
+        __syncthreads();
+        if (tid == 0 && i_done >= 0) {
+            const uint64_t tf0 = __builtin_amdgcn_s_memtime();
+#ifdef SET_WINO_FENCED
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fence_ticks += __builtin_amdgcn_s_memtime() - tf0;
+        }
+    };
+    while (n < ntasks) {
+        decode(n);
+        f32x16 m[2][4];
+        wino_init(lt, m);  // issued before the previous tile's store drain / publish and before the dependency wait
+        __builtin_amdgcn_sched_barrier(0);
+        publish();
+        int claimed = 0;
+        if (tid == 0) {
+            int ok_all = 1;
+            if (l > 0) {
+                const uint64_t tw0 = __builtin_amdgcn_s_memtime();
+                unsigned spins = 0;
+                const int *f0 = done + i, *fl = done + (j > 0 ? i - 1 : i), *fr = done + (j < tiles_per_utt - 1 ? i + 1 : i);
+                for (;;) {
+                    const int v0 = ld_agent(f0), v1 = ld_agent(fl), v2 = ld_agent(fr);  // three independent loads
+                    if (min(v0, min(v1, v2)) >= l) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > STACK_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
+                        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok_all = 0;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                wait_ticks += __builtin_amdgcn_s_memtime() - tw0;
+            }
+            s_task[1] = ok_all;
+            claimed = atomicAdd(counter, 1);  // claim the next task; the result is only needed after GEMM 1
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(s_task[1]) == 0) {
+            i_done = -1;
+            break;
+        }
+#ifdef SET_WINO_PHASES
+        { const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[0] += t_ - ph[7]; ph[7] = t_; }
+#endif
+        wino_main(lt, m, smem, ph, s_task, claimed);
+        i_done = i;
+        l_done = l;
+        n = __builtin_amdgcn_readfirstlane(s_task[0]);  // written by thread 0 before the barrier in front of GEMM 2
+    }
+    publish();
+#ifdef SET_WINO_PHASES
+    if (tid == 0)
+        for (int k = 0; k < 6; ++k) atomicAdd(a.sync_ws + 4 + ntiles + k, (int)(ph[k] >> 10));
+#endif
+    if (tid == 0) {  // units of 1024 ticks
+        atomicAdd(a.sync_ws + 2, (int)(wait_ticks >> 10));
+        atomicAdd(a.sync_ws + 3, (int)(fence_ticks >> 10));
+    }
+}
+
 __global__ void __launch_bounds__(256) pack_diffnet_layer_kernel(const float *w_dil, const float *w_out, float *w1p,
                                                                  float *w2p) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -343,7 +671,40 @@ __global__ void __launch_bounds__(256) pack_diffnet_layer_kernel(const float *w_
     }
 }
 
+// Winograd images: w1w[w][ks][lane][rf*4 + p] = G_p(Wdil[rf*256 + 32w + (lane&31)][2ks + (lane>>5)][0..2]),
+//                  w2w[w][ks][lane][rb]       = Wout[rb*256 + 32w + (lane&31)][2ks + (lane>>5)]          (8 waves)
+__global__ void __launch_bounds__(256) pack_diffnet_wino_kernel(const float *w_dil, const float *w_out, float *w1w,
+                                                                float *w2w) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n1 = (int64_t)8 * WN_KS * 64 * 8, n2 = (int64_t)8 * WN_KS * 64 * 2;
+    if (idx < n1) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const int ks = (int)((idx >> 9) % WN_KS), w = (int)((idx >> 9) / WN_KS);
+        const int rf = e >> 2, p = e & 3;
+        const int row = rf * DC + 32 * w + (lane & 31), c = 2 * ks + (lane >> 5);
+        const float *g = w_dil + ((int64_t)row * DC + c) * 3;
+        const double g0 = g[0], g1 = g[1], g2 = g[2];
+        const double v = p == 0 ? g0 : (p == 1 ? 0.5 * (g0 + g1 + g2) : (p == 2 ? 0.5 * (g0 - g1 + g2) : g2));
+        w1w[idx] = (float)v;
+    } else if (idx < n1 + n2) {
+        const int64_t j = idx - n1;
+        const int rb = (int)(j & 1), lane = (int)((j >> 1) & 63);
+        const int ks = (int)((j >> 7) % WN_KS), w = (int)((j >> 7) / WN_KS);
+        const int row = rb * DC + 32 * w + (lane & 31), c = 2 * ks + (lane >> 5);
+        w2w[j] = w_out[(int64_t)row * DC + c];
+    }
+}
+
 }  // namespace
+
+extern "C" int64_t set_diffnet_w1w_size(void) { return (int64_t)512 * 256 * 4; }
+extern "C" int set_pack_diffnet_layer_wino(const float *w_dil, const float *w_out, float *w1w, float *w2w, void *stream) {
+    SET_REQUIRE(w_dil && w_out && w1w && w2w, "set_pack_diffnet_layer_wino");
+    const int64_t total = set_diffnet_w1w_size() + (int64_t)512 * 256;
+    hipLaunchKernelGGL(pack_diffnet_wino_kernel, dim3(set_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, w_dil,
+                       w_out, w1w, w2w);
+    return set_check_launch("set_pack_diffnet_layer_wino");
+}
 
 extern "C" int64_t set_diffnet_w1p_size(void) { return (int64_t)512 * 768; }
 extern "C" int64_t set_diffnet_w2p_size(void) { return (int64_t)512 * 256; }
@@ -379,6 +740,23 @@ extern "C" int set_diffnet_layer(const SetDiffnetLayerArgs *args, void *stream) 
 
 extern "C" int64_t set_sizeof_diffnet_stack_args(void) { return (int64_t)sizeof(SetDiffnetStackArgs); }
 
+// 0 = direct kernel, 64-frame tiles; 1 = direct kernel, 32-frame tiles; 2 = Winograd F(2,3) kernel (64-frame tiles,
+// 8-wave blocks, needs its packed images, dilation 1 everywhere and more tiles than CUs to be worth it)
+static int stack_variant(int B, int T, int dcl, bool have_wino, int n_cu) {
+    const int64_t tiles64 = (int64_t)B * ((T + 63) / 64);
+    int ncb = tiles64 < 3 * n_cu ? 1 : 2;
+    if (const char *e = getenv("SET_AMD_STACK_NCB")) ncb = atoi(e) == 2 ? 2 : 1;
+    const bool wino_ok = have_wino && dcl == 1;
+    bool wino = wino_ok && tiles64 > n_cu;
+    if (const char *e = getenv("SET_AMD_WINO")) wino = wino_ok && (atoi(e) == 2 || (wino && atoi(e) != 0));  // 2 = force
+    return wino ? 2 : (ncb == 1 ? 1 : 0);
+}
+extern "C" int set_diffnet_stack_variant(int B, int T, int dilation_cycle_length, int have_wino_images) {
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    return stack_variant(B, T, dilation_cycle_length, have_wino_images != 0, n_cu);
+}
+
 extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) {
     SET_REQUIRE(args != nullptr, "set_diffnet_stack");
     const SetDiffnetStackArgs &a = *args;
@@ -391,11 +769,12 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     static int n_cu = 0;
     static bool attr_set = false;
     if (!attr_set) {
-        const void *fns[3] = {reinterpret_cast<const void *>(diffnet_stack_kernel<1, 8, 2>),
+        const void *fns[4] = {reinterpret_cast<const void *>(diffnet_stack_kernel<1, 8, 2>),
                               reinterpret_cast<const void *>(diffnet_stack_kernel<1, 4, 3>),
-                              reinterpret_cast<const void *>(diffnet_stack_kernel<2, 4, 2>)};
+                              reinterpret_cast<const void *>(diffnet_stack_kernel<2, 4, 2>),
+                              reinterpret_cast<const void *>(diffnet_stack_wino_kernel)};
         for (const void *f : fns)
-            SET_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+            SET_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024),
                     "set_diffnet_stack(attr)");
         int dev = 0;
         SET_HIP(hipGetDevice(&dev), "set_diffnet_stack");
@@ -406,9 +785,9 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     // runnable.  Workers (2 per CU) must stay BELOW that or the youngest ones only wait (measured: 36 % wait time
     // with 512 workers on 416 64-frame tiles).  Use 64-frame tiles when a layer has >= 1.5x the workers, else
     // 32-frame tiles (B=32, T=800: 800 tiles, no tail waste); the grid is capped at 0.8x the tile count.
-    int ncb = 2;
-    if ((int64_t)a.B * ((a.T + 63) / 64) < 3 * n_cu) ncb = 1;
-    if (const char *e = getenv("SET_AMD_STACK_NCB")) ncb = atoi(e) == 2 ? 2 : 1;
+    const int variant = stack_variant(a.B, a.T, a.dilation_cycle_length, a.w1w_all && a.w2w_all, n_cu);
+    const bool wino = variant == 2;
+    const int ncb = variant == 1 ? 1 : 2;
     const int ntt = 32 * ncb;
     const int tiles_per_utt = (a.T + ntt - 1) / ntt;
     const int ntiles = a.B * tiles_per_utt;
@@ -417,17 +796,22 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     const int max_dil = 1 << (a.dilation_cycle_length - 1);
     const int task_slot = DC * (ntt + 2 * max_dil);  // float index of the task word
     const size_t lds = (size_t)(task_slot + 4) * sizeof(float);
-    SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
+    SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + ntiles + (wino ? 8 : 0)) * sizeof(int32_t), s),
+            "set_diffnet_stack(memset)");
     int wps = 2;  // resident blocks per CU
     if (const char *e = getenv("SET_AMD_STACK_WPS")) wps = atoi(e) == 3 ? 3 : 2;
     if (ncb == 2) wps = 2;
+    if (wino) wps = 1;
     int grid = wps * n_cu;
     if (grid > ntiles * 4 / 5) grid = ntiles * 4 / 5;
     if (grid < n_cu) grid = n_cu < ntiles ? n_cu : ntiles;
     if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
     if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
     if (grid < 1) grid = 1;
-    if (ncb == 1 && wps == 3)
+    if (wino)
+        hipLaunchKernelGGL(diffnet_stack_wino_kernel, dim3(grid), dim3(512),
+                           (size_t)(WN_ZS_OFF + DC * WN_NT + 4) * sizeof(float), s, a, tiles_per_utt, ntiles, (int)ntasks64);
+    else if (ncb == 1 && wps == 3)
         hipLaunchKernelGGL((diffnet_stack_kernel<1, 4, 3>), dim3(grid), dim3(256), lds, s, a, tiles_per_utt, ntiles,
                            (int)ntasks64, task_slot);
     else if (ncb == 1)
@@ -676,6 +1060,7 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
             sa.condproj = condproj; sa.cp_bs = (int64_t)L * 512 * T; sa.cp_ls = (int64_t)512 * T;
             sa.dstep = a.dstep + sid; sa.d_bs = 0; sa.d_cs = a.steps; sa.d_ls = (int64_t)DC * a.steps;
             sa.w1p_all = a.w1p_all; sa.w2p_all = a.w2p_all; sa.b_dil_all = a.b_dil_all; sa.b_out_all = a.b_out_all;
+            sa.w1w_all = a.w1w_all; sa.w2w_all = a.w2w_all;
             sa.sync_ws = sync_ws;
             sa.B = Bg; sa.T = T; sa.L = L; sa.dilation_cycle_length = a.dilation_cycle_length;
             rc = set_diffnet_stack(&sa, s);

@@ -382,6 +382,13 @@ def pack_diffnet_layer(w_dil, w_out, w1p=None, w2p=None):
     return w1p, w2p
 
 
+def pack_diffnet_layer_wino(w_dil, w_out, w1w, w2w):
+    """Winograd F(2,3) images of one layer into slices of the contiguous [L][...] buffers."""
+    _f(w_dil), _f(w_out), _f(w1w), _f(w2w)
+    check(_lib.lib().set_pack_diffnet_layer_wino(_p(w_dil), _p(w_out), _p(w1w), _p(w2w), _stream()),
+          "set_pack_diffnet_layer_wino")
+
+
 def sync_ws_size(B, T):
     return 32 + B * ((T + 31) // 32)
 
@@ -392,7 +399,7 @@ def diffnet_stack(xa, xb, skip, condproj, dstep_ptr, d_bs, d_cs, d_ls, packs, di
     _f(xa), _f(xb), _f(skip), _f(condproj)
     B, Cc, T = xa.shape
     assert Cc == 256
-    w1p_all, w2p_all, b_dil_all, b_out_all = packs
+    w1p_all, w2p_all, b_dil_all, b_out_all = packs[:4]
     L = b_dil_all.shape[0]
     if sync_ws is None:
         sync_ws = torch.empty(sync_ws_size(B, T), dtype=torch.int32, device=xa.device)
@@ -401,6 +408,8 @@ def diffnet_stack(xa, xb, skip, condproj, dstep_ptr, d_bs, d_cs, d_ls, packs, di
     a.condproj, a.dstep = condproj.data_ptr(), dstep_ptr
     a.w1p_all, a.w2p_all = w1p_all.data_ptr(), w2p_all.data_ptr()
     a.b_dil_all, a.b_out_all = b_dil_all.data_ptr(), b_out_all.data_ptr()
+    if len(packs) >= 6 and packs[4] is not None:
+        a.w1w_all, a.w2w_all = packs[4].data_ptr(), packs[5].data_ptr()
     a.sync_ws = sync_ws.data_ptr()
     a.cp_bs, a.cp_ls = condproj.stride(0), 512 * T
     a.d_bs, a.d_cs, a.d_ls = int(d_bs), int(d_cs), int(d_ls)
@@ -496,9 +505,11 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs,
     a.seed = int(seed)
     a.condproj, a.dstep, a.coef4 = condproj.data_ptr(), dstep.data_ptr(), coef4.data_ptr()
     a.w_in_p, a.b_in = w_in.packed().data_ptr(), b_in.data_ptr()
-    w1p_all, w2p_all, b_dil_all, b_out_all = packs
+    w1p_all, w2p_all, b_dil_all, b_out_all = packs[:4]
     a.w1p_all, a.w2p_all = w1p_all.data_ptr(), w2p_all.data_ptr()
     a.b_dil_all, a.b_out_all = b_dil_all.data_ptr(), b_out_all.data_ptr()
+    if len(packs) >= 6 and packs[4] is not None:
+        a.w1w_all, a.w2w_all = packs[4].data_ptr(), packs[5].data_ptr()
     a.persistent = int(default_persistent() if persistent is None else bool(persistent))
     sync_ws = torch.empty(sync_ws_size(B, T), dtype=torch.int32, device=dev)
     a.sync_ws = sync_ws.data_ptr()

@@ -386,6 +386,79 @@ def test_persistent_stack_bit_identical_to_layer_launches(dev):
             assert torch.equal(xb if L % 2 else xa, x_ref), (B, T, rep)
 
 
+def test_winograd_stack_matches_direct_stack(dev, monkeypatch):
+    """The Winograd F(2,3) persistent kernel (4 GEMMs over output pairs, filter transform folded into the packed
+    weights) against the direct persistent kernel on the same weights: equal to fp32 rounding (not bit for bit: the
+    summation order differs), run-to-run bit-identical, no dependency time-out.  (32, 800, 20) takes the Winograd
+    path by default (more 64-frame tiles than CUs); the small ragged cases force it (odd T, one-frame tail tile)."""
+    from set_amd import ops
+    for (B, T, L, reps) in ((32, 800, 20, 4), (3, 203, 5, 2), (2, 65, 3, 2), (1, 1, 2, 1)):
+        g = torch.Generator().manual_seed(B * 1000 + T)
+        x0 = torch.randn(B, 256, T, generator=g).to(dev)
+        cp = (torch.randn(B, L * 512, T, generator=g) * 0.5).to(dev)
+        dtab = torch.randn(L * 256, 3, generator=g).to(dev)
+        w1 = torch.empty(L, 512 * 768, device=dev)
+        w2 = torch.empty(L, 512 * 256, device=dev)
+        w1w = torch.empty(L, 512 * 256 * 4, device=dev)
+        w2w = torch.empty(L, 512 * 256, device=dev)
+        bd = (torch.randn(L, 512, generator=g) * 0.1).to(dev)
+        bo = (torch.randn(L, 512, generator=g) * 0.1).to(dev)
+        for l in range(L):
+            wd = (torch.randn(512, 256, 3, generator=g) / 27.7).to(dev)
+            wo = (torch.randn(512, 256, 1, generator=g) / 16.0).to(dev)
+            ops.pack_diffnet_layer(wd, wo, w1[l], w2[l])
+            ops.pack_diffnet_layer_wino(wd, wo, w1w[l], w2w[l])
+        packs = (w1, w2, bd, bo, w1w, w2w)
+
+        def run(mode):
+            monkeypatch.setenv("SET_AMD_WINO", mode)
+            xa, xb, skip = x0.clone(), torch.full_like(x0, float("nan")), torch.full_like(x0, float("nan"))
+            ws = ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4, 0, 3, 256 * 3, packs, 1)
+            torch.cuda.synchronize()
+            assert int(ws[1]) == 0, "dependency wait timed out"
+            return (xb if L % 2 else xa).clone(), skip.clone(), int(ws[0])
+
+        x_ref, s_ref, _ = run("0")
+        first = None
+        for rep in range(reps):
+            x, sk, claimed = run("2")
+            assert claimed >= L * B * ((T + 63) // 64)
+            assert _maxdiff(x, x_ref) < 1e-5 * max(1.0, float(x_ref.abs().max())), (B, T)
+            assert _maxdiff(sk, s_ref) < 1e-5 * max(1.0, float(s_ref.abs().max())), (B, T)
+            if first is None:
+                first = (x, sk)
+            assert torch.equal(x, first[0]) and torch.equal(sk, first[1]), (B, T, rep)
+    # dilated stacks never take the Winograd body, even when forced
+    monkeypatch.setenv("SET_AMD_WINO", "2")
+    xa, xb, skip = x0.clone(), torch.empty_like(x0), torch.empty_like(x0)
+    ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4, 0, 3, 256 * 3, packs, 2)
+    monkeypatch.setenv("SET_AMD_WINO", "0")
+    ya, yb, skip2 = x0.clone(), torch.empty_like(x0), torch.empty_like(x0)
+    ops.diffnet_stack(ya, yb, skip2, cp, dtab.data_ptr() + 4, 0, 3, 256 * 3, packs, 2)
+    assert torch.equal(skip, skip2)
+
+
+@pytest.mark.parametrize("case", ["infer_tiny", "infer_pad", "infer_drift100"])
+def test_full_inference_matches_reference_with_winograd_forced(dev, monkeypatch, case):
+    """The parity bar (|dmel| < 1e-4 against the reference's output) with every DiffNet stack pass on the Winograd
+    kernel (small batches would otherwise use the direct kernel)."""
+    monkeypatch.setenv("SET_AMD_WINO", "2")
+    g = load_golden(case)
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"], **m["overrides"])
+    inp, noises = _case_inputs(g, dev)
+    ret = model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"],
+                inp["f0"], inp["uv"], infer=True, noises=noises, persistent=True, **m["flags"])
+    torch.cuda.synchronize()
+    d = _maxdiff(ret["mel_out"], g["mel_out"])
+    print("%s (winograd): max|dmel| = %.3e" % (case, d))
+    assert d < 1e-4
+    monkeypatch.setenv("SET_AMD_WINO", "0")
+    ret0 = model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"],
+                 inp["f0"], inp["uv"], infer=True, noises=noises, persistent=True, **m["flags"])
+    assert _maxdiff(ret["mel_out"], ret0["mel_out"]) < 5e-5
+
+
 def test_loop_persistent_equals_per_layer_launches(dev):
     g = load_golden("infer_pad")
     m = g["meta"]

@@ -20,7 +20,7 @@ find $OUT/prof -name "*kernel_trace.csv" -size +6M -delete
 if [ "${PMC:-0}" = "1" ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/pmc_$c
-    ( cd /tmp && PB=32 PT=800 timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_$c" -o pmc -- python "$OLDPWD/tools/stack_probe.py" > "$OLDPWD/$OUT/pmc_$c.log" 2>&1 )
+    ( cd /tmp && PB=32 PT=800 timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/$OUT/pmc_$c" -o pmc -- python "$OLDPWD/tools/wino_probe.py" > "$OLDPWD/$OUT/pmc_$c.log" 2>&1 )
   done
   python tools/pmc_traffic.py $(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $OUT/traffic_bytes_per_launch.json | tail -12
   find $OUT -name "*kernel_trace.csv" -size +2M -delete
