@@ -135,8 +135,9 @@ def main():
     persistent = bool(ret.get("persistent", 0))
     variant = _lib.lib().set_diffnet_stack_variant(B_PER_GPU // groups, T, model.denoise_fn.dilation_cycle_length, 1)
     stack_kernel = "diffnet_stack_wino_kernel" if variant == 2 else "diffnet_stack_kernel"
-    # the Winograd kernel issues 3/4 of the algorithmic MACs (k=3 conv as F(2,3): 4 instead of 6 multiplies per pair)
-    executed_ratio = (4 * 512 * 256 + 512 * 256) / (512 * 768 + 512 * 256) if (persistent and variant == 2) else 1.0
+    # the Winograd kernel issues 3/4 of the algorithmic MACs (k=3 conv as F(2,3): 4 multiplies per output PAIR and
+    # input channel instead of 6, i.e. 512x512 instead of 512x768 MACs per frame, plus the 512x256 1x1 conv)
+    executed_ratio = (512 * 512 + 512 * 256) / (512 * 768 + 512 * 256) if (persistent and variant == 2) else 1.0
     layers_per_launch = L if persistent else 1
     launch_ms = sum(spans) / len(spans) / (L // layers_per_launch)
     flop_per_launch = FLOP_PER_FRAME_LAYER * (B_PER_GPU / groups) * T * layers_per_launch

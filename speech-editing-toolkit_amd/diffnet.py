@@ -102,7 +102,14 @@ class DiffNet(nn.Module):
                 ops.pack_diffnet_layer(l.dilated_conv.weight, l.output_projection.weight, w1[i], w2[i])
             bd = torch.stack([l.dilated_conv.bias for l in layers]).contiguous()
             bo = torch.stack([l.output_projection.bias for l in layers]).contiguous()
-            self._packs, self._packs_key = (w1, w2, bd, bo), key
+            w1w = w2w = None
+            if self.dilation_cycle_length == 1:  # Winograd F(2,3) images for the persistent stack kernel
+                w1w = torch.empty(L, 512 * 256 * 4, dtype=torch.float32, device=dev)
+                w2w = torch.empty(L, 512 * 256, dtype=torch.float32, device=dev)
+                for i, l in enumerate(layers):
+                    ops.pack_diffnet_layer_wino(l.dilated_conv.weight.detach(), l.output_projection.weight.detach(),
+                                                w1w[i], w2w[i])
+            self._packs, self._packs_key = (w1, w2, bd, bo, w1w, w2w), key
         return self._packs
 
     def step_table(self, t_values):

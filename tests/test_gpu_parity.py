@@ -564,7 +564,7 @@ def test_vocoder_wrapper_spec2wav(dev, tmp_path):
 # ----------------------------------------------------------------------------------------------------
 # BASELINE size (B=32, T=800): size-independent properties + a 2-step oracle check
 # ----------------------------------------------------------------------------------------------------
-def test_full_size_properties(dev):
+def test_full_size_properties(dev, monkeypatch):
     from set_amd import parallel
     B, T, Tt, steps = 32, 800, 100, 2
     model, W = _build_model(dev, "spec_denoiser", 31, steps)
@@ -580,12 +580,21 @@ def test_full_size_properties(dev):
     again = run(di, noises)
     assert torch.equal(full["mel_out"], again["mel_out"])  # deterministic
     assert torch.isfinite(full["mel_out"]).all()
-    # sharding invariance (what the multi-GPU path relies on): rank r of 2 computes rows r::2 bit-identically
+    # sharding invariance (what the multi-GPU path relies on): rank r of 2 computes rows r::2.  B=32 runs the
+    # Winograd stack kernel and a 16-utterance shard the direct one (fewer tiles than CUs), so by default the two
+    # agree to fp32 rounding; with the kernel choice pinned the shard is bit-identical.
     for r in range(2):
         sh = parallel.shard_batch(di, r, 2)
         part = run(sh, noises[:, r::2].contiguous())
-        assert torch.equal(part["mel_out"], full["mel_out"][r::2])
+        assert _maxdiff(part["mel_out"], full["mel_out"][r::2]) < 2e-5
         assert torch.equal(part["mel2ph"], full["mel2ph"][r::2])
+    monkeypatch.setenv("SET_AMD_WINO", "0")
+    full_d = run(di, noises)
+    assert _maxdiff(full_d["mel_out"], full["mel_out"]) < 2e-5
+    for r in range(2):
+        part = run(parallel.shard_batch(di, r, 2), noises[:, r::2].contiguous())
+        assert torch.equal(part["mel_out"], full_d["mel_out"][r::2])
+    monkeypatch.delenv("SET_AMD_WINO")
     # oracle on the first 4 utterances (the CPU finishes this in seconds)
     sub = {k: v[:4] for k, v in inp.items()}
     oret = O.gaussian_diffusion_infer(W, steps, sub, [n[:4] for n in noises])

@@ -14,7 +14,7 @@ def per_kernel(path, counter):
         if r["Counter_Name"] == counter:
             name = r["Kernel_Name"]
             for key in ("diffnet_stack_wino_kernel", "diffnet_stack_kernel", "diffnet_layer_kernel", "conv1d_mfma_kernel"):
-                if key in name:
+                if key in name and "pack_" not in name:
                     acc[key].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
