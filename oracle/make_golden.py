@@ -338,6 +338,57 @@ def hifigan_case(name, h, B, T, wseed, iseed):
     npz(name, meta=np.array(json.dumps(dict(h=h, B=B, T=T, wseed=wseed, iseed=iseed))), mel=mel, wav=wav)
 
 
+def edit_case(hp, name, seed, steps, wseed, vseed, h, **gen):
+    """The reference's SpecDenoiserInfer.forward_model (inference/tts/spec_denoiser.py:63-149) on a synthetic edit
+    request: constructor bypassed (it needs dictionaries, a speaker encoder and checkpoints), `input_to_batch`
+    replaced by the identity, torch.randn replaced by a recording seeded generator (T_new is only known after the
+    duration predictor ran)."""
+    from modules.vocoder.hifigan.hifigan import HifiGanGenerator
+    SDI = ref_import.import_spec_denoiser_infer()
+    model = build_ref_model(hp, steps, dict(residual_layers=20, residual_channels=256, dilation_cycle_length=1))
+    W = load_seeded(model, wseed)
+    voc = HifiGanGenerator(h).eval()
+    Wv = Wt.seeded_weights([(k, tuple(s)) for k, s in manifest_of(voc)], vseed)
+    voc.load_state_dict(Wv, strict=True)
+    inf = object.__new__(SDI.SpecDenoiserInfer)
+    inf.hparams, inf.device, inf.model, inf.vocoder = hp, "cpu", model, voc
+    inf.input_to_batch = lambda item: item
+    sample = Wt.synthetic_edit_sample(seed, **gen)
+    gen_ = torch.Generator().manual_seed(seed + 1)
+    rec = []
+    real = torch.randn
+
+    def fake(*shape, **kw):
+        shp = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else shape
+        t = real(tuple(shp), generator=gen_)
+        rec.append(t.clone())
+        return t
+
+    ref_in = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample.items()}
+    torch.randn = fake
+    try:
+        wav_out, wav_gt, mel_out, mel_gt, masked_mel_out, masked_mel_gt = inf.forward_model(ref_in)
+    finally:
+        torch.randn = real
+    assert len(rec) == steps + 1
+    o = O.edit_forward_model(W, Wv, h, steps, sample, rec)
+    T_new = mel_out.shape[0]
+    assert o["edited_mel2ph"].shape[1] == T_new
+    d = {k: float(np.abs(o[k].numpy() - v).max()) for k, v in
+         (("wav_out", wav_out), ("wav_gt", wav_gt), ("mel_out", mel_out), ("mel_gt", mel_gt),
+          ("masked_mel_out", masked_mel_out), ("masked_mel_gt", masked_mel_gt))}
+    print("  [%s] T %d -> %d, head %d tail %d; oracle vs reference: %s" % (
+        name, sample["mel"].shape[1], T_new, o["head_idx"], o["tail_idx"],
+        " ".join("%s %.1e" % kv for kv in d.items())))
+    assert max(d.values()) < 2e-5, "oracle restatement deviates from the reference"
+    assert np.array_equal(masked_mel_out, o["masked_mel_out"].numpy())  # pure splicing: bit exact
+    npz(name, meta=np.array(json.dumps(dict(seed=seed, steps=steps, wseed=wseed, vseed=vseed, h=h, gen=gen))),
+        wav_out=wav_out, wav_gt=wav_gt, mel_out=mel_out, masked_mel_out=masked_mel_out, masked_mel_gt=masked_mel_gt,
+        noises=torch.stack(rec), edited_mel2ph=o["edited_mel2ph"], pred_mel2ph=o["pred_mel2ph"],
+        masked_dur=o["masked_dur"], dur_pred=o["dur_pred"], edited_f0=o["edited_f0"], edited_uv=o["edited_uv"],
+        time_mel_masks=o["time_mel_masks"], pitch=o["pitch"], head_tail=np.array([o["head_idx"], o["tail_idx"]]))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     hp = ref_import.install(timesteps=4)
@@ -373,7 +424,39 @@ def main():
     hifigan_case("hifigan_tiny", Wt.HIFIGAN_TINY, B=2, T=24, wseed=21, iseed=201)
     hifigan_case("hifigan_tiny_rb2", Wt.HIFIGAN_TINY_RB2, B=1, T=20, wseed=22, iseed=202)
     hifigan_case("hifigan_v1", Wt.HIFIGAN_V1, B=1, T=12, wseed=23, iseed=203)
+    edit_cases(hp)
+
+
+def region_helper_cases():
+    """inference/tts/infer_utils.py:29-53 (pure Python): input/output pairs of the reference's own functions."""
+    from inference.tts.infer_utils import get_words_region_from_origintxt_region, parse_region_list_from_str
+    strs = ["[3,4]", "[7,7][2,3]", "[1,1] [10,12]", "[0,3][4,5]", "", "[12,15][3,4][8,8]"]
+    word_lists = [
+        (["<BOS>", "this", "is", "|", "a", "test", ",", "okay", "<EOS>"], [[2, 3]]),
+        (["<BOS>", "one", "|", "two", "|", "three", "|", "four", "<EOS>"], [[1, 1], [3, 4]]),
+        (["hello", "world"], [[2, 2]]),
+        (["<BOS>", "a", "|", "b", "!", "c", "<pad>", "d"], [[2, 4]]),
+    ]
+    out = {"parse": [[s_, parse_region_list_from_str(s_)] for s_ in strs],
+           "words_region": [[w, r, get_words_region_from_origintxt_region(w, r)] for w, r in word_lists]}
+    with open(os.path.join(GOLD, "edit_regions.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote edit_regions.json")
+
+
+def edit_cases(hp):
+    region_helper_cases()
+    edit_case(hp, "edit_mid", seed=5, steps=4, wseed=31, vseed=21, h=Wt.HIFIGAN_TINY)
+    edit_case(hp, "edit_longer", seed=6, steps=3, wseed=32, vseed=21, h=Wt.HIFIGAN_TINY, n_words=8, region=(2, 3),
+              n_edited_words=5, max_dur=9)
+    edit_case(hp, "edit_end", seed=7, steps=2, wseed=33, vseed=21, h=Wt.HIFIGAN_TINY, n_words=5, region=(5, 5),
+              n_edited_words=2)
+    edit_case(hp, "edit_start", seed=9, steps=2, wseed=34, vseed=21, h=Wt.HIFIGAN_TINY, n_words=5, region=(1, 2),
+              n_edited_words=3)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "edit":  # regenerate only the edit_* cases
+        edit_cases(ref_import.install(timesteps=4))
+    else:
+        main()

@@ -370,6 +370,121 @@ def gaussian_diffusion_train(W, timesteps, inputs, t, noise, dilation_cycle_leng
 # --------------------------------------------------------------------------
 # a17: HiFi-GAN generator forward
 # --------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------
+# caller side of inference: the edit bookkeeping in front of the hot path
+# ---------------------------------------------------------------------------------------------
+def parse_region_list_from_str(region_str):
+    """inference/tts/infer_utils.py:47-53: "[3,4][7,7]" -> [[3,4],[7,7]] sorted by start (1-based, no leading 0)."""
+    import re
+    found = re.findall(r"\[([1-9]\d*),([1-9]\d*)]", region_str)
+    return sorted([[int(a), int(b)] for a, b in found], key=lambda r: r[0])
+
+
+def words_region_from_text_region(words, region_list, is_skipped):
+    """inference/tts/infer_utils.py:29-44: map regions counted in real words to positions in the word list that
+    still contains boundary tokens (`is_skipped(word)`: silence tokens among '|', '<BOS>', '<pad>')."""
+    assert len(region_list) >= 1
+    out = [[0, 0] for _ in region_list]
+    word_id, rid = 0, 0
+    for i, w in enumerate(words):
+        if is_skipped(w):
+            continue
+        word_id += 1
+        if word_id == region_list[rid][0]:
+            out[rid][0] = i + 1
+        if word_id == region_list[rid][1]:
+            out[rid][1] = i + 1
+            rid += 1
+        if rid == len(region_list):
+            break
+    return out
+
+
+def edit_plan_durations(sample):
+    """inference/tts/spec_denoiser.py:83-96 (integer part): ground-truth durations of the untouched head / tail
+    phonemes laid over the EDITED phoneme sequence, and the frame mask of the edited words in the original."""
+    ph2word, e_ph2word, dur = sample["ph2word"], sample["edited_ph2word"], sample["dur"]
+    w0, w1 = sample["words_region"][0]
+    masked_dur = torch.zeros_like(e_ph2word)
+    n_head = int((ph2word < w0).sum())
+    masked_dur[:, :n_head] = dur[:, :n_head]
+    if int(ph2word.max()) > w1:
+        n_tail = int((ph2word > w1).sum())
+        masked_dur[:, -n_tail:] = dur[:, -n_tail:]
+    in_region = (sample["mel2word"] >= w0) & (sample["mel2word"] <= w1)
+    return masked_dur, in_region
+
+
+def edit_splice(sample, pred_mel2ph):
+    """inference/tts/spec_denoiser.py:97-135: splice the predicted alignment of the new words between the original
+    head and tail (tail phoneme indices re-based to `max(new) + 2`, :110), and build the masked reference mel,
+    f0 / uv and the time mask of the edited utterance.  All integer work; returns a dict of tensors."""
+    w0, w1 = sample["words_region"][0]
+    c0, c1 = sample["edited_words_region"][0]
+    mel, mel2ph, mel2word = sample["mel"], sample["mel2ph"], sample["mel2word"]
+    f0, uv = sample["f0"], sample["uv"]
+    e_ph2word = sample["edited_ph2word"][0]
+    e_mel2word = e_ph2word[pred_mel2ph[0] - 1][None, :]  # index -1 (p == 0) wraps to the last phoneme, as upstream
+    sel = (e_mel2word >= c0) & (e_mel2word <= c1)
+    in_region = (mel2word >= w0) & (mel2word <= w1)
+    delta = int(sel.sum()) - int(in_region.sum())
+    head = int((mel2word < w0).sum())
+    tail = int((mel2word <= w1).sum()) + delta
+    T_new = mel2ph.shape[1] + delta
+    new_m2p = torch.zeros(1, T_new, dtype=torch.int64)
+    new_m2p[:, :head] = mel2ph[:, :head]
+    new_m2p[:, head:tail] = pred_mel2ph[sel]
+    after = mel2word > w1
+    if int(mel2word.max()) > w1:
+        tv = mel2ph[after]
+        new_m2p[:, tail:] = tv - tv.min() + pred_mel2ph[sel].max() + 2
+    ref = torch.zeros(1, T_new, mel.shape[2])
+    ref[:, :head] = mel[:, :head]
+    ref[:, tail:] = mel[after]
+    nf0, nuv = torch.zeros(1, T_new), torch.zeros(1, T_new)
+    nf0[:, :head], nuv[:, :head] = f0[:, :head], uv[:, :head]
+    nf0[:, tail:], nuv[:, tail:] = f0[after], uv[after]
+    tmask = torch.zeros(1, T_new, 1)
+    tmask[:, head:tail] = 1.0
+    return {"mel2ph": new_m2p, "ref_mels": ref, "f0": nf0, "uv": nuv, "time_mel_masks": tmask,
+            "head_idx": head, "tail_idx": tail, "length_edited": delta}
+
+
+def edit_forward_model(W, Wv, h, timesteps, sample, noises):
+    """SpecDenoiserInfer.forward_model (inference/tts/spec_denoiser.py:63-149) on an already batched sample, with
+    explicit noise: duration prediction on the edited text with the head/tail ground-truth durations embedded,
+    splice, masked diffusion inference with use_pred_pitch, paste, vocode.  `noises` is a list (x_T, eps...) or a
+    callable T_new -> list.  Returns the upstream 6-tuple plus the integer intermediates."""
+    p = "fs."
+    txt = sample["edited_txt_tokens"]
+    masked_dur, in_region = edit_plan_durations(sample)
+    enc = text_encoder(W, txt, p + "encoder.")
+    src_nonpad = (txt > 0).float()[:, :, None]
+    style = F.linear(sample["spk_embed"], W[p + "spk_embed_proj.weight"], W[p + "spk_embed_proj.bias"])[:, None, :]
+    dur_inp = (enc + style) * src_nonpad
+    dur_inp = dur_inp + F.embedding(masked_dur, W[p + "dur_embed.weight"], padding_idx=0)  # fs.py:141-142
+    src_padding = txt == 0
+    dur = duration_predictor(W, dur_inp, src_padding, p + "dur_predictor.")
+    pred_mel2ph = length_regulator(dur, src_padding)
+    sp = edit_splice(sample, pred_mel2ph)
+    inputs = {"txt_tokens": txt, "time_mel_masks": sp["time_mel_masks"], "mel2ph": sp["mel2ph"],
+              "spk_embed": sample["spk_embed"], "ref_mels": sp["ref_mels"], "f0": sp["f0"], "uv": sp["uv"]}
+    if callable(noises):
+        noises = noises(sp["mel2ph"].shape[1])
+    ret = gaussian_diffusion_infer(W, timesteps, inputs, noises, use_pred_pitch=True)
+    m = sp["time_mel_masks"]
+    mel_out = ret["mel_out"] * m + sp["ref_mels"] * (1 - m)
+    wav_out = hifigan_forward(Wv, h, mel_out.transpose(1, 2))[:, 0]
+    wav_gt = hifigan_forward(Wv, h, sample["mel"].transpose(1, 2))[:, 0]
+    masked_mel_gt = sample["mel"] * in_region.long()[:, :, None]
+    return {"wav_out": wav_out[0], "wav_gt": wav_gt[0], "mel_out": mel_out[0], "mel_gt": sample["mel"][0],
+            "masked_mel_out": sp["ref_mels"][0], "masked_mel_gt": masked_mel_gt[0],
+            "masked_dur": masked_dur, "dur_pred": dur, "pred_mel2ph": pred_mel2ph, "edited_mel2ph": sp["mel2ph"],
+            "edited_f0": sp["f0"], "edited_uv": sp["uv"], "time_mel_masks": sp["time_mel_masks"],
+            "head_idx": sp["head_idx"], "tail_idx": sp["tail_idx"], "model_mel_out": ret["mel_out"],
+            "pitch": ret["pitch"]}
+
+
 def weight_norm_fold(g, v):
     """torch.nn.utils.weight_norm (dim=0): w = g * v / ||v||, norm over all dims but 0."""
     n = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))

@@ -81,3 +81,21 @@ def install(timesteps=None, overrides=None):
     if overrides:
         hparams.update(overrides)
     return hparams
+
+
+def import_spec_denoiser_infer():
+    """The reference's inference caller, inference/tts/spec_denoiser.py.  It imports its own base class and helpers
+    through a package name that is absent from the repository (`inference_acl.tts.*`, :13-14); alias that name to
+    the modules that ARE in the repository (`inference.tts.base_tts_infer`, `inference.tts.infer_utils`)."""
+    import importlib
+    base = importlib.import_module("inference.tts.base_tts_infer")
+    utils_ = importlib.import_module("inference.tts.infer_utils")
+    pkg = types.ModuleType("inference_acl")
+    pkg.__path__ = []
+    sub = types.ModuleType("inference_acl.tts")
+    sub.__path__ = []
+    sys.modules.setdefault("inference_acl", pkg)
+    sys.modules.setdefault("inference_acl.tts", sub)
+    sys.modules.setdefault("inference_acl.tts.base_tts_infer", base)
+    sys.modules.setdefault("inference_acl.tts.infer_utils", utils_)
+    return importlib.import_module("inference.tts.spec_denoiser")

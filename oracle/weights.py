@@ -105,6 +105,50 @@ def synthetic_inputs(B, T, T_txt, seed=1234, pad_tail=False, n_tokens=80):
     }
 
 
+def synthetic_edit_sample(seed, n_words=6, region=(3, 4), n_edited_words=3, max_ph=3, max_dur=6, n_tokens=80):
+    """One utterance + an edit request in the batch format of the reference's
+    SpecDenoiserInfer.input_to_batch (inference/tts/spec_denoiser.py:198-248), synthetic:
+    words 1..n_words with 1..max_ph phonemes each and 1..max_dur frames per phoneme, a trailing
+    zero-duration end token that belongs to the last word (so the reference's `+2` re-indexing of the
+    tail, :110, stays inside the edited token sequence); words region[0]..region[1] (1-based,
+    inclusive) are replaced by `n_edited_words` new words.  numpy default_rng(seed)."""
+    rng = np.random.default_rng(seed)
+    w0, w1 = region
+    assert 1 <= w0 <= w1 <= n_words
+
+    def phones_of(nw):
+        return [int(rng.integers(1, max_ph + 1)) for _ in range(nw)]
+
+    cnt = phones_of(n_words)
+    ph2word = [w + 1 for w, c in enumerate(cnt) for _ in range(c)] + [n_words]
+    dur = [int(rng.integers(1, max_dur + 1)) for _ in range(sum(cnt))] + [0]
+    mel2ph = [i + 1 for i, d in enumerate(dur) for _ in range(d)]
+    mel2word = [ph2word[p - 1] for p in mel2ph]
+    T = len(mel2ph)
+    ecnt = cnt[:w0 - 1] + phones_of(n_edited_words) + cnt[w1:]
+    n_ew = len(ecnt)
+    edited_ph2word = [w + 1 for w, c in enumerate(ecnt) for _ in range(c)] + [n_ew]
+    c0, c1 = w0, w0 + n_edited_words - 1
+    Te = len(edited_ph2word)
+    mel = np.clip(rng.normal(-3.0, 1.5, size=(1, T, 80)), -6.0, 1.5).astype(np.float32)
+    f0 = rng.uniform(6.5, 9.2, size=(1, T)).astype(np.float32)
+    uv = (rng.uniform(size=(1, T)) < 0.3).astype(np.float32)
+    f0[uv > 0] = 0.0
+    return {
+        "edited_txt_tokens": torch.from_numpy(rng.integers(1, n_tokens, size=(1, Te), dtype=np.int64)),
+        "mel": torch.from_numpy(mel),
+        "mel2ph": torch.tensor([mel2ph], dtype=torch.int64),
+        "mel2word": torch.tensor([mel2word], dtype=torch.int64),
+        "dur": torch.tensor([dur], dtype=torch.int64),
+        "ph2word": torch.tensor([ph2word], dtype=torch.int64),
+        "edited_ph2word": torch.tensor([edited_ph2word], dtype=torch.int64),
+        "f0": torch.from_numpy(f0), "uv": torch.from_numpy(uv),
+        "words_region": [[w0, w1]], "edited_words_region": [[c0, c1]],
+        "spk_embed": torch.from_numpy((rng.standard_normal(size=(1, 256)) / 16.0).astype(np.float32)),
+        "text": ["synthetic"], "item_name": ["edit_%d" % seed],
+    }
+
+
 def synthetic_noises(B, T, steps, seed=4321, M=80):
     """x_T followed by one eps per executed step (i = steps-1 .. 0)."""
     rng = np.random.default_rng(seed)

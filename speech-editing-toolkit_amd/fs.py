@@ -234,6 +234,22 @@ class FastSpeech(nn.Module):
                                               kernel_size=hp["predictor_kernel"])
         self._w_spk = _cw(self.spk_embed_proj)
 
+    def predict_alignment(self, txt_tokens, spk_embed, masked_dur):
+        """The duration half of the model on its own, as the inference caller uses it (inference/tts/
+        spec_denoiser.py:81-96): `forward_dur(dur_inp, ..., masked_dur=masked_dur, use_pred_mel2ph=True)`
+        (fs.py:123-151) with `dur_inp = (encoder(txt) + style) * nonpadding`.  `masked_dur` int64 [B,T_txt] holds
+        the known durations (0 = to be predicted).  Returns (dur fp32 [B,T_txt], mel2ph int64 [B,T_pred])."""
+        F = _backend()
+        B = txt_tokens.shape[0]
+        enc = self.encoder.run_tokens(txt_tokens)
+        src_nonpad = F.index_mask(txt_tokens)
+        style = F.conv1d(spk_embed.reshape(B, 256, 1).contiguous(), self._w_spk, self.spk_embed_proj.bias)
+        dur_inp = F.add_chan_mask(enc, style.reshape(B, self.hidden_size), src_nonpad)
+        dur_inp = F.embedding_bct(masked_dur.contiguous(), self.dur_embed.weight, out=dur_inp, accumulate=True,
+                                  padding_idx=0)
+        dur = self.dur_predictor.run(dur_inp, src_nonpad, 0)
+        return dur, self.length_regulator(dur.detach(), txt_tokens)
+
     def forward(self, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv, spk_id=None, skip_decoder=True,
                 infer=False, use_pred_mel2ph=False, use_pred_pitch=False, **kwargs):
         """Returns ret with `decoder_inp_bct` [B,H,T] (internal layout) next to the reference's keys
