@@ -70,3 +70,79 @@ def bucketed_all_reduce_sum_(flat, bucket_elems):
     for w in works:
         w.wait()
     return dist.get_world_size()
+
+
+class GradBucketer:
+    """Overlap the data-parallel gradient exchange with backward ("bucketed and overlapped").
+
+    The gradients live in ONE flat buffer in parameter order (training.FlatAdamW); backward produces them roughly in
+    reverse order, so the buffer is cut into contiguous buckets from the END and every parameter gets a
+    post-accumulate-grad hook: when the last gradient of a bucket has been accumulated, that bucket's SUM all-reduce
+    is launched asynchronously (RCCL runs it on its own stream behind an event on the compute stream, i.e. under the
+    rest of backward).  `finish()` launches whatever never fired (parameters without gradients: fs.decoder /
+    fs.mel_out stay zero) and waits.  Few large buckets: xGMI rings are per-link bound, small messages waste them."""
+
+    def __init__(self, params, flat_g, bucket_elems):
+        self.flat_g = flat_g
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.buckets = []      # [start, end) element ranges, last bucket of the buffer first
+        self.launch_log = []   # bucket ids in launch order, "hook" / "finish" (diagnostics + tests)
+        self._pending, self._works, self._handles = [], {}, []
+        if not self.enabled:
+            return
+        offs, off = [], 0
+        for p in params:
+            offs.append((off, off + p.numel()))
+            off += p.numel()
+        # cut from the end so the first gradients to arrive complete a bucket early
+        owner = [0] * len(params)
+        end, count, cur = off, 0, 0
+        for i in range(len(params) - 1, -1, -1):
+            owner[i] = cur
+            count += params[i].numel()
+            if count >= bucket_elems or i == 0:
+                self.buckets.append((offs[i][0], end))
+                end, count, cur = offs[i][0], 0, cur + 1
+        if self.buckets and self.buckets[0][1] < flat_g.numel():  # padding tail of the flat buffer rides with bucket 0
+            self.buckets[0] = (self.buckets[0][0], flat_g.numel())
+        self._members = [0] * len(self.buckets)
+        for i, p in enumerate(params):
+            if p.requires_grad:
+                self._members[owner[i]] += 1
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(owner[i])))
+        self.reset()
+
+    def _make_hook(self, b):
+        def hook(_param):
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b, "hook")
+        return hook
+
+    def _launch(self, b, why):
+        s, e = self.buckets[b]
+        self._works[b] = dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True)
+        self.launch_log.append((b, why))
+
+    def reset(self):
+        """Call before every backward."""
+        if self.enabled:
+            self._pending = list(self._members)
+            self._works = {}
+            self.launch_log = []
+
+    def finish(self):
+        """All buckets reduced (SUM) when this returns; returns the world size (1 when not distributed)."""
+        if not self.enabled:
+            return 1
+        for b in range(len(self.buckets)):
+            if b not in self._works:
+                self._launch(b, "finish")
+        for w in self._works.values():
+            w.wait()
+        return dist.get_world_size()
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

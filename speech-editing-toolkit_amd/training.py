@@ -2,7 +2,8 @@
 
 * parameters and gradients live in two flat fp32 buffers (each nn.Parameter / .grad is a view), so the optimizer is
   ONE fused kernel (`set_adamw`: clip_grad_norm_ + AdamW, torch semantics) and the data-parallel gradient exchange is
-  a few large RCCL all-reduces over xGMI instead of one per tensor (the reference relies on torch DDP's 25 MB
+  a few large RCCL all-reduces over xGMI, launched from autograd hooks so they overlap with the rest of backward
+  (`parallel.GradBucketer`), instead of one per tensor (the reference relies on torch DDP's 25 MB
   buckets, utils/commons/trainer.py:475-479; fs.decoder / fs.mel_out never receive gradients there either);
 * learning rate = WarmupSchedule (utils/nn/schedulers.py:42-57): lr * min(step / warmup, 1), floored at 1e-7.
 """
@@ -34,6 +35,8 @@ class FlatAdamW:
         self.lr0, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.clip, self.warmup = clip_grad_norm, warmup_updates
         self.bucket = int(bucket_mb * (1 << 20) // 4)
+        # gradient exchange overlapped with backward: buckets launch from autograd hooks (no-op when world == 1)
+        self.bucketer = parallel.GradBucketer(self.params, self.flat_g, self.bucket)
         self.num_updates = 0
         ops.bump_weights_epoch()
 
@@ -43,15 +46,17 @@ class FlatAdamW:
 
     def zero_grad(self):
         self.flat_g.zero_()
+        self.bucketer.reset()
         for p in self.params:  # autograd may have re-pointed .grad; restore the views
             if p.grad is None or p.grad.data_ptr() < self.flat_g.data_ptr() or \
                     p.grad.data_ptr() >= self.flat_g.data_ptr() + 4 * self.flat_g.numel():
                 raise RuntimeError("a .grad left the flat gradient buffer")
 
     def step(self):
-        """gradient all-reduce (SUM, few large buckets) -> clip_grad_norm_(max_norm) + AdamW on the mean gradient,
-        then the warm-up schedule (base_task.py:129-137)."""
-        world = parallel.bucketed_all_reduce_sum_(self.flat_g, self.bucket)
+        """gradient all-reduce (SUM, few large buckets, launched from autograd hooks while backward was still running;
+        whatever is left goes now) -> clip_grad_norm_(max_norm) + AdamW on the mean gradient, then the warm-up
+        schedule (base_task.py:129-137)."""
+        world = self.bucketer.finish()
         sumsq = A.grad_sumsq(self.flat_g) if self.clip > 0 else None
         lr = self.lr_at(self.num_updates)
         self.num_updates += 1

@@ -54,6 +54,80 @@ def test_shard_and_reduce_world2():
     assert t0 == t1 == 2.0 and tot0 == tot1 == 6.0
 
 
+def _toy(seed=0):
+    torch.manual_seed(seed)
+    layers = [torch.nn.Linear(8, 8) for _ in range(5)]
+    unused = torch.nn.Linear(8, 3)  # never part of the graph (like fs.decoder / fs.mel_out in the reference)
+    params = [p for l in layers for p in l.parameters()] + list(unused.parameters())
+    n = sum(p.numel() for p in params)
+    flat_g = torch.zeros((n + 255) // 256 * 256)
+    off = 0
+    for p in params:
+        p.grad = flat_g[off:off + p.numel()].view(p.shape)
+        off += p.numel()
+
+    def loss_of(x):
+        h = x
+        for l in layers:
+            h = torch.tanh(l(h))
+        return (h * h).sum()
+
+    return params, flat_g, loss_of
+
+
+def _bucket_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import set_amd  # noqa: F401
+    from set_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    params, flat_g, loss_of = _toy()
+    bk = parallel.GradBucketer(params, flat_g, bucket_elems=100)  # 72-element layers -> several buckets
+    xs = [torch.randn(4, 8, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    logs = []
+    for it in range(2):  # second iteration: reset() re-arms the hooks
+        flat_g.zero_()
+        bk.reset()
+        loss_of(xs[rank]).backward()
+        n_hook = sum(1 for _, why in bk.launch_log if why == "hook")
+        assert bk.finish() == world
+        logs.append((list(bk.launch_log), n_hook))
+    got = flat_g.clone()
+    # expected: sum over ranks of the local gradients, computed without any hook machinery
+    want = torch.zeros_like(flat_g)
+    for r in range(world):
+        p2, g2, loss2 = _toy()
+        loss2(xs[r]).backward()
+        want += g2
+    q.put((rank, float((got - want).abs().max()), logs, [b for b in bk.buckets], all(p.grad.data_ptr() >= flat_g.data_ptr() for p in params)))
+    dist.destroy_process_group()
+
+
+def test_grad_bucketer_overlaps_and_matches_sum_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, logs, buckets, in_flat in res:
+        assert err < 1e-6 and in_flat
+        assert len(buckets) >= 3 and buckets[0][1] % 256 == 0          # several buckets, padding rides with the last range
+        assert sorted(b for b in buckets) == sorted(buckets) and all(s < e for s, e in buckets)
+        for log, n_hook in logs:
+            assert n_hook >= 2                                          # launched from autograd hooks, i.e. during backward
+            assert sorted(b for b, _ in log) == list(range(len(buckets)))  # every bucket exactly once
+            assert any(why == "finish" for _, why in log)               # the bucket holding the unused parameters
+    assert res[0][2] == res[1][2]                                       # same launch order on both ranks
+
+
 def test_single_process_is_identity():
     import set_amd  # noqa: F401
     from set_amd import parallel
@@ -62,3 +136,5 @@ def test_single_process_is_identity():
     assert parallel.max_over_ranks(3.5) == 3.5
     f = torch.ones(5)
     assert parallel.bucketed_all_reduce_sum_(f, 2) == 1 and torch.equal(f, torch.ones(5))
+    bk = parallel.GradBucketer([torch.nn.Parameter(torch.ones(5))], f, 2)
+    assert not bk.enabled and bk.finish() == 1
