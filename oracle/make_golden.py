@@ -427,6 +427,91 @@ def main():
     edit_cases(hp)
 
 
+def build_ref_campnet(hp):
+    import yaml
+    with open(os.path.join(ref_import.REF_ROOT, "egs", "campnet.yaml")) as f:
+        hp.update(yaml.safe_load(f))
+    from modules.speech_editing.campnet.campnet import CampNet
+    return CampNet(80, 100, hp).eval()
+
+
+def campnet_case(hp, name, B, T, T_txt, wseed, iseed, pad_tail=True):
+    """Reference CampNet forward (egs/campnet.yaml: dropout 0, so train == eval arithmetic) + the reference's own
+    mel losses + autograd; oracle cross-check of outputs, losses and every parameter gradient."""
+    from tasks.tts.speech_base import SpeechBaseTask
+
+    class FakeTask:
+        l1_loss = SpeechBaseTask.l1_loss
+        ssim_loss = SpeechBaseTask.ssim_loss
+        add_mel_loss = SpeechBaseTask.add_mel_loss
+
+    task = FakeTask()
+    task.mel_losses = {"l1": 0.5, "ssim": 0.5}
+    model = build_ref_campnet(hp)
+    man = manifest_of(model)
+    with open(os.path.join(GOLD, "manifest_campnet.json"), "w") as f:
+        json.dump(man, f)
+    W = load_seeded(model, wseed)
+    with torch.no_grad():  # the reference initialises these to exactly 0 / 1; give them real values
+        rng = np.random.default_rng(wseed + 1)
+        W["mask_emb"] = torch.from_numpy(rng.normal(0, 0.5, size=(1, 1, 80)).astype(np.float32))
+        W["decoder_coarse.pos_embed_alpha"] = torch.tensor([0.7], dtype=torch.float32)
+        model.load_state_dict(W, strict=False)
+    inp = Wt.synthetic_inputs(B, T, T_txt, seed=iseed, pad_tail=pad_tail)
+    if pad_tail:
+        inp["txt_tokens"][0, -3:] = 0  # padded phonemes too (key padding masks of both attentions)
+    txt, mels, tm = inp["txt_tokens"], inp["ref_mels"], inp["time_mel_masks"]
+    with torch.enable_grad():
+        out = model(txt, mels=mels, time_mel_masks=tm, infer=False, global_step=0)
+        losses = {}
+        task.add_mel_loss(out["mel_out_coarse"] * tm, mels * tm, losses, postfix="_coarse")
+        task.add_mel_loss(out["mel_out_fine"] * tm, mels * tm, losses, postfix="_fine")
+        total = sum(losses.values())
+        total.backward()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    Wg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in W.items()}
+    with torch.enable_grad():
+        olosses, oout = O.campnet_losses(Wg, txt, mels, tm)
+        sum(olosses.values()).backward()
+    d = {k: maxdiff(oout[k], out[k]) for k in ("mel_out_coarse", "mel_out_fine", "attn")}
+    for k in losses:
+        assert abs(float(losses[k]) - float(olosses[k])) < 1e-5 * max(1.0, abs(float(losses[k]))), k
+    worst, n_none = 0.0, 0
+    for k, g in grads.items():
+        og = Wg[k].grad
+        assert (g is None) == (og is None), k
+        if g is None:
+            n_none += 1
+        else:
+            worst = max(worst, float((g - og).abs().max()) / (float(g.abs().max()) + 1e-12))
+    print("  [%s] oracle vs reference: %s; losses %s; worst rel grad dev %.2e (%d params without grad)" % (
+        name, " ".join("%s %.1e" % kv for kv in d.items()),
+        " ".join("%s=%.4f" % (k, float(v)) for k, v in losses.items()), worst, n_none))
+    assert max(d.values()) < 2e-5 and worst < 1e-3
+    names = [k for k, _ in model.named_parameters()]
+    norms = np.array([float(grads[k].norm()) if grads[k] is not None else -1.0 for k in names], dtype=np.float64)
+    keep = ["mask_emb", "decoder_coarse.pos_embed_alpha", "encoder.embed_tokens.weight",
+            "encoder.layers.0.op.self_attn.in_proj_weight", "encoder.layers.2.op.ffn.ffn_2.bias",
+            "decoder_coarse.layers.0.op.encoder_attn.in_proj_weight", "decoder_coarse.layers.5.op.self_attn.out_proj.weight",
+            "decoder_coarse.layers.3.op.ffn.ffn_1.1.bias", "decoder_coarse.layer_norm.weight", "mel_out_coarse.weight",
+            "mel_out_fine.weight", "mel_encoder.fc_out.bias", "decoder_fine.res_blocks.4.blocks.1.4.bias"]
+    out_np = dict(meta=np.array(json.dumps(dict(B=B, T=T, T_txt=T_txt, wseed=wseed, iseed=iseed, pad_tail=pad_tail,
+                                                param_names=names))),
+                  mask_emb=W["mask_emb"], pos_embed_alpha=W["decoder_coarse.pos_embed_alpha"],
+                  txt_tokens=txt, mel_out_coarse=out["mel_out_coarse"], mel_out_fine=out["mel_out_fine"],
+                  attn=out["attn"], grad_norms=norms, total=total.detach(),
+                  **{"loss_" + k: v.detach() for k, v in losses.items()})
+    for k in keep:
+        g = grads[k]
+        out_np["grad::" + k] = g if g.numel() <= 30000 else g.reshape(-1)[:30000]
+    npz(name, **out_np)
+
+
+def campnet_cases(hp):
+    campnet_case(hp, "campnet_tiny", B=2, T=48, T_txt=12, wseed=41, iseed=301)
+    campnet_case(hp, "campnet_ragged", B=3, T=77, T_txt=19, wseed=42, iseed=302)
+
+
 def region_helper_cases():
     """inference/tts/infer_utils.py:29-53 (pure Python): input/output pairs of the reference's own functions."""
     from inference.tts.infer_utils import get_words_region_from_origintxt_region, parse_region_list_from_str
@@ -458,5 +543,7 @@ def edit_cases(hp):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "edit":  # regenerate only the edit_* cases
         edit_cases(ref_import.install(timesteps=4))
+    elif len(sys.argv) > 1 and sys.argv[1] == "campnet":
+        campnet_cases(ref_import.install(timesteps=4))
     else:
         main()

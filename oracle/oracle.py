@@ -485,6 +485,149 @@ def edit_forward_model(W, Wv, h, timesteps, sample, noises):
             "pitch": ret["pitch"]}
 
 
+# ---------------------------------------------------------------------------------------------
+# CampNet: masked-mel transformer, coarse + fine decoder
+# ---------------------------------------------------------------------------------------------
+def sinusoid_table(n, dim, padding_idx=0):
+    """modules/speech_editing/commons/transformer.py:31-48 (tensor2tensor flavour: [sin | cos], row padding_idx = 0)."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    e = torch.exp(torch.arange(half, dtype=torch.float) * -e)
+    e = torch.arange(n, dtype=torch.float).unsqueeze(1) * e.unsqueeze(0)
+    e = torch.cat([torch.sin(e), torch.cos(e)], dim=1).view(n, -1)
+    if dim % 2 == 1:
+        e = torch.cat([e, torch.zeros(n, 1)], dim=1)
+    e[padding_idx, :] = 0
+    return e
+
+
+def make_positions(x, padding_idx=0):
+    """utils/nn/seq_utils.py:6-18: 1,2,3.. over the entries != padding_idx, padding_idx elsewhere."""
+    m = x.ne(padding_idx).int()
+    return (torch.cumsum(m, dim=1).type_as(m) * m).long() + padding_idx
+
+
+def positional_embedding(x_first, dim):
+    """transformer.py:50-69: rows of the sinusoid table picked by make_positions(input[..., 0] or tokens)."""
+    pos = make_positions(x_first)
+    tab = sinusoid_table(max(2000, int(pos.max()) + 1), dim)
+    return tab[pos.reshape(-1)].view(x_first.shape[0], x_first.shape[1], dim)
+
+
+def mha(W, p, query, key, n_heads, key_padding_mask=None, fill=float("-inf")):
+    """Multi-head attention, bias-free projections (transformer.py:138-419).  query [Tq,B,H], key=value [Tk,B,H].
+    Self-attention takes torch's F.multi_head_attention_forward (-inf key-padding fill); encoder-decoder attention
+    (static_kv=True) takes the module's own path (:283-410) with a -1e8 fill.  The arithmetic is the same:
+    q = Wq x * d^-1/2, softmax_fp32(q k^T (+fill)) v, out_proj.  Returns (out [Tq,B,H], probs [B,heads,Tq,Tk])."""
+    Tq, B, H = query.shape
+    Tk = key.shape[0]
+    d = H // n_heads
+    w = W[p + "in_proj_weight"]
+    q = F.linear(query, w[:H]) * d ** -0.5
+    k = F.linear(key, w[H:2 * H])
+    v = F.linear(key, w[2 * H:])
+    q = q.contiguous().view(Tq, B * n_heads, d).transpose(0, 1)
+    k = k.contiguous().view(Tk, B * n_heads, d).transpose(0, 1)
+    v = v.contiguous().view(Tk, B * n_heads, d).transpose(0, 1)
+    s = torch.bmm(q, k.transpose(1, 2))
+    if key_padding_mask is not None:
+        s = s.view(B, n_heads, Tq, Tk).masked_fill(key_padding_mask[:, None, None, :], fill).view(B * n_heads, Tq, Tk)
+    pr = F.softmax(s, dim=-1, dtype=torch.float32)
+    o = torch.bmm(pr, v).transpose(0, 1).contiguous().view(Tq, B, H)
+    return F.linear(o, W[p + "out_proj.weight"]), pr.view(B, n_heads, Tq, Tk)
+
+
+def transformer_ffn(W, p, x, k, left_pad):
+    """transformer.py:76-113: conv k (H->4H, SAME or LEFT padding) * k^-1/2 -> GELU -> Linear(4H->H).  x [T,B,H]."""
+    h = x.permute(1, 2, 0)
+    if left_pad:
+        h = F.conv1d(F.pad(h, (k - 1, 0)), W[p + "ffn_1.1.weight"], W[p + "ffn_1.1.bias"])
+    else:
+        h = F.conv1d(h, W[p + "ffn_1.weight"], W[p + "ffn_1.bias"], padding=k // 2)
+    h = F.gelu(h.permute(2, 0, 1) * k ** -0.5)
+    return F.linear(h, W[p + "ffn_2.weight"], W[p + "ffn_2.bias"])
+
+
+def _ln(W, p, x):
+    return F.layer_norm(x, (x.shape[-1],), W[p + "weight"], W[p + "bias"], 1e-5)
+
+
+def campnet_text_encoder(W, txt, n_layers=3, n_heads=2, k=9, p="encoder."):
+    """TransformerEncoder (transformer.py:712-747) on FFTBlocks (:684-709) of EncSALayer (:504-528); dropout 0."""
+    H = W[p + "embed_tokens.weight"].shape[1]
+    pad = txt.eq(0)
+    x = math.sqrt(H) * F.embedding(txt, W[p + "embed_tokens.weight"], padding_idx=0) + positional_embedding(txt, H)
+    keep = 1 - pad.transpose(0, 1).float()[:, :, None]
+    x = x.transpose(0, 1) * keep
+    for i in range(n_layers):
+        q = "%slayers.%d.op." % (p, i)
+        a, _ = mha(W, q + "self_attn.", _ln(W, q + "layer_norm1.", x), _ln(W, q + "layer_norm1.", x), n_heads, pad)
+        x = (x + a) * keep
+        x = (x + transformer_ffn(W, q + "ffn.", _ln(W, q + "layer_norm2.", x), k, False)) * keep
+        x = x * keep
+    x = _ln(W, p + "layer_norm.", x) * keep
+    return x.transpose(0, 1)
+
+
+def campnet_coarse_decoder(W, x, enc_out, n_layers=6, n_heads=2, k=9, p="decoder_coarse."):
+    """TransformerDecoder (transformer.py:750-811) of DecSALayer (:549-609): self-attention WITHOUT any mask (the layer
+    is called without self_attn_padding_mask), encoder-decoder attention with the -1e8 key-padding fill, causal-padded
+    conv FFN.  Returns (x [B,T,H], head-averaged attention of the FIRST layer [B,T,T_txt])."""
+    H = x.shape[-1]
+    enc_pad = enc_out.abs().sum(-1).eq(0)
+    pad = x.abs().sum(-1).eq(0)
+    keep = 1 - pad.transpose(0, 1).float()[:, :, None]
+    x = x + W[p + "pos_embed_alpha"] * positional_embedding(x[..., 0], H)
+    x = x.transpose(0, 1) * keep
+    enc = enc_out.transpose(0, 1)
+    first = None
+    for i in range(n_layers):
+        q = "%slayers.%d.op." % (p, i)
+        h = _ln(W, q + "layer_norm1.", x)
+        a, _ = mha(W, q + "self_attn.", h, h, n_heads, None)
+        x = x + a
+        a, pr = mha(W, q + "encoder_attn.", _ln(W, q + "layer_norm2.", x), enc, n_heads, enc_pad, -1e8)
+        x = x + a
+        x = x + transformer_ffn(W, q + "ffn.", _ln(W, q + "layer_norm3.", x), k, True)
+        x = x * keep
+        if first is None:
+            first = pr.mean(dim=1)
+    x = _ln(W, p + "layer_norm.", x) * keep
+    return x.transpose(0, 1), first
+
+
+def campnet_forward(W, txt, mels, time_mel_masks, k=9):
+    """modules/speech_editing/campnet/campnet.py:42-69.  time_mel_masks [B,T,1]."""
+    src_nonpad = (txt > 0).float()[:, :, None]
+    enc = campnet_text_encoder(W, txt, k=k) * src_nonpad * src_nonpad
+    m = time_mel_masks
+    mel_nonpad = (mels.abs().sum(-1) > 0).float()[:, :, None]
+    x = mel_encoder(W, mels * (1 - m) + W["mask_emb"] * m) * mel_nonpad
+    h, attn = campnet_coarse_decoder(W, x, enc, k=k)
+    coarse = F.linear(h * mel_nonpad, W["mel_out_coarse.weight"]) * mel_nonpad
+    mel_coarse = mels * (1 - m) + coarse * m
+    x = mel_encoder(W, mel_coarse) * mel_nonpad
+    f = conv_blocks(W, "decoder_fine.", x, n_blocks=5, layers_in_block=2, kernel_size=5) * mel_nonpad
+    fine = F.linear(f, W["mel_out_fine.weight"]) * mel_nonpad
+    fine = mel_coarse + fine * m
+    return {"mel_out_coarse": coarse, "mel_out_fine": fine, "attn": attn}
+
+
+def campnet_losses(W, txt, mels, time_mel_masks, lambdas=None):
+    """tasks/speech_editing/campnet.py:50-69: l1 + ssim (mel_losses l1:0.5|ssim:0.5) on the masked coarse and fine
+    predictions; `mel_out` = fine prediction pasted into the original."""
+    lam = lambdas or {"l1": 0.5, "ssim": 0.5}
+    out = campnet_forward(W, txt, mels, time_mel_masks)
+    m = time_mel_masks
+    losses = {}
+    for name in ("coarse", "fine"):
+        pred, tgt = out["mel_out_" + name] * m, mels * m
+        losses["l1_" + name] = l1_loss(pred, tgt) * lam["l1"]
+        losses["ssim_" + name] = ssim_loss(pred, tgt) * lam["ssim"]
+    out["mel_out"] = out["mel_out_fine"] * m + mels * (1 - m)
+    return losses, out
+
+
 def weight_norm_fold(g, v):
     """torch.nn.utils.weight_norm (dim=0): w = g * v / ||v||, norm over all dims but 0."""
     n = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))
