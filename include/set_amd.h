@@ -375,6 +375,44 @@ int set_sumsq(const float *g, float *out, int64_t n, void *stream);
 int set_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,
               float weight_decay, int32_t step, const float *sumsq, float max_norm, float grad_scale, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Attention building blocks (CampNet rows; modules/speech_editing/commons/transformer.py)
+ * ------------------------------------------------------------------------------------------------ */
+/* Strided batched fp32 GEMM on MFMA:  C[b](m,n) = alpha * sum_k A[b](m,k) * B[b](k,n)  (+ C if accumulate).
+ * Batch index b = bo * n_inner + bi; every operand is addressed base + bo*X_bo + bi*X_bi + row*rs + col*cs, so the
+ * heads of a [B][heads*d][T] activation are batches and Q, K^T, V, O need no transposes (transformer.py:344-347,365,
+ * 403-405 do view/transpose/contiguous instead).  The same entry point serves the four gradient products. */
+typedef struct SetBmmArgs {
+    const float *A, *B;
+    float *C;
+    int64_t a_bo, a_bi, a_ms, a_ks;
+    int64_t b_bo, b_bi, b_ks, b_ns;
+    int64_t c_bo, c_bi, c_ms, c_ns;
+    int32_t n_outer, n_inner, M, N, K;
+    float alpha;
+    int32_t accumulate;
+} SetBmmArgs;
+int64_t set_sizeof_bmm_args(void);
+int set_bmm(const SetBmmArgs *args, void *stream);
+/* y[row] = softmax_fp32(x[row]) over `cols`; logits where key_padding_mask[row / rows_per_batch][col] != 0 are
+ * replaced by `fill` first (-inf: F.multi_head_attention_forward; -1e8: transformer.py:381-386).  mask may be NULL. */
+int set_softmax_rows(const float *x, const float *key_padding_mask, float *y, int64_t rows, int32_t cols,
+                     int64_t rows_per_batch, float fill, void *stream);
+/* ds = p * (dp - sum_cols(p * dp)) */
+int set_softmax_rows_bwd(const float *p, const float *dp, float *ds, int64_t rows, int32_t cols, void *stream);
+/* make_positions with padding_idx 0 (utils/nn/seq_utils.py:6-18): pos[b][t] = rank of entry t among the non-zero
+ * entries of row b (1-based), 0 where the entry is 0.  Entries: int64 tokens[B][T], or (tokens == NULL) the fp32
+ * values x[b*x_bs + t] (first channel of a [B][C][T] tensor: transformer.py:795 numbers frames by `x[..., 0]`). */
+int set_make_positions(const int64_t *tokens, const float *x, int64_t x_bs, int64_t *pos, int32_t B, int32_t T,
+                       void *stream);
+/* out[b][i] = mean over heads of p[b][h][i]   (transformer.py:414-416, need_head_weights=False) */
+int set_head_mean(const float *p, float *out, int32_t B, int32_t heads, int64_t n, void *stream);
+/* out[b][c][t] = x[b][c][t]*(1-m[b][t]) + e[c]*m[b][t]   (campnet.py:56 `mels*(1-mask) + mask_emb*mask`) */
+int set_mask_fill_chan(const float *x, const float *e, const float *m, float *out, int32_t B, int32_t C, int32_t T,
+                       void *stream);
+/* out[c] += sum_{b,t} d[b][c][t] * m[b][t]   (gradient of mask_emb) */
+int set_masked_channel_sum(const float *d, const float *m, float *out, int32_t B, int32_t C, int32_t T, void *stream);
+
 /* MFMA fragment-layout self test: runs a 32x32xK product through v_mfma_f32_32x32x2_f32 with the layout
  * this library assumes and returns the max abs error vs an in-kernel scalar reference via *max_err (HOST).
  * Synchronises.  Used by tests to pin the hardware layout assumption. */

@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_PKG, "libset_amd.so")
-SOURCES = ["conv1d.hip", "glue.hip", "diffnet.hip", "train.hip"]
+SOURCES = ["conv1d.hip", "glue.hip", "diffnet.hip", "train.hip", "attention.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
 # constants mirrored from set_amd.h
@@ -86,6 +86,17 @@ class SetDiffnetStackArgs(C.Structure):
     ]
 
 
+class SetBmmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("a_bo", C.c_int64), ("a_bi", C.c_int64), ("a_ms", C.c_int64), ("a_ks", C.c_int64),
+        ("b_bo", C.c_int64), ("b_bi", C.c_int64), ("b_ks", C.c_int64), ("b_ns", C.c_int64),
+        ("c_bo", C.c_int64), ("c_bi", C.c_int64), ("c_ms", C.c_int64), ("c_ns", C.c_int64),
+        ("n_outer", C.c_int32), ("n_inner", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("alpha", C.c_float), ("accumulate", C.c_int32),
+    ]
+
+
 _V, _I32, _I64, _U64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 
 # name -> (restype, argtypes); every symbol include/set_amd.h declares
@@ -130,6 +141,14 @@ SIGNATURES = {
     "set_randn": (C.c_int, [_V, _I64, _U64, _U64, _V]),
     "set_diffusion_loop": (C.c_int, [C.POINTER(SetDiffLoopArgs), _V]),
     "set_selftest_mfma": (C.c_int, [C.POINTER(C.c_float), _V]),
+    "set_sizeof_bmm_args": (_I64, []),
+    "set_bmm": (C.c_int, [C.POINTER(SetBmmArgs), _V]),
+    "set_softmax_rows": (C.c_int, [_V, _V, _V, _I64, _I32, _I64, _F, _V]),
+    "set_softmax_rows_bwd": (C.c_int, [_V, _V, _V, _I64, _I32, _V]),
+    "set_make_positions": (C.c_int, [_V, _V, _I64, _V, _I32, _I32, _V]),
+    "set_head_mean": (C.c_int, [_V, _V, _I32, _I32, _I64, _V]),
+    "set_mask_fill_chan": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _V]),
+    "set_masked_channel_sum": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _V]),
     "set_conv1d_wgrad": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _V]),
     "set_channel_sum": (C.c_int, [_V, _V, _I32, _I32, _I32, _V]),
     "set_row_sum": (C.c_int, [_V, _V, _I64, _I32, _F, _V]),
@@ -204,6 +223,7 @@ def lib():
     assert L.set_sizeof_diffnet_layer_args() == C.sizeof(SetDiffnetLayerArgs), "SetDiffnetLayerArgs ABI mismatch"
     assert L.set_sizeof_diff_loop_args() == C.sizeof(SetDiffLoopArgs), "SetDiffLoopArgs ABI mismatch"
     assert L.set_sizeof_diffnet_stack_args() == C.sizeof(SetDiffnetStackArgs), "SetDiffnetStackArgs ABI mismatch"
+    assert L.set_sizeof_bmm_args() == C.sizeof(SetBmmArgs), "SetBmmArgs ABI mismatch"
     _lib = L
     return L
 

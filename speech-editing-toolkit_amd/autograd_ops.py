@@ -38,10 +38,10 @@ def _wgrad_impl(T):
 # --------------------------------------------------------------------------------------------------
 class _Conv1dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, chan_add, res, cw, dil, pad, pro, pro_param, act, alpha, mask, impl):
+    def forward(ctx, x, weight, bias, chan_add, res, cw, dil, pad, pro, pro_param, act, alpha, mask, impl, t_out=None):
         x = x.contiguous()
         y = ops.conv1d(x, cw, bias, dil=dil, pad=pad, pro=pro, pro_param=pro_param, act=act, alpha=alpha, res=res,
-                       mask=mask, in_chan_add=chan_add, impl=impl)
+                       mask=mask, in_chan_add=chan_add, impl=impl, T_out=t_out)
         ctx.cw, ctx.cfg = cw, (dil, pad, pro, pro_param, act, alpha, impl)
         ctx.has = (bias is not None, chan_add is not None, res is not None)
         ctx.save_for_backward(x, chan_add, mask, y if act == "relu" else None)
@@ -78,15 +78,16 @@ class _Conv1dFn(torch.autograd.Function):
         dw = db = None
         if ctx.needs_input_grad[1]:
             w = cw.raw()
-            assert cw.base == 0 and cw.stap == 1 and cw.sci == cw.K and cw.sco == cw.Cin * cw.K, "plain conv layout"
+            # plain [Cout,Cin,K] rows, possibly a row slice of a larger parameter (packed q/k/v projections)
+            assert cw.stap == 1 and cw.sci == cw.K and cw.sco == cw.Cin * cw.K, "plain conv layout"
             dw = torch.zeros(w.shape, dtype=torch.float32, device=dy.device)
-            check(L().set_conv1d_wgrad(_p(g), _p(x), _p(chan_add), _p(dw), B, Cin, Cout, cw.K, dil, pad, T, T_in, PRO[pro],
+            check(L().set_conv1d_wgrad(_p(g), _p(x), _p(chan_add), dw.data_ptr() + 4 * cw.base, B, Cin, Cout, cw.K, dil, pad, T, T_in, PRO[pro],
                                        float(pro_param), _wgrad_impl(T), _stream()), "set_conv1d_wgrad")
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.zeros(Cout, dtype=torch.float32, device=dy.device)
             check(L().set_channel_sum(_p(g), _p(db), B, Cout, T, _stream()), "set_channel_sum")
         return (dx if ctx.needs_input_grad[0] else None, dw, db, dadd, dres, None, None, None, None, None, None, None,
-                None, None)
+                None, None, None)
 
 
 _SPLIT_ACTS = ("gelu", "mish", "softplus", "tanh")
@@ -98,15 +99,15 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
     """Differentiable set_conv1d (stride-1, plain [Cout,Cin,K] weights).  Activations other than ReLU run as a
     separate kernel so their pre-activation is available to the backward."""
     assert isinstance(weight, ConvWeight) and out is None and not accumulate and out_stride == 1 and out_off == 0
-    assert pro in ("none", "div")
+    assert pro in ("none", "div") and T_iter is None
     if act in _SPLIT_ACTS:
         assert res is None
         z = _Conv1dFn.apply(x, weight.raw(), bias, in_chan_add, None, weight, dil, pad, pro, pro_param, "none", alpha,
-                            None, impl)
+                            None, impl, T_out)
         y = activation(z, act, act_param)
         return add_chan_mask(y, None, mask) if mask is not None else y
     return _Conv1dFn.apply(x, weight.raw(), bias, in_chan_add, res, weight, dil, pad, pro, pro_param, act, alpha, mask,
-                           impl)
+                           impl, T_out)
 
 
 class _ActFn(torch.autograd.Function):
@@ -369,6 +370,138 @@ class _GradScaleFn(torch.autograd.Function):
 
 def grad_scale(x, s):
     return _GradScaleFn.apply(x, s) if s != 1 else x
+
+
+# --------------------------------------------------------------------------------------------------
+# attention + the small CampNet ops
+# --------------------------------------------------------------------------------------------------
+def _attn_bwd(qv, kv, vv, p, do, dqv, dkv, dvv, heads, alpha):
+    """Gradients of o = softmax(alpha q k^T) v into the views dqv / dkv / dvv (four strided batched GEMMs + one
+    softmax backward)."""
+    MV = ops.MatView
+    dov = MV.heads(do, heads)
+    dp = torch.empty_like(p)
+    ops.bmm(dov, vv.t, MV.scores(dp))            # dP = dO V^T
+    ops.bmm(MV.scores(p).t, dov, dvv)            # dV = P^T dO
+    ds = ops.softmax_rows_bwd(p, dp)
+    ops.bmm(MV.scores(ds), kv, dqv, alpha=alpha)   # dQ = alpha dS K
+    ops.bmm(MV.scores(ds).t, qv, dkv, alpha=alpha)  # dK = alpha dS^T Q
+
+
+class _SelfAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, heads, kpm, fill, alpha):
+        qkv = qkv.contiguous()
+        o, p = ops.self_attention(qkv, heads, kpm, fill, alpha)
+        ctx.save_for_backward(qkv, p)
+        ctx.cfg = (heads, alpha)
+        ctx.mark_non_differentiable(p)
+        return o, p
+
+    @staticmethod
+    def backward(ctx, do, _dp):
+        qkv, p = ctx.saved_tensors
+        heads, alpha = ctx.cfg
+        H = qkv.shape[1] // 3
+        MV = ops.MatView
+        d = torch.empty_like(qkv)
+        _attn_bwd(MV.heads(qkv, heads, 0, H), MV.heads(qkv, heads, H, H), MV.heads(qkv, heads, 2 * H, H), p, do.contiguous(),
+                  MV.heads(d, heads, 0, H), MV.heads(d, heads, H, H), MV.heads(d, heads, 2 * H, H), heads, alpha)
+        return d, None, None, None, None
+
+
+class _CrossAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, kv, heads, kpm, fill, alpha):
+        q, kv = q.contiguous(), kv.contiguous()
+        o, p = ops.cross_attention(q, kv, heads, kpm, fill, alpha)
+        ctx.save_for_backward(q, kv, p)
+        ctx.cfg = (heads, alpha)
+        ctx.mark_non_differentiable(p)
+        return o, p
+
+    @staticmethod
+    def backward(ctx, do, _dp):
+        q, kv, p = ctx.saved_tensors
+        heads, alpha = ctx.cfg
+        H = q.shape[1]
+        MV = ops.MatView
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        _attn_bwd(MV.heads(q, heads), MV.heads(kv, heads, 0, H), MV.heads(kv, heads, H, H), p, do.contiguous(),
+                  MV.heads(dq, heads), MV.heads(dkv, heads, 0, H), MV.heads(dkv, heads, H, H), heads, alpha)
+        return dq, dkv, None, None, None, None
+
+
+def self_attention(qkv, heads, key_padding_mask=None, fill=float("-inf"), alpha=1.0):
+    return _SelfAttnFn.apply(qkv, heads, key_padding_mask, fill, alpha)
+
+
+def cross_attention(q, kv, heads, key_padding_mask=None, fill=-1e8, alpha=1.0):
+    return _CrossAttnFn.apply(q, kv, heads, key_padding_mask, fill, alpha)
+
+
+class _PosAddFn(torch.autograd.Function):
+    """x + alpha * table[pos]   (transformer.py:795-796; alpha is the learnable pos_embed_alpha)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, pos, table):
+        out = ops.embedding_bct(pos, table, scale=float(alpha.item()), out=x.clone(), accumulate=True)
+        ctx.save_for_backward(pos, table)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        pos, table = ctx.saved_tensors
+        dalpha = None
+        if ctx.needs_input_grad[1]:
+            pe = ops.embedding_bct(pos, table)
+            prod = ops.blend_mask(torch.zeros_like(pe), pe, d.contiguous(), 1)  # pe * d elementwise
+            dalpha = _sum(prod).reshape(1)
+        return d, dalpha, None, None
+
+
+def pos_add(x, alpha, pos, table):
+    return _PosAddFn.apply(x, alpha, pos, table)
+
+
+class _MaskFillChanFn(torch.autograd.Function):
+    """x*(1-m) + e[c]*m on [B,C,T]; x carries no gradient here (it is the input mel), e = mask_emb does."""
+
+    @staticmethod
+    def forward(ctx, x, e, m):
+        ctx.save_for_backward(m)
+        ctx.C = x.shape[1]
+        return ops.mask_fill_chan(x, e.reshape(-1).contiguous(), m)
+
+    @staticmethod
+    def backward(ctx, d):
+        (m,) = ctx.saved_tensors
+        de = torch.zeros(ctx.C, dtype=torch.float32, device=d.device)
+        ops.masked_channel_sum(d.contiguous(), m, de)
+        return None, de.reshape(1, 1, -1), None
+
+
+def mask_fill_chan(x, e, m):
+    return _MaskFillChanFn.apply(x, e, m)
+
+
+class _AddMaskedFn(torch.autograd.Function):
+    """a + b * m[b][t]  on [B,C,T]   (campnet.py:62,68: `mels*(1-mask) + coarse*mask`, `mel_coarse + fine*mask`)."""
+
+    @staticmethod
+    def forward(ctx, a, b, m):
+        ctx.save_for_backward(m)
+        return ops.sum_div(a.contiguous(), ops.add_chan_mask(b, None, m))
+
+    @staticmethod
+    def backward(ctx, d):
+        (m,) = ctx.saved_tensors
+        d = d.contiguous()
+        return (d if ctx.needs_input_grad[0] else None), ops.add_chan_mask(d, None, m), None
+
+
+def add_masked(a, b, m):
+    return _AddMaskedFn.apply(a, b, m)
 
 
 # --------------------------------------------------------------------------------------------------

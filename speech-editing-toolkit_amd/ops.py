@@ -95,8 +95,9 @@ class ConvWeight:
     def transposed(self):
         """W'[ci][co][tap] = W[co][ci][tap]: the weight operand of the input-gradient convolution."""
         if getattr(self, "_tr", None) is None:
-            assert self.base == 0 and self.stap == 1
-            self._tr = ConvWeight(self._getter, self.Cin, self.Cout, self.K, base=0, sco=self.sci, sci=self.sco, stap=1)
+            assert self.stap == 1
+            self._tr = ConvWeight(self._getter, self.Cin, self.Cout, self.K, base=self.base, sco=self.sci, sci=self.sco,
+                                  stap=1)
         return self._tr
 
     def packed(self):
@@ -543,3 +544,155 @@ def default_groups(B, T):
     of a 416-block launch gets worse, not better -- hence 1.  Grouping never changes results."""
     env = os.environ.get("SET_AMD_GROUPS")
     return max(1, int(env)) if env else 1
+
+
+# --------------------------------------------------------------------------
+# attention building blocks (CampNet rows)
+# --------------------------------------------------------------------------
+class MatView:
+    """A batch of matrices inside a tensor: element (bo, bi, r, c) at  offset + bo*bo_s + bi*bi_s + r*rs + c*cs
+    (in floats).  `.t` swaps rows and columns.  Heads of a [B, heads*d, T] activation: MatView.heads(x, heads)."""
+
+    def __init__(self, tensor, n_outer, n_inner, rows, cols, bo_s, bi_s, rs, cs, offset=0):
+        self.tensor = _f(tensor)
+        self.n_outer, self.n_inner, self.rows, self.cols = int(n_outer), int(n_inner), int(rows), int(cols)
+        self.bo_s, self.bi_s, self.rs, self.cs, self.offset = int(bo_s), int(bi_s), int(rs), int(cs), int(offset)
+
+    @property
+    def t(self):
+        return MatView(self.tensor, self.n_outer, self.n_inner, self.cols, self.rows, self.bo_s, self.bi_s, self.cs,
+                       self.rs, self.offset)
+
+    @staticmethod
+    def heads(x, heads, chan0=0, width=None):
+        """Channels [chan0, chan0+width) of x [B, C, T] (contiguous) split into heads -> per (b, h) the matrix
+        [T, d]: rows = frames, cols = head channels.  (q / k / v are channel slices of one packed projection.)"""
+        B, Ctot, T = x.shape
+        H = Ctot - chan0 if width is None else width
+        d = H // heads
+        assert x.is_contiguous() and d * heads == H and chan0 + H <= Ctot
+        return MatView(x, B, heads, T, d, Ctot * T, d * T, 1, T, offset=chan0 * T)
+
+    @staticmethod
+    def scores(s):
+        """s [B, heads, Tq, Tk] (contiguous) -> per (b, h) the matrix [Tq, Tk]."""
+        B, h, Tq, Tk = s.shape
+        assert s.is_contiguous()
+        return MatView(s, B, h, Tq, Tk, h * Tq * Tk, Tq * Tk, Tk, 1)
+
+    def ptr(self):
+        return self.tensor.data_ptr() + 4 * self.offset
+
+
+def bmm(a, b, c, alpha=1.0, accumulate=False):
+    """c = alpha * a @ b (+ c) on MatViews.  When c is column-major the transposed problem is run so that the
+    stores stay coalesced (c^T = b^T a^T)."""
+    assert a.cols == b.rows and a.rows == c.rows and b.cols == c.cols
+    assert (a.n_outer, a.n_inner) == (b.n_outer, b.n_inner) == (c.n_outer, c.n_inner)
+    if c.rs == 1 and c.cs != 1:
+        a, b, c = b.t, a.t, c.t
+    g = _lib.SetBmmArgs()
+    g.A, g.B, g.C = a.ptr(), b.ptr(), c.ptr()
+    g.a_bo, g.a_bi, g.a_ms, g.a_ks = a.bo_s, a.bi_s, a.rs, a.cs
+    g.b_bo, g.b_bi, g.b_ks, g.b_ns = b.bo_s, b.bi_s, b.rs, b.cs
+    g.c_bo, g.c_bi, g.c_ms, g.c_ns = c.bo_s, c.bi_s, c.rs, c.cs
+    g.n_outer, g.n_inner, g.M, g.N, g.K = c.n_outer, c.n_inner, c.rows, c.cols, a.cols
+    g.alpha, g.accumulate = float(alpha), int(bool(accumulate))
+    check(_lib.lib().set_bmm(C.byref(g), _stream()), "set_bmm")
+    return c.tensor
+
+
+def softmax_rows(x, key_padding_mask=None, rows_per_batch=1, fill=float("-inf"), out=None):
+    """softmax over the last dim of a contiguous tensor; kpm [B, cols] fp32 (1 = pad), B = rows / rows_per_batch."""
+    _f(x), _f(key_padding_mask)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.lib().set_softmax_rows(_p(x), _p(key_padding_mask), _p(out), rows, cols, int(rows_per_batch), float(fill),
+                                      _stream()), "set_softmax_rows")
+    return out
+
+
+def softmax_rows_bwd(p, dp):
+    _f(p), _f(dp)
+    cols = p.shape[-1]
+    ds = torch.empty_like(p)
+    check(_lib.lib().set_softmax_rows_bwd(_p(p), _p(dp), _p(ds), p.numel() // cols, cols, _stream()), "set_softmax_rows_bwd")
+    return ds
+
+
+def make_positions(tokens=None, x_bct=None):
+    """int64 [B,T]: 1,2,3.. over the non-zero tokens (or the non-zero entries of channel 0 of x_bct), 0 elsewhere."""
+    if tokens is not None:
+        _i(tokens)
+        B, T = tokens.shape
+        pos = torch.empty(B, T, dtype=torch.int64, device=tokens.device)
+        check(_lib.lib().set_make_positions(_p(tokens), None, 0, _p(pos), B, T, _stream()), "set_make_positions")
+    else:
+        _f(x_bct)
+        B, Cc, T = x_bct.shape
+        pos = torch.empty(B, T, dtype=torch.int64, device=x_bct.device)
+        check(_lib.lib().set_make_positions(None, _p(x_bct), Cc * T, _p(pos), B, T, _stream()), "set_make_positions")
+    return pos
+
+
+def head_mean(p):
+    """p [B, heads, ...] -> mean over heads [B, ...]."""
+    _f(p)
+    B, h = p.shape[:2]
+    out = torch.empty((B,) + tuple(p.shape[2:]), dtype=torch.float32, device=p.device)
+    check(_lib.lib().set_head_mean(_p(p), _p(out), B, h, out.numel() // B, _stream()), "set_head_mean")
+    return out
+
+
+def mask_fill_chan(x, e, m):
+    """x [B,C,T]*(1-m[B,T]) + e[C]*m"""
+    _f(x), _f(e), _f(m)
+    B, Cc, T = x.shape
+    out = torch.empty_like(x)
+    check(_lib.lib().set_mask_fill_chan(_p(x), _p(e), _p(m), _p(out), B, Cc, T, _stream()), "set_mask_fill_chan")
+    return out
+
+
+def masked_channel_sum(d, m, out):
+    _f(d), _f(m), _f(out)
+    B, Cc, T = d.shape
+    check(_lib.lib().set_masked_channel_sum(_p(d), _p(m), _p(out), B, Cc, T, _stream()), "set_masked_channel_sum")
+    return out
+
+
+def attention_views(qv, kv, vv, heads, key_padding_mask=None, fill=float("-inf"), alpha=1.0):
+    """o = softmax(alpha * q k^T (+mask)) v per head; q/k/v given as MatView.heads views.  Returns (o [B,H,Tq]
+    contiguous, p [B,heads,Tq,Tk])."""
+    B, Tq, Tk, d = qv.n_outer, qv.rows, kv.rows, qv.cols
+    dev = qv.tensor.device
+    s = torch.empty(B, heads, Tq, Tk, dtype=torch.float32, device=dev)
+    bmm(qv, kv.t, MatView.scores(s), alpha=alpha)
+    p = softmax_rows(s, key_padding_mask, heads * Tq, fill, out=s)
+    o = torch.empty(B, heads * d, Tq, dtype=torch.float32, device=dev)
+    bmm(MatView.scores(p), vv, MatView.heads(o, heads))
+    return o, p
+
+
+def self_attention(qkv, heads, key_padding_mask=None, fill=float("-inf"), alpha=1.0):
+    """qkv [B, 3H, T] = packed in_proj output (transformer.py:421-422) -> (o [B,H,T], p)."""
+    H = qkv.shape[1] // 3
+    return attention_views(MatView.heads(qkv, heads, 0, H), MatView.heads(qkv, heads, H, H),
+                           MatView.heads(qkv, heads, 2 * H, H), heads, key_padding_mask, fill, alpha)
+
+
+def cross_attention(q, kv, heads, key_padding_mask=None, fill=-1e8, alpha=1.0):
+    """q [B,H,Tq], kv [B,2H,Tk] (in_proj_k / in_proj_v of the encoder output, transformer.py:433-451)."""
+    H = q.shape[1]
+    return attention_views(MatView.heads(q, heads), MatView.heads(kv, heads, 0, H), MatView.heads(kv, heads, H, H), heads,
+                           key_padding_mask, fill, alpha)
+
+
+def pos_add(x, alpha, pos, table):
+    """x + alpha * table[pos]  (transformer.py:795-796)"""
+    return embedding_bct(pos, table, scale=float(alpha.item()), out=x.clone(), accumulate=True)
+
+
+def add_masked(a, b, m):
+    """a + b * m[b][t] on [B,C,T]"""
+    return sum_div(a.contiguous(), add_chan_mask(b, None, m))

@@ -1,0 +1,176 @@
+"""CampNet rows (BASELINE config 5) on the GPU: the attention building blocks against
+plain torch fp32 references, and the whole model (forward, losses, every parameter gradient) against the fixtures
+generated from the reference's own CampNet + loss functions + autograd (oracle/make_golden.py::campnet_case)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import ROOT, load_golden
+from oracle import weights as Wt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(built_lib):
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _md(a, b):
+    a = a.detach().cpu().double() if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a)).double()
+    b = b.detach().cpu().double() if isinstance(b, torch.Tensor) else torch.from_numpy(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("B,heads,Tq,Tk,d", [(2, 2, 48, 12, 96), (3, 2, 77, 19, 96), (1, 4, 130, 130, 32), (2, 1, 5, 3, 7)])
+def test_bmm_views_match_torch(dev, B, heads, Tq, Tk, d):
+    """Strided batched GEMM in every orientation attention uses (QK^T, PV, dP, dV, dQ, dK), ragged sizes."""
+    from set_amd import ops
+    MV = ops.MatView
+    g = torch.Generator().manual_seed(Tq)
+    H = heads * d
+    q = torch.randn(B, H, Tq, generator=g)
+    kv = torch.randn(B, 2 * H, Tk, generator=g)
+    qd, kvd = q.to(dev), kv.to(dev)
+    qh = q.view(B, heads, d, Tq).transpose(2, 3)            # [B,h,Tq,d]
+    kh = kv[:, :H].reshape(B, heads, d, Tk).transpose(2, 3)  # [B,h,Tk,d]
+    vh = kv[:, H:].reshape(B, heads, d, Tk).transpose(2, 3)
+    s_ref = 0.37 * qh @ kh.transpose(2, 3)
+    s = torch.empty(B, heads, Tq, Tk, device=dev)
+    ops.bmm(MV.heads(qd, heads), MV.heads(kvd, heads, 0, H).t, MV.scores(s), alpha=0.37)
+    assert _md(s, s_ref) < 2e-5 * max(1.0, float(s_ref.abs().max()))
+    p = torch.softmax(s_ref, -1)
+    o = torch.empty(B, H, Tq, device=dev)
+    ops.bmm(MV.scores(p.to(dev).contiguous()), MV.heads(kvd, heads, H, H), MV.heads(o, heads))
+    o_ref = (p @ vh).transpose(2, 3).reshape(B, H, Tq)
+    assert _md(o, o_ref) < 2e-5 * max(1.0, float(o_ref.abs().max()))
+    # P^T dO -> dV written into a channel slice of a packed [B,2H,Tk] tensor, accumulate on top of existing data
+    do = torch.randn(B, H, Tq, generator=g)
+    dkv = torch.ones(B, 2 * H, Tk, device=dev)
+    ops.bmm(MV.scores(p.to(dev).contiguous()).t, MV.heads(do.to(dev), heads), MV.heads(dkv, heads, H, H), accumulate=True)
+    dv_ref = (p.transpose(2, 3) @ do.view(B, heads, d, Tq).transpose(2, 3)).transpose(2, 3).reshape(B, H, Tk) + 1.0
+    assert _md(dkv[:, H:], dv_ref) < 2e-5 * max(1.0, float(dv_ref.abs().max()))
+    assert torch.equal(dkv[:, :H].cpu(), torch.ones(B, H, Tk))
+
+
+def test_softmax_rows_and_positions(dev):
+    from set_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, h, Tq, Tk = 3, 2, 37, 70
+    s = torch.randn(B, h, Tq, Tk, generator=g) * 3
+    kpm = torch.zeros(B, Tk)
+    kpm[0, -9:] = 1
+    kpm[2, -1:] = 1
+    for fill in (float("-inf"), -1e8):
+        ref = torch.softmax(s.masked_fill(kpm.bool()[:, None, None, :], fill), -1)
+        got = ops.softmax_rows(s.to(dev), kpm.to(dev), h * Tq, fill)
+        assert _md(got, ref) < 1e-6
+        assert float(got[0, :, :, -9:].abs().max()) == 0.0
+    got = ops.softmax_rows(s.to(dev))
+    assert _md(got, torch.softmax(s, -1)) < 1e-6
+    dp = torch.randn(B, h, Tq, Tk, generator=g)
+    p = torch.softmax(s, -1)
+    ds_ref = p * (dp - (p * dp).sum(-1, keepdim=True))
+    assert _md(ops.softmax_rows_bwd(p.to(dev), dp.to(dev)), ds_ref) < 1e-6
+    # a fully masked row with the -inf fill is NaN in torch as well
+    full = torch.ones(1, Tk)
+    assert torch.isnan(ops.softmax_rows(s[:1].to(dev), full.to(dev), h * Tq, float("-inf"))).all()
+    # positions: tokens, and channel 0 of an activation (exact zeros are "padding")
+    txt = torch.randint(0, 3, (4, 150), generator=g)
+    mk = txt.ne(0).int()
+    want = (torch.cumsum(mk, 1) * mk).long()
+    assert torch.equal(ops.make_positions(tokens=txt.to(dev)).cpu(), want)
+    x = torch.randn(4, 5, 150, generator=g)
+    x[:, 0][txt == 0] = 0.0
+    assert torch.equal(ops.make_positions(x_bct=x.to(dev)).cpu(), want)
+    pm = torch.rand(3, 2, 11, 13, generator=g)
+    assert _md(ops.head_mean(pm.to(dev)), pm.mean(1)) < 1e-7
+
+
+def _campnet(dev, g):
+    import set_amd  # noqa: F401
+    from set_amd import hparams as H
+    from set_amd.tasks import CampNetTask
+    with open(os.path.join(ROOT, "speech-editing-toolkit_amd", "egs", "campnet.yaml")) as f:
+        hp = yaml.safe_load(f)
+    H.hparams.clear()
+    H.hparams.update(hp)
+    task = CampNetTask(80, 100)
+    model = task.build_tts_model()
+    W = Wt.seeded_weights(Wt.load_manifest("campnet"), g["meta"]["wseed"])
+    W["mask_emb"] = torch.from_numpy(g["mask_emb"])
+    W["decoder_coarse.pos_embed_alpha"] = torch.from_numpy(g["pos_embed_alpha"])
+    missing, unexpected = model.load_state_dict(W, strict=False)
+    assert not unexpected and all(Wt.is_buffer(k) for k in missing), (missing, unexpected)
+    model.to(dev)
+    m = g["meta"]
+    inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=m["pad_tail"])
+    sample = {"txt_tokens": torch.from_numpy(g["txt_tokens"]).to(dev), "mels": inp["ref_mels"].to(dev),
+              "time_mel_masks": inp["time_mel_masks"][:, :, 0].contiguous().to(dev)}
+    return task, model, sample
+
+
+@pytest.mark.parametrize("case", ["campnet_tiny", "campnet_ragged"])
+def test_campnet_forward_losses_and_gradients_match_reference(dev, case):
+    g = load_golden(case)
+    task, model, sample = _campnet(dev, g)
+    # inference branch
+    out = task.run_model(sample, infer=True)
+    torch.cuda.synchronize()
+    d = {k: _md(out[k], g[k]) for k in ("mel_out_coarse", "mel_out_fine", "attn")}
+    print(case, {k: "%.2e" % v for k, v in d.items()})
+    assert d["mel_out_coarse"] < 1e-4 and d["mel_out_fine"] < 1e-4 and d["attn"] < 1e-5
+    m = sample["time_mel_masks"][:, :, None]
+    assert _md(out["mel_out"], torch.from_numpy(g["mel_out_fine"]).to(m.device) * m + sample["mels"] * (1 - m)) < 1e-4
+    # training branch: losses + every gradient
+    for p in model.parameters():
+        p.grad = None
+    losses, out_t = task.run_model(sample, infer=False)
+    with torch.enable_grad():
+        total = sum(losses.values())
+    total.backward()
+    torch.cuda.synchronize()
+    for k in ("l1_coarse", "ssim_coarse", "l1_fine", "ssim_fine"):
+        assert abs(float(losses[k]) - float(g["loss_" + k])) < 1e-5 * max(1.0, abs(float(g["loss_" + k]))), k
+    assert abs(float(total) - float(g["total"])) < 2e-5 * max(1.0, abs(float(g["total"])))
+    names = g["meta"]["param_names"]
+    params = dict(model.named_parameters())
+    assert list(params) == names
+    worst = ("", 0.0)
+    for k, want in zip(names, g["grad_norms"]):
+        gr = params[k].grad
+        if want < 0:
+            assert gr is None or float(gr.abs().max()) == 0.0, k   # parameters the reference never reaches
+            continue
+        assert gr is not None, k
+        rel = abs(float(gr.norm()) - want) / (want + 1e-12)
+        if rel > worst[1]:
+            worst = (k, rel)
+    print("worst relative grad-norm deviation: %s %.2e" % worst)
+    assert worst[1] < 2e-3, worst
+    for key in g:
+        if key.startswith("grad::"):
+            k = key[6:]
+            want = torch.from_numpy(g[key])
+            got = params[k].grad.detach().cpu()
+            got = got if got.numel() <= 30000 else got.reshape(-1)[:30000]
+            assert _md(got, want) < 2e-3 * max(float(want.abs().max()), 1e-6), k
+
+
+def test_campnet_training_step_reduces_loss(dev):
+    """FlatAdamW on the CampNet parameters: a few steps on one batch reduce the loss; the packed weights follow."""
+    from set_amd.training import FlatAdamW
+    g = load_golden("campnet_tiny")
+    task, model, sample = _campnet(dev, g)
+    opt = FlatAdamW(model, lr=2e-3, warmup_updates=1)
+    first = last = None
+    for it in range(6):
+        total, losses, lr = task.training_step(sample, opt)
+        first = float(total) if first is None else first
+        last = float(total)
+    assert np.isfinite(last) and last < first - 1e-3, (first, last)
