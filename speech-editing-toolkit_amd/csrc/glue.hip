@@ -4,35 +4,48 @@
 // include/set_amd.h next to each prototype.
 #include "common.h"
 
-// ---- LayerNorm over C of [B][C][T]: one thread per (b, t), coalesced across t ----------------
+// ---- LayerNorm over C of [B][C][T]: block = 64 frames x 4 channel groups (one wave per group, loads coalesced along
+//      t), partial sums combined through LDS.  (One thread per frame walking all C channels left most CUs idle and
+//      serialised 3*C strided loads per thread: 95 us for [16][192][800].)
+__device__ __forceinline__ float ln_block_sum(float v, float (*red)[64], int cg, int tl) {
+    __syncthreads();  // previous use of red[] is over
+    red[cg][tl] = v;
+    __syncthreads();
+    return red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
+}
+
 __global__ void __launch_bounds__(256) layernorm_ch_kernel(const float *x, const float *gamma, const float *beta,
                                                            const float *mask, float *out, int B, int C, int T,
                                                            float eps) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)B * T) return;
-    const int b = (int)(idx / T), t = (int)(idx % T);
-    const float *xp = x + (int64_t)b * C * T + t;
+    __shared__ float red[4][64];
+    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int b = blockIdx.y, t = blockIdx.x * 64 + tl;
+    const bool valid = t < T;
+    const int tc = valid ? t : T - 1;
+    const int cq = (C + 3) / 4, c0 = cg * cq, c1 = min(C, c0 + cq);
+    const float *xp = x + (int64_t)b * C * T + tc;
     float s = 0.0f;
-    for (int c = 0; c < C; ++c) s += xp[(int64_t)c * T];
-    const float mean = s / (float)C;
+    for (int c = c0; c < c1; ++c) s += xp[(int64_t)c * T];
+    const float mean = ln_block_sum(s, red, cg, tl) / (float)C;
     float q = 0.0f;
-    for (int c = 0; c < C; ++c) {
+    for (int c = c0; c < c1; ++c) {
         const float d = xp[(int64_t)c * T] - mean;
         q = fmaf(d, d, q);
     }
-    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
-    const float m = mask ? mask[idx] : 1.0f;
+    const float rstd = 1.0f / sqrtf(ln_block_sum(q, red, cg, tl) / (float)C + eps);
+    if (!valid) return;
+    const float m = mask ? mask[(int64_t)b * T + t] : 1.0f;
     float *op = out + (int64_t)b * C * T + t;
-    for (int c = 0; c < C; ++c) {
+    for (int c = c0; c < c1; ++c) {
         const float v = (xp[(int64_t)c * T] - mean) * rstd * gamma[c] + beta[c];
         op[(int64_t)c * T] = mask ? v * m : v;
     }
 }
 extern "C" int set_layernorm_ch(const float *x, const float *gamma, const float *beta, const float *mask, float *out,
                                 int32_t B, int32_t C, int32_t T, float eps, void *stream) {
-    SET_REQUIRE(x && gamma && beta && out && B > 0 && C > 0 && T > 0, "set_layernorm_ch");
-    hipLaunchKernelGGL(layernorm_ch_kernel, dim3(set_blocks((int64_t)B * T, 256)), dim3(256), 0, (hipStream_t)stream,
-                       x, gamma, beta, mask, out, B, C, T, eps);
+    SET_REQUIRE(x && gamma && beta && out && B > 0 && C > 0 && T > 0 && B <= 65535, "set_layernorm_ch");
+    hipLaunchKernelGGL(layernorm_ch_kernel, dim3((T + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, mask,
+                       out, B, C, T, eps);
     return set_check_launch("set_layernorm_ch");
 }
 
@@ -59,18 +72,21 @@ extern "C" int set_embedding_bct(const int64_t *idx, const float *table, float *
 
 // ---- masks ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) abs_sum_mask_kernel(const float *x, float *mask, int B, int C, int T) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)B * T) return;
-    const int b = (int)(idx / T), t = (int)(idx % T);
-    const float *xp = x + (int64_t)b * C * T + t;
+    __shared__ float red[4][64];
+    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int b = blockIdx.y, t = blockIdx.x * 64 + tl;
+    const int tc = t < T ? t : T - 1;
+    const int cq = (C + 3) / 4, c0 = cg * cq, c1 = min(C, c0 + cq);
+    const float *xp = x + (int64_t)b * C * T + tc;
     float s = 0.0f;
-    for (int c = 0; c < C; ++c) s += fabsf(xp[(int64_t)c * T]);
-    mask[idx] = s > 0.0f ? 1.0f : 0.0f;
+    for (int c = c0; c < c1; ++c) s += fabsf(xp[(int64_t)c * T]);
+    red[cg][tl] = s;
+    __syncthreads();
+    if (cg == 0 && t < T) mask[(int64_t)b * T + t] = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) > 0.0f ? 1.0f : 0.0f;
 }
 extern "C" int set_abs_sum_mask(const float *x, float *mask, int32_t B, int32_t C, int32_t T, void *stream) {
-    SET_REQUIRE(x && mask && B > 0 && C > 0 && T > 0, "set_abs_sum_mask");
-    hipLaunchKernelGGL(abs_sum_mask_kernel, dim3(set_blocks((int64_t)B * T, 256)), dim3(256), 0, (hipStream_t)stream,
-                       x, mask, B, C, T);
+    SET_REQUIRE(x && mask && B > 0 && C > 0 && T > 0 && B <= 65535, "set_abs_sum_mask");
+    hipLaunchKernelGGL(abs_sum_mask_kernel, dim3((T + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, mask, B, C, T);
     return set_check_launch("set_abs_sum_mask");
 }
 

@@ -199,46 +199,50 @@ __global__ void __launch_bounds__(256) res_skip_bwd_kernel(const float *dx_out, 
     ob[(int64_t)C * T + ct] = dskip[i];
 }
 
-// ---- LayerNorm over channels, backward: one thread per (b,t) column; dgamma/dbeta via wave reduce + atomics ----
+// ---- LayerNorm over channels, backward: block = 64 frames x 4 channel groups (one wave per group), column sums
+//      through LDS; dgamma/dbeta: wave reduce over the 64 frames, one atomic per (block, channel).
+__device__ __forceinline__ float lnb_block_sum(float v, float (*red)[64], int cg, int tl) {
+    __syncthreads();
+    red[cg][tl] = v;
+    __syncthreads();
+    return red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
+}
+
 __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, const float *gamma, const float *mask,
                                                                const float *dy, float *dx, float *dgamma, float *dbeta,
                                                                int B, int C, int T, float eps) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = idx < (int64_t)B * T;
-    const int b = valid ? (int)(idx / T) : 0, t = valid ? (int)(idx % T) : 0;
-    const float *xp = x + (int64_t)b * C * T + t;
-    const float *dp = dy + (int64_t)b * C * T + t;
-    float mean = 0.0f, rstd = 0.0f, m = 0.0f, s1 = 0.0f, s2 = 0.0f;
-    if (valid) {
-        float s = 0.0f;
-        for (int c = 0; c < C; ++c) s += xp[(int64_t)c * T];
-        mean = s / (float)C;
-        float q = 0.0f;
-        for (int c = 0; c < C; ++c) { const float d = xp[(int64_t)c * T] - mean; q = fmaf(d, d, q); }
-        rstd = 1.0f / sqrtf(q / (float)C + eps);
-        m = mask ? mask[idx] : 1.0f;
-        for (int c = 0; c < C; ++c) {
-            const float xh = (xp[(int64_t)c * T] - mean) * rstd;
-            const float g = dp[(int64_t)c * T] * m * gamma[c];
-            s1 += g;
-            s2 = fmaf(g, xh, s2);
-        }
-        s1 /= (float)C;
-        s2 /= (float)C;
+    __shared__ float red[4][64];
+    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int b = blockIdx.y, t = blockIdx.x * 64 + tl;
+    const bool valid = t < T;
+    const int tc = valid ? t : T - 1;
+    const int cq = (C + 3) / 4, c0 = cg * cq, c1 = min(C, c0 + cq);
+    const float *xp = x + (int64_t)b * C * T + tc;
+    const float *dp = dy + (int64_t)b * C * T + tc;
+    float s = 0.0f;
+    for (int c = c0; c < c1; ++c) s += xp[(int64_t)c * T];
+    const float mean = lnb_block_sum(s, red, cg, tl) / (float)C;
+    float q = 0.0f;
+    for (int c = c0; c < c1; ++c) { const float d = xp[(int64_t)c * T] - mean; q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(lnb_block_sum(q, red, cg, tl) / (float)C + eps);
+    const float m = !valid ? 0.0f : (mask ? mask[(int64_t)b * T + t] : 1.0f);
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int c = c0; c < c1; ++c) {
+        const float xh = (xp[(int64_t)c * T] - mean) * rstd;
+        const float g = dp[(int64_t)c * T] * m * gamma[c];
+        s1 += g;
+        s2 = fmaf(g, xh, s2);
     }
-    float *op = dx + (int64_t)b * C * T + t;
-    const int lane = threadIdx.x & 63;
-    for (int c = 0; c < C; ++c) {
-        float dg = 0.0f, db = 0.0f;
-        if (valid) {
-            const float xh = (xp[(int64_t)c * T] - mean) * rstd;
-            const float dyc = dp[(int64_t)c * T] * m;
-            op[(int64_t)c * T] = rstd * (dyc * gamma[c] - s1 - xh * s2);
-            dg = dyc * xh;
-            db = dyc;
-        }
+    s1 = lnb_block_sum(s1, red, cg, tl) / (float)C;
+    s2 = lnb_block_sum(s2, red, cg, tl) / (float)C;
+    float *op = dx + (int64_t)b * C * T + tc;
+    for (int c = c0; c < c1; ++c) {
+        const float xh = (xp[(int64_t)c * T] - mean) * rstd;
+        const float dyc = dp[(int64_t)c * T] * m;  // m == 0 on the frames beyond T
+        if (valid) op[(int64_t)c * T] = rstd * (dyc * gamma[c] - s1 - xh * s2);
+        float dg = dyc * xh, db = dyc;
         for (int off = 32; off > 0; off >>= 1) { dg += __shfl_xor(dg, off); db += __shfl_xor(db, off); }
-        if (lane == 0) { atomicAdd(&dgamma[c], dg); atomicAdd(&dbeta[c], db); }
+        if (tl == 0) { atomicAdd(&dgamma[c], dg); atomicAdd(&dbeta[c], db); }
     }
 }
 
@@ -616,7 +620,8 @@ extern "C" int set_layernorm_ch_bwd(const float *x, const float *gamma, const fl
                                     float *dgamma, float *dbeta, int32_t B, int32_t C, int32_t T, float eps,
                                     void *stream) {
     SET_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && B > 0 && C > 0 && T > 0, "set_layernorm_ch_bwd");
-    hipLaunchKernelGGL(layernorm_ch_bwd_kernel, dim3(set_blocks((int64_t)B * T, 256)), dim3(256), 0, (hipStream_t)stream,
+    SET_REQUIRE(B <= 65535, "set_layernorm_ch_bwd(B)");
+    hipLaunchKernelGGL(layernorm_ch_bwd_kernel, dim3((T + 63) / 64, B), dim3(256), 0, (hipStream_t)stream,
                        x, gamma, mask, dy, dx, dgamma, dbeta, B, C, T, eps);
     return set_check_launch("set_layernorm_ch_bwd");
 }
