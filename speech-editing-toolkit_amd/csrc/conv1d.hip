@@ -81,21 +81,57 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(SetConv1dArgs a, int l
     f32x16 acc0 = {0}, acc1 = {0};
     const int cp_total = CinP / 2;
 
+    // Staging: wave w owns rows w, w+4, w+8, w+12 of the KC x W chunk, lanes run along t (coalesced, no div/mod).
+    // Loads are UNCONDITIONAL on clamped addresses and issued together (4 rows x 2 column blocks), the validity
+    // select happens at the LDS write: an `if (valid) v = load` makes hipcc branch and drain vmcnt(0) per element,
+    // i.e. one serialized global round trip per element (64 of them for Cin = 256; measured 88 us for a 256->256 1x1
+    // conv on 25.6k frames).  When the chunk is at most 128 columns wide the NEXT chunk's loads are issued before
+    // this chunk's MFMAs.
+    const float *addp = a.in_chan_add ? a.in_chan_add + (int64_t)b * a.Cin : inb;  // dummy stays a valid address
+    const bool has_add = a.in_chan_add != nullptr;
+    const int nj = (W + 63) >> 6;
+    float pv[4][2], pa[4];
+    auto issue = [&](int c0, int jj0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cc = min(c0 + wave + 4 * k, a.Cin - 1);
+            pa[k] = addp[cc];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ti = t0 + lo + (jj0 + u) * 64 + lane;
+                pv[k][u] = inb[(int64_t)cc * a.in_cs + min(max(ti, 0), a.T_in - 1)];
+            }
+        }
+    };
+    auto commit = [&](int c0, int jj0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = wave + 4 * k;
+            const bool cok = c0 + row < a.Cin;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = (jj0 + u) * 64 + lane;
+                const int ti = t0 + lo + j;
+                const float x = has_add ? pv[k][u] + pa[k] : pv[k][u];
+                if (j < W) smem[row * W + j] = (cok && ti >= 0 && ti < a.T_in) ? dev_pro(x, a.pro, a.pro_param) : 0.0f;
+            }
+        }
+    };
+    const bool piped = nj <= 2;
+    if (piped) issue(0, 0);
+
     for (int c0 = 0; c0 < CinP; c0 += KC) {
         __syncthreads();  // previous chunk fully consumed
-        for (int i = tid; i < KC * W; i += 256) {
-            const int ci = i / W, j = i - ci * W;
-            const int c = c0 + ci;
-            const int ti = t0 + lo + j;
-            float v = 0.0f;
-            if (c < a.Cin && ti >= 0 && ti < a.T_in) {
-                v = inb[(int64_t)c * a.in_cs + ti];
-                if (a.in_chan_add) v += a.in_chan_add[(int64_t)b * a.Cin + c];
-                v = dev_pro(v, a.pro, a.pro_param);
+        if (piped) {
+            commit(c0, 0);
+        } else {
+            for (int jj0 = 0; jj0 < nj; jj0 += 2) {
+                issue(c0, jj0);
+                commit(c0, jj0);
             }
-            smem[i] = v;
         }
         __syncthreads();
+        if (piped && c0 + KC < CinP) issue(c0 + KC, 0);
         if (rb_valid) {
             for (int tap = 0; tap < a.K; ++tap) {
                 const int off = tap * a.dil - a.pad - lo;  // >= 0
