@@ -1,5 +1,9 @@
-"""Checkpoint loading with the reference's file layout (utils/commons/ckpt_utils.py:7-66):
-`<dir>/model_ckpt_steps_<N>.ckpt` = {'state_dict': {<model_name>: {...}} | flat 'model_name.key' dict}."""
+"""Checkpoints in the reference's file layout.
+
+Loading (utils/commons/ckpt_utils.py:7-66): `<dir>/model_ckpt_steps_<N>.ckpt` = {'state_dict': {<model_name>: {...}} |
+flat 'model_name.key' dict}.  Saving / resuming (utils/commons/trainer.py:384-471): {'epoch', 'global_step',
+'checkpoint_callback_best', 'optimizer_states': [AdamW state_dict], 'state_dict': {'model': ...}}, written atomically,
+oldest files beyond `num_ckpt_keep` removed."""
 import glob
 import os
 import re
@@ -46,3 +50,35 @@ def load_ckpt(cur_model, ckpt_base_dir, model_name="model", force=True, strict=T
             del sd[k]
     cur_model.load_state_dict(sd, strict=strict)
     print("| load '%s' from '%s'." % (model_name, ckpt_path))
+
+
+def save_ckpt(work_dir, model, optimizer=None, global_step=0, epoch=0, best=None, num_ckpt_keep=3, model_name="model"):
+    """trainer.py:430-471 (`save_checkpoint` / `_atomic_save` / `dump_checkpoint`) for one model + one optimizer."""
+    os.makedirs(work_dir, exist_ok=True)
+    ckpt = {"epoch": int(epoch), "global_step": int(global_step), "checkpoint_callback_best": best,
+            "optimizer_states": [optimizer.state_dict()] if optimizer is not None else [],
+            "state_dict": {model_name: {k: v.detach().cpu() for k, v in model.state_dict().items()}}}
+    path = "%s/model_ckpt_steps_%d.ckpt" % (work_dir, int(global_step))
+    tmp = path + ".part"
+    torch.save(ckpt, tmp)
+    os.replace(tmp, path)
+    for old in get_all_ckpts(work_dir)[num_ckpt_keep:]:
+        os.remove(old)
+    return path
+
+
+def restore_ckpt(work_dir, model, optimizer=None, model_name="model", strict=True):
+    """trainer.py:384-428 (`restore_weights` + `restore_opt_state`).  Returns (global_step, epoch), (0, 0) if the
+    directory holds no checkpoint (the reference then trains from its random init, trainer.py:153-157)."""
+    checkpoint, path = get_last_checkpoint(work_dir)
+    if checkpoint is None:
+        return 0, 0
+    model.load_state_dict(checkpoint["state_dict"][model_name], strict=strict)
+    if optimizer is not None and checkpoint.get("optimizer_states"):
+        try:
+            optimizer.load_state_dict(checkpoint["optimizer_states"][0])
+        except ValueError:
+            print("| WARMING: optimizer parameters not match !!!")  # the reference's message, trainer.py:420
+    from . import ops
+    ops.bump_weights_epoch()  # packed weight images are stale now
+    return int(checkpoint["global_step"]), int(checkpoint["epoch"])

@@ -64,3 +64,50 @@ class FlatAdamW:
                      self.num_updates, sumsq, self.clip, 1.0 / world)
         ops.bump_weights_epoch()
         return lr, sumsq
+
+    # ---- checkpoint interchange with torch.optim.AdamW (the reference's optimizer, tasks/tts/speech_base.py:163-170):
+    #      `optimizer_states[0]` of a reference checkpoint (utils/commons/trainer.py:459-471) loads here and vice versa
+    def _offsets(self):
+        off = 0
+        for p in self.params:
+            yield off, p.numel(), p.shape
+            off += p.numel()
+
+    def state_dict(self):
+        state = {}
+        if self.num_updates > 0:
+            for i, (off, n, shape) in enumerate(self._offsets()):
+                state[i] = {"step": torch.tensor(float(self.num_updates)),
+                            "exp_avg": self.m[off:off + n].view(shape).clone(),
+                            "exp_avg_sq": self.v[off:off + n].view(shape).clone()}
+        group = {"lr": self.lr_at(self.num_updates), "betas": tuple(self.betas), "eps": self.eps,
+                 "weight_decay": self.wd, "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                 "differentiable": False, "fused": None, "initial_lr": self.lr0,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """Accepts torch.optim.AdamW's format; parameters without saved state (never reached by a gradient in the
+        saved run) start from zero moments.  The step counter is shared (torch keeps one per parameter)."""
+        groups = sd["param_groups"]
+        order = [i for g in groups for i in g["params"]]
+        if len(order) != len(self.params):
+            raise ValueError("optimizer parameters do not match: %d saved vs %d here" % (len(order), len(self.params)))
+        self.m.zero_()
+        self.v.zero_()
+        steps = 0
+        offs = list(self._offsets())
+        for pos, key in enumerate(order):
+            st = sd["state"].get(key)
+            if st is None:
+                continue
+            off, n, shape = offs[pos]
+            if tuple(st["exp_avg"].shape) != tuple(shape):
+                raise ValueError("optimizer state %d has shape %s, parameter has %s" % (key, tuple(st["exp_avg"].shape), tuple(shape)))
+            self.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps = max(steps, int(float(st["step"])))
+        self.num_updates = steps
+        g0 = groups[0]
+        self.betas, self.eps, self.wd = tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
+        self.lr0 = g0.get("initial_lr", self.lr0)

@@ -155,3 +155,45 @@ def test_load_ckpt_layouts(tmp_path):
     assert torch.equal(g.state_dict()["conv_pre.bias"], W["conv_pre.bias"] + 1)
     with pytest.raises(AssertionError):
         load_ckpt(g, str(tmp_path / "missing"), "model_gen")
+
+
+def test_checkpoint_save_resume_and_adamw_state_interchange(tmp_path):
+    """Reference checkpoint layout (utils/commons/trainer.py:384-471): save -> rotate -> restore, and the optimizer
+    state in torch.optim.AdamW's own format (a reference `optimizer_states[0]` loads here and ours loads there)."""
+    import torch
+    import set_amd  # noqa: F401
+    from set_amd import ckpt_utils
+    from set_amd.training import FlatAdamW
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    opt = FlatAdamW(model, lr=1e-3, warmup_updates=10)
+    opt.m.normal_()
+    opt.v.uniform_()
+    opt.num_updates = 7
+    sd = opt.state_dict()
+    ref = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.0)
+    ref.load_state_dict(sd)                       # our format is torch's format
+    back = ref.state_dict()
+    for d in (tmp_path / "a", ):
+        for step in (10, 20, 30, 40):
+            opt.num_updates = step
+            p = ckpt_utils.save_ckpt(str(d), model, opt, global_step=step, epoch=1, num_ckpt_keep=2)
+        import os
+        assert sorted(os.listdir(d)) == ["model_ckpt_steps_30.ckpt", "model_ckpt_steps_40.ckpt"] and p.endswith("40.ckpt")
+        raw = torch.load(p, map_location="cpu", weights_only=False)
+        assert set(raw) == {"epoch", "global_step", "checkpoint_callback_best", "optimizer_states", "state_dict"}
+        assert list(raw["state_dict"]) == ["model"]
+    m_saved, v_saved = opt.m.clone(), opt.v.clone()
+    model2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    opt2 = FlatAdamW(model2, lr=1e-3, warmup_updates=10)
+    step, epoch = ckpt_utils.restore_ckpt(str(tmp_path / "a"), model2, opt2)
+    assert (step, epoch) == (40, 1) and opt2.num_updates == 40
+    n = opt.n  # the flat buffers are padded to a multiple of 256; the padding is not part of any parameter
+    assert torch.equal(opt2.m[:n], m_saved[:n]) and torch.equal(opt2.v[:n], v_saved[:n])
+    for a, b in zip(model.parameters(), model2.parameters()):
+        assert torch.equal(a, b)
+    # a torch-AdamW state (what a reference checkpoint holds), incl. a parameter that never saw a gradient
+    del back["state"][3]
+    opt2.load_state_dict(back)
+    assert opt2.num_updates == 7 and float(opt2.m[n - 3:n].abs().sum()) == 0.0 and float(opt2.m[:n - 3].abs().sum()) > 0
+    assert ckpt_utils.restore_ckpt(str(tmp_path / "empty"), model2, opt2) == (0, 0)
