@@ -290,7 +290,7 @@ __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4],
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x;
 #ifdef SET_WINO_PHASES
-#define WPH(k) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - ph[7]; ph[7] = t_; }
+#define WPH(k) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - ph[9]; ph[9] = t_; }
 #else
 #define WPH(k)
 #endif
@@ -580,15 +580,22 @@ __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetSt
         lt.dbg = nullptr;
     };
 #ifdef SET_WINO_PHASES
-    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0] init+publish+wait, [1] stage, [2] gemm1, [3] gate.., [4] gemm2, [5] epilogue
-    ph[7] = __builtin_amdgcn_s_memtime();
+    // [0] init loads + vmcnt drain, [6] barrier, [8] flag/dep-wait/claim + barrier, [1] stage, [2] gemm1, [3] gate.., [4] gemm2, [5] epilogue
+    uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ph[9] = __builtin_amdgcn_s_memtime();
 #else
     uint64_t *ph = nullptr;
 #endif
     int i_done = -1, l_done = 0;  // finished but not yet published tile of this block
     auto publish = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave
+#ifdef SET_WINO_PHASES
+        { const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[0] += t_ - ph[9]; ph[9] = t_; }
+#endif
         __syncthreads();
+#ifdef SET_WINO_PHASES
+        { const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[6] += t_ - ph[9]; ph[9] = t_; }
+#endif
         if (tid == 0 && i_done >= 0) {
             const uint64_t tf0 = __builtin_amdgcn_s_memtime();
 #ifdef SET_WINO_FENCED
@@ -634,7 +641,7 @@ __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetSt
             break;
         }
 #ifdef SET_WINO_PHASES
-        { const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[0] += t_ - ph[7]; ph[7] = t_; }
+        { const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[8] += t_ - ph[9]; ph[9] = t_; }
 #endif
         wino_main(lt, m, smem, ph, s_task, claimed);
         i_done = i;
@@ -644,7 +651,7 @@ __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetSt
     publish();
 #ifdef SET_WINO_PHASES
     if (tid == 0)
-        for (int k = 0; k < 6; ++k) atomicAdd(a.sync_ws + 4 + ntiles + k, (int)(ph[k] >> 10));
+        for (int k = 0; k < 9; ++k) atomicAdd(a.sync_ws + 4 + ntiles + k, (int)(ph[k] >> 10));
 #endif
     if (tid == 0) {  // units of 1024 ticks
         atomicAdd(a.sync_ws + 2, (int)(wait_ticks >> 10));
@@ -796,7 +803,7 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     const int max_dil = 1 << (a.dilation_cycle_length - 1);
     const int task_slot = DC * (ntt + 2 * max_dil);  // float index of the task word
     const size_t lds = (size_t)(task_slot + 4) * sizeof(float);
-    SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + ntiles + (wino ? 8 : 0)) * sizeof(int32_t), s),
+    SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + ntiles + (wino ? 12 : 0)) * sizeof(int32_t), s),
             "set_diffnet_stack(memset)");
     int wps = 2;  // resident blocks per CU
     if (const char *e = getenv("SET_AMD_STACK_WPS")) wps = atoi(e) == 3 ? 3 : 2;

@@ -626,6 +626,26 @@ def test_ragged_and_extreme_shapes_vs_oracle(dev, B, T, Tt, steps, pad):
     assert _maxdiff(a["mel_out"], oret["mel_out"]) < 1e-4
 
 
+@pytest.mark.parametrize("B,T,Tt,steps", [(6, 1548, 120, 1), (3, 65, 11, 2), (1, 5, 2, 2)])
+def test_winograd_forced_ragged_and_max_length_vs_oracle(dev, monkeypatch, B, T, Tt, steps):
+    """The Winograd stack kernel at the reference's max_frames (1548 = 24 full tiles + a 12-frame tail, odd pair
+    count in the tail), across a tile boundary by one frame, and on a 5-frame utterance: vs the oracle to 1e-4."""
+    monkeypatch.setenv("SET_AMD_WINO", "2")
+    model, W = _build_model(dev, "spec_denoiser", 50 + T, steps)
+    inp = Wt.synthetic_inputs(B, T, Tt, seed=T + 3, pad_tail=True)
+    noises = Wt.synthetic_noises(B, T, steps, seed=T + 4)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    nz = torch.stack(noises).to(dev)
+    a = model(d["txt_tokens"], d["time_mel_masks"], d["mel2ph"], d["spk_embed"], d["ref_mels"], d["f0"], d["uv"],
+              infer=True, noises=nz, persistent=True)
+    n_or = min(B, 2)  # the oracle on the first utterances (seconds on the CPU even at T=1548)
+    sub = {k: v[:n_or] for k, v in inp.items()}
+    oret = O.gaussian_diffusion_infer(W, steps, sub, [n[:n_or] for n in noises])
+    assert torch.equal(a["mel2ph"][:n_or].cpu(), oret["mel2ph"])
+    assert _maxdiff(a["mel_out"][:n_or], oret["mel_out"]) < 1e-4
+    assert torch.isfinite(a["mel_out"]).all()
+
+
 def test_all_padding_and_all_masked_utterances(dev):
     """Degenerate inputs: one utterance fully padded (mel2ph == 0 everywhere), one fully masked, one unmasked."""
     steps, B, T, Tt = 2, 3, 48, 10

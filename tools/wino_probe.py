@@ -38,8 +38,9 @@ for mode in ("0", "2"):
     w = ws[:4].cpu().tolist()
     if mode == "2" and os.environ.get("WINO_PHASES"):
         nt = B * ((T + 63) // 64)
-        ph = ws[4 + nt:4 + nt + 6].cpu().tolist(); tot = float(sum(ph))
-        print("   phases (init+publish+wait, stage, gemm1, gate+prev, gemm2, epilogue) %%: %s" % " ".join("%.1f" % (100 * v / tot) for v in ph))
+        ph = ws[4 + nt:4 + nt + 9].cpu().tolist(); tot = float(sum(ph))
+        names = ["init+drain", "stage", "gemm1", "gate+prev", "gemm2", "epilogue", "barrier", "-", "flag/wait/claim"]
+        print("   phases %%: %s" % "  ".join("%s %.1f" % (n, 100 * v / tot) for n, v in zip(names, ph) if n != "-"))
     print("WINO=%s  %.3f ms  (%.1f us per layer, %.1f algorithmic TF/s)  tasks %d abort %d wait %d fence %d" % (
         mode, ms, ms * 1e3 / L, 2 * 524288 * B * T * L / ms / 1e9, w[0], w[1], w[2], w[3]))
 for k, name in ((0, "x"), (1, "skip")):
