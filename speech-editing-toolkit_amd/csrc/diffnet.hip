@@ -1019,6 +1019,186 @@ extern "C" int set_selftest_mfma(float *max_err_host, void *stream) {
 // ----------------------------------------------------------------------------------------------------------
 // the reverse loop: enqueue steps x (in-proj, L fused layers, skip-proj, out-proj, posterior)
 // ----------------------------------------------------------------------------------------------------------
+// ----------------------------------------------------------------------------------------------------------
+// Step boundary: everything between the layer stack of step k and the layer stack of step k+1 in ONE launch:
+//   h   = ReLU(W_skip * (skip / sqrt(L)) + b_skip)            (diffnet.py:128-130)
+//   x0  = W_out * h + b_out                                    (diffnet.py:131)
+//   x'  = c1 x0 + c2 x_t + nonzero * exp(logvar/2) * eps       (spec_denoiser.py:86-101, eps explicit or Philox)
+//   xin = ReLU(W_in * x' + b_in)                               (diffnet.py:118-120, input of the next step)
+// One block = one utterance x 64 frames, 4 waves, everything stays in LDS/registers between the three GEMMs.  The
+// four separate launches this replaces were latency-bound (31 + 75 + 51 + 14 us at B=32, T=800).  Weights are the
+// ordinary packed conv images (set_pack_conv_weight); arithmetic order (prologue divide, bias after the sum, Philox
+// quad = 4 consecutive frames of one row) equals the unfused kernels, so results are bit-identical to them.
+// Needs T % 4 == 0 (quad alignment), 256 residual channels, M <= 96 mel bins.
+// ----------------------------------------------------------------------------------------------------------
+struct BoundaryArgs {
+    const float *skip;      // [B][256][T]
+    float *x;               // [B][M][T]  in: x_t, out: x_{t-1}
+    const float *eps;       // [B][M][T] or NULL
+    const float *coef4;     // {c1, c2, logvar, nonzero} of this step (device)
+    const float *w_skip_p, *b_skip, *w_outp_p, *b_outp, *w_in_p, *b_in;
+    float *xin_next;        // [B][256][T] or NULL (last step)
+    float inv_div;          // unused (division by sqrt(L) is done exactly as the conv prologue does: x / p)
+    float div;
+    uint64_t seed, quad_offset;
+    int T, M, MP;           // MP = M rounded up to 16 (rows of the x' tile in LDS, K of the head GEMM)
+};
+constexpr int BD_LD = 64;
+
+__global__ void __launch_bounds__(256, 2) diffnet_boundary_kernel(BoundaryArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [256][64]: skip tile -> h tile -> x' tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y, t0 = blockIdx.x * 64, T = a.T, M = a.M;
+    // ---- phase 1: skip tile / sqrt(L) -> LDS (wave w: rows 64w .. 64w+63, lanes along t; unconditional clamped loads)
+    {
+        const rsrc_t rs = make_rsrc(a.skip + (int64_t)b * DC * T);
+        const unsigned vo = 4u * (unsigned)min(t0 + lane, T - 1);
+        const bool tv = t0 + lane < T;
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = buf_load(rs, vo, 4u * (unsigned)(64 * w + r0 + u) * (unsigned)T);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) smem[(64 * w + r0 + u) * BD_LD + lane] = tv ? v[u] / a.div : 0.0f;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: h = ReLU(W_skip * s + b): wave w owns rows [64w, 64w+64) = row blocks 2w, 2w+1
+    f32x16 acc[2][1][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        acc[i][0][0] = (f32x16){0};
+        acc[i][0][1] = (f32x16){0};
+        const float *wp = a.w_skip_p + (int64_t)(2 * w + i) * (DC / 2) * 64 + lane;
+        const float *bp = smem + half * BD_LD + l31;
+        gemm_groups<1, 2, 8>(acc[i], wp, bp, 2 * BD_LD, (DC / 2) / 8, [&](int) {
+            wp += 8 * 64;
+            bp += 8 * 2 * BD_LD;
+        });
+    }
+    __syncthreads();  // every wave is done reading the skip tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * (2 * w + i) + mfma32_row(r, lane);
+            const float bias = a.b_skip[row];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) smem[row * BD_LD + 32 * cb + l31] = fmaxf(acc[i][0][cb][r] + bias, 0.0f);
+        }
+    __syncthreads();
+    // ---- phase 3: x0 = W_out * h + b: row blocks 0..ceil(M/32)-1 on waves 0..2
+    const int rbn = (M + 31) / 32;
+    f32x16 xo[1][2];
+    xo[0][0] = (f32x16){0};
+    xo[0][1] = (f32x16){0};
+    if (w < rbn) {
+        const float *wp = a.w_outp_p + (int64_t)w * (DC / 2) * 64 + lane;
+        const float *bp = smem + half * BD_LD + l31;
+        gemm_groups<1, 2, 8>(xo, wp, bp, 2 * BD_LD, (DC / 2) / 8, [&](int) {
+            wp += 8 * 64;
+            bp += 8 * 2 * BD_LD;
+        });
+    }
+    __syncthreads();  // h tile consumed
+    if (w < rbn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * w + mfma32_row(r, lane);
+            const float bias = a.b_outp[min(row, M - 1)];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) smem[row * BD_LD + 32 * cb + l31] = row < M ? xo[0][cb][r] + bias : 0.0f;
+        }
+    }
+    __syncthreads();
+    // ---- phase 4: posterior update on quads of 4 consecutive frames (T % 4 == 0: a quad never straddles rows)
+    {
+        const float c1 = a.coef4[0], c2 = a.coef4[1], sig = a.coef4[3] * expf(0.5f * a.coef4[2]);
+        float *xb = a.x + (int64_t)b * M * T;
+        const float *eb = a.eps ? a.eps + (int64_t)b * M * T : nullptr;
+        for (int qi = tid; qi < a.MP * 16; qi += 256) {
+            const int m = qi >> 4, tq = qi & 15, t = t0 + 4 * tq;
+            float *cell = smem + m * BD_LD + 4 * tq;
+            if (m < M && t < T) {
+                const int64_t i = (int64_t)m * T + t;
+                const f32x4 xt = *reinterpret_cast<const f32x4 *>(xb + i);
+                float z[4];
+                if (eb) {
+                    const f32x4 e4 = *reinterpret_cast<const f32x4 *>(eb + i);
+                    z[0] = e4[0]; z[1] = e4[1]; z[2] = e4[2]; z[3] = e4[3];
+                } else {
+                    randn4(a.seed, a.quad_offset + (uint64_t)(((int64_t)b * M * T + i) >> 2), z);
+                }
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float mean = c1 * cell[k] + c2 * xt[k];
+                    o[k] = mean + sig * z[k];
+                }
+                *reinterpret_cast<f32x4 *>(xb + i) = o;
+                *reinterpret_cast<f32x4 *>(cell) = o;
+            } else {
+                *reinterpret_cast<f32x4 *>(cell) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};  // K padding rows / frames >= T
+            }
+        }
+    }
+    if (!a.xin_next) return;
+    __syncthreads();
+    // ---- phase 5: next step's input projection xin = ReLU(W_in * x' + b_in), K = MP
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        acc[i][0][0] = (f32x16){0};
+        acc[i][0][1] = (f32x16){0};
+        const float *wp = a.w_in_p + (int64_t)(2 * w + i) * (a.MP / 2) * 64 + lane;
+        const float *bp = smem + half * BD_LD + l31;
+        gemm_groups<1, 2, 4>(acc[i], wp, bp, 2 * BD_LD, (a.MP / 2) / 4, [&](int) {
+            wp += 4 * 64;
+            bp += 4 * 2 * BD_LD;
+        });
+    }
+    const rsrc_t ro = make_rsrc(a.xin_next + (int64_t)b * DC * T);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        if (t0 + 32 * cb + l31 < T) {
+            const unsigned so = 4u * (unsigned)(4 * half * T + t0 + 32 * cb + l31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ur = 32 * (2 * w + i) + urow16(r);  // wave-uniform; + 4*half rows in the lane offset
+                    const float bias = (a.b_in + ur)[4 * half];
+                    buf_store(fmaxf(acc[i][0][cb][r] + bias, 0.0f), ro, so, 4u * (unsigned)ur * (unsigned)T);
+                }
+        }
+    }
+}
+
+static bool boundary_fusable(const SetDiffLoopArgs &a) {
+    if (const char *e = getenv("SET_AMD_FUSED_BOUNDARY"))
+        if (atoi(e) == 0) return false;
+    return a.T % 4 == 0 && a.M <= 96 && a.M >= 2 && ((a.M + 15) / 16 * 16 / 2) % 8 == 0;
+}
+
+static int launch_boundary(const SetDiffLoopArgs &a, int Bg, const float *skip, float *x, const float *eps, int sid,
+                           uint64_t quad_offset, float *xin_next, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_boundary_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "boundary(attr)");
+        attr_set = true;
+    }
+    BoundaryArgs g = {};
+    g.skip = skip; g.x = x; g.eps = eps; g.coef4 = a.coef4 + 4 * sid;
+    g.w_skip_p = a.w_skip_p; g.b_skip = a.b_skip; g.w_outp_p = a.w_outp_p; g.b_outp = a.b_outp;
+    g.w_in_p = a.w_in_p; g.b_in = a.b_in; g.xin_next = xin_next;
+    g.div = sqrtf((float)a.L); g.seed = a.seed; g.quad_offset = quad_offset;
+    g.T = a.T; g.M = a.M; g.MP = (a.M + 15) / 16 * 16;
+    hipLaunchKernelGGL(diffnet_boundary_kernel, dim3((a.T + 63) / 64, Bg), dim3(256), (size_t)DC * BD_LD * sizeof(float), s, g);
+    return set_check_launch("set_diffusion_loop(boundary)");
+}
+
 static SetConv1dArgs conv1x1_args(const float *in, const float *wp, const float *bias, float *out, int B, int Cin,
                                   int Cout, int T) {
     SetConv1dArgs c = {};
@@ -1052,13 +1232,17 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
     const uint64_t quads_before = (uint64_t)((int64_t)b0 * per_batch / 4);
     const uint64_t quads_total = (uint64_t)(((int64_t)a.B * per_batch + 3) / 4);
     int rc = SET_OK;
+    const bool fused_boundary = boundary_fusable(a);
     for (int k = 0; k < a.steps && rc == SET_OK; ++k) {
         const int sid = a.steps - 1 - k;  // diffusion step id t = steps-1 .. 0 (spec_denoiser.py:181)
-        // input projection + ReLU (diffnet.py:118-120)
-        SetConv1dArgs cin = conv1x1_args(x, a.w_in_p, a.b_in, ws_x0, Bg, M, DC, T);
-        cin.act = SET_ACT_RELU;
-        rc = set_conv1d(&cin, s);
-        if (rc != SET_OK) break;
+        // input projection + ReLU (diffnet.py:118-120); with the fused boundary it is part of the previous step's
+        // boundary launch
+        if (!fused_boundary || k == 0) {
+            SetConv1dArgs cin = conv1x1_args(x, a.w_in_p, a.b_in, ws_x0, Bg, M, DC, T);
+            cin.act = SET_ACT_RELU;
+            rc = set_conv1d(&cin, s);
+            if (rc != SET_OK) break;
+        }
         float *cur = ws_x0, *nxt = ws_x1;
         if (ev) (void)hipEventRecord(ev[2 * k], s);
         if (a.persistent) {
@@ -1087,6 +1271,13 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
         }
         if (ev) (void)hipEventRecord(ev[2 * k + 1], s);
         if (rc != SET_OK) break;
+        const float *eps = a.noise ? a.noise + (int64_t)k * a.B * per_batch + (int64_t)b0 * per_batch : nullptr;
+        if (fused_boundary) {
+            // only the skip sum feeds the output head (diffnet.py:128); the next step's stack input buffer is ws_x0
+            rc = launch_boundary(a, Bg, ws_skip, x, eps, sid, (uint64_t)(k + 1) * quads_total + quads_before,
+                                 k + 1 < a.steps ? ws_x0 : nullptr, s);
+            continue;
+        }
         // skip sum / sqrt(L) -> skip_projection -> ReLU -> output_projection (diffnet.py:128-131)
         SetConv1dArgs cs = conv1x1_args(ws_skip, a.w_skip_p, a.b_skip, ws_h, Bg, DC, DC, T);
         cs.pro = SET_PRO_DIV; cs.pro_param = sqrtf((float)L); cs.act = SET_ACT_RELU;
@@ -1095,7 +1286,6 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
         SetConv1dArgs co = conv1x1_args(ws_h, a.w_outp_p, a.b_outp, ws_x0pred, Bg, DC, M, T);
         rc = set_conv1d(&co, s);
         if (rc != SET_OK) break;
-        const float *eps = a.noise ? a.noise + (int64_t)k * a.B * per_batch + (int64_t)b0 * per_batch : nullptr;
         // Philox counters are global element quads, so the noise does not depend on the grouping
         rc = set_posterior_step(ws_x0pred, x, eps, a.coef4 + 4 * sid, 0, x, Bg, per_batch, a.seed,
                                 (uint64_t)(k + 1) * quads_total + quads_before, s);

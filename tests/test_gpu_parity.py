@@ -459,6 +459,28 @@ def test_full_inference_matches_reference_with_winograd_forced(dev, monkeypatch,
     assert _maxdiff(ret["mel_out"], ret0["mel_out"]) < 5e-5
 
 
+@pytest.mark.parametrize("case", ["infer_pad", "infer_tiny"])
+def test_fused_step_boundary_equals_separate_kernels(dev, monkeypatch, case):
+    """One launch per step for skip-projection + output-projection + posterior update + next input projection
+    (T % 4 == 0) against the four separate kernels: same arithmetic order -> bit-identical, with explicit noise and
+    with the on-device Philox stream (same quad numbering)."""
+    g = load_golden(case)
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"])
+    inp, noises = _case_inputs(g, dev)
+    args = (inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"],
+            inp["uv"])
+    assert m["T"] % 4 == 0
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SET_AMD_FUSED_BOUNDARY", mode)
+        out[mode] = (model(*args, infer=True, noises=noises)["mel_out"], model(*args, infer=True, seed=11)["mel_out"],
+                     model(*args, infer=True, noises=noises, persistent=False)["mel_out"])
+    assert _maxdiff(out["1"][0], g["mel_out"]) < 1e-4
+    for a, b in zip(out["1"], out["0"]):
+        assert torch.equal(a, b), float((a - b).abs().max())
+
+
 def test_loop_persistent_equals_per_layer_launches(dev):
     g = load_golden("infer_pad")
     m = g["meta"]
