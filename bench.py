@@ -65,17 +65,25 @@ def cpu_baseline(model, inp, n_timed=3):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, 1, M, T, generator=g)
     times = []
+    parity = None
     for k in range(1 + n_timed):
         i = DIFF_STEPS - 1 - k
         tt = torch.full((B,), i, dtype=torch.long)
         eps = torch.randn(B, 1, M, T, generator=g)
         t0 = time.perf_counter()
         x0 = O.diffnet_forward(W, x, tt, cond)
+        if parity is None:  # the checker's by-product: the same DiffNet pass on the GPU path, full benchmark size
+            dev = next(model.parameters()).device
+            with torch.no_grad():
+                x0_gpu = model.denoise_fn(x.to(dev), tt.to(dev), cond.to(dev).contiguous())
+            parity = float((x0_gpu.cpu().double() - x0.double()).abs().max())
+            # (this is iteration 0, the warm-up, which is not part of the timed mean)
         x = O.q_posterior_sample(tab, x0, x, tt, eps)
         times.append(time.perf_counter() - t0)
     t_step = sum(times[1:]) / n_timed
     total = t_cond + DIFF_STEPS * t_step
     return {"value": B * T / total, "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "parity_max_abs_dx0_one_pass": parity,
             "sample": "conditioner once + %d timed DiffNet+posterior steps (after 1 warm-up) at B=%d,T=%d, scaled to "
                       "%d steps; s/step=%.3f, conditioner s=%.3f" % (n_timed, B, T, DIFF_STEPS, t_step, t_cond)}
 
