@@ -195,13 +195,23 @@ def build(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found; cannot build libset_amd.so")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    # one builder at a time: `torchrun --nproc-per-node 8 bench.py` calls this from every rank
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():  # another process built it while we waited
+                return LIB_PATH
+            tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
+            cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + r.stdout)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
