@@ -53,7 +53,20 @@ struct LayerTile {
     const float *w1p, *b_dil, *w2p, *b_out;
     int T, t0, dil, first;
     uint64_t *dbg;
+    // Winograd kernel only: tile geometry over frame offsets q = -1 .. 64 from the tile start.  Frames q >= o belong
+    // to the NEXT utterance (cross-utterance tiling of the concatenated frame axis; o = 1 << 20 when the tile lies
+    // inside one utterance): slab pointers above are those of the first utterance, x_bs4 / cp_bs4 the byte strides to
+    // the next one.  nvalid = frames of the tile that exist, halo_l / halo_r = frames q = -1 / q = 64 exist (and, for
+    // q = -1, belong to the same utterance as q = 0).
+    int o, nvalid, halo_l, halo_r;
+    unsigned x_bs4, cp_bs4;
 };
+
+// frame offset q (already clamped into the valid range) -> byte offset inside the first utterance's row
+__device__ __forceinline__ unsigned wn_voff(const LayerTile &a, int q, unsigned slab4) {
+    const bool side = q >= a.o;
+    return 4u * (unsigned)(a.t0 + q - (side ? a.T : 0)) + (side ? slab4 : 0u);
+}
 
 template <int NCB, int GS>
 __device__ __forceinline__ void layer_tile(const LayerTile &a, float *smem) {
@@ -251,7 +264,7 @@ __global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerAr
 // ds_read_b64 + 4 VALU per k-step); the filter transform is folded into the packed weights; bias + conditioner
 // projection are folded into the M1 / M4 accumulator init.  GEMM 2 and the epilogue are as in layer_tile<2>.
 constexpr int WN_NT = 64;
-constexpr int WN_XW = WN_NT + 2;
+constexpr int WN_XW = WN_NT + 4;  // frame -1, 64 frames, frame 64, + a 2-column zero gap at an utterance boundary
 constexpr int WN_KS = DC / 2;  // 128 k-steps (2 channels each) for every GEMM here
 constexpr int WN_GS = 2;       // k-steps per operand group of GEMM 1
 
@@ -263,8 +276,10 @@ __device__ __forceinline__ void wino_init(const LayerTile &a, f32x16 (&m)[2][4])
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int T = a.T;
-    const int te = a.t0 + 2 * l31;  // output pair j = l31 -> frames te (even slot), te + 1
-    const unsigned loe = 4u * (unsigned)(4 * half * T + min(te, T - 1)), loo = 4u * (unsigned)(4 * half * T + min(te + 1, T - 1));
+    // output pair j = l31 -> frame offsets 2j (even slot), 2j + 1; clamped to the last existing frame
+    const int qe = min(2 * l31, a.nvalid - 1), qo = min(2 * l31 + 1, a.nvalid - 1);
+    const unsigned rowh = 16u * (unsigned)half * (unsigned)T;  // + 4*half rows
+    const unsigned loe = rowh + wn_voff(a, qe, a.cp_bs4), loo = rowh + wn_voff(a, qo, a.cp_bs4);
     const unsigned lb = 16u * (unsigned)half;
     const rsrc_t rcp = make_rsrc(a.cpb), rb = make_rsrc(a.b_dil);
     // M1 <- b + cp(even), M4 <- -(b + cp(odd)), M2 = M3 = 0
@@ -282,7 +297,7 @@ __device__ __forceinline__ void wino_init(const LayerTile &a, f32x16 (&m)[2][4])
     }
 }
 
-// xs = smem[0 .. 256*66), zs = smem + WN_ZS_OFF (own region: no barrier between the last xs read and the zs write)
+// xs = smem[0 .. 256*68), zs = smem + WN_ZS_OFF (own region: no barrier between the last xs read and the zs write)
 constexpr int WN_ZS_OFF = DC * WN_XW;
 
 __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4], float *smem, uint64_t *ph, int *s_task,
@@ -300,14 +315,20 @@ __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4],
     const int t0 = a.t0, T = a.T;
     const unsigned T4 = 4u * (unsigned)T;
     float *zs = smem + WN_ZS_OFF;
-    const bool tve = t0 + 2 * l31 < T, tvo = t0 + 2 * l31 + 1 < T;
+    const bool tve = 2 * l31 < a.nvalid, tvo = 2 * l31 + 1 < a.nvalid;
     const rsrc_t rxin = make_rsrc(a.xin), rskp = make_rsrc(a.skp), rxout = make_rsrc(a.xout);
 
-    // ---- stage the raw (x + d) tile xs[256][66], column i <-> frame t0 - 1 + i; wave w owns channels [32w, 32w+32)
+    // ---- stage the raw (x + d) tile xs[256][68]; wave w owns channels [32w, 32w+32).  Frame offset q sits in column
+    //      q + 1 (+ 2 when it belongs to the next utterance): the two columns in between stay zero, so the last pair
+    //      of one utterance and the first pair of the next both see the conv's zero padding.
     {
-        const int tA = t0 - 1 + lane, tB = tA + 64;
-        const bool vA = tA >= 0 && tA < T, vB = tB >= 0 && tB < T;
-        const unsigned cA = 4u * (unsigned)min(max(tA, 0), T - 1), cB = 4u * (unsigned)min(max(tB, 0), T - 1);
+        const int qA = lane;                            // columns of frames 0..63
+        const int qB = lane == 0 ? -1 : 64;             // lanes 0 / 1: the halo frames -1 / 64
+        const bool vA = qA < a.nvalid, vB = lane == 0 ? a.halo_l != 0 : (lane == 1 && a.halo_r != 0);
+        const unsigned cA = wn_voff(a, min(qA, a.nvalid - 1), a.x_bs4);
+        const unsigned cB = vB ? wn_voff(a, qB, a.x_bs4) : cA;  // (invalid: any valid address, value unused)
+        const int colA = qA + 1 + (qA >= a.o ? 2 : 0), colB = qB + 1 + (qB >= a.o ? 2 : 0);
+        const bool gap = a.o <= 64;                     // an utterance boundary lies in (or at the end of) this tile
         for (int r0 = 0; r0 < 32; r0 += 16) {
             float xa[16], xb[16], dd[16];
 #pragma unroll
@@ -320,8 +341,9 @@ __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4],
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int c = 32 * w + r0 + u;
-                smem[c * WN_XW + lane] = vA ? xa[u] + dd[u] : 0.0f;
-                if (lane < 2) smem[c * WN_XW + 64 + lane] = vB ? xb[u] + dd[u] : 0.0f;
+                smem[c * WN_XW + colA] = vA ? xa[u] + dd[u] : 0.0f;
+                if (lane < 2) smem[c * WN_XW + colB] = vB ? xb[u] + dd[u] : 0.0f;
+                if (gap && lane >= 2 && lane < 4) smem[c * WN_XW + a.o + lane - 1] = 0.0f;  // columns o+1, o+2
             }
         }
     }
@@ -333,7 +355,7 @@ __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4],
         const rsrc_t rw = make_rsrc(a.w1p);
         const unsigned wv = 32u * (unsigned)lane;                // 8 floats per lane per k-step
         unsigned ws = (unsigned)w * (WN_KS * 64 * 8 * 4);        // wave-uniform byte offset of the current group
-        const f32x2 *bp = reinterpret_cast<const f32x2 *>(smem + half * WN_XW + 2 * l31);
+        const f32x2 *bp = reinterpret_cast<const f32x2 *>(smem + half * WN_XW + 2 * l31 + (2 * l31 >= a.o ? 2 : 0));
         struct Ops { f32x4 A[WN_GS][2]; f32x2 D[WN_GS][2]; };
         Ops P, Q;
         auto load_step = [&](Ops &o, int u) {
@@ -394,8 +416,9 @@ __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4],
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- put the residual / running-skip tiles in flight (m is dead now); they are consumed after GEMM 2
-    const unsigned lo0 = 4u * (unsigned)(4 * half * T + min(t0 + l31, T - 1)), lo1 = 4u * (unsigned)(4 * half * T + min(t0 + 32 + l31, T - 1));
-    const bool tv0 = t0 + l31 < T, tv1 = t0 + 32 + l31 < T;
+    const unsigned rowh = 16u * (unsigned)half * (unsigned)T;  // + 4*half rows
+    const unsigned lo0 = rowh + wn_voff(a, min(l31, a.nvalid - 1), a.x_bs4), lo1 = rowh + wn_voff(a, min(32 + l31, a.nvalid - 1), a.x_bs4);
+    const bool tv0 = l31 < a.nvalid, tv1 = 32 + l31 < a.nvalid;
     const bool first = a.first != 0;
     f32x16 prev[2][2];
 #pragma unroll
@@ -437,7 +460,7 @@ __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4],
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         if (cb == 0 ? tv0 : tv1) {
-            const unsigned so = 4u * (unsigned)(4 * half * T + t0 + 32 * cb + l31);
+            const unsigned so = cb == 0 ? lo0 : lo1;  // valid frame: the clamp was a no-op
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -548,7 +571,7 @@ __global__ void __launch_bounds__(256, WPS) diffnet_stack_kernel(SetDiffnetStack
 // tiles, so that wait, the store drain and the release fence of the previous task overlap with them.  Claiming
 // ahead is deadlock-free: a block finishes its claims in claim order, and a claim only ever waits on earlier ones.
 __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles,
-                                                                    int ntasks) {
+                                                                    int ntasks, int concat) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int *s_task = reinterpret_cast<int *>(smem + WN_ZS_OFF + DC * WN_NT);
     int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
@@ -562,8 +585,27 @@ __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetSt
     auto decode = [&](int task) {
         l = task / ntiles;
         i = task - l * ntiles;
-        const int b = i / tiles_per_utt;
-        j = i - b * tiles_per_utt;
+        int b;
+        if (concat) {  // tile i covers frames [64 i, 64 i + 64) of the concatenated axis; tiles_per_utt == ntiles, j == i
+            const int64_t f0 = (int64_t)WN_NT * i, F = (int64_t)a.B * a.T;
+            b = (int)(f0 / a.T);
+            j = i;
+            lt.t0 = (int)(f0 - (int64_t)b * a.T);
+            lt.o = (a.T - lt.t0 <= WN_NT && b + 1 < a.B) ? a.T - lt.t0 : (1 << 20);
+            lt.nvalid = (int)min((int64_t)WN_NT, (b + 1 < a.B ? F : (int64_t)(b + 1) * a.T) - f0);
+            lt.halo_l = lt.t0 > 0;
+            lt.halo_r = f0 + WN_NT < F;
+        } else {
+            b = i / tiles_per_utt;
+            j = i - b * tiles_per_utt;
+            lt.t0 = j * WN_NT;
+            lt.o = 1 << 20;
+            lt.nvalid = min(WN_NT, a.T - lt.t0);
+            lt.halo_l = lt.t0 > 0;
+            lt.halo_r = lt.t0 + WN_NT < a.T;
+        }
+        lt.x_bs4 = 4u * (unsigned)DC * (unsigned)a.T;
+        lt.cp_bs4 = 4u * (unsigned)a.cp_bs;
         const float *xi = (l & 1) ? a.xb : a.xa;
         float *xo = (l & 1) ? a.xa : a.xb;
         lt.xin = xi + (int64_t)b * DC * a.T;
@@ -576,7 +618,7 @@ __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetSt
         lt.w2p = a.w2w_all + (int64_t)l * (512 * 256);
         lt.b_dil = a.b_dil_all + (int64_t)l * 512;
         lt.b_out = a.b_out_all + (int64_t)l * 512;
-        lt.T = a.T; lt.t0 = j * WN_NT; lt.dil = 1; lt.first = (l == 0);
+        lt.T = a.T; lt.dil = 1; lt.first = (l == 0);
         lt.dbg = nullptr;
     };
 #ifdef SET_WINO_PHASES
@@ -796,8 +838,16 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     const bool wino = variant == 2;
     const int ncb = variant == 1 ? 1 : 2;
     const int ntt = 32 * ncb;
-    const int tiles_per_utt = (a.T + ntt - 1) / ntt;
-    const int ntiles = a.B * tiles_per_utt;
+    int tiles_per_utt = (a.T + ntt - 1) / ntt;
+    int ntiles = a.B * tiles_per_utt;
+    // Winograd kernel: tile the CONCATENATED frame axis when an utterance boundary can only fall between output pairs
+    // (T even) and at most once per tile (T >= 64): B*T/64 tiles instead of B*ceil(T/64) (T = 800: 400 vs 416).
+    bool concat = wino && a.T % 2 == 0 && a.T >= WN_NT && (int64_t)a.cp_bs * 4 < (1ll << 31) && a.d_bs == 0;
+    if (const char *e = getenv("SET_AMD_CONCAT")) concat = concat && atoi(e) != 0;
+    if (concat) {
+        ntiles = (int)(((int64_t)a.B * a.T + WN_NT - 1) / WN_NT);
+        tiles_per_utt = ntiles;  // one chain of tiles: neighbours are i-1 / i+1 everywhere
+    }
     const int64_t ntasks64 = (int64_t)ntiles * a.L;
     SET_REQUIRE(ntasks64 < (1ll << 30), "set_diffnet_stack(task count)");
     const int max_dil = 1 << (a.dilation_cycle_length - 1);
@@ -817,7 +867,8 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     if (grid < 1) grid = 1;
     if (wino)
         hipLaunchKernelGGL(diffnet_stack_wino_kernel, dim3(grid), dim3(512),
-                           (size_t)(WN_ZS_OFF + DC * WN_NT + 4) * sizeof(float), s, a, tiles_per_utt, ntiles, (int)ntasks64);
+                           (size_t)(WN_ZS_OFF + DC * WN_NT + 4) * sizeof(float), s, a, tiles_per_utt, ntiles, (int)ntasks64,
+                           concat ? 1 : 0);
     else if (ncb == 1 && wps == 3)
         hipLaunchKernelGGL((diffnet_stack_kernel<1, 4, 3>), dim3(grid), dim3(256), lds, s, a, tiles_per_utt, ntiles,
                            (int)ntasks64, task_slot);
