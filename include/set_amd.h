@@ -257,7 +257,12 @@ int set_q_sample(const float *x_start, const float *eps, const float *ab2, const
 int set_randn(float *out, int64_t n, uint64_t seed, uint64_t offset, void *stream);
 
 /* Whole reverse loop (spec_denoiser.py:178-184 + p_sample :103-108 + DiffNet.forward diffnet.py:110-132)
- * for residual_channels == 256.  All weights pre-packed by the caller; workspaces provided by the caller. */
+ * for residual_channels == 256.  All weights pre-packed by the caller; workspaces provided by the caller.
+ * Launch sequence: input projection once, then per step {layer stack (set_diffnet_stack, or L set_diffnet_layer
+ * launches when persistent == 0), step boundary}.  The step boundary -- skip projection + output projection +
+ * posterior update (explicit or Philox noise) + the NEXT step's input projection -- is one fused kernel when
+ * T % 4 == 0 and M <= 96 (bit-identical to the separate set_conv1d / set_posterior_step launches it replaces, which
+ * remain the path for other shapes; SET_AMD_FUSED_BOUNDARY=0 forces them). */
 typedef struct SetDiffLoopArgs {
     /* problem */
     int32_t B, T, M, L, steps, dilation_cycle_length;
