@@ -62,6 +62,9 @@ struct LayerTile {
     unsigned x_bs4, cp_bs4;
 };
 
+// pair index p (0..31) -> frame offset of its first output: blocks of 2d frames, (q, q + d) paired inside a block
+__device__ __forceinline__ int wn_pair_q(int p, int d) { return 2 * d * (p / d) + (p % d); }
+
 // frame offset q (already clamped into the valid range) -> byte offset inside the first utterance's row
 __device__ __forceinline__ unsigned wn_voff(const LayerTile &a, int q, unsigned slab4) {
     const bool side = q >= a.o;
@@ -264,7 +267,8 @@ __global__ void __launch_bounds__(256, 2) diffnet_layer_kernel(SetDiffnetLayerAr
 // ds_read_b64 + 4 VALU per k-step); the filter transform is folded into the packed weights; bias + conditioner
 // projection are folded into the M1 / M4 accumulator init.  GEMM 2 and the epilogue are as in layer_tile<2>.
 constexpr int WN_NT = 64;
-constexpr int WN_XW = WN_NT + 4;  // frame -1, 64 frames, frame 64, + a 2-column zero gap at an utterance boundary
+constexpr int WN_MAXD = 8;             // largest dilation (dilation_cycle_length <= 4)
+constexpr int WN_XW = WN_NT + 2 * WN_MAXD;  // 64 frames + a halo of d on each side (d = 1: + the 2-column boundary gap)
 constexpr int WN_KS = DC / 2;  // 128 k-steps (2 channels each) for every GEMM here
 constexpr int WN_GS = 2;       // k-steps per operand group of GEMM 1
 
@@ -276,8 +280,10 @@ __device__ __forceinline__ void wino_init(const LayerTile &a, f32x16 (&m)[2][4])
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int T = a.T;
-    // output pair j = l31 -> frame offsets 2j (even slot), 2j + 1; clamped to the last existing frame
-    const int qe = min(2 * l31, a.nvalid - 1), qo = min(2 * l31 + 1, a.nvalid - 1);
+    // output pair j = l31 -> frame offsets q_e ("even" slot) and q_e + d: the F(2,3) pairing runs over frames that are
+    // d apart (d = 1: 2j, 2j + 1); clamped to the last existing frame
+    const int qe0 = wn_pair_q(l31, a.dil);
+    const int qe = min(qe0, a.nvalid - 1), qo = min(qe0 + a.dil, a.nvalid - 1);
     const unsigned rowh = 16u * (unsigned)half * (unsigned)T;  // + 4*half rows
     const unsigned loe = rowh + wn_voff(a, qe, a.cp_bs4), loo = rowh + wn_voff(a, qo, a.cp_bs4);
     const unsigned lb = 16u * (unsigned)half;
@@ -300,6 +306,7 @@ __device__ __forceinline__ void wino_init(const LayerTile &a, f32x16 (&m)[2][4])
 // xs = smem[0 .. 256*68), zs = smem + WN_ZS_OFF (own region: no barrier between the last xs read and the zs write)
 constexpr int WN_ZS_OFF = DC * WN_XW;
 
+template <bool UNIT_DIL>  // UNIT_DIL: every layer has dilation 1 (compile-time, keeps the shipped configuration's inner loop lean)
 __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4], float *smem, uint64_t *ph, int *s_task,
                                           int claimed) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -315,19 +322,25 @@ __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4],
     const int t0 = a.t0, T = a.T;
     const unsigned T4 = 4u * (unsigned)T;
     float *zs = smem + WN_ZS_OFF;
-    const bool tve = 2 * l31 < a.nvalid, tvo = 2 * l31 + 1 < a.nvalid;
+    constexpr int XW = UNIT_DIL ? WN_NT + 4 : WN_XW;  // LDS row of the x tile (68 keeps the dilation-1 layout)
+    const int d = UNIT_DIL ? 1 : a.dil, qe = UNIT_DIL ? 2 * l31 : wn_pair_q(l31, d);
+    const bool tve = qe < a.nvalid, tvo = qe + d < a.nvalid;
     const rsrc_t rxin = make_rsrc(a.xin), rskp = make_rsrc(a.skp), rxout = make_rsrc(a.xout);
 
-    // ---- stage the raw (x + d) tile xs[256][68]; wave w owns channels [32w, 32w+32).  Frame offset q sits in column
-    //      q + 1 (+ 2 when it belongs to the next utterance): the two columns in between stay zero, so the last pair
-    //      of one utterance and the first pair of the next both see the conv's zero padding.
+    // ---- stage the raw (x + d) tile xs[256][XW]; wave w owns channels [32w, 32w+32).  Frame offset q sits in column
+    //      q + d (+ 2 when it belongs to the next utterance, d = 1 only): the two columns in between stay zero, so the
+    //      last pair of one utterance and the first pair of the next both see the conv's zero padding.
     {
-        const int qA = lane;                            // columns of frames 0..63
-        const int qB = lane == 0 ? -1 : 64;             // lanes 0 / 1: the halo frames -1 / 64
-        const bool vA = qA < a.nvalid, vB = lane == 0 ? a.halo_l != 0 : (lane == 1 && a.halo_r != 0);
+        const int qA = lane;                                         // columns of frames 0..63
+        const int qB = lane < d ? lane - d : 64 + lane - d;          // lanes 0..2d-1: the halo frames -d..-1, 64..64+d-1
+        const bool isB = lane < 2 * d;
+        // halo frames exist iff they lie in the same utterance (or, right halo in concatenated mode, in the batch)
+        const bool vA = qA < a.nvalid;
+        const bool vB = isB && (qB < 0 ? (d == 1 ? a.halo_l != 0 : a.t0 + qB >= 0)
+                                       : (d == 1 ? a.halo_r != 0 : a.t0 + qB < a.T));
         const unsigned cA = wn_voff(a, min(qA, a.nvalid - 1), a.x_bs4);
         const unsigned cB = vB ? wn_voff(a, qB, a.x_bs4) : cA;  // (invalid: any valid address, value unused)
-        const int colA = qA + 1 + (qA >= a.o ? 2 : 0), colB = qB + 1 + (qB >= a.o ? 2 : 0);
+        const int colA = qA + d + (qA >= a.o ? 2 : 0), colB = qB + d + (qB >= a.o ? 2 : 0);
         const bool gap = a.o <= 64;                     // an utterance boundary lies in (or at the end of) this tile
         for (int r0 = 0; r0 < 32; r0 += 16) {
             float xa[16], xb[16], dd[16];
@@ -341,9 +354,9 @@ __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4],
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int c = 32 * w + r0 + u;
-                smem[c * WN_XW + colA] = vA ? xa[u] + dd[u] : 0.0f;
-                if (lane < 2) smem[c * WN_XW + colB] = vB ? xb[u] + dd[u] : 0.0f;
-                if (gap && lane >= 2 && lane < 4) smem[c * WN_XW + a.o + lane - 1] = 0.0f;  // columns o+1, o+2
+                smem[c * XW + colA] = vA ? xa[u] + dd[u] : 0.0f;
+                if (isB) smem[c * XW + colB] = vB ? xb[u] + dd[u] : 0.0f;
+                if (gap && lane >= 32 && lane < 34) smem[c * XW + a.o + lane - 31] = 0.0f;  // columns o+1, o+2
             }
         }
     }
@@ -355,14 +368,22 @@ __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4],
         const rsrc_t rw = make_rsrc(a.w1p);
         const unsigned wv = 32u * (unsigned)lane;                // 8 floats per lane per k-step
         unsigned ws = (unsigned)w * (WN_KS * 64 * 8 * 4);        // wave-uniform byte offset of the current group
-        const f32x2 *bp = reinterpret_cast<const f32x2 *>(smem + half * WN_XW + 2 * l31 + (2 * l31 >= a.o ? 2 : 0));
+        // inputs of pair (q_e, q_e + d): frames q_e - d, q_e, q_e + d, q_e + 2d = columns c0, c0 + d, c0 + 2d, c0 + 3d
+        const float *bpf = smem + half * XW + qe + (qe >= a.o ? 2 : 0);
+        const f32x2 *bp = reinterpret_cast<const f32x2 *>(bpf);  // d = 1: two aligned 8-byte reads
         struct Ops { f32x4 A[WN_GS][2]; f32x2 D[WN_GS][2]; };
         Ops P, Q;
         auto load_step = [&](Ops &o, int u) {
             o.A[u][0] = buf_load4(rw, wv, ws + (unsigned)u * 2048u);
             o.A[u][1] = buf_load4(rw, wv + 16u, ws + (unsigned)u * 2048u);
-            o.D[u][0] = bp[u * WN_XW];      // (d0, d1): row stride 2*WN_XW floats = WN_XW float2
-            o.D[u][1] = bp[u * WN_XW + 1];  // (d2, d3)
+            if (UNIT_DIL) {
+                o.D[u][0] = bp[u * XW];      // (d0, d1): row stride 2*XW floats = XW float2
+                o.D[u][1] = bp[u * XW + 1];  // (d2, d3)
+            } else {
+                const float *q = bpf + u * 2 * XW;
+                o.D[u][0] = (f32x2){q[0], q[d]};
+                o.D[u][1] = (f32x2){q[2 * d], q[3 * d]};
+            }
         };
         auto mma_step = [&](const Ops &o, int u) {
             const float d0 = o.D[u][0][0], d1 = o.D[u][0][1], d2 = o.D[u][1][0], d3 = o.D[u][1][1];
@@ -383,7 +404,8 @@ __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4],
         for (int u = 0; u < WN_GS; ++u) load_step(P, u);
         for (int g = 0; g < NG; g += 2) {
             ws += WN_GS * 2048u;
-            bp += WN_GS * WN_XW;
+            bp += WN_GS * XW;
+            bpf += WN_GS * 2 * XW;
 #pragma unroll
             for (int u = 0; u < WN_GS; ++u) {
                 load_step(Q, u);
@@ -391,7 +413,7 @@ __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4],
                 mma_step(P, u);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (g + 2 < NG) { ws += WN_GS * 2048u; bp += WN_GS * WN_XW; }
+            if (g + 2 < NG) { ws += WN_GS * 2048u; bp += WN_GS * XW; bpf += WN_GS * 2 * XW; }
 #pragma unroll
             for (int u = 0; u < WN_GS; ++u) {
                 load_step(P, u);
@@ -411,7 +433,12 @@ __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4],
         const float z0 = tve ? fast_sigmoid(g0) * fast_tanh(f0) : 0.0f;
         const float z1 = tvo ? fast_sigmoid(g1) * fast_tanh(f1) : 0.0f;
         const int c = 32 * w + mfma32_row(r, lane);
-        *reinterpret_cast<f32x2 *>(zs + c * WN_NT + 2 * l31) = (f32x2){z0, z1};
+        if (UNIT_DIL) {
+            *reinterpret_cast<f32x2 *>(zs + c * WN_NT + qe) = (f32x2){z0, z1};
+        } else {
+            zs[c * WN_NT + qe] = z0;
+            zs[c * WN_NT + qe + d] = z1;
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -570,6 +597,7 @@ __global__ void __launch_bounds__(256, WPS) diffnet_stack_kernel(SetDiffnetStack
 // producer-independent loads (bias + conditioner projection -> accumulator init) BEFORE it waits for the producer
 // tiles, so that wait, the store drain and the release fence of the previous task overlap with them.  Claiming
 // ahead is deadlock-free: a block finishes its claims in claim order, and a claim only ever waits on earlier ones.
+template <bool UNIT_DIL>  // separate kernels: the dilation-1 one carries none of the dilated-layer code or registers
 __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles,
                                                                     int ntasks, int concat) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -618,7 +646,7 @@ __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetSt
         lt.w2p = a.w2w_all + (int64_t)l * (512 * 256);
         lt.b_dil = a.b_dil_all + (int64_t)l * 512;
         lt.b_out = a.b_out_all + (int64_t)l * 512;
-        lt.T = a.T; lt.dil = 1; lt.first = (l == 0);
+        lt.T = a.T; lt.dil = UNIT_DIL ? 1 : 1 << (l % a.dilation_cycle_length); lt.first = (l == 0);
         lt.dbg = nullptr;
     };
 #ifdef SET_WINO_PHASES
@@ -685,7 +713,7 @@ __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetSt
 #ifdef SET_WINO_PHASES
         { const uint64_t t_ = __builtin_amdgcn_s_memtime(); ph[8] += t_ - ph[9]; ph[9] = t_; }
 #endif
-        wino_main(lt, m, smem, ph, s_task, claimed);
+        wino_main<UNIT_DIL>(lt, m, smem, ph, s_task, claimed);
         i_done = i;
         l_done = l;
         n = __builtin_amdgcn_readfirstlane(s_task[0]);  // written by thread 0 before the barrier in front of GEMM 2
@@ -795,7 +823,7 @@ static int stack_variant(int B, int T, int dcl, bool have_wino, int n_cu) {
     const int64_t tiles64 = (int64_t)B * ((T + 63) / 64);
     int ncb = tiles64 < 3 * n_cu ? 1 : 2;
     if (const char *e = getenv("SET_AMD_STACK_NCB")) ncb = atoi(e) == 2 ? 2 : 1;
-    const bool wino_ok = have_wino && dcl == 1;
+    const bool wino_ok = have_wino && (1 << (dcl - 1)) <= WN_MAXD;
     bool wino = wino_ok && 5 * tiles64 >= 3 * n_cu;  // measured crossover vs the direct 32-frame kernel: ~0.6 tiles per CU
     if (const char *e = getenv("SET_AMD_WINO")) wino = wino_ok && (atoi(e) == 2 || (wino && atoi(e) != 0));  // 2 = force
     return wino ? 2 : (ncb == 1 ? 1 : 0);
@@ -821,7 +849,9 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
         const void *fns[4] = {reinterpret_cast<const void *>(diffnet_stack_kernel<1, 8, 2>),
                               reinterpret_cast<const void *>(diffnet_stack_kernel<1, 4, 3>),
                               reinterpret_cast<const void *>(diffnet_stack_kernel<2, 4, 2>),
-                              reinterpret_cast<const void *>(diffnet_stack_wino_kernel)};
+                              reinterpret_cast<const void *>(diffnet_stack_wino_kernel<true>)};
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_wino_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "set_diffnet_stack(attr)");
         for (const void *f : fns)
             SET_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024),
                     "set_diffnet_stack(attr)");
@@ -842,7 +872,8 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     int ntiles = a.B * tiles_per_utt;
     // Winograd kernel: tile the CONCATENATED frame axis when an utterance boundary can only fall between output pairs
     // (T even) and at most once per tile (T >= 64): B*T/64 tiles instead of B*ceil(T/64) (T = 800: 400 vs 416).
-    bool concat = wino && a.T % 2 == 0 && a.T >= WN_NT && (int64_t)a.cp_bs * 4 < (1ll << 31) && a.d_bs == 0;
+    bool concat = wino && a.dilation_cycle_length == 1 && a.T % 2 == 0 && a.T >= WN_NT &&
+                  (int64_t)a.cp_bs * 4 < (1ll << 31) && a.d_bs == 0;
     if (const char *e = getenv("SET_AMD_CONCAT")) concat = concat && atoi(e) != 0;
     if (concat) {
         ntiles = (int)(((int64_t)a.B * a.T + WN_NT - 1) / WN_NT);
@@ -866,9 +897,14 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
     if (grid < 1) grid = 1;
     if (wino)
-        hipLaunchKernelGGL(diffnet_stack_wino_kernel, dim3(grid), dim3(512),
-                           (size_t)(WN_ZS_OFF + DC * WN_NT + 4) * sizeof(float), s, a, tiles_per_utt, ntiles, (int)ntasks64,
-                           concat ? 1 : 0);
+        if (a.dilation_cycle_length == 1)
+            hipLaunchKernelGGL(diffnet_stack_wino_kernel<true>, dim3(grid), dim3(512),
+                               (size_t)(WN_ZS_OFF + DC * WN_NT + 4) * sizeof(float), s, a, tiles_per_utt, ntiles,
+                               (int)ntasks64, concat ? 1 : 0);
+        else
+            hipLaunchKernelGGL(diffnet_stack_wino_kernel<false>, dim3(grid), dim3(512),
+                               (size_t)(WN_ZS_OFF + DC * WN_NT + 4) * sizeof(float), s, a, tiles_per_utt, ntiles,
+                               (int)ntasks64, 0);
     else if (ncb == 1 && wps == 3)
         hipLaunchKernelGGL((diffnet_stack_kernel<1, 4, 3>), dim3(grid), dim3(256), lds, s, a, tiles_per_utt, ntiles,
                            (int)ntasks64, task_slot);

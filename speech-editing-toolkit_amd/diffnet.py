@@ -103,7 +103,7 @@ class DiffNet(nn.Module):
             bd = torch.stack([l.dilated_conv.bias for l in layers]).contiguous()
             bo = torch.stack([l.output_projection.bias for l in layers]).contiguous()
             w1w = w2w = None
-            if self.dilation_cycle_length == 1:  # Winograd F(2,3) images for the persistent stack kernel
+            if self.dilation_cycle_length <= 4:  # Winograd F(2,3) images for the persistent stack kernel (d <= 8)
                 w1w = torch.empty(L, 512 * 256 * 4, dtype=torch.float32, device=dev)
                 w2w = torch.empty(L, 512 * 256, dtype=torch.float32, device=dev)
                 for i, l in enumerate(layers):

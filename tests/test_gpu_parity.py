@@ -431,24 +431,29 @@ def test_winograd_stack_matches_direct_stack(dev, monkeypatch):
             if first is None:
                 first = (x, sk)
             assert torch.equal(x, first[0]) and torch.equal(sk, first[1]), (B, T, rep)
-    # dilated stacks never take the Winograd body, even when forced
-    monkeypatch.setenv("SET_AMD_WINO", "2")
-    xa, xb, skip = x0.clone(), torch.empty_like(x0), torch.empty_like(x0)
-    ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4, 0, 3, 256 * 3, packs, 2)
-    monkeypatch.setenv("SET_AMD_WINO", "0")
-    ya, yb, skip2 = x0.clone(), torch.empty_like(x0), torch.empty_like(x0)
-    ops.diffnet_stack(ya, yb, skip2, cp, dtab.data_ptr() + 4, 0, 3, 256 * 3, packs, 2)
-    assert torch.equal(skip, skip2)
+    # dilated stacks (dilation_cycle_length 2..4: d = 1, 2, 4, 8 per layer): the F(2,3) pairing runs over frames d apart
+    for dcl, Ld in ((2, 4), (3, 6), (4, 8)):
+        monkeypatch.setenv("SET_AMD_WINO", "2")
+        xa, xb, skip = x0.clone(), torch.empty_like(x0), torch.empty_like(x0)
+        pk = tuple(p[:Ld] if p is not None else None for p in packs)
+        ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4, 0, 3, 256 * 3, pk, dcl)
+        monkeypatch.setenv("SET_AMD_WINO", "0")
+        ya, yb, skip2 = x0.clone(), torch.empty_like(x0), torch.empty_like(x0)
+        ops.diffnet_stack(ya, yb, skip2, cp, dtab.data_ptr() + 4, 0, 3, 256 * 3, pk, dcl)
+        torch.cuda.synchronize()
+        assert _maxdiff(skip, skip2) < 1e-5 * max(1.0, float(skip2.abs().max())), dcl
+        assert _maxdiff(xa if Ld % 2 == 0 else xb, ya if Ld % 2 == 0 else yb) < 1e-5 * max(1.0, float(ya.abs().max())), dcl
 
 
-@pytest.mark.parametrize("case", ["infer_tiny", "infer_pad", "infer_drift100"])
+@pytest.mark.parametrize("case", ["infer_tiny", "infer_pad", "infer_drift100", "infer_dil"])
 def test_full_inference_matches_reference_with_winograd_forced(dev, monkeypatch, case):
     """The parity bar (|dmel| < 1e-4 against the reference's output) with every DiffNet stack pass on the Winograd
     kernel (small batches would otherwise use the direct kernel)."""
     monkeypatch.setenv("SET_AMD_WINO", "2")
     g = load_golden(case)
     m = g["meta"]
-    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"], **m["overrides"])
+    manifest = "spec_denoiser_dil" if case == "infer_dil" else "spec_denoiser"
+    model, W = _build_model(dev, manifest, m["wseed"], m["steps"], **m["overrides"])
     inp, noises = _case_inputs(g, dev)
     ret = model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"],
                 inp["f0"], inp["uv"], infer=True, noises=noises, persistent=True, **m["flags"])
