@@ -445,6 +445,54 @@ def test_winograd_stack_matches_direct_stack(dev, monkeypatch):
         assert _maxdiff(xa if Ld % 2 == 0 else xb, ya if Ld % 2 == 0 else yb) < 1e-5 * max(1.0, float(ya.abs().max())), dcl
 
 
+def test_winograd_stack_soak_is_bit_stable(dev, monkeypatch):
+    """The publish protocol of the Winograd kernel (agent-scope write-through stores + vmcnt drain + relaxed flag store,
+    acquire on the consumer side) under many launches and different worker counts: every run must be bit-identical
+    to the first one -- a stale read of a neighbour tile would show up as a different result -- and no dependency wait
+    may time out."""
+    from set_amd import ops
+    B, T, L = 32, 800, 20
+    g = torch.Generator().manual_seed(4242)
+    x0 = torch.randn(B, 256, T, generator=g).to(dev)
+    cp = (torch.randn(B, L * 512, T, generator=g) * 0.5).to(dev)
+    dtab = torch.randn(L * 256, 1, generator=g).to(dev)
+    w1 = torch.empty(L, 512 * 768, device=dev)
+    w2 = torch.empty(L, 512 * 256, device=dev)
+    w1w = torch.empty(L, 512 * 256 * 4, device=dev)
+    w2w = torch.empty(L, 512 * 256, device=dev)
+    bd = (torch.randn(L, 512, generator=g) * 0.1).to(dev)
+    bo = (torch.randn(L, 512, generator=g) * 0.1).to(dev)
+    for l in range(L):
+        wd = (torch.randn(512, 256, 3, generator=g) / 27.7).to(dev)
+        wo = (torch.randn(512, 256, 1, generator=g) / 16.0).to(dev)
+        ops.pack_diffnet_layer(wd, wo, w1[l], w2[l])
+        ops.pack_diffnet_layer_wino(wd, wo, w1w[l], w2w[l])
+    packs = (w1, w2, bd, bo, w1w, w2w)
+    ref = None
+    n_runs = 0
+    for grid in (None, "256", "200", "131", "64"):
+        if grid is None:
+            monkeypatch.delenv("SET_AMD_STACK_GRID", raising=False)
+        else:
+            monkeypatch.setenv("SET_AMD_STACK_GRID", grid)
+        for rep in range(40 if grid is None else 12):
+            xa, xb, skip = x0.clone(), torch.full_like(x0, float("nan")), torch.full_like(x0, float("nan"))
+            ws = ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr(), 0, 1, 256, packs, 1)
+            if rep % 8 == 0:
+                torch.cuda.synchronize()
+                assert int(ws[1]) == 0, "dependency wait timed out"
+            out = (xa, skip)
+            if ref is None:
+                torch.cuda.synchronize()
+                ref = (xa.clone(), skip.clone())
+                assert torch.isfinite(ref[0]).all() and torch.isfinite(ref[1]).all()
+            else:
+                assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), (grid, rep)
+            n_runs += 1
+    monkeypatch.delenv("SET_AMD_STACK_GRID", raising=False)
+    assert n_runs == 88
+
+
 @pytest.mark.parametrize("case", ["infer_tiny", "infer_pad", "infer_drift100", "infer_dil"])
 def test_full_inference_matches_reference_with_winograd_forced(dev, monkeypatch, case):
     """The parity bar (|dmel| < 1e-4 against the reference's output) with every DiffNet stack pass on the Winograd
