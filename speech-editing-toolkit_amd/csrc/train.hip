@@ -120,22 +120,20 @@ __global__ void __launch_bounds__(256) conv1d_wgrad_naive_kernel(WgradArgs a) {
     a.dw[idx] += s;
 }
 
-// out[c] += sum_{b,t} x[b][c][t]  (bias grads); one block per channel
+// out[c] += sum_{b,t} x[b][c][t]  (bias grads): grid (C, slices over the batch), wave-shuffle + LDS reduce, one atomic per
+// block.  (One block per channel left C <= 512 blocks to stream 50 MB: 27 us at B=32, T=800.)
 __global__ void __launch_bounds__(256) channel_sum_kernel(const float *x, float *out, int B, int C, int T) {
-    __shared__ float red[256];
+    __shared__ float red[4];
     const int c = blockIdx.x;
     float s = 0.0f;
-    for (int64_t i = threadIdx.x; i < (int64_t)B * T; i += 256) {
-        const int b = (int)(i / T), t = (int)(i % T);
-        s += x[((int64_t)b * C + c) * T + t];
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        const float *row = x + ((int64_t)b * C + c) * T;
+        for (int t = threadIdx.x; t < T; t += 256) s += row[t];
     }
-    red[threadIdx.x] = s;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[c] += red[0];
+    if (threadIdx.x == 0) atomicAdd(&out[c], red[0] + red[1] + red[2] + red[3]);
 }
 // out[b][c] = sum_t x[b][c][t] (* 1/div); one wave per (b,c)
 __global__ void __launch_bounds__(256) row_sum_kernel(const float *x, float *out, int64_t rows, int T, float scale) {
@@ -596,7 +594,10 @@ extern "C" int set_conv1d_wgrad(const float *g, const float *x, const float *cha
 
 extern "C" int set_channel_sum(const float *x, float *out, int32_t B, int32_t C, int32_t T, void *stream) {
     SET_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "set_channel_sum");
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, T);
+    int slices = (2048 + C - 1) / C;  // ~2048 blocks in total
+    if (slices > B) slices = B;
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, slices), dim3(256), 0, (hipStream_t)stream, x, out, B, C, T);
     return set_check_launch("set_channel_sum");
 }
 extern "C" int set_row_sum(const float *x, float *out, int64_t rows, int32_t T, float scale, void *stream) {
