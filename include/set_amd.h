@@ -234,6 +234,12 @@ typedef struct SetDiffnetStackArgs {
      * rounding (a few 1e-6), not bit for bit.  SET_AMD_WINO=0 in the environment disables it. */
     const float *w1w_all;
     const float *w2w_all;
+    /* optional, Winograd kernel only (training forward): x_all [L+1][B][256][T] replaces the xa/xb ping-pong (layer l
+     * reads slab l, writes slab l+1; slab 0 = input), save_y [L][B][512][T] receives the gate/filter pre-activations
+     * and save_z [L][B][256][T] the gated activations, i.e. what the backward pass needs (diffnet.py:73-77). */
+    float *x_all;
+    float *save_y;
+    float *save_z;
 } SetDiffnetStackArgs;
 int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream);
 int64_t set_sizeof_diffnet_stack_args(void);

@@ -83,6 +83,7 @@ class SetDiffnetStackArgs(C.Structure):
         ("cp_bs", C.c_int64), ("cp_ls", C.c_int64), ("d_bs", C.c_int64), ("d_cs", C.c_int64), ("d_ls", C.c_int64),
         ("B", C.c_int32), ("T", C.c_int32), ("L", C.c_int32), ("dilation_cycle_length", C.c_int32),
         ("w1w_all", C.c_void_p), ("w2w_all", C.c_void_p),
+        ("x_all", C.c_void_p), ("save_y", C.c_void_p), ("save_z", C.c_void_p),
     ]
 
 

@@ -373,6 +373,101 @@ def grad_scale(x, s):
 
 
 # --------------------------------------------------------------------------------------------------
+# DiffNet layer stack: fused forward (persistent Winograd kernel), hand-ordered backward
+# --------------------------------------------------------------------------------------------------
+class _DiffNetStackFn(torch.autograd.Function):
+    """All L residual layers (diffnet.py:60-81,121-127) as ONE forward launch that also stores every layer's input x_l,
+    pre-gate y_l and gated z_l; the backward walks the layers in reverse with the same kernels the per-op tape uses
+    (res-skip / gate backward, conv dgrad = set_conv1d on the transposed weights, wgrad, channel / row sums).
+    Inputs: hx [B,256,T], cond [B,H,T], dmat [B, L*256] (diffusion projections), then per layer
+    (W_cond, b_cond, W_dil, b_dil, W_out, b_out).  Output: the skip sum [B,256,T] (the last layer's x is unused)."""
+
+    @staticmethod
+    def forward(ctx, dn, hx, cond, dmat, *params):
+        L_, C_ = dn.n_layers, dn.C
+        hx, cond, dmat = hx.contiguous(), cond.contiguous(), dmat.contiguous()
+        B, _, T = hx.shape
+        dev = hx.device
+        layers = list(dn.residual_layers)
+        condproj = torch.empty(B, L_ * 2 * C_, T, dtype=torch.float32, device=dev)
+        for l, layer in enumerate(layers):
+            ops.conv1d(cond, layer._w_cond, layer.conditioner_projection.bias, out=condproj[:, l * 2 * C_:(l + 1) * 2 * C_])
+        x_all = torch.empty(L_ + 1, B, C_, T, dtype=torch.float32, device=dev)
+        x_all[0].copy_(hx)
+        y_all = torch.empty(L_, B, 2 * C_, T, dtype=torch.float32, device=dev)
+        z_all = torch.empty(L_, B, C_, T, dtype=torch.float32, device=dev)
+        skip = torch.empty(B, C_, T, dtype=torch.float32, device=dev)
+        ws = ops.diffnet_stack(x_all[0], x_all[1], skip, condproj, dmat.data_ptr(), L_ * C_, 1, C_, dn.fused_packs(),
+                               dn.dilation_cycle_length, x_all=x_all, save_y=y_all, save_z=z_all)
+        ctx.dn, ctx.ws = dn, ws
+        ctx.save_for_backward(cond, dmat, x_all, y_all, z_all)
+        return skip
+
+    @staticmethod
+    def backward(ctx, dskip):
+        dn = ctx.dn
+        cond, dmat, x_all, y_all, z_all = ctx.saved_tensors
+        L_, C_ = dn.n_layers, dn.C
+        B, H, T = cond.shape
+        dev = cond.device
+        layers = list(dn.residual_layers)
+        dskip = dskip.contiguous()
+        need_cond = ctx.needs_input_grad[2]
+        dcond = torch.zeros_like(cond) if need_cond else None
+        dd = torch.empty(B, L_ * C_, dtype=torch.float32, device=dev)
+        dx = torch.zeros(B, C_, T, dtype=torch.float32, device=dev)  # the last layer's x output feeds nothing
+        grads = []
+        impl_w = _wgrad_impl(T)
+        for l in range(L_ - 1, -1, -1):
+            layer = layers[l]
+            dil = layer.dilation
+            dxr = torch.empty_like(dx)
+            d_o = torch.empty(B, 2 * C_, T, dtype=torch.float32, device=dev)
+            check(L().set_res_skip_bwd(_p(dx), _p(dskip), _p(dxr), _p(d_o), B, C_, T, _stream()), "set_res_skip_bwd")
+            # output_projection (1x1, 256 -> 512)
+            dw_out = torch.zeros_like(layer.output_projection.weight)
+            check(L().set_conv1d_wgrad(_p(d_o), _p(z_all[l]), None, _p(dw_out), B, C_, 2 * C_, 1, 1, 0, T, T, 0, 0.0, impl_w,
+                                       _stream()), "set_conv1d_wgrad")
+            db_out = torch.zeros(2 * C_, dtype=torch.float32, device=dev)
+            check(L().set_channel_sum(_p(d_o), _p(db_out), B, 2 * C_, T, _stream()), "set_channel_sum")
+            dz = ops.conv1d(d_o, layer._w_out.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T)
+            # gate
+            dy = torch.empty(B, 2 * C_, T, dtype=torch.float32, device=dev)
+            check(L().set_gate_bwd(_p(y_all[l]), _p(dz), _p(dy), B, C_, T, _stream()), "set_gate_bwd")
+            # conditioner_projection (1x1, H -> 512): y = ... + W_cond cond + b_cond
+            dw_cond = torch.zeros_like(layer.conditioner_projection.weight)
+            check(L().set_conv1d_wgrad(_p(dy), _p(cond), None, _p(dw_cond), B, H, 2 * C_, 1, 1, 0, T, T, 0, 0.0, impl_w,
+                                       _stream()), "set_conv1d_wgrad")
+            db = torch.zeros(2 * C_, dtype=torch.float32, device=dev)
+            check(L().set_channel_sum(_p(dy), _p(db), B, 2 * C_, T, _stream()), "set_channel_sum")  # = db_cond = db_dil
+            if need_cond:
+                ops.conv1d(dy, layer._w_cond.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T, out=dcond,
+                           accumulate=True)
+            # dilated conv (k=3) on x_l + d_l
+            dl = dmat[:, l * C_:(l + 1) * C_].contiguous()
+            dw_dil = torch.zeros_like(layer.dilated_conv.weight)
+            check(L().set_conv1d_wgrad(_p(dy), _p(x_all[l]), _p(dl), _p(dw_dil), B, C_, 2 * C_, 3, dil, dil, T, T, 0, 0.0,
+                                       impl_w, _stream()), "set_conv1d_wgrad")
+            dxd = ops.conv1d(dy, layer._w_dil.transposed(), None, dil=-dil, pad=-dil, T_iter=T, T_out=T)
+            ddl = torch.empty(B, C_, dtype=torch.float32, device=dev)
+            check(L().set_row_sum(_p(dxd), _p(ddl), B * C_, T, 1.0, _stream()), "set_row_sum")
+            dd[:, l * C_:(l + 1) * C_] = ddl
+            dx = ops.sum_div(dxd, dxr)
+            grads.append((dw_cond, db, dw_dil, db.clone(), dw_out, db_out))
+        grads.reverse()
+        flat = [g for tup in grads for g in tup]
+        return (None, dx, dcond, dd, *flat)
+
+
+def diffnet_stack_train(dn, hx, cond, dmat):
+    params = []
+    for layer in dn.residual_layers:
+        params += [layer.conditioner_projection.weight, layer.conditioner_projection.bias, layer.dilated_conv.weight,
+                   layer.dilated_conv.bias, layer.output_projection.weight, layer.output_projection.bias]
+    return _DiffNetStackFn.apply(dn, hx, cond, dmat, *params)
+
+
+# --------------------------------------------------------------------------------------------------
 # attention + the small CampNet ops
 # --------------------------------------------------------------------------------------------------
 def _attn_bwd(qv, kv, vv, p, do, dqv, dkv, dvv, heads, alpha):

@@ -60,6 +60,7 @@ struct LayerTile {
     // q = -1, belong to the same utterance as q = 0).
     int o, nvalid, halo_l, halo_r;
     unsigned x_bs4, cp_bs4;
+    float *sy, *sz;  // optional: slabs [512][T] / [256][T] receiving the pre-gate values and the gated activations
 };
 
 // pair index p (0..31) -> frame offset of its first output: blocks of 2d frames, (q, q + d) paired inside a block
@@ -426,18 +427,37 @@ __device__ __forceinline__ void wino_main(const LayerTile &a, f32x16 (&m)[2][4],
 
     WPH(2)
     // ---- output transform + gate (lane-local): even frame y0 = M1 + M2 + M3, odd frame y1 = M2 - M3 - M4
+    {
+        const bool save = a.sy != nullptr;  // training forward: keep y (gate | filter rows) and z for the backward pass
+        const rsrc_t rsy = make_rsrc(save ? a.sy : a.xin), rsz = make_rsrc(save ? a.sz : a.xin);
+        const unsigned rowh_s = 16u * (unsigned)half * (unsigned)T;
+        const unsigned se = rowh_s + wn_voff(a, min(qe, a.nvalid - 1), 0u), so_ = rowh_s + wn_voff(a, min(qe + d, a.nvalid - 1), 0u);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float g0 = m[0][0][r] + m[0][1][r] + m[0][2][r], g1 = m[0][1][r] - m[0][2][r] - m[0][3][r];
-        const float f0 = m[1][0][r] + m[1][1][r] + m[1][2][r], f1 = m[1][1][r] - m[1][2][r] - m[1][3][r];
-        const float z0 = tve ? fast_sigmoid(g0) * fast_tanh(f0) : 0.0f;
-        const float z1 = tvo ? fast_sigmoid(g1) * fast_tanh(f1) : 0.0f;
-        const int c = 32 * w + mfma32_row(r, lane);
-        if (UNIT_DIL) {
-            *reinterpret_cast<f32x2 *>(zs + c * WN_NT + qe) = (f32x2){z0, z1};
-        } else {
-            zs[c * WN_NT + qe] = z0;
-            zs[c * WN_NT + qe + d] = z1;
+        for (int r = 0; r < 16; ++r) {
+            const float g0 = m[0][0][r] + m[0][1][r] + m[0][2][r], g1 = m[0][1][r] - m[0][2][r] - m[0][3][r];
+            const float f0 = m[1][0][r] + m[1][1][r] + m[1][2][r], f1 = m[1][1][r] - m[1][2][r] - m[1][3][r];
+            const float z0 = tve ? fast_sigmoid(g0) * fast_tanh(f0) : 0.0f;
+            const float z1 = tvo ? fast_sigmoid(g1) * fast_tanh(f1) : 0.0f;
+            const int c = 32 * w + mfma32_row(r, lane);
+            if (UNIT_DIL) {
+                *reinterpret_cast<f32x2 *>(zs + c * WN_NT + qe) = (f32x2){z0, z1};
+            } else {
+                zs[c * WN_NT + qe] = z0;
+                zs[c * WN_NT + qe + d] = z1;
+            }
+            if (save) {  // (uniform branch; the saved tensors are per utterance, so only the per-utterance tiling gets here)
+                const unsigned ur = (unsigned)(32 * w + urow16(r));
+                if (tve) {
+                    buf_store(g0, rsy, se, ur * T4);
+                    buf_store(f0, rsy, se, (ur + DC) * T4);
+                    buf_store(z0, rsz, se, ur * T4);
+                }
+                if (tvo) {
+                    buf_store(g1, rsy, so_, ur * T4);
+                    buf_store(f1, rsy, so_, (ur + DC) * T4);
+                    buf_store(z1, rsz, so_, ur * T4);
+                }
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -634,11 +654,14 @@ __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetSt
         }
         lt.x_bs4 = 4u * (unsigned)DC * (unsigned)a.T;
         lt.cp_bs4 = 4u * (unsigned)a.cp_bs;
-        const float *xi = (l & 1) ? a.xb : a.xa;
-        float *xo = (l & 1) ? a.xa : a.xb;
+        const int64_t slab = (int64_t)a.B * DC * a.T;
+        const float *xi = a.x_all ? a.x_all + l * slab : ((l & 1) ? a.xb : a.xa);
+        float *xo = a.x_all ? a.x_all + (l + 1) * slab : ((l & 1) ? a.xa : a.xb);
         lt.xin = xi + (int64_t)b * DC * a.T;
         lt.xout = xo + (int64_t)b * DC * a.T;
         lt.skp = a.skip + (int64_t)b * DC * a.T;
+        lt.sy = a.save_y ? a.save_y + 2 * l * slab + (int64_t)b * 2 * DC * a.T : nullptr;
+        lt.sz = a.save_z ? a.save_z + l * slab + (int64_t)b * DC * a.T : nullptr;
         lt.cpb = a.condproj + (int64_t)l * a.cp_ls + (int64_t)b * a.cp_bs;
         lt.dstep = a.dstep + (int64_t)l * a.d_ls + (int64_t)b * a.d_bs;
         lt.d_cs = a.d_cs;
@@ -873,7 +896,7 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     // Winograd kernel: tile the CONCATENATED frame axis when an utterance boundary can only fall between output pairs
     // (T even) and at most once per tile (T >= 64): B*T/64 tiles instead of B*ceil(T/64) (T = 800: 400 vs 416).
     bool concat = wino && a.dilation_cycle_length == 1 && a.T % 2 == 0 && a.T >= WN_NT &&
-                  (int64_t)a.cp_bs * 4 < (1ll << 31) && a.d_bs == 0;
+                  (int64_t)a.cp_bs * 4 < (1ll << 31) && a.d_bs == 0 && !a.save_y && !a.save_z;
     if (const char *e = getenv("SET_AMD_CONCAT")) concat = concat && atoi(e) != 0;
     if (concat) {
         ntiles = (int)(((int64_t)a.B * a.T + WN_NT - 1) / WN_NT);

@@ -5,6 +5,7 @@ reference's modules/speech_editing/spec_denoiser/diffnet.py:84-132, so reference
 nn.Conv1d / nn.Linear modules are used as parameter containers only; no torch arithmetic runs in forward.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -182,18 +183,27 @@ class DiffNet(nn.Module):
         cond = cond.contiguous()
         skip = None
         hs_ = A.fanout(h, L)         # every layer's diffusion_projection reads the step embedding
-        conds = A.fanout(cond, L)    # ... and its conditioner_projection reads cond
-        for li, layer in enumerate(self.residual_layers):
-            h, cond = hs_[li], conds[li]
-            hx, hx_res = A.fanout(hx, 2)  # dilated conv input + residual path
-            d = A.conv1d(h, layer._w_dproj, layer.diffusion_projection.bias)  # [1, C, n]
-            d_bc = d[0].t().contiguous()  # [n, C]: per-utterance channel offsets (layout change only)
-            cp = A.conv1d(cond, layer._w_cond, layer.conditioner_projection.bias)
-            y = A.conv1d(hx, layer._w_dil, layer.dilated_conv.bias, dil=layer.dilation, pad=layer.dilation,
-                         in_chan_add=d_bc, res=cp)
-            z = A.gate(y)
-            o = A.conv1d(z, layer._w_out, layer.output_projection.bias)
-            hx, skip = A.res_skip_fn(hx_res, o, skip)
+        use_stack = (self.can_fuse() and self.impl != "unfused" and os.environ.get("SET_AMD_TRAIN_STACK", "1") != "0"
+                     and ops.stack_variant(x.shape[0], x.shape[2], self.dilation_cycle_length) == 2)
+        if use_stack:
+            # fused forward: one persistent Winograd launch for all L layers (+ saved x/y/z), hand-ordered backward
+            ds = [A.conv1d(hs_[li], layer._w_dproj, layer.diffusion_projection.bias)[0].t()
+                  for li, layer in enumerate(self.residual_layers)]          # L x [n, C]
+            dmat = torch.cat(ds, dim=1)                                       # [n, L*C] (tiny; layout only)
+            skip = A.diffnet_stack_train(self, hx, cond, dmat)
+        else:
+            conds = A.fanout(cond, L)    # ... and its conditioner_projection reads cond
+            for li, layer in enumerate(self.residual_layers):
+                h, cond = hs_[li], conds[li]
+                hx, hx_res = A.fanout(hx, 2)  # dilated conv input + residual path
+                d = A.conv1d(h, layer._w_dproj, layer.diffusion_projection.bias)  # [1, C, n]
+                d_bc = d[0].t().contiguous()  # [n, C]: per-utterance channel offsets (layout change only)
+                cp = A.conv1d(cond, layer._w_cond, layer.conditioner_projection.bias)
+                y = A.conv1d(hx, layer._w_dil, layer.dilated_conv.bias, dil=layer.dilation, pad=layer.dilation,
+                             in_chan_add=d_bc, res=cp)
+                z = A.gate(y)
+                o = A.conv1d(z, layer._w_out, layer.output_projection.bias)
+                hx, skip = A.res_skip_fn(hx_res, o, skip)
         hs = A.conv1d(skip, self._w_skip, self.skip_projection.bias, pro="div", pro_param=math.sqrt(L), act="relu")
         return A.conv1d(hs, self._w_outp, self.output_projection.bias)[:, None, :, :]
 

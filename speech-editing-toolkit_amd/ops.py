@@ -394,8 +394,16 @@ def sync_ws_size(B, T):
     return 32 + B * ((T + 31) // 32)
 
 
-def diffnet_stack(xa, xb, skip, condproj, dstep_ptr, d_bs, d_cs, d_ls, packs, dilation_cycle_length, sync_ws=None):
-    """All L layers in one persistent launch.  condproj [B, L*512, T]; packs = (w1p_all, w2p_all, b_dil_all, b_out_all).
+def stack_variant(B, T, dilation_cycle_length, have_wino=True):
+    """0 / 1: direct kernel (64- / 32-frame tiles), 2: Winograd kernel -- what set_diffnet_stack would pick."""
+    return int(_lib.lib().set_diffnet_stack_variant(int(B), int(T), int(dilation_cycle_length), int(bool(have_wino))))
+
+
+def diffnet_stack(xa, xb, skip, condproj, dstep_ptr, d_bs, d_cs, d_ls, packs, dilation_cycle_length, sync_ws=None,
+                  x_all=None, save_y=None, save_z=None):
+    """All L layers in one persistent launch.  condproj [B, L*512, T]; packs = (w1p_all, w2p_all, b_dil_all, b_out_all
+    [, w1w_all, w2w_all]).  Training forward (Winograd kernel only): x_all [L+1,B,256,T] (slab 0 = input) replaces the
+    xa/xb ping-pong, save_y [L,B,512,T] / save_z [L,B,256,T] receive what the backward pass needs.
     Returns sync_ws (int32; [1] != 0 means a dependency wait timed out)."""
     _f(xa), _f(xb), _f(skip), _f(condproj)
     B, Cc, T = xa.shape
@@ -411,6 +419,8 @@ def diffnet_stack(xa, xb, skip, condproj, dstep_ptr, d_bs, d_cs, d_ls, packs, di
     a.b_dil_all, a.b_out_all = b_dil_all.data_ptr(), b_out_all.data_ptr()
     if len(packs) >= 6 and packs[4] is not None:
         a.w1w_all, a.w2w_all = packs[4].data_ptr(), packs[5].data_ptr()
+    if x_all is not None:
+        a.x_all, a.save_y, a.save_z = _f(x_all).data_ptr(), _f(save_y).data_ptr(), _f(save_z).data_ptr()
     a.sync_ws = sync_ws.data_ptr()
     a.cp_bs, a.cp_ls = condproj.stride(0), 512 * T
     a.d_bs, a.d_cs, a.d_ls = int(d_bs), int(d_cs), int(d_ls)

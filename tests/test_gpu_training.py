@@ -242,8 +242,15 @@ def _train_setup(dev, steps, wseed, over=None):
     return task, W
 
 
-def test_training_losses_and_all_gradients_match_reference(dev):
-    """tests/golden/train_losses.npz: the reference's own model + loss functions + autograd (oracle/make_golden.py)."""
+@pytest.mark.parametrize("stack", ["per_op", "fused_stack"])
+def test_training_losses_and_all_gradients_match_reference(dev, monkeypatch, stack):
+    """tests/golden/train_losses.npz: the reference's own model + loss functions + autograd (oracle/make_golden.py).
+    `fused_stack`: the DiffNet layers run as one persistent Winograd launch with saved activations and the
+    hand-ordered backward (what large batches use); `per_op`: one differentiable kernel per op."""
+    if stack == "fused_stack":
+        monkeypatch.setenv("SET_AMD_WINO", "2")       # tiny batch: force the kernel choice the big batches get
+    else:
+        monkeypatch.setenv("SET_AMD_TRAIN_STACK", "0")
     g = load_golden("train_losses")
     m = g["meta"]
     task, W = _train_setup(dev, m["steps"], m["wseed"])
