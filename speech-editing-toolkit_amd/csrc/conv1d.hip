@@ -85,19 +85,20 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(SetConv1dArgs a, int l
     // Loads are UNCONDITIONAL on clamped addresses and issued together (4 rows x 2 column blocks), the validity
     // select happens at the LDS write: an `if (valid) v = load` makes hipcc branch and drain vmcnt(0) per element,
     // i.e. one serialized global round trip per element (64 of them for Cin = 256; measured 88 us for a 256->256 1x1
-    // conv on 25.6k frames).  When the chunk is at most 128 columns wide the NEXT chunk's loads are issued before
-    // this chunk's MFMAs.
+    // conv on 25.6k frames).  When the chunk fits NJP = WN + 1 column blocks (halo <= 64) all of its loads are issued in
+    // one go and one chunk ahead of the MFMAs; wider halos fall back to column-block pairs without prefetch.
     const float *addp = a.in_chan_add ? a.in_chan_add + (int64_t)b * a.Cin : inb;  // dummy stays a valid address
     const bool has_add = a.in_chan_add != nullptr;
     const int nj = (W + 63) >> 6;
-    float pv[4][2], pa[4];
+    constexpr int NJP = WN + 1;
+    float pv[4][NJP], pa[4];
     auto issue = [&](int c0, int jj0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int cc = min(c0 + wave + 4 * k, a.Cin - 1);
             pa[k] = addp[cc];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NJP; ++u) {
                 const int ti = t0 + lo + (jj0 + u) * 64 + lane;
                 pv[k][u] = inb[(int64_t)cc * a.in_cs + min(max(ti, 0), a.T_in - 1)];
             }
@@ -109,7 +110,7 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(SetConv1dArgs a, int l
             const int row = wave + 4 * k;
             const bool cok = c0 + row < a.Cin;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NJP; ++u) {
                 const int j = (jj0 + u) * 64 + lane;
                 const int ti = t0 + lo + j;
                 const float x = has_add ? pv[k][u] + pa[k] : pv[k][u];
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(SetConv1dArgs a, int l
             }
         }
     };
-    const bool piped = nj <= 2;
+    const bool piped = nj <= NJP;
     if (piped) issue(0, 0);
 
     for (int c0 = 0; c0 < CinP; c0 += KC) {
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(SetConv1dArgs a, int l
         if (piped) {
             commit(c0, 0);
         } else {
-            for (int jj0 = 0; jj0 < nj; jj0 += 2) {
+            for (int jj0 = 0; jj0 < nj; jj0 += NJP) {
                 issue(c0, jj0);
                 commit(c0, jj0);
             }
