@@ -225,6 +225,12 @@ def lib():
         raise RuntimeError(
             "libset_amd.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`. "
             "There is no CPU/eager fallback for this path." % LIB_PATH)
+    # Bring torch's HIP runtime up BEFORE the library is mapped: torch ships its own libamdhip64 and the library links
+    # /opt/rocm's; mapped first, the library binds a second runtime copy that later sees "no ROCm-capable device"
+    # (observed when build() and smoke() run in one process).  No-op on a machine without a GPU.
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the header and the library disagree
