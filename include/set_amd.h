@@ -240,6 +240,9 @@ typedef struct SetDiffnetStackArgs {
     float *x_all;
     float *save_y;
     float *save_z;
+    /* optional sticky error word (never cleared by the library): set to 1 if a dependency wait ran into its spin
+     * limit and the launch gave up (sync_ws[1] says the same for the last launch only) */
+    int32_t *err_flag;
 } SetDiffnetStackArgs;
 int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream);
 int64_t set_sizeof_diffnet_stack_args(void);
@@ -308,6 +311,7 @@ typedef struct SetDiffLoopArgs {
      * >= 32 + B*ceil(T/32) int32); 0: one set_diffnet_layer launch per layer */
     int32_t persistent;
     int32_t *sync_ws;
+    int32_t *err_flag; /* optional sticky error word, see SetDiffnetStackArgs.err_flag */
 } SetDiffLoopArgs;
 int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream);
 

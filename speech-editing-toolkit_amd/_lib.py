@@ -72,6 +72,7 @@ class SetDiffLoopArgs(C.Structure):
         ("n_groups", C.c_int32),
         ("persistent", C.c_int32),
         ("sync_ws", C.c_void_p),
+        ("err_flag", C.c_void_p),
     ]
 
 
@@ -84,6 +85,7 @@ class SetDiffnetStackArgs(C.Structure):
         ("B", C.c_int32), ("T", C.c_int32), ("L", C.c_int32), ("dilation_cycle_length", C.c_int32),
         ("w1w_all", C.c_void_p), ("w2w_all", C.c_void_p),
         ("x_all", C.c_void_p), ("save_y", C.c_void_p), ("save_z", C.c_void_p),
+        ("err_flag", C.c_void_p),
     ]
 
 

@@ -563,6 +563,7 @@ __global__ void __launch_bounds__(256, WPS) diffnet_stack_kernel(SetDiffnetStack
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > STACK_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
                         __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (a.err_flag) __hip_atomic_store(a.err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         n = ntasks;
                         break;
                     }
@@ -619,7 +620,7 @@ __global__ void __launch_bounds__(256, WPS) diffnet_stack_kernel(SetDiffnetStack
 // ahead is deadlock-free: a block finishes its claims in claim order, and a claim only ever waits on earlier ones.
 template <bool UNIT_DIL>  // separate kernels: the dilation-1 one carries none of the dilated-layer code or registers
 __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles,
-                                                                    int ntasks, int concat) {
+                                                                    int ntasks, int concat, int fault_tile) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int *s_task = reinterpret_cast<int *>(smem + WN_ZS_OFF + DC * WN_NT);
     int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
@@ -695,7 +696,10 @@ __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetSt
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-            __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (fault_tile >= 0: test hook, SET_AMD_FAULT_TILE -- that tile of layer 0 is never published, so its
+            // consumers must run into the spin limit and the launch must report it)
+            if (!(l_done == 0 && i_done == fault_tile))
+                __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             fence_ticks += __builtin_amdgcn_s_memtime() - tf0;
         }
     };
@@ -718,6 +722,7 @@ __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetSt
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > STACK_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
                         __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (a.err_flag) __hip_atomic_store(a.err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ok_all = 0;
                         break;
                     }
@@ -919,16 +924,18 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
     if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
     if (grid < 1) grid = 1;
-    if (wino)
+    int fault_tile = -1;  // test hook: never publish this tile of layer 0 (exercises the time-out / error path)
+    if (const char *e = getenv("SET_AMD_FAULT_TILE")) fault_tile = atoi(e);
+    if (wino) {
         if (a.dilation_cycle_length == 1)
             hipLaunchKernelGGL(diffnet_stack_wino_kernel<true>, dim3(grid), dim3(512),
                                (size_t)(WN_ZS_OFF + DC * WN_NT + 4) * sizeof(float), s, a, tiles_per_utt, ntiles,
-                               (int)ntasks64, concat ? 1 : 0);
+                               (int)ntasks64, concat ? 1 : 0, fault_tile);
         else
             hipLaunchKernelGGL(diffnet_stack_wino_kernel<false>, dim3(grid), dim3(512),
                                (size_t)(WN_ZS_OFF + DC * WN_NT + 4) * sizeof(float), s, a, tiles_per_utt, ntiles,
-                               (int)ntasks64, 0);
-    else if (ncb == 1 && wps == 3)
+                               (int)ntasks64, 0, fault_tile);
+    } else if (ncb == 1 && wps == 3)
         hipLaunchKernelGGL((diffnet_stack_kernel<1, 4, 3>), dim3(grid), dim3(256), lds, s, a, tiles_per_utt, ntiles,
                            (int)ntasks64, task_slot);
     else if (ncb == 1)
@@ -1362,6 +1369,7 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
             sa.dstep = a.dstep + sid; sa.d_bs = 0; sa.d_cs = a.steps; sa.d_ls = (int64_t)DC * a.steps;
             sa.w1p_all = a.w1p_all; sa.w2p_all = a.w2p_all; sa.b_dil_all = a.b_dil_all; sa.b_out_all = a.b_out_all;
             sa.w1w_all = a.w1w_all; sa.w2w_all = a.w2w_all;
+            sa.err_flag = a.err_flag;
             sa.sync_ws = sync_ws;
             sa.B = Bg; sa.T = T; sa.L = L; sa.dilation_cycle_length = a.dilation_cycle_length;
             rc = set_diffnet_stack(&sa, s);

@@ -524,6 +524,8 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs,
     a.persistent = int(default_persistent() if persistent is None else bool(persistent))
     sync_ws = torch.empty(sync_ws_size(B, T), dtype=torch.int32, device=dev)
     a.sync_ws = sync_ws.data_ptr()
+    err = torch.zeros(1, dtype=torch.int32, device=dev)  # sticky: a dependency wait of the persistent kernel gave up
+    a.err_flag = err.data_ptr()
     a.w_skip_p, a.b_skip = w_skip.packed().data_ptr(), b_skip.data_ptr()
     a.w_outp_p, a.b_outp = w_outp.packed().data_ptr(), b_outp.data_ptr()
     a.ws_x0, a.ws_x1, a.ws_skip, a.ws_h = (w.data_ptr() for w in ws)
@@ -536,6 +538,8 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs,
         loop_ms = C.c_float(0.0)
         a.loop_ms = C.pointer(loop_ms)
     check(_lib.lib().set_diffusion_loop(C.byref(a), _stream()), "set_diffusion_loop")
+    if a.persistent and int(err.item()) != 0:  # (one 4-byte read-back per reverse loop; fail loudly, never return garbage)
+        raise _lib.SetAmdError("set_diffusion_loop: a tile dependency wait of the persistent layer-stack kernel timed out")
     # the group chains are joined back into the current stream, so stream-ordered reuse of these buffers is safe
     if spans is None:
         return None

@@ -445,6 +445,26 @@ def test_winograd_stack_matches_direct_stack(dev, monkeypatch):
         assert _maxdiff(xa if Ld % 2 == 0 else xb, ya if Ld % 2 == 0 else yb) < 1e-5 * max(1.0, float(ya.abs().max())), dcl
 
 
+def test_dependency_timeout_is_reported_not_swallowed(dev, monkeypatch):
+    """Error behaviour of the persistent kernel: if a producer tile is never published (test hook SET_AMD_FAULT_TILE)
+    its consumers give up after the spin limit, every block drains, and the reverse loop raises instead of returning
+    a mel computed from garbage.  The next call (hook removed) works again."""
+    from set_amd._lib import SetAmdError
+    g = load_golden("infer_tiny")
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"])
+    inp, noises = _case_inputs(g, dev)
+    args = (inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"],
+            inp["uv"])
+    monkeypatch.setenv("SET_AMD_WINO", "2")
+    monkeypatch.setenv("SET_AMD_FAULT_TILE", "0")
+    with pytest.raises(SetAmdError, match="timed out"):
+        model(*args, infer=True, noises=noises)
+    monkeypatch.delenv("SET_AMD_FAULT_TILE")
+    ok = model(*args, infer=True, noises=noises)["mel_out"]
+    assert _maxdiff(ok, g["mel_out"]) < 1e-4
+
+
 def test_winograd_stack_soak_is_bit_stable(dev, monkeypatch):
     """The publish protocol of the Winograd kernel (agent-scope write-through stores + vmcnt drain + relaxed flag store,
     acquire on the consumer side) under many launches and different worker counts: every run must be bit-identical
