@@ -9,6 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib, ops
+from ._lib import SetAmdError  # noqa: E402
 from ._lib import ACT, PRO, IMPL_MFMA, IMPL_NAIVE, check
 from .ops import _p, _stream, ConvWeight
 
@@ -406,6 +407,8 @@ class _DiffNetStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dskip):
         dn = ctx.dn
+        if int(ctx.ws[1]) != 0:  # (the forward's abort word; this read-back is the first host sync of the step)
+            raise SetAmdError("set_diffnet_stack: a tile dependency wait of the training forward timed out")
         cond, dmat, x_all, y_all, z_all = ctx.saved_tensors
         L_, C_ = dn.n_layers, dn.C
         B, H, T = cond.shape
