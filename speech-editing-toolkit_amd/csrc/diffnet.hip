@@ -72,7 +72,8 @@ __device__ __forceinline__ unsigned wn_voff(const LayerTile &a, int q, unsigned 
     return 4u * (unsigned)(a.t0 + q - (side ? a.T : 0)) + (side ? slab4 : 0u);
 }
 
-template <int NCB, int GS>
+// AGENT: tile outputs are stored agent-scope write-through (persistent kernel: the publish then needs no release fence)
+template <int NCB, int GS, bool AGENT = false>
 __device__ __forceinline__ void layer_tile(const LayerTile &a, float *smem) {
     constexpr int NTt = 32 * NCB;           // frames per tile;  GS = k-steps per operand group
     const int tid = threadIdx.x;
@@ -92,14 +93,19 @@ __device__ __forceinline__ void layer_tile(const LayerTile &a, float *smem) {
     // NB every global load below is UNCONDITIONAL on a clamped (always in-bounds) address and the validity
     // select happens afterwards: a `cond ? load : 0` makes hipcc branch around each load and drain vmcnt(0)
     // per element (128 serialized round trips per lane).
-    unsigned lo[NCB];  // per-lane load offsets (clamped) relative to a wave-uniform row pointer
+    // All global traffic goes through raw-buffer instructions: SGPR descriptor of the slab + SGPR row offset + ONE
+    // per-lane byte offset shared by every row (hipcc otherwise builds a 64-bit VGPR address per load / store).
+    unsigned lo[NCB];  // per-lane byte offsets (clamped) relative to a wave-uniform row
     bool tv[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-        lo[cb] = (unsigned)(4 * half * T + min(t0 + 32 * cb + l31, T - 1));
+        lo[cb] = 4u * (unsigned)(4 * half * T + min(t0 + 32 * cb + l31, T - 1));
         tv[cb] = t0 + 32 * cb + l31 < T;
     }
-    const unsigned lb = (unsigned)(4 * half);
+    const unsigned lb = 16u * (unsigned)half;
+    const unsigned T4 = 4u * (unsigned)T;
+    const rsrc_t rxin = make_rsrc(xin), rskp = make_rsrc(a.skp), rxout = make_rsrc(a.xout), rcp = make_rsrc(a.cpb),
+                 rbd = make_rsrc(a.b_dil), rbo = make_rsrc(a.b_out);
 
     // ---- phase 0a: accumulators of GEMM 1 start at  b_dil + condproj  (so the gate needs no loads later);
     //      all loads are independent and issued together.
@@ -108,11 +114,10 @@ __device__ __forceinline__ void layer_tile(const LayerTile &a, float *smem) {
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int ur = layer_row(w, rb, urow16(r));  // wave-uniform
-            const float bias = (a.b_dil + ur)[lb];
-            const float *cr = a.cpb + (int64_t)ur * T;
+            const unsigned ur = (unsigned)layer_row(w, rb, urow16(r));  // wave-uniform
+            const float bias = buf_load(rbd, lb, 4u * ur);
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = bias + cr[lo[cb]];
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = bias + buf_load(rcp, lo[cb], ur * T4);
         }
     // ---- phase 0b: stage the (x + d) tile: wave w owns channels [64w, 64w+64); one row = one coalesced
     //      64-lane load (+ a halo load when the row is wider than 64); 16 rows in flight.  Zero outside [0,T):
@@ -122,7 +127,7 @@ __device__ __forceinline__ void layer_tile(const LayerTile &a, float *smem) {
         const int tB = t0 - dil + 64 + lane;  // columns 64..XW-1
         const bool vA = tA >= 0 && tA < T;
         const bool vB = tB >= 0 && tB < T;
-        const unsigned cA = (unsigned)min(max(tA, 0), T - 1), cB = (unsigned)min(max(tB, 0), T - 1);
+        const unsigned cA = 4u * (unsigned)min(max(tA, 0), T - 1), cB = 4u * (unsigned)min(max(tB, 0), T - 1);
         const bool laneA = lane < XW;
         const bool laneB = 64 + lane < XW;
         for (int r0 = 0; r0 < 64; r0 += 16) {
@@ -130,9 +135,8 @@ __device__ __forceinline__ void layer_tile(const LayerTile &a, float *smem) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int c = 64 * w + r0 + u;
-                const float *row = xin + (int64_t)c * T;
-                xa[u] = row[cA];
-                if constexpr (NCB == 2) xb[u] = row[cB];
+                xa[u] = buf_load(rxin, cA, (unsigned)c * T4);
+                if constexpr (NCB == 2) xb[u] = buf_load(rxin, cB, (unsigned)c * T4);
                 dd[u] = a.dstep[(int64_t)c * a.d_cs];
             }
 #pragma unroll
@@ -187,19 +191,17 @@ __device__ __forceinline__ void layer_tile(const LayerTile &a, float *smem) {
     // ---- accumulators of GEMM 2 start at  x_in + b_out  (residual rows) /  skip + b_out  (skip rows): the
     //      epilogue is then store-only and these loads fly while the other waves finish their z stores.
     __builtin_amdgcn_sched_barrier(0);  // z registers are dead from here: keep the init loads below the z stores
-    float *skp = a.skp;
     const bool first = a.first != 0;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int ur = layer_row(w, rb, urow16(r));  // wave-uniform
-            const float bias = (a.b_out + ur)[lb];
+            const unsigned ur = (unsigned)layer_row(w, rb, urow16(r));  // wave-uniform
+            const float bias = buf_load(rbo, lb, 4u * ur);
             // residual rows read x_in, skip rows read the running skip sum (ignored by a select when first)
-            const float *src = (rb < 2 ? xin + (int64_t)ur * T : skp + (int64_t)(ur - DC) * T);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
-                const float sv = src[lo[cb]];
+                const float sv = rb < 2 ? buf_load(rxin, lo[cb], ur * T4) : buf_load(rskp, lo[cb], (ur - DC) * T4);
                 acc[rb][cb][r] = (rb >= 2 && first) ? bias : bias + sv;
             }
         }
@@ -221,19 +223,18 @@ __device__ __forceinline__ void layer_tile(const LayerTile &a, float *smem) {
     PHASE_STAMP(5)
 
     // ---- phase 4: store-only epilogue: x_out = (x + o_res) * 2^-1/2 ; skip = skip + o_skip ----------------------
-    float *xout = a.xout;
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-        if (tv[cb]) {  // one exec-mask region per column block, not one per store
-            const unsigned so = (unsigned)(4 * half * T + t0 + 32 * cb + l31);  // unclamped store offset
+        if (tv[cb]) {  // one exec-mask region per column block, not one per store (valid frame: the clamp was a no-op)
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ur = layer_row(w, rb, urow16(r));  // wave-uniform
-                    float *dst = (rb < 2 ? xout + (int64_t)ur * T : skp + (int64_t)(ur - DC) * T);
-                    const float sc = rb < 2 ? 0.70710678118654752440f : 1.0f;
-                    dst[so] = acc[rb][cb][r] * sc;
+                    const unsigned ur = (unsigned)layer_row(w, rb, urow16(r));  // wave-uniform
+                    const float v = acc[rb][cb][r] * (rb < 2 ? 0.70710678118654752440f : 1.0f);
+                    const unsigned so = rb < 2 ? ur * T4 : (ur - DC) * T4;
+                    if constexpr (AGENT) buf_store_agent(v, rb < 2 ? rxout : rskp, lo[cb], so);
+                    else buf_store(v, rb < 2 ? rxout : rskp, lo[cb], so);
                 }
         }
     }
@@ -555,11 +556,10 @@ __global__ void __launch_bounds__(256, WPS) diffnet_stack_kernel(SetDiffnetStack
             if (n < ntasks && n >= ntiles) {  // layer >= 1: wait for the three producer tiles of layer l-1
                 const int l = n / ntiles, i = n - l * ntiles, j = i % tiles_per_utt;
                 unsigned spins = 0;
+                const int *f0 = done + i, *fl = done + (j > 0 ? i - 1 : i), *fr = done + (j < tiles_per_utt - 1 ? i + 1 : i);
                 for (;;) {
-                    bool ok = ld_agent(done + i) >= l;
-                    if (j > 0) ok = ok && ld_agent(done + i - 1) >= l;
-                    if (j < tiles_per_utt - 1) ok = ok && ld_agent(done + i + 1) >= l;
-                    if (ok) break;
+                    const int v0 = ld_agent(f0), v1 = ld_agent(fl), v2 = ld_agent(fr);  // three independent loads
+                    if (min(v0, min(v1, v2)) >= l) break;
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > STACK_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
                         __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -599,14 +599,12 @@ __global__ void __launch_bounds__(256, WPS) diffnet_stack_kernel(SetDiffnetStack
         lt.b_out = a.b_out_all + (int64_t)l * 512;
         lt.T = a.T; lt.t0 = j * NTt; lt.dil = 1 << (l % a.dilation_cycle_length); lt.first = (l == 0);
         lt.dbg = nullptr;
-        layer_tile<NCB, GS>(lt, smem);
-        // publish tile i of layer l
+        layer_tile<NCB, GS, true>(lt, smem);
+        // publish tile i of layer l (outputs were stored agent-scope write-through: vmcnt drain = visible to every XCD)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave
         __syncthreads();
         if (tid == 0) {
             const uint64_t tf0 = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(done + i, l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             fence_ticks += __builtin_amdgcn_s_memtime() - tf0;
         }
