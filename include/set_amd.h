@@ -229,7 +229,7 @@ typedef struct SetDiffnetStackArgs {
     int64_t cp_bs, cp_ls, d_bs, d_cs, d_ls;
     int32_t B, T, L, dilation_cycle_length;
     /* optional Winograd F(2,3) images (set_pack_diffnet_layer_wino), [L][512*256*4] and [L][512*256]: when both are
-     * given, dilation_cycle_length <= 4 and the batch has at least 0.6 64-frame tiles per CU, the k=3 conv runs as four
+     * given, dilation_cycle_length <= 4 and the batch has at least 0.68 64-frame tiles per CU, the k=3 conv runs as four
      * 512x256 GEMMs over output pairs (2/3 of its MACs); results then agree with the direct kernels to fp32
      * rounding (a few 1e-6), not bit for bit.  SET_AMD_WINO=0 in the environment disables it. */
     const float *w1w_all;

@@ -844,13 +844,13 @@ extern "C" int set_diffnet_layer(const SetDiffnetLayerArgs *args, void *stream) 
 extern "C" int64_t set_sizeof_diffnet_stack_args(void) { return (int64_t)sizeof(SetDiffnetStackArgs); }
 
 // 0 = direct kernel, 64-frame tiles; 1 = direct kernel, 32-frame tiles; 2 = Winograd F(2,3) kernel (64-frame tiles,
-// 8-wave blocks, needs its packed images, dilation 1 everywhere and at least ~0.6 tiles per CU to be worth it)
+// 8-wave blocks, needs its packed images, dilation_cycle_length <= 4 and at least ~0.68 tiles per CU to be worth it)
 static int stack_variant(int B, int T, int dcl, bool have_wino, int n_cu) {
     const int64_t tiles64 = (int64_t)B * ((T + 63) / 64);
     int ncb = tiles64 < 3 * n_cu ? 1 : 2;
     if (const char *e = getenv("SET_AMD_STACK_NCB")) ncb = atoi(e) == 2 ? 2 : 1;
     const bool wino_ok = have_wino && (1 << (dcl - 1)) <= WN_MAXD;
-    bool wino = wino_ok && 5 * tiles64 >= 3 * n_cu;  // measured crossover vs the direct 32-frame kernel: ~0.6 tiles per CU
+    bool wino = wino_ok && 25 * tiles64 >= 17 * n_cu;  // measured crossover vs the direct 32-frame kernel: ~0.68 tiles per CU
     if (const char *e = getenv("SET_AMD_WINO")) wino = wino_ok && (atoi(e) == 2 || (wino && atoi(e) != 0));  // 2 = force
     return wino ? 2 : (ncb == 1 ? 1 : 0);
 }
