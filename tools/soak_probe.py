@@ -8,7 +8,9 @@ from set_amd import ops
 torch.set_grad_enabled(False)
 dev = torch.device("cuda:0")
 N = int(os.environ.get("SOAK_N", 600))
-for (B, T, L, dcl) in ((32, 800, 20, 1), (16, 800, 20, 1), (7, 1548, 20, 1), (32, 800, 8, 4), (24, 797, 20, 1)):
+SHAPES = ((32, 800, 20, 1, "2"), (16, 800, 20, 1, "2"), (7, 1548, 20, 1, "2"), (32, 800, 8, 4, "2"), (24, 797, 20, 1, "2"),
+          (8, 800, 20, 1, "0"), (32, 800, 20, 1, "0"), (3, 203, 20, 3, "0"))  # last column: SET_AMD_WINO (0 = direct kernels)
+for (B, T, L, dcl, wino) in SHAPES:
     g = torch.Generator().manual_seed(B * 7 + T)
     x0 = torch.randn(B, 256, T, generator=g).to(dev)
     cp = (torch.randn(B, L * 512, T, generator=g) * 0.5).to(dev)
@@ -19,7 +21,7 @@ for (B, T, L, dcl) in ((32, 800, 20, 1), (16, 800, 20, 1), (7, 1548, 20, 1), (32
     for l in range(L):
         wd = (torch.randn(512, 256, 3, generator=g) / 27.7).to(dev); wo = (torch.randn(512, 256, 1, generator=g) / 16.0).to(dev)
         ops.pack_diffnet_layer(wd, wo, w1[l], w2[l]); ops.pack_diffnet_layer_wino(wd, wo, w1w[l], w2w[l])
-    os.environ["SET_AMD_WINO"] = "2"
+    os.environ["SET_AMD_WINO"] = wino
     ref, bad, aborts = None, 0, 0
     for it in range(N):
         xa, xb, skip = x0.clone(), torch.empty_like(x0), torch.empty_like(x0)
@@ -31,4 +33,5 @@ for (B, T, L, dcl) in ((32, 800, 20, 1), (16, 800, 20, 1), (7, 1548, 20, 1), (32
             bad += int(not (torch.equal(out, ref[0]) and torch.equal(skip, ref[1])))
         if it % 50 == 0:
             aborts += int(ws[1])
-    print("B=%d T=%d L=%d dcl=%d: %d launches, %d mismatches, aborts %d" % (B, T, L, dcl, N, bad, aborts))
+    print("B=%d T=%d L=%d dcl=%d %s: %d launches, %d mismatches, aborts %d" % (
+        B, T, L, dcl, "winograd" if wino == "2" else "direct", N, bad, aborts))
