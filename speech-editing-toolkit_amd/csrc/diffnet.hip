@@ -873,11 +873,9 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     static bool attr_set = false;
     if (!attr_set) {
         const void *fns[4] = {reinterpret_cast<const void *>(diffnet_stack_kernel<1, 8, 2>),
-                              reinterpret_cast<const void *>(diffnet_stack_kernel<1, 4, 3>),
                               reinterpret_cast<const void *>(diffnet_stack_kernel<2, 4, 2>),
-                              reinterpret_cast<const void *>(diffnet_stack_wino_kernel<true>)};
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_wino_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "set_diffnet_stack(attr)");
+                              reinterpret_cast<const void *>(diffnet_stack_wino_kernel<true>),
+                              reinterpret_cast<const void *>(diffnet_stack_wino_kernel<false>)};
         for (const void *f : fns)
             SET_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024),
                     "set_diffnet_stack(attr)");
@@ -912,10 +910,7 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     const size_t lds = (size_t)(task_slot + 4) * sizeof(float);
     SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + ntiles + (wino ? 12 : 0)) * sizeof(int32_t), s),
             "set_diffnet_stack(memset)");
-    int wps = 2;  // resident blocks per CU
-    if (const char *e = getenv("SET_AMD_STACK_WPS")) wps = atoi(e) == 3 ? 3 : 2;
-    if (ncb == 2) wps = 2;
-    if (wino) wps = 1;
+    const int wps = wino ? 1 : 2;  // resident blocks per CU (three 168-VGPR blocks per CU measured slower: see DESIGN.md)
     int grid = wps * n_cu;
     if (grid > ntiles * 4 / 5) grid = ntiles * 4 / 5;
     if (grid < n_cu) grid = n_cu < ntiles ? n_cu : ntiles;
@@ -933,10 +928,7 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
             hipLaunchKernelGGL(diffnet_stack_wino_kernel<false>, dim3(grid), dim3(512),
                                (size_t)(WN_ZS_OFF + DC * WN_NT + 4) * sizeof(float), s, a, tiles_per_utt, ntiles,
                                (int)ntasks64, 0, fault_tile);
-    } else if (ncb == 1 && wps == 3)
-        hipLaunchKernelGGL((diffnet_stack_kernel<1, 4, 3>), dim3(grid), dim3(256), lds, s, a, tiles_per_utt, ntiles,
-                           (int)ntasks64, task_slot);
-    else if (ncb == 1)
+    } else if (ncb == 1)
         hipLaunchKernelGGL((diffnet_stack_kernel<1, 8, 2>), dim3(grid), dim3(256), lds, s, a, tiles_per_utt, ntiles,
                            (int)ntasks64, task_slot);
     else
