@@ -126,11 +126,14 @@ def infer_case(hp, name, B, T, T_txt, steps, wseed, iseed, pad_tail=False, overr
     # ---- oracle cross-check
     dcl = hp["dilation_cycle_length"]
     otrace = []
-    oret = O.gaussian_diffusion_infer(W, steps, inp, noises, dilation_cycle_length=dcl, trace=otrace, **flags)
+    use_pitch = bool(hp["use_pitch_embed"])
+    oflags = dict(flags) if use_pitch else dict(flags, use_pitch_embed=False)
+    oret = O.gaussian_diffusion_infer(W, steps, inp, noises, dilation_cycle_length=dcl, trace=otrace, **oflags)
     d_mel = maxdiff(oret["mel_out"], ret["mel_out"])
     d_cond = maxdiff(oret["decoder_inp"], ret["decoder_inp"])
     d_dur = maxdiff(oret["dur"], ret["dur"])
-    d_pp = maxdiff(oret["pitch_pred"], ret["pitch_pred"])
+    d_pp = maxdiff(oret["pitch_pred"], ret["pitch_pred"]) if use_pitch else 0.0
+    assert use_pitch or "pitch_pred" not in ret
     assert torch.equal(oret["mel2ph"], ret["mel2ph"])
     print("  [%s] oracle vs reference: mel %.2e cond %.2e dur %.2e pitch_pred %.2e" % (name, d_mel, d_cond, d_dur, d_pp))
     assert max(d_mel, d_cond, d_dur, d_pp) < 2e-5, "oracle restatement deviates from the reference"
@@ -143,9 +146,11 @@ def infer_case(hp, name, B, T, T_txt, steps, wseed, iseed, pad_tail=False, overr
                                       pad_tail=pad_tail, overrides=overrides or {}, flags=flags,
                                       trace_layers=list(trace_layers)))),
         mel_out=ret["mel_out"], decoder_inp=ret["decoder_inp"], dur=ret["dur"], mel2ph=ret["mel2ph"],
-        pitch_pred=ret["pitch_pred"], f0_denorm=ret["f0_denorm"], f0_denorm_pred=ret["f0_denorm_pred"],
-        masked_dur=oret["masked_dur"], masked_pitch=oret["masked_pitch"], pitch=oret["pitch"],
+        masked_dur=oret["masked_dur"],
     )
+    if use_pitch:
+        out.update(pitch_pred=ret["pitch_pred"], f0_denorm=ret["f0_denorm"], f0_denorm_pred=ret["f0_denorm_pred"],
+                   masked_pitch=oret["masked_pitch"], pitch=oret["pitch"])
     ks = range(steps) if keep_steps is None else keep_steps
     for k in ks:
         out["x0_step%d" % k] = rec["x0"][k]
@@ -214,7 +219,8 @@ def train_loss_case(hp, name, B, T, T_txt, steps, wseed, iseed):
             losses = {}
             task.add_mel_loss(out["mel_out"] * tm, inp["ref_mels"] * tm, losses, postfix="_coarse")
             task.add_dur_loss(out["dur"], inp["mel2ph"], inp["txt_tokens"], losses=losses)
-            task.add_pitch_loss(out, {"mel2ph": inp["mel2ph"], "f0": inp["f0"], "uv": inp["uv"]}, losses)
+            if hp["use_pitch_embed"]:  # tasks/speech_editing/spec_denoiser.py:55-56
+                task.add_pitch_loss(out, {"mel2ph": inp["mel2ph"], "f0": inp["f0"], "uv": inp["uv"]}, losses)
             total = sum(losses.values())
             total.backward()
     finally:
@@ -223,9 +229,10 @@ def train_loss_case(hp, name, B, T, T_txt, steps, wseed, iseed):
     # ---- oracle cross-check (values and every gradient)
     Wg = {k: v.clone().requires_grad_(True) for k, v in W.items()}
     with torch.enable_grad():
-        olosses, _ = O.training_losses(Wg, steps, inp, t, eps)
+        olosses, _ = O.training_losses(Wg, steps, inp, t, eps, use_pitch_embed=bool(hp["use_pitch_embed"]))
         sum(olosses.values()).backward()
     for k in losses:
+        assert np.isfinite(float(losses[k])), (k, "pick another input seed")
         assert abs(float(losses[k]) - float(olosses[k])) < 1e-5 * max(1.0, abs(float(losses[k]))), k
     worst = 0.0
     for k, g in grads.items():
@@ -240,6 +247,7 @@ def train_loss_case(hp, name, B, T, T_txt, steps, wseed, iseed):
             "fs.dur_predictor.linear.0.weight", "fs.pitch_predictor.linear.bias", "fs.encoder.embed_tokens.weight",
             "fs.spk_embed_proj.weight", "mel_encoder.fc_out.bias", "fs.encoder.res_blocks.0.blocks.0.0.weight",
             "fs.dur_embed.weight", "fs.pitch_embed.weight"]
+    keep = [k for k in keep if k in grads]
     names = [k for k, _ in model.named_parameters()]
     norms = np.array([float(grads[k].norm()) if grads[k] is not None else -1.0 for k in names], dtype=np.float64)
     out_np = dict(meta=np.array(json.dumps(dict(B=B, T=T, T_txt=T_txt, steps=steps, wseed=wseed, iseed=iseed,
@@ -425,6 +433,21 @@ def main():
     hifigan_case("hifigan_tiny_rb2", Wt.HIFIGAN_TINY_RB2, B=1, T=20, wseed=22, iseed=202)
     hifigan_case("hifigan_v1", Wt.HIFIGAN_V1, B=1, T=12, wseed=23, iseed=203)
     edit_cases(hp)
+    nopitch_cases(hp)
+
+
+def nopitch_cases(hp):
+    """egs/spec_denoiser_libritts.yaml: use_pitch_embed false (:169) -- no pitch_embed / pitch_predictor in the model
+    (fs.py:73-78), no pitch block in the conditioner (fs.py:97-99), no uv / f0 losses (tasks/.../spec_denoiser.py:55)."""
+    base = dict(residual_layers=20, residual_channels=256, dilation_cycle_length=1, use_pitch_embed=False)
+    m = build_ref_model(hp, 4, base)
+    with open(os.path.join(GOLD, "manifest_spec_denoiser_nopitch.json"), "w") as f:
+        json.dump(manifest_of(m), f)
+    infer_case(hp, "infer_nopitch", B=2, T=64, T_txt=16, steps=4, wseed=31, iseed=301, pad_tail=True, overrides=base,
+               keep_steps=(0, 3))
+    hp.update(base)
+    train_loss_case(hp, "train_losses_nopitch", B=2, T=64, T_txt=16, steps=8, wseed=32, iseed=108)
+    hp["use_pitch_embed"] = True
 
 
 def build_ref_campnet(hp):
@@ -543,6 +566,8 @@ def edit_cases(hp):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "edit":  # regenerate only the edit_* cases
         edit_cases(ref_import.install(timesteps=4))
+    elif len(sys.argv) > 1 and sys.argv[1] == "nopitch":
+        nopitch_cases(ref_import.install(timesteps=4))
     elif len(sys.argv) > 1 and sys.argv[1] == "campnet":
         campnet_cases(ref_import.install(timesteps=4))
     else:

@@ -275,9 +275,11 @@ def mel_encoder(W, x, p="mel_encoder."):
 
 
 def fastspeech_forward(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv,
-                       use_pred_mel2ph=False, use_pred_pitch=False, p="fs.", predictor_grad=0.1):
-    """fs.py:83-189 with skip_decoder=True, use_spk_embed, use_pitch_embed,
-    pitch_type 'frame', use_uv (egs/spec_denoiser.yaml).  Eval mode (no dropout).
+                       use_pred_mel2ph=False, use_pred_pitch=False, p="fs.", predictor_grad=0.1,
+                       use_pitch_embed=True):
+    """fs.py:83-189 with skip_decoder=True, use_spk_embed, pitch_type 'frame', use_uv (egs/spec_denoiser.yaml);
+    `use_pitch_embed=False` is egs/spec_denoiser_libritts.yaml:169 (the pitch block fs.py:97-99 is skipped and the
+    model has no pitch_embed / pitch_predictor, fs.py:73-78).  Eval mode (no dropout).
     Returns the ret dict incl. integer intermediates."""
     ret = {}
     enc = text_encoder(W, txt_tokens, p + "encoder.")
@@ -299,6 +301,9 @@ def fastspeech_forward(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv,
     ret["mel2ph"] = mel2ph
     tgt_nonpad = (mel2ph > 0).float()[:, :, None]
     dec_inp = expand_states(enc, mel2ph)
+    if not use_pitch_embed:
+        ret["decoder_inp"] = (dec_inp + style) * tgt_nonpad
+        return ret
     # -- pitch (fs.py:153-189)
     pitch_inp = (dec_inp + style) * tgt_nonpad
     pitch_padding = mel2ph == 0
@@ -331,11 +336,11 @@ def fastspeech_forward(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv,
 
 
 def conditioner(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv,
-                use_pred_mel2ph=False, use_pred_pitch=False):
+                use_pred_mel2ph=False, use_pred_pitch=False, use_pitch_embed=True):
     """spec_denoiser.py:159-167: fs(...) + mel_encoder(ref*(1-mask))*nonpad.
     Returns (ret, cond[B,H,T])."""
     ret = fastspeech_forward(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv,
-                             use_pred_mel2ph, use_pred_pitch)
+                             use_pred_mel2ph, use_pred_pitch, use_pitch_embed=use_pitch_embed)
     tgt_nonpad = (ret["mel2ph"] > 0).float()[:, :, None]
     dec = ret["decoder_inp"] + mel_encoder(W, ref_mels * (1 - time_mel_masks)) * tgt_nonpad
     ret["decoder_inp"] = dec
@@ -353,11 +358,12 @@ def gaussian_diffusion_infer(W, timesteps, inputs, noises, dilation_cycle_length
     return ret
 
 
-def gaussian_diffusion_train(W, timesteps, inputs, t, noise, dilation_cycle_length=1):
+def gaussian_diffusion_train(W, timesteps, inputs, t, noise, dilation_cycle_length=1, use_pitch_embed=True):
     """spec_denoiser.py:168-176 (infer=False) with explicit t and eps; eval-mode predictors."""
     tab, _ = diffusion_tables(timesteps)
     ret, cond = conditioner(W, inputs["txt_tokens"], inputs["time_mel_masks"], inputs["mel2ph"],
-                            inputs["spk_embed"], inputs["ref_mels"], inputs["f0"], inputs["uv"])
+                            inputs["spk_embed"], inputs["ref_mels"], inputs["f0"], inputs["uv"],
+                            use_pitch_embed=use_pitch_embed)
     nonpadding = (inputs["mel2ph"] != 0).float().unsqueeze(1).unsqueeze(1)
     x_start = inputs["ref_mels"].transpose(1, 2)[:, None]
     x_t = q_sample(tab, x_start, t, noise) * nonpadding
@@ -736,19 +742,21 @@ def pitch_losses(pitch_pred, f0, uv, mel2ph, lam_uv, lam_f0):
     return uvl, f0l
 
 
-def training_losses(W, timesteps, inputs, t, noise, sil_ids=(1, 2, 3), lambdas=None, dilation_cycle_length=1):
+def training_losses(W, timesteps, inputs, t, noise, sil_ids=(1, 2, 3), lambdas=None, dilation_cycle_length=1,
+                    use_pitch_embed=True):
     """tasks/speech_editing/spec_denoiser.py:39-62 (infer=False) on top of gaussian_diffusion_train; eval-mode
     predictors (no dropout).  Returns (losses dict, ret)."""
     lam = dict(l1=0.5, ssim=0.5, ph_dur=0.1, word_dur=1.0, uv=1.0, f0=1.0)
     lam.update(lambdas or {})
-    ret = gaussian_diffusion_train(W, timesteps, inputs, t, noise, dilation_cycle_length)
+    ret = gaussian_diffusion_train(W, timesteps, inputs, t, noise, dilation_cycle_length, use_pitch_embed)
     tm = inputs["time_mel_masks"]
     pred, target = ret["mel_out"] * tm, inputs["ref_mels"] * tm
     losses = {"l1_coarse": l1_loss(pred, target) * lam["l1"], "ssim_coarse": ssim_loss(pred, target) * lam["ssim"]}
     losses["pdur"], losses["wdur"] = dur_losses(ret["dur"], inputs["mel2ph"], inputs["txt_tokens"], sil_ids,
                                                 lam["ph_dur"], lam["word_dur"])
-    losses["uv"], losses["f0"] = pitch_losses(ret["pitch_pred"], inputs["f0"], inputs["uv"], inputs["mel2ph"],
-                                              lam["uv"], lam["f0"])
+    if use_pitch_embed:  # tasks/speech_editing/spec_denoiser.py:55-56
+        losses["uv"], losses["f0"] = pitch_losses(ret["pitch_pred"], inputs["f0"], inputs["uv"], inputs["mel2ph"],
+                                                  lam["uv"], lam["f0"])
     return losses, ret
 
 

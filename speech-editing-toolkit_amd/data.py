@@ -130,9 +130,12 @@ class StutterSpeechDataset:
         if hp["use_spk_embed"]:
             sample["spk_embed"] = torch.Tensor(np.asarray(item["spk_embed"]))
         sample["mel2ph"] = mel2ph = torch.LongTensor(np.asarray(item["mel2ph"]))[:T]
-        f0, uv = norm_interp_f0(np.asarray(item["f0"])[:T])
-        sample["f0"], sample["uv"] = f0, uv
-        sample["pitch"] = torch.LongTensor(np.asarray(item.get(hp.get("pitch_key", "pitch"), np.zeros(T))))[:T]
+        if hp["use_pitch_embed"]:  # dataset_utils.py:109-127; without it the three keys are None
+            f0, uv = norm_interp_f0(np.asarray(item["f0"])[:T])
+            sample["f0"], sample["uv"] = f0, uv
+            sample["pitch"] = torch.LongTensor(np.asarray(item.get(hp.get("pitch_key", "pitch"), np.zeros(T))))[:T]
+        else:
+            sample["f0"], sample["uv"], sample["pitch"] = None, None, None
         if not hp["infer"]:
             if hp.get("mask_type") == "random":
                 m = generate_time_mask(T, hp["training_mask_ratio"])
@@ -155,11 +158,13 @@ class StutterSpeechDataset:
             "txt_lengths": torch.LongTensor([s["txt_token"].numel() for s in samples]),
             "mel_lengths": torch.LongTensor([s["mel"].shape[0] for s in samples]),
             "mel2ph": collate_1d_or_2d([s["mel2ph"] for s in samples], 0),
-            "f0": collate_1d_or_2d([s["f0"] for s in samples], 0.0),
-            "uv": collate_1d_or_2d([s["uv"] for s in samples], 0.0),
-            "pitch": collate_1d_or_2d([s["pitch"] for s in samples], 0),
+            "f0": None, "uv": None, "pitch": None,
             "time_mel_masks": collate_1d_or_2d([s["time_mel_mask"] for s in samples], 0.0),
         }
+        if self.hparams["use_pitch_embed"]:  # dataset_utils.py:154-159
+            batch["f0"] = collate_1d_or_2d([s["f0"] for s in samples], 0.0)
+            batch["uv"] = collate_1d_or_2d([s["uv"] for s in samples], 0.0)
+            batch["pitch"] = collate_1d_or_2d([s["pitch"] for s in samples], 0)
         if self.hparams["use_spk_embed"]:
             batch["spk_embed"] = torch.stack([s["spk_embed"] for s in samples])
         return batch

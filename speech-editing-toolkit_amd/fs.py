@@ -218,8 +218,8 @@ class FastSpeech(nn.Module):
         self.mel_out = nn.Linear(H, self.out_dims, bias=True)
         if hp["use_spk_id"]:
             raise NotImplementedError("use_spk_id (spec_denoiser.yaml uses use_spk_embed)")
-        if not hp["use_spk_embed"] or not hp["use_pitch_embed"]:
-            raise NotImplementedError("spec_denoiser.yaml sets use_spk_embed and use_pitch_embed")
+        if not hp["use_spk_embed"]:
+            raise NotImplementedError("spec_denoiser.yaml / spec_denoiser_libritts.yaml set use_spk_embed")
         if hp.get("dec_inp_add_noise"):
             raise NotImplementedError("dec_inp_add_noise")
         self.spk_embed_proj = nn.Linear(256, H, bias=True)
@@ -229,9 +229,10 @@ class FastSpeech(nn.Module):
                                                dropout_rate=hp["predictor_dropout"],
                                                kernel_size=hp["dur_predictor_kernel"])
         self.length_regulator = LengthRegulator()
-        self.pitch_embed = _embedding(300, H, 0)
-        self.pitch_predictor = PitchPredictor(H, n_chans=ph, n_layers=5, dropout_rate=0.2, odim=2,
-                                              kernel_size=hp["predictor_kernel"])
+        if hp["use_pitch_embed"]:  # fs.py:73-78; egs/spec_denoiser_libritts.yaml:169 turns it off
+            self.pitch_embed = _embedding(300, H, 0)
+            self.pitch_predictor = PitchPredictor(H, n_chans=ph, n_layers=5, dropout_rate=0.2, odim=2,
+                                                  kernel_size=hp["predictor_kernel"])
         self._w_spk = _cw(self.spk_embed_proj)
 
     def predict_alignment(self, txt_tokens, spk_embed, masked_dur):
@@ -257,7 +258,7 @@ class FastSpeech(nn.Module):
         if not skip_decoder:
             raise NotImplementedError("FluentSpeech always calls fs(..., skip_decoder=True)")
         hp = self.hparams
-        if not (hp["pitch_type"] == "frame" and hp["use_uv"]):
+        if hp["use_pitch_embed"] and not (hp.get("pitch_type") == "frame" and hp["use_uv"]):
             raise NotImplementedError("pitch_type 'frame' + use_uv only")
         F = _backend()
         ret = {}
@@ -270,7 +271,10 @@ class FastSpeech(nn.Module):
         style = F.conv1d(spk_embed.reshape(B, 256, 1).contiguous(), self._w_spk, self.spk_embed_proj.bias)
         style = style.reshape(B, self.hidden_size)  # fs.py:114-121
         enc_d, enc = F.fanout(enc, 2)               # duration branch + alignment gather
-        style_d, style_p, style = F.fanout(style, 3)  # duration / pitch / decoder_inp
+        if hp["use_pitch_embed"]:
+            style_d, style_p, style = F.fanout(style, 3)  # duration / pitch / decoder_inp
+        else:
+            style_d, style = F.fanout(style, 2)
         # ---- duration (fs.py:123-151)
         dur_inp = F.add_chan_mask(enc_d, style_d, src_nonpad)
         mdur = F.masked_dur(mel2ph, tmask, txt_tokens)
@@ -286,6 +290,10 @@ class FastSpeech(nn.Module):
         ret["mel2ph"] = mel2ph
         tgt_nonpad = F.index_mask(mel2ph)
         dec = F.expand_states(enc, mel2ph)  # align_ops.py:21-25
+        ret["tgt_nonpad"] = tgt_nonpad
+        if not hp["use_pitch_embed"]:  # fs.py:97-102 without the pitch block
+            ret["decoder_inp_bct"] = F.add_chan_mask(dec, style, tgt_nonpad)
+            return ret
         dec_p, dec = F.fanout(dec, 2)
         # ---- pitch (fs.py:153-189)
         pitch_inp = F.add_chan_mask(dec_p, style_p, tgt_nonpad)
@@ -313,5 +321,4 @@ class FastSpeech(nn.Module):
                                                   mel2ph_pad=pad_idx, uv_from_logit=True, want_coarse=False)
         dec = F.embedding_bct(pitch, self.pitch_embed.weight, out=dec, accumulate=True, padding_idx=0)
         ret["decoder_inp_bct"] = F.add_chan_mask(dec, style, tgt_nonpad)
-        ret["tgt_nonpad"] = tgt_nonpad
         return ret

@@ -217,7 +217,8 @@ class SpecDenoiserInfer:
             aux = {"masked_dur": masked_dur, "dur_pred": dur.cpu().numpy(), "pred_mel2ph": pred_mel2ph.cpu().numpy(),
                    "edited_mel2ph": plan["mel2ph"], "edited_f0": edited_f0.cpu().numpy(),
                    "edited_uv": edited_uv.cpu().numpy(), "time_mel_masks": time_mel_masks.cpu().numpy(),
-                   "head_idx": head, "tail_idx": tail, "pitch": output["pitch"].cpu().numpy(),
-                   "mel2ph_out": output["mel2ph"].cpu().numpy()}
+                   "head_idx": head, "tail_idx": tail, "mel2ph_out": output["mel2ph"].cpu().numpy()}
+            if "pitch" in output:  # absent with use_pitch_embed false (egs/spec_denoiser_libritts.yaml)
+                aux["pitch"] = output["pitch"].cpu().numpy()
             return res + (aux,)
         return res

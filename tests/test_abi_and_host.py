@@ -126,6 +126,26 @@ def test_shipped_yaml_matches_reference_values():
     assert hp["task_cls"] == "tasks.speech_editing.spec_denoiser.SpeechDenoiserTask"
 
 
+def test_libritts_yaml_inherits_and_drops_the_pitch_block():
+    """egs/spec_denoiser_libritts.yaml of the reference: timesteps 4 (:86), use_pitch_embed false (:169); everything
+    else on the hot path as in spec_denoiser.yaml.  The model built from it has the reference's parameter set
+    (tests/golden/manifest_spec_denoiser_nopitch.json was dumped from the reference's own modules)."""
+    from set_amd import hparams as H
+    from set_amd.diffnet import DiffNet
+    from set_amd.spec_denoiser import GaussianDiffusion
+    from oracle import weights as Wt
+    fn = os.path.join(ROOT, "speech-editing-toolkit_amd", "egs", "spec_denoiser_libritts.yaml")
+    hp = H.set_hparams(config=fn, global_hparams=False, print_hparams=False)
+    assert hp["timesteps"] == 4 and hp["use_pitch_embed"] is False and hp["binary_data_dir"] == "data/binary/libritts"
+    assert (hp["residual_layers"], hp["residual_channels"], hp["hidden_size"]) == (20, 256, 192)
+    m = GaussianDiffusion(list(range(80)), 80, DiffNet(80, hp), timesteps=hp["timesteps"], time_scale=1,
+                          loss_type="l1", spec_min=[], spec_max=[], hp=hp)
+    want = [(k, tuple(s)) for k, s in Wt.load_manifest("spec_denoiser_nopitch")]
+    got = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert got == want
+    assert not any(k.startswith("fs.pitch_") for k, _ in got)
+
+
 def test_registries_and_aliases():
     from set_amd import tasks, vocoder_infer
     assert "wavenet" in tasks.DIFF_DECODERS

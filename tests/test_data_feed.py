@@ -68,3 +68,9 @@ def test_dataset_items_and_collater_layout():
     np.random.seed(2)
     s = D.StutterSpeechDataset("test", hp2)[1]
     assert s["time_mel_mask"].shape == (56,) and s["f0"].shape == (56,) and s["uv"].max() <= 1
+    # use_pitch_embed false (egs/spec_denoiser_libritts.yaml): the pitch keys are None (dataset_utils.py:125-127,158-159)
+    ds3 = D.StutterSpeechDataset("test", dict(hp, use_pitch_embed=False))
+    random.seed(1)
+    b3 = ds3.collater([ds3[i] for i in range(3)])
+    assert b3["f0"] is None and b3["uv"] is None and b3["pitch"] is None
+    assert torch.equal(b3["mels"], batch["mels"]) and torch.equal(b3["mel2ph"], batch["mel2ph"])

@@ -303,7 +303,8 @@ def test_fused_layer_matches_golden_layer_trace(dev):
 # ----------------------------------------------------------------------------------------------------
 FULL = [("infer_tiny", "spec_denoiser", {}), ("infer_pad", "spec_denoiser", {}),
         ("infer_predpitch", "spec_denoiser", {}), ("infer_drift100", "spec_denoiser", {}),
-        ("infer_dil", "spec_denoiser_dil", {}), ("infer_c64", "spec_denoiser_c64", {})]
+        ("infer_dil", "spec_denoiser_dil", {}), ("infer_c64", "spec_denoiser_c64", {}),
+        ("infer_nopitch", "spec_denoiser_nopitch", {})]  # egs/spec_denoiser_libritts.yaml: use_pitch_embed false
 
 
 @pytest.mark.parametrize("case,manifest,_", FULL)
@@ -318,13 +319,17 @@ def test_full_inference_matches_reference(dev, case, manifest, _):
     # integer / index tensors: bit exact
     assert torch.equal(ret["mel2ph"].cpu(), torch.from_numpy(g["mel2ph"]))
     assert torch.equal(ret["masked_dur"].cpu(), torch.from_numpy(g["masked_dur"]))
-    assert torch.equal(ret["masked_pitch"].cpu(), torch.from_numpy(g["masked_pitch"]))
-    assert torch.equal(ret["pitch"].cpu(), torch.from_numpy(g["pitch"]))
     # conditioner floats
     assert _maxdiff(ret["decoder_inp"], g["decoder_inp"]) < 2e-5
     assert _maxdiff(ret["dur"], g["dur"]) < 2e-5
-    assert _maxdiff(ret["pitch_pred"], g["pitch_pred"]) < 5e-5
-    assert _maxdiff(ret["f0_denorm"], g["f0_denorm"]) < 1e-3
+    if "pitch_pred" in g:
+        assert torch.equal(ret["masked_pitch"].cpu(), torch.from_numpy(g["masked_pitch"]))
+        assert torch.equal(ret["pitch"].cpu(), torch.from_numpy(g["pitch"]))
+        assert _maxdiff(ret["pitch_pred"], g["pitch_pred"]) < 5e-5
+        assert _maxdiff(ret["f0_denorm"], g["f0_denorm"]) < 1e-3
+    else:  # no pitch block (fs.py:97-99 skipped): the reference returns none of the pitch keys
+        assert not ({"pitch_pred", "pitch", "masked_pitch", "f0_denorm", "f0_denorm_pred"} & set(ret))
+        assert not any(k.startswith("fs.pitch_") for k in model.state_dict())
     # the bar: |dmel| < 1e-4 (fp32) after the whole reverse loop
     d = _maxdiff(ret["mel_out"], g["mel_out"])
     mcd = O.mel_mcd(ret["mel_out"].cpu().numpy(), g["mel_out"])

@@ -229,14 +229,14 @@ def test_losses_forward_backward(dev):
     assert _rel(dpp.grad.transpose(1, 2), lpp.grad) < 1e-5
 
 
-def _train_setup(dev, steps, wseed, over=None):
+def _train_setup(dev, steps, wseed, over=None, manifest="spec_denoiser"):
     from set_amd import hparams as H
     from set_amd import tasks
     H.hparams.clear()
     H.hparams.update(base_hparams(timesteps=steps, **(over or {})))
     task = tasks.SpeechDenoiserTask(build_vocoder=False)
     task.build_model()
-    W = Wt.seeded_weights(Wt.load_manifest("spec_denoiser"), wseed)
+    W = Wt.seeded_weights(Wt.load_manifest(manifest), wseed)
     task.model.load_state_dict(W, strict=False)
     task.model.to(dev).eval()  # eval: predictor dropout off, as in the fixtures
     return task, W
@@ -285,6 +285,47 @@ def test_training_losses_and_all_gradients_match_reference(dev, monkeypatch, sta
         ref = torch.from_numpy(g[key])
         gr = gr[:ref.shape[0]] if gr.shape != ref.shape else gr
         assert _rel(gr, ref) < 2e-4, name
+
+
+def test_training_without_pitch_embed_matches_reference(dev):
+    """egs/spec_denoiser_libritts.yaml (use_pitch_embed false): losses l1_coarse / ssim_coarse / pdur / wdur only
+    (tasks/speech_editing/spec_denoiser.py:55), no pitch parameters, f0 / uv are None in the batch
+    (tasks/speech_editing/dataset_utils.py:125-127).  Fixture: tests/golden/train_losses_nopitch.npz."""
+    g = load_golden("train_losses_nopitch")
+    m = g["meta"]
+    task, W = _train_setup(dev, m["steps"], m["wseed"], over=dict(use_pitch_embed=False),
+                           manifest="spec_denoiser_nopitch")
+    assert not any(k.startswith("fs.pitch_") for k in task.model.state_dict())
+    inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=True)
+    sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"],
+                  time_mel_masks=inp["time_mel_masks"].squeeze(-1), spk_embed=inp["spk_embed"])
+    sample = {k: v.to(dev) for k, v in sample.items()}
+    sample.update(f0=None, uv=None, pitch=None)
+    losses, out = task.run_model(sample, infer=False, t=torch.from_numpy(g["t"]).to(dev),
+                                 noises=torch.from_numpy(g["eps"]).to(dev))
+    assert sorted(losses) == ["l1_coarse", "pdur", "ssim_coarse", "wdur"]
+    for k in losses:
+        ref = float(g["loss_" + k])
+        assert abs(float(losses[k]) - ref) < 2e-5 * max(1.0, abs(ref)), (k, float(losses[k]), ref)
+    with torch.enable_grad():
+        total = sum(losses.values())
+    total.backward()
+    torch.cuda.synchronize()
+    params = dict(task.model.named_parameters())
+    assert list(params) == m["param_names"]
+    worst = 0.0
+    for k, ref in zip(m["param_names"], g["grad_norms"]):
+        p = params[k]
+        if ref < 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        worst = max(worst, abs(float(p.grad.norm()) - ref) / (ref + 1e-12))
+    assert worst < 1e-3, worst
+    for key in [k for k in g if k.startswith("grad::")]:
+        gr = params[key[len("grad::"):]].grad.cpu()
+        ref = torch.from_numpy(g[key])
+        gr = gr[:ref.shape[0]] if gr.shape != ref.shape else gr
+        assert _rel(gr, ref) < 2e-4, key
 
 
 def test_adamw_step_matches_torch(dev):

@@ -12,7 +12,8 @@ torch.set_grad_enabled(False)
 TOL = 2e-5
 
 INFER = [("infer_tiny", "spec_denoiser"), ("infer_pad", "spec_denoiser"), ("infer_predpitch", "spec_denoiser"),
-         ("infer_dil", "spec_denoiser_dil"), ("infer_c64", "spec_denoiser_c64"), ("infer_drift100", "spec_denoiser")]
+         ("infer_dil", "spec_denoiser_dil"), ("infer_c64", "spec_denoiser_c64"), ("infer_drift100", "spec_denoiser"),
+         ("infer_nopitch", "spec_denoiser_nopitch")]  # egs/spec_denoiser_libritts.yaml: use_pitch_embed false
 
 
 def _run_infer(case, manifest):
@@ -22,7 +23,10 @@ def _run_infer(case, manifest):
     inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=m["pad_tail"])
     noises = Wt.synthetic_noises(m["B"], m["T"], m["steps"], seed=m["iseed"] + 1)
     dcl = m["overrides"].get("dilation_cycle_length", 1)
-    ret = O.gaussian_diffusion_infer(W, m["steps"], inp, noises, dilation_cycle_length=dcl, **m["flags"])
+    flags = dict(m["flags"])
+    if not m["overrides"].get("use_pitch_embed", True):
+        flags["use_pitch_embed"] = False
+    ret = O.gaussian_diffusion_infer(W, m["steps"], inp, noises, dilation_cycle_length=dcl, **flags)
     return g, ret
 
 
@@ -32,9 +36,12 @@ def test_oracle_infer_matches_reference(case, manifest):
     assert np.abs(ret["mel_out"].numpy() - g["mel_out"]).max() < TOL
     assert np.abs(ret["decoder_inp"].numpy() - g["decoder_inp"]).max() < TOL
     assert np.abs(ret["dur"].numpy() - g["dur"]).max() < TOL
-    assert np.abs(ret["pitch_pred"].numpy() - g["pitch_pred"]).max() < TOL
     assert np.array_equal(ret["mel2ph"].numpy(), g["mel2ph"])
     assert np.array_equal(ret["masked_dur"].numpy(), g["masked_dur"])
+    if "pitch_pred" not in g:  # no pitch block: the reference's ret dict has none of the pitch keys either
+        assert not ({"pitch_pred", "pitch", "f0_denorm"} & set(ret))
+        return
+    assert np.abs(ret["pitch_pred"].numpy() - g["pitch_pred"]).max() < TOL
     assert np.array_equal(ret["pitch"].numpy(), g["pitch"])
 
 
@@ -47,15 +54,19 @@ def test_oracle_train_branch():
     assert np.abs(ret["mel_out"].numpy() - g["mel_out"]).max() < TOL
 
 
-def test_oracle_training_losses_and_grads():
+@pytest.mark.parametrize("case,manifest", [("train_losses", "spec_denoiser"),
+                                           ("train_losses_nopitch", "spec_denoiser_nopitch")])
+def test_oracle_training_losses_and_grads(case, manifest):
     """train_losses.npz = reference model + the reference's own loss functions + autograd (oracle/make_golden.py)."""
-    g = load_golden("train_losses")
+    g = load_golden(case)
     m = g["meta"]
-    W = {k: v.requires_grad_(True) for k, v in Wt.seeded_weights(Wt.load_manifest("spec_denoiser"), m["wseed"]).items()}
+    use_pitch = "nopitch" not in case
+    assert ("loss_uv" in g) == use_pitch
+    W = {k: v.requires_grad_(True) for k, v in Wt.seeded_weights(Wt.load_manifest(manifest), m["wseed"]).items()}
     inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=True)
     with torch.enable_grad():
         losses, _ = O.training_losses(W, m["steps"], inp, torch.from_numpy(g["t"]), torch.from_numpy(g["eps"]),
-                                      sil_ids=m["sil_ids"])
+                                      sil_ids=m["sil_ids"], use_pitch_embed=use_pitch)
         sum(losses.values()).backward()
     for k, v in losses.items():
         assert abs(float(v) - float(g["loss_" + k])) < 1e-5 * max(1.0, abs(float(v))), k
