@@ -45,11 +45,17 @@ def patched_randn(noises):
         torch.randn = real
 
 
+VARIANT = "masked"  # "normal": modules/speech_editing/spec_denoiser/spec_denoiser_normal.py (wo_masked_predictor)
+
+
 def build_ref_model(hp, timesteps, overrides=None):
     hp["timesteps"] = timesteps
     for k, v in (overrides or {}).items():
         hp[k] = v
-    from modules.speech_editing.spec_denoiser import spec_denoiser as SD
+    if VARIANT == "normal":
+        from modules.speech_editing.spec_denoiser import spec_denoiser_normal as SD
+    else:
+        from modules.speech_editing.spec_denoiser import spec_denoiser as SD
     from modules.speech_editing.spec_denoiser.diffnet import DiffNet
     SD.tqdm = lambda it, **kw: it
     m = SD.GaussianDiffusion(list(range(80)), 80, DiffNet(80), timesteps=timesteps, time_scale=1,
@@ -128,6 +134,8 @@ def infer_case(hp, name, B, T, T_txt, steps, wseed, iseed, pad_tail=False, overr
     otrace = []
     use_pitch = bool(hp["use_pitch_embed"])
     oflags = dict(flags) if use_pitch else dict(flags, use_pitch_embed=False)
+    if VARIANT != "masked":
+        oflags["variant"] = VARIANT
     oret = O.gaussian_diffusion_infer(W, steps, inp, noises, dilation_cycle_length=dcl, trace=otrace, **oflags)
     d_mel = maxdiff(oret["mel_out"], ret["mel_out"])
     d_cond = maxdiff(oret["decoder_inp"], ret["decoder_inp"])
@@ -144,13 +152,16 @@ def infer_case(hp, name, B, T, T_txt, steps, wseed, iseed, pad_tail=False, overr
     out = dict(
         meta=np.array(json.dumps(dict(B=B, T=T, T_txt=T_txt, steps=steps, wseed=wseed, iseed=iseed,
                                       pad_tail=pad_tail, overrides=overrides or {}, flags=flags,
-                                      trace_layers=list(trace_layers)))),
+                                      trace_layers=list(trace_layers), variant=VARIANT))),
         mel_out=ret["mel_out"], decoder_inp=ret["decoder_inp"], dur=ret["dur"], mel2ph=ret["mel2ph"],
-        masked_dur=oret["masked_dur"],
     )
+    if VARIANT == "masked":
+        out["masked_dur"] = oret["masked_dur"]
     if use_pitch:
         out.update(pitch_pred=ret["pitch_pred"], f0_denorm=ret["f0_denorm"], f0_denorm_pred=ret["f0_denorm_pred"],
-                   masked_pitch=oret["masked_pitch"], pitch=oret["pitch"])
+                   pitch=oret["pitch"])
+        if VARIANT == "masked":
+            out["masked_pitch"] = oret["masked_pitch"]
     ks = range(steps) if keep_steps is None else keep_steps
     for k in ks:
         out["x0_step%d" % k] = rec["x0"][k]
@@ -229,7 +240,8 @@ def train_loss_case(hp, name, B, T, T_txt, steps, wseed, iseed):
     # ---- oracle cross-check (values and every gradient)
     Wg = {k: v.clone().requires_grad_(True) for k, v in W.items()}
     with torch.enable_grad():
-        olosses, _ = O.training_losses(Wg, steps, inp, t, eps, use_pitch_embed=bool(hp["use_pitch_embed"]))
+        olosses, _ = O.training_losses(Wg, steps, inp, t, eps, use_pitch_embed=bool(hp["use_pitch_embed"]),
+                                       variant=VARIANT)
         sum(olosses.values()).backward()
     for k in losses:
         assert np.isfinite(float(losses[k])), (k, "pick another input seed")
@@ -251,7 +263,8 @@ def train_loss_case(hp, name, B, T, T_txt, steps, wseed, iseed):
     names = [k for k, _ in model.named_parameters()]
     norms = np.array([float(grads[k].norm()) if grads[k] is not None else -1.0 for k in names], dtype=np.float64)
     out_np = dict(meta=np.array(json.dumps(dict(B=B, T=T, T_txt=T_txt, steps=steps, wseed=wseed, iseed=iseed,
-                                                pad_tail=True, sil_ids=[1, 2, 3], param_names=names))),
+                                                pad_tail=True, sil_ids=[1, 2, 3], param_names=names,
+                                                variant=VARIANT))),
                   t=t, eps=eps, grad_norms=norms, total=total.detach(),
                   **{"loss_" + k: v.detach() for k, v in losses.items()})
     for k in keep:
@@ -434,6 +447,7 @@ def main():
     hifigan_case("hifigan_v1", Wt.HIFIGAN_V1, B=1, T=12, wseed=23, iseed=203)
     edit_cases(hp)
     nopitch_cases(hp)
+    normal_cases(hp)
 
 
 def nopitch_cases(hp):
@@ -448,6 +462,24 @@ def nopitch_cases(hp):
     hp.update(base)
     train_loss_case(hp, "train_losses_nopitch", B=2, T=64, T_txt=16, steps=8, wseed=32, iseed=108)
     hp["use_pitch_embed"] = True
+
+
+def normal_cases(hp):
+    """egs/spec_denoiser_wo_masked_predictor.yaml: SpeechDenoiserNormalTask over spec_denoiser_normal.GaussianDiffusion
+    (conditioner = modules/tts/fs.py FastSpeech, called with the positional binding of spec_denoiser_normal.py:158)."""
+    global VARIANT
+    VARIANT = "normal"
+    try:
+        base = dict(residual_layers=20, residual_channels=256, dilation_cycle_length=1, use_pitch_embed=True)
+        m = build_ref_model(hp, 4, base)
+        with open(os.path.join(GOLD, "manifest_spec_denoiser_normal.json"), "w") as f:
+            json.dump(manifest_of(m), f)
+        infer_case(hp, "infer_normal", B=2, T=64, T_txt=16, steps=4, wseed=41, iseed=401, pad_tail=True,
+                   overrides=base, keep_steps=(0, 3))
+        hp.update(base)
+        train_loss_case(hp, "train_losses_normal", B=2, T=64, T_txt=16, steps=8, wseed=43, iseed=109)
+    finally:
+        VARIANT = "masked"
 
 
 def build_ref_campnet(hp):
@@ -568,6 +600,8 @@ if __name__ == "__main__":
         edit_cases(ref_import.install(timesteps=4))
     elif len(sys.argv) > 1 and sys.argv[1] == "nopitch":
         nopitch_cases(ref_import.install(timesteps=4))
+    elif len(sys.argv) > 1 and sys.argv[1] == "normal":
+        normal_cases(ref_import.install(timesteps=4))
     elif len(sys.argv) > 1 and sys.argv[1] == "campnet":
         campnet_cases(ref_import.install(timesteps=4))
     else:

@@ -335,12 +335,54 @@ def fastspeech_forward(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv,
     return ret
 
 
+def fastspeech_normal_forward(W, txt_tokens, mel2ph, spk_embed, f0, uv, p="fs.", predictor_grad=0.1,
+                              use_pitch_embed=True):
+    """modules/tts/fs.py:81-168 with skip_decoder=True (the plain FastSpeech: predictors without masked ground
+    truth, `mel2ph is None` / `f0 is None` select the predictions).  Eval mode."""
+    ret = {}
+    enc = text_encoder(W, txt_tokens, p + "encoder.")
+    src_nonpad = (txt_tokens > 0).float()[:, :, None]
+    style = F.linear(spk_embed, W[p + "spk_embed_proj.weight"], W[p + "spk_embed_proj.bias"])[:, None, :]
+    dur_inp = (enc + style) * src_nonpad
+    dur_inp = dur_inp.detach() + predictor_grad * (dur_inp - dur_inp.detach())  # :132-133
+    src_padding = txt_tokens == 0
+    ret["dur"] = dur = duration_predictor(W, dur_inp, src_padding, p + "dur_predictor.")
+    if mel2ph is None:
+        mel2ph = length_regulator(dur, src_padding)
+    ret["mel2ph"] = mel2ph
+    tgt_nonpad = (mel2ph > 0).float()[:, :, None]
+    dec_inp = expand_states(enc, mel2ph)
+    if use_pitch_embed:  # :140-168, pitch_type 'frame'
+        pitch_inp = (dec_inp + style) * tgt_nonpad
+        pitch_padding = mel2ph == 0
+        pitch_inp = pitch_inp.detach() + predictor_grad * (pitch_inp - pitch_inp.detach())
+        h = predictor_stack(W, p + "pitch_predictor.", pitch_inp, 5, 5)
+        pitch_pred = F.linear(h, W[p + "pitch_predictor.linear.weight"], W[p + "pitch_predictor.linear.bias"])
+        ret["pitch_pred"] = pitch_pred
+        if f0 is None:
+            f0 = pitch_pred[:, :, 0]
+            uv = pitch_pred[:, :, 1] > 0
+        ret["f0_denorm"] = f0_denorm = denorm_f0(f0, uv, pitch_padding)
+        ret["pitch"] = pitch = f0_to_coarse(f0_denorm)
+        ret["f0_denorm_pred"] = denorm_f0(pitch_pred[:, :, 0], pitch_pred[:, :, 1] > 0, pitch_padding)
+        dec_inp = dec_inp + F.embedding(pitch, W[p + "pitch_embed.weight"], padding_idx=0)
+    ret["decoder_inp"] = (dec_inp + style) * tgt_nonpad
+    return ret
+
+
 def conditioner(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv,
-                use_pred_mel2ph=False, use_pred_pitch=False, use_pitch_embed=True):
+                use_pred_mel2ph=False, use_pred_pitch=False, use_pitch_embed=True, variant="masked"):
     """spec_denoiser.py:159-167: fs(...) + mel_encoder(ref*(1-mask))*nonpad.
-    Returns (ret, cond[B,H,T])."""
-    ret = fastspeech_forward(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv,
-                             use_pred_mel2ph, use_pred_pitch, use_pitch_embed=use_pitch_embed)
+    Returns (ret, cond[B,H,T]).  variant 'normal' = spec_denoiser_normal.py:158-162, whose positional call
+    `fs(txt_tokens, mel2ph, spk_embed, f0, uv, energy)` binds f0 -> spk_id (unused), uv -> f0, energy=None -> uv
+    against modules/tts/fs.py:81-82; restated as executed."""
+    if variant == "normal":
+        assert not (use_pred_mel2ph or use_pred_pitch)
+        ret = fastspeech_normal_forward(W, txt_tokens, mel2ph, spk_embed, f0=uv, uv=None,
+                                        use_pitch_embed=use_pitch_embed)
+    else:
+        ret = fastspeech_forward(W, txt_tokens, time_mel_masks, mel2ph, spk_embed, f0, uv,
+                                 use_pred_mel2ph, use_pred_pitch, use_pitch_embed=use_pitch_embed)
     tgt_nonpad = (ret["mel2ph"] > 0).float()[:, :, None]
     dec = ret["decoder_inp"] + mel_encoder(W, ref_mels * (1 - time_mel_masks)) * tgt_nonpad
     ret["decoder_inp"] = dec
@@ -358,12 +400,13 @@ def gaussian_diffusion_infer(W, timesteps, inputs, noises, dilation_cycle_length
     return ret
 
 
-def gaussian_diffusion_train(W, timesteps, inputs, t, noise, dilation_cycle_length=1, use_pitch_embed=True):
+def gaussian_diffusion_train(W, timesteps, inputs, t, noise, dilation_cycle_length=1, use_pitch_embed=True,
+                             variant="masked"):
     """spec_denoiser.py:168-176 (infer=False) with explicit t and eps; eval-mode predictors."""
     tab, _ = diffusion_tables(timesteps)
     ret, cond = conditioner(W, inputs["txt_tokens"], inputs["time_mel_masks"], inputs["mel2ph"],
                             inputs["spk_embed"], inputs["ref_mels"], inputs["f0"], inputs["uv"],
-                            use_pitch_embed=use_pitch_embed)
+                            use_pitch_embed=use_pitch_embed, variant=variant)
     nonpadding = (inputs["mel2ph"] != 0).float().unsqueeze(1).unsqueeze(1)
     x_start = inputs["ref_mels"].transpose(1, 2)[:, None]
     x_t = q_sample(tab, x_start, t, noise) * nonpadding
@@ -743,12 +786,12 @@ def pitch_losses(pitch_pred, f0, uv, mel2ph, lam_uv, lam_f0):
 
 
 def training_losses(W, timesteps, inputs, t, noise, sil_ids=(1, 2, 3), lambdas=None, dilation_cycle_length=1,
-                    use_pitch_embed=True):
+                    use_pitch_embed=True, variant="masked"):
     """tasks/speech_editing/spec_denoiser.py:39-62 (infer=False) on top of gaussian_diffusion_train; eval-mode
     predictors (no dropout).  Returns (losses dict, ret)."""
     lam = dict(l1=0.5, ssim=0.5, ph_dur=0.1, word_dur=1.0, uv=1.0, f0=1.0)
     lam.update(lambdas or {})
-    ret = gaussian_diffusion_train(W, timesteps, inputs, t, noise, dilation_cycle_length, use_pitch_embed)
+    ret = gaussian_diffusion_train(W, timesteps, inputs, t, noise, dilation_cycle_length, use_pitch_embed, variant)
     tm = inputs["time_mel_masks"]
     pred, target = ret["mel_out"] * tm, inputs["ref_mels"] * tm
     losses = {"l1_coarse": l1_loss(pred, target) * lam["l1"], "ssim_coarse": ssim_loss(pred, target) * lam["ssim"]}

@@ -201,6 +201,8 @@ class FastSpeech(nn.Module):
     """modules/speech_editing/spec_denoiser/fs.py:49-189 with skip_decoder=True (the only way
     GaussianDiffusion calls it, spec_denoiser.py:159-161).  `decoder` / `mel_out` exist as parameters
     (checkpoint compatibility) but are never run, exactly as in the reference."""
+    masked_predictor = True    # dur_embed + masked ground-truth duration / pitch fed to the predictors
+    pitch_dropout = 0.2        # fs.py:77
 
     def __init__(self, dict_size, hp, out_dims=None):
         super().__init__()
@@ -224,14 +226,15 @@ class FastSpeech(nn.Module):
             raise NotImplementedError("dec_inp_add_noise")
         self.spk_embed_proj = nn.Linear(256, H, bias=True)
         ph = hp["predictor_hidden"] if hp["predictor_hidden"] > 0 else H
-        self.dur_embed = _embedding(2000, H, 0)
+        if self.masked_predictor:
+            self.dur_embed = _embedding(2000, H, 0)
         self.dur_predictor = DurationPredictor(H, n_chans=ph, n_layers=hp["dur_predictor_layers"],
                                                dropout_rate=hp["predictor_dropout"],
                                                kernel_size=hp["dur_predictor_kernel"])
         self.length_regulator = LengthRegulator()
         if hp["use_pitch_embed"]:  # fs.py:73-78; egs/spec_denoiser_libritts.yaml:169 turns it off
             self.pitch_embed = _embedding(300, H, 0)
-            self.pitch_predictor = PitchPredictor(H, n_chans=ph, n_layers=5, dropout_rate=0.2, odim=2,
+            self.pitch_predictor = PitchPredictor(H, n_chans=ph, n_layers=5, dropout_rate=self.pitch_dropout, odim=2,
                                                   kernel_size=hp["predictor_kernel"])
         self._w_spk = _cw(self.spk_embed_proj)
 
@@ -319,6 +322,74 @@ class FastSpeech(nn.Module):
         ret["f0_denorm"] = f0_denorm
         ret["f0_denorm_pred"], _ = F.pitch_coarse(ppd[:, 0, :].contiguous(), ppd[:, 1, :].contiguous(),
                                                   mel2ph_pad=pad_idx, uv_from_logit=True, want_coarse=False)
+        dec = F.embedding_bct(pitch, self.pitch_embed.weight, out=dec, accumulate=True, padding_idx=0)
+        ret["decoder_inp_bct"] = F.add_chan_mask(dec, style, tgt_nonpad)
+        return ret
+
+
+class FastSpeechNormal(FastSpeech):
+    """modules/tts/fs.py:49-175 with skip_decoder=True: the conditioner of the `wo_masked_predictor` ablation
+    (egs/spec_denoiser_wo_masked_predictor.yaml -> modules/speech_editing/spec_denoiser/spec_denoiser_normal.py:11).
+    Against the masked variant above: no `dur_embed`, the predictors see no masked ground truth (:121-138,140-151),
+    pitch-predictor dropout 0.1 (:75), `mel2ph is None` / `f0 is None` select the predictions (:135,153-156)."""
+    masked_predictor = False
+    pitch_dropout = 0.1
+
+    def predict_alignment(self, *a, **k):
+        raise NotImplementedError("the edit caller (inference/tts/spec_denoiser.py) uses the masked predictor")
+
+    def forward(self, txt_tokens, mel2ph=None, spk_embed=None, spk_id=None, f0=None, uv=None, skip_decoder=True,
+                infer=False, **kwargs):
+        if not skip_decoder:
+            raise NotImplementedError("GaussianDiffusion always calls fs(..., skip_decoder=True)")
+        hp = self.hparams
+        if hp["use_pitch_embed"] and not (hp.get("pitch_type") == "frame" and hp["use_uv"]):
+            raise NotImplementedError("pitch_type 'frame' + use_uv only")
+        F = _backend()
+        ret = {}
+        B = txt_tokens.shape[0]
+        seed = int(kwargs.get("dropout_seed", 0))
+        pg = hp["predictor_grad"]
+        enc = self.encoder.run_tokens(txt_tokens)
+        src_nonpad = F.index_mask(txt_tokens)
+        style = F.conv1d(spk_embed.reshape(B, 256, 1).contiguous(), self._w_spk, self.spk_embed_proj.bias)
+        style = style.reshape(B, self.hidden_size)
+        enc_d, enc = F.fanout(enc, 2)
+        if hp["use_pitch_embed"]:
+            style_d, style_p, style = F.fanout(style, 3)
+        else:
+            style_d, style = F.fanout(style, 2)
+        # ---- duration (modules/tts/fs.py:121-138)
+        dur_inp = F.grad_scale(F.add_chan_mask(enc_d, style_d, src_nonpad), pg)
+        ret["dur"] = dur = self.dur_predictor.run(dur_inp, src_nonpad, seed)
+        if mel2ph is None:
+            mel2ph = self.length_regulator(dur.detach(), txt_tokens)
+        fm = hp["frames_multiple"]
+        if fm != 1:
+            mel2ph = mel2ph[:, :mel2ph.shape[1] // fm * fm].contiguous()
+        ret["mel2ph"] = mel2ph
+        ret["tgt_nonpad"] = tgt_nonpad = F.index_mask(mel2ph)
+        dec = F.expand_states(enc, mel2ph)
+        if not hp["use_pitch_embed"]:
+            ret["decoder_inp_bct"] = F.add_chan_mask(dec, style, tgt_nonpad)
+            return ret
+        # ---- pitch (modules/tts/fs.py:140-168)
+        dec_p, dec = F.fanout(dec, 2)
+        pitch_inp = F.grad_scale(F.add_chan_mask(dec_p, style_p, tgt_nonpad), pg)
+        pp = self.pitch_predictor.run(pitch_inp, seed + 1)  # [B,2,T]
+        ret["pitch_pred_bct"] = pp
+        ret["pitch_pred"] = F.bct_to_btc(pp)
+        ppd = pp.detach()
+        if f0 is None:  # :153-156 (the coarse bins carry no gradient, so detaching changes nothing)
+            f0_denorm, pitch = F.pitch_coarse(ppd[:, 0, :].contiguous(), ppd[:, 1, :].contiguous(), mel2ph_pad=mel2ph,
+                                              uv_from_logit=True)
+        else:
+            f0_denorm, pitch = F.pitch_coarse(f0.contiguous(), None if uv is None else uv.contiguous(),
+                                              mel2ph_pad=mel2ph)
+        ret["pitch"] = pitch
+        ret["f0_denorm"] = f0_denorm
+        ret["f0_denorm_pred"], _ = F.pitch_coarse(ppd[:, 0, :].contiguous(), ppd[:, 1, :].contiguous(),
+                                                  mel2ph_pad=mel2ph, uv_from_logit=True, want_coarse=False)
         dec = F.embedding_bct(pitch, self.pitch_embed.weight, out=dec, accumulate=True, padding_idx=0)
         ret["decoder_inp_bct"] = F.add_chan_mask(dec, style, tgt_nonpad)
         return ret

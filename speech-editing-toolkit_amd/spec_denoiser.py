@@ -11,18 +11,20 @@ from torch import nn
 
 from . import autograd_ops, ops
 from .diffusion_utils import get_noise_schedule_list
-from .fs import FastSpeech, MelEncoder
+from .fs import FastSpeech, FastSpeechNormal, MelEncoder
 from .hparams import hparams as _global_hparams
 
 
 class GaussianDiffusion(nn.Module):
+    fs_cls = FastSpeech
+
     def __init__(self, phone_encoder, out_dims, denoise_fn, timesteps=1000, time_scale=1, loss_type="l1",
                  betas=None, spec_min=None, spec_max=None, hp=None):
         super().__init__()
         hp = hp if hp is not None else _global_hparams
         self.hp = hp
         self.denoise_fn = denoise_fn
-        self.fs = FastSpeech(len(phone_encoder), hp)  # only len() is used, spec_denoiser.py:21
+        self.fs = self.fs_cls(len(phone_encoder), hp)  # only len() is used, spec_denoiser.py:21
         self.mel_encoder = MelEncoder(hidden_size=self.fs.hidden_size)
         self.mel_bins = out_dims
         if betas is not None:
@@ -186,3 +188,30 @@ class GaussianDiffusion(nn.Module):
         ret["mel_out"] = ops.bct_to_btc(x)  # x[:, 0].transpose(1, 2)
         ret["cond"] = cond
         return ret
+
+
+class GaussianDiffusionNormal(GaussianDiffusion):
+    """modules/speech_editing/spec_denoiser/spec_denoiser_normal.py:16-184 -- the `wo_masked_predictor` ablation
+    (egs/spec_denoiser_wo_masked_predictor.yaml:50).  Same diffusion, same DiffNet; the conditioner is the plain
+    FastSpeech of modules/tts/fs.py.
+
+    The reference calls it positionally, `self.fs(txt_tokens, mel2ph, spk_embed, f0, uv, energy, ...)` (:158-159),
+    against the signature `forward(txt_tokens, mel2ph, spk_embed, spk_id, f0, uv, ...)` (modules/tts/fs.py:81-82):
+    the caller's f0 lands in `spk_id` (unused without use_spk_id), the caller's UV FLAGS land in `f0` and `uv` is None.
+    The pitch embedding therefore sees f0_to_coarse(clamp(2**uv, 50, 900)) = bin 1 on every non-padded frame.  A
+    drop-in has to produce the same numbers from the same checkpoint, so that binding is kept, not repaired."""
+    fs_cls = FastSpeechNormal
+
+    def conditioner(self, txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv, infer=False,
+                    use_pred_mel2ph=False, use_pred_pitch=False, dropout_seed=0):
+        if use_pred_mel2ph or use_pred_pitch:
+            raise TypeError("spec_denoiser_normal.GaussianDiffusion.forward has no use_pred_mel2ph / use_pred_pitch")
+        F = autograd_ops if torch.is_grad_enabled() else ops
+        ret = self.fs(txt_tokens, mel2ph, spk_embed, f0, uv, None, skip_decoder=True, infer=infer,
+                      dropout_seed=dropout_seed)
+        B, T, M = ref_mels.shape
+        tmask = time_mel_masks.reshape(B, T).contiguous()
+        masked = ops.mul_one_minus_mask(ref_mels.contiguous(), tmask, M)
+        cond = self.mel_encoder.run(ops.btc_to_bct(masked), res=ret.pop("decoder_inp_bct"), mask=ret["tgt_nonpad"])
+        ret["decoder_inp"] = F.bct_to_btc(cond)
+        return ret, cond

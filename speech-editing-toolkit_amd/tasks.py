@@ -15,7 +15,7 @@ import torch
 from . import autograd_ops, ops
 from .diffnet import DiffNet
 from .hparams import hparams, set_hparams
-from .spec_denoiser import GaussianDiffusion
+from .spec_denoiser import GaussianDiffusion, GaussianDiffusionNormal
 from .vocoder_infer import get_vocoder_cls
 
 DIFF_DECODERS = {
@@ -26,10 +26,13 @@ DIFF_DECODERS = {
 TASK_ALIASES = {
     "tasks.speech_editing.spec_denoiser.SpeechDenoiserTask": "set_amd.tasks.SpeechDenoiserTask",
     "tasks.speech_editing.campnet.CampNetTask": "set_amd.tasks.CampNetTask",
+    "tasks.speech_editing.spec_denoiser_normal.SpeechDenoiserNormalTask": "set_amd.tasks.SpeechDenoiserNormalTask",
 }
 
 
 class SpeechDenoiserTask:
+    model_cls = GaussianDiffusion
+
     def __init__(self, build_vocoder=True):
         # phone set: <binary_data_dir>/phone_set.json (tasks/tts/speech_base.py:40-41); only its length is used
         ph_path = os.path.join(hparams.get("binary_data_dir", ""), "phone_set.json")
@@ -44,7 +47,7 @@ class SpeechDenoiserTask:
         self.model = None
 
     def build_tts_model(self):
-        self.model = GaussianDiffusion(
+        self.model = self.model_cls(
             phone_encoder=self.token_encoder, out_dims=hparams["audio_num_mel_bins"],
             denoise_fn=DIFF_DECODERS[hparams["diff_decoder_type"]](hparams),
             timesteps=hparams["timesteps"], time_scale=hparams["timescale"], loss_type=hparams["diff_loss_type"],
@@ -202,6 +205,12 @@ class SpeechDenoiserTask:
                                       "path; use training_step() with batches (tools/train_bench.py)")
         task = cls()
         task.test()
+
+
+class SpeechDenoiserNormalTask(SpeechDenoiserTask):
+    """tasks/speech_editing/spec_denoiser_normal.py:18-102 (egs/spec_denoiser_wo_masked_predictor.yaml:50): the same
+    task over the GaussianDiffusion whose conditioner has no masked predictors."""
+    model_cls = GaussianDiffusionNormal
 
 
 class CampNetTask:

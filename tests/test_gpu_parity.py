@@ -223,11 +223,12 @@ def test_posterior_qsample_randn(dev):
 # ----------------------------------------------------------------------------------------------------
 # DiffNet: fused layer kernel vs unfused kernels vs golden layer traces
 # ----------------------------------------------------------------------------------------------------
-def _build_model(dev, manifest, wseed, steps, **over):
+def _build_model(dev, manifest, wseed, steps, variant="masked", **over):
     from set_amd.diffnet import DiffNet
-    from set_amd.spec_denoiser import GaussianDiffusion
+    from set_amd import spec_denoiser as SD
     hp = base_hparams(timesteps=steps, **over)
-    m = GaussianDiffusion(list(range(80)), 80, DiffNet(80, hp), timesteps=steps, time_scale=1, loss_type="l1",
+    cls = SD.GaussianDiffusionNormal if variant == "normal" else SD.GaussianDiffusion
+    m = cls(list(range(80)), 80, DiffNet(80, hp), timesteps=steps, time_scale=1, loss_type="l1",
                           spec_min=[], spec_max=[], hp=hp)
     W = Wt.seeded_weights(Wt.load_manifest(manifest), wseed)
     missing, unexpected = m.load_state_dict(W, strict=False)
@@ -304,26 +305,31 @@ def test_fused_layer_matches_golden_layer_trace(dev):
 FULL = [("infer_tiny", "spec_denoiser", {}), ("infer_pad", "spec_denoiser", {}),
         ("infer_predpitch", "spec_denoiser", {}), ("infer_drift100", "spec_denoiser", {}),
         ("infer_dil", "spec_denoiser_dil", {}), ("infer_c64", "spec_denoiser_c64", {}),
-        ("infer_nopitch", "spec_denoiser_nopitch", {})]  # egs/spec_denoiser_libritts.yaml: use_pitch_embed false
+        ("infer_nopitch", "spec_denoiser_nopitch", {}),  # egs/spec_denoiser_libritts.yaml: use_pitch_embed false
+        ("infer_normal", "spec_denoiser_normal", {})]    # egs/spec_denoiser_wo_masked_predictor.yaml
 
 
 @pytest.mark.parametrize("case,manifest,_", FULL)
 def test_full_inference_matches_reference(dev, case, manifest, _):
     g = load_golden(case)
     m = g["meta"]
-    model, W = _build_model(dev, manifest, m["wseed"], m["steps"], **m["overrides"])
+    model, W = _build_model(dev, manifest, m["wseed"], m["steps"], variant=m.get("variant", "masked"), **m["overrides"])
     inp, noises = _case_inputs(g, dev)
     ret = model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"],
                 inp["f0"], inp["uv"], infer=True, noises=noises, **m["flags"])
     torch.cuda.synchronize()
     # integer / index tensors: bit exact
     assert torch.equal(ret["mel2ph"].cpu(), torch.from_numpy(g["mel2ph"]))
-    assert torch.equal(ret["masked_dur"].cpu(), torch.from_numpy(g["masked_dur"]))
+    if "masked_dur" in g:
+        assert torch.equal(ret["masked_dur"].cpu(), torch.from_numpy(g["masked_dur"]))
+    else:  # `normal` variant: no masked predictor inputs, no dur_embed (modules/tts/fs.py)
+        assert "masked_dur" not in ret and "fs.dur_embed.weight" not in model.state_dict()
     # conditioner floats
     assert _maxdiff(ret["decoder_inp"], g["decoder_inp"]) < 2e-5
     assert _maxdiff(ret["dur"], g["dur"]) < 2e-5
     if "pitch_pred" in g:
-        assert torch.equal(ret["masked_pitch"].cpu(), torch.from_numpy(g["masked_pitch"]))
+        if "masked_pitch" in g:
+            assert torch.equal(ret["masked_pitch"].cpu(), torch.from_numpy(g["masked_pitch"]))
         assert torch.equal(ret["pitch"].cpu(), torch.from_numpy(g["pitch"]))
         assert _maxdiff(ret["pitch_pred"], g["pitch_pred"]) < 5e-5
         assert _maxdiff(ret["f0_denorm"], g["f0_denorm"]) < 1e-3

@@ -229,12 +229,12 @@ def test_losses_forward_backward(dev):
     assert _rel(dpp.grad.transpose(1, 2), lpp.grad) < 1e-5
 
 
-def _train_setup(dev, steps, wseed, over=None, manifest="spec_denoiser"):
+def _train_setup(dev, steps, wseed, over=None, manifest="spec_denoiser", task_cls="SpeechDenoiserTask"):
     from set_amd import hparams as H
     from set_amd import tasks
     H.hparams.clear()
     H.hparams.update(base_hparams(timesteps=steps, **(over or {})))
-    task = tasks.SpeechDenoiserTask(build_vocoder=False)
+    task = getattr(tasks, task_cls)(build_vocoder=False)
     task.build_model()
     W = Wt.seeded_weights(Wt.load_manifest(manifest), wseed)
     task.model.load_state_dict(W, strict=False)
@@ -305,6 +305,46 @@ def test_training_without_pitch_embed_matches_reference(dev):
                                  noises=torch.from_numpy(g["eps"]).to(dev))
     assert sorted(losses) == ["l1_coarse", "pdur", "ssim_coarse", "wdur"]
     for k in losses:
+        ref = float(g["loss_" + k])
+        assert abs(float(losses[k]) - ref) < 2e-5 * max(1.0, abs(ref)), (k, float(losses[k]), ref)
+    with torch.enable_grad():
+        total = sum(losses.values())
+    total.backward()
+    torch.cuda.synchronize()
+    params = dict(task.model.named_parameters())
+    assert list(params) == m["param_names"]
+    worst = 0.0
+    for k, ref in zip(m["param_names"], g["grad_norms"]):
+        p = params[k]
+        if ref < 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        worst = max(worst, abs(float(p.grad.norm()) - ref) / (ref + 1e-12))
+    assert worst < 1e-3, worst
+    for key in [k for k in g if k.startswith("grad::")]:
+        gr = params[key[len("grad::"):]].grad.cpu()
+        ref = torch.from_numpy(g[key])
+        gr = gr[:ref.shape[0]] if gr.shape != ref.shape else gr
+        assert _rel(gr, ref) < 2e-4, key
+
+
+def test_training_normal_variant_matches_reference(dev):
+    """egs/spec_denoiser_wo_masked_predictor.yaml: SpeechDenoiserNormalTask (tasks/speech_editing/spec_denoiser_normal.py)
+    over the plain-FastSpeech conditioner, incl. the reference's positional binding uv -> f0 (spec_denoiser_normal.py:158).
+    Fixture: tests/golden/train_losses_normal.npz (reference model + its own loss functions + autograd)."""
+    g = load_golden("train_losses_normal")
+    m = g["meta"]
+    task, W = _train_setup(dev, m["steps"], m["wseed"], manifest="spec_denoiser_normal",
+                           task_cls="SpeechDenoiserNormalTask")
+    assert "fs.dur_embed.weight" not in task.model.state_dict()
+    inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=True)
+    sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"],
+                  time_mel_masks=inp["time_mel_masks"].squeeze(-1), spk_embed=inp["spk_embed"])
+    sample = {k: v.to(dev) for k, v in sample.items()}
+    losses, out = task.run_model(sample, infer=False, t=torch.from_numpy(g["t"]).to(dev),
+                                 noises=torch.from_numpy(g["eps"]).to(dev))
+    assert int(out["pitch"].max()) == 1 and int(out["pitch"].min()) == 1
+    for k in ("l1_coarse", "ssim_coarse", "pdur", "wdur", "uv", "f0"):
         ref = float(g["loss_" + k])
         assert abs(float(losses[k]) - ref) < 2e-5 * max(1.0, abs(ref)), (k, float(losses[k]), ref)
     with torch.enable_grad():

@@ -13,7 +13,8 @@ TOL = 2e-5
 
 INFER = [("infer_tiny", "spec_denoiser"), ("infer_pad", "spec_denoiser"), ("infer_predpitch", "spec_denoiser"),
          ("infer_dil", "spec_denoiser_dil"), ("infer_c64", "spec_denoiser_c64"), ("infer_drift100", "spec_denoiser"),
-         ("infer_nopitch", "spec_denoiser_nopitch")]  # egs/spec_denoiser_libritts.yaml: use_pitch_embed false
+         ("infer_nopitch", "spec_denoiser_nopitch"),  # egs/spec_denoiser_libritts.yaml: use_pitch_embed false
+         ("infer_normal", "spec_denoiser_normal")]    # egs/spec_denoiser_wo_masked_predictor.yaml
 
 
 def _run_infer(case, manifest):
@@ -26,6 +27,8 @@ def _run_infer(case, manifest):
     flags = dict(m["flags"])
     if not m["overrides"].get("use_pitch_embed", True):
         flags["use_pitch_embed"] = False
+    if m.get("variant", "masked") != "masked":
+        flags["variant"] = m["variant"]
     ret = O.gaussian_diffusion_infer(W, m["steps"], inp, noises, dilation_cycle_length=dcl, **flags)
     return g, ret
 
@@ -37,7 +40,10 @@ def test_oracle_infer_matches_reference(case, manifest):
     assert np.abs(ret["decoder_inp"].numpy() - g["decoder_inp"]).max() < TOL
     assert np.abs(ret["dur"].numpy() - g["dur"]).max() < TOL
     assert np.array_equal(ret["mel2ph"].numpy(), g["mel2ph"])
-    assert np.array_equal(ret["masked_dur"].numpy(), g["masked_dur"])
+    if "masked_dur" in g:  # the plain FastSpeech of the `normal` variant has no masked predictor inputs
+        assert np.array_equal(ret["masked_dur"].numpy(), g["masked_dur"])
+    else:
+        assert "masked_dur" not in ret and int(ret["pitch"].max()) == 1  # uv flags bound to f0: every frame -> bin 1
     if "pitch_pred" not in g:  # no pitch block: the reference's ret dict has none of the pitch keys either
         assert not ({"pitch_pred", "pitch", "f0_denorm"} & set(ret))
         return
@@ -55,7 +61,8 @@ def test_oracle_train_branch():
 
 
 @pytest.mark.parametrize("case,manifest", [("train_losses", "spec_denoiser"),
-                                           ("train_losses_nopitch", "spec_denoiser_nopitch")])
+                                           ("train_losses_nopitch", "spec_denoiser_nopitch"),
+                                           ("train_losses_normal", "spec_denoiser_normal")])
 def test_oracle_training_losses_and_grads(case, manifest):
     """train_losses.npz = reference model + the reference's own loss functions + autograd (oracle/make_golden.py)."""
     g = load_golden(case)
@@ -66,7 +73,8 @@ def test_oracle_training_losses_and_grads(case, manifest):
     inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=True)
     with torch.enable_grad():
         losses, _ = O.training_losses(W, m["steps"], inp, torch.from_numpy(g["t"]), torch.from_numpy(g["eps"]),
-                                      sil_ids=m["sil_ids"], use_pitch_embed=use_pitch)
+                                      sil_ids=m["sil_ids"], use_pitch_embed=use_pitch,
+                                      variant=m.get("variant", "masked"))
         sum(losses.values()).backward()
     for k, v in losses.items():
         assert abs(float(v) - float(g["loss_" + k])) < 1e-5 * max(1.0, abs(float(v))), k
