@@ -340,9 +340,13 @@ int set_gate_bwd(const float *y, const float *dz, float *dy, int32_t B, int32_t 
 /* backward of set_res_skip: dx = dx_out/sqrt2 ; d_o[:, :C] = dx_out/sqrt2 ; d_o[:, C:] = dskip */
 int set_res_skip_bwd(const float *dx_out, const float *dskip, float *dx, float *d_o, int32_t B, int32_t C, int32_t T,
                      void *stream);
-/* backward of set_layernorm_ch; dgamma/dbeta are accumulated (+=) */
+/* backward of set_layernorm_ch; dgamma/dbeta are accumulated (+=).  `partial`: scratch of
+ * set_layernorm_ch_bwd_scratch(B, C, T) floats (contents irrelevant) for a contention-free two-pass reduction of
+ * dgamma/dbeta; NULL falls back to one atomic per (block, channel), which serialises across XCDs. */
+int64_t set_layernorm_ch_bwd_scratch(int32_t B, int32_t C, int32_t T);
 int set_layernorm_ch_bwd(const float *x, const float *gamma, const float *mask, const float *dy, float *dx,
-                         float *dgamma, float *dbeta, int32_t B, int32_t C, int32_t T, float eps, void *stream);
+                         float *dgamma, float *dbeta, float *partial, int32_t B, int32_t C, int32_t T, float eps,
+                         void *stream);
 /* dtable[idx[b][t]][c] += scale * dout[b][c][t], except for row `padding_idx` (-1: none), whose gradient stays 0
  * as with nn.Embedding(padding_idx=...) (modules/commons/layers.py:45-50) */
 int set_embedding_bwd(const int64_t *idx, const float *dout, float *dtable, int32_t B, int32_t T, int32_t C,

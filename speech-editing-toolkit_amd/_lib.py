@@ -160,7 +160,8 @@ SIGNATURES = {
     "set_act_bwd": (C.c_int, [_V, _V, _V, _I64, _I32, _F, _V]),
     "set_gate_bwd": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _V]),
     "set_res_skip_bwd": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _V]),
-    "set_layernorm_ch_bwd": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _I32, _I32, _I32, _F, _V]),
+    "set_layernorm_ch_bwd": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _V, _I32, _I32, _I32, _F, _V]),
+    "set_layernorm_ch_bwd_scratch": (C.c_int64, [_I32, _I32, _I32]),
     "set_embedding_bwd": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _I32, _F, _I32, _V]),
     "set_expand_states_bwd": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _I32, _V]),
     "set_dropout": (C.c_int, [_V, _V, _I64, _F, _U64, _U64, _V]),

@@ -28,8 +28,47 @@ length_regulate = ops.length_regulate
 L = _lib.lib
 
 
+class _ZeroArena:
+    """Zero-initialised gradient temporaries (split-K wgrad targets, bias sums, scatter-add targets) of one training
+    step come out of ONE buffer cleared by ONE memset, instead of ~300 separate small fills per step (each a launch
+    of a few microseconds on the critical stream).  Opened by FlatAdamW.zero_grad() and closed by FlatAdamW.step():
+    only then is it safe, because the optimizer owns every .grad (views of its flat buffer), so autograd ADDS these
+    temporaries into .grad and nothing keeps a reference past the step.  Outside such a step `_gzeros` is torch.zeros.
+    Capacity follows the demand of the previous step."""
+    buf, off, need, active = None, 0, 0, False
+
+
+def zero_arena_begin(device, min_floats=0):
+    a = _ZeroArena
+    want = max(int(min_floats), int(a.need * 1.05) + 4096)
+    if a.buf is None or a.buf.device != device or a.buf.numel() < want:
+        a.buf = torch.empty(want, dtype=torch.float32, device=device)
+    a.buf.zero_()
+    a.off, a.need, a.active = 0, 0, True
+
+
+def zero_arena_end():
+    _ZeroArena.active = False
+
+
+def _gzeros(shape, device):
+    a = _ZeroArena
+    shape = tuple(int(d) for d in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
+    n = 1
+    for d in shape:
+        n *= d
+    if a.active and a.buf.device == device:
+        step = (n + 63) // 64 * 64  # 256-byte aligned slices
+        a.need += step
+        if a.off + step <= a.buf.numel():
+            t = a.buf[a.off:a.off + n].view(shape)
+            a.off += step
+            return t
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 def _zeros_like(t):
-    return torch.zeros_like(t, memory_format=torch.contiguous_format)
+    return _gzeros(t.shape, t.device)
 
 
 def _wgrad_impl(T):
@@ -81,11 +120,11 @@ class _Conv1dFn(torch.autograd.Function):
             w = cw.raw()
             # plain [Cout,Cin,K] rows, possibly a row slice of a larger parameter (packed q/k/v projections)
             assert cw.stap == 1 and cw.sci == cw.K and cw.sco == cw.Cin * cw.K, "plain conv layout"
-            dw = torch.zeros(w.shape, dtype=torch.float32, device=dy.device)
+            dw = _gzeros(w.shape, dy.device)
             check(L().set_conv1d_wgrad(_p(g), _p(x), _p(chan_add), dw.data_ptr() + 4 * cw.base, B, Cin, Cout, cw.K, dil, pad, T, T_in, PRO[pro],
                                        float(pro_param), _wgrad_impl(T), _stream()), "set_conv1d_wgrad")
         if has_bias and ctx.needs_input_grad[2]:
-            db = torch.zeros(Cout, dtype=torch.float32, device=dy.device)
+            db = _gzeros(Cout, dy.device)
             check(L().set_channel_sum(_p(g), _p(db), B, Cout, T, _stream()), "set_channel_sum")
         return (dx if ctx.needs_input_grad[0] else None, dw, db, dadd, dres, None, None, None, None, None, None, None,
                 None, None, None)
@@ -150,9 +189,10 @@ class _LayerNormChFn(torch.autograd.Function):
         dy = dy.contiguous()
         B, Cc, T = x.shape
         dx = torch.empty_like(x)
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(gamma)
-        check(L().set_layernorm_ch_bwd(_p(x), _p(gamma), _p(mask), _p(dy), _p(dx), _p(dg), _p(db), B, Cc, T,
+        dg = _zeros_like(gamma)
+        db = _zeros_like(gamma)
+        part = torch.empty(L().set_layernorm_ch_bwd_scratch(B, Cc, T), dtype=torch.float32, device=x.device)
+        check(L().set_layernorm_ch_bwd(_p(x), _p(gamma), _p(mask), _p(dy), _p(dx), _p(dg), _p(db), _p(part), B, Cc, T,
                                        float(ctx.eps), _stream()), "set_layernorm_ch_bwd")
         return dx, dg, db, None, None
 
@@ -181,7 +221,7 @@ class _EmbeddingFn(torch.autograd.Function):
         (n_rows, Cc), scale, has_base = ctx.cfg
         dout = dout.contiguous()
         B, T = idx.shape
-        dtab = torch.zeros(n_rows, Cc, dtype=torch.float32, device=dout.device)
+        dtab = _gzeros((n_rows, Cc), dout.device)
         check(L().set_embedding_bwd(_p(idx), _p(dout), _p(dtab), B, T, Cc, n_rows, float(scale), ctx.padding_idx,
                                     _stream()), "set_embedding_bwd")
         return None, dtab, (dout if has_base else None), None, None
@@ -204,7 +244,7 @@ class _ExpandStatesFn(torch.autograd.Function):
         (mel2ph,) = ctx.saved_tensors
         B, Cc, T_txt = ctx.shape
         dout = dout.contiguous()
-        denc = torch.zeros(B, Cc, T_txt, dtype=torch.float32, device=dout.device)
+        denc = _gzeros((B, Cc, T_txt), dout.device)
         check(L().set_expand_states_bwd(_p(mel2ph), _p(dout), _p(denc), B, Cc, T_txt, mel2ph.shape[1], _stream()),
               "set_expand_states_bwd")
         return denc, None
@@ -416,9 +456,9 @@ class _DiffNetStackFn(torch.autograd.Function):
         layers = list(dn.residual_layers)
         dskip = dskip.contiguous()
         need_cond = ctx.needs_input_grad[2]
-        dcond = torch.zeros_like(cond) if need_cond else None
+        dcond = _zeros_like(cond) if need_cond else None
         dd = torch.empty(B, L_ * C_, dtype=torch.float32, device=dev)
-        dx = torch.zeros(B, C_, T, dtype=torch.float32, device=dev)  # the last layer's x output feeds nothing
+        dx = _gzeros((B, C_, T), dev)  # the last layer's x output feeds nothing
         grads = []
         impl_w = _wgrad_impl(T)
         for l in range(L_ - 1, -1, -1):
@@ -428,27 +468,27 @@ class _DiffNetStackFn(torch.autograd.Function):
             d_o = torch.empty(B, 2 * C_, T, dtype=torch.float32, device=dev)
             check(L().set_res_skip_bwd(_p(dx), _p(dskip), _p(dxr), _p(d_o), B, C_, T, _stream()), "set_res_skip_bwd")
             # output_projection (1x1, 256 -> 512)
-            dw_out = torch.zeros_like(layer.output_projection.weight)
+            dw_out = _zeros_like(layer.output_projection.weight)
             check(L().set_conv1d_wgrad(_p(d_o), _p(z_all[l]), None, _p(dw_out), B, C_, 2 * C_, 1, 1, 0, T, T, 0, 0.0, impl_w,
                                        _stream()), "set_conv1d_wgrad")
-            db_out = torch.zeros(2 * C_, dtype=torch.float32, device=dev)
+            db_out = _gzeros(2 * C_, dev)
             check(L().set_channel_sum(_p(d_o), _p(db_out), B, 2 * C_, T, _stream()), "set_channel_sum")
             dz = ops.conv1d(d_o, layer._w_out.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T)
             # gate
             dy = torch.empty(B, 2 * C_, T, dtype=torch.float32, device=dev)
             check(L().set_gate_bwd(_p(y_all[l]), _p(dz), _p(dy), B, C_, T, _stream()), "set_gate_bwd")
             # conditioner_projection (1x1, H -> 512): y = ... + W_cond cond + b_cond
-            dw_cond = torch.zeros_like(layer.conditioner_projection.weight)
+            dw_cond = _zeros_like(layer.conditioner_projection.weight)
             check(L().set_conv1d_wgrad(_p(dy), _p(cond), None, _p(dw_cond), B, H, 2 * C_, 1, 1, 0, T, T, 0, 0.0, impl_w,
                                        _stream()), "set_conv1d_wgrad")
-            db = torch.zeros(2 * C_, dtype=torch.float32, device=dev)
+            db = _gzeros(2 * C_, dev)
             check(L().set_channel_sum(_p(dy), _p(db), B, 2 * C_, T, _stream()), "set_channel_sum")  # = db_cond = db_dil
             if need_cond:
                 ops.conv1d(dy, layer._w_cond.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T, out=dcond,
                            accumulate=True)
             # dilated conv (k=3) on x_l + d_l
             dl = dmat[:, l * C_:(l + 1) * C_].contiguous()
-            dw_dil = torch.zeros_like(layer.dilated_conv.weight)
+            dw_dil = _zeros_like(layer.dilated_conv.weight)
             check(L().set_conv1d_wgrad(_p(dy), _p(x_all[l]), _p(dl), _p(dw_dil), B, C_, 2 * C_, 3, dil, dil, T, T, 0, 0.0,
                                        impl_w, _stream()), "set_conv1d_wgrad")
             dxd = ops.conv1d(dy, layer._w_dil.transposed(), None, dil=-dil, pad=-dil, T_iter=T, T_out=T)
@@ -574,7 +614,7 @@ class _MaskFillChanFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d):
         (m,) = ctx.saved_tensors
-        de = torch.zeros(ctx.C, dtype=torch.float32, device=d.device)
+        de = _gzeros(ctx.C, d.device)
         ops.masked_channel_sum(d.contiguous(), m, de)
         return None, de.reshape(1, 1, -1), None
 

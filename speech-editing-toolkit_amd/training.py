@@ -46,6 +46,7 @@ class FlatAdamW:
 
     def zero_grad(self):
         self.flat_g.zero_()
+        A.zero_arena_begin(self.flat_g.device, self.n)  # this step's zero-initialised gradient temporaries
         self.bucketer.reset()
         for p in self.params:  # autograd may have re-pointed .grad; restore the views
             if p.grad is None or p.grad.data_ptr() < self.flat_g.data_ptr() or \
@@ -56,6 +57,7 @@ class FlatAdamW:
         """gradient all-reduce (SUM, few large buckets, launched from autograd hooks while backward was still running;
         whatever is left goes now) -> clip_grad_norm_(max_norm) + AdamW on the mean gradient, then the warm-up
         schedule (base_task.py:129-137)."""
+        A.zero_arena_end()
         world = self.bucketer.finish()
         sumsq = A.grad_sumsq(self.flat_g) if self.clip > 0 else None
         lr = self.lr_at(self.num_updates)

@@ -102,6 +102,14 @@ def test_small_op_backwards(dev):
         A.layernorm_ch(dv[0], dv[1], dv[2], mask.to(dev)).backward(gy.to(dev))
     for a, r in zip(dv, lv):
         assert _rel(a.grad, r.grad) < 2e-5
+    # the same entry point without scratch (partial = NULL): per-block atomics, and dgamma/dbeta are accumulated (+=)
+    from set_amd import _lib
+    from set_amd.ops import _p, _stream
+    xd, gd, md, gyd = x.to(dev), gam.to(dev), mask.to(dev), gy.to(dev)
+    dx2, dg2, db2 = torch.empty_like(xd), torch.ones(C, device=dev), torch.full((C,), 2.0, device=dev)
+    _lib.check(_lib.lib().set_layernorm_ch_bwd(_p(xd), _p(gd), _p(md), _p(gyd), _p(dx2), _p(dg2), _p(db2), None, B, C, T,
+                                               1e-5, _stream()), "set_layernorm_ch_bwd")
+    assert _rel(dx2, lv[0].grad) < 2e-5 and _rel(dg2 - 1.0, lv[1].grad) < 2e-5 and _rel(db2 - 2.0, lv[2].grad) < 2e-5
     # embedding (+ base), expand_states, add_chan_mask, transposes
     idx = torch.randint(0, 50, (B, T), generator=g)
     tab = torch.randn(50, C, generator=g)

@@ -26,3 +26,39 @@ dt = (time.perf_counter() - t0) / n
 flop = 2 * 307052544 * B * T
 print("HiFi-GAN V1 B=%d T=%d: %.1f ms/forward, %.0f mel-frames/s, %.1f TFLOP/s (fp32), wav %s finite=%s" % (
     B, T, dt * 1e3, B * T / dt, flop / dt / 1e12, tuple(wav.shape), bool(torch.isfinite(wav).all())))
+
+# ---- per-stage / per-resblock breakdown (set HSTAGES=1): where the forward time goes and at what MFMA rate
+if os.environ.get("HSTAGES"):
+    from set_amd import ops
+
+    def timed(fn, n=3):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n, out
+
+    x = ops.conv1d(mel, g._pre.conv_weight(), g.conv_pre.bias.data, pad=3)
+    for i in range(g.num_upsamples):
+        cin, cout, k, u, P = g._up_cfg[i]
+        up = g._ups[i]
+        up.folded()
+        ms, x = timed(lambda: ops.conv_transpose1d(x, lambda up=up: up._w, g.ups[i].bias.data, cin, cout, k, u, P,
+                                                    pro="lrelu", pro_param=0.1, cache=up._phases))
+        Tn = x.shape[2]
+        print("stage %d  up %4d->%4d k%-2d s%d  T=%6d : %7.2f ms  %6.1f TF/s" % (
+            i, cin, cout, k, u, Tn, ms, 2.0 * B * cin * cout * k / u * Tn / ms / 1e9))
+        outs = []
+        for j in range(g.num_kernels):
+            rb = g.resblocks[i * g.num_kernels + j]
+            ms, o = timed(lambda: rb.run(x))
+            fl = 2.0 * B * cout * cout * rb.k * Tn * 6
+            print("stage %d  resblock C=%3d k=%-2d dil=%s T=%6d : %7.2f ms  %6.1f TF/s  (%.2f ms/conv)" % (
+                i, cout, rb.k, rb.dil, Tn, ms, fl / ms / 1e9, ms / 6))
+            outs.append(o)
+        ms, x = timed(lambda: ops.sum_div(outs[0], outs[1], outs[2], 3.0))
+        print("stage %d  MRF mean                          : %7.2f ms  %6.0f GB/s" % (i, ms, 4 * x.numel() * 4 / ms / 1e6))
