@@ -79,6 +79,10 @@ __device__ __forceinline__ f32x4 buf_load4(rsrc_t r, unsigned voff, unsigned sof
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
+__device__ __forceinline__ void buf_store4(f32x4 v, rsrc_t r, unsigned voff, unsigned soff) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, 0);
+}
 __device__ __forceinline__ void buf_store(float v, rsrc_t r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }

@@ -3,6 +3,7 @@
 // Replaces every F.conv1d / nn.Linear / nn.ConvTranspose1d (polyphase) call on the hot path -- see
 // include/set_amd.h for the reference citations.
 #include "common.h"
+#include <type_traits>
 
 thread_local char g_set_err[512] = {0};
 
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(256) conv1d_naive_kernel(SetConv1dArgs a) {
 constexpr int KC = 16;  // input channels per LDS chunk (packed images pad Cin to a multiple of this)
 
 template <int WM, int WN>
-__global__ void __launch_bounds__(256) conv1d_mfma_kernel(SetConv1dArgs a, int lo, int halo, int CinP, int RBn) {
+__global__ void __launch_bounds__(256, 4) conv1d_mfma_kernel(SetConv1dArgs a, int lo, int halo, int CinP, int RBn) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BN = 64 * WN;
     const int W = BN + halo;
@@ -150,18 +151,84 @@ __global__ void __launch_bounds__(256) conv1d_mfma_kernel(SetConv1dArgs a, int l
         }
     }
     if (!rb_valid) return;
+    // cheap activations get a specialised batched epilogue; the transcendental ones (tanh on the 1-channel conv_post,
+    // gelu / mish / softplus on small layers) keep the compact per-element path, as does a ragged last row block
+    const bool act_simple = a.act == SET_ACT_NONE || a.act == SET_ACT_RELU || a.act == SET_ACT_LRELU;
+    if (rb * 32 + 32 > a.Cout || !act_simple) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = rb * 32 + mfma32_row(r, lane);
-        if (co >= a.Cout) continue;
+        for (int r = 0; r < 16; ++r) {
+            const int co = rb * 32 + mfma32_row(r, lane);
+            if (co >= a.Cout) continue;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int t = t0 + wn * 64 + cb * 32 + l31;
-            if (t >= a.T_iter) continue;
-            const int n = t * a.out_stride + a.out_off;
-            if (n < 0 || n >= a.T_out) continue;
-            conv_store(a, b, co, n, cb == 0 ? acc0[r] : acc1[r]);
+            for (int cb = 0; cb < 2; ++cb) {
+                const int t = t0 + wn * 64 + cb * 32 + l31;
+                if (t >= a.T_iter) continue;
+                const int n = t * a.out_stride + a.out_off;
+                if (n < 0 || n >= a.T_out) continue;
+                conv_store(a, b, co, n, cb == 0 ? acc0[r] : acc1[r]);
+            }
         }
+        return;
+    }
+    // Full row blocks.  Every optional operand (bias, residual, mask, previous output) is fetched as ONE batch under a
+    // wave-uniform test, on clamped (always valid) addresses, and the activation switch is resolved once per kernel:
+    // the per-element `if (a.res) v += a.res[i]` of conv_store makes hipcc emit a branch + s_waitcnt vmcnt(0) per
+    // load -- ~64 serialized memory round trips per lane, ~33 us of every block's lifetime in the 32/64-channel
+    // HiFi-GAN stages.  Addresses are buffer offsets: one VGPR per column block (the lane's part of the row, 4*half,
+    // and its frame) plus a scalar offset per accumulator register (set_conv1d checks they fit 31 bits).
+    const int lrow = rb * 32 + 4 * half;  // accumulator register r of this lane is row lrow + (r & 3) + 8 * (r >> 2)
+    const rsrc_t d_out = make_rsrc(a.out + (int64_t)b * a.out_bs);
+    unsigned vo[2], vr[2];
+    bool tv[2];
+    float mk[2] = {1.0f, 1.0f};
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int t = t0 + wn * 64 + cb * 32 + l31;
+        const int n = t * a.out_stride + a.out_off;
+        tv[cb] = t < a.T_iter && n >= 0 && n < a.T_out;
+        const int nc = min(max(n, 0), a.T_out - 1);
+        vo[cb] = (unsigned)(lrow * a.out_cs + nc) * 4u;
+        vr[cb] = (unsigned)(lrow * a.res_cs + nc) * 4u;
+        if (a.mask) mk[cb] = a.mask[(int64_t)b * a.T_out + nc];
+    }
+    float bi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bi[r] = 0.0f;
+    if (a.bias) {
+        const rsrc_t d_b = make_rsrc(a.bias);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bi[r] = buf_load(d_b, (unsigned)lrow * 4u, (unsigned)((r & 3) + 8 * (r >> 2)) * 4u);
+    }
+    const rsrc_t d_r = make_rsrc(a.res ? a.res + (int64_t)b * a.res_bs : a.out);
+    // one column block (16 registers) at a time: 16 residual (+16 previous-output) loads in flight, then compute, store
+    auto column = [&](auto ACT, const f32x16 &acc, int cb) __attribute__((always_inline)) {
+        constexpr int kAct = decltype(ACT)::value;
+        float rv[16], ov[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = ov[r] = 0.0f;
+        if (a.res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = buf_load(d_r, vr[cb], (unsigned)(((r & 3) + 8 * (r >> 2)) * a.res_cs) * 4u);
+        }
+        if (a.accumulate) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ov[r] = buf_load(d_out, vo[cb], (unsigned)(((r & 3) + 8 * (r >> 2)) * a.out_cs) * 4u);
+        }
+        if (!tv[cb]) return;  // frames outside the output: lanes masked off (after the loads: no wait inside a branch)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float y = (dev_act((acc[r] + bi[r]) * a.alpha, kAct, a.act_param) + rv[r]) * mk[cb] + ov[r];
+            buf_store(y, d_out, vo[cb], (unsigned)(((r & 3) + 8 * (r >> 2)) * a.out_cs) * 4u);
+        }
+    };
+    auto finish = [&](auto ACT) __attribute__((always_inline)) {
+        column(ACT, acc0, 0);
+        column(ACT, acc1, 1);
+    };
+    switch (a.act) {
+        case SET_ACT_RELU: finish(std::integral_constant<int, SET_ACT_RELU>{}); break;
+        case SET_ACT_LRELU: finish(std::integral_constant<int, SET_ACT_LRELU>{}); break;
+        default: finish(std::integral_constant<int, SET_ACT_NONE>{}); break;
     }
 }
 
@@ -177,7 +244,7 @@ constexpr int V2_GS = 4;     // k-steps per operand group
 constexpr int V2_CH = 256;   // max channels per LDS chunk
 
 template <int RB>
-__global__ void __launch_bounds__(256, 2) conv1d_mfma_v2_kernel(SetConv1dArgs a, int lo, int halo, int CinP, int ch_max) {
+__global__ void __launch_bounds__(256, RB == 1 ? 4 : (RB == 2 ? 3 : 2)) conv1d_mfma_v2_kernel(SetConv1dArgs a, int lo, int halo, int CinP, int ch_max) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef typename AVec<RB>::type avec_t;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -246,7 +313,8 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_v2_kernel(SetConv1dArgs a,
     // cooperative loop applies bias / alpha / act / res / mask with whole-row coalesced global accesses
     // (a fully unrolled per-register epilogue is ~40k instructions here and spills).
     // fast path: 4 consecutive frames per thread (16-byte LDS reads / global loads / stores)
-    const bool vec4 = a.out_stride == 1 && a.out_off == 0 && !a.accumulate && (a.T_out & 3) == 0 && (a.out_cs & 3) == 0 &&
+    const bool act_simple = a.act == SET_ACT_NONE || a.act == SET_ACT_RELU || a.act == SET_ACT_LRELU;
+    const bool vec4 = act_simple && a.out_stride == 1 && a.out_off == 0 && !a.accumulate && (a.T_out & 3) == 0 && (a.out_cs & 3) == 0 &&
                       (a.out_bs & 3) == 0 && (!a.res || ((a.res_cs & 3) == 0 && (a.res_bs & 3) == 0)) &&
                       t0 + 64 <= a.T_iter && a.T_iter <= a.T_out;
     const int col = vec4 ? (tid & 15) * 4 : (tid & 63);
@@ -259,8 +327,36 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_v2_kernel(SetConv1dArgs a,
         if (vec4) msk4 = *reinterpret_cast<const f32x4 *>(a.mask + (int64_t)b * a.T_out + n);
         else msk = a.mask[(int64_t)b * a.T_out + n];
     }
+    // Addresses are buffer offsets (one VGPR for the lane's row / frame part + a scalar offset per row group;
+    // launch_conv_v2 checks they fit 31 bits).  Loads go to clamped, always valid addresses; stores are masked.
+    const rsrc_t d_out = make_rsrc(a.out + (int64_t)b * a.out_bs);
+    const rsrc_t d_res = make_rsrc(a.res ? a.res + (int64_t)b * a.res_bs : a.out);
+    const rsrc_t d_b = make_rsrc(a.bias ? a.bias : a.out);
+    const int q = vec4 ? (tid >> 4) : 0;  // lane part of the row (fast path); the ragged path's rows are wave-uniform
+    const int nc = min(max(n, 0), a.T_out - 1);
+    const bool has_bias = a.bias != nullptr, has_res = a.res != nullptr;
+    // one row-block slice; a generic lambda over a compile-time rb instead of `#pragma unroll for (rb)`: with the
+    // per-activation bodies inside, the optimizer refused to unroll the loop and acc[rb] went to scratch
+    auto slice = [&](auto RBI) __attribute__((always_inline)) {
+        constexpr int rb = decltype(RBI)::value;
+        // fast path: the 8 rows this thread finishes (row = row0(i) + q), bias and residual fetched as one batch each
+        // BEFORE the LDS round trip (a per-row `if (a.res) load` costs one serialized memory round trip per row)
+        f32x4 rv4[8];
+        float bi8[8];
+        if (vec4) {
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
+            for (int i = 0; i < 8; ++i) {
+                const int row0 = g * 128 * RB + (i >> 1) * 32 * RB + rb * 32 + 16 * (i & 1);
+                const int rowc = min(row0 + q, a.Cout - 1);  // == row0 + q for every full 16-row group
+                bi8[i] = 0.0f;
+                rv4[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                if (has_bias) bi8[i] = buf_load(d_b, (unsigned)rowc * 4u, 0u);
+                if (has_res) {
+                    if (row0 + 16 <= a.Cout) rv4[i] = buf_load4(d_res, (unsigned)(q * a.res_cs + nc) * 4u, (unsigned)(row0 * a.res_cs) * 4u);
+                    else rv4[i] = buf_load4(d_res, (unsigned)(rowc * a.res_cs + nc) * 4u, 0u);
+                }
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
@@ -268,30 +364,52 @@ __global__ void __launch_bounds__(256, 2) conv1d_mfma_v2_kernel(SetConv1dArgs a,
             for (int r = 0; r < 16; ++r) smem[(32 * w + mfma32_row(r, lane)) * 64 + cb * 32 + l31] = acc[rb][cb][r];
         __syncthreads();
         if (vec4) {
-            for (int rr = tid >> 4; rr < 128; rr += 16) {
-                const int co = g * 128 * RB + (rr >> 5) * 32 * RB + rb * 32 + (rr & 31);
-                if (co >= a.Cout) continue;
-                f32x4 v = *reinterpret_cast<const f32x4 *>(smem + rr * 64 + col);
-                const float bi = a.bias ? a.bias[co] : 0.0f;
+            auto finish = [&](auto ACT) __attribute__((always_inline)) {
+                constexpr int kAct = decltype(ACT)::value;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = dev_act((v[k] + bi) * a.alpha, a.act, a.act_param);
-                if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + (int64_t)b * a.res_bs + (int64_t)co * a.res_cs + n);
-                v *= msk4;
-                *reinterpret_cast<f32x4 *>(a.out + (int64_t)b * a.out_bs + (int64_t)co * a.out_cs + n) = v;
+                for (int i = 0; i < 8; ++i) {
+                    const int row0 = g * 128 * RB + (i >> 1) * 32 * RB + rb * 32 + 16 * (i & 1);
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(smem + (q + 16 * i) * 64 + col);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = dev_act((v[k] + bi8[i]) * a.alpha, kAct, a.act_param);
+                    if (row0 + q < a.Cout)
+                        buf_store4((v + rv4[i]) * msk4, d_out, (unsigned)(q * a.out_cs + nc) * 4u, (unsigned)(row0 * a.out_cs) * 4u);
+                }
+            };
+            switch (a.act) {
+                case SET_ACT_RELU: finish(std::integral_constant<int, SET_ACT_RELU>{}); break;
+                case SET_ACT_LRELU: finish(std::integral_constant<int, SET_ACT_LRELU>{}); break;
+                default: finish(std::integral_constant<int, SET_ACT_NONE>{}); break;
             }
-        } else if (tvalid) {
-            for (int rr = tid >> 6; rr < 128; rr += 4) {
-                const int co = g * 128 * RB + (rr >> 5) * 32 * RB + rb * 32 + (rr & 31);
-                if (co >= a.Cout) continue;
-                float v = smem[rr * 64 + col];
-                if (a.bias) v += a.bias[co];
-                v = dev_act(v * a.alpha, a.act, a.act_param);
-                if (a.res) v += a.res[(int64_t)b * a.res_bs + (int64_t)co * a.res_cs + n];
-                v *= msk;
-                float *o = a.out + (int64_t)b * a.out_bs + (int64_t)co * a.out_cs + n;
-                *o = a.accumulate ? (*o + v) : v;
+        } else {  // ragged tiles, unaligned shapes, transcendental activations: one frame per thread, the 32 rows of
+                  // this wave in batches of 8 (a real loop: the activation switch is expanded 8 times, not 32)
+#pragma unroll 1
+            for (int i0 = 0; i0 < 32; i0 += 8) {
+                float bi[8], rv[8], ov[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int rr = w + 4 * (i0 + i);
+                    const int coc = min(g * 128 * RB + (rr >> 5) * 32 * RB + rb * 32 + (rr & 31), a.Cout - 1);  // uniform
+                    bi[i] = rv[i] = ov[i] = 0.0f;
+                    if (has_bias) bi[i] = buf_load(d_b, 0u, (unsigned)coc * 4u);
+                    if (has_res) rv[i] = buf_load(d_res, (unsigned)nc * 4u, (unsigned)(coc * a.res_cs) * 4u);
+                    if (a.accumulate) ov[i] = buf_load(d_out, (unsigned)nc * 4u, (unsigned)(coc * a.out_cs) * 4u);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int rr = w + 4 * (i0 + i);
+                    const int co = g * 128 * RB + (rr >> 5) * 32 * RB + rb * 32 + (rr & 31);
+                    float v = dev_act((smem[rr * 64 + col] + bi[i]) * a.alpha, a.act, a.act_param);
+                    if (co < a.Cout && tvalid) buf_store((v + rv[i]) * msk + ov[i], d_out, (unsigned)nc * 4u, (unsigned)(co * a.out_cs) * 4u);
+                }
             }
         }
+    };
+    slice(std::integral_constant<int, 0>{});
+    if constexpr (RB > 1) slice(std::integral_constant<int, 1>{});
+    if constexpr (RB > 2) {
+        slice(std::integral_constant<int, 2>{});
+        slice(std::integral_constant<int, 3>{});
     }
 }
 
@@ -350,12 +468,20 @@ extern "C" int set_pack_conv_weight_v2(const float *w, float *wp, int32_t Cout, 
     return set_check_launch("set_pack_conv_weight_v2");
 }
 
+// the epilogues address out / res with 32-bit byte offsets relative to the batch slice
+static inline bool epilogue_offsets_fit(const SetConv1dArgs &a, int rows_padded) {
+    const int64_t cs = a.res && a.res_cs > a.out_cs ? a.res_cs : a.out_cs;
+    return ((int64_t)rows_padded * cs + a.T_out) * 4 < ((int64_t)1 << 31);
+}
+
 static int launch_conv_v2(const SetConv1dArgs &a, hipStream_t s) {
     const int o_first = -a.pad, o_last = (a.K - 1) * a.dil - a.pad;
     const int lo = o_first < o_last ? o_first : o_last;
     const int halo = (o_first < o_last ? o_last : o_first) - lo;
     if (halo > 64) return set_fail(SET_E_UNSUPPORTED, "set_conv1d(mfma2)", "receptive field > 64");
     const int RB = v2_rb(a.Cout);
+    if (!epilogue_offsets_fit(a, round_up(a.Cout, 128 * RB)))
+        return set_fail(SET_E_UNSUPPORTED, "set_conv1d(mfma2)", "one batch slice of out / res exceeds 2 GiB");
     const int CinP = round_up(a.Cin, 16);
     const int ch_max = v2_ch_max(halo);
     const int ch = CinP < ch_max ? CinP : ch_max;
@@ -430,6 +556,8 @@ extern "C" int set_conv1d(const SetConv1dArgs *args, void *stream) {
     const int hi = o_first < o_last ? o_last : o_first;
     const int halo = hi - lo;
     if (halo > 512) return set_fail(SET_E_UNSUPPORTED, "set_conv1d(mfma)", "receptive field > 512");
+    if (!epilogue_offsets_fit(a, round_up(a.Cout, 32)))
+        return set_fail(SET_E_UNSUPPORTED, "set_conv1d(mfma)", "one batch slice of out / res exceeds 2 GiB");
     const int CinP = round_up(a.Cin, KC);
     const int RBn = (a.Cout + 31) / 32;
     dim3 block(256);
