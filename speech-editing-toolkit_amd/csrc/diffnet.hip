@@ -1266,6 +1266,13 @@ __global__ void __launch_bounds__(256, 2) diffnet_boundary_kernel(BoundaryArgs a
         });
     }
     const rsrc_t ro = make_rsrc(a.xin_next + (int64_t)b * DC * T);
+    // all 32 bias values first: a bias load placed between the stores cannot be moved across them (b_in may alias
+    // xin_next as far as the compiler knows), which serialises one L2 round trip per store
+    float bin[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bin[i][r] = (a.b_in + 32 * (2 * w + i) + urow16(r))[4 * half];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         if (t0 + 32 * cb + l31 < T) {
@@ -1275,8 +1282,7 @@ __global__ void __launch_bounds__(256, 2) diffnet_boundary_kernel(BoundaryArgs a
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ur = 32 * (2 * w + i) + urow16(r);  // wave-uniform; + 4*half rows in the lane offset
-                    const float bias = (a.b_in + ur)[4 * half];
-                    buf_store(fmaxf(acc[i][0][cb][r] + bias, 0.0f), ro, so, 4u * (unsigned)ur * (unsigned)T);
+                    buf_store(fmaxf(acc[i][0][cb][r] + bin[i][r], 0.0f), ro, so, 4u * (unsigned)ur * (unsigned)T);
                 }
         }
     }
