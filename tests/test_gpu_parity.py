@@ -59,6 +59,13 @@ CONV_CASES = [
     (1, 300, 200, 7, 3, 97, dict(pro="lrelu", pro_param=0.1, res=True)),  # ragged channels, two chunks
     (2, 512, 192, 1, 1, 64, dict()),
     (1, 128, 128, 11, 5, 300, dict(pro="lrelu", pro_param=0.1)),       # halo 50
+    # epilogue paths: batched operands on full row blocks (v1), 4-frame vectors with a partial 16-row group and a
+    # ragged tail tile (v2), previous-output accumulation, leaky-ReLU epilogue
+    (2, 96, 96, 3, 1, 256, dict(res=True, mask=True, act="relu")),
+    (2, 200, 200, 3, 1, 192, dict(res=True, act="relu")),
+    (2, 128, 128, 3, 1, 260, dict(res=True, mask=True, accumulate=True)),
+    (1, 32, 32, 7, 1, 1000, dict(res=True, accumulate=True, act="lrelu", act_param=0.2)),
+    (2, 64, 64, 3, 3, 300, dict(pro="lrelu", pro_param=0.1, res=True, mask=True, alpha=0.5)),
 ]
 
 
@@ -76,7 +83,7 @@ def _conv_ref(x, w, b, K, dil, ex, res, mask, add, prev):
     y = y * ex.get("alpha", 1.0)
     act = ex.get("act", "none")
     y = {"none": lambda v: v, "relu": F.relu, "gelu": F.gelu, "tanh": torch.tanh, "softplus": F.softplus,
-         "mish": O.mish}[act](y)
+         "mish": O.mish, "lrelu": lambda v: F.leaky_relu(v, ex.get("act_param", 0.0))}[act](y)
     if res is not None:
         y = y + res
     if mask is not None:
@@ -103,7 +110,7 @@ def test_conv1d_vs_torch(dev, impl, case):
     wd = w.to(dev)
     cw = ops.ConvWeight(lambda: wd, Cout, Cin, K)
     out = prev.clone().to(dev) if prev is not None else None
-    kw = {k: ex[k] for k in ("pro", "pro_param", "act", "alpha") if k in ex}
+    kw = {k: ex[k] for k in ("pro", "pro_param", "act", "act_param", "alpha") if k in ex}
     y = ops.conv1d(x.to(dev), cw, b.to(dev), dil=dil, pad=dil * (K - 1) // 2, res=None if res is None else res.to(dev),
                    mask=None if mask is None else mask.to(dev), in_chan_add=None if add is None else add.to(dev),
                    out=out, accumulate=prev is not None, impl=impl, **kw)
