@@ -8,9 +8,12 @@ from set_amd import ops
 torch.set_grad_enabled(False)
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
-for (B, Cin, Cout, K, dil, T) in [(32, 256, 512, 3, 1, 800), (32, 512, 256, 3, -1, 800), (32, 256, 512, 1, 1, 800),
-                                  (32, 512, 256, 1, 1, 800), (32, 192, 512, 1, 1, 800), (32, 512, 192, 1, 1, 800),
-                                  (32, 80, 256, 1, 1, 800), (16, 256, 256, 7, 3, 6400), (16, 32, 32, 11, 5, 51200)]:
+SHAPES = [(32, 256, 512, 3, 1, 800), (32, 512, 256, 3, -1, 800), (32, 256, 512, 1, 1, 800), (32, 512, 256, 1, 1, 800),
+          (32, 192, 512, 1, 1, 800), (32, 512, 192, 1, 1, 800), (32, 80, 256, 1, 1, 800), (32, 192, 192, 5, 1, 800),
+          (32, 192, 192, 5, 1, 100), (32, 192, 384, 9, 1, 800), (16, 256, 256, 1, 1, 800), (16, 256, 1024, 9, 1, 800),
+          (16, 256, 256, 3, 1, 6400), (16, 256, 256, 7, 3, 6400), (16, 256, 256, 11, 5, 6400),
+          (16, 128, 128, 3, 1, 51200), (16, 128, 128, 7, 1, 51200), (16, 128, 128, 11, 1, 51200)]
+for (B, Cin, Cout, K, dil, T) in SHAPES:
     x = torch.randn(B, Cin, T, generator=g).to(dev)
     w = (torch.randn(Cout, Cin, K, generator=g) / math.sqrt(Cin * K)).to(dev)
     b = torch.zeros(Cout, device=dev)
