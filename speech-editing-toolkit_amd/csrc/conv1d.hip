@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256, 4) conv1d_mfma_kernel(SetConv1dArgs a, in
             }
         }
     };
-    auto commit = [&](int c0, int jj0) {
+    auto commit = [&](int boff, int c0, int jj0) {  // boff: LDS float offset of the destination buffer
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int row = wave + 4 * k;
@@ -115,39 +115,54 @@ __global__ void __launch_bounds__(256, 4) conv1d_mfma_kernel(SetConv1dArgs a, in
                 const int j = (jj0 + u) * 64 + lane;
                 const int ti = t0 + lo + j;
                 const float x = has_add ? pv[k][u] + pa[k] : pv[k][u];
-                if (j < W) smem[row * W + j] = (cok && ti >= 0 && ti < a.T_in) ? dev_pro(x, a.pro, a.pro_param) : 0.0f;
+                if (j < W) smem[boff + row * W + j] = (cok && ti >= 0 && ti < a.T_in) ? dev_pro(x, a.pro, a.pro_param) : 0.0f;
+            }
+        }
+    };
+    auto mfmas = [&](int boff, int c0) {  // offsets, not pointers: a selected pointer loses its LDS address space
+        for (int tap = 0; tap < a.K; ++tap) {
+            const int off = tap * a.dil - a.pad - lo;  // >= 0
+            const float *ap = a.w + (((int64_t)rb * a.K + tap) * cp_total + (c0 >> 1)) * 64 + lane;
+            const float *bp = smem + boff + half * W + wn * 64 + l31 + off;
+#pragma unroll
+            for (int cp = 0; cp < KC / 2; ++cp) {
+                const float av = ap[cp * 64];
+                const float b0 = bp[(2 * cp) * W];
+                const float b1 = bp[(2 * cp) * W + 32];
+                acc0 = mfma32(av, b0, acc0);
+                acc1 = mfma32(av, b1, acc1);
             }
         }
     };
     const bool piped = nj <= NJP;
-    if (piped) issue(0, 0);
-
-    for (int c0 = 0; c0 < CinP; c0 += KC) {
-        __syncthreads();  // previous chunk fully consumed
-        if (piped) {
-            commit(c0, 0);
-        } else {
+    if (piped) {
+        // two LDS buffers, ONE barrier per chunk: while a wave runs the MFMAs of chunk i out of buffer i & 1, the loads of
+        // chunk i + 1 are in flight; it then writes them to the other buffer (last read one barrier ago) and issues
+        // the loads of chunk i + 2.  1x1 and 3-tap convs have only 16 - 48 MFMAs per chunk, so the second barrier and
+        // the exposed LDS write were a visible share of the loop.
+        const int bsz = KC * W;
+        issue(0, 0);
+        commit(0, 0, 0);
+        if (KC < CinP) issue(KC, 0);
+        __syncthreads();
+        int cur = 0;
+        for (int c0 = 0; c0 < CinP; c0 += KC, cur = bsz - cur) {
+            if (rb_valid) mfmas(cur, c0);
+            if (c0 + KC < CinP) {
+                commit(bsz - cur, c0 + KC, 0);
+                if (c0 + 2 * KC < CinP) issue(c0 + 2 * KC, 0);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int c0 = 0; c0 < CinP; c0 += KC) {
+            __syncthreads();  // previous chunk fully consumed
             for (int jj0 = 0; jj0 < nj; jj0 += NJP) {
                 issue(c0, jj0);
-                commit(c0, jj0);
+                commit(0, c0, jj0);
             }
-        }
-        __syncthreads();
-        if (piped && c0 + KC < CinP) issue(c0 + KC, 0);
-        if (rb_valid) {
-            for (int tap = 0; tap < a.K; ++tap) {
-                const int off = tap * a.dil - a.pad - lo;  // >= 0
-                const float *ap = a.w + (((int64_t)rb * a.K + tap) * cp_total + (c0 >> 1)) * 64 + lane;
-                const float *bp = smem + half * W + wn * 64 + l31 + off;
-#pragma unroll
-                for (int cp = 0; cp < KC / 2; ++cp) {
-                    const float av = ap[cp * 64];
-                    const float b0 = bp[(2 * cp) * W];
-                    const float b1 = bp[(2 * cp) * W + 32];
-                    acc0 = mfma32(av, b0, acc0);
-                    acc1 = mfma32(av, b1, acc1);
-                }
-            }
+            __syncthreads();
+            if (rb_valid) mfmas(0, c0);
         }
     }
     if (!rb_valid) return;
@@ -564,17 +579,17 @@ extern "C" int set_conv1d(const SetConv1dArgs *args, void *stream) {
     if (RBn >= 4) {
         constexpr int WM = 4, WN = 1;
         dim3 grid((a.T_iter + 64 * WN - 1) / (64 * WN), (RBn + WM - 1) / WM, a.B);
-        const size_t lds = (size_t)KC * (64 * WN + halo) * sizeof(float);
+        const size_t lds = (size_t)KC * (64 * WN + halo) * sizeof(float) * (halo <= 64 ? 2 : 1);  // two buffers when piped
         hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN>), grid, block, lds, s, a, lo, halo, CinP, RBn);
     } else if (RBn >= 2) {
         constexpr int WM = 2, WN = 2;
         dim3 grid((a.T_iter + 64 * WN - 1) / (64 * WN), (RBn + WM - 1) / WM, a.B);
-        const size_t lds = (size_t)KC * (64 * WN + halo) * sizeof(float);
+        const size_t lds = (size_t)KC * (64 * WN + halo) * sizeof(float) * (halo <= 64 ? 2 : 1);  // two buffers when piped
         hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN>), grid, block, lds, s, a, lo, halo, CinP, RBn);
     } else {
         constexpr int WM = 1, WN = 4;
         dim3 grid((a.T_iter + 64 * WN - 1) / (64 * WN), (RBn + WM - 1) / WM, a.B);
-        const size_t lds = (size_t)KC * (64 * WN + halo) * sizeof(float);
+        const size_t lds = (size_t)KC * (64 * WN + halo) * sizeof(float) * (halo <= 64 ? 2 : 1);  // two buffers when piped
         hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN>), grid, block, lds, s, a, lo, halo, CinP, RBn);
     }
     return set_check_launch("set_conv1d(mfma)");

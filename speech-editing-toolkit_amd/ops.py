@@ -134,11 +134,12 @@ def _pick_impl(impl, T_iter, Cout=0, Cin=0, K=1, dil=1):
     if impl == "auto":
         if T_iter < 16:
             return "naive"
-        # big-tile kernel: measured (tools/conv_probe.py, profiles/r01_conv_probe.log) +5-7 % when the reduction is
-        # deep (512 -> 256 / 192: the input-gradient convs of the DiffNet layers) on short sequences; the small-tile
-        # kernel is equal or better everywhere else since its epilogue fetches its operands in batches (256 -> 512 k3
-        # +4 %, 192 -> 192 k5 +7 %, 192 -> 384 k9 +40 %) and balances better on long sequences (HiFi-GAN)
-        if Cout >= 192 and Cin >= 384 and 32 <= T_iter <= 2048 and (K - 1) * abs(dil) <= 16:
+        # big-tile kernel: measured (tools/conv_probe.py, profiles/r01_conv_probe.log) +2 % for the 3-tap convs with a
+        # deep reduction (512 -> 256: the input-gradient convs of the DiffNet layers) on short sequences; the small-tile
+        # kernel is equal or better everywhere else since its epilogue fetches its operands in batches and its main loop
+        # is double-buffered (1x1 convs +3-12 %, 192 -> 192 k5 +10 %, 192 -> 384 k9 +45 %), and it balances better on
+        # long sequences (HiFi-GAN)
+        if Cout >= 192 and Cin >= 384 and K >= 3 and 32 <= T_iter <= 2048 and (K - 1) * abs(dil) <= 16:
             return "mfma2"
         return "mfma"
     return impl
