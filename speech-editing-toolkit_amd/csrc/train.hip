@@ -26,8 +26,8 @@ struct WgradArgs {
 };
 
 __global__ void __launch_bounds__(256) conv1d_wgrad_mfma_kernel(WgradArgs a) {
-    __shared__ float Gs[128 * WG_LD];
-    __shared__ float Xs[64 * WG_LD];
+    __shared__ float Gs[2 * 128 * WG_LD];  // two buffers each: one barrier per chunk (see the loop below)
+    __shared__ float Xs[2 * 64 * WG_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -64,30 +64,40 @@ __global__ void __launch_bounds__(256) conv1d_wgrad_mfma_kernel(WgradArgs a) {
             av[j] = has_add ? ad : 0.0f;
         }
     };
-    auto commit = [&](int ch) {
+    auto commit = [&](int buf, int ch) {  // buf 0/1 -> integer offsets (a selected pointer would lose its LDS address space)
+        const int go = buf * 128 * WG_LD, xo = buf * 64 * WG_LD;
         const int t0 = (ch % a.n_chunks_t) * WG_KC;
         const int t = t0 + sk, ti = t + shift;
         const bool tv = t < a.T, tiv = tv && ti >= 0 && ti < a.T_in;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) Gs[(sr0 + 8 * j) * WG_LD + sk] = (tv && co0 + sr0 + 8 * j < a.Cout) ? gv[j] : 0.0f;
+        for (int j = 0; j < 16; ++j) Gs[go + (sr0 + 8 * j) * WG_LD + sk] = (tv && co0 + sr0 + 8 * j < a.Cout) ? gv[j] : 0.0f;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            Xs[(sr0 + 8 * j) * WG_LD + sk] = (tiv && ci0 + sr0 + 8 * j < a.Cin) ? dev_pro(xv[j] + av[j], a.pro, a.pro_param) : 0.0f;
+            Xs[xo + (sr0 + 8 * j) * WG_LD + sk] = (tiv && ci0 + sr0 + 8 * j < a.Cin) ? dev_pro(xv[j] + av[j], a.pro, a.pro_param) : 0.0f;
     };
-    if (c_begin < c_end) issue(c_begin);
-    for (int ch = c_begin; ch < c_end; ++ch) {
-        __syncthreads();
-        commit(ch);
-        __syncthreads();
-        if (ch + 1 < c_end) issue(ch + 1);
-        const float *ap = Gs + (32 * w + l31) * WG_LD + half;
-        const float *bp = Xs + l31 * WG_LD + half;
+    // while a wave runs the MFMAs of chunk c out of buffer c & 1 the loads of chunk c + 1 are in flight; it then writes
+    // them to the other buffer (last read one barrier ago) and issues the loads of chunk c + 2
+    if (c_begin < c_end) {
+        issue(c_begin);
+        commit(0, c_begin);
+        if (c_begin + 1 < c_end) issue(c_begin + 1);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int ch = c_begin; ch < c_end; ++ch, cur ^= 1) {
+        const float *ap = Gs + cur * 128 * WG_LD + (32 * w + l31) * WG_LD + half;
+        const float *bp = Xs + cur * 64 * WG_LD + l31 * WG_LD + half;
 #pragma unroll
         for (int kk = 0; kk < WG_KC; kk += 2) {
             const float av = ap[kk];
             acc0 = mfma32(av, bp[kk], acc0);
             acc1 = mfma32(av, bp[32 * WG_LD + kk], acc1);
         }
+        if (ch + 1 < c_end) {
+            commit(cur ^ 1, ch + 1);
+            if (ch + 2 < c_end) issue(ch + 2);
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
