@@ -226,36 +226,98 @@ __global__ void __launch_bounds__(256) res_skip_bwd_kernel(const float *dx_out, 
     ob[(int64_t)C * T + ct] = dskip[i];
 }
 
-// ---- LayerNorm over channels, backward: block = 64 frames x 4 channel groups (one wave per group), column sums
-//      through LDS; dgamma/dbeta: wave reduce over the 64 frames, then one row of per-block partial sums
-//      (`partial[blk][2][C]`, reduced by lnb_partial_sum_kernel) -- or, without scratch, one atomic per (block,
-//      channel): every block hits the same 2C addresses, and same-address device-scope atomics from different XCDs
-//      serialise at ~0.7 us each (measured: 416 blocks -> 280 us for 80 MB of traffic), hence the scratch path.
-__device__ __forceinline__ float lnb_block_sum(float v, float (*red)[64], int cg, int tl) {
+// ---- LayerNorm over channels, backward: block = 32 frames x 8 channel groups (as the forward kernel), column sums
+//      through LDS; x and dy of the thread's <= 32 channels are fetched once as two batches and stay in registers for
+//      all four passes (C <= 256; wider inputs re-read).  dgamma/dbeta: reduce over the 32 frames of the group inside
+//      the wave, then one row of per-block partial sums (`partial[blk][2][C]`, reduced by lnb_partial_sum_kernel) --
+//      or, without scratch, one atomic per (block, channel): every block hits the same 2C addresses, and same-address
+//      device-scope atomics from different XCDs serialise at ~0.7 us each (measured: 416 blocks -> 280 us for 80 MB
+//      of traffic), hence the scratch path.
+constexpr int LNB_FT = 32, LNB_CG = 8, LNB_RC = 32;
+__device__ __forceinline__ float lnb_block_sum(float v, float (*red)[LNB_FT], int cg, int tl) {
     __syncthreads();
     red[cg][tl] = v;
     __syncthreads();
-    return red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
+    float s = 0.0f;
+#pragma unroll
+    for (int g = 0; g < LNB_CG; ++g) s += red[g][tl];
+    return s;
+}
+__device__ __forceinline__ void lnb_emit(float dg, float db, int c, int tl, float *dgamma, float *dbeta, float *partial,
+                                         int C) {
+    // sum over the 32 frames of this channel group (half a wave: xor offsets stay inside the half)
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) { dg += __shfl_xor(dg, off); db += __shfl_xor(db, off); }
+    if (tl == 0) {
+        if (partial) {
+            float *row = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
+            row[c] = dg;
+            row[C + c] = db;
+        } else {
+            atomicAdd(&dgamma[c], dg);
+            atomicAdd(&dbeta[c], db);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, const float *gamma, const float *mask,
                                                                const float *dy, float *dx, float *dgamma, float *dbeta,
                                                                float *partial, int B, int C, int T, float eps) {
-    __shared__ float red[4][64];
-    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    const int b = blockIdx.y, t = blockIdx.x * 64 + tl;
+    __shared__ float red[LNB_CG][LNB_FT];
+    const int tl = threadIdx.x % LNB_FT, cg = threadIdx.x / LNB_FT;
+    const int b = blockIdx.y, t = blockIdx.x * LNB_FT + tl;
     const bool valid = t < T;
     const int tc = valid ? t : T - 1;
-    const int cq = (C + 3) / 4, c0 = cg * cq, c1 = min(C, c0 + cq);
+    const int cq = (C + LNB_CG - 1) / LNB_CG, c0 = cg * cq, c1 = min(C, c0 + cq);
     const float *xp = x + (int64_t)b * C * T + tc;
     const float *dp = dy + (int64_t)b * C * T + tc;
+    float *op = dx + (int64_t)b * C * T + tc;
+    const float m = !valid ? 0.0f : (mask ? mask[(int64_t)b * T + t] : 1.0f);  // m == 0 on the frames beyond T
+    if (cq <= LNB_RC) {  // block-uniform
+        float xv[LNB_RC], gv[LNB_RC], gm[LNB_RC];
+#pragma unroll
+        for (int i = 0; i < LNB_RC; ++i) xv[i] = xp[(int64_t)min(c0 + i, C - 1) * T];
+#pragma unroll
+        for (int i = 0; i < LNB_RC; ++i) gv[i] = dp[(int64_t)min(c0 + i, C - 1) * T];
+#pragma unroll
+        for (int i = 0; i < LNB_RC; ++i) gm[i] = gamma[min(c0 + i, C - 1)];
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < LNB_RC; ++i) s += c0 + i < c1 ? xv[i] : 0.0f;
+        const float mean = lnb_block_sum(s, red, cg, tl) / (float)C;
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < LNB_RC; ++i) {
+            const float d = c0 + i < c1 ? xv[i] - mean : 0.0f;
+            q = fmaf(d, d, q);
+        }
+        const float rstd = 1.0f / sqrtf(lnb_block_sum(q, red, cg, tl) / (float)C + eps);
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < LNB_RC; ++i) {
+            xv[i] = (xv[i] - mean) * rstd;                 // x-hat
+            gv[i] = c0 + i < c1 ? gv[i] * m : 0.0f;        // masked dy (0 for the channels this thread does not own)
+            const float g = gv[i] * gm[i];
+            s1 += g;
+            s2 = fmaf(g, xv[i], s2);
+        }
+        s1 = lnb_block_sum(s1, red, cg, tl) / (float)C;
+        s2 = lnb_block_sum(s2, red, cg, tl) / (float)C;
+#pragma unroll
+        for (int i = 0; i < LNB_RC; ++i) {
+            if (c0 + i < c1) {  // uniform per channel group
+                if (valid) op[(int64_t)(c0 + i) * T] = rstd * (gv[i] * gm[i] - s1 - xv[i] * s2);
+                lnb_emit(gv[i] * xv[i], gv[i], c0 + i, tl, dgamma, dbeta, partial, C);
+            }
+        }
+        return;
+    }
     float s = 0.0f;
     for (int c = c0; c < c1; ++c) s += xp[(int64_t)c * T];
     const float mean = lnb_block_sum(s, red, cg, tl) / (float)C;
     float q = 0.0f;
     for (int c = c0; c < c1; ++c) { const float d = xp[(int64_t)c * T] - mean; q = fmaf(d, d, q); }
     const float rstd = 1.0f / sqrtf(lnb_block_sum(q, red, cg, tl) / (float)C + eps);
-    const float m = !valid ? 0.0f : (mask ? mask[(int64_t)b * T + t] : 1.0f);
     float s1 = 0.0f, s2 = 0.0f;
     for (int c = c0; c < c1; ++c) {
         const float xh = (xp[(int64_t)c * T] - mean) * rstd;
@@ -265,23 +327,11 @@ __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, c
     }
     s1 = lnb_block_sum(s1, red, cg, tl) / (float)C;
     s2 = lnb_block_sum(s2, red, cg, tl) / (float)C;
-    float *op = dx + (int64_t)b * C * T + tc;
     for (int c = c0; c < c1; ++c) {
         const float xh = (xp[(int64_t)c * T] - mean) * rstd;
-        const float dyc = dp[(int64_t)c * T] * m;  // m == 0 on the frames beyond T
+        const float dyc = dp[(int64_t)c * T] * m;
         if (valid) op[(int64_t)c * T] = rstd * (dyc * gamma[c] - s1 - xh * s2);
-        float dg = dyc * xh, db = dyc;
-        for (int off = 32; off > 0; off >>= 1) { dg += __shfl_xor(dg, off); db += __shfl_xor(db, off); }
-        if (tl == 0) {
-            if (partial) {
-                float *row = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
-                row[c] = dg;
-                row[C + c] = db;
-            } else {
-                atomicAdd(&dgamma[c], dg);
-                atomicAdd(&dbeta[c], db);
-            }
-        }
+        lnb_emit(dyc * xh, dyc, c, tl, dgamma, dbeta, partial, C);
     }
 }
 // out[j] += sum_r partial[r][j], j < n (= 2C: dgamma then dbeta); block = 64 columns x 4 row groups
@@ -680,14 +730,14 @@ extern "C" int set_res_skip_bwd(const float *dx_out, const float *dskip, float *
     return set_check_launch("set_res_skip_bwd");
 }
 extern "C" int64_t set_layernorm_ch_bwd_scratch(int32_t B, int32_t C, int32_t T) {
-    return (int64_t)B * ((T + 63) / 64) * 2 * C;
+    return (int64_t)B * ((T + LNB_FT - 1) / LNB_FT) * 2 * C;
 }
 extern "C" int set_layernorm_ch_bwd(const float *x, const float *gamma, const float *mask, const float *dy, float *dx,
                                     float *dgamma, float *dbeta, float *partial, int32_t B, int32_t C, int32_t T,
                                     float eps, void *stream) {
     SET_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && B > 0 && C > 0 && T > 0, "set_layernorm_ch_bwd");
     SET_REQUIRE(B <= 65535, "set_layernorm_ch_bwd(B)");
-    const int tiles = (T + 63) / 64;
+    const int tiles = (T + LNB_FT - 1) / LNB_FT;
     hipLaunchKernelGGL(layernorm_ch_bwd_kernel, dim3(tiles, B), dim3(256), 0, (hipStream_t)stream,
                        x, gamma, mask, dy, dx, dgamma, dbeta, partial, B, C, T, eps);
     if (partial) {
