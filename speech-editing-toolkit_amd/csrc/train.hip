@@ -23,6 +23,7 @@ struct WgradArgs {
     int B, Cin, Cout, K, dil, pad, T, T_in, pro;
     float pro_param;
     int chunks_per_slice, n_chunks_t;  // chunk id = b * n_chunks_t + tc
+    int gx, gy, gz, xcd_map;           // logical grid (tap x ci tile, co tile, split-K slice); launch is 1-D
 };
 
 __global__ void __launch_bounds__(256) conv1d_wgrad_mfma_kernel(WgradArgs a) {
@@ -31,14 +32,37 @@ __global__ void __launch_bounds__(256) conv1d_wgrad_mfma_kernel(WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
+    // Logical block (bx, by, bz) from the linear workgroup id.  Workgroups go to the 8 XCDs round-robin by that id and
+    // every XCD has its own L2: with xcd_map, slice bz (= one range of frames) is given to ONE XCD, so the gz/8 * gx*gy
+    // tiles that read the same g / x frames share them in that L2 instead of fetching them once per XCD.
+    int bx, by, bz;
+    {
+        const int L = blockIdx.x, nxy = a.gx * a.gy;
+        if (a.xcd_map) {
+            const int slot = L >> 3, xy = slot % nxy;
+            bz = (L & 7) + 8 * (slot / nxy);
+            bx = xy % a.gx;
+            by = xy / a.gx;
+        } else {
+            bx = L % a.gx;
+            by = (L / a.gx) % a.gy;
+            bz = L / nxy;
+        }
+        // the divisions run on the vector ALU: bring the results back to scalar registers, or every address derived
+        // from them occupies VGPRs (116 -> 140, one wave per SIMD less)
+        bx = __builtin_amdgcn_readfirstlane(bx);
+        by = __builtin_amdgcn_readfirstlane(by);
+        bz = __builtin_amdgcn_readfirstlane(bz);
+    }
     const int ci_tiles = (a.Cin + 63) / 64;
-    const int tap = blockIdx.x / ci_tiles, ci0 = (blockIdx.x % ci_tiles) * 64;
-    const int co0 = blockIdx.y * 128;
+    const int tap = bx / ci_tiles, ci0 = (bx % ci_tiles) * 64;
+    const int co0 = by * 128;
     const int shift = tap * a.dil - a.pad;
     f32x16 acc0 = {0}, acc1 = {0};
     const int total_chunks = a.B * a.n_chunks_t;
-    const int c_begin = blockIdx.z * a.chunks_per_slice;
+    const int c_begin = bz * a.chunks_per_slice;
     const int c_end = min(c_begin + a.chunks_per_slice, total_chunks);
+
     // Staging: thread (k = tid & 31 along t, r0 = tid >> 5) owns rows r0, r0+8, ... of both tiles.  All loads of a chunk
     // are UNCONDITIONAL on clamped addresses and issued together, one chunk AHEAD of the MFMAs (the validity select
     // happens at the LDS write): `if (valid) v = load` costs one serialized global round trip per element, 24 per chunk
@@ -99,6 +123,9 @@ __global__ void __launch_bounds__(256) conv1d_wgrad_mfma_kernel(WgradArgs a) {
         }
         __syncthreads();
     }
+    // a padding slice of an XCD-mapped grid has nothing to add (tested here, not before the loop: an early exit there
+    // changes the register allocation of the whole kernel, 116 -> 140 VGPRs)
+    if (c_begin >= c_end) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = co0 + 32 * w + mfma32_row(r, lane);
@@ -661,7 +688,7 @@ extern "C" int set_conv1d_wgrad(const float *g, const float *x, const float *cha
                                 int32_t Cout, int32_t K, int32_t dil, int32_t pad, int32_t T, int32_t T_in, int32_t pro,
                                 float pro_param, int32_t impl, void *stream) {
     SET_REQUIRE(g && x && dw && B > 0 && Cin > 0 && Cout > 0 && K > 0 && T > 0 && T_in > 0, "set_conv1d_wgrad");
-    WgradArgs a = {g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro, pro_param, 0, 0};
+    WgradArgs a = {g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro, pro_param, 0, 0, 0, 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     if (impl != SET_IMPL_MFMA) {
         hipLaunchKernelGGL(conv1d_wgrad_naive_kernel, dim3(set_blocks((int64_t)Cout * Cin * K, 256)), dim3(256), 0, s, a);
@@ -678,10 +705,18 @@ extern "C" int set_conv1d_wgrad(const float *g, const float *x, const float *cha
     int slices = (target_blocks + tiles - 1) / tiles;
     if (slices > total) slices = total;
     if (slices < 1) slices = 1;
+    // one XCD per slice needs a multiple of 8 slices (the padding slices, if any, exit at once)
+    bool xcd_map = slices >= 8;
+    if (const char *e = getenv("SET_AMD_WGRAD_XCD")) xcd_map = xcd_map && atoi(e) != 0;
+    if (xcd_map) slices = (slices + 7) / 8 * 8 <= total ? (slices + 7) / 8 * 8 : slices / 8 * 8;
     a.chunks_per_slice = (total + slices - 1) / slices;
     slices = (total + a.chunks_per_slice - 1) / a.chunks_per_slice;
-    dim3 grid(K * ((Cin + 63) / 64), (Cout + 127) / 128, slices);
-    hipLaunchKernelGGL(conv1d_wgrad_mfma_kernel, grid, dim3(256), 0, s, a);
+    if (xcd_map) slices = (slices + 7) / 8 * 8;
+    a.gx = K * ((Cin + 63) / 64);
+    a.gy = (Cout + 127) / 128;
+    a.gz = slices;
+    a.xcd_map = xcd_map ? 1 : 0;
+    hipLaunchKernelGGL(conv1d_wgrad_mfma_kernel, dim3((unsigned)a.gx * a.gy * a.gz), dim3(256), 0, s, a);
     return set_check_launch("set_conv1d_wgrad(mfma)");
 }
 
