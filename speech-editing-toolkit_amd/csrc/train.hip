@@ -380,7 +380,10 @@ __global__ void __launch_bounds__(256) lnb_partial_sum_kernel(const float *parti
 
 // ---- embedding / alignment gather backward (scatter-add) ------------------------------------------------------
 // one thread per (b, c) walks t and flushes one atomic per RUN of equal indices: masked regions / sorted alignments
-// map long stretches of frames to one row (e.g. every masked frame -> pitch bin 1), which serialises per-frame atomics
+// map long stretches of frames to one row (e.g. every masked frame -> pitch bin 1), which serialises per-frame atomics.
+// (Tried: one wave per (b, c, 64-frame segment) with a segmented scan -- coalesced and 13x more parallel, but the frame-
+// level pitch bins give one run per frame, and 5 M atomics issued at once on 58 k addresses cost 2.7 ms more per step
+// than this slow walk, which spreads them out.  The way forward is an LDS-privatised table per block, not more threads.)
 __global__ void __launch_bounds__(256) embedding_bwd_kernel(const int64_t *idx, const float *dout, float *dtable, int B,
                                                             int T, int C, int n_rows, float scale, int padding_idx) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
