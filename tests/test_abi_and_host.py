@@ -146,6 +146,25 @@ def test_libritts_yaml_inherits_and_drops_the_pitch_block():
     assert not any(k.startswith("fs.pitch_") for k, _ in got)
 
 
+def test_wo_masked_predictor_yaml_selects_the_normal_task():
+    """egs/spec_denoiser_wo_masked_predictor.yaml of the reference: same hot-path values, task class
+    tasks.speech_editing.spec_denoiser_normal.SpeechDenoiserNormalTask (:50) -> plain-FastSpeech conditioner."""
+    from set_amd import hparams as H, tasks
+    from set_amd.diffnet import DiffNet
+    from set_amd.spec_denoiser import GaussianDiffusionNormal
+    from oracle import weights as Wt
+    fn = os.path.join(ROOT, "speech-editing-toolkit_amd", "egs", "spec_denoiser_wo_masked_predictor.yaml")
+    hp = H.set_hparams(config=fn, global_hparams=False, print_hparams=False)
+    assert hp["timesteps"] == 8 and hp["use_pitch_embed"] is True
+    cls_path = tasks.TASK_ALIASES[hp["task_cls"]]
+    assert cls_path.endswith("SpeechDenoiserNormalTask") and tasks.SpeechDenoiserNormalTask.model_cls is GaussianDiffusionNormal
+    m = GaussianDiffusionNormal(list(range(80)), 80, DiffNet(80, hp), timesteps=4, time_scale=1, loss_type="l1",
+                                spec_min=[], spec_max=[], hp=hp)
+    want = [(k, tuple(s)) for k, s in Wt.load_manifest("spec_denoiser_normal")]
+    got = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert got == want and "fs.dur_embed.weight" not in dict(got)
+
+
 def test_registries_and_aliases():
     from set_amd import tasks, vocoder_infer
     assert "wavenet" in tasks.DIFF_DECODERS
