@@ -1,19 +1,30 @@
 """Headline benchmark: diffusion mel-frames/s of one full GaussianDiffusion.forward(infer=True)
 (conditioner once + 100 x (DiffNet + posterior step)) at B=32 per GPU, T=800, fp32.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--mode infer|train] [--dtype f32|bf16]
 
-One "step" = one pass of the hot path over one synthetic batch.  Utterances shard across ranks with NO
-data-path collective (weak scaling: B=32 per rank); timing = barrier + synchronize on both sides, MAX over
-ranks.  Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel =
-diffnet_layer_kernel, measured with hipEvents on the launch stream inside the timed region) and, at N=1,
-`cpu_baseline` (the CPU oracle = a port of the reference's torch-CPU path, timed on a bounded sample).
+With N > 1 and no WORLD_SIZE in the environment the script re-launches itself as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+(one rank per GPU over RCCL; the reference spawns its ranks the same way, utils/commons/trainer.py:116-137,481-485)
+and fails loudly when fewer than N devices are visible.  Under an external launcher it reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* as usual.
+
+One "step" = one pass of the hot path over one synthetic batch.
+  --mode infer (default, BASELINE.json's metric): utterances shard across ranks with NO data-path collective (weak
+      scaling, B=32 per rank).
+  --mode train (BASELINE configs[1]/[2]): forward + losses + backward + bucketed RCCL gradient all-reduce overlapped
+      with backward + clip + AdamW, after the rank-0 parameter broadcast and the two barriers of the reference's DDP
+      set-up; reports samples/s, all-reduce bytes per step and the exposed (not hidden by backward) exchange time.
+Timing = barrier + synchronize on both sides, MAX over ranks.  Rank 0 prints ONE JSON line with the contract fields plus
+`roofline` (dominant kernel = the persistent DiffNet layer-stack kernel, one launch = all 20 residual layers of one
+denoise step, measured with hipEvents on the launch stream inside the timed region) and, at N=1, `cpu_baseline` (the CPU
+oracle = a port of the reference's torch-CPU path, timed on bounded samples: SURVEY.md 8(d)'s protocol).
 """
 import argparse
 import json
-import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,20 +37,27 @@ import yaml  # noqa: E402
 
 B_PER_GPU, T, T_TXT, DIFF_STEPS, M, L, C, H = 32, 800, 100, 100, 80, 20, 256, 192
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
-# algorithmic work of ONE diffnet_layer_kernel launch (DESIGN.md section "roofline"):
+# algorithmic work of the residual layers of ONE denoise step, per frame and layer:
 #   k3 dilated conv 512x768 + output projection 512x256 = 524,288 MAC per frame (conditioner projection hoisted)
 FLOP_PER_FRAME_LAYER = 2 * (512 * 768 + 512 * 256)
-# algorithmic HBM bytes per frame per layer launch (fp32): x in 1024 + condproj 2048 + x out 1024 + skip rmw 2048
+# algorithmic HBM bytes per frame per layer (fp32): x in 1024 + condproj 2048 + x out 1024 + skip rmw 2048
 BYTES_PER_FRAME_LAYER = 1024 + 2048 + 1024 + 2048
+# one training step, algorithmic FLOPs per frame (~3 x forward of one DiffNet pass + conditioner)
+TRAIN_FLOP_PER_FRAME = 3 * (25_116_672 + 2_100_000)
+
+
+def load_hparams():
+    with open(os.path.join(ROOT, "speech-editing-toolkit_amd", "egs", "spec_denoiser.yaml")) as f:
+        return yaml.safe_load(f)
 
 
 def build_model(dev, steps):
     import set_amd  # noqa: F401
     from set_amd.diffnet import DiffNet
     from set_amd.spec_denoiser import GaussianDiffusion
-    with open(os.path.join(ROOT, "speech-editing-toolkit_amd", "egs", "spec_denoiser.yaml")) as f:
-        hp = yaml.safe_load(f)
+    hp = load_hparams()
     hp["timesteps"] = steps
     torch.manual_seed(1234)
     model = GaussianDiffusion(list(range(80)), M, DiffNet(M, hp), timesteps=steps, time_scale=1, loss_type="l1",
@@ -50,64 +68,134 @@ def build_model(dev, steps):
     return model.to(dev).eval()
 
 
-def cpu_baseline(model, inp, n_timed=3):
-    """The oracle (port of the reference's torch CPU path) on the SAME workload, bounded sample:
-    conditioner once + (1 warm-up + n_timed) DiffNet+posterior steps at B=32,T=800, scaled to 100 steps."""
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (SURVEY.md 8(d) "CPU baseline timing"): the oracle on the same synthetic workload, bounded samples
+# ------------------------------------------------------------------------------------------------------------------
+def _cpu_steps(O, W, tab, cond, n_timed, seed=0, gpu_model=None):
+    """1 warm-up + n_timed DiffNet+posterior steps on the rows of `cond`; returns (mean seconds per step, parity)."""
+    B = cond.shape[0]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 1, M, T, generator=g)
+    times, parity = [], None
+    for k in range(1 + n_timed):
+        tt = torch.full((B,), DIFF_STEPS - 1 - k, dtype=torch.long)
+        eps = torch.randn(B, 1, M, T, generator=g)
+        t0 = time.perf_counter()
+        x0 = O.diffnet_forward(W, x, tt, cond)
+        if parity is None and gpu_model is not None:
+            # the checker's by-product: the same DiffNet pass on the GPU path at the full benchmark size
+            # (this is iteration 0, the warm-up, which is not part of the timed mean)
+            dev = next(gpu_model.parameters()).device
+            with torch.no_grad():
+                x0_gpu = gpu_model.denoise_fn(x.to(dev), tt.to(dev), cond.to(dev).contiguous())
+            parity = float((x0_gpu.cpu().double() - x0.double()).abs().max())
+        x = O.q_posterior_sample(tab, x0, x, tt, eps)
+        times.append(time.perf_counter() - t0)
+    return sum(times[1:]) / n_timed, parity
+
+
+def cpu_baseline(model, inp, protocol="full"):
+    """`value` = the CPU's best: conditioner once + timed DiffNet+posterior steps at B=32, T=800 scaled to 100 steps,
+    at the best thread count of a sweep over {8, 16, 32, 64, all} (the sweep itself runs on the first 8 utterances).
+    Also reported: the single-thread figure (the reference pins OMP_NUM_THREADS=1, tasks/run.py:3), one COMPLETE
+    100-step run at B=4 as a cross-check of the scaling, and HiFi-GAN V1 at B=4."""
     from oracle import oracle as O
     W = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     cpu_in = {k: v.cpu() for k, v in inp.items()}
     tab, _ = O.diffusion_tables(DIFF_STEPS)
+    ncpu = os.cpu_count() or 1
     t0 = time.perf_counter()
     ret, cond = O.conditioner(W, cpu_in["txt_tokens"], cpu_in["time_mel_masks"], cpu_in["mel2ph"],
                               cpu_in["spk_embed"], cpu_in["ref_mels"], cpu_in["f0"], cpu_in["uv"])
     t_cond = time.perf_counter() - t0
     B = cond.shape[0]
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(B, 1, M, T, generator=g)
-    times = []
-    parity = None
-    for k in range(1 + n_timed):
-        i = DIFF_STEPS - 1 - k
-        tt = torch.full((B,), i, dtype=torch.long)
-        eps = torch.randn(B, 1, M, T, generator=g)
-        t0 = time.perf_counter()
-        x0 = O.diffnet_forward(W, x, tt, cond)
-        if parity is None:  # the checker's by-product: the same DiffNet pass on the GPU path, full benchmark size
-            dev = next(model.parameters()).device
-            with torch.no_grad():
-                x0_gpu = model.denoise_fn(x.to(dev), tt.to(dev), cond.to(dev).contiguous())
-            parity = float((x0_gpu.cpu().double() - x0.double()).abs().max())
-            # (this is iteration 0, the warm-up, which is not part of the timed mean)
-        x = O.q_posterior_sample(tab, x0, x, tt, eps)
-        times.append(time.perf_counter() - t0)
-    t_step = sum(times[1:]) / n_timed
+    sweep = {}
+    settings = sorted({n for n in (8, 16, 32, 64, ncpu) if n <= ncpu}) if protocol != "quick" else [min(ncpu, 32)]
+    for n in settings:
+        torch.set_num_threads(n)
+        s, _ = _cpu_steps(O, W, tab, cond[:8].contiguous(), 2)
+        sweep[n] = 8 * T / (DIFF_STEPS * s)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    t_step, parity = _cpu_steps(O, W, tab, cond, 3, gpu_model=model)
     total = t_cond + DIFF_STEPS * t_step
-    return {"value": B * T / total, "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "parity_max_abs_dx0_one_pass": parity,
-            "sample": "conditioner once + %d timed DiffNet+posterior steps (after 1 warm-up) at B=%d,T=%d, scaled to "
-                      "%d steps; s/step=%.3f, conditioner s=%.3f" % (n_timed, B, T, DIFF_STEPS, t_step, t_cond)}
+    out = {"value": B * T / total, "unit": "mel-frames/s", "cores": best, "host_cpus": ncpu, "kind": "port",
+           "parity_max_abs_dx0_one_pass": parity,
+           "thread_sweep_frames_per_s_B8": {str(k): v for k, v in sweep.items()},
+           "sample": "conditioner once + 3 timed DiffNet+posterior steps (after 1 warm-up) at B=%d,T=%d with %d threads "
+                     "(best of a sweep over %s on 8 utterances), scaled to %d steps; s/step=%.3f, conditioner s=%.3f"
+                     % (B, T, best, settings, DIFF_STEPS, t_step, t_cond)}
+    if protocol == "full":
+        # single thread, as the reference runs (OMP_NUM_THREADS=1): 2 utterances, 1 warm-up + 2 timed steps
+        torch.set_num_threads(1)
+        s1, _ = _cpu_steps(O, W, tab, cond[:2].contiguous(), 2)
+        out["single_thread"] = {"value": 2 * T / (DIFF_STEPS * s1), "unit": "mel-frames/s", "cores": 1,
+                                "sample": "2 timed steps at B=2,T=%d scaled to %d steps; s/step=%.3f" % (T, DIFF_STEPS, s1)}
+        # one complete 100-step reverse loop at B=4 (cross-check of the "scale 3 steps to 100" shortcut)
+        torch.set_num_threads(best)
+        c4 = cond[:4].contiguous()
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(4, 1, M, T, generator=g)
+        t0 = time.perf_counter()
+        for i in reversed(range(DIFF_STEPS)):
+            tt = torch.full((4,), i, dtype=torch.long)
+            x0 = O.diffnet_forward(W, x, tt, c4)
+            x = O.q_posterior_sample(tab, x0, x, tt, torch.randn(4, 1, M, T, generator=g))
+        t100 = time.perf_counter() - t0
+        out["full_100_steps_B4"] = {"value": 4 * T / t100, "unit": "mel-frames/s", "cores": best, "seconds": t100}
+        # HiFi-GAN V1 generator forward at B=4, T=800 (the vocoder half of BASELINE configs[3])
+        from oracle import weights as Wt
+        Wg = Wt.seeded_weights(Wt.load_manifest("hifigan_v1"), 21)
+        mel = cpu_in["ref_mels"][:4].transpose(1, 2).contiguous()
+        O.hifigan_forward(Wg, Wt.HIFIGAN_V1, mel[:1, :, :64])  # warm-up
+        t0 = time.perf_counter()
+        O.hifigan_forward(Wg, Wt.HIFIGAN_V1, mel)
+        th = time.perf_counter() - t0
+        out["hifigan_v1_B4"] = {"value": 4 * T / th, "unit": "mel-frames/s", "cores": best, "seconds": th}
+    torch.set_num_threads(ncpu)
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    import set_amd  # noqa: F401
+
+def maybe_self_launch(args):
+    """`python bench.py --gpus N` from a bare shell: start N ranks (one per GPU) and hand over to them."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible -- refusing to report a %d-GPU number from fewer "
+                         "devices" % (args.gpus, n_dev, args.gpus))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dist_facts(dev, world, elapsed):
+    """Proof that the ranks really talk: world size as the process group sees it, an all-reduce that every rank must
+    join (sum of rank+1), and every rank's own elapsed time."""
+    import torch.distributed as dist
+    if world == 1:
+        return {"rccl_ranks": 1, "backend": None, "per_rank_s": [elapsed]}
+    one = torch.tensor([float(dist.get_rank() + 1)], device=dev)
+    dist.all_reduce(one)
+    assert int(one.item()) == world * (world + 1) // 2, "all-reduce did not reach every rank"
+    per = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(per, torch.tensor([elapsed], dtype=torch.float64, device=dev))
+    return {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "per_rank_s": [float(p.item()) for p in per]}
+
+
+def run_infer(args, rank, world, dev):
     from set_amd import _lib, parallel
     from set_amd.synthetic import synthetic_inputs
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the set_amd hot path has no CPU fallback")
-    _lib.build()
-    rank, world, local_rank = parallel.init_from_env()
-    assert world == args.gpus or world == 1, (world, args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     torch.set_grad_enabled(False)
-
     model = build_model(dev, DIFF_STEPS)
     # global batch = 32 per rank; every rank takes its utterances r::world of the same synthetic batch
     full = synthetic_inputs(B_PER_GPU * world, T, T_TXT, seed=1234)
@@ -133,11 +221,12 @@ def main():
     parallel.barrier()
     t_max = parallel.max_over_ranks(elapsed, device=dev if world > 1 else "cpu")
     assert torch.isfinite(ret["mel_out"]).all()
+    facts = dist_facts(dev, world, elapsed)
 
     frames = B_PER_GPU * world * T * args.steps
     value = frames / t_max
-    # Dominant kernel.  Default path: ONE persistent diffnet_stack_kernel launch per denoise step runs all L residual
-    # layers (task queue over (layer, 32-frame tile)); SET_AMD_PERSISTENT=0: L diffnet_layer_kernel launches per step.
+    # Dominant kernel.  Default path: ONE persistent layer-stack launch per denoise step runs all L residual layers
+    # (task queue over (layer, tile)); SET_AMD_PERSISTENT=0: L diffnet_layer_kernel launches per step.
     #   launch_ms = mean duration of one launch, from hipEvent pairs on the launch stream over the timed region
     #   achieved  = algorithmic FLOPs of one launch / launch_ms  (x concurrent launches if utterance groups > 1)
     persistent = bool(ret.get("persistent", 0))
@@ -169,6 +258,8 @@ def main():
                                "BASELINE configs[1]); on-device Philox noise",
                    "B_per_gpu": B_PER_GPU, "T": T, "T_txt": T_TXT, "denoise_steps": DIFF_STEPS,
                    "sharding": "utterances r::N, no collective"},
+        "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"],
+        "per_rank_ms_per_step": [1e3 * s / args.steps for s in facts["per_rank_s"]],
         "roofline": {"kernel": stack_kernel if persistent else "diffnet_layer_kernel", "bound": "mfma",
                      "achieved": ach_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "launch_ms": launch_ms,
@@ -179,9 +270,106 @@ def main():
                      "achieved_wall_lower_bound": ach_wall, "frac_wall_lower_bound": ach_wall / PEAK_F32_MFMA_TFLOPS,
                      "hbm_algorithmic_GBps": ach_gbs, "hbm_frac": ach_gbs / PEAK_HBM_GBS},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model, inp)
+    if rank == 0 and world == 1 and args.cpu_baseline != "off":
+        out["cpu_baseline"] = cpu_baseline(model, inp, args.cpu_baseline)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    return out
+
+
+def run_train(args, rank, world, dev):
+    """BASELINE configs[1] (1 GPU) / configs[2] (8 GPUs, B=256 global): one optimisation step of the spec_denoiser task."""
+    from set_amd import hparams as HP, ops, parallel, tasks
+    from set_amd.synthetic import synthetic_inputs
+    from set_amd.training import FlatAdamW
+    HP.hparams.clear()
+    HP.hparams.update(load_hparams())
+    if args.dtype == "bf16":
+        ops.set_compute_dtype("bf16")
+    # every rank seeds DIFFERENTLY on purpose: the replicas must agree because of the rank-0 broadcast, not by luck
+    torch.manual_seed(1234 + rank)
+    task = tasks.SpeechDenoiserTask(build_vocoder=False)
+    task.build_model()
+    torch.nn.init.normal_(task.model.denoise_fn.output_projection.weight, std=1.0 / 16.0)
+    task.model.to(dev).train()
+    opt = FlatAdamW(task.model, lr=HP.hparams["lr"], betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=1.0,
+                    warmup_updates=8000)
+    bcast_bytes = parallel.configure_ddp(task.model, opt)  # barrier, rank-0 broadcast, barrier
+    if world > 1:  # replicas identical now?
+        chk = opt.flat_p.double().sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        assert float(lo) == float(hi), "parameter broadcast left the replicas different"
+    full = synthetic_inputs(B_PER_GPU * world, T, T_TXT, seed=1234, pad_tail=True)
+    inp = {k: v.to(dev) for k, v in parallel.shard_batch(full, rank, world).items()}
+    sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"],
+                  time_mel_masks=inp["time_mel_masks"].squeeze(-1).contiguous(), spk_embed=inp["spk_embed"])
+    for w in range(args.warmup):
+        task.training_step(sample, opt, seed=100 + w)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    exposed, reduced = 0.0, 0
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        total, parts, lr = task.training_step(sample, opt, seed=k)
+        exposed += opt.bucketer.exposed_s
+        reduced = opt.bucketer.bytes_reduced
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    parallel.barrier()
+    t_max = parallel.max_over_ranks(elapsed, device=dev if world > 1 else "cpu")
+    facts = dist_facts(dev, world, elapsed)
+    assert torch.isfinite(total).all()
+    n_samples = B_PER_GPU * world * args.steps
+    flop = TRAIN_FLOP_PER_FRAME * B_PER_GPU * T * args.steps  # per rank
+    peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    ach = flop / t_max / 1e12
+    return {
+        "metric": "spec_denoiser training samples/s (B=32/GPU, T=800)", "value": n_samples / t_max, "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_max / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "FluentSpeech spec_denoiser training step (conditioner + one DiffNet pass + l1/ssim/dur/"
+                               "pitch losses + backward + gradient all-reduce + clip + AdamW), synthetic 80-mel T=800 "
+                               "batches, B=32 per GPU (BASELINE configs[1]; configs[2] at 8 GPUs = 256 global)",
+                   "B_per_gpu": B_PER_GPU, "T": T, "T_txt": T_TXT, "sharding": "utterances r::N, gradient all-reduce (SUM, "
+                   "1/N folded into AdamW) in %d buckets" % max(1, len(opt.bucketer.buckets))},
+        "frames_per_s": n_samples * T / t_max,
+        "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"],
+        "per_rank_ms_per_step": [1e3 * s / args.steps for s in facts["per_rank_s"]],
+        "allreduce_bytes_per_step": reduced, "allreduce_exposed_ms_per_step": 1e3 * exposed / args.steps,
+        "param_broadcast_bytes": bcast_bytes, "grad_elems": opt.n,
+        "loss": float(total), "lr": lr, "losses": {k: float(v) for k, v in parts.items()},
+        "roofline": {"kernel": "whole training step", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                     "frac": ach / peak, "traffic": None, "flop_per_step": flop / args.steps},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=("infer", "train"), default="infer")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="train mode only: MFMA operand type")
+    ap.add_argument("--cpu-baseline", choices=("full", "quick", "off"), default="full")
+    ap.add_argument("--no-cpu-baseline", action="store_const", const="off", dest="cpu_baseline")
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the set_amd hot path has no CPU fallback")
+    maybe_self_launch(args)
+
+    import set_amd  # noqa: F401
+    from set_amd import _lib, parallel
+    _lib.build()
+    rank, world, local_rank = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    out = (run_train if args.mode == "train" else run_infer)(args, rank, world, dev)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SET_AMD_ABI_VERSION 1
+#define SET_AMD_ABI_VERSION 2
 
 /* error codes */
 #define SET_OK 0
@@ -76,6 +76,8 @@ const char *set_last_error(void);
  *     v    = v + res[b][co][n]                              (res optional)
  *     v    = v * mask[b][n]                                 (mask optional, [B][T_out])
  *     out[b][co][n] = accumulate ? out[b][co][n] + v : v
+ *     (accumulate && out_div != 0:  out = (out + v) / out_div -- the last term of a running mean, e.g. the MRF mean
+ *      `xs / num_kernels` of hifigan.py:131-137 folded into the last ResBlock's final conv; same summation order)
  *
  * `dil` may be negative (ConvTranspose polyphase taps read in[q - j]).
  * Weights: impl NAIVE reads w[w_base + co*w_sco + ci*w_sci + tap*w_stap];
@@ -95,6 +97,7 @@ typedef struct SetConv1dArgs {
     int32_t T_in, T_iter, T_out, out_stride, out_off;
     int32_t pro, act, accumulate, impl;
     float pro_param, act_param, alpha;
+    float out_div;            /* see above; 0 = plain accumulate */
 } SetConv1dArgs;
 
 int set_conv1d(const SetConv1dArgs *args, void *stream);

@@ -108,6 +108,14 @@ def infer_case(hp, name, B, T, T_txt, steps, wseed, iseed, pad_tail=False, overr
         step_ctr["n"] += 1
 
     hooks.append(model.denoise_fn.register_forward_hook(dn_hook))
+    # integer index tensors the reference feeds to its embedding tables (fs.py:123-189): captured AT the tables, so the
+    # fixtures hold the reference's own indices (dur_embed: masked durations; pitch_embed: 1st call masked-pitch bins,
+    # 2nd call the full pitch bins; the `normal` variant has no dur_embed and calls pitch_embed once)
+    cap = {"dur": [], "pitch": []}
+    if hasattr(model.fs, "dur_embed"):
+        hooks.append(model.fs.dur_embed.register_forward_pre_hook(lambda m, a: cap["dur"].append(a[0].clone())))
+    if bool(hp["use_pitch_embed"]):
+        hooks.append(model.fs.pitch_embed.register_forward_pre_hook(lambda m, a: cap["pitch"].append(a[0].clone())))
     for li in trace_layers:
         def mk(li):
             def h(mod, args, out):
@@ -147,8 +155,18 @@ def infer_case(hp, name, B, T, T_txt, steps, wseed, iseed, pad_tail=False, overr
     assert max(d_mel, d_cond, d_dur, d_pp) < 2e-5, "oracle restatement deviates from the reference"
     for k in range(steps):
         assert maxdiff(otrace[k][0], rec["x0"][k]) < 2e-5 and maxdiff(otrace[k][1], rec["x"][k]) < 2e-5
-    # integer intermediates from the oracle (the reference does not expose them) --
-    # they are validated indirectly: decoder_inp embeds them, so any bin mismatch shows up in d_cond.
+    # integer intermediates: the reference's own tensors (hooks above); the oracle must agree BIT FOR BIT
+    ref_int = {}
+    if VARIANT == "masked":
+        assert len(cap["dur"]) == 1 and cap["dur"][0].dtype == torch.int64
+        ref_int["masked_dur"] = cap["dur"][0]
+    if use_pitch:
+        assert len(cap["pitch"]) == (2 if VARIANT == "masked" else 1) and cap["pitch"][-1].dtype == torch.int64
+        ref_int["pitch"] = cap["pitch"][-1]
+        if VARIANT == "masked":
+            ref_int["masked_pitch"] = cap["pitch"][0]
+    for k, v in ref_int.items():
+        assert torch.equal(oret[k], v), "oracle %s differs from the reference's embedding index tensor" % k
     out = dict(
         meta=np.array(json.dumps(dict(B=B, T=T, T_txt=T_txt, steps=steps, wseed=wseed, iseed=iseed,
                                       pad_tail=pad_tail, overrides=overrides or {}, flags=flags,
@@ -156,12 +174,12 @@ def infer_case(hp, name, B, T, T_txt, steps, wseed, iseed, pad_tail=False, overr
         mel_out=ret["mel_out"], decoder_inp=ret["decoder_inp"], dur=ret["dur"], mel2ph=ret["mel2ph"],
     )
     if VARIANT == "masked":
-        out["masked_dur"] = oret["masked_dur"]
+        out["masked_dur"] = ref_int["masked_dur"]
     if use_pitch:
         out.update(pitch_pred=ret["pitch_pred"], f0_denorm=ret["f0_denorm"], f0_denorm_pred=ret["f0_denorm_pred"],
-                   pitch=oret["pitch"])
+                   pitch=ref_int["pitch"])
         if VARIANT == "masked":
-            out["masked_pitch"] = oret["masked_pitch"]
+            out["masked_pitch"] = ref_int["masked_pitch"]
     ks = range(steps) if keep_steps is None else keep_steps
     for k in ks:
         out["x0_step%d" % k] = rec["x0"][k]
@@ -341,14 +359,15 @@ def length_regulator_case():
     npz("length_regulator", dur=dur, pad=pad, mel2ph=ref)
 
 
-def hifigan_case(name, h, B, T, wseed, iseed):
+def hifigan_case(name, h, B, T, wseed, iseed, manifest=None):
     from modules.vocoder.hifigan.hifigan import HifiGanGenerator
     g = HifiGanGenerator(h).eval()
     man = manifest_of(g)
     W = Wt.seeded_weights([(k, tuple(s)) for k, s in man], wseed)
     g.load_state_dict(W, strict=True)
-    with open(os.path.join(GOLD, "manifest_%s.json" % name), "w") as f:
-        json.dump(man, f)
+    if manifest is None:
+        with open(os.path.join(GOLD, "manifest_%s.json" % name), "w") as f:
+            json.dump(man, f)
     rng = np.random.default_rng(iseed)
     mel = torch.from_numpy(np.clip(rng.normal(-3.0, 1.5, size=(B, 80, T)), -6.0, 1.5).astype(np.float32))
     wav = g(mel)
@@ -356,7 +375,8 @@ def hifigan_case(name, h, B, T, wseed, iseed):
     d = maxdiff(wav, mine)
     print("  [%s] oracle vs reference: wav %.2e (|wav| max %.3f)" % (name, d, float(wav.abs().max())))
     assert d < 2e-5
-    npz(name, meta=np.array(json.dumps(dict(h=h, B=B, T=T, wseed=wseed, iseed=iseed))), mel=mel, wav=wav)
+    npz(name, meta=np.array(json.dumps(dict(h=h, B=B, T=T, wseed=wseed, iseed=iseed, manifest=manifest or name))),
+        mel=mel, wav=wav)
 
 
 def edit_case(hp, name, seed, steps, wseed, vseed, h, **gen):
@@ -442,9 +462,12 @@ def main():
     train_loss_case(hp, "train_losses", B=2, T=64, T_txt=16, steps=8, wseed=18, iseed=108)
     length_regulator_case()
     data_feed_case()
+    batch_by_size_case()
     hifigan_case("hifigan_tiny", Wt.HIFIGAN_TINY, B=2, T=24, wseed=21, iseed=201)
     hifigan_case("hifigan_tiny_rb2", Wt.HIFIGAN_TINY_RB2, B=1, T=20, wseed=22, iseed=202)
     hifigan_case("hifigan_v1", Wt.HIFIGAN_V1, B=1, T=12, wseed=23, iseed=203)
+    # real-length V1: 56,320 output samples, many tiles per stage, every dilation x kernel halo crosses tile borders
+    hifigan_case("hifigan_v1_long", Wt.HIFIGAN_V1, B=1, T=220, wseed=23, iseed=204, manifest="hifigan_v1")
     edit_cases(hp)
     nopitch_cases(hp)
     normal_cases(hp)
@@ -562,6 +585,26 @@ def campnet_case(hp, name, B, T, T_txt, wseed, iseed, pad_tail=True):
     npz(name, **out_np)
 
 
+def batch_by_size_case():
+    """utils/commons/dataset_utils.py:65-119 (`batch_by_size`) on random length lists: the reference's own batches."""
+    import utils.commons.dataset_utils as RD
+    from set_amd import data as D
+    rng = np.random.default_rng(77)
+    cases = []
+    for n, mt, ms, mult in [(50, 3000, 8, 1), (37, 1500, 16, 2), (64, 40000, 16, 8), (23, 900, None, 4),
+                            (10, None, 3, 1), (41, 2500, 6, 3)]:
+        sizes = rng.integers(80, 800, size=n).tolist()
+        order = np.argsort(np.array(sizes), kind="mergesort").tolist() if n % 2 else rng.permutation(n).tolist()
+        ref = RD.batch_by_size(np.array(order), lambda i: sizes[i], max_tokens=mt, max_sentences=ms,
+                               required_batch_size_multiple=mult)
+        ref = [[int(i) for i in b] for b in ref]
+        assert D.batch_by_size(order, lambda i: sizes[i], mt, ms, mult) == ref, (n, mt, ms, mult)
+        cases.append(dict(sizes=sizes, order=order, max_tokens=mt, max_sentences=ms, mult=mult, batches=ref))
+    with open(os.path.join(GOLD, "batch_by_size.json"), "w") as f:
+        json.dump(cases, f)
+    print("wrote batch_by_size.json", [len(c["batches"]) for c in cases])
+
+
 def campnet_cases(hp):
     campnet_case(hp, "campnet_tiny", B=2, T=48, T_txt=12, wseed=41, iseed=301)
     campnet_case(hp, "campnet_ragged", B=3, T=77, T_txt=19, wseed=42, iseed=302)
@@ -604,5 +647,11 @@ if __name__ == "__main__":
         normal_cases(ref_import.install(timesteps=4))
     elif len(sys.argv) > 1 and sys.argv[1] == "campnet":
         campnet_cases(ref_import.install(timesteps=4))
+    elif len(sys.argv) > 1 and sys.argv[1] == "bbs":
+        ref_import.install(timesteps=4)
+        batch_by_size_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "hifigan_long":
+        ref_import.install(timesteps=4)
+        hifigan_case("hifigan_v1_long", Wt.HIFIGAN_V1, B=1, T=220, wseed=23, iseed=204, manifest="hifigan_v1")
     else:
         main()

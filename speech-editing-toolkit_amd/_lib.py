@@ -40,7 +40,7 @@ class SetConv1dArgs(C.Structure):
         ("T_in", C.c_int32), ("T_iter", C.c_int32), ("T_out", C.c_int32), ("out_stride", C.c_int32),
         ("out_off", C.c_int32),
         ("pro", C.c_int32), ("act", C.c_int32), ("accumulate", C.c_int32), ("impl", C.c_int32),
-        ("pro_param", C.c_float), ("act_param", C.c_float), ("alpha", C.c_float),
+        ("pro_param", C.c_float), ("act_param", C.c_float), ("alpha", C.c_float), ("out_div", C.c_float),
     ]
 
 

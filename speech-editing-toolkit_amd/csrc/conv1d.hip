@@ -21,7 +21,11 @@ __device__ __forceinline__ void conv_store(const SetConv1dArgs &a, int b, int co
     if (a.res) v += a.res[(int64_t)b * a.res_bs + (int64_t)co * a.res_cs + n];
     if (a.mask) v *= a.mask[(int64_t)b * a.T_out + n];
     float *o = a.out + (int64_t)b * a.out_bs + (int64_t)co * a.out_cs + n;
-    *o = a.accumulate ? (*o + v) : v;
+    if (a.accumulate) {
+        v += *o;
+        if (a.out_div != 0.0f) v = v / a.out_div;
+    }
+    *o = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -215,6 +219,7 @@ __global__ void __launch_bounds__(256, 4) conv1d_mfma_kernel(SetConv1dArgs a, in
         for (int r = 0; r < 16; ++r) bi[r] = buf_load(d_b, (unsigned)lrow * 4u, (unsigned)((r & 3) + 8 * (r >> 2)) * 4u);
     }
     const rsrc_t d_r = make_rsrc(a.res ? a.res + (int64_t)b * a.res_bs : a.out);
+    const bool has_div = a.accumulate && a.out_div != 0.0f;  // wave-uniform
     // one column block (16 registers) at a time: 16 residual (+16 previous-output) loads in flight, then compute, store
     auto column = [&](auto ACT, const f32x16 &acc, int cb) __attribute__((always_inline)) {
         constexpr int kAct = decltype(ACT)::value;
@@ -232,7 +237,8 @@ __global__ void __launch_bounds__(256, 4) conv1d_mfma_kernel(SetConv1dArgs a, in
         if (!tv[cb]) return;  // frames outside the output: lanes masked off (after the loads: no wait inside a branch)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float y = (dev_act((acc[r] + bi[r]) * a.alpha, kAct, a.act_param) + rv[r]) * mk[cb] + ov[r];
+            float y = (dev_act((acc[r] + bi[r]) * a.alpha, kAct, a.act_param) + rv[r]) * mk[cb] + ov[r];
+            if (has_div) y = y / a.out_div;
             buf_store(y, d_out, vo[cb], (unsigned)(((r & 3) + 8 * (r >> 2)) * a.out_cs) * 4u);
         }
     };
@@ -415,7 +421,9 @@ __global__ void __launch_bounds__(256, RB == 1 ? 4 : (RB == 2 ? 3 : 2)) conv1d_m
                     const int rr = w + 4 * (i0 + i);
                     const int co = g * 128 * RB + (rr >> 5) * 32 * RB + rb * 32 + (rr & 31);
                     float v = dev_act((smem[rr * 64 + col] + bi[i]) * a.alpha, a.act, a.act_param);
-                    if (co < a.Cout && tvalid) buf_store((v + rv[i]) * msk + ov[i], d_out, (unsigned)nc * 4u, (unsigned)(co * a.out_cs) * 4u);
+                    float y = (v + rv[i]) * msk + ov[i];
+                    if (a.accumulate && a.out_div != 0.0f) y = y / a.out_div;
+                    if (co < a.Cout && tvalid) buf_store(y, d_out, (unsigned)nc * 4u, (unsigned)(co * a.out_cs) * 4u);
                 }
             }
         }

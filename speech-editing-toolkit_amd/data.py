@@ -8,8 +8,10 @@
 * `norm_interp_f0` (utils/audio/pitch/utils.py:41-68) and the three mask generators
   (utils/spec_aug/time_mask.py:6-93) are integer / small-array host logic and stay in numpy, like the reference.
 """
+import os
 import pickle
 import random
+import sys
 
 import numpy as np
 import torch
@@ -104,20 +106,105 @@ def collate_1d_or_2d(values, pad_idx=0):
     return res
 
 
+def batch_by_size(indices, num_tokens_fn, max_tokens=None, max_sentences=None, required_batch_size_multiple=1):
+    """Token-budget bucketing of an ordered index list (utils/commons/dataset_utils.py:65-119, fairseq's rule):
+    a batch is closed when adding the next item would make (items + 1) x (longest item so far) exceed `max_tokens` or
+    when it already holds `max_sentences` items; a closed batch is cut to a multiple of `required_batch_size_multiple`
+    (the remainder opens the next batch).  Returns a list of index lists."""
+    max_tokens = sys.maxsize if max_tokens is None else max_tokens
+    max_sentences = sys.maxsize if max_sentences is None else max_sentences
+    mult = required_batch_size_multiple
+    batches, batch, lens, longest = [], [], [], 0
+    for idx in indices:
+        n = num_tokens_fn(idx)
+        lens.append(n)
+        longest = max(longest, n)
+        if longest > max_tokens:
+            raise AssertionError("sentence at index %d of size %d exceeds max_tokens limit of %d!" % (idx, longest, max_tokens))
+        full = len(batch) > 0 and (len(batch) == max_sentences or (len(batch) + 1) * longest > max_tokens)
+        if full:
+            keep = max(mult * (len(batch) // mult), len(batch) % mult)
+            batches.append(batch[:keep])
+            batch, lens = batch[keep:], lens[keep:]
+            longest = max(lens) if lens else 0
+        batch.append(idx)
+    if batch:
+        batches.append(batch)
+    return batches
+
+
+def build_batches(dataset, shuffle, max_tokens=None, max_sentences=None, required_batch_size_multiple=-1, endless=False,
+                  use_batch_by_size=True, world=1, rank=0, devices_cnt=None):
+    """The batch list `SpeechBaseTask.build_dataloader` hands to its DataLoader (tasks/tts/speech_base.py:91-137):
+    budgets are per device and scaled by the device count, batches are built over `dataset.ordered_indices()`,
+    shuffled as whole batches (numpy global RNG, re-shuffled for each of the 1000 repetitions of an endless loader),
+    and under data parallelism every rank keeps `batch[rank::world]` of the batches whose size divides evenly."""
+    devices_cnt = max(1, world if devices_cnt is None else devices_cnt)
+    if required_batch_size_multiple == -1:
+        required_batch_size_multiple = devices_cnt
+    if max_tokens is not None:
+        max_tokens *= devices_cnt
+    if max_sentences is not None:
+        max_sentences *= devices_cnt
+    indices = dataset.ordered_indices()
+    if use_batch_by_size:
+        sampler = batch_by_size(indices, dataset.num_tokens, max_tokens, max_sentences, required_batch_size_multiple)
+    else:
+        sampler = [list(indices[i:i + max_sentences]) for i in range(0, len(indices), max_sentences)]
+
+    def shuffled(bs):
+        np.random.shuffle(bs)
+        return bs
+
+    if shuffle:
+        batches = shuffled(list(sampler))
+        if endless:
+            batches = [b for _ in range(1000) for b in shuffled(list(sampler))]
+    else:
+        batches = [b for _ in range(1000) for b in sampler] if endless else list(sampler)
+    if world > 1:
+        batches = [b[rank::world] for b in batches if len(b) % world == 0]
+    return [[int(i) for i in b] for b in batches]
+
+
 class StutterSpeechDataset:
-    def __init__(self, prefix, hparams, items=None, data_dir=None):
+    def __init__(self, prefix, hparams, items=None, data_dir=None, shuffle=False):
         self.hparams = hparams
         self.prefix = prefix
+        self.shuffle = shuffle
+        self.sort_by_len = bool(hparams.get("sort_by_len", True))
         data_dir = data_dir or hparams["binary_data_dir"]
         if items is not None:
             self.ds, self.avail = items, list(range(len(items)))
+            self.sizes = [1] * len(items)
         else:
             self.ds = IndexedDataset("%s/%s" % (data_dir, prefix))
             ids = hparams.get("test_ids") or []
             self.avail = list(ids) if (prefix == "test" and len(ids) > 0) else list(range(len(self.ds)))
+            # `<prefix>_lengths.npy` = mel frames per item (tasks/tts/dataset_utils.py:27-34); train drops short items
+            lp = "%s/%s_lengths.npy" % (data_dir, prefix)
+            sizes = np.load(lp) if os.path.exists(lp) else np.array([len(self.ds[i]["mel"]) for i in range(len(self.ds))])
+            if prefix == "train" and hparams.get("min_frames", 0) > 0:
+                self.avail = [i for i in self.avail if sizes[i] >= hparams["min_frames"]]
+            self.sizes = [int(sizes[i]) for i in self.avail]
 
     def __len__(self):
         return len(self.avail)
+
+    def size(self, index):
+        return min(self.sizes[index], self.hparams["max_frames"])
+
+    num_tokens = size
+
+    def ordered_indices(self):
+        """utils/commons/dataset_utils.py:202-211: a numpy-RNG permutation, stably sorted by length when `sort_by_len`."""
+        if self.shuffle:
+            indices = np.random.permutation(len(self))
+            if self.sort_by_len:
+                indices = indices[np.argsort(np.array(self.sizes)[indices], kind="mergesort")]
+        else:
+            indices = np.arange(len(self))
+        return indices
 
     def __getitem__(self, index):
         hp = self.hparams

@@ -7,7 +7,7 @@ checkpoints load with strict=True.  forward(x[B,80,T]) -> [B,1,T*prod(upsample_r
 Kernel plan: weight norm is folded on the device when the parameters change (set_weight_norm_fold);
 every Conv1d is one fused set_conv1d launch (leaky-ReLU prologue, bias + residual epilogue);
 ConvTranspose1d runs as `stride` polyphase stride-1 convolutions writing interleaved outputs; the MRF
-mean is a 3-input elementwise kernel.
+sum / mean is folded into the epilogue of each ResBlock's final conv (accumulate + out_div).
 """
 import torch
 from torch import nn
@@ -68,13 +68,15 @@ class ResBlock1(_ResBlockBase):
         self._c1 = [_WNConv(m) for m in self.convs1]
         self._c2 = [_WNConv(m) for m in self.convs2]
 
-    def run(self, x):
+    def run(self, x, **last):
+        """`last` = out / accumulate / out_div of the block's FINAL conv (the MRF sum lives in its epilogue)."""
         k = self.k
-        for c1, c2, d in zip(self._c1, self._c2, self.dil):
+        n = len(self._c1)
+        for i, (c1, c2, d) in enumerate(zip(self._c1, self._c2, self.dil)):
             t = ops.conv1d(x, c1.conv_weight(), c1.mod.bias.data, dil=d, pad=_padding(k, d), pro="lrelu",
                            pro_param=LRELU_SLOPE)
             x = ops.conv1d(t, c2.conv_weight(), c2.mod.bias.data, dil=1, pad=_padding(k, 1), pro="lrelu",
-                           pro_param=LRELU_SLOPE, res=x)
+                           pro_param=LRELU_SLOPE, res=x, **(last if i == n - 1 else {}))
         return x
 
 
@@ -87,11 +89,12 @@ class ResBlock2(_ResBlockBase):
         self.convs = nn.ModuleList([weight_norm(self._wn(channels, kernel_size, d)) for d in dilation[:2]])
         self._c = [_WNConv(m) for m in self.convs]
 
-    def run(self, x):
+    def run(self, x, **last):
         k = self.k
-        for c, d in zip(self._c, self.dil):
+        n = len(self._c)
+        for i, (c, d) in enumerate(zip(self._c, self.dil)):
             x = ops.conv1d(x, c.conv_weight(), c.mod.bias.data, dil=d, pad=_padding(k, d), pro="lrelu",
-                           pro_param=LRELU_SLOPE, res=x)
+                           pro_param=LRELU_SLOPE, res=x, **(last if i == n - 1 else {}))
         return x
 
 
@@ -131,15 +134,15 @@ class HifiGanGenerator(nn.Module):
             up.folded()
             x = ops.conv_transpose1d(x, lambda up=up: up._w, self.ups[i].bias.data, cin, cout, k, u, P,
                                      pro="lrelu", pro_param=LRELU_SLOPE, cache=up._phases)
-            outs = [self.resblocks[i * self.num_kernels + j].run(x) for j in range(self.num_kernels)]
-            if len(outs) > 3:
-                acc = outs[0]
-                for o in outs[1:-1]:
-                    acc = ops.sum_div(acc, o, None, 1.0)
-                x = ops.sum_div(acc, outs[-1], None, float(self.num_kernels))
-            else:
-                x = ops.sum_div(outs[0], outs[1] if len(outs) > 1 else None, outs[2] if len(outs) > 2 else None,
-                                float(self.num_kernels))
+            # MRF (hifigan.py:131-137): xs = rb_0(x); xs += rb_j(x) ...; x = xs / num_kernels.  The running sum lives in
+            # the epilogue of each ResBlock's final conv (first block stores, the others accumulate, the last one also
+            # divides): same summation order and the same division as the reference, no separate pass over [B,C,T].
+            nk = self.num_kernels
+            xs = torch.empty_like(x)
+            for j in range(nk):
+                self.resblocks[i * nk + j].run(x, out=xs, accumulate=j > 0,
+                                               out_div=float(nk) if (j == nk - 1 and nk > 1) else 0.0)
+            x = xs
         # final leaky_relu uses the default slope 0.01 (hifigan.py:138), then conv_post, tanh
         return ops.conv1d(x, self._post.conv_weight(), self.conv_post.bias.data, pad=3, pro="lrelu", pro_param=0.01,
                           act="tanh")

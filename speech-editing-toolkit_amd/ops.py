@@ -147,7 +147,7 @@ def _pick_impl(impl, T_iter, Cout=0, Cin=0, K=1, dil=1):
 
 def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act="none", act_param=0.0, alpha=1.0,
            res=None, mask=None, in_chan_add=None, out=None, accumulate=False, impl=None,
-           T_iter=None, T_out=None, out_stride=1, out_off=0):
+           T_iter=None, T_out=None, out_stride=1, out_off=0, out_div=0.0):
     """Generic fused conv (see SetConv1dArgs in set_amd.h).  x [B,Cin,T_in] -> out [B,Cout,T_out]."""
     _f(x, "x")
     assert isinstance(weight, ConvWeight)
@@ -182,6 +182,8 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
     a.pro, a.act, a.accumulate = PRO[pro], ACT[act], int(bool(accumulate))
     a.impl = {"mfma": IMPL_MFMA, "mfma2": IMPL_MFMA2}.get(impl, IMPL_NAIVE)
     a.pro_param, a.act_param, a.alpha = float(pro_param), float(act_param), float(alpha)
+    a.out_div = float(out_div)
+    assert not (out_div and not accumulate)
     check(_lib.lib().set_conv1d(C.byref(a), _stream()), "set_conv1d")
     return out
 

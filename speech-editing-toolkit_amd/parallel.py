@@ -57,6 +57,60 @@ def sum_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def _forced():
+    """SET_AMD_FORCE_BUCKETER=1 keeps the collective machinery on at world size 1, so that a 1-GPU box still drives every
+    broadcast / all-reduce through RCCL (tests/test_gpu_dist.py)."""
+    return os.environ.get("SET_AMD_FORCE_BUCKETER", "0") == "1"
+
+
+def _collectives_on():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _forced())
+
+
+def broadcast_module_(module, src=0, flat_params=None):
+    """DDP construction semantics (utils/commons/trainer.py:475-479: torch's DistributedDataParallel broadcasts the
+    rank-0 parameters and buffers when it wraps the task, so replicas agree even when every rank initialised with its
+    own random state).  With a flat parameter buffer (training.FlatAdamW) that is ONE collective for all parameters;
+    buffers (the diffusion schedule tables) follow one by one.  Returns the number of bytes sent from `src`."""
+    if not _collectives_on():
+        return 0
+    sent = 0
+    with torch.no_grad():
+        if flat_params is not None:
+            dist.broadcast(flat_params, src=src)
+            sent += flat_params.numel() * flat_params.element_size()
+        else:
+            for p in module.parameters():
+                dist.broadcast(p.data, src=src)
+                sent += p.numel() * p.element_size()
+        for b in module.buffers():
+            if b.numel() > 0:
+                dist.broadcast(b, src=src)
+                sent += b.numel() * b.element_size()
+    return sent
+
+
+def configure_ddp(module, optimizer=None, src=0):
+    """What `Trainer.run_single_process` does for a replica (utils/commons/trainer.py:166-170, 402): wait until every
+    rank has built / restored its model, make the replicas identical to rank 0's, wait again.  `optimizer` (FlatAdamW)
+    supplies the flat parameter buffer and also gets its Adam moments and step counter broadcast so a resumed run agrees
+    on every rank."""
+    if not _collectives_on():
+        return 0
+    dist.barrier()
+    sent = broadcast_module_(module, src, flat_params=getattr(optimizer, "flat_p", None))
+    if optimizer is not None and hasattr(optimizer, "m"):
+        dist.broadcast(optimizer.m, src=src)
+        dist.broadcast(optimizer.v, src=src)
+        n = torch.tensor([optimizer.num_updates], dtype=torch.int64, device=optimizer.m.device)
+        dist.broadcast(n, src=src)
+        optimizer.num_updates = int(n.item())
+        from . import ops
+        ops.bump_weights_epoch()  # packed weight images were built from the pre-broadcast values
+    dist.barrier()
+    return sent
+
+
 def bucketed_all_reduce_sum_(flat, bucket_elems):
     """In-place SUM all-reduce of a flat buffer in a few large buckets (RCCL ring/direct over xGMI is per-link bound,
     so few large messages beat many small ones).  Returns the world size (the caller folds 1/world into its next
@@ -82,12 +136,15 @@ class GradBucketer:
     rest of backward).  `finish()` launches whatever never fired (parameters without gradients: fs.decoder /
     fs.mel_out stay zero) and waits.  Few large buckets: xGMI rings are per-link bound, small messages waste them."""
 
-    def __init__(self, params, flat_g, bucket_elems):
+    def __init__(self, params, flat_g, bucket_elems, force=False):
         self.flat_g = flat_g
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # force: keep the machinery on at world size 1 (a single-rank RCCL group on a 1-GPU box still runs every
+        # all-reduce through the library: tests/test_gpu_dist.py)
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
         self.buckets = []      # [start, end) element ranges, last bucket of the buffer first
         self.launch_log = []   # bucket ids in launch order, "hook" / "finish" (diagnostics + tests)
         self._pending, self._works, self._handles = [], {}, []
+        self.defer, self.bytes_reduced, self.exposed_s, self._owner_of = False, 0, 0.0, {}
         if not self.enabled:
             return
         offs, off = [], 0
@@ -109,37 +166,65 @@ class GradBucketer:
         for i, p in enumerate(params):
             if p.requires_grad:
                 self._members[owner[i]] += 1
+                self._owner_of[id(p)] = owner[i]
                 self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(owner[i])))
         self.reset()
 
     def _make_hook(self, b):
         def hook(_param):
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._launch(b, "hook")
+            self._arrive(b)
         return hook
+
+    def _arrive(self, b):
+        if self.defer or not self.enabled:
+            return
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b, "hook")
+        elif self._pending[b] < 0:
+            # a second backward into the same optimizer step: the bucket has already been SUM-reduced, local
+            # gradients added on top of it would never be exchanged and the replicas would silently diverge
+            raise RuntimeError("GradBucketer: a gradient arrived after its bucket was all-reduced (more than one "
+                               "backward per optimizer step); use reset(defer=True) for gradient accumulation")
+
+    def param_ready(self, param):
+        """Manual arrival for gradients written straight into the flat buffer by a backward kernel (the autograd
+        engine then sees no gradient for that parameter and fires no hook)."""
+        if self.enabled:
+            b = self._owner_of.get(id(param))
+            if b is not None:
+                self._arrive(b)
 
     def _launch(self, b, why):
         s, e = self.buckets[b]
         self._works[b] = dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True)
         self.launch_log.append((b, why))
+        self.bytes_reduced += 4 * (e - s)
 
-    def reset(self):
-        """Call before every backward."""
+    def reset(self, defer=False):
+        """Call before every backward of a new optimizer step.  defer=True (gradient accumulation: several backwards per
+        step, the reference's `accumulate_grad_batches`): nothing is launched from the hooks, finish() reduces every
+        bucket once after the last backward."""
         if self.enabled:
             self._pending = list(self._members)
             self._works = {}
             self.launch_log = []
+            self.defer = bool(defer)
+            self.bytes_reduced = 0
 
     def finish(self):
-        """All buckets reduced (SUM) when this returns; returns the world size (1 when not distributed)."""
+        """All buckets reduced (SUM) when this returns; returns the world size (1 when not distributed).
+        `exposed_s` = host time spent waiting here (communication that backward did not hide)."""
         if not self.enabled:
             return 1
+        import time
+        t0 = time.perf_counter()
         for b in range(len(self.buckets)):
             if b not in self._works:
                 self._launch(b, "finish")
         for w in self._works.values():
             w.wait()
+        self.exposed_s = time.perf_counter() - t0
         return dist.get_world_size()
 
     def remove(self):

@@ -1,10 +1,10 @@
 """Task-level operator surface of the hot path.
 
 `DIFF_DECODERS` and `SpeechDenoiserTask` mirror tasks/speech_editing/spec_denoiser.py:13-62 (registry,
-`build_tts_model`, `run_model` incl. the `mel_out*mask + target*(1-mask)` paste).  Scope of this build
-(SURVEY.md section 8): the inference hot path.  The trainer / dataset / loss code of the reference's task
-base classes (utils/commons/trainer.py, tasks/tts/speech_base.py) is NOT part of this path; `start()` only
-dispatches inference, and training entry points raise NotImplementedError.
+`build_tts_model`, `run_model` incl. the `mel_out*mask + target*(1-mask)` paste), the loss functions of the task base
+classes (tasks/tts/speech_base.py:219-257, speech_editing_base.py:58-108) and the hooks the Trainer counterpart
+(trainer.py) drives: `configure_optimizers`, `train_dataloader` / `val_dataloader`, `_training_step`,
+`validation_step`, `test`.  `start()` dispatches training or `--infer` like utils/commons/base_task.py:203-229.
 """
 import importlib
 import json
@@ -16,6 +16,7 @@ from . import autograd_ops, ops
 from .diffnet import DiffNet
 from .hparams import hparams, set_hparams
 from .spec_denoiser import GaussianDiffusion, GaussianDiffusionNormal
+from .text_encoder import build_token_encoder
 from .vocoder_infer import get_vocoder_cls
 
 DIFF_DECODERS = {
@@ -34,13 +35,16 @@ class SpeechDenoiserTask:
     model_cls = GaussianDiffusion
 
     def __init__(self, build_vocoder=True):
-        # phone set: <binary_data_dir>/phone_set.json (tasks/tts/speech_base.py:40-41); only its length is used
-        ph_path = os.path.join(hparams.get("binary_data_dir", ""), "phone_set.json")
+        # phone set: <binary_data_dir>/phone_set.json through the reference's TokenTextEncoder layout
+        # (tasks/tts/speech_base.py:40-44): 3 reserved ids first, so len() = 3 + the phones in the file.  Without the
+        # file (synthetic batches) the dictionary is `dict_size` anonymous ids and the silence ids come from hparams.
+        ph_path = os.path.join(hparams.get("binary_data_dir", "") or "", "phone_set.json")
         if os.path.exists(ph_path):
-            with open(ph_path) as f:
-                self.token_encoder = json.load(f)
+            self.token_encoder = build_token_encoder(ph_path)
+            self.sil_ids = self.token_encoder.sil_ids()  # speech_editing_base.py:20
         else:
             self.token_encoder = list(range(int(hparams.get("dict_size", 80))))
+            self.sil_ids = [int(i) for i in hparams.get("sil_token_ids", [1, 2, 3])]
         self.vocoder = None
         if build_vocoder and os.path.exists(os.path.join(hparams.get("vocoder_ckpt", ""), "config.yaml")):
             self.vocoder = get_vocoder_cls(hparams["vocoder"])()
@@ -56,14 +60,17 @@ class SpeechDenoiserTask:
 
     def build_model(self):
         self.build_tts_model()
+        if hparams.get("load_ckpt", "") != "":  # speech_base.py:143-144
+            from .ckpt_utils import load_ckpt
+            load_ckpt(self.model, hparams["load_ckpt"])
         return self.model
 
     # ---- losses (tasks/tts/speech_base.py:219-257, tasks/speech_editing/speech_editing_base.py:58-108) ----------
     def word_ids(self, txt_tokens):
-        """word_id = cumsum(is_sil) * (1 - is_sil); silence = tokens listed in hparams['sil_token_ids']
-        (the reference derives them from phone_set.json: phonemes whose first character is not a letter)."""
+        """word_id = cumsum(is_sil) * (1 - is_sil)  (speech_editing_base.py:69-78); silence = the phone set's
+        non-alphabetic tokens incl. the reserved ones (`self.sil_ids`, see __init__)."""
         sil = torch.zeros_like(txt_tokens, dtype=torch.bool)
-        for i in hparams.get("sil_token_ids", [1, 2, 3]):
+        for i in self.sil_ids:
             sil |= txt_tokens == int(i)
         sil = sil.long()
         word_id = (sil.cumsum(-1) * (1 - sil)).contiguous()
@@ -71,6 +78,11 @@ class SpeechDenoiserTask:
 
     def compute_losses(self, output, sample):
         """The loss dict of run_model(infer=False): l1_coarse, ssim_coarse, pdur, wdur, uv, f0 (all on the tape)."""
+        if float(hparams.get("lambda_sent_dur", 0.0)) > 0:
+            # speech_editing_base.py:86-89; every shipped config sets it to 0 -- refuse rather than silently drop a loss
+            raise NotImplementedError("lambda_sent_dur > 0 (the `sdur` loss) is not implemented on this path")
+        if not float(hparams.get("lambda_word_dur", 1.0)) > 0:
+            raise NotImplementedError("lambda_word_dur <= 0: the reference then emits no `wdur` term; not implemented")
         A = autograd_ops
         target = sample["mels"].contiguous()
         B, T, M = target.shape
@@ -127,13 +139,55 @@ class SpeechDenoiserTask:
 
     def training_step(self, sample, optimizer, **kwargs):
         """One optimisation step: forward + losses, backward, gradient all-reduce (if distributed), clip + AdamW."""
-        optimizer.zero_grad()
+        return _optimisation_step(self, sample, optimizer, **kwargs)
+
+    # ---- Trainer hooks (tasks/tts/speech_base.py:59-137,140-205; utils/commons/base_task.py:60-65) -----------------
+    def configure_optimizers(self):
+        """AdamW(lr, betas, weight_decay) + WarmupSchedule + clip_grad_norm as ONE fused flat optimizer
+        (speech_base.py:154-170, base_task.py:129-137)."""
+        from .training import FlatAdamW
+        if hparams.get("scheduler", "warmup") not in ("warmup",):
+            raise NotImplementedError("scheduler %r (only 'warmup' is on this path)" % hparams.get("scheduler"))
+        return FlatAdamW(self.model, lr=hparams["lr"],
+                         betas=(hparams["optimizer_adam_beta1"], hparams["optimizer_adam_beta2"]),
+                         weight_decay=hparams["weight_decay"], clip_grad_norm=hparams["clip_grad_norm"],
+                         warmup_updates=hparams["warmup_updates"])
+
+    def _loader(self, prefix, shuffle, max_tokens, max_sentences, endless, use_batch_by_size=True):
+        from .data import StutterSpeechDataset, build_batches
+        from .trainer import BatchLoader
+        tr = getattr(self, "trainer", None)
+        world, rank = (tr.world, tr.rank) if tr is not None else (1, 0)
+        ds = StutterSpeechDataset(prefix, hparams, shuffle=shuffle)
+        batches = build_batches(ds, shuffle, max_tokens, max_sentences, endless=endless,
+                                use_batch_by_size=use_batch_by_size, world=world, rank=rank)
+        return BatchLoader(ds, batches, hparams.get("seed", 1234))
+
+    def train_dataloader(self):
+        return self._loader(hparams["train_set_name"], True, hparams["max_tokens"], hparams["max_sentences"],
+                            hparams["endless_ds"])
+
+    def val_dataloader(self):
+        bd = hparams.get("binary_data_dir", "") or ""
+        if not os.path.exists(os.path.join(bd, hparams["valid_set_name"] + ".idx")):
+            return None
+        return self._loader(hparams["valid_set_name"], False, hparams["max_valid_tokens"],
+                            hparams["max_valid_sentences"], False, use_batch_by_size=False)
+
+    def _training_step(self, sample, batch_idx, optimizer_idx=-1, **kwargs):
+        """speech_base.py:172-176: (sum of the losses that carry a gradient, loss dict + batch_size)."""
         losses, _ = self.run_model(sample, infer=False, **kwargs)
-        with torch.enable_grad():  # callers may run under a global no_grad
-            total = sum(losses.values())
-        total.backward()
-        lr, _ = optimizer.step()
-        return total.detach(), {k: v.detach() for k, v in losses.items()}, lr
+        with torch.enable_grad():
+            total = sum(v for v in losses.values() if isinstance(v, torch.Tensor) and v.requires_grad)
+        log = {k: v.detach() for k, v in losses.items()}
+        log["batch_size"] = sample["txt_tokens"].shape[0]
+        return total, log
+
+    def validation_step(self, sample, batch_idx):
+        """speech_base.py:193-203 without the plot / vocoder side effects: the loss dict on a validation batch."""
+        losses, _ = self.run_model(sample, infer=False, seed=batch_idx)
+        losses = {k: float(v) for k, v in losses.items()}
+        return {"losses": losses, "total_loss": sum(losses.values()), "nsamples": sample.get("nsamples", 1)}
 
     # ---- dataset-driven inference: `--infer`  (utils/commons/base_task.py:203-229, speech_editing_base.py:151-192) --
     @torch.no_grad()
@@ -200,11 +254,24 @@ class SpeechDenoiserTask:
 
     @classmethod
     def start(cls):
+        """utils/commons/base_task.py:203-229: seed python / numpy, build the Trainer from hparams, fit or test."""
+        import random
+        import numpy as np
+        from .trainer import Trainer
+        random.seed(hparams.get("seed", 1234))
+        np.random.seed(hparams.get("seed", 1234))
+        trainer = Trainer(work_dir=hparams.get("work_dir") or "checkpoints/tmp",
+                          val_check_interval=hparams.get("val_check_interval", 2000),
+                          max_updates=hparams.get("max_updates", 2000000),
+                          num_sanity_val_steps=hparams.get("num_sanity_val_steps", 0) if not hparams.get("validate") else 10000,
+                          accumulate_grad_batches=hparams.get("accumulate_grad_batches", 1),
+                          num_ckpt_keep=hparams.get("num_ckpt_keep", 3), seed=hparams.get("seed", 1234),
+                          log_interval=hparams.get("tb_log_interval", 100))
         if not hparams.get("infer"):
-            raise NotImplementedError("SpeechDenoiserTask.start(): the dataset-driven trainer loop is not part of this "
-                                      "path; use training_step() with batches (tools/train_bench.py)")
-        task = cls()
-        task.test()
+            trainer.fit(cls)
+        else:
+            trainer.test(cls)
+        return trainer
 
 
 class SpeechDenoiserNormalTask(SpeechDenoiserTask):
@@ -275,14 +342,25 @@ class CampNetTask:
         return (losses, output) if not infer else output
 
     def training_step(self, sample, optimizer):
-        optimizer.zero_grad()
-        losses, _ = self.run_model(sample, infer=False)
-        with torch.enable_grad():
+        out = _optimisation_step(self, sample, optimizer)
+        self.global_step += 1
+        return out
+
+
+def _optimisation_step(task, sample, optimizer, **kwargs):
+    """zero_grad -> run_model -> backward -> optimizer.step (base_task.py:101-137 for one optimizer).  A step that
+    fails half way must not leave the zero arena open (later `_gzeros` calls would hand out stale, non-zero slices)."""
+    optimizer.zero_grad()
+    try:
+        losses, _ = task.run_model(sample, infer=False, **kwargs)
+        with torch.enable_grad():  # callers may run under a global no_grad
             total = sum(losses.values())
         total.backward()
-        lr, _ = optimizer.step()
-        self.global_step += 1
-        return total.detach(), {k: v.detach() for k, v in losses.items()}, lr
+    except BaseException:
+        autograd_ops.zero_arena_end()
+        raise
+    lr, _ = optimizer.step()
+    return total.detach(), {k: v.detach() for k, v in losses.items()}, lr
 
 
 def run_task():

@@ -1,0 +1,203 @@
+"""Trainer counterpart for the path's training rows (utils/commons/trainer.py:116-123,140-200,
+256-379,431-485 in the reference): build the task, restore the newest checkpoint, make the data-parallel replicas
+identical, then loop `run_training_batch` with a validation + checkpoint every `val_check_interval` updates.
+
+What is deliberately different from the reference (and why):
+* one process per GPU is started by the launcher (`torchrun`, or `bench.py`'s self-launch); `fit()` joins the process
+  group from the environment instead of calling `mp.spawn` itself -- RCCL wants one process per device either way;
+* every random stream of a step is a function of (hparams['seed'], global_step): the diffusion step ids `t`, the Philox
+  seed of noise / dropout, and the numpy / python / torch generators the dataset's mask generators draw from.  A run
+  resumed from `model_ckpt_steps_N.ckpt` therefore continues with exactly the batches and random numbers the
+  uninterrupted run would have used (the reference reseeds and restarts its endless batch list from the beginning);
+* the optimizer is the fused flat AdamW (training.FlatAdamW) whose state_dict is torch.optim.AdamW's, so checkpoints
+  interchange (`optimizer_states[0]`); clip + schedule are inside its step (base_task.py:129-137).
+No tensorboard, no progress bars, no code snapshots: logging is a dict per `log_interval` updates on rank 0.
+"""
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import ckpt_utils, parallel
+from .hparams import hparams
+
+
+def move_to_device(batch, device):
+    return {k: (v.to(device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+
+
+def step_seed(seed, global_step):
+    """Philox seed / generator seed of one update: a fixed mix of the run seed and the update index."""
+    return (int(seed) * 1000003 + int(global_step) * 7919 + 12345) % (2 ** 31 - 1)
+
+
+class BatchLoader:
+    """`dataset[i]` + `collater` over a list of index batches, addressed by update index.  The dataset's mask
+    generators draw from the global numpy / python / torch generators (utils/spec_aug/time_mask.py:6-93), so these are
+    seeded per batch position: what batch k contains does not depend on how many batches were fetched before it."""
+
+    def __init__(self, dataset, batches, seed):
+        self.dataset, self.batches, self.seed = dataset, batches, int(seed)
+
+    def __len__(self):
+        return len(self.batches)
+
+    def fetch(self, k):
+        idx = self.batches[k % len(self.batches)]
+        s = step_seed(self.seed, k)
+        np.random.seed(s)
+        random.seed(s)
+        torch.manual_seed(s)
+        return self.dataset.collater([self.dataset[i] for i in idx])
+
+
+class Trainer:
+    def __init__(self, work_dir, val_check_interval=2000, max_updates=160000, num_sanity_val_steps=0,
+                 accumulate_grad_batches=1, num_ckpt_keep=3, seed=1234, log_interval=100, device=None, **_unused):
+        self.work_dir = work_dir
+        self.val_check_interval = int(val_check_interval)
+        self.max_updates = int(max_updates)
+        self.num_sanity_val_steps = int(num_sanity_val_steps)
+        self.accumulate_grad_batches = int(accumulate_grad_batches)
+        self.num_ckpt_keep = int(num_ckpt_keep)
+        self.seed = int(seed)
+        self.log_interval = int(log_interval)
+        self.device = device
+        self.global_step, self.current_epoch = 0, 0
+        self.best_val_results = None
+        self.first_epoch = True
+        self.testing = False
+        self.task = self.optimizer = None
+        self.rank, self.world = 0, 1
+        self.history = []  # (global_step, total loss, losses) of every update of this process (tests, logging)
+
+    # ---- entry points (trainer.py:112-137) -----------------------------------------------------------------------
+    def test(self, task_cls):
+        self.testing = True
+        return self.fit(task_cls)
+
+    def fit(self, task_cls):
+        self.rank, self.world, local_rank = parallel.init_from_env()
+        if self.device is None:
+            self.device = torch.device("cuda", local_rank)
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        task = task_cls() if isinstance(task_cls, type) else task_cls
+        task.trainer = self
+        self.task = task
+        self.run_single_process(task)
+        return 1
+
+    def run_single_process(self, task):
+        """trainer.py:140-200: build, restore, optimizer, DDP set-up, then test or train."""
+        if self.testing:
+            task.test()
+            return
+        model = task.build_model()
+        model.to(self.device).train()
+        self.optimizer = task.configure_optimizers()
+        self.global_step, self.current_epoch = ckpt_utils.restore_ckpt(self.work_dir, model, self.optimizer)
+        if self.global_step > 0:
+            ck, _ = ckpt_utils.get_last_checkpoint(self.work_dir)
+            self.best_val_results = ck.get("checkpoint_callback_best")
+        task.global_step = self.global_step
+        # barrier, rank-0 parameter / buffer / optimizer-state broadcast, barrier (trainer.py:166-170,402,475-479)
+        parallel.configure_ddp(model, self.optimizer)
+        self.train()
+
+    # ---- training loop (trainer.py:256-304) -------------------------------------------------------------------------
+    def train(self):
+        task = self.task
+        if self.num_sanity_val_steps > 0:
+            self.evaluate(max_batches=self.num_sanity_val_steps)
+        loader = task.train_dataloader()
+        t_log = time.perf_counter()
+        while self.global_step <= self.max_updates:
+            if self.global_step % self.val_check_interval == 0 and not self.first_epoch:
+                self.run_evaluation()
+            self.run_training_batch(loader)
+            self.first_epoch = False
+            self.global_step += 1
+            task.global_step = self.global_step
+            if self.rank == 0 and self.log_interval > 0 and self.global_step % self.log_interval == 0:
+                gs, total, parts = self.history[-1]
+                total, parts = float(total), {k: float(v) for k, v in parts.items()}
+                dt = time.perf_counter() - t_log
+                t_log = time.perf_counter()
+                print("| step %d loss %.4f %s (%.1f ms/step)" % (self.global_step, total, " ".join(
+                    "%s=%.4f" % kv for kv in sorted(parts.items())), 1e3 * dt / self.log_interval), flush=True)
+        if self.rank == 0:
+            print("| Training end..")
+
+    def run_training_batch(self, loader):
+        """trainer.py:306-379 for one optimizer: `accumulate_grad_batches` forward/backward passes, then clip + AdamW
+        + schedule.  Gradient exchange: launched from autograd hooks during the (single) backward, or after the last
+        backward when accumulating."""
+        task, opt = self.task, self.optimizer
+        acc = self.accumulate_grad_batches
+        from . import autograd_ops
+        opt.zero_grad(accumulate=acc > 1)
+        total, parts = None, {}
+        try:
+            for micro in range(acc):
+                k = self.global_step * acc + micro
+                batch = move_to_device(loader.fetch(k), self.device)
+                seed = step_seed(self.seed, k)
+                B = batch["txt_tokens"].shape[0]
+                t = torch.from_numpy(np.random.default_rng([self.seed, k]).integers(
+                    0, int(task.model.num_timesteps) + 1, size=(B,), dtype=np.int64)).to(self.device) \
+                    if hasattr(task.model, "num_timesteps") else None
+                loss, log = task._training_step(batch, k, seed=seed, t=t)
+                with torch.enable_grad():
+                    (loss / acc if acc > 1 else loss).backward()
+                total = loss.detach() if total is None else total + loss.detach()
+                parts = log  # device scalars: converting here would add a host sync per loss per update
+        except BaseException:
+            autograd_ops.zero_arena_end()
+            raise
+        opt.step()
+        self.history.append((self.global_step, total / acc, parts))
+        if len(self.history) > 1024:
+            del self.history[:512]
+
+    # ---- validation + checkpoints (trainer.py:205-254, 431-470) ------------------------------------------------------
+    def run_evaluation(self):
+        res = self.evaluate(max_batches=hparams.get("eval_max_batches", -1))
+        if self.rank == 0:
+            self.save_checkpoint(logs=res)
+        parallel.barrier()
+        return res
+
+    def evaluate(self, max_batches=None):
+        task = self.task
+        loader = task.val_dataloader()
+        if loader is None or len(loader) == 0:
+            return None
+        if max_batches is None or max_batches < 0:
+            max_batches = len(loader)
+        task.model.eval()
+        tot, n = {}, 0
+        with torch.no_grad():
+            for k in range(min(max_batches, len(loader))):
+                batch = move_to_device(loader.fetch(k), self.device)
+                out = task.validation_step(batch, k)
+                ns = int(batch.get("nsamples", 1))
+                for kk, v in out["losses"].items():
+                    tot[kk] = tot.get(kk, 0.0) + float(v) * ns
+                tot["total_loss"] = tot.get("total_loss", 0.0) + float(out["total_loss"]) * ns
+                n += ns
+        task.model.train()
+        res = {k: round(v / max(n, 1), 4) for k, v in tot.items()}
+        if self.rank == 0:
+            print("| Validation results@%d: %s" % (self.global_step, res), flush=True)
+        return {"val_loss": res.get("total_loss"), "losses": res}
+
+    def save_checkpoint(self, logs=None):
+        cur = None if logs is None else logs.get("val_loss")
+        if cur is not None and (self.best_val_results is None or cur < self.best_val_results):
+            self.best_val_results = cur
+        return ckpt_utils.save_ckpt(self.work_dir, self.task.model, self.optimizer, global_step=self.global_step,
+                                    epoch=self.current_epoch, best=self.best_val_results,
+                                    num_ckpt_keep=self.num_ckpt_keep)

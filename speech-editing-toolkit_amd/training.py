@@ -7,6 +7,8 @@
   buckets, utils/commons/trainer.py:475-479; fs.decoder / fs.mel_out never receive gradients there either);
 * learning rate = WarmupSchedule (utils/nn/schedulers.py:42-57): lr * min(step / warmup, 1), floored at 1e-7.
 """
+import os
+
 import torch
 
 from . import autograd_ops as A
@@ -36,7 +38,8 @@ class FlatAdamW:
         self.clip, self.warmup = clip_grad_norm, warmup_updates
         self.bucket = int(bucket_mb * (1 << 20) // 4)
         # gradient exchange overlapped with backward: buckets launch from autograd hooks (no-op when world == 1)
-        self.bucketer = parallel.GradBucketer(self.params, self.flat_g, self.bucket)
+        self.bucketer = parallel.GradBucketer(self.params, self.flat_g, self.bucket,
+                                              force=os.environ.get("SET_AMD_FORCE_BUCKETER", "0") == "1")
         self.num_updates = 0
         ops.bump_weights_epoch()
 
@@ -44,10 +47,12 @@ class FlatAdamW:
         warm = min(num_updates / self.warmup, 1.0) if self.warmup > 0 else 1.0
         return max(self.lr0 * warm, 1e-7)
 
-    def zero_grad(self):
+    def zero_grad(self, accumulate=False):
+        """Start an optimizer step.  accumulate=True: more than one backward will run before step() (the reference's
+        `accumulate_grad_batches`, utils/commons/trainer.py:331-340); the gradient exchange then waits for step()."""
         self.flat_g.zero_()
         A.zero_arena_begin(self.flat_g.device, self.n)  # this step's zero-initialised gradient temporaries
-        self.bucketer.reset()
+        self.bucketer.reset(defer=accumulate)
         for p in self.params:  # autograd may have re-pointed .grad; restore the views
             if p.grad is None or p.grad.data_ptr() < self.flat_g.data_ptr() or \
                     p.grad.data_ptr() >= self.flat_g.data_ptr() + 4 * self.flat_g.numel():
@@ -95,17 +100,20 @@ class FlatAdamW:
         order = [i for g in groups for i in g["params"]]
         if len(order) != len(self.params):
             raise ValueError("optimizer parameters do not match: %d saved vs %d here" % (len(order), len(self.params)))
+        offs = list(self._offsets())
+        for pos, key in enumerate(order):  # validate everything BEFORE touching m / v: a mismatch must not leave them half-copied
+            st = sd["state"].get(key)
+            if st is not None and tuple(st["exp_avg"].shape) != tuple(offs[pos][2]):
+                raise ValueError("optimizer state %d has shape %s, parameter has %s"
+                                 % (key, tuple(st["exp_avg"].shape), tuple(offs[pos][2])))
         self.m.zero_()
         self.v.zero_()
         steps = 0
-        offs = list(self._offsets())
         for pos, key in enumerate(order):
             st = sd["state"].get(key)
             if st is None:
                 continue
             off, n, shape = offs[pos]
-            if tuple(st["exp_avg"].shape) != tuple(shape):
-                raise ValueError("optimizer state %d has shape %s, parameter has %s" % (key, tuple(st["exp_avg"].shape), tuple(shape)))
             self.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
             self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
             steps = max(steps, int(float(st["step"])))

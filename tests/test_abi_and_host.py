@@ -23,7 +23,7 @@ def test_header_symbols_exported(built_lib):
     assert names == set(_lib.SIGNATURES), names ^ set(_lib.SIGNATURES)
     for n in names:
         assert hasattr(built_lib, n), n
-    assert built_lib.set_abi_version() == 1
+    assert built_lib.set_abi_version() == 2
 
 
 def test_struct_mirror_sizes(built_lib):
@@ -236,3 +236,45 @@ def test_checkpoint_save_resume_and_adamw_state_interchange(tmp_path):
     opt2.load_state_dict(back)
     assert opt2.num_updates == 7 and float(opt2.m[n - 3:n].abs().sum()) == 0.0 and float(opt2.m[:n - 3].abs().sum()) > 0
     assert ckpt_utils.restore_ckpt(str(tmp_path / "empty"), model2, opt2) == (0, 0)
+
+
+def test_phone_set_json_follows_the_reference_token_encoder(tmp_path):
+    """the dictionary size is 3 reserved ids + the phones of phone_set.json, phone ids start at 3, and
+    the silence set of the duration losses is every non-alphabetic token incl. the reserved ones.  Expected values were
+    produced by the reference's own TokenTextEncoder / sil_phonemes() (utils/text/text_encoder.py:107-263) on this list."""
+    import json
+    from set_amd import hparams as H
+    from set_amd import tasks
+    from set_amd.text_encoder import TokenTextEncoder
+    from oracle import weights as Wt
+    phones = ["!", ",", ".", "<BOS>", "<EOS>", "?", "AA0", "AH1", "B", "ZH", "|", "sp", "<UNK>", "'", "EH2"]
+    enc = TokenTextEncoder(phones)
+    assert (len(enc), enc.pad(), enc.eos(), enc.unk(), enc.seg()) == (16, 0, 1, 2, 12)
+    assert enc.sil_ids() == [0, 1, 2, 3, 4, 5, 6, 7, 12, 14]
+    assert enc.encode("AA0 B | xx ZH") == [8, 10, 12, 2, 11]
+    assert enc.decode([6, 8, 0, 3], strip_padding=True) == "<BOS> AA0"
+    # a 77-phone set -> dictionary of 80 -> a reference-layout state_dict (embed_tokens [80,192]) loads STRICTLY
+    bd = tmp_path / "bin"
+    bd.mkdir()
+    json.dump(["P%02d" % i for i in range(72)] + ["!", ",", ".", "?", "|"], open(bd / "phone_set.json", "w"))
+    saved = dict(H.hparams)
+    try:
+        H.hparams.clear()
+        H.hparams.update(base_hparams(timesteps=4, binary_data_dir=str(bd)))
+        task = tasks.SpeechDenoiserTask(build_vocoder=False)
+        assert len(task.token_encoder) == 80 and task.sil_ids == [0, 1, 2, 75, 76, 77, 78, 79]
+        model = task.build_model()
+        assert tuple(model.fs.encoder.embed_tokens.weight.shape) == (80, 192)
+        W = Wt.seeded_weights(Wt.load_manifest("spec_denoiser"), 3)
+        sd = model.state_dict()  # incl. the 16 schedule buffers, as a reference checkpoint holds them
+        sd.update(W)
+        model.load_state_dict(sd, strict=True)
+        txt = torch.tensor([[75, 3, 4, 79, 5, 0, 0]])
+        word_id, n_words = task.word_ids(txt)
+        assert word_id.tolist() == [[0, 1, 1, 0, 2, 0, 0]] and n_words == 2
+        H.hparams["lambda_sent_dur"] = 1.0
+        with pytest.raises(NotImplementedError):
+            task.compute_losses({}, {"mels": torch.zeros(1, 4, 80), "time_mel_masks": torch.zeros(1, 4)})
+    finally:
+        H.hparams.clear()
+        H.hparams.update(saved)

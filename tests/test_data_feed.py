@@ -4,9 +4,12 @@ import os
 import random
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import GOLDEN, base_hparams, load_golden
+import set_amd  # noqa: F401,E402
+from set_amd import data as D  # noqa: E402
 
 
 def test_norm_interp_f0_and_masks_match_reference():
@@ -74,3 +77,55 @@ def test_dataset_items_and_collater_layout():
     b3 = ds3.collater([ds3[i] for i in range(3)])
     assert b3["f0"] is None and b3["uv"] is None and b3["pitch"] is None
     assert torch.equal(b3["mels"], batch["mels"]) and torch.equal(b3["mel2ph"], batch["mel2ph"])
+
+
+def test_batch_by_size_matches_reference_fixture():
+    """utils/commons/dataset_utils.py:65-119: fixture produced by the reference's own batch_by_size
+    (oracle/make_golden.py::batch_by_size_case) on six (sizes, order, budget, multiple) cases."""
+    import json
+    cases = json.load(open(os.path.join(GOLDEN, "batch_by_size.json")))
+    assert len(cases) == 6
+    for c in cases:
+        got = D.batch_by_size(c["order"], lambda i: c["sizes"][i], c["max_tokens"], c["max_sentences"], c["mult"])
+        assert got == c["batches"]
+        flat = [i for b in got for i in b]
+        assert flat == c["order"]                                   # a partition of the ordered indices, in order
+        if c["max_sentences"]:
+            assert max(len(b) for b in got) <= c["max_sentences"]
+        if c["max_tokens"]:
+            assert all(len(b) * max(c["sizes"][i] for i in b) <= c["max_tokens"] for b in got)
+    with pytest.raises(AssertionError):
+        D.batch_by_size([0], lambda i: 500, max_tokens=400)
+
+
+def test_build_batches_striding_and_loader_is_position_seeded():
+    """tasks/tts/speech_base.py:91-137: budgets scale with the device count, each rank keeps batch[rank::world] of the
+    evenly divisible batches; trainer.BatchLoader re-seeds the mask generators per batch position, so batch k is the same
+    whether or not batches 0..k-1 were fetched (what makes a resumed run continue exactly)."""
+    import numpy as np
+    from set_amd.trainer import BatchLoader
+    hp = base_hparams(binary_data_dir=os.path.join(GOLDEN, "binary_tiny"), infer=False, test_ids=[], max_frames=1548,
+                      max_input_tokens=1550, frames_multiple=1, sort_by_len=True, min_frames=0)
+    ds = D.StutterSpeechDataset("test", hp, shuffle=True)
+    assert [ds.num_tokens(i) for i in range(len(ds))] == [40, 56, 33]
+    np.random.seed(3)
+    order = ds.ordered_indices().tolist()
+    assert order == [2, 0, 1]                                       # sorted by length (stable) after the permutation
+    np.random.seed(3)
+    one = D.build_batches(ds, True, max_tokens=1000, max_sentences=2, endless=False, world=1, rank=0)
+    assert sorted(sorted(b) for b in one) == [[0, 2], [1]]
+    np.random.seed(3)
+    r0 = D.build_batches(ds, True, max_tokens=1000, max_sentences=1, endless=False, world=2, rank=0)
+    np.random.seed(3)
+    r1 = D.build_batches(ds, True, max_tokens=1000, max_sentences=1, endless=False, world=2, rank=1)
+    # max_sentences 1 x 2 devices = global batches of 2, multiple of 2: [2,0] is split, the odd remainder [1] is dropped
+    assert len(r0) == len(r1) == 1 and sorted(r0[0] + r1[0]) == [0, 2]
+    np.random.seed(3)
+    endless = D.build_batches(ds, True, max_tokens=1000, max_sentences=2, endless=True)
+    assert len(endless) == 2000
+    ld = BatchLoader(ds, one, seed=1234)
+    a = ld.fetch(1)
+    ld.fetch(0)
+    b = ld.fetch(1)
+    assert torch.equal(a["time_mel_masks"], b["time_mel_masks"]) and torch.equal(a["mels"], b["mels"])
+    assert set(a) >= {"txt_tokens", "mels", "mel2ph", "f0", "uv", "time_mel_masks", "spk_embed", "nsamples"}

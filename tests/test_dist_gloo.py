@@ -138,3 +138,81 @@ def test_single_process_is_identity():
     assert parallel.bucketed_all_reduce_sum_(f, 2) == 1 and torch.equal(f, torch.ones(5))
     bk = parallel.GradBucketer([torch.nn.Parameter(torch.ones(5))], f, 2)
     assert not bk.enabled and bk.finish() == 1
+
+
+def _ddp_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import set_amd  # noqa: F401
+    from set_amd import parallel
+    from set_amd.training import FlatAdamW
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(100 + rank)  # rank-divergent initial weights ON PURPOSE
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    model.register_buffer("table", torch.randn(7))
+    opt = FlatAdamW(model, lr=1e-3, warmup_updates=10, bucket_mb=1e-4)
+    opt.m.fill_(float(rank + 1))
+    opt.num_updates = 5 * (rank + 1)
+    before = opt.flat_p.clone()
+    sent = parallel.configure_ddp(model, opt)
+    # every replica now holds rank 0's parameters, buffers, Adam moments and step counter
+    torch.manual_seed(100)
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    ref_table = torch.randn(7)
+    same = all(torch.equal(a, b) for a, b in zip(model.parameters(), ref.parameters())) and torch.equal(model.table, ref_table)
+    views_ok = all(p.data_ptr() >= opt.flat_p.data_ptr() and p.data_ptr() < opt.flat_p.data_ptr() + 4 * opt.flat_p.numel()
+                   for p in model.parameters())
+    # gradient accumulation guard: a second backward after the buckets were reduced must raise, defer=True must not
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(rank))
+    opt.zero_grad()
+    model(x).pow(2).sum().backward()
+    raised = False
+    try:
+        model(x).pow(2).sum().backward()
+    except RuntimeError as e:
+        raised = "more than one backward" in str(e)
+    opt.bucketer.finish()
+    opt.zero_grad(accumulate=True)
+    model(x).pow(2).sum().backward()
+    model(x).pow(2).sum().backward()
+    n_hook = sum(1 for _, why in opt.bucketer.launch_log if why == "hook")
+    world_ret = opt.bucketer.finish()
+    g_sum = opt.flat_g.clone()
+    # expected: sum over ranks of 2 x the local gradient
+    want = torch.zeros_like(g_sum)
+    for r in range(world):
+        m2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+        m2.load_state_dict(ref.state_dict())
+        xr = torch.randn(4, 6, generator=torch.Generator().manual_seed(r))
+        (2 * m2(xr).pow(2).sum()).backward()
+        want[:opt.n] += torch.cat([p.grad.reshape(-1) for p in m2.parameters()])
+    q.put((rank, same, views_ok, sent, bool((before != opt.flat_p).any()), float(opt.m[0]), opt.num_updates, raised, n_hook,
+           world_ret, float((g_sum - want).abs().max()), opt.bucketer.bytes_reduced))
+    dist.destroy_process_group()
+
+
+def test_configure_ddp_broadcasts_rank0_state_and_accumulation_is_guarded_world2():
+    """Reference: DistributedDataParallel(task) + dist.barrier() (utils/commons/trainer.py:166-170,402,475-479) make
+    rank-divergent replicas identical to rank 0; ADVICE r1: a second backward per step must not double-reduce."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, views_ok, sent, changed, m0, n_upd, raised, n_hook, world_ret, err, reduced in res:
+        assert same and views_ok
+        assert sent == 4 * (256 + 7)            # one flat parameter buffer (padded to 256) + the buffer
+        assert changed == (rank == 1)           # rank 1's own init was overwritten, rank 0's was not
+        assert m0 == 1.0 and n_upd == 5         # optimizer state follows rank 0 too
+        assert raised                           # second backward without accumulate=True is refused
+        assert n_hook == 0 and world_ret == 2   # accumulate=True: nothing launched from hooks, finish() reduces
+        assert err < 1e-5
+        assert reduced == 4 * 256

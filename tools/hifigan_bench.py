@@ -52,13 +52,16 @@ if os.environ.get("HSTAGES"):
         Tn = x.shape[2]
         print("stage %d  up %4d->%4d k%-2d s%d  T=%6d : %7.2f ms  %6.1f TF/s" % (
             i, cin, cout, k, u, Tn, ms, 2.0 * B * cin * cout * k / u * Tn / ms / 1e9))
-        outs = []
-        for j in range(g.num_kernels):
-            rb = g.resblocks[i * g.num_kernels + j]
-            ms, o = timed(lambda: rb.run(x))
+        xs = torch.empty_like(x)
+        nk = g.num_kernels
+        for j in range(nk):
+            rb = g.resblocks[i * nk + j]
+            # the MRF sum / mean rides in the epilogue of the block's final conv (timed 3x into the same buffer: the
+            # accumulated values are garbage for j > 0, so the stage output is recomputed once below)
+            ms, _ = timed(lambda: rb.run(x, out=xs, accumulate=j > 0, out_div=float(nk) if j == nk - 1 else 0.0))
             fl = 2.0 * B * cout * cout * rb.k * Tn * 6
             print("stage %d  resblock C=%3d k=%-2d dil=%s T=%6d : %7.2f ms  %6.1f TF/s  (%.2f ms/conv)" % (
                 i, cout, rb.k, rb.dil, Tn, ms, fl / ms / 1e9, ms / 6))
-            outs.append(o)
-        ms, x = timed(lambda: ops.sum_div(outs[0], outs[1], outs[2], 3.0))
-        print("stage %d  MRF mean                          : %7.2f ms  %6.0f GB/s" % (i, ms, 4 * x.numel() * 4 / ms / 1e6))
+        for j in range(nk):
+            g.resblocks[i * nk + j].run(x, out=xs, accumulate=j > 0, out_div=float(nk) if j == nk - 1 else 0.0)
+        x = xs
