@@ -59,6 +59,14 @@ extern "C" {
                             Cout >= 384 / >= 192 / else); needs the image of set_pack_conv_weight_v2;
                             receptive field (K-1)*|dil| <= 64 */
 
+#define SET_IMPL_BF16 4  /* bf16 MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulate / epilogue / HBM tensors; `w` =
+                            the image of set_pack_conv_weight_bf16; stride-1 output only.  The training rows' "bf16"
+                            arithmetic (BASELINE configs[1]; the reference's autocast hooks: utils/commons/trainer.py:325,343) */
+
+/* operand type selector of the training GEMMs */
+#define SET_DTYPE_F32 0
+#define SET_DTYPE_BF16 1
+
 int set_abi_version(void);
 /* last hip error string of the calling thread's most recent failing call (host pointer, static storage) */
 const char *set_last_error(void);
@@ -328,6 +336,22 @@ int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream);
 int set_conv1d_wgrad(const float *g, const float *x, const float *chan_add, float *dw, int32_t B, int32_t Cin,
                      int32_t Cout, int32_t K, int32_t dil, int32_t pad, int32_t T, int32_t T_in, int32_t pro,
                      float pro_param, int32_t impl, void *stream);
+
+/* Deterministic weight gradient (same arithmetic contract as set_conv1d_wgrad, MFMA path): the frames are cut into S
+ * slices, slice z writes its partial dW to scratch[z][Cout][Cin][K] with plain stores, then dW += sum_z scratch[z] in
+ * slice order -- no atomics, bit-identical from run to run.  dtype SET_DTYPE_F32: fp32 MFMA operands; SET_DTYPE_BF16:
+ * g and x rounded to bf16 (RNE) on the way into LDS, fp32 accumulation.  `scratch` must hold
+ * set_conv1d_wgrad_scratch_floats(...) floats and may be reused by the next call on the same stream. */
+int64_t set_conv1d_wgrad_scratch_floats(int32_t B, int32_t Cin, int32_t Cout, int32_t K, int32_t T, int32_t dtype);
+int set_conv1d_wgrad_det(const float *g, const float *x, const float *chan_add, float *dw, int32_t B, int32_t Cin,
+                         int32_t Cout, int32_t K, int32_t dil, int32_t pad, int32_t T, int32_t T_in, int32_t pro,
+                         float pro_param, int32_t dtype, float *scratch, int64_t scratch_floats, void *stream);
+
+/* bf16 weight image for SET_IMPL_BF16: wp[tap][chunk][row][32] bf16, row < Cout rounded up to 128, chunk < ceil(Cin/32),
+ * zero padded; ..._size returns the number of bf16 ELEMENTS (2 bytes each). */
+int64_t set_packed_conv_weight_bf16_size(int32_t Cout, int32_t Cin, int32_t K);
+int set_pack_conv_weight_bf16(const float *w, void *wp, int32_t Cout, int32_t Cin, int32_t K, int64_t w_base,
+                              int64_t w_sco, int64_t w_sci, int64_t w_stap, void *stream);
 /* out[c] += sum_{b,t} x[b][c][t]   (bias gradients) */
 int set_channel_sum(const float *x, float *out, int32_t B, int32_t C, int32_t T, void *stream);
 /* out[row] = scale * sum_t x[row][t] */

@@ -15,14 +15,15 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_PKG, "libset_amd.so")
-SOURCES = ["conv1d.hip", "glue.hip", "diffnet.hip", "train.hip", "attention.hip"]
+SOURCES = ["conv1d.hip", "glue.hip", "diffnet.hip", "train.hip", "attention.hip", "bf16.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
 # constants mirrored from set_amd.h
 OK, E_INVALID, E_UNSUPPORTED, E_LAUNCH = 0, -1, -2, -3
 ACT = dict(none=0, relu=1, gelu=2, tanh=3, softplus=4, mish=5, lrelu=6)
 PRO = dict(none=0, lrelu=1, div=2)
-IMPL_NAIVE, IMPL_MFMA, IMPL_MFMA2 = 1, 2, 3
+IMPL_NAIVE, IMPL_MFMA, IMPL_MFMA2, IMPL_BF16 = 1, 2, 3, 4
+DTYPE_F32, DTYPE_BF16 = 0, 1
 
 c_f32p = C.POINTER(C.c_float)
 c_i64p = C.POINTER(C.c_int64)
@@ -153,6 +154,10 @@ SIGNATURES = {
     "set_mask_fill_chan": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _V]),
     "set_masked_channel_sum": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _V]),
     "set_conv1d_wgrad": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _V]),
+    "set_conv1d_wgrad_scratch_floats": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32]),
+    "set_conv1d_wgrad_det": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _V, _I64, _V]),
+    "set_packed_conv_weight_bf16_size": (_I64, [_I32, _I32, _I32]),
+    "set_pack_conv_weight_bf16": (C.c_int, [_V, _V, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _V]),
     "set_channel_sum": (C.c_int, [_V, _V, _I32, _I32, _I32, _V]),
     "set_row_sum": (C.c_int, [_V, _V, _I64, _I32, _F, _V]),
     "set_conv_epilogue_bwd": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _F, _V]),

@@ -75,6 +75,29 @@ def _wgrad_impl(T):
     return IMPL_MFMA if T >= 16 else IMPL_NAIVE
 
 
+_WG_SCRATCH = {}  # device -> slice-partial buffer of the deterministic weight-gradient path (reused: stream-ordered)
+DETERMINISTIC_WGRAD = True  # False: the round-1 split-K kernel with fp32 atomics (order-dependent bits)
+
+
+def conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro=0, pro_param=0.0, dw_ptr=None):
+    """dW[co][ci][tap] += sum_{b,t} G[b][co][t] * P(X[b][ci][t + tap*dil - pad] + chan_add[b][ci]).  MFMA shapes go
+    through set_conv1d_wgrad_det (per-slice partial sums reduced in slice order: bit-stable, no atomics) with bf16 or
+    fp32 operands according to ops.compute_dtype(); tiny T uses the one-thread-per-weight kernel."""
+    ptr = C.c_void_p(dw.data_ptr() if dw_ptr is None else dw_ptr)
+    if T < 16 or not DETERMINISTIC_WGRAD:
+        check(L().set_conv1d_wgrad(_p(g), _p(x), _p(chan_add), ptr, B, Cin, Cout, K, dil, pad, T, T_in, pro,
+                                   float(pro_param), _wgrad_impl(T), _stream()), "set_conv1d_wgrad")
+        return
+    dt = _lib.DTYPE_BF16 if (ops.compute_dtype() == "bf16" and Cout >= 32 and Cin >= 32) else _lib.DTYPE_F32
+    need = L().set_conv1d_wgrad_scratch_floats(B, Cin, Cout, K, T, dt)
+    buf = _WG_SCRATCH.get(g.device)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(int(need * 1.25) + 1024, dtype=torch.float32, device=g.device)
+        _WG_SCRATCH[g.device] = buf
+    check(L().set_conv1d_wgrad_det(_p(g), _p(x), _p(chan_add), ptr, B, Cin, Cout, K, dil, pad, T, T_in, pro,
+                                   float(pro_param), dt, _p(buf), buf.numel(), _stream()), "set_conv1d_wgrad_det")
+
+
 # --------------------------------------------------------------------------------------------------
 class _Conv1dFn(torch.autograd.Function):
     @staticmethod
@@ -96,9 +119,12 @@ class _Conv1dFn(torch.autograd.Function):
         dy = dy.contiguous()
         B, Cout, T = dy.shape
         Cin, T_in = x.shape[1], x.shape[2]
-        g = torch.empty_like(dy)
-        check(L().set_conv_epilogue_bwd(_p(dy), _p(y), _p(mask), _p(g), B, Cout, T, ACT[act], float(alpha), _stream()),
-              "set_conv_epilogue_bwd")
+        if act == "none" and mask is None and alpha == 1.0:
+            g = dy  # identity epilogue: no kernel, no copy (every DiffNet layer conv; 14 us x ~700 launches per step)
+        else:
+            g = torch.empty_like(dy)
+            check(L().set_conv_epilogue_bwd(_p(dy), _p(y), _p(mask), _p(g), B, Cout, T, ACT[act], float(alpha), _stream()),
+                  "set_conv_epilogue_bwd")
         dres = None
         if has_res and ctx.needs_input_grad[4]:
             if act == "none" and alpha == 1.0:
@@ -121,8 +147,8 @@ class _Conv1dFn(torch.autograd.Function):
             # plain [Cout,Cin,K] rows, possibly a row slice of a larger parameter (packed q/k/v projections)
             assert cw.stap == 1 and cw.sci == cw.K and cw.sco == cw.Cin * cw.K, "plain conv layout"
             dw = _gzeros(w.shape, dy.device)
-            check(L().set_conv1d_wgrad(_p(g), _p(x), _p(chan_add), dw.data_ptr() + 4 * cw.base, B, Cin, Cout, cw.K, dil, pad, T, T_in, PRO[pro],
-                                       float(pro_param), _wgrad_impl(T), _stream()), "set_conv1d_wgrad")
+            conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, cw.K, dil, pad, T, T_in, PRO[pro], pro_param,
+                       dw_ptr=dw.data_ptr() + 4 * cw.base)
         if has_bias and ctx.needs_input_grad[2]:
             db = _gzeros(Cout, dy.device)
             check(L().set_channel_sum(_p(g), _p(db), B, Cout, T, _stream()), "set_channel_sum")
@@ -469,8 +495,7 @@ class _DiffNetStackFn(torch.autograd.Function):
             check(L().set_res_skip_bwd(_p(dx), _p(dskip), _p(dxr), _p(d_o), B, C_, T, _stream()), "set_res_skip_bwd")
             # output_projection (1x1, 256 -> 512)
             dw_out = _zeros_like(layer.output_projection.weight)
-            check(L().set_conv1d_wgrad(_p(d_o), _p(z_all[l]), None, _p(dw_out), B, C_, 2 * C_, 1, 1, 0, T, T, 0, 0.0, impl_w,
-                                       _stream()), "set_conv1d_wgrad")
+            conv_wgrad(d_o, z_all[l], None, dw_out, B, C_, 2 * C_, 1, 1, 0, T, T)
             db_out = _gzeros(2 * C_, dev)
             check(L().set_channel_sum(_p(d_o), _p(db_out), B, 2 * C_, T, _stream()), "set_channel_sum")
             dz = ops.conv1d(d_o, layer._w_out.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T)
@@ -479,8 +504,7 @@ class _DiffNetStackFn(torch.autograd.Function):
             check(L().set_gate_bwd(_p(y_all[l]), _p(dz), _p(dy), B, C_, T, _stream()), "set_gate_bwd")
             # conditioner_projection (1x1, H -> 512): y = ... + W_cond cond + b_cond
             dw_cond = _zeros_like(layer.conditioner_projection.weight)
-            check(L().set_conv1d_wgrad(_p(dy), _p(cond), None, _p(dw_cond), B, H, 2 * C_, 1, 1, 0, T, T, 0, 0.0, impl_w,
-                                       _stream()), "set_conv1d_wgrad")
+            conv_wgrad(dy, cond, None, dw_cond, B, H, 2 * C_, 1, 1, 0, T, T)
             db = _gzeros(2 * C_, dev)
             check(L().set_channel_sum(_p(dy), _p(db), B, 2 * C_, T, _stream()), "set_channel_sum")  # = db_cond = db_dil
             if need_cond:
@@ -489,8 +513,7 @@ class _DiffNetStackFn(torch.autograd.Function):
             # dilated conv (k=3) on x_l + d_l
             dl = dmat[:, l * C_:(l + 1) * C_].contiguous()
             dw_dil = _zeros_like(layer.dilated_conv.weight)
-            check(L().set_conv1d_wgrad(_p(dy), _p(x_all[l]), _p(dl), _p(dw_dil), B, C_, 2 * C_, 3, dil, dil, T, T, 0, 0.0,
-                                       impl_w, _stream()), "set_conv1d_wgrad")
+            conv_wgrad(dy, x_all[l], dl, dw_dil, B, C_, 2 * C_, 3, dil, dil, T, T)
             dxd = ops.conv1d(dy, layer._w_dil.transposed(), None, dil=-dil, pad=-dil, T_iter=T, T_out=T)
             ddl = torch.empty(B, C_, dtype=torch.float32, device=dev)
             check(L().set_row_sum(_p(dxd), _p(ddl), B * C_, T, 1.0, _stream()), "set_row_sum")

@@ -1,0 +1,537 @@
+// bf16-operand path of the training rows (BASELINE configs[1] "1xMI355X bf16"; the reference's AMP hooks are
+// utils/commons/trainer.py:6,110,325,343-346 -- torch.autocast around the forward, fp32 master weights).
+//
+// What is bf16 here: the A / B fragments of the MFMA (v_mfma_f32_32x32x16_bf16, 16x the rate of the f32-input MFMA).
+// Everything else stays fp32: activations and gradients in HBM, accumulation, bias / activation / residual epilogues,
+// master weights and optimizer state.  Activations are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on their way into LDS,
+// weights once per optimizer step into a packed bf16 image.  At these shapes the GEMMs stop being the bound: the
+// kernels below are sized to run near the rate at which their fp32 operands can be streamed from HBM / L2.
+//
+//   conv1d_bf16_kernel       forward conv and (with transposed weight addressing + negated dilation) input gradient
+//   conv1d_wgrad_bf16_kernel weight gradient, reduction over frames, per-slice partial sums (no atomics)
+//   wgrad_reduce_kernel      dW += sum over slices, in slice order  ->  run-to-run bit-stable gradients
+//
+// MFMA operand maps (32x32x16, cdna_hip_programming.md section 3): lane l holds A[i = l & 31][k = 8*(l>>5) .. +7] and
+// B[k = 8*(l>>5) .. +7][j = l & 31] as 8 consecutive bf16 (one 16-byte LDS read); C/D as the f32 32x32 MFMA.  A and B use
+// the SAME lane -> k map, so the contraction is right for any permutation of k the hardware applies inside an instruction.
+#include "common.h"
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ unsigned short bf16_bits(float x) {
+    return __builtin_bit_cast(unsigned short, (__bf16)x);
+}
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+static inline int round_up_i(int x, int m) { return (x + m - 1) / m * m; }
+
+// prologue with the code resolved at compile time: inside the staging loops a run-time `switch (pro)` per element turns
+// into a scalar branch tree (+ an IEEE division sequence) per element -- measured 7.5 us per 32-channel stage against
+// 0.3 us of MFMA work.  The callers switch ONCE per stage and instantiate the loop per code.
+template <int PRO>
+__device__ __forceinline__ float pro_c(float v, float p) {
+    if constexpr (PRO == SET_PRO_LRELU) return v > 0.0f ? v : v * p;
+    else if constexpr (PRO == SET_PRO_DIV) return v / p;
+    else return v;
+}
+template <int N> using ic = std::integral_constant<int, N>;
+
+// =====================================================================================================================
+// packed bf16 weight image:  wp[tap][chunk][row][32]   (row < CoutP = Cout rounded to 128, chunk < CinP/32, zero padded)
+// One (tap, chunk, 64..128-row block) is a contiguous run of 64-byte rows: a block copies it to LDS with 16-byte units.
+// =====================================================================================================================
+__global__ void __launch_bounds__(256) pack_conv_weight_bf16_kernel(const float *w, unsigned short *wp, int Cout, int Cin, int K,
+                                                                    int CoutP, int CinP, int64_t total, int64_t w_base,
+                                                                    int64_t w_sco, int64_t w_sci, int64_t w_stap) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int kk = (int)(idx & 31);
+    int64_t r = idx >> 5;
+    const int row = (int)(r % CoutP);
+    r /= CoutP;
+    const int nchunk = CinP / 32;
+    const int chunk = (int)(r % nchunk);
+    const int tap = (int)(r / nchunk);
+    const int ci = chunk * 32 + kk;
+    float v = 0.0f;
+    if (row < Cout && ci < Cin) v = w[w_base + (int64_t)row * w_sco + (int64_t)ci * w_sci + (int64_t)tap * w_stap];
+    wp[idx] = bf16_bits(v);
+}
+
+// =====================================================================================================================
+// conv1d, bf16 operands.  Block = 4 waves arranged WM x WN, wave tile 64 rows x 64 frames (2 x 2 accumulators of
+// 32x32), block tile MB = 64*WM rows x NB = 64*WN frames.  One pipeline stage = KCH input channels x TG taps:
+//   As[tl][row][KCH]  bf16, the weight rows of the block for tap tg0+tl          (copied from the packed image)
+//   Bs[frame][KCH]    bf16, NB + halo frames of the input, prologue applied, rounded once per chunk of channels
+// rows padded by 16 bytes: a 16-byte fragment read of 16 consecutive rows then hits 64 distinct banks.
+// The loads of stage s+1 are issued (into registers) before the MFMAs of stage s; two barriers per stage.
+// =====================================================================================================================
+// Two shapes of stage: KCH = 32 with up to TGM = 4 taps (A tile <= 4 * 128 * 80 B = 40 KiB; every K, per-channel add
+// supported) and KCH = 64 with one tap for the 1x1 convs (twice the MFMAs per pair of barriers; no halo rows, no
+// per-channel add -- the staging registers of a 64-channel stage leave no room for them).
+template <int WM, int WN, int KCH, int TGM, bool HALO, bool ADD>
+__global__ void __launch_bounds__(256, 2) conv1d_bf16_kernel(SetConv1dArgs a, int lo, int halo, int CinP, int CoutP) {
+    constexpr int BF_TG_MAX = TGM;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int MB = 64 * WM, NB = 64 * WN;
+    constexpr int ROWB = KCH * 2 + 16;              // bytes per LDS row
+    constexpr int CPT = KCH / 2;                    // channels per thread per staging pass (2 channel groups)
+    constexpr int NPASS = NB / 128 + (HALO ? 1 : 0);  // frame passes of 128 rows (last one = halo rows)
+    constexpr int AU_MAX = BF_TG_MAX * (KCH / 32) * MB * 4 / 256;  // 16-byte units of the A tile per thread
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, t0 = blockIdx.x * NB, r0 = blockIdx.y * MB;
+    const int R = NB + halo;                        // frame rows of the B tile
+    unsigned char *As = smem_raw;                                   // [TG][MB][ROWB]
+    unsigned char *Bs = smem_raw + BF_TG_MAX * MB * ROWB;           // [R][ROWB]
+    const unsigned short *wimg = reinterpret_cast<const unsigned short *>(a.w);
+    const float *inb = a.in + (int64_t)b * a.in_bs;
+    const bool has_add = ADD && a.in_chan_add != nullptr;
+    const float *addp = has_add ? a.in_chan_add + (int64_t)b * a.Cin : inb;  // dummy stays a valid address
+    const int nchunk32 = CinP / 32;
+    const int nchunks = (CinP + KCH - 1) / KCH;
+    const int ngroups = (a.K + BF_TG_MAX - 1) / BF_TG_MAX;
+    const int nstages = nchunks * ngroups;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+
+    // ---- staging registers (one stage ahead) ----
+    float pv[NPASS][CPT], pa[ADD ? CPT : 1];
+    u32x4 au[AU_MAX];
+    const int sf = tid & 127, scg = tid >> 7;  // B staging: frame row sf (+128*pass), channel group scg
+
+    // raw-buffer addressing (common.h): one VGPR byte offset per frame pass + a scalar byte offset per channel (the
+    // thread's channel group is wave-uniform: waves 0,1 -> group 0, waves 2,3 -> group 1)
+    const rsrc_t d_in = make_rsrc(inb);
+    const rsrc_t d_add = make_rsrc(addp);
+    const int scg_u = __builtin_amdgcn_readfirstlane(scg);
+    auto issue_b = [&](int c0) {
+        if constexpr (ADD) {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) pa[k] = buf_load(d_add, 0u, (unsigned)min(c0 + scg_u * CPT + k, a.Cin - 1) * 4u);
+        }
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int ti = t0 + lo + p * 128 + sf;
+            const unsigned vo = (unsigned)min(max(ti, 0), a.T_in - 1) * 4u;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int cc = min(c0 + scg_u * CPT + k, a.Cin - 1);
+                pv[p][k] = buf_load(d_in, vo, (unsigned)(cc * (int)a.in_cs) * 4u);
+            }
+        }
+    };
+    auto commit_b = [&](auto PROC, int c0) __attribute__((always_inline)) {
+        constexpr int kPro = decltype(PROC)::value;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int row = p * 128 + sf;
+            const int ti = t0 + lo + row;
+            const bool tv = ti >= 0 && ti < a.T_in;
+            float x[CPT];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                float v = pv[p][k];
+                if constexpr (ADD) v = has_add ? v + pa[k] : v;
+                v = pro_c<kPro>(v, a.pro_param);                          // unconditional, straight-line
+                x[k] = (tv && c0 + scg_u * CPT + k < a.Cin) ? v : 0.0f;   // select, no branch
+            }
+            if (row < R) {
+#pragma unroll
+                for (int q = 0; q < CPT / 8; ++q) {
+                    u32x4 u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) u[e] = pack_bf16(x[8 * q + 2 * e], x[8 * q + 2 * e + 1]);
+                    *reinterpret_cast<u32x4 *>(Bs + row * ROWB + (scg * CPT + 8 * q) * 2) = u;
+                }
+            }
+        }
+    };
+    // A tile of stage (chunk c0, taps tg0 .. tg0+tgn-1): unit u -> (tap tl, 32-channel sub-chunk h, row, 16-byte part)
+    auto issue_a = [&](int c0, int tg0, int tgn) {
+        const int units = tgn * (KCH / 32) * MB * 4;
+#pragma unroll
+        for (int q = 0; q < AU_MAX; ++q) {
+            int u = tid + 256 * q;
+            u = u < units ? u : 0;  // clamped duplicate load; not committed
+            const int part = u & 3, row = (u >> 2) % MB, h = ((u >> 2) / MB) % (KCH / 32), tl = (u >> 2) / (MB * (KCH / 32));
+            const int ch32 = min(c0 / 32 + h, nchunk32 - 1);
+            const int64_t e = ((((int64_t)(tg0 + tl) * nchunk32 + ch32) * CoutP + r0 + row) * 32 + part * 8);
+            au[q] = *reinterpret_cast<const u32x4 *>(wimg + e);
+        }
+    };
+    auto commit_a = [&](int c0, int tgn) {
+        const int units = tgn * (KCH / 32) * MB * 4;
+#pragma unroll
+        for (int q = 0; q < AU_MAX; ++q) {
+            const int u = tid + 256 * q;
+            if (u < units) {
+                const int part = u & 3, row = (u >> 2) % MB, h = ((u >> 2) / MB) % (KCH / 32), tl = (u >> 2) / (MB * (KCH / 32));
+                u32x4 v = au[q];
+                if (c0 + 32 * h >= CinP) v = (u32x4){0u, 0u, 0u, 0u};  // KCH = 64 over an odd number of 32-channel chunks
+                *reinterpret_cast<u32x4 *>(As + (tl * MB + row) * ROWB + h * 64 + part * 16) = v;
+            }
+        }
+    };
+    auto stage_of = [&](int s, int &c0, int &tg0, int &tgn) {
+        const int ch = s / ngroups, g = s % ngroups;
+        c0 = ch * KCH;
+        tg0 = g * BF_TG_MAX;
+        tgn = min(BF_TG_MAX, a.K - tg0);
+    };
+
+    int c0, tg0, tgn;
+    stage_of(0, c0, tg0, tgn);
+    issue_b(c0);
+    issue_a(c0, tg0, tgn);
+    for (int s = 0; s < nstages; ++s) {
+        stage_of(s, c0, tg0, tgn);
+        __syncthreads();  // MFMAs of the previous stage are done with the tiles
+        if (tg0 == 0) {
+            switch (a.pro) {
+                case SET_PRO_LRELU: commit_b(ic<SET_PRO_LRELU>{}, c0); break;
+                case SET_PRO_DIV: commit_b(ic<SET_PRO_DIV>{}, c0); break;
+                default: commit_b(ic<SET_PRO_NONE>{}, c0); break;
+            }
+        }
+        commit_a(c0, tgn);
+        __syncthreads();
+        if (s + 1 < nstages) {
+            int c1, tg1, tgn1;
+            stage_of(s + 1, c1, tg1, tgn1);
+            if (tg1 == 0) issue_b(c1);
+            issue_a(c1, tg1, tgn1);
+        }
+        for (int tl = 0; tl < tgn; ++tl) {
+            const int off = (tg0 + tl) * a.dil - a.pad - lo;  // >= 0: frame-row shift of this tap inside the B tile
+            const unsigned char *ap = As + (tl * MB + wm * 64 + l31) * ROWB + half * 16;
+            const unsigned char *bp = Bs + (wn * 64 + l31 + off) * ROWB + half * 16;
+#pragma unroll
+            for (int ks = 0; ks < KCH / 16; ++ks) {
+                const u32x4 a0 = *reinterpret_cast<const u32x4 *>(ap + ks * 32);
+                const u32x4 a1 = *reinterpret_cast<const u32x4 *>(ap + 32 * ROWB + ks * 32);
+                const u32x4 b0 = *reinterpret_cast<const u32x4 *>(bp + ks * 32);
+                const u32x4 b1 = *reinterpret_cast<const u32x4 *>(bp + 32 * ROWB + ks * 32);
+                acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
+                acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
+                acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
+                acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+            }
+        }
+    }
+
+    // ---- epilogue (fp32): v = act((acc + bias) * alpha) + res ; * mask ; (+ previous output, / out_div) ----
+    // every optional operand is fetched as one batch of 16 on clamped addresses under ONE wave-uniform test, and the
+    // activation code is resolved once per kernel (cheap ones as template instances, the transcendental ones in a
+    // rolled loop): a per-element `if (ptr) v += ptr[i]` / `switch (act)` costs a branch (and a drained vmcnt) per element
+    const bool has_div = a.accumulate && a.out_div != 0.0f;
+    const bool has_res = a.res != nullptr, has_bias = a.bias != nullptr, has_acc = a.accumulate != 0;
+    const rsrc_t d_out = make_rsrc(a.out + (int64_t)b * a.out_bs);
+    const rsrc_t d_res = make_rsrc(has_res ? a.res + (int64_t)b * a.res_bs : a.out + (int64_t)b * a.out_bs);
+    const rsrc_t d_bias = make_rsrc(has_bias ? a.bias : a.out);
+    auto tile = [&](auto ACT, const f32x16 &av, int i, int j) __attribute__((always_inline)) {
+        constexpr int kAct = decltype(ACT)::value;
+        const int rbase = r0 + wm * 64 + i * 32 + 4 * half;  // register r of this lane is row rbase + (r&3) + 8*(r>>2)
+        const int t = t0 + wn * 64 + j * 32 + l31;
+        const bool tv = t < a.T_iter && t < a.T_out;
+        const int tc = min(t, a.T_out - 1);
+        float mk = 1.0f;
+        if (a.mask) mk = a.mask[(int64_t)b * a.T_out + tc];
+        float bi[16], rv[16], ov[16];
+        unsigned ro[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ro[r] = (unsigned)min(rbase + (r & 3) + 8 * (r >> 2), a.Cout - 1);
+            bi[r] = rv[r] = ov[r] = 0.0f;
+        }
+        if (has_bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bi[r] = buf_load(d_bias, ro[r] * 4u, 0u);
+        }
+        if (has_res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = buf_load(d_res, (ro[r] * (unsigned)a.res_cs + (unsigned)tc) * 4u, 0u);
+        }
+        if (has_acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ov[r] = buf_load(d_out, (ro[r] * (unsigned)a.out_cs + (unsigned)tc) * 4u, 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            float y = (av[r] + bi[r]) * a.alpha;
+            if constexpr (kAct == SET_ACT_RELU) y = y > 0.0f ? y : 0.0f;
+            else if constexpr (kAct == SET_ACT_LRELU) y = y > 0.0f ? y : y * a.act_param;
+            else if constexpr (kAct != SET_ACT_NONE) y = dev_act(y, a.act, a.act_param);
+            y = (y + rv[r]) * mk + ov[r];
+            if (has_div) y = y / a.out_div;
+            if (tv && row < a.Cout) buf_store(y, d_out, (ro[r] * (unsigned)a.out_cs + (unsigned)tc) * 4u, 0u);
+        }
+    };
+    auto finish = [&](auto ACT) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (r0 + wm * 64 + i * 32 >= a.Cout) continue;  // wave-uniform: a fully padded row block
+#pragma unroll
+            for (int j = 0; j < 2; ++j) tile(ACT, acc[i][j], i, j);
+        }
+    };
+    switch (a.act) {
+        case SET_ACT_NONE: finish(ic<SET_ACT_NONE>{}); break;
+        case SET_ACT_RELU: finish(ic<SET_ACT_RELU>{}); break;
+        case SET_ACT_LRELU: finish(ic<SET_ACT_LRELU>{}); break;
+        default: finish(ic<-1>{}); break;  // gelu / tanh / softplus / mish: run-time dev_act (small layers only)
+    }
+}
+
+template <int WM, int WN, int KCH, int TGM, bool HALO, bool ADD>
+static int launch_conv_bf16(const SetConv1dArgs &a, int lo, int halo, hipStream_t s) {
+    constexpr int MB = 64 * WM, NB = 64 * WN, ROWB = KCH * 2 + 16, BF_TG_MAX = TGM;
+    const int CinP = round_up_i(a.Cin, 32), CoutP = round_up_i(a.Cout, 128);
+    const size_t lds = (size_t)BF_TG_MAX * MB * ROWB + (size_t)(NB + halo) * ROWB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1d_bf16_kernel<WM, WN, KCH, TGM, HALO, ADD>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "conv bf16 attr");
+        attr_set = true;
+    }
+    if (lds > 96 * 1024) return set_fail(SET_E_UNSUPPORTED, "set_conv1d(bf16)", "tile does not fit LDS");
+    dim3 grid((a.T_iter + NB - 1) / NB, (a.Cout + MB - 1) / MB, a.B), block(256);
+    hipLaunchKernelGGL((conv1d_bf16_kernel<WM, WN, KCH, TGM, HALO, ADD>), grid, block, lds, s, a, lo, halo, CinP, CoutP);
+    return set_check_launch("set_conv1d(bf16)");
+}
+
+// =====================================================================================================================
+// weight gradient, bf16 operands:  dW[co][ci][tap] = sum_{b,t} G[b][co][t] * P(X[b][ci][t + tap*dil - pad])
+// GEMM M = Cout (128 per block), N = Cin (128 per block) for ONE tap, reduction over frames in chunks of 64:
+//   Gs[co][64 frames], Xs[ci][64 frames] bf16, rows padded to 144 bytes (conflict-free 16-byte fragment reads);
+//   the chunk loads of step c+1 are in flight (registers) under the MFMAs of step c.
+// Frames are split into `S` slices (grid.z); slice z writes its partial tile to partial[z][Cout][Cin][K] with plain
+// stores.  wgrad_reduce_kernel then adds the slices to dW in slice order: no atomics, the same bits every run.
+// =====================================================================================================================
+constexpr int WGB_KT = 64;
+constexpr int WGB_ROWB = WGB_KT * 2 + 16;
+
+struct WgradBf16Args {
+    const float *g, *x, *chan_add;
+    float *partial;  // [S][Cout][Cin][K]
+    int B, Cin, Cout, K, dil, pad, T, T_in, pro;
+    float pro_param;
+    int chunks_per_slice, n_chunks_t, ci_tiles;
+};
+
+__global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char Gs[128 * WGB_ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[128 * WGB_ROWB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tap = blockIdx.x / a.ci_tiles, ci0 = (blockIdx.x % a.ci_tiles) * 128;
+    const int co0 = blockIdx.y * 128;
+    const int shift = tap * a.dil - a.pad;
+    const int total_chunks = a.B * a.n_chunks_t;
+    const int c_begin = blockIdx.z * a.chunks_per_slice;
+    const int c_end = min(c_begin + a.chunks_per_slice, total_chunks);
+    const bool has_add = a.chan_add != nullptr;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+
+    // staging: lane = frame inside the chunk, the thread's wave owns rows wave, wave + 4, ... (32 rows per tile).
+    // raw-buffer addressing: per-lane byte offset of the frame + scalar byte offset of the row (wave-uniform)
+    const int sk = lane, sr0 = wave;
+    float gv[32], xv[32], av[32];
+    auto issue = [&](int ch) {
+        const int b = ch / a.n_chunks_t, t0 = (ch % a.n_chunks_t) * WGB_KT;
+        const unsigned vg = (unsigned)min(t0 + sk, a.T - 1) * 4u;
+        const unsigned vx = (unsigned)min(max(t0 + sk + shift, 0), a.T_in - 1) * 4u;
+        const rsrc_t d_g = make_rsrc(a.g + (int64_t)b * a.Cout * a.T);
+        const rsrc_t d_x = make_rsrc(a.x + (int64_t)b * a.Cin * a.T_in);
+        const rsrc_t d_a = make_rsrc(has_add ? a.chan_add + (int64_t)b * a.Cin : a.x);  // dummy stays a valid address
+#pragma unroll
+        for (int j = 0; j < 32; ++j) gv[j] = buf_load(d_g, vg, (unsigned)(min(co0 + sr0 + 4 * j, a.Cout - 1) * a.T) * 4u);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int cic = min(ci0 + sr0 + 4 * j, a.Cin - 1);
+            xv[j] = buf_load(d_x, vx, (unsigned)(cic * a.T_in) * 4u);
+            av[j] = buf_load(d_a, 0u, (unsigned)cic * 4u);
+        }
+    };
+    auto commit = [&](auto PROC, int ch) __attribute__((always_inline)) {
+        constexpr int kPro = decltype(PROC)::value;
+        const int t0 = (ch % a.n_chunks_t) * WGB_KT;
+        const int t = t0 + sk, ti = t + shift;
+        const bool tv = t < a.T, tiv = tv && ti >= 0 && ti < a.T_in;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int row = sr0 + 4 * j;
+            const float gval = (tv && co0 + row < a.Cout) ? gv[j] : 0.0f;
+            const float xp = pro_c<kPro>(has_add ? xv[j] + av[j] : xv[j], a.pro_param);  // unconditional, then select
+            const float xval = (tiv && ci0 + row < a.Cin) ? xp : 0.0f;
+            *reinterpret_cast<unsigned short *>(Gs + row * WGB_ROWB + sk * 2) = bf16_bits(gval);
+            *reinterpret_cast<unsigned short *>(Xs + row * WGB_ROWB + sk * 2) = bf16_bits(xval);
+        }
+    };
+    if (c_begin < c_end) issue(c_begin);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        __syncthreads();
+        switch (a.pro) {
+            case SET_PRO_LRELU: commit(ic<SET_PRO_LRELU>{}, ch); break;
+            case SET_PRO_DIV: commit(ic<SET_PRO_DIV>{}, ch); break;
+            default: commit(ic<SET_PRO_NONE>{}, ch); break;
+        }
+        __syncthreads();
+        if (ch + 1 < c_end) issue(ch + 1);
+        const unsigned char *ap = Gs + (wm * 64 + l31) * WGB_ROWB + half * 16;
+        const unsigned char *bp = Xs + (wn * 64 + l31) * WGB_ROWB + half * 16;
+#pragma unroll
+        for (int ks = 0; ks < WGB_KT / 16; ++ks) {
+            const u32x4 a0 = *reinterpret_cast<const u32x4 *>(ap + ks * 32);
+            const u32x4 a1 = *reinterpret_cast<const u32x4 *>(ap + 32 * WGB_ROWB + ks * 32);
+            const u32x4 b0 = *reinterpret_cast<const u32x4 *>(bp + ks * 32);
+            const u32x4 b1 = *reinterpret_cast<const u32x4 *>(bp + 32 * WGB_ROWB + ks * 32);
+            acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
+            acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
+            acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
+            acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+        }
+    }
+    // partial tile of this slice (zeros for an empty slice): plain stores
+    float *pz = a.partial + (int64_t)blockIdx.z * a.Cout * a.Cin * a.K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 64 + i * 32 + mfma32_row(r, lane);
+            if (co >= a.Cout) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ci = ci0 + wn * 64 + j * 32 + l31;
+                if (ci < a.Cin) pz[((int64_t)co * a.Cin + ci) * a.K + tap] = acc[i][j][r];
+            }
+        }
+}
+
+// dw[i] += sum_{s < S} partial[s][i]   (slice order: the sum has one fixed association)
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *partial, float *dw, int64_t n, int S) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int z = 0; z < S; ++z) s += partial[(int64_t)z * n + i];
+    dw[i] += s;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int64_t set_packed_conv_weight_bf16_size(int32_t Cout, int32_t Cin, int32_t K) {
+    return (int64_t)round_up_i(Cout, 128) * K * round_up_i(Cin, 32);  // number of bf16 elements
+}
+
+extern "C" int set_pack_conv_weight_bf16(const float *w, void *wp, int32_t Cout, int32_t Cin, int32_t K, int64_t w_base,
+                                         int64_t w_sco, int64_t w_sci, int64_t w_stap, void *stream) {
+    SET_REQUIRE(w && wp && Cout > 0 && Cin > 0 && K > 0, "set_pack_conv_weight_bf16");
+    const int64_t total = set_packed_conv_weight_bf16_size(Cout, Cin, K);
+    hipLaunchKernelGGL(pack_conv_weight_bf16_kernel, dim3(set_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<unsigned short *>(wp), Cout, Cin, K, round_up_i(Cout, 128), round_up_i(Cin, 32), total,
+                       w_base, w_sco, w_sci, w_stap);
+    return set_check_launch("set_pack_conv_weight_bf16");
+}
+
+// called by set_conv1d (conv1d.hip) for impl == SET_IMPL_BF16
+int set_conv1d_bf16_dispatch(const SetConv1dArgs &a, hipStream_t s) {
+    if (a.out_stride != 1 || a.out_off != 0)
+        return set_fail(SET_E_UNSUPPORTED, "set_conv1d(bf16)", "strided output (polyphase transposed conv) is an fp32 path");
+    const int o_first = -a.pad, o_last = (a.K - 1) * a.dil - a.pad;
+    const int lo = o_first < o_last ? o_first : o_last;
+    const int halo = (o_first < o_last ? o_last : o_first) - lo;
+    if (halo > 128) return set_fail(SET_E_UNSUPPORTED, "set_conv1d(bf16)", "receptive field > 128");
+    const int64_t cs = a.res && a.res_cs > a.out_cs ? a.res_cs : a.out_cs;
+    if (((int64_t)round_up_i(a.Cout, 128) * cs + a.T_out) * 4 >= ((int64_t)1 << 31) ||
+        ((int64_t)a.Cin * a.in_cs + a.T_in) * 4 >= ((int64_t)1 << 31))
+        return set_fail(SET_E_UNSUPPORTED, "set_conv1d(bf16)", "one batch slice of in / out / res exceeds 2 GiB");
+    const bool narrow = a.Cout <= 64 || (a.Cout > 128 && a.Cout <= 192);  // 64-row blocks waste less than 128-row ones
+    if (a.K == 1 && a.Cin > 32 && halo == 0 && !a.in_chan_add) {
+        return narrow ? launch_conv_bf16<1, 4, 64, 1, false, false>(a, lo, halo, s)
+                      : launch_conv_bf16<2, 2, 64, 1, false, false>(a, lo, halo, s);
+    }
+    return narrow ? launch_conv_bf16<1, 4, 32, 4, true, true>(a, lo, halo, s)
+                  : launch_conv_bf16<2, 2, 32, 4, true, true>(a, lo, halo, s);
+}
+
+// fp32 deterministic path: kernel + slice plan live in train.hip
+int wgrad_f32_slices(int B, int Cin, int Cout, int K, int T);
+int launch_wgrad_f32_partial(const float *g, const float *x, const float *chan_add, float *partial, int B, int Cin, int Cout,
+                             int K, int dil, int pad, int T, int T_in, int pro, float pro_param, hipStream_t s);
+
+static int wgrad_bf16_slices(int B, int Cin, int Cout, int K, int T) {
+    const int n_chunks_t = (T + WGB_KT - 1) / WGB_KT;
+    const int64_t total_chunks = (int64_t)B * n_chunks_t;
+    const int tiles = K * ((Cin + 127) / 128) * ((Cout + 127) / 128);
+    int64_t S = (640 + tiles - 1) / tiles;  // ~2.5 blocks per CU
+    if (S > total_chunks) S = total_chunks;
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    const int64_t cps = (total_chunks + S - 1) / S;
+    return (int)((total_chunks + cps - 1) / cps);  // no empty slices
+}
+
+extern "C" int64_t set_conv1d_wgrad_scratch_floats(int32_t B, int32_t Cin, int32_t Cout, int32_t K, int32_t T, int32_t dtype) {
+    const int S = dtype == SET_DTYPE_BF16 ? wgrad_bf16_slices(B, Cin, Cout, K, T) : wgrad_f32_slices(B, Cin, Cout, K, T);
+    return (int64_t)S * Cout * Cin * K;
+}
+
+extern "C" int set_conv1d_wgrad_det(const float *g, const float *x, const float *chan_add, float *dw, int32_t B, int32_t Cin,
+                                    int32_t Cout, int32_t K, int32_t dil, int32_t pad, int32_t T, int32_t T_in, int32_t pro,
+                                    float pro_param, int32_t dtype, float *scratch, int64_t scratch_floats, void *stream) {
+    SET_REQUIRE(g && x && dw && scratch && B > 0 && Cin > 0 && Cout > 0 && K > 0 && T > 0 && T_in > 0, "set_conv1d_wgrad_det");
+    const int64_t n = (int64_t)Cout * Cin * K;
+    const int64_t need = set_conv1d_wgrad_scratch_floats(B, Cin, Cout, K, T, dtype);
+    SET_REQUIRE(scratch_floats >= need, "set_conv1d_wgrad_det (scratch too small)");
+    SET_REQUIRE((int64_t)Cout * T * 4 < ((int64_t)1 << 31) && (int64_t)Cin * T_in * 4 < ((int64_t)1 << 31),
+                "set_conv1d_wgrad_det (one batch slice exceeds 2 GiB)");
+    const int S = (int)(need / n);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SET_DTYPE_BF16) {
+        WgradBf16Args a;
+        a.g = g; a.x = x; a.chan_add = chan_add; a.partial = scratch;
+        a.B = B; a.Cin = Cin; a.Cout = Cout; a.K = K; a.dil = dil; a.pad = pad; a.T = T; a.T_in = T_in; a.pro = pro;
+        a.pro_param = pro_param;
+        a.n_chunks_t = (T + WGB_KT - 1) / WGB_KT;
+        const int total_chunks = B * a.n_chunks_t;
+        a.chunks_per_slice = (total_chunks + S - 1) / S;
+        a.ci_tiles = (Cin + 127) / 128;
+        dim3 grid(K * a.ci_tiles, (Cout + 127) / 128, S);
+        hipLaunchKernelGGL(conv1d_wgrad_bf16_kernel, grid, dim3(256), 0, s, a);
+        const int rc = set_check_launch("set_conv1d_wgrad_det(bf16)");
+        if (rc != SET_OK) return rc;
+    } else {
+        const int rc = launch_wgrad_f32_partial(g, x, chan_add, scratch, B, Cin, Cout, K, dil, pad, T, T_in, pro, pro_param, s);
+        if (rc != SET_OK) return rc;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, s, scratch, dw, n, S);
+    return set_check_launch("set_conv1d_wgrad_det(reduce)");
+}

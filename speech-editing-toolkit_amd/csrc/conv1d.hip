@@ -560,6 +560,8 @@ extern "C" int set_pack_conv_weight(const float *w, float *wp, int32_t Cout, int
     return set_check_launch("set_pack_conv_weight");
 }
 
+int set_conv1d_bf16_dispatch(const SetConv1dArgs &a, hipStream_t s);  // bf16.hip
+
 extern "C" int set_conv1d(const SetConv1dArgs *args, void *stream) {
     SET_REQUIRE(args != nullptr, "set_conv1d");
     const SetConv1dArgs &a = *args;
@@ -569,6 +571,7 @@ extern "C" int set_conv1d(const SetConv1dArgs *args, void *stream) {
     if (a.T_iter <= 0) return SET_OK;
     hipStream_t s = (hipStream_t)stream;
     if (a.impl == SET_IMPL_MFMA2) return launch_conv_v2(a, s);
+    if (a.impl == SET_IMPL_BF16) return set_conv1d_bf16_dispatch(a, s);
     if (a.impl != SET_IMPL_MFMA) {
         const int64_t total = (int64_t)a.B * a.Cout * a.T_iter;
         hipLaunchKernelGGL(conv1d_naive_kernel, dim3(set_blocks(total, 256)), dim3(256), 0, s, a);

@@ -24,6 +24,7 @@ struct WgradArgs {
     float pro_param;
     int chunks_per_slice, n_chunks_t;  // chunk id = b * n_chunks_t + tc
     int gx, gy, gz, xcd_map;           // logical grid (tap x ci tile, co tile, split-K slice); launch is 1-D
+    float *partial;                    // deterministic mode: slice z stores its tile to partial[z][Cout][Cin][K] (no atomics)
 };
 
 __global__ void __launch_bounds__(256) conv1d_wgrad_mfma_kernel(WgradArgs a) {
@@ -125,7 +126,9 @@ __global__ void __launch_bounds__(256) conv1d_wgrad_mfma_kernel(WgradArgs a) {
     }
     // a padding slice of an XCD-mapped grid has nothing to add (tested here, not before the loop: an early exit there
     // changes the register allocation of the whole kernel, 116 -> 140 VGPRs)
-    if (c_begin >= c_end) return;
+    if (c_begin >= c_end && !a.partial) return;  // (deterministic mode: an empty slice stores zeros)
+    float *dst = a.partial ? a.partial + (int64_t)bz * a.Cout * a.Cin * a.K : a.dw;
+    const bool plain = a.partial != nullptr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = co0 + 32 * w + mfma32_row(r, lane);
@@ -134,7 +137,9 @@ __global__ void __launch_bounds__(256) conv1d_wgrad_mfma_kernel(WgradArgs a) {
         for (int cb = 0; cb < 2; ++cb) {
             const int ci = ci0 + 32 * cb + l31;
             if (ci >= a.Cin) continue;
-            atomicAdd(&a.dw[((int64_t)co * a.Cin + ci) * a.K + tap], cb == 0 ? acc0[r] : acc1[r]);
+            float *p = &dst[((int64_t)co * a.Cin + ci) * a.K + tap];
+            const float v = cb == 0 ? acc0[r] : acc1[r];
+            if (plain) *p = v; else atomicAdd(p, v);
         }
     }
 }
@@ -687,40 +692,61 @@ __global__ void __launch_bounds__(256) adamw_kernel(float *p, const float *g, fl
 // =====================================================================================================================
 // C ABI
 // =====================================================================================================================
-extern "C" int set_conv1d_wgrad(const float *g, const float *x, const float *chan_add, float *dw, int32_t B, int32_t Cin,
-                                int32_t Cout, int32_t K, int32_t dil, int32_t pad, int32_t T, int32_t T_in, int32_t pro,
-                                float pro_param, int32_t impl, void *stream) {
-    SET_REQUIRE(g && x && dw && B > 0 && Cin > 0 && Cout > 0 && K > 0 && T > 0 && T_in > 0, "set_conv1d_wgrad");
-    WgradArgs a = {g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro, pro_param, 0, 0, 0, 0, 0, 0};
-    hipStream_t s = (hipStream_t)stream;
-    if (impl != SET_IMPL_MFMA) {
-        hipLaunchKernelGGL(conv1d_wgrad_naive_kernel, dim3(set_blocks((int64_t)Cout * Cin * K, 256)), dim3(256), 0, s, a);
-        return set_check_launch("set_conv1d_wgrad(naive)");
-    }
-    a.n_chunks_t = (T + WG_KC - 1) / WG_KC;
-    const int total = B * a.n_chunks_t;
-    const int tiles = K * ((Cin + 63) / 64) * ((Cout + 127) / 128);
+// slice plan of the fp32 MFMA weight-gradient kernel (shared by the atomic and the deterministic entry points)
+static void wgrad_f32_plan(WgradArgs &a, bool for_atomics) {
+    a.n_chunks_t = (a.T + WG_KC - 1) / WG_KC;
+    const int total = a.B * a.n_chunks_t;
+    const int tiles = a.K * ((a.Cin + 63) / 64) * ((a.Cout + 127) / 128);
     // split-K slices: every block ends with one atomicAdd per weight element, and the adds of different XCDs on one
     // address serialise at the memory side -- ~2.5 blocks per CU beat 8 (swept: 2048 -> 637, 1024 -> 659, 512 -> 663,
     // 256 -> 616 training samples/s)
     int target_blocks = 640;
-    if (const char *e = getenv("SET_AMD_WGRAD_BLOCKS")) target_blocks = atoi(e) > 0 ? atoi(e) : target_blocks;
+    if (for_atomics)
+        if (const char *e = getenv("SET_AMD_WGRAD_BLOCKS")) target_blocks = atoi(e) > 0 ? atoi(e) : target_blocks;
     int slices = (target_blocks + tiles - 1) / tiles;
     if (slices > total) slices = total;
     if (slices < 1) slices = 1;
     // one XCD per slice needs a multiple of 8 slices (the padding slices, if any, exit at once)
     bool xcd_map = slices >= 8;
-    if (const char *e = getenv("SET_AMD_WGRAD_XCD")) xcd_map = xcd_map && atoi(e) != 0;
+    if (for_atomics)
+        if (const char *e = getenv("SET_AMD_WGRAD_XCD")) xcd_map = xcd_map && atoi(e) != 0;
     if (xcd_map) slices = (slices + 7) / 8 * 8 <= total ? (slices + 7) / 8 * 8 : slices / 8 * 8;
     a.chunks_per_slice = (total + slices - 1) / slices;
     slices = (total + a.chunks_per_slice - 1) / a.chunks_per_slice;
     if (xcd_map) slices = (slices + 7) / 8 * 8;
-    a.gx = K * ((Cin + 63) / 64);
-    a.gy = (Cout + 127) / 128;
+    a.gx = a.K * ((a.Cin + 63) / 64);
+    a.gy = (a.Cout + 127) / 128;
     a.gz = slices;
     a.xcd_map = xcd_map ? 1 : 0;
+}
+
+extern "C" int set_conv1d_wgrad(const float *g, const float *x, const float *chan_add, float *dw, int32_t B, int32_t Cin,
+                                int32_t Cout, int32_t K, int32_t dil, int32_t pad, int32_t T, int32_t T_in, int32_t pro,
+                                float pro_param, int32_t impl, void *stream) {
+    SET_REQUIRE(g && x && dw && B > 0 && Cin > 0 && Cout > 0 && K > 0 && T > 0 && T_in > 0, "set_conv1d_wgrad");
+    WgradArgs a = {g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro, pro_param, 0, 0, 0, 0, 0, 0, nullptr};
+    hipStream_t s = (hipStream_t)stream;
+    if (impl != SET_IMPL_MFMA) {
+        hipLaunchKernelGGL(conv1d_wgrad_naive_kernel, dim3(set_blocks((int64_t)Cout * Cin * K, 256)), dim3(256), 0, s, a);
+        return set_check_launch("set_conv1d_wgrad(naive)");
+    }
+    wgrad_f32_plan(a, true);
     hipLaunchKernelGGL(conv1d_wgrad_mfma_kernel, dim3((unsigned)a.gx * a.gy * a.gz), dim3(256), 0, s, a);
     return set_check_launch("set_conv1d_wgrad(mfma)");
+}
+
+// deterministic fp32 path (set_conv1d_wgrad_det in bf16.hip): number of slices, and the launch that fills partial[S][...]
+int wgrad_f32_slices(int B, int Cin, int Cout, int K, int T) {
+    WgradArgs a = {nullptr, nullptr, nullptr, nullptr, B, Cin, Cout, K, 1, 0, T, T, 0, 0.0f, 0, 0, 0, 0, 0, 0, nullptr};
+    wgrad_f32_plan(a, false);
+    return a.gz;
+}
+int launch_wgrad_f32_partial(const float *g, const float *x, const float *chan_add, float *partial, int B, int Cin, int Cout,
+                             int K, int dil, int pad, int T, int T_in, int pro, float pro_param, hipStream_t s) {
+    WgradArgs a = {g, x, chan_add, nullptr, B, Cin, Cout, K, dil, pad, T, T_in, pro, pro_param, 0, 0, 0, 0, 0, 0, partial};
+    wgrad_f32_plan(a, false);
+    hipLaunchKernelGGL(conv1d_wgrad_mfma_kernel, dim3((unsigned)a.gx * a.gy * a.gz), dim3(256), 0, s, a);
+    return set_check_launch("set_conv1d_wgrad_det(f32)");
 }
 
 extern "C" int set_channel_sum(const float *x, float *out, int32_t B, int32_t C, int32_t T, void *stream) {

@@ -183,7 +183,9 @@ class DiffNet(nn.Module):
         cond = cond.contiguous()
         skip = None
         hs_ = A.fanout(h, L)         # every layer's diffusion_projection reads the step embedding
+        # (the persistent Winograd stack kernel is an fp32-operand kernel: with bf16 operands the layers run op by op)
         use_stack = (self.can_fuse() and self.impl != "unfused" and os.environ.get("SET_AMD_TRAIN_STACK", "1") != "0"
+                     and ops.compute_dtype() == "f32"
                      and ops.stack_variant(x.shape[0], x.shape[2], self.dilation_cycle_length) == 2)
         if use_stack:
             # fused forward: one persistent Winograd launch for all L layers (+ saved x/y/z), hand-ordered backward

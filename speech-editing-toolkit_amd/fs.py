@@ -118,7 +118,7 @@ class _PredictorStack(nn.Module):
         super().__init__()
         self.kernel_size = kernel_size
         self.dropout_rate = dropout_rate
-        self._drop_calls = 0
+        self._drop_site = getattr(type(self), "_site", 0)  # distinguishes the Philox streams of the two predictors
         self.conv = nn.ModuleList()
         for idx in range(n_layers):
             cin = idim if idx == 0 else n_chans
@@ -140,13 +140,15 @@ class _PredictorStack(nn.Module):
             x = F.conv1d(x, w, f[0].bias, pad=k // 2, act="relu")
             x = F.layernorm_ch(x, f[2].weight, f[2].bias, mask=nonpad)
             if drop > 0:
-                self._drop_calls += 1
-                x = F.dropout(x, drop, seed, self._drop_calls * (1 << 28))
+                # the counter offset is a function of (site, layer) only: with the per-update seed that makes every
+                # mask a function of (seed, update, site, layer) -- a resumed run draws the masks the uninterrupted one did
+                x = F.dropout(x, drop, seed, (self._drop_site * 16 + li + 1) * (1 << 28))
         return x
 
 
 class DurationPredictor(_PredictorStack):
     """modules/commons/nar_tts_modules.py:8-34 (inference / eval: dropout is identity)."""
+    _site = 1
 
     def __init__(self, idim, n_layers=2, n_chans=384, kernel_size=3, dropout_rate=0.1):
         super().__init__(idim, n_layers, n_chans, kernel_size, dropout_rate)
@@ -161,6 +163,7 @@ class DurationPredictor(_PredictorStack):
 
 class PitchPredictor(_PredictorStack):
     """modules/commons/nar_tts_modules.py:75-100."""
+    _site = 2
 
     def __init__(self, idim, n_layers=5, n_chans=384, odim=2, kernel_size=5, dropout_rate=0.1):
         super().__init__(idim, n_layers, n_chans, kernel_size, dropout_rate)

@@ -12,11 +12,28 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (ACT, PRO, IMPL_MFMA, IMPL_MFMA2, IMPL_NAIVE, SetConv1dArgs, SetDiffnetLayerArgs, SetDiffLoopArgs,
-                   SetDiffnetStackArgs, check)
+from ._lib import (ACT, PRO, IMPL_BF16, IMPL_MFMA, IMPL_MFMA2, IMPL_NAIVE, SetConv1dArgs, SetDiffnetLayerArgs,
+                   SetDiffLoopArgs, SetDiffnetStackArgs, check)
 
 _DEFAULT_IMPL = os.environ.get("SET_AMD_CONV_IMPL", "auto")  # auto | naive | mfma
 _WEIGHTS_EPOCH = 0  # bumped by in-place optimizer updates (they do not touch tensor version counters)
+
+
+_COMPUTE_DTYPE = os.environ.get("SET_AMD_DTYPE", "f32")  # f32 | bf16: MFMA operand type of the conv / wgrad GEMMs
+
+
+def set_compute_dtype(dtype):
+    """'f32' (default; the parity path) or 'bf16': bf16 MFMA operands with fp32 accumulation, fp32 tensors in HBM and
+    fp32 master weights (BASELINE configs[1]; what the reference gets from torch.autocast, trainer.py:325).  Applies to
+    every conv / linear / weight-gradient GEMM large enough for the bf16 kernels; everything else is unchanged."""
+    global _COMPUTE_DTYPE
+    if dtype not in ("f32", "bf16"):
+        raise ValueError("compute dtype must be 'f32' or 'bf16', got %r" % (dtype,))
+    _COMPUTE_DTYPE = dtype
+
+
+def compute_dtype():
+    return _COMPUTE_DTYPE
 
 
 def bump_weights_epoch():
@@ -88,6 +105,7 @@ class ConvWeight:
         self._packed = None
         self._key = None
         self._packed2 = {}
+        self._packed16 = None
 
     def raw(self):
         return _f(self._getter(), "weight")
@@ -112,6 +130,18 @@ class ConvWeight:
         return self._packed
 
 
+    def packed_bf16(self):
+        """bf16 image for SET_IMPL_BF16 (re-rounded from the fp32 master weights whenever they change)."""
+        w = self.raw()
+        key = (w.data_ptr(), w._version, w.device, _WEIGHTS_EPOCH)
+        if self._packed16 is None or self._packed16[0] != key:
+            n = _lib.lib().set_packed_conv_weight_bf16_size(self.Cout, self.Cin, self.K)
+            wp = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+            check(_lib.lib().set_pack_conv_weight_bf16(_p(w), _p(wp), self.Cout, self.Cin, self.K, self.base, self.sco,
+                                                       self.sci, self.stap, _stream()), "set_pack_conv_weight_bf16")
+            self._packed16 = (key, wp)
+        return self._packed16[1]
+
     def packed_v2(self, dil):
         """Image for the big-tile kernel (depends on |dil| through the LDS chunking)."""
         w = self.raw()
@@ -129,11 +159,19 @@ class ConvWeight:
         return ent[1]
 
 
-def _pick_impl(impl, T_iter, Cout=0, Cin=0, K=1, dil=1):
+def bf16_eligible(T_iter, Cout, Cin, K, dil, out_stride=1, out_off=0):
+    """Shapes the bf16 kernels take: enough reduction depth and rows for a 64x64 wave tile to pay, stride-1 output."""
+    return (T_iter >= 32 and Cout >= 32 and Cin * K >= 64 and out_stride == 1 and out_off == 0
+            and (K - 1) * abs(dil) <= 128)
+
+
+def _pick_impl(impl, T_iter, Cout=0, Cin=0, K=1, dil=1, out_stride=1, out_off=0):
     impl = impl or _DEFAULT_IMPL
     if impl == "auto":
         if T_iter < 16:
             return "naive"
+        if _COMPUTE_DTYPE == "bf16" and bf16_eligible(T_iter, Cout, Cin, K, dil, out_stride, out_off):
+            return "bf16"
         # big-tile kernel: measured (tools/conv_probe.py, profiles/r01_conv_probe.log) +2 % for the 3-tap convs with a
         # deep reduction (512 -> 256: the input-gradient convs of the DiffNet layers) on short sequences; the small-tile
         # kernel is equal or better everywhere else since its epilogue fetches its operands in batches and its main loop
@@ -160,11 +198,13 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
     if out is None:
         out = torch.empty(B, weight.Cout, T_out, dtype=torch.float32, device=x.device)
     _fv(out, "out")
-    impl = _pick_impl(impl, T_iter, weight.Cout, Cin, weight.K, dil)
+    impl = _pick_impl(impl, T_iter, weight.Cout, Cin, weight.K, dil, out_stride, out_off)
     a = SetConv1dArgs()
     a.inp = x.data_ptr()
     if impl == "mfma2":
         a.w = weight.packed_v2(dil).data_ptr()
+    elif impl == "bf16":
+        a.w = weight.packed_bf16().data_ptr()
     else:
         a.w = (weight.packed() if impl == "mfma" else weight.raw()).data_ptr()
     a.bias = _f(bias, "bias").data_ptr() if bias is not None else None
@@ -180,7 +220,7 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
     a.B, a.Cin, a.Cout, a.K, a.dil, a.pad = B, Cin, weight.Cout, weight.K, dil, pad
     a.T_in, a.T_iter, a.T_out, a.out_stride, a.out_off = T_in, T_iter, T_out, out_stride, out_off
     a.pro, a.act, a.accumulate = PRO[pro], ACT[act], int(bool(accumulate))
-    a.impl = {"mfma": IMPL_MFMA, "mfma2": IMPL_MFMA2}.get(impl, IMPL_NAIVE)
+    a.impl = {"mfma": IMPL_MFMA, "mfma2": IMPL_MFMA2, "bf16": IMPL_BF16}.get(impl, IMPL_NAIVE)
     a.pro_param, a.act_param, a.alpha = float(pro_param), float(act_param), float(alpha)
     a.out_div = float(out_div)
     assert not (out_div and not accumulate)

@@ -42,6 +42,7 @@ def _paired_batch(B, T, T_txt):
         for i in range(B // 2):
             rows += [a[k][i], (a if k in ("txt_tokens", "mel2ph", "time_mel_masks", "uv") else b)[k][i]]
         out[k] = torch.stack(rows)
+    out["txt_tokens"][:, 3], out["txt_tokens"][:, 9] = 2, 1  # silence tokens: every utterance has words (finite wdur)
     pad = out["mel2ph"] == 0  # keep the padded frames of the second copy exactly zero too
     out["ref_mels"][pad] = 0.0
     out["f0"][pad] = 0.0

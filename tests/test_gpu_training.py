@@ -439,7 +439,7 @@ def _trainer_hparams(tmp_path, work):
                         train_set_name="test", valid_set_name="test", infer=False, test_ids=[], max_sentences=2,
                         max_tokens=1000, val_check_interval=3, max_updates=3, num_sanity_val_steps=1,
                         work_dir=str(tmp_path / work), num_ckpt_keep=2, warmup_updates=2, tb_log_interval=2,
-                        eval_max_batches=2)
+                        eval_max_batches=2, sil_token_ids=[1, 21, 22])  # every fixture item has a silence + a word
 
 
 def test_trainer_trains_saves_and_resumes_bit_identically(dev, tmp_path):
@@ -494,7 +494,7 @@ def test_gradient_accumulation_matches_one_big_step(dev, tmp_path):
         g_acc = tr.optimizer.flat_g.clone()
         # the same two micro-batches by hand
         task, opt = tr.task, tr.optimizer
-        loader = task.train_dataloader()
+        loader = task.train_dataloader()  # (built from hparams['seed']: the same batch list the trainer used)
         from set_amd.trainer import move_to_device, step_seed
         want = torch.zeros_like(g_acc)
         for k in range(2):
@@ -513,7 +513,8 @@ def test_gradient_accumulation_matches_one_big_step(dev, tmp_path):
             batch = move_to_device(loader.fetch(k), dev)
             t = torch.from_numpy(np.random.default_rng([tr.seed, k]).integers(0, 5, size=(1,), dtype=np.int64)).to(dev)
             loss, _ = task._training_step(batch, k, seed=step_seed(tr.seed, k), t=t)
-            (loss / 2).backward()
+            with torch.enable_grad():  # other test modules switch autograd off globally at import
+                (loss / 2).backward()
         from set_amd import autograd_ops as A
         A.zero_arena_end()
         got = opt.flat_g.clone()
