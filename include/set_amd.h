@@ -65,7 +65,9 @@ extern "C" {
 
 /* operand type selector of the training GEMMs */
 #define SET_DTYPE_F32 0
-#define SET_DTYPE_BF16 1
+#define SET_DTYPE_BF16 1         /* fp32 tensors in HBM, rounded to bf16 on the way into LDS */
+#define SET_DTYPE_BF16_G16 2     /* weight gradient only: the output gradient g already is bf16 [B][Cout][T] in HBM */
+#define SET_DTYPE_BF16_G16_X16 3 /* ... and so is the conv input x (no prologue / per-channel add then) */
 
 int set_abi_version(void);
 /* last hip error string of the calling thread's most recent failing call (host pointer, static storage) */
@@ -343,9 +345,59 @@ int set_conv1d_wgrad(const float *g, const float *x, const float *chan_add, floa
  * g and x rounded to bf16 (RNE) on the way into LDS, fp32 accumulation.  `scratch` must hold
  * set_conv1d_wgrad_scratch_floats(...) floats and may be reused by the next call on the same stream. */
 int64_t set_conv1d_wgrad_scratch_floats(int32_t B, int32_t Cin, int32_t Cout, int32_t K, int32_t T, int32_t dtype);
-int set_conv1d_wgrad_det(const float *g, const float *x, const float *chan_add, float *dw, int32_t B, int32_t Cin,
+int set_conv1d_wgrad_det(const void *g, const void *x, const float *chan_add, float *dw, int32_t B, int32_t Cin,
                          int32_t Cout, int32_t K, int32_t dil, int32_t pad, int32_t T, int32_t T_in, int32_t pro,
                          float pro_param, int32_t dtype, float *scratch, int64_t scratch_floats, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused DiffNet residual layer, bf16 MFMA operands, for the TRAINING path (residual_channels 256, hidden_size 192,
+ * kernel 3; modules/speech_editing/spec_denoiser/diffnet.py:60-81 and its transpose).  One launch per layer and
+ * direction; see csrc/diffnet_bf16.hip for the arithmetic and the HBM traffic it removes.
+ *   img    packed bf16 weight images of ONE layer (set_pack_diffnet_layer_bf16; set_diffnet_layer_bf16_image_size()
+ *          bf16 elements): forward GEMM 1 / GEMM 2 and the three transposed images of the backward
+ *   y16/z16/dy16/do16   bf16 [B][512|256][T]: pre-gate, gated activation, and their gradients (MFMA operands of the
+ *          weight-gradient GEMMs, inputs of the gate derivative)
+ *   dstep  d[b][c] = dstep[b*d_bs + c*d_cs]   (diffusion_projection(step embedding), per utterance)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct SetDiffnetLayerBf16Args {
+    const float *x_in;   /* [B][256][T] */
+    float *x_out;        /* [B][256][T] = (x_in + o_res) / sqrt2 */
+    float *skip;         /* [B][256][T] += o_skip (first != 0: = o_skip) */
+    const float *cond;   /* [B][192][T] */
+    const float *dstep;
+    const void *img;
+    const float *b_dil, *b_cond, *b_out; /* [512] each */
+    uint16_t *y16;       /* [B][512][T] bf16 out */
+    uint16_t *z16;       /* [B][256][T] bf16 out */
+    int64_t d_bs, d_cs;
+    int32_t B, T, dil, first;
+} SetDiffnetLayerBf16Args;
+int64_t set_sizeof_diffnet_layer_bf16_args(void);
+int64_t set_diffnet_layer_bf16_image_size(void);
+int set_pack_diffnet_layer_bf16(const float *wdil /*[512][256][3]*/, const float *wcond /*[512][192]*/,
+                                const float *wout /*[512][256]*/, void *img, void *stream);
+int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, void *stream);
+
+typedef struct SetDiffnetLayerBf16BwdArgs {
+    const float *dx_out; /* [B][256][T] gradient w.r.t. x_out; NULL = zero (the last layer's x_out feeds nothing) */
+    const float *dskip;  /* [B][256][T] gradient w.r.t. the skip sum (the same tensor for every layer) */
+    const uint16_t *y16; /* saved by the forward */
+    const void *img;
+    float *dx;           /* [B][256][T] out: gradient w.r.t. x_in (= w.r.t. x_in + d) */
+    uint16_t *dy16;      /* [B][512][T] bf16 out: gradient w.r.t. the pre-gate y */
+    uint16_t *do16;      /* [B][512][T] bf16 out: [dx_out / sqrt2 ; dskip] */
+    float *dcond;        /* [B][192][T] (+)= Wcond^T dy   (dcond_first != 0: written, not accumulated) */
+    float *part_dbo;     /* [B * tiles][512] per-tile sums of d_o over frames  (bias gradient of the output projection) */
+    float *part_dby;     /* [B * tiles][512] per-tile sums of dy               (bias gradient of dilated conv = conditioner) */
+    float *part_dd;      /* [B * tiles][256] per-tile sums of Wdil^T (*) dy    (gradient of the per-utterance step offsets) */
+    int32_t B, T, dil, dcond_first;
+} SetDiffnetLayerBf16BwdArgs;
+int64_t set_sizeof_diffnet_layer_bf16_bwd_args(void);
+int32_t set_diffnet_layer_bwd_bf16_tiles(int32_t T, int32_t dil); /* tiles per utterance = rows per b of the part_* arrays */
+int set_diffnet_layer_bwd_bf16(const SetDiffnetLayerBf16BwdArgs *args, void *stream);
+/* out[g][j] (+)= scale * sum_{r < rows} part[(g*rows + r)*cols + j]  in row order (deterministic reduction of per-tile partials) */
+int set_partial_rows_sum(const float *part, float *out, int32_t groups, int32_t rows, int32_t cols, int32_t accumulate,
+                         float scale, void *stream);
 
 /* bf16 weight image for SET_IMPL_BF16: wp[tap][chunk][row][32] bf16, row < Cout rounded up to 128, chunk < ceil(Cin/32),
  * zero padded; ..._size returns the number of bf16 ELEMENTS (2 bytes each). */

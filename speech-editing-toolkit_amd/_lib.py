@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_PKG, "libset_amd.so")
-SOURCES = ["conv1d.hip", "glue.hip", "diffnet.hip", "train.hip", "attention.hip", "bf16.hip"]
+SOURCES = ["conv1d.hip", "glue.hip", "diffnet.hip", "train.hip", "attention.hip", "bf16.hip", "diffnet_bf16.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
 # constants mirrored from set_amd.h
@@ -23,7 +23,7 @@ OK, E_INVALID, E_UNSUPPORTED, E_LAUNCH = 0, -1, -2, -3
 ACT = dict(none=0, relu=1, gelu=2, tanh=3, softplus=4, mish=5, lrelu=6)
 PRO = dict(none=0, lrelu=1, div=2)
 IMPL_NAIVE, IMPL_MFMA, IMPL_MFMA2, IMPL_BF16 = 1, 2, 3, 4
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_BF16_G16, DTYPE_BF16_G16_X16 = 0, 1, 2, 3
 
 c_f32p = C.POINTER(C.c_float)
 c_i64p = C.POINTER(C.c_int64)
@@ -87,6 +87,25 @@ class SetDiffnetStackArgs(C.Structure):
         ("w1w_all", C.c_void_p), ("w2w_all", C.c_void_p),
         ("x_all", C.c_void_p), ("save_y", C.c_void_p), ("save_z", C.c_void_p),
         ("err_flag", C.c_void_p),
+    ]
+
+
+class SetDiffnetLayerBf16Args(C.Structure):
+    _fields_ = [
+        ("x_in", C.c_void_p), ("x_out", C.c_void_p), ("skip", C.c_void_p), ("cond", C.c_void_p), ("dstep", C.c_void_p),
+        ("img", C.c_void_p), ("b_dil", C.c_void_p), ("b_cond", C.c_void_p), ("b_out", C.c_void_p),
+        ("y16", C.c_void_p), ("z16", C.c_void_p),
+        ("d_bs", C.c_int64), ("d_cs", C.c_int64),
+        ("B", C.c_int32), ("T", C.c_int32), ("dil", C.c_int32), ("first", C.c_int32),
+    ]
+
+
+class SetDiffnetLayerBf16BwdArgs(C.Structure):
+    _fields_ = [
+        ("dx_out", C.c_void_p), ("dskip", C.c_void_p), ("y16", C.c_void_p), ("img", C.c_void_p),
+        ("dx", C.c_void_p), ("dy16", C.c_void_p), ("do16", C.c_void_p), ("dcond", C.c_void_p),
+        ("part_dbo", C.c_void_p), ("part_dby", C.c_void_p), ("part_dd", C.c_void_p),
+        ("B", C.c_int32), ("T", C.c_int32), ("dil", C.c_int32), ("dcond_first", C.c_int32),
     ]
 
 
@@ -158,6 +177,14 @@ SIGNATURES = {
     "set_conv1d_wgrad_det": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _V, _I64, _V]),
     "set_packed_conv_weight_bf16_size": (_I64, [_I32, _I32, _I32]),
     "set_pack_conv_weight_bf16": (C.c_int, [_V, _V, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _V]),
+    "set_sizeof_diffnet_layer_bf16_args": (_I64, []),
+    "set_diffnet_layer_bf16_image_size": (_I64, []),
+    "set_pack_diffnet_layer_bf16": (C.c_int, [_V, _V, _V, _V, _V]),
+    "set_diffnet_layer_fwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayerBf16Args), _V]),
+    "set_sizeof_diffnet_layer_bf16_bwd_args": (_I64, []),
+    "set_diffnet_layer_bwd_bf16_tiles": (_I32, [_I32, _I32]),
+    "set_diffnet_layer_bwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayerBf16BwdArgs), _V]),
+    "set_partial_rows_sum": (C.c_int, [_V, _V, _I32, _I32, _I32, _I32, _F, _V]),
     "set_channel_sum": (C.c_int, [_V, _V, _I32, _I32, _I32, _V]),
     "set_row_sum": (C.c_int, [_V, _V, _I64, _I32, _F, _V]),
     "set_conv_epilogue_bwd": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _F, _V]),
@@ -249,6 +276,8 @@ def lib():
     assert L.set_sizeof_diff_loop_args() == C.sizeof(SetDiffLoopArgs), "SetDiffLoopArgs ABI mismatch"
     assert L.set_sizeof_diffnet_stack_args() == C.sizeof(SetDiffnetStackArgs), "SetDiffnetStackArgs ABI mismatch"
     assert L.set_sizeof_bmm_args() == C.sizeof(SetBmmArgs), "SetBmmArgs ABI mismatch"
+    assert L.set_sizeof_diffnet_layer_bf16_args() == C.sizeof(SetDiffnetLayerBf16Args), "SetDiffnetLayerBf16Args ABI mismatch"
+    assert L.set_sizeof_diffnet_layer_bf16_bwd_args() == C.sizeof(SetDiffnetLayerBf16BwdArgs), "SetDiffnetLayerBf16BwdArgs ABI mismatch"
     _lib = L
     return L
 

@@ -79,7 +79,7 @@ _WG_SCRATCH = {}  # device -> slice-partial buffer of the deterministic weight-g
 DETERMINISTIC_WGRAD = True  # False: the round-1 split-K kernel with fp32 atomics (order-dependent bits)
 
 
-def conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro=0, pro_param=0.0, dw_ptr=None):
+def conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro=0, pro_param=0.0, dw_ptr=None, dtype=None):
     """dW[co][ci][tap] += sum_{b,t} G[b][co][t] * P(X[b][ci][t + tap*dil - pad] + chan_add[b][ci]).  MFMA shapes go
     through set_conv1d_wgrad_det (per-slice partial sums reduced in slice order: bit-stable, no atomics) with bf16 or
     fp32 operands according to ops.compute_dtype(); tiny T uses the one-thread-per-weight kernel."""
@@ -88,7 +88,10 @@ def conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro=0, pr
         check(L().set_conv1d_wgrad(_p(g), _p(x), _p(chan_add), ptr, B, Cin, Cout, K, dil, pad, T, T_in, pro,
                                    float(pro_param), _wgrad_impl(T), _stream()), "set_conv1d_wgrad")
         return
-    dt = _lib.DTYPE_BF16 if (ops.compute_dtype() == "bf16" and Cout >= 32 and Cin >= 32) else _lib.DTYPE_F32
+    if dtype is not None:
+        dt = dtype  # bf16 operands already in HBM (fused layer kernels)
+    else:
+        dt = _lib.DTYPE_BF16 if (ops.compute_dtype() == "bf16" and Cout >= 32 and Cin >= 32) else _lib.DTYPE_F32
     need = L().set_conv1d_wgrad_scratch_floats(B, Cin, Cout, K, T, dt)
     buf = _WG_SCRATCH.get(g.device)
     if buf is None or buf.numel() < need:
@@ -523,6 +526,108 @@ class _DiffNetStackFn(torch.autograd.Function):
         grads.reverse()
         flat = [g for tup in grads for g in tup]
         return (None, dx, dcond, dd, *flat)
+
+
+class _DiffNetStackBf16Fn(torch.autograd.Function):
+    """All L residual layers with bf16 MFMA operands: one fused forward launch per layer that also saves the pre-gate y
+    and the gated z in bf16, one fused backward launch per layer (d_o -> dz -> gate derivative -> dx, dcond, bias / step
+    partial sums) and three weight-gradient GEMMs per layer on the saved bf16 operands (csrc/diffnet_bf16.hip).
+    Same inputs / outputs as _DiffNetStackFn."""
+
+    @staticmethod
+    def forward(ctx, dn, hx, cond, dmat, *params):
+        L_, C_ = dn.n_layers, dn.C
+        hx, cond, dmat = hx.contiguous(), cond.contiguous(), dmat.contiguous()
+        B, _, T = hx.shape
+        dev = hx.device
+        layers = list(dn.residual_layers)
+        imgs = dn.bf16_layer_images()
+        x_all = torch.empty(L_ + 1, B, C_, T, dtype=torch.float32, device=dev)
+        x_all[0].copy_(hx)
+        y16 = torch.empty(L_, B, 2 * C_, T, dtype=torch.bfloat16, device=dev)
+        z16 = torch.empty(L_, B, C_, T, dtype=torch.bfloat16, device=dev)
+        skip = torch.empty(B, C_, T, dtype=torch.float32, device=dev)
+        a = _lib.SetDiffnetLayerBf16Args()
+        a.skip, a.cond = skip.data_ptr(), cond.data_ptr()
+        a.d_bs, a.d_cs = dmat.stride(0), 1
+        a.B, a.T = B, T
+        for l, layer in enumerate(layers):
+            a.x_in, a.x_out = x_all[l].data_ptr(), x_all[l + 1].data_ptr()
+            a.dstep = dmat.data_ptr() + 4 * l * C_
+            a.img = imgs[l].data_ptr()
+            a.b_dil, a.b_cond, a.b_out = (layer.dilated_conv.bias.data_ptr(), layer.conditioner_projection.bias.data_ptr(),
+                                          layer.output_projection.bias.data_ptr())
+            a.y16, a.z16 = y16[l].data_ptr(), z16[l].data_ptr()
+            a.dil, a.first = layer.dilation, int(l == 0)
+            check(L().set_diffnet_layer_fwd_bf16(C.byref(a), _stream()), "set_diffnet_layer_fwd_bf16")
+        ctx.dn, ctx.imgs = dn, imgs
+        ctx.save_for_backward(cond, dmat, x_all, y16, z16)
+        return skip
+
+    @staticmethod
+    def backward(ctx, dskip):
+        dn, imgs = ctx.dn, ctx.imgs
+        cond, dmat, x_all, y16, z16 = ctx.saved_tensors
+        L_, C_ = dn.n_layers, dn.C
+        B, H, T = cond.shape
+        dev = cond.device
+        layers = list(dn.residual_layers)
+        dskip = dskip.contiguous()
+        dcond = torch.empty_like(cond)
+        dd = torch.empty(B, L_ * C_, dtype=torch.float32, device=dev)
+        dy16 = torch.empty(B, 2 * C_, T, dtype=torch.bfloat16, device=dev)
+        do16 = torch.empty(B, 2 * C_, T, dtype=torch.bfloat16, device=dev)
+        dx = [torch.empty(B, C_, T, dtype=torch.float32, device=dev) for _ in range(2)]
+        G16, GX16 = _lib.DTYPE_BF16_G16, _lib.DTYPE_BF16_G16_X16
+        a = _lib.SetDiffnetLayerBf16BwdArgs()
+        a.dskip, a.dcond = dskip.data_ptr(), dcond.data_ptr()
+        a.dy16, a.do16 = dy16.data_ptr(), do16.data_ptr()
+        a.B, a.T = B, T
+        grads = []
+        cur = None  # gradient w.r.t. the current layer's x_out (None for the last layer: its x_out feeds nothing)
+        for l in range(L_ - 1, -1, -1):
+            layer = layers[l]
+            dil = layer.dilation
+            tiles = L().set_diffnet_layer_bwd_bf16_tiles(T, dil)
+            pdbo_c = torch.empty(B * tiles, 2 * C_, dtype=torch.float32, device=dev)
+            pdby_c = torch.empty(B * tiles, 2 * C_, dtype=torch.float32, device=dev)
+            pdd_c = torch.empty(B * tiles, C_, dtype=torch.float32, device=dev)
+            out = dx[l & 1]
+            a.dx_out = None if cur is None else cur.data_ptr()
+            a.y16, a.img, a.dx = y16[l].data_ptr(), imgs[l].data_ptr(), out.data_ptr()
+            a.part_dbo, a.part_dby, a.part_dd = pdbo_c.data_ptr(), pdby_c.data_ptr(), pdd_c.data_ptr()
+            a.dil, a.dcond_first = dil, int(l == L_ - 1)
+            check(L().set_diffnet_layer_bwd_bf16(C.byref(a), _stream()), "set_diffnet_layer_bwd_bf16")
+            # bias / step-offset gradients: ordered sums of the per-tile partials
+            db_out = _gzeros(2 * C_, dev)
+            db_y = _gzeros(2 * C_, dev)
+            check(L().set_partial_rows_sum(_p(pdbo_c), _p(db_out), 1, B * tiles, 2 * C_, 1, 1.0, _stream()), "set_partial_rows_sum")
+            check(L().set_partial_rows_sum(_p(pdby_c), _p(db_y), 1, B * tiles, 2 * C_, 1, 1.0, _stream()), "set_partial_rows_sum")
+            ddl = torch.empty(B, C_, dtype=torch.float32, device=dev)
+            check(L().set_partial_rows_sum(_p(pdd_c), _p(ddl), B, tiles, C_, 0, 1.0, _stream()), "set_partial_rows_sum")
+            dd[:, l * C_:(l + 1) * C_] = ddl
+            # weight gradients on the bf16 operands the two kernels left in HBM
+            dw_out = _zeros_like(layer.output_projection.weight)
+            conv_wgrad(do16, z16[l], None, dw_out, B, C_, 2 * C_, 1, 1, 0, T, T, dtype=GX16)
+            dw_cond = _zeros_like(layer.conditioner_projection.weight)
+            conv_wgrad(dy16, cond, None, dw_cond, B, H, 2 * C_, 1, 1, 0, T, T, dtype=G16)
+            dw_dil = _zeros_like(layer.dilated_conv.weight)
+            dl = dmat[:, l * C_:(l + 1) * C_].contiguous()
+            conv_wgrad(dy16, x_all[l], dl, dw_dil, B, C_, 2 * C_, 3, dil, dil, T, T, dtype=G16)
+            grads.append((dw_cond, db_y, dw_dil, db_y.clone(), dw_out, db_out))
+            cur = out
+        grads.reverse()
+        flat = [g for tup in grads for g in tup]
+        need_cond = ctx.needs_input_grad[2]
+        return (None, cur, dcond if need_cond else None, dd, *flat)
+
+
+def diffnet_stack_train_bf16(dn, hx, cond, dmat):
+    params = []
+    for layer in dn.residual_layers:
+        params += [layer.conditioner_projection.weight, layer.conditioner_projection.bias, layer.dilated_conv.weight,
+                   layer.dilated_conv.bias, layer.output_projection.weight, layer.output_projection.bias]
+    return _DiffNetStackBf16Fn.apply(dn, hx, cond, dmat, *params)
 
 
 def diffnet_stack_train(dn, hx, cond, dmat):

@@ -332,13 +332,24 @@ constexpr int WGB_KT = 64;
 constexpr int WGB_ROWB = WGB_KT * 2 + 16;
 
 struct WgradBf16Args {
-    const float *g, *x, *chan_add;
+    const void *g, *x;  // fp32 [B][C][T], or bf16 when the kernel is instantiated with GB16 / XB16
+    const float *chan_add;
     float *partial;  // [S][Cout][Cin][K]
     int B, Cin, Cout, K, dil, pad, T, T_in, pro;
     float pro_param;
     int chunks_per_slice, n_chunks_t, ci_tiles;
 };
 
+__device__ __forceinline__ unsigned buf_load_raw(rsrc_t r, unsigned voff, unsigned soff) {
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ unsigned buf_load_raw16(rsrc_t r, unsigned voff, unsigned soff) {
+    return (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 0);
+}
+
+// GB16 / XB16: the operand already is bf16 in HBM (saved activations / gradients of the fused layer kernels): its bits
+// go to LDS unchanged (no prologue, no per-channel add on such an operand).
+template <bool GB16, bool XB16>
 __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char Gs[128 * WGB_ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char Xs[128 * WGB_ROWB];
@@ -352,7 +363,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
     const int total_chunks = a.B * a.n_chunks_t;
     const int c_begin = blockIdx.z * a.chunks_per_slice;
     const int c_end = min(c_begin + a.chunks_per_slice, total_chunks);
-    const bool has_add = a.chan_add != nullptr;
+    const bool has_add = !XB16 && a.chan_add != nullptr;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -363,21 +374,26 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
     // staging: lane = frame inside the chunk, the thread's wave owns rows wave, wave + 4, ... (32 rows per tile).
     // raw-buffer addressing: per-lane byte offset of the frame + scalar byte offset of the row (wave-uniform)
     const int sk = lane, sr0 = wave;
-    float gv[32], xv[32], av[32];
+    unsigned gv[32], xv[32];  // raw bits (fp32 or bf16): converting at issue time would wait for the load
+    float av[XB16 ? 1 : 32];
+    constexpr unsigned GE = GB16 ? 2u : 4u, XE = XB16 ? 2u : 4u;  // element sizes
     auto issue = [&](int ch) {
         const int b = ch / a.n_chunks_t, t0 = (ch % a.n_chunks_t) * WGB_KT;
-        const unsigned vg = (unsigned)min(t0 + sk, a.T - 1) * 4u;
-        const unsigned vx = (unsigned)min(max(t0 + sk + shift, 0), a.T_in - 1) * 4u;
-        const rsrc_t d_g = make_rsrc(a.g + (int64_t)b * a.Cout * a.T);
-        const rsrc_t d_x = make_rsrc(a.x + (int64_t)b * a.Cin * a.T_in);
-        const rsrc_t d_a = make_rsrc(has_add ? a.chan_add + (int64_t)b * a.Cin : a.x);  // dummy stays a valid address
+        const unsigned vg = (unsigned)min(t0 + sk, a.T - 1) * GE;
+        const unsigned vx = (unsigned)min(max(t0 + sk + shift, 0), a.T_in - 1) * XE;
+        const rsrc_t d_g = make_rsrc(reinterpret_cast<const unsigned char *>(a.g) + (int64_t)b * a.Cout * a.T * GE);
+        const rsrc_t d_x = make_rsrc(reinterpret_cast<const unsigned char *>(a.x) + (int64_t)b * a.Cin * a.T_in * XE);
+        const rsrc_t d_a = make_rsrc(has_add ? a.chan_add + (int64_t)b * a.Cin : reinterpret_cast<const float *>(a.x));
 #pragma unroll
-        for (int j = 0; j < 32; ++j) gv[j] = buf_load(d_g, vg, (unsigned)(min(co0 + sr0 + 4 * j, a.Cout - 1) * a.T) * 4u);
+        for (int j = 0; j < 32; ++j) {
+            const unsigned so = (unsigned)(min(co0 + sr0 + 4 * j, a.Cout - 1) * a.T) * GE;
+            gv[j] = GB16 ? buf_load_raw16(d_g, vg, so) : buf_load_raw(d_g, vg, so);
+        }
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             const int cic = min(ci0 + sr0 + 4 * j, a.Cin - 1);
-            xv[j] = buf_load(d_x, vx, (unsigned)(cic * a.T_in) * 4u);
-            av[j] = buf_load(d_a, 0u, (unsigned)cic * 4u);
+            xv[j] = XB16 ? buf_load_raw16(d_x, vx, (unsigned)(cic * a.T_in) * XE) : buf_load_raw(d_x, vx, (unsigned)(cic * a.T_in) * XE);
+            if constexpr (!XB16) av[j] = buf_load(d_a, 0u, (unsigned)cic * 4u);
         }
     };
     auto commit = [&](auto PROC, int ch) __attribute__((always_inline)) {
@@ -388,11 +404,16 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             const int row = sr0 + 4 * j;
-            const float gval = (tv && co0 + row < a.Cout) ? gv[j] : 0.0f;
-            const float xp = pro_c<kPro>(has_add ? xv[j] + av[j] : xv[j], a.pro_param);  // unconditional, then select
-            const float xval = (tiv && ci0 + row < a.Cin) ? xp : 0.0f;
-            *reinterpret_cast<unsigned short *>(Gs + row * WGB_ROWB + sk * 2) = bf16_bits(gval);
-            *reinterpret_cast<unsigned short *>(Xs + row * WGB_ROWB + sk * 2) = bf16_bits(xval);
+            unsigned short gb, xb;
+            if constexpr (GB16) gb = (unsigned short)gv[j];
+            else gb = bf16_bits(__builtin_bit_cast(float, gv[j]));
+            if constexpr (XB16) xb = (unsigned short)xv[j];
+            else {
+                const float xf = __builtin_bit_cast(float, xv[j]);
+                xb = bf16_bits(pro_c<kPro>(has_add ? xf + av[j] : xf, a.pro_param));  // unconditional, then select
+            }
+            *reinterpret_cast<unsigned short *>(Gs + row * WGB_ROWB + sk * 2) = (tv && co0 + row < a.Cout) ? gb : (unsigned short)0;
+            *reinterpret_cast<unsigned short *>(Xs + row * WGB_ROWB + sk * 2) = (tiv && ci0 + row < a.Cin) ? xb : (unsigned short)0;
         }
     };
     if (c_begin < c_end) issue(c_begin);
@@ -500,11 +521,11 @@ static int wgrad_bf16_slices(int B, int Cin, int Cout, int K, int T) {
 }
 
 extern "C" int64_t set_conv1d_wgrad_scratch_floats(int32_t B, int32_t Cin, int32_t Cout, int32_t K, int32_t T, int32_t dtype) {
-    const int S = dtype == SET_DTYPE_BF16 ? wgrad_bf16_slices(B, Cin, Cout, K, T) : wgrad_f32_slices(B, Cin, Cout, K, T);
+    const int S = dtype != SET_DTYPE_F32 ? wgrad_bf16_slices(B, Cin, Cout, K, T) : wgrad_f32_slices(B, Cin, Cout, K, T);
     return (int64_t)S * Cout * Cin * K;
 }
 
-extern "C" int set_conv1d_wgrad_det(const float *g, const float *x, const float *chan_add, float *dw, int32_t B, int32_t Cin,
+extern "C" int set_conv1d_wgrad_det(const void *g, const void *x, const float *chan_add, float *dw, int32_t B, int32_t Cin,
                                     int32_t Cout, int32_t K, int32_t dil, int32_t pad, int32_t T, int32_t T_in, int32_t pro,
                                     float pro_param, int32_t dtype, float *scratch, int64_t scratch_floats, void *stream) {
     SET_REQUIRE(g && x && dw && scratch && B > 0 && Cin > 0 && Cout > 0 && K > 0 && T > 0 && T_in > 0, "set_conv1d_wgrad_det");
@@ -515,7 +536,9 @@ extern "C" int set_conv1d_wgrad_det(const float *g, const float *x, const float 
                 "set_conv1d_wgrad_det (one batch slice exceeds 2 GiB)");
     const int S = (int)(need / n);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SET_DTYPE_BF16) {
+    if (dtype != SET_DTYPE_F32) {
+        SET_REQUIRE(dtype == SET_DTYPE_BF16 || dtype == SET_DTYPE_BF16_G16 || dtype == SET_DTYPE_BF16_G16_X16, "set_conv1d_wgrad_det (dtype)");
+        SET_REQUIRE(dtype != SET_DTYPE_BF16_G16_X16 || (chan_add == nullptr && pro == SET_PRO_NONE), "set_conv1d_wgrad_det (bf16 x takes no prologue)");
         WgradBf16Args a;
         a.g = g; a.x = x; a.chan_add = chan_add; a.partial = scratch;
         a.B = B; a.Cin = Cin; a.Cout = Cout; a.K = K; a.dil = dil; a.pad = pad; a.T = T; a.T_in = T_in; a.pro = pro;
@@ -525,11 +548,14 @@ extern "C" int set_conv1d_wgrad_det(const float *g, const float *x, const float 
         a.chunks_per_slice = (total_chunks + S - 1) / S;
         a.ci_tiles = (Cin + 127) / 128;
         dim3 grid(K * a.ci_tiles, (Cout + 127) / 128, S);
-        hipLaunchKernelGGL(conv1d_wgrad_bf16_kernel, grid, dim3(256), 0, s, a);
+        if (dtype == SET_DTYPE_BF16) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<false, false>), grid, dim3(256), 0, s, a);
+        else if (dtype == SET_DTYPE_BF16_G16) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, true>), grid, dim3(256), 0, s, a);
         const int rc = set_check_launch("set_conv1d_wgrad_det(bf16)");
         if (rc != SET_OK) return rc;
     } else {
-        const int rc = launch_wgrad_f32_partial(g, x, chan_add, scratch, B, Cin, Cout, K, dil, pad, T, T_in, pro, pro_param, s);
+        const int rc = launch_wgrad_f32_partial(reinterpret_cast<const float *>(g), reinterpret_cast<const float *>(x), chan_add,
+                                                scratch, B, Cin, Cout, K, dil, pad, T, T_in, pro, pro_param, s);
         if (rc != SET_OK) return rc;
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, s, scratch, dw, n, S);

@@ -1,0 +1,571 @@
+// Fused DiffNet residual layer for the TRAINING path with bf16 MFMA operands (BASELINE configs[1]).
+//
+//   forward  (diffnet.py:60-81):  y = Wdil (*) (x + d) + Wcond cond + b ;  z = sigmoid(y_g) tanh(y_f) ;
+//                                 o = Wout z + b ;  x' = (x + o_res) / sqrt2 ;  skip += o_skip
+//   backward (same lines, transposed):  d_o = [dx'/sqrt2 ; dskip] ;  dz = Wout^T d_o ;  dy = gate'(y) dz ;
+//                                 dx = dx'/sqrt2 + Wdil^T (*) dy ;  dcond += Wcond^T dy ;  dd = sum_t Wdil^T (*) dy
+//
+// One launch per layer and direction.  The per-op path moves ~0.7 GB (forward) + ~1.5 GB (backward) through HBM per
+// layer at B=32, T=800 (conditioner projection, pre-gate, gate, output projection and residual tensors each make a round
+// trip); fused, a layer reads x, cond (forward) / dx', dskip, y (backward) once and writes what the next kernel needs:
+//   forward   reads x 26 MB + cond 20 MB + skip 26 MB, writes x' 26 MB + skip 26 MB + y (bf16) 26 MB + z (bf16) 13 MB
+//   backward  reads dx' 26 + dskip 26 + y 26 + dcond 20, writes dx 26 + dy (bf16) 26 + d_o (bf16) 26 + dcond 20
+// y / z / dy / d_o are stored in bf16 [B][C][T]: they are MFMA operands of later GEMMs (weight gradients) or inputs of
+// the gate derivative, i.e. exactly the tensors torch.autocast keeps in bf16 in the reference's AMP path
+// (utils/commons/trainer.py:325).  x, skip, cond and their gradients stay fp32 in HBM, accumulation is fp32.
+//
+// Geometry (both kernels): block = 512 threads = 8 waves, tile = 128 frames x all rows; wave w owns 32 gate rows
+// [32w, 32w+32) and the matching 32 filter rows 256 + [32w, 32w+32) (forward: also residual / skip rows of GEMM 2), so
+// the gate and its derivative are lane-local in the accumulator layout.  B operands are LDS tiles [frame][channel] in
+// bf16, rows padded by 16 bytes (a 16-byte fragment read of 16 consecutive frames hits 64 distinct banks); the k = 3 taps
+// are row shifts of one tile.  A operands (weights) come from packed bf16 fragment images in global memory (L2
+// resident), one 1 KiB coalesced load per wave per (row block, k-step), prefetched 4 k-steps ahead.
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int FC = 256;    // residual channels
+constexpr int FH = 192;    // conditioner channels (hidden_size)
+constexpr int FNT = 128;   // frames per tile
+constexpr int XR = FC * 2 + 16;      // bytes per LDS row of a [frame][256] bf16 tile
+constexpr int CR = FH * 2 + 16;      // ... of the [frame][192] conditioner tile
+constexpr int DR = 2 * FC * 2 + 16;  // ... of a [frame][512] tile (backward)
+constexpr int KS_C = FH / 16;        // 12 k-steps of the conditioner projection
+constexpr int KS_T = FC / 16;        // 16 k-steps per tap
+constexpr int KS1 = KS_C + 3 * KS_T; // 60 k-steps of GEMM 1
+constexpr int KS2 = FC / 16;         // 16 k-steps of GEMM 2
+constexpr int PF = 4;                // A-fragment prefetch distance (k-steps)
+constexpr float RSQRT2 = 0.70710678118654752440f;
+
+__device__ __forceinline__ unsigned short f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ f32x16 mma16(u32x4_t a, u32x4_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4_t buf_load_u4(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ unsigned short buf_load_u16(rsrc_t r, unsigned voff, unsigned soff) {
+    return (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void buf_store_u16(unsigned short v, rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b16((short)v, r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ int urow(int r) { return (r & 3) + 8 * (r >> 2); }  // + 4 * (lane >> 5)
+
+// acc[NRB][NCB] += A * B over `nks` k-steps.  A: image [ks][NRB][lane][8 bf16] at `img` (byte offsets), one b128 load
+// per (ks, rb), ring of PF k-steps.  B: bfrag(ks, cb) returns the LDS byte address of this lane's 16-byte fragment.
+template <int NRB, int NCB, typename BF>
+__device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NRB][NCB], rsrc_t img, unsigned lane16, int ks0, int nks,
+                                          const unsigned char *lds, BF bfrag) {
+    u32x4_t A[PF][NRB];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+            A[p][rb] = buf_load_u4(img, lane16, (unsigned)(((ks0 + min(p, nks - 1)) * NRB + rb) * 1024));
+    for (int kb = 0; kb < nks; kb += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int ks = kb + p;  // nks is a multiple of PF
+            u32x4_t Bv[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) Bv[cb] = *reinterpret_cast<const u32x4_t *>(lds + bfrag(ks, cb));
+            u32x4_t Ac[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) Ac[rb] = A[p][rb];
+            const int kn = min(ks + PF, nks - 1);  // tail: harmless re-load of the last k-step
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) A[p][rb] = buf_load_u4(img, lane16, (unsigned)(((ks0 + kn) * NRB + rb) * 1024));
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mma16(Ac[rb], Bv[cb], acc[rb][cb]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+}
+
+// =====================================================================================================================
+// packed images (bf16), lane l of a fragment holds row (l & 31), k = 8 * (l >> 5) + e:
+//   w1b[w][ks][rb][l][e]   forward GEMM 1: row = (rb ? 256 : 0) + 32 w + (l&31);  ks < 12: Wcond[row][16 ks + k]
+//                          else tap = (ks-12)/16, Wdil[row][16 ((ks-12)%16) + k][tap]
+//   w2b[w][ks][rb][l][e]   forward GEMM 2: Wout[row][16 ks + k]
+//   wt2[w][ks][l][e]       backward dz:    row = 32 w + (l&31) (z channel), Wout[16 ks + k][row]
+//   wt1[w][ks][l][e]       backward dx:    tap = ks/32, row = 32 w + (l&31) (input channel), Wdil[16 (ks%32) + k][row][tap]
+//   wtc[g][ks][l][e]       backward dcond: g < 6, row = 32 g + (l&31) (conditioner channel), Wcond[16 ks + k][row]
+// =====================================================================================================================
+constexpr int64_t N_W1B = 8LL * KS1 * 2 * 64 * 8, N_W2B = 8LL * KS2 * 2 * 64 * 8;
+constexpr int64_t N_WT2 = 8LL * 32 * 64 * 8, N_WT1 = 8LL * 96 * 64 * 8, N_WTC = 6LL * 32 * 64 * 8;
+constexpr int64_t OFF_W2B = N_W1B, OFF_WT2 = OFF_W2B + N_W2B, OFF_WT1 = OFF_WT2 + N_WT2, OFF_WTC = OFF_WT1 + N_WT1;
+constexpr int64_t N_IMG = OFF_WTC + N_WTC;  // bf16 elements per layer
+
+__global__ void __launch_bounds__(256) pack_layer_bf16_kernel(const float *wdil, const float *wcond, const float *wout,
+                                                              unsigned short *img) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N_IMG) return;
+    float v;
+    if (idx < OFF_W2B) {
+        int64_t r = idx;
+        const int e = r & 7; r >>= 3;
+        const int l = r & 63; r >>= 6;
+        const int rb = r & 1; r >>= 1;
+        const int ks = (int)(r % KS1), w = (int)(r / KS1);
+        const int row = (rb ? FC : 0) + 32 * w + (l & 31), k = 8 * (l >> 5) + e;
+        if (ks < KS_C) v = wcond[(int64_t)row * FH + 16 * ks + k];
+        else { const int tap = (ks - KS_C) / KS_T, ch = 16 * ((ks - KS_C) % KS_T) + k; v = wdil[((int64_t)row * FC + ch) * 3 + tap]; }
+    } else if (idx < OFF_WT2) {
+        int64_t r = idx - OFF_W2B;
+        const int e = r & 7; r >>= 3;
+        const int l = r & 63; r >>= 6;
+        const int rb = r & 1; r >>= 1;
+        const int ks = (int)(r % KS2), w = (int)(r / KS2);
+        const int row = (rb ? FC : 0) + 32 * w + (l & 31), k = 8 * (l >> 5) + e;
+        v = wout[(int64_t)row * FC + 16 * ks + k];
+    } else if (idx < OFF_WT1) {
+        int64_t r = idx - OFF_WT2;
+        const int e = r & 7; r >>= 3;
+        const int l = r & 63; r >>= 6;
+        const int ks = (int)(r % 32), w = (int)(r / 32);
+        const int row = 32 * w + (l & 31), k = 16 * ks + 8 * (l >> 5) + e;
+        v = wout[(int64_t)k * FC + row];
+    } else if (idx < OFF_WTC) {
+        int64_t r = idx - OFF_WT1;
+        const int e = r & 7; r >>= 3;
+        const int l = r & 63; r >>= 6;
+        const int ks = (int)(r % 96), w = (int)(r / 96);
+        const int tap = ks / 32, row = 32 * w + (l & 31), k = 16 * (ks % 32) + 8 * (l >> 5) + e;
+        v = wdil[((int64_t)k * FC + row) * 3 + tap];
+    } else {
+        int64_t r = idx - OFF_WTC;
+        const int e = r & 7; r >>= 3;
+        const int l = r & 63; r >>= 6;
+        const int ks = (int)(r % 32), g = (int)(r / 32);
+        const int row = 32 * g + (l & 31), k = 16 * ks + 8 * (l >> 5) + e;
+        v = wcond[(int64_t)k * FH + row];
+    }
+    img[idx] = f2bf(v);
+}
+
+// =====================================================================================================================
+// forward
+// =====================================================================================================================
+__global__ void __launch_bounds__(512, 1) diffnet_layer_fwd_bf16_kernel(SetDiffnetLayerBf16Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y, t0 = blockIdx.x * FNT, T = a.T, d = a.dil;
+    const int XROWS = FNT + 2 * d;
+    unsigned char *xs = lds;                   // [XROWS][XR]   x + d, row j <-> frame t0 - d + j   (z overlays it: row j <-> t0 + j)
+    unsigned char *cs = lds + XROWS * XR;      // [FNT][CR]     cond,  row j <-> frame t0 + j
+    const unsigned T4 = 4u * (unsigned)T, T2 = 2u * (unsigned)T;
+    const rsrc_t rx = make_rsrc(a.x_in + (int64_t)b * FC * T), rxo = make_rsrc(a.x_out + (int64_t)b * FC * T);
+    const rsrc_t rsk = make_rsrc(a.skip + (int64_t)b * FC * T), rcd = make_rsrc(a.cond + (int64_t)b * FH * T);
+    const rsrc_t rd = make_rsrc(a.dstep + (int64_t)b * a.d_bs);
+    const rsrc_t ry = make_rsrc(a.y16 + (int64_t)b * 2 * FC * T), rz = make_rsrc(a.z16 + (int64_t)b * FC * T);
+    const rsrc_t rbd = make_rsrc(a.b_dil), rbc = make_rsrc(a.b_cond), rbo = make_rsrc(a.b_out);
+    const unsigned short *img = reinterpret_cast<const unsigned short *>(a.img);
+    const rsrc_t rw1 = make_rsrc(img + (int64_t)w * KS1 * 2 * 512), rw2 = make_rsrc(img + OFF_W2B + (int64_t)w * KS2 * 2 * 512);
+    const unsigned lane16 = 16u * (unsigned)lane;
+
+    // ---- stage the tiles: thread (frame row f, channel group cg); loads unconditional on clamped addresses, selects after
+    {
+        const int f = tid & 127, cg = __builtin_amdgcn_readfirstlane(tid >> 7);  // cg 0..3 (two waves each)
+        // x + d: channels [64 cg, 64 cg + 64), two passes of frame rows (the second one = the 2d halo rows)
+#pragma unroll 1
+        for (int p = 0; p < 2; ++p) {
+            const int j = p * FNT + f;
+            const int t = t0 - d + j;
+            const bool tv = t >= 0 && t < T, jv = j < XROWS;
+            if (!jv) continue;  // halo pass: only the first 2d lanes of the block have a row
+            const unsigned vo = 4u * (unsigned)min(max(t, 0), T - 1);
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {  // 32 channels at a time (register budget)
+                float v[32];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    const unsigned c = (unsigned)(64 * cg + 32 * hq + k);
+                    v[k] = buf_load(rx, vo, c * T4) + buf_load(rd, 0u, c * 4u * (unsigned)a.d_cs);
+                }
+                if (jv) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        u32x4_t u;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) u[e] = tv ? pack2(v[8 * q + 2 * e], v[8 * q + 2 * e + 1]) : 0u;
+                        *reinterpret_cast<u32x4_t *>(xs + j * XR + (64 * cg + 32 * hq + 8 * q) * 2) = u;
+                    }
+                }
+            }
+        }
+        // cond: channels [48 cg, 48 cg + 48)
+        {
+            const int t = t0 + f;
+            const bool tv = t < T;
+            const unsigned vo = 4u * (unsigned)min(t, T - 1);
+            float v[48];
+#pragma unroll
+            for (int k = 0; k < 48; ++k) v[k] = buf_load(rcd, vo, (unsigned)(48 * cg + k) * T4);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                u32x4_t u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[e] = tv ? pack2(v[8 * q + 2 * e], v[8 * q + 2 * e + 1]) : 0u;
+                *reinterpret_cast<u32x4_t *>(cs + f * CR + (48 * cg + 8 * q) * 2) = u;
+            }
+        }
+    }
+    // ---- accumulators start at the biases (b_dil + b_cond): row of register r = rowbase + urow(r) + 4 half
+    f32x16 acc[2][4];
+    const unsigned lb = 16u * (unsigned)half;  // byte offset of the lane's 4-row group
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned ur = (unsigned)((rb ? FC : 0) + 32 * w + urow(r));
+            const float bias = buf_load(rbd, lb, 4u * ur) + buf_load(rbc, lb, 4u * ur);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[rb][cb][r] = bias;
+        }
+    __syncthreads();
+
+    // ---- GEMM 1: y = [Wcond | Wdil tap 0 | tap 1 | tap 2] x [cond ; x+d shifted]
+    gemm_bf16<2, 4>(acc, rw1, lane16, 0, KS_C, lds, [&](int ks, int cb) {
+        return (unsigned)(XROWS * XR + (cb * 32 + l31) * CR + (ks * 16 + half * 8) * 2);
+    });
+    gemm_bf16<2, 4>(acc, rw1, lane16, KS_C, 3 * KS_T, lds, [&](int ks, int cb) {
+        const int tap = ks >> 4, c0 = (ks & 15) * 16;
+        return (unsigned)((cb * 32 + l31 + tap * d) * XR + (c0 + half * 8) * 2);
+    });
+
+    // ---- gate (lane-local: acc[0] = gate rows, acc[1] = filter rows); save y and z in bf16; z tile over the x tile
+    bool tv[4];
+    unsigned vo4[4], vo2[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int t = t0 + cb * 32 + l31;
+        tv[cb] = t < T;
+        vo4[cb] = 4u * (unsigned)(4 * half * T + min(t, T - 1));
+        vo2[cb] = 2u * (unsigned)(4 * half * T + min(t, T - 1));
+    }
+    __syncthreads();  // every wave is done reading the x tile
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float yg = acc[0][cb][r], yf = acc[1][cb][r];
+            const float z = tv[cb] ? fsig(yg) * ftanh(yf) : 0.0f;
+            const unsigned ur = (unsigned)(32 * w + urow(r));
+            const unsigned short zb = f2bf(z);
+            if (tv[cb]) {
+                buf_store_u16(f2bf(yg), ry, vo2[cb], ur * T2);
+                buf_store_u16(f2bf(yf), ry, vo2[cb], (ur + FC) * T2);
+                buf_store_u16(zb, rz, vo2[cb], ur * T2);
+            }
+            *reinterpret_cast<unsigned short *>(xs + (cb * 32 + l31) * XR + (32 * w + urow(r) + 4 * half) * 2) = zb;
+        }
+    // ---- accumulators of GEMM 2 start at x + b_out (residual rows) / skip + b_out (skip rows)
+    const bool first = a.first != 0;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned ur = (unsigned)(32 * w + urow(r));
+            const float bias = buf_load(rbo, lb, 4u * (ur + (rb ? FC : 0)));
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const float sv = rb == 0 ? buf_load(rx, vo4[cb], ur * T4) : buf_load(rsk, vo4[cb], ur * T4);
+                acc[rb][cb][r] = (rb == 1 && first) ? bias : bias + sv;
+            }
+        }
+    __syncthreads();
+
+    // ---- GEMM 2: o = Wout z
+    gemm_bf16<2, 4>(acc, rw2, lane16, 0, KS2, lds, [&](int ks, int cb) {
+        return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2);
+    });
+
+    // ---- store-only epilogue
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        if (tv[cb]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned ur = (unsigned)(32 * w + urow(r));
+                buf_store(acc[0][cb][r] * RSQRT2, rxo, vo4[cb], ur * T4);
+                buf_store(acc[1][cb][r], rsk, vo4[cb], ur * T4);
+            }
+        }
+    }
+}
+
+
+// =====================================================================================================================
+// backward.  Tile = 128 frames [ts, ts + 128), ts = tile * (128 - 2 dil) - dil: dz / dy are computed for all 128 frames,
+// dx / dcond / the stored dy, d_o and the bias partial sums for the central 128 - 2 dil (the halo frames are recomputed by
+// the neighbouring tiles).  LDS: one [128 + 2 dil][512] bf16 tile (tile row j lives in LDS row j + dil, so the +-dil
+// row shifts of the transposed taps stay inside the allocation): first d_o, then dy over it.
+// =====================================================================================================================
+__device__ __forceinline__ float half_sum(float v) {  // sum over the 32 lanes of a half-wave (xor offsets < 32)
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffnetLayerBf16BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y, T = a.T, d = a.dil;
+    const int NTc = FNT - 2 * d;
+    const int ts = blockIdx.x * NTc - d;
+    const int part_row = b * gridDim.x + blockIdx.x;
+    const unsigned T4 = 4u * (unsigned)T, T2 = 2u * (unsigned)T;
+    const bool has_dxo = a.dx_out != nullptr;
+    const rsrc_t rdxo = make_rsrc(has_dxo ? a.dx_out + (int64_t)b * FC * T : a.dskip + (int64_t)b * FC * T);
+    const rsrc_t rdsk = make_rsrc(a.dskip + (int64_t)b * FC * T);
+    const rsrc_t ry = make_rsrc(a.y16 + (int64_t)b * 2 * FC * T);
+    const rsrc_t rdx = make_rsrc(a.dx + (int64_t)b * FC * T);
+    const rsrc_t rdy = make_rsrc(a.dy16 + (int64_t)b * 2 * FC * T), rdo = make_rsrc(a.do16 + (int64_t)b * 2 * FC * T);
+    const rsrc_t rdc = make_rsrc(a.dcond + (int64_t)b * FH * T);
+    const unsigned short *img = reinterpret_cast<const unsigned short *>(a.img);
+    const rsrc_t rwt2 = make_rsrc(img + OFF_WT2 + (int64_t)w * 32 * 512);
+    const rsrc_t rwt1 = make_rsrc(img + OFF_WT1 + (int64_t)w * 96 * 512);
+    const rsrc_t rwtc = make_rsrc(img + OFF_WTC + (int64_t)min(w, 5) * 32 * 512);
+    const unsigned lane16 = 16u * (unsigned)lane;
+
+    // ---- stage d_o = [dx_out / sqrt2 ; dskip] as [frame][512] bf16 (+ its bf16 copy in HBM for the weight gradient)
+    {
+        const int f = tid & 127, cg = __builtin_amdgcn_readfirstlane(tid >> 7);
+        const int t = ts + f;
+        const bool tv = t >= 0 && t < T;
+        const bool central = tv && f >= d && f < FNT - d;
+        const unsigned tc = (unsigned)min(max(t, 0), T - 1);
+        const rsrc_t rs = cg < 2 ? rdxo : rdsk;
+        const float sc = cg < 2 ? (has_dxo ? RSQRT2 : 0.0f) : 1.0f;
+        const int cs0 = 128 * (cg & 1);  // channel inside the source tensor
+#pragma unroll
+        for (int hq = 0; hq < 4; ++hq) {
+            float v[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) v[k] = buf_load(rs, 4u * tc, (unsigned)(cs0 + 32 * hq + k) * T4) * sc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u32x4_t u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[e] = tv ? pack2(v[8 * q + 2 * e], v[8 * q + 2 * e + 1]) : 0u;
+                *reinterpret_cast<u32x4_t *>(lds + (f + d) * DR + (128 * cg + 32 * hq + 8 * q) * 2) = u;
+            }
+            if (central) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) buf_store_u16(f2bf(v[k]), rdo, 2u * tc, (unsigned)(128 * cg + 32 * hq + k) * T2);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- bias gradient of the output projection: column sums of the central rows of the d_o tile (thread = channel)
+    {
+        float s = 0.0f;
+        for (int j = d; j < FNT - d; ++j) s += bf2f(*reinterpret_cast<const unsigned short *>(lds + (j + d) * DR + tid * 2));
+        a.part_dbo[(int64_t)part_row * 2 * FC + tid] = s;  // rows outside [0, T) were staged as zeros
+    }
+
+    // ---- GEMM A: dz[256 x 128] = Wout^T d_o
+    f32x16 dz[1][4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) dz[0][cb] = (f32x16){0};
+    gemm_bf16<1, 4>(dz, rwt2, lane16, 0, 32, lds, [&](int ks, int cb) {
+        return (unsigned)((cb * 32 + l31 + d) * DR + (ks * 16 + half * 8) * 2);
+    });
+
+    // ---- gate derivative (lane-local), dy over the tile, dy to HBM, bias partial sums
+    bool cen[4];
+    unsigned vo4[4], vo2[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int j = cb * 32 + l31, t = ts + j;
+        cen[cb] = t >= 0 && t < T && j >= d && j < FNT - d;
+        const int tc = min(max(t, 0), T - 1);
+        vo4[cb] = 4u * (unsigned)(4 * half * T + tc);
+        vo2[cb] = 2u * (unsigned)(4 * half * T + tc);
+    }
+    __syncthreads();  // every wave is done reading the d_o tile
+    {
+        float sg[16], sf[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sg[r] = sf[r] = 0.0f;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            unsigned short yg[16], yf[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned ur = (unsigned)(32 * w + urow(r));
+                yg[r] = buf_load_u16(ry, vo2[cb], ur * T2);
+                yf[r] = buf_load_u16(ry, vo2[cb], (ur + FC) * T2);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned ur = (unsigned)(32 * w + urow(r));
+                const float s = fsig(bf2f(yg[r])), th = ftanh(bf2f(yf[r]));
+                const float g = dz[0][cb][r];  // exactly 0 on frames outside [0, T): d_o was staged as zeros there
+                const float dg = g * th * s * (1.0f - s), df = g * s * (1.0f - th * th);
+                const unsigned short bg = f2bf(dg), bfv = f2bf(df);
+                unsigned char *row = lds + (cb * 32 + l31 + d) * DR + (32 * w + urow(r) + 4 * half) * 2;
+                *reinterpret_cast<unsigned short *>(row) = bg;
+                *reinterpret_cast<unsigned short *>(row + FC * 2) = bfv;
+                if (cen[cb]) {
+                    buf_store_u16(bg, rdy, vo2[cb], ur * T2);
+                    buf_store_u16(bfv, rdy, vo2[cb], (ur + FC) * T2);
+                    sg[r] += bf2f(bg);
+                    sf[r] += bf2f(bfv);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a0 = half_sum(sg[r]), a1 = half_sum(sf[r]);
+            if (l31 == 0) {
+                const int c = 32 * w + urow(r) + 4 * half;
+                a.part_dby[(int64_t)part_row * 2 * FC + c] = a0;
+                a.part_dby[(int64_t)part_row * 2 * FC + FC + c] = a1;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- GEMM B: dxd[256 x 128] = sum_tap Wdil[tap]^T dy shifted by (1 - tap) dil ;  GEMM C (waves 0..5): dcond = Wcond^T dy
+    f32x16 dxd[1][4], dcn[1][4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) { dxd[0][cb] = (f32x16){0}; dcn[0][cb] = (f32x16){0}; }
+    gemm_bf16<1, 4>(dxd, rwt1, lane16, 0, 96, lds, [&](int ks, int cb) {
+        const int tap = ks >> 5, c0 = (ks & 31) * 16;
+        return (unsigned)((cb * 32 + l31 + (2 - tap) * d) * DR + (c0 + half * 8) * 2);
+    });
+    if (w < 6)
+        gemm_bf16<1, 4>(dcn, rwtc, lane16, 0, 32, lds, [&](int ks, int cb) {
+            return (unsigned)((cb * 32 + l31 + d) * DR + (ks * 16 + half * 8) * 2);
+        });
+
+    // ---- epilogue: dx = dx_out / sqrt2 + dxd ; step-embedding partial sums ; dcond (+)= dcn
+    {
+        float sd[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sd[r] = 0.0f;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = buf_load(rdxo, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+            if (cen[cb]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = dxd[0][cb][r];
+                    sd[r] += v;
+                    buf_store(has_dxo ? v + rv[r] * RSQRT2 : v, rdx, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a0 = half_sum(sd[r]);
+            if (l31 == 0) a.part_dd[(int64_t)part_row * FC + 32 * w + urow(r) + 4 * half] = a0;
+        }
+        if (w < 6) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pv[r] = buf_load(rdc, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+                if (cen[cb]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        buf_store(a.dcond_first ? dcn[0][cb][r] : pv[r] + dcn[0][cb][r], rdc, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+                }
+            }
+        }
+    }
+}
+
+// out[g][j] (+)= sum_r part[(g * rows + r) * cols + j]   (fixed order: deterministic)
+__global__ void __launch_bounds__(256) partial_rows_sum_kernel(const float *part, float *out, int groups, int rows, int cols,
+                                                               int accumulate, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)groups * cols) return;
+    const int g = (int)(i / cols), j = (int)(i % cols);
+    float s = 0.0f;
+    for (int r = 0; r < rows; ++r) s += part[((int64_t)g * rows + r) * cols + j];
+    s *= scale;
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+}  // namespace
+
+extern "C" int64_t set_diffnet_layer_bf16_image_size(void) { return N_IMG; }
+
+extern "C" int set_pack_diffnet_layer_bf16(const float *wdil, const float *wcond, const float *wout, void *img, void *stream) {
+    SET_REQUIRE(wdil && wcond && wout && img, "set_pack_diffnet_layer_bf16");
+    hipLaunchKernelGGL(pack_layer_bf16_kernel, dim3(set_blocks(N_IMG, 256)), dim3(256), 0, (hipStream_t)stream, wdil, wcond, wout,
+                       reinterpret_cast<unsigned short *>(img));
+    return set_check_launch("set_pack_diffnet_layer_bf16");
+}
+
+extern "C" int64_t set_sizeof_diffnet_layer_bf16_args(void) { return (int64_t)sizeof(SetDiffnetLayerBf16Args); }
+
+extern "C" int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, void *stream) {
+    SET_REQUIRE(args != nullptr, "set_diffnet_layer_fwd_bf16");
+    const SetDiffnetLayerBf16Args &a = *args;
+    SET_REQUIRE(a.x_in && a.x_out && a.skip && a.cond && a.dstep && a.img && a.b_dil && a.b_cond && a.b_out && a.y16 && a.z16,
+                "set_diffnet_layer_fwd_bf16");
+    SET_REQUIRE(a.B > 0 && a.T > 0 && a.dil >= 1 && a.dil <= 8, "set_diffnet_layer_fwd_bf16");
+    SET_REQUIRE((int64_t)2 * FC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_layer_fwd_bf16 (T too large)");
+    const size_t ldsz = (size_t)(FNT + 2 * a.dil) * XR + (size_t)FNT * CR;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layer fwd bf16 attr");
+        attr_set = true;
+    }
+    dim3 grid((a.T + FNT - 1) / FNT, a.B);
+    hipLaunchKernelGGL(diffnet_layer_fwd_bf16_kernel, grid, dim3(512), ldsz, (hipStream_t)stream, a);
+    return set_check_launch("set_diffnet_layer_fwd_bf16");
+}
+
+extern "C" int64_t set_sizeof_diffnet_layer_bf16_bwd_args(void) { return (int64_t)sizeof(SetDiffnetLayerBf16BwdArgs); }
+
+extern "C" int32_t set_diffnet_layer_bwd_bf16_tiles(int32_t T, int32_t dil) { return (T + (FNT - 2 * dil) - 1) / (FNT - 2 * dil); }
+
+extern "C" int set_diffnet_layer_bwd_bf16(const SetDiffnetLayerBf16BwdArgs *args, void *stream) {
+    SET_REQUIRE(args != nullptr, "set_diffnet_layer_bwd_bf16");
+    const SetDiffnetLayerBf16BwdArgs &a = *args;
+    SET_REQUIRE(a.dskip && a.y16 && a.img && a.dx && a.dy16 && a.do16 && a.dcond && a.part_dbo && a.part_dby && a.part_dd,
+                "set_diffnet_layer_bwd_bf16");
+    SET_REQUIRE(a.B > 0 && a.T > 0 && a.dil >= 1 && a.dil <= 8, "set_diffnet_layer_bwd_bf16");
+    SET_REQUIRE((int64_t)2 * FC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_layer_bwd_bf16 (T too large)");
+    const size_t ldsz = (size_t)(FNT + 2 * a.dil) * DR;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_bwd_bf16_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layer bwd bf16 attr");
+        attr_set = true;
+    }
+    dim3 grid(set_diffnet_layer_bwd_bf16_tiles(a.T, a.dil), a.B);
+    hipLaunchKernelGGL(diffnet_layer_bwd_bf16_kernel, grid, dim3(512), ldsz, (hipStream_t)stream, a);
+    return set_check_launch("set_diffnet_layer_bwd_bf16");
+}
+
+extern "C" int set_partial_rows_sum(const float *part, float *out, int32_t groups, int32_t rows, int32_t cols, int32_t accumulate,
+                                    float scale, void *stream) {
+    SET_REQUIRE(part && out && groups > 0 && rows > 0 && cols > 0, "set_partial_rows_sum");
+    hipLaunchKernelGGL(partial_rows_sum_kernel, dim3(set_blocks((int64_t)groups * cols, 256)), dim3(256), 0, (hipStream_t)stream,
+                       part, out, groups, rows, cols, accumulate, scale);
+    return set_check_launch("set_partial_rows_sum");
+}

@@ -113,6 +113,25 @@ class DiffNet(nn.Module):
             self._packs, self._packs_key = (w1, w2, bd, bo, w1w, w2w), key
         return self._packs
 
+    def bf16_layer_images(self):
+        """Per-layer packed bf16 weight images of the fused training kernels (forward GEMM 1 / 2 and the three transposed
+        images of the backward), re-rounded from the fp32 master weights whenever they change."""
+        layers = list(self.residual_layers)
+        key = tuple((p.data_ptr(), p._version) for l in layers for p in
+                    (l.dilated_conv.weight, l.conditioner_projection.weight, l.output_projection.weight))
+        key = key + (ops.weights_epoch(),)
+        if getattr(self, "_img16", None) is None or self._img16_key != key:
+            from . import _lib
+            n = _lib.lib().set_diffnet_layer_bf16_image_size()
+            dev = layers[0].dilated_conv.weight.device
+            img = torch.empty(len(layers), n, dtype=torch.bfloat16, device=dev)
+            for i, l in enumerate(layers):
+                _lib.check(_lib.lib().set_pack_diffnet_layer_bf16(
+                    ops._p(l.dilated_conv.weight.detach()), ops._p(l.conditioner_projection.weight.detach()),
+                    ops._p(l.output_projection.weight.detach()), ops._p(img[i]), ops._stream()), "set_pack_diffnet_layer_bf16")
+            self._img16, self._img16_key = img, key
+        return self._img16
+
     def step_table(self, t_values):
         """d[l][c][n] = diffusion_projection_l(mlp(sinusoid(t_n)))[c]  ->  tensor [L*C, n]
         (diffnet.py:121-122 and :69).  t_values: float tensor [n]; depends on t only, so the reverse
@@ -187,7 +206,16 @@ class DiffNet(nn.Module):
         use_stack = (self.can_fuse() and self.impl != "unfused" and os.environ.get("SET_AMD_TRAIN_STACK", "1") != "0"
                      and ops.compute_dtype() == "f32"
                      and ops.stack_variant(x.shape[0], x.shape[2], self.dilation_cycle_length) == 2)
-        if use_stack:
+        use_bf16_layers = (self.can_fuse() and self.impl != "unfused" and ops.compute_dtype() == "bf16"
+                           and self.encoder_hidden == 192 and os.environ.get("SET_AMD_TRAIN_STACK", "1") != "0"
+                           and x.shape[2] >= 32)
+        if use_bf16_layers:
+            # bf16 operands: one fused forward and one fused backward launch per layer (csrc/diffnet_bf16.hip)
+            ds = [A.conv1d(hs_[li], layer._w_dproj, layer.diffusion_projection.bias)[0].t()
+                  for li, layer in enumerate(self.residual_layers)]
+            dmat = torch.cat(ds, dim=1)
+            skip = A.diffnet_stack_train_bf16(self, hx, cond, dmat)
+        elif use_stack:
             # fused forward: one persistent Winograd launch for all L layers (+ saved x/y/z), hand-ordered backward
             ds = [A.conv1d(hs_[li], layer._w_dproj, layer.diffusion_projection.bias)[0].t()
                   for li, layer in enumerate(self.residual_layers)]          # L x [n, C]

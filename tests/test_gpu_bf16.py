@@ -192,9 +192,10 @@ def test_deterministic_wgrad_is_bit_stable_and_matches_the_atomic_kernel(dev, dt
     assert _rel(outs[0], ref) < tol
 
 
-def _run_training_golden(dev, dtype, monkeypatch):
+def _run_training_golden(dev, dtype, monkeypatch, fused=False):
     from set_amd import hparams as H, ops, tasks
-    monkeypatch.setenv("SET_AMD_TRAIN_STACK", "0")  # same op sequence for both operand types
+    # fused=False: one differentiable kernel per op for both operand types; True: the fused bf16 layer kernels
+    monkeypatch.setenv("SET_AMD_TRAIN_STACK", "1" if fused else "0")
     g = load_golden("train_losses")
     m = g["meta"]
     H.hparams.clear()
@@ -221,12 +222,14 @@ def _run_training_golden(dev, dtype, monkeypatch):
     return g, {k: float(v) for k, v in losses.items()}, out["mel_out_bct"].detach().transpose(1, 2).cpu(), grads
 
 
-def test_training_golden_within_the_bf16_tolerance(dev, monkeypatch):
+@pytest.mark.parametrize("layers", ["per_op", "fused_layers"])
+def test_training_golden_within_the_bf16_tolerance(dev, monkeypatch, layers):
     """The reference-generated training golden under bf16 operands: every loss within BF16_LOSS_REL of the reference's
     value, mel_out within BF16_MEL_MCD (mel-level MCD) of the fp32 path's, every parameter gradient within
-    BF16_GRAD_REL / BF16_GRAD_COS of the fp32 path's."""
+    BF16_GRAD_REL / BF16_GRAD_COS of the fp32 path's.  `fused_layers`: the DiffNet layers through the fused bf16 forward /
+    backward kernels (what a training run uses); `per_op`: one kernel per op."""
     g, l32, mel32, g32 = _run_training_golden(dev, "f32", monkeypatch)
-    _, l16, mel16, g16 = _run_training_golden(dev, "bf16", monkeypatch)
+    _, l16, mel16, g16 = _run_training_golden(dev, "bf16", monkeypatch, fused=(layers == "fused_layers"))
     for k in ("l1_coarse", "ssim_coarse", "pdur", "wdur", "uv", "f0"):
         ref = float(g["loss_" + k])
         assert abs(l32[k] - ref) < 2e-5 * max(1.0, abs(ref))                    # the fp32 leg is the parity path
@@ -257,11 +260,110 @@ def test_training_golden_within_the_bf16_tolerance(dev, monkeypatch):
 def test_bf16_training_step_is_deterministic(dev, monkeypatch):
     """Two identical bf16 steps from the same state give bit-identical gradients for every conv / linear weight (the
     weight-gradient GEMMs have no atomics).  Full-step determinism incl. the embedding tables is the fp32 test's job."""
-    _, _, _, a = _run_training_golden(dev, "bf16", monkeypatch)
-    _, _, _, b = _run_training_golden(dev, "bf16", monkeypatch)
+    _, _, _, a = _run_training_golden(dev, "bf16", monkeypatch, fused=True)
+    _, _, _, b = _run_training_golden(dev, "bf16", monkeypatch, fused=True)
     n = 0
     for k in a:
         if a[k] is not None and a[k].dim() >= 2 and "embed" not in k and "emb" not in k:
             assert torch.equal(a[k], b[k]), k
             n += 1
     assert n > 100
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fused bf16 DiffNet layer kernels (csrc/diffnet_bf16.hip) against a torch emulation with the same rounding points
+# ----------------------------------------------------------------------------------------------------------------------
+RS2 = 0.70710678118654752440
+
+
+def _emu_layer_fwd(x, skip, cond, dvec, Wd, bd, Wc, bc, Wo, bo, dil, first):
+    xin = _r(x + dvec[:, :, None])
+    y = F.conv1d(F.pad(xin, (dil, dil)), _r(Wd), None, dilation=dil) + F.conv1d(_r(cond), _r(Wc)) + (bd + bc)[None, :, None]
+    C = x.shape[1]
+    z = torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
+    o = F.conv1d(_r(z), _r(Wo)) + bo[None, :, None]
+    x_out = (x + o[:, :C]) * RS2
+    skip_out = o[:, C:] if first else skip + o[:, C:]
+    return x_out, skip_out, _r(y), _r(z), xin
+
+
+def _emu_layer_bwd(dxo, dsk, y16, z16, xin, cond, Wd, Wc, Wo, dil):
+    C = dsk.shape[1]
+    T = dsk.shape[2]
+    d_o = _r(torch.cat([(dxo * RS2) if dxo is not None else torch.zeros_like(dsk), dsk], 1))
+    dz = F.conv1d(d_o, _r(Wo).transpose(0, 1).contiguous())
+    s, th = torch.sigmoid(y16[:, :C]), torch.tanh(y16[:, C:])
+    dy = _r(torch.cat([dz * th * s * (1 - s), dz * s * (1 - th * th)], 1))
+    dxd = F.conv_transpose1d(dy, _r(Wd), None, dilation=dil)[:, :, dil:dil + T]
+    dx = dxd + (dxo * RS2 if dxo is not None else 0.0)
+    dcond = F.conv1d(dy, _r(Wc).transpose(0, 1).contiguous())
+    dd = dxd.sum(2)
+    xp = F.pad(xin, (dil, dil))
+    dWd = torch.stack([torch.einsum("bot,bit->oi", dy, xp[:, :, k * dil:k * dil + T]) for k in range(3)], dim=-1)
+    dWc = torch.einsum("bot,bit->oi", dy, _r(cond))[:, :, None]
+    dWo = torch.einsum("bot,bit->oi", d_o, z16)[:, :, None]
+    return dx, dcond, dd, dWd, dWc, dWo, d_o.sum((0, 2)), dy.sum((0, 2))
+
+
+@pytest.mark.parametrize("T,cycle", [(300, 1), (97, 2), (800, 1)])
+def test_fused_bf16_layers_match_emulation(dev, bf16, T, cycle):
+    """2-3 layers through _DiffNetStackBf16Fn (fused forward + fused backward + bf16 weight gradients) against a torch
+    emulation that rounds exactly where the kernels round (x+d, cond, z, d_o, dy, weights -> bf16; y / z saved in bf16).
+    Tolerances: a bf16 rounding that flips on an fp32 summation-order difference moves one product by 2^-9 relative, so
+    the bars are relative to the largest entry of each tensor, not 1e-5."""
+    from set_amd import autograd_ops as A
+    from set_amd.diffnet import DiffNet
+    L = 3 if cycle == 2 else 2
+    hp = base_hparams(residual_layers=L, dilation_cycle_length=cycle)
+    torch.manual_seed(T)
+    dn = DiffNet(80, hp).to(dev)
+    B, C, H = 2, 256, 192
+    g = torch.Generator().manual_seed(T + 7)
+    hx = torch.randn(B, C, T, generator=g)
+    cond = torch.randn(B, H, T, generator=g)
+    dmat = torch.randn(B, L * C, generator=g) * 0.5
+    gsk = torch.randn(B, C, T, generator=g)
+    W = []
+    for l in dn.residual_layers:
+        for p in (l.dilated_conv.weight, l.conditioner_projection.weight, l.output_projection.weight):
+            p.data.mul_(0.5)
+        for p in (l.dilated_conv.bias, l.conditioner_projection.bias, l.output_projection.bias):
+            p.data.normal_(0.0, 0.1)
+        W.append([t.detach().cpu().clone() for t in (l.dilated_conv.weight, l.dilated_conv.bias, l.conditioner_projection.weight,
+                                                       l.conditioner_projection.bias, l.output_projection.weight,
+                                                       l.output_projection.bias)])
+    # ---- emulation
+    x, skip, saves = hx, None, []
+    for l in range(L):
+        Wd, bd, Wc, bc, Wo, bo = W[l]
+        dil = dn.residual_layers[l].dilation
+        xo, skip, y16, z16, xin = _emu_layer_fwd(x, skip, cond, dmat[:, l * C:(l + 1) * C], Wd, bd, Wc, bc, Wo, bo, dil, l == 0)
+        saves.append((y16, z16, xin))
+        x = xo
+    want_skip = skip
+    dxo, dcond_w, dd_w, gw = None, torch.zeros_like(cond), [], []
+    for l in range(L - 1, -1, -1):
+        Wd, bd, Wc, bc, Wo, bo = W[l]
+        y16, z16, xin = saves[l]
+        dx, dc, dd, dWd, dWc, dWo, dbo, dby = _emu_layer_bwd(dxo, gsk, y16, z16, xin, cond, Wd, Wc, Wo, dn.residual_layers[l].dilation)
+        dcond_w += dc
+        dd_w.insert(0, dd)
+        gw.insert(0, (dWd, dby, dWc, dby, dWo, dbo))
+        dxo = dx
+    # ---- kernels
+    hxd, cd, dmd = (t.clone().to(dev).requires_grad_(True) for t in (hx, cond, dmat))
+    with torch.enable_grad():
+        got_skip = A.diffnet_stack_train_bf16(dn, hxd, cd, dmd)
+        got_skip.backward(gsk.to(dev))
+    torch.cuda.synchronize()
+    assert _rel(got_skip, want_skip) < 2e-3
+    assert _rel(hxd.grad, dxo) < 4e-3
+    assert _rel(cd.grad, dcond_w) < 4e-3
+    assert _rel(dmd.grad, torch.cat(dd_w, 1)) < 4e-3
+    for l, layer in enumerate(dn.residual_layers):
+        dWd, dby, dWc, _, dWo, dbo = gw[l]
+        assert _rel(layer.dilated_conv.weight.grad, dWd) < 4e-3, l
+        assert _rel(layer.conditioner_projection.weight.grad, dWc.reshape(layer.conditioner_projection.weight.shape)) < 4e-3, l
+        assert _rel(layer.output_projection.weight.grad, dWo.reshape(layer.output_projection.weight.shape)) < 4e-3, l
+        assert _rel(layer.dilated_conv.bias.grad, dby) < 4e-3 and _rel(layer.conditioner_projection.bias.grad, dby) < 4e-3, l
+        assert _rel(layer.output_projection.bias.grad, dbo) < 4e-3, l
