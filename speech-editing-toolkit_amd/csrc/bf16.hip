@@ -456,6 +456,123 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
         }
 }
 
+// ---- 3-tap weight gradient with all taps in one block -----------------------------------------------------------------
+// The one-tap-per-block kernel above re-reads the output gradient G once per (tap, ci tile) and the conv input X once per
+// (tap, co tile): 470 MB for the DiffNet dilated conv at B=32, T=800 (dW = 512 x 256 x 3) against 52 MB of operands.
+// Here a block owns a 128 (co) x 64 (ci) tile of dW for ALL three taps: G is staged once per 64-frame chunk, X once with
+// its 2 dil halo frames, written to three LDS copies shifted by the tap offsets (copy k, column j = frame t0 + j + k dil
+// - pad), so the MFMA fragment reads stay 16-byte aligned.  Traffic: G x Cin/64 + X x Cout/128 (208 MB for that conv).
+template <bool GB16>
+__global__ void __launch_bounds__(256, 2) conv1d_wgrad3_bf16_kernel(WgradBf16Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char Gs[128 * WGB_ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[3 * 64 * WGB_ROWB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 128;
+    const int sh0 = -a.pad, dil = a.dil;  // tap k reads frame t + k dil - pad
+    const int total_chunks = a.B * a.n_chunks_t;
+    const int c_begin = blockIdx.z * a.chunks_per_slice;
+    const int c_end = min(c_begin + a.chunks_per_slice, total_chunks);
+    const bool has_add = a.chan_add != nullptr;
+    constexpr unsigned GE = GB16 ? 2u : 4u;
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[k][i] = (f32x16){0};
+
+    const int sk = lane, sr0 = wave;
+    unsigned gv[32];
+    float xa[16], xb[16], av[16];
+    auto issue = [&](int ch) {
+        const int b = ch / a.n_chunks_t, t0 = (ch % a.n_chunks_t) * WGB_KT;
+        const unsigned vg = (unsigned)min(t0 + sk, a.T - 1) * GE;
+        const unsigned va = (unsigned)min(max(t0 + sh0 + sk, 0), a.T_in - 1) * 4u;
+        const unsigned vb = (unsigned)min(max(t0 + sh0 + 64 + sk, 0), a.T_in - 1) * 4u;
+        const rsrc_t d_g = make_rsrc(reinterpret_cast<const unsigned char *>(a.g) + (int64_t)b * a.Cout * a.T * GE);
+        const rsrc_t d_x = make_rsrc(reinterpret_cast<const float *>(a.x) + (int64_t)b * a.Cin * a.T_in);
+        const rsrc_t d_a = make_rsrc(has_add ? a.chan_add + (int64_t)b * a.Cin : reinterpret_cast<const float *>(a.x));
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const unsigned so = (unsigned)(min(co0 + sr0 + 4 * j, a.Cout - 1) * a.T) * GE;
+            gv[j] = GB16 ? buf_load_raw16(d_g, vg, so) : buf_load_raw(d_g, vg, so);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int cic = min(ci0 + sr0 + 4 * j, a.Cin - 1);
+            xa[j] = buf_load(d_x, va, (unsigned)(cic * a.T_in) * 4u);
+            xb[j] = buf_load(d_x, vb, (unsigned)(cic * a.T_in) * 4u);
+            av[j] = buf_load(d_a, 0u, (unsigned)cic * 4u);
+        }
+    };
+    auto commit = [&](int ch) {
+        const int t0 = (ch % a.n_chunks_t) * WGB_KT;
+        const bool tv = t0 + sk < a.T;
+        const int fa = t0 + sh0 + sk, fb = fa + 64;  // frames of the two loaded values
+        const bool va = fa >= 0 && fa < a.T_in, vb = fb >= 0 && fb < a.T_in;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int row = sr0 + 4 * j;
+            unsigned short gb;
+            if constexpr (GB16) gb = (unsigned short)gv[j];
+            else gb = bf16_bits(__builtin_bit_cast(float, gv[j]));
+            *reinterpret_cast<unsigned short *>(Gs + row * WGB_ROWB + sk * 2) = (tv && co0 + row < a.Cout) ? gb : (unsigned short)0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = sr0 + 4 * j;
+            const bool cv = ci0 + row < a.Cin;
+            const float ad = has_add ? av[j] : 0.0f;
+            const unsigned short ba = (va && cv) ? bf16_bits(xa[j] + ad) : (unsigned short)0;
+            const unsigned short bb = (vb && cv) ? bf16_bits(xb[j] + ad) : (unsigned short)0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                // value at tile offset q (= sk or 64 + sk, frame t0 - pad + q) is column q - k dil of copy k
+                const int ja = sk - k * dil, jb = 64 + sk - k * dil;
+                unsigned char *base = Xs + (k * 64 + row) * WGB_ROWB;
+                if (ja >= 0) *reinterpret_cast<unsigned short *>(base + ja * 2) = ba;
+                if (jb < 64) *reinterpret_cast<unsigned short *>(base + jb * 2) = bb;
+            }
+        }
+    };
+    if (c_begin < c_end) issue(c_begin);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        __syncthreads();
+        commit(ch);
+        __syncthreads();
+        if (ch + 1 < c_end) issue(ch + 1);
+        const unsigned char *ap = Gs + (wm * 64 + l31) * WGB_ROWB + half * 16;
+#pragma unroll
+        for (int ks = 0; ks < WGB_KT / 16; ++ks) {
+            const u32x4 a0 = *reinterpret_cast<const u32x4 *>(ap + ks * 32);
+            const u32x4 a1 = *reinterpret_cast<const u32x4 *>(ap + 32 * WGB_ROWB + ks * 32);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const u32x4 bk = *reinterpret_cast<const u32x4 *>(Xs + (k * 64 + wn * 32 + l31) * WGB_ROWB + half * 16 + ks * 32);
+                acc[k][0] = mfma_bf16(a0, bk, acc[k][0]);
+                acc[k][1] = mfma_bf16(a1, bk, acc[k][1]);
+            }
+        }
+    }
+    float *pz = a.partial + (int64_t)blockIdx.z * a.Cout * a.Cin * 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 64 + i * 32 + mfma32_row(r, lane);
+            const int ci = ci0 + wn * 32 + l31;
+            if (co < a.Cout && ci < a.Cin) {
+                float *p = pz + ((int64_t)co * a.Cin + ci) * 3;
+                p[0] = acc[0][i][r];
+                p[1] = acc[1][i][r];
+                p[2] = acc[2][i][r];
+            }
+        }
+}
+
 // dw[i] += sum_{s < S} partial[s][i]   (slice order: the sum has one fixed association)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *partial, float *dw, int64_t n, int S) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -508,20 +625,27 @@ int wgrad_f32_slices(int B, int Cin, int Cout, int K, int T);
 int launch_wgrad_f32_partial(const float *g, const float *x, const float *chan_add, float *partial, int B, int Cin, int Cout,
                              int K, int dil, int pad, int T, int T_in, int pro, float pro_param, hipStream_t s);
 
-static int wgrad_bf16_slices(int B, int Cin, int Cout, int K, int T) {
+static bool wgrad3_applies(int K, int dil, int pad, int pro, int dtype) {
+    const int d = dil < 0 ? -dil : dil;
+    return K == 3 && dil > 0 && 2 * d <= 64 && pad >= 0 && pro == SET_PRO_NONE && (dtype == SET_DTYPE_BF16 || dtype == SET_DTYPE_BF16_G16);
+}
+
+static int wgrad_bf16_slices(int B, int Cin, int Cout, int K, int T, bool taps3 = false) {
     const int n_chunks_t = (T + WGB_KT - 1) / WGB_KT;
     const int64_t total_chunks = (int64_t)B * n_chunks_t;
-    const int tiles = K * ((Cin + 127) / 128) * ((Cout + 127) / 128);
+    const int tiles = taps3 ? ((Cin + 63) / 64) * ((Cout + 127) / 128) : K * ((Cin + 127) / 128) * ((Cout + 127) / 128);
     int64_t S = (640 + tiles - 1) / tiles;  // ~2.5 blocks per CU
     if (S > total_chunks) S = total_chunks;
-    if (S > 64) S = 64;
+    if (S > (taps3 ? 32 : 64)) S = taps3 ? 32 : 64;
     if (S < 1) S = 1;
     const int64_t cps = (total_chunks + S - 1) / S;
     return (int)((total_chunks + cps - 1) / cps);  // no empty slices
 }
 
 extern "C" int64_t set_conv1d_wgrad_scratch_floats(int32_t B, int32_t Cin, int32_t Cout, int32_t K, int32_t T, int32_t dtype) {
-    const int S = dtype != SET_DTYPE_F32 ? wgrad_bf16_slices(B, Cin, Cout, K, T) : wgrad_f32_slices(B, Cin, Cout, K, T);
+    // upper bound over the kernel variants of the dtype (the 3-tap variant is chosen from dil / pad / pro at call time)
+    int S = dtype != SET_DTYPE_F32 ? wgrad_bf16_slices(B, Cin, Cout, K, T) : wgrad_f32_slices(B, Cin, Cout, K, T);
+    if (dtype != SET_DTYPE_F32 && K == 3) { const int S3 = wgrad_bf16_slices(B, Cin, Cout, K, T, true); S = S3 > S ? S3 : S; }
     return (int64_t)S * Cout * Cin * K;
 }
 
@@ -534,9 +658,24 @@ extern "C" int set_conv1d_wgrad_det(const void *g, const void *x, const float *c
     SET_REQUIRE(scratch_floats >= need, "set_conv1d_wgrad_det (scratch too small)");
     SET_REQUIRE((int64_t)Cout * T * 4 < ((int64_t)1 << 31) && (int64_t)Cin * T_in * 4 < ((int64_t)1 << 31),
                 "set_conv1d_wgrad_det (one batch slice exceeds 2 GiB)");
-    const int S = (int)(need / n);
+    int S = (int)(need / n);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype != SET_DTYPE_F32) {
+    if (wgrad3_applies(K, dil, pad, pro, dtype)) {
+        S = wgrad_bf16_slices(B, Cin, Cout, K, T, true);
+        WgradBf16Args a;
+        a.g = g; a.x = x; a.chan_add = chan_add; a.partial = scratch;
+        a.B = B; a.Cin = Cin; a.Cout = Cout; a.K = K; a.dil = dil; a.pad = pad; a.T = T; a.T_in = T_in; a.pro = pro;
+        a.pro_param = pro_param;
+        a.n_chunks_t = (T + WGB_KT - 1) / WGB_KT;
+        a.chunks_per_slice = (B * a.n_chunks_t + S - 1) / S;
+        a.ci_tiles = (Cin + 63) / 64;
+        dim3 grid(a.ci_tiles, (Cout + 127) / 128, S);
+        if (dtype == SET_DTYPE_BF16) hipLaunchKernelGGL((conv1d_wgrad3_bf16_kernel<false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv1d_wgrad3_bf16_kernel<true>), grid, dim3(256), 0, s, a);
+        const int rc = set_check_launch("set_conv1d_wgrad_det(bf16, 3 taps)");
+        if (rc != SET_OK) return rc;
+    } else if (dtype != SET_DTYPE_F32) {
+        S = wgrad_bf16_slices(B, Cin, Cout, K, T);
         SET_REQUIRE(dtype == SET_DTYPE_BF16 || dtype == SET_DTYPE_BF16_G16 || dtype == SET_DTYPE_BF16_G16_X16, "set_conv1d_wgrad_det (dtype)");
         SET_REQUIRE(dtype != SET_DTYPE_BF16_G16_X16 || (chan_add == nullptr && pro == SET_PRO_NONE), "set_conv1d_wgrad_det (bf16 x takes no prologue)");
         WgradBf16Args a;

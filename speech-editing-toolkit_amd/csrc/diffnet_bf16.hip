@@ -495,16 +495,23 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffn
     }
 }
 
-// out[g][j] (+)= sum_r part[(g * rows + r) * cols + j]   (fixed order: deterministic)
-__global__ void __launch_bounds__(256) partial_rows_sum_kernel(const float *part, float *out, int groups, int rows, int cols,
+// out[g][j] (+)= scale * sum_r part[(g * rows + r) * cols + j].  Block = 64 columns x 4 row groups: thread (j, rg) adds rows
+// rg, rg + 4, ... in order, the four group sums are combined in group order -> one fixed association, deterministic.
+__global__ void __launch_bounds__(256) partial_rows_sum_kernel(const float *part, float *out, int rows, int cols,
                                                                int accumulate, float scale) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)groups * cols) return;
-    const int g = (int)(i / cols), j = (int)(i % cols);
+    __shared__ float red[4][64];
+    const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tl, g = blockIdx.y;
     float s = 0.0f;
-    for (int r = 0; r < rows; ++r) s += part[((int64_t)g * rows + r) * cols + j];
-    s *= scale;
-    out[i] = accumulate ? out[i] + s : s;
+    if (j < cols)
+        for (int r = rg; r < rows; r += 4) s += part[((int64_t)g * rows + r) * cols + j];
+    red[rg][tl] = s;
+    __syncthreads();
+    if (rg == 0 && j < cols) {
+        s = (((red[0][tl] + red[1][tl]) + red[2][tl]) + red[3][tl]) * scale;
+        float *o = out + (int64_t)g * cols + j;
+        *o = accumulate ? *o + s : s;
+    }
 }
 
 }  // namespace
@@ -565,7 +572,7 @@ extern "C" int set_diffnet_layer_bwd_bf16(const SetDiffnetLayerBf16BwdArgs *args
 extern "C" int set_partial_rows_sum(const float *part, float *out, int32_t groups, int32_t rows, int32_t cols, int32_t accumulate,
                                     float scale, void *stream) {
     SET_REQUIRE(part && out && groups > 0 && rows > 0 && cols > 0, "set_partial_rows_sum");
-    hipLaunchKernelGGL(partial_rows_sum_kernel, dim3(set_blocks((int64_t)groups * cols, 256)), dim3(256), 0, (hipStream_t)stream,
-                       part, out, groups, rows, cols, accumulate, scale);
+    hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((cols + 63) / 64, groups), dim3(256), 0, (hipStream_t)stream, part, out, rows,
+                       cols, accumulate, scale);
     return set_check_launch("set_partial_rows_sum");
 }
