@@ -406,6 +406,29 @@ int set_pack_conv_weight_bf16(const float *w, void *wp, int32_t Cout, int32_t Ci
                               int64_t w_sco, int64_t w_sci, int64_t w_stap, void *stream);
 /* out[c] += sum_{b,t} x[b][c][t]   (bias gradients) */
 int set_channel_sum(const float *x, float *out, int32_t B, int32_t C, int32_t T, void *stream);
+
+/* Deterministic reductions of the training path.  The entry points above that accumulate with fp32 atomics
+ * (set_channel_sum, set_weighted_sum, set_sumsq, the `sums` pass of set_dur_loss / set_pitch_loss, set_embedding_bwd,
+ * set_expand_states_bwd) give results whose last bits depend on the arrival order of the blocks.  The *_det variants
+ * below write one partial result per block / slice into `scratch` and combine them in a fixed order: bit-identical from
+ * run to run (what makes a resumed training run repeat the uninterrupted one exactly).  `scratch` may be reused by the
+ * next call on the same stream.  Sizes (floats): channel_sum 2048 + C; weighted_sum 1024; sumsq 2048; dur 4 B;
+ * pitch 4 ceil(B T / 256); scatter_rows B * set_scatter_rows_segments(T) * n_rows * C. */
+int set_channel_sum_det(const float *x, float *out, int32_t B, int32_t C, int32_t T, float *scratch, void *stream);
+int set_weighted_sum_det(const float *x, const float *w, float *out, int64_t n, int64_t inner, float *scratch, void *stream);
+int set_sumsq_det(const float *g, float *out, int64_t n, float *scratch, void *stream);
+int set_dur_loss_sums_det(const float *dur_pred, const int64_t *mel2ph, const int64_t *txt, const int64_t *word_id,
+                          float *sums, int32_t B, int32_t T, int32_t T_txt, int32_t n_words, float *scratch, void *stream);
+int set_pitch_loss_sums_det(const float *pp, const float *f0, const float *uv, const int64_t *mel2ph, float *sums,
+                            int32_t B, int32_t T, float *scratch, void *stream);
+/* Scatter-add of gradient rows, no atomics.  doutT: the gradient TRANSPOSED to [B][T][C].
+ * mode 0 (embedding backward, layers.py:45-50): table[idx[b][t]][c] += scale * doutT[b][t][c]  (idx clamped to the table,
+ *        padding_idx skipped), table [n_rows][C];
+ * mode 1 (expand_states backward, align_ops.py:21-25): table[b][idx[b][t] - 1][c] += doutT[b][t][c] for idx > 0,
+ *        table [B][n_rows][C] (the gradient of the encoder output, transposed). */
+int32_t set_scatter_rows_segments(int32_t T);
+int set_scatter_rows_det(const int64_t *idx, const float *doutT, float *table, int32_t B, int32_t T, int32_t C,
+                         int32_t n_rows, float scale, int32_t padding_idx, int32_t mode, float *scratch, void *stream);
 /* out[row] = scale * sum_t x[row][t] */
 int set_row_sum(const float *x, float *out, int64_t rows, int32_t T, float scale, void *stream);
 /* G = dY * mask[b][t] * alpha * [act == RELU: y > 0]   (epilogue backward of set_conv1d; act NONE or RELU) */

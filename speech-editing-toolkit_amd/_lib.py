@@ -177,6 +177,13 @@ SIGNATURES = {
     "set_conv1d_wgrad_det": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _V, _I64, _V]),
     "set_packed_conv_weight_bf16_size": (_I64, [_I32, _I32, _I32]),
     "set_pack_conv_weight_bf16": (C.c_int, [_V, _V, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _V]),
+    "set_channel_sum_det": (C.c_int, [_V, _V, _I32, _I32, _I32, _V, _V]),
+    "set_weighted_sum_det": (C.c_int, [_V, _V, _V, _I64, _I64, _V, _V]),
+    "set_sumsq_det": (C.c_int, [_V, _V, _I64, _V, _V]),
+    "set_dur_loss_sums_det": (C.c_int, [_V, _V, _V, _V, _V, _I32, _I32, _I32, _I32, _V, _V]),
+    "set_pitch_loss_sums_det": (C.c_int, [_V, _V, _V, _V, _V, _I32, _I32, _V, _V]),
+    "set_scatter_rows_segments": (_I32, [_I32]),
+    "set_scatter_rows_det": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _I32, _F, _I32, _I32, _V, _V]),
     "set_sizeof_diffnet_layer_bf16_args": (_I64, []),
     "set_diffnet_layer_bf16_image_size": (_I64, []),
     "set_pack_diffnet_layer_bf16": (C.c_int, [_V, _V, _V, _V, _V]),

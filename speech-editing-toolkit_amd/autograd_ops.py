@@ -75,6 +75,22 @@ def _wgrad_impl(T):
     return IMPL_MFMA if T >= 16 else IMPL_NAIVE
 
 
+_DET_SCRATCH = {}  # device -> per-block / per-slice partial results of the ordered reductions (reused: stream-ordered)
+
+
+def _det_scratch(device, n_floats):
+    buf = _DET_SCRATCH.get(device)
+    if buf is None or buf.numel() < n_floats:
+        buf = torch.empty(int(n_floats * 1.25) + 4096, dtype=torch.float32, device=device)
+        _DET_SCRATCH[device] = buf
+    return buf
+
+
+def channel_sum_(x, out, B, Cc, T):
+    """out[c] += sum_{b,t} x[b][c][t], per-slice partials combined in slice order (deterministic)."""
+    check(L().set_channel_sum_det(_p(x), _p(out), B, Cc, T, _p(_det_scratch(x.device, 2048 + Cc)), _stream()), "set_channel_sum_det")
+
+
 _WG_SCRATCH = {}  # device -> slice-partial buffer of the deterministic weight-gradient path (reused: stream-ordered)
 DETERMINISTIC_WGRAD = True  # False: the round-1 split-K kernel with fp32 atomics (order-dependent bits)
 
@@ -154,7 +170,7 @@ class _Conv1dFn(torch.autograd.Function):
                        dw_ptr=dw.data_ptr() + 4 * cw.base)
         if has_bias and ctx.needs_input_grad[2]:
             db = _gzeros(Cout, dy.device)
-            check(L().set_channel_sum(_p(g), _p(db), B, Cout, T, _stream()), "set_channel_sum")
+            channel_sum_(g, db, B, Cout, T)
         return (dx if ctx.needs_input_grad[0] else None, dw, db, dadd, dres, None, None, None, None, None, None, None,
                 None, None, None)
 
@@ -251,8 +267,11 @@ class _EmbeddingFn(torch.autograd.Function):
         dout = dout.contiguous()
         B, T = idx.shape
         dtab = _gzeros((n_rows, Cc), dout.device)
-        check(L().set_embedding_bwd(_p(idx), _p(dout), _p(dtab), B, T, Cc, n_rows, float(scale), ctx.padding_idx,
-                                    _stream()), "set_embedding_bwd")
+        # ordered scatter (no atomics): gradient rows transposed to [B][T][C], per-(utterance, segment) partial tables
+        doutT = ops.bct_to_btc(dout)
+        S = L().set_scatter_rows_segments(T)
+        check(L().set_scatter_rows_det(_p(idx), _p(doutT), _p(dtab), B, T, Cc, n_rows, float(scale), ctx.padding_idx, 0,
+                                       _p(_det_scratch(dout.device, B * S * n_rows * Cc)), _stream()), "set_scatter_rows_det")
         return None, dtab, (dout if has_base else None), None, None
 
 
@@ -273,10 +292,13 @@ class _ExpandStatesFn(torch.autograd.Function):
         (mel2ph,) = ctx.saved_tensors
         B, Cc, T_txt = ctx.shape
         dout = dout.contiguous()
-        denc = _gzeros((B, Cc, T_txt), dout.device)
-        check(L().set_expand_states_bwd(_p(mel2ph), _p(dout), _p(denc), B, Cc, T_txt, mel2ph.shape[1], _stream()),
-              "set_expand_states_bwd")
-        return denc, None
+        T = mel2ph.shape[1]
+        doutT = ops.bct_to_btc(dout)
+        dencT = _gzeros((B, T_txt, Cc), dout.device)
+        S = L().set_scatter_rows_segments(T)
+        check(L().set_scatter_rows_det(_p(mel2ph), _p(doutT), _p(dencT), B, T, Cc, T_txt, 1.0, -1, 1,
+                                       _p(_det_scratch(dout.device, B * S * T_txt * Cc)), _stream()), "set_scatter_rows_det")
+        return ops.btc_to_bct(dencT), None
 
 
 def expand_states(enc_bct, mel2ph):
@@ -500,7 +522,7 @@ class _DiffNetStackFn(torch.autograd.Function):
             dw_out = _zeros_like(layer.output_projection.weight)
             conv_wgrad(d_o, z_all[l], None, dw_out, B, C_, 2 * C_, 1, 1, 0, T, T)
             db_out = _gzeros(2 * C_, dev)
-            check(L().set_channel_sum(_p(d_o), _p(db_out), B, 2 * C_, T, _stream()), "set_channel_sum")
+            channel_sum_(d_o, db_out, B, 2 * C_, T)
             dz = ops.conv1d(d_o, layer._w_out.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T)
             # gate
             dy = torch.empty(B, 2 * C_, T, dtype=torch.float32, device=dev)
@@ -509,7 +531,7 @@ class _DiffNetStackFn(torch.autograd.Function):
             dw_cond = _zeros_like(layer.conditioner_projection.weight)
             conv_wgrad(dy, cond, None, dw_cond, B, H, 2 * C_, 1, 1, 0, T, T)
             db = _gzeros(2 * C_, dev)
-            check(L().set_channel_sum(_p(dy), _p(db), B, 2 * C_, T, _stream()), "set_channel_sum")  # = db_cond = db_dil
+            channel_sum_(dy, db, B, 2 * C_, T)  # = db_cond = db_dil
             if need_cond:
                 ops.conv1d(dy, layer._w_cond.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T, out=dcond,
                            accumulate=True)
@@ -783,7 +805,8 @@ def frame_weights(target_btm):
 
 def _sum(x, w=None, inner=1):
     out = torch.zeros(1, dtype=torch.float32, device=x.device)
-    check(L().set_weighted_sum(_p(x), _p(w), _p(out), x.numel(), inner, _stream()), "set_weighted_sum")
+    check(L().set_weighted_sum_det(_p(x), _p(w), _p(out), x.numel(), inner, _p(_det_scratch(x.device, 1024)), _stream()),
+          "set_weighted_sum_det")
     return out
 
 
@@ -866,8 +889,8 @@ class _DurLossFn(torch.autograd.Function):
         B, T_txt = dur_pred.shape
         T = mel2ph.shape[1]
         sums = torch.zeros(4, dtype=torch.float32, device=dur_pred.device)
-        check(L().set_dur_loss(_p(dur_pred), _p(mel2ph), _p(txt), _p(word_id), _p(sums), None, None, B, T, T_txt, n_words,
-                               float(lam_p), float(lam_w), 1.0, _stream()), "set_dur_loss")
+        check(L().set_dur_loss_sums_det(_p(dur_pred), _p(mel2ph), _p(txt), _p(word_id), _p(sums), B, T, T_txt, n_words,
+                                        _p(_det_scratch(dur_pred.device, 4 * B)), _stream()), "set_dur_loss_sums_det")
         ctx.save_for_backward(dur_pred, mel2ph, txt, word_id, sums)
         ctx.cfg = (n_words, lam_p, lam_w)
         pd = sums[0] / sums[1] * lam_p
@@ -904,8 +927,9 @@ class _PitchLossFn(torch.autograd.Function):
         pp = pp.contiguous()
         B, _, T = pp.shape
         sums = torch.zeros(4, dtype=torch.float32, device=pp.device)
-        check(L().set_pitch_loss(_p(pp), _p(f0), _p(uv), _p(mel2ph), _p(sums), None, None, B, T, float(lam_uv),
-                                 float(lam_f0), 1.0, _stream()), "set_pitch_loss")
+        check(L().set_pitch_loss_sums_det(_p(pp), _p(f0), _p(uv), _p(mel2ph), _p(sums), B, T,
+                                          _p(_det_scratch(pp.device, 4 * ((B * T + 255) // 256))), _stream()),
+              "set_pitch_loss_sums_det")
         ctx.save_for_backward(pp, f0, uv, mel2ph, sums)
         ctx.cfg = (lam_uv, lam_f0)
         return sums[0] / sums[1] * lam_uv, sums[2] / sums[3] * lam_f0
@@ -934,7 +958,8 @@ def pitch_losses(pp_bct, f0, uv, mel2ph, lam_uv, lam_f0):
 # --------------------------------------------------------------------------------------------------
 def grad_sumsq(flat_grad):
     out = torch.zeros(1, dtype=torch.float32, device=flat_grad.device)
-    check(L().set_sumsq(_p(flat_grad), _p(out), flat_grad.numel(), _stream()), "set_sumsq")
+    check(L().set_sumsq_det(_p(flat_grad), _p(out), flat_grad.numel(), _p(_det_scratch(flat_grad.device, 2048)), _stream()),
+          "set_sumsq_det")
     return out
 
 

@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) conv1d_wgrad_naive_kernel(WgradArgs a) {
 
 // out[c] += sum_{b,t} x[b][c][t]  (bias grads): grid (C, slices over the batch), wave-shuffle + LDS reduce, one atomic per
 // block.  (One block per channel left C <= 512 blocks to stream 50 MB: 27 us at B=32, T=800.)
-__global__ void __launch_bounds__(256) channel_sum_kernel(const float *x, float *out, int B, int C, int T) {
+__global__ void __launch_bounds__(256) channel_sum_kernel(const float *x, float *out, int B, int C, int T, float *part = nullptr) {
     __shared__ float red[4];
     const int c = blockIdx.x;
     float s = 0.0f;
@@ -175,7 +175,10 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const float *x, float 
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&out[c], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        const float v = red[0] + red[1] + red[2] + red[3];
+        if (part) part[(int64_t)blockIdx.y * C + c] = v; else atomicAdd(&out[c], v);
+    }
 }
 // out[b][c] = sum_t x[b][c][t] (* 1/div); one wave per (b,c)
 __global__ void __launch_bounds__(256) row_sum_kernel(const float *x, float *out, int64_t rows, int T, float scale) {
@@ -458,7 +461,7 @@ __global__ void __launch_bounds__(256) frame_weight_kernel(const float *target, 
 }
 // sum-reduce helper: out[0] += sum x[i] (* w[i / inner])
 __global__ void __launch_bounds__(256) weighted_sum_kernel(const float *x, const float *w, float *out, int64_t n,
-                                                           int64_t inner) {
+                                                           int64_t inner, float *part = nullptr) {
     __shared__ float red[256];
     float s = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -469,7 +472,7 @@ __global__ void __launch_bounds__(256) weighted_sum_kernel(const float *x, const
         if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(out, red[0]);
+    if (threadIdx.x == 0) { if (part) part[blockIdx.x] = red[0]; else atomicAdd(out, red[0]); }
 }
 // |pred - target| (forward) / sign(pred - target) (backward), [n]
 __global__ void __launch_bounds__(256) l1_elem_kernel(const float *pred, const float *target, float *absd, float *sgn,
@@ -569,7 +572,7 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(const float *img1, const 
 __global__ void __launch_bounds__(256) dur_loss_kernel(const float *dur_pred, const int64_t *mel2ph, const int64_t *txt,
                                                        const int64_t *word_id, float *sums, const float *final_sums,
                                                        float *ddur, int T, int T_txt, int n_words, float lam_p,
-                                                       float lam_w, float gscale) {
+                                                       float lam_w, float gscale, float *part = nullptr) {
     extern __shared__ float sh[];  // dur_gt[T_txt+1] | wp[n_words+1] | wg[n_words+1]
     float *dg = sh, *wp = sh + (T_txt + 1), *wg = wp + (n_words + 1);
     const int b = blockIdx.x;
@@ -584,8 +587,14 @@ __global__ void __launch_bounds__(256) dur_loss_kernel(const float *dur_pred, co
     for (int j = threadIdx.x; j < T_txt; j += 256) {
         const float np = txt[(int64_t)b * T_txt + j] != 0 ? 1.0f : 0.0f;
         const int wi = (int)word_id[(int64_t)b * T_txt + j];
-        atomicAdd(&wp[wi], dur_pred[(int64_t)b * T_txt + j]);
-        atomicAdd(&wg[wi], dg[j + 1] * np);
+        atomicAdd(&wg[wi], dg[j + 1] * np);  // frame counts: integer-valued, exact in any order
+        // predicted word durations: a word is one contiguous run of tokens (word_id = cumsum(sil) * (1 - sil)), summed by
+        // the thread of its first token in token order -> the same bits every run (a float atomicAdd is order-dependent)
+        if (wi > 0 && (j == 0 || (int)word_id[(int64_t)b * T_txt + j - 1] != wi)) {
+            float acc = 0.0f;
+            for (int k = j; k < T_txt && (int)word_id[(int64_t)b * T_txt + k] == wi; ++k) acc += dur_pred[(int64_t)b * T_txt + k];
+            wp[wi] = acc;
+        }
     }
     __syncthreads();
     if (!ddur) {
@@ -600,7 +609,19 @@ __global__ void __launch_bounds__(256) dur_loss_kernel(const float *dur_pred, co
             const float d = logf(wp[wi] + 1.0f) - logf(wg[wi] + 1.0f);
             s2 += d * d * wm; s3 += wm;
         }
-        atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[2], s2); atomicAdd(&sums[3], s3);
+        // block sum in a fixed order, then one slot per utterance (part) or the order-dependent atomics
+        __shared__ float red4[4][256];
+        red4[0][threadIdx.x] = s0; red4[1][threadIdx.x] = s1; red4[2][threadIdx.x] = s2; red4[3][threadIdx.x] = s3;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st)
+                for (int k = 0; k < 4; ++k) red4[k][threadIdx.x] += red4[k][threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x < 4) {
+            if (part) part[(int64_t)b * 4 + threadIdx.x] = red4[threadIdx.x][0];
+            else atomicAdd(&sums[threadIdx.x], red4[threadIdx.x][0]);
+        }
     } else {
         for (int j = threadIdx.x; j < T_txt; j += 256) {
             const float np = txt[(int64_t)b * T_txt + j] != 0 ? 1.0f : 0.0f;
@@ -620,7 +641,8 @@ __global__ void __launch_bounds__(256) dur_loss_kernel(const float *dur_pred, co
 __global__ void __launch_bounds__(256) pitch_loss_kernel(const float *pp, const float *f0, const float *uv,
                                                          const int64_t *mel2ph, float *sums, const float *final_sums,
                                                          float *dpp, int B, int T, float lam_uv, float lam_f0,
-                                                         float gscale) {
+                                                         float gscale, float *part = nullptr) {
+    __shared__ float wsum[4][4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (i < (int64_t)B * T) {
@@ -645,15 +667,70 @@ __global__ void __launch_bounds__(256) pitch_loss_kernel(const float *pp, const 
         for (int off = 32; off > 0; off >>= 1) {
             s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); s3 += __shfl_xor(s3, off);
         }
-        if ((threadIdx.x & 63) == 0) {
+        if (part) {  // one slot per block, waves combined in wave order
+            if ((threadIdx.x & 63) == 0) {
+                const int wv = threadIdx.x >> 6;
+                wsum[0][wv] = s0; wsum[1][wv] = s1; wsum[2][wv] = s2; wsum[3][wv] = s3;
+            }
+            __syncthreads();
+            if (threadIdx.x < 4)
+                part[(int64_t)blockIdx.x * 4 + threadIdx.x] =
+                    ((wsum[threadIdx.x][0] + wsum[threadIdx.x][1]) + wsum[threadIdx.x][2]) + wsum[threadIdx.x][3];
+        } else if ((threadIdx.x & 63) == 0) {
             atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[2], s2); atomicAdd(&sums[3], s3);
         }
     }
 }
 
+// ---- deterministic scatter-add of [B][T][C] rows into a table (embedding / alignment-gather backward) --------------
+// doutT is the gradient TRANSPOSED to [B][T][C] (channels contiguous): wave = (utterance b, frame segment s, 64-channel
+// block); it walks its frames in order, keeps the running sum of the current run of equal rows in registers and adds it
+// to ITS OWN partial table part[(b * S + s)][row][c] (no other wave touches that slice) -- coalesced 256-byte accesses,
+// no atomics.  scatter_reduce_kernel then adds the slices to the table in slice order.  mode 0: row = idx (embedding:
+// out-of-range clamped, padding_idx skipped); mode 1: row = idx - 1, idx == 0 skipped (expand_states: mel2ph is 1-based)
+__global__ void __launch_bounds__(256) scatter_rows_kernel(const int64_t *idx, const float *doutT, float *part, int B, int T,
+                                                           int C, int n_rows, int S, float scale, int padding_idx, int mode) {
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int cblocks = (C + 63) / 64;
+    if (wv >= B * S * cblocks) return;
+    const int cb = wv % cblocks, s = (wv / cblocks) % S, b = wv / (cblocks * S);
+    const int c = cb * 64 + lane;
+    const bool cv = c < C;
+    const int seg = (T + S - 1) / S, t_begin = s * seg, t_end = min(T, t_begin + seg);
+    const int64_t *ib = idx + (int64_t)b * T;
+    const float *dp = doutT + (int64_t)b * T * C + (cv ? c : 0);
+    float *tab = part + (int64_t)(b * S + s) * n_rows * C + (cv ? c : 0);
+    int cur = -1;
+    float acc = 0.0f;
+    for (int t = t_begin; t < t_end; ++t) {
+        int64_t r64 = ib[t];
+        int row;
+        if (mode == 0) { row = (int)(r64 < 0 ? 0 : (r64 >= n_rows ? n_rows - 1 : r64)); if (row == padding_idx) row = -1; }
+        else row = (r64 > 0 && r64 <= n_rows) ? (int)r64 - 1 : -1;
+        if (row != cur) {  // wave-uniform
+            if (cur >= 0 && cv) tab[(int64_t)cur * C] += acc;
+            cur = row;
+            acc = 0.0f;
+        }
+        acc = fmaf(scale, dp[(int64_t)t * C], acc);
+    }
+    if (cur >= 0 && cv) tab[(int64_t)cur * C] += acc;
+}
+// table[g][i] += sum_{k < K} part[g * K + k][i]  (slice order).  Embedding: one group, K = B * S slices; alignment gather:
+// one group per utterance (it owns its rows), K = S segment slices.
+__global__ void __launch_bounds__(256) scatter_reduce_kernel(const float *part, float *table, int64_t n, int K) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int g = blockIdx.y;
+    float s = 0.0f;
+    for (int k = 0; k < K; ++k) s += part[((int64_t)g * K + k) * n + i];
+    table[(int64_t)g * n + i] += s;
+}
+
 // ---- optimizer ---------------------------------------------------------------------------------------------------
 // sum of squares of a flat buffer -> out[0] (atomic)
-__global__ void __launch_bounds__(256) sumsq_kernel(const float *g, float *out, int64_t n) {
+__global__ void __launch_bounds__(256) sumsq_kernel(const float *g, float *out, int64_t n, float *part = nullptr) {
     __shared__ float red[256];
     float s = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = fmaf(g[i], g[i], s);
@@ -663,7 +740,7 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float *g, float *out, 
         if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(out, red[0]);
+    if (threadIdx.x == 0) { if (part) part[blockIdx.x] = red[0]; else atomicAdd(out, red[0]); }
 }
 // AdamW (torch.optim.AdamW semantics, amsgrad off) over a flat buffer; grads are first scaled by
 // clip = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))  (torch.nn.utils.clip_grad_norm_), sumsq optional.
@@ -757,6 +834,83 @@ extern "C" int set_channel_sum(const float *x, float *out, int32_t B, int32_t C,
     hipLaunchKernelGGL(channel_sum_kernel, dim3(C, slices), dim3(256), 0, (hipStream_t)stream, x, out, B, C, T);
     return set_check_launch("set_channel_sum");
 }
+extern "C" int set_partial_rows_sum(const float *part, float *out, int32_t groups, int32_t rows, int32_t cols, int32_t accumulate,
+                                    float scale, void *stream);  // diffnet_bf16.hip
+
+// Deterministic variants: per-block partial results in `scratch`, combined in block order by set_partial_rows_sum.
+extern "C" int set_channel_sum_det(const float *x, float *out, int32_t B, int32_t C, int32_t T, float *scratch, void *stream) {
+    SET_REQUIRE(x && out && scratch && B > 0 && C > 0 && T > 0, "set_channel_sum_det");
+    int slices = (2048 + C - 1) / C;
+    if (slices > B) slices = B;
+    if (slices < 1) slices = 1;  // scratch: slices * C <= 2048 + C floats
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, slices), dim3(256), 0, (hipStream_t)stream, x, out, B, C, T, scratch);
+    const int rc = set_check_launch("set_channel_sum_det");
+    return rc ? rc : set_partial_rows_sum(scratch, out, 1, slices, C, 1, 1.0f, stream);
+}
+extern "C" int set_weighted_sum_det(const float *x, const float *w, float *out, int64_t n, int64_t inner, float *scratch,
+                                    void *stream) {
+    SET_REQUIRE(x && out && scratch && n > 0 && inner > 0, "set_weighted_sum_det");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;  // scratch: <= 1024 floats
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, out, n, inner, scratch);
+    const int rc = set_check_launch("set_weighted_sum_det");
+    return rc ? rc : set_partial_rows_sum(scratch, out, 1, (int)blocks, 1, 1, 1.0f, stream);
+}
+extern "C" int set_sumsq_det(const float *g, float *out, int64_t n, float *scratch, void *stream) {
+    SET_REQUIRE(g && out && scratch && n > 0, "set_sumsq_det");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;  // scratch: <= 2048 floats
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, out, n, scratch);
+    const int rc = set_check_launch("set_sumsq_det");
+    return rc ? rc : set_partial_rows_sum(scratch, out, 1, (int)blocks, 1, 1, 1.0f, stream);
+}
+// sums-only passes of the two loss kernels with ordered partials: scratch >= 4 * B (dur) / 4 * ceil(B*T/256) (pitch) floats
+extern "C" int set_dur_loss_sums_det(const float *dur_pred, const int64_t *mel2ph, const int64_t *txt, const int64_t *word_id,
+                                     float *sums, int32_t B, int32_t T, int32_t T_txt, int32_t n_words, float *scratch,
+                                     void *stream) {
+    SET_REQUIRE(dur_pred && mel2ph && txt && word_id && sums && scratch && B > 0 && T > 0 && T_txt > 0 && n_words >= 0,
+                "set_dur_loss_sums_det");
+    const size_t lds = (size_t)(T_txt + 1 + 2 * (n_words + 1)) * sizeof(float);
+    SET_REQUIRE(lds < 56000, "set_dur_loss_sums_det(T_txt too large)");
+    hipLaunchKernelGGL(dur_loss_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dur_pred, mel2ph, txt, word_id, sums,
+                       (const float *)nullptr, (float *)nullptr, T, T_txt, n_words, 0.0f, 0.0f, 1.0f, scratch);
+    const int rc = set_check_launch("set_dur_loss_sums_det");
+    return rc ? rc : set_partial_rows_sum(scratch, sums, 1, B, 4, 1, 1.0f, stream);
+}
+extern "C" int set_pitch_loss_sums_det(const float *pp, const float *f0, const float *uv, const int64_t *mel2ph, float *sums,
+                                       int32_t B, int32_t T, float *scratch, void *stream) {
+    SET_REQUIRE(pp && f0 && uv && mel2ph && sums && scratch && B > 0 && T > 0, "set_pitch_loss_sums_det");
+    const unsigned nb = set_blocks((int64_t)B * T, 256);
+    hipLaunchKernelGGL(pitch_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pp, f0, uv, mel2ph, sums,
+                       (const float *)nullptr, (float *)nullptr, B, T, 0.0f, 0.0f, 1.0f, scratch);
+    const int rc = set_check_launch("set_pitch_loss_sums_det");
+    return rc ? rc : set_partial_rows_sum(scratch, sums, 1, (int)nb, 4, 1, 1.0f, stream);
+}
+// table[n_rows][C] (mode 0) / denc^T[B * n_rows][C] (mode 1) += scatter of doutT [B][T][C]; scratch: B * S * n_rows * C floats
+// (mode 0) with S = set_scatter_rows_segments(T); it is zeroed here.
+extern "C" int32_t set_scatter_rows_segments(int32_t T) { int s = T / 128; return s < 1 ? 1 : (s > 8 ? 8 : s); }
+extern "C" int set_scatter_rows_det(const int64_t *idx, const float *doutT, float *table, int32_t B, int32_t T, int32_t C,
+                                    int32_t n_rows, float scale, int32_t padding_idx, int32_t mode, float *scratch,
+                                    void *stream) {
+    SET_REQUIRE(idx && doutT && table && scratch && B > 0 && T > 0 && C > 0 && n_rows > 0 && (mode == 0 || mode == 1),
+                "set_scatter_rows_det");
+    const int S = set_scatter_rows_segments(T);
+    const int64_t n = (int64_t)n_rows * C;
+    SET_HIP(hipMemsetAsync(scratch, 0, (size_t)B * S * n * sizeof(float), (hipStream_t)stream), "set_scatter_rows_det(memset)");
+    const int waves = B * S * ((C + 63) / 64);
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, idx, doutT, scratch, B, T,
+                       C, n_rows, S, scale, padding_idx, mode);
+    int rc = set_check_launch("set_scatter_rows_det");
+    if (rc) return rc;
+    if (mode == 0)
+        hipLaunchKernelGGL(scatter_reduce_kernel, dim3(set_blocks(n, 256), 1), dim3(256), 0, (hipStream_t)stream, scratch, table,
+                           n, B * S);
+    else  // every utterance owns its rows: the S segment slices of utterance b go to table[b]
+        hipLaunchKernelGGL(scatter_reduce_kernel, dim3(set_blocks(n, 256), B), dim3(256), 0, (hipStream_t)stream, scratch, table,
+                           n, S);
+    return set_check_launch("set_scatter_rows_det(reduce)");
+}
+
 extern "C" int set_row_sum(const float *x, float *out, int64_t rows, int32_t T, float scale, void *stream) {
     SET_REQUIRE(x && out && rows > 0 && T > 0, "set_row_sum");
     hipLaunchKernelGGL(row_sum_kernel, dim3(set_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, out, rows, T, scale);
