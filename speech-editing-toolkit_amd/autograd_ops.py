@@ -71,6 +71,16 @@ def _zeros_like(t):
     return _gzeros(t.shape, t.device)
 
 
+def grad_sink(param):
+    """(target, owner): the optimizer-owned .grad view to accumulate a parameter gradient into, or (None, None) when the
+    gradient has to travel through autograd (no flat optimizer, first step, parameter used more than once)."""
+    owner = getattr(param, "_flat_owner", None) if param is not None else None
+    if owner is None:
+        return None, None
+    t = owner.sink(param)
+    return (t, owner) if t is not None else (None, None)
+
+
 def _wgrad_impl(T):
     return IMPL_MFMA if T >= 16 else IMPL_NAIVE
 
@@ -126,6 +136,7 @@ class _Conv1dFn(torch.autograd.Function):
                        mask=mask, in_chan_add=chan_add, impl=impl, T_out=t_out)
         ctx.cw, ctx.cfg = cw, (dil, pad, pro, pro_param, act, alpha, impl)
         ctx.has = (bias is not None, chan_add is not None, res is not None)
+        ctx.wparam, ctx.bparam = weight, bias  # the Parameter objects (gradient sinks of the flat optimizer)
         ctx.save_for_backward(x, chan_add, mask, y if act == "relu" else None)
         return y
 
@@ -165,12 +176,19 @@ class _Conv1dFn(torch.autograd.Function):
             w = cw.raw()
             # plain [Cout,Cin,K] rows, possibly a row slice of a larger parameter (packed q/k/v projections)
             assert cw.stap == 1 and cw.sci == cw.K and cw.sco == cw.Cin * cw.K, "plain conv layout"
-            dw = _gzeros(w.shape, dy.device)
+            whole = cw.base == 0 and w.numel() == Cout * Cin * cw.K
+            sink, owner = grad_sink(ctx.wparam) if whole else (None, None)
+            dw = sink if sink is not None else _gzeros(w.shape, dy.device)
             conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, cw.K, dil, pad, T, T_in, PRO[pro], pro_param,
                        dw_ptr=dw.data_ptr() + 4 * cw.base)
+            if sink is not None:
+                dw = None  # written in place; autograd still fires the parameter's post-accumulate hook (bucket launch)
         if has_bias and ctx.needs_input_grad[2]:
-            db = _gzeros(Cout, dy.device)
+            sink, owner = grad_sink(ctx.bparam) if ctx.bparam.numel() == Cout else (None, None)
+            db = sink if sink is not None else _gzeros(Cout, dy.device)
             channel_sum_(g, db, B, Cout, T)
+            if sink is not None:
+                db = None
         return (dx if ctx.needs_input_grad[0] else None, dw, db, dadd, dres, None, None, None, None, None, None, None,
                 None, None, None)
 
@@ -620,23 +638,32 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
             a.part_dbo, a.part_dby, a.part_dd = pdbo_c.data_ptr(), pdby_c.data_ptr(), pdd_c.data_ptr()
             a.dil, a.dcond_first = dil, int(l == L_ - 1)
             check(L().set_diffnet_layer_bwd_bf16(C.byref(a), _stream()), "set_diffnet_layer_bwd_bf16")
-            # bias / step-offset gradients: ordered sums of the per-tile partials
-            db_out = _gzeros(2 * C_, dev)
-            db_y = _gzeros(2 * C_, dev)
-            check(L().set_partial_rows_sum(_p(pdbo_c), _p(db_out), 1, B * tiles, 2 * C_, 1, 1.0, _stream()), "set_partial_rows_sum")
-            check(L().set_partial_rows_sum(_p(pdby_c), _p(db_y), 1, B * tiles, 2 * C_, 1, 1.0, _stream()), "set_partial_rows_sum")
+            # bias / step-offset gradients: ordered sums of the per-tile partials (straight into .grad when the flat
+            # optimizer owns it, else into a zeroed temporary that autograd accumulates)
+            def acc_into(param, part_, cols):
+                sink, owner = grad_sink(param)
+                tgt = sink if sink is not None else _gzeros(cols, dev)
+                check(L().set_partial_rows_sum(_p(part_), _p(tgt), 1, B * tiles, cols, 1, 1.0, _stream()), "set_partial_rows_sum")
+                return None if sink is not None else tgt
+
+            def wg(param, *args, **kw):
+                sink, owner = grad_sink(param)
+                tgt = sink if sink is not None else _zeros_like(param)
+                conv_wgrad(args[0], args[1], args[2], tgt, *args[3:], **kw)
+                return None if sink is not None else tgt
+
+            db_out = acc_into(layer.output_projection.bias, pdbo_c, 2 * C_)
+            db_dil = acc_into(layer.dilated_conv.bias, pdby_c, 2 * C_)
+            db_cond = acc_into(layer.conditioner_projection.bias, pdby_c, 2 * C_)
             ddl = torch.empty(B, C_, dtype=torch.float32, device=dev)
             check(L().set_partial_rows_sum(_p(pdd_c), _p(ddl), B, tiles, C_, 0, 1.0, _stream()), "set_partial_rows_sum")
             dd[:, l * C_:(l + 1) * C_] = ddl
             # weight gradients on the bf16 operands the two kernels left in HBM
-            dw_out = _zeros_like(layer.output_projection.weight)
-            conv_wgrad(do16, z16[l], None, dw_out, B, C_, 2 * C_, 1, 1, 0, T, T, dtype=GX16)
-            dw_cond = _zeros_like(layer.conditioner_projection.weight)
-            conv_wgrad(dy16, cond, None, dw_cond, B, H, 2 * C_, 1, 1, 0, T, T, dtype=G16)
-            dw_dil = _zeros_like(layer.dilated_conv.weight)
+            dw_out = wg(layer.output_projection.weight, do16, z16[l], None, B, C_, 2 * C_, 1, 1, 0, T, T, dtype=GX16)
+            dw_cond = wg(layer.conditioner_projection.weight, dy16, cond, None, B, H, 2 * C_, 1, 1, 0, T, T, dtype=G16)
             dl = dmat[:, l * C_:(l + 1) * C_].contiguous()
-            conv_wgrad(dy16, x_all[l], dl, dw_dil, B, C_, 2 * C_, 3, dil, dil, T, T, dtype=G16)
-            grads.append((dw_cond, db_y, dw_dil, db_y.clone(), dw_out, db_out))
+            dw_dil = wg(layer.dilated_conv.weight, dy16, x_all[l], dl, B, C_, 2 * C_, 3, dil, dil, T, T, dtype=G16)
+            grads.append((dw_cond, db_cond, dw_dil, db_dil, dw_out, db_out))
             cur = out
         grads.reverse()
         flat = [g for tup in grads for g in tup]

@@ -171,6 +171,9 @@ class GradBucketer:
         self.reset()
 
     def _make_hook(self, b):
+        # NB torch fires a post-accumulate-grad hook for every leaf the backward graph reaches, also when the backward
+        # function returned None for it -- which is what lets the gradient kernels write .grad directly (training.
+        # FlatAdamW.sink) and still have their bucket launched from here, right after their kernel was enqueued.
         def hook(_param):
             self._arrive(b)
         return hook
@@ -188,8 +191,8 @@ class GradBucketer:
                                "backward per optimizer step); use reset(defer=True) for gradient accumulation")
 
     def param_ready(self, param):
-        """Manual arrival for gradients written straight into the flat buffer by a backward kernel (the autograd
-        engine then sees no gradient for that parameter and fires no hook)."""
+        """Manual arrival, for a gradient producer outside autograd (autograd itself fires the hook of every leaf it
+        reaches, also for gradients a kernel wrote straight into the flat buffer)."""
         if self.enabled:
             b = self._owner_of.get(id(param))
             if b is not None:

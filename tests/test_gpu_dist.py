@@ -50,6 +50,15 @@ def _paired_batch(B, T, T_txt):
 
 
 def _worker(rank, world, port, backend, force, q):
+    try:
+        _worker_body(rank, world, port, backend, force, q)
+    except BaseException:
+        import traceback
+        q.put(dict(rank=rank, error=traceback.format_exc()))
+        raise
+
+
+def _worker_body(rank, world, port, backend, force, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -109,7 +118,11 @@ def _worker(rank, world, port, backend, force, q):
         return opt.flat_g.clone() / w, float(total), w
 
     sh = parallel.shard_batch(full, rank, world)
+    g_first, _, _ = grads_of(sample_of(sh), t_full[rank::world], eps_full[rank::world])
+    opt._learned = True  # (normally set by the first optimizer.step(): from now on the gradient kernels write .grad directly)
     g_dist, loss_local, w = grads_of(sample_of(sh), t_full[rank::world], eps_full[rank::world])
+    direct_equal = bool(torch.equal(g_first, g_dist))  # autograd-accumulated vs directly written gradients: same bits
+    n_direct = sum(1 for v in opt._uses.values() if v == 1)
     log = list(opt.bucketer.launch_log)
     n_buckets = len(opt.bucketer.buckets)
     reduced = opt.bucketer.bytes_reduced
@@ -118,6 +131,7 @@ def _worker(rank, world, port, backend, force, q):
     rel = float((g_dist - g_full).abs().max() / g_full.abs().max())
     q.put(dict(rank=rank, own=own, after=float(chk), sent=sent, replicas_equal=replicas_equal, w=w, rel=rel,
                loss_local=loss_local, loss_full=loss_full, log=log, n_buckets=n_buckets, reduced=reduced, n=opt.n,
+               direct_equal=direct_equal, n_direct=n_direct,
                backend=dist.get_backend() if dist.is_initialized() else None))
     if dist.is_initialized():
         dist.barrier()
@@ -131,7 +145,15 @@ def _run(world, backend, force=False):
     procs = [ctx.Process(target=_worker, args=(r, world, port, backend, force, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=600) for _ in procs), key=lambda d: d["rank"])
+    try:
+        res = sorted((q.get(timeout=240) for _ in procs), key=lambda d: d["rank"])
+    except Exception:
+        for p in procs:  # a worker died (its traceback is on stderr): do not leave the other rank waiting in a collective
+            if p.is_alive():
+                p.kill()
+        raise
+    for r in res:
+        assert "error" not in r, r["error"]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -145,6 +167,7 @@ def _check_two_ranks(res):
     assert r0["after"] == r1["after"] == r0["own"]         # ... and both now hold rank 0's parameters
     assert r0["sent"] >= 4 * r0["n"]
     for r in res:
+        assert r["direct_equal"] and r["n_direct"] > 50  # second pass: kernels accumulate into .grad, buckets fire by hand
         assert r["w"] == 2
         # mean of the two shards' gradients == gradient of the concatenated batch (fp32 summation order differs)
         assert r["rel"] < 2e-5, r["rel"]
@@ -176,6 +199,7 @@ def test_single_rank_rccl_group_runs_the_collectives():
     assert r["n_buckets"] >= 3 and sorted(b for b, _ in r["log"]) == list(range(r["n_buckets"]))
     assert r["reduced"] >= 4 * r["n"]
     assert r["rel"] < 1e-5  # same kernels, same batch, all-reduce over one rank = identity
+    assert r["direct_equal"] and r["n_direct"] > 50
 
 
 def test_bench_refuses_more_gpus_than_visible():
