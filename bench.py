@@ -308,10 +308,12 @@ def run_train(args, rank, world, dev):
         task.training_step(sample, opt, seed=100 + w)
     torch.cuda.synchronize()
     parallel.barrier()
-    exposed, reduced = 0.0, 0
+    exposed, reduced, enqueue = 0.0, 0, 0.0
     t0 = time.perf_counter()
     for k in range(args.steps):
+        t1 = time.perf_counter()
         total, parts, lr = task.training_step(sample, opt, seed=k)
+        enqueue += time.perf_counter() - t1  # host time to ENQUEUE the step (no synchronisation inside)
         exposed += opt.bucketer.exposed_s
         reduced = opt.bucketer.bytes_reduced
     torch.cuda.synchronize()
@@ -333,7 +335,7 @@ def run_train(args, rank, world, dev):
                                "batches, B=32 per GPU (BASELINE configs[1]; configs[2] at 8 GPUs = 256 global)",
                    "B_per_gpu": B_PER_GPU, "T": T, "T_txt": T_TXT, "sharding": "utterances r::N, gradient all-reduce (SUM, "
                    "1/N folded into AdamW) in %d buckets" % max(1, len(opt.bucketer.buckets))},
-        "frames_per_s": n_samples * T / t_max,
+        "frames_per_s": n_samples * T / t_max, "host_enqueue_ms_per_step": 1e3 * enqueue / args.steps,
         "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"],
         "per_rank_ms_per_step": [1e3 * s / args.steps for s in facts["per_rank_s"]],
         "allreduce_bytes_per_step": reduced, "allreduce_exposed_ms_per_step": 1e3 * exposed / args.steps,

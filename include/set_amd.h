@@ -395,6 +395,10 @@ typedef struct SetDiffnetLayerBf16BwdArgs {
 int64_t set_sizeof_diffnet_layer_bf16_bwd_args(void);
 int32_t set_diffnet_layer_bwd_bf16_tiles(int32_t T, int32_t dil); /* tiles per utterance = rows per b of the part_* arrays */
 int set_diffnet_layer_bwd_bf16(const SetDiffnetLayerBf16BwdArgs *args, void *stream);
+/* the ordered partial sums of one layer's backward in one launch: db_out[512] += sum part_dbo, db_dil[512] and db_cond[512] +=
+ * sum part_dby (over all B*tiles rows), dd[b*dd_bs + c] = sum over the tiles of utterance b of part_dd (c < 256) */
+int set_diffnet_layer_bwd_reduce(const float *part_dbo, const float *part_dby, const float *part_dd, int32_t B, int32_t tiles,
+                                 float *db_out, float *db_dil, float *db_cond, float *dd, int64_t dd_bs, void *stream);
 /* out[g][j] (+)= scale * sum_{r < rows} part[(g*rows + r)*cols + j]  in row order (deterministic reduction of per-tile partials) */
 int set_partial_rows_sum(const float *part, float *out, int32_t groups, int32_t rows, int32_t cols, int32_t accumulate,
                          float scale, void *stream);

@@ -244,6 +244,7 @@ class _LayerNormChFn(torch.autograd.Function):
         y = ops.layernorm_ch(x, gamma, beta, mask, eps)
         ctx.save_for_backward(x, gamma, mask)
         ctx.eps = eps
+        ctx.gparam, ctx.bparam = gamma, beta
         return y
 
     @staticmethod
@@ -252,12 +253,14 @@ class _LayerNormChFn(torch.autograd.Function):
         dy = dy.contiguous()
         B, Cc, T = x.shape
         dx = torch.empty_like(x)
-        dg = _zeros_like(gamma)
-        db = _zeros_like(gamma)
+        sg, _ = grad_sink(ctx.gparam)
+        sb, _ = grad_sink(ctx.bparam)
+        dg = sg if sg is not None else _zeros_like(gamma)
+        db = sb if sb is not None else _zeros_like(gamma)
         part = torch.empty(L().set_layernorm_ch_bwd_scratch(B, Cc, T), dtype=torch.float32, device=x.device)
         check(L().set_layernorm_ch_bwd(_p(x), _p(gamma), _p(mask), _p(dy), _p(dx), _p(dg), _p(db), _p(part), B, Cc, T,
                                        float(ctx.eps), _stream()), "set_layernorm_ch_bwd")
-        return dx, dg, db, None, None
+        return dx, (None if sg is not None else dg), (None if sb is not None else db), None, None
 
 
 def layernorm_ch(x, gamma, beta, mask=None, eps=1e-5, out=None):
@@ -537,32 +540,39 @@ class _DiffNetStackFn(torch.autograd.Function):
             d_o = torch.empty(B, 2 * C_, T, dtype=torch.float32, device=dev)
             check(L().set_res_skip_bwd(_p(dx), _p(dskip), _p(dxr), _p(d_o), B, C_, T, _stream()), "set_res_skip_bwd")
             # output_projection (1x1, 256 -> 512)
-            dw_out = _zeros_like(layer.output_projection.weight)
+            def tgt(param):  # the optimizer's .grad view when it owns the parameter, else a zeroed temporary
+                sk, _ = grad_sink(param)
+                return (sk, True) if sk is not None else (_zeros_like(param), False)
+
+            dw_out, d1 = tgt(layer.output_projection.weight)
             conv_wgrad(d_o, z_all[l], None, dw_out, B, C_, 2 * C_, 1, 1, 0, T, T)
-            db_out = _gzeros(2 * C_, dev)
+            db_out, d2 = tgt(layer.output_projection.bias)
             channel_sum_(d_o, db_out, B, 2 * C_, T)
             dz = ops.conv1d(d_o, layer._w_out.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T)
             # gate
             dy = torch.empty(B, 2 * C_, T, dtype=torch.float32, device=dev)
             check(L().set_gate_bwd(_p(y_all[l]), _p(dz), _p(dy), B, C_, T, _stream()), "set_gate_bwd")
             # conditioner_projection (1x1, H -> 512): y = ... + W_cond cond + b_cond
-            dw_cond = _zeros_like(layer.conditioner_projection.weight)
+            dw_cond, d3 = tgt(layer.conditioner_projection.weight)
             conv_wgrad(dy, cond, None, dw_cond, B, H, 2 * C_, 1, 1, 0, T, T)
-            db = _gzeros(2 * C_, dev)
+            db, d4 = tgt(layer.conditioner_projection.bias)
             channel_sum_(dy, db, B, 2 * C_, T)  # = db_cond = db_dil
+            db2, d5 = tgt(layer.dilated_conv.bias)
+            channel_sum_(dy, db2, B, 2 * C_, T)
             if need_cond:
                 ops.conv1d(dy, layer._w_cond.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T, out=dcond,
                            accumulate=True)
             # dilated conv (k=3) on x_l + d_l
             dl = dmat[:, l * C_:(l + 1) * C_].contiguous()
-            dw_dil = _zeros_like(layer.dilated_conv.weight)
+            dw_dil, d6 = tgt(layer.dilated_conv.weight)
             conv_wgrad(dy, x_all[l], dl, dw_dil, B, C_, 2 * C_, 3, dil, dil, T, T)
             dxd = ops.conv1d(dy, layer._w_dil.transposed(), None, dil=-dil, pad=-dil, T_iter=T, T_out=T)
             ddl = torch.empty(B, C_, dtype=torch.float32, device=dev)
             check(L().set_row_sum(_p(dxd), _p(ddl), B * C_, T, 1.0, _stream()), "set_row_sum")
             dd[:, l * C_:(l + 1) * C_] = ddl
             dx = ops.sum_div(dxd, dxr)
-            grads.append((dw_cond, db, dw_dil, db.clone(), dw_out, db_out))
+            grads.append((None if d3 else dw_cond, None if d4 else db, None if d6 else dw_dil, None if d5 else db2,
+                          None if d1 else dw_out, None if d2 else db_out))
         grads.reverse()
         flat = [g for tup in grads for g in tup]
         return (None, dx, dcond, dd, *flat)
@@ -638,13 +648,14 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
             a.part_dbo, a.part_dby, a.part_dd = pdbo_c.data_ptr(), pdby_c.data_ptr(), pdd_c.data_ptr()
             a.dil, a.dcond_first = dil, int(l == L_ - 1)
             check(L().set_diffnet_layer_bwd_bf16(C.byref(a), _stream()), "set_diffnet_layer_bwd_bf16")
-            # bias / step-offset gradients: ordered sums of the per-tile partials (straight into .grad when the flat
-            # optimizer owns it, else into a zeroed temporary that autograd accumulates)
-            def acc_into(param, part_, cols):
-                sink, owner = grad_sink(param)
-                tgt = sink if sink is not None else _gzeros(cols, dev)
-                check(L().set_partial_rows_sum(_p(part_), _p(tgt), 1, B * tiles, cols, 1, 1.0, _stream()), "set_partial_rows_sum")
-                return None if sink is not None else tgt
+            # bias / step-offset gradients: ordered sums of the per-tile partials, one launch per layer (straight into
+            # .grad when the flat optimizer owns it, else into a zeroed temporary that autograd accumulates)
+            def btgt(param):  # (accumulation target, gradient to hand to autograd or None when written in place)
+                sink, _ = grad_sink(param)
+                if sink is not None:
+                    return sink, None
+                tmp = _gzeros(2 * C_, dev)
+                return tmp, tmp
 
             def wg(param, *args, **kw):
                 sink, owner = grad_sink(param)
@@ -652,13 +663,11 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
                 conv_wgrad(args[0], args[1], args[2], tgt, *args[3:], **kw)
                 return None if sink is not None else tgt
 
-            db_out = acc_into(layer.output_projection.bias, pdbo_c, 2 * C_)
-            db_dil = acc_into(layer.dilated_conv.bias, pdby_c, 2 * C_)
-            db_cond = acc_into(layer.conditioner_projection.bias, pdby_c, 2 * C_)
-            ddl = torch.empty(B, C_, dtype=torch.float32, device=dev)
-            check(L().set_partial_rows_sum(_p(pdd_c), _p(ddl), B, tiles, C_, 0, 1.0, _stream()), "set_partial_rows_sum")
-            dd[:, l * C_:(l + 1) * C_] = ddl
-            # weight gradients on the bf16 operands the two kernels left in HBM
+            (t_out, db_out), (t_dil, db_dil), (t_cond, db_cond) = (btgt(layer.output_projection.bias),
+                                                                   btgt(layer.dilated_conv.bias),
+                                                                   btgt(layer.conditioner_projection.bias))
+            check(L().set_diffnet_layer_bwd_reduce(_p(pdbo_c), _p(pdby_c), _p(pdd_c), B, tiles, _p(t_out), _p(t_dil), _p(t_cond),
+                                                   dd.data_ptr() + 4 * l * C_, dd.stride(0), _stream()), "set_diffnet_layer_bwd_reduce")
             dw_out = wg(layer.output_projection.weight, do16, z16[l], None, B, C_, 2 * C_, 1, 1, 0, T, T, dtype=GX16)
             dw_cond = wg(layer.conditioner_projection.weight, dy16, cond, None, B, H, 2 * C_, 1, 1, 0, T, T, dtype=G16)
             dl = dmat[:, l * C_:(l + 1) * C_].contiguous()

@@ -514,6 +514,37 @@ __global__ void __launch_bounds__(256) partial_rows_sum_kernel(const float *part
     }
 }
 
+// all ordered partial sums of one layer's backward in ONE launch (block = 64 columns x 4 row groups, fixed association):
+//   columns [0,512): db_out += sum over all rows of part_dbo ; [512,1024): db_dil, db_cond += ... of part_dby ;
+//   [1024,1280): dd[b][c] = sum over the tiles of utterance b of part_dd   (blockIdx.y = b there)
+__global__ void __launch_bounds__(256) layer_bwd_reduce_kernel(const float *pdbo, const float *pdby, const float *pdd, int B,
+                                                               int tiles, float *db_out, float *db_dil, float *db_cond,
+                                                               float *dd, int64_t dd_bs) {
+    __shared__ float red[4][64];
+    const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int cbk = blockIdx.x;  // 0..7 dbo, 8..15 dby, 16..19 dd
+    float s = 0.0f;
+    if (cbk < 16) {
+        if (blockIdx.y != 0) return;
+        const float *part = cbk < 8 ? pdbo : pdby;
+        const int j = (cbk & 7) * 64 + tl, rows = B * tiles;
+        for (int r = rg; r < rows; r += 4) s += part[(int64_t)r * 2 * FC + j];
+        red[rg][tl] = s;
+        __syncthreads();
+        if (rg == 0) {
+            s = ((red[0][tl] + red[1][tl]) + red[2][tl]) + red[3][tl];
+            if (cbk < 8) db_out[j] += s;
+            else { db_dil[j] += s; db_cond[j] += s; }
+        }
+    } else {
+        const int b = blockIdx.y, j = (cbk - 16) * 64 + tl;
+        for (int r = rg; r < tiles; r += 4) s += pdd[((int64_t)b * tiles + r) * FC + j];
+        red[rg][tl] = s;
+        __syncthreads();
+        if (rg == 0) dd[(int64_t)b * dd_bs + j] = ((red[0][tl] + red[1][tl]) + red[2][tl]) + red[3][tl];
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t set_diffnet_layer_bf16_image_size(void) { return N_IMG; }
@@ -575,4 +606,14 @@ extern "C" int set_partial_rows_sum(const float *part, float *out, int32_t group
     hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((cols + 63) / 64, groups), dim3(256), 0, (hipStream_t)stream, part, out, rows,
                        cols, accumulate, scale);
     return set_check_launch("set_partial_rows_sum");
+}
+
+extern "C" int set_diffnet_layer_bwd_reduce(const float *part_dbo, const float *part_dby, const float *part_dd, int32_t B,
+                                            int32_t tiles, float *db_out, float *db_dil, float *db_cond, float *dd, int64_t dd_bs,
+                                            void *stream) {
+    SET_REQUIRE(part_dbo && part_dby && part_dd && db_out && db_dil && db_cond && dd && B > 0 && tiles > 0,
+                "set_diffnet_layer_bwd_reduce");
+    hipLaunchKernelGGL(layer_bwd_reduce_kernel, dim3(20, B), dim3(256), 0, (hipStream_t)stream, part_dbo, part_dby, part_dd, B,
+                       tiles, db_out, db_dil, db_cond, dd, dd_bs);
+    return set_check_launch("set_diffnet_layer_bwd_reduce");
 }

@@ -74,7 +74,10 @@ class SpeechDenoiserTask:
             sil |= txt_tokens == int(i)
         sil = sil.long()
         word_id = (sil.cumsum(-1) * (1 - sil)).contiguous()
-        return word_id, int(word_id.max().item())
+        # number of word slots: the reference sizes its scatter target with word_id.max() + 1, a device->host read in the
+        # middle of every step; T_txt is an upper bound (a word has at least one token) and the empty slots have zero
+        # ground-truth duration, i.e. weight 0 in the loss -- same sums, no synchronisation
+        return word_id, int(txt_tokens.shape[1])
 
     def compute_losses(self, output, sample):
         """The loss dict of run_model(infer=False): l1_coarse, ssim_coarse, pdur, wdur, uv, f0 (all on the tape)."""

@@ -271,7 +271,7 @@ def test_phone_set_json_follows_the_reference_token_encoder(tmp_path):
         model.load_state_dict(sd, strict=True)
         txt = torch.tensor([[75, 3, 4, 79, 5, 0, 0]])
         word_id, n_words = task.word_ids(txt)
-        assert word_id.tolist() == [[0, 1, 1, 0, 2, 0, 0]] and n_words == 2
+        assert word_id.tolist() == [[0, 1, 1, 0, 2, 0, 0]] and n_words == 7  # slots: T_txt (upper bound, no host sync)
         H.hparams["lambda_sent_dur"] = 1.0
         with pytest.raises(NotImplementedError):
             task.compute_losses({}, {"mels": torch.zeros(1, 4, 80), "time_mel_masks": torch.zeros(1, 4)})

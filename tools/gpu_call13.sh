@@ -1,0 +1,9 @@
+#!/bin/bash
+set -u
+mkdir -p gpurun_out/r02
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+(timeout 300 python bench.py --mode train --dtype bf16 --steps 10 --warmup 3 2>&1 | tail -1) > gpurun_out/r02/bench_train_bf16.log
+(timeout 300 python bench.py --mode train --dtype f32 --steps 10 --warmup 3 2>&1 | tail -1) > gpurun_out/r02/bench_train_f32.log
+grep -o '"ms_per_step": [0-9.]*\|"host_enqueue_ms_per_step": [0-9.]*' gpurun_out/r02/bench_train_bf16.log gpurun_out/r02/bench_train_f32.log
+timeout 300 python -m pytest tests/test_gpu_training.py -q -m gpu -p no:cacheprovider -k "losses or trainer" 2>&1 | tail -2
