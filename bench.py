@@ -94,6 +94,62 @@ def _cpu_steps(O, W, tab, cond, n_timed, seed=0, gpu_model=None):
     return sum(times[1:]) / n_timed, parity
 
 
+def _cpu_mp_worker(rank, W, cond, threads, barrier, q):
+    """One of P concurrent CPU processes (all host cores busy): 1 warm-up + 2 timed steps on its own 4 utterances."""
+    torch.set_num_threads(threads)
+    torch.set_grad_enabled(False)
+    from oracle import oracle as O
+    tab, _ = O.diffusion_tables(DIFF_STEPS)
+    g = torch.Generator().manual_seed(rank)
+    x = torch.randn(cond.shape[0], 1, M, T, generator=g)
+    times = []
+    for k in range(3):
+        if k == 1:
+            barrier.wait()
+        tt = torch.full((cond.shape[0],), DIFF_STEPS - 1 - k, dtype=torch.long)
+        eps = torch.randn(cond.shape[0], 1, M, T, generator=g)
+        t0 = time.perf_counter()
+        x0 = O.diffnet_forward(W, x, tt, cond)
+        x = O.q_posterior_sample(tab, x0, x, tt, eps)
+        times.append(time.perf_counter() - t0)
+    q.put((rank, times[1:]))
+
+
+def cpu_all_cores(W, cond, threads, ncpu):
+    """Throughput with EVERY host core busy: P = host_cpus // threads processes, `threads` threads each, 4 utterances per
+    process (what a CPU deployment of the reference would do for throughput; one PyTorch process does not scale past a
+    few tens of threads on this workload)."""
+    import torch.multiprocessing as mp
+    P = max(1, min(ncpu // threads, 32))
+    ctx = mp.get_context("spawn")
+    q, barrier = ctx.Queue(), ctx.Barrier(P)
+    Wd = {k: v for k, v in W.items() if k.startswith("denoise_fn.")}
+    for v in Wd.values():
+        v.share_memory_()
+    c4 = cond[:4].contiguous().share_memory_()
+    procs = [ctx.Process(target=_cpu_mp_worker, args=(r, Wd, c4, threads, barrier, q)) for r in range(P)]
+    for p in procs:
+        p.start()
+    res, deadline = [], time.time() + 300
+    import queue as _queue
+    while len(res) < P:
+        try:
+            res.append(q.get(timeout=2))
+        except _queue.Empty:
+            if time.time() > deadline or any(p.exitcode not in (None, 0) for p in procs):
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise RuntimeError("a CPU baseline worker died or timed out")
+    for p in procs:
+        p.join(timeout=60)
+    step = max(sum(t) / len(t) for _, t in res)  # the slowest process bounds the aggregate
+    return {"value": P * 4 * T / (DIFF_STEPS * step), "unit": "mel-frames/s", "cores": P * threads, "processes": P,
+            "threads_per_process": threads,
+            "sample": "%d processes x %d threads, 4 utterances each, 2 timed DiffNet+posterior steps after a common "
+                      "barrier, scaled to %d steps; slowest process s/step=%.3f" % (P, threads, DIFF_STEPS, step)}
+
+
 def cpu_baseline(model, inp, protocol="full"):
     """`value` = the CPU's best: conditioner once + timed DiffNet+posterior steps at B=32, T=800 scaled to 100 steps,
     at the best thread count of a sweep over {8, 16, 32, 64, all} (the sweep itself runs on the first 8 utterances).
@@ -152,6 +208,20 @@ def cpu_baseline(model, inp, protocol="full"):
         O.hifigan_forward(Wg, Wt.HIFIGAN_V1, mel)
         th = time.perf_counter() - t0
         out["hifigan_v1_B4"] = {"value": 4 * T / th, "unit": "mel-frames/s", "cores": best, "seconds": th}
+        # every host core busy: P processes x `best` threads
+        try:
+            out["all_cores_multiprocess"] = cpu_all_cores(W, cond, min(best, 8), ncpu)
+        except Exception as e:  # a reported baseline must not take the benchmark down
+            out["all_cores_multiprocess"] = {"error": repr(e)}
+        # `value` is the CPU's best over everything measured above
+        cands = [("one process, B=32 (scaled from 3 steps)", out["value"], best),
+                 ("one process, complete 100 steps at B=4", out["full_100_steps_B4"]["value"], best)]
+        if "value" in out["all_cores_multiprocess"]:
+            cands.append(("all cores, %d processes" % out["all_cores_multiprocess"]["processes"],
+                          out["all_cores_multiprocess"]["value"], out["all_cores_multiprocess"]["cores"]))
+        name, val, cores = max(cands, key=lambda c: c[1])
+        out["one_process_B32"] = {"value": out["value"], "cores": best}
+        out["value"], out["cores"], out["best_of"] = val, cores, name
     torch.set_num_threads(ncpu)
     return out
 
