@@ -325,6 +325,12 @@ typedef struct SetDiffLoopArgs {
     int32_t persistent;
     int32_t *sync_ws;
     int32_t *err_flag; /* optional sticky error word, see SetDiffnetStackArgs.err_flag */
+    /* bf16-operand loop (opt-in, NOT the parity path; img16_all != NULL selects it): every residual layer runs as one
+     * set_diffnet_layer_fwd_bf16 launch reading cond [B][192][T] (the conditioner projection is a K-chunk of the layer's
+     * GEMM, condproj is not used), images [L][set_diffnet_layer_bf16_image_size()], conditioner biases [L][512] */
+    const float *cond;
+    const void *img16_all;
+    const float *b_cond_all;
 } SetDiffLoopArgs;
 int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream);
 
@@ -367,7 +373,7 @@ typedef struct SetDiffnetLayerBf16Args {
     const float *dstep;
     const void *img;
     const float *b_dil, *b_cond, *b_out; /* [512] each */
-    uint16_t *y16;       /* [B][512][T] bf16 out */
+    uint16_t *y16;       /* [B][512][T] bf16 out (both NULL: inference, nothing is saved) */
     uint16_t *z16;       /* [B][256][T] bf16 out */
     int64_t d_bs, d_cs;
     int32_t B, T, dil, first;

@@ -74,6 +74,7 @@ class SetDiffLoopArgs(C.Structure):
         ("persistent", C.c_int32),
         ("sync_ws", C.c_void_p),
         ("err_flag", C.c_void_p),
+        ("cond", C.c_void_p), ("img16_all", C.c_void_p), ("b_cond_all", C.c_void_p),
     ]
 
 

@@ -1339,13 +1339,14 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
     float *ws_x0 = a.ws_x0 + (int64_t)b0 * DC * T, *ws_x1 = a.ws_x1 + (int64_t)b0 * DC * T;
     float *ws_skip = a.ws_skip + (int64_t)b0 * DC * T, *ws_h = a.ws_h + (int64_t)b0 * DC * T;
     float *ws_x0pred = a.ws_x0pred + (int64_t)b0 * per_batch;
-    const float *condproj = a.condproj + (int64_t)b0 * L * 512 * T;
+    const float *condproj = a.condproj ? a.condproj + (int64_t)b0 * L * 512 * T : nullptr;
     const int tiles_per_utt = (T + NT - 1) / NT;
     int32_t *sync_ws = a.sync_ws ? a.sync_ws + 4 * (int64_t)g + (int64_t)b0 * ((T + 31) / 32) : nullptr;  // per-group slice
     const uint64_t quads_before = (uint64_t)((int64_t)b0 * per_batch / 4);
     const uint64_t quads_total = (uint64_t)(((int64_t)a.B * per_batch + 3) / 4);
     int rc = SET_OK;
     const bool fused_boundary = boundary_fusable(a);
+    const bool bf16_loop = a.img16_all != nullptr;
     for (int k = 0; k < a.steps && rc == SET_OK; ++k) {
         const int sid = a.steps - 1 - k;  // diffusion step id t = steps-1 .. 0 (spec_denoiser.py:181)
         // input projection + ReLU (diffnet.py:118-120); with the fused boundary it is part of the previous step's
@@ -1358,7 +1359,7 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
         }
         float *cur = ws_x0, *nxt = ws_x1;
         if (ev) (void)hipEventRecord(ev[2 * k], s);
-        if (a.persistent) {
+        if (a.persistent && !bf16_loop) {
             SetDiffnetStackArgs sa = {};
             sa.xa = ws_x0; sa.xb = ws_x1; sa.skip = ws_skip;
             sa.condproj = condproj; sa.cp_bs = (int64_t)L * 512 * T; sa.cp_ls = (int64_t)512 * T;
@@ -1370,7 +1371,21 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
             sa.B = Bg; sa.T = T; sa.L = L; sa.dilation_cycle_length = a.dilation_cycle_length;
             rc = set_diffnet_stack(&sa, s);
         }
-        for (int l = 0; l < L && rc == SET_OK && !a.persistent; ++l) {
+        for (int l = 0; l < L && rc == SET_OK && bf16_loop; ++l) {
+            // opt-in bf16-operand layers (csrc/diffnet_bf16.hip): conditioner projection inside the layer GEMM
+            SetDiffnetLayerBf16Args la = {};
+            la.x_in = cur; la.x_out = nxt; la.skip = ws_skip;
+            la.cond = a.cond + (int64_t)b0 * 192 * T;
+            la.dstep = a.dstep + (int64_t)l * DC * a.steps + sid;
+            la.d_bs = 0; la.d_cs = a.steps;
+            la.img = reinterpret_cast<const uint16_t *>(a.img16_all) + (int64_t)l * set_diffnet_layer_bf16_image_size();
+            la.b_dil = a.b_dil_all + (int64_t)l * 512; la.b_cond = a.b_cond_all + (int64_t)l * 512;
+            la.b_out = a.b_out_all + (int64_t)l * 512;
+            la.B = Bg; la.T = T; la.dil = 1 << (l % a.dilation_cycle_length); la.first = (l == 0);
+            rc = set_diffnet_layer_fwd_bf16(&la, s);
+            float *tmp = cur; cur = nxt; nxt = tmp;
+        }
+        for (int l = 0; l < L && rc == SET_OK && !a.persistent && !bf16_loop; ++l) {
             SetDiffnetLayerArgs la = {};
             la.x_in = cur; la.x_out = nxt; la.skip = ws_skip;
             la.condproj = condproj + (int64_t)l * 512 * T;
@@ -1412,10 +1427,14 @@ extern "C" int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream) {
     const SetDiffLoopArgs &a = *args;
     SET_REQUIRE(a.B > 0 && a.T > 0 && a.M > 0 && a.L > 0 && a.steps > 0 && a.dilation_cycle_length >= 1,
                 "set_diffusion_loop");
-    SET_REQUIRE(a.x && a.condproj && a.dstep && a.coef4 && a.w_in_p && a.b_in && a.w1p_all && a.w2p_all &&
-                    a.b_dil_all && a.b_out_all && a.w_skip_p && a.b_skip && a.w_outp_p && a.b_outp,
-                "set_diffusion_loop");
-    SET_REQUIRE(!a.persistent || a.sync_ws, "set_diffusion_loop(persistent needs sync_ws)");
+    SET_REQUIRE(a.x && a.dstep && a.coef4 && a.w_in_p && a.b_in && a.b_dil_all && a.b_out_all && a.w_skip_p && a.b_skip &&
+                    a.w_outp_p && a.b_outp, "set_diffusion_loop");
+    if (a.img16_all) {
+        SET_REQUIRE(a.cond && a.b_cond_all, "set_diffusion_loop(bf16 loop needs cond and b_cond_all)");
+    } else {
+        SET_REQUIRE(a.condproj && a.w1p_all && a.w2p_all, "set_diffusion_loop");
+        SET_REQUIRE(!a.persistent || a.sync_ws, "set_diffusion_loop(persistent needs sync_ws)");
+    }
     SET_REQUIRE(a.ws_x0 && a.ws_x1 && a.ws_skip && a.ws_h && a.ws_x0pred, "set_diffusion_loop");
     hipStream_t s = (hipStream_t)stream;
     const int64_t per_batch = (int64_t)a.M * a.T;

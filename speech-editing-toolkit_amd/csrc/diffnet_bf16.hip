@@ -157,6 +157,7 @@ __global__ void __launch_bounds__(256) pack_layer_bf16_kernel(const float *wdil,
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
+template <bool TRAIN>  // TRAIN: also store the pre-gate y and the gated z in bf16 (operands of the backward)
 __global__ void __launch_bounds__(512, 1) diffnet_layer_fwd_bf16_kernel(SetDiffnetLayerBf16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -170,56 +171,66 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_fwd_bf16_kernel(SetDiffn
     const rsrc_t rx = make_rsrc(a.x_in + (int64_t)b * FC * T), rxo = make_rsrc(a.x_out + (int64_t)b * FC * T);
     const rsrc_t rsk = make_rsrc(a.skip + (int64_t)b * FC * T), rcd = make_rsrc(a.cond + (int64_t)b * FH * T);
     const rsrc_t rd = make_rsrc(a.dstep + (int64_t)b * a.d_bs);
-    const rsrc_t ry = make_rsrc(a.y16 + (int64_t)b * 2 * FC * T), rz = make_rsrc(a.z16 + (int64_t)b * FC * T);
+    const rsrc_t ry = make_rsrc(TRAIN ? a.y16 + (int64_t)b * 2 * FC * T : (uint16_t *)a.skip);
+    const rsrc_t rz = make_rsrc(TRAIN ? a.z16 + (int64_t)b * FC * T : (uint16_t *)a.skip);
     const rsrc_t rbd = make_rsrc(a.b_dil), rbc = make_rsrc(a.b_cond), rbo = make_rsrc(a.b_out);
     const unsigned short *img = reinterpret_cast<const unsigned short *>(a.img);
     const rsrc_t rw1 = make_rsrc(img + (int64_t)w * KS1 * 2 * 512), rw2 = make_rsrc(img + OFF_W2B + (int64_t)w * KS2 * 2 * 512);
     const unsigned lane16 = 16u * (unsigned)lane;
 
-    // ---- stage the tiles: thread (frame row f, channel group cg); loads unconditional on clamped addresses, selects after
+    // ---- stage the tiles: thread (frame row f, channel group cg).  ALL loads of the main pass (64 x + 48 cond per
+    //      thread; no accumulator is live yet) are issued before the first one is consumed: one memory round trip instead
+    //      of one per 32-channel batch; the per-utterance step offsets d[256] go through LDS (one load per channel per
+    //      block instead of one per element).  Loads are unconditional on clamped addresses, selects after.
+    float *dsh = reinterpret_cast<float *>(lds + XROWS * XR + FNT * CR);  // [256]
     {
         const int f = tid & 127, cg = __builtin_amdgcn_readfirstlane(tid >> 7);  // cg 0..3 (two waves each)
-        // x + d: channels [64 cg, 64 cg + 64), two passes of frame rows (the second one = the 2d halo rows)
-#pragma unroll 1
-        for (int p = 0; p < 2; ++p) {
-            const int j = p * FNT + f;
-            const int t = t0 - d + j;
-            const bool tv = t >= 0 && t < T, jv = j < XROWS;
-            if (!jv) continue;  // halo pass: only the first 2d lanes of the block have a row
-            const unsigned vo = 4u * (unsigned)min(max(t, 0), T - 1);
+        if (tid < FC) dsh[tid] = buf_load(rd, 0u, (unsigned)tid * 4u * (unsigned)a.d_cs);
+        const int t = t0 - d + f;           // x row j = f
+        const bool tvx = t >= 0 && t < T;
+        const unsigned vox = 4u * (unsigned)min(max(t, 0), T - 1);
+        const int tcn = t0 + f;             // cond row f
+        const bool tvc = tcn < T;
+        const unsigned voc = 4u * (unsigned)min(tcn, T - 1);
+        float vx[64], vc[48];
 #pragma unroll
-            for (int hq = 0; hq < 2; ++hq) {  // 32 channels at a time (register budget)
-                float v[32];
+        for (int k = 0; k < 64; ++k) vx[k] = buf_load(rx, vox, (unsigned)(64 * cg + k) * T4);
 #pragma unroll
-                for (int k = 0; k < 32; ++k) {
-                    const unsigned c = (unsigned)(64 * cg + 32 * hq + k);
-                    v[k] = buf_load(rx, vo, c * T4) + buf_load(rd, 0u, c * 4u * (unsigned)a.d_cs);
-                }
-                if (jv) {
+        for (int k = 0; k < 48; ++k) vc[k] = buf_load(rcd, voc, (unsigned)(48 * cg + k) * T4);
+        __syncthreads();  // dsh
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        u32x4_t u;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) u[e] = tv ? pack2(v[8 * q + 2 * e], v[8 * q + 2 * e + 1]) : 0u;
-                        *reinterpret_cast<u32x4_t *>(xs + j * XR + (64 * cg + 32 * hq + 8 * q) * 2) = u;
-                    }
-                }
-            }
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dsh + 64 * cg + 8 * q);
+            const f32x4 d1 = *reinterpret_cast<const f32x4 *>(dsh + 64 * cg + 8 * q + 4);
+            u32x4_t u;
+            u[0] = tvx ? pack2(vx[8 * q + 0] + d0[0], vx[8 * q + 1] + d0[1]) : 0u;
+            u[1] = tvx ? pack2(vx[8 * q + 2] + d0[2], vx[8 * q + 3] + d0[3]) : 0u;
+            u[2] = tvx ? pack2(vx[8 * q + 4] + d1[0], vx[8 * q + 5] + d1[1]) : 0u;
+            u[3] = tvx ? pack2(vx[8 * q + 6] + d1[2], vx[8 * q + 7] + d1[3]) : 0u;
+            *reinterpret_cast<u32x4_t *>(xs + f * XR + (64 * cg + 8 * q) * 2) = u;
         }
-        // cond: channels [48 cg, 48 cg + 48)
-        {
-            const int t = t0 + f;
-            const bool tv = t < T;
-            const unsigned vo = 4u * (unsigned)min(t, T - 1);
-            float v[48];
 #pragma unroll
-            for (int k = 0; k < 48; ++k) v[k] = buf_load(rcd, vo, (unsigned)(48 * cg + k) * T4);
+        for (int q = 0; q < 6; ++q) {
+            u32x4_t u;
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
+            for (int e = 0; e < 4; ++e) u[e] = tvc ? pack2(vc[8 * q + 2 * e], vc[8 * q + 2 * e + 1]) : 0u;
+            *reinterpret_cast<u32x4_t *>(cs + f * CR + (48 * cg + 8 * q) * 2) = u;
+        }
+        // halo rows j = 128 .. 128 + 2d - 1: only the first 2d lanes of each channel group have one
+        if (f < 2 * d) {
+            const int j = FNT + f, th = t0 - d + j;
+            const bool tvh = th >= 0 && th < T;
+            const unsigned voh = 4u * (unsigned)min(max(th, 0), T - 1);
+            float vh[64];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) vh[k] = buf_load(rx, voh, (unsigned)(64 * cg + k) * T4);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
                 u32x4_t u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) u[e] = tv ? pack2(v[8 * q + 2 * e], v[8 * q + 2 * e + 1]) : 0u;
-                *reinterpret_cast<u32x4_t *>(cs + f * CR + (48 * cg + 8 * q) * 2) = u;
+                for (int e = 0; e < 4; ++e)
+                    u[e] = tvh ? pack2(vh[8 * q + 2 * e] + dsh[64 * cg + 8 * q + 2 * e], vh[8 * q + 2 * e + 1] + dsh[64 * cg + 8 * q + 2 * e + 1]) : 0u;
+                *reinterpret_cast<u32x4_t *>(xs + j * XR + (64 * cg + 8 * q) * 2) = u;
             }
         }
     }
@@ -256,6 +267,12 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_fwd_bf16_kernel(SetDiffn
         vo4[cb] = 4u * (unsigned)(4 * half * T + min(t, T - 1));
         vo2[cb] = 2u * (unsigned)(4 * half * T + min(t, T - 1));
     }
+    // residual rows of x for GEMM 2's accumulator start: issued here, consumed after the gate (hidden under it)
+    float xres[4][16];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xres[cb][r] = buf_load(rx, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
     __syncthreads();  // every wave is done reading the x tile
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
@@ -265,14 +282,17 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_fwd_bf16_kernel(SetDiffn
             const float z = tv[cb] ? fsig(yg) * ftanh(yf) : 0.0f;
             const unsigned ur = (unsigned)(32 * w + urow(r));
             const unsigned short zb = f2bf(z);
-            if (tv[cb]) {
-                buf_store_u16(f2bf(yg), ry, vo2[cb], ur * T2);
-                buf_store_u16(f2bf(yf), ry, vo2[cb], (ur + FC) * T2);
-                buf_store_u16(zb, rz, vo2[cb], ur * T2);
+            if constexpr (TRAIN) {
+                if (tv[cb]) {
+                    buf_store_u16(f2bf(yg), ry, vo2[cb], ur * T2);
+                    buf_store_u16(f2bf(yf), ry, vo2[cb], (ur + FC) * T2);
+                    buf_store_u16(zb, rz, vo2[cb], ur * T2);
+                }
             }
             *reinterpret_cast<unsigned short *>(xs + (cb * 32 + l31) * XR + (32 * w + urow(r) + 4 * half) * 2) = zb;
         }
-    // ---- accumulators of GEMM 2 start at x + b_out (residual rows) / skip + b_out (skip rows)
+    // ---- accumulators of GEMM 2: residual rows start at x + b_out, skip rows at b_out (the running skip sum is added in
+    //      the epilogue, after the x' stores are in flight)
     const bool first = a.first != 0;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -281,10 +301,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_fwd_bf16_kernel(SetDiffn
             const unsigned ur = (unsigned)(32 * w + urow(r));
             const float bias = buf_load(rbo, lb, 4u * (ur + (rb ? FC : 0)));
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                const float sv = rb == 0 ? buf_load(rx, vo4[cb], ur * T4) : buf_load(rsk, vo4[cb], ur * T4);
-                acc[rb][cb][r] = (rb == 1 && first) ? bias : bias + sv;
-            }
+            for (int cb = 0; cb < 4; ++cb) acc[rb][cb][r] = rb == 0 ? bias + xres[cb][r] : bias;
         }
     __syncthreads();
 
@@ -293,16 +310,25 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_fwd_bf16_kernel(SetDiffn
         return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2);
     });
 
-    // ---- store-only epilogue
+    // ---- epilogue: x' stores first (they need nothing), then the running skip sum is fetched and updated
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
         if (tv[cb]) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned ur = (unsigned)(32 * w + urow(r));
-                buf_store(acc[0][cb][r] * RSQRT2, rxo, vo4[cb], ur * T4);
-                buf_store(acc[1][cb][r], rsk, vo4[cb], ur * T4);
-            }
+            for (int r = 0; r < 16; ++r) buf_store(acc[0][cb][r] * RSQRT2, rxo, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+        }
+    }
+    float sk[4][16];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        if (tv[cb]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                buf_store(first ? acc[1][cb][r] : acc[1][cb][r] + sk[cb][r], rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
         }
     }
 }
@@ -353,22 +379,20 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffn
         const rsrc_t rs = cg < 2 ? rdxo : rdsk;
         const float sc = cg < 2 ? (has_dxo ? RSQRT2 : 0.0f) : 1.0f;
         const int cs0 = 128 * (cg & 1);  // channel inside the source tensor
+        // all 128 loads of the thread in flight at once (nothing else is live yet): one memory round trip
+        float v[128];
 #pragma unroll
-        for (int hq = 0; hq < 4; ++hq) {
-            float v[32];
+        for (int k = 0; k < 128; ++k) v[k] = buf_load(rs, 4u * tc, (unsigned)(cs0 + k) * T4) * sc;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) v[k] = buf_load(rs, 4u * tc, (unsigned)(cs0 + 32 * hq + k) * T4) * sc;
+        for (int q = 0; q < 16; ++q) {
+            u32x4_t u;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                u32x4_t u;
+            for (int e = 0; e < 4; ++e) u[e] = tv ? pack2(v[8 * q + 2 * e], v[8 * q + 2 * e + 1]) : 0u;
+            *reinterpret_cast<u32x4_t *>(lds + (f + d) * DR + (128 * cg + 8 * q) * 2) = u;
+        }
+        if (central) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) u[e] = tv ? pack2(v[8 * q + 2 * e], v[8 * q + 2 * e + 1]) : 0u;
-                *reinterpret_cast<u32x4_t *>(lds + (f + d) * DR + (128 * cg + 32 * hq + 8 * q) * 2) = u;
-            }
-            if (central) {
-#pragma unroll
-                for (int k = 0; k < 32; ++k) buf_store_u16(f2bf(v[k]), rdo, 2u * tc, (unsigned)(128 * cg + 32 * hq + k) * T2);
-            }
+            for (int k = 0; k < 128; ++k) buf_store_u16(f2bf(v[k]), rdo, 2u * tc, (unsigned)(128 * cg + k) * T2);
         }
     }
     __syncthreads();
@@ -403,19 +427,22 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffn
         float sg[16], sf[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) sg[r] = sf[r] = 0.0f;
+        // the saved pre-gate values of all four column blocks are fetched up front (one round trip, not four)
+        unsigned short yg[4][16], yf[4][16];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            unsigned short yg[16], yf[16];
+        for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned ur = (unsigned)(32 * w + urow(r));
-                yg[r] = buf_load_u16(ry, vo2[cb], ur * T2);
-                yf[r] = buf_load_u16(ry, vo2[cb], (ur + FC) * T2);
+                yg[cb][r] = buf_load_u16(ry, vo2[cb], ur * T2);
+                yf[cb][r] = buf_load_u16(ry, vo2[cb], (ur + FC) * T2);
             }
 #pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned ur = (unsigned)(32 * w + urow(r));
-                const float s = fsig(bf2f(yg[r])), th = ftanh(bf2f(yf[r]));
+                const float s = fsig(bf2f(yg[cb][r])), th = ftanh(bf2f(yf[cb][r]));
                 const float g = dz[0][cb][r];  // exactly 0 on frames outside [0, T): d_o was staged as zeros there
                 const float dg = g * th * s * (1.0f - s), df = g * s * (1.0f - th * th);
                 const unsigned short bg = f2bf(dg), bfv = f2bf(df);
@@ -561,19 +588,22 @@ extern "C" int64_t set_sizeof_diffnet_layer_bf16_args(void) { return (int64_t)si
 extern "C" int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, void *stream) {
     SET_REQUIRE(args != nullptr, "set_diffnet_layer_fwd_bf16");
     const SetDiffnetLayerBf16Args &a = *args;
-    SET_REQUIRE(a.x_in && a.x_out && a.skip && a.cond && a.dstep && a.img && a.b_dil && a.b_cond && a.b_out && a.y16 && a.z16,
-                "set_diffnet_layer_fwd_bf16");
+    SET_REQUIRE(a.x_in && a.x_out && a.skip && a.cond && a.dstep && a.img && a.b_dil && a.b_cond && a.b_out &&
+                    ((a.y16 != nullptr) == (a.z16 != nullptr)), "set_diffnet_layer_fwd_bf16");
     SET_REQUIRE(a.B > 0 && a.T > 0 && a.dil >= 1 && a.dil <= 8, "set_diffnet_layer_fwd_bf16");
     SET_REQUIRE((int64_t)2 * FC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_layer_fwd_bf16 (T too large)");
-    const size_t ldsz = (size_t)(FNT + 2 * a.dil) * XR + (size_t)FNT * CR;
+    const size_t ldsz = (size_t)(FNT + 2 * a.dil) * XR + (size_t)FNT * CR + FC * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel),
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layer fwd bf16 attr");
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layer fwd bf16 attr");
         attr_set = true;
     }
     dim3 grid((a.T + FNT - 1) / FNT, a.B);
-    hipLaunchKernelGGL(diffnet_layer_fwd_bf16_kernel, grid, dim3(512), ldsz, (hipStream_t)stream, a);
+    if (a.y16) hipLaunchKernelGGL(diffnet_layer_fwd_bf16_kernel<true>, grid, dim3(512), ldsz, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(diffnet_layer_fwd_bf16_kernel<false>, grid, dim3(512), ldsz, (hipStream_t)stream, a);
     return set_check_launch("set_diffnet_layer_fwd_bf16");
 }
 

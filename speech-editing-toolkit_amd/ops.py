@@ -547,8 +547,10 @@ def selftest_mfma():
 
 def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs, w_skip, b_skip,
                    w_outp, b_outp, L, steps, dilation_cycle_length, want_layer_spans=False, n_groups=None,
-                   persistent=None):
-    """Enqueue the whole reverse loop (set_diffusion_loop).  x [B,M,T] is updated in place."""
+                   persistent=None, bf16=None):
+    """Enqueue the whole reverse loop (set_diffusion_loop).  x [B,M,T] is updated in place.
+    bf16 = dict(cond=[B,192,T] fp32, imgs=[L, n] bf16 layer images, b_cond=[L,512]): the opt-in bf16-operand loop
+    (condproj is then unused and may be None)."""
     _f(x), _f(noise), _f(condproj), _f(dstep), _f(coef4)
     B, M, T = x.shape
     dev = x.device
@@ -559,7 +561,10 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs,
     a.x = x.data_ptr()
     a.noise = noise.data_ptr() if noise is not None else None
     a.seed = int(seed)
-    a.condproj, a.dstep, a.coef4 = condproj.data_ptr(), dstep.data_ptr(), coef4.data_ptr()
+    a.condproj = condproj.data_ptr() if condproj is not None else None
+    a.dstep, a.coef4 = dstep.data_ptr(), coef4.data_ptr()
+    if bf16 is not None:
+        a.cond, a.img16_all, a.b_cond_all = _f(bf16["cond"]).data_ptr(), bf16["imgs"].data_ptr(), _f(bf16["b_cond"]).data_ptr()
     a.w_in_p, a.b_in = w_in.packed().data_ptr(), b_in.data_ptr()
     w1p_all, w2p_all, b_dil_all, b_out_all = packs[:4]
     a.w1p_all, a.w2p_all = w1p_all.data_ptr(), w2p_all.data_ptr()
@@ -583,7 +588,7 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs,
         loop_ms = C.c_float(0.0)
         a.loop_ms = C.pointer(loop_ms)
     check(_lib.lib().set_diffusion_loop(C.byref(a), _stream()), "set_diffusion_loop")
-    if a.persistent and int(err.item()) != 0:  # (one 4-byte read-back per reverse loop; fail loudly, never return garbage)
+    if a.persistent and bf16 is None and int(err.item()) != 0:  # (one 4-byte read-back per reverse loop; fail loudly, never return garbage)
         raise _lib.SetAmdError("set_diffusion_loop: a tile dependency wait of the persistent layer-stack kernel timed out")
     # the group chains are joined back into the current stream, so stream-ordered reuse of these buffers is safe
     if spans is None:

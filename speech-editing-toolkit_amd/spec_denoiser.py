@@ -167,10 +167,15 @@ class GaussianDiffusion(nn.Module):
         ids = torch.arange(steps, device=dev)
         coef4 = self.posterior_coef(ids)
         dtab = dn.step_table(ids.to(torch.float32))  # [L*C, steps]
-        condproj = dn.cond_projections(cond)  # hoisted: independent of the step
+        # opt-in bf16-operand loop (ops.set_compute_dtype("bf16")): NOT the parity path -- see DESIGN.md section 3.5
+        bf16 = None
+        if ops.compute_dtype() == "bf16" and dn.use_fused() and dn.encoder_hidden == 192 and T >= 32:
+            bf16 = dict(cond=cond.contiguous(), imgs=dn.bf16_layer_images(),
+                        b_cond=torch.stack([l.conditioner_projection.bias for l in dn.residual_layers]).contiguous())
+        condproj = dn.cond_projections(cond) if bf16 is None else None  # hoisted: independent of the step
         if dn.use_fused():
             spans = ops.diffusion_loop(
-                x=x, noise=eps, seed=seed, condproj=condproj, dstep=dtab, coef4=coef4,
+                x=x, noise=eps, seed=seed, condproj=condproj, dstep=dtab, coef4=coef4, bf16=bf16,
                 w_in=dn._w_in, b_in=dn.input_projection.bias,
                 packs=dn.fused_packs(),
                 w_skip=dn._w_skip, b_skip=dn.skip_projection.bias,
