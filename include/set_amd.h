@@ -383,6 +383,8 @@ int64_t set_diffnet_layer_bf16_image_size(void);
 int set_pack_diffnet_layer_bf16(const float *wdil /*[512][256][3]*/, const float *wcond /*[512][192]*/,
                                 const float *wout /*[512][256]*/, void *img, void *stream);
 int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, void *stream);
+/* debug: block (1,1) of the bf16 layer kernels stamps s_memtime at its phase boundaries into buf[0..7] (NULL = off) */
+int set_debug_bf16_phase_buffer(uint64_t *buf);
 
 typedef struct SetDiffnetLayerBf16BwdArgs {
     const float *dx_out; /* [B][256][T] gradient w.r.t. x_out; NULL = zero (the last layer's x_out feeds nothing) */

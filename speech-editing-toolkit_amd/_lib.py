@@ -189,6 +189,7 @@ SIGNATURES = {
     "set_diffnet_layer_bf16_image_size": (_I64, []),
     "set_pack_diffnet_layer_bf16": (C.c_int, [_V, _V, _V, _V, _V]),
     "set_diffnet_layer_fwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayerBf16Args), _V]),
+    "set_debug_bf16_phase_buffer": (C.c_int, [_V]),
     "set_sizeof_diffnet_layer_bf16_bwd_args": (_I64, []),
     "set_diffnet_layer_bwd_bf16_tiles": (_I32, [_I32, _I32]),
     "set_diffnet_layer_bwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayerBf16BwdArgs), _V]),

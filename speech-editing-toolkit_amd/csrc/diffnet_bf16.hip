@@ -20,10 +20,17 @@
 // bf16, rows padded by 16 bytes (a 16-byte fragment read of 16 consecutive frames hits 64 distinct banks); the k = 3 taps
 // are row shifts of one tile.  A operands (weights) come from packed bf16 fragment images in global memory (L2
 // resident), one 1 KiB coalesced load per wave per (row block, k-step), prefetched 4 k-steps ahead.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// debug: phase time stamps (s_memtime) of one block of the layer kernels, see set_debug_bf16_phase_buffer
+__device__ uint64_t *g_bf16_phase_buf = nullptr;
+#define BF16_PHASE(i)                                                                                    \
+    if (g_bf16_phase_buf && blockIdx.x == 1 && blockIdx.y == 1 && threadIdx.x == 0) g_bf16_phase_buf[i] = __builtin_amdgcn_s_memtime();
 
 namespace {
 
@@ -157,16 +164,57 @@ __global__ void __launch_bounds__(256) pack_layer_bf16_kernel(const float *wdil,
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
-template <bool TRAIN>  // TRAIN: also store the pre-gate y and the gated z in bf16 (operands of the backward)
-__global__ void __launch_bounds__(512, 1) diffnet_layer_fwd_bf16_kernel(SetDiffnetLayerBf16Args a) {
+// acc[NRB][NCB] += A * B with a caller-supplied A address: aoff(ks, rb) = byte offset of the 1 KiB fragment block
+template <int NRB, int NCB, typename AF, typename BF>
+__device__ __forceinline__ void gemm_bf16_a(f32x16 (&acc)[NRB][NCB], rsrc_t img, unsigned lane16, int nks, const unsigned char *lds,
+                                            AF aoff, BF bfrag) {
+    u32x4_t A[PF][NRB];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) A[p][rb] = buf_load_u4(img, lane16, aoff(min(p, nks - 1), rb));
+    for (int kb = 0; kb < nks; kb += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int ks = kb + p;  // nks is a multiple of PF
+            u32x4_t Bv[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) Bv[cb] = *reinterpret_cast<const u32x4_t *>(lds + bfrag(ks, cb));
+            u32x4_t Ac[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) Ac[rb] = A[p][rb];
+            const int kn = min(ks + PF, nks - 1);  // tail: harmless re-load of the last k-step
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) A[p][rb] = buf_load_u4(img, lane16, aoff(kn, rb));
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mma16(Ac[rb], Bv[cb], acc[rb][cb]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+}
+
+// TRAIN: also store the pre-gate y and the gated z in bf16 (operands of the backward).
+// NT: frames per tile.  128 -> 8 waves, one 32-row gate block + its filter block per wave, one block per CU (120 KB of LDS);
+//     64 -> 4 waves, two gate blocks + their filter blocks per wave, 61 KB of LDS: TWO blocks per CU, which drift out
+//     of phase so that one block's HBM phases (stage, residual / skip read-modify-write) run under the other's GEMMs --
+//     at the price of reading the weight images twice as often from L2.  Accumulators: 8 x 32x32 per wave either way.
+template <bool TRAIN, int NT>
+__global__ void __launch_bounds__(NT * 4, NT == 128 ? 1 : 2) diffnet_layer_fwd_bf16_kernel(SetDiffnetLayerBf16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int NW = NT / 16;   // waves per block
+    constexpr int RBW = 8 / NW;   // 32-row gate blocks per wave (and as many filter blocks)
+    constexpr int NCB = NT / 32;  // 32-frame column blocks
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.y, t0 = blockIdx.x * FNT, T = a.T, d = a.dil;
-    const int XROWS = FNT + 2 * d;
+    const int b = blockIdx.y, t0 = blockIdx.x * NT, T = a.T, d = a.dil;
+    const int XROWS = NT + 2 * d;
     unsigned char *xs = lds;                   // [XROWS][XR]   x + d, row j <-> frame t0 - d + j   (z overlays it: row j <-> t0 + j)
-    unsigned char *cs = lds + XROWS * XR;      // [FNT][CR]     cond,  row j <-> frame t0 + j
+    unsigned char *cs = lds + XROWS * XR;      // [NT][CR]      cond,  row j <-> frame t0 + j
+    float *dsh = reinterpret_cast<float *>(lds + XROWS * XR + NT * CR);  // [256] per-utterance step offsets
     const unsigned T4 = 4u * (unsigned)T, T2 = 2u * (unsigned)T;
     const rsrc_t rx = make_rsrc(a.x_in + (int64_t)b * FC * T), rxo = make_rsrc(a.x_out + (int64_t)b * FC * T);
     const rsrc_t rsk = make_rsrc(a.skip + (int64_t)b * FC * T), rcd = make_rsrc(a.cond + (int64_t)b * FH * T);
@@ -175,16 +223,21 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_fwd_bf16_kernel(SetDiffn
     const rsrc_t rz = make_rsrc(TRAIN ? a.z16 + (int64_t)b * FC * T : (uint16_t *)a.skip);
     const rsrc_t rbd = make_rsrc(a.b_dil), rbc = make_rsrc(a.b_cond), rbo = make_rsrc(a.b_out);
     const unsigned short *img = reinterpret_cast<const unsigned short *>(a.img);
-    const rsrc_t rw1 = make_rsrc(img + (int64_t)w * KS1 * 2 * 512), rw2 = make_rsrc(img + OFF_W2B + (int64_t)w * KS2 * 2 * 512);
+    const rsrc_t rw1 = make_rsrc(img), rw2 = make_rsrc(img + OFF_W2B);
     const unsigned lane16 = 16u * (unsigned)lane;
+    // accumulator index rb = g * RBW + q: g = 0 gate / residual rows, 1 filter / skip rows; q-th 32-row block of the wave,
+    // i.e. block vw = RBW * w + q of the packed images ("virtual wave" of the 8-wave layout)
+    auto row0 = [&](int rb) { return ((rb / RBW) ? FC : 0) + 32 * (RBW * w + (rb % RBW)); };
+    auto aoff1 = [&](int ks, int rb) { return (unsigned)((((RBW * w + (rb % RBW)) * KS1 + ks) * 2 + rb / RBW) * 1024); };
+    auto aoff2 = [&](int ks, int rb) { return (unsigned)((((RBW * w + (rb % RBW)) * KS2 + ks) * 2 + rb / RBW) * 1024); };
 
+    BF16_PHASE(0)
     // ---- stage the tiles: thread (frame row f, channel group cg).  ALL loads of the main pass (64 x + 48 cond per
     //      thread; no accumulator is live yet) are issued before the first one is consumed: one memory round trip instead
     //      of one per 32-channel batch; the per-utterance step offsets d[256] go through LDS (one load per channel per
     //      block instead of one per element).  Loads are unconditional on clamped addresses, selects after.
-    float *dsh = reinterpret_cast<float *>(lds + XROWS * XR + FNT * CR);  // [256]
     {
-        const int f = tid & 127, cg = __builtin_amdgcn_readfirstlane(tid >> 7);  // cg 0..3 (two waves each)
+        const int f = tid % NT, cg = __builtin_amdgcn_readfirstlane(tid / NT);  // cg 0..3
         if (tid < FC) dsh[tid] = buf_load(rd, 0u, (unsigned)tid * 4u * (unsigned)a.d_cs);
         const int t = t0 - d + f;           // x row j = f
         const bool tvx = t >= 0 && t < T;
@@ -216,9 +269,9 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_fwd_bf16_kernel(SetDiffn
             for (int e = 0; e < 4; ++e) u[e] = tvc ? pack2(vc[8 * q + 2 * e], vc[8 * q + 2 * e + 1]) : 0u;
             *reinterpret_cast<u32x4_t *>(cs + f * CR + (48 * cg + 8 * q) * 2) = u;
         }
-        // halo rows j = 128 .. 128 + 2d - 1: only the first 2d lanes of each channel group have one
+        // halo rows j = NT .. NT + 2d - 1: only the first 2d lanes of each channel group have one
         if (f < 2 * d) {
-            const int j = FNT + f, th = t0 - d + j;
+            const int j = NT + f, th = t0 - d + j;
             const bool tvh = th >= 0 && th < T;
             const unsigned voh = 4u * (unsigned)min(max(th, 0), T - 1);
             float vh[64];
@@ -234,103 +287,120 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_fwd_bf16_kernel(SetDiffn
             }
         }
     }
-    // ---- accumulators start at the biases (b_dil + b_cond): row of register r = rowbase + urow(r) + 4 half
-    f32x16 acc[2][4];
+    // ---- accumulators start at the biases (b_dil + b_cond): row of register r = row0(rb) + urow(r) + 4 half
+    f32x16 acc[2 * RBW][NCB];
     const unsigned lb = 16u * (unsigned)half;  // byte offset of the lane's 4-row group
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < 2 * RBW; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const unsigned ur = (unsigned)((rb ? FC : 0) + 32 * w + urow(r));
+            const unsigned ur = (unsigned)(row0(rb) + urow(r));
             const float bias = buf_load(rbd, lb, 4u * ur) + buf_load(rbc, lb, 4u * ur);
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[rb][cb][r] = bias;
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = bias;
         }
     __syncthreads();
+    BF16_PHASE(1)
 
     // ---- GEMM 1: y = [Wcond | Wdil tap 0 | tap 1 | tap 2] x [cond ; x+d shifted]
-    gemm_bf16<2, 4>(acc, rw1, lane16, 0, KS_C, lds, [&](int ks, int cb) {
+    gemm_bf16_a<2 * RBW, NCB>(acc, rw1, lane16, KS_C, lds, aoff1, [&](int ks, int cb) {
         return (unsigned)(XROWS * XR + (cb * 32 + l31) * CR + (ks * 16 + half * 8) * 2);
     });
-    gemm_bf16<2, 4>(acc, rw1, lane16, KS_C, 3 * KS_T, lds, [&](int ks, int cb) {
+    gemm_bf16_a<2 * RBW, NCB>(acc, rw1, lane16, 3 * KS_T, lds, [&](int ks, int rb) { return aoff1(KS_C + ks, rb); },
+                              [&](int ks, int cb) {
         const int tap = ks >> 4, c0 = (ks & 15) * 16;
         return (unsigned)((cb * 32 + l31 + tap * d) * XR + (c0 + half * 8) * 2);
     });
 
-    // ---- gate (lane-local: acc[0] = gate rows, acc[1] = filter rows); save y and z in bf16; z tile over the x tile
-    bool tv[4];
-    unsigned vo4[4], vo2[4];
+    BF16_PHASE(2)
+    // ---- gate (lane-local: rb < RBW gate rows, rb + RBW the matching filter rows); save y and z in bf16; z tile over the x tile
+    bool tv[NCB];
+    unsigned vo4[NCB], vo2[NCB];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
         const int t = t0 + cb * 32 + l31;
         tv[cb] = t < T;
         vo4[cb] = 4u * (unsigned)(4 * half * T + min(t, T - 1));
         vo2[cb] = 2u * (unsigned)(4 * half * T + min(t, T - 1));
     }
     // residual rows of x for GEMM 2's accumulator start: issued here, consumed after the gate (hidden under it)
-    float xres[4][16];
+    float xres[RBW][NCB][16];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int q = 0; q < RBW; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xres[cb][r] = buf_load(rx, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xres[q][cb][r] = buf_load(rx, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
     __syncthreads();  // every wave is done reading the x tile
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int q = 0; q < RBW; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float yg = acc[0][cb][r], yf = acc[1][cb][r];
-            const float z = tv[cb] ? fsig(yg) * ftanh(yf) : 0.0f;
-            const unsigned ur = (unsigned)(32 * w + urow(r));
-            const unsigned short zb = f2bf(z);
-            if constexpr (TRAIN) {
-                if (tv[cb]) {
-                    buf_store_u16(f2bf(yg), ry, vo2[cb], ur * T2);
-                    buf_store_u16(f2bf(yf), ry, vo2[cb], (ur + FC) * T2);
-                    buf_store_u16(zb, rz, vo2[cb], ur * T2);
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float yg = acc[q][cb][r], yf = acc[RBW + q][cb][r];
+                const float z = tv[cb] ? fsig(yg) * ftanh(yf) : 0.0f;
+                const unsigned ur = (unsigned)(row0(q) + urow(r));
+                const unsigned short zb = f2bf(z);
+                if constexpr (TRAIN) {
+                    if (tv[cb]) {
+                        buf_store_u16(f2bf(yg), ry, vo2[cb], ur * T2);
+                        buf_store_u16(f2bf(yf), ry, vo2[cb], (ur + FC) * T2);
+                        buf_store_u16(zb, rz, vo2[cb], ur * T2);
+                    }
                 }
+                *reinterpret_cast<unsigned short *>(xs + (cb * 32 + l31) * XR + (row0(q) + urow(r) + 4 * half) * 2) = zb;
             }
-            *reinterpret_cast<unsigned short *>(xs + (cb * 32 + l31) * XR + (32 * w + urow(r) + 4 * half) * 2) = zb;
-        }
     // ---- accumulators of GEMM 2: residual rows start at x + b_out, skip rows at b_out (the running skip sum is added in
     //      the epilogue, after the x' stores are in flight)
     const bool first = a.first != 0;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < 2 * RBW; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const unsigned ur = (unsigned)(32 * w + urow(r));
-            const float bias = buf_load(rbo, lb, 4u * (ur + (rb ? FC : 0)));
+            const float bias = buf_load(rbo, lb, 4u * (unsigned)(row0(rb) + urow(r)));
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[rb][cb][r] = rb == 0 ? bias + xres[cb][r] : bias;
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = rb < RBW ? bias + xres[rb % RBW][cb][r] : bias;
         }
     __syncthreads();
+    BF16_PHASE(3)
 
     // ---- GEMM 2: o = Wout z
-    gemm_bf16<2, 4>(acc, rw2, lane16, 0, KS2, lds, [&](int ks, int cb) {
+    gemm_bf16_a<2 * RBW, NCB>(acc, rw2, lane16, KS2, lds, aoff2, [&](int ks, int cb) {
         return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2);
     });
 
+    BF16_PHASE(4)
     // ---- epilogue: x' stores first (they need nothing), then the running skip sum is fetched and updated
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        if (tv[cb]) {
+    for (int q = 0; q < RBW; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) buf_store(acc[0][cb][r] * RSQRT2, rxo, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+        for (int cb = 0; cb < NCB; ++cb) {
+            if (tv[cb]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) buf_store(acc[q][cb][r] * RSQRT2, rxo, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
+            }
         }
-    }
-    float sk[4][16];
+    float sk[RBW][NCB][16];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int q = 0; q < RBW; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        if (tv[cb]) {
+            for (int r = 0; r < 16; ++r) sk[q][cb][r] = buf_load(rsk, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                buf_store(first ? acc[1][cb][r] : acc[1][cb][r] + sk[cb][r], rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+    for (int q = 0; q < RBW; ++q)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            if (tv[cb]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    buf_store(first ? acc[RBW + q][cb][r] : acc[RBW + q][cb][r] + sk[q][cb][r], rsk, vo4[cb],
+                              (unsigned)(row0(q) + urow(r)) * T4);
+            }
         }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BF16_PHASE(5)
 }
 
 
@@ -592,18 +662,31 @@ extern "C" int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, v
                     ((a.y16 != nullptr) == (a.z16 != nullptr)), "set_diffnet_layer_fwd_bf16");
     SET_REQUIRE(a.B > 0 && a.T > 0 && a.dil >= 1 && a.dil <= 8, "set_diffnet_layer_fwd_bf16");
     SET_REQUIRE((int64_t)2 * FC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_layer_fwd_bf16 (T too large)");
-    const size_t ldsz = (size_t)(FNT + 2 * a.dil) * XR + (size_t)FNT * CR + FC * sizeof(float);
+    // tile width: 64 frames (4 waves, two blocks per CU) unless SET_AMD_BF16_TILE=128 (8 waves, one block per CU)
+    static int tile = 0;
+    if (!tile) { const char *e = getenv("SET_AMD_BF16_TILE"); tile = (e && atoi(e) == 128) ? 128 : 64; }
     static bool attr_set = false;
     if (!attr_set) {
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel<true>),
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel<true, 128>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layer fwd bf16 attr");
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel<false>),
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel<false, 128>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layer fwd bf16 attr");
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel<true, 64>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "layer fwd bf16 attr");
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel<false, 64>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "layer fwd bf16 attr");
         attr_set = true;
     }
-    dim3 grid((a.T + FNT - 1) / FNT, a.B);
-    if (a.y16) hipLaunchKernelGGL(diffnet_layer_fwd_bf16_kernel<true>, grid, dim3(512), ldsz, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(diffnet_layer_fwd_bf16_kernel<false>, grid, dim3(512), ldsz, (hipStream_t)stream, a);
+    const size_t ldsz = (size_t)(tile + 2 * a.dil) * XR + (size_t)tile * CR + FC * sizeof(float);
+    dim3 grid((a.T + tile - 1) / tile, a.B);
+    hipStream_t st = (hipStream_t)stream;
+    if (tile == 128) {
+        if (a.y16) hipLaunchKernelGGL((diffnet_layer_fwd_bf16_kernel<true, 128>), grid, dim3(512), ldsz, st, a);
+        else hipLaunchKernelGGL((diffnet_layer_fwd_bf16_kernel<false, 128>), grid, dim3(512), ldsz, st, a);
+    } else {
+        if (a.y16) hipLaunchKernelGGL((diffnet_layer_fwd_bf16_kernel<true, 64>), grid, dim3(256), ldsz, st, a);
+        else hipLaunchKernelGGL((diffnet_layer_fwd_bf16_kernel<false, 64>), grid, dim3(256), ldsz, st, a);
+    }
     return set_check_launch("set_diffnet_layer_fwd_bf16");
 }
 
@@ -646,4 +729,11 @@ extern "C" int set_diffnet_layer_bwd_reduce(const float *part_dbo, const float *
     hipLaunchKernelGGL(layer_bwd_reduce_kernel, dim3(20, B), dim3(256), 0, (hipStream_t)stream, part_dbo, part_dby, part_dd, B,
                        tiles, db_out, db_dil, db_cond, dd, dd_bs);
     return set_check_launch("set_diffnet_layer_bwd_reduce");
+}
+
+// debug hook (tools/bf16_phase_probe.py): block (1, 1), thread 0 of the layer kernels stores s_memtime at its phase
+// boundaries into buf[0..7]; NULL switches it off.  Not part of the product path.
+extern "C" int set_debug_bf16_phase_buffer(uint64_t *buf) {
+    SET_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bf16_phase_buf), &buf, sizeof(buf)), "set_debug_bf16_phase_buffer");
+    return SET_OK;
 }
