@@ -61,10 +61,10 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.xavier_uniform_(self.out_proj.weight)
         H = embed_dim
-        self._w_qkv = ops.ConvWeight(lambda: self.in_proj_weight, 3 * H, H, 1)
-        self._w_q = ops.ConvWeight(lambda: self.in_proj_weight, H, H, 1)
-        self._w_kv = ops.ConvWeight(lambda: self.in_proj_weight, 2 * H, H, 1, base=H * H)
-        self._w_out = ops.ConvWeight(lambda: self.out_proj.weight, H, H, 1)
+        self._w_qkv = ops.ConvWeight((self, "in_proj_weight"), 3 * H, H, 1)
+        self._w_q = ops.ConvWeight((self, "in_proj_weight"), H, H, 1)
+        self._w_kv = ops.ConvWeight((self, "in_proj_weight"), 2 * H, H, 1, base=H * H)
+        self._w_out = ops.ConvWeight((self, "out_proj.weight"), H, H, 1)
 
     def self_attn(self, h, res, key_padding=None, mask=None):
         """(res + out_proj(attention(h))) (* mask).  torch's multi_head_attention_forward path: -inf padding fill."""
@@ -94,8 +94,8 @@ class TransformerFFNLayer(nn.Module):
         self.ffn_1 = conv if padding == "SAME" else nn.Sequential(nn.Identity(), conv)
         self.ffn_2 = nn.Linear(filter_size, hidden_size)
         object.__setattr__(self, "_conv", conv)  # plain reference: the parameters are registered once, under ffn_1
-        self._w1 = ops.ConvWeight(lambda: self._conv.weight, filter_size, hidden_size, kernel_size)
-        self._w2 = ops.ConvWeight(lambda: self.ffn_2.weight, hidden_size, filter_size, 1)
+        self._w1 = ops.ConvWeight((self, "_conv.weight"), filter_size, hidden_size, kernel_size)
+        self._w2 = ops.ConvWeight((self, "ffn_2.weight"), hidden_size, filter_size, 1)
 
     def run(self, h, res, mask=None):
         F = _backend()
@@ -237,8 +237,8 @@ class CampNet(nn.Module):
         self.mel_out_coarse = nn.Linear(H, self.out_dims, bias=False)
         self.mel_out_fine = nn.Linear(H, self.out_dims, bias=False)
         self.mask_emb = nn.Parameter(torch.zeros(1, 1, 80))
-        self._w_coarse = ops.ConvWeight(lambda: self.mel_out_coarse.weight, self.out_dims, H, 1)
-        self._w_fine = ops.ConvWeight(lambda: self.mel_out_fine.weight, self.out_dims, H, 1)
+        self._w_coarse = ops.ConvWeight((self, "mel_out_coarse.weight"), self.out_dims, H, 1)
+        self._w_fine = ops.ConvWeight((self, "mel_out_fine.weight"), self.out_dims, H, 1)
 
     def forward(self, txt_tokens, spk_embed=None, spk_id=None, mels=None, stutter_mel_masks=None, time_mel_masks=None,
                 infer=False, global_step=None, *args, **kwargs):

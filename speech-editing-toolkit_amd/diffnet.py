@@ -32,10 +32,10 @@ class ResidualBlock(nn.Module):
         self.conditioner_projection = _kaiming_conv1d(encoder_hidden, 2 * C, 1)
         self.output_projection = _kaiming_conv1d(C, 2 * C, 1)
         H = encoder_hidden
-        self._w_dil = ops.ConvWeight(lambda: self.dilated_conv.weight, 2 * C, C, 3)
-        self._w_dproj = ops.ConvWeight(lambda: self.diffusion_projection.weight, C, C, 1)
-        self._w_cond = ops.ConvWeight(lambda: self.conditioner_projection.weight, 2 * C, H, 1)
-        self._w_out = ops.ConvWeight(lambda: self.output_projection.weight, 2 * C, C, 1)
+        self._w_dil = ops.ConvWeight((self, "dilated_conv.weight"), 2 * C, C, 3)
+        self._w_dproj = ops.ConvWeight((self, "diffusion_projection.weight"), C, C, 1)
+        self._w_cond = ops.ConvWeight((self, "conditioner_projection.weight"), 2 * C, H, 1)
+        self._w_out = ops.ConvWeight((self, "output_projection.weight"), 2 * C, C, 1)
         self._fused = None
         self._fused_key = None
 
@@ -68,11 +68,11 @@ class DiffNet(nn.Module):
         self.skip_projection = _kaiming_conv1d(C, C, 1)
         self.output_projection = _kaiming_conv1d(C, in_dims, 1)
         nn.init.zeros_(self.output_projection.weight)
-        self._w_in = ops.ConvWeight(lambda: self.input_projection.weight, C, in_dims, 1)
-        self._w_mlp0 = ops.ConvWeight(lambda: self.mlp[0].weight, 4 * C, C, 1)
-        self._w_mlp2 = ops.ConvWeight(lambda: self.mlp[2].weight, C, 4 * C, 1)
-        self._w_skip = ops.ConvWeight(lambda: self.skip_projection.weight, C, C, 1)
-        self._w_outp = ops.ConvWeight(lambda: self.output_projection.weight, in_dims, C, 1)
+        self._w_in = ops.ConvWeight((self, "input_projection.weight"), C, in_dims, 1)
+        self._w_mlp0 = ops.ConvWeight((self, "mlp.0.weight"), 4 * C, C, 1)
+        self._w_mlp2 = ops.ConvWeight((self, "mlp.2.weight"), C, 4 * C, 1)
+        self._w_skip = ops.ConvWeight((self, "skip_projection.weight"), C, C, 1)
+        self._w_outp = ops.ConvWeight((self, "output_projection.weight"), in_dims, C, 1)
         self.impl = "auto"  # auto | fused | unfused  (unfused = generic kernels; device-side cross-check)
         self._packs, self._packs_key = None, None
 

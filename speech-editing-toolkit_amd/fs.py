@@ -36,7 +36,7 @@ def _cw(conv_or_linear):
         cout, cin, k = w.shape
     else:
         (cout, cin), k = w.shape, 1
-    return ops.ConvWeight(lambda: conv_or_linear.weight, cout, cin, k)
+    return ops.ConvWeight((conv_or_linear, "weight"), cout, cin, k)
 
 
 class ResidualBlock(nn.Module):

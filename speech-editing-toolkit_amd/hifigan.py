@@ -48,7 +48,7 @@ class _WNConv:
         w = self.folded()
         if self._cw is None:
             cout, cin, k = w.shape
-            self._cw = ops.ConvWeight(lambda: self._w, cout, cin, k)
+            self._cw = ops.ConvWeight((self, "_w"), cout, cin, k)
         return self._cw
 
 
@@ -132,7 +132,7 @@ class HifiGanGenerator(nn.Module):
             cin, cout, k, u, P = self._up_cfg[i]
             up = self._ups[i]
             up.folded()
-            x = ops.conv_transpose1d(x, lambda up=up: up._w, self.ups[i].bias.data, cin, cout, k, u, P,
+            x = ops.conv_transpose1d(x, (up, "_w"), self.ups[i].bias.data, cin, cout, k, u, P,
                                      pro="lrelu", pro_param=LRELU_SLOPE, cache=up._phases)
             # MRF (hifigan.py:131-137): xs = rb_0(x); xs += rb_j(x) ...; x = xs / num_kernels.  The running sum lives in
             # the epilogue of each ResBlock's final conv (first block stores, the others accumulate, the last one also

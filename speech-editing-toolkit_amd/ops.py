@@ -96,7 +96,10 @@ class ConvWeight:
     [Cin,Cout,k] (base=p, sco=k, sci=Cout*k, stap=u)."""
 
     def __init__(self, getter, Cout, Cin, K, base=0, sco=None, sci=None, stap=1):
-        self._getter = getter if callable(getter) else (lambda: getter)
+        # `getter`: (owner, "attr.path") -- the weight is looked up on the owner at every use, so a deepcopy / pickle of
+        # the model (EMA or teacher copies) follows its own parameters (a closure over the original module would keep
+        # computing with the original's weights); a callable or a tensor is accepted too.
+        self._getter = getter
         self.Cout, self.Cin, self.K = int(Cout), int(Cin), int(K)
         self.base = int(base)
         self.sco = int(sco if sco is not None else Cin * K)
@@ -107,8 +110,17 @@ class ConvWeight:
         self._packed2 = {}
         self._packed16 = None
 
+    def _resolve(self):
+        g = self._getter
+        if isinstance(g, tuple):
+            obj = g[0]
+            for name in g[1].split("."):
+                obj = getattr(obj, name)
+            return obj
+        return g() if callable(g) else g
+
     def raw(self):
-        return _f(self._getter(), "weight")
+        return _f(self._resolve(), "weight")
 
     def transposed(self):
         """W'[ci][co][tap] = W[co][ci][tap]: the weight operand of the input-gradient convolution."""
@@ -270,10 +282,24 @@ def layernorm_ch(x, gamma, beta, mask=None, eps=1e-5, out=None):
     return out
 
 
+_VALIDATE = os.environ.get("SET_AMD_VALIDATE", "0") == "1"
+
+
+def set_validate(on):
+    """Host-side range checks of index tensors before the kernels that would otherwise clamp them (one device->host
+    read per call: a debugging aid, off by default; `--validate` / `--debug` runs switch it on)."""
+    global _VALIDATE
+    _VALIDATE = bool(on)
+
+
 def embedding_bct(idx, table, scale=1.0, out=None, accumulate=False, padding_idx=None):
     _i(idx), _f(table)
     B, T = idx.shape
     n_rows, Cc = table.shape
+    if _VALIDATE and idx.numel() > 0:
+        lo, hi = int(idx.min().item()), int(idx.max().item())
+        if lo < 0 or hi >= n_rows:  # nn.Embedding raises here; the kernel clamps for memory safety only
+            raise IndexError("embedding index out of range: [%d, %d] for a table of %d rows" % (lo, hi, n_rows))
     if out is None:
         assert not accumulate
         out = torch.empty(B, Cc, T, dtype=torch.float32, device=table.device)

@@ -270,6 +270,8 @@ class SpeechDenoiserTask:
         import random
         import numpy as np
         from .trainer import Trainer
+        if hparams.get("validate") or hparams.get("debug"):
+            ops.set_validate(True)  # index range checks before every embedding lookup (a wrong dictionary size fails loudly)
         random.seed(hparams.get("seed", 1234))
         np.random.seed(hparams.get("seed", 1234))
         trainer = Trainer(work_dir=hparams.get("work_dir") or "checkpoints/tmp",

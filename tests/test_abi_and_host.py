@@ -278,3 +278,35 @@ def test_phone_set_json_follows_the_reference_token_encoder(tmp_path):
     finally:
         H.hparams.clear()
         H.hparams.update(saved)
+
+
+def test_conv_weights_follow_a_deepcopy_of_the_model():
+    """a ConvWeight looks its tensor up on the owning module at every use, so copy.deepcopy(model) (EMA /
+    teacher copies) computes with the COPY's parameters, and the model pickles."""
+    import copy
+    import pickle
+    from set_amd.diffnet import DiffNet
+    dn = DiffNet(80, base_hparams(residual_layers=2))
+    cp = copy.deepcopy(dn)
+    with torch.no_grad():
+        cp.residual_layers[0].dilated_conv.weight.add_(1.0)
+        cp.mlp[0].weight.add_(1.0)
+    for a, b in ((dn, cp),):
+        assert a.residual_layers[0]._w_dil._resolve() is a.residual_layers[0].dilated_conv.weight
+        assert b.residual_layers[0]._w_dil._resolve() is b.residual_layers[0].dilated_conv.weight
+        assert b._w_mlp0._resolve() is b.mlp[0].weight
+    assert not torch.equal(dn.residual_layers[0]._w_dil._resolve(), cp.residual_layers[0]._w_dil._resolve())
+    assert cp.residual_layers[0]._w_dil.transposed()._resolve() is cp.residual_layers[0].dilated_conv.weight
+    rt = pickle.loads(pickle.dumps(dn))
+    assert rt.residual_layers[1]._w_out._resolve() is rt.residual_layers[1].output_projection.weight
+
+
+def test_embedding_validation_is_a_host_side_switch():
+    from set_amd import ops
+    assert ops._VALIDATE is False
+    ops.set_validate(True)
+    try:
+        with pytest.raises((IndexError, RuntimeError)):  # RuntimeError: no GPU here -- the range check comes first on a GPU box
+            ops.embedding_bct(torch.tensor([[0, 99]]), torch.zeros(80, 4))
+    finally:
+        ops.set_validate(False)
