@@ -228,7 +228,7 @@ int set_pack_diffnet_layer(const float *w_dil, const float *w_out, float *w1p, f
  * release/acquire), so no CU idles at layer boundaries (a 416-tile layer does not divide over 256 CUs).
  * Tiles are 64 frames when a layer has >= 3 x #CU of them, else 32 frames (keeps runnable tasks > workers).
  * Layer l reads (l even ? xa : xb) and writes the other buffer; skip accumulates in place; results are
- * bit-identical to L calls of set_diffnet_layer.  sync_ws: >= 4 + B*ceil(T/32) int32, zeroed by the call;
+ * bit-identical to L calls of set_diffnet_layer.  sync_ws: >= 16 + 2*B*ceil(T/32) int32, zeroed by the call;
  * sync_ws[1] != 0 afterwards means a dependency wait timed out (SET_E_LAUNCH is NOT raised asynchronously). */
 typedef struct SetDiffnetStackArgs {
     float *xa, *xb, *skip;        /* [B][256][T] each */
@@ -256,13 +256,21 @@ typedef struct SetDiffnetStackArgs {
     /* optional sticky error word (never cleared by the library): set to 1 if a dependency wait ran into its spin
      * limit and the launch gave up (sync_ws[1] says the same for the last launch only) */
     int32_t *err_flag;
+    /* optional, small batches (4*B*ceil(T/32) <= 2 x #CU): row-split images [L][512*768] / [L][512*256] in the layout
+     * [32-row block v = 4w + rb][k-step][lane] (the same values as w1p_all / w2p_all, which are [w][k-step][lane][rb])
+     * plus a workspace z_ws of B*ceil(T/32)*256*32 floats.  Every 32-frame tile is then computed by four co-operating
+     * blocks (one 32-row block per wave), bit-identical to the direct kernels.  SET_AMD_SPLIT=0 disables it. */
+    const float *w1s_all;
+    const float *w2s_all;
+    float *z_ws;
 } SetDiffnetStackArgs;
 int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream);
 int64_t set_sizeof_diffnet_stack_args(void);
 
 /* which kernel set_diffnet_stack picks for this shape on the current device: 0 direct/64-frame tiles,
- * 1 direct/32-frame tiles, 2 Winograd (diagnostics: bench.py names the kernel in its roofline object) */
-int set_diffnet_stack_variant(int B, int T, int dilation_cycle_length, int have_wino_images);
+ * 1 direct/32-frame tiles, 2 Winograd, 3 row-split (diagnostics: bench.py names the kernel in its roofline object);
+ * images: bit 0 = Winograd images given, bit 1 = row-split images + z_ws given */
+int set_diffnet_stack_variant(int B, int T, int dilation_cycle_length, int images);
 int64_t set_diffnet_w1w_size(void);
 int set_pack_diffnet_layer_wino(const float *w_dil, const float *w_out, float *w1w, float *w2w, void *stream);
 
@@ -304,6 +312,9 @@ typedef struct SetDiffLoopArgs {
     const float *b_out_all; /* [L][512] */
     const float *w1w_all;   /* optional Winograd images (see SetDiffnetStackArgs), used by the persistent path */
     const float *w2w_all;
+    const float *w1s_all;   /* optional row-split images + workspace (see SetDiffnetStackArgs), small batches */
+    const float *w2s_all;
+    float *z_ws;
     const float *w_skip_p; /* skip_projection packed */
     const float *b_skip;
     const float *w_outp_p; /* output_projection packed (Cout M, Cin 256) */
@@ -321,7 +332,7 @@ typedef struct SetDiffLoopArgs {
      * group's layer launch overlaps the next layer of another group.  Results are bit-identical for any n_groups. */
     int32_t n_groups;
     /* persistent != 0: run the L layers of every step as one set_diffnet_stack launch (needs sync_ws,
-     * >= 32 + B*ceil(T/32) int32); 0: one set_diffnet_layer launch per layer */
+     * >= 160 + 2*B*ceil(T/32) int32); 0: one set_diffnet_layer launch per layer */
     int32_t persistent;
     int32_t *sync_ws;
     int32_t *err_flag; /* optional sticky error word, see SetDiffnetStackArgs.err_flag */
@@ -385,6 +396,10 @@ int set_pack_diffnet_layer_bf16(const float *wdil /*[512][256][3]*/, const float
 int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, void *stream);
 /* debug: block (1,1) of the bf16 layer kernels stamps s_memtime at its phase boundaries into buf[0..7] (NULL = off) */
 int set_debug_bf16_phase_buffer(uint64_t *buf);
+/* debug: lane 0 of one block (tile 1, part 1) of the row-split stack kernel ADDS the s_memtime ticks it spends in each of
+ * its 8 phases (wait for the previous layer, stage, GEMM 1, gate + z publish, wait for z, z load, GEMM 2, epilogue +
+ * publish), summed over the layers, to buf[0..7] (NULL = off) */
+int set_debug_split_phase_buffer(uint64_t *buf);
 
 typedef struct SetDiffnetLayerBf16BwdArgs {
     const float *dx_out; /* [B][256][T] gradient w.r.t. x_out; NULL = zero (the last layer's x_out feeds nothing) */

@@ -65,6 +65,7 @@ class SetDiffLoopArgs(C.Structure):
         ("w_in_p", C.c_void_p), ("b_in", C.c_void_p),
         ("w1p_all", C.c_void_p), ("w2p_all", C.c_void_p), ("b_dil_all", C.c_void_p), ("b_out_all", C.c_void_p),
         ("w1w_all", C.c_void_p), ("w2w_all", C.c_void_p),
+        ("w1s_all", C.c_void_p), ("w2s_all", C.c_void_p), ("z_ws", C.c_void_p),
         ("w_skip_p", C.c_void_p), ("b_skip", C.c_void_p), ("w_outp_p", C.c_void_p), ("b_outp", C.c_void_p),
         ("ws_x0", C.c_void_p), ("ws_x1", C.c_void_p), ("ws_skip", C.c_void_p), ("ws_h", C.c_void_p),
         ("ws_x0pred", C.c_void_p),
@@ -88,6 +89,7 @@ class SetDiffnetStackArgs(C.Structure):
         ("w1w_all", C.c_void_p), ("w2w_all", C.c_void_p),
         ("x_all", C.c_void_p), ("save_y", C.c_void_p), ("save_z", C.c_void_p),
         ("err_flag", C.c_void_p),
+        ("w1s_all", C.c_void_p), ("w2s_all", C.c_void_p), ("z_ws", C.c_void_p),
     ]
 
 
@@ -190,6 +192,7 @@ SIGNATURES = {
     "set_pack_diffnet_layer_bf16": (C.c_int, [_V, _V, _V, _V, _V]),
     "set_diffnet_layer_fwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayerBf16Args), _V]),
     "set_debug_bf16_phase_buffer": (C.c_int, [_V]),
+    "set_debug_split_phase_buffer": (C.c_int, [_V]),
     "set_sizeof_diffnet_layer_bf16_bwd_args": (_I64, []),
     "set_diffnet_layer_bwd_bf16_tiles": (_I32, [_I32, _I32]),
     "set_diffnet_layer_bwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayerBf16BwdArgs), _V]),

@@ -611,6 +611,236 @@ __global__ void __launch_bounds__(256, WPS) diffnet_stack_kernel(SetDiffnetStack
     }
 }
 
+// ---- small batches: every 32-frame tile split over FOUR co-operating blocks ---------------------------------------
+// With a handful of utterances a layer has fewer tiles than the chip has CUs (B = 1, T = 800: 25 tiles on 256 CUs) and
+// the time of a layer is the time of ONE tile on ONE CU: 4 row blocks x 512 MFMAs per SIMD.  Here block (tile i, part h)
+// does the work of wave h of layer_tile<1>, one 32-row block per wave (wave j < 2: gate rows 64h + 32j.., then residual
+// rows; j >= 2: the matching filter rows, then skip rows), i.e. a quarter of the MFMA chain per SIMD on four times as
+// many CUs.  Blocks are bound to their (tile, part) for all L layers (grid = 4 x tiles, all co-resident) and meet twice
+// per layer through agent-scope counters:
+//   zcnt[i]  += 1 once the part's gated rows z[64h .. 64h+63] are stored (agent-scope write-through) to the tile's slot
+//               of z_ws; GEMM 2 of every part reads all 256 rows after zcnt[i] reached 4 (l + 1);
+//   ready[i] += 1 once the part's rows of x' are stored; layer l + 1 of tiles i-1, i, i+1 starts at ready >= 4 (l + 1).
+// Every output element sees the same accumulation chain as in layer_tile (same initial value, same k order), the gate
+// is the same product of the same two values (the tanh factor crosses from the filter wave to the gate wave through
+// LDS): results are bit-identical to the direct kernels.  Weight images: one float per lane per k-step and 32-row block
+// ([16][KS][64], set_diffnet_stack's w1s_all / w2s_all).
+constexpr int SP_XW = 32 + 2 * WN_MAXD;      // widest x tile (d = 8)
+constexpr int SP_LDS_FLOATS = DC * SP_XW + 64 * 32 + 4;
+constexpr unsigned SP_SPIN_LIMIT = 1u << 20;  // polls of ~1 us each (two agent-scope loads + s_sleep(1)): ~1-2 s
+
+// GEMM of the row-split kernel: ONE 32x32 accumulator per wave, so one MFMA (64 cycles) per k-step and nothing else in
+// the wave to hide operand latency behind.  The weight images are cold in L2 at every layer (2 MiB per layer, read once per
+// XCD), i.e. A comes from the memory side at ~1.5-2 us: A is prefetched 64 k-steps ahead (two sets of 64 registers,
+// ping-pong; the first set is loaded by split_preload BEFORE the inter-block wait that precedes the GEMM), B (LDS) 4 ahead.
+//   A k-step ks: wp[ks * 64];  B k-step ks: *bq, bq += rstep per k-step, += tap_jump after every 128th (next conv tap)
+__device__ __forceinline__ void split_preload(float (&A)[64], const float *wp) {
+#pragma unroll
+    for (int u = 0; u < 64; ++u) A[u] = wp[u * 64];
+}
+
+template <int KS>
+__device__ __forceinline__ void split_gemm(f32x16 &acc, const float *wp, float (&Ap)[64], const float *bq, int rstep,
+                                           int tap_jump) {
+    static_assert(KS % 128 == 0, "two 64-k-step sets per iteration");
+    float Aq[64], Bv[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        Bv[u] = *bq;
+        bq += rstep;
+    }
+    for (int g = 0; g < KS / 64; g += 2) {
+        const float *wq = wp + (int64_t)(g + 1) * 64 * 64;
+#pragma unroll
+        for (int u = 0; u < 64; ++u) {  // k-steps 64 g + u (g even: no tap boundary among the B prefetches of this half)
+            Aq[u] = wq[u * 64];
+            Bv[(u + 4) & 7] = *bq;
+            bq += rstep;
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma32(Ap[u], Bv[u & 7], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float *wn = wp + (int64_t)(g + 2 < KS / 64 ? g + 2 : g) * 64 * 64;  // last pair: harmless re-load
+#pragma unroll
+        for (int u = 0; u < 64; ++u) {  // k-steps 64 (g + 1) + u; the prefetch of k-step 64 (g + 2) starts the next tap
+            Ap[u] = wn[u * 64];
+            Bv[(u + 4) & 7] = *bq;  // (past the last k-step: a harmless read inside the tile)
+            bq += rstep;
+            if (u == 59) bq += tap_jump;
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma32(Aq[u], Bv[u & 7], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// debug: lane 0 of block (tile 1, part 1) adds the s_memtime ticks of its phases, summed over the layers, to buf[0..7]
+__device__ uint64_t *g_split_phase_buf = nullptr;
+
+// lane 0 of the block: wait until all three counters reach `want`; false = gave up (spin limit or another block aborted)
+__device__ __forceinline__ bool split_wait(const int *f0, const int *f1, const int *f2, int want, int *abort_flag,
+                                           int *err_flag) {
+    unsigned spins = 0;
+    for (;;) {
+        const int v0 = ld_agent(f0), v1 = ld_agent(f1), v2 = ld_agent(f2);
+        if (min(v0, min(v1, v2)) >= want) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > SP_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
+            __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (err_flag) __hip_atomic_store(err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
+__global__ void __launch_bounds__(256, 2) diffnet_stack_split_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles,
+                                                                    int fault_tile) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // x tile [256][32 + 2d]; the z tile [256][32] overlays it
+    float *gs = smem + DC * SP_XW;                                // [64][32] tanh(filter rows) of this part
+    int *s_ok = reinterpret_cast<int *>(gs + 64 * 32);
+    int *abort_flag = a.sync_ws + 1, *ready = a.sync_ws + 4, *zcnt = a.sync_ws + 4 + ntiles;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const int b = i / tiles_per_utt, jt = i - b * tiles_per_utt;
+    const int T = a.T, t0 = jt * 32;
+    const int il = jt > 0 ? i - 1 : i, ir = jt < tiles_per_utt - 1 ? i + 1 : i;
+    const unsigned T4 = 4u * (unsigned)T;
+    const unsigned lo = 4u * (unsigned)(4 * half * T + min(t0 + l31, T - 1));  // per-lane byte offset, clamped
+    const bool tv = t0 + l31 < T;
+    const unsigned lb = 16u * (unsigned)half;
+    const rsrc_t rz = make_rsrc(a.z_ws + (int64_t)i * (DC * 32));
+    const rsrc_t rskp = make_rsrc(a.skip + (int64_t)b * DC * T);
+    const int vr = 4 * h + j;  // 32-row block of the images
+    uint64_t *dbg = (blockIdx.x == 5 && tid == 0) ? g_split_phase_buf : nullptr;
+    uint64_t tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define SP_PHASE(p)                                           \
+    if (dbg) {                                                \
+        const uint64_t tn = __builtin_amdgcn_s_memtime();     \
+        dbg[p] += tn - tprev;                                 \
+        tprev = tn;                                           \
+    }
+    for (int l = 0; l < a.L; ++l) {
+        const int dil = 1 << (l % a.dilation_cycle_length), XW = 32 + 2 * dil;
+        const rsrc_t rxin = make_rsrc(((l & 1) ? a.xb : a.xa) + (int64_t)b * DC * T);
+        const rsrc_t rxout = make_rsrc(((l & 1) ? a.xa : a.xb) + (int64_t)b * DC * T);
+        const rsrc_t rcp = make_rsrc(a.condproj + (int64_t)l * a.cp_ls + (int64_t)b * a.cp_bs);
+        const rsrc_t rbd = make_rsrc(a.b_dil_all + (int64_t)l * 512), rbo = make_rsrc(a.b_out_all + (int64_t)l * 512);
+        const float *dstep = a.dstep + (int64_t)l * a.d_ls + (int64_t)b * a.d_bs;
+        // ---- GEMM 1 accumulator = b_dil + conditioner projection: independent of the previous layer, issued before the wait
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned ur = (unsigned)layer_row(h, j, urow16(r));  // wave-uniform
+            acc[0][0][r] = buf_load(rbd, lb, 4u * ur) + buf_load(rcp, lo, ur * T4);
+        }
+        float Ap[64];  // first 64 k-steps of the wave's weight rows (cold in L2): in flight during the wait and the staging
+        const float *wp1 = a.w1s_all + (int64_t)l * (512 * 768) + (int64_t)vr * KS1 * 64 + lane;
+        split_preload(Ap, wp1);
+        if (tid == 0) *s_ok = (l == 0 || split_wait(ready + i, ready + il, ready + ir, 4 * l, abort_flag, a.err_flag)) ? 1 : 0;
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(*s_ok) == 0) return;
+        SP_PHASE(0)
+        // ---- stage x + d (wave j: channels 64j .. 64j+63; zero outside [0, T): the conv pads x + d).  All 64 row loads
+        //      of the wave are in flight at once: one memory round trip
+        {
+            const int tA = t0 - dil + lane;
+            const bool vA = tA >= 0 && tA < T, laneA = lane < XW;
+            const unsigned cA = 4u * (unsigned)min(max(tA, 0), T - 1);
+            float xa[64];
+            // step offsets d[c] of the wave's 64 channels: ONE gather (lane u <-> channel 64j + u, stride d_cs: a table
+            // column per diffusion step), broadcast per row with v_readlane -- 64 dependent scalar loads would serialise
+            const float dv = dstep[(int64_t)(64 * j + lane) * a.d_cs];
+#pragma unroll
+            for (int u = 0; u < 64; ++u) xa[u] = buf_load(rxin, cA, (unsigned)(64 * j + u) * T4);
+#pragma unroll
+            for (int u = 0; u < 64; ++u) {
+                const float dd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), u));
+                if (laneA) smem[(64 * j + u) * XW + lane] = vA ? xa[u] + dd : 0.0f;
+            }
+        }
+        __syncthreads();
+        SP_PHASE(1)
+        // ---- GEMM 1: one 32-row block of  y = Wdil (*) (x + d)
+        split_gemm<KS1>(acc[0][0], wp1, Ap, smem + half * XW + l31, 2 * XW, dil - 128 * 2 * XW);
+        SP_PHASE(2)
+        // ---- gate: the filter waves hand tanh(y_f) to the gate waves through LDS
+        if (j >= 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gs[(32 * (j - 2) + mfma32_row(r, lane)) * 32 + l31] = fast_tanh(acc[0][0][r]);
+        }
+        __syncthreads();  // gs complete; every wave is done reading the x tile
+        if (j < 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z = fast_sigmoid(acc[0][0][r]) * gs[(32 * j + mfma32_row(r, lane)) * 32 + l31];
+                buf_store_agent(tv ? z : 0.0f, rz, 4u * (unsigned)(4 * half * 32 + l31),
+                                4u * 32u * (unsigned)(64 * h + 32 * j + urow16(r)));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the z rows of this wave are visible to every XCD
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(zcnt + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SP_PHASE(3)
+        // ---- GEMM 2 accumulator = b_out + x (residual rows) / + running skip sum (skip rows): these rows were written
+        //      by this very wave one layer ago; the loads fly while lane 0 waits for the other parts' z rows
+        {
+            // rows 64h + 32(j & 1) + .. of x (gate waves) or of the skip sum (filter waves): one descriptor, no per-row branch
+            const rsrc_t rsv = make_rsrc(j < 2 ? ((l & 1) ? a.xb : a.xa) + (int64_t)b * DC * T : a.skip + (int64_t)b * DC * T);
+            float bias[16], sv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                bias[r] = buf_load(rbo, lb, 4u * (unsigned)layer_row(h, j, urow16(r)));
+                sv[r] = buf_load(rsv, lo, (unsigned)(64 * h + 32 * (j & 1) + urow16(r)) * T4);
+            }
+            if (j >= 2 && l == 0) {  // first layer: the skip sum starts here (whatever the buffer held is ignored)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] = bias[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] = bias[r] + sv[r];
+            }
+        }
+        const float *wp2 = a.w2s_all + (int64_t)l * (512 * 256) + (int64_t)vr * KS2 * 64 + lane;
+        split_preload(Ap, wp2);
+        if (tid == 0) *s_ok = split_wait(zcnt + i, zcnt + i, zcnt + i, 4 * (l + 1), abort_flag, a.err_flag) ? 1 : 0;
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(*s_ok) == 0) return;
+        SP_PHASE(4)
+        // ---- the whole z tile [256][32] (one contiguous 32 KiB slot) -> LDS, same layout
+        {
+            f32x4 zv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) zv[k] = buf_load4(rz, 16u * (unsigned)tid, 4096u * (unsigned)k);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *reinterpret_cast<f32x4 *>(smem + 4 * tid + 1024 * k) = zv[k];
+        }
+        __syncthreads();
+        SP_PHASE(5)
+        // ---- GEMM 2: one 32-row block of  o = Wout z
+        split_gemm<KS2>(acc[0][0], wp2, Ap, smem + half * 32 + l31, 64, 0);
+        SP_PHASE(6)
+        // ---- epilogue: x' = (x + o_res) / sqrt 2 (agent scope: the neighbours' next layer reads it), skip += o_skip
+        if (tv && j < 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                buf_store_agent(acc[0][0][r] * 0.70710678118654752440f, rxout, lo, (unsigned)layer_row(h, j, urow16(r)) * T4);
+        } else if (tv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                buf_store(acc[0][0][r], rskp, lo, (unsigned)(layer_row(h, j, urow16(r)) - DC) * T4);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every store of the block has completed; the LDS tile is free for the next layer
+        if (tid == 0 && !(l == 0 && i == fault_tile && h == 0))
+            __hip_atomic_fetch_add(ready + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SP_PHASE(7)
+    }
+#undef SP_PHASE
+}
+
 // Winograd flavour of the persistent kernel: 512 threads, one block per CU, 64-frame tiles.  Same queue and flags
 // as above, but each block claims its NEXT task while the current one is in GEMM 2, and issues the next task's
 // producer-independent loads (bias + conditioner projection -> accumulator init) BEFORE it waits for the producer
@@ -841,12 +1071,24 @@ extern "C" int set_diffnet_layer(const SetDiffnetLayerArgs *args, void *stream) 
     return set_check_launch("set_diffnet_layer");
 }
 
+extern "C" int set_debug_split_phase_buffer(uint64_t *buf) {
+    SET_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_split_phase_buf), &buf, sizeof(buf)), "set_debug_split_phase_buffer");
+    return SET_OK;
+}
+
 extern "C" int64_t set_sizeof_diffnet_stack_args(void) { return (int64_t)sizeof(SetDiffnetStackArgs); }
 
 // 0 = direct kernel, 64-frame tiles; 1 = direct kernel, 32-frame tiles; 2 = Winograd F(2,3) kernel (64-frame tiles,
-// 8-wave blocks, needs its packed images, dilation_cycle_length <= 4 and at least ~0.68 tiles per CU to be worth it)
-static int stack_variant(int B, int T, int dcl, bool have_wino, int n_cu) {
+// 8-wave blocks, needs its packed images, dilation_cycle_length <= 4 and at least ~0.68 tiles per CU to be worth it);
+// 3 = row-split kernel for small batches (4 blocks per 32-frame tile, needs its images and the z workspace)
+static int stack_variant(int B, int T, int dcl, bool have_wino, bool have_split, int n_cu) {
     const int64_t tiles64 = (int64_t)B * ((T + 63) / 64);
+    // row-split kernel: 4 blocks per 32-frame tile, all co-resident (2 per CU); SET_AMD_SPLIT=0 disables, =2 forces it
+    // (when it fits); an explicit SET_AMD_WINO choice also rules it out
+    const bool split_fits = have_split && dcl <= 4 && 4 * (int64_t)B * ((T + 31) / 32) <= 2 * (int64_t)n_cu;
+    int split_env = 1;
+    if (const char *e = getenv("SET_AMD_SPLIT")) split_env = atoi(e);
+    if (split_fits && (split_env == 2 || (split_env == 1 && !getenv("SET_AMD_WINO")))) return 3;
     int ncb = tiles64 < 3 * n_cu ? 1 : 2;
     if (const char *e = getenv("SET_AMD_STACK_NCB")) ncb = atoi(e) == 2 ? 2 : 1;
     const bool wino_ok = have_wino && (1 << (dcl - 1)) <= WN_MAXD;
@@ -854,10 +1096,10 @@ static int stack_variant(int B, int T, int dcl, bool have_wino, int n_cu) {
     if (const char *e = getenv("SET_AMD_WINO")) wino = wino_ok && (atoi(e) == 2 || (wino && atoi(e) != 0));  // 2 = force
     return wino ? 2 : (ncb == 1 ? 1 : 0);
 }
-extern "C" int set_diffnet_stack_variant(int B, int T, int dilation_cycle_length, int have_wino_images) {
+extern "C" int set_diffnet_stack_variant(int B, int T, int dilation_cycle_length, int images) {
     int dev = 0, n_cu = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    return stack_variant(B, T, dilation_cycle_length, have_wino_images != 0, n_cu);
+    return stack_variant(B, T, dilation_cycle_length, (images & 1) != 0, (images & 2) != 0, n_cu);
 }
 
 extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) {
@@ -872,10 +1114,11 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     static int n_cu = 0;
     static bool attr_set = false;
     if (!attr_set) {
-        const void *fns[4] = {reinterpret_cast<const void *>(diffnet_stack_kernel<1, 8, 2>),
+        const void *fns[5] = {reinterpret_cast<const void *>(diffnet_stack_kernel<1, 8, 2>),
                               reinterpret_cast<const void *>(diffnet_stack_kernel<2, 4, 2>),
                               reinterpret_cast<const void *>(diffnet_stack_wino_kernel<true>),
-                              reinterpret_cast<const void *>(diffnet_stack_wino_kernel<false>)};
+                              reinterpret_cast<const void *>(diffnet_stack_wino_kernel<false>),
+                              reinterpret_cast<const void *>(diffnet_stack_split_kernel)};
         for (const void *f : fns)
             SET_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024),
                     "set_diffnet_stack(attr)");
@@ -888,7 +1131,17 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     // runnable.  Workers (2 per CU) must stay BELOW that or the youngest ones only wait (measured: 36 % wait time
     // with 512 workers on 416 64-frame tiles).  Use 64-frame tiles when a layer has >= 1.5x the workers, else
     // 32-frame tiles (B=32, T=800: 800 tiles, no tail waste); the grid is capped at 0.8x the tile count.
-    const int variant = stack_variant(a.B, a.T, a.dilation_cycle_length, a.w1w_all && a.w2w_all, n_cu);
+    const int variant = stack_variant(a.B, a.T, a.dilation_cycle_length, a.w1w_all && a.w2w_all,
+                                      a.w1s_all && a.w2s_all && a.z_ws && !a.x_all && !a.save_y && !a.save_z, n_cu);
+    int fault_tile = -1;  // test hook: never publish this tile of layer 0 (exercises the time-out / error path)
+    if (const char *e = getenv("SET_AMD_FAULT_TILE")) fault_tile = atoi(e);
+    if (variant == 3) {
+        const int tiles = (a.T + 31) / 32, nt = a.B * tiles;
+        SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + 2 * nt) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
+        hipLaunchKernelGGL(diffnet_stack_split_kernel, dim3(4 * nt), dim3(256), (size_t)SP_LDS_FLOATS * sizeof(float), s, a,
+                           tiles, nt, fault_tile);
+        return set_check_launch("set_diffnet_stack");
+    }
     const bool wino = variant == 2;
     const int ncb = variant == 1 ? 1 : 2;
     const int ntt = 32 * ncb;
@@ -917,8 +1170,6 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
     if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
     if (grid < 1) grid = 1;
-    int fault_tile = -1;  // test hook: never publish this tile of layer 0 (exercises the time-out / error path)
-    if (const char *e = getenv("SET_AMD_FAULT_TILE")) fault_tile = atoi(e);
     if (wino) {
         if (a.dilation_cycle_length == 1)
             hipLaunchKernelGGL(diffnet_stack_wino_kernel<true>, dim3(grid), dim3(512),
@@ -1341,7 +1592,7 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
     float *ws_x0pred = a.ws_x0pred + (int64_t)b0 * per_batch;
     const float *condproj = a.condproj ? a.condproj + (int64_t)b0 * L * 512 * T : nullptr;
     const int tiles_per_utt = (T + NT - 1) / NT;
-    int32_t *sync_ws = a.sync_ws ? a.sync_ws + 4 * (int64_t)g + (int64_t)b0 * ((T + 31) / 32) : nullptr;  // per-group slice
+    int32_t *sync_ws = a.sync_ws ? a.sync_ws + 16 * (int64_t)g + 2 * (int64_t)b0 * ((T + 31) / 32) : nullptr;  // per-group slice
     const uint64_t quads_before = (uint64_t)((int64_t)b0 * per_batch / 4);
     const uint64_t quads_total = (uint64_t)(((int64_t)a.B * per_batch + 3) / 4);
     int rc = SET_OK;
@@ -1366,6 +1617,8 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
             sa.dstep = a.dstep + sid; sa.d_bs = 0; sa.d_cs = a.steps; sa.d_ls = (int64_t)DC * a.steps;
             sa.w1p_all = a.w1p_all; sa.w2p_all = a.w2p_all; sa.b_dil_all = a.b_dil_all; sa.b_out_all = a.b_out_all;
             sa.w1w_all = a.w1w_all; sa.w2w_all = a.w2w_all;
+            sa.w1s_all = a.w1s_all; sa.w2s_all = a.w2s_all;
+            sa.z_ws = a.z_ws ? a.z_ws + (int64_t)b0 * DC * 32 * ((T + 31) / 32) : nullptr;
             sa.err_flag = a.err_flag;
             sa.sync_ws = sync_ws;
             sa.B = Bg; sa.T = T; sa.L = L; sa.dilation_cycle_length = a.dilation_cycle_length;

@@ -662,9 +662,10 @@ extern "C" int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, v
                     ((a.y16 != nullptr) == (a.z16 != nullptr)), "set_diffnet_layer_fwd_bf16");
     SET_REQUIRE(a.B > 0 && a.T > 0 && a.dil >= 1 && a.dil <= 8, "set_diffnet_layer_fwd_bf16");
     SET_REQUIRE((int64_t)2 * FC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_layer_fwd_bf16 (T too large)");
-    // tile width: 64 frames (4 waves, two blocks per CU) unless SET_AMD_BF16_TILE=128 (8 waves, one block per CU)
+    // tile width: 128 frames (8 waves, one block per CU); SET_AMD_BF16_TILE=64 selects the 64-frame variant (4 waves, two
+    // blocks per CU), measured slower and kept for experiments
     static int tile = 0;
-    if (!tile) { const char *e = getenv("SET_AMD_BF16_TILE"); tile = (e && atoi(e) == 128) ? 128 : 64; }
+    if (!tile) { const char *e = getenv("SET_AMD_BF16_TILE"); tile = (e && atoi(e) == 64) ? 64 : 128; }
     static bool attr_set = false;
     if (!attr_set) {
         SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel<true, 128>),

@@ -110,7 +110,8 @@ class DiffNet(nn.Module):
                 for i, l in enumerate(layers):
                     ops.pack_diffnet_layer_wino(l.dilated_conv.weight.detach(), l.output_projection.weight.detach(),
                                                 w1w[i], w2w[i])
-            self._packs, self._packs_key = (w1, w2, bd, bo, w1w, w2w), key
+            w1s, w2s = ops.split_images(w1, w2)  # small-batch (row-split) stack kernel
+            self._packs, self._packs_key = (w1, w2, bd, bo, w1w, w2w, w1s, w2s), key
         return self._packs
 
     def bf16_layer_images(self):

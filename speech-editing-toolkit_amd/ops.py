@@ -462,18 +462,38 @@ def pack_diffnet_layer_wino(w_dil, w_out, w1w, w2w):
 
 
 def sync_ws_size(B, T):
-    return 32 + B * ((T + 31) // 32)
+    return 160 + 2 * B * ((T + 31) // 32)
 
 
-def stack_variant(B, T, dilation_cycle_length, have_wino=True):
-    """0 / 1: direct kernel (64- / 32-frame tiles), 2: Winograd kernel -- what set_diffnet_stack would pick."""
-    return int(_lib.lib().set_diffnet_stack_variant(int(B), int(T), int(dilation_cycle_length), int(bool(have_wino))))
+def stack_variant(B, T, dilation_cycle_length, have_wino=True, have_split=True):
+    """0 / 1: direct kernel (64- / 32-frame tiles), 2: Winograd kernel, 3: row-split kernel (small batches) -- what
+    set_diffnet_stack would pick."""
+    return int(_lib.lib().set_diffnet_stack_variant(int(B), int(T), int(dilation_cycle_length),
+                                                    int(bool(have_wino)) | (2 if have_split else 0)))
+
+
+def split_images(w1p_all, w2p_all):
+    """Row-split images of the small-batch stack kernel from the packed layer images: the same values, one 32-row
+    block per wave ([L][w][k-step][lane][rb] -> [L][4w + rb][k-step][lane])."""
+    L = w1p_all.shape[0]
+    return tuple(w.view(L, 4, -1, 64, 4).permute(0, 1, 4, 2, 3).contiguous().view(L, -1) for w in (w1p_all, w2p_all))
+
+
+def _split_images(a, packs, B, T, dcl, dev):
+    """Row-split images + z workspace of the small-batch stack kernel into the args struct (only for shapes the kernel
+    is picked for); returns the workspace (the caller keeps it alive; stream-ordered reuse is safe)."""
+    if len(packs) < 8 or packs[6] is None or stack_variant(B, T, dcl) != 3:
+        return None
+    a.w1s_all, a.w2s_all = packs[6].data_ptr(), packs[7].data_ptr()
+    z_ws = torch.empty(B * ((T + 31) // 32) * 256 * 32, dtype=torch.float32, device=dev)
+    a.z_ws = z_ws.data_ptr()
+    return z_ws
 
 
 def diffnet_stack(xa, xb, skip, condproj, dstep_ptr, d_bs, d_cs, d_ls, packs, dilation_cycle_length, sync_ws=None,
                   x_all=None, save_y=None, save_z=None):
     """All L layers in one persistent launch.  condproj [B, L*512, T]; packs = (w1p_all, w2p_all, b_dil_all, b_out_all
-    [, w1w_all, w2w_all]).  Training forward (Winograd kernel only): x_all [L+1,B,256,T] (slab 0 = input) replaces the
+    [, w1w_all, w2w_all [, w1s_all, w2s_all]]).  Training forward (Winograd kernel only): x_all [L+1,B,256,T] (slab 0 = input) replaces the
     xa/xb ping-pong, save_y [L,B,512,T] / save_z [L,B,256,T] receive what the backward pass needs.
     Returns sync_ws (int32; [1] != 0 means a dependency wait timed out)."""
     _f(xa), _f(xb), _f(skip), _f(condproj)
@@ -492,6 +512,7 @@ def diffnet_stack(xa, xb, skip, condproj, dstep_ptr, d_bs, d_cs, d_ls, packs, di
         a.w1w_all, a.w2w_all = packs[4].data_ptr(), packs[5].data_ptr()
     if x_all is not None:
         a.x_all, a.save_y, a.save_z = _f(x_all).data_ptr(), _f(save_y).data_ptr(), _f(save_z).data_ptr()
+    z_ws = _split_images(a, packs, B, T, dilation_cycle_length, xa.device)  # noqa: F841 (kept alive until the launch is enqueued)
     a.sync_ws = sync_ws.data_ptr()
     a.cp_bs, a.cp_ls = condproj.stride(0), 512 * T
     a.d_bs, a.d_cs, a.d_ls = int(d_bs), int(d_cs), int(d_ls)
@@ -597,6 +618,7 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs,
     a.b_dil_all, a.b_out_all = b_dil_all.data_ptr(), b_out_all.data_ptr()
     if len(packs) >= 6 and packs[4] is not None:
         a.w1w_all, a.w2w_all = packs[4].data_ptr(), packs[5].data_ptr()
+    z_ws = _split_images(a, packs, B, T, dilation_cycle_length, dev)  # noqa: F841
     a.persistent = int(default_persistent() if persistent is None else bool(persistent))
     sync_ws = torch.empty(sync_ws_size(B, T), dtype=torch.int32, device=dev)
     a.sync_ws = sync_ws.data_ptr()

@@ -404,6 +404,68 @@ def test_persistent_stack_bit_identical_to_layer_launches(dev):
             assert torch.equal(xb if L % 2 else xa, x_ref), (B, T, rep)
 
 
+def test_row_split_stack_bit_identical_to_layer_launches(dev, monkeypatch):
+    """Small batches: every 32-frame tile of set_diffnet_stack is computed by four co-operating blocks (one 32-row block
+    per wave, z exchanged through L2, two counter rendezvous per layer).  Same accumulation chains as the per-layer
+    kernel -> bit-identical, run after run (a stale z or neighbour read would change bits), at one utterance of the
+    benchmark length, at ragged lengths, with dilations 1..8, and the time-out flag stays 0."""
+    from set_amd import ops
+    for (B, T, L, dcl, reps) in ((1, 800, 20, 1, 8), (4, 800, 20, 1, 3), (2, 333, 6, 4, 3), (1, 31, 3, 2, 2), (5, 200, 4, 3, 2),
+                                 (1, 1548, 3, 1, 1), (1, 1, 2, 1, 1)):
+        g = torch.Generator().manual_seed(B * 1000 + T + 7)
+        x0 = torch.randn(B, 256, T, generator=g).to(dev)
+        cp = (torch.randn(B, L * 512, T, generator=g) * 0.5).to(dev)
+        dtab = torch.randn(L * 256, 3, generator=g).to(dev)
+        w1 = torch.empty(L, 512 * 768, device=dev)
+        w2 = torch.empty(L, 512 * 256, device=dev)
+        bd = (torch.randn(L, 512, generator=g) * 0.1).to(dev)
+        bo = (torch.randn(L, 512, generator=g) * 0.1).to(dev)
+        for l in range(L):
+            wd = (torch.randn(512, 256, 3, generator=g) / 27.7).to(dev)
+            wo = (torch.randn(512, 256, 1, generator=g) / 16.0).to(dev)
+            ops.pack_diffnet_layer(wd, wo, w1[l], w2[l])
+        packs = (w1, w2, bd, bo, None, None) + ops.split_images(w1, w2)
+        col = 2
+        h, nxt, skip_ref = x0.clone(), torch.empty_like(x0), torch.empty_like(x0)
+        for l in range(L):
+            ops.diffnet_layer(h, cp[:, l * 512:(l + 1) * 512].data_ptr(), cp.stride(0),
+                              dtab.data_ptr() + 4 * (l * 256 * 3 + col), 0, 3, w1[l], bd[l], w2[l], bo[l], nxt, skip_ref,
+                              1 << (l % dcl), l == 0)
+            h, nxt = nxt, h
+        x_ref = h.clone()
+        monkeypatch.setenv("SET_AMD_SPLIT", "2")
+        assert ops.stack_variant(B, T, dcl) == 3
+        for rep in range(reps):
+            xa, xb, skip = x0.clone(), torch.full_like(x0, float("nan")), torch.full_like(x0, float("nan"))
+            ws = ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4 * col, 0, 3, 256 * 3, packs, dcl)
+            torch.cuda.synchronize()
+            assert int(ws[1]) == 0, "dependency wait timed out"
+            assert torch.equal(skip, skip_ref), (B, T, rep)
+            assert torch.equal(xb if L % 2 else xa, x_ref), (B, T, rep)
+        monkeypatch.delenv("SET_AMD_SPLIT")
+    # too many tiles for co-residency: the queue kernels take over
+    assert ops.stack_variant(8, 800, 1) != 3
+
+
+def test_row_split_timeout_is_reported(dev, monkeypatch):
+    """Same error contract as the queue kernels: a part that never publishes (SET_AMD_FAULT_TILE) makes its neighbours
+    give up after the spin limit, every block leaves, the reverse loop raises; the next call works."""
+    from set_amd._lib import SetAmdError
+    g = load_golden("infer_tiny")
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"])
+    inp, noises = _case_inputs(g, dev)
+    args = (inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"],
+            inp["uv"])
+    monkeypatch.setenv("SET_AMD_SPLIT", "2")
+    monkeypatch.setenv("SET_AMD_FAULT_TILE", "0")
+    with pytest.raises(SetAmdError, match="timed out"):
+        model(*args, infer=True, noises=noises)
+    monkeypatch.delenv("SET_AMD_FAULT_TILE")
+    ok = model(*args, infer=True, noises=noises)["mel_out"]
+    assert _maxdiff(ok, g["mel_out"]) < 1e-4
+
+
 def test_winograd_stack_matches_direct_stack(dev, monkeypatch):
     """The Winograd F(2,3) persistent kernel (4 GEMMs over output pairs, filter transform folded into the packed
     weights) against the direct persistent kernel on the same weights: equal to fp32 rounding (not bit for bit: the
