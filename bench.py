@@ -300,11 +300,21 @@ def run_infer(args, rank, world, dev):
     #   launch_ms = mean duration of one launch, from hipEvent pairs on the launch stream over the timed region
     #   achieved  = algorithmic FLOPs of one launch / launch_ms  (x concurrent launches if utterance groups > 1)
     persistent = bool(ret.get("persistent", 0))
-    variant = _lib.lib().set_diffnet_stack_variant(B_PER_GPU // groups, T, model.denoise_fn.dilation_cycle_length, 1)
-    stack_kernel = "diffnet_stack_wino_kernel" if variant == 2 else "diffnet_stack_kernel"
-    # the Winograd kernel issues 3/4 of the algorithmic MACs (k=3 conv as F(2,3): 4 multiplies per output PAIR and
-    # input channel instead of 6, i.e. 512x512 instead of 512x768 MACs per frame, plus the 512x256 1x1 conv)
-    executed_ratio = (512 * 512 + 512 * 256) / (512 * 768 + 512 * 256) if (persistent and variant == 2) else 1.0
+    from set_amd import ops
+    variant = ops.stack_variant(B_PER_GPU // groups, T, model.denoise_fn.dilation_cycle_length)
+    stack_kernel = ops.STACK_VARIANT_NAMES[variant]
+    # MFMA work actually issued per algorithmic FLOP, and the pipe it is issued on:
+    #   Winograd kernel (fp32 pipe): 3/4 (k=3 conv as F(2,3): 512x512 instead of 512x768 MACs per frame, plus the 1x1 conv)
+    #   split-operand kernels (16-bit pipe): every fp32 product = 6 bf16 x bf16 (three pieces) or 3 fp16 x fp16 (two pieces)
+    #   MFMA products with fp32 accumulation -- fp32-equivalent results on the 2.5 PFLOP/s pipe
+    executed_ratio, pipe_peak, pipe = 1.0, PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32"
+    if persistent and variant == 2:
+        executed_ratio = (512 * 512 + 512 * 256) / (512 * 768 + 512 * 256)
+    elif persistent and variant == 4:
+        executed_ratio, pipe_peak, pipe = 6.0, PEAK_BF16_MFMA_TFLOPS, "v_mfma_f32_32x32x16_bf16"
+    elif persistent and variant == 5:
+        executed_ratio, pipe_peak, pipe = 3.0, PEAK_BF16_MFMA_TFLOPS, "v_mfma_f32_32x32x16_f16"
+    split_operands = persistent and variant in (4, 5)
     layers_per_launch = L if persistent else 1
     launch_ms = sum(spans) / len(spans) / (L // layers_per_launch)
     flop_per_launch = FLOP_PER_FRAME_LAYER * (B_PER_GPU / groups) * T * layers_per_launch
@@ -322,7 +332,10 @@ def run_infer(args, rank, world, dev):
         "metric": "diffusion mel-frames/s (100-step p_sample, B=32/GPU, T=800)",
         "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": ("f32 (operands carried as %s, fp32 accumulate: fp32-equivalent, see roofline.note)" % (
+            "2 fp16 pieces, 3 MFMA products per term" if variant == 5 else "3 bf16 pieces, 6 MFMA products per term")
+                  if split_operands else "f32"),
+        "data": "synthetic",
         "config": {"workload": "FluentSpeech spec_denoiser 100-step p_sample inference (conditioner + 100 x "
                                "(DiffNet + posterior)), synthetic 80-mel T=800 batches, B=32 per GPU (shapes of "
                                "BASELINE configs[1]); on-device Philox noise",
@@ -330,22 +343,62 @@ def run_infer(args, rank, world, dev):
                    "sharding": "utterances r::N, no collective"},
         "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"],
         "per_rank_ms_per_step": [1e3 * s / args.steps for s in facts["per_rank_s"]],
+        # achieved = MFMA FLOPs the dominant kernel issues per launch / its mean launch duration, against the dense peak of
+        # the pipe it issues them on; algorithmic_* = the fp32 FLOPs of the layer math (conditioner
+        # projection hoisted) over the same time, for comparison with rounds that ran on the fp32 pipe
         "roofline": {"kernel": stack_kernel if persistent else "diffnet_layer_kernel", "bound": "mfma",
-                     "achieved": ach_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": ach_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "launch_ms": launch_ms,
+                     "achieved": executed_ratio * ach_tflops, "peak": pipe_peak, "unit": "TFLOP/s",
+                     "frac": executed_ratio * ach_tflops / pipe_peak, "traffic": traffic, "launch_ms": launch_ms,
+                     "mfma_instruction": pipe, "executed_mfma_flop_ratio": executed_ratio,
                      "flop_per_launch": flop_per_launch, "layers_per_launch": layers_per_launch,
-                     "executed_mfma_flop_ratio": executed_ratio,
-                     "mfma_issue_frac": executed_ratio * ach_tflops / PEAK_F32_MFMA_TFLOPS,
+                     "algorithmic_fp32_TFLOPs": ach_tflops,
+                     "algorithmic_vs_fp32_mfma_peak": ach_tflops / PEAK_F32_MFMA_TFLOPS,
                      "algorithmic_bytes_per_launch": bytes_per_launch, "concurrent_launches": groups,
-                     "achieved_wall_lower_bound": ach_wall, "frac_wall_lower_bound": ach_wall / PEAK_F32_MFMA_TFLOPS,
-                     "hbm_algorithmic_GBps": ach_gbs, "hbm_frac": ach_gbs / PEAK_HBM_GBS},
+                     "achieved_wall_lower_bound": executed_ratio * ach_wall,
+                     "frac_wall_lower_bound": executed_ratio * ach_wall / pipe_peak,
+                     "hbm_algorithmic_GBps": ach_gbs, "hbm_frac": ach_gbs / PEAK_HBM_GBS,
+                     "note": ("fp32 results from 16-bit MFMAs: each fp32 operand is the exact sum of its 16-bit pieces, every "
+                              "cross product that matters at fp32 precision is issued (fp32 accumulate); error against fp64 "
+                              "<= the fp32 MFMA kernel's and the same |dmel| < 1e-4 parity tests run on this kernel "
+                              "(tests/test_gpu_parity.py::test_x3_*, ::test_full_inference_*split_operand*). "
+                              "native_fp32_loop below = the same loop on the fp32 MFMA pipe (SET_AMD_X3=0)")
+                     if split_operands else None},
     }
+    if rank == 0 and world == 1 and split_operands and not args.no_native_fp32:
+        out["native_fp32_loop"] = native_fp32_line(model, inp, args, step(0)["mel_out"])
     if rank == 0 and world == 1 and not args.no_bf16_loop:
         out["bf16_operand_loop"] = bf16_loop_line(model, inp, args, ret_f32_seed0=step(0)["mel_out"])
     if rank == 0 and world == 1 and args.cpu_baseline != "off":
         out["cpu_baseline"] = cpu_baseline(model, inp, args.cpu_baseline)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
     return out
+
+
+def native_fp32_line(model, inp, args, mel_split):
+    """The same 100-step loop with the residual layers on the fp32 MFMA pipe (the Winograd persistent kernel, round 1's
+    headline path; SET_AMD_X3=0) and the difference between the two outputs on the same inputs and Philox noise."""
+    os.environ["SET_AMD_X3"] = "0"
+    try:
+        def step(seed, spans=False):
+            return model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"],
+                         inp["f0"], inp["uv"], infer=True, seed=seed, want_layer_spans=spans)
+        step(1000)
+        torch.cuda.synchronize()
+        spans = []
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            spans.extend(step(k, spans=True)["layer_span_ms"])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        mel32 = step(0)["mel_out"]
+    finally:
+        del os.environ["SET_AMD_X3"]
+    launch_ms = sum(spans) / len(spans)
+    tfl = FLOP_PER_FRAME_LAYER * B_PER_GPU * T * L / (launch_ms * 1e-3) / 1e12
+    return {"value": B_PER_GPU * T / dt, "unit": "mel-frames/s", "ms_per_step": 1e3 * dt, "dtype": "f32",
+            "kernel": "diffnet_stack_wino_kernel", "launch_ms": launch_ms, "algorithmic_fp32_TFLOPs": tfl,
+            "frac_of_fp32_mfma_peak": tfl / PEAK_F32_MFMA_TFLOPS,
+            "max_abs_dmel_split_vs_native": float((mel_split.float() - mel32.float()).abs().max())}
 
 
 def bf16_loop_line(model, inp, args, ret_f32_seed0):
@@ -468,6 +521,7 @@ def main():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32", help="train mode only: MFMA operand type")
     ap.add_argument("--cpu-baseline", choices=("full", "quick", "off"), default="full")
     ap.add_argument("--no-cpu-baseline", action="store_const", const="off", dest="cpu_baseline")
+    ap.add_argument("--no-native-fp32", action="store_true", help="skip the fp32-MFMA-pipe comparison run of the same loop")
     ap.add_argument("--no-bf16-loop", action="store_true", help="skip the extra (non-headline) bf16-operand loop line")
     args = ap.parse_args()
 

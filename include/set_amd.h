@@ -263,13 +263,30 @@ typedef struct SetDiffnetStackArgs {
     const float *w1s_all;
     const float *w2s_all;
     float *z_ws;
+    /* optional split-operand images [L][set_diffnet_layer_x3_image_size(x3_mode)] 16-bit (set_pack_diffnet_layer_x3): every
+     * fp32 weight and activation is carried as a sum of 16-bit pieces and every product is formed by several 16-bit MFMAs
+     * with fp32 accumulation -- fp32-equivalent accuracy (error against fp64 not larger than the fp32 MFMA chain's) at a
+     * fraction of the fp32 matrix-pipe time:
+     *   x3_mode 3: three bf16 pieces, six products (fp32 range, error ~2^-23 per product);
+     *   x3_mode 2: two fp16 pieces, three products (error ~2^-21 per product; an activation of magnitude >= 32768 sets
+     *              *err_flag = 2 instead of overflowing silently; weights are pre-scaled by a power of two at pack time).
+     * Used from the Winograd crossover on (batches that fill the chip); results agree with the fp32 kernels to fp32
+     * rounding, not bit for bit.  SET_AMD_X3=0 disables it, =2 forces it at any size. */
+    const void *wx3_all;
+    int32_t x3_mode;
 } SetDiffnetStackArgs;
 int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream);
 int64_t set_sizeof_diffnet_stack_args(void);
 
 /* which kernel set_diffnet_stack picks for this shape on the current device: 0 direct/64-frame tiles,
  * 1 direct/32-frame tiles, 2 Winograd, 3 row-split (diagnostics: bench.py names the kernel in its roofline object);
- * images: bit 0 = Winograd images given, bit 1 = row-split images + z_ws given */
+ * 4 split-operand 3 x bf16, 5 split-operand 2 x fp16; images: bit 0 = Winograd images given, bit 1 = row-split images +
+ * z_ws given, bit 2 = split-operand images of mode 3 given, bit 3 = of mode 2 */
+int64_t set_diffnet_layer_x3_image_size(int32_t mode); /* 16-bit elements per layer (mode 2 or 3; -1 otherwise) */
+/* k1 / k2: the weights of the dilated conv / the output projection are multiplied by 2^k before they are split (mode 2: pick
+ * k so that max |w| 2^k is in [8, 16), which keeps the residual pieces of all but the tiniest weights normal; mode 3: 0) */
+int set_pack_diffnet_layer_x3(const float *w_dil /*[512][256][3]*/, const float *w_out /*[512][256]*/, void *img, int32_t mode,
+                              int32_t k1, int32_t k2, void *stream);
 int set_diffnet_stack_variant(int B, int T, int dilation_cycle_length, int images);
 int64_t set_diffnet_w1w_size(void);
 int set_pack_diffnet_layer_wino(const float *w_dil, const float *w_out, float *w1w, float *w2w, void *stream);
@@ -315,6 +332,8 @@ typedef struct SetDiffLoopArgs {
     const float *w1s_all;   /* optional row-split images + workspace (see SetDiffnetStackArgs), small batches */
     const float *w2s_all;
     float *z_ws;
+    const void *wx3_all;    /* optional split-operand images (see SetDiffnetStackArgs), batches that fill the chip */
+    int32_t x3_mode;
     const float *w_skip_p; /* skip_projection packed */
     const float *b_skip;
     const float *w_outp_p; /* output_projection packed (Cout M, Cin 256) */
@@ -335,7 +354,8 @@ typedef struct SetDiffLoopArgs {
      * >= 160 + 2*B*ceil(T/32) int32); 0: one set_diffnet_layer launch per layer */
     int32_t persistent;
     int32_t *sync_ws;
-    int32_t *err_flag; /* optional sticky error word, see SetDiffnetStackArgs.err_flag */
+    int32_t *err_flag; /* optional sticky error word, see SetDiffnetStackArgs.err_flag (1: time-out, 2: activation out of the
+                        * fp16 split range) */
     /* bf16-operand loop (opt-in, NOT the parity path; img16_all != NULL selects it): every residual layer runs as one
      * set_diffnet_layer_fwd_bf16 launch reading cond [B][192][T] (the conditioner projection is a K-chunk of the layer's
      * GEMM, condproj is not used), images [L][set_diffnet_layer_bf16_image_size()], conditioner biases [L][512] */
@@ -400,6 +420,9 @@ int set_debug_bf16_phase_buffer(uint64_t *buf);
  * its 8 phases (wait for the previous layer, stage, GEMM 1, gate + z publish, wait for z, z load, GEMM 2, epilogue +
  * publish), summed over the layers, to buf[0..7] (NULL = off) */
 int set_debug_split_phase_buffer(uint64_t *buf);
+/* debug: lane 0 of block 0 of the split-operand stack kernel adds the s_memtime ticks of its phases (claim + wait, stage,
+ * GEMM 1, gate, GEMM 2, epilogue + publish), summed over its tasks, to buf[0..5] and its task count to buf[7] */
+int set_debug_x3_phase_buffer(uint64_t *buf);
 
 typedef struct SetDiffnetLayerBf16BwdArgs {
     const float *dx_out; /* [B][256][T] gradient w.r.t. x_out; NULL = zero (the last layer's x_out feeds nothing) */

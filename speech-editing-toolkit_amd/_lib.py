@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_PKG, "libset_amd.so")
-SOURCES = ["conv1d.hip", "glue.hip", "diffnet.hip", "train.hip", "attention.hip", "bf16.hip", "diffnet_bf16.hip"]
+SOURCES = ["conv1d.hip", "glue.hip", "diffnet.hip", "diffnet_x3.hip", "train.hip", "attention.hip", "bf16.hip", "diffnet_bf16.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
 # constants mirrored from set_amd.h
@@ -65,7 +65,8 @@ class SetDiffLoopArgs(C.Structure):
         ("w_in_p", C.c_void_p), ("b_in", C.c_void_p),
         ("w1p_all", C.c_void_p), ("w2p_all", C.c_void_p), ("b_dil_all", C.c_void_p), ("b_out_all", C.c_void_p),
         ("w1w_all", C.c_void_p), ("w2w_all", C.c_void_p),
-        ("w1s_all", C.c_void_p), ("w2s_all", C.c_void_p), ("z_ws", C.c_void_p),
+        ("w1s_all", C.c_void_p), ("w2s_all", C.c_void_p), ("z_ws", C.c_void_p), ("wx3_all", C.c_void_p),
+        ("x3_mode", C.c_int32),
         ("w_skip_p", C.c_void_p), ("b_skip", C.c_void_p), ("w_outp_p", C.c_void_p), ("b_outp", C.c_void_p),
         ("ws_x0", C.c_void_p), ("ws_x1", C.c_void_p), ("ws_skip", C.c_void_p), ("ws_h", C.c_void_p),
         ("ws_x0pred", C.c_void_p),
@@ -89,7 +90,8 @@ class SetDiffnetStackArgs(C.Structure):
         ("w1w_all", C.c_void_p), ("w2w_all", C.c_void_p),
         ("x_all", C.c_void_p), ("save_y", C.c_void_p), ("save_z", C.c_void_p),
         ("err_flag", C.c_void_p),
-        ("w1s_all", C.c_void_p), ("w2s_all", C.c_void_p), ("z_ws", C.c_void_p),
+        ("w1s_all", C.c_void_p), ("w2s_all", C.c_void_p), ("z_ws", C.c_void_p), ("wx3_all", C.c_void_p),
+        ("x3_mode", C.c_int32),
     ]
 
 
@@ -158,6 +160,8 @@ SIGNATURES = {
     "set_diffnet_w2p_size": (_I64, []),
     "set_pack_diffnet_layer": (C.c_int, [_V, _V, _V, _V, _V]),
     "set_diffnet_stack_variant": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "set_diffnet_layer_x3_image_size": (C.c_int64, [_I32]),
+    "set_pack_diffnet_layer_x3": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _V]),
     "set_diffnet_w1w_size": (_I64, []),
     "set_pack_diffnet_layer_wino": (C.c_int, [_V, _V, _V, _V, _V]),
     "set_diffnet_stack": (C.c_int, [C.POINTER(SetDiffnetStackArgs), _V]),
@@ -193,6 +197,7 @@ SIGNATURES = {
     "set_diffnet_layer_fwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayerBf16Args), _V]),
     "set_debug_bf16_phase_buffer": (C.c_int, [_V]),
     "set_debug_split_phase_buffer": (C.c_int, [_V]),
+    "set_debug_x3_phase_buffer": (C.c_int, [_V]),
     "set_sizeof_diffnet_layer_bf16_bwd_args": (_I64, []),
     "set_diffnet_layer_bwd_bf16_tiles": (_I32, [_I32, _I32]),
     "set_diffnet_layer_bwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayerBf16BwdArgs), _V]),

@@ -1080,8 +1080,10 @@ extern "C" int64_t set_sizeof_diffnet_stack_args(void) { return (int64_t)sizeof(
 
 // 0 = direct kernel, 64-frame tiles; 1 = direct kernel, 32-frame tiles; 2 = Winograd F(2,3) kernel (64-frame tiles,
 // 8-wave blocks, needs its packed images, dilation_cycle_length <= 4 and at least ~0.68 tiles per CU to be worth it);
-// 3 = row-split kernel for small batches (4 blocks per 32-frame tile, needs its images and the z workspace)
-static int stack_variant(int B, int T, int dcl, bool have_wino, bool have_split, int n_cu) {
+// 3 = row-split kernel for small batches (4 blocks per 32-frame tile, needs its images and the z workspace);
+// 4 / 5 = split-operand kernel (fp32 = 3 bf16 pieces, six bf16 MFMAs per product / 2 fp16 pieces, three; csrc/diffnet_x3.hip)
+static int stack_variant(int B, int T, int dcl, bool have_wino, bool have_split, int x3_mode, int n_cu) {
+    const bool have_x3 = x3_mode == 2 || x3_mode == 3;
     const int64_t tiles64 = (int64_t)B * ((T + 63) / 64);
     // row-split kernel: 4 blocks per 32-frame tile, all co-resident (2 per CU); SET_AMD_SPLIT=0 disables, =2 forces it
     // (when it fits); an explicit SET_AMD_WINO choice also rules it out
@@ -1089,6 +1091,12 @@ static int stack_variant(int B, int T, int dcl, bool have_wino, bool have_split,
     int split_env = 1;
     if (const char *e = getenv("SET_AMD_SPLIT")) split_env = atoi(e);
     if (split_fits && (split_env == 2 || (split_env == 1 && !getenv("SET_AMD_WINO")))) return 3;
+    // split-operand (3 x bf16) kernel: the throughput kernel from the same crossover as the Winograd kernel; SET_AMD_X3=0
+    // disables, =2 forces it at any size; an explicit SET_AMD_WINO choice also rules it out
+    int x3_env = 1;
+    if (const char *e = getenv("SET_AMD_X3")) x3_env = atoi(e);
+    if (have_x3 && dcl <= 4 && (x3_env == 2 || (x3_env == 1 && !getenv("SET_AMD_WINO") && 25 * tiles64 >= 17 * n_cu)))
+        return x3_mode == 3 ? 4 : 5;
     int ncb = tiles64 < 3 * n_cu ? 1 : 2;
     if (const char *e = getenv("SET_AMD_STACK_NCB")) ncb = atoi(e) == 2 ? 2 : 1;
     const bool wino_ok = have_wino && (1 << (dcl - 1)) <= WN_MAXD;
@@ -1099,8 +1107,11 @@ static int stack_variant(int B, int T, int dcl, bool have_wino, bool have_split,
 extern "C" int set_diffnet_stack_variant(int B, int T, int dilation_cycle_length, int images) {
     int dev = 0, n_cu = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    return stack_variant(B, T, dilation_cycle_length, (images & 1) != 0, (images & 2) != 0, n_cu);
+    return stack_variant(B, T, dilation_cycle_length, (images & 1) != 0, (images & 2) != 0,
+                         (images & 4) ? 3 : ((images & 8) ? 2 : 0), n_cu);
 }
+
+int set_launch_diffnet_stack_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s);  // csrc/diffnet_x3.hip
 
 extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) {
     SET_REQUIRE(args != nullptr, "set_diffnet_stack");
@@ -1131,10 +1142,12 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     // runnable.  Workers (2 per CU) must stay BELOW that or the youngest ones only wait (measured: 36 % wait time
     // with 512 workers on 416 64-frame tiles).  Use 64-frame tiles when a layer has >= 1.5x the workers, else
     // 32-frame tiles (B=32, T=800: 800 tiles, no tail waste); the grid is capped at 0.8x the tile count.
+    const bool plain = !a.x_all && !a.save_y && !a.save_z;
     const int variant = stack_variant(a.B, a.T, a.dilation_cycle_length, a.w1w_all && a.w2w_all,
-                                      a.w1s_all && a.w2s_all && a.z_ws && !a.x_all && !a.save_y && !a.save_z, n_cu);
+                                      a.w1s_all && a.w2s_all && a.z_ws && plain, (a.wx3_all && plain) ? a.x3_mode : 0, n_cu);
     int fault_tile = -1;  // test hook: never publish this tile of layer 0 (exercises the time-out / error path)
     if (const char *e = getenv("SET_AMD_FAULT_TILE")) fault_tile = atoi(e);
+    if (variant >= 4) return set_launch_diffnet_stack_x3(a, n_cu, fault_tile, s);
     if (variant == 3) {
         const int tiles = (a.T + 31) / 32, nt = a.B * tiles;
         SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + 2 * nt) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
@@ -1617,7 +1630,7 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
             sa.dstep = a.dstep + sid; sa.d_bs = 0; sa.d_cs = a.steps; sa.d_ls = (int64_t)DC * a.steps;
             sa.w1p_all = a.w1p_all; sa.w2p_all = a.w2p_all; sa.b_dil_all = a.b_dil_all; sa.b_out_all = a.b_out_all;
             sa.w1w_all = a.w1w_all; sa.w2w_all = a.w2w_all;
-            sa.w1s_all = a.w1s_all; sa.w2s_all = a.w2s_all;
+            sa.w1s_all = a.w1s_all; sa.w2s_all = a.w2s_all; sa.wx3_all = a.wx3_all; sa.x3_mode = a.x3_mode;
             sa.z_ws = a.z_ws ? a.z_ws + (int64_t)b0 * DC * 32 * ((T + 31) / 32) : nullptr;
             sa.err_flag = a.err_flag;
             sa.sync_ws = sync_ws;

@@ -1,0 +1,511 @@
+// DiffNet residual stack (inference) with fp32 operands SPLIT into three bf16 pieces -- the throughput kernel of the
+// reverse loop (spec_denoiser.py:178-184 -> diffnet.py:60-81, 110-132).
+//
+// Why: the layer is two GEMMs (512 x 768 and 512 x 256 per frame) and the fp32 matrix pipe of gfx950 does 256 FLOP per
+// CU-cycle-SIMD quarter... in numbers: v_mfma_f32_32x32x2_f32 = 157 TFLOP/s, v_mfma_f32_32x32x16_bf16 = 2.5 PFLOP/s (16 x).
+// An fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8 mantissa bits, round-to-nearest pieces):
+//     a = a0 + a1 + a2,   a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)
+// so a product a*b is  a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0) + O(2^-24 |ab|): SIX bf16 MFMAs (each product of two
+// bf16 values is exact in fp32, accumulation is fp32) give every term to within one fp32 ulp -- the same size as the
+// rounding of a native fp32 FMA -- at 6/16 of the fp32 MFMA time.  Measured against an fp64 reference the split GEMM is
+// at least as accurate as the fp32 MFMA chain (tests/test_gpu_parity.py::test_x3_stack_*), and the parity bar of the path
+// (|dmel| < 1e-4 against the reference) is met with the same margin.  It is NOT a reduced-precision path: nothing is
+// rounded to bf16 that is not also carried by a lower piece; HBM tensors, biases, the conditioner projection, the gate
+// and all accumulators are fp32 exactly as in csrc/diffnet.hip.
+//
+// Two splittings share the kernel (template parameter):
+//   SplitBf16x3  a = a0 + a1 + a2 (bf16), six products, fp32 range, error <= ~2^-23 |ab| per product          (mode 3)
+//   SplitF16x2   a = a0 + a1 (fp16: 11 + 11 mantissa bits; v_mfma_f32_32x32x16_f16 keeps subnormal inputs, checked on the
+//                device: tools/hw/mfma_f16_denorm.hip), three products a0b0 + a0b1 + a1b0, error <= ~2^-21 |ab| per
+//                product + 2^-25 absolute per operand -- still below what the fp32 accumulation itself adds over K = 768
+//                (measured: same error against fp64 as the fp32 MFMA chain), at HALF the matrix-pipe work of bf16x3.
+//                fp16 range: the weights are pre-scaled per layer and GEMM by a power of two (exact; undone on the
+//                accumulators) so that their residual pieces stay normal, and an activation of magnitude >= 32768
+//                raises the sticky error word (value 2) instead of overflowing silently.                       (mode 2)
+//
+// Geometry: persistent task queue over (layer, 64-frame tile) exactly as diffnet_stack_kernel (same flags, same publish
+// protocol, same sync_ws layout).  Block = 512 threads = 8 waves, one block per CU; wave w owns gate rows [32w, 32w+32) and
+// filter rows 256 + [32w, 32w+32) x 64 frames (4 accumulators of 32x32), then residual / skip rows of GEMM 2.
+//   B operands: LDS tiles [piece][frame][256 channels] bf16, rows padded by 16 B (conflict-free 16-byte fragment reads);
+//               the x tile is split once when it is staged, the gated z tile (which overlays it) once after the gate.
+//   A operands: per-layer images [wave][k-step][row block][piece][lane][8 bf16] in global memory (3 MiB per layer, L2),
+//               split once per weight version by set_pack_diffnet_layer_x3.
+//   Per k-step (16 channels of one tap) a wave issues 6 A loads + 6 B reads of 16 bytes and 24 MFMAs (768 cycles).
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+// debug: lane 0 of block 0 adds the s_memtime ticks of its phases (claim + wait, stage, GEMM 1, gate, GEMM 2, epilogue +
+// publish), summed over its tasks, to buf[0..5] (+ sub-phases of the gate in buf[8..10]) and its task count to buf[7]
+__device__ uint64_t *g_x3_phase_buf = nullptr;
+
+namespace {
+
+constexpr int XC = 256;            // residual channels
+constexpr int X_NT = 64;           // frames per tile
+constexpr int X_MAXD = 8;          // largest dilation
+constexpr int XR = XC * 2 + 16;    // bytes per LDS row
+constexpr int X_KS1 = 48;          // k-steps of GEMM 1 (3 taps x 16)
+constexpr int X_KS2 = 16;          // k-steps of GEMM 2
+constexpr float RSQRT2 = 0.70710678118654752440f;
+constexpr unsigned X_SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ unsigned short f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+// a = p0 + p1 + p2 exactly (up to 2^-24 |a|): the three bf16 pieces of an fp32 value
+__device__ __forceinline__ void split3(float a, unsigned short &p0, unsigned short &p1, unsigned short &p2) {
+    p0 = f2bf(a);
+    const float r1 = a - bf2f(p0);
+    p1 = f2bf(r1);
+    p2 = f2bf(r1 - bf2f(p1));
+}
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned short f2h(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
+__device__ __forceinline__ float h2f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+
+struct SplitBf16x3 {
+    static constexpr int NP = 3, NPROD = 6, MODE = 3, PF = 2;  // PF: A prefetch distance in k-steps
+    // piece pairs ordered by magnitude: 2^-16, 2^-16, 2^-16, 2^-8, 2^-8, 1
+    static __device__ __forceinline__ constexpr int qa(int t) { return t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0; }
+    static __device__ __forceinline__ constexpr int qb(int t) { return t == 2 ? 2 : (t == 1 || t == 4) ? 1 : 0; }
+    static __device__ __forceinline__ void split(float a, unsigned short (&p)[3]) { split3(a, p[0], p[1], p[2]); }
+    static __device__ __forceinline__ f32x16 mma(u32x4_t a, u32x4_t b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+struct SplitF16x2 {
+    static constexpr int NP = 2, NPROD = 3, MODE = 2, PF = 4;
+    static __device__ __forceinline__ constexpr int qa(int t) { return t == 0 ? 1 : 0; }  // a1 b0, a0 b1, a0 b0
+    static __device__ __forceinline__ constexpr int qb(int t) { return t == 1 ? 1 : 0; }
+    static __device__ __forceinline__ void split(float a, unsigned short (&p)[2]) {
+        p[0] = f2h(a);
+        p[1] = f2h(a - h2f(p[0]));
+    }
+    static __device__ __forceinline__ f32x16 mma(u32x4_t a, u32x4_t b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+// bf16/fp16 elements of one layer's image: GEMM 1 + GEMM 2 fragments, then 4 floats {s1, 1/s1, s2, 1/s2} (the power-of-two
+// scales the weights of the two GEMMs were multiplied by before splitting)
+template <typename S> constexpr int64_t x_n1() { return 8LL * X_KS1 * 2 * S::NP * 512; }
+template <typename S> constexpr int64_t x_n2() { return 8LL * X_KS2 * 2 * S::NP * 512; }
+template <typename S> constexpr int64_t x_nimg() { return x_n1<S>() + x_n2<S>() + 8; }
+__device__ __forceinline__ u32x4_t buf_load_u4(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ int urow(int r) { return (r & 3) + 8 * (r >> 2); }  // + 4 * (lane >> 5)
+__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---- weight images --------------------------------------------------------------------------------------------------
+// lane l of a fragment holds row (l & 31), k = 8 (l >> 5) + e, e < 8:
+//   w1x[w][ks][rb][p][l][e]  row = (rb ? 256 : 0) + 32 w + (l & 31), tap = ks / 16, channel = 16 (ks % 16) + k : piece p of Wdil
+//   w2x[w][ks][rb][p][l][e]  channel = 16 ks + k : piece p of Wout
+template <typename S>
+__global__ void __launch_bounds__(256) pack_layer_x3_kernel(const float *wdil, const float *wout, unsigned short *img, float s1, float s2) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (fragment element, all pieces)
+    constexpr int64_t n1 = x_n1<S>() / S::NP, n2 = x_n2<S>() / S::NP;
+    if (idx == 0) {
+        float *tail = reinterpret_cast<float *>(img + x_n1<S>() + x_n2<S>());
+        tail[0] = s1; tail[1] = 1.0f / s1; tail[2] = s2; tail[3] = 1.0f / s2;
+    }
+    if (idx >= n1 + n2) return;
+    const bool g2 = idx >= n1;
+    int64_t r = g2 ? idx - n1 : idx;
+    const int e = r & 7; r >>= 3;
+    const int l = r & 63; r >>= 6;
+    const int rb = r & 1; r >>= 1;
+    const int nks = g2 ? X_KS2 : X_KS1;
+    const int ks = (int)(r % nks), w = (int)(r / nks);
+    const int row = (rb ? XC : 0) + 32 * w + (l & 31), k = 8 * (l >> 5) + e;
+    const float v = g2 ? s2 * wout[(int64_t)row * XC + 16 * ks + k] : s1 * wdil[((int64_t)row * XC + 16 * (ks % 16) + k) * 3 + ks / 16];
+    unsigned short p[S::NP];
+    S::split(v, p);
+    unsigned short *base = img + (g2 ? x_n1<S>() : 0) + ((((int64_t)w * nks + ks) * 2 + rb) * S::NP) * 512 + l * 8 + e;
+#pragma unroll
+    for (int q = 0; q < S::NP; ++q) base[q * 512] = p[q];
+}
+
+// ---- the GEMM: acc[rb][cb] += sum over the piece products, smallest terms first ------------------------------------------
+//   A: image block of (ks, rb, piece) at byte offset abase + ((ks * 2 + rb) * NP + piece) * 1024 (+ lane * 16)
+//   B: piece q of this lane's fragment for (ks, cb) at lds + q * piece_bytes + bfrag(ks, cb)
+template <typename S, int NKS, typename BF>
+__device__ __forceinline__ void gemm_x3(f32x16 (&acc)[2][2], rsrc_t img, unsigned lane16, unsigned abase, const unsigned char *lds,
+                                        unsigned piece_bytes, BF bfrag) {
+    constexpr int NP = S::NP, X_PF = S::PF;
+    u32x4_t A[X_PF][2][NP];
+#pragma unroll
+    for (int p = 0; p < X_PF; ++p)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) A[p][rb][q] = buf_load_u4(img, lane16, abase + (unsigned)(((p * 2 + rb) * NP + q) * 1024));
+    for (int kb = 0; kb < NKS; kb += X_PF) {
+#pragma unroll
+        for (int p = 0; p < X_PF; ++p) {
+            const int ks = kb + p;  // NKS is a multiple of X_PF
+            u32x4_t Bv[2][NP];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const unsigned bo = bfrag(ks, cb);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) Bv[cb][q] = *reinterpret_cast<const u32x4_t *>(lds + q * piece_bytes + bo);
+            }
+            u32x4_t Ac[2][NP];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) Ac[rb][q] = A[p][rb][q];
+            const int kn = min(ks + X_PF, NKS - 1);  // tail: harmless re-load of the last k-step
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) A[p][rb][q] = buf_load_u4(img, lane16, abase + (unsigned)(((kn * 2 + rb) * NP + q) * 1024));
+            __builtin_amdgcn_s_setprio(1);
+            // the four accumulators interleave, so consecutive MFMAs never depend on each other
+#pragma unroll
+            for (int t = 0; t < S::NPROD; ++t)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = S::mma(Ac[rb][S::qa(t)], Bv[cb][S::qb(t)], acc[rb][cb]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+}
+
+struct X3Tile {
+    const float *xin;
+    float *xout, *skp;
+    const float *cpb, *dstep;
+    int64_t d_cs;
+    const unsigned short *img;
+    const float *b_dil, *b_out;
+    int32_t *err_flag;
+    int T, t0, dil, first;
+};
+
+// pack NP pieces of 8 consecutive channels (p[e][q]: element e, piece q) into one 16-byte word per piece
+template <int NP>
+__device__ __forceinline__ void pack8(const unsigned short (&p)[8][NP], u32x4_t (&u)[NP]) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[q][e] = (unsigned)p[2 * e][q] | ((unsigned)p[2 * e + 1][q] << 16);
+}
+
+// one (layer, 64-frame tile) task; lds = NP pieces of (64 + 2 max_dil) rows + 256 floats
+template <typename S>
+__device__ __forceinline__ void layer_tile_x3(const X3Tile &a, unsigned char *lds, unsigned piece_bytes, uint64_t *dbg, uint64_t &tprev) {
+#define X3_PHASE(p)                                           \
+    if (dbg) {                                                \
+        const uint64_t tn = __builtin_amdgcn_s_memtime();     \
+        dbg[p] += tn - tprev;                                 \
+        tprev = tn;                                           \
+    }
+    X3_PHASE(0)
+    constexpr int NP = S::NP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int T = a.T, t0 = a.t0, d = a.dil;
+    float *dsh = reinterpret_cast<float *>(lds + NP * piece_bytes);
+    const unsigned T4 = 4u * (unsigned)T;
+    const rsrc_t rx = make_rsrc(a.xin), rxo = make_rsrc(a.xout), rsk = make_rsrc(a.skp), rcp = make_rsrc(a.cpb);
+    const rsrc_t rbd = make_rsrc(a.b_dil), rbo = make_rsrc(a.b_out);
+    const rsrc_t rw = make_rsrc(a.img);
+    const unsigned lane16 = 16u * (unsigned)lane;
+    const unsigned lb = 16u * (unsigned)half;
+    auto row0 = [&](int rb) { return (rb ? XC : 0) + 32 * w; };
+    // power-of-two scales of the two weight images (1 for bf16x3): {s1, 1/s1, s2, 1/s2}
+    const float *sc = reinterpret_cast<const float *>(a.img + x_n1<S>() + x_n2<S>());
+    const float s1 = sc[0], is1 = sc[1], s2 = sc[2], is2 = sc[3];
+
+    // ---- GEMM 1 accumulators start at s1 (b_dil + conditioner projection) (fp32, hoisted out of the loop by the caller).
+    //      These loads come from HBM (the projection is streamed once per step) and depend on nothing the previous layer
+    //      wrote: they are issued first and fly under the staging of the x tile.
+    f32x16 acc[2][2];
+    bool tv[2];
+    unsigned vo4[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int t = t0 + cb * 32 + l31;
+        tv[cb] = t < T;
+        vo4[cb] = 4u * (unsigned)(4 * half * T + min(t, T - 1));
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned ur = (unsigned)(row0(rb) + urow(r));
+            const float bias = buf_load(rbd, lb, 4u * ur);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[rb][cb][r] = bias + buf_load(rcp, vo4[cb], ur * T4);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- stage x + d, split into its pieces: thread (frame row f, channel group cg of 32 channels); row j <-> frame
+    //      t0 - d + j.  All loads of the main pass are issued before the first one is consumed.
+    {
+        const int f = tid & 63, cg = __builtin_amdgcn_readfirstlane(tid >> 6);  // cg 0..7
+        if (tid < XC) dsh[tid] = a.dstep[(int64_t)tid * a.d_cs];
+        float amax = 0.0f;
+        auto put = [&](int j, const float (&v)[32], bool valid) {
+#pragma unroll
+            for (int q8 = 0; q8 < 4; ++q8) {  // 8 channels -> one 16-byte write per piece
+                unsigned short p[8][NP];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = 8 * q8 + e;
+                    const float xv = valid ? v[c] + dsh[32 * cg + c] : 0.0f;
+                    if constexpr (S::MODE == 2) amax = fmaxf(amax, fabsf(xv));
+                    S::split(xv, p[e]);
+                }
+                u32x4_t u[NP];
+                pack8<NP>(p, u);
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    *reinterpret_cast<u32x4_t *>(lds + q * piece_bytes + j * XR + (32 * cg + 8 * q8) * 2) = u[q];
+            }
+        };
+        const int t = t0 - d + f;
+        const bool tvx = t >= 0 && t < T;
+        const unsigned vox = 4u * (unsigned)min(max(t, 0), T - 1);
+        float vx[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) vx[k] = buf_load(rx, vox, (unsigned)(32 * cg + k) * T4);
+        const int jh = X_NT + f, th = t0 - d + jh;  // halo rows 64 .. 64 + 2d - 1: the first 2d lanes of each channel group
+        const bool has_h = f < 2 * d, tvh = th >= 0 && th < T;
+        const unsigned voh = 4u * (unsigned)min(max(th, 0), T - 1);
+        float vh[32];
+        if (has_h) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) vh[k] = buf_load(rx, voh, (unsigned)(32 * cg + k) * T4);
+        }
+        __syncthreads();  // dsh
+        put(f, vx, tvx);
+        if (has_h) put(jh, vh, tvh);
+        if constexpr (S::MODE == 2) {  // fp16 pieces: |x| >= 32768 (or NaN) is outside the range of the splitting -> say so
+            if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][cb][r] *= s1;
+    __syncthreads();
+    X3_PHASE(1)
+
+    // ---- GEMM 1: y = Wdil (*) (x + d); k-step ks -> tap ks / 16 (a row shift of tap * d), channels 16 (ks % 16) ..
+    gemm_x3<S, X_KS1>(acc, rw, lane16, (unsigned)(w * X_KS1 * 2 * NP * 1024), lds, piece_bytes, [&](int ks, int cb) {
+        return (unsigned)((cb * 32 + l31 + (ks >> 4) * d) * XR + ((ks & 15) * 16 + half * 8) * 2);
+    });
+    X3_PHASE(2)
+
+    // ---- residual rows of x for GEMM 2's accumulator start: issued here, consumed after the gate
+    float xres[2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xres[cb][r] = buf_load(rx, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
+    __syncthreads();  // every wave is done reading the x tile: the z tile overlays it (row j <-> frame t0 + j)
+    X3_PHASE(8)
+    // ---- gate (lane-local: acc[0] gate rows, acc[1] the matching filter rows), split z, 4 consecutive channels per write
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            unsigned short p[4][NP];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                const float z = tv[cb] ? fsig(acc[0][cb][r] * is1) * ftanh(acc[1][cb][r] * is1) : 0.0f;
+                S::split(z, p[e]);
+            }
+            const unsigned off = (unsigned)((cb * 32 + l31) * XR + (32 * w + 8 * g + 4 * half) * 2);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                u32x2_t u;
+                u[0] = (unsigned)p[0][q] | ((unsigned)p[1][q] << 16);
+                u[1] = (unsigned)p[2][q] | ((unsigned)p[3][q] << 16);
+                *reinterpret_cast<u32x2_t *>(lds + q * piece_bytes + off) = u;
+            }
+        }
+    X3_PHASE(9)
+    // ---- GEMM 2 accumulators: residual rows start at s2 (b_out + x), skip rows at s2 b_out (the running skip sum is added
+    //      in the epilogue, after the x' stores are in flight)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bias = buf_load(rbo, lb, 4u * (unsigned)(row0(rb) + urow(r)));
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[rb][cb][r] = (rb == 0 ? bias + xres[cb][r] : bias) * s2;
+        }
+    // the running skip sum of this tile (written by this block's predecessor on the tile, one layer ago): fetched under GEMM 2
+    float sk[2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+    X3_PHASE(10)
+    __syncthreads();
+    X3_PHASE(3)
+
+    // ---- GEMM 2: o = Wout z
+    gemm_x3<S, X_KS2>(acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + w * X_KS2 * 2 * NP * 1024), lds, piece_bytes, [&](int ks, int cb) {
+        return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2);
+    });
+    X3_PHASE(4)
+
+    // ---- epilogue: x' (agent-scope write-through: other XCDs read it right after the publish), then the skip sum
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        if (tv[cb]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                buf_store_agent((acc[0][cb][r] * is2) * RSQRT2, rxo, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
+        }
+    }
+    const bool first = a.first != 0;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        if (tv[cb]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                buf_store_agent(first ? acc[1][cb][r] * is2 : acc[1][cb][r] * is2 + sk[cb][r], rsk, vo4[cb],
+                                (unsigned)(32 * w + urow(r)) * T4);
+        }
+    }
+}
+#undef X3_PHASE
+
+// persistent (layer, tile) queue: the protocol of diffnet_stack_kernel (csrc/diffnet.hip)
+template <typename S>
+__global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles, int ntasks,
+                                                                   unsigned piece_bytes, int fault_tile) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int *s_task = reinterpret_cast<int *>(lds + S::NP * piece_bytes + XC * sizeof(float));
+    int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
+    const int tid = threadIdx.x;
+    uint64_t *dbg = (blockIdx.x == 0 && tid == 0) ? g_x3_phase_buf : nullptr;
+    uint64_t tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    for (;;) {
+        __syncthreads();  // LDS (tile + task slot) of the previous task is free
+        if (tid == 0) {
+            int n = atomicAdd(counter, 1);
+            if (n < ntasks && n >= ntiles) {  // layer >= 1: wait for the three producer tiles of layer l - 1
+                const int l = n / ntiles, i = n - l * ntiles, j = i % tiles_per_utt;
+                unsigned spins = 0;
+                const int *f0 = done + i, *fl = done + (j > 0 ? i - 1 : i), *fr = done + (j < tiles_per_utt - 1 ? i + 1 : i);
+                for (;;) {
+                    const int v0 = ld_agent(f0), v1 = ld_agent(fl), v2 = ld_agent(fr);
+                    if (min(v0, min(v1, v2)) >= l) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > X_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
+                        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (a.err_flag) __hip_atomic_store(a.err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        n = ntasks;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            *s_task = n;
+        }
+        __syncthreads();
+        const int n = __builtin_amdgcn_readfirstlane(*s_task);
+        if (n >= ntasks) break;
+        const int l = n / ntiles, i = n - l * ntiles;
+        const int b = i / tiles_per_utt, j = i - b * tiles_per_utt;
+        X3Tile lt;
+        lt.xin = ((l & 1) ? a.xb : a.xa) + (int64_t)b * XC * a.T;
+        lt.xout = ((l & 1) ? a.xa : a.xb) + (int64_t)b * XC * a.T;
+        lt.skp = a.skip + (int64_t)b * XC * a.T;
+        lt.cpb = a.condproj + (int64_t)l * a.cp_ls + (int64_t)b * a.cp_bs;
+        lt.dstep = a.dstep + (int64_t)l * a.d_ls + (int64_t)b * a.d_bs;
+        lt.d_cs = a.d_cs;
+        lt.img = reinterpret_cast<const unsigned short *>(a.wx3_all) + (int64_t)l * x_nimg<S>();
+        lt.b_dil = a.b_dil_all + (int64_t)l * 512;
+        lt.b_out = a.b_out_all + (int64_t)l * 512;
+        lt.err_flag = a.err_flag;
+        lt.T = a.T; lt.t0 = j * X_NT; lt.dil = 1 << (l % a.dilation_cycle_length); lt.first = (l == 0);
+        layer_tile_x3<S>(lt, lds, piece_bytes, dbg, tprev);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: the tile is visible to every XCD
+        __syncthreads();
+        if (tid == 0 && !(l == 0 && i == fault_tile))
+            __hip_atomic_store(done + i, l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (dbg) {
+            const uint64_t tn = __builtin_amdgcn_s_memtime();
+            dbg[5] += tn - tprev;
+            dbg[7] += 1;
+            tprev = tn;
+        }
+    }
+}
+
+template <typename S>
+int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_x3_kernel<S>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "set_diffnet_stack(x3 attr)");
+        attr_set = true;
+    }
+    const int tiles_per_utt = (a.T + X_NT - 1) / X_NT, ntiles = a.B * tiles_per_utt;
+    const int64_t ntasks64 = (int64_t)ntiles * a.L;
+    SET_REQUIRE(ntasks64 < (1ll << 30), "set_diffnet_stack(task count)");
+    SET_REQUIRE((int64_t)2 * XC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_stack(split-operand kernel: T too large)");
+    const int max_dil = 1 << (a.dilation_cycle_length - 1);
+    const unsigned piece_bytes = (unsigned)((X_NT + 2 * max_dil) * XR);
+    const size_t ldsz = (size_t)S::NP * piece_bytes + XC * sizeof(float) + 16;
+    SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
+    int grid = n_cu;
+    if (grid > ntiles * 4 / 5) grid = ntiles * 4 / 5;  // workers stay below the runnable-task count (see diffnet.hip)
+    if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
+    if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(diffnet_stack_x3_kernel<S>, dim3(grid), dim3(512), ldsz, s, a, tiles_per_utt, ntiles, (int)ntasks64,
+                       piece_bytes, fault_tile);
+    return set_check_launch("set_diffnet_stack");
+}
+
+}  // namespace
+
+extern "C" int set_debug_x3_phase_buffer(uint64_t *buf) {
+    SET_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_x3_phase_buf), &buf, sizeof(buf)), "set_debug_x3_phase_buffer");
+    return SET_OK;
+}
+
+extern "C" int64_t set_diffnet_layer_x3_image_size(int32_t mode) {
+    return mode == 2 ? x_nimg<SplitF16x2>() : (mode == 3 ? x_nimg<SplitBf16x3>() : -1);
+}
+
+extern "C" int set_pack_diffnet_layer_x3(const float *w_dil, const float *w_out, void *img, int32_t mode, int32_t k1, int32_t k2,
+                                         void *stream) {
+    SET_REQUIRE(w_dil && w_out && img && (mode == 2 || mode == 3), "set_pack_diffnet_layer_x3");
+    SET_REQUIRE(k1 >= -60 && k1 <= 60 && k2 >= -60 && k2 <= 60, "set_pack_diffnet_layer_x3(scale exponents)");
+    const float s1 = ldexpf(1.0f, k1), s2 = ldexpf(1.0f, k2);
+    unsigned short *im = reinterpret_cast<unsigned short *>(img);
+    if (mode == 2)
+        hipLaunchKernelGGL(pack_layer_x3_kernel<SplitF16x2>, dim3(set_blocks((x_nimg<SplitF16x2>() - 8) / 2, 256)), dim3(256), 0,
+                           (hipStream_t)stream, w_dil, w_out, im, s1, s2);
+    else
+        hipLaunchKernelGGL(pack_layer_x3_kernel<SplitBf16x3>, dim3(set_blocks((x_nimg<SplitBf16x3>() - 8) / 3, 256)), dim3(256), 0,
+                           (hipStream_t)stream, w_dil, w_out, im, s1, s2);
+    return set_check_launch("set_pack_diffnet_layer_x3");
+}
+
+// called by set_diffnet_stack (csrc/diffnet.hip) once it has picked this kernel
+int set_launch_diffnet_stack_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s) {
+    if (a.x3_mode == 2) return launch_x3<SplitF16x2>(a, n_cu, fault_tile, s);
+    SET_REQUIRE(a.x3_mode == 3, "set_diffnet_stack(x3_mode must be 2 = f16x2 or 3 = bf16x3)");
+    return launch_x3<SplitBf16x3>(a, n_cu, fault_tile, s);
+}

@@ -93,7 +93,7 @@ class DiffNet(nn.Module):
         layers = list(self.residual_layers)
         key = tuple((p.data_ptr(), p._version) for l in layers for p in
                     (l.dilated_conv.weight, l.output_projection.weight, l.dilated_conv.bias, l.output_projection.bias))
-        key = key + (ops.weights_epoch(),)
+        key = key + (ops.weights_epoch(), ops.split_operand_mode())
         if self._packs is None or key != self._packs_key:
             dev = layers[0].dilated_conv.weight.device
             L = len(layers)
@@ -111,7 +111,12 @@ class DiffNet(nn.Module):
                     ops.pack_diffnet_layer_wino(l.dilated_conv.weight.detach(), l.output_projection.weight.detach(),
                                                 w1w[i], w2w[i])
             w1s, w2s = ops.split_images(w1, w2)  # small-batch (row-split) stack kernel
-            self._packs, self._packs_key = (w1, w2, bd, bo, w1w, w2w, w1s, w2s), key
+            wx3 = None
+            if self.dilation_cycle_length <= 4:  # split-operand images of the throughput kernel (csrc/diffnet_x3.hip)
+                wx3 = ops.SplitOperandImages(L, ops.split_operand_mode(), dev)
+                for i, l in enumerate(layers):
+                    wx3.pack(i, l.dilated_conv.weight.detach(), l.output_projection.weight.detach())
+            self._packs, self._packs_key = (w1, w2, bd, bo, w1w, w2w, w1s, w2s, wx3), key
         return self._packs
 
     def bf16_layer_images(self):

@@ -465,11 +465,71 @@ def sync_ws_size(B, T):
     return 160 + 2 * B * ((T + 31) // 32)
 
 
-def stack_variant(B, T, dilation_cycle_length, have_wino=True, have_split=True):
-    """0 / 1: direct kernel (64- / 32-frame tiles), 2: Winograd kernel, 3: row-split kernel (small batches) -- what
-    set_diffnet_stack would pick."""
-    return int(_lib.lib().set_diffnet_stack_variant(int(B), int(T), int(dilation_cycle_length),
-                                                    int(bool(have_wino)) | (2 if have_split else 0)))
+class SplitRangeError(_lib.SetAmdError):
+    """An activation left the range of the fp16 operand splitting (the loop's output is not valid)."""
+
+
+_SPLIT_MODE_OVERRIDE = [None]
+
+
+def split_operand_mode():
+    """Which splitting the throughput stack kernel uses: 2 = two fp16 pieces (three MFMA products per term), 3 = three bf16
+    pieces (six products, fp32 range).  SET_AMD_SPLIT_OPERAND=bf16x3 / f16x2 overrides the default."""
+    if _SPLIT_MODE_OVERRIDE[0] is not None:
+        return _SPLIT_MODE_OVERRIDE[0]
+    v = os.environ.get("SET_AMD_SPLIT_OPERAND", "f16x2").lower()
+    if v not in ("f16x2", "bf16x3"):
+        raise ValueError("SET_AMD_SPLIT_OPERAND must be f16x2 or bf16x3, not %r" % v)
+    return 2 if v == "f16x2" else 3
+
+
+class split_operand_mode_as:
+    """with split_operand_mode_as(3): ...  -- pin the splitting for a block (the fallback of the reverse loop)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev, _SPLIT_MODE_OVERRIDE[0] = _SPLIT_MODE_OVERRIDE[0], self.mode
+
+    def __exit__(self, *exc):
+        _SPLIT_MODE_OVERRIDE[0] = self.prev
+
+
+def stack_variant(B, T, dilation_cycle_length, have_wino=True, have_split=True, x3_mode=None):
+    """0 / 1: direct kernel (64- / 32-frame tiles), 2: Winograd kernel, 3: row-split kernel (small batches), 4 / 5: split-operand
+    kernel (3 x bf16 / 2 x fp16) -- what set_diffnet_stack would pick.  x3_mode: 0 (no split-operand images), 2, 3, or None =
+    split_operand_mode()."""
+    m = split_operand_mode() if x3_mode is None else int(x3_mode)
+    bits = int(bool(have_wino)) | (2 if have_split else 0) | (4 if m == 3 else 0) | (8 if m == 2 else 0)
+    return int(_lib.lib().set_diffnet_stack_variant(int(B), int(T), int(dilation_cycle_length), bits))
+
+
+STACK_VARIANT_NAMES = {0: "diffnet_stack_kernel<2,4,2>", 1: "diffnet_stack_kernel<1,8,2>", 2: "diffnet_stack_wino_kernel",
+                       3: "diffnet_stack_split_kernel", 4: "diffnet_stack_x3_kernel<SplitBf16x3>",
+                       5: "diffnet_stack_x3_kernel<SplitF16x2>"}
+
+
+class SplitOperandImages:
+    """[L][n] 16-bit images of the split-operand stack kernel + the mode they were packed for."""
+
+    def __init__(self, L, mode, device):
+        self.mode = int(mode)
+        n = int(_lib.lib().set_diffnet_layer_x3_image_size(self.mode))
+        self.data = torch.empty(L, n, dtype=torch.int16, device=device)
+
+    def pack(self, i, w_dil, w_out):
+        """Layer i.  fp16 pieces: scale the weights by a power of two so that max |w| lands in [8, 16) (exact; undone on
+        the accumulators by the kernel) -- one host read-back per layer and weight version."""
+        _f(w_dil), _f(w_out)
+        k1 = k2 = 0
+        if self.mode == 2:
+            import math
+            m1, m2 = float(w_dil.abs().max()), float(w_out.abs().max())
+            k1 = max(-60, min(60, 3 - math.frexp(m1)[1] + 1)) if m1 > 0 and math.isfinite(m1) else 0
+            k2 = max(-60, min(60, 3 - math.frexp(m2)[1] + 1)) if m2 > 0 and math.isfinite(m2) else 0
+        check(_lib.lib().set_pack_diffnet_layer_x3(_p(w_dil), _p(w_out), self.data[i].data_ptr(), self.mode, k1, k2, _stream()),
+              "set_pack_diffnet_layer_x3")
 
 
 def split_images(w1p_all, w2p_all):
@@ -482,7 +542,10 @@ def split_images(w1p_all, w2p_all):
 def _split_images(a, packs, B, T, dcl, dev):
     """Row-split images + z workspace of the small-batch stack kernel into the args struct (only for shapes the kernel
     is picked for); returns the workspace (the caller keeps it alive; stream-ordered reuse is safe)."""
-    if len(packs) < 8 or packs[6] is None or stack_variant(B, T, dcl) != 3:
+    x3 = packs[8] if len(packs) >= 9 else None
+    if x3 is not None:
+        a.wx3_all, a.x3_mode = x3.data.data_ptr(), x3.mode
+    if len(packs) < 8 or packs[6] is None or stack_variant(B, T, dcl, x3_mode=x3.mode if x3 is not None else 0) != 3:
         return None
     a.w1s_all, a.w2s_all = packs[6].data_ptr(), packs[7].data_ptr()
     z_ws = torch.empty(B * ((T + 31) // 32) * 256 * 32, dtype=torch.float32, device=dev)
@@ -491,9 +554,9 @@ def _split_images(a, packs, B, T, dcl, dev):
 
 
 def diffnet_stack(xa, xb, skip, condproj, dstep_ptr, d_bs, d_cs, d_ls, packs, dilation_cycle_length, sync_ws=None,
-                  x_all=None, save_y=None, save_z=None):
+                  x_all=None, save_y=None, save_z=None, err_flag=None):
     """All L layers in one persistent launch.  condproj [B, L*512, T]; packs = (w1p_all, w2p_all, b_dil_all, b_out_all
-    [, w1w_all, w2w_all [, w1s_all, w2s_all]]).  Training forward (Winograd kernel only): x_all [L+1,B,256,T] (slab 0 = input) replaces the
+    [, w1w_all, w2w_all [, w1s_all, w2s_all [, wx3_all]]]).  Training forward (Winograd kernel only): x_all [L+1,B,256,T] (slab 0 = input) replaces the
     xa/xb ping-pong, save_y [L,B,512,T] / save_z [L,B,256,T] receive what the backward pass needs.
     Returns sync_ws (int32; [1] != 0 means a dependency wait timed out)."""
     _f(xa), _f(xb), _f(skip), _f(condproj)
@@ -513,6 +576,8 @@ def diffnet_stack(xa, xb, skip, condproj, dstep_ptr, d_bs, d_cs, d_ls, packs, di
     if x_all is not None:
         a.x_all, a.save_y, a.save_z = _f(x_all).data_ptr(), _f(save_y).data_ptr(), _f(save_z).data_ptr()
     z_ws = _split_images(a, packs, B, T, dilation_cycle_length, xa.device)  # noqa: F841 (kept alive until the launch is enqueued)
+    if err_flag is not None:  # optional sticky int32 error word (1: a dependency wait timed out, 2: out of the fp16 split range)
+        a.err_flag = err_flag.data_ptr()
     a.sync_ws = sync_ws.data_ptr()
     a.cp_bs, a.cp_ls = condproj.stride(0), 512 * T
     a.d_bs, a.d_cs, a.d_ls = int(d_bs), int(d_cs), int(d_ls)
@@ -636,8 +701,13 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs,
         loop_ms = C.c_float(0.0)
         a.loop_ms = C.pointer(loop_ms)
     check(_lib.lib().set_diffusion_loop(C.byref(a), _stream()), "set_diffusion_loop")
-    if a.persistent and bf16 is None and int(err.item()) != 0:  # (one 4-byte read-back per reverse loop; fail loudly, never return garbage)
-        raise _lib.SetAmdError("set_diffusion_loop: a tile dependency wait of the persistent layer-stack kernel timed out")
+    if a.persistent and bf16 is None:  # (one 4-byte read-back per reverse loop; fail loudly, never return garbage)
+        code = int(err.item())
+        if code == 2:
+            raise SplitRangeError("set_diffusion_loop: an activation of magnitude >= 32768 is outside the range of the fp16 "
+                                  "operand splitting; set SET_AMD_SPLIT_OPERAND=bf16x3 (fp32 range) or SET_AMD_X3=0")
+        if code != 0:
+            raise _lib.SetAmdError("set_diffusion_loop: a tile dependency wait of the persistent layer-stack kernel timed out")
     # the group chains are joined back into the current stream, so stream-ordered reuse of these buffers is safe
     if spans is None:
         return None

@@ -174,14 +174,28 @@ class GaussianDiffusion(nn.Module):
                         b_cond=torch.stack([l.conditioner_projection.bias for l in dn.residual_layers]).contiguous())
         condproj = dn.cond_projections(cond) if bf16 is None else None  # hoisted: independent of the step
         if dn.use_fused():
-            spans = ops.diffusion_loop(
-                x=x, noise=eps, seed=seed, condproj=condproj, dstep=dtab, coef4=coef4, bf16=bf16,
-                w_in=dn._w_in, b_in=dn.input_projection.bias,
-                packs=dn.fused_packs(),
-                w_skip=dn._w_skip, b_skip=dn.skip_projection.bias,
-                w_outp=dn._w_outp, b_outp=dn.output_projection.bias,
-                L=dn.n_layers, steps=steps, dilation_cycle_length=dn.dilation_cycle_length,
-                want_layer_spans=want_layer_spans, n_groups=n_groups, persistent=persistent)
+            def loop():
+                return ops.diffusion_loop(
+                    x=x, noise=eps, seed=seed, condproj=condproj, dstep=dtab, coef4=coef4, bf16=bf16,
+                    w_in=dn._w_in, b_in=dn.input_projection.bias,
+                    packs=dn.fused_packs(),
+                    w_skip=dn._w_skip, b_skip=dn.skip_projection.bias,
+                    w_outp=dn._w_outp, b_outp=dn.output_projection.bias,
+                    L=dn.n_layers, steps=steps, dilation_cycle_length=dn.dilation_cycle_length,
+                    want_layer_spans=want_layer_spans, n_groups=n_groups, persistent=persistent)
+            x_T = x.clone()  # [B, 80, T]: the loop updates x in place
+            try:
+                spans = loop()
+            except ops.SplitRangeError:
+                # an activation beyond the fp16 range of the two-piece splitting (never seen with trained weights; the
+                # kernel flags it instead of overflowing): repeat the loop from x_T on the three-piece bf16 splitting,
+                # which has fp32's range.  Same noise (explicit, or the same Philox stream), so nothing else changes.
+                import warnings
+                warnings.warn("spec_denoiser: activation outside the fp16 split range; repeating the reverse loop with the "
+                              "bf16x3 splitting")
+                x.copy_(x_T)
+                with ops.split_operand_mode_as(3):
+                    spans = loop()
             if spans is not None:
                 ret.update(spans)
         else:

@@ -466,6 +466,174 @@ def test_row_split_timeout_is_reported(dev, monkeypatch):
     assert _maxdiff(ok, g["mel_out"]) < 1e-4
 
 
+def _random_stack(dev, B, T, L, seed, x3_mode=3):
+    """Random layer stack: unpacked weights (for references) + every packed image set_diffnet_stack can use."""
+    from set_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(B, 256, T, generator=g).to(dev)
+    cp = (torch.randn(B, L * 512, T, generator=g) * 0.5).to(dev)
+    dtab = torch.randn(L * 256, 3, generator=g).to(dev)
+    w1 = torch.empty(L, 512 * 768, device=dev)
+    w2 = torch.empty(L, 512 * 256, device=dev)
+    wx3 = ops.SplitOperandImages(L, x3_mode, dev)
+    bd = (torch.randn(L, 512, generator=g) * 0.1).to(dev)
+    bo = (torch.randn(L, 512, generator=g) * 0.1).to(dev)
+    wds, wos = [], []
+    for l in range(L):
+        wd = (torch.randn(512, 256, 3, generator=g) / 27.7).to(dev)
+        wo = (torch.randn(512, 256, 1, generator=g) / 16.0).to(dev)
+        ops.pack_diffnet_layer(wd, wo, w1[l], w2[l])
+        wx3.pack(l, wd, wo)
+        wds.append(wd), wos.append(wo)
+    packs = (w1, w2, bd, bo, None, None) + ops.split_images(w1, w2) + (wx3,)
+    return x0, cp, dtab, packs, wds, wos, bd, bo
+
+
+@pytest.mark.parametrize("x3_mode", [2, 3])
+def test_x3_stack_matches_fp32_stack_and_fp64(dev, monkeypatch, x3_mode):
+    """The split-operand kernel (every fp32 operand = two fp16 / three bf16 pieces, three / six 16-bit MFMAs per product,
+    fp32 accumulate) against the fp32-MFMA direct kernel on the same weights: equal to fp32 rounding, run-to-run
+    bit-identical, no time-out; and against an fp64 evaluation of the same layers (diffnet.py:60-81): its error is not
+    larger than the fp32 kernel's (bf16x3) / than 1.5 x the fp32 kernel's (f16x2) -- an fp32-equivalent path, not a
+    reduced-precision one."""
+    from set_amd import ops
+    import torch.nn.functional as F
+    for (B, T, L, dcl, reps) in ((32, 800, 20, 1, 3), (3, 203, 5, 3, 2), (2, 65, 3, 1, 2), (1, 1, 2, 1, 1), (5, 66, 8, 4, 2),
+                                 (2, 1548, 2, 2, 1)):
+        x0, cp, dtab, packs, wds, wos, bd, bo = _random_stack(dev, B, T, L, B * 1000 + T + 11, x3_mode)
+        col = 1
+
+        def run(x3):
+            monkeypatch.setenv("SET_AMD_X3", x3)
+            monkeypatch.setenv("SET_AMD_SPLIT", "0")
+            assert ops.stack_variant(B, T, dcl, have_wino=False, x3_mode=x3_mode) == (
+                (7 - x3_mode) if x3 == "2" else (0 if B * ((T + 63) // 64) >= 768 else 1))
+            xa, xb, skip = x0.clone(), torch.full_like(x0, float("nan")), torch.full_like(x0, float("nan"))
+            ws = ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4 * col, 0, 3, 256 * 3, packs, dcl)
+            torch.cuda.synchronize()
+            assert int(ws[1]) == 0, "dependency wait timed out"
+            return (xb if L % 2 else xa).clone(), skip.clone()
+
+        x_ref, s_ref = run("0")
+        first = None
+        for rep in range(reps):
+            x, sk = run("2")
+            assert _maxdiff(x, x_ref) < 1e-5 * max(1.0, float(x_ref.abs().max())), (B, T)
+            assert _maxdiff(sk, s_ref) < 1e-5 * max(1.0, float(s_ref.abs().max())), (B, T)
+            if first is None:
+                first = (x, sk)
+            assert torch.equal(x, first[0]) and torch.equal(sk, first[1]), (B, T, rep)
+        if B * T <= 2048:  # fp64 evaluation on the device
+            xd, skd = x0.double(), torch.zeros_like(x0, dtype=torch.float64)
+            for l in range(L):
+                d = 1 << (l % dcl)
+                dv = dtab[l * 256:(l + 1) * 256, col].double()[None, :, None]
+                y = F.conv1d(xd + dv, wds[l].double(), bd[l].double(), padding=d, dilation=d) + cp[:, l * 512:(l + 1) * 512].double()
+                z = torch.sigmoid(y[:, :256]) * torch.tanh(y[:, 256:])
+                o = F.conv1d(z, wos[l].double(), bo[l].double())
+                xd, skd = (xd + o[:, :256]) / 2 ** 0.5, skd + o[:, 256:]
+            e32 = max(float((x_ref.double() - xd).abs().max()), float((s_ref.double() - skd).abs().max()))
+            e3 = max(float((first[0].double() - xd).abs().max()), float((first[1].double() - skd).abs().max()))
+            print("stack (%d, %d, L=%d): max err vs fp64: fp32 kernel %.3e, split-operand kernel (mode %d) %.3e" % (
+                B, T, L, e32, x3_mode, e3))
+            assert e3 < (1.0 if x3_mode == 3 else 1.5) * e32 + 1e-7, (B, T, e3, e32)
+    monkeypatch.delenv("SET_AMD_X3")
+    monkeypatch.delenv("SET_AMD_SPLIT")
+
+
+@pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("case", ["infer_tiny", "infer_pad", "infer_drift100", "infer_dil"])
+def test_full_inference_matches_reference_with_split_operand_kernel_forced(dev, monkeypatch, case, split):
+    """The parity bar (|dmel| < 1e-4 against the reference's output, 100-step drift case included) with every DiffNet
+    stack pass on the split-operand kernel (these small batches would otherwise take the row-split fp32 kernel)."""
+    monkeypatch.setenv("SET_AMD_X3", "2")
+    monkeypatch.setenv("SET_AMD_SPLIT", "0")
+    monkeypatch.setenv("SET_AMD_SPLIT_OPERAND", split)
+    g = load_golden(case)
+    m = g["meta"]
+    manifest = "spec_denoiser_dil" if case == "infer_dil" else "spec_denoiser"
+    model, W = _build_model(dev, manifest, m["wseed"], m["steps"], **m["overrides"])
+    inp, noises = _case_inputs(g, dev)
+    ret = model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"],
+                inp["f0"], inp["uv"], infer=True, noises=noises, persistent=True, **m["flags"])
+    torch.cuda.synchronize()
+    d = _maxdiff(ret["mel_out"], g["mel_out"])
+    monkeypatch.setenv("SET_AMD_X3", "0")
+    ret0 = model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"],
+                 inp["f0"], inp["uv"], infer=True, noises=noises, persistent=True, **m["flags"])
+    d0 = _maxdiff(ret0["mel_out"], g["mel_out"])
+    print("%s: max|dmel| vs the reference: split-operand kernel (%s) %.3e, fp32 kernel %.3e" % (case, split, d, d0))
+    assert d < 1e-4
+    assert _maxdiff(ret["mel_out"], ret0["mel_out"]) < 5e-5
+
+
+def test_f16x2_range_guard_is_loud(dev, monkeypatch):
+    """fp16 pieces cover |x| < 65504: an activation beyond 32768 must raise (sticky error word 2), never overflow silently;
+    the bf16x3 splitting has fp32's range and runs the same input."""
+    from set_amd import ops
+    B, T, L = 2, 130, 2
+    for mode in (2, 3):
+        x0, cp, dtab, packs, wds, wos, bd, bo = _random_stack(dev, B, T, L, 99, mode)
+        x0[1, 7, 60] = 5.0e4
+        monkeypatch.setenv("SET_AMD_X3", "2")
+        monkeypatch.setenv("SET_AMD_SPLIT", "0")
+        xa, xb, skip = x0.clone(), torch.empty_like(x0), torch.empty_like(x0)
+        from set_amd import _lib
+        a_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4, 0, 3, 256 * 3, packs, 1, err_flag=a_err)
+        torch.cuda.synchronize()
+        assert int(ws[1]) == 0
+        assert int(a_err) == (2 if mode == 2 else 0)
+        if mode == 3:
+            assert torch.isfinite(xa).all() and torch.isfinite(skip).all()
+    monkeypatch.delenv("SET_AMD_X3")
+    monkeypatch.delenv("SET_AMD_SPLIT")
+
+
+def test_f16x2_range_fallback_repeats_the_loop_on_bf16x3(dev, monkeypatch):
+    """End to end: weights that drive the residual stream beyond the fp16 range make the two-piece kernel flag the loop;
+    GaussianDiffusion.forward then repeats it from x_T with the three-piece bf16 splitting (fp32 range) and returns exactly
+    what a run pinned to that splitting returns -- never an overflowed mel."""
+    g = load_golden("infer_tiny")
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"])
+    inp, noises = _case_inputs(g, dev)
+    args = (inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"], inp["uv"])
+    with torch.no_grad():
+        model.denoise_fn.input_projection.weight.mul_(2.0e5)
+    from set_amd import ops
+    ops.bump_weights_epoch()
+    monkeypatch.setenv("SET_AMD_SPLIT", "0")
+    monkeypatch.setenv("SET_AMD_X3", "2")
+    monkeypatch.setenv("SET_AMD_SPLIT_OPERAND", "bf16x3")
+    ref = model(*args, infer=True, noises=noises)["mel_out"]
+    monkeypatch.setenv("SET_AMD_SPLIT_OPERAND", "f16x2")
+    with pytest.warns(UserWarning, match="fp16 split range"):
+        out = model(*args, infer=True, noises=noises)["mel_out"]
+    assert torch.isfinite(out).all()
+    # (with activations of 1e5 the net is ill-conditioned -- kernels with different rounding drift apart -- so the check is
+    # against the kernel the fallback is supposed to have run, bit for bit)
+    assert torch.equal(out, ref)
+
+
+def test_split_operand_timeout_is_reported(dev, monkeypatch):
+    from set_amd._lib import SetAmdError
+    g = load_golden("infer_tiny")
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"])
+    inp, noises = _case_inputs(g, dev)
+    args = (inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"],
+            inp["uv"])
+    monkeypatch.setenv("SET_AMD_X3", "2")
+    monkeypatch.setenv("SET_AMD_SPLIT", "0")
+    monkeypatch.setenv("SET_AMD_FAULT_TILE", "0")
+    with pytest.raises(SetAmdError, match="timed out"):
+        model(*args, infer=True, noises=noises)
+    monkeypatch.delenv("SET_AMD_FAULT_TILE")
+    ok = model(*args, infer=True, noises=noises)["mel_out"]
+    assert _maxdiff(ok, g["mel_out"]) < 1e-4
+
+
 def test_winograd_stack_matches_direct_stack(dev, monkeypatch):
     """The Winograd F(2,3) persistent kernel (4 GEMMs over output pairs, filter transform folded into the packed
     weights) against the direct persistent kernel on the same weights: equal to fp32 rounding (not bit for bit: the
