@@ -199,9 +199,39 @@ __device__ __forceinline__ void pack8(const unsigned short (&p)[8][NP], u32x4_t 
         for (int e = 0; e < 4; ++e) u[q][e] = (unsigned)p[2 * e][q] | ((unsigned)p[2 * e + 1][q] << 16);
 }
 
-// one (layer, 64-frame tile) task; lds = NP pieces of (64 + 2 max_dil) rows + 256 floats
+// One (layer, 64-frame tile) task in two parts, so that the persistent kernel can order them around its dependency wait:
+//   x3_init  accumulators of GEMM 1 = b_dil + conditioner projection (fp32, hoisted out of the loop by the caller).  These
+//            loads come from HBM (the projection is streamed once per step) and depend on nothing the previous layer
+//            wrote: they are issued BEFORE the previous task's store drain and the wait for the producer tiles.
+//   x3_main  stage x, GEMM 1, gate, GEMM 2, epilogue (stores only; the caller drains and publishes)
+// lds = NP pieces of (64 + 2 max_dil) rows + 256 floats
+__device__ __forceinline__ void x3_init(const X3Tile &a, f32x16 (&acc)[2][2]) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int T = a.T;
+    const unsigned T4 = 4u * (unsigned)T;
+    const rsrc_t rcp = make_rsrc(a.cpb);
+    unsigned vo4[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) vo4[cb] = 4u * (unsigned)(4 * half * T + min(a.t0 + cb * 32 + l31, T - 1));
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const float *bd = a.b_dil + (rb ? XC : 0) + 32 * w;  // wave-uniform: scalar loads, no vector-memory slots
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned ur = (unsigned)((rb ? XC : 0) + 32 * w + urow(r));
+            const float blo = bd[urow(r)], bhi = bd[urow(r) + 4];
+            const float bias = half ? bhi : blo;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[rb][cb][r] = bias + buf_load(rcp, vo4[cb], ur * T4);
+        }
+    }
+}
+
 template <typename S>
-__device__ __forceinline__ void layer_tile_x3(const X3Tile &a, unsigned char *lds, unsigned piece_bytes, uint64_t *dbg, uint64_t &tprev) {
+__device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][2], unsigned char *lds, unsigned piece_bytes, uint64_t *dbg,
+                                        uint64_t &tprev) {
 #define X3_PHASE(p)                                           \
     if (dbg) {                                                \
         const uint64_t tn = __builtin_amdgcn_s_memtime();     \
@@ -216,20 +246,13 @@ __device__ __forceinline__ void layer_tile_x3(const X3Tile &a, unsigned char *ld
     const int T = a.T, t0 = a.t0, d = a.dil;
     float *dsh = reinterpret_cast<float *>(lds + NP * piece_bytes);
     const unsigned T4 = 4u * (unsigned)T;
-    const rsrc_t rx = make_rsrc(a.xin), rxo = make_rsrc(a.xout), rsk = make_rsrc(a.skp), rcp = make_rsrc(a.cpb);
-    const rsrc_t rbd = make_rsrc(a.b_dil), rbo = make_rsrc(a.b_out);
+    const rsrc_t rx = make_rsrc(a.xin), rxo = make_rsrc(a.xout), rsk = make_rsrc(a.skp);
     const rsrc_t rw = make_rsrc(a.img);
     const unsigned lane16 = 16u * (unsigned)lane;
-    const unsigned lb = 16u * (unsigned)half;
     auto row0 = [&](int rb) { return (rb ? XC : 0) + 32 * w; };
     // power-of-two scales of the two weight images (1 for bf16x3): {s1, 1/s1, s2, 1/s2}
     const float *sc = reinterpret_cast<const float *>(a.img + x_n1<S>() + x_n2<S>());
     const float s1 = sc[0], is1 = sc[1], s2 = sc[2], is2 = sc[3];
-
-    // ---- GEMM 1 accumulators start at s1 (b_dil + conditioner projection) (fp32, hoisted out of the loop by the caller).
-    //      These loads come from HBM (the projection is streamed once per step) and depend on nothing the previous layer
-    //      wrote: they are issued first and fly under the staging of the x tile.
-    f32x16 acc[2][2];
     bool tv[2];
     unsigned vo4[2];
 #pragma unroll
@@ -238,16 +261,6 @@ __device__ __forceinline__ void layer_tile_x3(const X3Tile &a, unsigned char *ld
         tv[cb] = t < T;
         vo4[cb] = 4u * (unsigned)(4 * half * T + min(t, T - 1));
     }
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned ur = (unsigned)(row0(rb) + urow(r));
-            const float bias = buf_load(rbd, lb, 4u * ur);
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[rb][cb][r] = bias + buf_load(rcp, vo4[cb], ur * T4);
-        }
-    __builtin_amdgcn_sched_barrier(0);
 
     // ---- stage x + d, split into its pieces: thread (frame row f, channel group cg of 32 channels); row j <-> frame
     //      t0 - d + j.  All loads of the main pass are issued before the first one is consumed.
@@ -259,10 +272,14 @@ __device__ __forceinline__ void layer_tile_x3(const X3Tile &a, unsigned char *ld
 #pragma unroll
             for (int q8 = 0; q8 < 4; ++q8) {  // 8 channels -> one 16-byte write per piece
                 unsigned short p[8][NP];
+                // step offsets d[c] of these 8 channels (wave-uniform address: LDS broadcast), read unconditionally
+                const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dsh + 32 * cg + 8 * q8);
+                const f32x4 d1 = *reinterpret_cast<const f32x4 *>(dsh + 32 * cg + 8 * q8 + 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = 8 * q8 + e;
-                    const float xv = valid ? v[c] + dsh[32 * cg + c] : 0.0f;
+                    const float xs = v[c] + (e < 4 ? d0[e & 3] : d1[e & 3]);  // select after: `valid ? load + .. : 0` branches per element
+                    const float xv = valid ? xs : 0.0f;
                     if constexpr (S::MODE == 2) amax = fmaxf(amax, fabsf(xv));
                     S::split(xv, p[e]);
                 }
@@ -326,7 +343,8 @@ __device__ __forceinline__ void layer_tile_x3(const X3Tile &a, unsigned char *ld
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * g + e;
-                const float z = tv[cb] ? fsig(acc[0][cb][r] * is1) * ftanh(acc[1][cb][r] * is1) : 0.0f;
+                const float zz = fsig(acc[0][cb][r] * is1) * ftanh(acc[1][cb][r] * is1);
+                const float z = tv[cb] ? zz : 0.0f;
                 S::split(z, p[e]);
             }
             const unsigned off = (unsigned)((cb * 32 + l31) * XR + (32 * w + 8 * g + 4 * half) * 2);
@@ -342,13 +360,16 @@ __device__ __forceinline__ void layer_tile_x3(const X3Tile &a, unsigned char *ld
     // ---- GEMM 2 accumulators: residual rows start at s2 (b_out + x), skip rows at s2 b_out (the running skip sum is added
     //      in the epilogue, after the x' stores are in flight)
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < 2; ++rb) {
+        const float *bo = a.b_out + row0(rb);  // wave-uniform: scalar loads
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float bias = buf_load(rbo, lb, 4u * (unsigned)(row0(rb) + urow(r)));
+            const float blo = bo[urow(r)], bhi = bo[urow(r) + 4];
+            const float bias = half ? bhi : blo;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) acc[rb][cb][r] = (rb == 0 ? bias + xres[cb][r] : bias) * s2;
         }
+    }
     // the running skip sum of this tile (written by this block's predecessor on the tile, one layer ago): fetched under GEMM 2
     float sk[2][16];
 #pragma unroll
@@ -392,37 +413,20 @@ template <typename S>
 __global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles, int ntasks,
                                                                    unsigned piece_bytes, int fault_tile) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int *s_task = reinterpret_cast<int *>(lds + S::NP * piece_bytes + XC * sizeof(float));
+    int *s_task = reinterpret_cast<int *>(lds + S::NP * piece_bytes + XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
     int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
     const int tid = threadIdx.x;
     uint64_t *dbg = (blockIdx.x == 0 && tid == 0) ? g_x3_phase_buf : nullptr;
     uint64_t tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
-    for (;;) {
-        __syncthreads();  // LDS (tile + task slot) of the previous task is free
-        if (tid == 0) {
-            int n = atomicAdd(counter, 1);
-            if (n < ntasks && n >= ntiles) {  // layer >= 1: wait for the three producer tiles of layer l - 1
-                const int l = n / ntiles, i = n - l * ntiles, j = i % tiles_per_utt;
-                unsigned spins = 0;
-                const int *f0 = done + i, *fl = done + (j > 0 ? i - 1 : i), *fr = done + (j < tiles_per_utt - 1 ? i + 1 : i);
-                for (;;) {
-                    const int v0 = ld_agent(f0), v1 = ld_agent(fl), v2 = ld_agent(fr);
-                    if (min(v0, min(v1, v2)) >= l) break;
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > X_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
-                        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (a.err_flag) __hip_atomic_store(a.err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        n = ntasks;
-                        break;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            *s_task = n;
-        }
-        __syncthreads();
-        const int n = __builtin_amdgcn_readfirstlane(*s_task);
-        if (n >= ntasks) break;
+    // Each block claims its NEXT task while the current one runs (the result is read at the end of the task), issues the
+    // next task's producer-independent loads before it drains the stores of the finished tile, and publishes that tile
+    // before it waits for its own producers.  Claiming ahead is deadlock-free: a block finishes its claims in claim order,
+    // and a claim only ever waits on earlier ones (same argument as diffnet_stack_wino_kernel).
+    if (tid == 0) s_task[0] = atomicAdd(counter, 1);
+    __syncthreads();
+    int n = __builtin_amdgcn_readfirstlane(s_task[0]);
+    int i_done = -1, l_done = 0;  // finished but not yet published tile of this block
+    while (n < ntasks) {
         const int l = n / ntiles, i = n - l * ntiles;
         const int b = i / tiles_per_utt, j = i - b * tiles_per_utt;
         X3Tile lt;
@@ -437,11 +441,56 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStac
         lt.b_out = a.b_out_all + (int64_t)l * 512;
         lt.err_flag = a.err_flag;
         lt.T = a.T; lt.t0 = j * X_NT; lt.dil = 1 << (l % a.dilation_cycle_length); lt.first = (l == 0);
-        layer_tile_x3<S>(lt, lds, piece_bytes, dbg, tprev);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: the tile is visible to every XCD
-        __syncthreads();
-        if (tid == 0 && !(l == 0 && i == fault_tile))
-            __hip_atomic_store(done + i, l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f32x16 acc[2][2];
+        x3_init(lt, acc);  // issued before the previous tile's store drain / publish and before the dependency wait
+        __builtin_amdgcn_sched_barrier(0);
+        // Lane 0 PEEKS at the three producer flags and claims the next task; both round trips overlap the store drain
+        // below.  Only a peek: this block's finished tile is not published yet, and a blocking wait here could wait on a
+        // tile that (transitively) waits on ours.  If the producers are not there yet, the blocking wait follows the publish.
+        const int *f0 = done + i, *fl = done + (j > 0 ? i - 1 : i), *fr = done + (j < tiles_per_utt - 1 ? i + 1 : i);
+        int peek = l, claimed = 0;
+        if (tid == 0) {
+            if (l > 0) peek = min(ld_agent(f0), min(ld_agent(fl), ld_agent(fr)));
+            claimed = atomicAdd(counter, 1);
+        }
+        if (dbg) { const uint64_t tn = __builtin_amdgcn_s_memtime(); dbg[11] += tn - tprev; tprev = tn; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: the finished tile is visible to every XCD
+        if (dbg) { const uint64_t tn = __builtin_amdgcn_s_memtime(); dbg[12] += tn - tprev; tprev = tn; }
+        if (tid == 0) {
+            if (peek >= l) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_task[0] = claimed;
+            s_task[1] = peek >= l ? 1 : 2;
+        }
+        __syncthreads();  // (also: the LDS tile is free)
+        if (tid == 0 && i_done >= 0 && !(l_done == 0 && i_done == fault_tile))
+            __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        i_done = -1;
+        if (__builtin_amdgcn_readfirstlane(s_task[1]) == 2) {  // producers not finished at the peek: wait for them now
+            if (tid == 0) {
+                int ok = 1;
+                unsigned spins = 0;
+                for (;;) {
+                    const int v0 = ld_agent(f0), v1 = ld_agent(fl), v2 = ld_agent(fr);
+                    if (min(v0, min(v1, v2)) >= l) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > X_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
+                        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (a.err_flag) __hip_atomic_store(a.err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                s_task[2] = ok;
+            }
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(s_task[2]) == 0) break;
+        }
+        const int n_next = __builtin_amdgcn_readfirstlane(s_task[0]);
+        x3_main<S>(lt, acc, lds, piece_bytes, dbg, tprev);
+        i_done = i;
+        l_done = l;
+        n = n_next;
         if (dbg) {
             const uint64_t tn = __builtin_amdgcn_s_memtime();
             dbg[5] += tn - tprev;
@@ -449,6 +498,11 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStac
             tprev = tn;
         }
     }
+    // the last finished tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && i_done >= 0 && !(l_done == 0 && i_done == fault_tile))
+        __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <typename S>
@@ -465,7 +519,7 @@ int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_
     SET_REQUIRE((int64_t)2 * XC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_stack(split-operand kernel: T too large)");
     const int max_dil = 1 << (a.dilation_cycle_length - 1);
     const unsigned piece_bytes = (unsigned)((X_NT + 2 * max_dil) * XR);
-    const size_t ldsz = (size_t)S::NP * piece_bytes + XC * sizeof(float) + 16;
+    const size_t ldsz = (size_t)S::NP * piece_bytes + XC * sizeof(float) + 16;  // + task slots
     SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
     int grid = n_cu;
     if (grid > ntiles * 4 / 5) grid = ntiles * 4 / 5;  // workers stay below the runnable-task count (see diffnet.hip)

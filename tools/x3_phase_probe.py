@@ -36,8 +36,8 @@ for B, T in [tuple(int(v) for v in s.split("x")) for s in os.environ.get("SIZES"
     _lib.lib().set_debug_x3_phase_buffer(None)
     us = e0.elapsed_time(e1) * 1000 / n
     st = buf.cpu().tolist()
-    tot = sum(st[:6]) + sum(st[8:11]); ntask = max(1, st[7])
-    NAMES = ("claim+wait", "stage", "gemm1", "gate:tail-barrier", "gemm2", "epi+publish", "-", "-", "gate:xres+barrier", "gate:math+lds", "gate:init")
+    tot = sum(st[:6]) + sum(st[8:13]); ntask = max(1, st[7])
+    NAMES = ("claim+wait", "stage", "gemm1", "gate:tail-barrier", "gemm2", "epi+publish", "-", "-", "gate:xres+barrier", "gate:math+lds", "gate:init", "boundary:issue", "boundary:drain")
     print("mode %d, ticks per us: %.1f" % (wx3.mode, tot / (us * n)))
     print("B=%d T=%d: %.1f us per 20-layer launch; block 0: %d tasks/launch, %.1f us per task | share: %s" % (
         B, T, us, ntask // n, us / (ntask / n), " ".join("%s %.1f%%" % (nm, 100.0 * v / tot) for nm, v in zip(NAMES, st) if nm != "-")))
