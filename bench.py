@@ -327,7 +327,8 @@ def run_infer(args, rank, world, dev):
     if os.path.exists(tfile):  # HBM bytes per launch from the PMC passes (tools/pmc_traffic.py), same kernel + shape
         with open(tfile) as f:
             tj = json.load(f)
-        traffic = tj.get(stack_kernel if persistent else "diffnet_layer_kernel")
+        key = stack_kernel if persistent else "diffnet_layer_kernel"
+        traffic = tj.get(key, tj.get(key.split("<")[0]))
     out = {
         "metric": "diffusion mel-frames/s (100-step p_sample, B=32/GPU, T=800)",
         "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -62,6 +62,10 @@ extern "C" {
 #define SET_IMPL_BF16 4  /* bf16 MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulate / epilogue / HBM tensors; `w` =
                             the image of set_pack_conv_weight_bf16; stride-1 output only.  The training rows' "bf16"
                             arithmetic (BASELINE configs[1]; the reference's autocast hooks: utils/commons/trainer.py:325,343) */
+#define SET_IMPL_F16X2 5 /* fp32 operands carried as two fp16 pieces, three fp16 MFMAs per product, fp32 accumulate (fp32-
+                          * equivalent results, see SetDiffnetStackArgs.wx3_all); `w` = the image of
+                          * set_pack_conv_weight_x2; no in_chan_add; an activation of magnitude >= 32768 raises the sticky
+                          * flag of set_conv_x2_range_flag (the caller repeats on an fp32 impl) */
 
 /* operand type selector of the training GEMMs */
 #define SET_DTYPE_F32 0
@@ -119,6 +123,15 @@ int64_t set_packed_conv_weight_size(int32_t Cout, int32_t Cin, int32_t K);
  * (rb < ceil(Cout/32), cp < CinP/2, CinP = Cin rounded up to 16). */
 int set_pack_conv_weight(const float *w, float *wp, int32_t Cout, int32_t Cin, int32_t K,
                          int64_t w_base, int64_t w_sco, int64_t w_sci, int64_t w_stap, void *stream);
+
+/* image for SET_IMPL_F16X2: [32-row block][16-channel group][tap][piece][lane][8 fp16] + 4 floats {2^k, 2^-k, 0, 0}; the
+ * weights are multiplied by 2^scale_exp before they are split (pick it so that max |w| 2^k is in [8, 16)); ..._size in fp16
+ * ELEMENTS */
+int64_t set_packed_conv_weight_x2_size(int32_t Cout, int32_t Cin, int32_t K);
+int set_pack_conv_weight_x2(const float *w, void *wp, int32_t Cout, int32_t Cin, int32_t K, int64_t w_base, int64_t w_sco,
+                            int64_t w_sci, int64_t w_stap, int32_t scale_exp, void *stream);
+/* *flag = sticky "an activation left the fp16 range of the F16X2 splitting" word (synchronises); reset != 0 clears it */
+int set_conv_x2_range_flag(int32_t *flag, int32_t reset);
 
 /* packed image for SET_IMPL_MFMA2 (layout depends on Cout, K and |dil| as well as on the weights) */
 int64_t set_packed_conv_weight_v2_size(int32_t Cout, int32_t Cin, int32_t K);

@@ -15,14 +15,14 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_PKG, "libset_amd.so")
-SOURCES = ["conv1d.hip", "glue.hip", "diffnet.hip", "diffnet_x3.hip", "train.hip", "attention.hip", "bf16.hip", "diffnet_bf16.hip"]
+SOURCES = ["conv1d.hip", "conv_x2.hip", "glue.hip", "diffnet.hip", "diffnet_x3.hip", "train.hip", "attention.hip", "bf16.hip", "diffnet_bf16.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
 # constants mirrored from set_amd.h
 OK, E_INVALID, E_UNSUPPORTED, E_LAUNCH = 0, -1, -2, -3
 ACT = dict(none=0, relu=1, gelu=2, tanh=3, softplus=4, mish=5, lrelu=6)
 PRO = dict(none=0, lrelu=1, div=2)
-IMPL_NAIVE, IMPL_MFMA, IMPL_MFMA2, IMPL_BF16 = 1, 2, 3, 4
+IMPL_NAIVE, IMPL_MFMA, IMPL_MFMA2, IMPL_BF16, IMPL_F16X2 = 1, 2, 3, 4, 5
 DTYPE_F32, DTYPE_BF16, DTYPE_BF16_G16, DTYPE_BF16_G16_X16 = 0, 1, 2, 3
 
 c_f32p = C.POINTER(C.c_float)
@@ -160,6 +160,9 @@ SIGNATURES = {
     "set_diffnet_w2p_size": (_I64, []),
     "set_pack_diffnet_layer": (C.c_int, [_V, _V, _V, _V, _V]),
     "set_diffnet_stack_variant": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "set_packed_conv_weight_x2_size": (C.c_int64, [_I32, _I32, _I32]),
+    "set_pack_conv_weight_x2": (C.c_int, [_V, _V, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I32, _V]),
+    "set_conv_x2_range_flag": (C.c_int, [C.POINTER(C.c_int32), _I32]),
     "set_diffnet_layer_x3_image_size": (C.c_int64, [_I32]),
     "set_pack_diffnet_layer_x3": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _V]),
     "set_diffnet_w1w_size": (_I64, []),

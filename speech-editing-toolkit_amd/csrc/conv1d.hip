@@ -561,6 +561,7 @@ extern "C" int set_pack_conv_weight(const float *w, float *wp, int32_t Cout, int
 }
 
 int set_conv1d_bf16_dispatch(const SetConv1dArgs &a, hipStream_t s);  // bf16.hip
+int set_conv1d_x2_dispatch(const SetConv1dArgs &a, hipStream_t s);    // csrc/conv_x2.hip
 
 extern "C" int set_conv1d(const SetConv1dArgs *args, void *stream) {
     SET_REQUIRE(args != nullptr, "set_conv1d");
@@ -572,6 +573,7 @@ extern "C" int set_conv1d(const SetConv1dArgs *args, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     if (a.impl == SET_IMPL_MFMA2) return launch_conv_v2(a, s);
     if (a.impl == SET_IMPL_BF16) return set_conv1d_bf16_dispatch(a, s);
+    if (a.impl == SET_IMPL_F16X2) return set_conv1d_x2_dispatch(a, s);
     if (a.impl != SET_IMPL_MFMA) {
         const int64_t total = (int64_t)a.B * a.Cout * a.T_iter;
         hipLaunchKernelGGL(conv1d_naive_kernel, dim3(set_blocks(total, 256)), dim3(256), 0, s, a);

@@ -1087,15 +1087,20 @@ static int stack_variant(int B, int T, int dcl, bool have_wino, bool have_split,
     const int64_t tiles64 = (int64_t)B * ((T + 63) / 64);
     // row-split kernel: 4 blocks per 32-frame tile, all co-resident (2 per CU); SET_AMD_SPLIT=0 disables, =2 forces it
     // (when it fits); an explicit SET_AMD_WINO choice also rules it out
-    const bool split_fits = have_split && dcl <= 4 && 4 * (int64_t)B * ((T + 31) / 32) <= 2 * (int64_t)n_cu;
+    // (measured at T = 800: one utterance 75 ms per 100 steps, two 79 ms; from three utterances on two blocks would share a CU
+    // and the split-operand kernel, ~123 ms whatever the batch up to B = 16, is the faster one)
+    const int64_t split_blocks = 4 * (int64_t)B * ((T + 31) / 32);
+    const bool split_fits = have_split && dcl <= 4 && split_blocks <= 2 * (int64_t)n_cu;        // co-residency
+    const bool split_pays = split_blocks <= (int64_t)(have_x3 ? 1 : 2) * n_cu;
     int split_env = 1;
     if (const char *e = getenv("SET_AMD_SPLIT")) split_env = atoi(e);
-    if (split_fits && (split_env == 2 || (split_env == 1 && !getenv("SET_AMD_WINO")))) return 3;
-    // split-operand (3 x bf16) kernel: the throughput kernel from the same crossover as the Winograd kernel; SET_AMD_X3=0
-    // disables, =2 forces it at any size; an explicit SET_AMD_WINO choice also rules it out
+    if (split_fits && (split_env == 2 || (split_env == 1 && !getenv("SET_AMD_WINO") && split_pays))) return 3;
+    // split-operand kernel: every batch the row-split kernel does not take (a task is 61 us against 77 us for a 32-frame
+    // task of the direct fp32 kernel, so it wins even when the chip is far from full; tiny inputs stay on the fp32 kernels);
+    // SET_AMD_X3=0 disables, =2 forces it at any size; an explicit SET_AMD_WINO choice also rules it out
     int x3_env = 1;
     if (const char *e = getenv("SET_AMD_X3")) x3_env = atoi(e);
-    if (have_x3 && dcl <= 4 && (x3_env == 2 || (x3_env == 1 && !getenv("SET_AMD_WINO") && 25 * tiles64 >= 17 * n_cu)))
+    if (have_x3 && dcl <= 4 && (x3_env == 2 || (x3_env == 1 && !getenv("SET_AMD_WINO") && tiles64 >= 8)))
         return x3_mode == 3 ? 4 : 5;
     int ncb = tiles64 < 3 * n_cu ? 1 : 2;
     if (const char *e = getenv("SET_AMD_STACK_NCB")) ncb = atoi(e) == 2 ? 2 : 1;

@@ -126,6 +126,22 @@ class HifiGanGenerator(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, f0=None):
+        """The wide convolutions run on the two-piece fp16 kernel (fp32 operands split into two fp16 values, three MFMAs per
+        product, fp32 accumulate: fp32-equivalent results, csrc/conv_x2.hip; SET_AMD_VOCODER_SPLIT=0 keeps the fp32 MFMA
+        kernels).  Should an activation leave the fp16 range of the splitting (|x| >= 32768; never seen with real
+        checkpoints), the kernels raise a flag instead of overflowing and the forward is repeated on the fp32 kernels."""
+        import os
+        if os.environ.get("SET_AMD_VOCODER_SPLIT", "1") != "0":
+            ops.conv_x2_range_flag(reset=True)
+            with ops.split_convs():
+                y = self._forward(x)
+            if not ops.conv_x2_range_flag(reset=True):
+                return y
+            import warnings
+            warnings.warn("HifiGanGenerator: activation outside the fp16 split range; repeating on the fp32 kernels")
+        return self._forward(x)
+
+    def _forward(self, x):
         x = x.contiguous()
         x = ops.conv1d(x, self._pre.conv_weight(), self.conv_pre.bias.data, pad=3)
         for i in range(self.num_upsamples):

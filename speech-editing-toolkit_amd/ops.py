@@ -154,6 +154,22 @@ class ConvWeight:
             self._packed16 = (key, wp)
         return self._packed16[1]
 
+    def packed_x2(self):
+        """Two-piece fp16 image for SET_IMPL_F16X2 (re-split from the fp32 master weights whenever they change); the weights
+        are scaled by a power of two so that max |w| lands in [8, 16): one host read-back per weight version."""
+        w = self.raw()
+        key = (w.data_ptr(), w._version, w.device, _WEIGHTS_EPOCH)
+        if getattr(self, "_packed_x2", None) is None or self._packed_x2[0] != key:
+            import math
+            n = _lib.lib().set_packed_conv_weight_x2_size(self.Cout, self.Cin, self.K)
+            wp = torch.empty(n, dtype=torch.float16, device=w.device)
+            m = float(w.abs().max())
+            k = max(-60, min(60, 4 - math.frexp(m)[1])) if m > 0 and math.isfinite(m) else 0
+            check(_lib.lib().set_pack_conv_weight_x2(_p(w), _p(wp), self.Cout, self.Cin, self.K, self.base, self.sco, self.sci,
+                                                     self.stap, k, _stream()), "set_pack_conv_weight_x2")
+            self._packed_x2 = (key, wp)
+        return self._packed_x2[1]
+
     def packed_v2(self, dil):
         """Image for the big-tile kernel (depends on |dil| through the LDS chunking)."""
         w = self.raw()
@@ -171,17 +187,49 @@ class ConvWeight:
         return ent[1]
 
 
+def f16x2_eligible(T_iter, Cout, Cin, K, dil):
+    """Shapes the two-piece fp16 conv kernel takes (and pays for): wide enough, receptive field <= 128 frames."""
+    return T_iter >= 64 and Cout >= 32 and Cin >= 32 and Cin * K >= 96 and (K - 1) * abs(dil) <= 128
+
+
+def conv_x2_range_flag(reset=True):
+    """True if an activation left the fp16 range of the F16X2 splitting since the last reset (synchronises the device)."""
+    v = C.c_int32(0)
+    check(_lib.lib().set_conv_x2_range_flag(C.byref(v), int(bool(reset))), "set_conv_x2_range_flag")
+    return bool(v.value)
+
+
 def bf16_eligible(T_iter, Cout, Cin, K, dil, out_stride=1, out_off=0):
     """Shapes the bf16 kernels take: enough reduction depth and rows for a 64x64 wave tile to pay, stride-1 output."""
     return (T_iter >= 32 and Cout >= 32 and Cin * K >= 64 and out_stride == 1 and out_off == 0
             and (K - 1) * abs(dil) <= 128)
 
 
-def _pick_impl(impl, T_iter, Cout=0, Cin=0, K=1, dil=1, out_stride=1, out_off=0):
+_AUTO_SPLIT = [False]
+
+
+class split_convs:
+    """with split_convs(): ...  -- inside, `auto` convolutions that are wide enough run on the two-piece fp16 kernel
+    (SET_IMPL_F16X2: fp32-equivalent results on the 16-bit MFMA pipe).  The caller checks conv_x2_range_flag() afterwards and
+    repeats the computation outside the scope if an activation left the fp16 range."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev, _AUTO_SPLIT[0] = _AUTO_SPLIT[0], self.on
+
+    def __exit__(self, *exc):
+        _AUTO_SPLIT[0] = self.prev
+
+
+def _pick_impl(impl, T_iter, Cout=0, Cin=0, K=1, dil=1, out_stride=1, out_off=0, chan_add=False):
     impl = impl or _DEFAULT_IMPL
     if impl == "auto":
         if T_iter < 16:
             return "naive"
+        if _AUTO_SPLIT[0] and not chan_add and f16x2_eligible(T_iter, Cout, Cin, K, dil):
+            return "f16x2"
         if _COMPUTE_DTYPE == "bf16" and bf16_eligible(T_iter, Cout, Cin, K, dil, out_stride, out_off):
             return "bf16"
         # big-tile kernel: measured (tools/conv_probe.py, profiles/r01_conv_probe.log) +2 % for the 3-tap convs with a
@@ -210,13 +258,15 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
     if out is None:
         out = torch.empty(B, weight.Cout, T_out, dtype=torch.float32, device=x.device)
     _fv(out, "out")
-    impl = _pick_impl(impl, T_iter, weight.Cout, Cin, weight.K, dil, out_stride, out_off)
+    impl = _pick_impl(impl, T_iter, weight.Cout, Cin, weight.K, dil, out_stride, out_off, in_chan_add is not None)
     a = SetConv1dArgs()
     a.inp = x.data_ptr()
     if impl == "mfma2":
         a.w = weight.packed_v2(dil).data_ptr()
     elif impl == "bf16":
         a.w = weight.packed_bf16().data_ptr()
+    elif impl == "f16x2":
+        a.w = weight.packed_x2().data_ptr()
     else:
         a.w = (weight.packed() if impl == "mfma" else weight.raw()).data_ptr()
     a.bias = _f(bias, "bias").data_ptr() if bias is not None else None
@@ -232,7 +282,7 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
     a.B, a.Cin, a.Cout, a.K, a.dil, a.pad = B, Cin, weight.Cout, weight.K, dil, pad
     a.T_in, a.T_iter, a.T_out, a.out_stride, a.out_off = T_in, T_iter, T_out, out_stride, out_off
     a.pro, a.act, a.accumulate = PRO[pro], ACT[act], int(bool(accumulate))
-    a.impl = {"mfma": IMPL_MFMA, "mfma2": IMPL_MFMA2, "bf16": IMPL_BF16}.get(impl, IMPL_NAIVE)
+    a.impl = {"mfma": IMPL_MFMA, "mfma2": IMPL_MFMA2, "bf16": IMPL_BF16, "f16x2": _lib.IMPL_F16X2}.get(impl, IMPL_NAIVE)
     a.pro_param, a.act_param, a.alpha = float(pro_param), float(act_param), float(alpha)
     a.out_div = float(out_div)
     assert not (out_div and not accumulate)

@@ -499,7 +499,7 @@ def test_x3_stack_matches_fp32_stack_and_fp64(dev, monkeypatch, x3_mode):
     from set_amd import ops
     import torch.nn.functional as F
     for (B, T, L, dcl, reps) in ((32, 800, 20, 1, 3), (3, 203, 5, 3, 2), (2, 65, 3, 1, 2), (1, 1, 2, 1, 1), (5, 66, 8, 4, 2),
-                                 (2, 1548, 2, 2, 1)):
+                                 (2, 1548, 2, 2, 1), (2, 800, 20, 1, 1)):  # the last one: full depth and length, vs fp64
         x0, cp, dtab, packs, wds, wos, bd, bo = _random_stack(dev, B, T, L, B * 1000 + T + 11, x3_mode)
         col = 1
 

@@ -1,0 +1,103 @@
+"""The two-piece fp16 conv kernel (SET_IMPL_F16X2, csrc/conv_x2.hip): fp32 operands split into two fp16 values, three fp16
+MFMAs per product, fp32 accumulate.  Against the fp32 MFMA kernel (same SetConv1dArgs semantics) and against fp64."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import set_amd  # noqa: F401
+    return torch.device("cuda:0")
+
+
+def _w(dev, Cout, Cin, K, seed, scale=None):
+    from set_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    w = (torch.randn(Cout, Cin, K, generator=g) * (scale if scale is not None else (Cin * K) ** -0.5)).to(dev)
+    return w, ops.ConvWeight(w, Cout, Cin, K)
+
+
+CASES = [  # B, Cin, Cout, K, dil, T, extras
+    (2, 256, 256, 3, 1, 300, {}),
+    (2, 256, 256, 11, 5, 257, dict(pro="lrelu", pro_param=0.1)),
+    (1, 128, 128, 7, 3, 1000, dict(pro="lrelu", pro_param=0.1, res=True)),
+    (3, 64, 64, 11, 1, 515, dict(pro="lrelu", pro_param=0.1, res=True, accumulate=True, out_div=3.0)),
+    (2, 32, 32, 3, 5, 700, dict(pro="lrelu", pro_param=0.1, res=True, accumulate=True)),
+    (2, 80, 512, 7, 1, 130, {}),
+    (1, 512, 256, 2, -1, 100, dict(pro="lrelu", pro_param=0.1)),        # one polyphase branch: negative dilation, pad 0
+    (2, 192, 384, 9, 1, 65, dict(act="gelu", mask=True)),
+    (1, 100, 70, 5, 2, 64, dict(act="relu", alpha=0.5)),                # ragged channel counts (padded rows / channels)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_f16x2_conv_matches_fp32_conv_and_fp64(dev, case):
+    from set_amd import ops
+    import torch.nn.functional as F
+    B, Cin, Cout, K, dil, T, ex = case
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + K)
+    x = torch.randn(B, Cin, T, generator=g).to(dev)
+    w, cw = _w(dev, Cout, Cin, K, 5)
+    bias = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    pad = (K - 1) * abs(dil) // 2 if dil > 0 else 0
+    T_out = T + 2 * pad - dil * (K - 1) if dil > 0 else T + K - 1
+    kw = dict(dil=dil, pad=pad, pro=ex.get("pro", "none"), pro_param=ex.get("pro_param", 0.0), act=ex.get("act", "none"),
+              alpha=ex.get("alpha", 1.0))
+    if dil < 0:
+        kw.update(T_iter=T + K - 1, T_out=T_out)
+    res = torch.randn(B, Cout, T_out, generator=g).to(dev) if ex.get("res") else None
+    mask = (torch.rand(B, T_out, generator=g) > 0.2).float().to(dev) if ex.get("mask") else None
+    prev = torch.randn(B, Cout, T_out, generator=g).to(dev)
+
+    def run(impl):
+        out = prev.clone()
+        ops.conv1d(x, cw, bias, res=res, mask=mask, out=out, accumulate=bool(ex.get("accumulate")),
+                   out_div=ex.get("out_div", 0.0), impl=impl, **kw)
+        return out
+
+    ops.conv_x2_range_flag(reset=True)
+    y32, y2 = run("mfma"), run("f16x2")
+    assert not ops.conv_x2_range_flag()
+    scale = float(y32.abs().max())
+    assert float((y2 - y32).abs().max()) < 2e-5 * max(1.0, scale), case
+    if ex.get("act", "none") in ("none", "relu") and dil > 0:
+        xd = x.double()
+        if kw["pro"] == "lrelu":
+            xd = F.leaky_relu(xd, kw["pro_param"])
+        yd = (F.conv1d(xd, w.double(), None, padding=pad, dilation=dil) + bias.double()[None, :, None]) * kw["alpha"]
+        if kw["act"] == "relu":
+            yd = yd.clamp_min(0)
+        if res is not None:
+            yd = yd + res.double()
+        if ex.get("accumulate"):
+            yd = yd + prev.double()
+            if ex.get("out_div"):
+                yd = yd / ex["out_div"]
+        e32, e2 = float((y32.double() - yd).abs().max()), float((y2.double() - yd).abs().max())
+        print("%s: max err vs fp64: fp32 MFMA kernel %.3e, f16x2 kernel %.3e" % (case[:6], e32, e2))
+        assert e2 < 1.5 * e32 + 1e-7
+
+
+def test_f16x2_conv_small_weights_and_range_flag(dev):
+    """Weights of magnitude 1e-4 (their fp16 residuals would be subnormal without the pack-time power-of-two scale) keep
+    fp32-level accuracy; an input beyond the fp16 range raises the sticky flag."""
+    from set_amd import ops
+    import torch.nn.functional as F
+    B, C, K, T = 2, 128, 3, 400
+    x = torch.randn(B, C, T, device=dev)
+    w, cw = _w(dev, C, C, K, 9, scale=1e-4)
+    ops.conv_x2_range_flag(reset=True)
+    y2 = ops.conv1d(x, cw, None, pad=1, impl="f16x2")
+    y32 = ops.conv1d(x, cw, None, pad=1, impl="mfma")
+    yd = F.conv1d(x.double(), w.double(), None, padding=1)
+    e32, e2 = float((y32.double() - yd).abs().max()), float((y2.double() - yd).abs().max())
+    assert e2 < 1.5 * e32 + 1e-12, (e2, e32)
+    assert not ops.conv_x2_range_flag()
+    x[1, 5, 77] = 4.0e4
+    ops.conv1d(x, cw, None, pad=1, impl="f16x2")
+    assert ops.conv_x2_range_flag(reset=True)
+    assert not ops.conv_x2_range_flag()

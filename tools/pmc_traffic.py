@@ -13,8 +13,11 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             name = r["Kernel_Name"]
-            for key in ("diffnet_stack_wino_kernel", "diffnet_stack_kernel", "diffnet_layer_kernel", "conv1d_mfma_kernel"):
+            for key in ("diffnet_stack_x3_kernel", "diffnet_stack_wino_kernel", "diffnet_stack_kernel", "diffnet_layer_kernel",
+                        "conv1d_mfma_kernel"):
                 if key in name and "pack_" not in name:
+                    if key == "diffnet_stack_x3_kernel":  # one entry per splitting
+                        key += "<SplitF16x2>" if "SplitF16x2" in name else "<SplitBf16x3>"
                     acc[key].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
