@@ -30,6 +30,9 @@ print("HiFi-GAN V1 B=%d T=%d: %.1f ms/forward, %.0f mel-frames/s, %.1f TFLOP/s (
 # ---- per-stage / per-resblock breakdown (set HSTAGES=1): where the forward time goes and at what MFMA rate
 if os.environ.get("HSTAGES"):
     from set_amd import ops
+    if os.environ.get("SET_AMD_VOCODER_SPLIT", "1") != "0":
+        ops.split_convs().__enter__()  # the stages below on the kernels the forward uses (two-piece fp16 convs)
+        print("(stages timed on the f16x2 conv kernel; TF/s = algorithmic fp32 FLOPs / time)")
 
     def timed(fn, n=3):
         fn()
