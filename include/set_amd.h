@@ -130,6 +130,16 @@ int set_pack_conv_weight(const float *w, float *wp, int32_t Cout, int32_t Cin, i
 int64_t set_packed_conv_weight_x2_size(int32_t Cout, int32_t Cin, int32_t K);
 int set_pack_conv_weight_x2(const float *w, void *wp, int32_t Cout, int32_t Cin, int32_t K, int64_t w_base, int64_t w_sco,
                             int64_t w_sci, int64_t w_stap, int32_t scale_exp, void *stream);
+/* nn.ConvTranspose1d(Cin, Cout, k, stride u, padding P) on the same kernel, EVERY output phase in one launch (the fp32 path
+ * runs one strided-output conv per phase): the rows of the GEMM are (channel, phase) pairs, so with u % 4 == 0 the four rows
+ * of an accumulator register group are four consecutive output samples -> 16-byte stores instead of stride-u scatters.
+ * w: the module's weight [Cin][Cout][k]; out[b][co][n] = bias[co] + sum_ci sum_j w[ci][co][u j + p] pro(in[b][ci][q - j]),
+ * n + P = u q + p (hifigan.py:114-115); in / out contiguous [B][C][T], T_out = (T_in - 1) u - 2 P + k. */
+int64_t set_packed_conv_transpose_x2_size(int32_t Cout, int32_t Cin, int32_t k, int32_t u);
+int set_pack_conv_transpose_x2(const float *w, void *wp, int32_t Cout, int32_t Cin, int32_t k, int32_t u, int32_t scale_exp,
+                               void *stream);
+int set_conv_transpose1d_x2(const float *in, const void *wp, const float *bias, float *out, int32_t B, int32_t Cin, int32_t Cout,
+                            int32_t k, int32_t u, int32_t P, int32_t T_in, int32_t pro, float pro_param, void *stream);
 /* *flag = sticky "an activation left the fp16 range of the F16X2 splitting" word (synchronises); reset != 0 clears it */
 int set_conv_x2_range_flag(int32_t *flag, int32_t reset);
 

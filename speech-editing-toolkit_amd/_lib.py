@@ -163,6 +163,9 @@ SIGNATURES = {
     "set_packed_conv_weight_x2_size": (C.c_int64, [_I32, _I32, _I32]),
     "set_pack_conv_weight_x2": (C.c_int, [_V, _V, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I32, _V]),
     "set_conv_x2_range_flag": (C.c_int, [C.POINTER(C.c_int32), _I32]),
+    "set_packed_conv_transpose_x2_size": (C.c_int64, [_I32, _I32, _I32, _I32]),
+    "set_pack_conv_transpose_x2": (C.c_int, [_V, _V, _I32, _I32, _I32, _I32, _I32, _V]),
+    "set_conv_transpose1d_x2": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _V]),
     "set_diffnet_layer_x3_image_size": (C.c_int64, [_I32]),
     "set_pack_diffnet_layer_x3": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _V]),
     "set_diffnet_w1w_size": (_I64, []),

@@ -510,7 +510,7 @@ class _DiffNetStackFn(torch.autograd.Function):
         y_all = torch.empty(L_, B, 2 * C_, T, dtype=torch.float32, device=dev)
         z_all = torch.empty(L_, B, C_, T, dtype=torch.float32, device=dev)
         skip = torch.empty(B, C_, T, dtype=torch.float32, device=dev)
-        ws = ops.diffnet_stack(x_all[0], x_all[1], skip, condproj, dmat.data_ptr(), L_ * C_, 1, C_, dn.fused_packs(),
+        ws = ops.diffnet_stack(x_all[0], x_all[1], skip, condproj, dmat.data_ptr(), L_ * C_, 1, C_, dn.fused_packs(inference=False),
                                dn.dilation_cycle_length, x_all=x_all, save_y=y_all, save_z=z_all)
         ctx.dn, ctx.ws = dn, ws
         ctx.save_for_backward(cond, dmat, x_all, y_all, z_all)

@@ -47,9 +47,11 @@ __device__ __forceinline__ float cx_pro(float v, float p) {
 static inline int cx_round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // image: [rb32 < CoutP/32][g16 < CinP/16][tap][piece][lane][8]; lane l holds row 32 rb32 + (l & 31), channel 16 g16 + 8 (l >> 5) + e
+// phases = u > 0 (all output phases of a ConvTranspose1d [Cin][Cout_t][kfull] in one image): row R = co * u + p, tap j ->
+// Wt[ci][co][u j + p] (zero beyond kfull); Cout counts these rows (= u * Cout_t).
 __global__ void __launch_bounds__(256) pack_conv_x2_kernel(const float *w, unsigned short *img, int Cout, int Cin, int K, int CoutP,
                                                            int CinP, int64_t n_frag_elems, int64_t w_base, int64_t w_sco,
-                                                           int64_t w_sci, int64_t w_stap, float scale) {
+                                                           int64_t w_sci, int64_t w_stap, float scale, int phases, int kfull) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per fragment element (both pieces)
     if (idx == 0) {
         float *tail = reinterpret_cast<float *>(img + 2 * n_frag_elems);
@@ -64,15 +66,25 @@ __global__ void __launch_bounds__(256) pack_conv_x2_kernel(const float *w, unsig
     const int g16 = (int)(r % ng16), rb = (int)(r / ng16);
     const int row = 32 * rb + (l & 31), ci = 16 * g16 + 8 * (l >> 5) + e;
     float v = 0.0f;
-    if (row < Cout && ci < Cin) v = scale * w[w_base + (int64_t)row * w_sco + (int64_t)ci * w_sci + (int64_t)tap * w_stap];
+    if (row < Cout && ci < Cin) {
+        if (phases > 0) {
+            const int co = row / phases, kk = phases * tap + row % phases;
+            if (kk < kfull) v = scale * w[(int64_t)ci * (Cout / phases) * kfull + (int64_t)co * kfull + kk];
+        } else {
+            v = scale * w[w_base + (int64_t)row * w_sco + (int64_t)ci * w_sci + (int64_t)tap * w_stap];
+        }
+    }
     const unsigned short p0 = cx_f2h(v), p1 = cx_f2h(v - cx_h2f(p0));
     unsigned short *base = img + ((((int64_t)rb * ng16 + g16) * K + tap) * 2) * 512 + l * 8 + e;
     base[0] = p0;
     base[512] = p1;
 }
 
-template <int WM, int WN, int RBW, int NCB>
-__global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int lo, int halo, int CinP, int CoutP) {
+// PH > 0: the rows are (output channel, phase) pairs of a transposed conv with stride PH (row R = co * PH + p); sample
+// t of row R is output sample n = t * PH + p - ph_pad of channel co.  With PH % 4 == 0 the four rows of a register group are
+// four CONSECUTIVE samples of one channel: one 16-byte store instead of four strided 4-byte ones.
+template <int WM, int WN, int RBW, int NCB, bool PHASES>
+__global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int lo, int halo, int CinP, int CoutP, int ph_u, int ph_pad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int MB = 32 * RBW * WM, NB = 32 * NCB * WN;
     constexpr int NPASS_MAX = (NB + 128 + 127) / 128;  // frame passes of 128 rows (halo <= 128)
@@ -212,6 +224,45 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
     }
     if (!(amax < 32768.0f)) __hip_atomic_store(&g_x2_range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
+    if constexpr (PHASES) {
+        // ---- transposed-conv epilogue: out[co][t u + p - P] = acc / scale + bias[co] ----
+        const rsrc_t d_o = make_rsrc(a.out + (int64_t)b * a.out_bs);
+        const int n_ch = a.Cout / ph_u;
+        const bool vec = (ph_u & 3) == 0 && (ph_pad & 3) == 0 && (a.out_cs & 3) == 0 && (a.T_out & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < RBW; ++i) {
+            if (r0 + (wm * RBW + i) * 32 >= a.Cout) continue;
+#pragma unroll
+            for (int j = 0; j < NCB; ++j) {
+                const int t = t0 + (wn * NCB + j) * 32 + l31;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int R0 = r0 + (wm * RBW + i) * 32 + 8 * g + 4 * half;  // rows R0 .. R0 + 3
+                    const int co = R0 / ph_u, p0 = R0 % ph_u;
+                    const float bias = a.bias ? a.bias[min(co, n_ch - 1)] : 0.0f;
+                    const int n0 = t * ph_u + p0 - ph_pad;
+                    if (vec) {
+                        if (t < a.T_iter && co < n_ch && n0 >= 0 && n0 + 3 < a.T_out) {
+                            f32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] * inv_scale + bias;
+                            buf_store4(o, d_o, (unsigned)(co * (int)a.out_cs + n0) * 4u, 0u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int R = R0 + e, c = R / ph_u, n = t * ph_u + R % ph_u - ph_pad;
+                            if (t < a.T_iter && c < n_ch && n >= 0 && n < a.T_out) {
+                                const float be = a.bias ? a.bias[c] : 0.0f;
+                                buf_store(acc[i][j][4 * g + e] * inv_scale + be, d_o, (unsigned)(c * (int)a.out_cs + n) * 4u, 0u);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue (fp32): v = act((acc / scale + bias) * alpha) + res ; * mask ; (+ previous output, / out_div) ----
     const bool has_div = a.accumulate && a.out_div != 0.0f;
     const bool has_res = a.res != nullptr, has_bias = a.bias != nullptr, has_acc = a.accumulate != 0;
@@ -274,20 +325,20 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
     }
 }
 
-template <int WM, int WN, int RBW, int NCB>
-int launch_conv_x2(const SetConv1dArgs &a, int lo, int halo, hipStream_t s) {
+template <int WM, int WN, int RBW, int NCB, bool PHASES = false>
+int launch_conv_x2(const SetConv1dArgs &a, int lo, int halo, hipStream_t s, int ph_u = 0, int ph_pad = 0) {
     constexpr int MB = 32 * RBW * WM, NB = 32 * NCB * WN;
     const int CinP = cx_round_up(a.Cin, CX_KCH), CoutP = cx_round_up(a.Cout, 32);
     const size_t lds = (size_t)2 * (NB + halo) * CX_ROWB;
     static bool attr_set = false;
     if (!attr_set) {
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1d_x2_kernel<WM, WN, RBW, NCB>),
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1d_x2_kernel<WM, WN, RBW, NCB, PHASES>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "conv x2 attr");
         attr_set = true;
     }
     if (lds > 96 * 1024) return set_fail(SET_E_UNSUPPORTED, "set_conv1d(f16x2)", "tile does not fit LDS");
     dim3 grid((a.T_iter + NB - 1) / NB, (a.Cout + MB - 1) / MB, a.B), block(256);
-    hipLaunchKernelGGL((conv1d_x2_kernel<WM, WN, RBW, NCB>), grid, block, lds, s, a, lo, halo, CinP, CoutP);
+    hipLaunchKernelGGL((conv1d_x2_kernel<WM, WN, RBW, NCB, PHASES>), grid, block, lds, s, a, lo, halo, CinP, CoutP, ph_u, ph_pad);
     return set_check_launch("set_conv1d(f16x2)");
 }
 
@@ -297,15 +348,53 @@ extern "C" int64_t set_packed_conv_weight_x2_size(int32_t Cout, int32_t Cin, int
     return (int64_t)2 * (cx_round_up(Cout, 32) / 32) * (cx_round_up(Cin, CX_KCH) / 16) * K * 512 + 8;  // fp16 elements (+ 4 floats)
 }
 
-extern "C" int set_pack_conv_weight_x2(const float *w, void *wp, int32_t Cout, int32_t Cin, int32_t K, int64_t w_base, int64_t w_sco,
-                                       int64_t w_sci, int64_t w_stap, int32_t scale_exp, void *stream) {
-    SET_REQUIRE(w && wp && Cout > 0 && Cin > 0 && K > 0 && scale_exp >= -60 && scale_exp <= 60, "set_pack_conv_weight_x2");
+static int pack_x2(const float *w, void *wp, int Cout, int Cin, int K, int64_t w_base, int64_t w_sco, int64_t w_sci, int64_t w_stap,
+                   int scale_exp, int phases, int kfull, void *stream, const char *what) {
+    SET_REQUIRE(w && wp && Cout > 0 && Cin > 0 && K > 0 && scale_exp >= -60 && scale_exp <= 60, what);
     const int CoutP = cx_round_up(Cout, 32), CinP = cx_round_up(Cin, CX_KCH);
     const int64_t n = (int64_t)(CoutP / 32) * (CinP / 16) * K * 512;
     hipLaunchKernelGGL(pack_conv_x2_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        reinterpret_cast<unsigned short *>(wp), Cout, Cin, K, CoutP, CinP, n, w_base, w_sco, w_sci, w_stap,
-                       ldexpf(1.0f, scale_exp));
-    return set_check_launch("set_pack_conv_weight_x2");
+                       ldexpf(1.0f, scale_exp), phases, kfull);
+    return set_check_launch(what);
+}
+
+extern "C" int set_pack_conv_weight_x2(const float *w, void *wp, int32_t Cout, int32_t Cin, int32_t K, int64_t w_base, int64_t w_sco,
+                                       int64_t w_sci, int64_t w_stap, int32_t scale_exp, void *stream) {
+    return pack_x2(w, wp, Cout, Cin, K, w_base, w_sco, w_sci, w_stap, scale_exp, 0, 0, stream, "set_pack_conv_weight_x2");
+}
+
+// ConvTranspose1d weight [Cin][Cout][k], stride u: image of the u * Cout (channel, phase) rows x ceil(k / u) taps
+extern "C" int64_t set_packed_conv_transpose_x2_size(int32_t Cout, int32_t Cin, int32_t k, int32_t u) {
+    return set_packed_conv_weight_x2_size(Cout * u, Cin, (k + u - 1) / u);
+}
+extern "C" int set_pack_conv_transpose_x2(const float *w, void *wp, int32_t Cout, int32_t Cin, int32_t k, int32_t u, int32_t scale_exp,
+                                          void *stream) {
+    SET_REQUIRE(u >= 1 && k >= u, "set_pack_conv_transpose_x2");
+    return pack_x2(w, wp, Cout * u, Cin, (k + u - 1) / u, 0, 0, 0, 0, scale_exp, u, k, stream, "set_pack_conv_transpose_x2");
+}
+
+/* nn.ConvTranspose1d(Cin, Cout, k, stride u, padding P) forward, every output phase in ONE launch: out[b][co][n] = bias[co] +
+ * sum_ci sum_j Wt[ci][co][u j + p] * pro(in[b][ci][q - j]),  n + P = u q + p  (hifigan.py:114-115).  in [B][Cin][T_in], out
+ * [B][Cout][T_out = (T_in - 1) u - 2 P + k] contiguous; wp = image of set_pack_conv_transpose_x2. */
+extern "C" int set_conv_transpose1d_x2(const float *in, const void *wp, const float *bias, float *out, int32_t B, int32_t Cin,
+                                       int32_t Cout, int32_t k, int32_t u, int32_t P, int32_t T_in, int32_t pro, float pro_param,
+                                       void *stream) {
+    SET_REQUIRE(in && wp && out && B > 0 && Cin > 0 && Cout > 0 && u >= 1 && k >= u && P >= 0 && T_in > 0, "set_conv_transpose1d_x2");
+    const int J = (k + u - 1) / u;
+    SetConv1dArgs a = {};
+    a.in = in; a.w = reinterpret_cast<const float *>(wp); a.bias = bias; a.out = out;
+    a.T_in = T_in; a.T_iter = T_in + J - 1; a.T_out = (T_in - 1) * u - 2 * P + k;
+    a.in_bs = (int64_t)Cin * T_in; a.in_cs = T_in; a.out_bs = (int64_t)Cout * a.T_out; a.out_cs = a.T_out;
+    a.B = B; a.Cin = Cin; a.Cout = Cout * u; a.K = J; a.dil = -1; a.pad = 0;
+    a.out_stride = u; a.out_off = -P; a.pro = pro; a.pro_param = pro_param; a.alpha = 1.0f; a.impl = SET_IMPL_F16X2;
+    SET_REQUIRE(a.T_out > 0, "set_conv_transpose1d_x2");
+    if (((int64_t)Cout * a.T_out) * 4 >= ((int64_t)1 << 31) || ((int64_t)Cin * T_in) * 4 >= ((int64_t)1 << 31))
+        return set_fail(SET_E_UNSUPPORTED, "set_conv_transpose1d_x2", "one batch slice of in / out exceeds 2 GiB");
+    const int lo = -(J - 1), halo = J - 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (a.Cout > 64) return launch_conv_x2<2, 2, 2, 2, true>(a, lo, halo, s, u, P);
+    return launch_conv_x2<1, 4, 2, 2, true>(a, lo, halo, s, u, P);
 }
 
 /* *flag = the sticky "an activation left the fp16 range of the splitting" word (synchronises the device); reset != 0 clears it */

@@ -87,16 +87,18 @@ class DiffNet(nn.Module):
             raise RuntimeError("fused DiffNet layer kernel needs residual_channels == 256 and dilation <= 8")
         return self.can_fuse()
 
-    def fused_packs(self):
-        """Contiguous [L][...] packed weights + biases for the fused layer / persistent stack kernels
-        (re-packed when any layer parameter changes)."""
+    def fused_packs(self, inference=True):
+        """Contiguous [L][...] packed weights + biases for the fused layer / persistent stack kernels (re-packed when any
+        layer parameter changes): (w1p, w2p, b_dil, b_out, w1w, w2w [Winograd], w1s, w2s [row-split], wx3 [split-operand]).
+        inference=False (the training forward, whose weights change every step): only what the Winograd training kernel
+        reads -- the last three are None (no extra 40 MB permutation and no per-layer scale read-backs per step)."""
         layers = list(self.residual_layers)
         key = tuple((p.data_ptr(), p._version) for l in layers for p in
                     (l.dilated_conv.weight, l.output_projection.weight, l.dilated_conv.bias, l.output_projection.bias))
-        key = key + (ops.weights_epoch(), ops.split_operand_mode())
+        key = key + (ops.weights_epoch(),)
+        dev = layers[0].dilated_conv.weight.device
+        L = len(layers)
         if self._packs is None or key != self._packs_key:
-            dev = layers[0].dilated_conv.weight.device
-            L = len(layers)
             w1 = torch.empty(L, 512 * 768, dtype=torch.float32, device=dev)
             w2 = torch.empty(L, 512 * 256, dtype=torch.float32, device=dev)
             for i, l in enumerate(layers):
@@ -110,14 +112,20 @@ class DiffNet(nn.Module):
                 for i, l in enumerate(layers):
                     ops.pack_diffnet_layer_wino(l.dilated_conv.weight.detach(), l.output_projection.weight.detach(),
                                                 w1w[i], w2w[i])
-            w1s, w2s = ops.split_images(w1, w2)  # small-batch (row-split) stack kernel
+            self._packs, self._packs_key = (w1, w2, bd, bo, w1w, w2w), key
+            self._packs_extra_key = None
+        if not inference:
+            return self._packs + (None, None, None)
+        ekey = key + (ops.split_operand_mode(),)
+        if getattr(self, "_packs_extra_key", None) != ekey:
+            w1s, w2s = ops.split_images(self._packs[0], self._packs[1])  # small-batch (row-split) stack kernel
             wx3 = None
             if self.dilation_cycle_length <= 4:  # split-operand images of the throughput kernel (csrc/diffnet_x3.hip)
                 wx3 = ops.SplitOperandImages(L, ops.split_operand_mode(), dev)
                 for i, l in enumerate(layers):
                     wx3.pack(i, l.dilated_conv.weight.detach(), l.output_projection.weight.detach())
-            self._packs, self._packs_key = (w1, w2, bd, bo, w1w, w2w, w1s, w2s, wx3), key
-        return self._packs
+            self._packs_extra, self._packs_extra_key = (w1s, w2s, wx3), ekey
+        return self._packs + self._packs_extra
 
     def bf16_layer_images(self):
         """Per-layer packed bf16 weight images of the fused training kernels (forward GEMM 1 / 2 and the three transposed
@@ -211,7 +219,7 @@ class DiffNet(nn.Module):
         # (the persistent Winograd stack kernel is an fp32-operand kernel: with bf16 operands the layers run op by op)
         use_stack = (self.can_fuse() and self.impl != "unfused" and os.environ.get("SET_AMD_TRAIN_STACK", "1") != "0"
                      and ops.compute_dtype() == "f32"
-                     and ops.stack_variant(x.shape[0], x.shape[2], self.dilation_cycle_length) == 2)
+                     and ops.stack_variant(x.shape[0], x.shape[2], self.dilation_cycle_length, have_split=False, x3_mode=0) == 2)
         use_bf16_layers = (self.can_fuse() and self.impl != "unfused" and ops.compute_dtype() == "bf16"
                            and self.encoder_hidden == 192 and os.environ.get("SET_AMD_TRAIN_STACK", "1") != "0"
                            and x.shape[2] >= 32)

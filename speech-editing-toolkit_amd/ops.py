@@ -299,6 +299,22 @@ def conv_transpose1d(x, w_getter, bias, Cin, Cout, k, stride, padding, *, pro="n
     T_out = (T_in - 1) * u - 2 * P + k
     out = torch.empty(B, Cout, T_out, dtype=torch.float32, device=x.device)
     phases = cache if cache is not None else {}
+    if impl is None and _AUTO_SPLIT[0] and Cin >= 32 and u * Cout >= 32 and T_in >= 64 and k >= u:
+        # split-operand scope: every phase in one launch on the two-piece fp16 kernel (contiguous 16-byte stores)
+        w = _f(ConvWeight(w_getter, Cout, Cin, k)._resolve(), "weight")
+        key = (w.data_ptr(), w._version, w.device, _WEIGHTS_EPOCH)
+        ent = phases.get("x2")
+        if ent is None or ent[0] != key:
+            import math
+            wp = torch.empty(_lib.lib().set_packed_conv_transpose_x2_size(Cout, Cin, k, u), dtype=torch.float16, device=w.device)
+            m = float(w.abs().max())
+            ke = max(-60, min(60, 4 - math.frexp(m)[1])) if m > 0 and math.isfinite(m) else 0
+            check(_lib.lib().set_pack_conv_transpose_x2(_p(w), _p(wp), Cout, Cin, k, u, ke, _stream()), "set_pack_conv_transpose_x2")
+            ent = phases["x2"] = (key, wp)
+        _f(x, "x")
+        check(_lib.lib().set_conv_transpose1d_x2(_p(x), _p(ent[1]), _p(bias) if bias is not None else None, _p(out), B, Cin, Cout, k,
+                                                 u, P, T_in, PRO[pro], float(pro_param), _stream()), "set_conv_transpose1d_x2")
+        return out
     for p in range(u):
         J = (k - p + u - 1) // u
         if J <= 0:

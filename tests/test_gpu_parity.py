@@ -434,7 +434,7 @@ def test_row_split_stack_bit_identical_to_layer_launches(dev, monkeypatch):
             h, nxt = nxt, h
         x_ref = h.clone()
         monkeypatch.setenv("SET_AMD_SPLIT", "2")
-        assert ops.stack_variant(B, T, dcl) == 3
+        assert ops.stack_variant(B, T, dcl, x3_mode=0) == 3
         for rep in range(reps):
             xa, xb, skip = x0.clone(), torch.full_like(x0, float("nan")), torch.full_like(x0, float("nan"))
             ws = ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4 * col, 0, 3, 256 * 3, packs, dcl)

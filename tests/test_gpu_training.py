@@ -593,3 +593,12 @@ def test_full_length_training_matches_oracle_on_two_utterances(dev):
         if k.startswith("denoise_fn.") or k.startswith("mel_encoder."):
             assert mx < 2e-4, (k, mx)
         assert nr < 2e-3 and mx < 5e-3, (k, mx, nr)
+
+
+def test_training_forward_uses_the_fused_stack_at_the_benchmark_size(dev):
+    """Regression guard: the fp32 training forward decides for the persistent Winograd stack kernel by asking the library
+    which fp32-pipe kernel it would pick; the inference-only kernels (row-split, split-operand) must not enter that answer."""
+    from set_amd import ops
+    assert ops.stack_variant(32, 800, 1, have_split=False, x3_mode=0) == 2
+    assert ops.stack_variant(32, 800, 1) in (4, 5)      # inference: the split-operand kernel
+    assert ops.stack_variant(1, 800, 1) == 3            # one utterance: the row-split kernel

@@ -101,3 +101,27 @@ def test_f16x2_conv_small_weights_and_range_flag(dev):
     ops.conv1d(x, cw, None, pad=1, impl="f16x2")
     assert ops.conv_x2_range_flag(reset=True)
     assert not ops.conv_x2_range_flag()
+
+
+@pytest.mark.parametrize("Cin,Cout,k,u,P,T,B", [(512, 256, 16, 8, 4, 100, 2), (128, 64, 4, 2, 1, 333, 2), (64, 32, 4, 2, 1, 1000, 1),
+                                                (256, 128, 8, 4, 2, 65, 3), (96, 48, 7, 3, 2, 200, 2)])
+def test_all_phase_transposed_conv_matches_polyphase_fp32_and_fp64(dev, Cin, Cout, k, u, P, T, B):
+    """nn.ConvTranspose1d with every output phase in one launch of the two-piece fp16 kernel (rows = (channel, phase), 16-byte
+    stores when the stride is a multiple of 4) against the fp32 path (one strided-output conv per phase) and fp64 torch."""
+    from set_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(Cin + k)
+    x = torch.randn(B, Cin, T, generator=g).to(dev)
+    w = (torch.randn(Cin, Cout, k, generator=g) * (Cin * k / u) ** -0.5).to(dev)
+    bias = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    y32 = ops.conv_transpose1d(x, w, bias, Cin, Cout, k, u, P, pro="lrelu", pro_param=0.1, cache={})
+    ops.conv_x2_range_flag(reset=True)
+    with ops.split_convs():
+        y2 = ops.conv_transpose1d(x, w, bias, Cin, Cout, k, u, P, pro="lrelu", pro_param=0.1, cache={})
+    assert not ops.conv_x2_range_flag()
+    assert y2.shape == y32.shape
+    yd = F.conv_transpose1d(F.leaky_relu(x.double(), 0.1), w.double(), bias.double(), stride=u, padding=P)
+    e32, e2 = float((y32.double() - yd).abs().max()), float((y2.double() - yd).abs().max())
+    print("convT %d->%d k%d s%d: max err vs fp64: fp32 polyphase %.3e, all-phase f16x2 %.3e" % (Cin, Cout, k, u, e32, e2))
+    assert float((y2 - y32).abs().max()) < 2e-5 * max(1.0, float(y32.abs().max()))
+    assert e2 < 1.5 * e32 + 1e-7
