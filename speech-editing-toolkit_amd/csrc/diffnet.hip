@@ -1117,6 +1117,7 @@ extern "C" int set_diffnet_stack_variant(int B, int T, int dilation_cycle_length
 }
 
 int set_launch_diffnet_stack_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s);  // csrc/diffnet_x3.hip
+int set_launch_diffnet_stack_split_x2(const SetDiffnetStackArgs &a, int fault_tile, hipStream_t s);      // csrc/diffnet_x3.hip
 
 extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) {
     SET_REQUIRE(args != nullptr, "set_diffnet_stack");
@@ -1153,6 +1154,8 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     int fault_tile = -1;  // test hook: never publish this tile of layer 0 (exercises the time-out / error path)
     if (const char *e = getenv("SET_AMD_FAULT_TILE")) fault_tile = atoi(e);
     if (variant >= 4) return set_launch_diffnet_stack_x3(a, n_cu, fault_tile, s);
+    if (variant == 3 && a.wx3_all && a.x3_mode == 2 && !(getenv("SET_AMD_SPLIT_F32") && atoi(getenv("SET_AMD_SPLIT_F32")) != 0))
+        return set_launch_diffnet_stack_split_x2(a, fault_tile, s);  // the same scheme on the two-piece fp16 operands
     if (variant == 3) {
         const int tiles = (a.T + 31) / 32, nt = a.B * tiles;
         SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + 2 * nt) * sizeof(int32_t), s), "set_diffnet_stack(memset)");

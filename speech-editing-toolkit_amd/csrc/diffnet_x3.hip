@@ -531,7 +531,281 @@ int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_
     return set_check_launch("set_diffnet_stack");
 }
 
+// =====================================================================================================================
+// Small batches: the row-split scheme of diffnet_stack_split_kernel (csrc/diffnet.hip: every 32-frame tile computed by FOUR
+// co-operating blocks, one 32-row block per wave, two counter rendezvous per layer) on the two-piece fp16 operands.  With a
+// handful of utterances the time of a layer is a chain of memory round trips plus ONE accumulator's MFMA chain per wave: on
+// the fp32 pipe that chain is 512 dependent MFMAs of 64 cycles (21 us of the 34 us per layer), here 192 of 32 cycles.
+//   block (tile i, part h), wave j: image block w8 = 2h + (j & 1), row block rb = j >> 1 (0: gate rows 32 w8 .., then
+//   residual rows; 1: the matching filter rows, then skip rows) -- the images of the throughput kernel, as they are.
+//   z crosses between the parts already split: z_ws slot of a tile = [piece][frame 32][256 channels] fp16 (32 KiB), written
+//   with 8-byte agent-scope stores of 4 channels, copied to LDS with 16-byte loads.
+// Same products in the same order per accumulator as diffnet_stack_x3_kernel<SplitF16x2>: bit-identical to it.
+// =====================================================================================================================
+constexpr unsigned SX_SPIN_LIMIT = 1u << 20;
+constexpr int SX_PF = 4;  // A prefetch distance in k-steps (2 x 16 bytes each).  The images are cold in L2 at every layer (42 MB
+                          // cycle through 4 MB per XCD), so a memory-side round trip per SX_PF k-steps bounds the GEMMs; deeper
+                          // rings (8, 16: spills), an LDS-fragment ring and an explicit L2 prefetch of the next layer's
+                          // slices were measured and were not faster end to end (61.8 ms per 100 steps at B = 1 as is)
+
+__device__ __forceinline__ bool sx_wait(const int *f0, const int *f1, const int *f2, int want, int *abort_flag, int *err_flag) {
+    unsigned spins = 0;
+    for (;;) {
+        const int v0 = ld_agent(f0), v1 = ld_agent(f1), v2 = ld_agent(f2);
+        if (min(v0, min(v1, v2)) >= want) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > SX_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
+            __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (err_flag) __hip_atomic_store(err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
+// acc += A B over NKS k-steps, ONE accumulator: A fragments of (k-step, piece) at abase + (ks * 4 + piece) * 1024 (the image's
+// [ks][rb][piece] order with this wave's rb folded into abase), ring of SX_PF k-steps (preloaded by the caller into A);
+// B piece q of k-step ks at lds + q * piece_bytes + bfrag(ks)
+template <int NKS, typename BF>
+__device__ __forceinline__ void sx_gemm(f32x16 &acc, u32x4_t (&A)[SX_PF][2], rsrc_t img, unsigned lane16, unsigned abase,
+                                        const unsigned char *lds, unsigned piece_bytes, BF bfrag) {
+    for (int kb = 0; kb < NKS; kb += SX_PF) {
+#pragma unroll
+        for (int p = 0; p < SX_PF; ++p) {
+            const int ks = kb + p;
+            const unsigned bo = bfrag(ks);
+            const u32x4_t b0 = *reinterpret_cast<const u32x4_t *>(lds + bo);
+            const u32x4_t b1 = *reinterpret_cast<const u32x4_t *>(lds + piece_bytes + bo);
+            const u32x4_t a0 = A[p][0], a1 = A[p][1];
+            const int kn = min(ks + SX_PF, NKS - 1);
+            A[p][0] = buf_load_u4(img, lane16, abase + (unsigned)(kn * 4 * 1024));
+            A[p][1] = buf_load_u4(img, lane16, abase + (unsigned)((kn * 4 + 1) * 1024));
+            acc = SplitF16x2::mma(a1, b0, acc);  // the order of SplitF16x2::qa / qb
+            acc = SplitF16x2::mma(a0, b1, acc);
+            acc = SplitF16x2::mma(a0, b0, acc);
+        }
+    }
+}
+__device__ __forceinline__ void sx_preload(u32x4_t (&A)[SX_PF][2], rsrc_t img, unsigned lane16, unsigned abase) {
+#pragma unroll
+    for (int p = 0; p < SX_PF; ++p) {
+        A[p][0] = buf_load_u4(img, lane16, abase + (unsigned)(p * 4 * 1024));
+        A[p][1] = buf_load_u4(img, lane16, abase + (unsigned)((p * 4 + 1) * 1024));
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) diffnet_stack_split_x2_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles,
+                                                                         unsigned piece_bytes, int fault_tile) {
+    typedef SplitF16x2 S;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // x tile pieces [2][32 + 2 maxd][XR]; z tile overlays it
+    float *gs = reinterpret_cast<float *>(lds + 2 * piece_bytes);       // [64][32] tanh(filter rows) of this part
+    float *dsh = gs + 64 * 32;                                          // [256] step offsets
+    int *s_ok = reinterpret_cast<int *>(dsh + XC);
+    int *abort_flag = a.sync_ws + 1, *ready = a.sync_ws + 4, *zcnt = a.sync_ws + 4 + ntiles;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const int b = i / tiles_per_utt, jt = i - b * tiles_per_utt;
+    const int T = a.T, t0 = jt * 32;
+    const int il = jt > 0 ? i - 1 : i, ir = jt < tiles_per_utt - 1 ? i + 1 : i;
+    const unsigned T4 = 4u * (unsigned)T;
+    const int w8 = 2 * h + (j & 1), rb = j >> 1;       // image block / row block of this wave
+    const int ch0 = 32 * w8;                          // its gate / residual / skip channel base; GEMM rows rb * 256 + ch0 ..
+    const int tq = t0 + l31;
+    const bool tv = tq < T;
+    const unsigned vo4 = 4u * (unsigned)(4 * half * T + min(tq, T - 1));
+    const unsigned lane16 = 16u * (unsigned)lane;
+    unsigned short *zt = reinterpret_cast<unsigned short *>(a.z_ws) + (int64_t)i * (2 * 32 * XC);  // [piece][frame][256]
+    const rsrc_t rz = make_rsrc(zt);
+    const rsrc_t rsk = make_rsrc(a.skip + (int64_t)b * XC * T);
+    uint64_t *dbg = (blockIdx.x == 5 && tid == 0) ? g_x3_phase_buf : nullptr;  // debug: phase ticks of one block, see below
+    uint64_t tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define SX_PHASE(p)                                           \
+    if (dbg) {                                                \
+        const uint64_t tn = __builtin_amdgcn_s_memtime();     \
+        dbg[p] += tn - tprev;                                 \
+        tprev = tn;                                           \
+    }
+    for (int l = 0; l < a.L; ++l) {
+        const int d = 1 << (l % a.dilation_cycle_length);
+        const unsigned short *img = reinterpret_cast<const unsigned short *>(a.wx3_all) + (int64_t)l * x_nimg<S>();
+        const rsrc_t rw = make_rsrc(img);
+        const float *sc = reinterpret_cast<const float *>(img + x_n1<S>() + x_n2<S>());
+        const float s1 = sc[0], is1 = sc[1], s2 = sc[2], is2 = sc[3];
+        const rsrc_t rxin = make_rsrc(((l & 1) ? a.xb : a.xa) + (int64_t)b * XC * T);
+        const rsrc_t rxout = make_rsrc(((l & 1) ? a.xa : a.xb) + (int64_t)b * XC * T);
+        const rsrc_t rcp = make_rsrc(a.condproj + (int64_t)l * a.cp_ls + (int64_t)b * a.cp_bs);
+        const float *dstep = a.dstep + (int64_t)l * a.d_ls + (int64_t)b * a.d_bs;
+        const float *bd = a.b_dil_all + (int64_t)l * 512 + rb * XC + ch0, *bo = a.b_out_all + (int64_t)l * 512 + rb * XC + ch0;
+        // ---- producer-independent loads first: A ring of GEMM 1, accumulator = b_dil + conditioner projection
+        u32x4_t A[SX_PF][2];
+        const unsigned ab1 = (unsigned)(((w8 * X_KS1) * 2 + rb) * 2 * 1024);
+        sx_preload(A, rw, lane16, ab1);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float blo = bd[urow(r)], bhi = bd[urow(r) + 4];
+            acc[r] = (half ? bhi : blo) + buf_load(rcp, vo4, (unsigned)(rb * XC + ch0 + urow(r)) * T4);
+        }
+        if (tid == 0) *s_ok = (l == 0 || sx_wait(ready + i, ready + il, ready + ir, 4 * l, abort_flag, a.err_flag)) ? 1 : 0;
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(*s_ok) == 0) return;
+        SX_PHASE(0)
+        // ---- stage x + d as two fp16 pieces: thread (frame row f, 32 channels cg); rows 32 .. 32 + 2d - 1 by the lanes f < 2d
+        {
+            const int f = tid & 31, cg = tid >> 5;  // 8 channel groups
+            dsh[tid] = dstep[(int64_t)tid * a.d_cs];
+            float amax = 0.0f;
+            auto put = [&](int row, const float (&v)[32], bool valid) {
+#pragma unroll
+                for (int q8 = 0; q8 < 4; ++q8) {
+                    unsigned short p[8][2];
+                    const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dsh + 32 * cg + 8 * q8);
+                    const f32x4 d1 = *reinterpret_cast<const f32x4 *>(dsh + 32 * cg + 8 * q8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xs = v[8 * q8 + e] + (e < 4 ? d0[e & 3] : d1[e & 3]);
+                        const float xv = valid ? xs : 0.0f;
+                        amax = fmaxf(amax, fabsf(xv));
+                        S::split(xv, p[e]);
+                    }
+                    u32x4_t u[2];
+                    pack8<2>(p, u);
+                    *reinterpret_cast<u32x4_t *>(lds + row * XR + (32 * cg + 8 * q8) * 2) = u[0];
+                    *reinterpret_cast<u32x4_t *>(lds + piece_bytes + row * XR + (32 * cg + 8 * q8) * 2) = u[1];
+                }
+            };
+            const int t = t0 - d + f, th = t0 - d + 32 + f;
+            const bool tvx = t >= 0 && t < T, has_h = f < 2 * d, tvh = th >= 0 && th < T;
+            const unsigned vox = 4u * (unsigned)min(max(t, 0), T - 1), voh = 4u * (unsigned)min(max(th, 0), T - 1);
+            float vx[32], vh[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) vx[k] = buf_load(rxin, vox, (unsigned)(32 * cg + k) * T4);
+            if (has_h) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) vh[k] = buf_load(rxin, voh, (unsigned)(32 * cg + k) * T4);
+            }
+            __syncthreads();  // dsh
+            put(f, vx, tvx);
+            if (has_h) put(32 + f, vh, tvh);
+            if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] *= s1;
+        __syncthreads();
+        SX_PHASE(1)
+        // ---- GEMM 1: one 32-row block of  y = Wdil (*) (x + d)
+        sx_gemm<X_KS1>(acc, A, rw, lane16, ab1, lds, piece_bytes, [&](int ks) {
+            return (unsigned)((l31 + (ks >> 4) * d) * XR + ((ks & 15) * 16 + half * 8) * 2);
+        });
+        SX_PHASE(2)
+        // ---- gate: the filter waves hand tanh(y_f) to the gate waves through LDS; z leaves already split
+        if (rb == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gs[(32 * (j & 1) + urow(r) + 4 * half) * 32 + l31] = ftanh(acc[r] * is1);
+        }
+        __syncthreads();  // gs complete; every wave is done reading the x tile
+        if (rb == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned short p[4][2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const float zz = fsig(acc[r] * is1) * gs[(32 * (j & 1) + urow(r) + 4 * half) * 32 + l31];
+                    S::split(tv ? zz : 0.0f, p[e]);
+                }
+                const unsigned off = (unsigned)(l31 * (XC * 2) + (ch0 + 8 * g + 4 * half) * 2);  // [frame][256] fp16, no padding
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    u32x2_t u;
+                    u[0] = (unsigned)p[0][q] | ((unsigned)p[1][q] << 16);
+                    u[1] = (unsigned)p[2][q] | ((unsigned)p[3][q] << 16);
+                    __builtin_amdgcn_raw_buffer_store_b64(u, rz, (int)(off + (unsigned)q * (32u * XC * 2u)), 0, 16);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the z rows of this wave are visible to every XCD
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(zcnt + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SX_PHASE(3)
+        // ---- GEMM 2: A ring + accumulator start (residual rows: b_out + x; skip rows: b_out, the running sum joins in the
+        //      epilogue) -- rows this very wave wrote one layer ago; the loads fly while lane 0 waits for the other parts' z
+        const unsigned ab2 = (unsigned)(x_n1<S>() * 2 + ((w8 * X_KS2) * 2 + rb) * 2 * 1024);
+        sx_preload(A, rw, lane16, ab2);
+        float prev[16];  // x rows (rb 0) / running skip sum (rb 1) of channels ch0 ..
+        {
+            const rsrc_t rp = make_rsrc(rb == 0 ? ((l & 1) ? a.xb : a.xa) + (int64_t)b * XC * T : a.skip + (int64_t)b * XC * T);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) prev[r] = buf_load(rp, vo4, (unsigned)(ch0 + urow(r)) * T4);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float blo = bo[urow(r)], bhi = bo[urow(r) + 4];
+            const float bias = half ? bhi : blo;
+            acc[r] = (rb == 0 ? bias + prev[r] : bias) * s2;
+        }
+        if (tid == 0) *s_ok = sx_wait(zcnt + i, zcnt + i, zcnt + i, 4 * (l + 1), abort_flag, a.err_flag) ? 1 : 0;
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(*s_ok) == 0) return;
+        SX_PHASE(4)
+        // ---- the whole z tile (two pieces, 32 frames x 512 bytes each) -> LDS rows of XR bytes
+        {
+            u32x4_t zv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) zv[k] = buf_load_u4(rz, 16u * (unsigned)tid, 4096u * (unsigned)k);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int unit = tid + 256 * k;            // 16-byte unit of the 32 KiB slot
+                const int q = unit >> 10, fr = (unit >> 5) & 31, part = unit & 31;
+                *reinterpret_cast<u32x4_t *>(lds + q * piece_bytes + fr * XR + part * 16) = zv[k];
+            }
+        }
+        __syncthreads();
+        SX_PHASE(5)
+        // ---- GEMM 2: one 32-row block of  o = Wout z
+        sx_gemm<X_KS2>(acc, A, rw, lane16, ab2, lds, piece_bytes, [&](int ks) {
+            return (unsigned)(l31 * XR + (ks * 16 + half * 8) * 2);
+        });
+        SX_PHASE(6)
+        // ---- epilogue
+        if (tv && rb == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) buf_store_agent((acc[r] * is2) * RSQRT2, rxout, vo4, (unsigned)(ch0 + urow(r)) * T4);
+        } else if (tv) {
+            const bool first = l == 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                buf_store(first ? acc[r] * is2 : acc[r] * is2 + prev[r], rsk, vo4, (unsigned)(ch0 + urow(r)) * T4);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every store of the block has completed; the LDS tile is free for the next layer
+        if (tid == 0 && !(l == 0 && i == fault_tile && h == 0))
+            __hip_atomic_fetch_add(ready + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SX_PHASE(7)
+    }
+#undef SX_PHASE
+}
+
 }  // namespace
+
+// called by set_diffnet_stack (csrc/diffnet.hip) for the row-split variant when two-piece fp16 images are given
+int set_launch_diffnet_stack_split_x2(const SetDiffnetStackArgs &a, int fault_tile, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_split_x2_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "set_diffnet_stack(split x2 attr)");
+        attr_set = true;
+    }
+    const int tiles = (a.T + 31) / 32, nt = a.B * tiles;
+    const int max_dil = 1 << (a.dilation_cycle_length - 1);
+    const unsigned piece_bytes = (unsigned)((32 + 2 * max_dil) * XR);
+    const size_t ldsz = (size_t)2 * piece_bytes + (64 * 32 + XC) * sizeof(float) + 16;
+    SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + 2 * nt) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
+    hipLaunchKernelGGL(diffnet_stack_split_x2_kernel, dim3(4 * nt), dim3(256), ldsz, s, a, tiles, nt, piece_bytes, fault_tile);
+    return set_check_launch("set_diffnet_stack");
+}
 
 extern "C" int set_debug_x3_phase_buffer(uint64_t *buf) {
     SET_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_x3_phase_buf), &buf, sizeof(buf)), "set_debug_x3_phase_buffer");

@@ -447,6 +447,41 @@ def test_row_split_stack_bit_identical_to_layer_launches(dev, monkeypatch):
     assert ops.stack_variant(8, 800, 1) != 3
 
 
+def test_row_split_f16x2_stack_bit_identical_to_split_operand_kernel(dev, monkeypatch):
+    """Small batches with two-piece fp16 images: the row-split scheme runs on the split operands (one accumulator per wave,
+    z exchanged already split).  Same products in the same order per accumulator as the throughput kernel -> bit-identical
+    to it, run after run, at one utterance of the benchmark length, ragged lengths, dilations 1..8; no time-out."""
+    from set_amd import ops
+    for (B, T, L, dcl, reps) in ((1, 800, 20, 1, 6), (2, 333, 6, 4, 3), (1, 31, 3, 2, 2), (3, 200, 4, 3, 2), (1, 1548, 3, 1, 1),
+                                 (1, 1, 2, 1, 1)):
+        x0, cp, dtab, packs, wds, wos, bd, bo = _random_stack(dev, B, T, L, B * 1000 + T + 3, 2)
+        col = 2
+
+        def run():
+            xa, xb, skip = x0.clone(), torch.full_like(x0, float("nan")), torch.full_like(x0, float("nan"))
+            ws = ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4 * col, 0, 3, 256 * 3, packs, dcl)
+            torch.cuda.synchronize()
+            assert int(ws[1]) == 0, "dependency wait timed out"
+            return (xb if L % 2 else xa).clone(), skip.clone()
+
+        monkeypatch.setenv("SET_AMD_SPLIT", "0")
+        monkeypatch.setenv("SET_AMD_X3", "2")
+        assert ops.stack_variant(B, T, dcl, x3_mode=2) == 5
+        x_ref, s_ref = run()
+        monkeypatch.setenv("SET_AMD_SPLIT", "2")
+        assert ops.stack_variant(B, T, dcl, x3_mode=2) == 3
+        for rep in range(reps):
+            x, sk = run()
+            assert torch.equal(sk, s_ref), (B, T, rep)
+            assert torch.equal(x, x_ref), (B, T, rep)
+        monkeypatch.setenv("SET_AMD_SPLIT_F32", "1")  # the fp32-pipe row-split kernel on the same inputs: fp32 rounding apart
+        x32, s32 = run()
+        assert _maxdiff(x32, x_ref) < 1e-5 * max(1.0, float(x_ref.abs().max()))
+        monkeypatch.delenv("SET_AMD_SPLIT_F32")
+    monkeypatch.delenv("SET_AMD_SPLIT")
+    monkeypatch.delenv("SET_AMD_X3")
+
+
 def test_row_split_timeout_is_reported(dev, monkeypatch):
     """Same error contract as the queue kernels: a part that never publishes (SET_AMD_FAULT_TILE) makes its neighbours
     give up after the spin limit, every block leaves, the reverse loop raises; the next call works."""
