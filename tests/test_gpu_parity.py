@@ -840,18 +840,24 @@ def test_fused_step_boundary_equals_separate_kernels(dev, monkeypatch, case):
         assert torch.equal(a, b), float((a - b).abs().max())
 
 
-def test_loop_persistent_equals_per_layer_launches(dev):
+def test_loop_persistent_equals_per_layer_launches(dev, monkeypatch):
+    """fp32-pipe kernels pinned (SET_AMD_X3=0, SET_AMD_SPLIT_F32=1): the persistent loop, with and without utterance
+    groups, is bit-identical to one launch per layer.  The default kernels (split operands) agree to fp32 rounding."""
     g = load_golden("infer_pad")
     m = g["meta"]
     model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"])
     inp, noises = _case_inputs(g, dev)
     args = (inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"],
             inp["uv"])
+    dflt = model(*args, infer=True, noises=noises, persistent=True)["mel_out"]
+    monkeypatch.setenv("SET_AMD_X3", "0")
+    monkeypatch.setenv("SET_AMD_SPLIT_F32", "1")
     a = model(*args, infer=True, noises=noises, persistent=False)["mel_out"]
     b = model(*args, infer=True, noises=noises, persistent=True)["mel_out"]
     c = model(*args, infer=True, noises=noises, persistent=True, n_groups=2)["mel_out"]
     assert torch.equal(a, b) and torch.equal(a, c)
     assert _maxdiff(a, g["mel_out"]) < 1e-4
+    assert _maxdiff(dflt, g["mel_out"]) < 1e-4 and _maxdiff(dflt, a) < 2e-5
 
 
 def test_utterance_groups_do_not_change_results(dev):
@@ -1014,9 +1020,10 @@ def test_full_size_properties(dev, monkeypatch):
 # ----------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,T,Tt,steps,pad", [(1, 5, 2, 3, False), (2, 31, 7, 2, True), (1, 33, 9, 2, False),
                                               (3, 65, 11, 2, True), (1, 1548, 120, 1, True), (5, 200, 40, 2, True)])
-def test_ragged_and_extreme_shapes_vs_oracle(dev, B, T, Tt, steps, pad):
-    """T below / across the 32- and 64-frame tile sizes, B=1, the reference's max_frames (1548), padded tails;
-    persistent and per-layer loops must agree with each other bit for bit and with the oracle to 1e-4."""
+def test_ragged_and_extreme_shapes_vs_oracle(dev, monkeypatch, B, T, Tt, steps, pad):
+    """T below / across the 32- and 64-frame tile sizes, B=1, the reference's max_frames (1548), padded tails: the default
+    kernels (split operands) against the oracle to 1e-4; with the fp32-pipe kernels pinned the persistent and per-layer
+    loops agree bit for bit."""
     model, W = _build_model(dev, "spec_denoiser", 40 + T, steps)
     inp = Wt.synthetic_inputs(B, T, Tt, seed=T, pad_tail=pad)
     noises = Wt.synthetic_noises(B, T, steps, seed=T + 1)
@@ -1024,8 +1031,14 @@ def test_ragged_and_extreme_shapes_vs_oracle(dev, B, T, Tt, steps, pad):
     nz = torch.stack(noises).to(dev)
     args = (d["txt_tokens"], d["time_mel_masks"], d["mel2ph"], d["spk_embed"], d["ref_mels"], d["f0"], d["uv"])
     a = model(*args, infer=True, noises=nz, persistent=True)
+    monkeypatch.setenv("SET_AMD_X3", "0")
+    monkeypatch.setenv("SET_AMD_SPLIT_F32", "1")
+    a32 = model(*args, infer=True, noises=nz, persistent=True)
     b = model(*args, infer=True, noises=nz, persistent=False)
-    assert torch.equal(a["mel_out"], b["mel_out"])
+    monkeypatch.delenv("SET_AMD_X3")
+    monkeypatch.delenv("SET_AMD_SPLIT_F32")
+    assert torch.equal(a32["mel_out"], b["mel_out"])
+    assert _maxdiff(a["mel_out"], b["mel_out"]) < 2e-5
     oret = O.gaussian_diffusion_infer(W, steps, inp, noises)
     assert torch.equal(a["mel2ph"].cpu(), oret["mel2ph"]) and torch.equal(a["pitch"].cpu(), oret["pitch"])
     assert torch.equal(a["masked_dur"].cpu(), oret["masked_dur"])
