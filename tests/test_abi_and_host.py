@@ -310,3 +310,37 @@ def test_embedding_validation_is_a_host_side_switch():
             ops.embedding_bct(torch.tensor([[0, 99]]), torch.zeros(80, 4))
     finally:
         ops.set_validate(False)
+
+
+def test_stack_kernel_selection_rules(built_lib, monkeypatch):
+    """Which persistent stack kernel set_diffnet_stack picks (host logic, no GPU needed; 256 CUs assumed off-device):
+    one block per CU of row-split work -> row-split; every other batch -> the split-operand kernel when its images are
+    given; without them the fp32-pipe rules of round 1; explicit environment choices pin the fp32 pipe."""
+    from set_amd import ops
+    for k in ("SET_AMD_X3", "SET_AMD_SPLIT", "SET_AMD_WINO", "SET_AMD_SPLIT_OPERAND", "SET_AMD_STACK_NCB"):
+        monkeypatch.delenv(k, raising=False)
+    assert ops.split_operand_mode() == 2
+    assert ops.stack_variant(1, 800, 1) == 3 and ops.stack_variant(2, 800, 1) == 3      # 100 / 200 blocks
+    assert ops.stack_variant(3, 800, 1) == 5 and ops.stack_variant(32, 800, 1) == 5      # two-piece fp16
+    assert ops.stack_variant(32, 800, 1, x3_mode=3) == 4                                # three-piece bf16
+    assert ops.stack_variant(32, 800, 1, x3_mode=0) == 2                                # fp32 pipe: Winograd
+    assert ops.stack_variant(8, 800, 1, have_split=False, x3_mode=0) == 1               # fp32 pipe: direct, 32-frame tiles
+    assert ops.stack_variant(4, 800, 1, x3_mode=0) == 3                                 # fp32 row-split: up to 2 blocks per CU
+    assert ops.stack_variant(32, 800, 5) == 0 or ops.stack_variant(32, 800, 5) == 1     # dilation 16: direct kernels only
+    monkeypatch.setenv("SET_AMD_X3", "0")
+    assert ops.stack_variant(32, 800, 1) == 2
+    monkeypatch.setenv("SET_AMD_X3", "2")
+    monkeypatch.setenv("SET_AMD_SPLIT", "0")
+    assert ops.stack_variant(1, 64, 1) == 5
+    monkeypatch.delenv("SET_AMD_X3")
+    monkeypatch.setenv("SET_AMD_WINO", "0")                                             # pins the fp32 direct kernels
+    assert ops.stack_variant(32, 800, 1) in (0, 1)
+    monkeypatch.delenv("SET_AMD_WINO")
+    monkeypatch.setenv("SET_AMD_SPLIT_OPERAND", "bf16x3")
+    assert ops.split_operand_mode() == 3 and ops.stack_variant(32, 800, 1) == 4
+    monkeypatch.setenv("SET_AMD_SPLIT_OPERAND", "fp8")
+    import pytest as _pt
+    with _pt.raises(ValueError):
+        ops.split_operand_mode()
+    with ops.split_operand_mode_as(3):
+        assert ops.split_operand_mode() == 3
