@@ -46,7 +46,6 @@ __device__ uint64_t *g_x3_phase_buf = nullptr;
 namespace {
 
 constexpr int XC = 256;            // residual channels
-constexpr int X_NT = 64;           // frames per tile
 constexpr int X_MAXD = 8;          // largest dilation
 constexpr int XR = XC * 2 + 16;    // bytes per LDS row
 constexpr int X_KS1 = 48;          // k-steps of GEMM 1 (3 taps x 16)
@@ -134,8 +133,8 @@ __global__ void __launch_bounds__(256) pack_layer_x3_kernel(const float *wdil, c
 // ---- the GEMM: acc[rb][cb] += sum over the piece products, smallest terms first ------------------------------------------
 //   A: image block of (ks, rb, piece) at byte offset abase + ((ks * 2 + rb) * NP + piece) * 1024 (+ lane * 16)
 //   B: piece q of this lane's fragment for (ks, cb) at lds + q * piece_bytes + bfrag(ks, cb)
-template <typename S, int NKS, typename BF>
-__device__ __forceinline__ void gemm_x3(f32x16 (&acc)[2][2], rsrc_t img, unsigned lane16, unsigned abase, const unsigned char *lds,
+template <typename S, int NKS, int NCB, typename BF>
+__device__ __forceinline__ void gemm_x3(f32x16 (&acc)[2][NCB], rsrc_t img, unsigned lane16, unsigned abase, const unsigned char *lds,
                                         unsigned piece_bytes, BF bfrag) {
     constexpr int NP = S::NP, X_PF = S::PF;
     u32x4_t A[X_PF][2][NP];
@@ -149,9 +148,9 @@ __device__ __forceinline__ void gemm_x3(f32x16 (&acc)[2][2], rsrc_t img, unsigne
 #pragma unroll
         for (int p = 0; p < X_PF; ++p) {
             const int ks = kb + p;  // NKS is a multiple of X_PF
-            u32x4_t Bv[2][NP];
+            u32x4_t Bv[NCB][NP];
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
+            for (int cb = 0; cb < NCB; ++cb) {
                 const unsigned bo = bfrag(ks, cb);
 #pragma unroll
                 for (int q = 0; q < NP; ++q) Bv[cb][q] = *reinterpret_cast<const u32x4_t *>(lds + q * piece_bytes + bo);
@@ -173,7 +172,7 @@ __device__ __forceinline__ void gemm_x3(f32x16 (&acc)[2][2], rsrc_t img, unsigne
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = S::mma(Ac[rb][S::qa(t)], Bv[cb][S::qb(t)], acc[rb][cb]);
+                    for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = S::mma(Ac[rb][S::qa(t)], Bv[cb][S::qb(t)], acc[rb][cb]);
             __builtin_amdgcn_s_setprio(0);
         }
     }
@@ -205,16 +204,17 @@ __device__ __forceinline__ void pack8(const unsigned short (&p)[8][NP], u32x4_t 
 //            wrote: they are issued BEFORE the previous task's store drain and the wait for the producer tiles.
 //   x3_main  stage x, GEMM 1, gate, GEMM 2, epilogue (stores only; the caller drains and publishes)
 // lds = NP pieces of (64 + 2 max_dil) rows + 256 floats
-__device__ __forceinline__ void x3_init(const X3Tile &a, f32x16 (&acc)[2][2]) {
+template <int NCB>
+__device__ __forceinline__ void x3_init(const X3Tile &a, f32x16 (&acc)[2][NCB]) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int T = a.T;
     const unsigned T4 = 4u * (unsigned)T;
     const rsrc_t rcp = make_rsrc(a.cpb);
-    unsigned vo4[2];
+    unsigned vo4[NCB];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) vo4[cb] = 4u * (unsigned)(4 * half * T + min(a.t0 + cb * 32 + l31, T - 1));
+    for (int cb = 0; cb < NCB; ++cb) vo4[cb] = 4u * (unsigned)(4 * half * T + min(a.t0 + cb * 32 + l31, T - 1));
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const float *bd = a.b_dil + (rb ? XC : 0) + 32 * w;  // wave-uniform: scalar loads, no vector-memory slots
@@ -224,13 +224,13 @@ __device__ __forceinline__ void x3_init(const X3Tile &a, f32x16 (&acc)[2][2]) {
             const float blo = bd[urow(r)], bhi = bd[urow(r) + 4];
             const float bias = half ? bhi : blo;
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[rb][cb][r] = bias + buf_load(rcp, vo4[cb], ur * T4);
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = bias + buf_load(rcp, vo4[cb], ur * T4);
         }
     }
 }
 
-template <typename S>
-__device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][2], unsigned char *lds, unsigned piece_bytes, uint64_t *dbg,
+template <typename S, int NCB>
+__device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], unsigned char *lds, unsigned piece_bytes, uint64_t *dbg,
                                         uint64_t &tprev) {
 #define X3_PHASE(p)                                           \
     if (dbg) {                                                \
@@ -253,10 +253,11 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][2], un
     // power-of-two scales of the two weight images (1 for bf16x3): {s1, 1/s1, s2, 1/s2}
     const float *sc = reinterpret_cast<const float *>(a.img + x_n1<S>() + x_n2<S>());
     const float s1 = sc[0], is1 = sc[1], s2 = sc[2], is2 = sc[3];
-    bool tv[2];
-    unsigned vo4[2];
+    constexpr int NT = 32 * NCB;  // frames per tile
+    bool tv[NCB];
+    unsigned vo4[NCB];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
         const int t = t0 + cb * 32 + l31;
         tv[cb] = t < T;
         vo4[cb] = 4u * (unsigned)(4 * half * T + min(t, T - 1));
@@ -265,16 +266,18 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][2], un
     // ---- stage x + d, split into its pieces: thread (frame row f, channel group cg of 32 channels); row j <-> frame
     //      t0 - d + j.  All loads of the main pass are issued before the first one is consumed.
     {
-        const int f = tid & 63, cg = __builtin_amdgcn_readfirstlane(tid >> 6);  // cg 0..7
+        // 512 threads: frame row f < NT, channel group cg of CPT = 256 NT / 512 channels (NT = 64: 8 groups of 32; 32: 16 of 16)
+        constexpr int CPT = XC * NT / 512;
+        const int f = tid & (NT - 1), cg = NT == 64 ? __builtin_amdgcn_readfirstlane(tid / NT) : tid / NT;  // (64: wave-uniform)
         if (tid < XC) dsh[tid] = a.dstep[(int64_t)tid * a.d_cs];
         float amax = 0.0f;
-        auto put = [&](int j, const float (&v)[32], bool valid) {
+        auto put = [&](int j, const float (&v)[CPT], bool valid) {
 #pragma unroll
-            for (int q8 = 0; q8 < 4; ++q8) {  // 8 channels -> one 16-byte write per piece
+            for (int q8 = 0; q8 < CPT / 8; ++q8) {  // 8 channels -> one 16-byte write per piece
                 unsigned short p[8][NP];
-                // step offsets d[c] of these 8 channels (wave-uniform address: LDS broadcast), read unconditionally
-                const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dsh + 32 * cg + 8 * q8);
-                const f32x4 d1 = *reinterpret_cast<const f32x4 *>(dsh + 32 * cg + 8 * q8 + 4);
+                // step offsets d[c] of these 8 channels, read unconditionally
+                const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dsh + CPT * cg + 8 * q8);
+                const f32x4 d1 = *reinterpret_cast<const f32x4 *>(dsh + CPT * cg + 8 * q8 + 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = 8 * q8 + e;
@@ -287,22 +290,23 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][2], un
                 pack8<NP>(p, u);
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    *reinterpret_cast<u32x4_t *>(lds + q * piece_bytes + j * XR + (32 * cg + 8 * q8) * 2) = u[q];
+                    *reinterpret_cast<u32x4_t *>(lds + q * piece_bytes + j * XR + (CPT * cg + 8 * q8) * 2) = u[q];
             }
         };
         const int t = t0 - d + f;
         const bool tvx = t >= 0 && t < T;
         const unsigned vox = 4u * (unsigned)min(max(t, 0), T - 1);
-        float vx[32];
+        const unsigned cgo = (unsigned)(CPT * cg) * T4;  // the channel group's rows (per lane: with 32-frame tiles a wave spans two groups)
+        float vx[CPT];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) vx[k] = buf_load(rx, vox, (unsigned)(32 * cg + k) * T4);
-        const int jh = X_NT + f, th = t0 - d + jh;  // halo rows 64 .. 64 + 2d - 1: the first 2d lanes of each channel group
+        for (int k = 0; k < CPT; ++k) vx[k] = buf_load(rx, vox + cgo, (unsigned)k * T4);
+        const int jh = NT + f, th = t0 - d + jh;  // halo rows NT .. NT + 2d - 1: the first 2d lanes of each channel group
         const bool has_h = f < 2 * d, tvh = th >= 0 && th < T;
         const unsigned voh = 4u * (unsigned)min(max(th, 0), T - 1);
-        float vh[32];
+        float vh[CPT];
         if (has_h) {
 #pragma unroll
-            for (int k = 0; k < 32; ++k) vh[k] = buf_load(rx, voh, (unsigned)(32 * cg + k) * T4);
+            for (int k = 0; k < CPT; ++k) vh[k] = buf_load(rx, voh + cgo, (unsigned)k * T4);
         }
         __syncthreads();  // dsh
         put(f, vx, tvx);
@@ -314,29 +318,29 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][2], un
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rb][cb][r] *= s1;
     __syncthreads();
     X3_PHASE(1)
 
     // ---- GEMM 1: y = Wdil (*) (x + d); k-step ks -> tap ks / 16 (a row shift of tap * d), channels 16 (ks % 16) ..
-    gemm_x3<S, X_KS1>(acc, rw, lane16, (unsigned)(w * X_KS1 * 2 * NP * 1024), lds, piece_bytes, [&](int ks, int cb) {
+    gemm_x3<S, X_KS1, NCB>(acc, rw, lane16, (unsigned)(w * X_KS1 * 2 * NP * 1024), lds, piece_bytes, [&](int ks, int cb) {
         return (unsigned)((cb * 32 + l31 + (ks >> 4) * d) * XR + ((ks & 15) * 16 + half * 8) * 2);
     });
     X3_PHASE(2)
 
     // ---- residual rows of x for GEMM 2's accumulator start: issued here, consumed after the gate
-    float xres[2][16];
+    float xres[NCB][16];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) xres[cb][r] = buf_load(rx, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
     __syncthreads();  // every wave is done reading the x tile: the z tile overlays it (row j <-> frame t0 + j)
     X3_PHASE(8)
     // ---- gate (lane-local: acc[0] gate rows, acc[1] the matching filter rows), split z, 4 consecutive channels per write
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             unsigned short p[4][NP];
@@ -367,13 +371,13 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][2], un
             const float blo = bo[urow(r)], bhi = bo[urow(r) + 4];
             const float bias = half ? bhi : blo;
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[rb][cb][r] = (rb == 0 ? bias + xres[cb][r] : bias) * s2;
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = (rb == 0 ? bias + xres[cb][r] : bias) * s2;
         }
     }
     // the running skip sum of this tile (written by this block's predecessor on the tile, one layer ago): fetched under GEMM 2
-    float sk[2][16];
+    float sk[NCB][16];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
     X3_PHASE(10)
@@ -381,14 +385,14 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][2], un
     X3_PHASE(3)
 
     // ---- GEMM 2: o = Wout z
-    gemm_x3<S, X_KS2>(acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + w * X_KS2 * 2 * NP * 1024), lds, piece_bytes, [&](int ks, int cb) {
+    gemm_x3<S, X_KS2, NCB>(acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + w * X_KS2 * 2 * NP * 1024), lds, piece_bytes, [&](int ks, int cb) {
         return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2);
     });
     X3_PHASE(4)
 
     // ---- epilogue: x' (agent-scope write-through: other XCDs read it right after the publish), then the skip sum
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
         if (tv[cb]) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -397,7 +401,7 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][2], un
     }
     const bool first = a.first != 0;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
         if (tv[cb]) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -409,7 +413,9 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][2], un
 #undef X3_PHASE
 
 // persistent (layer, tile) queue: the protocol of diffnet_stack_kernel (csrc/diffnet.hip)
-template <typename S>
+// NCB: 32-frame column blocks per tile (2: 64-frame tiles, the throughput shape; 1: 32-frame tiles for batches that leave
+// most CUs without a 64-frame tile -- the time of a layer is then the time of one task)
+template <typename S, int NCB>
 __global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles, int ntasks,
                                                                    unsigned piece_bytes, int fault_tile) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -440,9 +446,9 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStac
         lt.b_dil = a.b_dil_all + (int64_t)l * 512;
         lt.b_out = a.b_out_all + (int64_t)l * 512;
         lt.err_flag = a.err_flag;
-        lt.T = a.T; lt.t0 = j * X_NT; lt.dil = 1 << (l % a.dilation_cycle_length); lt.first = (l == 0);
-        f32x16 acc[2][2];
-        x3_init(lt, acc);  // issued before the previous tile's store drain / publish and before the dependency wait
+        lt.T = a.T; lt.t0 = j * (32 * NCB); lt.dil = 1 << (l % a.dilation_cycle_length); lt.first = (l == 0);
+        f32x16 acc[2][NCB];
+        x3_init<NCB>(lt, acc);  // issued before the previous tile's store drain / publish and before the dependency wait
         __builtin_amdgcn_sched_barrier(0);
         // Lane 0 PEEKS at the three producer flags and claims the next task; both round trips overlap the store drain
         // below.  Only a peek: this block's finished tile is not published yet, and a blocking wait here could wait on a
@@ -487,7 +493,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStac
             if (__builtin_amdgcn_readfirstlane(s_task[2]) == 0) break;
         }
         const int n_next = __builtin_amdgcn_readfirstlane(s_task[0]);
-        x3_main<S>(lt, acc, lds, piece_bytes, dbg, tprev);
+        x3_main<S, NCB>(lt, acc, lds, piece_bytes, dbg, tprev);
         i_done = i;
         l_done = l;
         n = n_next;
@@ -505,20 +511,21 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStac
         __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename S>
+template <typename S, int NCB>
 int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s) {
+    constexpr int NT = 32 * NCB;
     static bool attr_set = false;
     if (!attr_set) {
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_x3_kernel<S>),
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_x3_kernel<S, NCB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "set_diffnet_stack(x3 attr)");
         attr_set = true;
     }
-    const int tiles_per_utt = (a.T + X_NT - 1) / X_NT, ntiles = a.B * tiles_per_utt;
+    const int tiles_per_utt = (a.T + NT - 1) / NT, ntiles = a.B * tiles_per_utt;
     const int64_t ntasks64 = (int64_t)ntiles * a.L;
     SET_REQUIRE(ntasks64 < (1ll << 30), "set_diffnet_stack(task count)");
     SET_REQUIRE((int64_t)2 * XC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_stack(split-operand kernel: T too large)");
     const int max_dil = 1 << (a.dilation_cycle_length - 1);
-    const unsigned piece_bytes = (unsigned)((X_NT + 2 * max_dil) * XR);
+    const unsigned piece_bytes = (unsigned)((NT + 2 * max_dil) * XR);
     const size_t ldsz = (size_t)S::NP * piece_bytes + XC * sizeof(float) + 16;  // + task slots
     SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
     int grid = n_cu;
@@ -526,7 +533,7 @@ int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_
     if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
     if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(diffnet_stack_x3_kernel<S>, dim3(grid), dim3(512), ldsz, s, a, tiles_per_utt, ntiles, (int)ntasks64,
+    hipLaunchKernelGGL((diffnet_stack_x3_kernel<S, NCB>), dim3(grid), dim3(512), ldsz, s, a, tiles_per_utt, ntiles, (int)ntasks64,
                        piece_bytes, fault_tile);
     return set_check_launch("set_diffnet_stack");
 }
@@ -833,7 +840,12 @@ extern "C" int set_pack_diffnet_layer_x3(const float *w_dil, const float *w_out,
 
 // called by set_diffnet_stack (csrc/diffnet.hip) once it has picked this kernel
 int set_launch_diffnet_stack_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s) {
-    if (a.x3_mode == 2) return launch_x3<SplitF16x2>(a, n_cu, fault_tile, s);
-    SET_REQUIRE(a.x3_mode == 3, "set_diffnet_stack(x3_mode must be 2 = f16x2 or 3 = bf16x3)");
-    return launch_x3<SplitBf16x3>(a, n_cu, fault_tile, s);
+    SET_REQUIRE(a.x3_mode == 2 || a.x3_mode == 3, "set_diffnet_stack(x3_mode must be 2 = f16x2 or 3 = bf16x3)");
+    // tile width: 64 frames from ~0.6 tiles per CU on; below that 32-frame tiles (twice the tasks, each about half as long:
+    // the time of a layer is the time of one task while the chip is not full).  SET_AMD_X3_TILE=32|64 overrides.
+    const int64_t tiles64 = (int64_t)a.B * ((a.T + 63) / 64);
+    bool narrow = 5 * tiles64 < 3 * (int64_t)n_cu;
+    if (const char *e = getenv("SET_AMD_X3_TILE")) narrow = atoi(e) == 32;
+    if (a.x3_mode == 2) return narrow ? launch_x3<SplitF16x2, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitF16x2, 2>(a, n_cu, fault_tile, s);
+    return narrow ? launch_x3<SplitBf16x3, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitBf16x3, 2>(a, n_cu, fault_tile, s);
 }

@@ -576,6 +576,27 @@ def test_x3_stack_matches_fp32_stack_and_fp64(dev, monkeypatch, x3_mode):
     monkeypatch.delenv("SET_AMD_SPLIT")
 
 
+@pytest.mark.parametrize("x3_mode", [2, 3])
+def test_x3_stack_tile_widths_agree_bit_for_bit(dev, monkeypatch, x3_mode):
+    """The split-operand kernel with 32-frame tiles (batches that leave most CUs without a 64-frame tile) computes every
+    output element with the same products in the same order as with 64-frame tiles: bit-identical."""
+    from set_amd import ops
+    monkeypatch.setenv("SET_AMD_X3", "2")
+    monkeypatch.setenv("SET_AMD_SPLIT", "0")
+    for (B, T, L, dcl) in ((8, 800, 20, 1), (3, 203, 5, 3), (1, 1, 2, 1), (5, 66, 8, 4), (2, 1548, 2, 2)):
+        x0, cp, dtab, packs, wds, wos, bd, bo = _random_stack(dev, B, T, L, B * 100 + T + 9, x3_mode)
+        outs = []
+        for tile in ("64", "32"):
+            monkeypatch.setenv("SET_AMD_X3_TILE", tile)
+            xa, xb, skip = x0.clone(), torch.full_like(x0, float("nan")), torch.full_like(x0, float("nan"))
+            ws = ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4, 0, 3, 256 * 3, packs, dcl)
+            torch.cuda.synchronize()
+            assert int(ws[1]) == 0
+            outs.append(((xb if L % 2 else xa).clone(), skip.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (B, T)
+    monkeypatch.delenv("SET_AMD_X3_TILE")
+
+
 @pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
 @pytest.mark.parametrize("case", ["infer_tiny", "infer_pad", "infer_drift100", "infer_dil"])
 def test_full_inference_matches_reference_with_split_operand_kernel_forced(dev, monkeypatch, case, split):
