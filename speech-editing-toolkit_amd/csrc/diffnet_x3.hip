@@ -178,16 +178,37 @@ __device__ __forceinline__ void gemm_x3(f32x16 (&acc)[2][NCB], rsrc_t img, unsig
     }
 }
 
+// A tile = NCB consecutive 32-frame COLUMN BLOCKS of the batch's block list: utterance b owns blocks b nbu .. b nbu + nbu - 1
+// (nbu = ceil(T / 32), the last one partial when 32 does not divide T).  Every column block carries its own utterance, its
+// own first frame and its own halo rows in LDS, so a tile may straddle an utterance boundary (T = 800: 25 blocks per
+// utterance, 400 tiles of 64 frames for B = 32 instead of 32 x 13 = 416) and the conv still sees zeros beyond each
+// utterance's ends.
 struct X3Tile {
-    const float *xin;
+    const float *xin;       // BATCH bases ([B][256][T])
     float *xout, *skp;
-    const float *cpb, *dstep;
-    int64_t d_cs;
+    const float *cp;        // conditioner projection of this layer, utterance 0; utterance stride cp_bs
+    const float *dstep;     // step offsets of this layer, utterance 0; utterance stride d_bs, channel stride d_cs
+    int64_t cp_bs, d_bs, d_cs;
     const unsigned short *img;
     const float *b_dil, *b_out;
     int32_t *err_flag;
-    int T, t0, dil, first;
+    int T, dil, first;
+    int q0, nbu, Q;         // first column block of the tile, blocks per utterance, blocks in the batch
 };
+
+// column block cb of a tile: utterance and first frame (wave-uniform); `ok` = the block exists
+struct X3Col {
+    int b, t0;
+    bool ok;
+};
+__device__ __forceinline__ X3Col x3_col(const X3Tile &a, int cb) {
+    const int q = a.q0 + cb, qc = min(q, a.Q - 1);
+    X3Col c;
+    c.b = qc / a.nbu;
+    c.t0 = (qc - c.b * a.nbu) * 32;
+    c.ok = q < a.Q;
+    return c;
+}
 
 // pack NP pieces of 8 consecutive channels (p[e][q]: element e, piece q) into one 16-byte word per piece
 template <int NP>
@@ -211,20 +232,20 @@ __device__ __forceinline__ void x3_init(const X3Tile &a, f32x16 (&acc)[2][NCB]) 
     const int half = lane >> 5, l31 = lane & 31;
     const int T = a.T;
     const unsigned T4 = 4u * (unsigned)T;
-    const rsrc_t rcp = make_rsrc(a.cpb);
-    unsigned vo4[NCB];
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) vo4[cb] = 4u * (unsigned)(4 * half * T + min(a.t0 + cb * 32 + l31, T - 1));
+    for (int cb = 0; cb < NCB; ++cb) {
+        const X3Col c = x3_col(a, cb);
+        const rsrc_t rcp = make_rsrc(a.cp + (int64_t)c.b * a.cp_bs);
+        const unsigned vo4 = 4u * (unsigned)(4 * half * T + min(c.t0 + l31, T - 1));
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const float *bd = a.b_dil + (rb ? XC : 0) + 32 * w;  // wave-uniform: scalar loads, no vector-memory slots
+        for (int rb = 0; rb < 2; ++rb) {
+            const float *bd = a.b_dil + (rb ? XC : 0) + 32 * w;  // wave-uniform: scalar loads, no vector-memory slots
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned ur = (unsigned)((rb ? XC : 0) + 32 * w + urow(r));
-            const float blo = bd[urow(r)], bhi = bd[urow(r) + 4];
-            const float bias = half ? bhi : blo;
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = bias + buf_load(rcp, vo4[cb], ur * T4);
+            for (int r = 0; r < 16; ++r) {
+                const unsigned ur = (unsigned)((rb ? XC : 0) + 32 * w + urow(r));
+                const float blo = bd[urow(r)], bhi = bd[urow(r) + 4];
+                acc[rb][cb][r] = (half ? bhi : blo) + buf_load(rcp, vo4, ur * T4);
+            }
         }
     }
 }
@@ -243,45 +264,52 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int T = a.T, t0 = a.t0, d = a.dil;
-    float *dsh = reinterpret_cast<float *>(lds + NP * piece_bytes);
+    const int T = a.T, d = a.dil;
+    const int RB = 32 + 2 * d;  // LDS rows of one column block of the x tile: row jj <-> frame t0 - d + jj
+    float *dsh = reinterpret_cast<float *>(lds + NP * piece_bytes);  // [NCB][256] step offsets
     const unsigned T4 = 4u * (unsigned)T;
-    const rsrc_t rx = make_rsrc(a.xin), rxo = make_rsrc(a.xout), rsk = make_rsrc(a.skp);
     const rsrc_t rw = make_rsrc(a.img);
     const unsigned lane16 = 16u * (unsigned)lane;
     auto row0 = [&](int rb) { return (rb ? XC : 0) + 32 * w; };
     // power-of-two scales of the two weight images (1 for bf16x3): {s1, 1/s1, s2, 1/s2}
     const float *sc = reinterpret_cast<const float *>(a.img + x_n1<S>() + x_n2<S>());
     const float s1 = sc[0], is1 = sc[1], s2 = sc[2], is2 = sc[3];
-    constexpr int NT = 32 * NCB;  // frames per tile
     bool tv[NCB];
     unsigned vo4[NCB];
+    int64_t ub[NCB];  // element offset of the column block's utterance in the [B][256][T] tensors
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-        const int t = t0 + cb * 32 + l31;
-        tv[cb] = t < T;
+        const X3Col c = x3_col(a, cb);
+        const int t = c.t0 + l31;
+        tv[cb] = c.ok && t < T;
         vo4[cb] = 4u * (unsigned)(4 * half * T + min(t, T - 1));
+        ub[cb] = (int64_t)c.b * XC * T;
     }
 
-    // ---- stage x + d, split into its pieces: thread (frame row f, channel group cg of 32 channels); row j <-> frame
-    //      t0 - d + j.  All loads of the main pass are issued before the first one is consumed.
+    // ---- stage x + d, split into its pieces.  Wave w stages column block w % NCB (one utterance per wave: a wave-uniform
+    //      buffer descriptor), frame row fr = lane & 31 (+ the halo rows 32 .. 32 + 2d - 1 on the lanes fr < 2d), channel
+    //      group cg of CPT channels.  All loads of the main pass are issued before the first one is consumed.
     {
-        // 512 threads: frame row f < NT, channel group cg of CPT = 256 NT / 512 channels (NT = 64: 8 groups of 32; 32: 16 of 16)
-        constexpr int CPT = XC * NT / 512;
-        const int f = tid & (NT - 1), cg = NT == 64 ? __builtin_amdgcn_readfirstlane(tid / NT) : tid / NT;  // (64: wave-uniform)
-        if (tid < XC) dsh[tid] = a.dstep[(int64_t)tid * a.d_cs];
+        constexpr int CPT = 16 * NCB;
+        const int cbs = w % NCB, fr = lane & 31, cg = (w / NCB) * 2 + (lane >> 5);
+        const X3Col c = x3_col(a, cbs);
+        const rsrc_t rx = make_rsrc(a.xin + (int64_t)c.b * XC * T);
+        if (tid < XC * NCB) {
+            const X3Col cd = x3_col(a, tid >> 8);
+            dsh[tid] = a.dstep[(int64_t)cd.b * a.d_bs + (int64_t)(tid & 255) * a.d_cs];
+        }
         float amax = 0.0f;
-        auto put = [&](int j, const float (&v)[CPT], bool valid) {
+        auto put = [&](int jj, const float (&v)[CPT], bool valid) {
 #pragma unroll
             for (int q8 = 0; q8 < CPT / 8; ++q8) {  // 8 channels -> one 16-byte write per piece
                 unsigned short p[8][NP];
                 // step offsets d[c] of these 8 channels, read unconditionally
-                const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dsh + CPT * cg + 8 * q8);
-                const f32x4 d1 = *reinterpret_cast<const f32x4 *>(dsh + CPT * cg + 8 * q8 + 4);
+                const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dsh + XC * cbs + CPT * cg + 8 * q8);
+                const f32x4 d1 = *reinterpret_cast<const f32x4 *>(dsh + XC * cbs + CPT * cg + 8 * q8 + 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int c = 8 * q8 + e;
-                    const float xs = v[c] + (e < 4 ? d0[e & 3] : d1[e & 3]);  // select after: `valid ? load + .. : 0` branches per element
+                    const int ch = 8 * q8 + e;
+                    const float xs = v[ch] + (e < 4 ? d0[e & 3] : d1[e & 3]);  // select after: `valid ? load + .. : 0` branches per element
                     const float xv = valid ? xs : 0.0f;
                     if constexpr (S::MODE == 2) amax = fmaxf(amax, fabsf(xv));
                     S::split(xv, p[e]);
@@ -290,27 +318,23 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], 
                 pack8<NP>(p, u);
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    *reinterpret_cast<u32x4_t *>(lds + q * piece_bytes + j * XR + (CPT * cg + 8 * q8) * 2) = u[q];
+                    *reinterpret_cast<u32x4_t *>(lds + q * piece_bytes + (cbs * RB + jj) * XR + (CPT * cg + 8 * q8) * 2) = u[q];
             }
         };
-        const int t = t0 - d + f;
-        const bool tvx = t >= 0 && t < T;
-        const unsigned vox = 4u * (unsigned)min(max(t, 0), T - 1);
-        const unsigned cgo = (unsigned)(CPT * cg) * T4;  // the channel group's rows (per lane: with 32-frame tiles a wave spans two groups)
-        float vx[CPT];
+        const int t = c.t0 - d + fr, th = c.t0 - d + 32 + fr;
+        const bool tvx = c.ok && t >= 0 && t < T, has_h = fr < 2 * d, tvh = c.ok && th >= 0 && th < T;
+        const unsigned cgo = (unsigned)(CPT * cg) * T4;  // the channel group's rows (per lane: a wave spans two groups)
+        const unsigned vox = 4u * (unsigned)min(max(t, 0), T - 1) + cgo, voh = 4u * (unsigned)min(max(th, 0), T - 1) + cgo;
+        float vx[CPT], vh[CPT];
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) vx[k] = buf_load(rx, vox + cgo, (unsigned)k * T4);
-        const int jh = NT + f, th = t0 - d + jh;  // halo rows NT .. NT + 2d - 1: the first 2d lanes of each channel group
-        const bool has_h = f < 2 * d, tvh = th >= 0 && th < T;
-        const unsigned voh = 4u * (unsigned)min(max(th, 0), T - 1);
-        float vh[CPT];
+        for (int k = 0; k < CPT; ++k) vx[k] = buf_load(rx, vox, (unsigned)k * T4);
         if (has_h) {
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) vh[k] = buf_load(rx, voh + cgo, (unsigned)k * T4);
+            for (int k = 0; k < CPT; ++k) vh[k] = buf_load(rx, voh, (unsigned)k * T4);
         }
         __syncthreads();  // dsh
-        put(f, vx, tvx);
-        if (has_h) put(jh, vh, tvh);
+        put(fr, vx, tvx);
+        if (has_h) put(32 + fr, vh, tvh);
         if constexpr (S::MODE == 2) {  // fp16 pieces: |x| >= 32768 (or NaN) is outside the range of the splitting -> say so
             if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -326,17 +350,19 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], 
 
     // ---- GEMM 1: y = Wdil (*) (x + d); k-step ks -> tap ks / 16 (a row shift of tap * d), channels 16 (ks % 16) ..
     gemm_x3<S, X_KS1, NCB>(acc, rw, lane16, (unsigned)(w * X_KS1 * 2 * NP * 1024), lds, piece_bytes, [&](int ks, int cb) {
-        return (unsigned)((cb * 32 + l31 + (ks >> 4) * d) * XR + ((ks & 15) * 16 + half * 8) * 2);
+        return (unsigned)((cb * RB + l31 + (ks >> 4) * d) * XR + ((ks & 15) * 16 + half * 8) * 2);
     });
     X3_PHASE(2)
 
     // ---- residual rows of x for GEMM 2's accumulator start: issued here, consumed after the gate
     float xres[NCB][16];
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
+    for (int cb = 0; cb < NCB; ++cb) {
+        const rsrc_t rx = make_rsrc(a.xin + ub[cb]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) xres[cb][r] = buf_load(rx, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
-    __syncthreads();  // every wave is done reading the x tile: the z tile overlays it (row j <-> frame t0 + j)
+    }
+    __syncthreads();  // every wave is done reading the x tile: the z tile overlays it (row cb * 32 + l31 <-> that block's frame)
     X3_PHASE(8)
     // ---- gate (lane-local: acc[0] gate rows, acc[1] the matching filter rows), split z, 4 consecutive channels per write
 #pragma unroll
@@ -377,9 +403,11 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], 
     // the running skip sum of this tile (written by this block's predecessor on the tile, one layer ago): fetched under GEMM 2
     float sk[NCB][16];
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
+    for (int cb = 0; cb < NCB; ++cb) {
+        const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+    }
     X3_PHASE(10)
     __syncthreads();
     X3_PHASE(3)
@@ -394,6 +422,7 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], 
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         if (tv[cb]) {
+            const rsrc_t rxo = make_rsrc(a.xout + ub[cb]);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 buf_store_agent((acc[0][cb][r] * is2) * RSQRT2, rxo, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
@@ -403,6 +432,7 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], 
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         if (tv[cb]) {
+            const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 buf_store_agent(first ? acc[1][cb][r] * is2 : acc[1][cb][r] * is2 + sk[cb][r], rsk, vo4[cb],
@@ -419,7 +449,7 @@ template <typename S, int NCB>
 __global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles, int ntasks,
                                                                    unsigned piece_bytes, int fault_tile) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int *s_task = reinterpret_cast<int *>(lds + S::NP * piece_bytes + XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
+    int *s_task = reinterpret_cast<int *>(lds + S::NP * piece_bytes + NCB * XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
     int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
     const int tid = threadIdx.x;
     uint64_t *dbg = (blockIdx.x == 0 && tid == 0) ? g_x3_phase_buf : nullptr;
@@ -433,20 +463,19 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStac
     int n = __builtin_amdgcn_readfirstlane(s_task[0]);
     int i_done = -1, l_done = 0;  // finished but not yet published tile of this block
     while (n < ntasks) {
-        const int l = n / ntiles, i = n - l * ntiles;
-        const int b = i / tiles_per_utt, j = i - b * tiles_per_utt;
+        const int l = n / ntiles, i = n - l * ntiles, j = i;  // one chain of tiles over the batch: neighbours are i - 1 / i + 1
         X3Tile lt;
-        lt.xin = ((l & 1) ? a.xb : a.xa) + (int64_t)b * XC * a.T;
-        lt.xout = ((l & 1) ? a.xa : a.xb) + (int64_t)b * XC * a.T;
-        lt.skp = a.skip + (int64_t)b * XC * a.T;
-        lt.cpb = a.condproj + (int64_t)l * a.cp_ls + (int64_t)b * a.cp_bs;
-        lt.dstep = a.dstep + (int64_t)l * a.d_ls + (int64_t)b * a.d_bs;
-        lt.d_cs = a.d_cs;
+        lt.xin = (l & 1) ? a.xb : a.xa;
+        lt.xout = (l & 1) ? a.xa : a.xb;
+        lt.skp = a.skip;
+        lt.cp = a.condproj + (int64_t)l * a.cp_ls; lt.cp_bs = a.cp_bs;
+        lt.dstep = a.dstep + (int64_t)l * a.d_ls; lt.d_bs = a.d_bs; lt.d_cs = a.d_cs;
         lt.img = reinterpret_cast<const unsigned short *>(a.wx3_all) + (int64_t)l * x_nimg<S>();
         lt.b_dil = a.b_dil_all + (int64_t)l * 512;
         lt.b_out = a.b_out_all + (int64_t)l * 512;
         lt.err_flag = a.err_flag;
-        lt.T = a.T; lt.t0 = j * (32 * NCB); lt.dil = 1 << (l % a.dilation_cycle_length); lt.first = (l == 0);
+        lt.T = a.T; lt.dil = 1 << (l % a.dilation_cycle_length); lt.first = (l == 0);
+        lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * NCB;
         f32x16 acc[2][NCB];
         x3_init<NCB>(lt, acc);  // issued before the previous tile's store drain / publish and before the dependency wait
         __builtin_amdgcn_sched_barrier(0);
@@ -513,20 +542,20 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStac
 
 template <typename S, int NCB>
 int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s) {
-    constexpr int NT = 32 * NCB;
     static bool attr_set = false;
     if (!attr_set) {
         SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_x3_kernel<S, NCB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "set_diffnet_stack(x3 attr)");
         attr_set = true;
     }
-    const int tiles_per_utt = (a.T + NT - 1) / NT, ntiles = a.B * tiles_per_utt;
+    const int Q = a.B * ((a.T + 31) / 32);                    // 32-frame column blocks of the batch
+    const int ntiles = (Q + NCB - 1) / NCB, tiles_per_utt = ntiles;  // tiles are cut from the batch's block list (see X3Tile)
     const int64_t ntasks64 = (int64_t)ntiles * a.L;
     SET_REQUIRE(ntasks64 < (1ll << 30), "set_diffnet_stack(task count)");
     SET_REQUIRE((int64_t)2 * XC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_stack(split-operand kernel: T too large)");
     const int max_dil = 1 << (a.dilation_cycle_length - 1);
-    const unsigned piece_bytes = (unsigned)((NT + 2 * max_dil) * XR);
-    const size_t ldsz = (size_t)S::NP * piece_bytes + XC * sizeof(float) + 16;  // + task slots
+    const unsigned piece_bytes = (unsigned)(NCB * (32 + 2 * max_dil) * XR);  // every column block has its own halo rows
+    const size_t ldsz = (size_t)S::NP * piece_bytes + NCB * XC * sizeof(float) + 16;  // + step offsets + task slots
     SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
     int grid = n_cu;
     if (grid > ntiles * 4 / 5) grid = ntiles * 4 / 5;  // workers stay below the runnable-task count (see diffnet.hip)
