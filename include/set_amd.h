@@ -357,6 +357,10 @@ typedef struct SetDiffLoopArgs {
     float *z_ws;
     const void *wx3_all;    /* optional split-operand images (see SetDiffnetStackArgs), batches that fill the chip */
     int32_t x3_mode;
+    /* optional set_pack_conv_weight_x2 images of skip_projection (256 x 256), output_projection (M x 256) and
+     * input_projection (256 x M): with x3_mode == 2 the fused step boundary then runs on the two-piece fp16 operands as well
+     * (SET_AMD_BOUNDARY_X2=0 keeps the fp32 MFMA boundary kernel) */
+    const void *w_skip_x2, *w_outp_x2, *w_in_x2;
     const float *w_skip_p; /* skip_projection packed */
     const float *b_skip;
     const float *w_outp_p; /* output_projection packed (Cout M, Cin 256) */

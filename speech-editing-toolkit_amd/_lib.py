@@ -67,6 +67,7 @@ class SetDiffLoopArgs(C.Structure):
         ("w1w_all", C.c_void_p), ("w2w_all", C.c_void_p),
         ("w1s_all", C.c_void_p), ("w2s_all", C.c_void_p), ("z_ws", C.c_void_p), ("wx3_all", C.c_void_p),
         ("x3_mode", C.c_int32),
+        ("w_skip_x2", C.c_void_p), ("w_outp_x2", C.c_void_p), ("w_in_x2", C.c_void_p),
         ("w_skip_p", C.c_void_p), ("b_skip", C.c_void_p), ("w_outp_p", C.c_void_p), ("b_outp", C.c_void_p),
         ("ws_x0", C.c_void_p), ("ws_x1", C.c_void_p), ("ws_skip", C.c_void_p), ("ws_h", C.c_void_p),
         ("ws_x0pred", C.c_void_p),

@@ -1560,6 +1560,272 @@ __global__ void __launch_bounds__(256, 2) diffnet_boundary_kernel(BoundaryArgs a
     }
 }
 
+// ---- the same step boundary on the two-piece fp16 operands (csrc/diffnet_x3.hip, csrc/conv_x2.hip: fp32 operands as two
+// fp16 pieces, three fp16 MFMAs per product, fp32 accumulate).  The fp32 kernel above is bound by its three small GEMMs on
+// the fp32 MFMA pipe (23 us of pipe time per 64-frame tile); here they take a fifth of that.  Same tile, same five phases;
+// the operand tiles live in LDS as [piece][frame][channel] fp16 (rows padded by 16 B), the weights come from the images of
+// set_pack_conv_weight_x2 (A-fragment order, straight from global memory), x0 / x' pass through an fp32 tile for the
+// posterior update exactly as above.  Used by the reverse loop whenever the layer stack runs on two-piece fp16 operands.
+typedef _Float16 bx_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned bx_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned bx_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int BX_XR = DC * 2 + 16;     // bytes per row of the s / h tiles [frame][256]
+constexpr int BX_PR = 96 * 2 + 16;     // ... of the x' tile [frame][96]
+constexpr int BX_PIECE = 64 * BX_XR;   // one piece of a [64][256] tile
+
+struct BoundaryX2Args {
+    BoundaryArgs g;
+    const unsigned short *w_skip_x2, *w_outp_x2, *w_in_x2;
+    int32_t *err_flag;
+};
+
+__device__ __forceinline__ void bx_split(float v, unsigned short &p0, unsigned short &p1) {
+    const _Float16 h0 = (_Float16)v;
+    p0 = __builtin_bit_cast(unsigned short, h0);
+    p1 = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h0));
+}
+__device__ __forceinline__ f32x16 bx_mma(bx_u32x4 a, bx_u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bx_f16x8, a), __builtin_bit_cast(bx_f16x8, b), c, 0, 0, 0);
+}
+// acc[NRB][2] += W[32 (rb0 + i) .. ][16 ks ..] * B over nks k-steps; image [rb32][ng16][piece][lane][8] (K = 1 tap);
+// B piece q of (ks, cb) at lds + q * piece_bytes + bfrag(ks, cb)
+template <int NRB, typename BF>
+__device__ __forceinline__ void bx_gemm(f32x16 (&acc)[NRB][2], rsrc_t img, unsigned lane16, int rb0, int ng16, int nks,
+                                        const unsigned char *lds, unsigned piece_bytes, BF bfrag) {
+    auto a_load = [&](int ks, int i, int q) {
+        return (bx_u32x4)__builtin_amdgcn_raw_buffer_load_b128(img, (int)lane16, (int)((((rb0 + i) * ng16 + ks) * 2 + q) * 1024), 0);
+    };
+    bx_u32x4 A[2][NRB][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < NRB; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) A[p][i][q] = a_load(min(p, nks - 1), i, q);
+    for (int kb = 0; kb < nks; kb += 2) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int ks = min(kb + p, nks - 1);
+            const bool live = kb + p < nks;  // (odd nks: the last slot repeats the final k-step and is skipped)
+            bx_u32x4 Bv[2][2], Ac[NRB][2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const unsigned bo = bfrag(ks, cb);
+                Bv[cb][0] = *reinterpret_cast<const bx_u32x4 *>(lds + bo);
+                Bv[cb][1] = *reinterpret_cast<const bx_u32x4 *>(lds + piece_bytes + bo);
+            }
+#pragma unroll
+            for (int i = 0; i < NRB; ++i) {
+                Ac[i][0] = A[p][i][0];
+                Ac[i][1] = A[p][i][1];
+                A[p][i][0] = a_load(min(ks + 2, nks - 1), i, 0);
+                A[p][i][1] = a_load(min(ks + 2, nks - 1), i, 1);
+            }
+            if (live) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)  // a1 b0, a0 b1, a0 b0
+#pragma unroll
+                    for (int i = 0; i < NRB; ++i)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb) acc[i][cb] = bx_mma(Ac[i][t == 0 ? 1 : 0], Bv[cb][t == 1 ? 1 : 0], acc[i][cb]);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) diffnet_boundary_x2_kernel(BoundaryX2Args ax) {
+    const BoundaryArgs &a = ax.g;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bl[];  // [2][64][BX_XR]: s -> h pieces; x0 / x' (fp32) and x' pieces overlay
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y, t0 = blockIdx.x * 64, T = a.T, M = a.M;
+    const unsigned lane16 = 16u * (unsigned)lane;
+    const unsigned T4 = 4u * (unsigned)T;
+    float amax = 0.0f;
+    // ---- phase 1: skip tile / sqrt(L), split -> LDS [piece][frame][256]: thread (frame f, 64 channels cg)
+    {
+        const int f = lane, cg = w;
+        const rsrc_t rs = make_rsrc(a.skip + (int64_t)b * DC * T);
+        const unsigned vo = 4u * (unsigned)min(t0 + f, T - 1);
+        const bool tv = t0 + f < T;
+        for (int c0 = 0; c0 < 64; c0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = buf_load(rs, vo, (unsigned)(64 * cg + c0 + u) * T4);
+#pragma unroll
+            for (int q8 = 0; q8 < 2; ++q8) {
+                bx_u32x4 u0, u1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned short p0[2], p1[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float sv = v[8 * q8 + 2 * e + k] / a.div;
+                        const float x = tv ? sv : 0.0f;
+                        amax = fmaxf(amax, fabsf(x));
+                        bx_split(x, p0[k], p1[k]);
+                    }
+                    u0[e] = (unsigned)p0[0] | ((unsigned)p0[1] << 16);
+                    u1[e] = (unsigned)p1[0] | ((unsigned)p1[1] << 16);
+                }
+                *reinterpret_cast<bx_u32x4 *>(bl + f * BX_XR + (64 * cg + c0 + 8 * q8) * 2) = u0;
+                *reinterpret_cast<bx_u32x4 *>(bl + BX_PIECE + f * BX_XR + (64 * cg + c0 + 8 * q8) * 2) = u1;
+            }
+        }
+    }
+    __syncthreads();
+    auto bfrag256 = [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * BX_XR + (ks * 16 + half * 8) * 2); };
+    // ---- phase 2: h = ReLU(W_skip s + b): wave w owns rows [64w, 64w+64)
+    {
+        const rsrc_t rw = make_rsrc(ax.w_skip_x2);
+        const float inv = reinterpret_cast<const float *>(ax.w_skip_x2 + (DC / 32) * (DC / 16) * 1024)[1];
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[i][cb] = (f32x16){0};
+        bx_gemm<2>(acc, rw, lane16, 2 * w, DC / 16, DC / 16, bl, BX_PIECE, bfrag256);
+        __syncthreads();  // every wave is done reading the s tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned short p0[4], p1[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = 32 * (2 * w + i) + 8 * g + 4 * half + e;
+                        const float h = fmaxf(acc[i][cb][4 * g + e] * inv + a.b_skip[row], 0.0f);
+                        amax = fmaxf(amax, h);
+                        bx_split(h, p0[e], p1[e]);
+                    }
+                    const unsigned off = (unsigned)((cb * 32 + l31) * BX_XR + (32 * (2 * w + i) + 8 * g + 4 * half) * 2);
+                    bx_u32x2 u;
+                    u[0] = (unsigned)p0[0] | ((unsigned)p0[1] << 16); u[1] = (unsigned)p0[2] | ((unsigned)p0[3] << 16);
+                    *reinterpret_cast<bx_u32x2 *>(bl + off) = u;
+                    u[0] = (unsigned)p1[0] | ((unsigned)p1[1] << 16); u[1] = (unsigned)p1[2] | ((unsigned)p1[3] << 16);
+                    *reinterpret_cast<bx_u32x2 *>(bl + BX_PIECE + off) = u;
+                }
+    }
+    __syncthreads();
+    // ---- phase 3: x0 = W_out h + b: row blocks 0 .. ceil(M/32)-1 on waves 0..2; x0 -> fp32 tile xs[96][64] (over piece 0)
+    float *xs = reinterpret_cast<float *>(bl);
+    {
+        const int rbn = (M + 31) / 32;
+        f32x16 xo[1][2];
+        xo[0][0] = (f32x16){0};
+        xo[0][1] = (f32x16){0};
+        const float inv = reinterpret_cast<const float *>(ax.w_outp_x2 + ((M + 31) / 32) * (DC / 16) * 1024)[1];
+        if (w < rbn) bx_gemm<1>(xo, make_rsrc(ax.w_outp_x2), lane16, w, DC / 16, DC / 16, bl, BX_PIECE, bfrag256);
+        __syncthreads();  // h tile consumed
+        if (w < 3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * w + mfma32_row(r, lane);
+                const float bias = a.b_outp[min(row, M - 1)];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) xs[row * 64 + 32 * cb + l31] = (w < rbn && row < M) ? xo[0][cb][r] * inv + bias : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 4: posterior update on quads of 4 consecutive frames (T % 4 == 0), as in the fp32 kernel
+    {
+        const float c1 = a.coef4[0], c2 = a.coef4[1], sig = a.coef4[3] * expf(0.5f * a.coef4[2]);
+        float *xb = a.x + (int64_t)b * M * T;
+        const float *eb = a.eps ? a.eps + (int64_t)b * M * T : nullptr;
+        for (int qi = tid; qi < 96 * 16; qi += 256) {
+            const int m = qi >> 4, tq = qi & 15, t = t0 + 4 * tq;
+            float *cell = xs + m * 64 + 4 * tq;
+            if (m < M && t < T) {
+                const int64_t i = (int64_t)m * T + t;
+                const f32x4 xt = *reinterpret_cast<const f32x4 *>(xb + i);
+                float z[4];
+                if (eb) {
+                    const f32x4 e4 = *reinterpret_cast<const f32x4 *>(eb + i);
+                    z[0] = e4[0]; z[1] = e4[1]; z[2] = e4[2]; z[3] = e4[3];
+                } else {
+                    randn4(a.seed, a.quad_offset + (uint64_t)(((int64_t)b * M * T + i) >> 2), z);
+                }
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float mean = c1 * cell[k] + c2 * xt[k];
+                    o[k] = mean + sig * z[k];
+                }
+                *reinterpret_cast<f32x4 *>(xb + i) = o;
+                *reinterpret_cast<f32x4 *>(cell) = o;
+            } else {
+                *reinterpret_cast<f32x4 *>(cell) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};  // K padding rows / frames >= T
+            }
+        }
+    }
+    if (!a.xin_next) {
+        if (!(amax < 32768.0f) && ax.err_flag) __hip_atomic_store(ax.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    __syncthreads();
+    // ---- x' (fp32 [96][64]) -> two fp16 pieces [frame][96] in the piece-1 region: thread (frame f, 24 channels cg)
+    unsigned char *xp = bl + BX_PIECE;
+    constexpr unsigned XP_PIECE = 64 * BX_PR;
+    {
+        const int f = lane, cg = w;
+#pragma unroll
+        for (int q8 = 0; q8 < 3; ++q8) {
+            bx_u32x4 u0, u1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned short p0[2], p1[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float x = xs[(24 * cg + 8 * q8 + 2 * e + k) * 64 + f];
+                    amax = fmaxf(amax, fabsf(x));
+                    bx_split(x, p0[k], p1[k]);
+                }
+                u0[e] = (unsigned)p0[0] | ((unsigned)p0[1] << 16);
+                u1[e] = (unsigned)p1[0] | ((unsigned)p1[1] << 16);
+            }
+            *reinterpret_cast<bx_u32x4 *>(xp + f * BX_PR + (24 * cg + 8 * q8) * 2) = u0;
+            *reinterpret_cast<bx_u32x4 *>(xp + XP_PIECE + f * BX_PR + (24 * cg + 8 * q8) * 2) = u1;
+        }
+    }
+    if (!(amax < 32768.0f) && ax.err_flag) __hip_atomic_store(ax.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // ---- phase 5: next step's input projection xin = ReLU(W_in x' + b_in), K = M rounded up to 32 (zero padded)
+    {
+        const int ngin = ((M + 31) / 32) * 2;  // 16-channel groups of the image (Cin = M rounded up to 32, zero padded)
+        const float inv = reinterpret_cast<const float *>(ax.w_in_x2 + (DC / 32) * ngin * 1024)[1];
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[i][cb] = (f32x16){0};
+        bx_gemm<2>(acc, make_rsrc(ax.w_in_x2), lane16, 2 * w, ngin, ngin, xp, XP_PIECE,
+                   [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * BX_PR + (ks * 16 + half * 8) * 2); });
+        const rsrc_t ro = make_rsrc(a.xin_next + (int64_t)b * DC * T);
+        float bin[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bin[i][r] = (a.b_in + 32 * (2 * w + i) + urow16(r))[4 * half];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            if (t0 + 32 * cb + l31 < T) {
+                const unsigned so = 4u * (unsigned)(4 * half * T + t0 + 32 * cb + l31);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ur = 32 * (2 * w + i) + urow16(r);
+                        buf_store(fmaxf(acc[i][cb][r] * inv + bin[i][r], 0.0f), ro, so, 4u * (unsigned)ur * (unsigned)T);
+                    }
+            }
+        }
+    }
+}
+
 static bool boundary_fusable(const SetDiffLoopArgs &a) {
     if (const char *e = getenv("SET_AMD_FUSED_BOUNDARY"))
         if (atoi(e) == 0) return false;
@@ -1567,10 +1833,12 @@ static bool boundary_fusable(const SetDiffLoopArgs &a) {
 }
 
 static int launch_boundary(const SetDiffLoopArgs &a, int Bg, const float *skip, float *x, const float *eps, int sid,
-                           uint64_t quad_offset, float *xin_next, hipStream_t s) {
+                           uint64_t quad_offset, float *xin_next, bool x2, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_boundary_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "boundary(attr)");
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_boundary_x2_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "boundary(attr)");
         attr_set = true;
     }
@@ -1580,7 +1848,17 @@ static int launch_boundary(const SetDiffLoopArgs &a, int Bg, const float *skip, 
     g.w_in_p = a.w_in_p; g.b_in = a.b_in; g.xin_next = xin_next;
     g.div = sqrtf((float)a.L); g.seed = a.seed; g.quad_offset = quad_offset;
     g.T = a.T; g.M = a.M; g.MP = (a.M + 15) / 16 * 16;
-    hipLaunchKernelGGL(diffnet_boundary_kernel, dim3((a.T + 63) / 64, Bg), dim3(256), (size_t)DC * BD_LD * sizeof(float), s, g);
+    if (x2) {
+        BoundaryX2Args gx = {};
+        gx.g = g;
+        gx.w_skip_x2 = reinterpret_cast<const unsigned short *>(a.w_skip_x2);
+        gx.w_outp_x2 = reinterpret_cast<const unsigned short *>(a.w_outp_x2);
+        gx.w_in_x2 = reinterpret_cast<const unsigned short *>(a.w_in_x2);
+        gx.err_flag = a.err_flag;
+        hipLaunchKernelGGL(diffnet_boundary_x2_kernel, dim3((a.T + 63) / 64, Bg), dim3(256), (size_t)2 * BX_PIECE, s, gx);
+    } else {
+        hipLaunchKernelGGL(diffnet_boundary_kernel, dim3((a.T + 63) / 64, Bg), dim3(256), (size_t)DC * BD_LD * sizeof(float), s, g);
+    }
     return set_check_launch("set_diffusion_loop(boundary)");
 }
 
@@ -1619,6 +1897,21 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
     int rc = SET_OK;
     const bool fused_boundary = boundary_fusable(a);
     const bool bf16_loop = a.img16_all != nullptr;
+    // the step boundary on two-piece fp16 operands whenever the layer stack runs on them (same splitting, same range guard)
+    static int n_cu_chain = 0;
+    if (!n_cu_chain) {
+        int dev = 0;
+        SET_HIP(hipGetDevice(&dev), "set_diffusion_loop");
+        SET_HIP(hipDeviceGetAttribute(&n_cu_chain, hipDeviceAttributeMultiprocessorCount, dev), "set_diffusion_loop");
+    }
+    bool boundary_x2 = false;
+    if (a.persistent && !bf16_loop && fused_boundary && a.w_skip_x2 && a.w_outp_x2 && a.w_in_x2 && a.wx3_all && a.x3_mode == 2 &&
+        a.M <= 96) {
+        const int v = stack_variant(Bg, T, a.dilation_cycle_length, a.w1w_all && a.w2w_all, a.w1s_all && a.w2s_all && a.z_ws,
+                                    a.x3_mode, n_cu_chain);
+        boundary_x2 = v == 5 || (v == 3 && !(getenv("SET_AMD_SPLIT_F32") && atoi(getenv("SET_AMD_SPLIT_F32")) != 0));
+    }
+    if (const char *e = getenv("SET_AMD_BOUNDARY_X2")) boundary_x2 = boundary_x2 && atoi(e) != 0;
     for (int k = 0; k < a.steps && rc == SET_OK; ++k) {
         const int sid = a.steps - 1 - k;  // diffusion step id t = steps-1 .. 0 (spec_denoiser.py:181)
         // input projection + ReLU (diffnet.py:118-120); with the fused boundary it is part of the previous step's
@@ -1678,7 +1971,7 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
         if (fused_boundary) {
             // only the skip sum feeds the output head (diffnet.py:128); the next step's stack input buffer is ws_x0
             rc = launch_boundary(a, Bg, ws_skip, x, eps, sid, (uint64_t)(k + 1) * quads_total + quads_before,
-                                 k + 1 < a.steps ? ws_x0 : nullptr, s);
+                                 k + 1 < a.steps ? ws_x0 : nullptr, boundary_x2, s);
             continue;
         }
         // skip sum / sqrt(L) -> skip_projection -> ReLU -> output_projection (diffnet.py:128-131)

@@ -755,6 +755,9 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs,
     a.sync_ws = sync_ws.data_ptr()
     err = torch.zeros(1, dtype=torch.int32, device=dev)  # sticky: a dependency wait of the persistent kernel gave up
     a.err_flag = err.data_ptr()
+    if a.wx3_all and a.x3_mode == 2 and M <= 96 and os.environ.get("SET_AMD_BOUNDARY_X2", "1") != "0":
+        # the fused step boundary on the same two-piece fp16 operands
+        a.w_skip_x2, a.w_outp_x2, a.w_in_x2 = (w.packed_x2().data_ptr() for w in (w_skip, w_outp, w_in))
     a.w_skip_p, a.b_skip = w_skip.packed().data_ptr(), b_skip.data_ptr()
     a.w_outp_p, a.b_outp = w_outp.packed().data_ptr(), b_outp.data_ptr()
     a.ws_x0, a.ws_x1, a.ws_skip, a.ws_h = (w.data_ptr() for w in ws)

@@ -852,6 +852,7 @@ def test_fused_step_boundary_equals_separate_kernels(dev, monkeypatch, case):
             inp["uv"])
     assert m["T"] % 4 == 0
     out = {}
+    monkeypatch.setenv("SET_AMD_BOUNDARY_X2", "0")  # the fp32 MFMA boundary kernel (the split-operand one: next test)
     for mode in ("1", "0"):
         monkeypatch.setenv("SET_AMD_FUSED_BOUNDARY", mode)
         out[mode] = (model(*args, infer=True, noises=noises)["mel_out"], model(*args, infer=True, seed=11)["mel_out"],
@@ -859,6 +860,29 @@ def test_fused_step_boundary_equals_separate_kernels(dev, monkeypatch, case):
     assert _maxdiff(out["1"][0], g["mel_out"]) < 1e-4
     for a, b in zip(out["1"], out["0"]):
         assert torch.equal(a, b), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("case", ["infer_pad", "infer_tiny", "infer_drift100"])
+def test_split_operand_step_boundary(dev, monkeypatch, case):
+    """The fused step boundary on two-piece fp16 operands (what the loop runs whenever the layer stack does) against the
+    fp32 MFMA boundary kernel on the same stack kernel, and against the reference: same parity bar, explicit noise and the
+    Philox stream (identical noise either way)."""
+    g = load_golden(case)
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"])
+    inp, noises = _case_inputs(g, dev)
+    args = (inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"],
+            inp["uv"])
+    for forced in ("0", "2"):  # row-split kernel (small batch) and the throughput kernel
+        monkeypatch.setenv("SET_AMD_SPLIT", "2" if forced == "0" else "0")
+        monkeypatch.setenv("SET_AMD_X3", forced if forced == "2" else "1")
+        monkeypatch.setenv("SET_AMD_BOUNDARY_X2", "1")
+        a, ap = model(*args, infer=True, noises=noises)["mel_out"], model(*args, infer=True, seed=11)["mel_out"]
+        monkeypatch.setenv("SET_AMD_BOUNDARY_X2", "0")
+        b, bp = model(*args, infer=True, noises=noises)["mel_out"], model(*args, infer=True, seed=11)["mel_out"]
+        assert not torch.equal(a, b)  # (the switch does switch kernels)
+        assert _maxdiff(a, b) < 2e-5 and _maxdiff(ap, bp) < 2e-5
+        assert _maxdiff(a, g["mel_out"]) < 1e-4
 
 
 def test_loop_persistent_equals_per_layer_launches(dev, monkeypatch):
