@@ -132,9 +132,10 @@ class HifiGanGenerator(nn.Module):
         checkpoints), the kernels raise a flag instead of overflowing and the forward is repeated on the fp32 kernels."""
         import os
         if os.environ.get("SET_AMD_VOCODER_SPLIT", "1") != "0":
-            ops.conv_x2_range_flag(reset=True)
             with ops.split_convs():
                 y = self._forward(x)
+            # one read-back per forward (the flag is sticky and cleared when it is read as set: a stale one from another
+            # caller costs a spurious repeat, never a wrong result)
             if not ops.conv_x2_range_flag(reset=True):
                 return y
             import warnings
