@@ -189,7 +189,8 @@ class ConvWeight:
 
 def f16x2_eligible(T_iter, Cout, Cin, K, dil):
     """Shapes the two-piece fp16 conv kernel takes (and pays for): wide enough, receptive field <= 128 frames."""
-    return T_iter >= 64 and Cout >= 32 and Cin >= 32 and Cin * K >= 96 and (K - 1) * abs(dil) <= 128
+    # (K = 1: two k-steps per 32-channel chunk between barriers -- measured slower than the fp32 kernel; not taken)
+    return T_iter >= 64 and Cout >= 32 and Cin >= 32 and K >= 2 and Cin * K >= 96 and (K - 1) * abs(dil) <= 128
 
 
 def conv_x2_range_flag(reset=True):
