@@ -1,9 +1,9 @@
-// DiffNet residual stack (inference) with fp32 operands SPLIT into three bf16 pieces -- the throughput kernel of the
-// reverse loop (spec_denoiser.py:178-184 -> diffnet.py:60-81, 110-132).
+// DiffNet residual stack (inference) with fp32 operands SPLIT into 16-bit pieces (two fp16 or three bf16) -- the throughput
+// kernel of the reverse loop, its 32-frame-tile variant for part-filled chips and the row-split small-batch kernel (spec_denoiser.py:178-184 -> diffnet.py:60-81, 110-132).
 //
-// Why: the layer is two GEMMs (512 x 768 and 512 x 256 per frame) and the fp32 matrix pipe of gfx950 does 256 FLOP per
-// CU-cycle-SIMD quarter... in numbers: v_mfma_f32_32x32x2_f32 = 157 TFLOP/s, v_mfma_f32_32x32x16_bf16 = 2.5 PFLOP/s (16 x).
-// An fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8 mantissa bits, round-to-nearest pieces):
+// Why: the layer is two GEMMs (512 x 768 and 512 x 256 per frame) and the fp32 matrix instruction of gfx950
+// (v_mfma_f32_32x32x2_f32, 157 TFLOP/s) is 16 x slower than its 16-bit ones (v_mfma_f32_32x32x16_{f16,bf16}, 2.5 PFLOP/s).
+// An fp32 value is the sum of three bf16 values (8 + 8 + 8 mantissa bits, round-to-nearest pieces) to within 2^-24:
 //     a = a0 + a1 + a2,   a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)
 // so a product a*b is  a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0) + O(2^-24 |ab|): SIX bf16 MFMAs (each product of two
 // bf16 values is exact in fp32, accumulation is fp32) give every term to within one fp32 ulp -- the same size as the
