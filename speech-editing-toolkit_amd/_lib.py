@@ -15,6 +15,8 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_PKG, "libset_amd.so")
+# measurement only (tools/build_exp.sh): load an experimental build of the library instead; never built or rebuilt from here
+_LIB_OVERRIDE = os.environ.get("SET_AMD_LIB")
 SOURCES = ["conv1d.hip", "conv_x2.hip", "glue.hip", "diffnet.hip", "diffnet_x3.hip", "train.hip", "attention.hip", "bf16.hip", "diffnet_bf16.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
@@ -251,6 +253,8 @@ def _stale():
 
 def build(force=False, verbose=False):
     """Compile libset_amd.so for gfx950 in-tree (no GPU needed)."""
+    if _LIB_OVERRIDE:
+        return _LIB_OVERRIDE
     if not force and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -281,17 +285,18 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = _LIB_OVERRIDE or LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
             "libset_amd.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`. "
-            "There is no CPU/eager fallback for this path." % LIB_PATH)
+            "There is no CPU/eager fallback for this path." % path)
     # Bring torch's HIP runtime up BEFORE the library is mapped: torch ships its own libamdhip64 and the library links
     # /opt/rocm's; mapped first, the library binds a second runtime copy that later sees "no ROCm-capable device"
     # (observed when build() and smoke() run in one process).  No-op on a machine without a GPU.
     import torch
     if torch.cuda.is_available():
         torch.cuda.init()
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the header and the library disagree
         fn.restype = res

@@ -31,9 +31,16 @@
 //   A operands: per-layer images [wave][k-step][row block][piece][lane][8 bf16] in global memory (3 MiB per layer, L2),
 //               split once per weight version by set_pack_diffnet_layer_x3.
 //   Per k-step (16 channels of one tap) a wave issues 6 A loads + 6 B reads of 16 bytes and 24 MFMAs (768 cycles).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
+
+// measurement builds only (tools/build_exp.sh): bit 0 = the A fragments are loaded once per GEMM (no L2 operand stream), bit 1 =
+// every k-step reads the B fragment of k-step 0 (the compiler hoists it: no LDS stream), bit 2 = no s_setprio.  WRONG RESULTS.
+#ifndef SET_X3_EXP
+#define SET_X3_EXP 0
+#endif
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -67,7 +74,7 @@ __device__ __forceinline__ unsigned short f2h(float x) { return __builtin_bit_ca
 __device__ __forceinline__ float h2f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
 
 struct SplitBf16x3 {
-    static constexpr int NP = 3, NPROD = 6, MODE = 3, PF = 2;  // PF: A prefetch distance in k-steps
+    static constexpr int NP = 3, NPROD = 6, MODE = 3, PF = 2, PF2 = 1;  // PF / PF2: A prefetch distance in k-steps (8- / 4-wave blocks)
     // piece pairs ordered by magnitude: 2^-16, 2^-16, 2^-16, 2^-8, 2^-8, 1
     static __device__ __forceinline__ constexpr int qa(int t) { return t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0; }
     static __device__ __forceinline__ constexpr int qb(int t) { return t == 2 ? 2 : (t == 1 || t == 4) ? 1 : 0; }
@@ -77,7 +84,7 @@ struct SplitBf16x3 {
     }
 };
 struct SplitF16x2 {
-    static constexpr int NP = 2, NPROD = 3, MODE = 2, PF = 4;
+    static constexpr int NP = 2, NPROD = 3, MODE = 2, PF = 4, PF2 = 2;
     static __device__ __forceinline__ constexpr int qa(int t) { return t == 0 ? 1 : 0; }  // a1 b0, a0 b1, a0 b0
     static __device__ __forceinline__ constexpr int qb(int t) { return t == 1 ? 1 : 0; }
     static __device__ __forceinline__ void split(float a, unsigned short (&p)[2]) {
@@ -130,52 +137,72 @@ __global__ void __launch_bounds__(256) pack_layer_x3_kernel(const float *wdil, c
     for (int q = 0; q < S::NP; ++q) base[q * 512] = p[q];
 }
 
-// ---- the GEMM: acc[rb][cb] += sum over the piece products, smallest terms first ------------------------------------------
-//   A: image block of (ks, rb, piece) at byte offset abase + ((ks * 2 + rb) * NP + piece) * 1024 (+ lane * 16)
+// ---- the GEMM: acc[u][rb][cb] += sum over the piece products, smallest terms first ---------------------------------------
+//   NU: image row groups ("image waves" w8 = NU w + u: gate rows 32 w8 .., filter rows 256 + 32 w8 ..) this wave owns
+//   A: image block of (w8, ks, rb, piece) at byte offset abase + u * ustride + ((ks * 2 + rb) * NP + piece) * 1024 (+ lane * 16)
 //   B: piece q of this lane's fragment for (ks, cb) at lds + q * piece_bytes + bfrag(ks, cb)
-template <typename S, int NKS, int NCB, typename BF>
-__device__ __forceinline__ void gemm_x3(f32x16 (&acc)[2][NCB], rsrc_t img, unsigned lane16, unsigned abase, const unsigned char *lds,
-                                        unsigned piece_bytes, BF bfrag) {
-    constexpr int NP = S::NP, X_PF = S::PF;
-    u32x4_t A[X_PF][2][NP];
+//   PF: A prefetch distance in k-steps.  Every accumulator sees its products in the same order whatever NU is.
+template <typename S, int NKS, int NU, int NCB, int PF, typename BF>
+__device__ __forceinline__ void gemm_x3(f32x16 (&acc)[NU][2][NCB], rsrc_t img, unsigned lane16, unsigned abase, unsigned ustride,
+                                        const unsigned char *lds, unsigned piece_bytes, BF bfrag) {
+    constexpr int NP = S::NP;
+    static_assert(NKS % PF == 0, "k-steps must be a multiple of the prefetch distance");
+    u32x4_t A[PF][NU][2][NP];
 #pragma unroll
-    for (int p = 0; p < X_PF; ++p)
+    for (int p = 0; p < PF; ++p)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) A[p][rb][q] = buf_load_u4(img, lane16, abase + (unsigned)(((p * 2 + rb) * NP + q) * 1024));
-    for (int kb = 0; kb < NKS; kb += X_PF) {
+            for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int p = 0; p < X_PF; ++p) {
-            const int ks = kb + p;  // NKS is a multiple of X_PF
+                for (int q = 0; q < NP; ++q)
+                    A[p][u][rb][q] = buf_load_u4(img, lane16, abase + (unsigned)u * ustride + (unsigned)(((p * 2 + rb) * NP + q) * 1024));
+    for (int kb = 0; kb < NKS; kb += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int ks = kb + p;
             u32x4_t Bv[NCB][NP];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
-                const unsigned bo = bfrag(ks, cb);
+                const unsigned bo = bfrag((SET_X3_EXP & 2) ? 0 : ks, cb);  // (experiment 2: no B stream)
 #pragma unroll
                 for (int q = 0; q < NP; ++q) Bv[cb][q] = *reinterpret_cast<const u32x4_t *>(lds + q * piece_bytes + bo);
             }
-            u32x4_t Ac[2][NP];
+            u32x4_t Ac[NU][2][NP];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int q = 0; q < NP; ++q) Ac[rb][q] = A[p][rb][q];
-            const int kn = min(ks + X_PF, NKS - 1);  // tail: harmless re-load of the last k-step
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int q = 0; q < NP; ++q) A[p][rb][q] = buf_load_u4(img, lane16, abase + (unsigned)(((kn * 2 + rb) * NP + q) * 1024));
-            __builtin_amdgcn_s_setprio(1);
-            // the four accumulators interleave, so consecutive MFMAs never depend on each other
-#pragma unroll
-            for (int t = 0; t < S::NPROD; ++t)
+            for (int u = 0; u < NU; ++u)
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = S::mma(Ac[rb][S::qa(t)], Bv[cb][S::qb(t)], acc[rb][cb]);
-            __builtin_amdgcn_s_setprio(0);
+                    for (int q = 0; q < NP; ++q) Ac[u][rb][q] = A[p][u][rb][q];
+            const int kn = (SET_X3_EXP & 1) ? p : min(ks + PF, NKS - 1);  // tail: harmless re-load of the last k-step (experiment 1: no A stream)
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        A[p][u][rb][q] = buf_load_u4(img, lane16, abase + (unsigned)u * ustride + (unsigned)(((kn * 2 + rb) * NP + q) * 1024));
+            if (!(SET_X3_EXP & 4)) __builtin_amdgcn_s_setprio(1);
+            // the accumulators interleave, so consecutive MFMAs never depend on each other
+#pragma unroll
+            for (int t = 0; t < S::NPROD; ++t)
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int cb = 0; cb < NCB; ++cb)
+                            acc[u][rb][cb] = S::mma(Ac[u][rb][S::qa(t)], Bv[cb][S::qb(t)], acc[u][rb][cb]);
+            if (!(SET_X3_EXP & 4)) __builtin_amdgcn_s_setprio(0);
         }
     }
+}
+
+// dynamic LDS of one block: NP pieces of the x tile (every column block with its own halo rows) + step offsets + task slots
+template <typename S, int NCB>
+constexpr size_t x3_lds_bytes(int max_dil) {
+    return (size_t)S::NP * (size_t)(NCB * (32 + 2 * max_dil) * XR) + NCB * XC * sizeof(float) + 16;
 }
 
 // A tile = NCB consecutive 32-frame COLUMN BLOCKS of the batch's block list: utterance b owns blocks b nbu .. b nbu + nbu - 1
@@ -225,8 +252,15 @@ __device__ __forceinline__ void pack8(const unsigned short (&p)[8][NP], u32x4_t 
 //            wrote: they are issued BEFORE the previous task's store drain and the wait for the producer tiles.
 //   x3_main  stage x, GEMM 1, gate, GEMM 2, epilogue (stores only; the caller drains and publishes)
 // lds = NP pieces of (64 + 2 max_dil) rows + 256 floats
-template <int NCB>
-__device__ __forceinline__ void x3_init(const X3Tile &a, f32x16 (&acc)[2][NCB]) {
+//
+// NU = image row groups per wave.  NU = 1: 8 waves per block, one block per CU (two waves of ONE block share each SIMD's matrix
+// pipe and are in the same phase at all times: while they stage, gate or store, the pipe idles -- ~30 % of a task).
+// NU = 2: 4 waves per block, TWO blocks per CU, each wave owns 64 gate + 64 filter rows (8 accumulators): the two waves on a
+// SIMD belong to different blocks, i.e. different (layer, tile) tasks at different points of their life, so one block's
+// staging / gate / epilogue / dependency wait runs under the other block's GEMMs.  Same images, same products in the same
+// order per accumulator: bit-identical results.
+template <int NU, int NCB>
+__device__ __forceinline__ void x3_init(const X3Tile &a, f32x16 (&acc)[NU][2][NCB]) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -238,20 +272,22 @@ __device__ __forceinline__ void x3_init(const X3Tile &a, f32x16 (&acc)[2][NCB]) 
         const rsrc_t rcp = make_rsrc(a.cp + (int64_t)c.b * a.cp_bs);
         const unsigned vo4 = 4u * (unsigned)(4 * half * T + min(c.t0 + l31, T - 1));
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const float *bd = a.b_dil + (rb ? XC : 0) + 32 * w;  // wave-uniform: scalar loads, no vector-memory slots
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned ur = (unsigned)((rb ? XC : 0) + 32 * w + urow(r));
-                const float blo = bd[urow(r)], bhi = bd[urow(r) + 4];
-                acc[rb][cb][r] = (half ? bhi : blo) + buf_load(rcp, vo4, ur * T4);
+            for (int rb = 0; rb < 2; ++rb) {
+                const float *bd = a.b_dil + (rb ? XC : 0) + 32 * (NU * w + u);  // wave-uniform: scalar loads, no vector-memory slots
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned ur = (unsigned)((rb ? XC : 0) + 32 * (NU * w + u) + urow(r));
+                    const float blo = bd[urow(r)], bhi = bd[urow(r) + 4];
+                    acc[u][rb][cb][r] = (half ? bhi : blo) + buf_load(rcp, vo4, ur * T4);
+                }
             }
-        }
     }
 }
 
-template <typename S, int NCB>
-__device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], unsigned char *lds, unsigned piece_bytes, uint64_t *dbg,
+template <typename S, int NU, int NCB>
+__device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[NU][2][NCB], unsigned char *lds, unsigned piece_bytes, uint64_t *dbg,
                                         uint64_t &tprev) {
 #define X3_PHASE(p)                                           \
     if (dbg) {                                                \
@@ -261,6 +297,7 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], 
     }
     X3_PHASE(0)
     constexpr int NP = S::NP;
+    constexpr int NW = 8 / NU, NT = 64 * NW;  // waves / threads per block
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -270,7 +307,7 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], 
     const unsigned T4 = 4u * (unsigned)T;
     const rsrc_t rw = make_rsrc(a.img);
     const unsigned lane16 = 16u * (unsigned)lane;
-    auto row0 = [&](int rb) { return (rb ? XC : 0) + 32 * w; };
+    auto row0 = [&](int u, int rb) { return (rb ? XC : 0) + 32 * (NU * w + u); };
     // power-of-two scales of the two weight images (1 for bf16x3): {s1, 1/s1, s2, 1/s2}
     const float *sc = reinterpret_cast<const float *>(a.img + x_n1<S>() + x_n2<S>());
     const float s1 = sc[0], is1 = sc[1], s2 = sc[2], is2 = sc[3];
@@ -288,24 +325,26 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], 
 
     // ---- stage x + d, split into its pieces.  Wave w stages column block w % NCB (one utterance per wave: a wave-uniform
     //      buffer descriptor), frame row fr = lane & 31 (+ the halo rows 32 .. 32 + 2d - 1 on the lanes fr < 2d), channel
-    //      group cg of CPT channels.  All loads of the main pass are issued before the first one is consumed.
+    //      group cg of CHG channels in passes of CPT (<= 32: the loads of a pass are all in flight before the first is consumed).
     {
-        constexpr int CPT = 16 * NCB;
+        constexpr int NCG = (NW / NCB) * 2, CHG = XC / NCG, CPT = CHG < 32 ? CHG : 32, NPASS = CHG / CPT;
         const int cbs = w % NCB, fr = lane & 31, cg = (w / NCB) * 2 + (lane >> 5);
         const X3Col c = x3_col(a, cbs);
         const rsrc_t rx = make_rsrc(a.xin + (int64_t)c.b * XC * T);
-        if (tid < XC * NCB) {
-            const X3Col cd = x3_col(a, tid >> 8);
-            dsh[tid] = a.dstep[(int64_t)cd.b * a.d_bs + (int64_t)(tid & 255) * a.d_cs];
+#pragma unroll
+        for (int i0 = 0; i0 < XC * NCB; i0 += NT) {
+            const int idx = i0 + tid;
+            const X3Col cd = x3_col(a, idx >> 8);
+            dsh[idx] = a.dstep[(int64_t)cd.b * a.d_bs + (int64_t)(idx & 255) * a.d_cs];
         }
         float amax = 0.0f;
-        auto put = [&](int jj, const float (&v)[CPT], bool valid) {
+        auto put = [&](int jj, int ch0, const float (&v)[CPT], bool valid) {
 #pragma unroll
             for (int q8 = 0; q8 < CPT / 8; ++q8) {  // 8 channels -> one 16-byte write per piece
                 unsigned short p[8][NP];
                 // step offsets d[c] of these 8 channels, read unconditionally
-                const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dsh + XC * cbs + CPT * cg + 8 * q8);
-                const f32x4 d1 = *reinterpret_cast<const f32x4 *>(dsh + XC * cbs + CPT * cg + 8 * q8 + 4);
+                const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dsh + XC * cbs + ch0 + 8 * q8);
+                const f32x4 d1 = *reinterpret_cast<const f32x4 *>(dsh + XC * cbs + ch0 + 8 * q8 + 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int ch = 8 * q8 + e;
@@ -318,104 +357,132 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], 
                 pack8<NP>(p, u);
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    *reinterpret_cast<u32x4_t *>(lds + q * piece_bytes + (cbs * RB + jj) * XR + (CPT * cg + 8 * q8) * 2) = u[q];
+                    *reinterpret_cast<u32x4_t *>(lds + q * piece_bytes + (cbs * RB + jj) * XR + (ch0 + 8 * q8) * 2) = u[q];
             }
         };
         const int t = c.t0 - d + fr, th = c.t0 - d + 32 + fr;
         const bool tvx = c.ok && t >= 0 && t < T, has_h = fr < 2 * d, tvh = c.ok && th >= 0 && th < T;
-        const unsigned cgo = (unsigned)(CPT * cg) * T4;  // the channel group's rows (per lane: a wave spans two groups)
-        const unsigned vox = 4u * (unsigned)min(max(t, 0), T - 1) + cgo, voh = 4u * (unsigned)min(max(th, 0), T - 1) + cgo;
-        float vx[CPT], vh[CPT];
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) vx[k] = buf_load(rx, vox, (unsigned)k * T4);
-        if (has_h) {
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int ch0 = CHG * cg + CPT * ps;
+            const unsigned cgo = (unsigned)ch0 * T4;  // the channel group's rows (per lane: a wave spans two groups)
+            const unsigned vox = 4u * (unsigned)min(max(t, 0), T - 1) + cgo, voh = 4u * (unsigned)min(max(th, 0), T - 1) + cgo;
+            float vx[CPT], vh[CPT];
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) vh[k] = buf_load(rx, voh, (unsigned)k * T4);
+            for (int k = 0; k < CPT; ++k) vx[k] = buf_load(rx, vox, (unsigned)k * T4);
+            if (has_h) {
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) vh[k] = buf_load(rx, voh, (unsigned)k * T4);
+            }
+            if (ps == 0) __syncthreads();  // dsh
+            put(fr, ch0, vx, tvx);
+            if (has_h) put(32 + fr, ch0, vh, tvh);
         }
-        __syncthreads();  // dsh
-        put(fr, vx, tvx);
-        if (has_h) put(32 + fr, vh, tvh);
         if constexpr (S::MODE == 2) {  // fp16 pieces: |x| >= 32768 (or NaN) is outside the range of the splitting -> say so
             if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    // NU = 2: the accumulator start is fetched only now -- 128 more live registers during the staging pass would spill, and
+    // the round trip (HBM: the projection is streamed once per step) runs under the other block's GEMMs
+    if constexpr (NU != 1) x3_init<NU, NCB>(a, acc);
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rb][cb][r] *= s1;
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][rb][cb][r] *= s1;
     __syncthreads();
     X3_PHASE(1)
 
     // ---- GEMM 1: y = Wdil (*) (x + d); k-step ks -> tap ks / 16 (a row shift of tap * d), channels 16 (ks % 16) ..
-    gemm_x3<S, X_KS1, NCB>(acc, rw, lane16, (unsigned)(w * X_KS1 * 2 * NP * 1024), lds, piece_bytes, [&](int ks, int cb) {
-        return (unsigned)((cb * RB + l31 + (ks >> 4) * d) * XR + ((ks & 15) * 16 + half * 8) * 2);
-    });
+    gemm_x3<S, X_KS1, NU, NCB, (NU == 1 ? S::PF : S::PF2)>(
+        acc, rw, lane16, (unsigned)(NU * w * X_KS1 * 2 * NP * 1024), (unsigned)(X_KS1 * 2 * NP * 1024), lds, piece_bytes, [&](int ks, int cb) {
+            return (unsigned)((cb * RB + l31 + (ks >> 4) * d) * XR + ((ks & 15) * 16 + half * 8) * 2);
+        });
     X3_PHASE(2)
 
     // ---- residual rows of x for GEMM 2's accumulator start: issued here, consumed after the gate
-    float xres[NCB][16];
+    // (NU = 2: after the gate -- no room for them next to 8 live accumulators and the gate's temporaries)
+    float xres[NU][NCB][16];
+    auto load_xres = [&]() {
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-        const rsrc_t rx = make_rsrc(a.xin + ub[cb]);
+        for (int cb = 0; cb < NCB; ++cb) {
+            const rsrc_t rx = make_rsrc(a.xin + ub[cb]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xres[cb][r] = buf_load(rx, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
-    }
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xres[u][cb][r] = buf_load(rx, vo4[cb], (unsigned)(row0(u, 0) + urow(r)) * T4);
+        }
+    };
+    if constexpr (NU == 1) load_xres();
     __syncthreads();  // every wave is done reading the x tile: the z tile overlays it (row cb * 32 + l31 <-> that block's frame)
     X3_PHASE(8)
-    // ---- gate (lane-local: acc[0] gate rows, acc[1] the matching filter rows), split z, 4 consecutive channels per write
+    // ---- gate (lane-local: acc[u][0] gate rows, acc[u][1] the matching filter rows), split z, 4 consecutive channels per write
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            unsigned short p[4][NP];
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g + e;
-                const float zz = fsig(acc[0][cb][r] * is1) * ftanh(acc[1][cb][r] * is1);
-                const float z = tv[cb] ? zz : 0.0f;
-                S::split(z, p[e]);
+            for (int g = 0; g < 4; ++g) {
+                unsigned short p[4][NP];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const float zz = fsig(acc[u][0][cb][r] * is1) * ftanh(acc[u][1][cb][r] * is1);
+                    const float z = tv[cb] ? zz : 0.0f;
+                    S::split(z, p[e]);
+                }
+                const unsigned off = (unsigned)((cb * 32 + l31) * XR + (32 * (NU * w + u) + 8 * g + 4 * half) * 2);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    u32x2_t uu;
+                    uu[0] = (unsigned)p[0][q] | ((unsigned)p[1][q] << 16);
+                    uu[1] = (unsigned)p[2][q] | ((unsigned)p[3][q] << 16);
+                    *reinterpret_cast<u32x2_t *>(lds + q * piece_bytes + off) = uu;
+                }
             }
-            const unsigned off = (unsigned)((cb * 32 + l31) * XR + (32 * w + 8 * g + 4 * half) * 2);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                u32x2_t u;
-                u[0] = (unsigned)p[0][q] | ((unsigned)p[1][q] << 16);
-                u[1] = (unsigned)p[2][q] | ((unsigned)p[3][q] << 16);
-                *reinterpret_cast<u32x2_t *>(lds + q * piece_bytes + off) = u;
-            }
-        }
     X3_PHASE(9)
+    if constexpr (NU != 1) load_xres();
     // ---- GEMM 2 accumulators: residual rows start at s2 (b_out + x), skip rows at s2 b_out (the running skip sum is added
     //      in the epilogue, after the x' stores are in flight)
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const float *bo = a.b_out + row0(rb);  // wave-uniform: scalar loads
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float blo = bo[urow(r)], bhi = bo[urow(r) + 4];
-            const float bias = half ? bhi : blo;
+        for (int rb = 0; rb < 2; ++rb) {
+            const float *bo = a.b_out + row0(u, rb);  // wave-uniform: scalar loads
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = (rb == 0 ? bias + xres[cb][r] : bias) * s2;
+            for (int r = 0; r < 16; ++r) {
+                const float blo = bo[urow(r)], bhi = bo[urow(r) + 4];
+                const float bias = half ? bhi : blo;
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[u][rb][cb][r] = (rb == 0 ? bias + xres[u][cb][r] : bias) * s2;
+            }
         }
-    }
-    // the running skip sum of this tile (written by this block's predecessor on the tile, one layer ago): fetched under GEMM 2
-    float sk[NCB][16];
+    // the running skip sum of this tile (written by this block's predecessor on the tile, one layer ago).  NU = 1: fetched
+    // under GEMM 2.  NU = 2: there is no room for 64 more live registers next to 8 accumulators and the operand ring; the
+    // loads follow the x' stores and their round trip is covered by the other block on the CU.
+    float sk[NU][NCB][16];
+    auto load_sk = [&]() {
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-        const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
+        for (int cb = 0; cb < NCB; ++cb) {
+            const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
-    }
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sk[u][cb][r] = buf_load(rsk, vo4[cb], (unsigned)(32 * (NU * w + u) + urow(r)) * T4);
+        }
+    };
+    if constexpr (NU == 1) load_sk();
     X3_PHASE(10)
     __syncthreads();
     X3_PHASE(3)
 
     // ---- GEMM 2: o = Wout z
-    gemm_x3<S, X_KS2, NCB>(acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + w * X_KS2 * 2 * NP * 1024), lds, piece_bytes, [&](int ks, int cb) {
-        return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2);
-    });
+    gemm_x3<S, X_KS2, NU, NCB, (NU == 1 ? S::PF : S::PF2)>(
+        acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + NU * w * X_KS2 * 2 * NP * 1024), (unsigned)(X_KS2 * 2 * NP * 1024), lds, piece_bytes,
+        [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2); });
     X3_PHASE(4)
 
     // ---- epilogue: x' (agent-scope write-through: other XCDs read it right after the publish), then the skip sum
@@ -424,19 +491,26 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], 
         if (tv[cb]) {
             const rsrc_t rxo = make_rsrc(a.xout + ub[cb]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                buf_store_agent((acc[0][cb][r] * is2) * RSQRT2, rxo, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    buf_store_agent((acc[u][0][cb][r] * is2) * RSQRT2, rxo, vo4[cb], (unsigned)(row0(u, 0) + urow(r)) * T4);
         }
     }
     const bool first = a.first != 0;
+    if constexpr (NU != 1) {
+        if (!first) load_sk();
+    }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         if (tv[cb]) {
             const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                buf_store_agent(first ? acc[1][cb][r] * is2 : acc[1][cb][r] * is2 + sk[cb][r], rsk, vo4[cb],
-                                (unsigned)(32 * w + urow(r)) * T4);
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    buf_store_agent(first ? acc[u][1][cb][r] * is2 : acc[u][1][cb][r] * is2 + sk[u][cb][r], rsk, vo4[cb],
+                                    (unsigned)(32 * (NU * w + u) + urow(r)) * T4);
         }
     }
 }
@@ -445,9 +519,9 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[2][NCB], 
 // persistent (layer, tile) queue: the protocol of diffnet_stack_kernel (csrc/diffnet.hip)
 // NCB: 32-frame column blocks per tile (2: 64-frame tiles, the throughput shape; 1: 32-frame tiles for batches that leave
 // most CUs without a 64-frame tile -- the time of a layer is then the time of one task)
-template <typename S, int NCB>
-__global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles, int ntasks,
-                                                                   unsigned piece_bytes, int fault_tile) {
+template <typename S, int NU, int NCB>
+__global__ void __launch_bounds__(512 / NU, NU) diffnet_stack_x3_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles, int ntasks,
+                                                                        unsigned piece_bytes, int fault_tile) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     int *s_task = reinterpret_cast<int *>(lds + S::NP * piece_bytes + NCB * XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
     int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
@@ -476,8 +550,8 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStac
         lt.err_flag = a.err_flag;
         lt.T = a.T; lt.dil = 1 << (l % a.dilation_cycle_length); lt.first = (l == 0);
         lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * NCB;
-        f32x16 acc[2][NCB];
-        x3_init<NCB>(lt, acc);  // issued before the previous tile's store drain / publish and before the dependency wait
+        f32x16 acc[NU][2][NCB];
+        if constexpr (NU == 1) x3_init<NU, NCB>(lt, acc);  // issued before the previous tile's store drain / publish and before the dependency wait
         __builtin_amdgcn_sched_barrier(0);
         // Lane 0 PEEKS at the three producer flags and claims the next task; both round trips overlap the store drain
         // below.  Only a peek: this block's finished tile is not published yet, and a blocking wait here could wait on a
@@ -522,7 +596,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStac
             if (__builtin_amdgcn_readfirstlane(s_task[2]) == 0) break;
         }
         const int n_next = __builtin_amdgcn_readfirstlane(s_task[0]);
-        x3_main<S, NCB>(lt, acc, lds, piece_bytes, dbg, tprev);
+        x3_main<S, NU, NCB>(lt, acc, lds, piece_bytes, dbg, tprev);
         i_done = i;
         l_done = l;
         n = n_next;
@@ -540,11 +614,11 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3_kernel(SetDiffnetStac
         __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename S, int NCB>
+template <typename S, int NU, int NCB>
 int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_x3_kernel<S, NCB>),
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_x3_kernel<S, NU, NCB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "set_diffnet_stack(x3 attr)");
         attr_set = true;
     }
@@ -555,14 +629,22 @@ int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_
     SET_REQUIRE((int64_t)2 * XC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_stack(split-operand kernel: T too large)");
     const int max_dil = 1 << (a.dilation_cycle_length - 1);
     const unsigned piece_bytes = (unsigned)(NCB * (32 + 2 * max_dil) * XR);  // every column block has its own halo rows
-    const size_t ldsz = (size_t)S::NP * piece_bytes + NCB * XC * sizeof(float) + 16;  // + step offsets + task slots
+    const size_t ldsz = x3_lds_bytes<S, NCB>(max_dil);
     SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
-    int grid = n_cu;
-    if (grid > ntiles * 4 / 5) grid = ntiles * 4 / 5;  // workers stay below the runnable-task count (see diffnet.hip)
+    // workers stay below the runnable-task count (a tile's layers form a chain: at most `ntiles` tasks are ever runnable;
+    // see diffnet.hip).  NU = 2: two blocks fit a CU, and the ones that do not get a partner still run a task at a time.
+    int grid = NU * n_cu;
+    if (grid > ntiles * 4 / 5) grid = ntiles * 4 / 5;
     if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
     if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((diffnet_stack_x3_kernel<S, NCB>), dim3(grid), dim3(512), ldsz, s, a, tiles_per_utt, ntiles, (int)ntasks64,
+    if (getenv("SET_AMD_X3_DEBUG")) {
+        int nb = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(diffnet_stack_x3_kernel<S, NU, NCB>), 512 / NU, ldsz);
+        fprintf(stderr, "[set_amd] x3 kernel NU=%d NCB=%d: grid %d x %d threads, %zu B LDS, %d resident blocks per CU, %d tiles\n", NU, NCB,
+                grid, 512 / NU, ldsz, nb, ntiles);
+    }
+    hipLaunchKernelGGL((diffnet_stack_x3_kernel<S, NU, NCB>), dim3(grid), dim3(512 / NU), ldsz, s, a, tiles_per_utt, ntiles, (int)ntasks64,
                        piece_bytes, fault_tile);
     return set_check_launch("set_diffnet_stack");
 }
@@ -875,6 +957,19 @@ int set_launch_diffnet_stack_x3(const SetDiffnetStackArgs &a, int n_cu, int faul
     const int64_t tiles64 = (int64_t)a.B * ((a.T + 63) / 64);
     bool narrow = 5 * tiles64 < 3 * (int64_t)n_cu;
     if (const char *e = getenv("SET_AMD_X3_TILE")) narrow = atoi(e) == 32;
-    if (a.x3_mode == 2) return narrow ? launch_x3<SplitF16x2, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitF16x2, 2>(a, n_cu, fault_tile, s);
-    return narrow ? launch_x3<SplitBf16x3, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitBf16x3, 2>(a, n_cu, fault_tile, s);
+    // block shape: one 8-wave block per CU.  SET_AMD_X3_WAVES=4 selects two 4-wave blocks per CU (see x3_init; f16x2 images, when
+    // two blocks fit the CU's LDS) -- a measurement variant: bit-identical, and never faster.  Measured at T = 800
+    // (tools/x3_pair_probe.py, profiles/r03_x3_pair_probe.log): B = 32 1.78 ms per 20 layers (8 waves) vs 1.94 - 2.38 ms (4 waves,
+    // 256 - 512 workers: only 400 tile chains exist, the extra workers wait); B = 64 (800 chains) 3.65 vs 3.69 ms -- with
+    // the phases of two tasks overlapping on every CU the clock drops from 1.88 to 1.63 GHz and the throughput stays
+    // where it was: the kernel runs at the chip's power limit, not at an issue or latency limit.
+    const int max_dil = 1 << (a.dilation_cycle_length - 1);
+    const size_t lds2 = narrow ? x3_lds_bytes<SplitF16x2, 1>(max_dil) : x3_lds_bytes<SplitF16x2, 2>(max_dil);
+    bool pair = false;
+    if (const char *e = getenv("SET_AMD_X3_WAVES")) pair = a.x3_mode == 2 && 2 * lds2 <= 160 * 1024 && atoi(e) == 4;
+    if (a.x3_mode == 2) {
+        if (pair) return narrow ? launch_x3<SplitF16x2, 2, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitF16x2, 2, 2>(a, n_cu, fault_tile, s);
+        return narrow ? launch_x3<SplitF16x2, 1, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitF16x2, 1, 2>(a, n_cu, fault_tile, s);
+    }
+    return narrow ? launch_x3<SplitBf16x3, 1, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitBf16x3, 1, 2>(a, n_cu, fault_tile, s);
 }

@@ -597,6 +597,37 @@ def test_x3_stack_tile_widths_agree_bit_for_bit(dev, monkeypatch, x3_mode):
     monkeypatch.delenv("SET_AMD_X3_TILE")
 
 
+@pytest.mark.parametrize("x3_mode", [2, 3])
+def test_x3_stack_block_shapes_agree_bit_for_bit(dev, monkeypatch, x3_mode):
+    """Two 4-wave blocks per CU (each wave owns 64 gate + 64 filter rows; the partner block's GEMMs cover this block's
+    staging / gate / epilogue) against one 8-wave block per CU: the same images, the same products in the same order per
+    accumulator -- bit-identical, for both tile widths, ragged lengths, utterance boundaries inside a tile, several worker
+    counts (the dependency protocol must hold with two blocks per CU and with more workers than CUs)."""
+    from set_amd import ops
+    monkeypatch.setenv("SET_AMD_X3", "2")
+    monkeypatch.setenv("SET_AMD_SPLIT", "0")
+    for (B, T, L, dcl, tile) in ((8, 800, 20, 1, "64"), (3, 203, 5, 1, "32"), (1, 1, 2, 1, "64"), (5, 66, 8, 2, "64"),
+                                 (2, 1548, 3, 1, "32"), (32, 800, 4, 1, "64")):
+        x0, cp, dtab, packs, wds, wos, bd, bo = _random_stack(dev, B, T, L, B * 100 + T + 11, x3_mode)
+        monkeypatch.setenv("SET_AMD_X3_TILE", tile)
+        outs = []
+        for waves, grid in (("8", None), ("4", None), ("4", "7"), ("4", "512")):
+            monkeypatch.setenv("SET_AMD_X3_WAVES", waves)
+            if grid is None:
+                monkeypatch.delenv("SET_AMD_STACK_GRID", raising=False)
+            else:
+                monkeypatch.setenv("SET_AMD_STACK_GRID", grid)
+            xa, xb, skip = x0.clone(), torch.full_like(x0, float("nan")), torch.full_like(x0, float("nan"))
+            ws = ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4, 0, 3, 256 * 3, packs, dcl)
+            torch.cuda.synchronize()
+            assert int(ws[1]) == 0
+            outs.append(((xb if L % 2 else xa).clone(), skip.clone()))
+        for o in outs[1:]:
+            assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]), (B, T)
+    for k in ("SET_AMD_X3_TILE", "SET_AMD_X3_WAVES", "SET_AMD_STACK_GRID"):
+        monkeypatch.delenv(k, raising=False)
+
+
 @pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
 @pytest.mark.parametrize("case", ["infer_tiny", "infer_pad", "infer_drift100", "infer_dil"])
 def test_full_inference_matches_reference_with_split_operand_kernel_forced(dev, monkeypatch, case, split):
@@ -960,21 +991,47 @@ def test_task_run_model_paste(dev):
 # ----------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,h", [("hifigan_tiny", Wt.HIFIGAN_TINY), ("hifigan_tiny_rb2", Wt.HIFIGAN_TINY_RB2),
                                     ("hifigan_v1", Wt.HIFIGAN_V1), ("hifigan_v1_long", Wt.HIFIGAN_V1)])
-@pytest.mark.parametrize("impl", ["naive", "mfma"])
+@pytest.mark.parametrize("impl", ["auto", "naive", "mfma"])
 def test_hifigan_matches_reference(dev, name, h, impl, monkeypatch):
     """`hifigan_v1_long` = the V1 generator at T=220 (56,320 samples): many tiles per stage, every dilation x kernel halo
-    crosses tile borders (VERDICT r1 weak #3)."""
+    crosses tile borders.  `auto` is the SHIPPED path -- what `HifiGanGenerator.forward` runs when
+    nobody pins a kernel: the two-piece fp16 conv kernel / fused ResBlock kernels, the all-phase transposed convs, and the
+    fp32 MFMA kernel only for the shapes those do not take -- against the reference's own waveforms;
+    the fp16 range flag must stay clear (a set flag would mean the forward silently fell back to the fp32 kernels)."""
     from set_amd import ops
     from set_amd.hifigan import HifiGanGenerator
     if impl == "naive" and name.endswith("_long"):
         pytest.skip("the one-thread-per-output cross-check kernel is exercised by the short cases")
-    monkeypatch.setattr(ops, "_DEFAULT_IMPL", impl)
+    if impl == "auto":
+        assert ops._DEFAULT_IMPL == "auto"
+        monkeypatch.delenv("SET_AMD_VOCODER_SPLIT", raising=False)
+        ops.conv_x2_range_flag(reset=True)
+    else:
+        monkeypatch.setattr(ops, "_DEFAULT_IMPL", impl)
     g = load_golden(name)
     gen = HifiGanGenerator(h)
     gen.load_state_dict(Wt.seeded_weights(Wt.load_manifest(g["meta"].get("manifest", name)), g["meta"]["wseed"]), strict=True)
     gen.to(dev).eval()
-    wav = gen(torch.from_numpy(g["mel"]).to(dev))
-    torch.cuda.synchronize()
+    if impl == "auto":
+        # the shipped forward with the kernel picks recorded: the split-operand kernels must actually have run
+        picks = []
+        real_pick = ops._pick_impl
+
+        def spy(*a, **k):
+            r = real_pick(*a, **k)
+            picks.append(r)
+            return r
+        monkeypatch.setattr(ops, "_pick_impl", spy)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")  # the range fallback warns: it must not happen
+            wav = gen(torch.from_numpy(g["mel"]).to(dev))
+        torch.cuda.synchronize()
+        assert not ops.conv_x2_range_flag(reset=True)
+        assert "f16x2" in picks, picks
+    else:
+        wav = gen(torch.from_numpy(g["mel"]).to(dev))
+        torch.cuda.synchronize()
     assert wav.shape == g["wav"].shape
     assert _maxdiff(wav, g["wav"]) < 1e-4
 
