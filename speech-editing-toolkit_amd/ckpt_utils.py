@@ -55,7 +55,10 @@ def load_ckpt(cur_model, ckpt_base_dir, model_name="model", force=True, strict=T
 def save_ckpt(work_dir, model, optimizer=None, global_step=0, epoch=0, best=None, num_ckpt_keep=3, model_name="model"):
     """trainer.py:430-471 (`save_checkpoint` / `_atomic_save` / `dump_checkpoint`) for one model + one optimizer."""
     os.makedirs(work_dir, exist_ok=True)
+    # `global_step_unit`: this trainer counts optimizer updates, the reference counts batches (they differ only under
+    # accumulate_grad_batches > 1; trainer.Trainer checks the key before resuming such a run)
     ckpt = {"epoch": int(epoch), "global_step": int(global_step), "checkpoint_callback_best": best,
+            "global_step_unit": "updates",
             "optimizer_states": [optimizer.state_dict()] if optimizer is not None else [],
             "state_dict": {model_name: {k: v.detach().cpu() for k, v in model.state_dict().items()}}}
     path = "%s/model_ckpt_steps_%d.ckpt" % (work_dir, int(global_step))

@@ -151,20 +151,31 @@ def build_batches(dataset, shuffle, max_tokens=None, max_sentences=None, require
         sampler = batch_by_size(indices, dataset.num_tokens, max_tokens, max_sentences, required_batch_size_multiple)
     else:
         sampler = [list(indices[i:i + max_sentences]) for i in range(0, len(indices), max_sentences)]
+    # One epoch's batches as python ints, ONCE; the (up to 1000) repetitions of an endless loader only repeat references
+    # to these lists, like the reference does.  (Copying every repetition cost GBs of host memory and tens of seconds
+    # per rank on a VCTK-sized set: ~2.7 k batches x 1000 repetitions.)
+    sampler = [[int(i) for i in b] for b in sampler]
+    if world > 1:  # speech_base.py:128-131: the rank's share of the batches whose size divides evenly
+        kept = [b[rank::world] if len(b) % world == 0 else None for b in sampler]
+    else:
+        kept = sampler
+    n = len(sampler)
 
-    def shuffled(bs):
-        np.random.shuffle(bs)
-        return bs
+    def epoch_order():
+        # np.random.shuffle on a python list of n items draws the same numbers and applies the same swaps whatever the
+        # items are, so shuffling the batch NUMBERS reproduces the reference's shuffle of the batch list itself
+        order = list(range(n))
+        if shuffle:
+            np.random.shuffle(order)
+        return order
 
     if shuffle:
-        batches = shuffled(list(sampler))
+        order = epoch_order()  # (the reference shuffles once, then again for each repetition of an endless loader)
         if endless:
-            batches = [b for _ in range(1000) for b in shuffled(list(sampler))]
+            order = [i for _ in range(1000) for i in epoch_order()]
     else:
-        batches = [b for _ in range(1000) for b in sampler] if endless else list(sampler)
-    if world > 1:
-        batches = [b[rank::world] for b in batches if len(b) % world == 0]
-    return [[int(i) for i in b] for b in batches]
+        order = [i for _ in range(1000) for i in range(n)] if endless else list(range(n))
+    return [kept[i] for i in order if kept[i] is not None]
 
 
 class StutterSpeechDataset:

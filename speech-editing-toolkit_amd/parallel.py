@@ -129,52 +129,69 @@ def bucketed_all_reduce_sum_(flat, bucket_elems):
 class GradBucketer:
     """Overlap the data-parallel gradient exchange with backward ("bucketed and overlapped").
 
-    The gradients live in ONE flat buffer in parameter order (training.FlatAdamW); backward produces them roughly in
-    reverse order, so the buffer is cut into contiguous buckets from the END and every parameter gets a
-    post-accumulate-grad hook: when the last gradient of a bucket has been accumulated, that bucket's SUM all-reduce
-    is launched asynchronously (RCCL runs it on its own stream behind an event on the compute stream, i.e. under the
-    rest of backward).  `finish()` launches whatever never fired (parameters without gradients: fs.decoder /
-    fs.mel_out stay zero) and waits.  Few large buckets: xGMI rings are per-link bound, small messages waste them."""
+    The gradients live in ONE flat buffer in parameter order (training.FlatAdamW).  Backward produces them roughly in
+    reverse order WITHIN a top-level module, and module by module in reverse data-flow order: for the spec_denoiser the
+    parameter order is denoise_fn.* (57.7 MB), fs.*, mel_encoder.* while backward reaches denoise_fn FIRST (back to
+    front) and the conditioner LAST.  So the buffer is cut into contiguous buckets from the END, a bucket is closed when
+    it holds `bucket_elems` gradients -- and also at a top-level module boundary (`groups`), so that the tail of
+    denoise_fn (the first gradients to exist) never waits in one bucket with the conditioner's (the last).  Every parameter
+    gets a post-accumulate-grad hook: when the last gradient of a bucket has been accumulated, that bucket's SUM
+    all-reduce is launched asynchronously (RCCL runs it on its own stream behind an event on the compute stream, i.e.
+    under the rest of backward).  `finish()` launches whatever never fired (parameters without gradients: fs.decoder /
+    fs.mel_out stay zero) and waits.  A few ~25 MB buckets: xGMI rings are per-link bound, small messages waste them,
+    one 64 MB bucket that ends in the conditioner leaves most of the exchange exposed after backward."""
 
-    def __init__(self, params, flat_g, bucket_elems, force=False):
+    def __init__(self, params, flat_g, bucket_elems, force=False, groups=None):
         self.flat_g = flat_g
         # force: keep the machinery on at world size 1 (a single-rank RCCL group on a 1-GPU box still runs every
         # all-reduce through the library: tests/test_gpu_dist.py)
         self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
         self.buckets = []      # [start, end) element ranges, last bucket of the buffer first
         self.launch_log = []   # bucket ids in launch order, "hook" / "finish" (diagnostics + tests)
+        self.event_log = []    # ("arrive", parameter index) / ("launch", bucket id) in program order (tests)
         self._pending, self._works, self._handles = [], {}, []
         self.defer, self.bytes_reduced, self.exposed_s, self._owner_of = False, 0, 0.0, {}
+        self.bucket_of = []    # bucket id of every parameter
         if not self.enabled:
             return
-        offs, off = [], 0
-        for p in params:
-            offs.append((off, off + p.numel()))
-            off += p.numel()
-        # cut from the end so the first gradients to arrive complete a bucket early
-        owner = [0] * len(params)
-        end, count, cur = off, 0, 0
-        for i in range(len(params) - 1, -1, -1):
-            owner[i] = cur
-            count += params[i].numel()
-            if count >= bucket_elems or i == 0:
-                self.buckets.append((offs[i][0], end))
-                end, count, cur = offs[i][0], 0, cur + 1
-        if self.buckets and self.buckets[0][1] < flat_g.numel():  # padding tail of the flat buffer rides with bucket 0
-            self.buckets[0] = (self.buckets[0][0], flat_g.numel())
+        self.buckets, self.bucket_of = self.cut_buckets([p.numel() for p in params], bucket_elems, groups, flat_g.numel())
+        owner = self.bucket_of
         self._members = [0] * len(self.buckets)
         for i, p in enumerate(params):
             if p.requires_grad:
                 self._members[owner[i]] += 1
                 self._owner_of[id(p)] = owner[i]
-                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(owner[i])))
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(owner[i], i)))
         self.reset()
 
-    def _make_hook(self, b):
+    @staticmethod
+    def cut_buckets(numels, bucket_elems, groups=None, flat_numel=None):
+        """(buckets, bucket id per parameter): contiguous [start, end) ranges cut from the END of the flat buffer; closed
+        at `bucket_elems` elements or at a change of `groups[i]` once the bucket holds bucket_elems / 8 (a tiny module --
+        the 0.36 MB mel_encoder -- rides with its neighbour rather than paying a collective's latency for itself)."""
+        offs, off = [], 0
+        for n in numels:
+            offs.append((off, off + n))
+            off += n
+        buckets, owner = [], [0] * len(numels)
+        end, count, cur = off, 0, 0
+        for i in range(len(numels) - 1, -1, -1):
+            owner[i] = cur
+            count += numels[i]
+            boundary = groups is not None and i > 0 and groups[i - 1] != groups[i] and count >= max(1, bucket_elems // 8)
+            if count >= bucket_elems or boundary or i == 0:
+                buckets.append((offs[i][0], end))
+                end, count, cur = offs[i][0], 0, cur + 1
+        if buckets and flat_numel is not None and buckets[0][1] < flat_numel:  # padding tail of the flat buffer rides with bucket 0
+            buckets[0] = (buckets[0][0], flat_numel)
+        return buckets, owner
+
+    def _make_hook(self, b, index=-1):
         # NB torch fires a post-accumulate-grad hook for every leaf the backward graph reaches, also when the backward
         # function returned None for it -- which is what lets the gradient kernels write .grad directly (training.
         # FlatAdamW.sink) and still have their bucket launched from here, right after their kernel was enqueued.
         def hook(_param):
+            self.event_log.append(("arrive", index))
             self._arrive(b)
         return hook
 
@@ -202,6 +219,7 @@ class GradBucketer:
         s, e = self.buckets[b]
         self._works[b] = dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True)
         self.launch_log.append((b, why))
+        self.event_log.append(("launch", b))
         self.bytes_reduced += 4 * (e - s)
 
     def reset(self, defer=False):
@@ -212,6 +230,7 @@ class GradBucketer:
             self._pending = list(self._members)
             self._works = {}
             self.launch_log = []
+            self.event_log = []
             self.defer = bool(defer)
             self.bytes_reduced = 0
 

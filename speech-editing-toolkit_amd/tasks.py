@@ -1,6 +1,6 @@
 """Task-level operator surface of the hot path.
 
-`DIFF_DECODERS` and `SpeechDenoiserTask` mirror tasks/speech_editing/spec_denoiser.py:13-62 (registry,
+`SpeechEditingBaseTask` carries what both tasks share with the Trainer; `DIFF_DECODERS` and `SpeechDenoiserTask` mirror tasks/speech_editing/spec_denoiser.py:13-62 (registry,
 `build_tts_model`, `run_model` incl. the `mel_out*mask + target*(1-mask)` paste), the loss functions of the task base
 classes (tasks/tts/speech_base.py:219-257, speech_editing_base.py:58-108) and the hooks the Trainer counterpart
 (trainer.py) drives: `configure_optimizers`, `train_dataloader` / `val_dataloader`, `_training_step`,
@@ -31,8 +31,12 @@ TASK_ALIASES = {
 }
 
 
-class SpeechDenoiserTask:
-    model_cls = GaussianDiffusion
+class SpeechEditingBaseTask:
+    """What the Trainer counterpart drives, shared by the two tasks of the path (tasks/speech_editing/
+    speech_editing_base.py:16-192 over tasks/tts/speech_base.py:35-380 and utils/commons/base_task.py:24-232): phone set +
+    vocoder in the constructor, `build_model`, optimizer, train / validation loaders over `StutterSpeechDataset`,
+    `_training_step`, `validation_step`, the dataset-driven `test`, and `start()`.  Subclasses provide `build_tts_model`
+    and `run_model`."""
 
     def __init__(self, build_vocoder=True):
         # phone set: <binary_data_dir>/phone_set.json through the reference's TokenTextEncoder layout
@@ -46,17 +50,16 @@ class SpeechDenoiserTask:
             self.token_encoder = list(range(int(hparams.get("dict_size", 80))))
             self.sil_ids = [int(i) for i in hparams.get("sil_token_ids", [1, 2, 3])]
         self.vocoder = None
-        if build_vocoder and os.path.exists(os.path.join(hparams.get("vocoder_ckpt", ""), "config.yaml")):
+        if build_vocoder and os.path.exists(os.path.join(hparams.get("vocoder_ckpt", "") or "", "config.yaml")):
             self.vocoder = get_vocoder_cls(hparams["vocoder"])()
         self.model = None
+        self.global_step = 0
 
     def build_tts_model(self):
-        self.model = self.model_cls(
-            phone_encoder=self.token_encoder, out_dims=hparams["audio_num_mel_bins"],
-            denoise_fn=DIFF_DECODERS[hparams["diff_decoder_type"]](hparams),
-            timesteps=hparams["timesteps"], time_scale=hparams["timescale"], loss_type=hparams["diff_loss_type"],
-            spec_min=hparams["spec_min"], spec_max=hparams["spec_max"], hp=hparams)
-        return self.model
+        raise NotImplementedError
+
+    def run_model(self, sample, infer=False, **kwargs):
+        raise NotImplementedError
 
     def build_model(self):
         self.build_tts_model()
@@ -64,81 +67,6 @@ class SpeechDenoiserTask:
             from .ckpt_utils import load_ckpt
             load_ckpt(self.model, hparams["load_ckpt"])
         return self.model
-
-    # ---- losses (tasks/tts/speech_base.py:219-257, tasks/speech_editing/speech_editing_base.py:58-108) ----------
-    def word_ids(self, txt_tokens):
-        """word_id = cumsum(is_sil) * (1 - is_sil)  (speech_editing_base.py:69-78); silence = the phone set's
-        non-alphabetic tokens incl. the reserved ones (`self.sil_ids`, see __init__)."""
-        sil = torch.zeros_like(txt_tokens, dtype=torch.bool)
-        for i in self.sil_ids:
-            sil |= txt_tokens == int(i)
-        sil = sil.long()
-        word_id = (sil.cumsum(-1) * (1 - sil)).contiguous()
-        # number of word slots: the reference sizes its scatter target with word_id.max() + 1, a device->host read in the
-        # middle of every step; T_txt is an upper bound (a word has at least one token) and the empty slots have zero
-        # ground-truth duration, i.e. weight 0 in the loss -- same sums, no synchronisation
-        return word_id, int(txt_tokens.shape[1])
-
-    def compute_losses(self, output, sample):
-        """The loss dict of run_model(infer=False): l1_coarse, ssim_coarse, pdur, wdur, uv, f0 (all on the tape)."""
-        if float(hparams.get("lambda_sent_dur", 0.0)) > 0:
-            # speech_editing_base.py:86-89; every shipped config sets it to 0 -- refuse rather than silently drop a loss
-            raise NotImplementedError("lambda_sent_dur > 0 (the `sdur` loss) is not implemented on this path")
-        if not float(hparams.get("lambda_word_dur", 1.0)) > 0:
-            raise NotImplementedError("lambda_word_dur <= 0: the reference then emits no `wdur` term; not implemented")
-        A = autograd_ops
-        target = sample["mels"].contiguous()
-        B, T, M = target.shape
-        tm = sample["time_mel_masks"].reshape(B, T).contiguous()
-        pred = A.bct_to_btc(A.add_chan_mask(output["mel_out_bct"], None, tm))          # mel_out * mask
-        target_m = ops.blend_mask(torch.zeros_like(target), target, tm, M)             # target * mask
-        w = A.frame_weights(target_m)
-        losses = {}
-        for item in str(hparams["mel_losses"]).split("|"):
-            name, lam = (item.split(":") + ["1.0"])[:2]
-            if name == "l1":
-                losses["l1_coarse"] = A.masked_l1(pred, target_m, w) * float(lam)
-            elif name == "ssim":
-                losses["ssim_coarse"] = A.ssim_loss(pred, target_m, w) * float(lam)
-            else:
-                raise NotImplementedError("mel loss %r" % name)
-        word_id, n_words = self.word_ids(sample["txt_tokens"])
-        losses["pdur"], losses["wdur"] = A.dur_losses(output["dur"], sample["mel2ph"], sample["txt_tokens"], word_id,
-                                                       n_words, hparams["lambda_ph_dur"], hparams["lambda_word_dur"])
-        if hparams["use_pitch_embed"]:
-            losses["uv"], losses["f0"] = A.pitch_losses(output["pitch_pred_bct"], sample["f0"], sample["uv"],
-                                                        sample["mel2ph"], hparams["lambda_uv"], hparams["lambda_f0"])
-        return losses
-
-    def run_model(self, sample, infer=False, **kwargs):
-        """tasks/speech_editing/spec_denoiser.py:39-62.  infer=False returns (losses, output) on an autograd tape
-        whose every node is a kernel of libset_amd.so; infer=True returns the pasted output."""
-        if not infer:
-            target = sample["mels"]
-            tmask = sample["time_mel_masks"][:, :, None]
-            spk = sample.get("spk_embed") if not hparams["use_spk_id"] else sample.get("spk_ids")
-            with torch.enable_grad():
-                output = self.model(sample["txt_tokens"], tmask, mel2ph=sample["mel2ph"], spk_embed=spk,
-                                    ref_mels=target, f0=sample["f0"], uv=sample["uv"], energy=None, infer=False, **kwargs)
-                losses = self.compute_losses(output, sample)
-            with torch.no_grad():
-                B, T, M = target.shape
-                output["mel_out"] = ops.blend_mask(target.contiguous(), output["mel_out"].detach().contiguous(),
-                                                   tmask.reshape(B, T).contiguous(), M)
-            return losses, output
-        return self._run_model_infer(sample, **kwargs)
-
-    @torch.no_grad()
-    def _run_model_infer(self, sample, **kwargs):
-        target = sample["mels"]
-        tmask = sample["time_mel_masks"][:, :, None]
-        spk = sample.get("spk_embed") if not hparams["use_spk_id"] else sample.get("spk_ids")
-        output = self.model(sample["txt_tokens"], tmask, mel2ph=sample["mel2ph"], spk_embed=spk, ref_mels=target,
-                            f0=sample["f0"], uv=sample["uv"], energy=None, infer=True, **kwargs)
-        B, T, M = target.shape
-        # mel_out*mask + target*(1-mask)   (spec_denoiser.py:53)
-        output["mel_out"] = ops.blend_mask(target.contiguous(), output["mel_out"], tmask.reshape(B, T).contiguous(), M)
-        return output
 
     def training_step(self, sample, optimizer, **kwargs):
         """One optimisation step: forward + losses, backward, gradient all-reduce (if distributed), clip + AdamW."""
@@ -197,7 +125,7 @@ class SpeechDenoiserTask:
 
     def validation_step(self, sample, batch_idx):
         """speech_base.py:193-203 without the plot / vocoder side effects: the loss dict on a validation batch."""
-        losses, _ = self.run_model(sample, infer=False, seed=batch_idx)
+        losses, _ = self.run_model(sample, infer=False, tape=False, seed=batch_idx)
         losses = {k: float(v) for k, v in losses.items()}
         return {"losses": losses, "total_loss": sum(losses.values()), "nsamples": sample.get("nsamples", 1)}
 
@@ -287,6 +215,92 @@ class SpeechDenoiserTask:
             trainer.test(cls)
         return trainer
 
+class SpeechDenoiserTask(SpeechEditingBaseTask):
+    model_cls = GaussianDiffusion
+
+    def build_tts_model(self):
+        self.model = self.model_cls(
+            phone_encoder=self.token_encoder, out_dims=hparams["audio_num_mel_bins"],
+            denoise_fn=DIFF_DECODERS[hparams["diff_decoder_type"]](hparams),
+            timesteps=hparams["timesteps"], time_scale=hparams["timescale"], loss_type=hparams["diff_loss_type"],
+            spec_min=hparams["spec_min"], spec_max=hparams["spec_max"], hp=hparams)
+        return self.model
+
+    # ---- losses (tasks/tts/speech_base.py:219-257, tasks/speech_editing/speech_editing_base.py:58-108) ----------
+    def word_ids(self, txt_tokens):
+        """word_id = cumsum(is_sil) * (1 - is_sil)  (speech_editing_base.py:69-78); silence = the phone set's
+        non-alphabetic tokens incl. the reserved ones (`self.sil_ids`, see __init__)."""
+        sil = torch.zeros_like(txt_tokens, dtype=torch.bool)
+        for i in self.sil_ids:
+            sil |= txt_tokens == int(i)
+        sil = sil.long()
+        word_id = (sil.cumsum(-1) * (1 - sil)).contiguous()
+        # number of word slots: the reference sizes its scatter target with word_id.max() + 1, a device->host read in the
+        # middle of every step; T_txt is an upper bound (a word has at least one token) and the empty slots have zero
+        # ground-truth duration, i.e. weight 0 in the loss -- same sums, no synchronisation
+        return word_id, int(txt_tokens.shape[1])
+
+    def compute_losses(self, output, sample):
+        """The loss dict of run_model(infer=False): l1_coarse, ssim_coarse, pdur, wdur, uv, f0 (all on the tape)."""
+        if float(hparams.get("lambda_sent_dur", 0.0)) > 0:
+            # speech_editing_base.py:86-89; every shipped config sets it to 0 -- refuse rather than silently drop a loss
+            raise NotImplementedError("lambda_sent_dur > 0 (the `sdur` loss) is not implemented on this path")
+        if not float(hparams.get("lambda_word_dur", 1.0)) > 0:
+            raise NotImplementedError("lambda_word_dur <= 0: the reference then emits no `wdur` term; not implemented")
+        A = autograd_ops
+        target = sample["mels"].contiguous()
+        B, T, M = target.shape
+        tm = sample["time_mel_masks"].reshape(B, T).contiguous()
+        pred = A.bct_to_btc(A.add_chan_mask(output["mel_out_bct"], None, tm))          # mel_out * mask
+        target_m = ops.blend_mask(torch.zeros_like(target), target, tm, M)             # target * mask
+        w = A.frame_weights(target_m)
+        losses = {}
+        for item in str(hparams["mel_losses"]).split("|"):
+            name, lam = (item.split(":") + ["1.0"])[:2]
+            if name == "l1":
+                losses["l1_coarse"] = A.masked_l1(pred, target_m, w) * float(lam)
+            elif name == "ssim":
+                losses["ssim_coarse"] = A.ssim_loss(pred, target_m, w) * float(lam)
+            else:
+                raise NotImplementedError("mel loss %r" % name)
+        word_id, n_words = self.word_ids(sample["txt_tokens"])
+        losses["pdur"], losses["wdur"] = A.dur_losses(output["dur"], sample["mel2ph"], sample["txt_tokens"], word_id,
+                                                       n_words, hparams["lambda_ph_dur"], hparams["lambda_word_dur"])
+        if hparams["use_pitch_embed"]:
+            losses["uv"], losses["f0"] = A.pitch_losses(output["pitch_pred_bct"], sample["f0"], sample["uv"],
+                                                        sample["mel2ph"], hparams["lambda_uv"], hparams["lambda_f0"])
+        return losses
+
+    def run_model(self, sample, infer=False, tape=True, **kwargs):
+        """tasks/speech_editing/spec_denoiser.py:39-62.  infer=False returns (losses, output) on an autograd tape
+        whose every node is a kernel of libset_amd.so (tape=False: the same losses with no graph kept -- validation);
+        infer=True returns the pasted output."""
+        if not infer:
+            target = sample["mels"]
+            tmask = sample["time_mel_masks"][:, :, None]
+            spk = sample.get("spk_embed") if not hparams["use_spk_id"] else sample.get("spk_ids")
+            with (torch.enable_grad() if tape else torch.no_grad()):
+                output = self.model(sample["txt_tokens"], tmask, mel2ph=sample["mel2ph"], spk_embed=spk,
+                                    ref_mels=target, f0=sample["f0"], uv=sample["uv"], energy=None, infer=False, **kwargs)
+                losses = self.compute_losses(output, sample)
+            with torch.no_grad():
+                B, T, M = target.shape
+                output["mel_out"] = ops.blend_mask(target.contiguous(), output["mel_out"].detach().contiguous(),
+                                                   tmask.reshape(B, T).contiguous(), M)
+            return losses, output
+        return self._run_model_infer(sample, **kwargs)
+
+    @torch.no_grad()
+    def _run_model_infer(self, sample, **kwargs):
+        target = sample["mels"]
+        tmask = sample["time_mel_masks"][:, :, None]
+        spk = sample.get("spk_embed") if not hparams["use_spk_id"] else sample.get("spk_ids")
+        output = self.model(sample["txt_tokens"], tmask, mel2ph=sample["mel2ph"], spk_embed=spk, ref_mels=target,
+                            f0=sample["f0"], uv=sample["uv"], energy=None, infer=True, **kwargs)
+        B, T, M = target.shape
+        # mel_out*mask + target*(1-mask)   (spec_denoiser.py:53)
+        output["mel_out"] = ops.blend_mask(target.contiguous(), output["mel_out"], tmask.reshape(B, T).contiguous(), M)
+        return output
 
 class SpeechDenoiserNormalTask(SpeechDenoiserTask):
     """tasks/speech_editing/spec_denoiser_normal.py:18-102 (egs/spec_denoiser_wo_masked_predictor.yaml:50): the same
@@ -294,23 +308,29 @@ class SpeechDenoiserNormalTask(SpeechDenoiserTask):
     model_cls = GaussianDiffusionNormal
 
 
-class CampNetTask:
-    """tasks/speech_editing/campnet.py:19-82: model construction, `run_model` (coarse + fine masked mel losses,
-    `mel_out` = fine prediction pasted into the original) and one optimisation step.  The dataset-driven trainer
-    loop around it is out of scope, as for SpeechDenoiserTask."""
+class CampNetTask(SpeechEditingBaseTask):
+    """tasks/speech_editing/campnet.py:19-138 (BASELINE configs[4]): `CampNetTask(SpeechEditingBaseTask)` -- the phone and
+    word dictionaries of <binary_data_dir> size the model (`word_set.json`, campnet.py:22-23,28-31), `run_model` returns
+    the coarse + fine masked mel losses and `mel_out` = the fine prediction pasted into the original (:49-82), one AdamW
+    over all parameters with the warm-up schedule (:119-138), and the base class's `start()` / loaders over
+    `StutterSpeechDataset` / validation / `--infer` test loop.  The attention-statistics logging (:101-117) and the
+    tensorboard side of `save_valid_result` are not part of the build."""
 
-    def __init__(self, ph_dict_size=None, word_dict_size=None):
-        self.ph_dict_size = int(ph_dict_size if ph_dict_size is not None else hparams.get("dict_size", 80))
-        self.word_dict_size = int(word_dict_size if word_dict_size is not None else hparams.get("word_dict_size", 100))
-        self.model = None
-        self.global_step = 0
+    def __init__(self, ph_dict_size=None, word_dict_size=None, build_vocoder=True):
+        super().__init__(build_vocoder=build_vocoder)
+        bd = hparams.get("binary_data_dir", "") or ""
+        word_path = os.path.join(bd, "word_set.json")
+        self.word_encoder = build_token_encoder(word_path) if os.path.exists(word_path) else None
+        if ph_dict_size is None:
+            ph_dict_size = len(self.token_encoder)
+        if word_dict_size is None:
+            word_dict_size = len(self.word_encoder) if self.word_encoder is not None else hparams.get("word_dict_size", 100)
+        self.ph_dict_size, self.word_dict_size = int(ph_dict_size), int(word_dict_size)
 
     def build_tts_model(self):
         from .campnet import CampNet
         self.model = CampNet(self.ph_dict_size, self.word_dict_size, hparams)
         return self.model
-
-    build_model = build_tts_model
 
     def compute_losses(self, output, sample):
         """add_mel_loss on `mel_out_{coarse,fine} * mask` vs `mels * mask` (campnet.py:63-64; speech_base.py:219-257)."""
@@ -323,10 +343,7 @@ class CampNetTask:
         losses = {}
         for post in ("coarse", "fine"):
             pred = A.bct_to_btc(A.add_chan_mask(output["mel_out_%s_bct" % post], None, tm))
-            if post == "coarse":
-                pred_l1, pred_ssim = A.fanout(pred, 2)
-            else:
-                pred_l1, pred_ssim = A.fanout(pred, 2)
+            pred_l1, pred_ssim = A.fanout(pred, 2)
             for item in str(hparams["mel_losses"]).split("|"):
                 name, lam = (item.split(":") + ["1.0"])[:2]
                 if name == "l1":
@@ -337,12 +354,15 @@ class CampNetTask:
                     raise NotImplementedError("mel loss %r" % name)
         return losses
 
-    def run_model(self, sample, infer=False, **kwargs):
+    def run_model(self, sample, infer=False, tape=True, **kwargs):
+        """campnet.py:49-82.  `seed` / `t` (the Trainer passes every task the update's random streams) are not used: every
+        dropout of egs/campnet.yaml is 0 and the model draws no noise.  tape=False: the losses without an autograd graph
+        (validation)."""
         mels = sample["mels"]
         tmask = sample["time_mel_masks"][:, :, None]
         B, T, M = mels.shape
         if not infer:
-            with torch.enable_grad():
+            with (torch.enable_grad() if tape else torch.no_grad()):
                 output = self.model(sample["txt_tokens"], spk_embed=sample.get("spk_embed"), spk_id=sample.get("spk_ids"),
                                     mels=mels, time_mel_masks=tmask, infer=False, global_step=self.global_step)
                 losses = self.compute_losses(output, sample)
@@ -351,12 +371,12 @@ class CampNetTask:
                 output = self.model(sample["txt_tokens"], spk_embed=sample.get("spk_embed"), spk_id=sample.get("spk_ids"),
                                     mels=mels, time_mel_masks=tmask, infer=True)
         with torch.no_grad():
-            output["mel_out"] = ops.blend_mask(mels.contiguous(), output["mel_out_fine"].contiguous(),
+            output["mel_out"] = ops.blend_mask(mels.contiguous(), output["mel_out_fine"].detach().contiguous(),
                                                tmask.reshape(B, T).contiguous(), M)
         return (losses, output) if not infer else output
 
-    def training_step(self, sample, optimizer):
-        out = _optimisation_step(self, sample, optimizer)
+    def training_step(self, sample, optimizer, **kwargs):
+        out = _optimisation_step(self, sample, optimizer, **kwargs)
         self.global_step += 1
         return out
 
@@ -371,7 +391,7 @@ def _optimisation_step(task, sample, optimizer, **kwargs):
             total = sum(losses.values())
         total.backward()
     except BaseException:
-        autograd_ops.zero_arena_end()
+        optimizer.abort_step()
         raise
     lr, _ = optimizer.step()
     return total.detach(), {k: v.detach() for k, v in losses.items()}, lr
@@ -381,7 +401,7 @@ def run_task():
     """tasks/run.py:9-14."""
     path = TASK_ALIASES.get(hparams["task_cls"], hparams["task_cls"])
     pkg, cls_name = path.rsplit(".", 1)
-    getattr(importlib.import_module(pkg), cls_name).start()
+    return getattr(importlib.import_module(pkg), cls_name).start()
 
 
 if __name__ == "__main__":

@@ -9,6 +9,11 @@ What is deliberately different from the reference (and why):
   seed of noise / dropout, and the numpy / python / torch generators the dataset's mask generators draw from.  A run
   resumed from `model_ckpt_steps_N.ckpt` therefore continues with exactly the batches and random numbers the
   uninterrupted run would have used (the reference reseeds and restarts its endless batch list from the beginning);
+* `global_step` counts OPTIMIZER UPDATES; with `accumulate_grad_batches` = a > 1 an update consumes a batches (the
+  reference counts batches and steps the optimizer on every a-th, scheduling on global_step // a): `max_updates`,
+  `val_check_interval`, the warm-up and the step number in checkpoint names therefore mean a times more data here than in
+  a reference run with the same yaml, and a reference checkpoint's `global_step` is read as batches / a when resumed with
+  a > 1 -- `restore_ckpt` refuses that combination rather than mis-schedule it;
 * the optimizer is the fused flat AdamW (training.FlatAdamW) whose state_dict is torch.optim.AdamW's, so checkpoints
   interchange (`optimizer_states[0]`); clip + schedule are inside its step (base_task.py:129-137).
 No tensorboard, no progress bars, no code snapshots: logging is a dict per `log_interval` updates on rank 0.
@@ -72,6 +77,7 @@ class Trainer:
         self.task = self.optimizer = None
         self.rank, self.world = 0, 1
         self.history = []  # (global_step, total loss, losses) of every update of this process (tests, logging)
+        self._prefetch = None
 
     # ---- entry points (trainer.py:112-137) -----------------------------------------------------------------------
     def test(self, task_cls):
@@ -102,6 +108,10 @@ class Trainer:
         if self.global_step > 0:
             ck, _ = ckpt_utils.get_last_checkpoint(self.work_dir)
             self.best_val_results = ck.get("checkpoint_callback_best")
+            if self.accumulate_grad_batches > 1 and ck.get("global_step_unit") != "updates":
+                raise RuntimeError("resuming a checkpoint whose global_step counts batches (written by the reference "
+                                   "trainer) with accumulate_grad_batches=%d: this trainer counts optimizer updates, the "
+                                   "schedule would be off by that factor" % self.accumulate_grad_batches)
         task.global_step = self.global_step
         # barrier, rank-0 parameter / buffer / optimizer-state broadcast, barrier (trainer.py:166-170,402,475-479)
         parallel.configure_ddp(model, self.optimizer)
@@ -131,22 +141,48 @@ class Trainer:
         if self.rank == 0:
             print("| Training end..")
 
+    def _next_batch(self, loader, k):
+        """Batch k of the training list.  With hparams['ds_workers'] > 0 (the reference's DataLoader-worker knob,
+        utils/commons/dataset_utils.py:213-215) batch k + 1 is assembled (dataset[i], mask generators, collate, pinned host
+        buffers) on a background thread while update k runs on the GPU; `fetch(k)` is a pure function of k, so the
+        prefetched batch is the one a synchronous fetch would have produced (a resumed run stays bit-identical).  The
+        worker is the only code that draws from the global numpy / python / torch generators while training runs."""
+        if int(hparams.get("ds_workers", 0) or 0) <= 0:
+            return loader.fetch(k)
+        if self._prefetch is None or self._prefetch[0] is not loader:
+            from concurrent.futures import ThreadPoolExecutor
+            self._prefetch = (loader, ThreadPoolExecutor(max_workers=1), {})
+        _, pool, pending = self._prefetch
+        pin = self.device is not None and self.device.type == "cuda"
+
+        def work(kk):
+            b = loader.fetch(kk)
+            return {n: (v.pin_memory() if pin and isinstance(v, torch.Tensor) else v) for n, v in b.items()}
+        fut = pending.pop(k, None)
+        for stale in [j for j in pending if j != k + 1]:
+            pending.pop(stale).cancel()
+        batch = fut.result() if fut is not None else work(k)
+        if k + 1 not in pending:
+            pending[k + 1] = pool.submit(work, k + 1)
+        return batch
+
     def run_training_batch(self, loader):
         """trainer.py:306-379 for one optimizer: `accumulate_grad_batches` forward/backward passes, then clip + AdamW
         + schedule.  Gradient exchange: launched from autograd hooks during the (single) backward, or after the last
         backward when accumulating."""
         task, opt = self.task, self.optimizer
         acc = self.accumulate_grad_batches
-        from . import autograd_ops
         opt.zero_grad(accumulate=acc > 1)
         total, parts = None, {}
         try:
             for micro in range(acc):
                 k = self.global_step * acc + micro
-                batch = move_to_device(loader.fetch(k), self.device)
-                seed = step_seed(self.seed, k)
+                batch = move_to_device(self._next_batch(loader, k), self.device)
+                # model-side randomness (diffusion steps, noise, dropout) also depends on the rank: data-parallel replicas
+                # must not draw the same t / eps / dropout stream for their i-th sample (the batch LIST stays rank-free)
+                seed = (step_seed(self.seed, k) + 104729 * self.rank) % (2 ** 31 - 1)
                 B = batch["txt_tokens"].shape[0]
-                t = torch.from_numpy(np.random.default_rng([self.seed, k]).integers(
+                t = torch.from_numpy(np.random.default_rng([self.seed, k] + ([self.rank] if self.rank else [])).integers(
                     0, int(task.model.num_timesteps) + 1, size=(B,), dtype=np.int64)).to(self.device) \
                     if hasattr(task.model, "num_timesteps") else None
                 loss, log = task._training_step(batch, k, seed=seed, t=t)
@@ -155,7 +191,7 @@ class Trainer:
                 total = loss.detach() if total is None else total + loss.detach()
                 parts = log  # device scalars: converting here would add a host sync per loss per update
         except BaseException:
-            autograd_ops.zero_arena_end()
+            opt.abort_step()
             raise
         opt.step()
         self.history.append((self.global_step, total / acc, parts))

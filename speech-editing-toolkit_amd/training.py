@@ -17,8 +17,10 @@ from . import ops, parallel
 
 class FlatAdamW:
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, clip_grad_norm=1.0,
-                 warmup_updates=8000, bucket_mb=64):
-        self.params = [p for p in model.parameters()]
+                 warmup_updates=8000, bucket_mb=25):
+        named = list(model.named_parameters())
+        self.params = [p for _, p in named]
+        self.param_names = [n for n, _ in named]
         dev = self.params[0].device
         n = sum(p.numel() for p in self.params)
         n_pad = (n + 255) // 256 * 256
@@ -49,8 +51,10 @@ class FlatAdamW:
         self.clip, self.warmup = clip_grad_norm, warmup_updates
         self.bucket = int(bucket_mb * (1 << 20) // 4)
         # gradient exchange overlapped with backward: buckets launch from autograd hooks (no-op when world == 1)
+        # (buckets follow the order gradients appear in: cut from the end of the buffer, never across a top-level module)
         self.bucketer = parallel.GradBucketer(self.params, self.flat_g, self.bucket,
-                                              force=os.environ.get("SET_AMD_FORCE_BUCKETER", "0") == "1")
+                                              force=os.environ.get("SET_AMD_FORCE_BUCKETER", "0") == "1",
+                                              groups=[n.split(".", 1)[0] for n in self.param_names])
         self.num_updates = 0
         ops.bump_weights_epoch()
 
@@ -80,6 +84,12 @@ class FlatAdamW:
             if p.grad is None or p.grad.data_ptr() < self.flat_g.data_ptr() or \
                     p.grad.data_ptr() >= self.flat_g.data_ptr() + 4 * self.flat_g.numel():
                 raise RuntimeError("a .grad left the flat gradient buffer")
+
+    def abort_step(self):
+        """A step that failed between zero_grad() and step(): close the zero arena and leave the "in step" state, so that a
+        later backward outside a zero_grad()/step() pair goes through autograd instead of writing into the flat buffer."""
+        A.zero_arena_end()
+        self.in_step = False
 
     def step(self):
         """gradient all-reduce (SUM, few large buckets, launched from autograd hooks while backward was still running;

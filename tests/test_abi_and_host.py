@@ -220,7 +220,9 @@ def test_checkpoint_save_resume_and_adamw_state_interchange(tmp_path):
         import os
         assert sorted(os.listdir(d)) == ["model_ckpt_steps_30.ckpt", "model_ckpt_steps_40.ckpt"] and p.endswith("40.ckpt")
         raw = torch.load(p, map_location="cpu", weights_only=False)
-        assert set(raw) == {"epoch", "global_step", "checkpoint_callback_best", "optimizer_states", "state_dict"}
+        # the reference's five keys (utils/commons/trainer.py:459-471) + the step-unit marker its loader ignores
+        assert set(raw) == {"epoch", "global_step", "checkpoint_callback_best", "optimizer_states", "state_dict",
+                            "global_step_unit"} and raw["global_step_unit"] == "updates"
         assert list(raw["state_dict"]) == ["model"]
     m_saved, v_saved = opt.m.clone(), opt.v.clone()
     model2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))

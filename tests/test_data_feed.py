@@ -129,3 +129,41 @@ def test_build_batches_striding_and_loader_is_position_seeded():
     b = ld.fetch(1)
     assert torch.equal(a["time_mel_masks"], b["time_mel_masks"]) and torch.equal(a["mels"], b["mels"])
     assert set(a) >= {"txt_tokens", "mels", "mel2ph", "f0", "uv", "time_mel_masks", "spk_embed", "nsamples"}
+
+
+def test_endless_batch_list_follows_the_reference_shuffle_and_shares_its_batches():
+    """The endless training list (tasks/tts/speech_base.py:113-121: the epoch's batch list shuffled once, then once more
+    for each of 1000 repetitions, numpy global generator) restated literally here on a synthetic index set; the
+    product builds it from shuffled batch NUMBERS and must give the same sequence, on every rank -- and the repetitions
+    must share one epoch's lists instead of copying them (GBs of host memory on a VCTK-sized set)."""
+    import numpy as np
+
+    class Stub:
+        sizes = [17, 60, 33, 41, 25, 58, 12, 49, 30, 44, 21]
+
+        def ordered_indices(self):
+            return np.argsort(np.array(self.sizes), kind="mergesort")
+
+        def num_tokens(self, i):
+            return self.sizes[i]
+
+    ds = Stub()
+    for world in (1, 2):
+        sampler = D.batch_by_size(ds.ordered_indices(), ds.num_tokens, 130 * world, 3 * world, world)
+        np.random.seed(11)
+
+        def shuffled(bs):
+            np.random.shuffle(bs)
+            return bs
+        want = shuffled(list(sampler))
+        want = [b for _ in range(1000) for b in shuffled(list(sampler))]
+        for rank in range(world):
+            np.random.seed(11)
+            got = D.build_batches(ds, True, 130, 3, endless=True, world=world, rank=rank)
+            exp = [[int(i) for i in b[rank::world]] for b in want if len(b) % world == 0]
+            assert got == exp
+            assert all(type(i) is int for b in got[:5] for i in b)
+            assert len({id(b) for b in got}) <= len(sampler)  # one epoch's lists, referenced 1000 times
+    np.random.seed(5)
+    fixed = D.build_batches(ds, False, 130, 3, endless=True)
+    assert fixed[:len(fixed) // 1000] * 1000 == fixed

@@ -216,3 +216,41 @@ def test_configure_ddp_broadcasts_rank0_state_and_accumulation_is_guarded_world2
         assert n_hook == 0 and world_ret == 2   # accumulate=True: nothing launched from hooks, finish() reduces
         assert err < 1e-5
         assert reduced == 4 * 256
+
+
+def test_bucket_cut_follows_gradient_arrival_order_of_the_spec_denoiser():
+    """parameter order is denoise_fn.* (57.7 MB) -> fs.* -> mel_encoder.* while backward reaches denoise_fn
+    first (back to front) and the conditioner last.  Buckets are contiguous ranges cut from the END of the flat buffer;
+    cutting by size alone (64 MB) made bucket 0 = conditioner + the back half of DiffNet, which can only launch at the very
+    end of backward.  With the module-boundary rule and ~25 MB buckets: no bucket mixes denoise_fn with the conditioner, the
+    buckets that hold only denoise_fn tensors come in back-to-front order, the tiny mel_encoder rides with fs, and the whole
+    buffer is covered exactly once."""
+    import json
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from oracle import weights as Wt
+    from set_amd.parallel import GradBucketer
+    man = [(k, int(np.prod(shape)) if shape else 1) for k, shape in json.load(open(os.path.join(GOLDEN, "manifest_spec_denoiser.json")))
+           if not Wt.is_buffer(k)]
+    names, numels = [k for k, _ in man], [n for _, n in man]
+    groups = [k.split(".", 1)[0] for k in names]
+    assert groups[0] == "denoise_fn" and groups[-1] == "mel_encoder" and "fs" in groups
+    total = sum(numels)
+    for mb in (25, 64):
+        buckets, owner = GradBucketer.cut_buckets(numels, mb * (1 << 20) // 4, groups, total + 7)
+        # exact cover, last bucket of the buffer first, padding tail in bucket 0
+        assert buckets[0][1] == total + 7 and buckets[-1][0] == 0
+        assert all(buckets[i][0] == buckets[i + 1][1] for i in range(len(buckets) - 1))
+        mods = [sorted({groups[i] for i in range(len(names)) if owner[i] == b}) for b in range(len(buckets))]
+        assert all(not ("denoise_fn" in m and len(m) > 1) for m in mods), mods
+        assert mods[0] == ["fs", "mel_encoder"]            # 0.36 MB does not get a collective of its own
+        dn = [b for b, m in enumerate(mods) if m == ["denoise_fn"]]
+        assert dn == list(range(dn[0], len(buckets)))      # contiguous, and they end the list: front of the buffer last
+        if mb == 25:
+            assert len(dn) == 3 and len(buckets) == 5, (len(dn), len(buckets))
+            sizes = [4 * (e - s) / 2 ** 20 for s, e in buckets]
+            assert all(sz <= 2 * 25 for sz in sizes)
+    # without groups: the old behaviour (one bucket spanning both) is still what a caller without names gets
+    b_old, own_old = GradBucketer.cut_buckets(numels, 64 * (1 << 20) // 4, None, total)
+    assert len({groups[i] for i in range(len(names)) if own_old[i] == 0}) == 3

@@ -49,16 +49,16 @@ def _paired_batch(B, T, T_txt):
     return out
 
 
-def _worker(rank, world, port, backend, force, q):
+def _worker(rank, world, port, backend, force, q, model="denoiser"):
     try:
-        _worker_body(rank, world, port, backend, force, q)
+        _worker_body(rank, world, port, backend, force, q, model)
     except BaseException:
         import traceback
         q.put(dict(rank=rank, error=traceback.format_exc()))
         raise
 
 
-def _worker_body(rank, world, port, backend, force, q):
+def _worker_body(rank, world, port, backend, force, q, model="denoiser"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -78,11 +78,21 @@ def _worker_body(rank, world, port, backend, force, q):
         if not dist.is_initialized():
             dist.init_process_group(backend, rank=rank, world_size=world)
     H.hparams.clear()
-    H.hparams.update(base_hparams(timesteps=4, residual_layers=3))
     torch.manual_seed(100 + rank)  # rank-divergent initial weights ON PURPOSE
-    task = tasks.SpeechDenoiserTask(build_vocoder=False)
-    task.build_model()
-    torch.nn.init.normal_(task.model.denoise_fn.output_projection.weight, std=1.0 / 16.0)
+    if model == "campnet":  # BASELINE configs[4]: the masked-mel transformer under the same data-parallel machinery
+        import yaml
+        with open(os.path.join(ROOT, "speech-editing-toolkit_amd", "egs", "campnet.yaml")) as f:
+            H.hparams.update(yaml.safe_load(f))
+        H.hparams.update(binary_data_dir="", vocoder_ckpt="")
+        task = tasks.CampNetTask(80, 100, build_vocoder=False)
+        task.build_model()
+        late_prefix = "encoder."      # the text encoder is the LAST module backward reaches
+    else:
+        H.hparams.update(base_hparams(timesteps=4, residual_layers=3))
+        task = tasks.SpeechDenoiserTask(build_vocoder=False)
+        task.build_model()
+        torch.nn.init.normal_(task.model.denoise_fn.output_projection.weight, std=1.0 / 16.0)
+        late_prefix = "fs."           # ... the conditioner here (parameter order: denoise_fn, fs, mel_encoder)
     task.model.to(dev).eval()  # eval: no predictor dropout (its Philox counters depend on the batch layout)
     opt = FlatAdamW(task.model, lr=2e-4, clip_grad_norm=1.0, warmup_updates=8000, bucket_mb=4)
     own = float(opt.flat_p.double().sum())
@@ -108,7 +118,8 @@ def _worker_body(rank, world, port, backend, force, q):
 
     def grads_of(sample, t, eps):
         opt.zero_grad()
-        losses, _ = task.run_model(sample, infer=False, t=t.to(dev), noises=eps.to(dev).contiguous())
+        kw = dict(t=t.to(dev), noises=eps.to(dev).contiguous()) if model != "campnet" else {}
+        losses, _ = task.run_model(sample, infer=False, **kw)
         with torch.enable_grad():
             total = sum(losses.values())
         total.backward()
@@ -124,6 +135,13 @@ def _worker_body(rank, world, port, backend, force, q):
     direct_equal = bool(torch.equal(g_first, g_dist))  # autograd-accumulated vs directly written gradients: same bits
     n_direct = sum(1 for v in opt._uses.values() if v == 1)
     log = list(opt.bucketer.launch_log)
+    # bucket order follows gradient arrival: the first all-reduce is in flight before the first gradient of the module
+    # backward reaches last exists (a bucket that ends in the conditioner would leave the exchange exposed)
+    ev = list(opt.bucketer.event_log)
+    first_launch = next((i for i, e in enumerate(ev) if e[0] == "launch"), None)
+    first_late = next((i for i, e in enumerate(ev) if e[0] == "arrive" and opt.param_names[e[1]].startswith(late_prefix)), None)
+    launch_before_late = first_launch is not None and first_late is not None and first_launch < first_late
+    spans = len({opt.param_names[i].split(".", 1)[0] for i, b in enumerate(opt.bucketer.bucket_of) if b == 0})
     n_buckets = len(opt.bucketer.buckets)
     reduced = opt.bucketer.bytes_reduced
     opt.bucketer.enabled = False  # single-process reference on the concatenated batch: no collective
@@ -131,18 +149,18 @@ def _worker_body(rank, world, port, backend, force, q):
     rel = float((g_dist - g_full).abs().max() / g_full.abs().max())
     q.put(dict(rank=rank, own=own, after=float(chk), sent=sent, replicas_equal=replicas_equal, w=w, rel=rel,
                loss_local=loss_local, loss_full=loss_full, log=log, n_buckets=n_buckets, reduced=reduced, n=opt.n,
-               direct_equal=direct_equal, n_direct=n_direct,
+               direct_equal=direct_equal, n_direct=n_direct, launch_before_late=launch_before_late, bucket0_modules=spans,
                backend=dist.get_backend() if dist.is_initialized() else None))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _run(world, backend, force=False):
+def _run(world, backend, force=False, model="denoiser"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, force, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, force, q, model)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -173,6 +191,7 @@ def _check_two_ranks(res):
         assert r["rel"] < 2e-5, r["rel"]
         assert r["n_buckets"] >= 3 and sorted(b for b, _ in r["log"]) == list(range(r["n_buckets"]))
         assert sum(1 for _, why in r["log"] if why == "hook") >= 2   # launched during backward
+        assert r["launch_before_late"], "no all-reduce was in flight before backward reached its last module"
         assert r["reduced"] >= 4 * r["n"]
     assert r0["log"] == r1["log"]                          # same launch order on both ranks (no deadlock by construction)
     assert abs(0.5 * (r0["loss_local"] + r1["loss_local"]) - r0["loss_full"]) < 1e-4 * abs(r0["loss_full"])
@@ -181,6 +200,20 @@ def _check_two_ranks(res):
 def test_two_ranks_share_one_gpu_gradients_equal_concatenated_batch():
     """Runs on the 1-GPU box: both ranks on cuda:0, gloo moves the device tensors."""
     _check_two_ranks(_run(2, "gloo"))
+
+
+def test_two_ranks_share_one_gpu_campnet_gradients_equal_concatenated_batch():
+    """BASELINE configs[4] (CampNet under DDP): the same check on the masked-mel transformer -- rank-divergent weights
+    become rank 0's, the mean of the two shards' gradients equals the gradient of the concatenated batch, buckets launch
+    from the hooks in the same order on both ranks and the first one before backward reaches the text encoder."""
+    _check_two_ranks(_run(2, "gloo", model="campnet"))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL refuses two ranks on one device)")
+def test_two_ranks_rccl_campnet_gradients_equal_concatenated_batch():
+    res = _run(2, "nccl", model="campnet")
+    _check_two_ranks(res)
+    assert res[0]["backend"] == "nccl"
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL refuses two ranks on one device)")

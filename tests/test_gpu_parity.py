@@ -1095,9 +1095,10 @@ def test_full_size_properties(dev, monkeypatch):
     again = run(di, noises)
     assert torch.equal(full["mel_out"], again["mel_out"])  # deterministic
     assert torch.isfinite(full["mel_out"]).all()
-    # sharding invariance (what the multi-GPU path relies on): rank r of 2 computes rows r::2.  B=32 runs the
-    # Winograd stack kernel and a 16-utterance shard the direct one (fewer tiles than CUs), so by default the two
-    # agree to fp32 rounding; with the kernel choice pinned the shard is bit-identical.
+    # sharding invariance (what the multi-GPU path relies on): rank r of 2 computes rows r::2.  B=32 and a 16-utterance
+    # shard both run the split-operand stack kernel (64-frame tiles; tiles are cut from the batch's block list, so a tile of
+    # the full batch may straddle two utterances where the shard's does not): the two agree to fp32 rounding by default,
+    # and bit for bit with the fp32 direct kernel pinned (SET_AMD_WINO=0: per-utterance tiles).
     for r in range(2):
         sh = parallel.shard_batch(di, r, 2)
         part = run(sh, noises[:, r::2].contiguous())
@@ -1115,6 +1116,52 @@ def test_full_size_properties(dev, monkeypatch):
     oret = O.gaussian_diffusion_infer(W, steps, sub, [n[:4] for n in noises])
     assert _maxdiff(full["mel_out"][:4], oret["mel_out"]) < 1e-4
     assert torch.equal(full["pitch"][:4].cpu(), oret["pitch"])
+
+
+def test_config3_batch64_diffusion_plus_vocoder_vs_oracle(dev):
+    """BASELINE configs[3] (batched inference + HiFi-GAN vocoder at B=64, T=800) end to end at full size with explicit
+    noise (2 denoise steps: the oracle finishes two utterances in seconds): conditioner + reverse loop on the kernels a
+    64-utterance batch selects, then the V1 generator on the pasted mels exactly as `run_vocoder` batches them
+    (inference/tts/base_tts_infer.py:44-47).  First and last utterance against the oracle: integer tensors bit-exact,
+    |dmel| < 1e-4, |dwav| < 1e-4 on the oracle's own mel and 5e-4 through both stages; the batch is deterministic and an
+    utterance does not depend on the batch it rides in."""
+    from set_amd import ops
+    from set_amd.hifigan import HifiGanGenerator
+    B, T, Tt, steps = 64, 800, 100, 2
+    model, W = _build_model(dev, "spec_denoiser", 31, steps)
+    inp = Wt.synthetic_inputs(B, T, Tt, seed=6464, pad_tail=True)
+    noises = torch.stack(Wt.synthetic_noises(B, T, steps, seed=78))
+    di = {k: v.to(dev) for k, v in inp.items()}
+
+    def run(d, nz):
+        return model(d["txt_tokens"], d["time_mel_masks"], d["mel2ph"], d["spk_embed"], d["ref_mels"], d["f0"], d["uv"],
+                     infer=True, noises=nz.to(dev))
+
+    assert ops.stack_variant(B, T, 1) == 5  # the split-operand throughput kernel is what this batch runs
+    full = run(di, noises)
+    again = run(di, noises)
+    assert torch.equal(full["mel_out"], again["mel_out"]) and torch.isfinite(full["mel_out"]).all()
+    rows = [0, B - 1]
+    sub = {k: v[rows] for k, v in inp.items()}
+    oret = O.gaussian_diffusion_infer(W, steps, sub, [n[rows] for n in noises])
+    assert _maxdiff(full["mel_out"][rows], oret["mel_out"]) < 1e-4
+    for k in ("mel2ph", "pitch", "masked_dur"):
+        assert torch.equal(full[k][rows].cpu(), oret[k]), k
+    # the vocoder leg on the batch of edited mels
+    Wg = Wt.seeded_weights(Wt.load_manifest("hifigan_v1"), 23)
+    gen = HifiGanGenerator(Wt.HIFIGAN_V1)
+    gen.load_state_dict(Wg, strict=True)
+    gen.to(dev).eval()
+    mel_bct = full["mel_out"].transpose(1, 2).contiguous()
+    wav = gen(mel_bct)
+    torch.cuda.synchronize()
+    assert wav.shape == (B, 1, T * 256) and torch.isfinite(wav).all() and float(wav.abs().max()) <= 1.0
+    assert not ops.conv_x2_range_flag(reset=True)
+    ref_same_mel = O.hifigan_forward(Wg, Wt.HIFIGAN_V1, mel_bct[rows].cpu())
+    assert _maxdiff(wav[rows], ref_same_mel) < 1e-4
+    ref_chain = O.hifigan_forward(Wg, Wt.HIFIGAN_V1, oret["mel_out"].transpose(1, 2).contiguous())
+    assert _maxdiff(wav[rows], ref_chain) < 5e-4
+    assert torch.equal(gen(mel_bct[rows].contiguous()), wav[rows])
 
 
 def test_full_size_100_steps_split_operand_vs_fp32_pipe(dev, monkeypatch):

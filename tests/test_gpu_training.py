@@ -439,7 +439,8 @@ def _trainer_hparams(tmp_path, work):
                         train_set_name="test", valid_set_name="test", infer=False, test_ids=[], max_sentences=2,
                         max_tokens=1000, val_check_interval=3, max_updates=3, num_sanity_val_steps=1,
                         work_dir=str(tmp_path / work), num_ckpt_keep=2, warmup_updates=2, tb_log_interval=2,
-                        eval_max_batches=2, sil_token_ids=[1, 21, 22])  # every fixture item has a silence + a word
+                        eval_max_batches=2, sil_token_ids=[1, 21, 22],  # every fixture item has a silence + a word
+                        ds_workers=1)  # batch k + 1 is assembled on a background thread while update k runs
 
 
 def test_trainer_trains_saves_and_resumes_bit_identically(dev, tmp_path):
