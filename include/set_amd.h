@@ -143,6 +143,33 @@ int set_conv_transpose1d_x2(const float *in, const void *wp, const float *bias, 
 /* *flag = sticky "an activation left the fp16 range of the F16X2 splitting" word (synchronises); reset != 0 clears it */
 int set_conv_x2_range_flag(int32_t *flag, int32_t reset);
 
+/* One iteration of HiFi-GAN's ResBlock1 loop, fused (replaces modules/vocoder/hifigan/hifigan.py:51-58
+ *     xt = leaky_relu(x, slope); xt = c1(xt); xt = leaky_relu(xt, slope); xt = c2(xt); x = xt + x
+ * with c1 = Conv1d(C, C, K, dilation=dil, padding=dil (K-1)/2), c2 = Conv1d(C, C, K, dilation=1, padding=(K-1)/2)):
+ *     out = (c2(lrelu(c1(lrelu(x)) )) + x  [+ previous out if accumulate]) [/ out_div if != 0]
+ * accumulate / out_div carry the MRF sum and mean of hifigan.py:131-137 like SetConv1dArgs does.  Two-piece fp16 operands
+ * (SET_IMPL_F16X2 arithmetic; w1 / w2 = images of set_pack_conv_weight_x2(C, C, K)); the intermediate xt lives in LDS only
+ * (20 C T bytes of HBM traffic per pair become 8 C T).  Results are bit-identical to the two set_conv1d(F16X2) launches.
+ * x / out: [B][C][T] with unit frame stride; out must not alias x.  Shapes: see set_resblock_pair_x2_supported.
+ * An activation of magnitude >= 32768 raises the sticky flag of set_conv_x2_range_flag. */
+typedef struct SetResblockPairArgs {
+    const float *x;
+    const void *w1;
+    const float *b1;
+    const void *w2;
+    const float *b2;
+    float *out;
+    int64_t x_bs, x_cs, out_bs, out_cs;  /* batch / channel strides in elements */
+    int32_t B, C, K, dil, T;
+    int32_t accumulate;
+    float slope, out_div;
+} SetResblockPairArgs;
+int64_t set_sizeof_resblock_pair_args(void);
+/* SET_OK if the fused kernel takes the shape (16 <= C <= 256, odd 3 <= K <= 15 -- <= 5 above 128 channels --, dil (K-1) <= 128,
+ * T >= 64) */
+int set_resblock_pair_x2_supported(int32_t C, int32_t K, int32_t dil, int32_t T);
+int set_resblock_pair_x2(const SetResblockPairArgs *args, void *stream);
+
 /* packed image for SET_IMPL_MFMA2 (layout depends on Cout, K and |dil| as well as on the weights) */
 int64_t set_packed_conv_weight_v2_size(int32_t Cout, int32_t Cin, int32_t K);
 int set_pack_conv_weight_v2(const float *w, float *wp, int32_t Cout, int32_t Cin, int32_t K, int32_t dil,

@@ -17,7 +17,7 @@ INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_PKG, "libset_amd.so")
 # measurement only (tools/build_exp.sh): load an experimental build of the library instead; never built or rebuilt from here
 _LIB_OVERRIDE = os.environ.get("SET_AMD_LIB")
-SOURCES = ["conv1d.hip", "conv_x2.hip", "glue.hip", "diffnet.hip", "diffnet_x3.hip", "train.hip", "attention.hip", "bf16.hip", "diffnet_bf16.hip"]
+SOURCES = ["conv1d.hip", "conv_x2.hip", "resblock_x2.hip", "glue.hip", "diffnet.hip", "diffnet_x3.hip", "train.hip", "attention.hip", "bf16.hip", "diffnet_bf16.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
 # constants mirrored from set_amd.h
@@ -117,6 +117,16 @@ class SetDiffnetLayerBf16BwdArgs(C.Structure):
     ]
 
 
+class SetResblockPairArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("out", C.c_void_p),
+        ("x_bs", C.c_int64), ("x_cs", C.c_int64), ("out_bs", C.c_int64), ("out_cs", C.c_int64),
+        ("B", C.c_int32), ("C", C.c_int32), ("K", C.c_int32), ("dil", C.c_int32), ("T", C.c_int32),
+        ("accumulate", C.c_int32),
+        ("slope", C.c_float), ("out_div", C.c_float),
+    ]
+
+
 class SetBmmArgs(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
@@ -166,6 +176,9 @@ SIGNATURES = {
     "set_packed_conv_weight_x2_size": (C.c_int64, [_I32, _I32, _I32]),
     "set_pack_conv_weight_x2": (C.c_int, [_V, _V, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I32, _V]),
     "set_conv_x2_range_flag": (C.c_int, [C.POINTER(C.c_int32), _I32]),
+    "set_sizeof_resblock_pair_args": (_I64, []),
+    "set_resblock_pair_x2_supported": (C.c_int, [_I32, _I32, _I32, _I32]),
+    "set_resblock_pair_x2": (C.c_int, [C.POINTER(SetResblockPairArgs), _V]),
     "set_packed_conv_transpose_x2_size": (C.c_int64, [_I32, _I32, _I32, _I32]),
     "set_pack_conv_transpose_x2": (C.c_int, [_V, _V, _I32, _I32, _I32, _I32, _I32, _V]),
     "set_conv_transpose1d_x2": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _V]),
@@ -306,6 +319,7 @@ def lib():
     assert L.set_sizeof_diff_loop_args() == C.sizeof(SetDiffLoopArgs), "SetDiffLoopArgs ABI mismatch"
     assert L.set_sizeof_diffnet_stack_args() == C.sizeof(SetDiffnetStackArgs), "SetDiffnetStackArgs ABI mismatch"
     assert L.set_sizeof_bmm_args() == C.sizeof(SetBmmArgs), "SetBmmArgs ABI mismatch"
+    assert L.set_sizeof_resblock_pair_args() == C.sizeof(SetResblockPairArgs), "SetResblockPairArgs ABI mismatch"
     assert L.set_sizeof_diffnet_layer_bf16_args() == C.sizeof(SetDiffnetLayerBf16Args), "SetDiffnetLayerBf16Args ABI mismatch"
     assert L.set_sizeof_diffnet_layer_bf16_bwd_args() == C.sizeof(SetDiffnetLayerBf16BwdArgs), "SetDiffnetLayerBf16BwdArgs ABI mismatch"
     _lib = L

@@ -398,10 +398,13 @@ extern "C" int set_conv_transpose1d_x2(const float *in, const void *wp, const fl
 }
 
 /* *flag = the sticky "an activation left the fp16 range of the splitting" word (synchronises the device); reset != 0 clears it */
+int set_resblock_pair_range_flag_(int *flag, int reset);  // csrc/resblock_x2.hip (its own device word)
+
 extern "C" int set_conv_x2_range_flag(int32_t *flag, int32_t reset) {
-    int v = 0;
+    int v = 0, vp = 0;
     SET_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_x2_range_flag), sizeof(int)), "set_conv_x2_range_flag");
-    if (flag) *flag = v;
+    if (int rc = set_resblock_pair_range_flag_(&vp, reset)) return rc;
+    if (flag) *flag = v | vp;
     if (reset && v) {
         const int z = 0;
         SET_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_x2_range_flag), &z, sizeof(int)), "set_conv_x2_range_flag");

@@ -5,7 +5,9 @@
 checkpoints load with strict=True.  forward(x[B,80,T]) -> [B,1,T*prod(upsample_rates)]  (:126-142).
 
 Kernel plan: weight norm is folded on the device when the parameters change (set_weight_norm_fold);
-every Conv1d is one fused set_conv1d launch (leaky-ReLU prologue, bias + residual epilogue);
+every Conv1d is one fused set_conv1d launch (leaky-ReLU prologue, bias + residual epilogue), and each
+lrelu -> conv(k, d) -> lrelu -> conv(k, 1) -> +x iteration of a ResBlock1 with <= 128 channels is ONE launch whose
+intermediate stays in LDS (set_resblock_pair_x2);
 ConvTranspose1d runs as `stride` polyphase stride-1 convolutions writing interleaved outputs; the MRF
 sum / mean is folded into the epilogue of each ResBlock's final conv (accumulate + out_div).
 """
@@ -73,6 +75,12 @@ class ResBlock1(_ResBlockBase):
         k = self.k
         n = len(self._c1)
         for i, (c1, c2, d) in enumerate(zip(self._c1, self._c2, self.dil)):
+            if ops.resblock_pair_eligible(x.shape[1], k, d, x.shape[2]):
+                # lrelu -> conv(k, d) -> lrelu -> conv(k, 1) -> + x as ONE launch, intermediate in LDS (csrc/resblock_x2.hip);
+                # bit-identical to the two launches below on the same (split-operand) arithmetic
+                x = ops.resblock_pair(x, c1.conv_weight(), c1.mod.bias.data, c2.conv_weight(), c2.mod.bias.data, d,
+                                      slope=LRELU_SLOPE, **(last if i == n - 1 else {}))
+                continue
             t = ops.conv1d(x, c1.conv_weight(), c1.mod.bias.data, dil=d, pad=_padding(k, d), pro="lrelu",
                            pro_param=LRELU_SLOPE)
             x = ops.conv1d(t, c2.conv_weight(), c2.mod.bias.data, dil=1, pad=_padding(k, 1), pro="lrelu",

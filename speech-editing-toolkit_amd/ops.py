@@ -291,6 +291,35 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
     return out
 
 
+def resblock_pair_eligible(C, K, dil, T):
+    """Shapes the fused ResBlock-pair kernel takes while the split-operand scope is on (csrc/resblock_x2.hip)."""
+    return bool(_AUTO_SPLIT[0]) and _DEFAULT_IMPL == "auto" and os.environ.get("SET_AMD_RESBLOCK_FUSED", "1") != "0" and \
+        _lib.lib().set_resblock_pair_x2_supported(int(C), int(K), int(dil), int(T)) == 0
+
+
+def resblock_pair(x, w1, b1, w2, b2, dil, *, slope=0.1, out=None, accumulate=False, out_div=0.0):
+    """out = c2(lrelu(c1(lrelu(x)))) + x (+ out, / out_div): one iteration of HiFi-GAN's ResBlock1 loop (hifigan.py:51-58)
+    as ONE launch on the two-piece fp16 operands; the intermediate never leaves LDS.  Bit-identical to the two conv1d
+    launches with impl='f16x2'.  w1 / w2: ConvWeight [C, C, K]."""
+    _f(x, "x")
+    assert isinstance(w1, ConvWeight) and isinstance(w2, ConvWeight)
+    B, Cc, T = x.shape
+    assert (w1.Cout, w1.Cin, w2.Cout, w2.Cin) == (Cc, Cc, Cc, Cc) and w1.K == w2.K
+    if out is None:
+        out = torch.empty_like(x)
+    _fv(out, "out")
+    assert out.data_ptr() != x.data_ptr() and not (out_div and not accumulate)
+    a = _lib.SetResblockPairArgs()
+    a.x, a.out = x.data_ptr(), out.data_ptr()
+    a.w1, a.w2 = w1.packed_x2().data_ptr(), w2.packed_x2().data_ptr()
+    a.b1, a.b2 = _f(b1, "b1").data_ptr(), _f(b2, "b2").data_ptr()
+    a.x_bs, a.x_cs, a.out_bs, a.out_cs = Cc * T, T, out.stride(0), out.stride(1)
+    a.B, a.C, a.K, a.dil, a.T = B, Cc, w1.K, int(dil), T
+    a.accumulate, a.slope, a.out_div = int(bool(accumulate)), float(slope), float(out_div)
+    check(_lib.lib().set_resblock_pair_x2(C.byref(a), _stream()), "set_resblock_pair_x2")
+    return out
+
+
 def conv_transpose1d(x, w_getter, bias, Cin, Cout, k, stride, padding, *, pro="none", pro_param=0.0, impl=None,
                      cache=None):
     """nn.ConvTranspose1d as `stride` polyphase stride-1 convolutions (hifigan.py:114-115).

@@ -1015,13 +1015,18 @@ def test_hifigan_matches_reference(dev, name, h, impl, monkeypatch):
     if impl == "auto":
         # the shipped forward with the kernel picks recorded: the split-operand kernels must actually have run
         picks = []
-        real_pick = ops._pick_impl
+        real_pick, real_pair = ops._pick_impl, ops.resblock_pair
 
         def spy(*a, **k):
             r = real_pick(*a, **k)
             picks.append(r)
             return r
+
+        def spy_pair(*a, **k):
+            picks.append("f16x2")  # the fused ResBlock pair: the same arithmetic, one launch (csrc/resblock_x2.hip)
+            return real_pair(*a, **k)
         monkeypatch.setattr(ops, "_pick_impl", spy)
+        monkeypatch.setattr(ops, "resblock_pair", spy_pair)
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("error")  # the range fallback warns: it must not happen

@@ -125,3 +125,75 @@ def test_all_phase_transposed_conv_matches_polyphase_fp32_and_fp64(dev, Cin, Cou
     print("convT %d->%d k%d s%d: max err vs fp64: fp32 polyphase %.3e, all-phase f16x2 %.3e" % (Cin, Cout, k, u, e32, e2))
     assert float((y2 - y32).abs().max()) < 2e-5 * max(1.0, float(y32.abs().max()))
     assert e2 < 1.5 * e32 + 1e-7
+
+
+PAIR_CASES = [  # B, C, K, dil, T, accumulate, out_div
+    (2, 32, 3, 1, 700, False, 0.0),
+    (2, 32, 11, 5, 1000, True, 3.0),      # widest receptive field of the 32-channel stage, MRF mean in the epilogue
+    (1, 64, 7, 3, 515, True, 0.0),        # ragged T: last block partly out of range
+    (3, 64, 3, 5, 256, False, 0.0),
+    (1, 128, 3, 3, 300, True, 3.0),       # 128-row x 128-frame tiles
+    (2, 128, 11, 1, 131, False, 0.0),
+    (1, 48, 5, 2, 200, False, 0.0),       # channel count that is not a multiple of 32 (padded rows / channels)
+    (1, 100, 7, 1, 64, True, 2.0),
+    (2, 256, 3, 5, 200, True, 3.0),       # 256 rows x 64-frame tiles (3-tap pairs of the widest stage)
+    (1, 160, 5, 1, 97, False, 0.0),
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_fused_resblock_pair_equals_two_convs(dev, case):
+    """set_resblock_pair_x2 (lrelu -> conv(k, d) -> lrelu -> conv(k, 1) -> + x, intermediate in LDS, MRF accumulate /
+    divide in the epilogue; hifigan.py:51-58,131-137) against the two set_conv1d(F16X2) launches it replaces -- the same
+    products in the same order, the same fp32 intermediate before it is split: BIT-identical -- and against torch in
+    fp64 (1e-5 of the output's size, the bar of the split-operand conv tests)."""
+    from set_amd import ops
+    import torch.nn.functional as F
+    B, C, K, dil, T, accumulate, out_div = case
+    g = torch.Generator().manual_seed(C * 13 + K * 5 + dil)
+    x = torch.randn(B, C, T, generator=g).to(dev)
+    w1, cw1 = _w(dev, C, C, K, 7)
+    w2, cw2 = _w(dev, C, C, K, 8)
+    b1 = (torch.randn(C, generator=g) * 0.1).to(dev)
+    b2 = (torch.randn(C, generator=g) * 0.1).to(dev)
+    prev = torch.randn(B, C, T, generator=g).to(dev)
+    p1, p2 = dil * (K - 1) // 2, (K - 1) // 2
+    t = ops.conv1d(x, cw1, b1, dil=dil, pad=p1, pro="lrelu", pro_param=0.1, impl="f16x2")
+    want = prev.clone()
+    ops.conv1d(t, cw2, b2, dil=1, pad=p2, pro="lrelu", pro_param=0.1, res=x, out=want, accumulate=accumulate,
+               out_div=out_div, impl="f16x2")
+    got = prev.clone()
+    ops.resblock_pair(x, cw1, b1, cw2, b2, dil, slope=0.1, out=got, accumulate=accumulate, out_div=out_div)
+    torch.cuda.synchronize()
+    assert not ops.conv_x2_range_flag(reset=True)
+    assert torch.equal(got, want), float((got - want).abs().max())
+    xd = x.double().cpu()
+    td = F.conv1d(F.leaky_relu(xd, 0.1), w1.double().cpu(), b1.double().cpu(), dilation=dil, padding=p1)
+    yd = F.conv1d(F.leaky_relu(td, 0.1), w2.double().cpu(), b2.double().cpu(), padding=p2) + xd
+    if accumulate:
+        yd = yd + prev.double().cpu()
+    if out_div:
+        yd = yd / out_div
+    err = float((got.double().cpu() - yd).abs().max())
+    assert err < 1e-5 * max(1.0, float(yd.abs().max())), err
+
+
+def test_fused_resblock_pair_raises_the_range_flag(dev):
+    """An activation outside the fp16 range of the splitting -- in x or in the intermediate -- sets the sticky flag that
+    HifiGanGenerator.forward checks (it then repeats on the fp32 kernels)."""
+    from set_amd import ops
+    C, K, T = 32, 3, 128
+    w1, cw1 = _w(dev, C, C, K, 7)
+    w2, cw2 = _w(dev, C, C, K, 8)
+    b = torch.zeros(C, device=dev)
+    ops.conv_x2_range_flag(reset=True)
+    x = torch.randn(1, C, T, device=dev)
+    ops.resblock_pair(x, cw1, b, cw2, b, 1)
+    assert not ops.conv_x2_range_flag(reset=True)
+    x[0, 3, 50] = 4.0e4
+    ops.resblock_pair(x, cw1, b, cw2, b, 1)
+    assert ops.conv_x2_range_flag(reset=True)
+    big = torch.full((C,), 5.0e4, device=dev)  # the intermediate: conv 1's bias alone leaves the range
+    ops.resblock_pair(torch.randn(1, C, T, device=dev), cw1, big, cw2, b, 1)
+    assert ops.conv_x2_range_flag(reset=True)
+    assert not ops.conv_x2_range_flag(reset=True)
