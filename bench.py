@@ -322,13 +322,25 @@ def run_infer(args, rank, world, dev):
     ach_tflops = groups * flop_per_launch / (launch_ms * 1e-3) / 1e12
     ach_wall = FLOP_PER_FRAME_LAYER * B_PER_GPU * T * L * DIFF_STEPS * len(loop_ms) / (sum(loop_ms) * 1e-3) / 1e12
     ach_gbs = groups * bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic_bytes_per_launch.json")
-    if os.path.exists(tfile):  # HBM bytes per launch from the PMC passes (tools/pmc_traffic.py), same kernel + shape
+    # HBM bytes per launch of the dominant kernel from the PMC passes (tools/gpu_pmc_r03.sh: separate --pmc runs, 2 x FETCH_SIZE +
+    # WRITE_SIZE per MI355X_MICROARCH.md).  Counters cannot be collected inside this process, so the figure is the one measured
+    # on the SAME kernel sources: the file carries their sha256 and the figure is withheld (null) when the sources changed since.
+    traffic, traffic_note, pmc = None, None, None
+    tfile = os.path.join(ROOT, "profiles", "r03_pmc_x3.json")
+    if os.path.exists(tfile) and persistent and variant in (4, 5):
+        import hashlib
         with open(tfile) as f:
             tj = json.load(f)
-        key = stack_kernel if persistent else "diffnet_layer_kernel"
-        traffic = tj.get(key, tj.get(key.split("<")[0]))
+        h = hashlib.sha256()
+        for src in tj.get("kernel_sources", []):
+            with open(os.path.join(ROOT, src), "rb") as f:
+                h.update(f.read())
+        ent = tj.get("diffnet_stack_x3_kernel<%s>" % ("SplitF16x2" if variant == 5 else "SplitBf16x3"))
+        if ent is not None and h.hexdigest() == tj.get("kernel_source_sha256"):
+            traffic, pmc = ent["traffic_bytes"], ent
+            traffic_note = "PMC passes of this kernel build (profiles/r03_pmc_x3.json, source sha256 matches)"
+        else:
+            traffic_note = "withheld: the kernel sources changed since the PMC passes in profiles/r03_pmc_x3.json"
     out = {
         "metric": "diffusion mel-frames/s (100-step p_sample, B=32/GPU, T=800)",
         "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -358,15 +370,30 @@ def run_infer(args, rank, world, dev):
                      "achieved_wall_lower_bound": executed_ratio * ach_wall,
                      "frac_wall_lower_bound": executed_ratio * ach_wall / pipe_peak,
                      "hbm_algorithmic_GBps": ach_gbs, "hbm_frac": ach_gbs / PEAK_HBM_GBS,
-                     "note": ("fp32 results from 16-bit MFMAs: each fp32 operand is the exact sum of its 16-bit pieces, every "
-                              "cross product that matters at fp32 precision is issued (fp32 accumulate); error against fp64 "
-                              "<= the fp32 MFMA kernel's and the same |dmel| < 1e-4 parity tests run on this kernel "
-                              "(tests/test_gpu_parity.py::test_x3_*, ::test_full_inference_*split_operand*). "
-                              "native_fp32_loop below = the same loop on the fp32 MFMA pipe (SET_AMD_X3=0)")
+                     "traffic_note": traffic_note,
+                     "traffic_over_algorithmic_bytes": traffic / bytes_per_launch if traffic else None,
+                     "pmc_mfma_busy_frac_of_simd_cycles": pmc["mfma_busy_frac_of_simd_cycles"] if pmc else None,
+                     "pmc_sclk_GHz": pmc["cycles_per_launch"] / (launch_ms * 1e6) if pmc and pmc.get("cycles_per_launch") else None,
+                     "limit": "power: with twice the tasks in flight per CU the clock falls from 1.88 to 1.63 GHz at equal "
+                              "throughput, and without any operand traffic the kernel is 6.7 % faster "
+                              "(profiles/r03_x3_pair_probe.log, DESIGN.md 3.1f)",
+                     "note": (("fp32-equivalent results from 16-bit MFMAs.  f16x2: every fp32 operand is carried as TWO fp16 pieces "
+                               "(11 + 11 = 22 significand bits, 2 fewer than fp32's 24) and a product is a0 b0 + a0 b1 + a1 b0 -- "
+                               "the a1 b1 term (~2^-22 |ab|) is dropped; fp32 accumulation.  " if variant == 5 else
+                               "fp32-equivalent results from 16-bit MFMAs.  bf16x3: every fp32 operand is the sum of THREE bf16 "
+                               "pieces (8 + 8 + 8 = 24 significand bits) and a product is the six cross terms down to 2^-16; fp32 "
+                               "accumulation.  ") +
+                              "Asserted: error of a layer stack against fp64 <= 1.5 x the native fp32-MFMA chain's "
+                              "(tests/test_gpu_parity.py::test_x3_stack_matches_fp32_stack_and_fp64), the reference goldens incl. "
+                              "the 100-step drift case at |dmel| ~1.2e-6 through this kernel (::test_full_inference_*split_operand*). "
+                              "native_fp32_loop = the same loop on the fp32 MFMA pipe (SET_AMD_X3=0); bf16x3_operand_loop = the same "
+                              "loop on the exact 24-bit splitting")
                      if split_operands else None},
     }
     if rank == 0 and world == 1 and split_operands and not args.no_native_fp32:
         out["native_fp32_loop"] = native_fp32_line(model, inp, args, step(0)["mel_out"])
+    if rank == 0 and world == 1 and split_operands and variant == 5 and not args.no_bf16x3_loop:
+        out["bf16x3_operand_loop"] = bf16x3_line(model, inp, args, step(0)["mel_out"])
     if rank == 0 and world == 1 and not args.no_bf16_loop:
         out["bf16_operand_loop"] = bf16_loop_line(model, inp, args, ret_f32_seed0=step(0)["mel_out"])
     if rank == 0 and world == 1 and args.cpu_baseline != "off":
@@ -400,6 +427,35 @@ def native_fp32_line(model, inp, args, mel_split):
             "kernel": "diffnet_stack_wino_kernel", "launch_ms": launch_ms, "algorithmic_fp32_TFLOPs": tfl,
             "frac_of_fp32_mfma_peak": tfl / PEAK_F32_MFMA_TFLOPS,
             "max_abs_dmel_split_vs_native": float((mel_split.float() - mel32.float()).abs().max())}
+
+
+def bf16x3_line(model, inp, args, mel_f16x2):
+    """The same 100-step loop with every fp32 operand carried as THREE bf16 pieces (8 + 8 + 8 = all 24 significand bits, six
+    MFMA products per term, fp32 range; SET_AMD_SPLIT_OPERAND=bf16x3) -- the exact splitting, twice the matrix-pipe work of
+    the headline's two-piece fp16 one -- and the difference between the two outputs on the same inputs and Philox noise."""
+    os.environ["SET_AMD_SPLIT_OPERAND"] = "bf16x3"
+    try:
+        def step(seed, spans=False):
+            return model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"],
+                         inp["f0"], inp["uv"], infer=True, seed=seed, want_layer_spans=spans)
+        step(1000)
+        torch.cuda.synchronize()
+        spans = []
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            spans.extend(step(k, spans=True)["layer_span_ms"])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        mel3 = step(0)["mel_out"]
+    finally:
+        del os.environ["SET_AMD_SPLIT_OPERAND"]
+    launch_ms = sum(spans) / len(spans)
+    tfl = FLOP_PER_FRAME_LAYER * B_PER_GPU * T * L / (launch_ms * 1e-3) / 1e12
+    return {"value": B_PER_GPU * T / dt, "unit": "mel-frames/s", "ms_per_step": 1e3 * dt,
+            "dtype": "f32 (operands carried as 3 bf16 pieces, 6 MFMA products per term, fp32 accumulate)",
+            "kernel": "diffnet_stack_x3_kernel<SplitBf16x3>", "launch_ms": launch_ms, "algorithmic_fp32_TFLOPs": tfl,
+            "executed_bf16_mfma_TFLOPs": 6.0 * tfl, "frac_of_bf16_mfma_peak": 6.0 * tfl / PEAK_BF16_MFMA_TFLOPS,
+            "max_abs_dmel_bf16x3_vs_f16x2": float((mel3.float() - mel_f16x2.float()).abs().max())}
 
 
 def bf16_loop_line(model, inp, args, ret_f32_seed0):
@@ -443,20 +499,42 @@ def bf16_loop_line(model, inp, args, ret_f32_seed0):
                          "mfma_TFLOPs": tfl, "mfma_frac_of_bf16_peak": tfl / PEAK_BF16_MFMA_TFLOPS}}
 
 
+# CampNet (BASELINE configs[4]), algorithmic FLOPs of one training step per mel frame at T = 800, T_txt = 100: forward MACs =
+# mel-side weights (decoder_coarse 10.63 M + decoder_fine 4.54 M + mel encoder / output layers 0.13 M: every weight once per
+# frame) + text encoder 5.89 M per TOKEN (x 100 / 800) + attention (6 x (2 T + 2 T_txt) x 192 per frame); x 2 FLOP x 3 (fwd + bwd)
+CAMPNET_B_PER_GPU = 16
+CAMPNET_TRAIN_FLOP_PER_FRAME = 3 * 2 * (15.30e6 + 5.89e6 * T_TXT / T + 6 * (2 * T + 2 * T_TXT) * 192)
+
+
 def run_train(args, rank, world, dev):
-    """BASELINE configs[1] (1 GPU) / configs[2] (8 GPUs, B=256 global): one optimisation step of the spec_denoiser task."""
+    """--model spec_denoiser: BASELINE configs[1] (1 GPU) / configs[2] (8 GPUs, B=256 global); --model campnet: configs[4]
+    (CampNet masked-mel transformer, B=16 per GPU = egs/campnet.yaml max_sentences).  One optimisation step of the task
+    under the reference's DDP set-up (barrier, rank-0 broadcast, barrier; bucketed gradient all-reduce from autograd hooks)."""
     from set_amd import hparams as HP, ops, parallel, tasks
     from set_amd.synthetic import synthetic_inputs
     from set_amd.training import FlatAdamW
+    campnet = args.model == "campnet"
+    bpg = CAMPNET_B_PER_GPU if campnet else B_PER_GPU
     HP.hparams.clear()
-    HP.hparams.update(load_hparams())
+    if campnet:
+        with open(os.path.join(ROOT, "speech-editing-toolkit_amd", "egs", "campnet.yaml")) as f:
+            HP.hparams.update(yaml.safe_load(f))
+        HP.hparams.update(binary_data_dir="", vocoder_ckpt="")
+    else:
+        HP.hparams.update(load_hparams())
     if args.dtype == "bf16":
         ops.set_compute_dtype("bf16")
     # every rank seeds DIFFERENTLY on purpose: the replicas must agree because of the rank-0 broadcast, not by luck
     torch.manual_seed(1234 + rank)
-    task = tasks.SpeechDenoiserTask(build_vocoder=False)
-    task.build_model()
-    torch.nn.init.normal_(task.model.denoise_fn.output_projection.weight, std=1.0 / 16.0)
+    if campnet:
+        task = tasks.CampNetTask(80, 100, build_vocoder=False)
+        task.build_model()
+        with torch.no_grad():
+            task.model.mask_emb.normal_(0, 0.5)
+    else:
+        task = tasks.SpeechDenoiserTask(build_vocoder=False)
+        task.build_model()
+        torch.nn.init.normal_(task.model.denoise_fn.output_projection.weight, std=1.0 / 16.0)
     task.model.to(dev).train()
     opt = FlatAdamW(task.model, lr=HP.hparams["lr"], betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=1.0,
                     warmup_updates=8000)
@@ -467,10 +545,14 @@ def run_train(args, rank, world, dev):
         torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         assert float(lo) == float(hi), "parameter broadcast left the replicas different"
-    full = synthetic_inputs(B_PER_GPU * world, T, T_TXT, seed=1234, pad_tail=True)
+    full = synthetic_inputs(bpg * world, T, T_TXT, seed=1234, pad_tail=True)
     inp = {k: v.to(dev) for k, v in parallel.shard_batch(full, rank, world).items()}
-    sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"],
-                  time_mel_masks=inp["time_mel_masks"].squeeze(-1).contiguous(), spk_embed=inp["spk_embed"])
+    if campnet:
+        sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], spk_embed=inp["spk_embed"],
+                      time_mel_masks=inp["time_mel_masks"].squeeze(-1).contiguous())
+    else:
+        sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"],
+                      time_mel_masks=inp["time_mel_masks"].squeeze(-1).contiguous(), spk_embed=inp["spk_embed"])
     for w in range(args.warmup):
         task.training_step(sample, opt, seed=100 + w)
     torch.cuda.synchronize()
@@ -489,18 +571,26 @@ def run_train(args, rank, world, dev):
     t_max = parallel.max_over_ranks(elapsed, device=dev if world > 1 else "cpu")
     facts = dist_facts(dev, world, elapsed)
     assert torch.isfinite(total).all()
-    n_samples = B_PER_GPU * world * args.steps
-    flop = TRAIN_FLOP_PER_FRAME * B_PER_GPU * T * args.steps  # per rank
+    n_samples = bpg * world * args.steps
+    flop = (CAMPNET_TRAIN_FLOP_PER_FRAME if campnet else TRAIN_FLOP_PER_FRAME) * bpg * T * args.steps  # per rank
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
     ach = flop / t_max / 1e12
+    if campnet:
+        metric = "CampNet training samples/s (B=16/GPU, T=800)"
+        workload = ("CampNet masked-mel transformer training step (text encoder + coarse transformer decoder with self / "
+                    "encoder-decoder attention + fine conv decoder, coarse + fine l1/ssim losses, backward, gradient all-reduce, "
+                    "clip + AdamW), synthetic 80-mel T=800 batches, B=16 per GPU (BASELINE configs[4]: egs/campnet.yaml)")
+    else:
+        metric = "spec_denoiser training samples/s (B=32/GPU, T=800)"
+        workload = ("FluentSpeech spec_denoiser training step (conditioner + one DiffNet pass + l1/ssim/dur/"
+                    "pitch losses + backward + gradient all-reduce + clip + AdamW), synthetic 80-mel T=800 "
+                    "batches, B=32 per GPU (BASELINE configs[1]; configs[2] at 8 GPUs = 256 global)")
     return {
-        "metric": "spec_denoiser training samples/s (B=32/GPU, T=800)", "value": n_samples / t_max, "unit": "samples/s",
+        "metric": metric, "value": n_samples / t_max, "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_max / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "FluentSpeech spec_denoiser training step (conditioner + one DiffNet pass + l1/ssim/dur/"
-                               "pitch losses + backward + gradient all-reduce + clip + AdamW), synthetic 80-mel T=800 "
-                               "batches, B=32 per GPU (BASELINE configs[1]; configs[2] at 8 GPUs = 256 global)",
-                   "B_per_gpu": B_PER_GPU, "T": T, "T_txt": T_TXT, "sharding": "utterances r::N, gradient all-reduce (SUM, "
+        "config": {"workload": workload,
+                   "B_per_gpu": bpg, "T": T, "T_txt": T_TXT, "sharding": "utterances r::N, gradient all-reduce (SUM, "
                    "1/N folded into AdamW) in %d buckets" % max(1, len(opt.bucketer.buckets))},
         "frames_per_s": n_samples * T / t_max, "host_enqueue_ms_per_step": 1e3 * enqueue / args.steps,
         "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"],
@@ -524,6 +614,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_const", const="off", dest="cpu_baseline")
     ap.add_argument("--no-native-fp32", action="store_true", help="skip the fp32-MFMA-pipe comparison run of the same loop")
     ap.add_argument("--no-bf16-loop", action="store_true", help="skip the extra (non-headline) bf16-operand loop line")
+    ap.add_argument("--no-bf16x3-loop", action="store_true", help="skip the exact three-piece splitting of the same loop")
+    ap.add_argument("--model", choices=("spec_denoiser", "campnet"), default="spec_denoiser",
+                    help="train mode only: campnet = BASELINE configs[4] (B=16/GPU, T=800)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():

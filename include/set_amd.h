@@ -619,6 +619,40 @@ typedef struct SetBmmArgs {
 } SetBmmArgs;
 int64_t set_sizeof_bmm_args(void);
 int set_bmm(const SetBmmArgs *args, void *stream);
+/* Fused multi-head attention (replaces the bmm -> softmax -> bmm of modules/speech_editing/commons/transformer.py:361-406 and
+ * the self-attention of torch's multi_head_attention_forward that EncSALayer / DecSALayer call, :505-513,:566-575):
+ *     o[b][h] = softmax_keys(scale q[b][h] k[b][h]^T  (+ key padding -> fill)) v[b][h]
+ * on the channel-major layout: element (b, head h, channel c < head_dim, frame t) of q sits at q + b q_bs + (h head_dim + c) q_cs
+ * + t, likewise k / v (Tk frames) and o; q / k / v may be channel slices of one packed projection.  The scores never reach HBM
+ * (online softmax over 32-key tiles); lse [B][heads][2][Tq] = the softmax statistics the backward needs: row max m and sum l = sum exp(s - m)
+ * (log-sum-exp = m + log l; kept apart because log l vanishes in fp32 next to a -1e8 fill).  p (optional):
+ * the probabilities [B][heads][Tq][Tk] for callers that return them (transformer.py:396-410).  kpm (optional) [B][Tk], != 0 =
+ * padded key; fill = -inf (torch: a fully padded row is NaN) or -1e8 (transformer.py:381-386: a fully padded row is uniform).
+ * bf16 != 0: bf16 MFMA operands (fp32 scores / softmax / accumulation), else fp32 MFMA throughout.  head_dim: 32, 64 or 96. */
+typedef struct SetAttnArgs {
+    const float *q, *k, *v;
+    float *o, *lse, *p;
+    const float *kpm;
+    int64_t q_bs, k_bs, v_bs, o_bs;
+    int32_t q_cs, k_cs, v_cs, o_cs;
+    int32_t B, heads, head_dim, Tq, Tk;
+    float scale, fill;
+    int32_t bf16;
+} SetAttnArgs;
+int64_t set_sizeof_attn_args(void);
+int set_attention(const SetAttnArgs *args, void *stream);
+/* Gradients of set_attention: P is recomputed from q, k and fwd.lse (fwd.o = the forward's output, fwd.p unused).  d_o has o's
+ * layout; dq / dk / dv are addressed like q / k / v with their own strides and are overwritten; delta [B][heads][Tq] is scratch
+ * (sum_c dO O).  Two launches (per query tile: dq; per key tile: dk, dv), no atomics: bit-stable from run to run. */
+typedef struct SetAttnBwdArgs {
+    SetAttnArgs fwd;
+    const float *d_o;
+    float *delta, *dq, *dk, *dv;
+    int64_t dq_bs, dk_bs, dv_bs;
+    int32_t dq_cs, dk_cs, dv_cs;
+} SetAttnBwdArgs;
+int64_t set_sizeof_attn_bwd_args(void);
+int set_attention_bwd(const SetAttnBwdArgs *args, void *stream);
 /* y[row] = softmax_fp32(x[row]) over `cols`; logits where key_padding_mask[row / rows_per_batch][col] != 0 are
  * replaced by `fill` first (-inf: F.multi_head_attention_forward; -1e8: transformer.py:381-386).  mask may be NULL. */
 int set_softmax_rows(const float *x, const float *key_padding_mask, float *y, int64_t rows, int32_t cols,

@@ -17,7 +17,7 @@ INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_PKG, "libset_amd.so")
 # measurement only (tools/build_exp.sh): load an experimental build of the library instead; never built or rebuilt from here
 _LIB_OVERRIDE = os.environ.get("SET_AMD_LIB")
-SOURCES = ["conv1d.hip", "conv_x2.hip", "resblock_x2.hip", "glue.hip", "diffnet.hip", "diffnet_x3.hip", "train.hip", "attention.hip", "bf16.hip", "diffnet_bf16.hip"]
+SOURCES = ["conv1d.hip", "conv_x2.hip", "resblock_x2.hip", "glue.hip", "diffnet.hip", "diffnet_x3.hip", "train.hip", "attention.hip", "attention_fused.hip", "bf16.hip", "diffnet_bf16.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
 # constants mirrored from set_amd.h
@@ -138,6 +138,27 @@ class SetBmmArgs(C.Structure):
     ]
 
 
+class SetAttnArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p), ("p", C.c_void_p),
+        ("kpm", C.c_void_p),
+        ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("v_bs", C.c_int64), ("o_bs", C.c_int64),
+        ("q_cs", C.c_int32), ("k_cs", C.c_int32), ("v_cs", C.c_int32), ("o_cs", C.c_int32),
+        ("B", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32),
+        ("scale", C.c_float), ("fill", C.c_float),
+        ("bf16", C.c_int32),
+    ]
+
+
+class SetAttnBwdArgs(C.Structure):
+    _fields_ = [
+        ("fwd", SetAttnArgs),
+        ("d_o", C.c_void_p), ("delta", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
+        ("dq_bs", C.c_int64), ("dk_bs", C.c_int64), ("dv_bs", C.c_int64),
+        ("dq_cs", C.c_int32), ("dk_cs", C.c_int32), ("dv_cs", C.c_int32),
+    ]
+
+
 _V, _I32, _I64, _U64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 
 # name -> (restype, argtypes); every symbol include/set_amd.h declares
@@ -193,6 +214,10 @@ SIGNATURES = {
     "set_randn": (C.c_int, [_V, _I64, _U64, _U64, _V]),
     "set_diffusion_loop": (C.c_int, [C.POINTER(SetDiffLoopArgs), _V]),
     "set_selftest_mfma": (C.c_int, [C.POINTER(C.c_float), _V]),
+    "set_sizeof_attn_args": (_I64, []),
+    "set_sizeof_attn_bwd_args": (_I64, []),
+    "set_attention": (C.c_int, [C.POINTER(SetAttnArgs), _V]),
+    "set_attention_bwd": (C.c_int, [C.POINTER(SetAttnBwdArgs), _V]),
     "set_sizeof_bmm_args": (_I64, []),
     "set_bmm": (C.c_int, [C.POINTER(SetBmmArgs), _V]),
     "set_softmax_rows": (C.c_int, [_V, _V, _V, _I64, _I32, _I64, _F, _V]),
@@ -320,6 +345,8 @@ def lib():
     assert L.set_sizeof_diffnet_stack_args() == C.sizeof(SetDiffnetStackArgs), "SetDiffnetStackArgs ABI mismatch"
     assert L.set_sizeof_bmm_args() == C.sizeof(SetBmmArgs), "SetBmmArgs ABI mismatch"
     assert L.set_sizeof_resblock_pair_args() == C.sizeof(SetResblockPairArgs), "SetResblockPairArgs ABI mismatch"
+    assert L.set_sizeof_attn_args() == C.sizeof(SetAttnArgs), "SetAttnArgs ABI mismatch"
+    assert L.set_sizeof_attn_bwd_args() == C.sizeof(SetAttnBwdArgs), "SetAttnBwdArgs ABI mismatch"
     assert L.set_sizeof_diffnet_layer_bf16_args() == C.sizeof(SetDiffnetLayerBf16Args), "SetDiffnetLayerBf16Args ABI mismatch"
     assert L.set_sizeof_diffnet_layer_bf16_bwd_args() == C.sizeof(SetDiffnetLayerBf16BwdArgs), "SetDiffnetLayerBf16BwdArgs ABI mismatch"
     _lib = L

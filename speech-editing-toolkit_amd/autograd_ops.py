@@ -713,55 +713,94 @@ def _attn_bwd(qv, kv, vv, p, do, dqv, dkv, dvv, heads, alpha):
 
 
 class _SelfAttnFn(torch.autograd.Function):
+    """qkv [B, 3H, T] (packed in_proj output) -> o [B, H, T] (+ p when asked).  Default: the fused kernels -- the scores
+    never reach HBM and the backward recomputes P from the saved log-sum-exp (csrc/attention_fused.hip); SET_AMD_ATTN_FUSED=0:
+    bmm -> softmax -> bmm with the probabilities saved."""
+
     @staticmethod
-    def forward(ctx, qkv, heads, kpm, fill, alpha):
+    def forward(ctx, qkv, heads, kpm, fill, alpha, want_p):
         qkv = qkv.contiguous()
-        o, p = ops.self_attention(qkv, heads, kpm, fill, alpha)
-        ctx.save_for_backward(qkv, p)
-        ctx.cfg = (heads, alpha)
+        H = qkv.shape[1] // 3
+        MV = ops.MatView
+        ctx.cfg = (heads, alpha, kpm, fill)
+        if ops.attention_fused_on():
+            o, lse, p = ops.attention_fused(MV.heads(qkv, heads, 0, H), MV.heads(qkv, heads, H, H), MV.heads(qkv, heads, 2 * H, H),
+                                            heads, kpm, fill, alpha, want_p)
+            ctx.fused = True
+            ctx.save_for_backward(qkv, o, lse)
+        else:
+            o, p = ops.attention_views(MV.heads(qkv, heads, 0, H), MV.heads(qkv, heads, H, H), MV.heads(qkv, heads, 2 * H, H),
+                                       heads, kpm, fill, alpha)
+            ctx.fused = False
+            ctx.save_for_backward(qkv, p)
+        if p is None:
+            p = qkv.new_empty(0)
         ctx.mark_non_differentiable(p)
         return o, p
 
     @staticmethod
     def backward(ctx, do, _dp):
-        qkv, p = ctx.saved_tensors
-        heads, alpha = ctx.cfg
+        heads, alpha, kpm, fill = ctx.cfg
+        qkv = ctx.saved_tensors[0]
         H = qkv.shape[1] // 3
         MV = ops.MatView
         d = torch.empty_like(qkv)
-        _attn_bwd(MV.heads(qkv, heads, 0, H), MV.heads(qkv, heads, H, H), MV.heads(qkv, heads, 2 * H, H), p, do.contiguous(),
-                  MV.heads(d, heads, 0, H), MV.heads(d, heads, H, H), MV.heads(d, heads, 2 * H, H), heads, alpha)
-        return d, None, None, None, None
+        views = (MV.heads(qkv, heads, 0, H), MV.heads(qkv, heads, H, H), MV.heads(qkv, heads, 2 * H, H))
+        dviews = (MV.heads(d, heads, 0, H), MV.heads(d, heads, H, H), MV.heads(d, heads, 2 * H, H))
+        if ctx.fused:
+            _, o, lse = ctx.saved_tensors
+            ops.attention_fused_bwd(*views, o, lse, do.contiguous(), *dviews, heads, kpm, fill, alpha)
+        else:
+            _attn_bwd(*views, ctx.saved_tensors[1], do.contiguous(), *dviews, heads, alpha)
+        return d, None, None, None, None, None
 
 
 class _CrossAttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, kv, heads, kpm, fill, alpha):
+    def forward(ctx, q, kv, heads, kpm, fill, alpha, want_p):
         q, kv = q.contiguous(), kv.contiguous()
-        o, p = ops.cross_attention(q, kv, heads, kpm, fill, alpha)
-        ctx.save_for_backward(q, kv, p)
-        ctx.cfg = (heads, alpha)
+        H = q.shape[1]
+        MV = ops.MatView
+        ctx.cfg = (heads, alpha, kpm, fill)
+        if ops.attention_fused_on():
+            o, lse, p = ops.attention_fused(MV.heads(q, heads), MV.heads(kv, heads, 0, H), MV.heads(kv, heads, H, H), heads, kpm,
+                                            fill, alpha, want_p)
+            ctx.fused = True
+            ctx.save_for_backward(q, kv, o, lse)
+        else:
+            o, p = ops.attention_views(MV.heads(q, heads), MV.heads(kv, heads, 0, H), MV.heads(kv, heads, H, H), heads, kpm,
+                                       fill, alpha)
+            ctx.fused = False
+            ctx.save_for_backward(q, kv, p)
+        if p is None:
+            p = q.new_empty(0)
         ctx.mark_non_differentiable(p)
         return o, p
 
     @staticmethod
     def backward(ctx, do, _dp):
-        q, kv, p = ctx.saved_tensors
-        heads, alpha = ctx.cfg
+        heads, alpha, kpm, fill = ctx.cfg
+        q, kv = ctx.saved_tensors[:2]
         H = q.shape[1]
         MV = ops.MatView
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-        _attn_bwd(MV.heads(q, heads), MV.heads(kv, heads, 0, H), MV.heads(kv, heads, H, H), p, do.contiguous(),
-                  MV.heads(dq, heads), MV.heads(dkv, heads, 0, H), MV.heads(dkv, heads, H, H), heads, alpha)
-        return dq, dkv, None, None, None, None
+        views = (MV.heads(q, heads), MV.heads(kv, heads, 0, H), MV.heads(kv, heads, H, H))
+        dviews = (MV.heads(dq, heads), MV.heads(dkv, heads, 0, H), MV.heads(dkv, heads, H, H))
+        if ctx.fused:
+            o, lse = ctx.saved_tensors[2:]
+            ops.attention_fused_bwd(*views, o, lse, do.contiguous(), *dviews, heads, kpm, fill, alpha)
+        else:
+            _attn_bwd(*views, ctx.saved_tensors[2], do.contiguous(), *dviews, heads, alpha)
+        return dq, dkv, None, None, None, None, None
 
 
-def self_attention(qkv, heads, key_padding_mask=None, fill=float("-inf"), alpha=1.0):
-    return _SelfAttnFn.apply(qkv, heads, key_padding_mask, fill, alpha)
+def self_attention(qkv, heads, key_padding_mask=None, fill=float("-inf"), alpha=1.0, want_p=False):
+    """(o, p): p is an empty tensor unless want_p (the fused kernels do not materialise the probabilities)."""
+    return _SelfAttnFn.apply(qkv, heads, key_padding_mask, fill, alpha, want_p)
 
 
-def cross_attention(q, kv, heads, key_padding_mask=None, fill=-1e8, alpha=1.0):
-    return _CrossAttnFn.apply(q, kv, heads, key_padding_mask, fill, alpha)
+def cross_attention(q, kv, heads, key_padding_mask=None, fill=-1e8, alpha=1.0, want_p=True):
+    return _CrossAttnFn.apply(q, kv, heads, key_padding_mask, fill, alpha, want_p)
 
 
 class _PosAddFn(torch.autograd.Function):

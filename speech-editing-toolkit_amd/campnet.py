@@ -5,8 +5,8 @@ modules/speech_editing/commons/transformer.py (EncSALayer :489-528, DecSALayer :
 TransformerDecoder :750-811), so a reference checkpoint loads with strict=True -- including the members the reference
 inherits from modules/tts/fs.py FastSpeech and never runs (`mel_out`, `pitch_embed`, `pitch_predictor`,
 `encoder.pre_net`).  Everything runs on the [B][C][T] layout of the rest of the library: Linear = 1x1 conv, LayerNorm
-over channels, heads = channel slices addressed through strides (no transposes), attention = strided batched MFMA
-GEMMs + a masked row softmax.  With an autograd tape every node (forward and backward) is a kernel of libset_amd.so.
+over channels, heads = channel slices addressed through strides (no transposes), attention = one fused kernel per layer and
+direction (QK^T on MFMA -> masked fp32 online softmax in registers -> PV, scores never in HBM; csrc/attention_fused.hip).  With an autograd tape every node (forward and backward) is a kernel of libset_amd.so.
 egs/campnet.yaml sets every dropout to 0, so there is no train/eval difference in the arithmetic.
 """
 import math
@@ -73,13 +73,14 @@ class MultiheadAttention(nn.Module):
         o, _ = F.self_attention(qkv, self.num_heads, key_padding, float("-inf"), self.scaling)
         return F.conv1d(o, self._w_out, res=res, mask=mask)
 
-    def cross_attn(self, h, enc, res, enc_padding):
+    def cross_attn(self, h, enc, res, enc_padding, want_p=True):
         """encoder-decoder attention, the module's own path (static_kv=True, transformer.py:283-410): -1e8 fill.
-        Returns (res + out_proj(...), probabilities [B, heads, T, T_txt])."""
+        Returns (res + out_proj(...), probabilities [B, heads, T, T_txt] -- only when asked: the fused kernel keeps them
+        on chip and the decoder returns the first layer's alone)."""
         F = _backend()
         q = F.conv1d(h, self._w_q)
         kv = F.conv1d(enc, self._w_kv)
-        o, p = F.cross_attention(q, kv, self.num_heads, enc_padding, -1e8, self.scaling)
+        o, p = F.cross_attention(q, kv, self.num_heads, enc_padding, -1e8, self.scaling, want_p=want_p)
         return F.conv1d(o, self._w_out, res=res), p
 
 
@@ -133,7 +134,7 @@ class DecSALayer(nn.Module):
         self.layer_norm3 = nn.LayerNorm(c)
         self.ffn = TransformerFFNLayer(c, 4 * c, padding="LEFT", kernel_size=kernel_size)
 
-    def run(self, x, enc, enc_padding, keep):
+    def run(self, x, enc, enc_padding, keep, want_p=True):
         """The self-attention gets NO padding mask (the reference calls the layer without self_attn_padding_mask,
         transformer.py:803); returns (x, cross-attention probabilities)."""
         F = _backend()
@@ -142,7 +143,7 @@ class DecSALayer(nn.Module):
         x = self.self_attn.self_attn(h, x_res)
         x_ln, x_res = F.fanout(x, 2)
         h = F.layernorm_ch(x_ln, self.layer_norm2.weight, self.layer_norm2.bias)
-        x, p = self.encoder_attn.cross_attn(h, enc, x_res, enc_padding)
+        x, p = self.encoder_attn.cross_attn(h, enc, x_res, enc_padding, want_p)
         x_ln, x_res = F.fanout(x, 2)
         h = F.layernorm_ch(x_ln, self.layer_norm3.weight, self.layer_norm3.bias)
         return self.ffn.run(h, x_res, keep), p
@@ -208,7 +209,7 @@ class TransformerDecoder(nn.Module):
         encs = F.fanout(enc, len(self.layers))
         attn = None
         for layer, e in zip(self.layers, encs):
-            x, p = layer.op.run(x, e, enc_pad, keep)
+            x, p = layer.op.run(x, e, enc_pad, keep, want_p=attn is None)
             if attn is None:
                 attn = ops.head_mean(p.detach())
         return F.layernorm_ch(x, self.layer_norm.weight, self.layer_norm.bias, mask=keep), attn

@@ -942,6 +942,56 @@ def masked_channel_sum(d, m, out):
     return out
 
 
+def attention_fused_on():
+    """The fused attention kernels (csrc/attention_fused.hip) are the default; SET_AMD_ATTN_FUSED=0 runs the three-launch
+    bmm -> softmax -> bmm composition (kept as the cross-check of the tests)."""
+    return os.environ.get("SET_AMD_ATTN_FUSED", "1") != "0"
+
+
+def _attn_args(qv, kv, vv, o, lse, heads, key_padding_mask, fill, alpha, p=None):
+    d = qv.cols
+    assert qv.rs == 1 and kv.rs == 1 and vv.rs == 1 and kv.cols == d and vv.cols == d and kv.rows == vv.rows
+    assert qv.bi_s == d * qv.cs and kv.bi_s == d * kv.cs and vv.bi_s == d * vv.cs  # heads = consecutive channel slices
+    a = _lib.SetAttnArgs()
+    a.q, a.k, a.v = qv.ptr(), kv.ptr(), vv.ptr()
+    a.o, a.lse = o.data_ptr(), lse.data_ptr()
+    a.p = p.data_ptr() if p is not None else None
+    a.kpm = _f(key_padding_mask, "key_padding_mask").data_ptr() if key_padding_mask is not None else None
+    a.q_bs, a.k_bs, a.v_bs, a.o_bs = qv.bo_s, kv.bo_s, vv.bo_s, o.stride(0)
+    a.q_cs, a.k_cs, a.v_cs, a.o_cs = qv.cs, kv.cs, vv.cs, o.stride(1)
+    a.B, a.heads, a.head_dim, a.Tq, a.Tk = qv.n_outer, heads, d, qv.rows, kv.rows
+    a.scale, a.fill = float(alpha), float(fill)
+    a.bf16 = int(_COMPUTE_DTYPE == "bf16")
+    return a
+
+
+def attention_fused(qv, kv, vv, heads, key_padding_mask=None, fill=float("-inf"), alpha=1.0, want_p=False):
+    """o = softmax(alpha q k^T (+ mask)) v per head in ONE launch (scores never in HBM): returns (o [B,H,Tq], lse
+    [B,heads,2,Tq] = row max and sum of the softmax, p [B,heads,Tq,Tk] or None).  q / k / v: MatView.heads views."""
+    B, Tq, Tk, d = qv.n_outer, qv.rows, kv.rows, qv.cols
+    dev = qv.tensor.device
+    o = torch.empty(B, heads * d, Tq, dtype=torch.float32, device=dev)
+    lse = torch.empty(B, heads, 2, Tq, dtype=torch.float32, device=dev)  # row max m, sum l (log-sum-exp = m + log l)
+    p = torch.empty(B, heads, Tq, Tk, dtype=torch.float32, device=dev) if want_p else None
+    a = _attn_args(qv, kv, vv, o, lse, heads, key_padding_mask, fill, alpha, p)
+    check(_lib.lib().set_attention(C.byref(a), _stream()), "set_attention")
+    return o, lse, p
+
+
+def attention_fused_bwd(qv, kv, vv, o, lse, do, dqv, dkv, dvv, heads, key_padding_mask=None, fill=float("-inf"), alpha=1.0):
+    """Gradients of attention_fused into the views dqv / dkv / dvv (two launches, P recomputed from lse)."""
+    g = _lib.SetAttnBwdArgs()
+    g.fwd = _attn_args(qv, kv, vv, o, lse, heads, key_padding_mask, fill, alpha)
+    _f(do, "do")
+    assert do.shape == o.shape and do.stride() == o.stride()
+    delta = torch.empty(lse.shape[0], lse.shape[1], lse.shape[3], dtype=torch.float32, device=lse.device)
+    g.d_o, g.delta = do.data_ptr(), delta.data_ptr()
+    g.dq, g.dk, g.dv = dqv.ptr(), dkv.ptr(), dvv.ptr()
+    g.dq_bs, g.dk_bs, g.dv_bs = dqv.bo_s, dkv.bo_s, dvv.bo_s
+    g.dq_cs, g.dk_cs, g.dv_cs = dqv.cs, dkv.cs, dvv.cs
+    check(_lib.lib().set_attention_bwd(C.byref(g), _stream()), "set_attention_bwd")
+
+
 def attention_views(qv, kv, vv, heads, key_padding_mask=None, fill=float("-inf"), alpha=1.0):
     """o = softmax(alpha * q k^T (+mask)) v per head; q/k/v given as MatView.heads views.  Returns (o [B,H,Tq]
     contiguous, p [B,heads,Tq,Tk])."""
@@ -955,18 +1005,24 @@ def attention_views(qv, kv, vv, heads, key_padding_mask=None, fill=float("-inf")
     return o, p
 
 
-def self_attention(qkv, heads, key_padding_mask=None, fill=float("-inf"), alpha=1.0):
-    """qkv [B, 3H, T] = packed in_proj output (transformer.py:421-422) -> (o [B,H,T], p)."""
+def self_attention(qkv, heads, key_padding_mask=None, fill=float("-inf"), alpha=1.0, want_p=False):
+    """qkv [B, 3H, T] = packed in_proj output (transformer.py:421-422) -> (o [B,H,T], p or None)."""
     H = qkv.shape[1] // 3
-    return attention_views(MatView.heads(qkv, heads, 0, H), MatView.heads(qkv, heads, H, H),
-                           MatView.heads(qkv, heads, 2 * H, H), heads, key_padding_mask, fill, alpha)
+    views = (MatView.heads(qkv, heads, 0, H), MatView.heads(qkv, heads, H, H), MatView.heads(qkv, heads, 2 * H, H))
+    if attention_fused_on():
+        o, _, p = attention_fused(*views, heads, key_padding_mask, fill, alpha, want_p)
+        return o, p
+    return attention_views(*views, heads, key_padding_mask, fill, alpha)
 
 
-def cross_attention(q, kv, heads, key_padding_mask=None, fill=-1e8, alpha=1.0):
+def cross_attention(q, kv, heads, key_padding_mask=None, fill=-1e8, alpha=1.0, want_p=True):
     """q [B,H,Tq], kv [B,2H,Tk] (in_proj_k / in_proj_v of the encoder output, transformer.py:433-451)."""
     H = q.shape[1]
-    return attention_views(MatView.heads(q, heads), MatView.heads(kv, heads, 0, H), MatView.heads(kv, heads, H, H), heads,
-                           key_padding_mask, fill, alpha)
+    views = (MatView.heads(q, heads), MatView.heads(kv, heads, 0, H), MatView.heads(kv, heads, H, H))
+    if attention_fused_on():
+        o, _, p = attention_fused(*views, heads, key_padding_mask, fill, alpha, want_p)
+        return o, p
+    return attention_views(*views, heads, key_padding_mask, fill, alpha)
 
 
 def pos_add(x, alpha, pos, table):

@@ -269,3 +269,144 @@ def test_campnet_task_starts_trains_saves_and_resumes_bit_identically(dev, tmp_p
     finally:
         H.hparams.clear()
         H.hparams.update(saved)
+
+
+ATTN_CASES = [  # B, heads, d, Tq, Tk, fill, padded keys per utterance (None = no mask), self-attention?
+    (2, 2, 96, 48, 48, float("-inf"), None, True),
+    (3, 2, 96, 77, 19, -1e8, [5, 0, 19], False),     # ragged, a fully padded utterance (uniform with the -1e8 fill)
+    (2, 2, 96, 800, 800, float("-inf"), None, True),  # BASELINE configs[4] self-attention shape (25 key tiles)
+    (2, 2, 96, 800, 100, -1e8, [10, 37], False),      # ... and its encoder-decoder attention
+    (1, 4, 32, 130, 131, float("-inf"), [3], True),
+    (2, 1, 64, 33, 70, float("-inf"), [0, 69], False),
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_fused_attention_forward_and_gradients(dev, case, dtype):
+    """set_attention / set_attention_bwd (one launch forward, two backward, scores never in HBM; transformer.py:361-406)
+    against torch in fp64 on the same inputs: output, log-sum-exp, the probabilities it can emit, and dq / dk / dv.
+    fp32 operands: 2e-5 of each tensor's size; bf16 operands (fp32 softmax / accumulate): against fp64 attention of the
+    bf16-ROUNDED q, k, v (what the kernel multiplies), 2e-2 -- P and dS are rounded once more inside."""
+    from set_amd import ops
+    B, heads, d, Tq, Tk, fill, npad, self_attn = case
+    MV = ops.MatView
+    H = heads * d
+    g = torch.Generator().manual_seed(Tq * 7 + Tk)
+    if self_attn:
+        qkv = torch.randn(B, 3 * H, Tq, generator=g)
+        q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+        Tk = Tq
+    else:
+        q = torch.randn(B, H, Tq, generator=g)
+        kvt = torch.randn(B, 2 * H, Tk, generator=g)
+        k, v = kvt[:, :H], kvt[:, H:]
+    kpm = None
+    if npad is not None:
+        kpm = torch.zeros(B, Tk)
+        for b_, n in enumerate(npad):
+            if n:
+                kpm[b_, Tk - n:] = 1
+    alpha = d ** -0.5
+    do = torch.randn(B, H, Tq, generator=g)
+    rnd = (lambda t: t.bfloat16().double()) if dtype == "bf16" else (lambda t: t.double())
+    qh = rnd(q).view(B, heads, d, Tq).transpose(2, 3).requires_grad_(True)   # [B,h,Tq,d]
+    kh = rnd(k).reshape(B, heads, d, Tk).transpose(2, 3).requires_grad_(True)
+    vh = rnd(v).reshape(B, heads, d, Tk).transpose(2, 3).requires_grad_(True)
+    sc = (qh * (alpha if dtype != "bf16" else 1.0)) @ kh.transpose(2, 3)
+    if dtype == "bf16":  # the kernel rounds alpha * q
+        qs = rnd(q * alpha).view(B, heads, d, Tq).transpose(2, 3)
+        sc = qs @ kh.transpose(2, 3) + 0.0 * qh.sum()
+    if kpm is not None:
+        sc = sc.masked_fill(kpm.bool()[:, None, None, :], fill)
+    pr = torch.softmax(sc, -1)
+    o_ref = (pr @ vh).transpose(2, 3).reshape(B, H, Tq)
+    nan_rows = torch.isnan(o_ref).any(1)  # fully padded utterances with the -inf fill: NaN in torch, NaN here
+    ops.set_compute_dtype(dtype)
+    try:
+        if self_attn:
+            x = qkv.to(dev).contiguous()
+            views = (MV.heads(x, heads, 0, H), MV.heads(x, heads, H, H), MV.heads(x, heads, 2 * H, H))
+        else:
+            xq, xkv = q.contiguous().to(dev), kvt.to(dev).contiguous()
+            views = (MV.heads(xq, heads), MV.heads(xkv, heads, 0, H), MV.heads(xkv, heads, H, H))
+        kd = kpm.to(dev) if kpm is not None else None
+        o, lse, p = ops.attention_fused(*views, heads, kd, fill, alpha, want_p=True)
+        if self_attn:
+            dx = torch.full_like(x, float("nan"))
+            dviews = (MV.heads(dx, heads, 0, H), MV.heads(dx, heads, H, H), MV.heads(dx, heads, 2 * H, H))
+        else:
+            dxq, dxkv = torch.full_like(xq, float("nan")), torch.full_like(xkv, float("nan"))
+            dviews = (MV.heads(dxq, heads), MV.heads(dxkv, heads, 0, H), MV.heads(dxkv, heads, H, H))
+        ops.attention_fused_bwd(*views, o, lse, do.to(dev), *dviews, heads, kd, fill, alpha)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_compute_dtype("f32")
+    tol = 2e-5 if dtype == "f32" else 2e-2
+    ok = ~nan_rows
+    assert torch.isnan(o.cpu()[nan_rows.unsqueeze(1).expand_as(o_ref)]).all()
+
+    def close(got, want, name, t=tol):
+        got, want = got.double().cpu(), want.detach()
+        m = torch.isfinite(want)
+        err = float((got[m] - want[m]).abs().max()) if m.any() else 0.0
+        assert err < t * max(1.0, float(want[m].abs().max()) if m.any() else 1.0), (name, err)
+
+    close(o, o_ref, "o")
+    close(p, pr, "p", 1e-5 if dtype == "f32" else 2e-2)
+    close(lse[:, :, 0] + torch.log(lse[:, :, 1]), torch.logsumexp(sc, -1), "lse", 1e-5 if dtype == "f32" else 2e-2)
+    if not bool(nan_rows.any()):
+        o_ref.backward(do.double())
+        # gradients w.r.t. the ROUNDED operands are what the kernel computes in bf16 mode (dq additionally carries alpha)
+        if dtype == "bf16":
+            with torch.enable_grad():
+                qs2 = rnd(q * alpha).view(B, heads, d, Tq).transpose(2, 3).requires_grad_(True)
+                sc2 = qs2 @ kh.detach().transpose(2, 3)
+                if kpm is not None:
+                    sc2 = sc2.masked_fill(kpm.bool()[:, None, None, :], fill)
+                (torch.softmax(sc2, -1) @ vh.detach()).transpose(2, 3).reshape(B, H, Tq).backward(do.double())
+            dq_ref = qs2.grad * alpha
+        else:
+            dq_ref = qh.grad
+        back = lambda t: t.transpose(2, 3).reshape(B, H, -1)
+        if self_attn:
+            got_q, got_k, got_v = dx[:, :H], dx[:, H:2 * H], dx[:, 2 * H:]
+        else:
+            got_q, got_k, got_v = dxq, dxkv[:, :H], dxkv[:, H:]
+        gt = 5e-5 if dtype == "f32" else 3e-2
+        close(got_q, back(dq_ref), "dq", gt)
+        close(got_k, back(kh.grad), "dk", gt)
+        close(got_v, back(vh.grad), "dv", gt)
+
+
+def test_fused_attention_is_what_the_model_runs_and_matches_the_composition(dev, monkeypatch):
+    """CampNet through the fused attention (default) against the bmm -> softmax -> bmm composition (SET_AMD_ATTN_FUSED=0)
+    on the reference fixture: the same outputs and the same parameter gradients to fp32 rounding, and the fused path really
+    is the one that ran (no score tensor is allocated: set_bmm is never called)."""
+    from set_amd import ops
+    g = load_golden("campnet_tiny")
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SET_AMD_ATTN_FUSED", mode)
+        task, model, sample = _campnet(dev, g)
+        calls = []
+        real = ops.bmm
+        monkeypatch.setattr(ops, "bmm", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        for p_ in model.parameters():
+            p_.grad = None
+        losses, out = task.run_model(sample, infer=False)
+        with torch.enable_grad():
+            total = sum(losses.values())
+        total.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(ops, "bmm", real)
+        assert (len(calls) == 0) == (mode == "1"), (mode, len(calls))
+        outs[mode] = (float(total), out["mel_out_fine"].detach().clone(), out["attn"].detach().clone(),
+                      {k: p_.grad.detach().clone() for k, p_ in model.named_parameters() if p_.grad is not None})
+    monkeypatch.delenv("SET_AMD_ATTN_FUSED")
+    a, b = outs["1"], outs["0"]
+    assert abs(a[0] - b[0]) < 1e-5 * max(1.0, abs(b[0]))
+    assert _md(a[1], b[1]) < 2e-5 and _md(a[2], b[2]) < 1e-6
+    assert set(a[3]) == set(b[3])
+    for k in a[3]:
+        assert _md(a[3][k], b[3][k]) < 2e-4 * max(float(b[3][k].abs().max()), 1e-6), k

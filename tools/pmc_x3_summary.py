@@ -1,0 +1,49 @@
+"""rocprofv3 --pmc passes of the split-operand stack kernel -> one JSON: HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, the
+gfx950 half-count correction of MI355X_MICROARCH.md's HBM section), MFMA busy cycles / clock, and the sha256 of the kernel's
+sources at measurement time (bench.py refuses to quote the traffic figure for a kernel whose sources changed since).
+usage: python tools/pmc_x3_summary.py <fetch.csv> <write.csv> <util.csv> <out.json>"""
+import collections
+import csv
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ["speech-editing-toolkit_amd/csrc/diffnet_x3.hip", "speech-editing-toolkit_amd/csrc/common.h"]
+
+
+def source_sha():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()
+
+
+def collect(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        n = r["Kernel_Name"]
+        if "diffnet_stack_x3_kernel" in n and "pack_" not in n:
+            key = "diffnet_stack_x3_kernel<%s>" % ("SplitF16x2" if "SplitF16x2" in n else "SplitBf16x3")
+            acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in acc.items()}
+
+
+if __name__ == "__main__":
+    fetch, write, util = collect(sys.argv[1]), collect(sys.argv[2]), collect(sys.argv[3])
+    out = {"_note": "per launch, mean over launches; traffic_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (FETCH_SIZE / WRITE_SIZE in "
+                    "KB; gfx950 reports half of wide coalesced reads); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
+                    "GRBM_GUI_ACTIVE / 8 XCDs)",
+           "kernel_sources": KERNEL_SOURCES, "kernel_source_sha256": source_sha(), "shape": "B=32, T=800, L=20 (tools/x3_phase_probe.py)"}
+    for k in fetch:
+        f, nf = fetch[k]["FETCH_SIZE"]
+        w, nw = write.get(k, {}).get("WRITE_SIZE", (0.0, 0))
+        m = {c: v for c, (v, _) in util.get(k, {}).items()}
+        cyc = m.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        out[k] = {"traffic_bytes": 2.0 * f * 1024.0 + w * 1024.0, "fetch_KB_raw": f, "write_KB_raw": w, "launches": [nf, nw],
+                  "counters": m, "cycles_per_launch": cyc,
+                  "mfma_busy_frac_of_simd_cycles": m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc) if cyc else None,
+                  "mfma_instructions_per_launch": m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 32.0}
+    json.dump(out, open(sys.argv[4], "w"), indent=1)
+    print(json.dumps(out, indent=1))
