@@ -189,6 +189,10 @@ int set_layernorm_ch(const float *x, const float *gamma, const float *beta, cons
 /* out[b][c][t] (+)= scale * table[idx[b][t]][c]     (layers.py:45-50, conv.py:138, fs.py:138,164,188) */
 int set_embedding_bct(const int64_t *idx, const float *table, float *out, int32_t B, int32_t T, int32_t C,
                       int32_t n_rows, float scale, int32_t accumulate, void *stream);
+/* the same with the scale read from device memory (scale_dev[0]): a learnable scale -- the decoder's pos_embed_alpha,
+ * transformer.py:795-796 -- without a device-to-host read in the middle of the step */
+int set_embedding_bct_dev_scale(const int64_t *idx, const float *table, float *out, int32_t B, int32_t T, int32_t C,
+                                int32_t n_rows, const float *scale_dev, int32_t accumulate, void *stream);
 /* mask[b][t] = (sum_c |x[b][c][t]|) > 0 ? 1 : 0     (conv.py:58,108) */
 int set_abs_sum_mask(const float *x, float *mask, int32_t B, int32_t C, int32_t T, void *stream);
 /* mask[i] = idx[i] > 0 ? 1 : 0                       (fs.py:87,93 ; spec_denoiser.py:163,166) */

@@ -173,6 +173,7 @@ SIGNATURES = {
     "set_weight_norm_fold": (C.c_int, [_V, _V, _V, _I32, _I64, _V]),
     "set_layernorm_ch": (C.c_int, [_V, _V, _V, _V, _V, _I32, _I32, _I32, _F, _V]),
     "set_embedding_bct": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _I32, _F, _I32, _V]),
+    "set_embedding_bct_dev_scale": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _I32, _V, _I32, _V]),
     "set_abs_sum_mask": (C.c_int, [_V, _V, _I32, _I32, _I32, _V]),
     "set_index_mask": (C.c_int, [_V, _V, _I64, _V]),
     "set_expand_states": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _I32, _V]),

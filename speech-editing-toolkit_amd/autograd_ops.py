@@ -808,7 +808,7 @@ class _PosAddFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, alpha, pos, table):
-        out = ops.embedding_bct(pos, table, scale=float(alpha.item()), out=x.clone(), accumulate=True)
+        out = ops.embedding_bct(pos, table, scale=alpha.detach().reshape(1).contiguous(), out=x.clone(), accumulate=True)
         ctx.save_for_backward(pos, table)
         return out
 

@@ -13,7 +13,11 @@
 // Two operand types (template): fp32 (v_mfma_f32_32x32x2_f32: the parity path, exact fp32 products) and bf16
 // (v_mfma_f32_32x32x16_bf16, fp32 accumulate and softmax: the training rows' bf16 arithmetic, BASELINE configs[4]).
 // K and V tiles are staged by the whole block: K transposed to [key][d], V as [d][key]; the next tile's global loads are in
-// flight under the current tile's MFMAs.
+// flight under the current tile's MFMAs.  Every lane-dependent address part (frame, the half's channel offset) sits in the
+// VECTOR offset of the buffer instructions: a lane-varying SCALAR offset makes the compiler wrap each access in a waterfall
+// loop (one serialised round trip per distinct value) -- the first version of this file ran 3 - 6 x slower for exactly that.
+// (Measured alternative, dropped: one wave per block reading its operands straight from global memory in fragment order -- no
+// LDS, no barrier, but 3 - 5 x the vector-memory instructions and ~250 live registers: 323 vs 171 us for the T = 800 backward.)
 #include <math.h>
 
 #include "common.h"
@@ -47,9 +51,9 @@ template <int D, bool BF16> struct AfTile {
 template <int D, int NT>
 __device__ __forceinline__ void af_issue(float (&reg)[D * AF_KT / NT], rsrc_t src, int cs, int t0, int Tk, int tid) {
     const int key = tid & 31, dg = tid >> 5;
-    const unsigned vo = 4u * (unsigned)min(t0 + key, Tk - 1);
+    const unsigned vo = 4u * (unsigned)(min(t0 + key, Tk - 1) + dg * cs);
 #pragma unroll
-    for (int i = 0; i < D * AF_KT / NT; ++i) reg[i] = buf_load(src, vo, 4u * (unsigned)((dg + (NT / 32) * i) * cs));
+    for (int i = 0; i < D * AF_KT / NT; ++i) reg[i] = buf_load(src, vo, 4u * (unsigned)(((NT / 32) * i) * cs));
 }
 // transposed: LDS[key][d]
 template <int D, int NT, bool BF16>
@@ -87,13 +91,13 @@ template <int D, bool BF16> struct AfFrag {
 };
 template <int D, bool BF16>
 __device__ __forceinline__ void af_load_frag(AfFrag<D, BF16> &o, rsrc_t src, int cs, int t, int half, float mul) {
-    const unsigned vo = 4u * (unsigned)t;
+    const unsigned vo = 4u * (unsigned)(t + (BF16 ? 8 : 4) * half * cs);
     if constexpr (BF16) {
 #pragma unroll
         for (int j = 0; j < D / 16; ++j) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = buf_load(src, vo, 4u * (unsigned)((16 * j + 8 * half + e) * cs)) * mul;
+            for (int e = 0; e < 8; ++e) v[e] = buf_load(src, vo, 4u * (unsigned)((16 * j + e) * cs)) * mul;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o.b[j][e] = af_pk(v[2 * e], v[2 * e + 1]);
         }
@@ -101,27 +105,34 @@ __device__ __forceinline__ void af_load_frag(AfFrag<D, BF16> &o, rsrc_t src, int
 #pragma unroll
         for (int g = 0; g < D / 8; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o.f[4 * g + e] = buf_load(src, vo, 4u * (unsigned)((8 * g + 4 * half + e) * cs)) * mul;
+            for (int e = 0; e < 4; ++e) o.f[4 * g + e] = buf_load(src, vo, 4u * (unsigned)((8 * g + e) * cs)) * mul;
     }
 }
 
 // acc[key][col] += sum_d Ks[key][d] * frag[d][col]      (Ks = LDS tile [key][d])
 template <int D, bool BF16>
 __device__ __forceinline__ void af_gemm_kd(f32x16 &acc, const unsigned char *ks, const AfFrag<D, BF16> &fr, int l31, int half) {
+    f32x16 a1 = (f32x16){0};  // two accumulation chains: consecutive MFMAs do not wait for each other
     if constexpr (BF16) {
 #pragma unroll
         for (int j = 0; j < D / 16; ++j) {
             const af_u32x4 a = *reinterpret_cast<const af_u32x4 *>(ks + l31 * AfTile<D, true>::KROW + (16 * j + 8 * half) * 2);
-            acc = af_mma16(a, fr.b[j], acc);
+            if (j & 1) a1 = af_mma16(a, fr.b[j], a1);
+            else acc = af_mma16(a, fr.b[j], acc);
         }
     } else {
 #pragma unroll
         for (int g = 0; g < D / 8; ++g) {
             const f32x4 a = *reinterpret_cast<const f32x4 *>(ks + l31 * AfTile<D, false>::KROW + (8 * g + 4 * half) * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma32(a[e], fr.f[4 * g + e], acc);
+            for (int e = 0; e < 4; ++e) {
+                if (e & 1) a1 = mfma32(a[e], fr.f[4 * g + e], a1);
+                else acc = mfma32(a[e], fr.f[4 * g + e], acc);
+            }
         }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += a1[r];
 }
 // acc[rb][d][col] += sum_key Vs[d][key] * p[key][col], p = an accumulator-layout register file (its key order)
 template <int D, bool BF16>
@@ -216,11 +227,11 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(SetAttnArgs a) {
         mt = fmaxf(mt, af_xor32(mt));
         const float mn = fmaxf(m, mt);
         const bool dead = mn == -INFINITY;  // nothing but -inf so far: keep the state neutral (exp(-inf + inf) would poison it)
-        const float corr = dead ? 1.0f : expf(m - mn);
+        const float corr = dead ? 1.0f : __expf(m - mn);
         float ps = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = dead ? 0.0f : expf(s[r] - mn);
+            s[r] = dead ? 0.0f : __expf(s[r] - mn);
             ps += s[r];
         }
         l = l * corr + ps;
@@ -239,7 +250,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(SetAttnArgs a) {
         for (int rb = 0; rb < D / 32; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                buf_store(oacc[rb][r] * inv, ro, 4u * (unsigned)qi, 4u * (unsigned)((32 * rb + af_row(r, half)) * a.o_cs));
+                buf_store(oacc[rb][r] * inv, ro, 4u * (unsigned)(qi + 4 * half * a.o_cs), 4u * (unsigned)((32 * rb + af_row(r, 0)) * a.o_cs));
         if (half == 0) {  // the softmax statistics, kept apart: m + log(l) would round log(l) away next to a -1e8 fill
             float *st = a.lse + ((int64_t)b * a.heads + h) * 2 * a.Tq;
             st[qi] = m;
@@ -269,7 +280,7 @@ __global__ void __launch_bounds__(256) attn_probs_kernel(SetAttnArgs a) {
 #pragma unroll
         for (int d = 0; d < D; ++d) s += qv[d] * k[(int64_t)d * a.k_cs + key];  // k: the same address in every lane (broadcast)
         if (kpm && kpm[key] != 0.0f) s = a.fill;
-        p[key] = expf(s - mx) * linv;
+        p[key] = __expf(s - mx) * linv;
     }
 }
 
@@ -305,10 +316,11 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(SetAttnBwdArgs g) {
     float delta = 0.0f;
     {
         const unsigned vo = 4u * (unsigned)qc;
+        const unsigned voh = vo + 4u * (unsigned)(half * a.o_cs);
 #pragma unroll
         for (int i = 0; i < D / 2; ++i) {
-            const unsigned so = 4u * (unsigned)((2 * i + half) * a.o_cs);
-            delta += buf_load(rdo, vo, so) * buf_load(ro, vo, so);
+            const unsigned so = 4u * (unsigned)((2 * i) * a.o_cs);
+            delta += buf_load(rdo, voh, so) * buf_load(ro, voh, so);
         }
         delta += af_xor32(delta);
         if (qi < a.Tq && half == 0) g.delta[row] = delta;
@@ -323,23 +335,27 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(SetAttnBwdArgs g) {
     constexpr int NR = D * AF_KT / 256;
     float kreg[NR], vreg[NR];
     const int ntiles = (a.Tk + AF_KT - 1) / AF_KT;
+    af_issue<D, 256>(kreg, rk, a.k_cs, 0, a.Tk, tid);
+    af_issue<D, 256>(vreg, rv, a.v_cs, 0, a.Tk, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int t0 = kt * AF_KT;
-        af_issue<D, 256>(kreg, rk, a.k_cs, t0, a.Tk, tid);
-        af_issue<D, 256>(vreg, rv, a.v_cs, t0, a.Tk, tid);
         __syncthreads();
         af_commit_kd<D, 256, BF16>(kreg, Ks, t0, a.Tk, tid);
         af_commit_dk<D, 256, BF16>(kreg, Kt, t0, a.Tk, tid);
         af_commit_kd<D, 256, BF16>(vreg, Vk, t0, a.Tk, tid);
         if (tid < AF_KT) codes[tid] = t0 + tid >= a.Tk ? 2.0f : ((kpm && kpm[t0 + tid] != 0.0f) ? 1.0f : 0.0f);
         __syncthreads();
+        if (kt + 1 < ntiles) {  // next tile's loads fly under this tile's math
+            af_issue<D, 256>(kreg, rk, a.k_cs, t0 + AF_KT, a.Tk, tid);
+            af_issue<D, 256>(vreg, rv, a.v_cs, t0 + AF_KT, a.Tk, tid);
+        }
         f32x16 s = (f32x16){0}, dp = (f32x16){0};
         af_gemm_kd<D, BF16>(s, Ks, qf, l31, half);
         af_gemm_kd<D, BF16>(dp, Vk, dof, l31, half);
         af_mask(s, codes, half, a.fill);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = expf(s[r] - mx) * linv;
+            const float p = __expf(s[r] - mx) * linv;
             // masked keys: the score is the constant `fill`, its derivative with respect to q and k is zero
             const float c = codes[af_row(r, half)];
             s[r] = c != 0.0f ? 0.0f : p * (dp[r] - delta);
@@ -352,7 +368,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(SetAttnBwdArgs g) {
         for (int rb = 0; rb < D / 32; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                buf_store(dq[rb][r] * a.scale, rdq, 4u * (unsigned)qi, 4u * (unsigned)((32 * rb + af_row(r, half)) * g.dq_cs));
+                buf_store(dq[rb][r] * a.scale, rdq, 4u * (unsigned)(qi + 4 * half * g.dq_cs), 4u * (unsigned)((32 * rb + af_row(r, 0)) * g.dq_cs));
     }
 }
 
@@ -395,10 +411,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(SetAttnBwdArgs g) {
     constexpr int NR = D * AF_KT / 256;
     float qreg[NR], oreg[NR];
     const int ntiles = (a.Tq + AF_KT - 1) / AF_KT;
+    af_issue<D, 256>(qreg, rq, a.q_cs, 0, a.Tq, tid);
+    af_issue<D, 256>(oreg, rdo, a.o_cs, 0, a.Tq, tid);
     for (int qt = 0; qt < ntiles; ++qt) {
         const int t0 = qt * AF_KT;
-        af_issue<D, 256>(qreg, rq, a.q_cs, t0, a.Tq, tid);
-        af_issue<D, 256>(oreg, rdo, a.o_cs, t0, a.Tq, tid);
 #pragma unroll
         for (int i = 0; i < NR; ++i) qreg[i] *= a.scale;
         __syncthreads();
@@ -413,6 +429,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(SetAttnBwdArgs g) {
             delta_s[tid] = ok ? g.delta[row0 + t0 + tid] : 0.0f;
         }
         __syncthreads();
+        if (qt + 1 < ntiles) {  // next tile's loads fly under this tile's math
+            af_issue<D, 256>(qreg, rq, a.q_cs, t0 + AF_KT, a.Tq, tid);
+            af_issue<D, 256>(oreg, rdo, a.o_cs, t0 + AF_KT, a.Tq, tid);
+        }
         f32x16 s = (f32x16){0}, dp = (f32x16){0};
         af_gemm_kd<D, BF16>(s, Qs, kf, l31, half);    // S [query][key]
         af_gemm_kd<D, BF16>(dp, Os, vf, l31, half);   // dP [query][key] = dO V^T
@@ -420,7 +440,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(SetAttnBwdArgs g) {
         for (int r = 0; r < 16; ++r) {
             const int qr = af_row(r, half);
             const float sc = !kvalid ? -INFINITY : (kmasked ? a.fill : s[r]);
-            const float p = expf(sc - m_s[qr]) * linv_s[qr];
+            const float p = __expf(sc - m_s[qr]) * linv_s[qr];
             s[r] = p;
             dp[r] = kmasked ? 0.0f : p * (dp[r] - delta_s[qr]);  // dS (a padded key's score is the constant `fill`)
         }
@@ -434,10 +454,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(SetAttnBwdArgs g) {
         for (int rb = 0; rb < D / 32; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const unsigned so_k = 4u * (unsigned)((32 * rb + af_row(r, half)) * g.dk_cs);
-                const unsigned so_v = 4u * (unsigned)((32 * rb + af_row(r, half)) * g.dv_cs);
-                buf_store(dk[rb][r], rdk, 4u * (unsigned)ki, so_k);
-                buf_store(dv[rb][r], rdv, 4u * (unsigned)ki, so_v);
+                const unsigned so_k = 4u * (unsigned)((32 * rb + af_row(r, 0)) * g.dk_cs);
+                const unsigned so_v = 4u * (unsigned)((32 * rb + af_row(r, 0)) * g.dv_cs);
+                buf_store(dk[rb][r], rdk, 4u * (unsigned)(ki + 4 * half * g.dk_cs), so_k);
+                buf_store(dv[rb][r], rdv, 4u * (unsigned)(ki + 4 * half * g.dv_cs), so_v);
             }
     }
 }

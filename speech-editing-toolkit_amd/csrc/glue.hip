@@ -86,7 +86,8 @@ extern "C" int set_layernorm_ch(const float *x, const float *gamma, const float 
 
 // ---- embedding lookup written channel-major --------------------------------------------------
 __global__ void __launch_bounds__(256) embedding_bct_kernel(const int64_t *idx, const float *table, float *out, int B,
-                                                            int T, int C, int n_rows, float scale, int accumulate) {
+                                                            int T, int C, int n_rows, float scale, const float *scale_dev,
+                                                            int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)B * C * T) return;
     const int t = (int)(i % T);
@@ -94,15 +95,23 @@ __global__ void __launch_bounds__(256) embedding_bct_kernel(const int64_t *idx, 
     const int b = (int)(i / ((int64_t)T * C));
     int64_t row = idx[(int64_t)b * T + t];
     row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
-    const float v = scale * table[row * C + c];
+    const float sc = scale_dev ? scale_dev[0] : scale;
+    const float v = sc * table[row * C + c];
     out[i] = accumulate ? out[i] + v : v;
 }
 extern "C" int set_embedding_bct(const int64_t *idx, const float *table, float *out, int32_t B, int32_t T, int32_t C,
                                  int32_t n_rows, float scale, int32_t accumulate, void *stream) {
     SET_REQUIRE(idx && table && out && B > 0 && T > 0 && C > 0 && n_rows > 0, "set_embedding_bct");
     hipLaunchKernelGGL(embedding_bct_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0,
-                       (hipStream_t)stream, idx, table, out, B, T, C, n_rows, scale, accumulate);
+                       (hipStream_t)stream, idx, table, out, B, T, C, n_rows, scale, (const float *)nullptr, accumulate);
     return set_check_launch("set_embedding_bct");
+}
+extern "C" int set_embedding_bct_dev_scale(const int64_t *idx, const float *table, float *out, int32_t B, int32_t T, int32_t C,
+                                           int32_t n_rows, const float *scale_dev, int32_t accumulate, void *stream) {
+    SET_REQUIRE(idx && table && out && scale_dev && B > 0 && T > 0 && C > 0 && n_rows > 0, "set_embedding_bct_dev_scale");
+    hipLaunchKernelGGL(embedding_bct_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0,
+                       (hipStream_t)stream, idx, table, out, B, T, C, n_rows, 1.0f, scale_dev, accumulate);
+    return set_check_launch("set_embedding_bct_dev_scale");
 }
 
 // ---- masks ------------------------------------------------------------------------------------

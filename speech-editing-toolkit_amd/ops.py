@@ -45,7 +45,14 @@ def weights_epoch():
     return _WEIGHTS_EPOCH
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current torch HIP stream of the current device as a raw handle.  (torch.cuda.current_stream() builds a Stream
+    object through several Python layers -- ~10 us, once per kernel launch: ~3 ms of a 1,400-launch training step.)"""
+    if _RAW_STREAM is not None:
+        return C.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -134,8 +141,11 @@ class ConvWeight:
         w = self.raw()
         key = (w.data_ptr(), w._version, w.device, _WEIGHTS_EPOCH)
         if self._packed is None or self._key != key:
-            n = _lib.lib().set_packed_conv_weight_size(self.Cout, self.Cin, self.K)
-            wp = torch.empty(n, dtype=torch.float32, device=w.device)
+            if self._packed is not None and self._packed.device == w.device:
+                wp = self._packed
+            else:
+                n = _lib.lib().set_packed_conv_weight_size(self.Cout, self.Cin, self.K)
+                wp = torch.empty(n, dtype=torch.float32, device=w.device)
             check(_lib.lib().set_pack_conv_weight(_p(w), _p(wp), self.Cout, self.Cin, self.K, self.base, self.sco,
                                                   self.sci, self.stap, _stream()), "set_pack_conv_weight")
             self._packed, self._key = wp, key
@@ -147,8 +157,11 @@ class ConvWeight:
         w = self.raw()
         key = (w.data_ptr(), w._version, w.device, _WEIGHTS_EPOCH)
         if self._packed16 is None or self._packed16[0] != key:
-            n = _lib.lib().set_packed_conv_weight_bf16_size(self.Cout, self.Cin, self.K)
-            wp = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+            if self._packed16 is not None and self._packed16[1].device == w.device:
+                wp = self._packed16[1]  # re-rounded in place once per optimizer step (stream order keeps earlier readers safe)
+            else:
+                n = _lib.lib().set_packed_conv_weight_bf16_size(self.Cout, self.Cin, self.K)
+                wp = torch.empty(n, dtype=torch.bfloat16, device=w.device)
             check(_lib.lib().set_pack_conv_weight_bf16(_p(w), _p(wp), self.Cout, self.Cin, self.K, self.base, self.sco,
                                                        self.sci, self.stap, _stream()), "set_pack_conv_weight_bf16")
             self._packed16 = (key, wp)
@@ -399,6 +412,10 @@ def embedding_bct(idx, table, scale=1.0, out=None, accumulate=False, padding_idx
     if out is None:
         assert not accumulate
         out = torch.empty(B, Cc, T, dtype=torch.float32, device=table.device)
+    if isinstance(scale, torch.Tensor):  # a scale that lives on the device (a parameter): no host read
+        check(_lib.lib().set_embedding_bct_dev_scale(_p(idx), _p(table), _p(_f(out)), B, T, Cc, n_rows, _p(_f(scale, "scale")),
+                                                     int(bool(accumulate)), _stream()), "set_embedding_bct_dev_scale")
+        return out
     check(_lib.lib().set_embedding_bct(_p(idx), _p(table), _p(_f(out)), B, T, Cc, n_rows, float(scale),
                                        int(bool(accumulate)), _stream()), "set_embedding_bct")
     return out
@@ -1027,7 +1044,7 @@ def cross_attention(q, kv, heads, key_padding_mask=None, fill=-1e8, alpha=1.0, w
 
 def pos_add(x, alpha, pos, table):
     """x + alpha * table[pos]  (transformer.py:795-796)"""
-    return embedding_bct(pos, table, scale=float(alpha.item()), out=x.clone(), accumulate=True)
+    return embedding_bct(pos, table, scale=alpha.detach().reshape(1).contiguous(), out=x.clone(), accumulate=True)
 
 
 def add_masked(a, b, m):

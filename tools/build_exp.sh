@@ -1,6 +1,6 @@
 #!/bin/bash
 # Experimental builds of the library for A/B measurements: build/exp/libset_amd_<tag>.so, loaded with SET_AMD_LIB=<path>.
-# usage: tools/build_exp.sh <tag> <file.hip> [extra hipcc flags...]   -- rebuilds <file.hip> with the flags, links with the
+# usage: [SRC_OVERRIDE=path] tools/build_exp.sh <tag> <file.hip> [extra hipcc flags...]   -- rebuilds <file.hip> with the flags, links with the
 # other objects (compiled once into build/exp/obj/).
 set -e
 cd "$(dirname "$0")/.."
@@ -14,7 +14,8 @@ for f in conv1d conv_x2 resblock_x2 glue diffnet diffnet_x3 train attention atte
   fi
 done
 wait
-/opt/rocm/bin/hipcc $FLAGS "$@" -c $CS/$SRC -o build/exp/obj/${SRC%.hip}_$TAG.o
+# SRC_OVERRIDE=<path>: compile that file in place of $CS/$SRC (an older or patched version of the same module)
+/opt/rocm/bin/hipcc $FLAGS -I $CS "$@" -c ${SRC_OVERRIDE:-$CS/$SRC} -o build/exp/obj/${SRC%.hip}_$TAG.o
 OBJS=""
 for f in conv1d conv_x2 resblock_x2 glue diffnet diffnet_x3 train attention attention_fused bf16 diffnet_bf16; do
   if [ "$f.hip" == "$SRC" ]; then OBJS="$OBJS build/exp/obj/${f}_$TAG.o"; else OBJS="$OBJS build/exp/obj/$f.o"; fi
