@@ -310,17 +310,18 @@ def test_fused_attention_forward_and_gradients(dev, case, dtype):
     alpha = d ** -0.5
     do = torch.randn(B, H, Tq, generator=g)
     rnd = (lambda t: t.bfloat16().double()) if dtype == "bf16" else (lambda t: t.double())
-    qh = rnd(q).view(B, heads, d, Tq).transpose(2, 3).requires_grad_(True)   # [B,h,Tq,d]
-    kh = rnd(k).reshape(B, heads, d, Tk).transpose(2, 3).requires_grad_(True)
-    vh = rnd(v).reshape(B, heads, d, Tk).transpose(2, 3).requires_grad_(True)
-    sc = (qh * (alpha if dtype != "bf16" else 1.0)) @ kh.transpose(2, 3)
-    if dtype == "bf16":  # the kernel rounds alpha * q
-        qs = rnd(q * alpha).view(B, heads, d, Tq).transpose(2, 3)
-        sc = qs @ kh.transpose(2, 3) + 0.0 * qh.sum()
-    if kpm is not None:
-        sc = sc.masked_fill(kpm.bool()[:, None, None, :], fill)
-    pr = torch.softmax(sc, -1)
-    o_ref = (pr @ vh).transpose(2, 3).reshape(B, H, Tq)
+    with torch.enable_grad():  # (other test modules switch autograd off globally at import)
+        qh = rnd(q).view(B, heads, d, Tq).transpose(2, 3).requires_grad_(True)   # [B,h,Tq,d]
+        kh = rnd(k).reshape(B, heads, d, Tk).transpose(2, 3).requires_grad_(True)
+        vh = rnd(v).reshape(B, heads, d, Tk).transpose(2, 3).requires_grad_(True)
+        sc = (qh * (alpha if dtype != "bf16" else 1.0)) @ kh.transpose(2, 3)
+        if dtype == "bf16":  # the kernel rounds alpha * q
+            qs = rnd(q * alpha).view(B, heads, d, Tq).transpose(2, 3)
+            sc = qs @ kh.transpose(2, 3) + 0.0 * qh.sum()
+        if kpm is not None:
+            sc = sc.masked_fill(kpm.bool()[:, None, None, :], fill)
+        pr = torch.softmax(sc, -1)
+        o_ref = (pr @ vh).transpose(2, 3).reshape(B, H, Tq)
     nan_rows = torch.isnan(o_ref).any(1)  # fully padded utterances with the -inf fill: NaN in torch, NaN here
     ops.set_compute_dtype(dtype)
     try:
@@ -356,7 +357,8 @@ def test_fused_attention_forward_and_gradients(dev, case, dtype):
     close(p, pr, "p", 1e-5 if dtype == "f32" else 2e-2)
     close(lse[:, :, 0] + torch.log(lse[:, :, 1]), torch.logsumexp(sc, -1), "lse", 1e-5 if dtype == "f32" else 2e-2)
     if not bool(nan_rows.any()):
-        o_ref.backward(do.double())
+        with torch.enable_grad():
+            o_ref.backward(do.double())
         # gradients w.r.t. the ROUNDED operands are what the kernel computes in bf16 mode (dq additionally carries alpha)
         if dtype == "bf16":
             with torch.enable_grad():
