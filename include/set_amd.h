@@ -67,6 +67,11 @@ extern "C" {
                           * set_pack_conv_weight_x2; no in_chan_add; an activation of magnitude >= 32768 raises the sticky
                           * flag of set_conv_x2_range_flag (the caller repeats on an fp32 impl) */
 
+#define SET_IMPL_FEWOUT 6 /* Cout <= 2 over a long sequence (HiFi-GAN conv_post): one thread per four output samples, fp32 VALU,
+                          * input streamed once with 16-byte loads; `w` = the RAW weight (w_base / w_s* addressing, as the naive
+                          * kernel); needs K <= 9, dil 1, 0 <= pad <= 4, K - pad <= 5, T_in == T_out, T % 4 == 0, no res / mask /
+                          * in_chan_add / accumulate, 16-byte aligned in / out */
+
 /* operand type selector of the training GEMMs */
 #define SET_DTYPE_F32 0
 #define SET_DTYPE_BF16 1         /* fp32 tensors in HBM, rounded to bf16 on the way into LDS */

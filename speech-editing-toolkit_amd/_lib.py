@@ -24,7 +24,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 OK, E_INVALID, E_UNSUPPORTED, E_LAUNCH = 0, -1, -2, -3
 ACT = dict(none=0, relu=1, gelu=2, tanh=3, softplus=4, mish=5, lrelu=6)
 PRO = dict(none=0, lrelu=1, div=2)
-IMPL_NAIVE, IMPL_MFMA, IMPL_MFMA2, IMPL_BF16, IMPL_F16X2 = 1, 2, 3, 4, 5
+IMPL_NAIVE, IMPL_MFMA, IMPL_MFMA2, IMPL_BF16, IMPL_F16X2, IMPL_FEWOUT = 1, 2, 3, 4, 5, 6
 DTYPE_F32, DTYPE_BF16, DTYPE_BF16_G16, DTYPE_BF16_G16_X16 = 0, 1, 2, 3
 
 c_f32p = C.POINTER(C.c_float)

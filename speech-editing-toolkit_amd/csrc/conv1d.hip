@@ -563,6 +563,77 @@ extern "C" int set_pack_conv_weight(const float *w, float *wp, int32_t Cout, int
 int set_conv1d_bf16_dispatch(const SetConv1dArgs &a, hipStream_t s);  // bf16.hip
 int set_conv1d_x2_dispatch(const SetConv1dArgs &a, hipStream_t s);    // csrc/conv_x2.hip
 
+// ------------------------------------------------------------------------------------------
+// SET_IMPL_FEWOUT: a convolution with ONE or TWO output channels over a long sequence (HiFi-GAN's conv_post, hifigan.py:123,
+// 138-140: 32 -> 1 channels, 7 taps, 13 M output samples at B = 64).  As a GEMM it has one useful row in 32 (the MFMA kernel
+// spends 1.9 ms on it); it is a streaming read of the input with 224 multiply-adds per sample, so: one thread = four consecutive
+// output samples of one utterance, per input channel three aligned 16-byte loads (the 12 samples around them: pad <= 4 taps to
+// the left, K - pad <= 5 to the right), weights through the scalar cache (the address is wave-uniform), prologue on load,
+// bias / alpha / activation and one 16-byte store at the end.  HBM-bound: the input is read once.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv1d_fewout_kernel(SetConv1dArgs a) {
+    const int b = blockIdx.y;
+    const int t4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t4 >= a.T_out) return;
+    const int T = a.T_in;
+    const float *inb = a.in + (int64_t)b * a.in_bs;
+    const bool v0 = t4 >= 4, v2 = t4 + 8 <= T;
+    const int o0 = v0 ? t4 - 4 : 0, o2 = v2 ? t4 + 4 : t4;
+    float acc[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        const float *row = inb + (int64_t)ci * a.in_cs;
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(row + o0);
+        const f32x4 w1 = *reinterpret_cast<const f32x4 *>(row + t4);
+        const f32x4 w2 = *reinterpret_cast<const f32x4 *>(row + o2);
+        float v[12];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = v0 ? w0[e] : 0.0f;
+            v[4 + e] = w1[e];
+            v[8 + e] = v2 ? w2[e] : 0.0f;
+        }
+        if (a.pro == SET_PRO_LRELU) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) v[j] = v[j] > 0.0f ? v[j] : v[j] * a.pro_param;
+        } else if (a.pro == SET_PRO_DIV) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) v[j] = v[j] / a.pro_param;
+        }
+#pragma unroll
+        for (int co = 0; co < 2; ++co) {
+            if (co < a.Cout) {
+                const float *wr = a.w + a.w_base + (int64_t)co * a.w_sco + (int64_t)ci * a.w_sci;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    if (k < a.K) {
+                        const float wv = wr[(int64_t)k * a.w_stap];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[co][e] += wv * v[4 + e + k - a.pad];
+                    }
+                }
+            }
+        }
+    }
+    for (int co = 0; co < a.Cout; ++co) {
+        const float bias = a.bias ? a.bias[co] : 0.0f;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = dev_act((acc[co][e] + bias) * a.alpha, a.act, a.act_param);
+        *reinterpret_cast<f32x4 *>(a.out + (int64_t)b * a.out_bs + (int64_t)co * a.out_cs + t4) = o;
+    }
+}
+
+static int launch_conv_fewout(const SetConv1dArgs &a, hipStream_t s) {
+    const bool ok = a.Cout <= 2 && a.K <= 9 && a.dil == 1 && a.pad >= 0 && a.pad <= 4 && a.K - a.pad <= 5 && a.out_stride == 1 &&
+                    a.out_off == 0 && a.T_in == a.T_out && a.T_iter == a.T_out && (a.T_in & 3) == 0 && !a.res && !a.mask &&
+                    !a.in_chan_add && !a.accumulate && (a.in_bs & 3) == 0 && (a.in_cs & 3) == 0 && (a.out_bs & 3) == 0 &&
+                    (a.out_cs & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0 &&
+                    a.B <= 65535;
+    if (!ok) return set_fail(SET_E_UNSUPPORTED, "set_conv1d(fewout)", "needs Cout <= 2, K <= 9, dil 1, same-length output, T % 4 == 0, plain epilogue");
+    hipLaunchKernelGGL(conv1d_fewout_kernel, dim3((a.T_out / 4 + 255) / 256, a.B), dim3(256), 0, s, a);
+    return set_check_launch("set_conv1d(fewout)");
+}
+
 extern "C" int set_conv1d(const SetConv1dArgs *args, void *stream) {
     SET_REQUIRE(args != nullptr, "set_conv1d");
     const SetConv1dArgs &a = *args;
@@ -574,6 +645,7 @@ extern "C" int set_conv1d(const SetConv1dArgs *args, void *stream) {
     if (a.impl == SET_IMPL_MFMA2) return launch_conv_v2(a, s);
     if (a.impl == SET_IMPL_BF16) return set_conv1d_bf16_dispatch(a, s);
     if (a.impl == SET_IMPL_F16X2) return set_conv1d_x2_dispatch(a, s);
+    if (a.impl == SET_IMPL_FEWOUT) return launch_conv_fewout(a, s);
     if (a.impl != SET_IMPL_MFMA) {
         const int64_t total = (int64_t)a.B * a.Cout * a.T_iter;
         hipLaunchKernelGGL(conv1d_naive_kernel, dim3(set_blocks(total, 256)), dim3(256), 0, s, a);

@@ -18,6 +18,10 @@
 // The k-step order of both GEMMs is the one of conv1d_x2_kernel (chunk, tap, half-chunk; pieces a1 b0, a0 b1, a0 b0) and the
 // intermediate takes the same fp32 value before it is split, so the fused pair is BIT-IDENTICAL to the two launches it
 // replaces (tests/test_gpu_x2conv.py::test_fused_resblock_pair_equals_two_convs).
+// Measured and dropped (round 3): a persistent variant (blocks walk tiles; the next tile's first x chunk is fetched as soon as the
+// chunk registers are free, under phase 1's MFMAs / epilogue 1 / phase 2 / epilogue 2).  The 48 chunk registers then live across
+// the whole tile: 55 - 84 spilled VGPRs for the 64- / 128- / 256-channel shapes, occupancy 3 -> 2 for the 32-channel one, and the
+// V1 forward went from 105 to 127 ms.
 #include <stdlib.h>
 
 #include "common.h"

@@ -237,11 +237,15 @@ class split_convs:
         _AUTO_SPLIT[0] = self.prev
 
 
-def _pick_impl(impl, T_iter, Cout=0, Cin=0, K=1, dil=1, out_stride=1, out_off=0, chan_add=False):
+def _pick_impl(impl, T_iter, Cout=0, Cin=0, K=1, dil=1, out_stride=1, out_off=0, chan_add=False, plain=False, pad=0):
     impl = impl or _DEFAULT_IMPL
     if impl == "auto":
         if T_iter < 16:
             return "naive"
+        # one or two output channels over a long sequence (HiFi-GAN conv_post): a streaming VALU kernel, not a GEMM
+        if plain and Cout <= 2 and K <= 9 and dil == 1 and 0 <= pad <= 4 and K - pad <= 5 and out_stride == 1 and \
+                T_iter >= 4096 and T_iter % 4 == 0 and _COMPUTE_DTYPE != "bf16":
+            return "fewout"
         if _AUTO_SPLIT[0] and not chan_add and f16x2_eligible(T_iter, Cout, Cin, K, dil):
             return "f16x2"
         if _COMPUTE_DTYPE == "bf16" and bf16_eligible(T_iter, Cout, Cin, K, dil, out_stride, out_off):
@@ -272,7 +276,9 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
     if out is None:
         out = torch.empty(B, weight.Cout, T_out, dtype=torch.float32, device=x.device)
     _fv(out, "out")
-    impl = _pick_impl(impl, T_iter, weight.Cout, Cin, weight.K, dil, out_stride, out_off, in_chan_add is not None)
+    plain = res is None and mask is None and in_chan_add is None and not accumulate and T_out == T_in and T_iter == T_out and \
+        out.is_contiguous() and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0
+    impl = _pick_impl(impl, T_iter, weight.Cout, Cin, weight.K, dil, out_stride, out_off, in_chan_add is not None, plain, pad)
     a = SetConv1dArgs()
     a.inp = x.data_ptr()
     if impl == "mfma2":
@@ -281,7 +287,7 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
         a.w = weight.packed_bf16().data_ptr()
     elif impl == "f16x2":
         a.w = weight.packed_x2().data_ptr()
-    else:
+    else:  # "mfma": packed image; "naive" / "fewout": the raw weight
         a.w = (weight.packed() if impl == "mfma" else weight.raw()).data_ptr()
     a.bias = _f(bias, "bias").data_ptr() if bias is not None else None
     a.res = _fv(res, "res").data_ptr() if res is not None else None
@@ -296,7 +302,8 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
     a.B, a.Cin, a.Cout, a.K, a.dil, a.pad = B, Cin, weight.Cout, weight.K, dil, pad
     a.T_in, a.T_iter, a.T_out, a.out_stride, a.out_off = T_in, T_iter, T_out, out_stride, out_off
     a.pro, a.act, a.accumulate = PRO[pro], ACT[act], int(bool(accumulate))
-    a.impl = {"mfma": IMPL_MFMA, "mfma2": IMPL_MFMA2, "bf16": IMPL_BF16, "f16x2": _lib.IMPL_F16X2}.get(impl, IMPL_NAIVE)
+    a.impl = {"mfma": IMPL_MFMA, "mfma2": IMPL_MFMA2, "bf16": IMPL_BF16, "f16x2": _lib.IMPL_F16X2,
+              "fewout": _lib.IMPL_FEWOUT}.get(impl, IMPL_NAIVE)
     a.pro_param, a.act_param, a.alpha = float(pro_param), float(act_param), float(alpha)
     a.out_div = float(out_div)
     assert not (out_div and not accumulate)

@@ -197,3 +197,33 @@ def test_fused_resblock_pair_raises_the_range_flag(dev):
     ops.resblock_pair(torch.randn(1, C, T, device=dev), cw1, big, cw2, b, 1)
     assert ops.conv_x2_range_flag(reset=True)
     assert not ops.conv_x2_range_flag(reset=True)
+
+
+@pytest.mark.parametrize("cfg", [(3, 32, 1, 7, 3, 8192, "lrelu", "tanh"), (2, 17, 2, 3, 1, 4100, "none", "none"),
+                                 (1, 64, 1, 9, 4, 4096, "lrelu", "none"), (2, 8, 2, 5, 0, 5000, "none", "relu")])
+def test_few_output_channel_conv_matches_torch(dev, cfg):
+    """SET_IMPL_FEWOUT (HiFi-GAN conv_post, hifigan.py:123,138-140: 32 -> 1 channels over 13 M samples): the streaming VALU
+    kernel against torch fp64 and against the MFMA kernel it replaces on that shape; `auto` must pick it there."""
+    from set_amd import ops
+    import torch.nn.functional as F
+    B, Cin, Cout, K, pad, T, pro, act = cfg
+    g = torch.Generator().manual_seed(Cin * 3 + K)
+    x = torch.randn(B, Cin, T, generator=g).to(dev)
+    w, cw = _w(dev, Cout, Cin, K, 9)
+    bias = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    same = T + 2 * pad - (K - 1) == T
+    if not same:
+        with pytest.raises(Exception):  # not a same-length convolution: the kernel must refuse, not compute something else
+            ops.conv1d(x, cw, bias, pad=pad, pro=pro, pro_param=0.01, act=act, impl="fewout")
+        return
+    got = ops.conv1d(x, cw, bias, pad=pad, pro=pro, pro_param=0.01, act=act, impl="fewout")
+    ref_k = ops.conv1d(x, cw, bias, pad=pad, pro=pro, pro_param=0.01, act=act, impl="mfma")
+    torch.cuda.synchronize()
+    xd = x.double().cpu()
+    xd = F.leaky_relu(xd, 0.01) if pro == "lrelu" else xd
+    yd = F.conv1d(xd, w.double().cpu(), bias.double().cpu(), padding=pad)
+    yd = torch.tanh(yd) if act == "tanh" else (torch.relu(yd) if act == "relu" else yd)
+    assert float((got.double().cpu() - yd).abs().max()) < 2e-5 * max(1.0, float(yd.abs().max()))
+    assert float((got - ref_k).abs().max()) < 2e-5 * max(1.0, float(yd.abs().max()))
+    picked = ops._pick_impl(None, T, Cout, Cin, K, 1, 1, 0, False, True, pad)
+    assert picked == "fewout", picked
