@@ -517,6 +517,17 @@ int set_partial_rows_sum(const float *part, float *out, int32_t groups, int32_t 
 int64_t set_packed_conv_weight_bf16_size(int32_t Cout, int32_t Cin, int32_t K);
 int set_pack_conv_weight_bf16(const float *w, void *wp, int32_t Cout, int32_t Cin, int32_t K, int64_t w_base,
                               int64_t w_sco, int64_t w_sci, int64_t w_stap, void *stream);
+/* All bf16 images of a model in ONE launch (after an optimizer step).  descs_dev: n descriptors IN DEVICE MEMORY, sorted by
+ * `start` = index of the image's first element in the concatenated element space [0, total); per image the layout of
+ * set_pack_conv_weight_bf16 (CoutP = Cout rounded up to 128, CinP = Cin rounded up to 32). */
+typedef struct SetPackBf16Desc {
+    const float *w;
+    void *wp;
+    int64_t w_base, w_sco, w_sci, w_stap, start;
+    int32_t Cout, Cin, K, CoutP, CinP, pad_;
+} SetPackBf16Desc;
+int64_t set_sizeof_pack_bf16_desc(void);
+int set_pack_conv_weights_bf16_batch(const SetPackBf16Desc *descs_dev, int32_t n, int64_t total, void *stream);
 /* out[c] += sum_{b,t} x[b][c][t]   (bias gradients) */
 int set_channel_sum(const float *x, float *out, int32_t B, int32_t C, int32_t T, void *stream);
 

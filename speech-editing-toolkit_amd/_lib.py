@@ -127,6 +127,14 @@ class SetResblockPairArgs(C.Structure):
     ]
 
 
+class SetPackBf16Desc(C.Structure):
+    _fields_ = [
+        ("w", C.c_void_p), ("wp", C.c_void_p),
+        ("w_base", C.c_int64), ("w_sco", C.c_int64), ("w_sci", C.c_int64), ("w_stap", C.c_int64), ("start", C.c_int64),
+        ("Cout", C.c_int32), ("Cin", C.c_int32), ("K", C.c_int32), ("CoutP", C.c_int32), ("CinP", C.c_int32), ("pad_", C.c_int32),
+    ]
+
+
 class SetBmmArgs(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
@@ -232,6 +240,8 @@ SIGNATURES = {
     "set_conv1d_wgrad_det": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _V, _I64, _V]),
     "set_packed_conv_weight_bf16_size": (_I64, [_I32, _I32, _I32]),
     "set_pack_conv_weight_bf16": (C.c_int, [_V, _V, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _V]),
+    "set_sizeof_pack_bf16_desc": (_I64, []),
+    "set_pack_conv_weights_bf16_batch": (C.c_int, [_V, _I32, _I64, _V]),
     "set_channel_sum_det": (C.c_int, [_V, _V, _I32, _I32, _I32, _V, _V]),
     "set_weighted_sum_det": (C.c_int, [_V, _V, _V, _I64, _I64, _V, _V]),
     "set_sumsq_det": (C.c_int, [_V, _V, _I64, _V, _V]),
@@ -347,6 +357,7 @@ def lib():
     assert L.set_sizeof_bmm_args() == C.sizeof(SetBmmArgs), "SetBmmArgs ABI mismatch"
     assert L.set_sizeof_resblock_pair_args() == C.sizeof(SetResblockPairArgs), "SetResblockPairArgs ABI mismatch"
     assert L.set_sizeof_attn_args() == C.sizeof(SetAttnArgs), "SetAttnArgs ABI mismatch"
+    assert L.set_sizeof_pack_bf16_desc() == C.sizeof(SetPackBf16Desc), "SetPackBf16Desc ABI mismatch"
     assert L.set_sizeof_attn_bwd_args() == C.sizeof(SetAttnBwdArgs), "SetAttnBwdArgs ABI mismatch"
     assert L.set_sizeof_diffnet_layer_bf16_args() == C.sizeof(SetDiffnetLayerBf16Args), "SetDiffnetLayerBf16Args ABI mismatch"
     assert L.set_sizeof_diffnet_layer_bf16_bwd_args() == C.sizeof(SetDiffnetLayerBf16BwdArgs), "SetDiffnetLayerBf16BwdArgs ABI mismatch"

@@ -71,6 +71,31 @@ __global__ void __launch_bounds__(256) pack_conv_weight_bf16_kernel(const float 
     wp[idx] = bf16_bits(v);
 }
 
+// every registered bf16 image in ONE launch (after the optimizer step: ~100 - 170 tiny pack launches per training step
+// otherwise): element idx of the concatenated image space -> its descriptor by binary search over `start`
+__global__ void __launch_bounds__(256) pack_conv_weights_bf16_batch_kernel(const SetPackBf16Desc *d, int n, int64_t total) {
+    const int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gidx >= total) return;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (d[mid].start <= gidx) lo = mid; else hi = mid - 1;
+    }
+    const SetPackBf16Desc e = d[lo];
+    const int64_t idx = gidx - e.start;
+    const int kk = (int)(idx & 31);
+    int64_t r = idx >> 5;
+    const int row = (int)(r % e.CoutP);
+    r /= e.CoutP;
+    const int nchunk = e.CinP / 32;
+    const int chunk = (int)(r % nchunk);
+    const int tap = (int)(r / nchunk);
+    const int ci = chunk * 32 + kk;
+    float v = 0.0f;
+    if (row < e.Cout && ci < e.Cin) v = e.w[e.w_base + (int64_t)row * e.w_sco + (int64_t)ci * e.w_sci + (int64_t)tap * e.w_stap];
+    reinterpret_cast<unsigned short *>(e.wp)[idx] = bf16_bits(v);
+}
+
 // =====================================================================================================================
 // conv1d, bf16 operands.  Block = 4 waves arranged WM x WN, wave tile 64 rows x 64 frames (2 x 2 accumulators of
 // 32x32), block tile MB = 64*WM rows x NB = 64*WN frames.  One pipeline stage = KCH input channels x TG taps:
@@ -597,6 +622,15 @@ extern "C" int set_pack_conv_weight_bf16(const float *w, void *wp, int32_t Cout,
                        reinterpret_cast<unsigned short *>(wp), Cout, Cin, K, round_up_i(Cout, 128), round_up_i(Cin, 32), total,
                        w_base, w_sco, w_sci, w_stap);
     return set_check_launch("set_pack_conv_weight_bf16");
+}
+
+extern "C" int64_t set_sizeof_pack_bf16_desc(void) { return (int64_t)sizeof(SetPackBf16Desc); }
+
+extern "C" int set_pack_conv_weights_bf16_batch(const SetPackBf16Desc *descs_dev, int32_t n, int64_t total, void *stream) {
+    SET_REQUIRE(descs_dev && n > 0 && total > 0, "set_pack_conv_weights_bf16_batch");
+    hipLaunchKernelGGL(pack_conv_weights_bf16_batch_kernel, dim3(set_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, descs_dev,
+                       n, total);
+    return set_check_launch("set_pack_conv_weights_bf16_batch");
 }
 
 // called by set_conv1d (conv1d.hip) for impl == SET_IMPL_BF16

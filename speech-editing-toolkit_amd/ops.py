@@ -45,6 +45,45 @@ def weights_epoch():
     return _WEIGHTS_EPOCH
 
 
+import weakref  # noqa: E402
+
+_BF16_IMAGES = weakref.WeakSet()   # ConvWeights that hold a bf16 image (training rows, compute dtype bf16)
+_BF16_BATCH = [None, None, 0]      # (signature, device descriptor table, total elements) of the last batch re-pack
+
+
+def repack_bf16_images():
+    """Re-round EVERY live bf16 weight image from its fp32 master weight in ONE launch and mark the images current for the
+    present weights epoch.  Called by the optimizer right after its step: the lazy per-weight check in `packed_bf16()` then
+    finds nothing to do, instead of launching 100 - 170 tiny pack kernels (and allocating as many tensors) per training step.
+    The descriptor table lives on the device and is rebuilt only when the set of images or their storage changes."""
+    cws = [cw for cw in _BF16_IMAGES if cw._packed16 is not None]
+    if not cws:
+        return 0
+    ws = [cw.raw() for cw in cws]
+    dev = ws[0].device
+    keep = [i for i, w in enumerate(ws) if w.device == dev and cws[i]._packed16[1].device == dev]
+    cws, ws = [cws[i] for i in keep], [ws[i] for i in keep]
+    sig = tuple((id(cw), w.data_ptr(), cw._packed16[1].data_ptr()) for cw, w in zip(cws, ws))
+    if _BF16_BATCH[0] != sig:
+        arr = (_lib.SetPackBf16Desc * len(cws))()
+        start = 0
+        for d, cw, w in zip(arr, cws, ws):
+            wp = cw._packed16[1]
+            d.w, d.wp = w.data_ptr(), wp.data_ptr()
+            d.w_base, d.w_sco, d.w_sci, d.w_stap, d.start = cw.base, cw.sco, cw.sci, cw.stap, start
+            d.Cout, d.Cin, d.K = cw.Cout, cw.Cin, cw.K
+            d.CoutP, d.CinP = (cw.Cout + 127) // 128 * 128, (cw.Cin + 31) // 32 * 32
+            assert wp.numel() == d.CoutP * d.K * d.CinP
+            start += wp.numel()
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        _BF16_BATCH[0], _BF16_BATCH[1], _BF16_BATCH[2] = sig, raw, start
+    check(_lib.lib().set_pack_conv_weights_bf16_batch(C.c_void_p(_BF16_BATCH[1].data_ptr()), len(cws), _BF16_BATCH[2], _stream()),
+          "set_pack_conv_weights_bf16_batch")
+    for cw, w in zip(cws, ws):
+        cw._packed16 = ((w.data_ptr(), w._version, w.device, _WEIGHTS_EPOCH), cw._packed16[1])
+    return len(cws)
+
+
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -165,6 +204,7 @@ class ConvWeight:
             check(_lib.lib().set_pack_conv_weight_bf16(_p(w), _p(wp), self.Cout, self.Cin, self.K, self.base, self.sco,
                                                        self.sci, self.stap, _stream()), "set_pack_conv_weight_bf16")
             self._packed16 = (key, wp)
+            _BF16_IMAGES.add(self)  # from now on the optimizer re-rounds it with all the others (repack_bf16_images)
         return self._packed16[1]
 
     def packed_x2(self):

@@ -105,6 +105,8 @@ class FlatAdamW:
         A.adamw_step(self.flat_p, self.flat_g, self.m, self.v, lr, self.betas[0], self.betas[1], self.eps, self.wd,
                      self.num_updates, sumsq, self.clip, 1.0 / world)
         ops.bump_weights_epoch()
+        if ops.compute_dtype() == "bf16":
+            ops.repack_bf16_images()  # every bf16 weight image in one launch (they are all stale now)
         return lr, sumsq
 
     # ---- checkpoint interchange with torch.optim.AdamW (the reference's optimizer, tasks/tts/speech_base.py:163-170):

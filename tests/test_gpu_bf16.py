@@ -402,3 +402,35 @@ def test_bf16_inference_loop_tolerance(dev):
         assert torch.equal(ret["mel2ph"].cpu(), torch.from_numpy(g["mel2ph"]))  # integer bookkeeping is untouched
     print("bf16 loop vs reference mel: %s" % {k: "mcd %.4f max|d| %.4f" % v for k, v in worst.items()})
     assert max(v[0] for v in worst.values()) < 0.5
+
+
+def test_batch_repack_equals_per_weight_packs(dev):
+    """ops.repack_bf16_images (what FlatAdamW.step calls in bf16 mode): every registered bf16 weight image re-rounded from its
+    fp32 master weight in ONE launch -- bit-equal to the per-weight pack kernel, for plain, transposed (input-gradient) and
+    offset / strided (a slice of a packed projection) weights; afterwards the lazy per-weight check finds the images current."""
+    import ctypes as C
+    from set_amd import _lib, ops
+    g = torch.Generator().manual_seed(7)
+    ws = [torch.randn(192, 96, 5, generator=g).to(dev), torch.randn(80, 33, 1, generator=g).to(dev),
+          torch.randn(3 * 64, 64, generator=g).to(dev), torch.randn(256, 512, 3, generator=g).to(dev)]
+    cws = [ops.ConvWeight(ws[0], 192, 96, 5), ops.ConvWeight(ws[1], 80, 33, 1),
+           ops.ConvWeight(ws[2], 128, 64, 1, base=64 * 64),   # rows 64.. of a packed [3 * 64, 64] projection (kv slice)
+           ops.ConvWeight(ws[3], 256, 512, 3)]
+    cws.append(cws[0].transposed())
+    cws.append(cws[3].transposed())
+    imgs = [cw.packed_bf16() for cw in cws]          # first use: per-weight packs, registration
+    ptrs = [im.data_ptr() for im in imgs]
+    for w in ws:
+        w.mul_(1.37).add_(0.01)                        # "optimizer step": the master weights move
+    ops.bump_weights_epoch()
+    n = ops.repack_bf16_images()
+    assert n >= len(cws)
+    torch.cuda.synchronize()
+    for cw, im, ptr in zip(cws, imgs, ptrs):
+        assert cw._packed16[0][3] == ops.weights_epoch() and cw._packed16[1].data_ptr() == ptr
+        fresh = torch.empty_like(im)
+        _lib.check(_lib.lib().set_pack_conv_weight_bf16(C.c_void_p(cw.raw().data_ptr()), C.c_void_p(fresh.data_ptr()), cw.Cout, cw.Cin,
+                                                        cw.K, cw.base, cw.sco, cw.sci, cw.stap, None), "pack")
+        torch.cuda.synchronize()
+        assert torch.equal(im.view(torch.int16), fresh.view(torch.int16))
+        assert cw.packed_bf16().data_ptr() == ptr     # current: no re-pack, same storage
