@@ -448,6 +448,15 @@ int64_t set_conv1d_wgrad_scratch_floats(int32_t B, int32_t Cin, int32_t Cout, in
 int set_conv1d_wgrad_det(const void *g, const void *x, const float *chan_add, float *dw, int32_t B, int32_t Cin,
                          int32_t Cout, int32_t K, int32_t dil, int32_t pad, int32_t T, int32_t T_in, int32_t pro,
                          float pro_param, int32_t dtype, float *scratch, int64_t scratch_floats, void *stream);
+/* The same for `groups` equal GEMMs in ONE launch (+ one ordered reduce) -- the weight gradients of all L residual layers of the
+ * DiffNet at once: group q reads g + q g_gs, x + q x_gs, chan_add + q add_gs and ADDS into dw + q dw_gs (strides in elements of the
+ * respective type).  With L x the tiles a few frame slices per group fill the chip: 13 - 64 slices per GEMM become 2 - 4 (as much
+ * less partial-sum traffic), 120 launches become 6.  bf16 dtypes only, no prologue. */
+int64_t set_conv1d_wgrad_grouped_scratch_floats(int32_t groups, int32_t B, int32_t Cin, int32_t Cout, int32_t K, int32_t T);
+int set_conv1d_wgrad_det_grouped(const void *g, const void *x, const float *chan_add, float *dw, int32_t groups, int64_t g_gs,
+                                 int64_t x_gs, int64_t add_gs, int64_t dw_gs, int32_t B, int32_t Cin, int32_t Cout, int32_t K,
+                                 int32_t dil, int32_t pad, int32_t T, int32_t T_in, int32_t dtype, float *scratch,
+                                 int64_t scratch_floats, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused DiffNet residual layer, bf16 MFMA operands, for the TRAINING path (residual_channels 256, hidden_size 192,

@@ -238,6 +238,9 @@ SIGNATURES = {
     "set_conv1d_wgrad": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _V]),
     "set_conv1d_wgrad_scratch_floats": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32]),
     "set_conv1d_wgrad_det": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _V, _I64, _V]),
+    "set_conv1d_wgrad_grouped_scratch_floats": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32]),
+    "set_conv1d_wgrad_det_grouped": (C.c_int, [_V, _V, _V, _V, _I32, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
+                                               _I32, _V, _I64, _V]),
     "set_packed_conv_weight_bf16_size": (_I64, [_I32, _I32, _I32]),
     "set_pack_conv_weight_bf16": (C.c_int, [_V, _V, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _V]),
     "set_sizeof_pack_bf16_desc": (_I64, []),

@@ -5,6 +5,7 @@ torch.autograd is used as the tape only: every forward AND backward below is a k
 from ops.py unchanged.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -125,6 +126,35 @@ def conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro=0, pr
         _WG_SCRATCH[g.device] = buf
     check(L().set_conv1d_wgrad_det(_p(g), _p(x), _p(chan_add), ptr, B, Cin, Cout, K, dil, pad, T, T_in, pro,
                                    float(pro_param), dt, _p(buf), buf.numel(), _stream()), "set_conv1d_wgrad_det")
+
+
+def conv_wgrad_grouped(g, x, chan_add, dw_ptr, groups, g_gs, x_gs, add_gs, dw_gs, B, Cin, Cout, K, dil, pad, T, T_in, dtype):
+    """`groups` equal bf16 weight-gradient GEMMs (the same conv of every residual layer) in one launch + one ordered reduce;
+    group q reads g + q g_gs, x + q x_gs, chan_add + q add_gs and adds into dw_ptr + q dw_gs (element strides)."""
+    need = L().set_conv1d_wgrad_grouped_scratch_floats(groups, B, Cin, Cout, K, T)
+    buf = _WG_SCRATCH.get(g.device)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(int(need * 1.25) + 1024, dtype=torch.float32, device=g.device)
+        _WG_SCRATCH[g.device] = buf
+    check(L().set_conv1d_wgrad_det_grouped(_p(g), _p(x), _p(chan_add), C.c_void_p(dw_ptr), groups, g_gs, x_gs, add_gs, dw_gs, B, Cin,
+                                           Cout, K, dil, pad, T, T_in, dtype, _p(buf), buf.numel(), _stream()),
+          "set_conv1d_wgrad_det_grouped")
+
+
+def _grouped_targets(params, dev):
+    """Where the gradients of one parameter kind of all layers go: (base pointer, element stride between layers, what to hand to
+    autograd per layer).  In place when the flat optimizer owns every one of them at a uniform stride (its layout is: each layer's
+    parameters contiguous, in the same order); otherwise one zeroed [L, ...] temporary whose slices autograd accumulates."""
+    sinks = [grad_sink(p_)[0] for p_ in params]
+    n = params[0].numel()
+    if all(t is not None for t in sinks):
+        ptrs = [t.data_ptr() for t in sinks]
+        step = (ptrs[1] - ptrs[0]) if len(ptrs) > 1 else 4 * n
+        if step % 4 == 0 and step >= 4 * n and all(ptrs[i] == ptrs[0] + i * step for i in range(len(ptrs))):
+            return ptrs[0], step // 4, [None] * len(params)
+        # owned, but not at a uniform stride (never seen with FlatAdamW): through autograd like unowned parameters
+    tmp = _gzeros(len(params) * n, dev).view(len(params), *params[0].shape)
+    return tmp.data_ptr(), n, [tmp[l] for l in range(len(params))]
 
 
 # --------------------------------------------------------------------------------------------------
@@ -625,13 +655,16 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
         dskip = dskip.contiguous()
         dcond = torch.empty_like(cond)
         dd = torch.empty(B, L_ * C_, dtype=torch.float32, device=dev)
-        dy16 = torch.empty(B, 2 * C_, T, dtype=torch.bfloat16, device=dev)
-        do16 = torch.empty(B, 2 * C_, T, dtype=torch.bfloat16, device=dev)
+        # Weight gradients of ALL layers in three grouped launches after the sweep (dy / d_o of every layer are kept: 2 x L x 26 MB
+        # at B = 32, T = 800) when the layers share one dilation; else three GEMMs per layer inside the sweep.
+        grouped = len({layer.dilation for layer in layers}) == 1 and os.environ.get("SET_AMD_GROUPED_WGRAD", "1") != "0"
+        n_slab = L_ if grouped else 1
+        dy16_all = torch.empty(n_slab, B, 2 * C_, T, dtype=torch.bfloat16, device=dev)
+        do16_all = torch.empty(n_slab, B, 2 * C_, T, dtype=torch.bfloat16, device=dev)
         dx = [torch.empty(B, C_, T, dtype=torch.float32, device=dev) for _ in range(2)]
         G16, GX16 = _lib.DTYPE_BF16_G16, _lib.DTYPE_BF16_G16_X16
         a = _lib.SetDiffnetLayerBf16BwdArgs()
         a.dskip, a.dcond = dskip.data_ptr(), dcond.data_ptr()
-        a.dy16, a.do16 = dy16.data_ptr(), do16.data_ptr()
         a.B, a.T = B, T
         grads = []
         cur = None  # gradient w.r.t. the current layer's x_out (None for the last layer: its x_out feeds nothing)
@@ -643,6 +676,8 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
             pdby_c = torch.empty(B * tiles, 2 * C_, dtype=torch.float32, device=dev)
             pdd_c = torch.empty(B * tiles, C_, dtype=torch.float32, device=dev)
             out = dx[l & 1]
+            dy16, do16 = dy16_all[l if grouped else 0], do16_all[l if grouped else 0]
+            a.dy16, a.do16 = dy16.data_ptr(), do16.data_ptr()
             a.dx_out = None if cur is None else cur.data_ptr()
             a.y16, a.img, a.dx = y16[l].data_ptr(), imgs[l].data_ptr(), out.data_ptr()
             a.part_dbo, a.part_dby, a.part_dd = pdbo_c.data_ptr(), pdby_c.data_ptr(), pdd_c.data_ptr()
@@ -668,13 +703,28 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
                                                                    btgt(layer.conditioner_projection.bias))
             check(L().set_diffnet_layer_bwd_reduce(_p(pdbo_c), _p(pdby_c), _p(pdd_c), B, tiles, _p(t_out), _p(t_dil), _p(t_cond),
                                                    dd.data_ptr() + 4 * l * C_, dd.stride(0), _stream()), "set_diffnet_layer_bwd_reduce")
-            dw_out = wg(layer.output_projection.weight, do16, z16[l], None, B, C_, 2 * C_, 1, 1, 0, T, T, dtype=GX16)
-            dw_cond = wg(layer.conditioner_projection.weight, dy16, cond, None, B, H, 2 * C_, 1, 1, 0, T, T, dtype=G16)
-            dl = dmat[:, l * C_:(l + 1) * C_].contiguous()
-            dw_dil = wg(layer.dilated_conv.weight, dy16, x_all[l], dl, B, C_, 2 * C_, 3, dil, dil, T, T, dtype=G16)
-            grads.append((dw_cond, db_cond, dw_dil, db_dil, dw_out, db_out))
+            if grouped:
+                dw_out = dw_cond = dw_dil = None  # filled in below
+            else:
+                dw_out = wg(layer.output_projection.weight, do16, z16[l], None, B, C_, 2 * C_, 1, 1, 0, T, T, dtype=GX16)
+                dw_cond = wg(layer.conditioner_projection.weight, dy16, cond, None, B, H, 2 * C_, 1, 1, 0, T, T, dtype=G16)
+                dl = dmat[:, l * C_:(l + 1) * C_].contiguous()
+                dw_dil = wg(layer.dilated_conv.weight, dy16, x_all[l], dl, B, C_, 2 * C_, 3, dil, dil, T, T, dtype=G16)
+            grads.append([dw_cond, db_cond, dw_dil, db_dil, dw_out, db_out])
             cur = out
         grads.reverse()
+        if grouped:
+            dil = layers[0].dilation
+            n_act = B * 2 * C_ * T
+            p_out, s_out, r_out = _grouped_targets([ly.output_projection.weight for ly in layers], dev)
+            conv_wgrad_grouped(do16_all, z16, None, p_out, L_, n_act, B * C_ * T, 0, s_out, B, C_, 2 * C_, 1, 1, 0, T, T, GX16)
+            p_c, s_c, r_c = _grouped_targets([ly.conditioner_projection.weight for ly in layers], dev)
+            conv_wgrad_grouped(dy16_all, cond, None, p_c, L_, n_act, 0, 0, s_c, B, H, 2 * C_, 1, 1, 0, T, T, G16)
+            dl_all = dmat.view(B, L_, C_).transpose(0, 1).contiguous()  # [L][B][C] step offsets (the conv's input is x + d)
+            p_d, s_d, r_d = _grouped_targets([ly.dilated_conv.weight for ly in layers], dev)
+            conv_wgrad_grouped(dy16_all, x_all, dl_all, p_d, L_, n_act, B * C_ * T, B * C_, s_d, B, C_, 2 * C_, 3, dil, dil, T, T, G16)
+            for l in range(L_):
+                grads[l][0], grads[l][2], grads[l][4] = r_c[l], r_d[l], r_out[l]
         flat = [g for tup in grads for g in tup]
         need_cond = ctx.needs_input_grad[2]
         return (None, cur, dcond if need_cond else None, dd, *flat)

@@ -363,6 +363,10 @@ struct WgradBf16Args {
     int B, Cin, Cout, K, dil, pad, T, T_in, pro;
     float pro_param;
     int chunks_per_slice, n_chunks_t, ci_tiles;
+    // grouped launch (the same GEMM shape for every residual layer of the DiffNet: grid.z = group * S + slice): byte strides of g
+    // and x between groups, float stride of chan_add; S = slices per group.  One group: S = gridDim.z, strides 0.
+    int S;
+    int64_t g_gs, x_gs, add_gs;
 };
 
 __device__ __forceinline__ unsigned buf_load_raw(rsrc_t r, unsigned voff, unsigned soff) {
@@ -386,9 +390,13 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
     const int co0 = blockIdx.y * 128;
     const int shift = tap * a.dil - a.pad;
     const int total_chunks = a.B * a.n_chunks_t;
-    const int c_begin = blockIdx.z * a.chunks_per_slice;
+    const int grp = blockIdx.z / a.S;
+    const int c_begin = (blockIdx.z - grp * a.S) * a.chunks_per_slice;
     const int c_end = min(c_begin + a.chunks_per_slice, total_chunks);
     const bool has_add = !XB16 && a.chan_add != nullptr;
+    a.g = reinterpret_cast<const unsigned char *>(a.g) + grp * a.g_gs;
+    a.x = reinterpret_cast<const unsigned char *>(a.x) + grp * a.x_gs;
+    if (has_add) a.chan_add += grp * a.add_gs;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -498,9 +506,13 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad3_bf16_kernel(WgradBf16Arg
     const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 128;
     const int sh0 = -a.pad, dil = a.dil;  // tap k reads frame t + k dil - pad
     const int total_chunks = a.B * a.n_chunks_t;
-    const int c_begin = blockIdx.z * a.chunks_per_slice;
+    const int grp = blockIdx.z / a.S;
+    const int c_begin = (blockIdx.z - grp * a.S) * a.chunks_per_slice;
     const int c_end = min(c_begin + a.chunks_per_slice, total_chunks);
     const bool has_add = a.chan_add != nullptr;
+    a.g = reinterpret_cast<const unsigned char *>(a.g) + grp * a.g_gs;
+    a.x = reinterpret_cast<const unsigned char *>(a.x) + grp * a.x_gs;
+    if (has_add) a.chan_add += grp * a.add_gs;
     constexpr unsigned GE = GB16 ? 2u : 4u;
 
     f32x16 acc[3][2];
@@ -599,12 +611,14 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad3_bf16_kernel(WgradBf16Arg
 }
 
 // dw[i] += sum_{s < S} partial[s][i]   (slice order: the sum has one fixed association)
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *partial, float *dw, int64_t n, int S) {
+// (grid.y = group: partial[(group * S + z) * n + i], dw + group * dw_gs)
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *partial, float *dw, int64_t n, int S, int64_t dw_gs) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const float *pp = partial + (int64_t)blockIdx.y * S * n;
     float s = 0.0f;
-    for (int z = 0; z < S; ++z) s += partial[(int64_t)z * n + i];
-    dw[i] += s;
+    for (int z = 0; z < S; ++z) s += pp[(int64_t)z * n + i];
+    dw[(int64_t)blockIdx.y * dw_gs + i] += s;
 }
 
 }  // namespace
@@ -676,11 +690,72 @@ static int wgrad_bf16_slices(int B, int Cin, int Cout, int K, int T, bool taps3 
     return (int)((total_chunks + cps - 1) / cps);  // no empty slices
 }
 
+// slices per group of a launch over `groups` equal GEMMs: with many groups a few slices fill the chip
+static int wgrad_bf16_slices_grouped(int B, int Cin, int Cout, int K, int T, bool taps3, int groups) {
+    const int n_chunks_t = (T + WGB_KT - 1) / WGB_KT;
+    const int64_t total_chunks = (int64_t)B * n_chunks_t;
+    const int64_t tiles = (int64_t)groups * (taps3 ? ((Cin + 63) / 64) * ((Cout + 127) / 128) : K * ((Cin + 127) / 128) * ((Cout + 127) / 128));
+    int64_t S = (640 + tiles - 1) / tiles;  // ~2.5 blocks per CU
+    if (S > total_chunks) S = total_chunks;
+    if (S > (taps3 ? 32 : 64)) S = taps3 ? 32 : 64;
+    if (S < 1) S = 1;
+    const int64_t cps = (total_chunks + S - 1) / S;
+    return (int)((total_chunks + cps - 1) / cps);  // no empty slices
+}
+
 extern "C" int64_t set_conv1d_wgrad_scratch_floats(int32_t B, int32_t Cin, int32_t Cout, int32_t K, int32_t T, int32_t dtype) {
     // upper bound over the kernel variants of the dtype (the 3-tap variant is chosen from dil / pad / pro at call time)
     int S = dtype != SET_DTYPE_F32 ? wgrad_bf16_slices(B, Cin, Cout, K, T) : wgrad_f32_slices(B, Cin, Cout, K, T);
     if (dtype != SET_DTYPE_F32 && K == 3) { const int S3 = wgrad_bf16_slices(B, Cin, Cout, K, T, true); S = S3 > S ? S3 : S; }
     return (int64_t)S * Cout * Cin * K;
+}
+
+extern "C" int64_t set_conv1d_wgrad_grouped_scratch_floats(int32_t groups, int32_t B, int32_t Cin, int32_t Cout, int32_t K, int32_t T) {
+    if (groups < 1) return 0;
+    int S = wgrad_bf16_slices_grouped(B, Cin, Cout, K, T, false, groups);
+    if (K == 3) { const int S3 = wgrad_bf16_slices_grouped(B, Cin, Cout, K, T, true, groups); S = S3 > S ? S3 : S; }
+    return (int64_t)groups * S * Cout * Cin * K;
+}
+
+// bf16 weight gradients of `groups` equal GEMMs in one launch (+ one ordered reduce): group q reads g + q g_gs, x + q x_gs,
+// chan_add + q add_gs (element strides) and adds into dw + q dw_gs
+static int wgrad_bf16_launch(const void *g, const void *x, const float *chan_add, float *dw, int B, int Cin, int Cout, int K, int dil,
+                             int pad, int T, int T_in, int pro, float pro_param, int dtype, float *scratch, int groups, int64_t g_gs,
+                             int64_t x_gs, int64_t add_gs, int64_t dw_gs, int S_plain, int S_taps3, hipStream_t s) {
+    const int64_t n = (int64_t)Cout * Cin * K;
+    const bool g16 = dtype != SET_DTYPE_BF16, x16 = dtype == SET_DTYPE_BF16_G16_X16;
+    WgradBf16Args a;
+    a.g = g; a.x = x; a.chan_add = chan_add; a.partial = scratch;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.K = K; a.dil = dil; a.pad = pad; a.T = T; a.T_in = T_in; a.pro = pro;
+    a.pro_param = pro_param;
+    a.n_chunks_t = (T + WGB_KT - 1) / WGB_KT;
+    a.g_gs = g_gs * (g16 ? 2 : 4); a.x_gs = x_gs * (x16 ? 2 : 4); a.add_gs = add_gs;
+    int S;
+    if (wgrad3_applies(K, dil, pad, pro, dtype)) {
+        S = S_taps3;
+        a.S = S;
+        a.chunks_per_slice = (B * a.n_chunks_t + S - 1) / S;
+        a.ci_tiles = (Cin + 63) / 64;
+        dim3 grid(a.ci_tiles, (Cout + 127) / 128, S * groups);
+        if (dtype == SET_DTYPE_BF16) hipLaunchKernelGGL((conv1d_wgrad3_bf16_kernel<false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv1d_wgrad3_bf16_kernel<true>), grid, dim3(256), 0, s, a);
+        const int rc = set_check_launch("set_conv1d_wgrad_det(bf16, 3 taps)");
+        if (rc != SET_OK) return rc;
+    } else {
+        S = S_plain;
+        a.S = S;
+        const int total_chunks = B * a.n_chunks_t;
+        a.chunks_per_slice = (total_chunks + S - 1) / S;
+        a.ci_tiles = (Cin + 127) / 128;
+        dim3 grid(K * a.ci_tiles, (Cout + 127) / 128, S * groups);
+        if (dtype == SET_DTYPE_BF16) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<false, false>), grid, dim3(256), 0, s, a);
+        else if (dtype == SET_DTYPE_BF16_G16) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, true>), grid, dim3(256), 0, s, a);
+        const int rc = set_check_launch("set_conv1d_wgrad_det(bf16)");
+        if (rc != SET_OK) return rc;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(set_blocks(n, 256), groups), dim3(256), 0, s, scratch, dw, n, S, dw_gs);
+    return set_check_launch("set_conv1d_wgrad_det(reduce)");
 }
 
 extern "C" int set_conv1d_wgrad_det(const void *g, const void *x, const float *chan_add, float *dw, int32_t B, int32_t Cin,
@@ -692,45 +767,34 @@ extern "C" int set_conv1d_wgrad_det(const void *g, const void *x, const float *c
     SET_REQUIRE(scratch_floats >= need, "set_conv1d_wgrad_det (scratch too small)");
     SET_REQUIRE((int64_t)Cout * T * 4 < ((int64_t)1 << 31) && (int64_t)Cin * T_in * 4 < ((int64_t)1 << 31),
                 "set_conv1d_wgrad_det (one batch slice exceeds 2 GiB)");
-    int S = (int)(need / n);
     hipStream_t s = (hipStream_t)stream;
-    if (wgrad3_applies(K, dil, pad, pro, dtype)) {
-        S = wgrad_bf16_slices(B, Cin, Cout, K, T, true);
-        WgradBf16Args a;
-        a.g = g; a.x = x; a.chan_add = chan_add; a.partial = scratch;
-        a.B = B; a.Cin = Cin; a.Cout = Cout; a.K = K; a.dil = dil; a.pad = pad; a.T = T; a.T_in = T_in; a.pro = pro;
-        a.pro_param = pro_param;
-        a.n_chunks_t = (T + WGB_KT - 1) / WGB_KT;
-        a.chunks_per_slice = (B * a.n_chunks_t + S - 1) / S;
-        a.ci_tiles = (Cin + 63) / 64;
-        dim3 grid(a.ci_tiles, (Cout + 127) / 128, S);
-        if (dtype == SET_DTYPE_BF16) hipLaunchKernelGGL((conv1d_wgrad3_bf16_kernel<false>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv1d_wgrad3_bf16_kernel<true>), grid, dim3(256), 0, s, a);
-        const int rc = set_check_launch("set_conv1d_wgrad_det(bf16, 3 taps)");
-        if (rc != SET_OK) return rc;
-    } else if (dtype != SET_DTYPE_F32) {
-        S = wgrad_bf16_slices(B, Cin, Cout, K, T);
+    if (dtype != SET_DTYPE_F32) {
         SET_REQUIRE(dtype == SET_DTYPE_BF16 || dtype == SET_DTYPE_BF16_G16 || dtype == SET_DTYPE_BF16_G16_X16, "set_conv1d_wgrad_det (dtype)");
         SET_REQUIRE(dtype != SET_DTYPE_BF16_G16_X16 || (chan_add == nullptr && pro == SET_PRO_NONE), "set_conv1d_wgrad_det (bf16 x takes no prologue)");
-        WgradBf16Args a;
-        a.g = g; a.x = x; a.chan_add = chan_add; a.partial = scratch;
-        a.B = B; a.Cin = Cin; a.Cout = Cout; a.K = K; a.dil = dil; a.pad = pad; a.T = T; a.T_in = T_in; a.pro = pro;
-        a.pro_param = pro_param;
-        a.n_chunks_t = (T + WGB_KT - 1) / WGB_KT;
-        const int total_chunks = B * a.n_chunks_t;
-        a.chunks_per_slice = (total_chunks + S - 1) / S;
-        a.ci_tiles = (Cin + 127) / 128;
-        dim3 grid(K * a.ci_tiles, (Cout + 127) / 128, S);
-        if (dtype == SET_DTYPE_BF16) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<false, false>), grid, dim3(256), 0, s, a);
-        else if (dtype == SET_DTYPE_BF16_G16) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, false>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, true>), grid, dim3(256), 0, s, a);
-        const int rc = set_check_launch("set_conv1d_wgrad_det(bf16)");
-        if (rc != SET_OK) return rc;
-    } else {
-        const int rc = launch_wgrad_f32_partial(reinterpret_cast<const float *>(g), reinterpret_cast<const float *>(x), chan_add,
-                                                scratch, B, Cin, Cout, K, dil, pad, T, T_in, pro, pro_param, s);
-        if (rc != SET_OK) return rc;
+        return wgrad_bf16_launch(g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro, pro_param, dtype, scratch, 1, 0, 0, 0, 0,
+                                 wgrad_bf16_slices(B, Cin, Cout, K, T), wgrad_bf16_slices(B, Cin, Cout, K, T, true), s);
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, s, scratch, dw, n, S);
+    const int S = (int)(need / n);
+    const int rc = launch_wgrad_f32_partial(reinterpret_cast<const float *>(g), reinterpret_cast<const float *>(x), chan_add,
+                                            scratch, B, Cin, Cout, K, dil, pad, T, T_in, pro, pro_param, s);
+    if (rc != SET_OK) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(set_blocks(n, 256), 1), dim3(256), 0, s, scratch, dw, n, S, (int64_t)0);
     return set_check_launch("set_conv1d_wgrad_det(reduce)");
+}
+
+extern "C" int set_conv1d_wgrad_det_grouped(const void *g, const void *x, const float *chan_add, float *dw, int32_t groups,
+                                            int64_t g_gs, int64_t x_gs, int64_t add_gs, int64_t dw_gs, int32_t B, int32_t Cin,
+                                            int32_t Cout, int32_t K, int32_t dil, int32_t pad, int32_t T, int32_t T_in, int32_t dtype,
+                                            float *scratch, int64_t scratch_floats, void *stream) {
+    SET_REQUIRE(g && x && dw && scratch && groups > 0 && B > 0 && Cin > 0 && Cout > 0 && K > 0 && T > 0 && T_in > 0,
+                "set_conv1d_wgrad_det_grouped");
+    SET_REQUIRE(dtype == SET_DTYPE_BF16 || dtype == SET_DTYPE_BF16_G16 || dtype == SET_DTYPE_BF16_G16_X16, "set_conv1d_wgrad_det_grouped (dtype)");
+    SET_REQUIRE(dtype != SET_DTYPE_BF16_G16_X16 || chan_add == nullptr, "set_conv1d_wgrad_det_grouped (bf16 x takes no per-channel add)");
+    SET_REQUIRE(scratch_floats >= set_conv1d_wgrad_grouped_scratch_floats(groups, B, Cin, Cout, K, T), "set_conv1d_wgrad_det_grouped (scratch too small)");
+    SET_REQUIRE((int64_t)Cout * T * 4 < ((int64_t)1 << 31) && (int64_t)Cin * T_in * 4 < ((int64_t)1 << 31),
+                "set_conv1d_wgrad_det_grouped (one batch slice exceeds 2 GiB)");
+    const int S1 = wgrad_bf16_slices_grouped(B, Cin, Cout, K, T, false, groups), S3 = wgrad_bf16_slices_grouped(B, Cin, Cout, K, T, true, groups);
+    SET_REQUIRE((int64_t)groups * (S1 > S3 ? S1 : S3) <= 65535, "set_conv1d_wgrad_det_grouped (grid.z)");
+    return wgrad_bf16_launch(g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, SET_PRO_NONE, 0.0f, dtype, scratch, groups, g_gs, x_gs,
+                             add_gs, dw_gs, S1, S3, (hipStream_t)stream);
 }
