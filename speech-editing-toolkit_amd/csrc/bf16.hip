@@ -14,6 +14,8 @@
 // MFMA operand maps (32x32x16, cdna_hip_programming.md section 3): lane l holds A[i = l & 31][k = 8*(l>>5) .. +7] and
 // B[k = 8*(l>>5) .. +7][j = l & 31] as 8 consecutive bf16 (one 16-byte LDS read); C/D as the f32 32x32 MFMA.  A and B use
 // the SAME lane -> k map, so the contraction is right for any permutation of k the hardware applies inside an instruction.
+#include <stdlib.h>
+
 #include "common.h"
 #include <type_traits>
 
@@ -695,7 +697,11 @@ static int wgrad_bf16_slices_grouped(int B, int Cin, int Cout, int K, int T, boo
     const int n_chunks_t = (T + WGB_KT - 1) / WGB_KT;
     const int64_t total_chunks = (int64_t)B * n_chunks_t;
     const int64_t tiles = (int64_t)groups * (taps3 ? ((Cin + 63) / 64) * ((Cout + 127) / 128) : K * ((Cin + 127) / 128) * ((Cout + 127) / 128));
-    int64_t S = (640 + tiles - 1) / tiles;  // ~2.5 blocks per CU
+    // blocks of a grouped launch are long (each walks 1 / S of ALL frames): aim at ~2.5 full waves of the chip's 512 block slots,
+    // not at the 2.5 blocks per CU of a single GEMM (measured, ms per bf16 training step: 640 blocks 15.75, 1280 15.16, 2048 15.29, 4096 15.39)
+    static int target = 0;
+    if (!target) { const char *e = getenv("SET_AMD_WGRAD_GROUP_BLOCKS"); target = e && atoi(e) > 0 ? atoi(e) : 1280; }
+    int64_t S = (target + tiles - 1) / tiles;
     if (S > total_chunks) S = total_chunks;
     if (S > (taps3 ? 32 : 64)) S = taps3 ? 32 : 64;
     if (S < 1) S = 1;
