@@ -495,6 +495,10 @@ int set_debug_split_phase_buffer(uint64_t *buf);
 /* debug: lane 0 of block 0 of the split-operand stack kernel adds the s_memtime ticks of its phases (claim + wait, stage,
  * GEMM 1, gate, GEMM 2, epilogue + publish), summed over its tasks, to buf[0..5] and its task count to buf[7] */
 int set_debug_x3_phase_buffer(uint64_t *buf);
+/* debug: thread 0 of every 16th block of batch row 1 of the fused ResBlock-pair kernel adds the s_memtime ticks of its phases (x
+ * chunk wait + split, GEMM 1 issue, GEMM 1 drain + epilogue 1, GEMM 2 issue, GEMM 2 drain + epilogue 2) to buf[0..4], block count
+ * to buf[7] */
+int set_debug_resblock_phase_buffer(uint64_t *buf);
 
 typedef struct SetDiffnetLayerBf16BwdArgs {
     const float *dx_out; /* [B][256][T] gradient w.r.t. x_out; NULL = zero (the last layer's x_out feeds nothing) */

@@ -259,6 +259,7 @@ SIGNATURES = {
     "set_debug_bf16_phase_buffer": (C.c_int, [_V]),
     "set_debug_split_phase_buffer": (C.c_int, [_V]),
     "set_debug_x3_phase_buffer": (C.c_int, [_V]),
+    "set_debug_resblock_phase_buffer": (C.c_int, [_V]),
     "set_sizeof_diffnet_layer_bf16_bwd_args": (_I64, []),
     "set_diffnet_layer_bwd_bf16_tiles": (_I32, [_I32, _I32]),
     "set_diffnet_layer_bwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayerBf16BwdArgs), _V]),

@@ -248,6 +248,27 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
                             for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] * inv_scale + bias;
                             buf_store4(o, d_o, (unsigned)(co * (int)a.out_cs + n0) * 4u, 0u);
                         }
+                    } else if (ph_u == 2) {
+                        // stride 2: registers 4 g + {0, 1} are the two phases of channel co at frame t -> one 8-byte store (a wave
+                        // then writes 64 consecutive samples of a channel instead of every other one), {2, 3} those of co + 1
+                        typedef unsigned cx_u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int c = co + q;
+                            const float be = a.bias ? a.bias[min(c, n_ch - 1)] : 0.0f;
+                            const float v0 = acc[i][j][4 * g + 2 * q] * inv_scale + be, v1 = acc[i][j][4 * g + 2 * q + 1] * inv_scale + be;
+                            const unsigned off = (unsigned)(c * (int)a.out_cs + n0) * 4u;
+                            if (t < a.T_iter && c < n_ch) {
+                                if (n0 >= 0 && n0 + 1 < a.T_out) {
+                                    cx_u32x2 o;
+                                    o[0] = __builtin_bit_cast(unsigned, v0); o[1] = __builtin_bit_cast(unsigned, v1);
+                                    __builtin_amdgcn_raw_buffer_store_b64(o, d_o, (int)off, 0, 0);
+                                } else {
+                                    if (n0 >= 0 && n0 < a.T_out) buf_store(v0, d_o, off, 0u);
+                                    if (n0 + 1 >= 0 && n0 + 1 < a.T_out) buf_store(v1, d_o, off + 4u, 0u);
+                                }
+                            }
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {

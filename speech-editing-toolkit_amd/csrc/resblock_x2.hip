@@ -18,6 +18,14 @@
 // The k-step order of both GEMMs is the one of conv1d_x2_kernel (chunk, tap, half-chunk; pieces a1 b0, a0 b1, a0 b0) and the
 // intermediate takes the same fp32 value before it is split, so the fused pair is BIT-IDENTICAL to the two launches it
 // replaces (tests/test_gpu_x2conv.py::test_fused_resblock_pair_equals_two_convs).
+// Measured and dropped (round 3): the residual x of epilogue 2 fetched before GEMM 2 (epilogue 2 is 43 - 55 % of a 32- / 64-channel
+// block's life, tools/resblock_phase_probe.py): same-box A/B of the V1 stages 3.96 -> 3.94 ms (C = 32, k = 3), 4.99 -> 5.15 (C = 64),
+// the 64 extra live registers cost the wider shapes more than the earlier issue gains -- the blocks wait on memory THROUGHPUT
+// (2.6 - 3.8 TB/s of dword-per-lane accesses), not on the position of the loads.
+// Measured and dropped (round 3): 128-frame tiles for the 32- / 64-channel shapes (124 / 156 registers: 4 / 3 blocks per CU instead of
+// 3 / 2): same-box A/B of the V1 stages 3.9 -> 4.2 ms (C = 32, k = 3), 6.3 -> 7.6 (k = 11), 10.2 -> 12.0 (C = 64, k = 11).  A plain copy
+// of the same row tiles runs at 5.7 TB/s (tools/hw/rowtile_copy.hip; 0.59 ms per 32-channel pair against 1.3 - 1.5 ms here): the
+// phases of a block (x round trip, GEMM 1, LDS tile, GEMM 2, residual round trip) add up, and co-resident blocks hide little of it.
 // Measured and dropped (round 3): a persistent variant (blocks walk tiles; the next tile's first x chunk is fetched as soon as the
 // chunk registers are free, under phase 1's MFMAs / epilogue 1 / phase 2 / epilogue 2).  The 48 chunk registers then live across
 // the whole tile: 55 - 84 spilled VGPRs for the 64- / 128- / 256-channel shapes, occupancy 3 -> 2 for the 32-channel one, and the
@@ -33,6 +41,9 @@ typedef unsigned rp_u32x2 __attribute__((ext_vector_type(2)));
 // (device symbols do not link across translation units without -fgpu-rdc: this file keeps its own sticky range word, and
 // set_conv_x2_range_flag (csrc/conv_x2.hip) reads both through set_resblock_pair_range_flag_)
 __device__ int g_rp_range_flag = 0;
+// debug, builds with -DSET_RP_PROBE only (tools/resblock_phase_probe.py): thread 0 of every 16th block of batch row 1 adds the
+// s_memtime ticks of its phases to buf[0..4] and counts itself in buf[7], see set_debug_resblock_phase_buffer
+__device__ uint64_t *g_rp_phase_buf = nullptr;
 
 namespace {
 
@@ -78,6 +89,20 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_x2_kernel(SetResblockPai
     const rsrc_t d_x = make_rsrc(xb);
     const unsigned lane16 = 16u * (unsigned)lane;
     const int rb_first = wm * RBW;
+#ifdef SET_RP_PROBE
+    uint64_t *const pbuf = g_rp_phase_buf;
+    const bool probe = pbuf != nullptr && tid == 0 && blockIdx.y == 1 && (blockIdx.x & 15) == 1;
+    uint64_t tprev = probe ? __builtin_amdgcn_s_memtime() : 0;
+    auto stamp = [&](int k) {
+        if (probe) {
+            const uint64_t t = __builtin_amdgcn_s_memtime();
+            atomicAdd(reinterpret_cast<unsigned long long *>(pbuf + k), (unsigned long long)(t - tprev));
+            tprev = t;
+        }
+    };
+#else
+    auto stamp = [](int) {};
+#endif
 
     f32x16 acc[RBW][NCB];
 #pragma unroll
@@ -160,6 +185,7 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_x2_kernel(SetResblockPai
             __syncthreads();  // MFMAs of the previous chunk are done with the tile
             commit_b(c * RP_KCH);
             __syncthreads();
+            stamp(0);  // wait for the chunk's loads + convert + LDS write
             if (c + 1 < nchunks) issue_b((c + 1) * RP_KCH);
             for (int tap = 0; tap < K; ++tap) {
                 const int off = tap * a.dil;  // frame-row shift of this tap inside the chunk tile
@@ -191,6 +217,7 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_x2_kernel(SetResblockPai
                     __builtin_amdgcn_s_setprio(0);
                 }
             }
+            stamp(1);  // GEMM 1 of the chunk issued
         }
     }
     // the first fragments of W2 fly under epilogue 1
@@ -240,6 +267,7 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_x2_kernel(SetResblockPai
     }
     if (!(amax < 32768.0f)) __hip_atomic_store(&g_rp_range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    stamp(2);  // GEMM 1 drained + epilogue 1
 
     // =========================== phase 2: y = W2 (*) t ============================================================
     for (int c = 0; c < nchunks; ++c) {
@@ -274,6 +302,7 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_x2_kernel(SetResblockPai
         }
     }
 
+    stamp(3);  // GEMM 2 issued
     // ---- epilogue 2 (fp32): y = ((acc / s2 + b2) + x) (+ previous output) (/ out_div) on the NV central columns ----
     const bool has_acc = a.accumulate != 0, has_div = has_acc && a.out_div != 0.0f;
     const rsrc_t d_out = make_rsrc(a.out + (int64_t)b * a.out_bs);
@@ -313,6 +342,10 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_x2_kernel(SetResblockPai
             }
         }
     }
+    stamp(4);  // GEMM 2 drained + epilogue 2 (residual / accumulate loads, stores issued)
+#ifdef SET_RP_PROBE
+    if (probe) atomicAdd(reinterpret_cast<unsigned long long *>(pbuf + 7), 1ull);
+#endif
 }
 
 template <int WM, int WN, int RBW, int NCB>
@@ -346,6 +379,14 @@ int set_resblock_pair_range_flag_(int *flag, int reset) {
         const int z = 0;
         SET_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rp_range_flag), &z, sizeof(int)), "set_conv_x2_range_flag");
     }
+    return SET_OK;
+}
+
+extern "C" int set_debug_resblock_phase_buffer(uint64_t *buf) {
+#ifndef SET_RP_PROBE
+    if (buf) return set_fail(SET_E_UNSUPPORTED, "set_debug_resblock_phase_buffer", "library built without -DSET_RP_PROBE");
+#endif
+    SET_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rp_phase_buf), &buf, sizeof(buf)), "set_debug_resblock_phase_buffer");
     return SET_OK;
 }
 
