@@ -612,6 +612,141 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad3_bf16_kernel(WgradBf16Arg
         }
 }
 
+// ---- K-tap weight gradient (odd K <= 9, dilation 1, "same" padding) with all taps in one block --------------------------------
+// The FFN convs of the FFT blocks / CampNet layers are 9-tap convs (192 -> 768 at 12,800 frames, 256 -> 1024 at 25,600): with one
+// tap per block the output gradient G is re-read K x (ci tiles) times and the conv input X K x (co tiles) times -- the blocks
+// waited on operand loads (118 - 188 TFLOP/s against 330 - 440 of the forward kernel, tools/small_conv_probe.py).
+// Here a block owns a 64 (co) x 64 (ci) tile of dW for ALL K taps (wave: 32 x 32 x K = K accumulators).  Per 64-frame chunk G is
+// staged once and X once with 8 halo frames on either side; the taps are K views of the SAME LDS rows shifted by one frame each.
+// A shifted view is not 16-byte aligned, so a lane reads the three aligned 8-frame groups around its k-group once and cuts the K
+// windows out of those 12 registers (even shifts: a register renaming; odd shifts: 4 v_alignbit).  Operand traffic per chunk:
+// (64 + 64 rows) x 64 frames for 36 MFMAs per wave instead of 4.
+constexpr int WGT_XF = WGB_KT + 16;         // frames of an X row: chunk + 8 halo frames on either side
+constexpr int WGT_XROWB = WGT_XF * 2 + 16;  // 176 bytes: conflict-free 16-byte reads (44 dwords per row)
+
+template <int O>
+__device__ __forceinline__ u32x4 wgt_window(const u32x4 (&W)[3]) {  // 8 bf16 starting at element O of the 24 in W
+    unsigned w[12];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[4 * g + e] = W[g][e];
+    u32x4 o;
+    if constexpr (O % 2 == 0) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] = w[O / 2 + d];
+    } else {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_alignbit(w[(O - 1) / 2 + d + 1], w[(O - 1) / 2 + d], 16);
+    }
+    return o;
+}
+
+template <int K, int TAP = 0>
+__device__ __forceinline__ void wgt_taps(f32x16 (&acc)[K], u32x4 av, const u32x4 (&W)[3]) {
+    if constexpr (TAP < K) {
+        acc[TAP] = mfma_bf16(av, wgt_window<8 + TAP - (K - 1) / 2>(W), acc[TAP]);
+        wgt_taps<K, TAP + 1>(acc, av, W);
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256, 2) conv1d_wgrad_taps_bf16_kernel(WgradBf16Args a) {
+    constexpr int PAD = (K - 1) / 2;
+    __shared__ __attribute__((aligned(16))) unsigned char Gs[64 * WGB_ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[64 * WGT_XROWB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+    const int total_chunks = a.B * a.n_chunks_t;
+    const int c_begin = blockIdx.z * a.chunks_per_slice;
+    const int c_end = min(c_begin + a.chunks_per_slice, total_chunks);
+
+    f32x16 acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = (f32x16){0};
+
+    // staging (one chunk ahead, raw fp32 bits in registers): G rows wave, wave + 4, ... x frame t0 + lane; X the same rows x frame
+    // t0 - 8 + lane, and the 16 frames t0 + 56 .. t0 + 71 of row tid >> 2 (4 frames per thread)
+    unsigned gv[16], xv[16], xe[4];
+    const int er = tid >> 2, ef = (tid & 3) * 4;
+    auto issue = [&](int ch) {
+        const int b = ch / a.n_chunks_t, t0 = (ch % a.n_chunks_t) * WGB_KT;
+        const rsrc_t d_g = make_rsrc(reinterpret_cast<const float *>(a.g) + (int64_t)b * a.Cout * a.T);
+        const rsrc_t d_x = make_rsrc(reinterpret_cast<const float *>(a.x) + (int64_t)b * a.Cin * a.T_in);
+        const unsigned vg = (unsigned)min(t0 + lane, a.T - 1) * 4u;
+        const unsigned vx = (unsigned)min(max(t0 - 8 + lane, 0), a.T_in - 1) * 4u;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gv[j] = buf_load_raw(d_g, vg, (unsigned)(min(co0 + wave + 4 * j, a.Cout - 1) * a.T) * 4u);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xv[j] = buf_load_raw(d_x, vx, (unsigned)(min(ci0 + wave + 4 * j, a.Cin - 1) * a.T_in) * 4u);
+        const unsigned ro = (unsigned)(min(ci0 + er, a.Cin - 1) * a.T_in) * 4u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xe[e] = buf_load_raw(d_x, ro + (unsigned)min(max(t0 + 56 + ef + e, 0), a.T_in - 1) * 4u, 0u);
+    };
+    auto commit = [&](auto PROC, int ch) __attribute__((always_inline)) {
+        constexpr int kPro = decltype(PROC)::value;
+        const int t0 = (ch % a.n_chunks_t) * WGB_KT;
+        const bool tv = t0 + lane < a.T, xvld = t0 - 8 + lane >= 0 && t0 - 8 + lane < a.T_in;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = wave + 4 * j;
+            const unsigned short gb = bf16_bits(__builtin_bit_cast(float, gv[j]));
+            const unsigned short xb = bf16_bits(pro_c<kPro>(__builtin_bit_cast(float, xv[j]), a.pro_param));
+            *reinterpret_cast<unsigned short *>(Gs + row * WGB_ROWB + lane * 2) = (tv && co0 + row < a.Cout) ? gb : (unsigned short)0;
+            *reinterpret_cast<unsigned short *>(Xs + row * WGT_XROWB + lane * 2) = (xvld && ci0 + row < a.Cin) ? xb : (unsigned short)0;
+        }
+        unsigned short q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ti = t0 + 56 + ef + e;
+            const unsigned short xb = bf16_bits(pro_c<kPro>(__builtin_bit_cast(float, xe[e]), a.pro_param));
+            q[e] = (ti >= 0 && ti < a.T_in && ci0 + er < a.Cin) ? xb : (unsigned short)0;
+        }
+        typedef unsigned wgt_u32x2 __attribute__((ext_vector_type(2)));
+        wgt_u32x2 u;
+        u[0] = (unsigned)q[0] | ((unsigned)q[1] << 16); u[1] = (unsigned)q[2] | ((unsigned)q[3] << 16);
+        *reinterpret_cast<wgt_u32x2 *>(Xs + er * WGT_XROWB + (64 + ef) * 2) = u;
+    };
+    if (c_begin < c_end) issue(c_begin);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        __syncthreads();
+        switch (a.pro) {
+            case SET_PRO_LRELU: commit(ic<SET_PRO_LRELU>{}, ch); break;
+            case SET_PRO_DIV: commit(ic<SET_PRO_DIV>{}, ch); break;
+            default: commit(ic<SET_PRO_NONE>{}, ch); break;
+        }
+        __syncthreads();
+        if (ch + 1 < c_end) issue(ch + 1);
+        // X row element e <-> frame t0 - 8 + e; the lane's k-group of G covers frames t0 + 16 ks + 8 half + (0 .. 7), tap `tap` pairs
+        // them with X frames shifted by tap - PAD: elements 16 ks + 8 half + 8 + tap - PAD + (0 .. 7) -> offset 8 + tap - PAD in W
+        const unsigned char *ap = Gs + (wm * 32 + l31) * WGB_ROWB + half * 16;
+        const unsigned char *bp = Xs + (wn * 32 + l31) * WGT_XROWB + half * 16;
+#pragma unroll
+        for (int ks = 0; ks < WGB_KT / 16; ++ks) {
+            const u32x4 av = *reinterpret_cast<const u32x4 *>(ap + ks * 32);
+            u32x4 W[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) W[g] = *reinterpret_cast<const u32x4 *>(bp + ks * 32 + g * 16);
+            wgt_taps<K>(acc, av, W);
+        }
+    }
+    // partial tile of this slice (zeros for an empty slice): K consecutive floats per (co, ci)
+    float *pz = a.partial + (int64_t)blockIdx.z * a.Cout * a.Cin * K;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 32 + mfma32_row(r, lane);
+        const int ci = ci0 + wn * 32 + l31;
+        if (co < a.Cout && ci < a.Cin) {
+            float *o = pz + ((int64_t)co * a.Cin + ci) * K;
+#pragma unroll
+            for (int k = 0; k < K; ++k) o[k] = acc[k][r];
+        }
+    }
+}
+
 // dw[i] += sum_{s < S} partial[s][i]   (slice order: the sum has one fixed association)
 // (grid.y = group: partial[(group * S + z) * n + i], dw + group * dw_gs)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *partial, float *dw, int64_t n, int S, int64_t dw_gs) {
@@ -692,6 +827,25 @@ static int wgrad_bf16_slices(int B, int Cin, int Cout, int K, int T, bool taps3 
     return (int)((total_chunks + cps - 1) / cps);  // no empty slices
 }
 
+// all-taps kernel (conv1d_wgrad_taps_bf16_kernel): odd 5 <= K <= 9, dilation 1, "same" padding, fp32 operands, no per-channel add
+static bool wgrad_taps_applies(int K, int dil, int pad, int dtype, bool chan_add) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("SET_AMD_WGRAD_TAPS"); on = !(e && atoi(e) == 0); }
+    return on && dtype == SET_DTYPE_BF16 && !chan_add && (K == 5 || K == 7 || K == 9) && dil == 1 && pad == (K - 1) / 2;
+}
+static int wgrad_taps_slices(int B, int Cin, int Cout, int T) {
+    const int64_t total_chunks = (int64_t)B * ((T + WGB_KT - 1) / WGB_KT);
+    const int tiles = ((Cin + 63) / 64) * ((Cout + 63) / 64);
+    static int target = 0;
+    if (!target) { const char *e = getenv("SET_AMD_WGRAD_TAPS_BLOCKS"); target = e && atoi(e) > 0 ? atoi(e) : 512; }
+    int64_t S = (target + tiles - 1) / tiles;  // two blocks per CU; every slice costs a K-tap partial image (write + read)
+    if (S > total_chunks) S = total_chunks;
+    if (S > 16) S = 16;
+    if (S < 1) S = 1;
+    const int64_t cps = (total_chunks + S - 1) / S;
+    return (int)((total_chunks + cps - 1) / cps);  // no empty slices
+}
+
 // slices per group of a launch over `groups` equal GEMMs: with many groups a few slices fill the chip
 static int wgrad_bf16_slices_grouped(int B, int Cin, int Cout, int K, int T, bool taps3, int groups) {
     const int n_chunks_t = (T + WGB_KT - 1) / WGB_KT;
@@ -713,6 +867,7 @@ extern "C" int64_t set_conv1d_wgrad_scratch_floats(int32_t B, int32_t Cin, int32
     // upper bound over the kernel variants of the dtype (the 3-tap variant is chosen from dil / pad / pro at call time)
     int S = dtype != SET_DTYPE_F32 ? wgrad_bf16_slices(B, Cin, Cout, K, T) : wgrad_f32_slices(B, Cin, Cout, K, T);
     if (dtype != SET_DTYPE_F32 && K == 3) { const int S3 = wgrad_bf16_slices(B, Cin, Cout, K, T, true); S = S3 > S ? S3 : S; }
+    if (dtype == SET_DTYPE_BF16 && (K == 5 || K == 7 || K == 9)) { const int St = wgrad_taps_slices(B, Cin, Cout, T); S = St > S ? St : S; }
     return (int64_t)S * Cout * Cin * K;
 }
 
@@ -737,7 +892,18 @@ static int wgrad_bf16_launch(const void *g, const void *x, const float *chan_add
     a.n_chunks_t = (T + WGB_KT - 1) / WGB_KT;
     a.g_gs = g_gs * (g16 ? 2 : 4); a.x_gs = x_gs * (x16 ? 2 : 4); a.add_gs = add_gs;
     int S;
-    if (wgrad3_applies(K, dil, pad, pro, dtype)) {
+    if (groups == 1 && wgrad_taps_applies(K, dil, pad, dtype, chan_add != nullptr)) {
+        S = wgrad_taps_slices(B, Cin, Cout, T);
+        a.S = S;
+        a.chunks_per_slice = (B * a.n_chunks_t + S - 1) / S;
+        a.ci_tiles = (Cin + 63) / 64;
+        dim3 grid(a.ci_tiles, (Cout + 63) / 64, S);
+        if (K == 9) hipLaunchKernelGGL((conv1d_wgrad_taps_bf16_kernel<9>), grid, dim3(256), 0, s, a);
+        else if (K == 7) hipLaunchKernelGGL((conv1d_wgrad_taps_bf16_kernel<7>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv1d_wgrad_taps_bf16_kernel<5>), grid, dim3(256), 0, s, a);
+        const int rc = set_check_launch("set_conv1d_wgrad_det(bf16, all taps)");
+        if (rc != SET_OK) return rc;
+    } else if (wgrad3_applies(K, dil, pad, pro, dtype)) {
         S = S_taps3;
         a.S = S;
         a.chunks_per_slice = (B * a.n_chunks_t + S - 1) / S;

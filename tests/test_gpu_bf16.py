@@ -163,6 +163,47 @@ def test_conv1d_bf16_backward_equals_rounded_operand_gradients(dev, case, bf16):
     assert _rel(d[2].grad, gg.sum((0, 2))) < 2e-5
 
 
+TAPS_CASES = [
+    # B, Cin, Cout, K, T, prologue: the all-taps weight-gradient kernel (odd 5 <= K <= 9, dilation 1, "same" padding)
+    (2, 192, 768, 9, 800, None),           # CampNet FFN conv
+    (3, 100, 200, 9, 333, None),           # ragged channels (partial 64-row tiles), ragged T, chunks that straddle nothing
+    (2, 80, 130, 5, 150, ("lrelu", 0.1)),  # 5 taps, prologue on the conv input
+    (2, 64, 64, 7, 65, ("div", 3.0)),      # 7 taps, a second chunk of one frame
+    (1, 256, 1024, 9, 64, None),           # exactly one chunk: every halo frame is padding
+]
+
+
+@pytest.mark.parametrize("case", TAPS_CASES)
+def test_wgrad_all_taps_kernel_equals_rounded_operand_products(dev, case, monkeypatch):
+    """dW[co][ci][k] = sum_{b,t} r(G[b][co][t]) r(P(X[b][ci][t + k - pad])) with zero padding: every tap of the 64 x 64 tile comes
+    from shifted views of one staged X row (csrc/bf16.hip: conv1d_wgrad_taps_bf16_kernel); also against the one-tap-per-block kernel
+    (same products, another summation order) and bit-stable from run to run."""
+    from set_amd import _lib, autograd_ops as A
+    B, Cin, Cout, K, T, pro = case
+    g = torch.Generator().manual_seed(Cin + Cout + K + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    gy = torch.randn(B, Cout, T, generator=g)
+    pad = (K - 1) // 2
+    xin = x
+    code, param = 0, 0.0
+    if pro is not None:
+        code, param = _lib.PRO[pro[0]], pro[1]
+        xin = F.leaky_relu(x, param) if pro[0] == "lrelu" else x / param
+    xp = F.pad(_r(xin), (pad, pad))
+    want = torch.stack([torch.einsum("bot,bit->oi", _r(gy), xp[:, :, k:k + T]) for k in range(K)], dim=-1)
+    xd, gd = x.to(dev), gy.to(dev)
+    outs = []
+    for _ in range(2):
+        dw = torch.zeros(Cout, Cin, K, device=dev)
+        A.conv_wgrad(gd, xd, None, dw, B, Cin, Cout, K, 1, pad, T, T, code, param, dtype=_lib.DTYPE_BF16)
+        outs.append(dw)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert _rel(outs[0], want) < 2e-5
+    A.conv_wgrad(gd, xd, None, outs[1], B, Cin, Cout, K, 1, pad, T, T, code, param, dtype=_lib.DTYPE_BF16)  # adds on top
+    assert _rel(outs[1], 2 * want) < 2e-5
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_deterministic_wgrad_is_bit_stable_and_matches_the_atomic_kernel(dev, dtype):
     from set_amd import _lib, autograd_ops as A, ops
