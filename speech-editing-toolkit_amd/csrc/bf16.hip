@@ -747,15 +747,23 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_taps_bf16_kernel(WgradBf1
     }
 }
 
-// dw[i] += sum_{s < S} partial[s][i]   (slice order: the sum has one fixed association)
+// dw[i] += sum_{s < S} partial[s][i]   (one fixed association: four interleaved chains over the slices, combined pairwise -- four
+// loads in flight per thread instead of one dependent add per memory round trip)
 // (grid.y = group: partial[(group * S + z) * n + i], dw + group * dw_gs)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *partial, float *dw, int64_t n, int S, int64_t dw_gs) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float *pp = partial + (int64_t)blockIdx.y * S * n;
-    float s = 0.0f;
-    for (int z = 0; z < S; ++z) s += pp[(int64_t)z * n + i];
-    dw[(int64_t)blockIdx.y * dw_gs + i] += s;
+    const float *pp = partial + (int64_t)blockIdx.y * S * n + i;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int z = 0;
+    for (; z + 3 < S; z += 4) {
+        s0 += pp[(int64_t)z * n];
+        s1 += pp[(int64_t)(z + 1) * n];
+        s2 += pp[(int64_t)(z + 2) * n];
+        s3 += pp[(int64_t)(z + 3) * n];
+    }
+    for (; z < S; ++z) s0 += pp[(int64_t)z * n];
+    dw[(int64_t)blockIdx.y * dw_gs + i] += (s0 + s1) + (s2 + s3);
 }
 
 }  // namespace
@@ -796,7 +804,10 @@ int set_conv1d_bf16_dispatch(const SetConv1dArgs &a, hipStream_t s) {
     if (((int64_t)round_up_i(a.Cout, 128) * cs + a.T_out) * 4 >= ((int64_t)1 << 31) ||
         ((int64_t)a.Cin * a.in_cs + a.T_in) * 4 >= ((int64_t)1 << 31))
         return set_fail(SET_E_UNSUPPORTED, "set_conv1d(bf16)", "one batch slice of in / out / res exceeds 2 GiB");
-    const bool narrow = a.Cout <= 64 || (a.Cout > 128 && a.Cout <= 192);  // 64-row blocks waste less than 128-row ones
+    // 64-row blocks waste less than 128-row ones on 129 .. 192 rows -- but they read the input once more, and the 1x1 convs of
+    // that height (CampNet's 192-channel projections at 12,800 frames) wait on their input, not on MFMAs: 27 -> 22 us (192 -> 192),
+    // 56 -> 45 us (768 -> 192) with 128-row blocks; the 9-tap convs keep the 64-row ones (146 vs 149 us)
+    const bool narrow = a.Cout <= 64 || (a.Cout > 128 && a.Cout <= 192 && a.K > 1);
     if (a.K == 1 && a.Cin > 32 && halo == 0 && !a.in_chan_add) {
         return narrow ? launch_conv_bf16<1, 4, 64, 1, false, false>(a, lo, halo, s)
                       : launch_conv_bf16<2, 2, 64, 1, false, false>(a, lo, halo, s);

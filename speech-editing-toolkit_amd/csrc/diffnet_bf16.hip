@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "rows_sum.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -592,53 +593,43 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffn
     }
 }
 
-// out[g][j] (+)= scale * sum_r part[(g * rows + r) * cols + j].  Block = 64 columns x 4 row groups: thread (j, rg) adds rows
-// rg, rg + 4, ... in order, the four group sums are combined in group order -> one fixed association, deterministic.
-__global__ void __launch_bounds__(256) partial_rows_sum_kernel(const float *part, float *out, int rows, int cols,
-                                                               int accumulate, float scale) {
-    __shared__ float red[4][64];
+// out[g][j] (+)= scale * sum_r part[(g * rows + r) * cols + j].  Block = 64 columns x ROWS_RG row groups, one fixed association
+// (rows_sum.h): deterministic.
+__global__ void __launch_bounds__(64 * ROWS_RG) partial_rows_sum_kernel(const float *part, float *out, int rows, int cols,
+                                                                        int accumulate, float scale) {
+    __shared__ float red[ROWS_RG][64];
     const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + tl, g = blockIdx.y;
-    float s = 0.0f;
-    if (j < cols)
-        for (int r = rg; r < rows; r += 4) s += part[((int64_t)g * rows + r) * cols + j];
-    red[rg][tl] = s;
-    __syncthreads();
+    float s = j < cols ? rows_sum_chains(part + (int64_t)g * rows * cols + j, cols, rg, rows) : 0.0f;
+    s = rows_sum_groups(s, red, rg, tl) * scale;
     if (rg == 0 && j < cols) {
-        s = (((red[0][tl] + red[1][tl]) + red[2][tl]) + red[3][tl]) * scale;
         float *o = out + (int64_t)g * cols + j;
         *o = accumulate ? *o + s : s;
     }
 }
 
-// all ordered partial sums of one layer's backward in ONE launch (block = 64 columns x 4 row groups, fixed association):
+// all ordered partial sums of one layer's backward in ONE launch (block = 64 columns x ROWS_RG row groups, fixed association):
 //   columns [0,512): db_out += sum over all rows of part_dbo ; [512,1024): db_dil, db_cond += ... of part_dby ;
 //   [1024,1280): dd[b][c] = sum over the tiles of utterance b of part_dd   (blockIdx.y = b there)
-__global__ void __launch_bounds__(256) layer_bwd_reduce_kernel(const float *pdbo, const float *pdby, const float *pdd, int B,
-                                                               int tiles, float *db_out, float *db_dil, float *db_cond,
-                                                               float *dd, int64_t dd_bs) {
-    __shared__ float red[4][64];
+__global__ void __launch_bounds__(64 * ROWS_RG) layer_bwd_reduce_kernel(const float *pdbo, const float *pdby, const float *pdd, int B,
+                                                                        int tiles, float *db_out, float *db_dil, float *db_cond,
+                                                                        float *dd, int64_t dd_bs) {
+    __shared__ float red[ROWS_RG][64];
     const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int cbk = blockIdx.x;  // 0..7 dbo, 8..15 dby, 16..19 dd
-    float s = 0.0f;
     if (cbk < 16) {
         if (blockIdx.y != 0) return;
         const float *part = cbk < 8 ? pdbo : pdby;
-        const int j = (cbk & 7) * 64 + tl, rows = B * tiles;
-        for (int r = rg; r < rows; r += 4) s += part[(int64_t)r * 2 * FC + j];
-        red[rg][tl] = s;
-        __syncthreads();
+        const int j = (cbk & 7) * 64 + tl;
+        const float s = rows_sum_groups(rows_sum_chains(part + j, 2 * FC, rg, B * tiles), red, rg, tl);
         if (rg == 0) {
-            s = ((red[0][tl] + red[1][tl]) + red[2][tl]) + red[3][tl];
             if (cbk < 8) db_out[j] += s;
             else { db_dil[j] += s; db_cond[j] += s; }
         }
     } else {
         const int b = blockIdx.y, j = (cbk - 16) * 64 + tl;
-        for (int r = rg; r < tiles; r += 4) s += pdd[((int64_t)b * tiles + r) * FC + j];
-        red[rg][tl] = s;
-        __syncthreads();
-        if (rg == 0) dd[(int64_t)b * dd_bs + j] = ((red[0][tl] + red[1][tl]) + red[2][tl]) + red[3][tl];
+        const float s = rows_sum_groups(rows_sum_chains(pdd + (int64_t)b * tiles * FC + j, FC, rg, tiles), red, rg, tl);
+        if (rg == 0) dd[(int64_t)b * dd_bs + j] = s;
     }
 }
 
@@ -717,7 +708,7 @@ extern "C" int set_diffnet_layer_bwd_bf16(const SetDiffnetLayerBf16BwdArgs *args
 extern "C" int set_partial_rows_sum(const float *part, float *out, int32_t groups, int32_t rows, int32_t cols, int32_t accumulate,
                                     float scale, void *stream) {
     SET_REQUIRE(part && out && groups > 0 && rows > 0 && cols > 0, "set_partial_rows_sum");
-    hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((cols + 63) / 64, groups), dim3(256), 0, (hipStream_t)stream, part, out, rows,
+    hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((cols + 63) / 64, groups), dim3(64 * ROWS_RG), 0, (hipStream_t)stream, part, out, rows,
                        cols, accumulate, scale);
     return set_check_launch("set_partial_rows_sum");
 }
@@ -727,7 +718,7 @@ extern "C" int set_diffnet_layer_bwd_reduce(const float *part_dbo, const float *
                                             void *stream) {
     SET_REQUIRE(part_dbo && part_dby && part_dd && db_out && db_dil && db_cond && dd && B > 0 && tiles > 0,
                 "set_diffnet_layer_bwd_reduce");
-    hipLaunchKernelGGL(layer_bwd_reduce_kernel, dim3(20, B), dim3(256), 0, (hipStream_t)stream, part_dbo, part_dby, part_dd, B,
+    hipLaunchKernelGGL(layer_bwd_reduce_kernel, dim3(20, B), dim3(64 * ROWS_RG), 0, (hipStream_t)stream, part_dbo, part_dby, part_dd, B,
                        tiles, db_out, db_dil, db_cond, dd, dd_bs);
     return set_check_launch("set_diffnet_layer_bwd_reduce");
 }

@@ -4,6 +4,7 @@
 // their gradients, fused AdamW and the global grad norm.  Input gradients of convolutions reuse set_conv1d
 // (a convolution with transposed weight addressing and negated dilation/padding).
 #include "common.h"
+#include "rows_sum.h"
 
 namespace {
 
@@ -369,19 +370,15 @@ __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, c
         lnb_emit(dyc * xh, dyc, c, tl, dgamma, dbeta, partial, C);
     }
 }
-// out[j] += sum_r partial[r][j], j < n (= 2C: dgamma then dbeta); block = 64 columns x 4 row groups
-__global__ void __launch_bounds__(256) lnb_partial_sum_kernel(const float *partial, float *dgamma, float *dbeta, int rows,
-                                                              int C) {
-    __shared__ float red[4][64];
+// out[j] += sum_r partial[r][j], j < n (= 2C: dgamma then dbeta); block = 64 columns x ROWS_RG row groups (rows_sum.h)
+__global__ void __launch_bounds__(64 * ROWS_RG) lnb_partial_sum_kernel(const float *partial, float *dgamma, float *dbeta, int rows,
+                                                                       int C) {
+    __shared__ float red[ROWS_RG][64];
     const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + tl, n = 2 * C;
-    float s = 0.0f;
-    if (j < n)
-        for (int r = rg; r < rows; r += 4) s += partial[(int64_t)r * n + j];
-    red[rg][tl] = s;
-    __syncthreads();
+    float s = j < n ? rows_sum_chains(partial + j, n, rg, rows) : 0.0f;
+    s = rows_sum_groups(s, red, rg, tl);
     if (rg == 0 && j < n) {
-        s = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
         if (j < C) dgamma[j] += s; else dbeta[j - C] += s;
     }
 }
@@ -961,7 +958,7 @@ extern "C" int set_layernorm_ch_bwd(const float *x, const float *gamma, const fl
     if (partial) {
         const int rc = set_check_launch("set_layernorm_ch_bwd");
         if (rc) return rc;
-        hipLaunchKernelGGL(lnb_partial_sum_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(lnb_partial_sum_kernel, dim3((2 * C + 63) / 64), dim3(64 * ROWS_RG), 0, (hipStream_t)stream,
                            partial, dgamma, dbeta, tiles * B, C);
     }
     return set_check_launch("set_layernorm_ch_bwd");
