@@ -525,6 +525,17 @@ int set_diffnet_layer_bwd_reduce(const float *part_dbo, const float *part_dby, c
 int set_partial_rows_sum(const float *part, float *out, int32_t groups, int32_t rows, int32_t cols, int32_t accumulate,
                          float scale, void *stream);
 
+/* Every residual layer's diffusion_projection of the step embedding in one launch (reference: modules/speech_editing/spec_denoiser/
+ * diffnet.py:66,72 -- one Linear(C, C) per layer on the [N, C] embedding):  out[n][l*C + co] = b_l[co] + sum_ci W_l[co][ci] h[ci][n]
+ * with h [C][N], W_l = w + l*w_ls ([C][C] row-major), b_l = b + l*b_ls, out [N][L*C].  fp32 FMAs.  C % 64 == 0, N <= 64.
+ * ..._bwd: dh[ci][n] = sum_{l,co} W_l[co][ci] g[n][l*C+co] (partials in scratch, summed in (l, co-quarter) order),
+ * dW_l[co][ci] += sum_n g[n][l*C+co] h[ci][n], db_l[co] += sum_n g[n][l*C+co]; scratch >= set_step_proj_bwd_scratch_floats floats. */
+int set_step_proj_fwd(const float *h, const float *w, int64_t w_ls, const float *b, int64_t b_ls, float *out, int32_t L, int32_t C,
+                      int32_t N, void *stream);
+int64_t set_step_proj_bwd_scratch_floats(int32_t L, int32_t C, int32_t N);
+int set_step_proj_bwd(const float *h, const float *g, const float *w, int64_t w_ls, float *dh, float *dw, int64_t dw_ls, float *db,
+                      int64_t db_ls, float *scratch, int32_t L, int32_t C, int32_t N, void *stream);
+
 /* bf16 weight image for SET_IMPL_BF16: wp[tap][chunk][row][32] bf16, row < Cout rounded up to 128, chunk < ceil(Cin/32),
  * zero padded; ..._size returns the number of bf16 ELEMENTS (2 bytes each). */
 int64_t set_packed_conv_weight_bf16_size(int32_t Cout, int32_t Cin, int32_t K);

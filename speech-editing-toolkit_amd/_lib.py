@@ -264,6 +264,9 @@ SIGNATURES = {
     "set_diffnet_layer_bwd_bf16_tiles": (_I32, [_I32, _I32]),
     "set_diffnet_layer_bwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayerBf16BwdArgs), _V]),
     "set_partial_rows_sum": (C.c_int, [_V, _V, _I32, _I32, _I32, _I32, _F, _V]),
+    "set_step_proj_fwd": (C.c_int, [_V, _V, _I64, _V, _I64, _V, _I32, _I32, _I32, _V]),
+    "set_step_proj_bwd_scratch_floats": (_I64, [_I32, _I32, _I32]),
+    "set_step_proj_bwd": (C.c_int, [_V, _V, _V, _I64, _V, _V, _I64, _V, _I64, _V, _I32, _I32, _I32, _V]),
     "set_diffnet_layer_bwd_reduce": (C.c_int, [_V, _V, _V, _I32, _I32, _V, _V, _V, _V, _I64, _V]),
     "set_channel_sum": (C.c_int, [_V, _V, _I32, _I32, _I32, _V]),
     "set_row_sum": (C.c_int, [_V, _V, _I64, _I32, _F, _V]),

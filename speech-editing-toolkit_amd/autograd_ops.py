@@ -730,6 +730,64 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
         return (None, cur, dcond if need_cond else None, dd, *flat)
 
 
+def _uniform_stride(tensors):
+    """Element stride between the (equal-shaped, contiguous fp32) tensors when they sit at one stride in memory, else None."""
+    ptrs = [t.data_ptr() for t in tensors]
+    n = tensors[0].numel()
+    step = (ptrs[1] - ptrs[0]) if len(ptrs) > 1 else 4 * n
+    if step % 4 or step < 4 * n or any(ptrs[i] != ptrs[0] + i * step for i in range(len(ptrs))):
+        return None
+    if any((not t.is_contiguous()) or t.dtype != torch.float32 for t in tensors):
+        return None
+    return step // 4
+
+
+class _StepProjFn(torch.autograd.Function):
+    """dmat[n][l*C + co] = diffusion_projection_l(h)[co] for every residual layer l in one launch (diffnet.py:66,72); backward: one
+    launch for the input gradient partials (+ their ordered sum) and one for all weight / bias gradients (csrc/train.hip)."""
+
+    @staticmethod
+    def forward(ctx, h, w_ls, b_ls, *params):
+        L_ = len(params) // 2
+        ws, bs = params[:L_], params[L_:]
+        Cc, N = h.shape[1], h.shape[2]
+        h = h.contiguous()
+        out = torch.empty(N, L_ * Cc, dtype=torch.float32, device=h.device)
+        check(L().set_step_proj_fwd(_p(h), _p(ws[0]), w_ls, _p(bs[0]), b_ls, _p(out), L_, Cc, N, _stream()), "set_step_proj_fwd")
+        ctx.ws, ctx.bs, ctx.w_ls = ws, bs, w_ls
+        ctx.save_for_backward(h)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (h,) = ctx.saved_tensors
+        ws, bs = ctx.ws, ctx.bs
+        L_, Cc, N = len(ws), h.shape[1], h.shape[2]
+        g = g.contiguous()
+        dev = h.device
+        p_w, s_w, r_w = _grouped_targets(list(ws), dev)
+        p_b, s_b, r_b = _grouped_targets(list(bs), dev)
+        dh = torch.empty_like(h)
+        scratch = _det_scratch(dev, L().set_step_proj_bwd_scratch_floats(L_, Cc, N))
+        check(L().set_step_proj_bwd(_p(h), _p(g), _p(ws[0]), ctx.w_ls, _p(dh), C.c_void_p(p_w), s_w, C.c_void_p(p_b), s_b, _p(scratch),
+                                    L_, Cc, N, _stream()), "set_step_proj_bwd")
+        return (dh, None, None, *r_w, *r_b)
+
+
+def step_projections(dn, h):
+    """[n, L*C] step offsets of all residual layers from the step embedding h [1, C, n]; None when the layers' parameters are not laid
+    out at one stride (no flat optimizer and separately allocated tensors) or the shape is outside the kernel."""
+    ws = [layer.diffusion_projection.weight for layer in dn.residual_layers]
+    bs = [layer.diffusion_projection.bias for layer in dn.residual_layers]
+    Cc, N = h.shape[1], h.shape[2]
+    if h.shape[0] != 1 or Cc % 64 or N > 64 or Cc * (32 if N <= 32 else 64) > 16384:
+        return None
+    w_ls, b_ls = _uniform_stride(ws), _uniform_stride(bs)
+    if w_ls is None or b_ls is None:
+        return None
+    return _StepProjFn.apply(h, w_ls, b_ls, *ws, *bs)
+
+
 def diffnet_stack_train_bf16(dn, hx, cond, dmat):
     params = []
     for layer in dn.residual_layers:

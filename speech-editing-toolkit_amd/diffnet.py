@@ -215,7 +215,6 @@ class DiffNet(nn.Module):
         hx = A.conv1d(x, self._w_in, self.input_projection.bias, act="relu")
         cond = cond.contiguous()
         skip = None
-        hs_ = A.fanout(h, L)         # every layer's diffusion_projection reads the step embedding
         # (the persistent Winograd stack kernel is an fp32-operand kernel: with bf16 operands the layers run op by op)
         use_stack = (self.can_fuse() and self.impl != "unfused" and os.environ.get("SET_AMD_TRAIN_STACK", "1") != "0"
                      and ops.compute_dtype() == "f32"
@@ -223,19 +222,23 @@ class DiffNet(nn.Module):
         use_bf16_layers = (self.can_fuse() and self.impl != "unfused" and ops.compute_dtype() == "bf16"
                            and self.encoder_hidden == 192 and os.environ.get("SET_AMD_TRAIN_STACK", "1") != "0"
                            and x.shape[2] >= 32)
+        dmat = None
+        if use_bf16_layers or use_stack:
+            # [n, L*C] step offsets of every layer: one launch when the layers' parameters sit at one stride (flat optimizer), else
+            # one 1x1 conv per layer over the fanned-out embedding
+            dmat = A.step_projections(self, h) if os.environ.get("SET_AMD_STEP_PROJ", "1") != "0" else None
+            if dmat is None:
+                hs_ = A.fanout(h, L)
+                dmat = torch.cat([A.conv1d(hs_[li], layer._w_dproj, layer.diffusion_projection.bias)[0].t()
+                                  for li, layer in enumerate(self.residual_layers)], dim=1)
         if use_bf16_layers:
             # bf16 operands: one fused forward and one fused backward launch per layer (csrc/diffnet_bf16.hip)
-            ds = [A.conv1d(hs_[li], layer._w_dproj, layer.diffusion_projection.bias)[0].t()
-                  for li, layer in enumerate(self.residual_layers)]
-            dmat = torch.cat(ds, dim=1)
             skip = A.diffnet_stack_train_bf16(self, hx, cond, dmat)
         elif use_stack:
             # fused forward: one persistent Winograd launch for all L layers (+ saved x/y/z), hand-ordered backward
-            ds = [A.conv1d(hs_[li], layer._w_dproj, layer.diffusion_projection.bias)[0].t()
-                  for li, layer in enumerate(self.residual_layers)]          # L x [n, C]
-            dmat = torch.cat(ds, dim=1)                                       # [n, L*C] (tiny; layout only)
             skip = A.diffnet_stack_train(self, hx, cond, dmat)
         else:
+            hs_ = A.fanout(h, L)         # every layer's diffusion_projection reads the step embedding
             conds = A.fanout(cond, L)    # ... and its conditioner_projection reads cond
             for li, layer in enumerate(self.residual_layers):
                 h, cond = hs_[li], conds[li]

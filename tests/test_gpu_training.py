@@ -603,3 +603,47 @@ def test_training_forward_uses_the_fused_stack_at_the_benchmark_size(dev):
     assert ops.stack_variant(32, 800, 1, have_split=False, x3_mode=0) == 2
     assert ops.stack_variant(32, 800, 1) in (4, 5)      # inference: the split-operand kernel
     assert ops.stack_variant(1, 800, 1) == 3            # one utterance: the row-split kernel
+
+
+@pytest.mark.parametrize("L_,Cc,N,gap", [(20, 256, 32, 0), (3, 128, 5, 7), (2, 64, 64, 1), (4, 192, 33, 0)])
+def test_step_projections_of_all_layers_equal_the_per_layer_linears(dev, L_, Cc, N, gap):
+    """diffusion_projection of every residual layer in one launch (reference diffnet.py:66,72; csrc/train.hip step_proj_*): forward
+    and every gradient against fp64 torch Linear layers; parameters at one stride inside a flat buffer (what the flat optimizer
+    builds), gradients handed back through autograd (no sinks here).  fp32 FMA chains: 1e-5 relative."""
+    from set_amd import autograd_ops as A
+    g = torch.Generator().manual_seed(L_ * 1000 + Cc + N)
+    per = Cc * Cc + Cc + gap
+    flat = (torch.randn(L_ * per, generator=g) / math.sqrt(Cc)).to(dev)
+    ws = [flat[l * per:l * per + Cc * Cc].view(Cc, Cc).requires_grad_(True) for l in range(L_)]
+    bs = [flat[l * per + Cc * Cc:l * per + Cc * Cc + Cc].requires_grad_(True) for l in range(L_)]
+    h = torch.randn(1, Cc, N, generator=g).to(dev).requires_grad_(True)
+    gy = torch.randn(N, L_ * Cc, generator=g).to(dev)
+    assert A._uniform_stride(ws) == per and A._uniform_stride(bs) == per
+    with torch.enable_grad():
+        out = A._StepProjFn.apply(h, per, per, *ws, *bs)
+        out.backward(gy)
+    torch.cuda.synchronize()
+    hd = h.detach().cpu().double().requires_grad_(True)
+    wd = [w.detach().cpu().double().requires_grad_(True) for w in ws]
+    bd = [b.detach().cpu().double().requires_grad_(True) for b in bs]
+    want = torch.cat([F.linear(hd[0].t(), wd[l], bd[l]) for l in range(L_)], dim=1)
+    want.backward(gy.cpu().double())
+    assert _rel(out, want.float()) < 1e-5
+    assert _rel(h.grad, hd.grad.float()) < 1e-5
+    for l in range(L_):
+        assert _rel(ws[l].grad, wd[l].grad.float()) < 1e-5
+        assert _rel(bs[l].grad, bd[l].grad.float()) < 1e-5
+    # a second backward gives the same bits (ordered sums, no atomics)
+    h2 = h.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        A._StepProjFn.apply(h2, per, per, *[w.detach().requires_grad_(True) for w in ws], *[b.detach().requires_grad_(True) for b in bs]).backward(gy)
+    assert torch.equal(h2.grad, h.grad)
+
+
+def test_step_projections_fall_back_when_the_layers_are_not_at_one_stride(dev):
+    from set_amd import autograd_ops as A
+    ws = [torch.randn(64, 64, device=dev), torch.randn(64, 64, device=dev), torch.randn(70, 64, device=dev)[:64]]
+    ws2 = [torch.randn(64, 64, device=dev) for _ in range(2)] + [torch.randn(64, 64, device=dev).t()]
+    assert A._uniform_stride(ws2) is None
+    flat = torch.randn(3 * 64 * 64 + 5, device=dev)
+    assert A._uniform_stride([flat[0:4096].view(64, 64), flat[4096:8192].view(64, 64), flat[8197:].view(64, 64)]) is None
