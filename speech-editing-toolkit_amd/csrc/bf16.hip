@@ -812,6 +812,12 @@ int set_conv1d_bf16_dispatch(const SetConv1dArgs &a, hipStream_t s) {
         return narrow ? launch_conv_bf16<1, 4, 64, 1, false, false>(a, lo, halo, s)
                       : launch_conv_bf16<2, 2, 64, 1, false, false>(a, lo, halo, s);
     }
+    static int tgm = 0;
+    if (!tgm) { const char *e = getenv("SET_AMD_BF16_TGM"); tgm = e ? atoi(e) : 5; }
+    // taps per stage: 5 and 9 taps (the predictor / FFN convs) are 1 and 2 stages per 32-channel chunk with 5 taps per stage, 2 and 3
+    // with 4 -- these convs wait on their stage round trips, not on MFMAs (tools/small_conv_probe.py)
+    if (tgm == 5 && (a.K == 5 || a.K > 8))
+        return narrow ? launch_conv_bf16<1, 4, 32, 5, true, true>(a, lo, halo, s) : launch_conv_bf16<2, 2, 32, 5, true, true>(a, lo, halo, s);
     return narrow ? launch_conv_bf16<1, 4, 32, 4, true, true>(a, lo, halo, s)
                   : launch_conv_bf16<2, 2, 32, 4, true, true>(a, lo, halo, s);
 }
