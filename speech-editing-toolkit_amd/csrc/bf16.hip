@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad3_bf16_kernel(WgradBf16Arg
         }
 }
 
-// ---- K-tap weight gradient (odd K <= 9, dilation 1, "same" padding) with all taps in one block --------------------------------
+// ---- K-tap weight gradient (5 <= K <= 9, dilation 1, "same" or causal padding) with all taps in one block --------------------------------
 // The FFN convs of the FFT blocks / CampNet layers are 9-tap convs (192 -> 768 at 12,800 frames, 256 -> 1024 at 25,600): with one
 // tap per block the output gradient G is re-read K x (ci tiles) times and the conv input X K x (co tiles) times -- the blocks
 // waited on operand loads (118 - 188 TFLOP/s against 330 - 440 of the forward kernel, tools/small_conv_probe.py).
@@ -642,17 +642,18 @@ __device__ __forceinline__ u32x4 wgt_window(const u32x4 (&W)[3]) {  // 8 bf16 st
     return o;
 }
 
-template <int K, int TAP = 0>
+template <int K, int PAD, int TAP = 0>
 __device__ __forceinline__ void wgt_taps(f32x16 (&acc)[K], u32x4 av, const u32x4 (&W)[3]) {
     if constexpr (TAP < K) {
-        acc[TAP] = mfma_bf16(av, wgt_window<8 + TAP - (K - 1) / 2>(W), acc[TAP]);
-        wgt_taps<K, TAP + 1>(acc, av, W);
+        acc[TAP] = mfma_bf16(av, wgt_window<8 + TAP - PAD>(W), acc[TAP]);
+        wgt_taps<K, PAD, TAP + 1>(acc, av, W);
     }
 }
 
-template <int K>
+// PAD = frames of left padding: (K - 1) / 2 for the "same" convs, K - 1 for the causal ("LEFT"-padded) FFN convs of the decoders
+template <int K, int PAD>
 __global__ void __launch_bounds__(256, 2) conv1d_wgrad_taps_bf16_kernel(WgradBf16Args a) {
-    constexpr int PAD = (K - 1) / 2;
+    static_assert(PAD >= 0 && PAD <= 8 && K - 1 - PAD >= 0 && K - 1 - PAD <= 8, "tap shifts must stay inside the 8-frame halo");
     __shared__ __attribute__((aligned(16))) unsigned char Gs[64 * WGB_ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char Xs[64 * WGT_XROWB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -730,7 +731,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_taps_bf16_kernel(WgradBf1
             u32x4 W[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g) W[g] = *reinterpret_cast<const u32x4 *>(bp + ks * 32 + g * 16);
-            wgt_taps<K>(acc, av, W);
+            wgt_taps<K, PAD>(acc, av, W);
         }
     }
     // partial tile of this slice (zeros for an empty slice): K consecutive floats per (co, ci)
@@ -844,11 +845,12 @@ static int wgrad_bf16_slices(int B, int Cin, int Cout, int K, int T, bool taps3 
     return (int)((total_chunks + cps - 1) / cps);  // no empty slices
 }
 
-// all-taps kernel (conv1d_wgrad_taps_bf16_kernel): odd 5 <= K <= 9, dilation 1, "same" padding, fp32 operands, no per-channel add
+// all-taps kernel (conv1d_wgrad_taps_bf16_kernel): K = 5, 7, 9, dilation 1, "same" (pad = (K - 1) / 2) or causal (pad = K - 1)
+// padding, fp32 operands, no per-channel add
 static bool wgrad_taps_applies(int K, int dil, int pad, int dtype, bool chan_add) {
     static int on = -1;
     if (on < 0) { const char *e = getenv("SET_AMD_WGRAD_TAPS"); on = !(e && atoi(e) == 0); }
-    return on && dtype == SET_DTYPE_BF16 && !chan_add && (K == 5 || K == 7 || K == 9) && dil == 1 && pad == (K - 1) / 2;
+    return on && dtype == SET_DTYPE_BF16 && !chan_add && (K == 5 || K == 7 || K == 9) && dil == 1 && (pad == (K - 1) / 2 || pad == K - 1);
 }
 static int wgrad_taps_slices(int B, int Cin, int Cout, int T) {
     const int64_t total_chunks = (int64_t)B * ((T + WGB_KT - 1) / WGB_KT);
@@ -915,9 +917,13 @@ static int wgrad_bf16_launch(const void *g, const void *x, const float *chan_add
         a.chunks_per_slice = (B * a.n_chunks_t + S - 1) / S;
         a.ci_tiles = (Cin + 63) / 64;
         dim3 grid(a.ci_tiles, (Cout + 63) / 64, S);
-        if (K == 9) hipLaunchKernelGGL((conv1d_wgrad_taps_bf16_kernel<9>), grid, dim3(256), 0, s, a);
-        else if (K == 7) hipLaunchKernelGGL((conv1d_wgrad_taps_bf16_kernel<7>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv1d_wgrad_taps_bf16_kernel<5>), grid, dim3(256), 0, s, a);
+        const bool causal = pad == K - 1;
+        if (K == 9 && !causal) hipLaunchKernelGGL((conv1d_wgrad_taps_bf16_kernel<9, 4>), grid, dim3(256), 0, s, a);
+        else if (K == 9) hipLaunchKernelGGL((conv1d_wgrad_taps_bf16_kernel<9, 8>), grid, dim3(256), 0, s, a);
+        else if (K == 7 && !causal) hipLaunchKernelGGL((conv1d_wgrad_taps_bf16_kernel<7, 3>), grid, dim3(256), 0, s, a);
+        else if (K == 7) hipLaunchKernelGGL((conv1d_wgrad_taps_bf16_kernel<7, 6>), grid, dim3(256), 0, s, a);
+        else if (!causal) hipLaunchKernelGGL((conv1d_wgrad_taps_bf16_kernel<5, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv1d_wgrad_taps_bf16_kernel<5, 4>), grid, dim3(256), 0, s, a);
         const int rc = set_check_launch("set_conv1d_wgrad_det(bf16, all taps)");
         if (rc != SET_OK) return rc;
     } else if (wgrad3_applies(K, dil, pad, pro, dtype)) {

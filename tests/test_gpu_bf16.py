@@ -164,12 +164,15 @@ def test_conv1d_bf16_backward_equals_rounded_operand_gradients(dev, case, bf16):
 
 
 TAPS_CASES = [
-    # B, Cin, Cout, K, T, prologue: the all-taps weight-gradient kernel (odd 5 <= K <= 9, dilation 1, "same" padding)
-    (2, 192, 768, 9, 800, None),           # CampNet FFN conv
-    (3, 100, 200, 9, 333, None),           # ragged channels (partial 64-row tiles), ragged T, chunks that straddle nothing
-    (2, 80, 130, 5, 150, ("lrelu", 0.1)),  # 5 taps, prologue on the conv input
-    (2, 64, 64, 7, 65, ("div", 3.0)),      # 7 taps, a second chunk of one frame
-    (1, 256, 1024, 9, 64, None),           # exactly one chunk: every halo frame is padding
+    # B, Cin, Cout, K, T, prologue, causal: the all-taps weight-gradient kernel (K = 5, 7, 9, dilation 1, "same" or causal padding)
+    (2, 192, 768, 9, 800, None, False),           # CampNet FFN conv
+    (2, 192, 768, 9, 800, None, True),            # ... of a decoder layer: 8 frames of left padding (transformer FFN, padding='LEFT')
+    (3, 100, 200, 9, 333, None, False),           # ragged channels (partial 64-row tiles), ragged T
+    (2, 80, 130, 5, 150, ("lrelu", 0.1), False),  # 5 taps, prologue on the conv input
+    (2, 80, 130, 5, 150, None, True),
+    (2, 64, 64, 7, 65, ("div", 3.0), False),      # 7 taps, a second chunk of one frame
+    (2, 64, 96, 7, 130, None, True),
+    (1, 256, 1024, 9, 64, None, False),           # exactly one chunk: every halo frame is padding
 ]
 
 
@@ -179,17 +182,17 @@ def test_wgrad_all_taps_kernel_equals_rounded_operand_products(dev, case, monkey
     from shifted views of one staged X row (csrc/bf16.hip: conv1d_wgrad_taps_bf16_kernel); also against the one-tap-per-block kernel
     (same products, another summation order) and bit-stable from run to run."""
     from set_amd import _lib, autograd_ops as A
-    B, Cin, Cout, K, T, pro = case
+    B, Cin, Cout, K, T, pro, causal = case
     g = torch.Generator().manual_seed(Cin + Cout + K + T)
     x = torch.randn(B, Cin, T, generator=g)
     gy = torch.randn(B, Cout, T, generator=g)
-    pad = (K - 1) // 2
+    pad = K - 1 if causal else (K - 1) // 2
     xin = x
     code, param = 0, 0.0
     if pro is not None:
         code, param = _lib.PRO[pro[0]], pro[1]
         xin = F.leaky_relu(x, param) if pro[0] == "lrelu" else x / param
-    xp = F.pad(_r(xin), (pad, pad))
+    xp = F.pad(_r(xin), (pad, K - 1 - pad))
     want = torch.stack([torch.einsum("bot,bit->oi", _r(gy), xp[:, :, k:k + T]) for k in range(K)], dim=-1)
     xd, gd = x.to(dev), gy.to(dev)
     outs = []
