@@ -98,6 +98,74 @@ __global__ void __launch_bounds__(256) pack_conv_weights_bf16_batch_kernel(const
     reinterpret_cast<unsigned short *>(e.wp)[idx] = bf16_bits(v);
 }
 
+// ---- epilogue (fp32) of the bf16 conv kernels: v = act((acc + bias) * alpha) + res ; * mask ; (+ previous output, / out_div) ----
+// acc[i][j]: rows r0 + wm*64 + i*32 .., frames t0 + wn*64 + j*32 ..
+template <int WM, int WN>
+__device__ __forceinline__ void conv_bf16_epilogue(const SetConv1dArgs &a, const f32x16 (&acc)[2][2], int b, int t0, int r0, int wm, int wn,
+                                                   int half, int l31) {
+    // every optional operand is fetched as one batch of 16 on clamped addresses under ONE wave-uniform test, and the
+    // activation code is resolved once per kernel (cheap ones as template instances, the transcendental ones in a
+    // rolled loop): a per-element `if (ptr) v += ptr[i]` / `switch (act)` costs a branch (and a drained vmcnt) per element
+    const bool has_div = a.accumulate && a.out_div != 0.0f;
+    const bool has_res = a.res != nullptr, has_bias = a.bias != nullptr, has_acc = a.accumulate != 0;
+    const rsrc_t d_out = make_rsrc(a.out + (int64_t)b * a.out_bs);
+    const rsrc_t d_res = make_rsrc(has_res ? a.res + (int64_t)b * a.res_bs : a.out + (int64_t)b * a.out_bs);
+    const rsrc_t d_bias = make_rsrc(has_bias ? a.bias : a.out);
+    auto tile = [&](auto ACT, const f32x16 &av, int i, int j) __attribute__((always_inline)) {
+        constexpr int kAct = decltype(ACT)::value;
+        const int rbase = r0 + wm * 64 + i * 32 + 4 * half;  // register r of this lane is row rbase + (r&3) + 8*(r>>2)
+        const int t = t0 + wn * 64 + j * 32 + l31;
+        const bool tv = t < a.T_iter && t < a.T_out;
+        const int tc = min(t, a.T_out - 1);
+        float mk = 1.0f;
+        if (a.mask) mk = a.mask[(int64_t)b * a.T_out + tc];
+        float bi[16], rv[16], ov[16];
+        unsigned ro[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ro[r] = (unsigned)min(rbase + (r & 3) + 8 * (r >> 2), a.Cout - 1);
+            bi[r] = rv[r] = ov[r] = 0.0f;
+        }
+        if (has_bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bi[r] = buf_load(d_bias, ro[r] * 4u, 0u);
+        }
+        if (has_res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = buf_load(d_res, (ro[r] * (unsigned)a.res_cs + (unsigned)tc) * 4u, 0u);
+        }
+        if (has_acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ov[r] = buf_load(d_out, (ro[r] * (unsigned)a.out_cs + (unsigned)tc) * 4u, 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            float y = (av[r] + bi[r]) * a.alpha;
+            if constexpr (kAct == SET_ACT_RELU) y = y > 0.0f ? y : 0.0f;
+            else if constexpr (kAct == SET_ACT_LRELU) y = y > 0.0f ? y : y * a.act_param;
+            else if constexpr (kAct != SET_ACT_NONE) y = dev_act(y, a.act, a.act_param);
+            y = (y + rv[r]) * mk + ov[r];
+            if (has_div) y = y / a.out_div;
+            if (tv && row < a.Cout) buf_store(y, d_out, (ro[r] * (unsigned)a.out_cs + (unsigned)tc) * 4u, 0u);
+        }
+    };
+    auto finish = [&](auto ACT) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (r0 + wm * 64 + i * 32 >= a.Cout) continue;  // wave-uniform: a fully padded row block
+#pragma unroll
+            for (int j = 0; j < 2; ++j) tile(ACT, acc[i][j], i, j);
+        }
+    };
+    switch (a.act) {
+        case SET_ACT_NONE: finish(ic<SET_ACT_NONE>{}); break;
+        case SET_ACT_RELU: finish(ic<SET_ACT_RELU>{}); break;
+        case SET_ACT_LRELU: finish(ic<SET_ACT_LRELU>{}); break;
+        default: finish(ic<-1>{}); break;  // gelu / tanh / softplus / mish: run-time dev_act (small layers only)
+    }
+}
+
 // =====================================================================================================================
 // conv1d, bf16 operands.  Block = 4 waves arranged WM x WN, wave tile 64 rows x 64 frames (2 x 2 accumulators of
 // 32x32), block tile MB = 64*WM rows x NB = 64*WN frames.  One pipeline stage = KCH input channels x TG taps:
@@ -266,68 +334,111 @@ __global__ void __launch_bounds__(256, 2) conv1d_bf16_kernel(SetConv1dArgs a, in
         }
     }
 
-    // ---- epilogue (fp32): v = act((acc + bias) * alpha) + res ; * mask ; (+ previous output, / out_div) ----
-    // every optional operand is fetched as one batch of 16 on clamped addresses under ONE wave-uniform test, and the
-    // activation code is resolved once per kernel (cheap ones as template instances, the transcendental ones in a
-    // rolled loop): a per-element `if (ptr) v += ptr[i]` / `switch (act)` costs a branch (and a drained vmcnt) per element
-    const bool has_div = a.accumulate && a.out_div != 0.0f;
-    const bool has_res = a.res != nullptr, has_bias = a.bias != nullptr, has_acc = a.accumulate != 0;
-    const rsrc_t d_out = make_rsrc(a.out + (int64_t)b * a.out_bs);
-    const rsrc_t d_res = make_rsrc(has_res ? a.res + (int64_t)b * a.res_bs : a.out + (int64_t)b * a.out_bs);
-    const rsrc_t d_bias = make_rsrc(has_bias ? a.bias : a.out);
-    auto tile = [&](auto ACT, const f32x16 &av, int i, int j) __attribute__((always_inline)) {
-        constexpr int kAct = decltype(ACT)::value;
-        const int rbase = r0 + wm * 64 + i * 32 + 4 * half;  // register r of this lane is row rbase + (r&3) + 8*(r>>2)
-        const int t = t0 + wn * 64 + j * 32 + l31;
-        const bool tv = t < a.T_iter && t < a.T_out;
-        const int tc = min(t, a.T_out - 1);
-        float mk = 1.0f;
-        if (a.mask) mk = a.mask[(int64_t)b * a.T_out + tc];
-        float bi[16], rv[16], ov[16];
-        unsigned ro[16];
+    conv_bf16_epilogue<WM, WN>(a, acc, b, t0, r0, wm, wn, half, l31);
+}
+
+// ---- 1x1 conv with at most 256 input channels, the whole input tile in one round trip ------------------------------------------------
+// The 1x1 convs of the FFT / transformer blocks (attention projections, 192 or 256 channels, 12,800 - 25,600 frames) are ~200 blocks of
+// a few MFMAs each: in the staged kernel above a block walks Cin / 64 stages of load -> convert -> barrier -> 16 MFMAs -> barrier with
+// one stage of loads in flight, i.e. it spends its life in 3 - 4 dependent memory round trips (22 - 31 us per conv against 4 - 10 us of
+// HBM time, tools/small_conv_probe.py).  Here every thread issues ALL its input loads at once (Cin / 2 dwords: frame tid & 127, channel
+// half tid >> 7), the tile [128 frames][Cin] goes to LDS in one pass, and the GEMM runs over the whole K with the weight fragments
+// straight from the packed image (L2-resident, ring of 4 k-steps): one input round trip, one barrier.
+template <int CINP>
+__global__ void __launch_bounds__(256, 2) conv1x1_oneshot_bf16_kernel(SetConv1dArgs a, int CoutP, int nchunk32) {
+    constexpr int WM = 2, WN = 2, NB = 128;
+    constexpr int ROWB = CINP * 2 + 16;  // bytes per frame row of the tile
+    constexpr int CPT = CINP / 2;        // channels per thread
+    constexpr int NKS = CINP / 16;       // k-steps
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char *Bs = smem_raw;        // [128][ROWB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, t0 = blockIdx.x * NB, r0 = blockIdx.y * 128;
+    const unsigned short *wimg = reinterpret_cast<const unsigned short *>(a.w);
+    const rsrc_t d_in = make_rsrc(a.in + (int64_t)b * a.in_bs);
+    const int sf = tid & 127, scg = __builtin_amdgcn_readfirstlane(tid >> 7);
+
+    float pv[CPT];
+    {
+        const unsigned vo = (unsigned)min(t0 + sf, a.T_in - 1) * 4u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            ro[r] = (unsigned)min(rbase + (r & 3) + 8 * (r >> 2), a.Cout - 1);
-            bi[r] = rv[r] = ov[r] = 0.0f;
-        }
-        if (has_bias) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bi[r] = buf_load(d_bias, ro[r] * 4u, 0u);
-        }
-        if (has_res) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = buf_load(d_res, (ro[r] * (unsigned)a.res_cs + (unsigned)tc) * 4u, 0u);
-        }
-        if (has_acc) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ov[r] = buf_load(d_out, (ro[r] * (unsigned)a.out_cs + (unsigned)tc) * 4u, 0u);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rbase + (r & 3) + 8 * (r >> 2);
-            float y = (av[r] + bi[r]) * a.alpha;
-            if constexpr (kAct == SET_ACT_RELU) y = y > 0.0f ? y : 0.0f;
-            else if constexpr (kAct == SET_ACT_LRELU) y = y > 0.0f ? y : y * a.act_param;
-            else if constexpr (kAct != SET_ACT_NONE) y = dev_act(y, a.act, a.act_param);
-            y = (y + rv[r]) * mk + ov[r];
-            if (has_div) y = y / a.out_div;
-            if (tv && row < a.Cout) buf_store(y, d_out, (ro[r] * (unsigned)a.out_cs + (unsigned)tc) * 4u, 0u);
-        }
-    };
-    auto finish = [&](auto ACT) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (r0 + wm * 64 + i * 32 >= a.Cout) continue;  // wave-uniform: a fully padded row block
-#pragma unroll
-            for (int j = 0; j < 2; ++j) tile(ACT, acc[i][j], i, j);
-        }
-    };
-    switch (a.act) {
-        case SET_ACT_NONE: finish(ic<SET_ACT_NONE>{}); break;
-        case SET_ACT_RELU: finish(ic<SET_ACT_RELU>{}); break;
-        case SET_ACT_LRELU: finish(ic<SET_ACT_LRELU>{}); break;
-        default: finish(ic<-1>{}); break;  // gelu / tanh / softplus / mish: run-time dev_act (small layers only)
+        for (int k = 0; k < CPT; ++k) pv[k] = buf_load(d_in, vo, (unsigned)(min(scg * CPT + k, a.Cin - 1) * (int)a.in_cs) * 4u);
     }
+    // weight fragments: lane (row l31 of row block i, k-half `half`) of k-step ks reads 16 bytes of wp[chunk ks / 2][row][32]
+    const rsrc_t d_w = make_rsrc(wimg);
+    auto a_off = [&](int ks, int i) {
+        // (k-steps beyond the image's last 32-channel chunk re-read it: their B rows are zero)
+        return (unsigned)(((min(ks >> 1, nchunk32 - 1) * CoutP + r0 + wm * 64 + i * 32 + l31) * 32 + (ks & 1) * 16 + half * 8) * 2);
+    };
+    constexpr int RING = NKS < 4 ? NKS : 4;
+    u32x4 A[RING][2];
+#pragma unroll
+    for (int q = 0; q < RING; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) A[q][i] = __builtin_amdgcn_raw_buffer_load_b128(d_w, (int)a_off(q, i), 0, 0);
+
+    auto commit = [&](auto PROC) __attribute__((always_inline)) {
+        constexpr int kPro = decltype(PROC)::value;
+        const bool tv = t0 + sf < a.T_in;
+#pragma unroll
+        for (int q = 0; q < CPT / 8; ++q) {
+            u32x4 u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v0 = pro_c<kPro>(pv[8 * q + 2 * e], a.pro_param), v1 = pro_c<kPro>(pv[8 * q + 2 * e + 1], a.pro_param);
+                v0 = (tv && scg * CPT + 8 * q + 2 * e < a.Cin) ? v0 : 0.0f;
+                v1 = (tv && scg * CPT + 8 * q + 2 * e + 1 < a.Cin) ? v1 : 0.0f;
+                u[e] = pack_bf16(v0, v1);
+            }
+            *reinterpret_cast<u32x4 *>(Bs + sf * ROWB + (scg * CPT + 8 * q) * 2) = u;
+        }
+    };
+    switch (a.pro) {
+        case SET_PRO_LRELU: commit(ic<SET_PRO_LRELU>{}); break;
+        case SET_PRO_DIV: commit(ic<SET_PRO_DIV>{}); break;
+        default: commit(ic<SET_PRO_NONE>{}); break;
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+    const unsigned char *bp = Bs + (wn * 64 + l31) * ROWB + half * 16;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const u32x4 a0 = A[ks % RING][0], a1 = A[ks % RING][1];
+        if (ks + RING < NKS) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) A[ks % RING][i] = __builtin_amdgcn_raw_buffer_load_b128(d_w, (int)a_off(ks + RING, i), 0, 0);
+        }
+        const u32x4 b0 = *reinterpret_cast<const u32x4 *>(bp + ks * 32);
+        const u32x4 b1 = *reinterpret_cast<const u32x4 *>(bp + 32 * ROWB + ks * 32);
+        acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
+        acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
+        acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
+        acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+    }
+    conv_bf16_epilogue<WM, WN>(a, acc, b, t0, r0, wm, wn, half, l31);
+}
+
+template <int CINP>
+static int launch_conv1x1_oneshot(const SetConv1dArgs &a, hipStream_t s) {
+    const int CoutP = round_up_i(a.Cout, 128);
+    const size_t lds = (size_t)128 * (CINP * 2 + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_oneshot_bf16_kernel<CINP>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "conv 1x1 attr");
+        attr_set = true;
+    }
+    dim3 grid((a.T_iter + 127) / 128, (a.Cout + 127) / 128, a.B), block(256);
+    hipLaunchKernelGGL((conv1x1_oneshot_bf16_kernel<CINP>), grid, block, lds, s, a, CoutP, round_up_i(a.Cin, 32) / 32);
+    return set_check_launch("set_conv1d(bf16, 1x1)");
 }
 
 template <int WM, int WN, int KCH, int TGM, bool HALO, bool ADD>
@@ -809,6 +920,15 @@ int set_conv1d_bf16_dispatch(const SetConv1dArgs &a, hipStream_t s) {
     // that height (CampNet's 192-channel projections at 12,800 frames) wait on their input, not on MFMAs: 27 -> 22 us (192 -> 192),
     // 56 -> 45 us (768 -> 192) with 128-row blocks; the 9-tap convs keep the 64-row ones (146 vs 149 us)
     const bool narrow = a.Cout <= 64 || (a.Cout > 128 && a.Cout <= 192 && a.K > 1);
+    static int oneshot = -1;
+    if (oneshot < 0) { const char *e = getenv("SET_AMD_BF16_ONESHOT"); oneshot = !(e && atoi(e) == 0); }
+    if (oneshot && a.K == 1 && a.Cin > 32 && a.Cin <= 256 && a.Cout > 64 && halo == 0 && !a.in_chan_add && a.pad == 0) {
+        const int cp = round_up_i(a.Cin, 32);
+        if (cp <= 64) return launch_conv1x1_oneshot<64>(a, s);
+        if (cp <= 128) return launch_conv1x1_oneshot<128>(a, s);
+        if (cp <= 192) return launch_conv1x1_oneshot<192>(a, s);
+        return launch_conv1x1_oneshot<256>(a, s);
+    }
     if (a.K == 1 && a.Cin > 32 && halo == 0 && !a.in_chan_add) {
         return narrow ? launch_conv_bf16<1, 4, 64, 1, false, false>(a, lo, halo, s)
                       : launch_conv_bf16<2, 2, 64, 1, false, false>(a, lo, halo, s);
