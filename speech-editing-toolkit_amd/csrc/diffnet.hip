@@ -1090,7 +1090,10 @@ static int stack_variant(int B, int T, int dcl, bool have_wino, bool have_split,
     // (measured at T = 800: one utterance 75 ms per 100 steps, two 79 ms; from three utterances on two blocks would share a CU
     // and the split-operand kernel, ~123 ms whatever the batch up to B = 16, is the faster one)
     const int64_t split_blocks = 4 * (int64_t)B * ((T + 31) / 32);
-    const bool split_fits = have_split && dcl <= 4 && split_blocks <= 2 * (int64_t)n_cu;        // co-residency
+    // co-residency: two blocks per CU for the fp32-pipe kernel, ONE for the two-piece fp16 one (its A ring takes the whole register
+    // file of a SIMD lane group: launch bounds (256, 1)) unless SET_AMD_SPLIT_F32 pins the fp32-pipe kernel
+    const bool split_one_per_cu = have_x3 && !(getenv("SET_AMD_SPLIT_F32") && atoi(getenv("SET_AMD_SPLIT_F32")) != 0);
+    const bool split_fits = have_split && dcl <= 4 && split_blocks <= (split_one_per_cu ? 1 : 2) * (int64_t)n_cu;
     const bool split_pays = split_blocks <= (int64_t)(have_x3 ? 1 : 2) * n_cu;
     int split_env = 1;
     if (const char *e = getenv("SET_AMD_SPLIT")) split_env = atoi(e);

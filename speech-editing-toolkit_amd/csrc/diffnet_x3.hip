@@ -661,10 +661,12 @@ int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_
 // Same products in the same order per accumulator as diffnet_stack_x3_kernel<SplitF16x2>: bit-identical to it.
 // =====================================================================================================================
 constexpr unsigned SX_SPIN_LIMIT = 1u << 20;
-constexpr int SX_PF = 4;  // A prefetch distance in k-steps (2 x 16 bytes each).  The images are cold in L2 at every layer (42 MB
-                          // cycle through 4 MB per XCD), so a memory-side round trip per SX_PF k-steps bounds the GEMMs; deeper
-                          // rings (8, 16: spills), an LDS-fragment ring and an explicit L2 prefetch of the next layer's
-                          // slices were measured and were not faster end to end (61.8 ms per 100 steps at B = 1 as is)
+constexpr int SX_PF = 8;  // A prefetch distance in k-steps (2 x 16 bytes each).  The images are cold in L2 at every layer (42 MB
+                          // cycle through 4 MB per XCD), so a memory-side round trip per SX_PF k-steps bounds the GEMMs.  The kernel
+                          // only runs with one block per CU (launch bounds (256, 1): the ring may spill into AGPRs): 4 -> 8 k-steps
+                          // 66.3 -> 64.4 ms per 100 steps at B = 1 (GEMM 1 11.2 -> 10.4 us, GEMM 2 3.6 -> 2.8 us per layer);
+                          // 16 k-steps: GEMM 1 8.8 / GEMM 2 1.1 us but the x staging doubles (AGPR traffic), 80.6 ms.  An
+                          // LDS-fragment ring and an explicit L2 prefetch of the next layer's slices were not faster either.
 
 __device__ __forceinline__ bool sx_wait(const int *f0, const int *f1, const int *f2, int want, int *abort_flag, int *err_flag) {
     unsigned spins = 0;
@@ -713,7 +715,7 @@ __device__ __forceinline__ void sx_preload(u32x4_t (&A)[SX_PF][2], rsrc_t img, u
     }
 }
 
-__global__ void __launch_bounds__(256, 2) diffnet_stack_split_x2_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles,
+__global__ void __launch_bounds__(256, 1) diffnet_stack_split_x2_kernel(SetDiffnetStackArgs a, int tiles_per_utt, int ntiles,
                                                                          unsigned piece_bytes, int fault_tile) {
     typedef SplitF16x2 S;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // x tile pieces [2][32 + 2 maxd][XR]; z tile overlays it
@@ -723,6 +725,39 @@ __global__ void __launch_bounds__(256, 2) diffnet_stack_split_x2_kernel(SetDiffn
     int *abort_flag = a.sync_ws + 1, *ready = a.sync_ws + 4, *zcnt = a.sync_ws + 4 + ntiles;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((int)blockIdx.x >= 4 * ntiles) {
+        // ---- L2 warmers (launched when CUs are left over: 8 extra blocks, one per XCD -- workgroups go to the XCDs round-robin, so
+        // block 4 ntiles + q shares its L2 with the compute blocks of part (4 ntiles + q) & 3).  42 MB of images cycle through 4 MB of
+        // L2 per XCD: without them every ring turn of a GEMM is a miss to memory (GEMM 1 10.4 us per layer for 2.2 us of MFMAs).  The
+        // warmer reads the part's fragments of layer l (384 + 128 KB, contiguous) while the compute blocks are on layer l - 1; it is
+        // paced by tile 0's progress counter and touches nothing the compute blocks write.
+        const int hp = blockIdx.x & 3;
+        for (int l = 1; l < a.L; ++l) {
+            unsigned spins = 0;
+            while (l >= 2 && ld_agent(ready) < 4 * (l - 1)) {  // tile 0 has finished layer l - 2: it is on layer l - 1 now
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > SX_SPIN_LIMIT || ld_agent(abort_flag) != 0) return;
+            }
+            const unsigned char *img = reinterpret_cast<const unsigned char *>(a.wx3_all) + (int64_t)l * x_nimg<S>() * 2;
+            const rsrc_t r1 = make_rsrc(img + (size_t)(2 * hp) * X_KS1 * 4 * 1024);
+            const rsrc_t r2 = make_rsrc(img + x_n1<S>() * 2 + (size_t)(2 * hp) * X_KS2 * 4 * 1024);
+            for (unsigned off = 16u * tid; off < 2u * X_KS1 * 4 * 1024; off += 8u * 4096u) {
+#pragma unroll
+                for (unsigned q = 0; q < 8; ++q) {
+                    const u32x4_t v = buf_load_u4(r1, off + q * 4096u, 0u);
+                    asm volatile("" ::"v"(v));
+                }
+            }
+            for (unsigned off = 16u * tid; off < 2u * X_KS2 * 4 * 1024; off += 8u * 4096u) {
+#pragma unroll
+                for (unsigned q = 0; q < 8; ++q) {
+                    const u32x4_t v = buf_load_u4(r2, off + q * 4096u, 0u);
+                    asm volatile("" ::"v"(v));
+                }
+            }
+        }
+        return;
+    }
     const int i = blockIdx.x >> 2, h = blockIdx.x & 3;
     const int b = i / tiles_per_utt, jt = i - b * tiles_per_utt;
     const int T = a.T, t0 = jt * 32;
@@ -921,7 +956,16 @@ int set_launch_diffnet_stack_split_x2(const SetDiffnetStackArgs &a, int fault_ti
     const unsigned piece_bytes = (unsigned)((32 + 2 * max_dil) * XR);
     const size_t ldsz = (size_t)2 * piece_bytes + (64 * 32 + XC) * sizeof(float) + 16;
     SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + 2 * nt) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
-    hipLaunchKernelGGL(diffnet_stack_split_x2_kernel, dim3(4 * nt), dim3(256), ldsz, s, a, tiles, nt, piece_bytes, fault_tile);
+    // 8 L2-warmer blocks (one per XCD) when the chip has CUs to spare and the block -> XCD round-robin lines them up with the parts
+    static int warm = -1, n_cu = 0;
+    if (warm < 0) {
+        const char *e = getenv("SET_AMD_SPLIT_WARMERS");
+        warm = !(e && atoi(e) == 0);
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 0;
+    }
+    const int extra = (warm && 4 * nt + 8 <= n_cu && a.L > 1) ? 8 : 0;  // (block q: XCD q % 8, part q & 3 = (q % 8) & 3 -- consistent)
+    hipLaunchKernelGGL(diffnet_stack_split_x2_kernel, dim3(4 * nt + extra), dim3(256), ldsz, s, a, tiles, nt, piece_bytes, fault_tile);
     return set_check_launch("set_diffnet_stack");
 }
 
