@@ -647,3 +647,40 @@ def test_step_projections_fall_back_when_the_layers_are_not_at_one_stride(dev):
     assert A._uniform_stride(ws2) is None
     flat = torch.randn(3 * 64 * 64 + 5, device=dev)
     assert A._uniform_stride([flat[0:4096].view(64, 64), flat[4096:8192].view(64, 64), flat[8197:].view(64, 64)]) is None
+
+
+def test_training_step_with_grouped_step_projections_equals_the_per_layer_path(dev, monkeypatch):
+    """The whole loss + gradient computation (fp32, fused layer stack) with the 20 diffusion_projection layers laid out at one stride
+    (as the flat optimizer lays them out) -> `set_step_proj_*` -- against the same step with SET_AMD_STEP_PROJ=0 (one 1x1 conv per
+    layer): losses to 1e-6, every gradient to 2e-5 of its largest entry."""
+    from set_amd import autograd_ops as A
+    monkeypatch.setenv("SET_AMD_WINO", "2")  # two utterances: force the kernel choice (and with it the fused path) of the big batches
+    task, _ = _train_setup(dev, 8, 18)
+    layers = list(task.model.denoise_fn.residual_layers)
+    Cc = layers[0].diffusion_projection.weight.shape[0]
+    per = Cc * Cc + Cc
+    flat = torch.empty(len(layers) * per, device=dev)
+    for l, layer in enumerate(layers):
+        w, b = layer.diffusion_projection.weight, layer.diffusion_projection.bias
+        flat[l * per:l * per + Cc * Cc].copy_(w.data.reshape(-1))
+        flat[l * per + Cc * Cc:(l + 1) * per].copy_(b.data)
+        w.data = flat[l * per:l * per + Cc * Cc].view(Cc, Cc)
+        b.data = flat[l * per + Cc * Cc:(l + 1) * per]
+    assert A._uniform_stride([ly.diffusion_projection.weight for ly in layers]) == per
+    calls = []
+    real = A._StepProjFn.apply
+    monkeypatch.setattr(A, "step_projections", (lambda f: (lambda dn, h: (calls.append(1), f(dn, h))[1]))(A.step_projections))
+    l1, g1, *_ = _full_size_step(dev, task, 2, "f32")
+    assert calls, "the grouped step projections were not taken"
+    monkeypatch.setenv("SET_AMD_STEP_PROJ", "0")
+    l0, g0, *_ = _full_size_step(dev, task, 2, "f32")
+    for k in l0:
+        assert abs(l1[k] - l0[k]) < 1e-6 * max(1.0, abs(l0[k])), k
+    off = 0
+    for name, p in task.model.named_parameters():
+        if p.grad is None:
+            continue
+        n = p.numel()
+        a, b = g1[off:off + n], g0[off:off + n]
+        off += n
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, name
