@@ -237,6 +237,9 @@ __global__ void __launch_bounds__(NT * 4, NT == 128 ? 1 : 2) diffnet_layer_fwd_b
     //      thread; no accumulator is live yet) are issued before the first one is consumed: one memory round trip instead
     //      of one per 32-channel batch; the per-utterance step offsets d[256] go through LDS (one load per channel per
     //      block instead of one per element).  Loads are unconditional on clamped addresses, selects after.
+    //      (Measured and dropped, round 3: 16-byte loads -- a lane fetching 4 consecutive frames of a channel, 24 - 40 loads per
+    //      thread instead of 112 - 176, 4 rows x 16 bytes to LDS per 8 loads: the kernel went from 61.7 to 75.7 us; the x tile starts
+    //      at frame t0 - d, so every one of those loads is misaligned, and the LDS writes of a wave land 4 rows apart.)
     {
         const int f = tid % NT, cg = __builtin_amdgcn_readfirstlane(tid / NT);  // cg 0..3
         if (tid < FC) dsh[tid] = buf_load(rd, 0u, (unsigned)tid * 4u * (unsigned)a.d_cs);
