@@ -425,6 +425,11 @@ typedef struct SetDiffLoopArgs {
     const float *cond;
     const void *img16_all;
     const float *b_cond_all;
+    /* optional workspace of the bf16 loop: with bf16_ws_floats >= set_diffnet_layers_bf16_scratch_floats(B, T, 0, 4,
+     * dilation_cycle_length) (and dilation_cycle_length <= 2) the layers run four per launch (set_diffnet_layers_fwd_bf16);
+     * NULL / too small: one launch per layer.  SET_AMD_BF16_FUSE=n overrides the group size (1 = per layer). */
+    float *bf16_ws;
+    int64_t bf16_ws_floats;
 } SetDiffLoopArgs;
 int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream);
 
@@ -486,6 +491,29 @@ int64_t set_diffnet_layer_bf16_image_size(void);
 int set_pack_diffnet_layer_bf16(const float *wdil /*[512][256][3]*/, const float *wcond /*[512][192]*/,
                                 const float *wout /*[512][256]*/, void *img, void *stream);
 int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, void *stream);
+/* Several consecutive residual layers per launch (bf16 operands, inference: nothing is saved): a block keeps its 128-frame tile on
+ * chip for `nl` layers l0 .. l0 + nl - 1 (x and the conditioner are read once, the running skip sum and a private fp32 copy of x'
+ * go through L2 between the layers) and stores the 128 - 2 H frames whose receptive field stayed inside the tile, H = sum of the
+ * dilations 2^((l0 + m) % dilation_cycle_length), m = 1 .. nl - 1.  Same arithmetic per frame as nl set_diffnet_layer_fwd_bf16
+ * launches.  Arrays are the per-layer operands of those launches laid out one layer after the other: img [nl][image_size],
+ * b_dil / b_cond / b_out [nl][512], dstep of layer l at dstep + l * d_ls (l counted from layer 0 of the network).
+ * scratch >= set_diffnet_layers_bf16_scratch_floats(B, T, l0, nl, dilation_cycle_length) floats, x_in != x_out. */
+typedef struct SetDiffnetLayersBf16Args {
+    const float *x_in;   /* [B][256][T] input of layer l0 */
+    float *x_out;        /* [B][256][T] output of layer l0 + nl - 1 */
+    float *skip;         /* [B][256][T] += sum of the nl skip contributions (first != 0: =) */
+    const float *cond;   /* [B][192][T] */
+    const float *dstep;
+    const void *img;
+    const float *b_dil, *b_cond, *b_out;
+    float *scratch;
+    int64_t scratch_floats;
+    int64_t d_bs, d_cs, d_ls;
+    int32_t B, T, l0, nl, dilation_cycle_length, first;
+} SetDiffnetLayersBf16Args;
+int64_t set_sizeof_diffnet_layers_bf16_args(void);
+int64_t set_diffnet_layers_bf16_scratch_floats(int32_t B, int32_t T, int32_t l0, int32_t nl, int32_t dilation_cycle_length);
+int set_diffnet_layers_fwd_bf16(const SetDiffnetLayersBf16Args *args, void *stream);
 /* debug: block (1,1) of the bf16 layer kernels stamps s_memtime at its phase boundaries into buf[0..7] (NULL = off) */
 int set_debug_bf16_phase_buffer(uint64_t *buf);
 /* debug: lane 0 of one block (tile 1, part 1) of the row-split stack kernel ADDS the s_memtime ticks it spends in each of

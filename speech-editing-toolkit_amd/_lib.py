@@ -80,6 +80,7 @@ class SetDiffLoopArgs(C.Structure):
         ("sync_ws", C.c_void_p),
         ("err_flag", C.c_void_p),
         ("cond", C.c_void_p), ("img16_all", C.c_void_p), ("b_cond_all", C.c_void_p),
+        ("bf16_ws", C.c_void_p), ("bf16_ws_floats", C.c_int64),
     ]
 
 
@@ -105,6 +106,17 @@ class SetDiffnetLayerBf16Args(C.Structure):
         ("y16", C.c_void_p), ("z16", C.c_void_p),
         ("d_bs", C.c_int64), ("d_cs", C.c_int64),
         ("B", C.c_int32), ("T", C.c_int32), ("dil", C.c_int32), ("first", C.c_int32),
+    ]
+
+
+class SetDiffnetLayersBf16Args(C.Structure):
+    _fields_ = [
+        ("x_in", C.c_void_p), ("x_out", C.c_void_p), ("skip", C.c_void_p), ("cond", C.c_void_p), ("dstep", C.c_void_p),
+        ("img", C.c_void_p), ("b_dil", C.c_void_p), ("b_cond", C.c_void_p), ("b_out", C.c_void_p),
+        ("scratch", C.c_void_p), ("scratch_floats", C.c_int64),
+        ("d_bs", C.c_int64), ("d_cs", C.c_int64), ("d_ls", C.c_int64),
+        ("B", C.c_int32), ("T", C.c_int32), ("l0", C.c_int32), ("nl", C.c_int32), ("dilation_cycle_length", C.c_int32),
+        ("first", C.c_int32),
     ]
 
 
@@ -256,6 +268,9 @@ SIGNATURES = {
     "set_diffnet_layer_bf16_image_size": (_I64, []),
     "set_pack_diffnet_layer_bf16": (C.c_int, [_V, _V, _V, _V, _V]),
     "set_diffnet_layer_fwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayerBf16Args), _V]),
+    "set_sizeof_diffnet_layers_bf16_args": (_I64, []),
+    "set_diffnet_layers_bf16_scratch_floats": (_I64, [_I32, _I32, _I32, _I32, _I32]),
+    "set_diffnet_layers_fwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayersBf16Args), _V]),
     "set_debug_bf16_phase_buffer": (C.c_int, [_V]),
     "set_debug_split_phase_buffer": (C.c_int, [_V]),
     "set_debug_x3_phase_buffer": (C.c_int, [_V]),
@@ -367,6 +382,7 @@ def lib():
     assert L.set_sizeof_pack_bf16_desc() == C.sizeof(SetPackBf16Desc), "SetPackBf16Desc ABI mismatch"
     assert L.set_sizeof_attn_bwd_args() == C.sizeof(SetAttnBwdArgs), "SetAttnBwdArgs ABI mismatch"
     assert L.set_sizeof_diffnet_layer_bf16_args() == C.sizeof(SetDiffnetLayerBf16Args), "SetDiffnetLayerBf16Args ABI mismatch"
+    assert L.set_sizeof_diffnet_layers_bf16_args() == C.sizeof(SetDiffnetLayersBf16Args), "SetDiffnetLayersBf16Args ABI mismatch"
     assert L.set_sizeof_diffnet_layer_bf16_bwd_args() == C.sizeof(SetDiffnetLayerBf16BwdArgs), "SetDiffnetLayerBf16BwdArgs ABI mismatch"
     _lib = L
     return L

@@ -1941,8 +1941,30 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
             sa.B = Bg; sa.T = T; sa.L = L; sa.dilation_cycle_length = a.dilation_cycle_length;
             rc = set_diffnet_stack(&sa, s);
         }
-        for (int l = 0; l < L && rc == SET_OK && bf16_loop; ++l) {
-            // opt-in bf16-operand layers (csrc/diffnet_bf16.hip): conditioner projection inside the layer GEMM
+        // opt-in bf16-operand layers, `fuse` per launch when the workspace is there (csrc/diffnet_bf16.hip: the tile stays on chip
+        // between the layers of a group)
+        int fuse = 1;
+        if (bf16_loop && a.bf16_ws && a.dilation_cycle_length <= 2) {
+            fuse = 4;
+            if (const char *e = getenv("SET_AMD_BF16_FUSE")) fuse = atoi(e) < 1 ? 1 : (atoi(e) > 8 ? 8 : atoi(e));
+            if (fuse > 1 && a.bf16_ws_floats < set_diffnet_layers_bf16_scratch_floats(a.B, T, 0, fuse, a.dilation_cycle_length)) fuse = 1;
+        }
+        for (int l = 0; l < L && rc == SET_OK && bf16_loop && fuse > 1; l += fuse) {
+            SetDiffnetLayersBf16Args fa = {};
+            fa.x_in = cur; fa.x_out = nxt; fa.skip = ws_skip;
+            fa.cond = a.cond + (int64_t)b0 * 192 * T;
+            fa.dstep = a.dstep + sid; fa.d_bs = 0; fa.d_cs = a.steps; fa.d_ls = (int64_t)DC * a.steps;
+            fa.img = reinterpret_cast<const uint16_t *>(a.img16_all) + (int64_t)l * set_diffnet_layer_bf16_image_size();
+            fa.b_dil = a.b_dil_all + (int64_t)l * 512; fa.b_cond = a.b_cond_all + (int64_t)l * 512; fa.b_out = a.b_out_all + (int64_t)l * 512;
+            fa.scratch = a.bf16_ws + (int64_t)b0 * (set_diffnet_layers_bf16_scratch_floats(1, T, 0, fuse, a.dilation_cycle_length));
+            fa.scratch_floats = a.bf16_ws_floats - (int64_t)b0 * (set_diffnet_layers_bf16_scratch_floats(1, T, 0, fuse, a.dilation_cycle_length));
+            fa.B = Bg; fa.T = T; fa.l0 = l; fa.nl = L - l < fuse ? L - l : fuse; fa.dilation_cycle_length = a.dilation_cycle_length;
+            fa.first = (l == 0);
+            rc = set_diffnet_layers_fwd_bf16(&fa, s);
+            float *tmp = cur; cur = nxt; nxt = tmp;
+        }
+        for (int l = 0; l < L && rc == SET_OK && bf16_loop && fuse == 1; ++l) {
+            // one launch per layer: conditioner projection inside the layer GEMM
             SetDiffnetLayerBf16Args la = {};
             la.x_in = cur; la.x_out = nxt; la.skip = ws_skip;
             la.cond = a.cond + (int64_t)b0 * 192 * T;

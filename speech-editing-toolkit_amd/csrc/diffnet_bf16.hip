@@ -409,6 +409,226 @@ __global__ void __launch_bounds__(NT * 4, NT == 128 ? 1 : 2) diffnet_layer_fwd_b
 
 
 // =====================================================================================================================
+// Several residual layers per launch (inference).  One launch per layer streams x (1024 B per frame), the conditioner (768),
+// x' (1024) and the running skip sum (2048, read-modify-write) through HBM for ~17 us of MFMA work per tile, and the HBM phases
+// of all 224 blocks coincide (one block per CU): 55 us per layer, 28 % of the HBM peak.  Here a block keeps its tile ON CHIP for
+// NL consecutive layers: x is loaded once, the conditioner tile once (every layer projects the SAME conditioner), the layer
+// output goes straight back into the LDS operand tile, and only the block's private fp32 copy of x' (the residual chain) and
+// its slice of the skip sum go through memory between the layers -- L2 / Infinity-Cache traffic of the same CU, no other block
+// reads it.  Price: a tile of 128 computed frames yields 128 - 2 H valid ones, H = sum of the dilations of layers 1 .. NL - 1
+// (frames whose receptive field left the tile are recomputed by the neighbour): 122 of 128 for four layers of dilation 1.
+//   compute frames of the tile: ts + j, j < 128, ts = tile * NV - H;  stored: the NV frames from ts + H on
+//   xs row j of layer m <-> frame ts - d_m + j   (d_m halo rows on either side; beyond the loaded / computed frames: garbage that
+//   only ever reaches frames outside the stored range)
+// Same arithmetic per frame as diffnet_layer_fwd_bf16_kernel (same images, same k order, same rounding points).
+// =====================================================================================================================
+struct LayersArgs {
+    SetDiffnetLayersBf16Args a;
+    int hh, nv;  // halo H and valid frames per tile
+};
+
+__global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersArgs la) {
+    const SetDiffnetLayersBf16Args &a = la.a;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int NT = FNT, NCB = NT / 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y, T = a.T;
+    const int tv0 = blockIdx.x * la.nv, ts = tv0 - la.hh;  // first stored / first computed frame
+    const int tv1 = min(tv0 + la.nv, T);                    // end of the stored range
+    int dmax = 1;
+    for (int m = 0; m < a.nl; ++m) dmax = max(dmax, 1 << ((a.l0 + m) % a.dilation_cycle_length));
+    const int XROWS_MAX = NT + 2 * dmax;
+    unsigned char *xs = lds;                       // [XROWS_MAX][XR]
+    unsigned char *cs = lds + XROWS_MAX * XR;      // [NT][CR]
+    float *dsh = reinterpret_cast<float *>(lds + XROWS_MAX * XR + NT * CR);  // [nl][256] step offsets
+    const unsigned T4 = 4u * (unsigned)T;
+    const rsrc_t rx = make_rsrc(a.x_in + (int64_t)b * FC * T), rxo = make_rsrc(a.x_out + (int64_t)b * FC * T);
+    const rsrc_t rsk = make_rsrc(a.skip + (int64_t)b * FC * T), rcd = make_rsrc(a.cond + (int64_t)b * FH * T);
+    float *priv = a.scratch + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (FC * NT);  // [256][128] fp32: x' between the layers
+    const rsrc_t rpx = make_rsrc(priv);
+    const unsigned lane16 = 16u * (unsigned)lane;
+    auto row0 = [&](int rb) { return (rb ? FC : 0) + 32 * w; };
+    auto aoff1 = [&](int ks, int rb) { return (unsigned)(((w * KS1 + ks) * 2 + rb) * 1024); };
+    auto aoff2 = [&](int ks, int rb) { return (unsigned)(((w * KS2 + ks) * 2 + rb) * 1024); };
+
+    // ---- stage: step offsets of every fused layer, x + d_0 (halo d of layer 0), the conditioner tile
+    {
+        for (int i = tid; i < a.nl * FC; i += 512) {
+            const int m = i >> 8, c = i & 255;
+            dsh[i] = a.dstep[(int64_t)(a.l0 + m) * a.d_ls + (int64_t)b * a.d_bs + (int64_t)c * a.d_cs];
+        }
+        const int d = 1 << (a.l0 % a.dilation_cycle_length);
+        const int f = tid % NT, cg = __builtin_amdgcn_readfirstlane(tid / NT);  // cg 0..3
+        const int t = ts - d + f;
+        const bool tvx = t >= 0 && t < T;
+        const unsigned vox = 4u * (unsigned)min(max(t, 0), T - 1);
+        const int tcn = ts + f;
+        const bool tvc = tcn >= 0 && tcn < T;
+        const unsigned voc = 4u * (unsigned)min(max(tcn, 0), T - 1);
+        float vx[64], vc[48];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) vx[k] = buf_load(rx, vox, (unsigned)(64 * cg + k) * T4);
+#pragma unroll
+        for (int k = 0; k < 48; ++k) vc[k] = buf_load(rcd, voc, (unsigned)(48 * cg + k) * T4);
+        // rows beyond layer 0's tile (layers with a larger dilation address up to XROWS_MAX rows): finite filler
+        for (int i = tid; i < (XROWS_MAX - (NT + 2 * d)) * (XR / 16); i += 512)
+            *reinterpret_cast<u32x4_t *>(xs + (NT + 2 * d) * XR + i * 16) = (u32x4_t){0u, 0u, 0u, 0u};
+        __syncthreads();  // dsh
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dsh + 64 * cg + 8 * q);
+            const f32x4 d1 = *reinterpret_cast<const f32x4 *>(dsh + 64 * cg + 8 * q + 4);
+            u32x4_t u;
+            u[0] = tvx ? pack2(vx[8 * q + 0] + d0[0], vx[8 * q + 1] + d0[1]) : 0u;
+            u[1] = tvx ? pack2(vx[8 * q + 2] + d0[2], vx[8 * q + 3] + d0[3]) : 0u;
+            u[2] = tvx ? pack2(vx[8 * q + 4] + d1[0], vx[8 * q + 5] + d1[1]) : 0u;
+            u[3] = tvx ? pack2(vx[8 * q + 6] + d1[2], vx[8 * q + 7] + d1[3]) : 0u;
+            *reinterpret_cast<u32x4_t *>(xs + f * XR + (64 * cg + 8 * q) * 2) = u;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            u32x4_t u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = tvc ? pack2(vc[8 * q + 2 * e], vc[8 * q + 2 * e + 1]) : 0u;
+            *reinterpret_cast<u32x4_t *>(cs + f * CR + (48 * cg + 8 * q) * 2) = u;
+        }
+        if (f < 2 * d) {
+            const int j = NT + f, th = ts - d + j;
+            const bool tvh = th >= 0 && th < T;
+            const unsigned voh = 4u * (unsigned)min(max(th, 0), T - 1);
+            float vh[64];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) vh[k] = buf_load(rx, voh, (unsigned)(64 * cg + k) * T4);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                u32x4_t u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    u[e] = tvh ? pack2(vh[8 * q + 2 * e] + dsh[64 * cg + 8 * q + 2 * e], vh[8 * q + 2 * e + 1] + dsh[64 * cg + 8 * q + 2 * e + 1]) : 0u;
+                *reinterpret_cast<u32x4_t *>(xs + j * XR + (64 * cg + 8 * q) * 2) = u;
+            }
+        }
+    }
+    // per column block: frame of this lane, whether it lies inside the utterance, whether it is stored
+    bool inT[NCB], st[NCB];
+    unsigned vo4[NCB], vop[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int t = ts + cb * 32 + l31;
+        inT[cb] = t >= 0 && t < T;
+        st[cb] = t >= tv0 && t < tv1;
+        vo4[cb] = 4u * (unsigned)(4 * half * T + min(max(t, 0), T - 1));
+        vop[cb] = 4u * (unsigned)(4 * half * NT + cb * 32 + l31);
+    }
+    const unsigned lb = 16u * (unsigned)half;
+
+    for (int m = 0; m < a.nl; ++m) {
+        const int l = a.l0 + m, d = 1 << (l % a.dilation_cycle_length);
+        const bool last = m == a.nl - 1;
+        const unsigned short *img = reinterpret_cast<const unsigned short *>(a.img) + (int64_t)m * N_IMG;
+        const rsrc_t rw1 = make_rsrc(img), rw2 = make_rsrc(img + OFF_W2B);
+        const rsrc_t rbd = make_rsrc(a.b_dil + (int64_t)m * 512), rbc = make_rsrc(a.b_cond + (int64_t)m * 512);
+        const rsrc_t rbo = make_rsrc(a.b_out + (int64_t)m * 512);
+        const int XROWS = NT + 2 * d;
+        f32x16 acc[2][NCB];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned ur = (unsigned)(row0(rb) + urow(r));
+                const float bias = buf_load(rbd, lb, 4u * ur) + buf_load(rbc, lb, 4u * ur);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = bias;
+            }
+        __syncthreads();  // the x tile of this layer (staged above / written by the previous layer's epilogue) is complete
+
+        // ---- GEMM 1: y = [Wcond | Wdil tap 0 | tap 1 | tap 2] x [cond ; x + d shifted]
+        gemm_bf16_a<2, NCB>(acc, rw1, lane16, KS_C, lds, aoff1, [&](int ks, int cb) {
+            return (unsigned)(XROWS_MAX * XR + (cb * 32 + l31) * CR + (ks * 16 + half * 8) * 2);
+        });
+        gemm_bf16_a<2, NCB>(acc, rw1, lane16, 3 * KS_T, lds, [&](int ks, int rb) { return aoff1(KS_C + ks, rb); },
+                            [&](int ks, int cb) {
+            const int tap = ks >> 4, c0 = (ks & 15) * 16;
+            return (unsigned)((cb * 32 + l31 + tap * d) * XR + (c0 + half * 8) * 2);
+        });
+
+        // ---- gate; residual rows of x: from HBM for the first fused layer, from the block's private copy afterwards
+        float xres[NCB][16];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                xres[cb][r] = m == 0 ? buf_load(rx, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4)
+                                     : buf_load(rpx, vop[cb], (unsigned)(row0(0) + urow(r)) * (4u * NT));
+        __syncthreads();  // every wave is done reading the x tile
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float yg = acc[0][cb][r], yf = acc[1][cb][r];
+                const float z = inT[cb] ? fsig(yg) * ftanh(yf) : 0.0f;
+                *reinterpret_cast<unsigned short *>(xs + (cb * 32 + l31) * XR + (row0(0) + urow(r) + 4 * half) * 2) = f2bf(z);
+            }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bias = buf_load(rbo, lb, 4u * (unsigned)(row0(rb) + urow(r)));
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = rb == 0 ? bias + xres[cb][r] : bias;
+            }
+        __syncthreads();
+
+        // ---- GEMM 2: o = Wout z  (z tile row j <-> frame ts + j)
+        gemm_bf16_a<2, NCB>(acc, rw2, lane16, KS2, lds, aoff2, [&](int ks, int cb) {
+            return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2);
+        });
+
+        // ---- epilogue: x' = (x + o_res) / sqrt 2 -> private fp32 copy + operand tile of the next layer, or the output tensor
+        __syncthreads();  // every wave is done reading the z tile: the next layer's x tile goes over it
+        if (!last) {
+            const int dn = 1 << ((l + 1) % a.dilation_cycle_length);
+            const float *dnx = dsh + (m + 1) * FC;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = row0(0) + urow(r) + 4 * half;
+                    const float xn = acc[0][cb][r] * RSQRT2;
+                    buf_store(xn, rpx, vop[cb], (unsigned)(row0(0) + urow(r)) * (4u * NT));
+                    *reinterpret_cast<unsigned short *>(xs + (dn + cb * 32 + l31) * XR + ch * 2) = inT[cb] ? f2bf(xn + dnx[ch]) : (unsigned short)0;
+                }
+        } else {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                if (st[cb]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) buf_store(acc[0][cb][r] * RSQRT2, rxo, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
+                }
+            }
+        }
+        // running skip sum of the stored frames (this block's slice only: L2-hot between the layers of a launch)
+        const bool first = a.first != 0 && m == 0;
+        float sk[NCB][16];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load(rsk, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            if (st[cb]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    buf_store(first ? acc[1][cb][r] : acc[1][cb][r] + sk[cb][r], rsk, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the private x' rows are re-read by the same lanes in the next layer)
+    }
+}
+
+// =====================================================================================================================
 // backward.  Tile = 128 frames [ts, ts + 128), ts = tile * (128 - 2 dil) - dil: dz / dy are computed for all 128 frames,
 // dx / dcond / the stored dy, d_o and the bias partial sums for the central 128 - 2 dil (the halo frames are recomputed by
 // the neighbouring tiles).  LDS: one [128 + 2 dil][512] bf16 tile (tile row j lives in LDS row j + dil, so the +-dil
@@ -683,6 +903,55 @@ extern "C" int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, v
         else hipLaunchKernelGGL((diffnet_layer_fwd_bf16_kernel<false, 64>), grid, dim3(256), ldsz, st, a);
     }
     return set_check_launch("set_diffnet_layer_fwd_bf16");
+}
+
+static int layers_halo(int l0, int nl, int dcl) {
+    int h = 0;
+    for (int m = 1; m < nl; ++m) h += 1 << ((l0 + m) % dcl);
+    return h;
+}
+
+extern "C" int64_t set_sizeof_diffnet_layers_bf16_args(void) { return (int64_t)sizeof(SetDiffnetLayersBf16Args); }
+
+extern "C" int64_t set_diffnet_layers_bf16_scratch_floats(int32_t B, int32_t T, int32_t l0, int32_t nl, int32_t dcl) {
+    // (an upper bound over the groups of a network: the halo of the worst first layer for this group size, so that one buffer
+    // serves every group and every utterance slice starts at a multiple of the per-utterance size)
+    if (B < 1 || T < 1 || nl < 1 || dcl < 1 || l0 < 0) return 0;
+    int hmax = 0;
+    for (int s0 = 0; s0 < dcl; ++s0) { const int h = layers_halo(s0, nl, dcl); hmax = h > hmax ? h : hmax; }
+    const int nv = FNT - 2 * hmax;
+    if (nv < 32) return 0;
+    return (int64_t)B * ((T + nv - 1) / nv) * FC * FNT;
+}
+
+extern "C" int set_diffnet_layers_fwd_bf16(const SetDiffnetLayersBf16Args *args, void *stream) {
+    SET_REQUIRE(args != nullptr, "set_diffnet_layers_fwd_bf16");
+    LayersArgs la;
+    la.a = *args;
+    const SetDiffnetLayersBf16Args &a = la.a;
+    SET_REQUIRE(a.x_in && a.x_out && a.x_in != a.x_out && a.skip && a.cond && a.dstep && a.img && a.b_dil && a.b_cond && a.b_out && a.scratch,
+                "set_diffnet_layers_fwd_bf16");
+    SET_REQUIRE(a.B > 0 && a.T > 0 && a.nl >= 1 && a.nl <= 8 && a.l0 >= 0 && a.dilation_cycle_length >= 1 && a.dilation_cycle_length <= 4,
+                "set_diffnet_layers_fwd_bf16");
+    SET_REQUIRE((int64_t)2 * FC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_layers_fwd_bf16 (T too large)");
+    la.hh = layers_halo(a.l0, a.nl, a.dilation_cycle_length);
+    la.nv = FNT - 2 * la.hh;
+    if (la.nv < 32) return set_fail(SET_E_UNSUPPORTED, "set_diffnet_layers_fwd_bf16", "halo of the fused layers leaves fewer than 32 valid frames per tile");
+    SET_REQUIRE(a.scratch_floats >= set_diffnet_layers_bf16_scratch_floats(a.B, a.T, a.l0, a.nl, a.dilation_cycle_length),
+                "set_diffnet_layers_fwd_bf16 (scratch too small)");
+    int dmax = 1;
+    for (int m = 0; m < a.nl; ++m) { const int d = 1 << ((a.l0 + m) % a.dilation_cycle_length); dmax = d > dmax ? d : dmax; }
+    const size_t ldsz = (size_t)(FNT + 2 * dmax) * XR + (size_t)FNT * CR + (size_t)a.nl * FC * sizeof(float);
+    if (ldsz > 160 * 1024) return set_fail(SET_E_UNSUPPORTED, "set_diffnet_layers_fwd_bf16", "tiles do not fit LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layers_fwd_bf16_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layers fwd bf16 attr");
+        attr_set = true;
+    }
+    dim3 grid((a.T + la.nv - 1) / la.nv, a.B);
+    hipLaunchKernelGGL(diffnet_layers_fwd_bf16_kernel, grid, dim3(512), ldsz, (hipStream_t)stream, la);
+    return set_check_launch("set_diffnet_layers_fwd_bf16");
 }
 
 extern "C" int64_t set_sizeof_diffnet_layer_bf16_bwd_args(void) { return (int64_t)sizeof(SetDiffnetLayerBf16BwdArgs); }

@@ -478,3 +478,61 @@ def test_batch_repack_equals_per_weight_packs(dev):
         torch.cuda.synchronize()
         assert torch.equal(im.view(torch.int16), fresh.view(torch.int16))
         assert cw.packed_bf16().data_ptr() == ptr     # current: no re-pack, same storage
+
+
+@pytest.mark.parametrize("B,T,L_,dcl,fuse", [(2, 800, 8, 1, 4), (3, 333, 7, 1, 4), (2, 500, 6, 2, 3), (1, 97, 5, 1, 5), (2, 128, 4, 2, 2)])
+def test_fused_layer_groups_equal_one_launch_per_layer(dev, B, T, L_, dcl, fuse):
+    """set_diffnet_layers_fwd_bf16 (the tile stays on chip for `fuse` consecutive layers, 128 - 2 H stored frames per tile) against
+    one set_diffnet_layer_fwd_bf16 launch per layer on the same images: same arithmetic per frame -> x and the skip sum are
+    bit-identical, incl. ragged T (partial last tile), a group shorter than `fuse` at the end, dilation cycles."""
+    import ctypes as C
+    from set_amd import _lib
+    Lb = _lib.lib()
+    g = torch.Generator().manual_seed(B * 1000 + T + L_)
+    n_img = Lb.set_diffnet_layer_bf16_image_size()
+    imgs = torch.empty(L_, n_img, dtype=torch.bfloat16, device=dev)
+    for l in range(L_):
+        wd = (torch.randn(512, 256, 3, generator=g) * 0.03).to(dev)
+        wc = (torch.randn(512, 192, generator=g) * 0.05).to(dev)
+        wo = (torch.randn(512, 256, generator=g) * 0.05).to(dev)
+        _lib.check(Lb.set_pack_diffnet_layer_bf16(wd.data_ptr(), wc.data_ptr(), wo.data_ptr(), imgs[l].data_ptr(), None), "pack")
+    x0 = torch.randn(B, 256, T, generator=g).to(dev)
+    cond = torch.randn(B, 192, T, generator=g).to(dev)
+    dstep = (torch.randn(L_, B, 256, generator=g) * 0.3).to(dev)
+    bd, bc, bo = ((torch.randn(L_, 512, generator=g) * 0.1).to(dev) for _ in range(3))
+
+    def per_layer():
+        cur, nxt, skip = x0.clone(), torch.empty_like(x0), torch.full_like(x0, float("nan"))
+        a = _lib.SetDiffnetLayerBf16Args()
+        for l in range(L_):
+            a.x_in, a.x_out, a.skip, a.cond = cur.data_ptr(), nxt.data_ptr(), skip.data_ptr(), cond.data_ptr()
+            a.dstep, a.img = dstep[l].data_ptr(), imgs[l].data_ptr()
+            a.b_dil, a.b_cond, a.b_out = bd[l].data_ptr(), bc[l].data_ptr(), bo[l].data_ptr()
+            a.d_bs, a.d_cs, a.B, a.T, a.dil, a.first = 256, 1, B, T, 1 << (l % dcl), int(l == 0)
+            _lib.check(Lb.set_diffnet_layer_fwd_bf16(C.byref(a), None), "layer")
+            cur, nxt = nxt, cur
+        return cur, skip
+
+    def fused():
+        cur, nxt, skip = x0.clone(), torch.full_like(x0, float("nan")), torch.full_like(x0, float("nan"))
+        n_ws = Lb.set_diffnet_layers_bf16_scratch_floats(B, T, 0, fuse, dcl)
+        assert n_ws > 0
+        ws = torch.full((n_ws,), float("nan"), device=dev)
+        a = _lib.SetDiffnetLayersBf16Args()
+        for l in range(0, L_, fuse):
+            a.x_in, a.x_out, a.skip, a.cond = cur.data_ptr(), nxt.data_ptr(), skip.data_ptr(), cond.data_ptr()
+            a.dstep, a.img = dstep.data_ptr(), imgs[l].data_ptr()
+            a.b_dil, a.b_cond, a.b_out = bd[l].data_ptr(), bc[l].data_ptr(), bo[l].data_ptr()
+            a.scratch, a.scratch_floats = ws.data_ptr(), n_ws
+            a.d_bs, a.d_cs, a.d_ls = 256, 1, B * 256
+            a.B, a.T, a.l0, a.nl, a.dilation_cycle_length, a.first = B, T, l, min(fuse, L_ - l), dcl, int(l == 0)
+            _lib.check(Lb.set_diffnet_layers_fwd_bf16(C.byref(a), None), "layers")
+            cur, nxt = nxt, cur
+        return cur, skip
+
+    x_ref, s_ref = per_layer()
+    x_f, s_f = fused()
+    torch.cuda.synchronize()
+    assert torch.isfinite(x_f).all() and torch.isfinite(s_f).all()
+    assert torch.equal(s_f, s_ref)
+    assert torch.equal(x_f, x_ref)
