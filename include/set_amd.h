@@ -425,8 +425,8 @@ typedef struct SetDiffLoopArgs {
     const float *cond;
     const void *img16_all;
     const float *b_cond_all;
-    /* optional workspace of the bf16 loop: with bf16_ws_floats >= set_diffnet_layers_bf16_scratch_floats(B, T, 0, 4,
-     * dilation_cycle_length) (and dilation_cycle_length <= 2) the layers run four per launch (set_diffnet_layers_fwd_bf16);
+    /* optional workspace of the bf16 loop: with bf16_ws_floats >= set_diffnet_layers_bf16_scratch_floats(B, T, 0, 5,
+     * dilation_cycle_length) (and dilation_cycle_length <= 2) the layers run five per launch (set_diffnet_layers_fwd_bf16);
      * NULL / too small: one launch per layer.  SET_AMD_BF16_FUSE=n overrides the group size (1 = per layer). */
     float *bf16_ws;
     int64_t bf16_ws_floats;

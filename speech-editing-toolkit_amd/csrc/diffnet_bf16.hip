@@ -446,7 +446,11 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
     const unsigned T4 = 4u * (unsigned)T;
     const rsrc_t rx = make_rsrc(a.x_in + (int64_t)b * FC * T), rxo = make_rsrc(a.x_out + (int64_t)b * FC * T);
     const rsrc_t rsk = make_rsrc(a.skip + (int64_t)b * FC * T), rcd = make_rsrc(a.cond + (int64_t)b * FH * T);
-    float *priv = a.scratch + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (FC * NT);  // [256][128] fp32: x' between the layers
+    // private memory of the block: the fp32 copy of x' between the layers ([256][128]; re-read by the lanes that wrote it).
+    // (Measured and dropped: the skip contributions of the layers parked next to it and summed by the last layer -- one HBM
+    // read-modify-write per group instead of one L2-hot one per layer: 53 -> 54 us per layer for groups of 4, 57 -> 66 for groups of
+    // 8; twice the stores per epilogue and a footprint that outgrows the L2.)
+    float *priv = a.scratch + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (FC * NT);
     const rsrc_t rpx = make_rsrc(priv);
     const unsigned lane16 = 16u * (unsigned)lane;
     auto row0 = [&](int rb) { return (rb ? FC : 0) + 32 * w; };
@@ -523,8 +527,19 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
         vop[cb] = 4u * (unsigned)(4 * half * NT + cb * 32 + l31);
     }
     const unsigned lb = 16u * (unsigned)half;
+    // debug (tools/bf16_phase_probe.py): thread 0 of block (1, 1) adds the s_memtime ticks of the phases of its layers m >= 1 to
+    // buf[0..4] (accumulator init + barrier, GEMM 1, gate, GEMM 2, epilogue) and counts them in buf[7]
+    uint64_t *const pb = (g_bf16_phase_buf && blockIdx.x == 1 && blockIdx.y == 1 && tid == 0) ? g_bf16_phase_buf : nullptr;
+    uint64_t tprev = 0;
+#define LF_PHASE(i)                                                   \
+    if (pb && m >= 1) {                                               \
+        const uint64_t tn = __builtin_amdgcn_s_memtime();             \
+        pb[i] += tn - tprev;                                          \
+        tprev = tn;                                                   \
+    }
 
     for (int m = 0; m < a.nl; ++m) {
+        if (pb) tprev = __builtin_amdgcn_s_memtime();
         const int l = a.l0 + m, d = 1 << (l % a.dilation_cycle_length);
         const bool last = m == a.nl - 1;
         const unsigned short *img = reinterpret_cast<const unsigned short *>(a.img) + (int64_t)m * N_IMG;
@@ -543,6 +558,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
                 for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = bias;
             }
         __syncthreads();  // the x tile of this layer (staged above / written by the previous layer's epilogue) is complete
+        LF_PHASE(0)
 
         // ---- GEMM 1: y = [Wcond | Wdil tap 0 | tap 1 | tap 2] x [cond ; x + d shifted]
         gemm_bf16_a<2, NCB>(acc, rw1, lane16, KS_C, lds, aoff1, [&](int ks, int cb) {
@@ -554,8 +570,10 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
             return (unsigned)((cb * 32 + l31 + tap * d) * XR + (c0 + half * 8) * 2);
         });
 
+        LF_PHASE(1)
         // ---- gate; residual rows of x: from HBM for the first fused layer, from the block's private copy afterwards
         float xres[NCB][16];
+        if (m > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the x' rows this lane stored in the previous epilogue are in memory
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -563,13 +581,17 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
                 xres[cb][r] = m == 0 ? buf_load(rx, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4)
                                      : buf_load(rpx, vop[cb], (unsigned)(row0(0) + urow(r)) * (4u * NT));
         __syncthreads();  // every wave is done reading the x tile
+        typedef unsigned lf_u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float yg = acc[0][cb][r], yf = acc[1][cb][r];
-                const float z = inT[cb] ? fsig(yg) * ftanh(yf) : 0.0f;
-                *reinterpret_cast<unsigned short *>(xs + (cb * 32 + l31) * XR + (row0(0) + urow(r) + 4 * half) * 2) = f2bf(z);
+            for (int g4 = 0; g4 < 4; ++g4) {  // registers 4 g4 .. 4 g4 + 3 are 4 consecutive channels: one 8-byte write
+                float z[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = inT[cb] ? fsig(acc[0][cb][4 * g4 + e]) * ftanh(acc[1][cb][4 * g4 + e]) : 0.0f;
+                lf_u32x2 u;
+                u[0] = pack2(z[0], z[1]); u[1] = pack2(z[2], z[3]);
+                *reinterpret_cast<lf_u32x2 *>(xs + (cb * 32 + l31) * XR + (row0(0) + 8 * g4 + 4 * half) * 2) = u;
             }
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
@@ -580,26 +602,35 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
                 for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = rb == 0 ? bias + xres[cb][r] : bias;
             }
         __syncthreads();
+        LF_PHASE(2)
 
         // ---- GEMM 2: o = Wout z  (z tile row j <-> frame ts + j)
         gemm_bf16_a<2, NCB>(acc, rw2, lane16, KS2, lds, aoff2, [&](int ks, int cb) {
             return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2);
         });
 
+        LF_PHASE(3)
         // ---- epilogue: x' = (x + o_res) / sqrt 2 -> private fp32 copy + operand tile of the next layer, or the output tensor
         __syncthreads();  // every wave is done reading the z tile: the next layer's x tile goes over it
         if (!last) {
             const int dn = 1 << ((l + 1) % a.dilation_cycle_length);
             const float *dnx = dsh + (m + 1) * FC;
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
+            for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ch = row0(0) + urow(r) + 4 * half;
-                    const float xn = acc[0][cb][r] * RSQRT2;
-                    buf_store(xn, rpx, vop[cb], (unsigned)(row0(0) + urow(r)) * (4u * NT));
-                    *reinterpret_cast<unsigned short *>(xs + (dn + cb * 32 + l31) * XR + ch * 2) = inT[cb] ? f2bf(xn + dnx[ch]) : (unsigned short)0;
+                    buf_store(acc[0][cb][r] * RSQRT2, rpx, vop[cb], (unsigned)(row0(0) + urow(r)) * (4u * NT));
                 }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int ch = row0(0) + 8 * g4 + 4 * half;
+                    const f32x4 dv = *reinterpret_cast<const f32x4 *>(dnx + ch);
+                    lf_u32x2 u;
+                    u[0] = inT[cb] ? pack2(acc[0][cb][4 * g4] * RSQRT2 + dv[0], acc[0][cb][4 * g4 + 1] * RSQRT2 + dv[1]) : 0u;
+                    u[1] = inT[cb] ? pack2(acc[0][cb][4 * g4 + 2] * RSQRT2 + dv[2], acc[0][cb][4 * g4 + 3] * RSQRT2 + dv[3]) : 0u;
+                    *reinterpret_cast<lf_u32x2 *>(xs + (dn + cb * 32 + l31) * XR + ch * 2) = u;
+                }
+            }
         } else {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
@@ -609,7 +640,8 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
                 }
             }
         }
-        // running skip sum of the stored frames (this block's slice only: L2-hot between the layers of a launch)
+        // running skip sum of the stored frames (this block's slice only: L2-hot between the layers of a launch; the stores of the
+        // previous layer completed before this layer's residual loads, see the wait there)
         const bool first = a.first != 0 && m == 0;
         float sk[NCB][16];
 #pragma unroll
@@ -624,8 +656,10 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
                     buf_store(first ? acc[1][cb][r] : acc[1][cb][r] + sk[cb][r], rsk, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the private x' rows are re-read by the same lanes in the next layer)
+        LF_PHASE(4)
+        if (pb && m >= 1) pb[7] += 1;
     }
+#undef LF_PHASE
 }
 
 // =====================================================================================================================
@@ -921,7 +955,7 @@ extern "C" int64_t set_diffnet_layers_bf16_scratch_floats(int32_t B, int32_t T, 
     for (int s0 = 0; s0 < dcl; ++s0) { const int h = layers_halo(s0, nl, dcl); hmax = h > hmax ? h : hmax; }
     const int nv = FNT - 2 * hmax;
     if (nv < 32) return 0;
-    return (int64_t)B * ((T + nv - 1) / nv) * FC * FNT;
+    return (int64_t)B * ((T + nv - 1) / nv) * FC * FNT;  // per block: the fp32 copy of x' 
 }
 
 extern "C" int set_diffnet_layers_fwd_bf16(const SetDiffnetLayersBf16Args *args, void *stream) {

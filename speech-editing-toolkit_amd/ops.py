@@ -837,8 +837,10 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs,
     a.dstep, a.coef4 = dstep.data_ptr(), coef4.data_ptr()
     if bf16 is not None:
         a.cond, a.img16_all, a.b_cond_all = _f(bf16["cond"]).data_ptr(), bf16["imgs"].data_ptr(), _f(bf16["b_cond"]).data_ptr()
-        # workspace of the four-layers-per-launch kernel (a block's private fp32 copy of x' between its layers)
-        n_ws = _lib.lib().set_diffnet_layers_bf16_scratch_floats(B, T, 0, 4, dilation_cycle_length) if dilation_cycle_length <= 2 else 0
+        # workspace of the several-layers-per-launch kernel (a block's private fp32 copy of x' between its layers); sized for
+        # the smallest tiles any group size up to 8 produces
+        n_ws = max(_lib.lib().set_diffnet_layers_bf16_scratch_floats(B, T, 0, n, dilation_cycle_length) for n in range(2, 9)) \
+            if dilation_cycle_length <= 2 else 0
         if n_ws > 0:
             bf16_ws = torch.empty(n_ws, dtype=torch.float32, device=dev)  # noqa: F841 (kept alive until the loop is enqueued: stream-ordered free)
             a.bf16_ws, a.bf16_ws_floats = bf16_ws.data_ptr(), n_ws
