@@ -626,8 +626,9 @@ def test_step_projections_of_all_layers_equal_the_per_layer_linears(dev, L_, Cc,
     hd = h.detach().cpu().double().requires_grad_(True)
     wd = [w.detach().cpu().double().requires_grad_(True) for w in ws]
     bd = [b.detach().cpu().double().requires_grad_(True) for b in bs]
-    want = torch.cat([F.linear(hd[0].t(), wd[l], bd[l]) for l in range(L_)], dim=1)
-    want.backward(gy.cpu().double())
+    with torch.enable_grad():  # (other test modules switch the global grad mode off)
+        want = torch.cat([F.linear(hd[0].t(), wd[l], bd[l]) for l in range(L_)], dim=1)
+        want.backward(gy.cpu().double())
     assert _rel(out, want.float()) < 1e-5
     assert _rel(h.grad, hd.grad.float()) < 1e-5
     for l in range(L_):
