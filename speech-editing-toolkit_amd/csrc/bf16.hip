@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_bf16_kernel(SetConv1dArgs a, in
     conv_bf16_epilogue<WM, WN>(a, acc, b, t0, r0, wm, wn, half, l31);
 }
 
-// ---- 1x1 conv with at most 256 input channels, the whole input tile in one round trip ------------------------------------------------
+// ---- 1x1 conv, the input tile in one round trip per 256 input channels ----------------------------------------------------------------
 // The 1x1 convs of the FFT / transformer blocks (attention projections, 192 or 256 channels, 12,800 - 25,600 frames) are ~200 blocks of
 // a few MFMAs each: in the staged kernel above a block walks Cin / 64 stages of load -> convert -> barrier -> 16 MFMAs -> barrier with
 // one stage of loads in flight, i.e. it spends its life in 3 - 4 dependent memory round trips (22 - 31 us per conv against 4 - 10 us of
@@ -348,8 +348,8 @@ template <int CINP>
 __global__ void __launch_bounds__(256, 2) conv1x1_oneshot_bf16_kernel(SetConv1dArgs a, int CoutP, int nchunk32) {
     constexpr int WM = 2, WN = 2, NB = 128;
     constexpr int ROWB = CINP * 2 + 16;  // bytes per frame row of the tile
-    constexpr int CPT = CINP / 2;        // channels per thread
-    constexpr int NKS = CINP / 16;       // k-steps
+    constexpr int CPT = CINP / 2;        // channels per thread (of one chunk of CINP channels)
+    constexpr int NKS = CINP / 16;       // k-steps per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char *Bs = smem_raw;        // [128][ROWB]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -360,48 +360,38 @@ __global__ void __launch_bounds__(256, 2) conv1x1_oneshot_bf16_kernel(SetConv1dA
     const unsigned short *wimg = reinterpret_cast<const unsigned short *>(a.w);
     const rsrc_t d_in = make_rsrc(a.in + (int64_t)b * a.in_bs);
     const int sf = tid & 127, scg = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int nchunks = (a.Cin + CINP - 1) / CINP;  // 1 for Cin <= CINP; wider inputs: chunks of CINP channels, one round trip each
+    const unsigned vo = (unsigned)min(t0 + sf, a.T_in - 1) * 4u;
+    const bool tv = t0 + sf < a.T_in;
 
     float pv[CPT];
-    {
-        const unsigned vo = (unsigned)min(t0 + sf, a.T_in - 1) * 4u;
+    auto issue = [&](int c0) {
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) pv[k] = buf_load(d_in, vo, (unsigned)(min(scg * CPT + k, a.Cin - 1) * (int)a.in_cs) * 4u);
-    }
-    // weight fragments: lane (row l31 of row block i, k-half `half`) of k-step ks reads 16 bytes of wp[chunk ks / 2][row][32]
+        for (int k = 0; k < CPT; ++k) pv[k] = buf_load(d_in, vo, (unsigned)(min(c0 + scg * CPT + k, a.Cin - 1) * (int)a.in_cs) * 4u);
+    };
+    // weight fragments: lane (row l31 of row block i, k-half `half`) of k-step ks (counted over the whole K) reads 16 bytes of
+    // wp[chunk ks / 2][row][32]   (k-steps beyond the image's last 32-channel chunk re-read it: their B rows are zero)
     const rsrc_t d_w = make_rsrc(wimg);
     auto a_off = [&](int ks, int i) {
-        // (k-steps beyond the image's last 32-channel chunk re-read it: their B rows are zero)
         return (unsigned)(((min(ks >> 1, nchunk32 - 1) * CoutP + r0 + wm * 64 + i * 32 + l31) * 32 + (ks & 1) * 16 + half * 8) * 2);
     };
     constexpr int RING = NKS < 4 ? NKS : 4;
     u32x4 A[RING][2];
-#pragma unroll
-    for (int q = 0; q < RING; ++q)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) A[q][i] = __builtin_amdgcn_raw_buffer_load_b128(d_w, (int)a_off(q, i), 0, 0);
-
-    auto commit = [&](auto PROC) __attribute__((always_inline)) {
+    auto commit = [&](auto PROC, int c0) __attribute__((always_inline)) {
         constexpr int kPro = decltype(PROC)::value;
-        const bool tv = t0 + sf < a.T_in;
 #pragma unroll
         for (int q = 0; q < CPT / 8; ++q) {
             u32x4 u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v0 = pro_c<kPro>(pv[8 * q + 2 * e], a.pro_param), v1 = pro_c<kPro>(pv[8 * q + 2 * e + 1], a.pro_param);
-                v0 = (tv && scg * CPT + 8 * q + 2 * e < a.Cin) ? v0 : 0.0f;
-                v1 = (tv && scg * CPT + 8 * q + 2 * e + 1 < a.Cin) ? v1 : 0.0f;
+                v0 = (tv && c0 + scg * CPT + 8 * q + 2 * e < a.Cin) ? v0 : 0.0f;
+                v1 = (tv && c0 + scg * CPT + 8 * q + 2 * e + 1 < a.Cin) ? v1 : 0.0f;
                 u[e] = pack_bf16(v0, v1);
             }
             *reinterpret_cast<u32x4 *>(Bs + sf * ROWB + (scg * CPT + 8 * q) * 2) = u;
         }
     };
-    switch (a.pro) {
-        case SET_PRO_LRELU: commit(ic<SET_PRO_LRELU>{}); break;
-        case SET_PRO_DIV: commit(ic<SET_PRO_DIV>{}); break;
-        default: commit(ic<SET_PRO_NONE>{}); break;
-    }
-    __syncthreads();
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -409,19 +399,35 @@ __global__ void __launch_bounds__(256, 2) conv1x1_oneshot_bf16_kernel(SetConv1dA
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
     const unsigned char *bp = Bs + (wn * 64 + l31) * ROWB + half * 16;
+    issue(0);
+    for (int c = 0; c < nchunks; ++c) {
+        const int c0 = c * CINP, ks0 = c * NKS;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const u32x4 a0 = A[ks % RING][0], a1 = A[ks % RING][1];
-        if (ks + RING < NKS) {
+        for (int q = 0; q < RING; ++q)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) A[ks % RING][i] = __builtin_amdgcn_raw_buffer_load_b128(d_w, (int)a_off(ks + RING, i), 0, 0);
+            for (int i = 0; i < 2; ++i) A[q][i] = __builtin_amdgcn_raw_buffer_load_b128(d_w, (int)a_off(ks0 + q, i), 0, 0);
+        if (c > 0) __syncthreads();  // the MFMAs of the previous chunk are done with the tile
+        switch (a.pro) {
+            case SET_PRO_LRELU: commit(ic<SET_PRO_LRELU>{}, c0); break;
+            case SET_PRO_DIV: commit(ic<SET_PRO_DIV>{}, c0); break;
+            default: commit(ic<SET_PRO_NONE>{}, c0); break;
         }
-        const u32x4 b0 = *reinterpret_cast<const u32x4 *>(bp + ks * 32);
-        const u32x4 b1 = *reinterpret_cast<const u32x4 *>(bp + 32 * ROWB + ks * 32);
-        acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
-        acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
-        acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
-        acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+        __syncthreads();
+        if (c + 1 < nchunks) issue(c0 + CINP);  // the next chunk's loads fly under this chunk's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const u32x4 a0 = A[ks % RING][0], a1 = A[ks % RING][1];
+            if (ks + RING < NKS) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) A[ks % RING][i] = __builtin_amdgcn_raw_buffer_load_b128(d_w, (int)a_off(ks0 + ks + RING, i), 0, 0);
+            }
+            const u32x4 b0 = *reinterpret_cast<const u32x4 *>(bp + ks * 32);
+            const u32x4 b1 = *reinterpret_cast<const u32x4 *>(bp + 32 * ROWB + ks * 32);
+            acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
+            acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
+            acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
+            acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+        }
     }
     conv_bf16_epilogue<WM, WN>(a, acc, b, t0, r0, wm, wn, half, l31);
 }
@@ -921,13 +927,13 @@ int set_conv1d_bf16_dispatch(const SetConv1dArgs &a, hipStream_t s) {
     // 56 -> 45 us (768 -> 192) with 128-row blocks; the 9-tap convs keep the 64-row ones (146 vs 149 us)
     const bool narrow = a.Cout <= 64 || (a.Cout > 128 && a.Cout <= 192 && a.K > 1);
     static int oneshot = -1;
-    if (oneshot < 0) { const char *e = getenv("SET_AMD_BF16_ONESHOT"); oneshot = !(e && atoi(e) == 0); }
-    if (oneshot && a.K == 1 && a.Cin > 32 && a.Cin <= 256 && a.Cout > 64 && halo == 0 && !a.in_chan_add && a.pad == 0) {
+    if (oneshot < 0) { const char *e = getenv("SET_AMD_BF16_ONESHOT"); oneshot = e ? atoi(e) : 1; }
+    if (oneshot && a.K == 1 && a.Cin > 32 && a.Cout > 64 && halo == 0 && !a.in_chan_add && a.pad == 0) {
         const int cp = round_up_i(a.Cin, 32);
         if (cp <= 64) return launch_conv1x1_oneshot<64>(a, s);
         if (cp <= 128) return launch_conv1x1_oneshot<128>(a, s);
         if (cp <= 192) return launch_conv1x1_oneshot<192>(a, s);
-        return launch_conv1x1_oneshot<256>(a, s);
+        if (oneshot == 1 || cp <= 256) return launch_conv1x1_oneshot<256>(a, s);  // wider inputs: chunks of 256 channels (SET_AMD_BF16_ONESHOT=2: staged kernel)
     }
     if (a.K == 1 && a.Cin > 32 && halo == 0 && !a.in_chan_add) {
         return narrow ? launch_conv_bf16<1, 4, 64, 1, false, false>(a, lo, halo, s)
