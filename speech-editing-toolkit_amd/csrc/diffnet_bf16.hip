@@ -166,25 +166,25 @@ __global__ void __launch_bounds__(256) pack_layer_bf16_kernel(const float *wdil,
 // forward
 // =====================================================================================================================
 // acc[NRB][NCB] += A * B with a caller-supplied A address: aoff(ks, rb) = byte offset of the 1 KiB fragment block
-template <int NRB, int NCB, typename AF, typename BF>
+template <int NRB, int NCB, int PFD = PF, typename AF, typename BF>
 __device__ __forceinline__ void gemm_bf16_a(f32x16 (&acc)[NRB][NCB], rsrc_t img, unsigned lane16, int nks, const unsigned char *lds,
                                             AF aoff, BF bfrag) {
-    u32x4_t A[PF][NRB];
+    u32x4_t A[PFD][NRB];
 #pragma unroll
-    for (int p = 0; p < PF; ++p)
+    for (int p = 0; p < PFD; ++p)
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) A[p][rb] = buf_load_u4(img, lane16, aoff(min(p, nks - 1), rb));
-    for (int kb = 0; kb < nks; kb += PF) {
+    for (int kb = 0; kb < nks; kb += PFD) {
 #pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const int ks = kb + p;  // nks is a multiple of PF
+        for (int p = 0; p < PFD; ++p) {
+            const int ks = kb + p;  // nks is a multiple of PFD
             u32x4_t Bv[NCB];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) Bv[cb] = *reinterpret_cast<const u32x4_t *>(lds + bfrag(ks, cb));
             u32x4_t Ac[NRB];
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) Ac[rb] = A[p][rb];
-            const int kn = min(ks + PF, nks - 1);  // tail: harmless re-load of the last k-step
+            const int kn = min(ks + PFD, nks - 1);  // tail: harmless re-load of the last k-step
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) A[p][rb] = buf_load_u4(img, lane16, aoff(kn, rb));
             __builtin_amdgcn_s_setprio(1);
@@ -427,10 +427,18 @@ struct LayersArgs {
     int hh, nv;  // halo H and valid frames per tile
 };
 
-__global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersArgs la) {
+// NT = 128 (default): 8 waves, one 32-row gate block + its filter block per wave, one block per CU.  NT = 64 (experiment): 4 waves, two
+// gate blocks + their filter blocks per wave, 62 KB of LDS, two independent blocks per CU; the weight images are then streamed once
+// per 64 frames instead of once per 128 and a tile yields 64 - 2 H stored frames -- measured slower, see layers_tile().
+template <int NT>
+__global__ void __launch_bounds__(NT * 4, NT == 128 ? 1 : 2) diffnet_layers_fwd_bf16_kernel(LayersArgs la) {
     const SetDiffnetLayersBf16Args &a = la.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int NT = FNT, NCB = NT / 32;
+    constexpr int NW = NT / 16;   // waves per block
+    constexpr int RBW = 8 / NW;   // 32-row gate blocks per wave (and as many filter blocks)
+    constexpr int NCB = NT / 32;  // 32-frame column blocks
+    constexpr int NTH = NT * 4;   // threads
+    constexpr int PFD = NT == 128 ? PF : 2;  // A ring depth: 2 x RBW fragments per k-step
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -453,13 +461,14 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
     float *priv = a.scratch + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (FC * NT);
     const rsrc_t rpx = make_rsrc(priv);
     const unsigned lane16 = 16u * (unsigned)lane;
-    auto row0 = [&](int rb) { return (rb ? FC : 0) + 32 * w; };
-    auto aoff1 = [&](int ks, int rb) { return (unsigned)(((w * KS1 + ks) * 2 + rb) * 1024); };
-    auto aoff2 = [&](int ks, int rb) { return (unsigned)(((w * KS2 + ks) * 2 + rb) * 1024); };
+    // accumulator index rb = g * RBW + q: g = 0 gate / residual rows, 1 filter / skip rows; q-th 32-row block of the wave
+    auto row0 = [&](int rb) { return ((rb / RBW) ? FC : 0) + 32 * (RBW * w + (rb % RBW)); };
+    auto aoff1 = [&](int ks, int rb) { return (unsigned)((((RBW * w + (rb % RBW)) * KS1 + ks) * 2 + rb / RBW) * 1024); };
+    auto aoff2 = [&](int ks, int rb) { return (unsigned)((((RBW * w + (rb % RBW)) * KS2 + ks) * 2 + rb / RBW) * 1024); };
 
     // ---- stage: step offsets of every fused layer, x + d_0 (halo d of layer 0), the conditioner tile
     {
-        for (int i = tid; i < a.nl * FC; i += 512) {
+        for (int i = tid; i < a.nl * FC; i += NTH) {
             const int m = i >> 8, c = i & 255;
             dsh[i] = a.dstep[(int64_t)(a.l0 + m) * a.d_ls + (int64_t)b * a.d_bs + (int64_t)c * a.d_cs];
         }
@@ -477,7 +486,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
 #pragma unroll
         for (int k = 0; k < 48; ++k) vc[k] = buf_load(rcd, voc, (unsigned)(48 * cg + k) * T4);
         // rows beyond layer 0's tile (layers with a larger dilation address up to XROWS_MAX rows): finite filler
-        for (int i = tid; i < (XROWS_MAX - (NT + 2 * d)) * (XR / 16); i += 512)
+        for (int i = tid; i < (XROWS_MAX - (NT + 2 * d)) * (XR / 16); i += NTH)
             *reinterpret_cast<u32x4_t *>(xs + (NT + 2 * d) * XR + i * 16) = (u32x4_t){0u, 0u, 0u, 0u};
         __syncthreads();  // dsh
 #pragma unroll
@@ -547,9 +556,9 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
         const rsrc_t rbd = make_rsrc(a.b_dil + (int64_t)m * 512), rbc = make_rsrc(a.b_cond + (int64_t)m * 512);
         const rsrc_t rbo = make_rsrc(a.b_out + (int64_t)m * 512);
         const int XROWS = NT + 2 * d;
-        f32x16 acc[2][NCB];
+        f32x16 acc[2 * RBW][NCB];
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < 2 * RBW; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned ur = (unsigned)(row0(rb) + urow(r));
@@ -561,10 +570,10 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
         LF_PHASE(0)
 
         // ---- GEMM 1: y = [Wcond | Wdil tap 0 | tap 1 | tap 2] x [cond ; x + d shifted]
-        gemm_bf16_a<2, NCB>(acc, rw1, lane16, KS_C, lds, aoff1, [&](int ks, int cb) {
+        gemm_bf16_a<2 * RBW, NCB, PFD>(acc, rw1, lane16, KS_C, lds, aoff1, [&](int ks, int cb) {
             return (unsigned)(XROWS_MAX * XR + (cb * 32 + l31) * CR + (ks * 16 + half * 8) * 2);
         });
-        gemm_bf16_a<2, NCB>(acc, rw1, lane16, 3 * KS_T, lds, [&](int ks, int rb) { return aoff1(KS_C + ks, rb); },
+        gemm_bf16_a<2 * RBW, NCB, PFD>(acc, rw1, lane16, 3 * KS_T, lds, [&](int ks, int rb) { return aoff1(KS_C + ks, rb); },
                             [&](int ks, int cb) {
             const int tap = ks >> 4, c0 = (ks & 15) * 16;
             return (unsigned)((cb * 32 + l31 + tap * d) * XR + (c0 + half * 8) * 2);
@@ -572,40 +581,44 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
 
         LF_PHASE(1)
         // ---- gate; residual rows of x: from HBM for the first fused layer, from the block's private copy afterwards
-        float xres[NCB][16];
+        float xres[RBW][NCB][16];
         if (m > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the x' rows this lane stored in the previous epilogue are in memory
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
+        for (int q = 0; q < RBW; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                xres[cb][r] = m == 0 ? buf_load(rx, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4)
-                                     : buf_load(rpx, vop[cb], (unsigned)(row0(0) + urow(r)) * (4u * NT));
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    xres[q][cb][r] = m == 0 ? buf_load(rx, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4)
+                                            : buf_load(rpx, vop[cb], (unsigned)(row0(q) + urow(r)) * (4u * NT));
         __syncthreads();  // every wave is done reading the x tile
         typedef unsigned lf_u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
+        for (int q = 0; q < RBW; ++q)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {  // registers 4 g4 .. 4 g4 + 3 are 4 consecutive channels: one 8-byte write
-                float z[4];
+            for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) z[e] = inT[cb] ? fsig(acc[0][cb][4 * g4 + e]) * ftanh(acc[1][cb][4 * g4 + e]) : 0.0f;
-                lf_u32x2 u;
-                u[0] = pack2(z[0], z[1]); u[1] = pack2(z[2], z[3]);
-                *reinterpret_cast<lf_u32x2 *>(xs + (cb * 32 + l31) * XR + (row0(0) + 8 * g4 + 4 * half) * 2) = u;
-            }
+                for (int g4 = 0; g4 < 4; ++g4) {  // registers 4 g4 .. 4 g4 + 3 are 4 consecutive channels: one 8-byte write
+                    float z[4];
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+                    for (int e = 0; e < 4; ++e) z[e] = inT[cb] ? fsig(acc[q][cb][4 * g4 + e]) * ftanh(acc[RBW + q][cb][4 * g4 + e]) : 0.0f;
+                    lf_u32x2 u;
+                    u[0] = pack2(z[0], z[1]); u[1] = pack2(z[2], z[3]);
+                    *reinterpret_cast<lf_u32x2 *>(xs + (cb * 32 + l31) * XR + (row0(q) + 8 * g4 + 4 * half) * 2) = u;
+                }
+#pragma unroll
+        for (int rb = 0; rb < 2 * RBW; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float bias = buf_load(rbo, lb, 4u * (unsigned)(row0(rb) + urow(r)));
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = rb == 0 ? bias + xres[cb][r] : bias;
+                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = rb < RBW ? bias + xres[rb % RBW][cb][r] : bias;
             }
         __syncthreads();
         LF_PHASE(2)
 
         // ---- GEMM 2: o = Wout z  (z tile row j <-> frame ts + j)
-        gemm_bf16_a<2, NCB>(acc, rw2, lane16, KS2, lds, aoff2, [&](int ks, int cb) {
+        gemm_bf16_a<2 * RBW, NCB, PFD>(acc, rw2, lane16, KS2, lds, aoff2, [&](int ks, int cb) {
             return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2);
         });
 
@@ -616,46 +629,54 @@ __global__ void __launch_bounds__(512, 1) diffnet_layers_fwd_bf16_kernel(LayersA
             const int dn = 1 << ((l + 1) % a.dilation_cycle_length);
             const float *dnx = dsh + (m + 1) * FC;
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
+            for (int q = 0; q < RBW; ++q)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    buf_store(acc[0][cb][r] * RSQRT2, rpx, vop[cb], (unsigned)(row0(0) + urow(r)) * (4u * NT));
-                }
+                for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int ch = row0(0) + 8 * g4 + 4 * half;
-                    const f32x4 dv = *reinterpret_cast<const f32x4 *>(dnx + ch);
-                    lf_u32x2 u;
-                    u[0] = inT[cb] ? pack2(acc[0][cb][4 * g4] * RSQRT2 + dv[0], acc[0][cb][4 * g4 + 1] * RSQRT2 + dv[1]) : 0u;
-                    u[1] = inT[cb] ? pack2(acc[0][cb][4 * g4 + 2] * RSQRT2 + dv[2], acc[0][cb][4 * g4 + 3] * RSQRT2 + dv[3]) : 0u;
-                    *reinterpret_cast<lf_u32x2 *>(xs + (dn + cb * 32 + l31) * XR + ch * 2) = u;
+                    for (int r = 0; r < 16; ++r)
+                        buf_store(acc[q][cb][r] * RSQRT2, rpx, vop[cb], (unsigned)(row0(q) + urow(r)) * (4u * NT));
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int ch = row0(q) + 8 * g4 + 4 * half;
+                        const f32x4 dv = *reinterpret_cast<const f32x4 *>(dnx + ch);
+                        lf_u32x2 u;
+                        u[0] = inT[cb] ? pack2(acc[q][cb][4 * g4] * RSQRT2 + dv[0], acc[q][cb][4 * g4 + 1] * RSQRT2 + dv[1]) : 0u;
+                        u[1] = inT[cb] ? pack2(acc[q][cb][4 * g4 + 2] * RSQRT2 + dv[2], acc[q][cb][4 * g4 + 3] * RSQRT2 + dv[3]) : 0u;
+                        *reinterpret_cast<lf_u32x2 *>(xs + (dn + cb * 32 + l31) * XR + ch * 2) = u;
+                    }
                 }
-            }
         } else {
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                if (st[cb]) {
+            for (int q = 0; q < RBW; ++q)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) buf_store(acc[0][cb][r] * RSQRT2, rxo, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
+                for (int cb = 0; cb < NCB; ++cb) {
+                    if (st[cb]) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) buf_store(acc[q][cb][r] * RSQRT2, rxo, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
+                    }
                 }
-            }
         }
         // running skip sum of the stored frames (this block's slice only: L2-hot between the layers of a launch; the stores of the
         // previous layer completed before this layer's residual loads, see the wait there)
         const bool first = a.first != 0 && m == 0;
-        float sk[NCB][16];
+        float sk[RBW][NCB][16];
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
+        for (int q = 0; q < RBW; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load(rsk, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
+            for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-            if (st[cb]) {
+                for (int r = 0; r < 16; ++r) sk[q][cb][r] = buf_load(rsk, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    buf_store(first ? acc[1][cb][r] : acc[1][cb][r] + sk[cb][r], rsk, vo4[cb], (unsigned)(row0(0) + urow(r)) * T4);
+        for (int q = 0; q < RBW; ++q)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                if (st[cb]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        buf_store(first ? acc[RBW + q][cb][r] : acc[RBW + q][cb][r] + sk[q][cb][r], rsk, vo4[cb],
+                                  (unsigned)(row0(q) + urow(r)) * T4);
+                }
             }
-        }
         LF_PHASE(4)
         if (pb && m >= 1) pb[7] += 1;
     }
@@ -944,18 +965,30 @@ static int layers_halo(int l0, int nl, int dcl) {
     for (int m = 1; m < nl; ++m) h += 1 << ((l0 + m) % dcl);
     return h;
 }
+static int layers_tile() {  // frames per tile of the fused-layers kernel: 128 (one block per CU); SET_AMD_BF16_FUSE_TILE=64: two
+    // independent 4-wave blocks per CU -- measured slower (B = 32, T = 800, groups of 5: 0.93 -> 1.01 ms per 20 layers): the blocks
+    // do not drift far enough apart to hide each other's gate / epilogue phases, and 56 of 64 frames per tile are kept
+    static int tile = 0;
+    if (!tile) { const char *e = getenv("SET_AMD_BF16_FUSE_TILE"); tile = (e && atoi(e) == 64) ? 64 : 128; }
+    return tile;
+}
 
 extern "C" int64_t set_sizeof_diffnet_layers_bf16_args(void) { return (int64_t)sizeof(SetDiffnetLayersBf16Args); }
 
 extern "C" int64_t set_diffnet_layers_bf16_scratch_floats(int32_t B, int32_t T, int32_t l0, int32_t nl, int32_t dcl) {
     // (an upper bound over the groups of a network: the halo of the worst first layer for this group size, so that one buffer
-    // serves every group and every utterance slice starts at a multiple of the per-utterance size)
+    // serves every group and every utterance slice starts at a multiple of the per-utterance size; and over both tile widths)
     if (B < 1 || T < 1 || nl < 1 || dcl < 1 || l0 < 0) return 0;
     int hmax = 0;
     for (int s0 = 0; s0 < dcl; ++s0) { const int h = layers_halo(s0, nl, dcl); hmax = h > hmax ? h : hmax; }
-    const int nv = FNT - 2 * hmax;
-    if (nv < 32) return 0;
-    return (int64_t)B * ((T + nv - 1) / nv) * FC * FNT;  // per block: the fp32 copy of x' 
+    int64_t need = 0;
+    for (int nt = 64; nt <= 128; nt += 64) {
+        const int nv = nt - 2 * hmax;
+        if (nv < 32) continue;
+        const int64_t n = (int64_t)B * ((T + nv - 1) / nv) * FC * nt;  // per block: the fp32 copy of x'
+        need = n > need ? n : need;
+    }
+    return need;
 }
 
 extern "C" int set_diffnet_layers_fwd_bf16(const SetDiffnetLayersBf16Args *args, void *stream) {
@@ -969,22 +1002,27 @@ extern "C" int set_diffnet_layers_fwd_bf16(const SetDiffnetLayersBf16Args *args,
                 "set_diffnet_layers_fwd_bf16");
     SET_REQUIRE((int64_t)2 * FC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_layers_fwd_bf16 (T too large)");
     la.hh = layers_halo(a.l0, a.nl, a.dilation_cycle_length);
-    la.nv = FNT - 2 * la.hh;
+    int tile = layers_tile();
+    if (tile - 2 * la.hh < 32) tile = FNT;  // a wide halo: the 128-frame tile
+    la.nv = tile - 2 * la.hh;
     if (la.nv < 32) return set_fail(SET_E_UNSUPPORTED, "set_diffnet_layers_fwd_bf16", "halo of the fused layers leaves fewer than 32 valid frames per tile");
     SET_REQUIRE(a.scratch_floats >= set_diffnet_layers_bf16_scratch_floats(a.B, a.T, a.l0, a.nl, a.dilation_cycle_length),
                 "set_diffnet_layers_fwd_bf16 (scratch too small)");
     int dmax = 1;
     for (int m = 0; m < a.nl; ++m) { const int d = 1 << ((a.l0 + m) % a.dilation_cycle_length); dmax = d > dmax ? d : dmax; }
-    const size_t ldsz = (size_t)(FNT + 2 * dmax) * XR + (size_t)FNT * CR + (size_t)a.nl * FC * sizeof(float);
+    const size_t ldsz = (size_t)(tile + 2 * dmax) * XR + (size_t)tile * CR + (size_t)a.nl * FC * sizeof(float);
     if (ldsz > 160 * 1024) return set_fail(SET_E_UNSUPPORTED, "set_diffnet_layers_fwd_bf16", "tiles do not fit LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layers_fwd_bf16_kernel),
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layers_fwd_bf16_kernel<128>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layers fwd bf16 attr");
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layers_fwd_bf16_kernel<64>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "layers fwd bf16 attr");
         attr_set = true;
     }
     dim3 grid((a.T + la.nv - 1) / la.nv, a.B);
-    hipLaunchKernelGGL(diffnet_layers_fwd_bf16_kernel, grid, dim3(512), ldsz, (hipStream_t)stream, la);
+    if (tile == 128) hipLaunchKernelGGL(diffnet_layers_fwd_bf16_kernel<128>, grid, dim3(512), ldsz, (hipStream_t)stream, la);
+    else hipLaunchKernelGGL(diffnet_layers_fwd_bf16_kernel<64>, grid, dim3(256), ldsz, (hipStream_t)stream, la);
     return set_check_launch("set_diffnet_layers_fwd_bf16");
 }
 
