@@ -346,3 +346,20 @@ def test_stack_kernel_selection_rules(built_lib, monkeypatch):
         ops.split_operand_mode()
     with ops.split_operand_mode_as(3):
         assert ops.split_operand_mode() == 3
+
+
+def test_uniform_stride_of_layer_parameters():
+    """Host logic of the grouped step projections (autograd_ops.step_projections): the per-layer weights must sit at ONE element stride
+    (what the flat optimizer's buffer gives); anything else -> None -> one conv per layer."""
+    import torch
+    from set_amd import autograd_ops as A
+    flat = torch.zeros(3 * 70 + 5)
+    same = [flat[0:64].view(8, 8), flat[70:134].view(8, 8), flat[140:204].view(8, 8)]
+    assert A._uniform_stride(same) == 70
+    assert A._uniform_stride([same[0]]) == 64
+    assert A._uniform_stride([same[0], same[1], flat[141:205].view(8, 8)]) is None      # uneven gap
+    assert A._uniform_stride([same[1], same[0]]) is None                                 # descending addresses
+    assert A._uniform_stride([same[0], same[1].t()]) is None                             # not contiguous
+    assert A._uniform_stride([same[0], same[1].double()]) is None                        # another dtype
+    r = A._uniform_stride([torch.zeros(8, 8), torch.zeros(8, 8), torch.zeros(8, 8)])  # separate allocations: None or a real stride
+    assert r is None or r >= 64
