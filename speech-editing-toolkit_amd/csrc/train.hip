@@ -685,8 +685,9 @@ __global__ void __launch_bounds__(256) pitch_loss_kernel(const float *pp, const 
 // to ITS OWN partial table part[(b * S + s)][row][c] (no other wave touches that slice) -- coalesced 256-byte accesses,
 // no atomics.  scatter_reduce_kernel then adds the slices to the table in slice order.  mode 0: row = idx (embedding:
 // out-of-range clamped, padding_idx skipped); mode 1: row = idx - 1, idx == 0 skipped (expand_states: mel2ph is 1-based)
-__global__ void __launch_bounds__(256) scatter_rows_kernel(const int64_t *idx, const float *doutT, float *part, int B, int T,
-                                                           int C, int n_rows, int S, float scale, int padding_idx, int mode) {
+__global__ void __launch_bounds__(256) scatter_rows_kernel(const int64_t *__restrict__ idx, const float *__restrict__ doutT,
+                                                           float *__restrict__ part, int B, int T, int C, int n_rows, int S, float scale,
+                                                           int padding_idx, int mode) {
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int cblocks = (C + 63) / 64;
@@ -700,12 +701,32 @@ __global__ void __launch_bounds__(256) scatter_rows_kernel(const int64_t *idx, c
     float *tab = part + (int64_t)(b * S + s) * n_rows * C + (cv ? c : 0);
     int cur = -1;
     float acc = 0.0f;
-    for (int t = t_begin; t < t_end; ++t) {
-        int64_t r64 = ib[t];
-        int row;
-        if (mode == 0) { row = (int)(r64 < 0 ? 0 : (r64 >= n_rows ? n_rows - 1 : r64)); if (row == padding_idx) row = -1; }
-        else row = (r64 > 0 && r64 <= n_rows) ? (int)r64 - 1 : -1;
-        if (row != cur) {  // wave-uniform
+    auto row_of = [&](int64_t r64) {
+        if (mode == 0) { const int row = (int)(r64 < 0 ? 0 : (r64 >= n_rows ? n_rows - 1 : r64)); return row == padding_idx ? -1 : row; }
+        return (r64 > 0 && r64 <= n_rows) ? (int)r64 - 1 : -1;
+    };
+    // frames in batches of 8: the eight index / gradient loads are issued together (with frame-level indices -- pitch bins -- every
+    // frame starts a new run, and one load-then-store round trip per frame made the walk 78 us); the adds keep the frame order
+    int t = t_begin;
+    for (; t + 8 <= t_end; t += 8) {
+        int64_t r64[8];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { r64[e] = ib[t + e]; v[e] = dp[(int64_t)(t + e) * C]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int row = row_of(r64[e]);
+            if (row != cur) {  // wave-uniform
+                if (cur >= 0 && cv) tab[(int64_t)cur * C] += acc;
+                cur = row;
+                acc = 0.0f;
+            }
+            acc = fmaf(scale, v[e], acc);
+        }
+    }
+    for (; t < t_end; ++t) {
+        const int row = row_of(ib[t]);
+        if (row != cur) {
             if (cur >= 0 && cv) tab[(int64_t)cur * C] += acc;
             cur = row;
             acc = 0.0f;
