@@ -741,9 +741,17 @@ __global__ void __launch_bounds__(256) scatter_reduce_kernel(const float *part, 
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int g = blockIdx.y;
-    float s = 0.0f;
-    for (int k = 0; k < K; ++k) s += part[((int64_t)g * K + k) * n + i];
-    table[(int64_t)g * n + i] += s;
+    const float *pp = part + (int64_t)g * K * n + i;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;  // four interleaved chains over the slices: four loads in flight, one fixed association
+    int k = 0;
+    for (; k + 3 < K; k += 4) {
+        s0 += pp[(int64_t)k * n];
+        s1 += pp[(int64_t)(k + 1) * n];
+        s2 += pp[(int64_t)(k + 2) * n];
+        s3 += pp[(int64_t)(k + 3) * n];
+    }
+    for (; k < K; ++k) s0 += pp[(int64_t)k * n];
+    table[(int64_t)g * n + i] += (s0 + s1) + (s2 + s3);
 }
 
 // ---- optimizer ---------------------------------------------------------------------------------------------------
