@@ -427,18 +427,25 @@ struct LayersArgs {
     int hh, nv;  // halo H and valid frames per tile
 };
 
-// NT = 128 (default): 8 waves, one 32-row gate block + its filter block per wave, one block per CU.  NT = 64 (experiment): 4 waves, two
-// gate blocks + their filter blocks per wave, 62 KB of LDS, two independent blocks per CU; the weight images are then streamed once
-// per 64 frames instead of once per 128 and a tile yields 64 - 2 H stored frames -- measured slower, see layers_tile().
-template <int NT>
-__global__ void __launch_bounds__(NT * 4, NT == 128 ? 1 : 2) diffnet_layers_fwd_bf16_kernel(LayersArgs la) {
+// <NT, NW> = frames per tile, waves per block:
+//   <128, 8>  one 32-row gate block + its filter block per wave, 4 column blocks: 128 accumulator registers; the fp32 copy of x' and the
+//             running skip sum of the tile go through the block's private memory / the skip tensor between the layers (PMC: that traffic
+//             is still 144 MB per layer against 170 MB unfused -- all 224 blocks re-read their 128 KB at the same moment)
+//   <64, 8>   REG variant: the same row split over 2 column blocks: 64 accumulator registers, which leaves room to keep BOTH the fp32 x'
+//             (32 registers) and the skip sum (32) of the wave's rows in registers for the whole group: between the layers nothing
+//             leaves the CU; price: the weight images are streamed once per 64 frames, a tile yields 64 - 2 H stored frames
+//   <64, 4>   (experiment) two gate blocks + their filter blocks per wave, two independent blocks per CU: measured slower
+template <int NT, int NW>
+__global__ void __launch_bounds__(NW * 64, (NT == 64 && NW == 4) ? 2 : 1) diffnet_layers_fwd_bf16_kernel(LayersArgs la) {
     const SetDiffnetLayersBf16Args &a = la.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int NW = NT / 16;   // waves per block
     constexpr int RBW = 8 / NW;   // 32-row gate blocks per wave (and as many filter blocks)
     constexpr int NCB = NT / 32;  // 32-frame column blocks
-    constexpr int NTH = NT * 4;   // threads
-    constexpr int PFD = NT == 128 ? PF : 2;  // A ring depth: 2 x RBW fragments per k-step
+    constexpr int NTH = NW * 64;  // threads
+    constexpr int NCG = NTH / NT; // channel groups of the staging pass (thread = frame row x channel group)
+    constexpr int CPX = FC / NCG, CPC = FH / NCG;  // x / conditioner channels per thread
+    constexpr bool REG = NT == 64 && NW == 8;       // x' and the skip sum stay in registers between the layers
+    constexpr int PFD = RBW == 1 ? PF : 2;  // A ring depth: 2 x RBW fragments per k-step
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -473,54 +480,54 @@ __global__ void __launch_bounds__(NT * 4, NT == 128 ? 1 : 2) diffnet_layers_fwd_
             dsh[i] = a.dstep[(int64_t)(a.l0 + m) * a.d_ls + (int64_t)b * a.d_bs + (int64_t)c * a.d_cs];
         }
         const int d = 1 << (a.l0 % a.dilation_cycle_length);
-        const int f = tid % NT, cg = __builtin_amdgcn_readfirstlane(tid / NT);  // cg 0..3
+        const int f = tid % NT, cg = __builtin_amdgcn_readfirstlane(tid / NT);  // cg 0 .. NCG - 1
         const int t = ts - d + f;
         const bool tvx = t >= 0 && t < T;
         const unsigned vox = 4u * (unsigned)min(max(t, 0), T - 1);
         const int tcn = ts + f;
         const bool tvc = tcn >= 0 && tcn < T;
         const unsigned voc = 4u * (unsigned)min(max(tcn, 0), T - 1);
-        float vx[64], vc[48];
+        float vx[CPX], vc[CPC];
 #pragma unroll
-        for (int k = 0; k < 64; ++k) vx[k] = buf_load(rx, vox, (unsigned)(64 * cg + k) * T4);
+        for (int k = 0; k < CPX; ++k) vx[k] = buf_load(rx, vox, (unsigned)(CPX * cg + k) * T4);
 #pragma unroll
-        for (int k = 0; k < 48; ++k) vc[k] = buf_load(rcd, voc, (unsigned)(48 * cg + k) * T4);
+        for (int k = 0; k < CPC; ++k) vc[k] = buf_load(rcd, voc, (unsigned)(CPC * cg + k) * T4);
         // rows beyond layer 0's tile (layers with a larger dilation address up to XROWS_MAX rows): finite filler
         for (int i = tid; i < (XROWS_MAX - (NT + 2 * d)) * (XR / 16); i += NTH)
             *reinterpret_cast<u32x4_t *>(xs + (NT + 2 * d) * XR + i * 16) = (u32x4_t){0u, 0u, 0u, 0u};
         __syncthreads();  // dsh
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dsh + 64 * cg + 8 * q);
-            const f32x4 d1 = *reinterpret_cast<const f32x4 *>(dsh + 64 * cg + 8 * q + 4);
+        for (int q = 0; q < CPX / 8; ++q) {
+            const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dsh + CPX * cg + 8 * q);
+            const f32x4 d1 = *reinterpret_cast<const f32x4 *>(dsh + CPX * cg + 8 * q + 4);
             u32x4_t u;
             u[0] = tvx ? pack2(vx[8 * q + 0] + d0[0], vx[8 * q + 1] + d0[1]) : 0u;
             u[1] = tvx ? pack2(vx[8 * q + 2] + d0[2], vx[8 * q + 3] + d0[3]) : 0u;
             u[2] = tvx ? pack2(vx[8 * q + 4] + d1[0], vx[8 * q + 5] + d1[1]) : 0u;
             u[3] = tvx ? pack2(vx[8 * q + 6] + d1[2], vx[8 * q + 7] + d1[3]) : 0u;
-            *reinterpret_cast<u32x4_t *>(xs + f * XR + (64 * cg + 8 * q) * 2) = u;
+            *reinterpret_cast<u32x4_t *>(xs + f * XR + (CPX * cg + 8 * q) * 2) = u;
         }
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
+        for (int q = 0; q < CPC / 8; ++q) {
             u32x4_t u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) u[e] = tvc ? pack2(vc[8 * q + 2 * e], vc[8 * q + 2 * e + 1]) : 0u;
-            *reinterpret_cast<u32x4_t *>(cs + f * CR + (48 * cg + 8 * q) * 2) = u;
+            *reinterpret_cast<u32x4_t *>(cs + f * CR + (CPC * cg + 8 * q) * 2) = u;
         }
         if (f < 2 * d) {
             const int j = NT + f, th = ts - d + j;
             const bool tvh = th >= 0 && th < T;
             const unsigned voh = 4u * (unsigned)min(max(th, 0), T - 1);
-            float vh[64];
+            float vh[CPX];
 #pragma unroll
-            for (int k = 0; k < 64; ++k) vh[k] = buf_load(rx, voh, (unsigned)(64 * cg + k) * T4);
+            for (int k = 0; k < CPX; ++k) vh[k] = buf_load(rx, voh, (unsigned)(CPX * cg + k) * T4);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < CPX / 8; ++q) {
                 u32x4_t u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    u[e] = tvh ? pack2(vh[8 * q + 2 * e] + dsh[64 * cg + 8 * q + 2 * e], vh[8 * q + 2 * e + 1] + dsh[64 * cg + 8 * q + 2 * e + 1]) : 0u;
-                *reinterpret_cast<u32x4_t *>(xs + j * XR + (64 * cg + 8 * q) * 2) = u;
+                    u[e] = tvh ? pack2(vh[8 * q + 2 * e] + dsh[CPX * cg + 8 * q + 2 * e], vh[8 * q + 2 * e + 1] + dsh[CPX * cg + 8 * q + 2 * e + 1]) : 0u;
+                *reinterpret_cast<u32x4_t *>(xs + j * XR + (CPX * cg + 8 * q) * 2) = u;
             }
         }
     }
@@ -536,6 +543,20 @@ __global__ void __launch_bounds__(NT * 4, NT == 128 ? 1 : 2) diffnet_layers_fwd_
         vop[cb] = 4u * (unsigned)(4 * half * NT + cb * 32 + l31);
     }
     const unsigned lb = 16u * (unsigned)half;
+    // REG: the wave's rows of x (fp32, the residual chain) and of the skip sum for the whole group
+    float xkeep[REG ? RBW : 1][REG ? NCB : 1][16], skacc[REG ? RBW : 1][REG ? NCB : 1][16];
+    if constexpr (REG) {
+        const bool first0 = a.first != 0;
+#pragma unroll
+        for (int q = 0; q < RBW; ++q)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    xkeep[q][cb][r] = buf_load(rx, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
+                    skacc[q][cb][r] = first0 ? 0.0f : buf_load(rsk, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
+                }
+    }
     // debug (tools/bf16_phase_probe.py): thread 0 of block (1, 1) adds the s_memtime ticks of the phases of its layers m >= 1 to
     // buf[0..4] (accumulator init + barrier, GEMM 1, gate, GEMM 2, epilogue) and counts them in buf[7]
     uint64_t *const pb = (g_bf16_phase_buf && blockIdx.x == 1 && blockIdx.y == 1 && tid == 0) ? g_bf16_phase_buf : nullptr;
@@ -581,16 +602,18 @@ __global__ void __launch_bounds__(NT * 4, NT == 128 ? 1 : 2) diffnet_layers_fwd_
 
         LF_PHASE(1)
         // ---- gate; residual rows of x: from HBM for the first fused layer, from the block's private copy afterwards
-        float xres[RBW][NCB][16];
-        if (m > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the x' rows this lane stored in the previous epilogue are in memory
+        float xres[REG ? 1 : RBW][REG ? 1 : NCB][16];
+        if constexpr (!REG) {
+            if (m > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the x' rows this lane stored in the previous epilogue are in memory
 #pragma unroll
-        for (int q = 0; q < RBW; ++q)
+            for (int q = 0; q < RBW; ++q)
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
+                for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    xres[q][cb][r] = m == 0 ? buf_load(rx, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4)
-                                            : buf_load(rpx, vop[cb], (unsigned)(row0(q) + urow(r)) * (4u * NT));
+                    for (int r = 0; r < 16; ++r)
+                        xres[q][cb][r] = m == 0 ? buf_load(rx, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4)
+                                                : buf_load(rpx, vop[cb], (unsigned)(row0(q) + urow(r)) * (4u * NT));
+        }
         __syncthreads();  // every wave is done reading the x tile
         typedef unsigned lf_u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -612,7 +635,10 @@ __global__ void __launch_bounds__(NT * 4, NT == 128 ? 1 : 2) diffnet_layers_fwd_
             for (int r = 0; r < 16; ++r) {
                 const float bias = buf_load(rbo, lb, 4u * (unsigned)(row0(rb) + urow(r)));
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = rb < RBW ? bias + xres[rb % RBW][cb][r] : bias;
+                for (int cb = 0; cb < NCB; ++cb) {
+                    if constexpr (REG) acc[rb][cb][r] = rb < RBW ? bias + xkeep[rb % RBW][cb][r] : bias;
+                    else acc[rb][cb][r] = rb < RBW ? bias + xres[rb % RBW][cb][r] : bias;
+                }
             }
         __syncthreads();
         LF_PHASE(2)
@@ -625,58 +651,101 @@ __global__ void __launch_bounds__(NT * 4, NT == 128 ? 1 : 2) diffnet_layers_fwd_
         LF_PHASE(3)
         // ---- epilogue: x' = (x + o_res) / sqrt 2 -> private fp32 copy + operand tile of the next layer, or the output tensor
         __syncthreads();  // every wave is done reading the z tile: the next layer's x tile goes over it
-        if (!last) {
-            const int dn = 1 << ((l + 1) % a.dilation_cycle_length);
-            const float *dnx = dsh + (m + 1) * FC;
+        if constexpr (REG) {
+            // x' and the skip sum stay in the wave's registers; only the bf16 operand tile of the next layer goes through LDS
 #pragma unroll
             for (int q = 0; q < RBW; ++q)
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) {
+                for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        buf_store(acc[q][cb][r] * RSQRT2, rpx, vop[cb], (unsigned)(row0(q) + urow(r)) * (4u * NT));
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int ch = row0(q) + 8 * g4 + 4 * half;
-                        const f32x4 dv = *reinterpret_cast<const f32x4 *>(dnx + ch);
-                        lf_u32x2 u;
-                        u[0] = inT[cb] ? pack2(acc[q][cb][4 * g4] * RSQRT2 + dv[0], acc[q][cb][4 * g4 + 1] * RSQRT2 + dv[1]) : 0u;
-                        u[1] = inT[cb] ? pack2(acc[q][cb][4 * g4 + 2] * RSQRT2 + dv[2], acc[q][cb][4 * g4 + 3] * RSQRT2 + dv[3]) : 0u;
-                        *reinterpret_cast<lf_u32x2 *>(xs + (dn + cb * 32 + l31) * XR + ch * 2) = u;
+                    for (int r = 0; r < 16; ++r) {
+                        xkeep[q][cb][r] = acc[q][cb][r] * RSQRT2;
+                        skacc[q][cb][r] = (a.first != 0 && m == 0) ? acc[RBW + q][cb][r] : acc[RBW + q][cb][r] + skacc[q][cb][r];
                     }
-                }
+            if (!last) {
+                const int dn = 1 << ((l + 1) % a.dilation_cycle_length);
+                const float *dnx = dsh + (m + 1) * FC;
+#pragma unroll
+                for (int q = 0; q < RBW; ++q)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int ch = row0(q) + 8 * g4 + 4 * half;
+                            const f32x4 dv = *reinterpret_cast<const f32x4 *>(dnx + ch);
+                            lf_u32x2 u;
+                            u[0] = inT[cb] ? pack2(xkeep[q][cb][4 * g4] + dv[0], xkeep[q][cb][4 * g4 + 1] + dv[1]) : 0u;
+                            u[1] = inT[cb] ? pack2(xkeep[q][cb][4 * g4 + 2] + dv[2], xkeep[q][cb][4 * g4 + 3] + dv[3]) : 0u;
+                            *reinterpret_cast<lf_u32x2 *>(xs + (dn + cb * 32 + l31) * XR + ch * 2) = u;
+                        }
+            } else {
+#pragma unroll
+                for (int q = 0; q < RBW; ++q)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        if (st[cb]) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                buf_store(xkeep[q][cb][r], rxo, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
+                                buf_store(skacc[q][cb][r], rsk, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
+                            }
+                        }
+                    }
+            }
         } else {
+    if (!last) {
+                const int dn = 1 << ((l + 1) % a.dilation_cycle_length);
+                const float *dnx = dsh + (m + 1) * FC;
+#pragma unroll
+                for (int q = 0; q < RBW; ++q)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            buf_store(acc[q][cb][r] * RSQRT2, rpx, vop[cb], (unsigned)(row0(q) + urow(r)) * (4u * NT));
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int ch = row0(q) + 8 * g4 + 4 * half;
+                            const f32x4 dv = *reinterpret_cast<const f32x4 *>(dnx + ch);
+                            lf_u32x2 u;
+                            u[0] = inT[cb] ? pack2(acc[q][cb][4 * g4] * RSQRT2 + dv[0], acc[q][cb][4 * g4 + 1] * RSQRT2 + dv[1]) : 0u;
+                            u[1] = inT[cb] ? pack2(acc[q][cb][4 * g4 + 2] * RSQRT2 + dv[2], acc[q][cb][4 * g4 + 3] * RSQRT2 + dv[3]) : 0u;
+                            *reinterpret_cast<lf_u32x2 *>(xs + (dn + cb * 32 + l31) * XR + ch * 2) = u;
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int q = 0; q < RBW; ++q)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        if (st[cb]) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) buf_store(acc[q][cb][r] * RSQRT2, rxo, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
+                        }
+                    }
+            }
+            // running skip sum of the stored frames (this block's slice only: L2-hot between the layers of a launch; the stores of the
+            // previous layer completed before this layer's residual loads, see the wait there)
+            const bool first = a.first != 0 && m == 0;
+            float sk[RBW][NCB][16];
+#pragma unroll
+            for (int q = 0; q < RBW; ++q)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sk[q][cb][r] = buf_load(rsk, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
 #pragma unroll
             for (int q = 0; q < RBW; ++q)
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
                     if (st[cb]) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) buf_store(acc[q][cb][r] * RSQRT2, rxo, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
+                        for (int r = 0; r < 16; ++r)
+                            buf_store(first ? acc[RBW + q][cb][r] : acc[RBW + q][cb][r] + sk[q][cb][r], rsk, vo4[cb],
+                                      (unsigned)(row0(q) + urow(r)) * T4);
                     }
                 }
         }
-        // running skip sum of the stored frames (this block's slice only: L2-hot between the layers of a launch; the stores of the
-        // previous layer completed before this layer's residual loads, see the wait there)
-        const bool first = a.first != 0 && m == 0;
-        float sk[RBW][NCB][16];
-#pragma unroll
-        for (int q = 0; q < RBW; ++q)
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sk[q][cb][r] = buf_load(rsk, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
-#pragma unroll
-        for (int q = 0; q < RBW; ++q)
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                if (st[cb]) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        buf_store(first ? acc[RBW + q][cb][r] : acc[RBW + q][cb][r] + sk[q][cb][r], rsk, vo4[cb],
-                                  (unsigned)(row0(q) + urow(r)) * T4);
-                }
-            }
         LF_PHASE(4)
         if (pb && m >= 1) pb[7] += 1;
     }
@@ -965,11 +1034,10 @@ static int layers_halo(int l0, int nl, int dcl) {
     for (int m = 1; m < nl; ++m) h += 1 << ((l0 + m) % dcl);
     return h;
 }
-static int layers_tile() {  // frames per tile of the fused-layers kernel: 128 (one block per CU); SET_AMD_BF16_FUSE_TILE=64: two
-    // independent 4-wave blocks per CU -- measured slower (B = 32, T = 800, groups of 5: 0.93 -> 1.01 ms per 20 layers): the blocks
-    // do not drift far enough apart to hide each other's gate / epilogue phases, and 56 of 64 frames per tile are kept
+static int layers_tile() {  // shape of the fused-layers kernel: 64 = <64, 8> (x' and the skip sum in registers), 128 = <128, 8>,
+    // 464 = <64, 4> (two independent 4-wave blocks per CU: measured slower at B = 32, T = 800, groups of 5: 0.93 -> 1.01 ms per 20 layers)
     static int tile = 0;
-    if (!tile) { const char *e = getenv("SET_AMD_BF16_FUSE_TILE"); tile = (e && atoi(e) == 64) ? 64 : 128; }
+    if (!tile) { const char *e = getenv("SET_AMD_BF16_FUSE_TILE"); tile = e ? atoi(e) : 64; if (tile != 64 && tile != 128 && tile != 464) tile = 64; }
     return tile;
 }
 
@@ -1002,7 +1070,8 @@ extern "C" int set_diffnet_layers_fwd_bf16(const SetDiffnetLayersBf16Args *args,
                 "set_diffnet_layers_fwd_bf16");
     SET_REQUIRE((int64_t)2 * FC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_layers_fwd_bf16 (T too large)");
     la.hh = layers_halo(a.l0, a.nl, a.dilation_cycle_length);
-    int tile = layers_tile();
+    const int shape = layers_tile();
+    int tile = shape == 128 ? 128 : 64;
     if (tile - 2 * la.hh < 32) tile = FNT;  // a wide halo: the 128-frame tile
     la.nv = tile - 2 * la.hh;
     if (la.nv < 32) return set_fail(SET_E_UNSUPPORTED, "set_diffnet_layers_fwd_bf16", "halo of the fused layers leaves fewer than 32 valid frames per tile");
@@ -1014,15 +1083,18 @@ extern "C" int set_diffnet_layers_fwd_bf16(const SetDiffnetLayersBf16Args *args,
     if (ldsz > 160 * 1024) return set_fail(SET_E_UNSUPPORTED, "set_diffnet_layers_fwd_bf16", "tiles do not fit LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layers_fwd_bf16_kernel<128>),
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layers_fwd_bf16_kernel<128, 8>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layers fwd bf16 attr");
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layers_fwd_bf16_kernel<64>),
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layers_fwd_bf16_kernel<64, 8>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "layers fwd bf16 attr");
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layers_fwd_bf16_kernel<64, 4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "layers fwd bf16 attr");
         attr_set = true;
     }
     dim3 grid((a.T + la.nv - 1) / la.nv, a.B);
-    if (tile == 128) hipLaunchKernelGGL(diffnet_layers_fwd_bf16_kernel<128>, grid, dim3(512), ldsz, (hipStream_t)stream, la);
-    else hipLaunchKernelGGL(diffnet_layers_fwd_bf16_kernel<64>, grid, dim3(256), ldsz, (hipStream_t)stream, la);
+    if (tile == 128) hipLaunchKernelGGL((diffnet_layers_fwd_bf16_kernel<128, 8>), grid, dim3(512), ldsz, (hipStream_t)stream, la);
+    else if (shape == 464) hipLaunchKernelGGL((diffnet_layers_fwd_bf16_kernel<64, 4>), grid, dim3(256), ldsz, (hipStream_t)stream, la);
+    else hipLaunchKernelGGL((diffnet_layers_fwd_bf16_kernel<64, 8>), grid, dim3(512), ldsz, (hipStream_t)stream, la);
     return set_check_launch("set_diffnet_layers_fwd_bf16");
 }
 
