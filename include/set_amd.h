@@ -425,9 +425,9 @@ typedef struct SetDiffLoopArgs {
     const float *cond;
     const void *img16_all;
     const float *b_cond_all;
-    /* optional workspace of the bf16 loop: with bf16_ws_floats >= set_diffnet_layers_bf16_scratch_floats(B, T, 0, 5,
-     * dilation_cycle_length) (and dilation_cycle_length <= 2) the layers run five per launch (set_diffnet_layers_fwd_bf16);
-     * NULL / too small: one launch per layer.  SET_AMD_BF16_FUSE=n overrides the group size (1 = per layer). */
+    /* bf16 loop: with bf16_ws_floats >= set_diffnet_layers_bf16_scratch_floats(B, T, 0, n, dilation_cycle_length) for the group size
+     * n in use and dilation_cycle_length <= 2 the layers run set_diffnet_layers_bf16_plan() per launch
+     * (set_diffnet_layers_fwd_bf16); NULL: one launch per layer.  SET_AMD_BF16_FUSE=n overrides the group size (1 = per layer). */
     float *bf16_ws;
     int64_t bf16_ws_floats;
 } SetDiffLoopArgs;
@@ -491,13 +491,17 @@ int64_t set_diffnet_layer_bf16_image_size(void);
 int set_pack_diffnet_layer_bf16(const float *wdil /*[512][256][3]*/, const float *wcond /*[512][192]*/,
                                 const float *wout /*[512][256]*/, void *img, void *stream);
 int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, void *stream);
-/* Several consecutive residual layers per launch (bf16 operands, inference: nothing is saved): a block keeps its 128-frame tile on
- * chip for `nl` layers l0 .. l0 + nl - 1 (x and the conditioner are read once, the running skip sum and a private fp32 copy of x'
- * go through L2 between the layers) and stores the 128 - 2 H frames whose receptive field stayed inside the tile, H = sum of the
- * dilations 2^((l0 + m) % dilation_cycle_length), m = 1 .. nl - 1.  Same arithmetic per frame as nl set_diffnet_layer_fwd_bf16
- * launches.  Arrays are the per-layer operands of those launches laid out one layer after the other: img [nl][image_size],
- * b_dil / b_cond / b_out [nl][512], dstep of layer l at dstep + l * d_ls (l counted from layer 0 of the network).
- * scratch >= set_diffnet_layers_bf16_scratch_floats(B, T, l0, nl, dilation_cycle_length) floats, x_in != x_out. */
+/* Several consecutive residual layers per launch (bf16 operands, inference: nothing is saved): a block keeps its tile on chip for
+ * `nl` (<= 16) layers l0 .. l0 + nl - 1 (x and the conditioner are read once; the fp32 residual rows stay in registers; the running
+ * skip sum stays in registers (64-frame tiles) or goes through L2 per layer (128-frame tiles)) and stores the tile - 2 H frames whose
+ * receptive field stayed inside the tile, H = sum of the dilations 2^((l0 + m) % dilation_cycle_length), m = 1 .. nl - 1.  The tile
+ * width is chosen per launch: 128 frames when B * ceil(T / (128 - 2 H)) blocks still fill 3/4 of the CUs, else 64.  Same arithmetic
+ * per frame as nl set_diffnet_layer_fwd_bf16 launches (x bit-identical; the skip sum bit-identical at 64 frames, equal up to fp32
+ * rounding order at 128).  Arrays are the per-layer operands of those launches laid out one layer after the other: img
+ * [nl][image_size], b_dil / b_cond / b_out [nl][512], dstep of layer l at dstep + l * d_ls (l counted from layer 0 of the network).
+ * x_in != x_out.  scratch >= set_diffnet_layers_bf16_scratch_floats(B, T, l0, nl, dilation_cycle_length) floats (128-frame tiles:
+ * a block's private copy of its skip rows between the layers of the group).
+ * set_diffnet_layers_bf16_plan(B, T, L, dilation_cycle_length): the group size the reverse loop uses for a stack of L layers. */
 typedef struct SetDiffnetLayersBf16Args {
     const float *x_in;   /* [B][256][T] input of layer l0 */
     float *x_out;        /* [B][256][T] output of layer l0 + nl - 1 */
@@ -513,6 +517,7 @@ typedef struct SetDiffnetLayersBf16Args {
 } SetDiffnetLayersBf16Args;
 int64_t set_sizeof_diffnet_layers_bf16_args(void);
 int64_t set_diffnet_layers_bf16_scratch_floats(int32_t B, int32_t T, int32_t l0, int32_t nl, int32_t dilation_cycle_length);
+int32_t set_diffnet_layers_bf16_plan(int32_t B, int32_t T, int32_t L, int32_t dilation_cycle_length);
 int set_diffnet_layers_fwd_bf16(const SetDiffnetLayersBf16Args *args, void *stream);
 /* debug: block (1,1) of the bf16 layer kernels stamps s_memtime at its phase boundaries into buf[0..7] (NULL = off) */
 int set_debug_bf16_phase_buffer(uint64_t *buf);

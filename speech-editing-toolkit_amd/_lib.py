@@ -271,6 +271,7 @@ SIGNATURES = {
     "set_sizeof_diffnet_layers_bf16_args": (_I64, []),
     "set_diffnet_layers_bf16_scratch_floats": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "set_diffnet_layers_fwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayersBf16Args), _V]),
+    "set_diffnet_layers_bf16_plan": (_I32, [_I32, _I32, _I32, _I32]),
     "set_debug_bf16_phase_buffer": (C.c_int, [_V]),
     "set_debug_split_phase_buffer": (C.c_int, [_V]),
     "set_debug_x3_phase_buffer": (C.c_int, [_V]),
@@ -318,7 +319,8 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h"]] + [os.path.join(INCLUDE, "set_amd.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] \
+        + [os.path.join(INCLUDE, "set_amd.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -339,12 +341,29 @@ def build(force=False, verbose=False):
             if not force and not _stale():  # another process built it while we waited
                 return LIB_PATH
             tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
-            cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", tmp]
+            # one object per source under build/obj (only stale ones are recompiled, all of them in parallel), then one link
+            objdir = os.path.join(_ROOT, "build", "obj")
+            os.makedirs(objdir, exist_ok=True)
+            hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "set_amd.h")]
+            t_hdr = max(os.path.getmtime(h) for h in hdrs)
+            cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+            jobs = []
+            for f in SOURCES:
+                src, obj = os.path.join(CSRC, f), os.path.join(objdir, f[:-4] + ".o")
+                if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), t_hdr):
+                    jobs.append([hipcc] + cflags + ["-I", INCLUDE, "-c", src, "-o", obj])
             if verbose:
-                print(" ".join(cmd))
+                for j in jobs:
+                    print(" ".join(j))
+            procs = [subprocess.Popen(j, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for j in jobs]
+            outs = [(p.communicate()[0], p.returncode) for p in procs]
+            bad = [o for o, rc in outs if rc != 0]
+            if bad:
+                raise RuntimeError("hipcc failed:\n" + "\n".join(bad))
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(objdir, f[:-4] + ".o") for f in SOURCES] + ["-o", tmp]
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             if r.returncode != 0:
-                raise RuntimeError("hipcc failed:\n" + r.stdout)
+                raise RuntimeError("hipcc link failed:\n" + r.stdout)
             os.replace(tmp, LIB_PATH)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

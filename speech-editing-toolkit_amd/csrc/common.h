@@ -86,6 +86,20 @@ __device__ __forceinline__ void buf_store4(f32x4 v, rsrc_t r, unsigned voff, uns
 __device__ __forceinline__ void buf_store(float v, rsrc_t r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
+// streaming 16-byte accesses of data ONE CU writes and reads once per pass (a block's private buffer): nt load (evict-first at the
+// L2), sc1 store (written through and dropped from the L2) -- they must not push the weights every CU of the XCD re-reads out of the L2
+__device__ __forceinline__ f32x4 buf_load4_stream(rsrc_t r, unsigned voff, unsigned soff) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 2));
+}
+__device__ __forceinline__ void buf_store4_stream(f32x4 v, rsrc_t r, unsigned voff, unsigned soff) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, 16);
+}
+// fp32 add at the L2 without return (buffer_atomic_add_f32): for read-modify-write of data this block owns exclusively
+__device__ __forceinline__ void buf_atomic_add(float v, rsrc_t r, unsigned voff, unsigned soff) {
+    (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, r, (int)voff, (int)soff, 0);
+}
 // agent-scope write-through store (sc1): complete (vmcnt) = visible to every XCD, no L2 write-back needed later
 __device__ __forceinline__ void buf_store_agent(float v, rsrc_t r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 16);

@@ -1945,8 +1945,8 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
         // between the layers of a group)
         int fuse = 1;
         if (bf16_loop && a.bf16_ws && a.dilation_cycle_length <= 2) {
-            fuse = 5;  // (measured at B = 32, T = 800, 20 layers, one box: 1 -> 1.096 ms per step, 2 -> 1.03, 4 -> 0.94, 5 -> 0.92, 10 -> 1.14)
-            if (const char *e = getenv("SET_AMD_BF16_FUSE")) fuse = atoi(e) < 1 ? 1 : (atoi(e) > 8 ? 8 : atoi(e));
+            fuse = set_diffnet_layers_bf16_plan(Bg, T, L, a.dilation_cycle_length);  // 10 (128-frame tiles fill the chip) or 5
+            if (const char *e = getenv("SET_AMD_BF16_FUSE")) fuse = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
             if (fuse > 1 && a.bf16_ws_floats < set_diffnet_layers_bf16_scratch_floats(a.B, T, 0, fuse, a.dilation_cycle_length)) fuse = 1;
         }
         for (int l = 0; l < L && rc == SET_OK && bf16_loop && fuse > 1; l += fuse) {
@@ -1956,8 +1956,7 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
             fa.dstep = a.dstep + sid; fa.d_bs = 0; fa.d_cs = a.steps; fa.d_ls = (int64_t)DC * a.steps;
             fa.img = reinterpret_cast<const uint16_t *>(a.img16_all) + (int64_t)l * set_diffnet_layer_bf16_image_size();
             fa.b_dil = a.b_dil_all + (int64_t)l * 512; fa.b_cond = a.b_cond_all + (int64_t)l * 512; fa.b_out = a.b_out_all + (int64_t)l * 512;
-            fa.scratch = a.bf16_ws + (int64_t)b0 * (set_diffnet_layers_bf16_scratch_floats(1, T, 0, fuse, a.dilation_cycle_length));
-            fa.scratch_floats = a.bf16_ws_floats - (int64_t)b0 * (set_diffnet_layers_bf16_scratch_floats(1, T, 0, fuse, a.dilation_cycle_length));
+            fa.scratch = a.bf16_ws; fa.scratch_floats = a.bf16_ws_floats;  // the groups run one after the other: one buffer
             fa.B = Bg; fa.T = T; fa.l0 = l; fa.nl = L - l < fuse ? L - l : fuse; fa.dilation_cycle_length = a.dilation_cycle_length;
             fa.first = (l == 0);
             rc = set_diffnet_layers_fwd_bf16(&fa, s);

@@ -411,41 +411,121 @@ __global__ void __launch_bounds__(NT * 4, NT == 128 ? 1 : 2) diffnet_layer_fwd_b
 // =====================================================================================================================
 // Several residual layers per launch (inference).  One launch per layer streams x (1024 B per frame), the conditioner (768),
 // x' (1024) and the running skip sum (2048, read-modify-write) through HBM for ~17 us of MFMA work per tile, and the HBM phases
-// of all 224 blocks coincide (one block per CU): 55 us per layer, 28 % of the HBM peak.  Here a block keeps its tile ON CHIP for
-// NL consecutive layers: x is loaded once, the conditioner tile once (every layer projects the SAME conditioner), the layer
-// output goes straight back into the LDS operand tile, and only the block's private fp32 copy of x' (the residual chain) and
-// its slice of the skip sum go through memory between the layers -- L2 / Infinity-Cache traffic of the same CU, no other block
-// reads it.  Price: a tile of 128 computed frames yields 128 - 2 H valid ones, H = sum of the dilations of layers 1 .. NL - 1
-// (frames whose receptive field left the tile are recomputed by the neighbour): 122 of 128 for four layers of dilation 1.
-//   compute frames of the tile: ts + j, j < 128, ts = tile * NV - H;  stored: the NV frames from ts + H on
+// of all blocks coincide: 55 us per layer, 28 % of the HBM peak.  In the kernels below a block keeps its tile ON CHIP for NL consecutive
+// layers: x is loaded once, the conditioner tile once (every layer projects the SAME conditioner), the layer output goes straight back
+// into the LDS operand tile.  Price: a tile of NT computed frames yields NT - 2 H valid ones, H = sum of the dilations of layers
+// 1 .. NL - 1 (frames whose receptive field left the tile are recomputed by the neighbour).
+//   compute frames of the tile: ts + j, j < NT, ts = tile * NV - H;  stored: the NV frames from ts + H on
 //   xs row j of layer m <-> frame ts - d_m + j   (d_m halo rows on either side; beyond the loaded / computed frames: garbage that
 //   only ever reaches frames outside the stored range)
-// Same arithmetic per frame as diffnet_layer_fwd_bf16_kernel (same images, same k order, same rounding points).
+// (Round 3's shapes -- <128, 8> with the fp32 x' and the skip sum through the block's private memory, <64, 4> as two blocks per CU --
+// were measured slower and are gone; history: DESIGN.md section 3.5.)
 // =====================================================================================================================
 struct LayersArgs {
     SetDiffnetLayersBf16Args a;
     int hh, nv;  // halo H and valid frames per tile
 };
 
-// <NT, NW> = frames per tile, waves per block:
-//   <128, 8>  one 32-row gate block + its filter block per wave, 4 column blocks: 128 accumulator registers; the fp32 copy of x' and the
-//             running skip sum of the tile go through the block's private memory / the skip tensor between the layers (PMC: that traffic
-//             is still 144 MB per layer against 170 MB unfused -- all 224 blocks re-read their 128 KB at the same moment)
-//   <64, 8>   REG variant: the same row split over 2 column blocks: 64 accumulator registers, which leaves room to keep BOTH the fp32 x'
-//             (32 registers) and the skip sum (32) of the wave's rows in registers for the whole group: between the layers nothing
-//             leaves the CU; price: the weight images are streamed once per 64 frames, a tile yields 64 - 2 H stored frames
-//   <64, 4>   (experiment) two gate blocks + their filter blocks per wave, two independent blocks per CU: measured slower
-template <int NT, int NW>
-__global__ void __launch_bounds__(NW * 64, (NT == 64 && NW == 4) ? 2 : 1) diffnet_layers_fwd_bf16_kernel(LayersArgs la) {
+// =====================================================================================================================
+// Register-resident fused layer groups (round 4; the default shape of set_diffnet_layers_fwd_bf16): 64-frame tiles on 8 waves,
+// the wave's rows of the fp32 x' and of the skip sum in registers for the whole group (as the round-3 <64, 8> shape), and
+//   * the gated z has its OWN LDS tile: a layer has two barriers (x tile complete -> GEMM 1; z tile complete -> GEMM 2) instead of
+//     four -- a wave that leaves GEMM 1 goes straight into its gate math (VALU) while its SIMD partner is still issuing MFMAs, and
+//     its epilogue runs under the partner's GEMM 2;
+//   * barriers wait for LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): the A-fragment loads of the NEXT GEMM are issued
+//     BEFORE the barrier that opens it, so the L2 round trip of the first k-steps is spent waiting for the slowest wave anyway;
+//   * GEMM 1 is ONE 60-k-step stream (12 conditioner + 3 x 16 tap k-steps; the ring of PFD k-steps never drains between the
+//     conditioner and the taps);
+//   * the biases of every fused layer are staged in LDS once per launch (they were 96 dependent 4-byte L2 loads per wave and layer);
+//   * SKEW: waves 0-3 (one per SIMD; wave w and w + 4 share a SIMD) run at a higher static priority than waves 4-7, so the two
+//     waves of a SIMD drift half a phase apart: the first one's gate / epilogue VALU work runs under the second one's MFMAs.
+// Same arithmetic per frame as diffnet_layer_fwd_bf16_kernel (same images, k order, accumulator start, rounding points): bit-identical.
+// =====================================================================================================================
+// acc[2][2] += A B over NKS k-steps in groups of 4; the ring A[4 D][2] holds k-steps 0 .. 4 D - 1 on entry (gemm_reg_prefetch) and is
+// refilled 4 D k-steps ahead (D = 1, 2 groups).  The schedule is pinned, one sched_barrier per k-step:
+//     ds_read B(k + 1)  |  4 MFMAs of k-step k  |  buffer_load A(k + 4 D) into the registers those MFMAs just read
+// Left to itself the scheduler (a) fully unrolled: sank every A load to one MFMA pair in front of its use and spilled the hoisted SGPR
+// offsets of 120 loads; (b) as a loop: moved all refills of a group to the END of the group and waited for all of them (vmcnt(0))
+// at the top of the next -- an L2 round trip per 16 MFMAs.  The group loop is not unrolled (ring registers are loop-carried).
+// bgrp(kb) returns the LDS byte addresses of the lane's B fragments of k-step kb for the two column blocks; k-step kb + p is 32 p
+// bytes further (a group of 4 never straddles the conditioner / tap segments: 12 and 16 are multiples of 4).
+template <int NKS, int D, bool TOGGLE, typename BG>
+__device__ __forceinline__ void gemm_reg_run(f32x16 (&acc)[2][2], u32x4_t (&A)[4 * D][2], rsrc_t img, unsigned lane16, unsigned abase,
+                                             const unsigned char *lds, BG bgrp) {
+    // abase: byte offset of the wave's first fragment block (k-step 0, gate rows); k-step ks, row block rb at abase + (2 ks + rb) KiB
+    constexpr int NG = NKS / 4;
+    static_assert(NKS % 4 == 0 && NG >= 2 * D && (D == 1 || D == 2), "gemm_reg_run");
+    u32x4_t Bq[2][2];  // B fragments of the current / the next k-step (parity of the k-step), [cb]
+    {
+        unsigned b0, b1;
+        bgrp(0, b0, b1);
+        Bq[0][0] = *reinterpret_cast<const u32x4_t *>(lds + b0);
+        Bq[0][1] = *reinterpret_cast<const u32x4_t *>(lds + b1);
+    }
+    auto group = [&](int kb, int slot, bool refill, bool more) {  // slot / refill / more: compile-time at every call site
+        unsigned b0, b1, n0 = 0, n1 = 0;
+        bgrp(kb, b0, b1);
+        if (more) bgrp(kb + 4, n0, n1);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (p < 3) {
+                Bq[(p + 1) & 1][0] = *reinterpret_cast<const u32x4_t *>(lds + b0 + 32 * (p + 1));
+                Bq[(p + 1) & 1][1] = *reinterpret_cast<const u32x4_t *>(lds + b1 + 32 * (p + 1));
+            } else if (more) {
+                Bq[0][0] = *reinterpret_cast<const u32x4_t *>(lds + n0);
+                Bq[0][1] = *reinterpret_cast<const u32x4_t *>(lds + n1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (TOGGLE) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mma16(A[4 * slot + p][rb], Bq[p & 1][cb], acc[rb][cb]);
+            if (TOGGLE) __builtin_amdgcn_s_setprio(0);
+            if (refill) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    A[4 * slot + p][rb] = buf_load_u4(img, lane16, abase + (unsigned)((2 * (kb + p + 4 * D) + rb) * 1024));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (D == 1) {
+#pragma unroll 1
+        for (int g = 0; g < NG - 1; ++g) group(4 * g, 0, true, true);
+        group(4 * (NG - 1), 0, false, false);
+    } else {
+        constexpr int NR = NG - 2;          // groups that refill their slot
+        constexpr int NP = NR / 2;          // ... in pairs
+#pragma unroll 1
+        for (int g = 0; g < 2 * NP; g += 2) { group(4 * g, 0, true, true); group(4 * g + 4, 1, true, true); }
+        if constexpr (NR % 2) {             // (NG odd) one more refilling group: slot 0, then slots 1, 0 drain
+            group(4 * (NG - 3), 0, true, true); group(4 * (NG - 2), 1, false, true); group(4 * (NG - 1), 0, false, false);
+        } else {
+            group(4 * (NG - 2), 0, false, true); group(4 * (NG - 1), 1, false, false);
+        }
+    }
+}
+template <int PFD>
+__device__ __forceinline__ void gemm_reg_prefetch(u32x4_t (&A)[PFD][2], rsrc_t img, unsigned lane16, unsigned abase) {
+#pragma unroll
+    for (int p = 0; p < PFD; ++p)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) A[p][rb] = buf_load_u4(img, lane16, abase + (unsigned)((2 * p + rb) * 1024));
+}
+// pin a computed value where it is written in the source: an empty volatile asm that "modifies" the register.  Without it LLVM sinks a
+// pure computation to its first use -- e.g. the gate of pass 0, used only after the barrier behind pass 1, moved below pass 1 and kept
+// the 64 accumulators of pass 0 alive through it (92 spilled registers), and the packing of the next x tile moved behind its barrier
+__device__ __forceinline__ void pin(unsigned &v) { asm volatile("" : "+v"(v)); }
+// LDS-only barrier: the waves exchange nothing but LDS tiles, and the A-fragment loads in flight must stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool SKEW, int PF1>
+__global__ void __launch_bounds__(512, 1) diffnet_layers_reg_bf16_kernel(LayersArgs la) {
     const SetDiffnetLayersBf16Args &a = la.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int RBW = 8 / NW;   // 32-row gate blocks per wave (and as many filter blocks)
-    constexpr int NCB = NT / 32;  // 32-frame column blocks
-    constexpr int NTH = NW * 64;  // threads
-    constexpr int NCG = NTH / NT; // channel groups of the staging pass (thread = frame row x channel group)
-    constexpr int CPX = FC / NCG, CPC = FH / NCG;  // x / conditioner channels per thread
-    constexpr bool REG = NT == 64 && NW == 8;       // x' and the skip sum stay in registers between the layers
-    constexpr int PFD = RBW == 1 ? PF : 2;  // A ring depth: 2 x RBW fragments per k-step
+    constexpr int NT = 64, NCB = 2, NTH = 512, NCG = NTH / NT, CPX = FC / NCG, CPC = FH / NCG;
+    constexpr int PF2 = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -455,32 +535,31 @@ __global__ void __launch_bounds__(NW * 64, (NT == 64 && NW == 4) ? 2 : 1) diffne
     int dmax = 1;
     for (int m = 0; m < a.nl; ++m) dmax = max(dmax, 1 << ((a.l0 + m) % a.dilation_cycle_length));
     const int XROWS_MAX = NT + 2 * dmax;
-    unsigned char *xs = lds;                       // [XROWS_MAX][XR]
-    unsigned char *cs = lds + XROWS_MAX * XR;      // [NT][CR]
-    float *dsh = reinterpret_cast<float *>(lds + XROWS_MAX * XR + NT * CR);  // [nl][256] step offsets
+    // LDS: x operand tile [XROWS_MAX][XR] | conditioner tile [NT][CR] | z tile [NT][XR] | step offsets [nl][256] | biases [nl][2][512]
+    const unsigned XS = 0u, CS = (unsigned)(XROWS_MAX * XR), ZS = CS + NT * CR, DS = ZS + NT * XR;
+    unsigned char *xs = lds + XS, *cs = lds + CS, *zs = lds + ZS;
+    float *dsh = reinterpret_cast<float *>(lds + DS);
+    float *bsh = dsh + a.nl * FC;  // [m][0]: b_dil + b_cond, [m][1]: b_out
     const unsigned T4 = 4u * (unsigned)T;
     const rsrc_t rx = make_rsrc(a.x_in + (int64_t)b * FC * T), rxo = make_rsrc(a.x_out + (int64_t)b * FC * T);
     const rsrc_t rsk = make_rsrc(a.skip + (int64_t)b * FC * T), rcd = make_rsrc(a.cond + (int64_t)b * FH * T);
-    // private memory of the block: the fp32 copy of x' between the layers ([256][128]; re-read by the lanes that wrote it).
-    // (Measured and dropped: the skip contributions of the layers parked next to it and summed by the last layer -- one HBM
-    // read-modify-write per group instead of one L2-hot one per layer: 53 -> 54 us per layer for groups of 4, 57 -> 66 for groups of
-    // 8; twice the stores per epilogue and a footprint that outgrows the L2.)
-    float *priv = a.scratch + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (FC * NT);
-    const rsrc_t rpx = make_rsrc(priv);
     const unsigned lane16 = 16u * (unsigned)lane;
-    // accumulator index rb = g * RBW + q: g = 0 gate / residual rows, 1 filter / skip rows; q-th 32-row block of the wave
-    auto row0 = [&](int rb) { return ((rb / RBW) ? FC : 0) + 32 * (RBW * w + (rb % RBW)); };
-    auto aoff1 = [&](int ks, int rb) { return (unsigned)((((RBW * w + (rb % RBW)) * KS1 + ks) * 2 + rb / RBW) * 1024); };
-    auto aoff2 = [&](int ks, int rb) { return (unsigned)((((RBW * w + (rb % RBW)) * KS2 + ks) * 2 + rb / RBW) * 1024); };
+    const int row_g = 32 * w;                  // the wave's gate / residual rows [row_g, row_g + 32); filter / skip rows + 256
+    const unsigned ab1 = (unsigned)(w * KS1 * 2 * 1024), ab2 = (unsigned)(w * KS2 * 2 * 1024);
 
-    // ---- stage: step offsets of every fused layer, x + d_0 (halo d of layer 0), the conditioner tile
+    // ---- stage: step offsets and biases of every fused layer, x + d_0 (halo d of layer 0), the conditioner tile
     {
         for (int i = tid; i < a.nl * FC; i += NTH) {
             const int m = i >> 8, c = i & 255;
             dsh[i] = a.dstep[(int64_t)(a.l0 + m) * a.d_ls + (int64_t)b * a.d_bs + (int64_t)c * a.d_cs];
         }
+        for (int i = tid; i < a.nl * 512; i += NTH) {
+            const int m = i >> 9, r = i & 511;
+            bsh[m * 1024 + r] = a.b_dil[i] + a.b_cond[i];
+            bsh[m * 1024 + 512 + r] = a.b_out[i];
+        }
         const int d = 1 << (a.l0 % a.dilation_cycle_length);
-        const int f = tid % NT, cg = __builtin_amdgcn_readfirstlane(tid / NT);  // cg 0 .. NCG - 1
+        const int f = tid % NT, cg = __builtin_amdgcn_readfirstlane(tid / NT);  // cg 0 .. 7
         const int t = ts - d + f;
         const bool tvx = t >= 0 && t < T;
         const unsigned vox = 4u * (unsigned)min(max(t, 0), T - 1);
@@ -532,224 +611,596 @@ __global__ void __launch_bounds__(NW * 64, (NT == 64 && NW == 4) ? 2 : 1) diffne
         }
     }
     // per column block: frame of this lane, whether it lies inside the utterance, whether it is stored
-    bool inT[NCB], st[NCB];
-    unsigned vo4[NCB], vop[NCB];
+    // (mT: all-ones / zero word ANDed onto the packed bf16 pairs -- a `frame inside T ? f(y) : 0` select compiled to one exec-mask
+    //  branch per ELEMENT around the transcendental chain, 32 serialized chains per wave and gate)
+    bool st[NCB];
+    unsigned vo4[NCB], mT[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         const int t = ts + cb * 32 + l31;
-        inT[cb] = t >= 0 && t < T;
+        mT[cb] = (t >= 0 && t < T) ? 0xffffffffu : 0u;
         st[cb] = t >= tv0 && t < tv1;
         vo4[cb] = 4u * (unsigned)(4 * half * T + min(max(t, 0), T - 1));
-        vop[cb] = 4u * (unsigned)(4 * half * NT + cb * 32 + l31);
     }
-    const unsigned lb = 16u * (unsigned)half;
-    // REG: the wave's rows of x (fp32, the residual chain) and of the skip sum for the whole group
-    float xkeep[REG ? RBW : 1][REG ? NCB : 1][16], skacc[REG ? RBW : 1][REG ? NCB : 1][16];
-    if constexpr (REG) {
+    // the wave's rows of x (fp32, the residual chain) and of the skip sum, in registers for the whole group
+    float xkeep[NCB][16], skacc[NCB][16];
+    {
         const bool first0 = a.first != 0;
 #pragma unroll
-        for (int q = 0; q < RBW; ++q)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    xkeep[q][cb][r] = buf_load(rx, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
-                    skacc[q][cb][r] = first0 ? 0.0f : buf_load(rsk, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
-                }
+            for (int r = 0; r < 16; ++r) {
+                xkeep[cb][r] = buf_load(rx, vo4[cb], (unsigned)(row_g + urow(r)) * T4);
+                skacc[cb][r] = first0 ? 0.0f : buf_load(rsk, vo4[cb], (unsigned)(row_g + urow(r)) * T4);
+            }
     }
-    // debug (tools/bf16_phase_probe.py): thread 0 of block (1, 1) adds the s_memtime ticks of the phases of its layers m >= 1 to
-    // buf[0..4] (accumulator init + barrier, GEMM 1, gate, GEMM 2, epilogue) and counts them in buf[7]
-    uint64_t *const pb = (g_bf16_phase_buf && blockIdx.x == 1 && blockIdx.y == 1 && tid == 0) ? g_bf16_phase_buf : nullptr;
-    uint64_t tprev = 0;
-#define LF_PHASE(i)                                                   \
-    if (pb && m >= 1) {                                               \
+    // per-lane LDS byte offsets of the B fragments (frame row l31, k half) and of the lane's 4-row groups in the bias vectors
+    const unsigned bc0 = CS + (unsigned)(l31 * CR + half * 16);   // conditioner tile
+    const unsigned bx0 = XS + (unsigned)(l31 * XR + half * 16);   // x tile, tap 0
+    const unsigned bz0 = ZS + (unsigned)(l31 * XR + half * 16);   // z tile
+    const unsigned bb0 = DS + (unsigned)(a.nl * FC * 4) + (unsigned)((row_g + 4 * half) * 4);
+
+    // debug (tools/bf16_layers_probe.py): s_memtime ticks of the phases of the layers m >= 1 of block (1, 1), summed in scalar registers
+    // and written once at the end by wave 0 (buf[0..4], count in buf[7]) and wave 4 (buf[8..12]): no memory operation inside the
+    // layer loop (a flat access there made the wait-count pass drain the A ring, vmcnt(0), at the top of every k-step group)
+    const bool probe = g_bf16_phase_buf && blockIdx.x == 1 && blockIdx.y == 1;
+    uint64_t tprev = 0, tph[5] = {0, 0, 0, 0, 0};
+#define LR_PHASE(i)                                                   \
+    if (probe && m >= 1) {                                            \
         const uint64_t tn = __builtin_amdgcn_s_memtime();             \
-        pb[i] += tn - tprev;                                          \
+        tph[i] += tn - tprev;                                         \
         tprev = tn;                                                   \
     }
-
+    typedef unsigned lr_u32x2 __attribute__((ext_vector_type(2)));
+    // SKEW: a static priority instead of the per-k-step toggles -- waves 0-3 win every arbitration against their SIMD partners 4-7
+    if (SKEW && w < 4) __builtin_amdgcn_s_setprio(1);
+    u32x4_t A1[PF1][2], A2[PF2][2];
+    {
+        const rsrc_t rw1 = make_rsrc(reinterpret_cast<const unsigned short *>(a.img));
+        gemm_reg_prefetch<PF1>(A1, rw1, lane16, ab1);
+    }
     for (int m = 0; m < a.nl; ++m) {
-        if (pb) tprev = __builtin_amdgcn_s_memtime();
+        if (probe) tprev = __builtin_amdgcn_s_memtime();
         const int l = a.l0 + m, d = 1 << (l % a.dilation_cycle_length);
         const bool last = m == a.nl - 1;
         const unsigned short *img = reinterpret_cast<const unsigned short *>(a.img) + (int64_t)m * N_IMG;
         const rsrc_t rw1 = make_rsrc(img), rw2 = make_rsrc(img + OFF_W2B);
-        const rsrc_t rbd = make_rsrc(a.b_dil + (int64_t)m * 512), rbc = make_rsrc(a.b_cond + (int64_t)m * 512);
-        const rsrc_t rbo = make_rsrc(a.b_out + (int64_t)m * 512);
-        const int XROWS = NT + 2 * d;
-        f32x16 acc[2 * RBW][NCB];
+        const unsigned bbm = bb0 + (unsigned)(m * 4096);
+        f32x16 acc[2][NCB];
+        // accumulators start at b_dil + b_cond: register r <-> row (rb ? 256 : 0) + row_g + urow(r) + 4 half
 #pragma unroll
-        for (int rb = 0; rb < 2 * RBW; ++rb)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned ur = (unsigned)(row0(rb) + urow(r));
-                const float bias = buf_load(rbd, lb, 4u * ur) + buf_load(rbc, lb, 4u * ur);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + bbm + (unsigned)((rb * FC + 8 * g4) * 4));
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = bias;
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][4 * g4 + e] = bv[e];
             }
-        __syncthreads();  // the x tile of this layer (staged above / written by the previous layer's epilogue) is complete
-        LF_PHASE(0)
+        lds_barrier();  // the x tile of this layer (staged above / written by the previous layer's epilogue) is complete
+        LR_PHASE(0)
 
         // ---- GEMM 1: y = [Wcond | Wdil tap 0 | tap 1 | tap 2] x [cond ; x + d shifted]
-        gemm_bf16_a<2 * RBW, NCB, PFD>(acc, rw1, lane16, KS_C, lds, aoff1, [&](int ks, int cb) {
-            return (unsigned)(XROWS_MAX * XR + (cb * 32 + l31) * CR + (ks * 16 + half * 8) * 2);
-        });
-        gemm_bf16_a<2 * RBW, NCB, PFD>(acc, rw1, lane16, 3 * KS_T, lds, [&](int ks, int rb) { return aoff1(KS_C + ks, rb); },
-                            [&](int ks, int cb) {
-            const int tap = ks >> 4, c0 = (ks & 15) * 16;
-            return (unsigned)((cb * 32 + l31 + tap * d) * XR + (c0 + half * 8) * 2);
-        });
-
-        LF_PHASE(1)
-        // ---- gate; residual rows of x: from HBM for the first fused layer, from the block's private copy afterwards
-        float xres[REG ? 1 : RBW][REG ? 1 : NCB][16];
-        if constexpr (!REG) {
-            if (m > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the x' rows this lane stored in the previous epilogue are in memory
-#pragma unroll
-            for (int q = 0; q < RBW; ++q)
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        xres[q][cb][r] = m == 0 ? buf_load(rx, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4)
-                                                : buf_load(rpx, vop[cb], (unsigned)(row0(q) + urow(r)) * (4u * NT));
+        {
+            const unsigned dx = (unsigned)(d * XR);
+            auto bf1 = [&](int kb, unsigned &b0, unsigned &b1) {
+                // branch-free (a select on the uniform kb compiled to branches inside the k loop, which made the wait-count
+                // pass give up on the ring: vmcnt(0) at the top of every group)
+                const unsigned mc = (unsigned)((kb - KS_C) >> 31);  // all ones for the conditioner k-steps
+                const unsigned kt = (unsigned)(kb - KS_C) & 63u, tap = kt >> 4, c0 = (kt & 15u) * 32u;
+                b0 = (mc & (bc0 + (unsigned)kb * 32u)) | (~mc & (bx0 + tap * dx + c0));
+                b1 = b0 + ((mc & (32u * CR)) | (~mc & (32u * XR)));
+            };
+            gemm_reg_run<KS1, PF1 / 4, !SKEW>(acc, A1, rw1, lane16, ab1, lds, bf1);
         }
-        __syncthreads();  // every wave is done reading the x tile
-        typedef unsigned lf_u32x2 __attribute__((ext_vector_type(2)));
+        gemm_reg_prefetch<PF2>(A2, rw2, lane16, ab2);  // GEMM 2's first fragments travel under the gate
+        LR_PHASE(1)
+
+        // ---- gate -> z tile (own LDS tile: no wave has to wait for the others to leave GEMM 1)
 #pragma unroll
-        for (int q = 0; q < RBW; ++q)
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {  // registers 4 g4 .. 4 g4 + 3 are 4 consecutive channels: one 8-byte write
+                float z[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = fsig(acc[0][cb][4 * g4 + e]) * ftanh(acc[1][cb][4 * g4 + e]);
+                lr_u32x2 u;
+                u[0] = pack2(z[0], z[1]) & mT[cb]; u[1] = pack2(z[2], z[3]) & mT[cb];
+                *reinterpret_cast<lr_u32x2 *>(zs + (cb * 32 + l31) * XR + (row_g + 8 * g4 + 4 * half) * 2) = u;
+            }
+        // accumulators of GEMM 2: residual rows start at b_out + x, skip rows at b_out
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + bbm + (unsigned)((512 + rb * FC + 8 * g4) * 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][4 * g4 + e] = rb == 0 ? bv[e] + xkeep[cb][4 * g4 + e] : bv[e];
+            }
+        lds_barrier();  // the z tile is complete (and every wave has left GEMM 1: the x tile may be overwritten)
+        LR_PHASE(2)
+
+        // ---- GEMM 2: o = Wout z  (z tile row j <-> frame ts + j)
+        {
+            auto bf2 = [&](int kb, unsigned &b0, unsigned &b1) { b0 = bz0 + (unsigned)kb * 32u; b1 = b0 + 32u * XR; };
+            gemm_reg_run<KS2, PF2 / 4, !SKEW>(acc, A2, rw2, lane16, ab2, lds, bf2);
+        }
+        if (!last) gemm_reg_prefetch<PF1>(A1, make_rsrc(img + N_IMG), lane16, ab1);  // the next layer's first fragments
+        LR_PHASE(3)
+
+        // ---- epilogue: x' = (x + o_res) / sqrt 2 and the skip sum stay in registers; bf16(x' + d_next) -> the x tile
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                xkeep[cb][r] = acc[0][cb][r] * RSQRT2;
+                skacc[cb][r] = (a.first != 0 && m == 0) ? acc[1][cb][r] : acc[1][cb][r] + skacc[cb][r];
+            }
+        if (!last) {
+            const int dn = 1 << ((l + 1) % a.dilation_cycle_length);
+            const float *dnx = dsh + (m + 1) * FC;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {  // registers 4 g4 .. 4 g4 + 3 are 4 consecutive channels: one 8-byte write
-                    float z[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) z[e] = inT[cb] ? fsig(acc[q][cb][4 * g4 + e]) * ftanh(acc[RBW + q][cb][4 * g4 + e]) : 0.0f;
-                    lf_u32x2 u;
-                    u[0] = pack2(z[0], z[1]); u[1] = pack2(z[2], z[3]);
-                    *reinterpret_cast<lf_u32x2 *>(xs + (cb * 32 + l31) * XR + (row0(q) + 8 * g4 + 4 * half) * 2) = u;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int ch = row_g + 8 * g4 + 4 * half;
+                    const f32x4 dv = *reinterpret_cast<const f32x4 *>(dnx + ch);
+                    lr_u32x2 u;
+                    u[0] = pack2(xkeep[cb][4 * g4] + dv[0], xkeep[cb][4 * g4 + 1] + dv[1]) & mT[cb];
+                    u[1] = pack2(xkeep[cb][4 * g4 + 2] + dv[2], xkeep[cb][4 * g4 + 3] + dv[3]) & mT[cb];
+                    *reinterpret_cast<lr_u32x2 *>(xs + (dn + cb * 32 + l31) * XR + ch * 2) = u;
                 }
+        } else {
 #pragma unroll
-        for (int rb = 0; rb < 2 * RBW; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float bias = buf_load(rbo, lb, 4u * (unsigned)(row0(rb) + urow(r)));
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) {
-                    if constexpr (REG) acc[rb][cb][r] = rb < RBW ? bias + xkeep[rb % RBW][cb][r] : bias;
-                    else acc[rb][cb][r] = rb < RBW ? bias + xres[rb % RBW][cb][r] : bias;
-                }
-            }
-        __syncthreads();
-        LF_PHASE(2)
-
-        // ---- GEMM 2: o = Wout z  (z tile row j <-> frame ts + j)
-        gemm_bf16_a<2 * RBW, NCB, PFD>(acc, rw2, lane16, KS2, lds, aoff2, [&](int ks, int cb) {
-            return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2);
-        });
-
-        LF_PHASE(3)
-        // ---- epilogue: x' = (x + o_res) / sqrt 2 -> private fp32 copy + operand tile of the next layer, or the output tensor
-        __syncthreads();  // every wave is done reading the z tile: the next layer's x tile goes over it
-        if constexpr (REG) {
-            // x' and the skip sum stay in the wave's registers; only the bf16 operand tile of the next layer goes through LDS
-#pragma unroll
-            for (int q = 0; q < RBW; ++q)
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb)
+            for (int cb = 0; cb < NCB; ++cb) {
+                if (st[cb]) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        xkeep[q][cb][r] = acc[q][cb][r] * RSQRT2;
-                        skacc[q][cb][r] = (a.first != 0 && m == 0) ? acc[RBW + q][cb][r] : acc[RBW + q][cb][r] + skacc[q][cb][r];
+                        buf_store(xkeep[cb][r], rxo, vo4[cb], (unsigned)(row_g + urow(r)) * T4);
+                        buf_store(skacc[cb][r], rsk, vo4[cb], (unsigned)(row_g + urow(r)) * T4);
                     }
+                }
+            }
+        }
+        LR_PHASE(4)
+    }
+#undef LR_PHASE
+    if (probe && (tid == 0 || tid == 256)) {
+        uint64_t *pb = g_bf16_phase_buf + (tid ? 8 : 0);
+        for (int i = 0; i < 5; ++i) pb[i] += tph[i];
+        pb[7] += (uint64_t)(a.nl - 1);
+    }
+}
+
+// =====================================================================================================================
+// 128-frame register-resident fused layer groups (round 4; the shape for batches that fill the chip).
+//
+// Why: at 64 frames per block every weight fragment (1 KiB from L2) feeds 2 MFMAs per wave -- 16 x 1 KiB loads per CU and k-step = 256
+// cycles of the 64 B/clk L1 path against 256 cycles of MFMA issue per SIMD: the weight stream co-limits the matrix pipe, and a deeper
+// ring / fewer barriers did not move the time (profiles/r04_bf16_ab.log).  Here a block owns 128 frames and GEMM 1 runs in TWO PASSES
+// over the wave's rows: pass h multiplies ONE 32-row A block [16 gate rows ; the matching 16 filter rows] (gathered from the same
+// packed image: lanes 0-15 of each k half read gate-row fragments, lanes 16-31 filter-row fragments) by 4 column blocks -- 4 MFMAs
+// per 1 KiB of weights, half the L2 bytes per MFMA, 64 accumulator registers per pass.  The gate stays lane-local (gate row i in
+// register r, filter row i in register r + 8).  128 frames also make B = 32, T = 800 exactly ONE round: 8 tiles per utterance = 256
+// blocks on 256 CUs for any halo <= 14 (64-frame tiles: 480 blocks = 1.9 rounds).
+//   registers: x' rows 64 (they ARE GEMM 2's residual accumulators) + pass accumulators 64 + packed z of pass 0 (16) + A ring 16 +
+//   B fragments 16; the skip sum does not fit next to them: between the layers of a group the block's skip rows live in a private
+//   buffer in ACCUMULATOR order (16 coalesced 16-byte loads + 16 stores per wave and layer; the skip tensor itself is touched by the
+//   first and the last layer of the group only), and GEMM 2 runs in two passes too -- skip rows first, with the old rows requested
+//   before the barrier in front of it and added right behind it (the round trip hides under the pass), residual rows second.  (Measured on the way: reading the
+//   row-major skip tensor before GEMM 2 and storing after it -- 64 + 64 dword accesses and the L2 round trip in front of a barrier:
+//   50 us per layer, 18 % of it there; adding the rows at the L2 with buffer_atomic_add_f32: 56 us, the atomics of 256 blocks
+//   serialise and GEMM 2's fragment loads queue behind them.)
+//   LDS: x tile (z overlays it), conditioner tile, step offsets of the group, biases double-buffered per layer: 4 barriers per layer, but
+//   all VALU work (gate, x' epilogue, packing) is done BEFORE the barrier that frees the tile it is written to; between those barrier
+//   pairs a wave only issues its 16 / 32 LDS writes.
+// Arithmetic per frame as diffnet_layer_fwd_bf16_kernel (same images, k order, accumulator start, rounding points, skip = old + (bias +
+// products)): x and the skip sum are bit-identical.
+// =====================================================================================================================
+// acc[NRB][4] += A B over NKS k-steps in groups of 4 with the pinned schedule of gemm_reg_run; ring A[4 D][NRB].
+// aoff(ks, rb): wave-uniform byte offset of the fragment block; avo: per-lane byte offset inside it.
+#ifndef SET_T128_EXP
+#define SET_T128_EXP 0
+#endif
+template <int NRB, int NKS, int D, bool TOGGLE, bool BDB, typename AO, typename BG>
+__device__ __forceinline__ void gemm_t128_run(f32x16 (&acc)[NRB][4], u32x4_t (&A)[4 * D][NRB], rsrc_t img, unsigned avo, AO aoff,
+                                              const unsigned char *lds, BG bgrp) {
+    // BDB: the B fragments of k-step k + 1 are read under the MFMAs of k-step k (16 more registers); else each k-step reads its own
+    constexpr int NG = NKS / 4;
+    static_assert(NKS % 4 == 0 && NG >= 2 * D && (D == 1 || D == 2), "gemm_t128_run");
+    u32x4_t Bq[BDB ? 2 : 1][4];
+    if (BDB) {
+        unsigned b0, bs;
+        bgrp(0, b0, bs);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) Bq[0][cb] = *reinterpret_cast<const u32x4_t *>(lds + b0 + cb * bs);
+    }
+    auto group = [&](int kb, int slot, bool refill, bool more) {
+        unsigned b0, bs, n0 = 0, ns = 0;
+        bgrp(kb, b0, bs);
+        if (BDB && more) bgrp(kb + 4, n0, ns);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#if (SET_T128_EXP & 2)  // measurement build (tools/build_exp.sh): no B-fragment reads after the first k-step (results are wrong)
+            if (kb == 0 && p == 0) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) Bq[0][cb] = *reinterpret_cast<const u32x4_t *>(lds + b0 + cb * bs);
+                if (BDB) { for (int cb = 0; cb < 4; ++cb) Bq[1][cb] = Bq[0][cb]; }
+            }
+#else
+            if (!BDB) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) Bq[0][cb] = *reinterpret_cast<const u32x4_t *>(lds + b0 + cb * bs + 32 * p);
+            } else if (p < 3) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) Bq[(p + 1) & 1][cb] = *reinterpret_cast<const u32x4_t *>(lds + b0 + cb * bs + 32 * (p + 1));
+            } else if (more) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) Bq[0][cb] = *reinterpret_cast<const u32x4_t *>(lds + n0 + cb * ns);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if (TOGGLE) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = mma16(A[4 * slot + p][rb], Bq[BDB ? (p & 1) : 0][cb], acc[rb][cb]);
+            if (TOGGLE) __builtin_amdgcn_s_setprio(0);
+#if !(SET_T128_EXP & 1)  // measurement build: bit 0 = no weight-fragment refills (results are wrong)
+            if (refill) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) A[4 * slot + p][rb] = buf_load_u4(img, avo, aoff(kb + p + 4 * D, rb));
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (D == 1) {
+#pragma unroll 1
+        for (int g = 0; g < NG - 1; ++g) group(4 * g, 0, true, true);
+        group(4 * (NG - 1), 0, false, false);
+    } else {
+        constexpr int NR = NG - 2, NP = NR / 2;
+#pragma unroll 1
+        for (int g = 0; g < 2 * NP; g += 2) { group(4 * g, 0, true, true); group(4 * g + 4, 1, true, true); }
+        if constexpr (NR % 2) {
+            group(4 * (NG - 3), 0, true, true); group(4 * (NG - 2), 1, false, true); group(4 * (NG - 1), 0, false, false);
+        } else {
+            group(4 * (NG - 2), 0, false, true); group(4 * (NG - 1), 1, false, false);
+        }
+    }
+}
+template <int NRB, int PFD, typename AO>
+__device__ __forceinline__ void gemm_t128_prefetch(u32x4_t (&A)[PFD][NRB], rsrc_t img, unsigned avo, AO aoff) {
+#pragma unroll
+    for (int p = 0; p < PFD; ++p)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) A[p][rb] = buf_load_u4(img, avo, aoff(p, rb));
+}
+
+template <bool SKEW, int NSKR>
+__global__ void __launch_bounds__(512, 1) diffnet_layers_t128_bf16_kernel(LayersArgs la) {
+    const SetDiffnetLayersBf16Args &a = la.a;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int NT = 128, NCB = 4, NTH = 512, NCG = NTH / NT, CPX = FC / NCG, CPC = FH / NCG;
+    constexpr int D1 = 1, D2 = 1;  // A ring depth in groups of 4 k-steps: GEMM 1 passes 4 k-steps x 1 fragment, GEMM 2 4 k-steps x 2
+    constexpr bool BDB1 = false, BDB2 = false;  // B fragments single-buffered (the SIMD partner covers the LDS latency; the registers go to the ring / the old skip rows)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y, T = a.T;
+    const int tv0 = blockIdx.x * la.nv, ts = tv0 - la.hh;  // first stored / first computed frame
+    const int tv1 = min(tv0 + la.nv, T);                    // end of the stored range
+    int dmax = 1;
+    for (int m = 0; m < a.nl; ++m) dmax = max(dmax, 1 << ((a.l0 + m) % a.dilation_cycle_length));
+    const int XROWS_MAX = NT + 2 * dmax;
+    // LDS: x operand tile [XROWS_MAX][XR] (z overlays rows 0 .. 127) | conditioner tile [NT][CR] | step offsets [nl][256] | biases [2][2][512]
+    const unsigned XS = 0u, CS = (unsigned)(XROWS_MAX * XR), DS = CS + NT * CR, BS = DS + (unsigned)(a.nl * FC * 4);
+    unsigned char *xs = lds + XS, *cs = lds + CS;
+    float *dsh = reinterpret_cast<float *>(lds + DS);
+    float *bsh = reinterpret_cast<float *>(lds + BS);  // [parity of m][0: b_dil + b_cond, 1: b_out][512]
+    const unsigned T4 = 4u * (unsigned)T;
+    const rsrc_t rx = make_rsrc(a.x_in + (int64_t)b * FC * T), rxo = make_rsrc(a.x_out + (int64_t)b * FC * T);
+    const rsrc_t rsk = make_rsrc(a.skip + (int64_t)b * FC * T), rcd = make_rsrc(a.cond + (int64_t)b * FH * T);
+    const unsigned lane16 = 16u * (unsigned)lane;
+    const int row_g = 32 * w;  // the wave's gate / residual rows [row_g, row_g + 32); filter / skip rows + 256
+    // the block's private copy of its skip rows between the layers of the group, in accumulator order: [wave][cb][g4][lane][4 floats]
+    // (one coalesced 16-byte access per lane and 4 registers; the skip tensor itself is row-major: 4-byte accesses)
+    const rsrc_t rps = make_rsrc(a.scratch + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (FC * NT) + (int64_t)w * (NCB * 4 * 64 * 4));
+    // GEMM 1 pass h: lane l of the A block holds row i = l & 31: i < 16 gate row row_g + 16 h + i, else filter row row_g + 16 h + i - 16;
+    // in the packed image w1b[w][ks][rb][lane'][8] that fragment is rb = i >> 4, lane' = 16 h + (i & 15) + 32 (l >> 5)
+    const unsigned avo1 = (unsigned)(((l31 >> 4) * 64 + (l31 & 15) + 32 * half) * 16);
+    auto aoff1h = [&](int h) { return [=](int ks, int) { return (unsigned)((w * KS1 + ks) * 2048 + h * 256); }; };
+    auto aoff2r = [&](int rbsel) { return [=](int ks, int) { return (unsigned)(((w * KS2 + ks) * 2 + rbsel) * 1024); }; };  // GEMM 2: rb 0 residual rows, 1 skip rows
+
+    // ---- stage: step offsets of every fused layer, biases of layer 0, x + d_0 (halo d of layer 0), the conditioner tile
+    {
+        for (int i = tid; i < a.nl * FC; i += NTH) {
+            const int m = i >> 8, c = i & 255;
+            dsh[i] = a.dstep[(int64_t)(a.l0 + m) * a.d_ls + (int64_t)b * a.d_bs + (int64_t)c * a.d_cs];
+        }
+        bsh[tid] = a.b_dil[tid] + a.b_cond[tid];
+        bsh[512 + tid] = a.b_out[tid];
+        const int d = 1 << (a.l0 % a.dilation_cycle_length);
+        const int f = tid % NT, cg = __builtin_amdgcn_readfirstlane(tid / NT);  // cg 0 .. 3
+        const int t = ts - d + f;
+        const bool tvx = t >= 0 && t < T;
+        const unsigned vox = 4u * (unsigned)min(max(t, 0), T - 1);
+        const int tcn = ts + f;
+        const bool tvc = tcn >= 0 && tcn < T;
+        const unsigned voc = 4u * (unsigned)min(max(tcn, 0), T - 1);
+        float vx[CPX], vc[CPC];
+#pragma unroll
+        for (int k = 0; k < CPX; ++k) vx[k] = buf_load(rx, vox, (unsigned)(CPX * cg + k) * T4);
+#pragma unroll
+        for (int k = 0; k < CPC; ++k) vc[k] = buf_load(rcd, voc, (unsigned)(CPC * cg + k) * T4);
+        for (int i = tid; i < (XROWS_MAX - (NT + 2 * d)) * (XR / 16); i += NTH)
+            *reinterpret_cast<u32x4_t *>(xs + (NT + 2 * d) * XR + i * 16) = (u32x4_t){0u, 0u, 0u, 0u};
+        __syncthreads();  // dsh
+#pragma unroll
+        for (int q = 0; q < CPX / 8; ++q) {
+            const f32x4 d0 = *reinterpret_cast<const f32x4 *>(dsh + CPX * cg + 8 * q);
+            const f32x4 d1 = *reinterpret_cast<const f32x4 *>(dsh + CPX * cg + 8 * q + 4);
+            u32x4_t u;
+            u[0] = tvx ? pack2(vx[8 * q + 0] + d0[0], vx[8 * q + 1] + d0[1]) : 0u;
+            u[1] = tvx ? pack2(vx[8 * q + 2] + d0[2], vx[8 * q + 3] + d0[3]) : 0u;
+            u[2] = tvx ? pack2(vx[8 * q + 4] + d1[0], vx[8 * q + 5] + d1[1]) : 0u;
+            u[3] = tvx ? pack2(vx[8 * q + 6] + d1[2], vx[8 * q + 7] + d1[3]) : 0u;
+            *reinterpret_cast<u32x4_t *>(xs + f * XR + (CPX * cg + 8 * q) * 2) = u;
+        }
+#pragma unroll
+        for (int q = 0; q < CPC / 8; ++q) {
+            u32x4_t u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = tvc ? pack2(vc[8 * q + 2 * e], vc[8 * q + 2 * e + 1]) : 0u;
+            *reinterpret_cast<u32x4_t *>(cs + f * CR + (CPC * cg + 8 * q) * 2) = u;
+        }
+        if (f < 2 * d) {
+            const int j = NT + f, th = ts - d + j;
+            const bool tvh = th >= 0 && th < T;
+            const unsigned voh = 4u * (unsigned)min(max(th, 0), T - 1);
+            float vh[CPX];
+#pragma unroll
+            for (int k = 0; k < CPX; ++k) vh[k] = buf_load(rx, voh, (unsigned)(CPX * cg + k) * T4);
+#pragma unroll
+            for (int q = 0; q < CPX / 8; ++q) {
+                u32x4_t u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    u[e] = tvh ? pack2(vh[8 * q + 2 * e] + dsh[CPX * cg + 8 * q + 2 * e], vh[8 * q + 2 * e + 1] + dsh[CPX * cg + 8 * q + 2 * e + 1]) : 0u;
+                *reinterpret_cast<u32x4_t *>(xs + j * XR + (CPX * cg + 8 * q) * 2) = u;
+            }
+        }
+    }
+    // per column block: frame of this lane; mT: all-ones inside the utterance (ANDed onto packed bf16 pairs); st: stored by this block
+    bool st[NCB];
+    unsigned vo4[NCB], mT[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int t = ts + cb * 32 + l31;
+        mT[cb] = (t >= 0 && t < T) ? 0xffffffffu : 0u;
+        st[cb] = t >= tv0 && t < tv1;
+        vo4[cb] = 4u * (unsigned)(4 * half * T + min(max(t, 0), T - 1));
+    }
+    f32x16 accx[1][NCB];  // the wave's rows of x (fp32, the residual chain): GEMM 2's residual accumulators, live across the layers
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[0][cb][r] = buf_load(rx, vo4[cb], (unsigned)(row_g + urow(r)) * T4);
+    const unsigned bc0 = CS + (unsigned)(l31 * CR + half * 16);   // conditioner tile
+    const unsigned bx0 = XS + (unsigned)(l31 * XR + half * 16);   // x tile, tap 0 (and the z tile)
+    // byte offsets of the lane's 4-row groups in a bias vector: GEMM 1 block [16 gate ; 16 filter] rows, GEMM 2 32-row blocks
+    const unsigned bb1 = BS + (unsigned)((row_g + 4 * half) * 4), bb2 = BS + 2048u + (unsigned)((row_g + 4 * half) * 4);
+
+    const bool probe = g_bf16_phase_buf && blockIdx.x == 1 && blockIdx.y == 1;
+    uint64_t tprev = 0, tph[6] = {0, 0, 0, 0, 0, 0};
+#define LT_PHASE(i)                                                   \
+    if (probe && m >= 1) {                                            \
+        const uint64_t tn = __builtin_amdgcn_s_memtime();             \
+        tph[i] += tn - tprev;                                         \
+        tprev = tn;                                                   \
+    }
+    typedef unsigned lt_u32x2 __attribute__((ext_vector_type(2)));
+    if (SKEW && w < 4) __builtin_amdgcn_s_setprio(1);
+    // old skip rows per column block: blocks < NSKR live in registers for the whole group, the others travel through the private copy per layer
+    f32x16 sko[NCB];
+    u32x4_t A1[4 * D1][1], A2[4 * D2][1];
+    gemm_t128_prefetch<1, 4 * D1>(A1, make_rsrc(reinterpret_cast<const unsigned short *>(a.img)), avo1, aoff1h(0));
+    for (int m = 0; m < a.nl; ++m) {
+        if (probe) tprev = __builtin_amdgcn_s_memtime();
+        const int l = a.l0 + m, d = 1 << (l % a.dilation_cycle_length);
+        const bool last = m == a.nl - 1;
+        const unsigned short *img = reinterpret_cast<const unsigned short *>(a.img) + (int64_t)m * N_IMG;
+        const rsrc_t rw1 = make_rsrc(img), rw2 = make_rsrc(img + OFF_W2B);
+        const unsigned bpm = (unsigned)((m & 1) * 4096);
+        // the next layer's biases: loaded now, written to the other LDS buffer after the next barrier pair
+        float nb1 = 0.0f, nb2 = 0.0f;
+        if (!last) { nb1 = a.b_dil[(m + 1) * 512 + tid] + a.b_cond[(m + 1) * 512 + tid]; nb2 = a.b_out[(m + 1) * 512 + tid]; }
+        const unsigned dx = (unsigned)(d * XR);
+        auto bf1 = [&](int kb, unsigned &b0, unsigned &bs) {
+            const unsigned mc = (unsigned)((kb - KS_C) >> 31);  // all ones for the conditioner k-steps
+            const unsigned kt = (unsigned)(kb - KS_C) & 63u, tap = kt >> 4, c0 = (kt & 15u) * 32u;
+            b0 = (mc & (bc0 + (unsigned)kb * 32u)) | (~mc & (bx0 + tap * dx + c0));
+            bs = (mc & (32u * CR)) | (~mc & (32u * XR));
+        };
+        unsigned zp[2][NCB][2][2];  // packed gated z of both passes: [h][cb][g2][2 words = 4 channels]
+        lds_barrier();  // B1: the x tile of this layer (staged above / written by the previous layer's epilogue) is complete
+        LT_PHASE(0)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // ---- GEMM 1, pass h: rows [16 gate ; 16 filter] x 128 frames, accumulators start at b_dil + b_cond
+            f32x16 acc[1][NCB];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + bb1 + bpm + (unsigned)(((g4 >> 1) * FC + 16 * h + 8 * (g4 & 1)) * 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) acc[0][cb][4 * g4 + e] = bv[e];
+            }
+            gemm_t128_run<1, KS1, D1, !SKEW, BDB1>(acc, A1, rw1, avo1, aoff1h(h), lds, bf1);
+            if (h == 0) gemm_t128_prefetch<1, 4 * D1>(A1, rw1, avo1, aoff1h(1));  // pass 1's first fragments travel under the gate of pass 0
+            // ---- gate of the pass (lane-local: gate row in register r < 8, its filter row in register r + 8), packed, kept in registers
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    float z[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[e] = fsig(acc[0][cb][4 * g2 + e]) * ftanh(acc[0][cb][8 + 4 * g2 + e]);
+                    zp[h][cb][g2][0] = pack2(z[0], z[1]) & mT[cb];
+                    zp[h][cb][g2][1] = pack2(z[2], z[3]) & mT[cb];
+                    pin(zp[h][cb][g2][0]); pin(zp[h][cb][g2][1]);
+                    __builtin_amdgcn_sched_barrier(0);  // 4 chains in flight are enough to fill the VALU; 32 at once cost 23 spilled registers
+                }
+            __builtin_amdgcn_sched_barrier(0);  // (phase fences: the scheduler otherwise hoists the next phase's loads over this one's live values)
+        }
+        // GEMM 2 runs in two passes as well: skip rows first, residual rows second.  The old skip rows (from the skip tensor for the first
+        // layer of the group unless it is the first of the network, from the private copy afterwards) and the first weight fragments are
+        // requested here: they travel while this wave waits for the others and through the skip pass
+        gemm_t128_prefetch<1, 4 * D2>(A2, rw2, lane16, aoff2r(1));
+        const bool sk_zero = (SET_T128_EXP & 4) ? true : (a.first != 0 && m == 0);  // measurement build bit 2: no skip traffic between the layers
+        if (m == 0 || (SET_T128_EXP & 4)) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sko[cb][r] = sk_zero ? 0.0f : buf_load(rsk, vo4[cb], (unsigned)(row_g + urow(r)) * T4);
+        } else {
+#pragma unroll
+            for (int cb = NSKR; cb < NCB; ++cb) {
+                if (st[cb]) {  // the frames this block stores: the others never leave the tile
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 v = (SET_T128_EXP & 8) ? buf_load4(rps, lane16, (unsigned)((cb * 4 + g4) * 1024)) : buf_load4_stream(rps, lane16, (unsigned)((cb * 4 + g4) * 1024));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sko[cb][4 * g4 + e] = v[e];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        LT_PHASE(1)
+        lds_barrier();  // B2: every wave has left GEMM 1: the z tile goes over the x tile
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    lt_u32x2 u;
+                    u[0] = zp[h][cb][g2][0]; u[1] = zp[h][cb][g2][1];
+                    *reinterpret_cast<lt_u32x2 *>(xs + (cb * 32 + l31) * XR + (row_g + 16 * h + 8 * g2 + 4 * half) * 2) = u;
+                }
+        if (!last) { bsh[((m + 1) & 1) * 1024 + tid] = nb1; bsh[((m + 1) & 1) * 1024 + 512 + tid] = nb2; }
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();  // B3: the z tile is complete
+        LT_PHASE(2)
+
+        auto bf2 = [&](int kb, unsigned &b0, unsigned &bs) { b0 = bx0 + (unsigned)kb * 32u; bs = 32u * XR; };
+        // ---- GEMM 2, skip pass: o_skip = Wout[skip rows] z + b_out; new skip rows = o_skip + old ones -> private copy / skip tensor
+        {
+            f32x16 acc[1][NCB];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + bb2 + bpm + (unsigned)((FC + 8 * g4) * 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) acc[0][cb][4 * g4 + e] = bv[e];
+            }
+            gemm_t128_run<1, KS2, D2, !SKEW, BDB2>(acc, A2, rw2, lane16, aoff2r(1), lds, bf2);
+            gemm_t128_prefetch<1, 4 * D2>(A2, rw2, lane16, aoff2r(0));
             if (!last) {
-                const int dn = 1 << ((l + 1) % a.dilation_cycle_length);
-                const float *dnx = dsh + (m + 1) * FC;
 #pragma unroll
-                for (int q = 0; q < RBW; ++q)
+                for (int cb = 0; cb < NSKR; ++cb)
 #pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb)
+                    for (int r = 0; r < 16; ++r) sko[cb][r] = acc[0][cb][r] + sko[cb][r];
+                if (!(SET_T128_EXP & 4)) {
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const int ch = row0(q) + 8 * g4 + 4 * half;
-                            const f32x4 dv = *reinterpret_cast<const f32x4 *>(dnx + ch);
-                            lf_u32x2 u;
-                            u[0] = inT[cb] ? pack2(xkeep[q][cb][4 * g4] + dv[0], xkeep[q][cb][4 * g4 + 1] + dv[1]) : 0u;
-                            u[1] = inT[cb] ? pack2(xkeep[q][cb][4 * g4 + 2] + dv[2], xkeep[q][cb][4 * g4 + 3] + dv[3]) : 0u;
-                            *reinterpret_cast<lf_u32x2 *>(xs + (dn + cb * 32 + l31) * XR + ch * 2) = u;
-                        }
-            } else {
-#pragma unroll
-                for (int q = 0; q < RBW; ++q)
-#pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb) {
+                    for (int cb = NSKR; cb < NCB; ++cb) {
                         if (st[cb]) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                buf_store(xkeep[q][cb][r], rxo, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
-                                buf_store(skacc[q][cb][r], rsk, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                f32x4 v;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = acc[0][cb][4 * g4 + e] + sko[cb][4 * g4 + e];
+                                if (SET_T128_EXP & 8) buf_store4(v, rps, lane16, (unsigned)((cb * 4 + g4) * 1024)); else buf_store4_stream(v, rps, lane16, (unsigned)((cb * 4 + g4) * 1024));
                             }
                         }
                     }
-            }
-        } else {
-    if (!last) {
-                const int dn = 1 << ((l + 1) % a.dilation_cycle_length);
-                const float *dnx = dsh + (m + 1) * FC;
-#pragma unroll
-                for (int q = 0; q < RBW; ++q)
-#pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            buf_store(acc[q][cb][r] * RSQRT2, rpx, vop[cb], (unsigned)(row0(q) + urow(r)) * (4u * NT));
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const int ch = row0(q) + 8 * g4 + 4 * half;
-                            const f32x4 dv = *reinterpret_cast<const f32x4 *>(dnx + ch);
-                            lf_u32x2 u;
-                            u[0] = inT[cb] ? pack2(acc[q][cb][4 * g4] * RSQRT2 + dv[0], acc[q][cb][4 * g4 + 1] * RSQRT2 + dv[1]) : 0u;
-                            u[1] = inT[cb] ? pack2(acc[q][cb][4 * g4 + 2] * RSQRT2 + dv[2], acc[q][cb][4 * g4 + 3] * RSQRT2 + dv[3]) : 0u;
-                            *reinterpret_cast<lf_u32x2 *>(xs + (dn + cb * 32 + l31) * XR + ch * 2) = u;
-                        }
-                    }
+                }
             } else {
-#pragma unroll
-                for (int q = 0; q < RBW; ++q)
-#pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb) {
-                        if (st[cb]) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) buf_store(acc[q][cb][r] * RSQRT2, rxo, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
-                        }
-                    }
-            }
-            // running skip sum of the stored frames (this block's slice only: L2-hot between the layers of a launch; the stores of the
-            // previous layer completed before this layer's residual loads, see the wait there)
-            const bool first = a.first != 0 && m == 0;
-            float sk[RBW][NCB][16];
-#pragma unroll
-            for (int q = 0; q < RBW; ++q)
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sk[q][cb][r] = buf_load(rsk, vo4[cb], (unsigned)(row0(q) + urow(r)) * T4);
-#pragma unroll
-            for (int q = 0; q < RBW; ++q)
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
                     if (st[cb]) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            buf_store(first ? acc[RBW + q][cb][r] : acc[RBW + q][cb][r] + sk[q][cb][r], rsk, vo4[cb],
-                                      (unsigned)(row0(q) + urow(r)) * T4);
+                        for (int r = 0; r < 16; ++r) buf_store(acc[0][cb][r] + sko[cb][r], rsk, vo4[cb], (unsigned)(row_g + urow(r)) * T4);
                     }
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        LF_PHASE(4)
-        if (pb && m >= 1) pb[7] += 1;
+        // ---- GEMM 2, residual pass: accumulators = the x rows + b_out
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + bb2 + bpm + (unsigned)((8 * g4) * 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) accx[0][cb][4 * g4 + e] += bv[e];
+        }
+        gemm_t128_run<1, KS2, D2, !SKEW, BDB2>(accx, A2, rw2, lane16, aoff2r(0), lds, bf2);
+        LT_PHASE(3)
+
+        // ---- epilogue: x' = (x + o_res) / sqrt 2 stays in accx; the next layer's first weight fragments; bf16(x' + d_next) packed in
+        //      registers and written to the x tile once every wave has left GEMM 2
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accx[0][cb][r] *= RSQRT2;
+        if (!last) {
+            gemm_t128_prefetch<1, 4 * D1>(A1, make_rsrc(img + N_IMG), avo1, aoff1h(0));  // the next layer's first fragments
+            const int dn = 1 << ((l + 1) % a.dilation_cycle_length);
+            const float *dnx = dsh + (m + 1) * FC;
+            unsigned xp[NCB][4][2];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 dv = *reinterpret_cast<const f32x4 *>(dnx + row_g + 8 * g4 + 4 * half);
+                    xp[cb][g4][0] = pack2(accx[0][cb][4 * g4] + dv[0], accx[0][cb][4 * g4 + 1] + dv[1]) & mT[cb];
+                    xp[cb][g4][1] = pack2(accx[0][cb][4 * g4 + 2] + dv[2], accx[0][cb][4 * g4 + 3] + dv[3]) & mT[cb];
+                    pin(xp[cb][g4][0]); pin(xp[cb][g4][1]);
+                }
+            lds_barrier();  // B4: every wave has left GEMM 2: the next x tile goes over the z tile
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    lt_u32x2 u;
+                    u[0] = xp[cb][g4][0]; u[1] = xp[cb][g4][1];
+                    *reinterpret_cast<lt_u32x2 *>(xs + (dn + cb * 32 + l31) * XR + (row_g + 8 * g4 + 4 * half) * 2) = u;
+                }
+        } else {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                if (st[cb]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) buf_store(accx[0][cb][r], rxo, vo4[cb], (unsigned)(row_g + urow(r)) * T4);
+                }
+            }
+        }
+        LT_PHASE(4)
     }
-#undef LF_PHASE
+#undef LT_PHASE
+    if (probe && (tid == 0 || tid == 256)) {
+        uint64_t *pb = g_bf16_phase_buf + (tid ? 8 : 0);
+        for (int i = 0; i < 5; ++i) pb[i] += tph[i];
+        pb[7] += (uint64_t)(a.nl - 1);
+    }
 }
 
 // =====================================================================================================================
@@ -1034,29 +1485,55 @@ static int layers_halo(int l0, int nl, int dcl) {
     for (int m = 1; m < nl; ++m) h += 1 << ((l0 + m) % dcl);
     return h;
 }
-static int layers_tile() {  // shape of the fused-layers kernel: 64 = <64, 8> (x' and the skip sum in registers), 128 = <128, 8>,
-    // 464 = <64, 4> (two independent 4-wave blocks per CU: measured slower at B = 32, T = 800, groups of 5: 0.93 -> 1.01 ms per 20 layers)
-    static int tile = 0;
-    if (!tile) { const char *e = getenv("SET_AMD_BF16_FUSE_TILE"); tile = e ? atoi(e) : 64; if (tile != 64 && tile != 128 && tile != 464) tile = 64; }
-    return tile;
-}
+// measurement / test switches, read at every launch: SET_AMD_BF16_FUSE_TILE = 64 | 128 forces the tile width (default: by occupancy);
+// SET_AMD_BF16_REG_VARIANT bit 0 = static priority skew (both shapes), bit 1 = A ring of GEMM 1 8 k-steps deep (64-frame shape) /
+// B fragments of GEMM 1 double-buffered (128-frame shape)
+static int layers_tile_env() { const char *e = getenv("SET_AMD_BF16_FUSE_TILE"); const int t = e ? atoi(e) : 0; return (t == 64 || t == 128) ? t : 0; }
+static int layers_reg_variant() { const char *e = getenv("SET_AMD_BF16_REG_VARIANT"); return e ? atoi(e) & 3 : 0; }
 
 extern "C" int64_t set_sizeof_diffnet_layers_bf16_args(void) { return (int64_t)sizeof(SetDiffnetLayersBf16Args); }
 
+static int layers_cu_count() {
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; hipDeviceProp_t pr; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+    return n_cu;
+}
+// tile width for a group: 128 frames (half the weight bytes per MFMA, 4 barriers per layer) when that still fills 3/4 of the chip,
+// else 64 (twice the blocks); a halo that leaves fewer than 32 of 64 frames: 128
+static int layers_pick_tile(int B, int T, int hh) {
+    int tile = layers_tile_env();
+    if (!tile) {
+        tile = 64;
+        if (128 - 2 * hh >= 32) {
+            const int64_t tiles128 = (int64_t)B * ((T + (128 - 2 * hh) - 1) / (128 - 2 * hh));
+            if (tiles128 * 4 >= (int64_t)layers_cu_count() * 3) tile = 128;
+        }
+    }
+    if (tile - 2 * hh < 32) tile = 128;
+    return tile;
+}
+// layers per launch for a stack of L layers (the bf16 reverse loop asks): 10 where 128-frame tiles fill the chip (B = 32, T = 800: 8 tiles
+// of 100 stored frames per utterance = 256 blocks), else 5 (64-frame tiles: 56 of 64 computed frames stored)
+extern "C" int32_t set_diffnet_layers_bf16_plan(int32_t B, int32_t T, int32_t L, int32_t dcl) {
+    if (B < 1 || T < 1 || L < 1 || dcl < 1 || dcl > 2) return 1;
+    const int n10 = L < 10 ? L : 10;
+    const int h10 = layers_halo(0, n10, dcl);
+    if (128 - 2 * h10 >= 32 && layers_pick_tile(B, T, h10) == 128) return n10;
+    return L < 5 ? L : 5;
+}
+
+// balanced tiles: the same number of tiles per utterance as width - 2 H stored frames would give, equal stored widths
+static int layers_balanced_nv(int T, int tile, int hh) { const int nv = tile - 2 * hh, nt = (T + nv - 1) / nv; return (T + nt - 1) / nt; }
+
 extern "C" int64_t set_diffnet_layers_bf16_scratch_floats(int32_t B, int32_t T, int32_t l0, int32_t nl, int32_t dcl) {
-    // (an upper bound over the groups of a network: the halo of the worst first layer for this group size, so that one buffer
-    // serves every group and every utterance slice starts at a multiple of the per-utterance size; and over both tile widths)
+    // 128-frame tiles: a block's private copy of its skip rows (256 x 128 fp32) between the layers of a group; an upper bound over the
+    // first layers l0 of the groups of a network (so that one buffer serves every group); 64-frame tiles keep everything in registers
     if (B < 1 || T < 1 || nl < 1 || dcl < 1 || l0 < 0) return 0;
     int hmax = 0;
     for (int s0 = 0; s0 < dcl; ++s0) { const int h = layers_halo(s0, nl, dcl); hmax = h > hmax ? h : hmax; }
-    int64_t need = 0;
-    for (int nt = 64; nt <= 128; nt += 64) {
-        const int nv = nt - 2 * hmax;
-        if (nv < 32) continue;
-        const int64_t n = (int64_t)B * ((T + nv - 1) / nv) * FC * nt;  // per block: the fp32 copy of x'
-        need = n > need ? n : need;
-    }
-    return need;
+    if (128 - 2 * hmax < 32) return 64;
+    const int nv = layers_balanced_nv(T, 128, hmax);
+    return (int64_t)B * ((T + nv - 1) / nv) * FC * 128;
 }
 
 extern "C" int set_diffnet_layers_fwd_bf16(const SetDiffnetLayersBf16Args *args, void *stream) {
@@ -1066,35 +1543,49 @@ extern "C" int set_diffnet_layers_fwd_bf16(const SetDiffnetLayersBf16Args *args,
     const SetDiffnetLayersBf16Args &a = la.a;
     SET_REQUIRE(a.x_in && a.x_out && a.x_in != a.x_out && a.skip && a.cond && a.dstep && a.img && a.b_dil && a.b_cond && a.b_out && a.scratch,
                 "set_diffnet_layers_fwd_bf16");
-    SET_REQUIRE(a.B > 0 && a.T > 0 && a.nl >= 1 && a.nl <= 8 && a.l0 >= 0 && a.dilation_cycle_length >= 1 && a.dilation_cycle_length <= 4,
+    SET_REQUIRE(a.B > 0 && a.T > 0 && a.nl >= 1 && a.nl <= 16 && a.l0 >= 0 && a.dilation_cycle_length >= 1 && a.dilation_cycle_length <= 4,
                 "set_diffnet_layers_fwd_bf16");
     SET_REQUIRE((int64_t)2 * FC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_layers_fwd_bf16 (T too large)");
     la.hh = layers_halo(a.l0, a.nl, a.dilation_cycle_length);
-    const int shape = layers_tile();
-    int tile = shape == 128 ? 128 : 64;
-    if (tile - 2 * la.hh < 32) tile = FNT;  // a wide halo: the 128-frame tile
+    const int tile = layers_pick_tile(a.B, a.T, la.hh);
     la.nv = tile - 2 * la.hh;
     if (la.nv < 32) return set_fail(SET_E_UNSUPPORTED, "set_diffnet_layers_fwd_bf16", "halo of the fused layers leaves fewer than 32 valid frames per tile");
-    SET_REQUIRE(a.scratch_floats >= set_diffnet_layers_bf16_scratch_floats(a.B, a.T, a.l0, a.nl, a.dilation_cycle_length),
-                "set_diffnet_layers_fwd_bf16 (scratch too small)");
+    la.nv = layers_balanced_nv(a.T, tile, la.hh);
+    if (tile == 128) SET_REQUIRE(a.scratch_floats >= (int64_t)a.B * ((a.T + la.nv - 1) / la.nv) * FC * 128, "set_diffnet_layers_fwd_bf16 (scratch too small)");
     int dmax = 1;
     for (int m = 0; m < a.nl; ++m) { const int d = 1 << ((a.l0 + m) % a.dilation_cycle_length); dmax = d > dmax ? d : dmax; }
-    const size_t ldsz = (size_t)(tile + 2 * dmax) * XR + (size_t)tile * CR + (size_t)a.nl * FC * sizeof(float);
+    // 64: x tile | conditioner tile | z tile | step offsets | biases of the group;  128: x tile (z over it) | conditioner | step offsets | 2 bias buffers
+    const size_t ldsz = tile == 64 ? (size_t)(64 + 2 * dmax) * XR + (size_t)64 * CR + (size_t)64 * XR + (size_t)a.nl * (FC + 1024) * sizeof(float)
+                                   : (size_t)(128 + 2 * dmax) * XR + (size_t)128 * CR + (size_t)a.nl * FC * sizeof(float) + 2 * 1024 * sizeof(float);
     if (ldsz > 160 * 1024) return set_fail(SET_E_UNSUPPORTED, "set_diffnet_layers_fwd_bf16", "tiles do not fit LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layers_fwd_bf16_kernel<128, 8>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layers fwd bf16 attr");
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layers_fwd_bf16_kernel<64, 8>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "layers fwd bf16 attr");
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layers_fwd_bf16_kernel<64, 4>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "layers fwd bf16 attr");
+        const void *ks[] = {reinterpret_cast<const void *>(diffnet_layers_reg_bf16_kernel<false, 4>), reinterpret_cast<const void *>(diffnet_layers_reg_bf16_kernel<true, 4>),
+                            reinterpret_cast<const void *>(diffnet_layers_reg_bf16_kernel<false, 8>), reinterpret_cast<const void *>(diffnet_layers_reg_bf16_kernel<true, 8>),
+                            reinterpret_cast<const void *>(diffnet_layers_t128_bf16_kernel<false, 0>), reinterpret_cast<const void *>(diffnet_layers_t128_bf16_kernel<false, 1>),
+                            reinterpret_cast<const void *>(diffnet_layers_t128_bf16_kernel<false, 2>), reinterpret_cast<const void *>(diffnet_layers_t128_bf16_kernel<false, 3>),
+                            reinterpret_cast<const void *>(diffnet_layers_t128_bf16_kernel<false, 4>)};
+        for (const void *k : ks) SET_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layers bf16 attr");
         attr_set = true;
     }
     dim3 grid((a.T + la.nv - 1) / la.nv, a.B);
-    if (tile == 128) hipLaunchKernelGGL((diffnet_layers_fwd_bf16_kernel<128, 8>), grid, dim3(512), ldsz, (hipStream_t)stream, la);
-    else if (shape == 464) hipLaunchKernelGGL((diffnet_layers_fwd_bf16_kernel<64, 4>), grid, dim3(256), ldsz, (hipStream_t)stream, la);
-    else hipLaunchKernelGGL((diffnet_layers_fwd_bf16_kernel<64, 8>), grid, dim3(512), ldsz, (hipStream_t)stream, la);
+    const int v = layers_reg_variant();
+    if (tile == 128) {
+        int nskr = 1;  // measured (B = 32, T = 800, 10 layers per launch, sustained): 0: 40.7, 1: 39.4, 2: 39.6, 3: 39.8, 4: 41.8 us per layer (21 / 45 / 67 spilled registers from 2 on)
+        if (const char *e = getenv("SET_AMD_BF16_T128_NSKR")) nskr = atoi(e);
+        switch (nskr) {
+            case 0: hipLaunchKernelGGL((diffnet_layers_t128_bf16_kernel<false, 0>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
+            default: hipLaunchKernelGGL((diffnet_layers_t128_bf16_kernel<false, 1>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
+            case 3: hipLaunchKernelGGL((diffnet_layers_t128_bf16_kernel<false, 3>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
+            case 4: hipLaunchKernelGGL((diffnet_layers_t128_bf16_kernel<false, 4>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
+            case 2: hipLaunchKernelGGL((diffnet_layers_t128_bf16_kernel<false, 2>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
+        }
+    } else switch (v) {
+        case 0: hipLaunchKernelGGL((diffnet_layers_reg_bf16_kernel<false, 4>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
+        case 1: hipLaunchKernelGGL((diffnet_layers_reg_bf16_kernel<true, 4>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
+        case 2: hipLaunchKernelGGL((diffnet_layers_reg_bf16_kernel<false, 8>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
+        default: hipLaunchKernelGGL((diffnet_layers_reg_bf16_kernel<true, 8>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
+    }
     return set_check_launch("set_diffnet_layers_fwd_bf16");
 }
 

@@ -3,6 +3,7 @@
 // coalesced along T (the contiguous axis of the [B][C][T] layout).  Reference citations are in
 // include/set_amd.h next to each prototype.
 #include "common.h"
+#include "pitch_edges.h"
 
 // ---- LayerNorm over C of [B][C][T]: block = 32 frames x 8 channel groups (loads coalesced along t, 128 B per group
 //      row), partial sums combined through LDS.  A thread owns ceil(C/8) channels of one frame; up to 32 of them
@@ -232,15 +233,21 @@ __global__ void __launch_bounds__(256) pitch_coarse_kernel(const float *f0_in, c
     if (mel2ph_pad && mel2ph_pad[i] == 0) f = 0.0f;
     if (f0_denorm) f0_denorm[i] = f;
     if (coarse) {
-        // f0_to_coarse (pitch/utils.py:17-28); constants evaluated in fp64 then rounded like the
-        // reference's python-float scalars entering fp32 tensor ops
-        const float mel_min = (float)(1127.0 * log(1.0 + 50.0 / 700.0));
-        const float mel_max_minus_min = (float)(1127.0 * log(1.0 + 900.0 / 700.0) - 1127.0 * log(1.0 + 50.0 / 700.0));
-        float m = 1127.0f * logf(1.0f + f / 700.0f);
-        if (m > 0.0f) m = (m - mel_min) * 254.0f / mel_max_minus_min + 1.0f;
-        if (m <= 1.0f) m = 1.0f;
-        if (m > 255.0f) m = 255.0f;
-        coarse[i] = (int64_t)(m + 0.5f);
+        // f0_to_coarse(denorm_f0(f0)) (pitch/utils.py:17-28,71-82) is a monotone step function of the fp32 input whose edges depend on
+        // torch-CPU's (not correctly rounded) pow and log: the runs of equal bins were read off the reference on every fp32 in [5, 10.5]
+        // (oracle/make_pitch_edges.py -> pitch_edges.h); a binary search over the run starts is bit-exact for every input.  Unvoiced /
+        // padded frames: f = 0 -> mel 0 -> bin 1, the bin of run 0.
+        int k = 0;
+        if (f != 0.0f && f0 > 5.0f) {
+            const unsigned u = __float_as_uint(fminf(f0, 10.5f));
+            int lo = 0, hi = PITCH_RUNS - 1;  // largest k with PITCH_RUN_BITS[k] <= u (positive floats order like their bit patterns)
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (PITCH_RUN_BITS[mid] <= u) lo = mid; else hi = mid - 1;
+            }
+            k = lo;
+        }
+        coarse[i] = (int64_t)PITCH_RUN_BIN[k];
     }
 }
 extern "C" int set_pitch_coarse(const float *f0_in, const float *uv_in, const float *tmask, const int64_t *mel2ph_pad,

@@ -837,9 +837,9 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs,
     a.dstep, a.coef4 = dstep.data_ptr(), coef4.data_ptr()
     if bf16 is not None:
         a.cond, a.img16_all, a.b_cond_all = _f(bf16["cond"]).data_ptr(), bf16["imgs"].data_ptr(), _f(bf16["b_cond"]).data_ptr()
-        # workspace of the several-layers-per-launch kernel (a block's private fp32 copy of x' between its layers); sized for
-        # the smallest tiles any group size up to 8 produces
-        n_ws = max(_lib.lib().set_diffnet_layers_bf16_scratch_floats(B, T, 0, n, dilation_cycle_length) for n in range(2, 9)) \
+        # workspace of the several-layers-per-launch kernels (128-frame tiles: a block's private copy of its skip rows between the layers
+        # of a group), sized for whatever group size the loop picks
+        n_ws = max(_lib.lib().set_diffnet_layers_bf16_scratch_floats(B, T, 0, n, dilation_cycle_length) for n in range(2, 17)) \
             if dilation_cycle_length <= 2 else 0
         if n_ws > 0:
             bf16_ws = torch.empty(n_ws, dtype=torch.float32, device=dev)  # noqa: F841 (kept alive until the loop is enqueued: stream-ordered free)

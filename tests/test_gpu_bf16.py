@@ -480,13 +480,17 @@ def test_batch_repack_equals_per_weight_packs(dev):
         assert cw.packed_bf16().data_ptr() == ptr     # current: no re-pack, same storage
 
 
-@pytest.mark.parametrize("B,T,L_,dcl,fuse", [(2, 800, 8, 1, 4), (3, 333, 7, 1, 4), (2, 500, 6, 2, 3), (1, 97, 5, 1, 5), (2, 128, 4, 2, 2)])
-def test_fused_layer_groups_equal_one_launch_per_layer(dev, B, T, L_, dcl, fuse):
-    """set_diffnet_layers_fwd_bf16 (the tile stays on chip for `fuse` consecutive layers, 128 - 2 H stored frames per tile) against
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("B,T,L_,dcl,fuse", [(2, 800, 8, 1, 4), (3, 333, 7, 1, 4), (2, 500, 6, 2, 3), (1, 97, 5, 1, 5), (2, 128, 4, 2, 2), (2, 800, 20, 1, 10)])
+def test_fused_layer_groups_equal_one_launch_per_layer(dev, monkeypatch, tile, B, T, L_, dcl, fuse):
+    """set_diffnet_layers_fwd_bf16 (the tile stays on chip for `fuse` consecutive layers, tile - 2 H stored frames per tile; both tile
+    widths: 64 frames with x' and the skip sum in registers, 128 frames with two GEMM-1 passes and the skip rows added at the L2) against
     one set_diffnet_layer_fwd_bf16 launch per layer on the same images: same arithmetic per frame -> x and the skip sum are
-    bit-identical, incl. ragged T (partial last tile), a group shorter than `fuse` at the end, dilation cycles."""
+    bit-identical, incl. ragged T (partial last tile), a
+    group shorter than `fuse` at the end, dilation cycles, a 10-layer group."""
     import ctypes as C
     from set_amd import _lib
+    monkeypatch.setenv("SET_AMD_BF16_FUSE_TILE", str(tile))
     Lb = _lib.lib()
     g = torch.Generator().manual_seed(B * 1000 + T + L_)
     n_img = Lb.set_diffnet_layer_bf16_image_size()
@@ -534,5 +538,5 @@ def test_fused_layer_groups_equal_one_launch_per_layer(dev, B, T, L_, dcl, fuse)
     x_f, s_f = fused()
     torch.cuda.synchronize()
     assert torch.isfinite(x_f).all() and torch.isfinite(s_f).all()
-    assert torch.equal(s_f, s_ref)
     assert torch.equal(x_f, x_ref)
+    assert torch.equal(s_f, s_ref)

@@ -193,12 +193,20 @@ def test_integer_bookkeeping_bit_exact(dev):
                                  mel2ph_pad=inp["mel2ph"].to(dev))
     assert torch.equal(bins.cpu(), ref_bins)
     assert _maxdiff(den, ref_den) < 1e-3  # Hz; exp2f vs torch pow(2, x)
-    # dense sweep of the bin function over the whole f0 range
-    f = torch.linspace(5.0, 10.5, 20001)
-    ref_bins = O.f0_to_coarse(O.denorm_f0(f, None))
+    # the bin function on EVERY fp32 in [5.0, 10.5] (8.9 M values; outside, the clamp makes it constant) against the oracle, and on the
+    # reference-generated edge neighbourhoods (tests/golden/pitch_edges.npz, oracle/make_pitch_edges.py): no mismatch allowed
+    lo, hi = int(np.float32(5.0).view(np.uint32)), int(np.float32(10.5).view(np.uint32))
+    f = torch.from_numpy(np.arange(lo, hi + 1, dtype=np.uint32).view(np.float32).copy())
+    ref_bins = O.f0_to_coarse(O.denorm_f0(f.clone(), None))
     _, bins = ops.pitch_coarse(f.to(dev), None)
-    mism = int((bins.cpu() != ref_bins).sum())
-    assert mism <= 2, mism  # bin edges: exp2f vs pow rounding can flip a sample sitting exactly on an edge
+    assert int((bins.cpu() != ref_bins).sum()) == 0
+    ge = load_golden("pitch_edges")
+    fe = torch.from_numpy(ge["f0_bits"].view(np.float32).copy())
+    _, bins = ops.pitch_coarse(fe.to(dev), None)
+    assert torch.equal(bins.cpu(), torch.from_numpy(ge["bins"].astype(np.int64)))
+    fo = torch.tensor([-1e30, -3.0, 0.0, 4.999, 5.0, 10.5, 10.51, 50.0, 1e30])
+    _, bins = ops.pitch_coarse(fo.to(dev), None)
+    assert torch.equal(bins.cpu(), O.f0_to_coarse(O.denorm_f0(fo.clone(), None)))
     g = load_golden("length_regulator")
     txt = torch.from_numpy((~g["pad"]).astype(np.int64))
     out = ops.length_regulate(torch.from_numpy(g["dur"]).to(dev), txt.to(dev))

@@ -126,3 +126,11 @@ def test_mel_mcd_zero_and_scale():
     a = rng.normal(size=(50, 80))
     assert O.mel_mcd(a, a) == 0.0
     assert O.mel_mcd(a, a + 1e-4) < 1e-2
+
+
+def test_pitch_bin_edges_golden():
+    """The oracle's f0 -> coarse bin on the reference-generated edge neighbourhoods (every value within 8 ulp of a bin edge)."""
+    g = load_golden("pitch_edges")
+    f = torch.from_numpy(g["f0_bits"].view(np.float32).copy())
+    bins = O.f0_to_coarse(O.denorm_f0(f, None))
+    assert torch.equal(bins, torch.from_numpy(g["bins"].astype(np.int64)))

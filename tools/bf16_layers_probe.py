@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT)
 import set_amd  # noqa
 from set_amd import _lib
 dev = torch.device("cuda:0")
-B, T, NL = 32, 800, 8
+NLS = tuple(int(v) for v in os.environ.get("NLS", "1,2,4,8").split(","))
+B, T, NL = 32, 800, max(NLS)
 L = _lib.lib()
 n = L.set_diffnet_layer_bf16_image_size()
 imgs = torch.empty(NL, n, dtype=torch.bfloat16, device=dev)
@@ -18,9 +19,9 @@ x, xo, sk = (torch.randn(B, 256, T, device=dev) for _ in range(3))
 cond = torch.randn(B, 192, T, device=dev)
 dst = torch.randn(NL, B, 256, device=dev)
 bias = [torch.zeros(NL, 512, device=dev) for _ in range(3)]
-buf = torch.zeros(8, dtype=torch.int64, device=dev)
+buf = torch.zeros(16, dtype=torch.int64, device=dev)
 NAMES = ("init+barrier", "gemm1", "gate", "gemm2", "epilogue")
-for nl in (1, 2, 4, 8):
+for nl in NLS:
     n_ws = L.set_diffnet_layers_bf16_scratch_floats(B, T, 0, nl, 1)
     ws = torch.empty(n_ws, device=dev)
     a = _lib.SetDiffnetLayersBf16Args()
@@ -32,14 +33,26 @@ for nl in (1, 2, 4, 8):
     torch.cuda.synchronize()
     buf.zero_()
     _lib.check(L.set_debug_bf16_phase_buffer(buf.data_ptr()), "dbg")
+    # sustained: ~0.6 s of back-to-back launches to bring the clocks up (the GPU idles at 94 MHz between probes: ten launches after a
+    # synchronisation measured 43 - 49 us per layer where the sustained loop runs 40 - 41), then REPS timed launches
+    import time
+    REPS = int(os.environ.get("REPS", "2000"))
+    t0 = time.time()
+    while time.time() - t0 < 0.6:
+        for _ in range(100):
+            _lib.check(L.set_diffnet_layers_fwd_bf16(C.byref(a), None), "fwd")
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10):
+    for _ in range(REPS):
         _lib.check(L.set_diffnet_layers_fwd_bf16(C.byref(a), None), "fwd")
     e1.record(); torch.cuda.synchronize()
     L.set_debug_bf16_phase_buffer(None)
-    us = e0.elapsed_time(e1) * 100
+    us = e0.elapsed_time(e1) * 1000 / REPS
     st = buf.cpu().tolist()
     tot = max(1, sum(st[:5]))
-    print("nl=%d: %.1f us per launch = %.1f us per layer | layers m >= 1: %s" % (
-        nl, us, us / nl, " ".join("%s %.0f%%" % (nm, 100.0 * v / tot) for nm, v in zip(NAMES, st)) if st[7] else "-"))
+    tot4 = max(1, sum(st[8:13]))
+    print("variant=%s tile=%s nl=%d: %.1f us per launch = %.1f us per layer | layers m >= 1, wave 0: %s (%.0f ticks per layer) | wave 4: %s" % (
+        os.environ.get("SET_AMD_BF16_REG_VARIANT", "-"), os.environ.get("SET_AMD_BF16_FUSE_TILE", "64"), nl, us, us / nl,
+        " ".join("%s %.0f%%" % (nm, 100.0 * v / tot) for nm, v in zip(NAMES, st)) if st[7] else "-", tot / max(1, st[7]),
+        " ".join("%s %.0f%%" % (nm, 100.0 * v / tot4) for nm, v in zip(NAMES, st[8:13])) if st[7] and sum(st[8:13]) else "-"))

@@ -1,45 +1,53 @@
 #!/bin/bash
-# PMC passes (separate runs, --kernel-trace only) of the fused bf16 layer-group kernel at B = 32, T = 800 (tools/bf16_layers_probe.py):
-# MFMA busy cycles / clock and HBM bytes per launch -> gpurun_out/pmc_bf16_layers.json
+# PMC passes (separate runs, --kernel-trace only) of the fused bf16 layer-group kernels at B = 32, T = 800 (tools/bf16_layers_probe.py):
+# MFMA busy cycles / clock / wait shares / LDS bank conflicts and HBM bytes per launch -> gpurun_out/pmc_bf16_layers_<tile>.json
+# usage: TILE=64|128 [VARIANT=0..3] [NLS=5,10] tools/gpu_pmc_bf16_layers.sh
 set -u
 cd "$GRAFT_REPO_ROOT"; OUT=gpurun_out/pmc_bf16; mkdir -p $OUT; export TMPDIR=/tmp; R="$GRAFT_REPO_ROOT"
+export SET_AMD_BF16_FUSE_TILE=${TILE:-128} SET_AMD_BF16_REG_VARIANT=${VARIANT:-0} NLS=${NLS:-5,10}
 rm -rf $OUT/*
-(cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$R/$OUT/util" -o pmc -- python "$R/tools/bf16_layers_probe.py" > "$R/$OUT/util.log" 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d "$R/$OUT/util" -o pmc -- python "$R/tools/bf16_layers_probe.py" > "$R/$OUT/util.log" 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d "$R/$OUT/lds" -o pmc -- python "$R/tools/bf16_layers_probe.py" > "$R/$OUT/lds.log" 2>&1)
 (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/$OUT/fetch" -o pmc -- python "$R/tools/bf16_layers_probe.py" > "$R/$OUT/fetch.log" 2>&1)
 (cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$R/$OUT/write" -o pmc -- python "$R/tools/bf16_layers_probe.py" > "$R/$OUT/write.log" 2>&1)
 python - <<'PY'
-import csv, glob, json, collections
-out = {}
+import csv, glob, json, collections, os
+out = {"tile": os.environ["SET_AMD_BF16_FUSE_TILE"], "variant": os.environ["SET_AMD_BF16_REG_VARIANT"]}
+nls = [int(v) for v in os.environ["NLS"].split(",")]
 def collect(d):
     f = glob.glob("gpurun_out/pmc_bf16/%s/**/*counter_collection.csv" % d, recursive=True)
-    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
     kt = glob.glob("gpurun_out/pmc_bf16/%s/**/*kernel_trace.csv" % d, recursive=True)
+    if not f: return {}, {}
     for r in csv.DictReader(open(f[0])):
-        if "diffnet_layers_fwd_bf16_kernel" in r["Kernel_Name"]:
-            acc[r["Dispatch_Id"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "diffnet_layers_" in r["Kernel_Name"]:
+            acc[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
     dur = {}
     if kt:
         for r in csv.DictReader(open(kt[0])):
-            if "diffnet_layers_fwd_bf16_kernel" in r["Kernel_Name"]:
+            if "diffnet_layers_" in r["Kernel_Name"]:
                 dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     return acc, dur
-u, du = collect("util"); f, df = collect("fetch"); w, dw = collect("write")
-# the probe launches groups of 1, 2, 4, 8 layers: 11 dispatches each (1 warm-up + 10); take the last dispatch of each group size
-ids = sorted(u.keys(), key=int)
-for gi, nl in enumerate((1, 2, 4, 8)):
-    did = ids[gi * 11 + 10] if len(ids) >= (gi + 1) * 11 else None
+u, du = collect("util"); l, dl = collect("lds"); f, df = collect("fetch"); w, dw = collect("write")
+def pick(d, gi):  # the probe launches each group size 11 times (1 warm-up + 10): the last dispatch of group gi
+    ids = sorted(d.keys(), key=int)
+    return ids[gi * 11 + 10] if len(ids) >= (gi + 1) * 11 else None
+for gi, nl in enumerate(nls):
+    did = pick(u, gi)
     if did is None: continue
-    c = {k: sum(v) for k, v in u[did].items()}
-    fid, wid = sorted(f.keys(), key=int)[gi * 11 + 10], sorted(w.keys(), key=int)[gi * 11 + 10]
-    fetch_kb, write_kb = sum(f[fid]["FETCH_SIZE"]), sum(w[wid]["WRITE_SIZE"])
+    c = u[did]
     cyc = c["GRBM_GUI_ACTIVE"] / 8.0
-    out["layers_per_launch_%d" % nl] = {
-        "duration_us_under_pmc": du.get(did), "cycles_per_launch": cyc, "sclk_GHz": (cyc / du[did] / 1e3) if did in du else None,
-        "mfma_busy_frac_of_simd_cycles": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc),
-        "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
-        "algorithmic_bytes_per_launch": 4864 * 25600 * nl,
-    }
-json.dump(out, open("gpurun_out/pmc_bf16_layers.json", "w"), indent=1)
+    o = {"duration_us_under_pmc": du.get(did), "cycles_per_launch": cyc, "sclk_GHz": (cyc / du[did] / 1e3) if did in du else None,
+         "mfma_busy_frac_of_simd_cycles": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc),
+         "wave_cycles": c["SQ_WAVE_CYCLES"], "wait_any_frac": c["SQ_WAIT_ANY"] / max(1.0, c["SQ_WAVE_CYCLES"]),
+         "wait_inst_any_frac": c["SQ_WAIT_INST_ANY"] / max(1.0, c["SQ_WAVE_CYCLES"]), "active_inst_any_frac": c["SQ_ACTIVE_INST_ANY"] / max(1.0, c["SQ_WAVE_CYCLES"]),
+         "algorithmic_bytes_per_launch": 4864 * 25600 * nl}
+    lid = pick(l, gi)
+    if lid: o.update({k.lower(): v for k, v in l[lid].items()})
+    fid, wid = pick(f, gi), pick(w, gi)
+    if fid and wid: o["hbm_bytes_per_launch"] = 2 * f[fid]["FETCH_SIZE"] * 1024 + w[wid]["WRITE_SIZE"] * 1024
+    out["layers_per_launch_%d" % nl] = o
+json.dump(out, open("gpurun_out/pmc_bf16_layers_%s.json" % out["tile"], "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
 find $OUT -name "*.csv" -delete
