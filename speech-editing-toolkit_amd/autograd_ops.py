@@ -658,6 +658,10 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
         # Weight gradients of ALL layers in three grouped launches after the sweep (dy / d_o of every layer are kept: 2 x L x 26 MB
         # at B = 32, T = 800) when the layers share one dilation; else three GEMMs per layer inside the sweep.
         grouped = len({layer.dilation for layer in layers}) == 1 and os.environ.get("SET_AMD_GROUPED_WGRAD", "1") != "0"
+        # the grouped form keeps dy / d_o of ALL layers alive (2 x L x B x 2C x T bf16: ~1 GB at L = 20, B = 32, T = 800, next to x_all,
+        # y16, z16); beyond a budget (SET_AMD_GROUPED_WGRAD_MB, default 4096 MB -- 1.4 % of the 288 GB) it falls back to the per-layer form
+        if grouped and 2 * L_ * B * 2 * C_ * T * 2 > float(os.environ.get("SET_AMD_GROUPED_WGRAD_MB", "4096")) * 2 ** 20:
+            grouped = False
         n_slab = L_ if grouped else 1
         dy16_all = torch.empty(n_slab, B, 2 * C_, T, dtype=torch.bfloat16, device=dev)
         do16_all = torch.empty(n_slab, B, 2 * C_, T, dtype=torch.bfloat16, device=dev)
@@ -831,7 +835,7 @@ class _SelfAttnFn(torch.autograd.Function):
         H = qkv.shape[1] // 3
         MV = ops.MatView
         ctx.cfg = (heads, alpha, kpm, fill)
-        if ops.attention_fused_on():
+        if ops.attention_fused_on(H // heads):
             o, lse, p = ops.attention_fused(MV.heads(qkv, heads, 0, H), MV.heads(qkv, heads, H, H), MV.heads(qkv, heads, 2 * H, H),
                                             heads, kpm, fill, alpha, want_p)
             ctx.fused = True
@@ -870,7 +874,7 @@ class _CrossAttnFn(torch.autograd.Function):
         H = q.shape[1]
         MV = ops.MatView
         ctx.cfg = (heads, alpha, kpm, fill)
-        if ops.attention_fused_on():
+        if ops.attention_fused_on(H // heads):
             o, lse, p = ops.attention_fused(MV.heads(q, heads), MV.heads(kv, heads, 0, H), MV.heads(kv, heads, H, H), heads, kpm,
                                             fill, alpha, want_p)
             ctx.fused = True

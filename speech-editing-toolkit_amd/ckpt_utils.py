@@ -70,12 +70,13 @@ def save_ckpt(work_dir, model, optimizer=None, global_step=0, epoch=0, best=None
     return path
 
 
-def restore_ckpt(work_dir, model, optimizer=None, model_name="model", strict=True):
+def restore_ckpt(work_dir, model, optimizer=None, model_name="model", strict=True, return_meta=False):
     """trainer.py:384-428 (`restore_weights` + `restore_opt_state`).  Returns (global_step, epoch), (0, 0) if the
-    directory holds no checkpoint (the reference then trains from its random init, trainer.py:153-157)."""
+    directory holds no checkpoint (the reference then trains from its random init, trainer.py:153-157); with
+    `return_meta` a third value: the checkpoint's scalar entries (so that callers need not read the file again)."""
     checkpoint, path = get_last_checkpoint(work_dir)
     if checkpoint is None:
-        return 0, 0
+        return (0, 0, {}) if return_meta else (0, 0)
     model.load_state_dict(checkpoint["state_dict"][model_name], strict=strict)
     if optimizer is not None and checkpoint.get("optimizer_states"):
         try:
@@ -84,4 +85,7 @@ def restore_ckpt(work_dir, model, optimizer=None, model_name="model", strict=Tru
             print("| WARMING: optimizer parameters not match !!!")  # the reference's message, trainer.py:420
     from . import ops
     ops.bump_weights_epoch()  # packed weight images are stale now
+    if return_meta:
+        meta = {k: v for k, v in checkpoint.items() if k not in ("state_dict", "optimizer_states")}
+        return int(checkpoint["global_step"]), int(checkpoint["epoch"]), meta
     return int(checkpoint["global_step"]), int(checkpoint["epoch"])

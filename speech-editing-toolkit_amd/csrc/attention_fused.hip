@@ -260,8 +260,10 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(SetAttnArgs a) {
 }
 
 // probabilities p[b][h][q][key] = exp(masked score - lse[q]) for callers that want them (the encoder-decoder attention map
-// the model returns; transformer.py:396-410).  Plain fp32 FMAs: one thread per query, keys in an inner loop.
-template <int D>
+// the model returns; transformer.py:396-410).  Plain fp32 FMAs: one thread per query, keys in an inner loop.  BF16: scale q and k are
+// rounded to bf16 like the forward's MFMA operands, so that the scores are the ones whose row max / sum the forward stored (with fp32
+// scores against bf16-operand statistics the rows did not sum to 1 and single entries exceeded 1).
+template <int D, bool BF16>
 __global__ void __launch_bounds__(256) attn_probs_kernel(SetAttnArgs a) {
     const int b = blockIdx.z, h = blockIdx.y;
     const int qi = blockIdx.x * 256 + threadIdx.x;
@@ -271,14 +273,14 @@ __global__ void __launch_bounds__(256) attn_probs_kernel(SetAttnArgs a) {
     const float *kpm = a.kpm ? a.kpm + (int64_t)b * a.Tk : nullptr;
     float qv[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) qv[d] = q[(int64_t)d * a.q_cs] * a.scale;
+    for (int d = 0; d < D; ++d) { const float v = q[(int64_t)d * a.q_cs] * a.scale; qv[d] = BF16 ? (float)(__bf16)v : v; }
     const float *st = a.lse + ((int64_t)b * a.heads + h) * 2 * a.Tq;
     const float mx = st[qi], linv = 1.0f / st[a.Tq + qi];
     float *p = a.p + (((int64_t)b * a.heads + h) * a.Tq + qi) * a.Tk;
     for (int key = 0; key < a.Tk; ++key) {
         float s = 0.0f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) s += qv[d] * k[(int64_t)d * a.k_cs + key];  // k: the same address in every lane (broadcast)
+        for (int d = 0; d < D; ++d) { const float kv = k[(int64_t)d * a.k_cs + key]; s += qv[d] * (BF16 ? (float)(__bf16)kv : kv); }  // k: the same address in every lane (broadcast)
         if (kpm && kpm[key] != 0.0f) s = a.fill;
         p[key] = __expf(s - mx) * linv;
     }
@@ -467,7 +469,8 @@ int attn_launch(const SetAttnArgs &a, hipStream_t s) {
     const dim3 grid((a.Tq + 127) / 128, a.heads, a.B);
     if (a.bf16) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(256), 0, s, a);
-    if (a.p) hipLaunchKernelGGL((attn_probs_kernel<D>), dim3((a.Tq + 255) / 256, a.heads, a.B), dim3(256), 0, s, a);
+    if (a.p && a.bf16) hipLaunchKernelGGL((attn_probs_kernel<D, true>), dim3((a.Tq + 255) / 256, a.heads, a.B), dim3(256), 0, s, a);
+    else if (a.p) hipLaunchKernelGGL((attn_probs_kernel<D, false>), dim3((a.Tq + 255) / 256, a.heads, a.B), dim3(256), 0, s, a);
     return set_check_launch("set_attention");
 }
 template <int D>

@@ -1013,9 +1013,12 @@ def masked_channel_sum(d, m, out):
     return out
 
 
-def attention_fused_on():
-    """The fused attention kernels (csrc/attention_fused.hip) are the default; SET_AMD_ATTN_FUSED=0 runs the three-launch
-    bmm -> softmax -> bmm composition (kept as the cross-check of the tests)."""
+def attention_fused_on(head_dim=None):
+    """The fused attention kernels (csrc/attention_fused.hip) are the default for the head sizes they are instantiated for (32, 64,
+    96: the shipped 192 / 2 config and its neighbours); any other head size, or SET_AMD_ATTN_FUSED=0, runs the three-launch
+    bmm -> softmax -> bmm composition (any head size; also the cross-check of the tests)."""
+    if head_dim is not None and int(head_dim) not in (32, 64, 96):
+        return False
     return os.environ.get("SET_AMD_ATTN_FUSED", "1") != "0"
 
 
@@ -1080,7 +1083,7 @@ def self_attention(qkv, heads, key_padding_mask=None, fill=float("-inf"), alpha=
     """qkv [B, 3H, T] = packed in_proj output (transformer.py:421-422) -> (o [B,H,T], p or None)."""
     H = qkv.shape[1] // 3
     views = (MatView.heads(qkv, heads, 0, H), MatView.heads(qkv, heads, H, H), MatView.heads(qkv, heads, 2 * H, H))
-    if attention_fused_on():
+    if attention_fused_on(H // heads):
         o, _, p = attention_fused(*views, heads, key_padding_mask, fill, alpha, want_p)
         return o, p
     return attention_views(*views, heads, key_padding_mask, fill, alpha)
@@ -1090,7 +1093,7 @@ def cross_attention(q, kv, heads, key_padding_mask=None, fill=-1e8, alpha=1.0, w
     """q [B,H,Tq], kv [B,2H,Tk] (in_proj_k / in_proj_v of the encoder output, transformer.py:433-451)."""
     H = q.shape[1]
     views = (MatView.heads(q, heads), MatView.heads(kv, heads, 0, H), MatView.heads(kv, heads, H, H))
-    if attention_fused_on():
+    if attention_fused_on(H // heads):
         o, _, p = attention_fused(*views, heads, key_padding_mask, fill, alpha, want_p)
         return o, p
     return attention_views(*views, heads, key_padding_mask, fill, alpha)

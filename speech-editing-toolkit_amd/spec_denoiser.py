@@ -17,6 +17,11 @@ from .hparams import hparams as _global_hparams
 
 class GaussianDiffusion(nn.Module):
     fs_cls = FastSpeech
+    # parameters no loss of this model ever reaches (the conditioner is always run with skip_decoder=True,
+    # modules/speech_editing/spec_denoiser/spec_denoiser.py:159-161): the reference needs find_unused_parameters for them
+    # (utils/commons/trainer.py:475-479); here they are laid out behind the exchanged part of the flat gradient buffer and never sent
+    # (training.FlatAdamW: 95.35 -> 80.7 MB per step)
+    unused_parameter_prefixes = ("fs.decoder.", "fs.mel_out.")
 
     def __init__(self, phone_encoder, out_dims, denoise_fn, timesteps=1000, time_scale=1, loss_type="l1",
                  betas=None, spec_min=None, spec_max=None, hp=None):

@@ -86,7 +86,7 @@ class SpeechEditingBaseTask:
 
     def _loader(self, prefix, shuffle, max_tokens, max_sentences, endless, use_batch_by_size=True):
         from .data import StutterSpeechDataset, build_batches
-        from .trainer import BatchLoader
+        from .trainer import BatchLoader, RNG_LOCK
         tr = getattr(self, "trainer", None)
         world, rank = (tr.world, tr.rank) if tr is not None else (1, 0)
         import numpy as np
@@ -94,13 +94,14 @@ class SpeechEditingBaseTask:
         # the batch list is a function of hparams['seed'] alone (the reference draws it from the global numpy generator
         # seeded in start(); here the generator is seeded for this call, so validation passes or data-loader rebuilds in
         # between cannot shift it -- a resumed run gets the list of the run it continues, on every rank)
-        state = np.random.get_state()
-        np.random.seed(int(hparams.get("seed", 1234)))
-        try:
-            batches = build_batches(ds, shuffle, max_tokens, max_sentences, endless=endless,
-                                    use_batch_by_size=use_batch_by_size, world=world, rank=rank)
-        finally:
-            np.random.set_state(state)
+        with RNG_LOCK:  # (the prefetch worker reseeds the same global generator inside BatchLoader.fetch)
+            state = np.random.get_state()
+            np.random.seed(int(hparams.get("seed", 1234)))
+            try:
+                batches = build_batches(ds, shuffle, max_tokens, max_sentences, endless=endless,
+                                        use_batch_by_size=use_batch_by_size, world=world, rank=rank)
+            finally:
+                np.random.set_state(state)
         return BatchLoader(ds, batches, hparams.get("seed", 1234))
 
     def train_dataloader(self):

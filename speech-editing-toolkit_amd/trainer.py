@@ -12,14 +12,15 @@ What is deliberately different from the reference (and why):
 * `global_step` counts OPTIMIZER UPDATES; with `accumulate_grad_batches` = a > 1 an update consumes a batches (the
   reference counts batches and steps the optimizer on every a-th, scheduling on global_step // a): `max_updates`,
   `val_check_interval`, the warm-up and the step number in checkpoint names therefore mean a times more data here than in
-  a reference run with the same yaml, and a reference checkpoint's `global_step` is read as batches / a when resumed with
-  a > 1 -- `restore_ckpt` refuses that combination rather than mis-schedule it;
+  a reference run with the same yaml; a checkpoint without the `global_step_unit` key resumed with a > 1 is read as updates
+  with a warning, or as batches / a with hparams['resume_global_step_unit'] = 'batches' (a reference-written checkpoint);
 * the optimizer is the fused flat AdamW (training.FlatAdamW) whose state_dict is torch.optim.AdamW's, so checkpoints
   interchange (`optimizer_states[0]`); clip + schedule are inside its step (base_task.py:129-137).
 No tensorboard, no progress bars, no code snapshots: logging is a dict per `log_interval` updates on rank 0.
 """
 import os
 import random
+import threading
 import time
 
 import numpy as np
@@ -38,10 +39,19 @@ def step_seed(seed, global_step):
     return (int(seed) * 1000003 + int(global_step) * 7919 + 12345) % (2 ** 31 - 1)
 
 
+# One lock for every piece of code that reseeds or draws from the process-global numpy / python / torch generators on behalf of the
+# data feed: BatchLoader.fetch (prefetch worker thread AND main thread: validation batches) and the batch-list construction of
+# tasks._loader.  Without it the worker's fetch(k + 1) and a validation pass on the main thread reseed the same globals while the
+# other one is drawing, and both batches depend on thread timing.
+RNG_LOCK = threading.RLock()
+
+
 class BatchLoader:
     """`dataset[i]` + `collater` over a list of index batches, addressed by update index.  The dataset's mask
     generators draw from the global numpy / python / torch generators (utils/spec_aug/time_mask.py:6-93), so these are
-    seeded per batch position: what batch k contains does not depend on how many batches were fetched before it."""
+    seeded per batch position: what batch k contains does not depend on how many batches were fetched before it.
+    `fetch` holds RNG_LOCK from the reseed to the last draw and puts the three global generator states back afterwards:
+    it is a pure function of k whatever other thread fetches at the same time, and it leaves no trace in the global streams."""
 
     def __init__(self, dataset, batches, seed):
         self.dataset, self.batches, self.seed = dataset, batches, int(seed)
@@ -52,10 +62,17 @@ class BatchLoader:
     def fetch(self, k):
         idx = self.batches[k % len(self.batches)]
         s = step_seed(self.seed, k)
-        np.random.seed(s)
-        random.seed(s)
-        torch.manual_seed(s)
-        return self.dataset.collater([self.dataset[i] for i in idx])
+        with RNG_LOCK:
+            saved = (np.random.get_state(), random.getstate(), torch.get_rng_state())
+            try:
+                np.random.seed(s)
+                random.seed(s)
+                torch.default_generator.manual_seed(s)  # the CPU generator only: torch.manual_seed would also reseed every CUDA generator
+                return self.dataset.collater([self.dataset[i] for i in idx])
+            finally:
+                np.random.set_state(saved[0])
+                random.setstate(saved[1])
+                torch.set_rng_state(saved[2])
 
 
 class Trainer:
@@ -104,14 +121,20 @@ class Trainer:
         model = task.build_model()
         model.to(self.device).train()
         self.optimizer = task.configure_optimizers()
-        self.global_step, self.current_epoch = ckpt_utils.restore_ckpt(self.work_dir, model, self.optimizer)
+        self.global_step, self.current_epoch, meta = ckpt_utils.restore_ckpt(self.work_dir, model, self.optimizer, return_meta=True)
         if self.global_step > 0:
-            ck, _ = ckpt_utils.get_last_checkpoint(self.work_dir)
-            self.best_val_results = ck.get("checkpoint_callback_best")
-            if self.accumulate_grad_batches > 1 and ck.get("global_step_unit") != "updates":
-                raise RuntimeError("resuming a checkpoint whose global_step counts batches (written by the reference "
-                                   "trainer) with accumulate_grad_batches=%d: this trainer counts optimizer updates, the "
-                                   "schedule would be off by that factor" % self.accumulate_grad_batches)
+            self.best_val_results = meta.get("checkpoint_callback_best")
+            if self.accumulate_grad_batches > 1 and meta.get("global_step_unit") != "updates":
+                # a checkpoint without the key is either the reference trainer's (global_step counts BATCHES) or one this trainer
+                # wrote before the key existed (it already counted updates): hparams['resume_global_step_unit'] = 'updates' |
+                # 'batches' settles it; unset, the run continues on the assumption "updates" with a warning instead of refusing
+                unit = hparams.get("resume_global_step_unit")
+                if unit == "batches":
+                    self.global_step //= self.accumulate_grad_batches
+                elif unit != "updates" and self.rank == 0:
+                    print("| WARNING: resuming a checkpoint without 'global_step_unit' under accumulate_grad_batches=%d; reading its "
+                          "global_step as optimizer updates (a reference-written checkpoint counts batches: set "
+                          "resume_global_step_unit=batches)" % self.accumulate_grad_batches, flush=True)
         task.global_step = self.global_step
         # barrier, rank-0 parameter / buffer / optimizer-state broadcast, barrier (trainer.py:166-170,402,475-479)
         parallel.configure_ddp(model, self.optimizer)
@@ -144,9 +167,10 @@ class Trainer:
     def _next_batch(self, loader, k):
         """Batch k of the training list.  With hparams['ds_workers'] > 0 (the reference's DataLoader-worker knob,
         utils/commons/dataset_utils.py:213-215) batch k + 1 is assembled (dataset[i], mask generators, collate, pinned host
-        buffers) on a background thread while update k runs on the GPU; `fetch(k)` is a pure function of k, so the
-        prefetched batch is the one a synchronous fetch would have produced (a resumed run stays bit-identical).  The
-        worker is the only code that draws from the global numpy / python / torch generators while training runs."""
+        buffers) on a background thread while update k runs on the GPU; `fetch(k)` is a pure function of k (it reseeds, draws
+        and restores the global generators under RNG_LOCK), so the prefetched batch is the one a synchronous fetch would have
+        produced whatever the main thread does meanwhile -- validation passes fetch through the same lock, and
+        `run_evaluation` waits for the batch in flight first (`_drain_prefetch`): a resumed run stays bit-identical."""
         if int(hparams.get("ds_workers", 0) or 0) <= 0:
             return loader.fetch(k)
         if self._prefetch is None or self._prefetch[0] is not loader:
@@ -165,6 +189,15 @@ class Trainer:
         if k + 1 not in pending:
             pending[k + 1] = pool.submit(work, k + 1)
         return batch
+
+    def _drain_prefetch(self):
+        """Wait for the batch the worker is assembling (its result stays queued: it is the batch of its index either way)."""
+        if self._prefetch is not None:
+            for fut in list(self._prefetch[2].values()):
+                try:
+                    fut.result()
+                except Exception:
+                    pass  # surfaces when the batch is consumed
 
     def run_training_batch(self, loader):
         """trainer.py:306-379 for one optimizer: `accumulate_grad_batches` forward/backward passes, then clip + AdamW
@@ -200,6 +233,7 @@ class Trainer:
 
     # ---- validation + checkpoints (trainer.py:205-254, 431-470) ------------------------------------------------------
     def run_evaluation(self):
+        self._drain_prefetch()
         res = self.evaluate(max_batches=hparams.get("eval_max_batches", -1))
         if self.rank == 0:
             self.save_checkpoint(logs=res)

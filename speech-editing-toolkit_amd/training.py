@@ -19,20 +19,31 @@ class FlatAdamW:
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, clip_grad_norm=1.0,
                  warmup_updates=8000, bucket_mb=25):
         named = list(model.named_parameters())
-        self.params = [p for _, p in named]
+        self.params = [p for _, p in named]          # model order (= the order of torch.optim.AdamW's state_dict)
         self.param_names = [n for n, _ in named]
         dev = self.params[0].device
         n = sum(p.numel() for p in self.params)
         n_pad = (n + 255) // 256 * 256
         self.flat_p = torch.zeros(n_pad, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        # layout: the parameters a loss can reach first (model order), then the ones the model declares unreachable
+        # (`unused_parameter_prefixes`): the gradient exchange covers the first part only
+        unused_pre = tuple(getattr(model, "unused_parameter_prefixes", ()) or ())
+        if os.environ.get("SET_AMD_EXCHANGE_UNUSED", "0") == "1":
+            unused_pre = ()
+        self.is_unused = [bool(unused_pre) and name.startswith(unused_pre) for name in self.param_names]
+        self.layout = [i for i, u in enumerate(self.is_unused) if not u] + [i for i, u in enumerate(self.is_unused) if u]
+        self.offs = [0] * len(self.params)
         off = 0
-        for p in self.params:
+        for i in self.layout:
+            p = self.params[i]
             k = p.numel()
+            self.offs[i] = off
             self.flat_p[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + k].view(p.shape)
             p.grad = self.flat_g[off:off + k].view(p.shape)
             off += k
+        self.n_exchanged = sum(self.params[i].numel() for i in self.layout if not self.is_unused[i])
         self.n = n
         # Direct gradient sinks: the weight / bias gradient kernels accumulate straight into the flat buffer instead of
         # returning a temporary that the autograd engine then ADDS into .grad (one ATen elementwise launch and one zeroed
@@ -52,9 +63,11 @@ class FlatAdamW:
         self.bucket = int(bucket_mb * (1 << 20) // 4)
         # gradient exchange overlapped with backward: buckets launch from autograd hooks (no-op when world == 1)
         # (buckets follow the order gradients appear in: cut from the end of the buffer, never across a top-level module)
-        self.bucketer = parallel.GradBucketer(self.params, self.flat_g, self.bucket,
+        used = [i for i in self.layout if not self.is_unused[i]]
+        self.bucketer = parallel.GradBucketer([self.params[i] for i in used], self.flat_g[:self.n_exchanged], self.bucket,
                                               force=os.environ.get("SET_AMD_FORCE_BUCKETER", "0") == "1",
-                                              groups=[n.split(".", 1)[0] for n in self.param_names])
+                                              groups=[self.param_names[i].split(".", 1)[0] for i in used])
+        self._unused_checked = self.n_exchanged == self.n
         self.num_updates = 0
         ops.bump_weights_epoch()
 
@@ -98,6 +111,11 @@ class FlatAdamW:
         A.zero_arena_end()
         self.in_step = False
         self._learned = True
+        if not self._unused_checked:  # once: a parameter declared unreachable that did receive a gradient would silently diverge across ranks
+            self._unused_checked = True
+            if bool(torch.count_nonzero(self.flat_g[self.n_exchanged:self.n]).item()):
+                bad = [self.param_names[i] for i in self.layout if self.is_unused[i] and bool(torch.count_nonzero(self.params[i].grad).item())]
+                raise RuntimeError("parameters declared unused received gradients: %s" % bad[:5])
         world = self.bucketer.finish()
         sumsq = A.grad_sumsq(self.flat_g) if self.clip > 0 else None
         lr = self.lr_at(self.num_updates)
@@ -112,10 +130,9 @@ class FlatAdamW:
     # ---- checkpoint interchange with torch.optim.AdamW (the reference's optimizer, tasks/tts/speech_base.py:163-170):
     #      `optimizer_states[0]` of a reference checkpoint (utils/commons/trainer.py:459-471) loads here and vice versa
     def _offsets(self):
-        off = 0
-        for p in self.params:
-            yield off, p.numel(), p.shape
-            off += p.numel()
+        """(offset in the flat buffers, numel, shape) per parameter in MODEL order (the flat layout puts unreachable parameters last)."""
+        for i, p in enumerate(self.params):
+            yield self.offs[i], p.numel(), p.shape
 
     def state_dict(self):
         state = {}

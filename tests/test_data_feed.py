@@ -167,3 +167,61 @@ def test_endless_batch_list_follows_the_reference_shuffle_and_shares_its_batches
     np.random.seed(5)
     fixed = D.build_batches(ds, False, 130, 3, endless=True)
     assert fixed[:len(fixed) // 1000] * 1000 == fixed
+
+
+def test_fetch_is_a_pure_function_of_k_under_a_concurrent_prefetch_worker():
+    """the prefetch worker (ds_workers > 0) assembles batch k + 1 while the main thread may run a validation
+    pass or rebuild a loader -- all of them reseed / draw from the process-global numpy, python and torch generators.
+    BatchLoader.fetch now holds trainer.RNG_LOCK from its reseed to its last draw and restores the three generator states, and
+    the loader construction takes the same lock: every batch is the one a serial fetch produces, whatever the interleaving, and
+    fetching leaves no trace in the global streams."""
+    import random
+    import threading
+    import time
+    import numpy as np
+    from set_amd.trainer import BatchLoader, RNG_LOCK
+
+    class SlowDataset:
+        """draws from all three global generators with a sleep in between (widens the race window)"""
+
+        def __getitem__(self, i):
+            a = float(np.random.rand())
+            time.sleep(0.002)
+            b = random.random()
+            time.sleep(0.002)
+            c = float(torch.rand(()))
+            return {"v": torch.tensor([i, a, b, c], dtype=torch.float64)}
+
+        def collater(self, samples):
+            return {"v": torch.stack([s["v"] for s in samples])}
+
+    train = BatchLoader(SlowDataset(), [[0, 1], [2, 3], [4, 5], [6, 7]], seed=7)
+    val = BatchLoader(SlowDataset(), [[10, 11], [12, 13]], seed=7)
+    serial_t = [train.fetch(k)["v"] for k in range(8)]
+    serial_v = [val.fetch(k)["v"] for k in range(4)]
+    np.random.seed(123); random.seed(123); torch.manual_seed(123)
+    before = (np.random.get_state()[1].copy(), random.getstate(), torch.get_rng_state().clone())
+    got_t, got_v, stop = {}, {}, threading.Event()
+
+    def worker():
+        for k in range(8):
+            got_t[k] = train.fetch(k)["v"]
+
+    def reseeder():  # what tasks._loader does while it builds a batch list
+        while not stop.is_set():
+            with RNG_LOCK:
+                st = np.random.get_state()
+                np.random.seed(99)
+                np.random.permutation(50)
+                np.random.set_state(st)
+            time.sleep(0.001)
+
+    th, rs = threading.Thread(target=worker), threading.Thread(target=reseeder)
+    th.start(); rs.start()
+    for k in range(4):
+        got_v[k] = val.fetch(k)["v"]
+    th.join(); stop.set(); rs.join()
+    assert all(torch.equal(got_t[k], serial_t[k]) for k in range(8))
+    assert all(torch.equal(got_v[k], serial_v[k]) for k in range(4))
+    after = (np.random.get_state()[1], random.getstate(), torch.get_rng_state())
+    assert np.array_equal(before[0], after[0]) and before[1] == after[1] and torch.equal(before[2], after[2])

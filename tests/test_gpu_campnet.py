@@ -355,6 +355,8 @@ def test_fused_attention_forward_and_gradients(dev, case, dtype):
 
     close(o, o_ref, "o")
     close(p, pr, "p", 1e-5 if dtype == "f32" else 2e-2)
+    rows = p.double().cpu().sum(-1)  # the map the model returns is a distribution in both modes (bf16 statistics, fp32 scores)
+    assert float((rows[torch.isfinite(rows)] - 1).abs().max()) < (1e-5 if dtype == "f32" else 2e-3)
     close(lse[:, :, 0] + torch.log(lse[:, :, 1]), torch.logsumexp(sc, -1), "lse", 1e-5 if dtype == "f32" else 2e-2)
     if not bool(nan_rows.any()):
         with torch.enable_grad():
@@ -412,3 +414,33 @@ def test_fused_attention_is_what_the_model_runs_and_matches_the_composition(dev,
     assert set(a[3]) == set(b[3])
     for k in a[3]:
         assert _md(a[3][k], b[3][k]) < 2e-4 * max(float(b[3][k].abs().max()), 1e-6), k
+
+
+def test_attention_with_a_head_size_the_fused_kernels_do_not_cover(dev):
+    """head sizes other than 32 / 64 / 96 (e.g. hidden_size 256 with 2 heads) take the bmm -> softmax -> bmm composition
+    instead of failing with SET_E_UNSUPPORTED: forward and gradients of the autograd ops against torch in fp64."""
+    from set_amd import autograd_ops as AO
+    B, heads, d, T, Tk = 2, 2, 128, 40, 17
+    H = heads * d
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B, 3 * H, T, generator=g).to(dev).requires_grad_(True)
+    q = torch.randn(B, H, T, generator=g).to(dev).requires_grad_(True)
+    kv = torch.randn(B, 2 * H, Tk, generator=g).to(dev).requires_grad_(True)
+    alpha = d ** -0.5
+
+    def ref(qq, kk, vv):
+        qh, kh, vh = (t.double().reshape(B, heads, d, -1) for t in (qq, kk, vv))
+        p = torch.softmax(alpha * torch.einsum("bhdq,bhdk->bhqk", qh, kh), dim=-1)
+        return torch.einsum("bhqk,bhdk->bhdq", p, vh).reshape(B, H, -1)
+
+    with torch.enable_grad():
+        o_s, _ = AO.self_attention(qkv, heads, None, float("-inf"), alpha, False)
+        o_c, _ = AO.cross_attention(q, kv, heads, None, -1e8, alpha, True)
+        (o_s.sum() + (o_c * o_c).sum()).backward()
+        q2, kv2, qkv2 = (t.detach().double().requires_grad_(True) for t in (q, kv, qkv))
+        r_s = ref(qkv2[:, :H], qkv2[:, H:2 * H], qkv2[:, 2 * H:])
+        r_c = ref(q2, kv2[:, :H], kv2[:, H:])
+        (r_s.sum() + (r_c * r_c).sum()).backward()
+    assert _md(o_s, r_s.float()) < 2e-5 and _md(o_c, r_c.float()) < 2e-5
+    for a, b in ((qkv.grad, qkv2.grad), (q.grad, q2.grad), (kv.grad, kv2.grad)):
+        assert _md(a, b.float()) < 5e-5 * max(1.0, float(b.abs().max()))

@@ -193,20 +193,23 @@ def test_integer_bookkeeping_bit_exact(dev):
                                  mel2ph_pad=inp["mel2ph"].to(dev))
     assert torch.equal(bins.cpu(), ref_bins)
     assert _maxdiff(den, ref_den) < 1e-3  # Hz; exp2f vs torch pow(2, x)
-    # the bin function on EVERY fp32 in [5.0, 10.5] (8.9 M values; outside, the clamp makes it constant) against the oracle, and on the
-    # reference-generated edge neighbourhoods (tests/golden/pitch_edges.npz, oracle/make_pitch_edges.py): no mismatch allowed
-    lo, hi = int(np.float32(5.0).view(np.uint32)), int(np.float32(10.5).view(np.uint32))
-    f = torch.from_numpy(np.arange(lo, hi + 1, dtype=np.uint32).view(np.float32).copy())
-    ref_bins = O.f0_to_coarse(O.denorm_f0(f.clone(), None))
-    _, bins = ops.pitch_coarse(f.to(dev), None)
-    assert int((bins.cpu() != ref_bins).sum()) == 0
+    # the bin function against the REFERENCE run committed as tests/golden/pitch_edges.npz (oracle/make_pitch_edges.py: the reference's
+    # own functions on every fp32 in [5.0, 10.5], recorded as runs of equal bins + every value within 8 ulp of a run boundary): the
+    # edge neighbourhoods, then EVERY fp32 of the sweep (8.9 M values) against the run table -- no mismatch allowed.  (Not against
+    # torch-CPU at test time: its pow / log are not correctly rounded and differ BETWEEN host CPUs -- the same oracle code gave
+    # 3 other bins of 8.9 M on the GPU box's host than in the container the reference ran in; the committed run is the pin.)
     ge = load_golden("pitch_edges")
     fe = torch.from_numpy(ge["f0_bits"].view(np.float32).copy())
     _, bins = ops.pitch_coarse(fe.to(dev), None)
     assert torch.equal(bins.cpu(), torch.from_numpy(ge["bins"].astype(np.int64)))
+    lo, hi = int(np.float32(5.0).view(np.uint32)), int(np.float32(10.5).view(np.uint32))
+    allbits = np.arange(lo, hi + 1, dtype=np.uint32)
+    want = ge["run_bin"].astype(np.int64)[np.searchsorted(ge["run_bits"], allbits, side="right") - 1]
+    _, bins = ops.pitch_coarse(torch.from_numpy(allbits.view(np.float32).copy()).to(dev), None)
+    assert int((bins.cpu() != torch.from_numpy(want)).sum()) == 0
     fo = torch.tensor([-1e30, -3.0, 0.0, 4.999, 5.0, 10.5, 10.51, 50.0, 1e30])
     _, bins = ops.pitch_coarse(fo.to(dev), None)
-    assert torch.equal(bins.cpu(), O.f0_to_coarse(O.denorm_f0(fo.clone(), None)))
+    assert bins.cpu().tolist() == [1, 1, 1, 1, 1, 255, 255, 255, 255]
     g = load_golden("length_regulator")
     txt = torch.from_numpy((~g["pad"]).astype(np.int64))
     out = ops.length_regulate(torch.from_numpy(g["dur"]).to(dev), txt.to(dev))
