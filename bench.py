@@ -553,15 +553,20 @@ def run_train(args, rank, world, dev):
     else:
         sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"],
                       time_mel_masks=inp["time_mel_masks"].squeeze(-1).contiguous(), spk_embed=inp["spk_embed"])
-    for w in range(args.warmup):
-        task.training_step(sample, opt, seed=100 + w)
+    # one captured HIP graph per batch shape (training.GraphedTrainStep: eager for the first steps, with more than one rank and
+    # under SET_AMD_GRAPH_STEP=0); the timed steps below are replays when the warm-up was long enough to capture
+    from set_amd.training import GraphedTrainStep
+    step_fn = GraphedTrainStep(task, opt)
+    for w in range(max(args.warmup, step_fn.eager_steps + 2) if step_fn.usable() else args.warmup):
+        step_fn(sample, seed=100 + w)
     torch.cuda.synchronize()
     parallel.barrier()
     exposed, reduced, enqueue = 0.0, 0, 0.0
+    replays0 = step_fn.replays
     t0 = time.perf_counter()
     for k in range(args.steps):
         t1 = time.perf_counter()
-        total, parts, lr = task.training_step(sample, opt, seed=k)
+        total, parts, lr = step_fn(sample, seed=k)
         enqueue += time.perf_counter() - t1  # host time to ENQUEUE the step (no synchronisation inside)
         exposed += opt.bucketer.exposed_s
         reduced = opt.bucketer.bytes_reduced
@@ -593,6 +598,7 @@ def run_train(args, rank, world, dev):
                    "B_per_gpu": bpg, "T": T, "T_txt": T_TXT, "sharding": "utterances r::N, gradient all-reduce (SUM, "
                    "1/N folded into AdamW) in %d buckets" % max(1, len(opt.bucketer.buckets))},
         "frames_per_s": n_samples * T / t_max, "host_enqueue_ms_per_step": 1e3 * enqueue / args.steps,
+        "graph_replays": step_fn.replays - replays0,
         "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"],
         "per_rank_ms_per_step": [1e3 * s / args.steps for s in facts["per_rank_s"]],
         "allreduce_bytes_per_step": reduced, "allreduce_exposed_ms_per_step": 1e3 * exposed / args.steps,

@@ -361,6 +361,11 @@ int set_q_sample(const float *x_start, const float *eps, const float *ab2, const
                  int32_t B, int32_t M, int32_t T, void *stream);
 /* fill with N(0,1): Philox4x32-10 + Box-Muller (throughput runs; spec_denoiser.py:180) */
 int set_randn(float *out, int64_t n, uint64_t seed, uint64_t offset, void *stream);
+/* Graph capture of a training step: every Philox kernel launched through set_randn / set_posterior_step / set_dropout adds the device
+ * word *dev_word to its seed argument (NULL = off, the default).  A captured step carries the seeds of the step it was captured at; the
+ * replay of step k stores (seed_k - seed_captured) in the word before it launches the graph and draws exactly the numbers the eager
+ * step k draws.  Process-wide; the word must stay allocated while it is set. */
+int set_rng_seed_delta(const uint64_t *dev_word);
 
 /* Whole reverse loop (spec_denoiser.py:178-184 + p_sample :103-108 + DiffNet.forward diffnet.py:110-132)
  * for residual_channels == 256.  All weights pre-packed by the caller; workspaces provided by the caller.
@@ -676,6 +681,12 @@ int set_sumsq(const float *g, float *out, int64_t n, void *stream);
  * scaled by min(1, max_norm / (sqrt(sumsq[0])*grad_scale + 1e-6)) when sumsq != NULL (sumsq = sum g^2). */
 int set_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,
               float weight_decay, int32_t step, const float *sumsq, float max_norm, float grad_scale, void *stream);
+/* The same update with lr and the bias corrections 1 - beta^step read from device memory hyper = [lr, bc1, bc2] (a captured training
+ * step is replayed for every update: its kernel arguments are frozen).  set_adamw_hyper computes bc1, bc2 on the host exactly as
+ * set_adamw does (out2[0], out2[1]). */
+int set_adamw_hyper(float beta1, float beta2, int32_t step, float *out2);
+int set_adamw_dev(float *p, const float *g, float *m, float *v, int64_t n, const float *hyper, float beta1, float beta2, float eps,
+                  float weight_decay, const float *sumsq, float max_norm, float grad_scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention building blocks (CampNet rows; modules/speech_editing/commons/transformer.py)

@@ -233,6 +233,7 @@ SIGNATURES = {
     "set_posterior_step": (C.c_int, [_V, _V, _V, _V, _I64, _V, _I32, _I64, _U64, _U64, _V]),
     "set_q_sample": (C.c_int, [_V, _V, _V, _V, _V, _I32, _I32, _I32, _V]),
     "set_randn": (C.c_int, [_V, _I64, _U64, _U64, _V]),
+    "set_rng_seed_delta": (C.c_int, [_V]),
     "set_diffusion_loop": (C.c_int, [C.POINTER(SetDiffLoopArgs), _V]),
     "set_selftest_mfma": (C.c_int, [C.POINTER(C.c_float), _V]),
     "set_sizeof_attn_args": (_I64, []),
@@ -307,6 +308,8 @@ SIGNATURES = {
     "set_pitch_loss": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _I32, _I32, _F, _F, _F, _V]),
     "set_sumsq": (C.c_int, [_V, _V, _I64, _V]),
     "set_adamw": (C.c_int, [_V, _V, _V, _V, _I64, _F, _F, _F, _F, _F, _I32, _V, _F, _F, _V]),
+    "set_adamw_hyper": (C.c_int, [_F, _F, _I32, C.POINTER(C.c_float)]),
+    "set_adamw_dev": (C.c_int, [_V, _V, _V, _V, _I64, _V, _F, _F, _F, _F, _V, _F, _F, _V]),
     "set_sizeof_conv1d_args": (_I64, []),
     "set_sizeof_diffnet_layer_args": (_I64, []),
     "set_sizeof_diff_loop_args": (_I64, []),

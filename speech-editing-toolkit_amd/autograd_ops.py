@@ -35,30 +35,45 @@ class _ZeroArena:
     of a few microseconds on the critical stream).  Opened by FlatAdamW.zero_grad() and closed by FlatAdamW.step():
     only then is it safe, because the optimizer owns every .grad (views of its flat buffer), so autograd ADDS these
     temporaries into .grad and nothing keeps a reference past the step.  Outside such a step `_gzeros` is torch.zeros.
-    Capacity follows the demand of the previous step."""
-    buf, off, need, active = None, 0, 0, False
+    Capacity follows the demand of the previous step.  One arena per owner (optimizer): a captured step
+    (training.GraphedTrainStep) holds the address of the arena it was captured with."""
+
+    def __init__(self):
+        self.buf, self.off, self.need = None, 0, 0
 
 
-def zero_arena_begin(device, min_floats=0):
-    a = _ZeroArena
+_ARENAS = {}        # owner id -> _ZeroArena
+_ACTIVE = [None]    # the arena of the optimisation step in progress (steps do not nest)
+# Buffers replaced by a larger one are parked here instead of being freed: a captured training step holds the ADDRESS of the arena /
+# scratch buffers it was captured with, and a freed buffer is handed to other tensors by the allocator.  Growth is geometric, so the
+# parked buffers sum to a small multiple of the final size.
+_RETIRED = []
+CAPTURED_ABORT_WORDS = []  # sync workspaces of persistent stack kernels inside captured steps ([1] != 0: a dependency wait timed out)
+
+
+def zero_arena_begin(device, min_floats=0, owner=None):
+    a = _ARENAS.setdefault(id(owner), _ZeroArena())
     want = max(int(min_floats), int(a.need * 1.05) + 4096)
     if a.buf is None or a.buf.device != device or a.buf.numel() < want:
+        if a.buf is not None:
+            _RETIRED.append(a.buf)
         a.buf = torch.empty(want, dtype=torch.float32, device=device)
     a.buf.zero_()
-    a.off, a.need, a.active = 0, 0, True
+    a.off, a.need = 0, 0
+    _ACTIVE[0] = a
 
 
 def zero_arena_end():
-    _ZeroArena.active = False
+    _ACTIVE[0] = None
 
 
 def _gzeros(shape, device):
-    a = _ZeroArena
+    a = _ACTIVE[0]
     shape = tuple(int(d) for d in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
     n = 1
     for d in shape:
         n *= d
-    if a.active and a.buf.device == device:
+    if a is not None and a.buf.device == device:
         step = (n + 63) // 64 * 64  # 256-byte aligned slices
         a.need += step
         if a.off + step <= a.buf.numel():
@@ -92,6 +107,8 @@ _DET_SCRATCH = {}  # device -> per-block / per-slice partial results of the orde
 def _det_scratch(device, n_floats):
     buf = _DET_SCRATCH.get(device)
     if buf is None or buf.numel() < n_floats:
+        if buf is not None:
+            _RETIRED.append(buf)
         buf = torch.empty(int(n_floats * 1.25) + 4096, dtype=torch.float32, device=device)
         _DET_SCRATCH[device] = buf
     return buf
@@ -122,6 +139,8 @@ def conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro=0, pr
     need = L().set_conv1d_wgrad_scratch_floats(B, Cin, Cout, K, T, dt)
     buf = _WG_SCRATCH.get(g.device)
     if buf is None or buf.numel() < need:
+        if buf is not None:
+            _RETIRED.append(buf)
         buf = torch.empty(int(need * 1.25) + 1024, dtype=torch.float32, device=g.device)
         _WG_SCRATCH[g.device] = buf
     check(L().set_conv1d_wgrad_det(_p(g), _p(x), _p(chan_add), ptr, B, Cin, Cout, K, dil, pad, T, T_in, pro,
@@ -134,6 +153,8 @@ def conv_wgrad_grouped(g, x, chan_add, dw_ptr, groups, g_gs, x_gs, add_gs, dw_gs
     need = L().set_conv1d_wgrad_grouped_scratch_floats(groups, B, Cin, Cout, K, T)
     buf = _WG_SCRATCH.get(g.device)
     if buf is None or buf.numel() < need:
+        if buf is not None:
+            _RETIRED.append(buf)
         buf = torch.empty(int(need * 1.25) + 1024, dtype=torch.float32, device=g.device)
         _WG_SCRATCH[g.device] = buf
     check(L().set_conv1d_wgrad_det_grouped(_p(g), _p(x), _p(chan_add), C.c_void_p(dw_ptr), groups, g_gs, x_gs, add_gs, dw_gs, B, Cin,
@@ -549,7 +570,9 @@ class _DiffNetStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dskip):
         dn = ctx.dn
-        if int(ctx.ws[1]) != 0:  # (the forward's abort word; this read-back is the first host sync of the step)
+        if torch.cuda.is_current_stream_capturing():
+            CAPTURED_ABORT_WORDS.append(ctx.ws)  # no host read inside a capture: training.GraphedTrainStep polls the word between replays
+        elif int(ctx.ws[1]) != 0:  # (the forward's abort word; this read-back is the first host sync of the step)
             raise SetAmdError("set_diffnet_stack: a tile dependency wait of the training forward timed out")
         cond, dmat, x_all, y_all, z_all = ctx.saved_tensors
         L_, C_ = dn.n_layers, dn.C
@@ -1148,6 +1171,19 @@ def grad_sumsq(flat_grad):
     check(L().set_sumsq_det(_p(flat_grad), _p(out), flat_grad.numel(), _p(_det_scratch(flat_grad.device, 2048)), _stream()),
           "set_sumsq_det")
     return out
+
+
+def adamw_step_dev(flat_p, flat_g, m, v, hyper, beta1, beta2, eps, weight_decay, sumsq=None, max_norm=0.0, grad_scale=1.0):
+    """adamw_step with [lr, bc1, bc2] in device memory (graph replay: training.GraphedTrainStep)."""
+    check(L().set_adamw_dev(_p(flat_p), _p(flat_g), _p(m), _p(v), flat_p.numel(), _p(hyper), float(beta1), float(beta2), float(eps),
+                            float(weight_decay), _p(sumsq), float(max_norm), float(grad_scale), _stream()), "set_adamw_dev")
+
+
+def adamw_hyper(beta1, beta2, step):
+    """(bc1, bc2) = 1 - beta^step in fp32, computed by the library's host code (bit-identical to set_adamw's own)."""
+    out = (C.c_float * 2)()
+    check(L().set_adamw_hyper(float(beta1), float(beta2), int(step), out), "set_adamw_hyper")
+    return float(out[0]), float(out[1])
 
 
 def adamw_step(flat_p, flat_g, m, v, lr, beta1, beta2, eps, weight_decay, step, sumsq=None, max_norm=0.0,

@@ -31,6 +31,18 @@ static inline int set_check_launch(const char *what) {
         if (e__ != hipSuccess) return set_fail(SET_E_LAUNCH, what, hipGetErrorString(e__)); \
     } while (0)
 
+const uint64_t *set_seed_delta_ptr();  // the device word of set_rng_seed_delta (csrc/diffnet.hip), NULL when unset
+// Clear `words` 32-bit words with a KERNEL.  Not hipMemsetAsync: as a memset node of a captured graph (training.GraphedTrainStep) a clear
+// was not ordered against eager work enqueued between two replays (ROCm 7.2) -- buffers came out as uninitialised memory.
+static __global__ void __launch_bounds__(256) set_zero_words_kernel(unsigned *p, int64_t words) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < words) p[i] = 0u;
+}
+static inline hipError_t set_zero_async(void *p, size_t bytes, hipStream_t s) {
+    const int64_t words = (int64_t)((bytes + 3) / 4);
+    hipLaunchKernelGGL(set_zero_words_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, reinterpret_cast<unsigned *>(p), words);
+    return hipGetLastError();
+}
 static inline unsigned set_blocks(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 // ---- activations (match torch CPU fp32 semantics) -----------------------------------------

@@ -1161,7 +1161,7 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
         return set_launch_diffnet_stack_split_x2(a, fault_tile, s);  // the same scheme on the two-piece fp16 operands
     if (variant == 3) {
         const int tiles = (a.T + 31) / 32, nt = a.B * tiles;
-        SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + 2 * nt) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
+        SET_HIP(set_zero_async(a.sync_ws, (size_t)(4 + 2 * nt) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
         hipLaunchKernelGGL(diffnet_stack_split_kernel, dim3(4 * nt), dim3(256), (size_t)SP_LDS_FLOATS * sizeof(float), s, a,
                            tiles, nt, fault_tile);
         return set_check_launch("set_diffnet_stack");
@@ -1185,7 +1185,7 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     const int max_dil = 1 << (a.dilation_cycle_length - 1);
     const int task_slot = DC * (ntt + 2 * max_dil);  // float index of the task word
     const size_t lds = (size_t)(task_slot + 4) * sizeof(float);
-    SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + ntiles + (wino ? 12 : 0)) * sizeof(int32_t), s),
+    SET_HIP(set_zero_async(a.sync_ws, (size_t)(4 + ntiles + (wino ? 12 : 0)) * sizeof(int32_t), s),
             "set_diffnet_stack(memset)");
     const int wps = wino ? 1 : 2;  // resident blocks per CU (three 168-VGPR blocks per CU measured slower: see DESIGN.md)
     int grid = wps * n_cu;
@@ -1278,9 +1278,12 @@ __device__ __forceinline__ void randn4(uint64_t seed, uint64_t ctr, float out[4]
     out[0] = r0 * c0; out[1] = r0 * s0; out[2] = r1 * c1; out[3] = r1 * s1;
 }
 
-__global__ void __launch_bounds__(256) randn_kernel(float *out, int64_t n, uint64_t seed, uint64_t offset) {
+// seed_delta (set_rng_seed_delta, may be NULL): a device word ADDED to the seed argument -- a captured graph carries the seed of the
+// step it was captured at; the replay of step k stores (seed_k - seed_captured) there and draws exactly the eager step's numbers
+__global__ void __launch_bounds__(256) randn_kernel(float *out, int64_t n, uint64_t seed, uint64_t offset, const uint64_t *seed_delta) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;  // quad index
     if (q * 4 >= n) return;
+    if (seed_delta) seed += *seed_delta;
     float z[4];
     randn4(seed, offset + (uint64_t)q, z);
 #pragma unroll
@@ -1292,9 +1295,10 @@ __global__ void __launch_bounds__(256) randn_kernel(float *out, int64_t n, uint6
 __global__ void __launch_bounds__(256) posterior_kernel(const float *x0, const float *x_t, const float *eps,
                                                         const float *coef4, int64_t coef_bs, float *x_prev,
                                                         int64_t per_batch, int64_t n, uint64_t seed,
-                                                        uint64_t offset) {
+                                                        uint64_t offset, const uint64_t *seed_delta) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q * 4 >= n) return;
+    if (seed_delta) seed += *seed_delta;
     float z[4];
     if (!eps) randn4(seed, offset + (uint64_t)q, z);
 #pragma unroll
@@ -1361,10 +1365,17 @@ extern "C" int set_sinusoid_embed(const float *t, float *out, int32_t dim, int32
                        out, dim, n);
     return set_check_launch("set_sinusoid_embed");
 }
+static const uint64_t *g_seed_delta = nullptr;
+const uint64_t *set_seed_delta_ptr() { return g_seed_delta; }
+extern "C" int set_rng_seed_delta(const uint64_t *dev_word) {
+    g_seed_delta = dev_word;
+    return SET_OK;
+}
+
 extern "C" int set_randn(float *out, int64_t n, uint64_t seed, uint64_t offset, void *stream) {
     SET_REQUIRE(out && n > 0, "set_randn");
     hipLaunchKernelGGL(randn_kernel, dim3(set_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n,
-                       seed, offset);
+                       seed, offset, g_seed_delta);
     return set_check_launch("set_randn");
 }
 extern "C" int set_posterior_step(const float *x0, const float *x_t, const float *eps, const float *coef4,
@@ -1373,7 +1384,7 @@ extern "C" int set_posterior_step(const float *x0, const float *x_t, const float
     SET_REQUIRE(x0 && x_t && coef4 && x_prev && B > 0 && per_batch > 0, "set_posterior_step");
     const int64_t n = (int64_t)B * per_batch;
     hipLaunchKernelGGL(posterior_kernel, dim3(set_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, x0,
-                       x_t, eps, coef4, coef_bs, x_prev, per_batch, n, seed, offset);
+                       x_t, eps, coef4, coef_bs, x_prev, per_batch, n, seed, offset, g_seed_delta);
     return set_check_launch("set_posterior_step");
 }
 extern "C" int set_q_sample(const float *x_start, const float *eps, const float *ab2, const float *nonpad, float *x_t,

@@ -30,8 +30,14 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 // debug: phase time stamps (s_memtime) of one block of the layer kernels, see set_debug_bf16_phase_buffer
 __device__ uint64_t *g_bf16_phase_buf = nullptr;
+// (the per-layer kernels' stamps are stores through a generic pointer: compiled in only with -DSET_BF16_PROBE=1 -- tools/build_exp.sh
+// bf16probe diffnet_bf16.hip -DSET_BF16_PROBE=1 --, because one flat access makes the wait-count pass drain the weight ring with
+// vmcnt(0) at the top of every k-step group of the PRODUCTION kernel; the fused-layers kernels sum their stamps in scalar registers)
+#ifndef SET_BF16_PROBE
+#define SET_BF16_PROBE 0
+#endif
 #define BF16_PHASE(i)                                                                                    \
-    if (g_bf16_phase_buf && blockIdx.x == 1 && blockIdx.y == 1 && threadIdx.x == 0) g_bf16_phase_buf[i] = __builtin_amdgcn_s_memtime();
+    if (SET_BF16_PROBE && g_bf16_phase_buf && blockIdx.x == 1 && blockIdx.y == 1 && threadIdx.x == 0) g_bf16_phase_buf[i] = __builtin_amdgcn_s_memtime();
 
 namespace {
 
@@ -85,18 +91,19 @@ __device__ __forceinline__ void gemm_bf16(f32x16 (&acc)[NRB][NCB], rsrc_t img, u
             u32x4_t Bv[NCB];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) Bv[cb] = *reinterpret_cast<const u32x4_t *>(lds + bfrag(ks, cb));
-            u32x4_t Ac[NRB];
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) Ac[rb] = A[p][rb];
-            const int kn = min(ks + PF, nks - 1);  // tail: harmless re-load of the last k-step
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) A[p][rb] = buf_load_u4(img, lane16, (unsigned)(((ks0 + kn) * NRB + rb) * 1024));
+            // pinned order (round 4): B fragments | MFMAs straight from the ring slot | the slot's refill PF k-steps ahead.  (Copying the
+            // slot and refilling it in front of the MFMAs made the compiler rotate the ring through v_mov chains behind vmcnt(0).)
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mma16(Ac[rb], Bv[cb], acc[rb][cb]);
+                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mma16(A[p][rb], Bv[cb], acc[rb][cb]);
             __builtin_amdgcn_s_setprio(0);
+            const int kn = min(ks + PF, nks - 1);  // tail: harmless re-load of the last k-step
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) A[p][rb] = buf_load_u4(img, lane16, (unsigned)(((ks0 + kn) * NRB + rb) * 1024));
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -181,29 +188,25 @@ __device__ __forceinline__ void gemm_bf16_a(f32x16 (&acc)[NRB][NCB], rsrc_t img,
             u32x4_t Bv[NCB];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) Bv[cb] = *reinterpret_cast<const u32x4_t *>(lds + bfrag(ks, cb));
-            u32x4_t Ac[NRB];
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) Ac[rb] = A[p][rb];
-            const int kn = min(ks + PFD, nks - 1);  // tail: harmless re-load of the last k-step
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) A[p][rb] = buf_load_u4(img, lane16, aoff(kn, rb));
+            __builtin_amdgcn_sched_barrier(0);  // pinned order, see gemm_bf16
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mma16(Ac[rb], Bv[cb], acc[rb][cb]);
+                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mma16(A[p][rb], Bv[cb], acc[rb][cb]);
             __builtin_amdgcn_s_setprio(0);
+            const int kn = min(ks + PFD, nks - 1);  // tail: harmless re-load of the last k-step
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) A[p][rb] = buf_load_u4(img, lane16, aoff(kn, rb));
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
 // TRAIN: also store the pre-gate y and the gated z in bf16 (operands of the backward).
-// NT: frames per tile.  128 -> 8 waves, one 32-row gate block + its filter block per wave, one block per CU (120 KB of LDS);
-//     64 -> 4 waves, two gate blocks + their filter blocks per wave, 61 KB of LDS: TWO blocks per CU, which drift out
-//     of phase so that one block's HBM phases (stage, residual / skip read-modify-write) run under the other's GEMMs --
-//     at the price of reading the weight images twice as often from L2.  Accumulators: 8 x 32x32 per wave either way.
+// NT: frames per tile = 128: 8 waves, one 32-row gate block + its filter block per wave, one block per CU (120 KB of LDS).
 template <bool TRAIN, int NT>
-__global__ void __launch_bounds__(NT * 4, NT == 128 ? 1 : 2) diffnet_layer_fwd_bf16_kernel(SetDiffnetLayerBf16Args a) {
+__global__ void __launch_bounds__(NT * 4, 1) diffnet_layer_fwd_bf16_kernel(SetDiffnetLayerBf16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int NW = NT / 16;   // waves per block
     constexpr int RBW = 8 / NW;   // 32-row gate blocks per wave (and as many filter blocks)
@@ -1451,32 +1454,22 @@ extern "C" int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, v
                     ((a.y16 != nullptr) == (a.z16 != nullptr)), "set_diffnet_layer_fwd_bf16");
     SET_REQUIRE(a.B > 0 && a.T > 0 && a.dil >= 1 && a.dil <= 8, "set_diffnet_layer_fwd_bf16");
     SET_REQUIRE((int64_t)2 * FC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_layer_fwd_bf16 (T too large)");
-    // tile width: 128 frames (8 waves, one block per CU); SET_AMD_BF16_TILE=64 selects the 64-frame variant (4 waves, two
-    // blocks per CU), measured slower and kept for experiments
-    static int tile = 0;
-    if (!tile) { const char *e = getenv("SET_AMD_BF16_TILE"); tile = (e && atoi(e) == 64) ? 64 : 128; }
+    // tile: 128 frames, 8 waves, one block per CU (round 3's 64-frame / two-blocks-per-CU experiment spilled registers, measured
+    // slower, and is gone)
+    constexpr int tile = 128;
     static bool attr_set = false;
     if (!attr_set) {
         SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel<true, 128>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layer fwd bf16 attr");
         SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel<false, 128>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layer fwd bf16 attr");
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel<true, 64>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "layer fwd bf16 attr");
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_fwd_bf16_kernel<false, 64>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "layer fwd bf16 attr");
         attr_set = true;
     }
     const size_t ldsz = (size_t)(tile + 2 * a.dil) * XR + (size_t)tile * CR + FC * sizeof(float);
     dim3 grid((a.T + tile - 1) / tile, a.B);
     hipStream_t st = (hipStream_t)stream;
-    if (tile == 128) {
-        if (a.y16) hipLaunchKernelGGL((diffnet_layer_fwd_bf16_kernel<true, 128>), grid, dim3(512), ldsz, st, a);
-        else hipLaunchKernelGGL((diffnet_layer_fwd_bf16_kernel<false, 128>), grid, dim3(512), ldsz, st, a);
-    } else {
-        if (a.y16) hipLaunchKernelGGL((diffnet_layer_fwd_bf16_kernel<true, 64>), grid, dim3(256), ldsz, st, a);
-        else hipLaunchKernelGGL((diffnet_layer_fwd_bf16_kernel<false, 64>), grid, dim3(256), ldsz, st, a);
-    }
+    if (a.y16) hipLaunchKernelGGL((diffnet_layer_fwd_bf16_kernel<true, 128>), grid, dim3(512), ldsz, st, a);
+    else hipLaunchKernelGGL((diffnet_layer_fwd_bf16_kernel<false, 128>), grid, dim3(512), ldsz, st, a);
     return set_check_launch("set_diffnet_layer_fwd_bf16");
 }
 

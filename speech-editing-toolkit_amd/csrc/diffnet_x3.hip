@@ -49,6 +49,13 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 // debug: lane 0 of block 0 adds the s_memtime ticks of its phases (claim + wait, stage, GEMM 1, gate, GEMM 2, epilogue +
 // publish), summed over its tasks, to buf[0..5] (+ sub-phases of the gate in buf[8..10]) and its task count to buf[7]
 __device__ uint64_t *g_x3_phase_buf = nullptr;
+// The stamps are compiled in only with -DSET_X3_PROBE=1 (tools/build_exp.sh x3probe diffnet_x3.hip -DSET_X3_PROBE=1): they add to
+// counters through a generic pointer, and one flat access inside the task loop makes the wait-count pass treat every outstanding
+// load as possibly out of order -- s_waitcnt vmcnt(0) at the top of every 4-k-step group of both GEMMs, i.e. the weight ring drained
+// once per group in the PRODUCTION kernel (found in round 4 on the bf16 layer kernels, same mechanism here).
+#ifndef SET_X3_PROBE
+#define SET_X3_PROBE 0
+#endif
 
 namespace {
 
@@ -168,21 +175,10 @@ __device__ __forceinline__ void gemm_x3(f32x16 (&acc)[NU][2][NCB], rsrc_t img, u
 #pragma unroll
                 for (int q = 0; q < NP; ++q) Bv[cb][q] = *reinterpret_cast<const u32x4_t *>(lds + q * piece_bytes + bo);
             }
-            u32x4_t Ac[NU][2][NP];
-#pragma unroll
-            for (int u = 0; u < NU; ++u)
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) Ac[u][rb][q] = A[p][u][rb][q];
-            const int kn = (SET_X3_EXP & 1) ? p : min(ks + PF, NKS - 1);  // tail: harmless re-load of the last k-step (experiment 1: no A stream)
-#pragma unroll
-            for (int u = 0; u < NU; ++u)
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int q = 0; q < NP; ++q)
-                        A[p][u][rb][q] = buf_load_u4(img, lane16, abase + (unsigned)u * ustride + (unsigned)(((kn * 2 + rb) * NP + q) * 1024));
+            // pinned order (round 4): B fragments | the k-step's MFMAs straight from the ring slot | the slot's refill PF k-steps ahead.
+            // (Copying the slot to temporaries and refilling it BEFORE the MFMAs -- the earlier form -- made the compiler rotate the ring
+            // through v_mov chains behind s_waitcnt vmcnt(0) at the end of every PF k-steps: the ring drained once per loop iteration.)
+            __builtin_amdgcn_sched_barrier(0);
             if (!(SET_X3_EXP & 4)) __builtin_amdgcn_s_setprio(1);
             // the accumulators interleave, so consecutive MFMAs never depend on each other
 #pragma unroll
@@ -193,8 +189,17 @@ __device__ __forceinline__ void gemm_x3(f32x16 (&acc)[NU][2][NCB], rsrc_t img, u
                     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                         for (int cb = 0; cb < NCB; ++cb)
-                            acc[u][rb][cb] = S::mma(Ac[u][rb][S::qa(t)], Bv[cb][S::qb(t)], acc[u][rb][cb]);
+                            acc[u][rb][cb] = S::mma(A[p][u][rb][S::qa(t)], Bv[cb][S::qb(t)], acc[u][rb][cb]);
             if (!(SET_X3_EXP & 4)) __builtin_amdgcn_s_setprio(0);
+            const int kn = (SET_X3_EXP & 1) ? p : min(ks + PF, NKS - 1);  // tail: harmless re-load of the last k-step (experiment 1: no A stream)
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        A[p][u][rb][q] = buf_load_u4(img, lane16, abase + (unsigned)u * ustride + (unsigned)(((kn * 2 + rb) * NP + q) * 1024));
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -526,7 +531,7 @@ __global__ void __launch_bounds__(512 / NU, NU) diffnet_stack_x3_kernel(SetDiffn
     int *s_task = reinterpret_cast<int *>(lds + S::NP * piece_bytes + NCB * XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
     int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
     const int tid = threadIdx.x;
-    uint64_t *dbg = (blockIdx.x == 0 && tid == 0) ? g_x3_phase_buf : nullptr;
+    uint64_t *dbg = (SET_X3_PROBE && blockIdx.x == 0 && tid == 0) ? g_x3_phase_buf : nullptr;
     uint64_t tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
     // Each block claims its NEXT task while the current one runs (the result is read at the end of the task), issues the
     // next task's producer-independent loads before it drains the stores of the finished tile, and publishes that tile
@@ -630,7 +635,7 @@ int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_
     const int max_dil = 1 << (a.dilation_cycle_length - 1);
     const unsigned piece_bytes = (unsigned)(NCB * (32 + 2 * max_dil) * XR);  // every column block has its own halo rows
     const size_t ldsz = x3_lds_bytes<S, NCB>(max_dil);
-    SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
+    SET_HIP(set_zero_async(a.sync_ws, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
     // workers stay below the runnable-task count (a tile's layers form a chain: at most `ntiles` tasks are ever runnable;
     // see diffnet.hip).  NU = 2: two blocks fit a CU, and the ones that do not get a partner still run a task at a time.
     int grid = NU * n_cu;
@@ -782,7 +787,7 @@ __global__ void __launch_bounds__(256, 1) diffnet_stack_split_x2_kernel(SetDiffn
     unsigned short *zt = reinterpret_cast<unsigned short *>(a.z_ws) + (int64_t)i * (2 * 32 * XC);  // [piece][frame][256]
     const rsrc_t rz = make_rsrc(zt);
     const rsrc_t rsk = make_rsrc(a.skip + (int64_t)b * XC * T);
-    uint64_t *dbg = (blockIdx.x == 5 && tid == 0) ? g_x3_phase_buf : nullptr;  // debug: phase ticks of one block, see below
+    uint64_t *dbg = (SET_X3_PROBE && blockIdx.x == 5 && tid == 0) ? g_x3_phase_buf : nullptr;  // debug: phase ticks of one block, see below
     uint64_t tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
 #define SX_PHASE(p)                                           \
     if (dbg) {                                                \
@@ -975,7 +980,7 @@ int set_launch_diffnet_stack_split_x2(const SetDiffnetStackArgs &a, int fault_ti
     const int max_dil = 1 << (a.dilation_cycle_length - 1);
     const unsigned piece_bytes = (unsigned)((32 + 2 * max_dil) * XR);
     const size_t ldsz = (size_t)2 * piece_bytes + (64 * 32 + XC) * sizeof(float) + 16;
-    SET_HIP(hipMemsetAsync(a.sync_ws, 0, (size_t)(4 + 2 * nt) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
+    SET_HIP(set_zero_async(a.sync_ws, (size_t)(4 + 2 * nt) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
     // 8 L2-warmer blocks (one per XCD) when the chip has CUs to spare and the block -> XCD round-robin lines them up with the parts
     static int warm = -1, n_cu = 0;
     if (warm < 0) {
@@ -1025,19 +1030,12 @@ int set_launch_diffnet_stack_x3(const SetDiffnetStackArgs &a, int n_cu, int faul
     const int64_t tiles64 = (int64_t)a.B * ((a.T + 63) / 64);
     bool narrow = 5 * tiles64 < 3 * (int64_t)n_cu;
     if (const char *e = getenv("SET_AMD_X3_TILE")) narrow = atoi(e) == 32;
-    // block shape: one 8-wave block per CU.  SET_AMD_X3_WAVES=4 selects two 4-wave blocks per CU (see x3_init; f16x2 images, when
-    // two blocks fit the CU's LDS) -- a measurement variant: bit-identical, and never faster.  Measured at T = 800
-    // (tools/x3_pair_probe.py, profiles/r03_x3_pair_probe.log): B = 32 1.78 ms per 20 layers (8 waves) vs 1.94 - 2.38 ms (4 waves,
-    // 256 - 512 workers: only 400 tile chains exist, the extra workers wait); B = 64 (800 chains) 3.65 vs 3.69 ms -- with
-    // the phases of two tasks overlapping on every CU the clock drops from 1.88 to 1.63 GHz and the throughput stays
-    // where it was: the kernel runs at the chip's power limit, not at an issue or latency limit.
-    const int max_dil = 1 << (a.dilation_cycle_length - 1);
-    const size_t lds2 = narrow ? x3_lds_bytes<SplitF16x2, 1>(max_dil) : x3_lds_bytes<SplitF16x2, 2>(max_dil);
-    bool pair = false;
-    if (const char *e = getenv("SET_AMD_X3_WAVES")) pair = a.x3_mode == 2 && 2 * lds2 <= 160 * 1024 && atoi(e) == 4;
-    if (a.x3_mode == 2) {
-        if (pair) return narrow ? launch_x3<SplitF16x2, 2, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitF16x2, 2, 2>(a, n_cu, fault_tile, s);
+    // block shape: one 8-wave block per CU.  (Round 3 also shipped two 4-wave blocks per CU behind SET_AMD_X3_WAVES=4 -- bit-identical,
+    // never faster: B = 32 1.78 ms per 20 layers (8 waves) vs 1.94 - 2.38 ms, B = 64 3.65 vs 3.69 ms with the clock dropping from 1.88
+    // to 1.63 GHz; profiles/r03_x3_pair_probe.log -- but its 64-frame instantiation spilled registers, which confounded the
+    // comparison; round 4 measured the power limit directly instead (profiles/r04_power.log, r04_mfma_ceiling.log) and removed the
+    // variant from the library.  The NU template parameter of the kernel stays for tools/build_exp.sh experiments.)
+    if (a.x3_mode == 2)
         return narrow ? launch_x3<SplitF16x2, 1, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitF16x2, 1, 2>(a, n_cu, fault_tile, s);
-    }
     return narrow ? launch_x3<SplitBf16x3, 1, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitBf16x3, 1, 2>(a, n_cu, fault_tile, s);
 }

@@ -431,9 +431,10 @@ __device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_
     }
 }
 __global__ void __launch_bounds__(256) dropout_kernel(const float *x, float *y, int64_t n, float p, uint64_t seed,
-                                                      uint64_t offset) {
+                                                      uint64_t offset, const uint64_t *seed_delta) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q * 4 >= n) return;
+    if (seed_delta) seed += *seed_delta;  // set_rng_seed_delta: see randn_kernel
     const uint64_t ctr = offset + (uint64_t)q;
     uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0x5eedu, 0u};
     philox_round(c, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -770,11 +771,14 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float *g, float *out, 
 }
 // AdamW (torch.optim.AdamW semantics, amsgrad off) over a flat buffer; grads are first scaled by
 // clip = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))  (torch.nn.utils.clip_grad_norm_), sumsq optional.
+// hyper != NULL (set_adamw_dev): lr and the two bias corrections come from device memory [lr, bc1, bc2] -- the step of a captured
+// graph, whose kernel arguments are frozen, reads the values of the update it is replayed for
 __global__ void __launch_bounds__(256) adamw_kernel(float *p, const float *g, float *m, float *v, int64_t n, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1, float bc2,
-                                                    const float *sumsq, float max_norm, float grad_scale) {
+                                                    const float *sumsq, float max_norm, float grad_scale, const float *hyper) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }
     float clip = 1.0f;
     if (sumsq && max_norm > 0.0f) {
         const float c = max_norm / (sqrtf(sumsq[0]) * grad_scale + 1e-6f);
@@ -1042,6 +1046,12 @@ extern "C" int set_pitch_loss_sums_det(const float *pp, const float *f0, const f
 }
 // table[n_rows][C] (mode 0) / denc^T[B * n_rows][C] (mode 1) += scatter of doutT [B][T][C]; scratch: B * S * n_rows * C floats
 // (mode 0) with S = set_scatter_rows_segments(T); it is zeroed here.
+// (a kernel, not hipMemsetAsync: as a memset NODE of a captured training step the 6 MB clear was not ordered against eager work of
+// another stream between two replays -- the partial tables came out as uninitialised memory; tests/test_gpu_training.py)
+__global__ void __launch_bounds__(256) zero_f32x4_kernel(f32x4 *p, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) p[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+}
 extern "C" int32_t set_scatter_rows_segments(int32_t T) { int s = T / 128; return s < 1 ? 1 : (s > 8 ? 8 : s); }
 extern "C" int set_scatter_rows_det(const int64_t *idx, const float *doutT, float *table, int32_t B, int32_t T, int32_t C,
                                     int32_t n_rows, float scale, int32_t padding_idx, int32_t mode, float *scratch,
@@ -1050,7 +1060,10 @@ extern "C" int set_scatter_rows_det(const int64_t *idx, const float *doutT, floa
                 "set_scatter_rows_det");
     const int S = set_scatter_rows_segments(T);
     const int64_t n = (int64_t)n_rows * C;
-    SET_HIP(hipMemsetAsync(scratch, 0, (size_t)B * S * n * sizeof(float), (hipStream_t)stream), "set_scatter_rows_det(memset)");
+    {
+        const int64_t n4 = ((int64_t)B * S * n + 3) / 4;  // the scratch buffers are allocated with slack: rounding up to 16 bytes stays inside
+        hipLaunchKernelGGL(zero_f32x4_kernel, dim3(set_blocks(n4, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<f32x4 *>(scratch), n4);
+    }
     const int waves = B * S * ((C + 63) / 64);
     hipLaunchKernelGGL(scatter_rows_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, idx, doutT, scratch, B, T,
                        C, n_rows, S, scale, padding_idx, mode);
@@ -1137,7 +1150,7 @@ extern "C" int set_expand_states_bwd(const int64_t *mel2ph, const float *dout, f
 extern "C" int set_dropout(const float *x, float *y, int64_t n, float p, uint64_t seed, uint64_t offset, void *stream) {
     SET_REQUIRE(x && y && n > 0 && p >= 0.0f && p < 1.0f, "set_dropout");
     hipLaunchKernelGGL(dropout_kernel, dim3(set_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, p,
-                       seed, offset);
+                       seed, offset, set_seed_delta_ptr());
     return set_check_launch("set_dropout");
 }
 extern "C" int set_frame_weight(const float *target, float *w, int64_t frames, int32_t M, void *stream) {
@@ -1234,6 +1247,19 @@ extern "C" int set_adamw(float *p, const float *g, float *m, float *v, int64_t n
     SET_REQUIRE(p && g && m && v && n > 0 && step >= 1, "set_adamw");
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                       beta2, eps, weight_decay, bc1, bc2, sumsq, max_norm, grad_scale);
+                       beta2, eps, weight_decay, bc1, bc2, sumsq, max_norm, grad_scale, (const float *)nullptr);
     return set_check_launch("set_adamw");
+}
+extern "C" int set_adamw_hyper(float beta1, float beta2, int32_t step, float *out2) {
+    SET_REQUIRE(out2 && step >= 1, "set_adamw_hyper");
+    out2[0] = 1.0f - powf(beta1, (float)step);  // exactly what set_adamw computes on the host
+    out2[1] = 1.0f - powf(beta2, (float)step);
+    return SET_OK;
+}
+extern "C" int set_adamw_dev(float *p, const float *g, float *m, float *v, int64_t n, const float *hyper, float beta1, float beta2,
+                             float eps, float weight_decay, const float *sumsq, float max_norm, float grad_scale, void *stream) {
+    SET_REQUIRE(p && g && m && v && n > 0 && hyper, "set_adamw_dev");
+    hipLaunchKernelGGL(adamw_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.0f, beta1,
+                       beta2, eps, weight_decay, 1.0f, 1.0f, sumsq, max_norm, grad_scale, hyper);
+    return set_check_launch("set_adamw_dev");
 }

@@ -685,3 +685,62 @@ def test_training_step_with_grouped_step_projections_equals_the_per_layer_path(d
         a, b = g1[off:off + n], g0[off:off + n]
         off += n
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, name
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_graphed_training_step_equals_the_eager_step_bit_for_bit(dev, dtype, monkeypatch):
+    """training.GraphedTrainStep: the optimisation step captured once per batch shape and replayed (the step was
+    host-bound, ~500 launches enqueued from Python).  Two identical replicas, eight updates each with a different batch content,
+    explicit diffusion steps t, a different Philox seed (noise, predictor dropout) and the warm-up schedule moving the lr: replica A
+    runs every step eagerly, replica B through GraphedTrainStep (two eager steps, then capture + replays).  Losses, every parameter and
+    both Adam moments must be bit-identical after every update -- seeds reach the replay through set_rng_seed_delta, lr and the bias
+    corrections through set_adamw_dev."""
+    from set_amd import ops
+    from set_amd.training import FlatAdamW, GraphedTrainStep
+    monkeypatch.setenv("SET_AMD_GRAPH_STEP", "1")
+    ops.set_compute_dtype(dtype)
+    try:
+        reps = []
+        for _ in range(2):
+            task, W = _train_setup(dev, 8, 31)
+            task.model.train()  # dropout on
+            reps.append((task, FlatAdamW(task.model, lr=1e-3, warmup_updates=5, clip_grad_norm=1.0)))
+        (ta, oa), (tb, ob) = reps
+        assert torch.equal(oa.flat_p, ob.flat_p)
+        gs = GraphedTrainStep(tb, ob, eager_steps=2)
+        assert gs.usable()
+        base = Wt.synthetic_inputs(4, 96, 24, seed=77, pad_tail=True)
+        for it in range(8):
+            inp = Wt.synthetic_inputs(4, 96, 24, seed=77 + it, pad_tail=True)
+            sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"],
+                          time_mel_masks=inp["time_mel_masks"].squeeze(-1), spk_embed=inp["spk_embed"])
+            sample = {k: v.to(dev) for k, v in sample.items()}
+            t = torch.tensor([(1 + it) % 9, 3, (5 + 2 * it) % 9, 7], device=dev)
+            seed = 1000 + 37 * it
+            gs.eager_mode()  # (two replicas in one process: the eager one must not see the last replay's seed delta)
+            tot_a, parts_a, lr_a = ta.training_step(sample, oa, t=t, seed=seed)
+            tot_b, parts_b, lr_b = gs(sample, seed, t)
+            assert lr_a == lr_b and oa.num_updates == ob.num_updates == it + 1
+            assert torch.equal(tot_a, tot_b), it
+            assert set(parts_a) == set(parts_b) and all(torch.equal(parts_a[k].reshape(()), parts_b[k].reshape(()).to(parts_a[k].dtype)) for k in parts_a), it
+            assert torch.equal(oa.flat_p, ob.flat_p) and torch.equal(oa.m, ob.m) and torch.equal(oa.v, ob.v), it
+        assert gs.replays == 6 and sum(1 for e in gs.entries.values() if e["graph"] is not None) == 1
+        # a second batch shape gets its own eager steps, then its own graph
+        inp = Wt.synthetic_inputs(2, 64, 16, seed=5, pad_tail=True)
+        sample = {k: v.to(dev) for k, v in dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"],
+                                                uv=inp["uv"], time_mel_masks=inp["time_mel_masks"].squeeze(-1), spk_embed=inp["spk_embed"]).items()}
+        for it in range(4):
+            t = torch.tensor([2, (4 + it) % 9], device=dev)
+            gs.eager_mode()
+            tot_a, _, _ = ta.training_step(sample, oa, t=t, seed=7 + it)
+            tot_b, _, _ = gs(sample, 7 + it, t)
+            assert torch.equal(tot_a, tot_b) and torch.equal(oa.flat_p, ob.flat_p), it
+        assert gs.replays == 8
+    finally:
+        ops.set_compute_dtype("f32")
+        _lib_reset_seed_delta()
+
+
+def _lib_reset_seed_delta():
+    from set_amd import _lib
+    _lib.check(_lib.lib().set_rng_seed_delta(None), "set_rng_seed_delta")

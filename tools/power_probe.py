@@ -161,5 +161,23 @@ if __name__ == "__main__":
             l, keep, nl = make_bf16_layers(128, 10); run("bf16 layer groups, 128-frame tiles, 10 layers per launch", l, nl)
         elif wname == "x3":
             l, keep, nl = make_x3(); run("split-operand stack kernel (headline loop), 20 layers per launch", l, nl)
+        elif wname == "ceiling":  # tools/hw/mfma_ceiling (bare MFMA / + LDS fragments / + L2 fragments) under the same telemetry
+            import subprocess
+            exe = os.path.join(ROOT, "tools", "hw", "mfma_ceiling")
+            for mode in (0, 1, 2):
+                files = hwmon_files()
+                smp = Sampler(files)
+                smp.start()
+                t0 = time.time()
+                r = subprocess.run([exe, "6", str(mode)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                t1 = time.time()
+                smp.stop_flag = True
+                smp.join()
+                rows = [x for x in smp.rows if x["t"] > t0 + 0.5 * (t1 - t0)]  # the second half: clocks settled, kernel running
+                pw = [x["power1_input"] / 1e6 for x in rows if "power1_input" in x]
+                fq = [x["freq1_input"] / 1e9 for x in rows if "freq1_input" in x]
+                print(json.dumps({"kernel": "mfma_ceiling mode %d" % mode, "stdout": r.stdout.strip(), "samples": len(rows),
+                                  "power_W_mean": sum(pw) / max(1, len(pw)), "power_W_max": max(pw) if pw else None,
+                                  "sclk_GHz_mean": sum(fq) / max(1, len(fq))}), flush=True)
         elif wname == "idle":
             run("idle (no launches)", lambda: time.sleep(0.001), 0, seconds=3.0)
