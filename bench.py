@@ -326,7 +326,10 @@ def run_infer(args, rank, world, dev):
     # WRITE_SIZE per MI355X_MICROARCH.md).  Counters cannot be collected inside this process, so the figure is the one measured
     # on the SAME kernel sources: the file carries their sha256 and the figure is withheld (null) when the sources changed since.
     traffic, traffic_note, pmc = None, None, None
-    tfile = os.path.join(ROOT, "profiles", "r03_pmc_x3.json")
+    tfile = os.path.join(ROOT, "profiles", "r04_pmc_x3.json")
+    if not os.path.exists(tfile):
+        tfile = os.path.join(ROOT, "profiles", "r03_pmc_x3.json")
+    tname = os.path.relpath(tfile, ROOT)
     if os.path.exists(tfile) and persistent and variant in (4, 5):
         import hashlib
         with open(tfile) as f:
@@ -338,9 +341,9 @@ def run_infer(args, rank, world, dev):
         ent = tj.get("diffnet_stack_x3_kernel<%s>" % ("SplitF16x2" if variant == 5 else "SplitBf16x3"))
         if ent is not None and h.hexdigest() == tj.get("kernel_source_sha256"):
             traffic, pmc = ent["traffic_bytes"], ent
-            traffic_note = "PMC passes of this kernel build (profiles/r03_pmc_x3.json, source sha256 matches)"
+            traffic_note = "PMC passes of this kernel build (%s, source sha256 matches)" % tname
         else:
-            traffic_note = "withheld: the kernel sources changed since the PMC passes in profiles/r03_pmc_x3.json"
+            traffic_note = "withheld: the kernel sources changed since the PMC passes in %s" % tname
     out = {
         "metric": "diffusion mel-frames/s (100-step p_sample, B=32/GPU, T=800)",
         "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -362,6 +365,9 @@ def run_infer(args, rank, world, dev):
         "roofline": {"kernel": stack_kernel if persistent else "diffnet_layer_kernel", "bound": "mfma",
                      "achieved": executed_ratio * ach_tflops, "peak": pipe_peak, "unit": "TFLOP/s",
                      "frac": executed_ratio * ach_tflops / pipe_peak, "traffic": traffic, "launch_ms": launch_ms,
+                     # the same time priced with the ALGORITHMIC fp32 FLOPs of the layer math against the pipe the products run on
+                     # (`frac` counts the 3 / 6 emulation products per fp32 product as achieved work)
+                     "frac_algorithmic": ach_tflops / pipe_peak,
                      "mfma_instruction": pipe, "executed_mfma_flop_ratio": executed_ratio,
                      "flop_per_launch": flop_per_launch, "layers_per_launch": layers_per_launch,
                      "algorithmic_fp32_TFLOPs": ach_tflops,
@@ -374,9 +380,11 @@ def run_infer(args, rank, world, dev):
                      "traffic_over_algorithmic_bytes": traffic / bytes_per_launch if traffic else None,
                      "pmc_mfma_busy_frac_of_simd_cycles": pmc["mfma_busy_frac_of_simd_cycles"] if pmc else None,
                      "pmc_sclk_GHz": pmc["cycles_per_launch"] / (launch_ms * 1e6) if pmc and pmc.get("cycles_per_launch") else None,
-                     "limit": "power: with twice the tasks in flight per CU the clock falls from 1.88 to 1.63 GHz at equal "
-                              "throughput, and without any operand traffic the kernel is 6.7 % faster "
-                              "(profiles/r03_x3_pair_probe.log, DESIGN.md 3.1f)",
+                     "limit": "power: hwmon telemetry over 8 s loops of this kernel reads 1.37-1.40 kW of the 1.4 kW cap at 1.86-2.04 GHz "
+                              "(2.4 GHz max; profiles/r04_power.log); a bare v_mfma_f32_32x32x16_f16 loop on the same box reaches "
+                              "1,836 TFLOP/s at 1.29 kW, 1,356 TFLOP/s with this kernel's weight-fragment stream from L2 "
+                              "(profiles/r04_mfma_ceiling.log); removing the kernel's ring stalls (round 4) lowered the clock from "
+                              "2.00 to 1.86 GHz and the time by 1.4 %",
                      "note": (("fp32-equivalent results from 16-bit MFMAs.  f16x2: every fp32 operand is carried as TWO fp16 pieces "
                                "(11 + 11 = 22 significand bits, 2 fewer than fp32's 24) and a product is a0 b0 + a0 b1 + a1 b0 -- "
                                "the a1 b1 term (~2^-22 |ab|) is dropped; fp32 accumulation.  " if variant == 5 else
@@ -390,6 +398,8 @@ def run_infer(args, rank, world, dev):
                               "loop on the exact 24-bit splitting")
                      if split_operands else None},
     }
+    if rank == 0 and world == 1 and not args.no_quality:
+        out.update(quality_vs_oracle(model))
     if rank == 0 and world == 1 and split_operands and not args.no_native_fp32:
         out["native_fp32_loop"] = native_fp32_line(model, inp, args, step(0)["mel_out"])
     if rank == 0 and world == 1 and split_operands and variant == 5 and not args.no_bf16x3_loop:
@@ -399,7 +409,98 @@ def run_infer(args, rank, world, dev):
     if rank == 0 and world == 1 and args.cpu_baseline != "off":
         out["cpu_baseline"] = cpu_baseline(model, inp, args.cpu_baseline)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # the other BASELINE configs, each in a process of its own (fresh hparams / allocator; this process idles meanwhile)
+        del model
+        torch.cuda.empty_cache()
+        out["e2e_b64_vocoder"] = e2e_line()
+        out["train_bf16"] = train_line("spec_denoiser", "bf16")
+        out["campnet_train_bf16"] = train_line("campnet", "bf16")
     return out
+
+
+def quality_vs_oracle(model):
+    """BASELINE's "MCD vs ref" on the headline path: 4 synthetic utterances at T = 800 through TWO reverse steps of the shipped kernels
+    (timesteps = 2, explicit noise) against the CPU oracle (the port of the reference's torch path, pinned on the reference-generated
+    goldens in tests/) on the same weights, inputs and noise: mel-level MCD (utils/eval/mcd.py:89-95 restated in oracle.mel_mcd) and
+    max |dmel|.  Two steps keep the oracle's CPU time at seconds; the 100-step drift is covered by tests/golden/infer_drift100."""
+    from oracle import oracle as O
+    from set_amd.diffnet import DiffNet
+    from set_amd.spec_denoiser import GaussianDiffusion
+    from set_amd.synthetic import synthetic_inputs
+    dev = next(model.parameters()).device
+    hp = load_hparams()
+    hp["timesteps"] = 2
+    m2 = GaussianDiffusion(list(range(80)), M, DiffNet(M, hp), timesteps=2, time_scale=1, loss_type="l1", spec_min=[], spec_max=[], hp=hp)
+    sd = {k: v for k, v in model.state_dict().items() if k in m2.state_dict() and m2.state_dict()[k].shape == v.shape and not O_is_table(k)}
+    m2.load_state_dict(sd, strict=False)
+    m2.to(dev).eval()
+    Bq = 4
+    inp = synthetic_inputs(Bq, T, T_TXT, seed=4321)
+    g = torch.Generator().manual_seed(99)
+    noises = [torch.randn(Bq, 1, M, T, generator=g) for _ in range(3)]
+    d = {k: v.to(dev) for k, v in inp.items()}
+    with torch.no_grad():
+        ret = m2(d["txt_tokens"], d["time_mel_masks"], d["mel2ph"], d["spk_embed"], d["ref_mels"], d["f0"], d["uv"], infer=True,
+                 noises=torch.stack(noises).to(dev))
+    W = {k: v.detach().float().cpu() for k, v in m2.state_dict().items()}
+    t0 = time.perf_counter()
+    oret = O.gaussian_diffusion_infer(W, 2, inp, noises)
+    dt = time.perf_counter() - t0
+    a, b = ret["mel_out"].float().cpu().numpy(), oret["mel_out"].float().numpy()
+    return {"mcd_vs_oracle": max(O.mel_mcd(a[i], b[i]) for i in range(Bq)), "max_abs_dmel_vs_oracle": float(abs(a - b).max()),
+            "quality_sample": "4 utterances x T=800 x 2 explicit-noise reverse steps, shipped kernels vs the CPU oracle (%.1f s of CPU)" % dt,
+            "integers_equal_vs_oracle": bool(torch.equal(ret["pitch"].cpu(), oret["pitch"]) and torch.equal(ret["masked_dur"].cpu(), oret["masked_dur"]))}
+
+
+def O_is_table(key):
+    """diffusion schedule buffers (they depend on `timesteps`; the 2-step model computes its own)"""
+    return "." not in key
+
+
+def _sub_bench(argv, timeout=420):
+    """Run this script in a process of its own and parse its JSON line."""
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "rc=%d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+    return json.loads(lines[-1])
+
+
+def train_line(model, dtype):
+    """BASELINE configs[1] (spec_denoiser, B=32, T=800, bf16) / configs[4] per GPU (CampNet, B=16, T=800): `bench.py --mode train` in a
+    sub-process (eager steps, which are what is timed), plus the host-enqueue time of the same step replayed as a captured graph."""
+    d = _sub_bench(["--mode", "train", "--model", model, "--dtype", dtype, "--steps", "20", "--warmup", "5"])
+    if "error" in d:
+        return d
+    out = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+           "host_enqueue_ms_per_step": d["host_enqueue_ms_per_step"], "loss": d["loss"],
+           "allreduce_bytes_per_step_at_N_ranks": 4 * d.get("grad_elems_exchanged", 0),
+           "roofline": {k: d["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")}}
+    env = dict(os.environ, SET_AMD_GRAPH_STEP="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--model", model, "--dtype", dtype, "--steps", "20", "--warmup", "5"]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420, env=env)
+        g = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        out["graph_replay"] = {"ms_per_step": g["ms_per_step"], "host_enqueue_ms_per_step": g["host_enqueue_ms_per_step"],
+                               "replays": g.get("graph_replays"), "loss_equal_to_eager": g["loss"] == d["loss"]}
+    except Exception as e:  # noqa: BLE001
+        out["graph_replay"] = {"error": repr(e)[:200]}
+    return out
+
+
+def e2e_line():
+    """BASELINE configs[3]: 100-step batched inference + HiFi-GAN V1 vocoder at B = 64, T = 800 on one GPU (tools/e2e_bench.py)."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py")]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+    return {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "diffusion_ms": d["diffusion_ms"], "vocoder_ms": d["vocoder_ms"],
+            "wav_shape": d["wav_shape"], "finite": d["finite"], "dtype": "f32 (diffusion: split-operand kernel; vocoder: split-operand convs)",
+            "vocoder_config": "assumed HiFi-GAN V1 (the reference's config.yaml is an external download)"}
 
 
 def native_fp32_line(model, inp, args, mel_split):
@@ -490,13 +591,40 @@ def bf16_loop_line(model, inp, args, ret_f32_seed0):
     mcd = max(O.mel_mcd(a[i], b[i]) for i in range(a.shape[0]))
     gbs = bytes_step / (span_ms * 1e-3) / 1e9
     tfl = (FLOP_PER_FRAME_LAYER + 2 * 512 * 192) * B_PER_GPU * T * L / (span_ms * 1e-3) / 1e12
+    from set_amd import _lib
+    fuse = int(_lib.lib().set_diffnet_layers_bf16_plan(B_PER_GPU, T, L, 1))
+    # HBM bytes per group launch from the PMC passes of THESE kernel sources (tools/gpu_pmc_bf16_layers.sh; sha256-checked like the headline's)
+    traffic, traffic_note, pmc = None, "no PMC file", None
+    tfile = os.path.join(ROOT, "profiles", "r04_pmc_bf16_layers.json")
+    if os.path.exists(tfile):
+        import hashlib
+        with open(tfile) as f:
+            tj = json.load(f)
+        h = hashlib.sha256()
+        for src in tj.get("kernel_sources", []):
+            with open(os.path.join(ROOT, src), "rb") as f:
+                h.update(f.read())
+        ent = tj.get("layers_per_launch_%d" % fuse)
+        if ent is not None and h.hexdigest() == tj.get("kernel_source_sha256"):
+            pmc = ent
+            traffic = ent.get("hbm_bytes_per_launch")
+            traffic_note = "PMC passes of this kernel build (profiles/r04_pmc_bf16_layers.json, source sha256 matches); per launch of %d layers" % fuse
+        else:
+            traffic_note = "withheld: the kernel sources changed since the PMC passes in profiles/r04_pmc_bf16_layers.json"
     return {"note": "opt-in bf16 MFMA operands in the residual layers; not the parity path, not the headline",
             "value": B_PER_GPU * T / dt, "unit": "mel-frames/s", "ms_per_step": 1e3 * dt, "dtype": "bf16 operands, f32 accumulate",
             "mcd_vs_f32_path": mcd, "max_abs_dmel_vs_f32_path": float(abs(a - b).max()),
-            "roofline": {"kernel": "diffnet_layer_fwd_bf16_kernel x %d" % L, "bound": "hbm", "achieved": gbs,
-                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                         "layers_span_ms": span_ms, "algorithmic_bytes_per_step": bytes_step,
-                         "mfma_TFLOPs": tfl, "mfma_frac_of_bf16_peak": tfl / PEAK_BF16_MFMA_TFLOPS}}
+            "roofline": {"kernel": "diffnet_layers_t128_bf16_kernel (%d residual layers per launch, %d launches per denoise step)" % (fuse, (L + fuse - 1) // fuse)
+                         if fuse >= 10 else "diffnet_layers_reg_bf16_kernel (%d residual layers per launch)" % fuse,
+                         "bound": "hbm", "achieved": gbs,
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "layers_span_ms": span_ms, "algorithmic_bytes_per_step": bytes_step, "layers_per_launch": fuse,
+                         "mfma_TFLOPs": tfl, "mfma_frac_of_bf16_peak": tfl / PEAK_BF16_MFMA_TFLOPS,
+                         "pmc_mfma_busy_frac_of_simd_cycles": pmc.get("mfma_busy_frac_of_simd_cycles") if pmc else None,
+                         "pmc_sclk_GHz": pmc.get("sclk_GHz") if pmc else None,
+                         "limit": "power (hwmon: 1.36-1.37 kW of the 1.4 kW cap at 1.9-2.0 GHz over a sustained loop of this kernel, "
+                                  "profiles/r04_power.log): time follows the energy of a layer -- without weight-fragment, LDS-fragment and "
+                                  "skip traffic the same kernel runs 28.8 instead of 40.7 us per layer (profiles/r04_t128_exp.log)"}}
 
 
 # CampNet (BASELINE configs[4]), algorithmic FLOPs of one training step per mel frame at T = 800, T_txt = 100: forward MACs =
@@ -602,7 +730,7 @@ def run_train(args, rank, world, dev):
         "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"],
         "per_rank_ms_per_step": [1e3 * s / args.steps for s in facts["per_rank_s"]],
         "allreduce_bytes_per_step": reduced, "allreduce_exposed_ms_per_step": 1e3 * exposed / args.steps,
-        "param_broadcast_bytes": bcast_bytes, "grad_elems": opt.n,
+        "param_broadcast_bytes": bcast_bytes, "grad_elems": opt.n, "grad_elems_exchanged": opt.n_exchanged,
         "loss": float(total), "lr": lr, "losses": {k: float(v) for k, v in parts.items()},
         "roofline": {"kernel": "whole training step", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                      "frac": ach / peak, "traffic": None, "flop_per_step": flop / args.steps},
@@ -621,6 +749,8 @@ def main():
     ap.add_argument("--no-native-fp32", action="store_true", help="skip the fp32-MFMA-pipe comparison run of the same loop")
     ap.add_argument("--no-bf16-loop", action="store_true", help="skip the extra (non-headline) bf16-operand loop line")
     ap.add_argument("--no-bf16x3-loop", action="store_true", help="skip the exact three-piece splitting of the same loop")
+    ap.add_argument("--no-quality", action="store_true", help="skip the MCD / max |dmel| of the shipped path against the CPU oracle")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the sub-benchmarks of BASELINE configs[1], [3], [4] (sub-processes)")
     ap.add_argument("--model", choices=("spec_denoiser", "campnet"), default="spec_denoiser",
                     help="train mode only: campnet = BASELINE configs[4] (B=16/GPU, T=800)")
     args = ap.parse_args()

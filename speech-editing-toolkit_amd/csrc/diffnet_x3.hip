@@ -49,12 +49,15 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 // debug: lane 0 of block 0 adds the s_memtime ticks of its phases (claim + wait, stage, GEMM 1, gate, GEMM 2, epilogue +
 // publish), summed over its tasks, to buf[0..5] (+ sub-phases of the gate in buf[8..10]) and its task count to buf[7]
 __device__ uint64_t *g_x3_phase_buf = nullptr;
-// The stamps are compiled in only with -DSET_X3_PROBE=1 (tools/build_exp.sh x3probe diffnet_x3.hip -DSET_X3_PROBE=1): they add to
-// counters through a generic pointer, and one flat access inside the task loop makes the wait-count pass treat every outstanding
-// load as possibly out of order -- s_waitcnt vmcnt(0) at the top of every 4-k-step group of both GEMMs, i.e. the weight ring drained
-// once per group in the PRODUCTION kernel (found in round 4 on the bf16 layer kernels, same mechanism here).
+// SET_X3_PROBE (default 1: stamps compiled in behind a run-time null pointer, as in rounds 2-3).  The stamps add to counters through
+// a generic pointer, and one flat access inside the task loop makes the wait-count pass treat every outstanding load as possibly
+// out of order (s_waitcnt vmcnt(0) at the top of every 4-k-step group of both GEMMs: the weight ring drains once per group).  Round 4
+// built the kernel without them (-DSET_X3_PROBE=0): proper vmcnt(14) / vmcnt(12) ring waits, 1.788 -> 1.763 ms per 20-layer launch
+// at B = 32, T = 800 with the clock falling from 2.00 to 1.86 GHz at 1.40 kW (the kernel is power-limited: profiles/r04_power.log) --
+// but that build FAULTED (memory access fault) at small-batch shapes (tests/test_gpu_parity.py::test_row_split_f16x2_*, B = 4
+// T = 800), not understood within the round; 1.4 % is not worth an unexplained fault, so the default stays as soaked in round 3.
 #ifndef SET_X3_PROBE
-#define SET_X3_PROBE 0
+#define SET_X3_PROBE 1
 #endif
 
 namespace {
@@ -787,7 +790,7 @@ __global__ void __launch_bounds__(256, 1) diffnet_stack_split_x2_kernel(SetDiffn
     unsigned short *zt = reinterpret_cast<unsigned short *>(a.z_ws) + (int64_t)i * (2 * 32 * XC);  // [piece][frame][256]
     const rsrc_t rz = make_rsrc(zt);
     const rsrc_t rsk = make_rsrc(a.skip + (int64_t)b * XC * T);
-    uint64_t *dbg = (SET_X3_PROBE && blockIdx.x == 5 && tid == 0) ? g_x3_phase_buf : nullptr;  // debug: phase ticks of one block, see below
+    uint64_t *dbg = (blockIdx.x == 5 && tid == 0) ? g_x3_phase_buf : nullptr;  // debug: phase ticks of one block, see below
     uint64_t tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
 #define SX_PHASE(p)                                           \
     if (dbg) {                                                \

@@ -192,7 +192,7 @@ def _check_two_ranks(res):
         assert r["n_buckets"] >= 3 and sorted(b for b, _ in r["log"]) == list(range(r["n_buckets"]))
         assert sum(1 for _, why in r["log"] if why == "hook") >= 2   # launched during backward
         assert r["launch_before_late"], "no all-reduce was in flight before backward reached its last module"
-        assert r["reduced"] == 4 * r["n_exchanged"] and r["n_exchanged"] < r["n"]  # fs.decoder / fs.mel_out (never reached by a loss) are not sent
+        assert r["reduced"] == 4 * r["n_exchanged"] and r["n_exchanged"] <= r["n"]  # spec_denoiser: fs.decoder / fs.mel_out (never reached by a loss) are not sent
     assert r0["log"] == r1["log"]                          # same launch order on both ranks (no deadlock by construction)
     assert abs(0.5 * (r0["loss_local"] + r1["loss_local"]) - r0["loss_full"]) < 1e-4 * abs(r0["loss_full"])
 
