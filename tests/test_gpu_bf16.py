@@ -445,7 +445,35 @@ def test_bf16_inference_loop_tolerance(dev):
         worst[name] = (mcd, float(np.abs(mel - g["mel_out"]).max()))
         assert torch.equal(ret["mel2ph"].cpu(), torch.from_numpy(g["mel2ph"]))  # integer bookkeeping is untouched
     print("bf16 loop vs reference mel: %s" % {k: "mcd %.4f max|d| %.4f" % v for k, v in worst.items()})
-    assert max(v[0] for v in worst.values()) < 0.5
+    assert max(v[0] for v in worst.values()) < 0.20  # SURVEY.md 8(d)'s bar for a bf16 path (measured 0.05-0.06)
+
+
+def test_bf16_inference_loop_quality_at_the_benchmark_size(dev):
+    """the quality bar of the bf16-operand loop where it is tight -- B = 32, T = 800, 100 reverse steps, on-device
+    Philox noise, the benchmark's random-init weights: mel-level MCD against the fp32 path on the same inputs and noise < 0.20
+    (measured 0.179) and max |dmel| < 0.05 (0.026).  The loop runs ten residual layers per launch on 128-frame tiles here."""
+    import bench
+    from set_amd import _lib, ops
+    from set_amd.synthetic import synthetic_inputs
+    model = bench.build_model(dev, 100)
+    inp = {k: v.to(dev) for k, v in synthetic_inputs(32, 800, 100, seed=1234).items()}
+
+    def run():
+        with torch.no_grad():
+            return model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"], inp["uv"],
+                         infer=True, seed=0)["mel_out"].float().cpu().numpy()
+    assert int(_lib.lib().set_diffnet_layers_bf16_plan(32, 800, 20, 1)) == 10
+    ref = run()
+    ops.set_compute_dtype("bf16")
+    try:
+        got = run()
+    finally:
+        ops.set_compute_dtype("f32")
+    assert np.isfinite(got).all()
+    mcd = max(O.mel_mcd(got[b], ref[b]) for b in range(got.shape[0]))
+    dmax = float(np.abs(got - ref).max())
+    print("bf16 loop vs fp32 path at B=32, T=800, 100 steps: mcd %.4f max|d| %.4f" % (mcd, dmax))
+    assert mcd < 0.20 and dmax < 0.05
 
 
 def test_batch_repack_equals_per_weight_packs(dev):
