@@ -680,7 +680,7 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
         dd = torch.empty(B, L_ * C_, dtype=torch.float32, device=dev)
         # Weight gradients of ALL layers in three grouped launches after the sweep (dy / d_o of every layer are kept: 2 x L x 26 MB
         # at B = 32, T = 800) when the layers share one dilation; else three GEMMs per layer inside the sweep.
-        grouped = len({layer.dilation for layer in layers}) == 1 and os.environ.get("SET_AMD_GROUPED_WGRAD", "1") != "0"
+        grouped = len({layer.dilation for layer in layers}) == 1
         # the grouped form keeps dy / d_o of ALL layers alive (2 x L x B x 2C x T bf16: ~1 GB at L = 20, B = 32, T = 800, next to x_all,
         # y16, z16); beyond a budget (SET_AMD_GROUPED_WGRAD_MB, default 4096 MB -- 1.4 % of the 288 GB) it falls back to the per-layer form
         if grouped and 2 * L_ * B * 2 * C_ * T * 2 > float(os.environ.get("SET_AMD_GROUPED_WGRAD_MB", "4096")) * 2 ** 20:

@@ -926,24 +926,20 @@ int set_conv1d_bf16_dispatch(const SetConv1dArgs &a, hipStream_t s) {
     // that height (CampNet's 192-channel projections at 12,800 frames) wait on their input, not on MFMAs: 27 -> 22 us (192 -> 192),
     // 56 -> 45 us (768 -> 192) with 128-row blocks; the 9-tap convs keep the 64-row ones (146 vs 149 us)
     const bool narrow = a.Cout <= 64 || (a.Cout > 128 && a.Cout <= 192 && a.K > 1);
-    static int oneshot = -1;
-    if (oneshot < 0) { const char *e = getenv("SET_AMD_BF16_ONESHOT"); oneshot = e ? atoi(e) : 1; }
-    if (oneshot && a.K == 1 && a.Cin > 32 && a.Cout > 64 && halo == 0 && !a.in_chan_add && a.pad == 0) {
+    if (a.K == 1 && a.Cin > 32 && a.Cout > 64 && halo == 0 && !a.in_chan_add && a.pad == 0) {
         const int cp = round_up_i(a.Cin, 32);
         if (cp <= 64) return launch_conv1x1_oneshot<64>(a, s);
         if (cp <= 128) return launch_conv1x1_oneshot<128>(a, s);
         if (cp <= 192) return launch_conv1x1_oneshot<192>(a, s);
-        if (oneshot == 1 || cp <= 256) return launch_conv1x1_oneshot<256>(a, s);  // wider inputs: chunks of 256 channels (SET_AMD_BF16_ONESHOT=2: staged kernel)
+        return launch_conv1x1_oneshot<256>(a, s);  // wider inputs: chunks of 256 channels
     }
     if (a.K == 1 && a.Cin > 32 && halo == 0 && !a.in_chan_add) {
         return narrow ? launch_conv_bf16<1, 4, 64, 1, false, false>(a, lo, halo, s)
                       : launch_conv_bf16<2, 2, 64, 1, false, false>(a, lo, halo, s);
     }
-    static int tgm = 0;
-    if (!tgm) { const char *e = getenv("SET_AMD_BF16_TGM"); tgm = e ? atoi(e) : 5; }
     // taps per stage: 5 and 9 taps (the predictor / FFN convs) are 1 and 2 stages per 32-channel chunk with 5 taps per stage, 2 and 3
     // with 4 -- these convs wait on their stage round trips, not on MFMAs (tools/small_conv_probe.py)
-    if (tgm == 5 && (a.K == 5 || a.K > 8))
+    if (a.K == 5 || a.K > 8)
         return narrow ? launch_conv_bf16<1, 4, 32, 5, true, true>(a, lo, halo, s) : launch_conv_bf16<2, 2, 32, 5, true, true>(a, lo, halo, s);
     return narrow ? launch_conv_bf16<1, 4, 32, 4, true, true>(a, lo, halo, s)
                   : launch_conv_bf16<2, 2, 32, 4, true, true>(a, lo, halo, s);
@@ -974,15 +970,12 @@ static int wgrad_bf16_slices(int B, int Cin, int Cout, int K, int T, bool taps3 
 // all-taps kernel (conv1d_wgrad_taps_bf16_kernel): K = 5, 7, 9, dilation 1, "same" (pad = (K - 1) / 2) or causal (pad = K - 1)
 // padding, fp32 operands, no per-channel add
 static bool wgrad_taps_applies(int K, int dil, int pad, int dtype, bool chan_add) {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("SET_AMD_WGRAD_TAPS"); on = !(e && atoi(e) == 0); }
-    return on && dtype == SET_DTYPE_BF16 && !chan_add && (K == 5 || K == 7 || K == 9) && dil == 1 && (pad == (K - 1) / 2 || pad == K - 1);
+    return dtype == SET_DTYPE_BF16 && !chan_add && (K == 5 || K == 7 || K == 9) && dil == 1 && (pad == (K - 1) / 2 || pad == K - 1);
 }
 static int wgrad_taps_slices(int B, int Cin, int Cout, int T) {
     const int64_t total_chunks = (int64_t)B * ((T + WGB_KT - 1) / WGB_KT);
     const int tiles = ((Cin + 63) / 64) * ((Cout + 63) / 64);
-    static int target = 0;
-    if (!target) { const char *e = getenv("SET_AMD_WGRAD_TAPS_BLOCKS"); target = e && atoi(e) > 0 ? atoi(e) : 512; }
+    const int target = 512;
     int64_t S = (target + tiles - 1) / tiles;  // two blocks per CU; every slice costs a K-tap partial image (write + read)
     if (S > total_chunks) S = total_chunks;
     if (S > 16) S = 16;
@@ -998,8 +991,7 @@ static int wgrad_bf16_slices_grouped(int B, int Cin, int Cout, int K, int T, boo
     const int64_t tiles = (int64_t)groups * (taps3 ? ((Cin + 63) / 64) * ((Cout + 127) / 128) : K * ((Cin + 127) / 128) * ((Cout + 127) / 128));
     // blocks of a grouped launch are long (each walks 1 / S of ALL frames): aim at ~2.5 full waves of the chip's 512 block slots,
     // not at the 2.5 blocks per CU of a single GEMM (measured, ms per bf16 training step: 640 blocks 15.75, 1280 15.16, 2048 15.29, 4096 15.39)
-    static int target = 0;
-    if (!target) { const char *e = getenv("SET_AMD_WGRAD_GROUP_BLOCKS"); target = e && atoi(e) > 0 ? atoi(e) : 1280; }
+    const int target = 1280;
     int64_t S = (target + tiles - 1) / tiles;
     if (S > total_chunks) S = total_chunks;
     if (S > (taps3 ? 32 : 64)) S = taps3 ? 32 : 64;

@@ -1175,7 +1175,6 @@ extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) 
     // (T even) and at most once per tile (T >= 64): B*T/64 tiles instead of B*ceil(T/64) (T = 800: 400 vs 416).
     bool concat = wino && a.dilation_cycle_length == 1 && a.T % 2 == 0 && a.T >= WN_NT &&
                   (int64_t)a.cp_bs * 4 < (1ll << 31) && a.d_bs == 0 && !a.save_y && !a.save_z;
-    if (const char *e = getenv("SET_AMD_CONCAT")) concat = concat && atoi(e) != 0;
     if (concat) {
         ntiles = (int)(((int64_t)a.B * a.T + WN_NT - 1) / WN_NT);
         tiles_per_utt = ntiles;  // one chain of tiles: neighbours are i-1 / i+1 everywhere

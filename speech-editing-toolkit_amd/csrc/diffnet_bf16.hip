@@ -440,8 +440,9 @@ struct LayersArgs {
 //   * GEMM 1 is ONE 60-k-step stream (12 conditioner + 3 x 16 tap k-steps; the ring of PFD k-steps never drains between the
 //     conditioner and the taps);
 //   * the biases of every fused layer are staged in LDS once per launch (they were 96 dependent 4-byte L2 loads per wave and layer);
-//   * SKEW: waves 0-3 (one per SIMD; wave w and w + 4 share a SIMD) run at a higher static priority than waves 4-7, so the two
-//     waves of a SIMD drift half a phase apart: the first one's gate / epilogue VALU work runs under the second one's MFMAs.
+//   * SKEW (template parameter, not instantiated in the shipped library): a static priority for waves 0-3 (wave w and w + 4 share a
+//     SIMD) instead of the per-k-step toggles.  Measured both ways round (priority to the older / to the younger half): the favoured
+//     half leaves GEMM 1 after 54 % of a layer and waits at the barrier, the other after 69 %; the layer takes the same time.
 // Same arithmetic per frame as diffnet_layer_fwd_bf16_kernel (same images, k order, accumulator start, rounding points): bit-identical.
 // =====================================================================================================================
 // acc[2][2] += A B over NKS k-steps in groups of 4; the ring A[4 D][2] holds k-steps 0 .. 4 D - 1 on entry (gemm_reg_prefetch) and is
@@ -1478,11 +1479,8 @@ static int layers_halo(int l0, int nl, int dcl) {
     for (int m = 1; m < nl; ++m) h += 1 << ((l0 + m) % dcl);
     return h;
 }
-// measurement / test switches, read at every launch: SET_AMD_BF16_FUSE_TILE = 64 | 128 forces the tile width (default: by occupancy);
-// SET_AMD_BF16_REG_VARIANT bit 0 = static priority skew (both shapes), bit 1 = A ring of GEMM 1 8 k-steps deep (64-frame shape) /
-// B fragments of GEMM 1 double-buffered (128-frame shape)
+// test switch, read at every launch: SET_AMD_BF16_FUSE_TILE = 64 | 128 forces the tile width (default: by occupancy, layers_pick_tile)
 static int layers_tile_env() { const char *e = getenv("SET_AMD_BF16_FUSE_TILE"); const int t = e ? atoi(e) : 0; return (t == 64 || t == 128) ? t : 0; }
-static int layers_reg_variant() { const char *e = getenv("SET_AMD_BF16_REG_VARIANT"); return e ? atoi(e) & 3 : 0; }
 
 extern "C" int64_t set_sizeof_diffnet_layers_bf16_args(void) { return (int64_t)sizeof(SetDiffnetLayersBf16Args); }
 
@@ -1553,32 +1551,18 @@ extern "C" int set_diffnet_layers_fwd_bf16(const SetDiffnetLayersBf16Args *args,
     if (ldsz > 160 * 1024) return set_fail(SET_E_UNSUPPORTED, "set_diffnet_layers_fwd_bf16", "tiles do not fit LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        const void *ks[] = {reinterpret_cast<const void *>(diffnet_layers_reg_bf16_kernel<false, 4>), reinterpret_cast<const void *>(diffnet_layers_reg_bf16_kernel<true, 4>),
-                            reinterpret_cast<const void *>(diffnet_layers_reg_bf16_kernel<false, 8>), reinterpret_cast<const void *>(diffnet_layers_reg_bf16_kernel<true, 8>),
-                            reinterpret_cast<const void *>(diffnet_layers_t128_bf16_kernel<false, 0>), reinterpret_cast<const void *>(diffnet_layers_t128_bf16_kernel<false, 1>),
-                            reinterpret_cast<const void *>(diffnet_layers_t128_bf16_kernel<false, 2>), reinterpret_cast<const void *>(diffnet_layers_t128_bf16_kernel<false, 3>),
-                            reinterpret_cast<const void *>(diffnet_layers_t128_bf16_kernel<false, 4>)};
+        const void *ks[] = {reinterpret_cast<const void *>(diffnet_layers_reg_bf16_kernel<false, 4>),
+                            reinterpret_cast<const void *>(diffnet_layers_t128_bf16_kernel<false, 1>)};
         for (const void *k : ks) SET_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layers bf16 attr");
         attr_set = true;
     }
     dim3 grid((a.T + la.nv - 1) / la.nv, a.B);
-    const int v = layers_reg_variant();
-    if (tile == 128) {
-        int nskr = 1;  // measured (B = 32, T = 800, 10 layers per launch, sustained): 0: 40.7, 1: 39.4, 2: 39.6, 3: 39.8, 4: 41.8 us per layer (21 / 45 / 67 spilled registers from 2 on)
-        if (const char *e = getenv("SET_AMD_BF16_T128_NSKR")) nskr = atoi(e);
-        switch (nskr) {
-            case 0: hipLaunchKernelGGL((diffnet_layers_t128_bf16_kernel<false, 0>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
-            default: hipLaunchKernelGGL((diffnet_layers_t128_bf16_kernel<false, 1>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
-            case 3: hipLaunchKernelGGL((diffnet_layers_t128_bf16_kernel<false, 3>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
-            case 4: hipLaunchKernelGGL((diffnet_layers_t128_bf16_kernel<false, 4>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
-            case 2: hipLaunchKernelGGL((diffnet_layers_t128_bf16_kernel<false, 2>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
-        }
-    } else switch (v) {
-        case 0: hipLaunchKernelGGL((diffnet_layers_reg_bf16_kernel<false, 4>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
-        case 1: hipLaunchKernelGGL((diffnet_layers_reg_bf16_kernel<true, 4>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
-        case 2: hipLaunchKernelGGL((diffnet_layers_reg_bf16_kernel<false, 8>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
-        default: hipLaunchKernelGGL((diffnet_layers_reg_bf16_kernel<true, 8>), grid, dim3(512), ldsz, (hipStream_t)stream, la); break;
-    }
+    // Shipped instantiations only.  Measured in round 4 and left out (B = 32, T = 800, sustained us per layer; profiles/r04_bf16_ab.log):
+    // 128-frame shape with 0 / 1 / 2 / 3 / 4 column blocks of the skip rows in registers 40.7 / 39.4 / 39.6 / 39.8 / 41.8 (21 / 45 / 67
+    // spilled registers from 2 on); 64-frame shape with a static priority for one half of the waves instead of the k-step toggles and / or
+    // a ring of 8 k-steps: within 0.5 % of the shipped one.
+    if (tile == 128) hipLaunchKernelGGL((diffnet_layers_t128_bf16_kernel<false, 1>), grid, dim3(512), ldsz, (hipStream_t)stream, la);
+    else hipLaunchKernelGGL((diffnet_layers_reg_bf16_kernel<false, 4>), grid, dim3(512), ldsz, (hipStream_t)stream, la);
     return set_check_launch("set_diffnet_layers_fwd_bf16");
 }
 

@@ -646,12 +646,6 @@ int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_
     if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
     if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
     if (grid < 1) grid = 1;
-    if (getenv("SET_AMD_X3_DEBUG")) {
-        int nb = -1;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(diffnet_stack_x3_kernel<S, NU, NCB>), 512 / NU, ldsz);
-        fprintf(stderr, "[set_amd] x3 kernel NU=%d NCB=%d: grid %d x %d threads, %zu B LDS, %d resident blocks per CU, %d tiles\n", NU, NCB,
-                grid, 512 / NU, ldsz, nb, ntiles);
-    }
     hipLaunchKernelGGL((diffnet_stack_x3_kernel<S, NU, NCB>), dim3(grid), dim3(512 / NU), ldsz, s, a, tiles_per_utt, ntiles, (int)ntasks64,
                        piece_bytes, fault_tile);
     return set_check_launch("set_diffnet_stack");
@@ -987,16 +981,14 @@ int set_launch_diffnet_stack_split_x2(const SetDiffnetStackArgs &a, int fault_ti
     // 8 L2-warmer blocks (one per XCD) when the chip has CUs to spare and the block -> XCD round-robin lines them up with the parts
     static int warm = -1, n_cu = 0;
     if (warm < 0) {
-        const char *e = getenv("SET_AMD_SPLIT_WARMERS");
-        warm = !(e && atoi(e) == 0);
+        warm = 1;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 0;
     }
     const int extra = (warm && 4 * nt + 8 <= n_cu && a.L > 1) ? 8 : 0;  // (block q: XCD q % 8, part q & 3 = (q % 8) & 3 -- consistent)
-    // agent-scope loads for the tiles other blocks produced instead of an acquire fence after each wait (SET_AMD_SPLIT_NOFENCE=0: the
-    // fences): 62.7 -> 61.4 ms per 100 steps at B = 1, 66.9 -> 62.3 at B = 2 (T = 800), bit-identical either way
-    static int nofence = -1;
-    if (nofence < 0) { const char *e = getenv("SET_AMD_SPLIT_NOFENCE"); nofence = e ? atoi(e) != 0 : 1; }
+    // agent-scope loads for the tiles other blocks produced instead of an acquire fence after each wait (measured in round 3 against
+    // the fences: 62.7 -> 61.4 ms per 100 steps at B = 1, 66.9 -> 62.3 at B = 2 (T = 800), bit-identical either way)
+    const int nofence = 1;
     hipLaunchKernelGGL(diffnet_stack_split_x2_kernel, dim3(4 * nt + extra), dim3(256), ldsz, s, a, tiles, nt, piece_bytes, fault_tile, nofence);
     return set_check_launch("set_diffnet_stack");
 }

@@ -397,8 +397,7 @@ extern "C" int set_resblock_pair_x2_supported(int32_t C, int32_t K, int32_t dil,
     // up to 128 channels a block holds a 128- or 256-frame tile; 129 .. 256 channels only fit 64-frame tiles, of which
     // K - 1 columns are recomputed by the neighbours: measured (B = 64, C = 256, T = 6400, three pairs) 3.54 vs 4.38 ms for
     // K = 3, 6.62 vs 6.73 for K = 7, 10.64 vs 9.17 for K = 11 -> fused up to 5 taps only
-    int max_c = 256;
-    if (const char *e = getenv("SET_AMD_RESBLOCK_FUSED_MAXC")) max_c = atoi(e);
+    const int max_c = 256;
     if (C > 128 && K > 5) return SET_E_UNSUPPORTED;
     if (C < 16 || C > max_c || C > 256 || K < 3 || (K & 1) == 0 || K > 15 || dil < 1 || dil * (K - 1) > 128 || T < 64) return SET_E_UNSUPPORTED;
     return SET_OK;

@@ -907,15 +907,11 @@ static void wgrad_f32_plan(WgradArgs &a, bool for_atomics) {
     // address serialise at the memory side -- ~2.5 blocks per CU beat 8 (swept: 2048 -> 637, 1024 -> 659, 512 -> 663,
     // 256 -> 616 training samples/s)
     int target_blocks = 640;
-    if (for_atomics)
-        if (const char *e = getenv("SET_AMD_WGRAD_BLOCKS")) target_blocks = atoi(e) > 0 ? atoi(e) : target_blocks;
     int slices = (target_blocks + tiles - 1) / tiles;
     if (slices > total) slices = total;
     if (slices < 1) slices = 1;
     // one XCD per slice needs a multiple of 8 slices (the padding slices, if any, exit at once)
     bool xcd_map = slices >= 8;
-    if (for_atomics)
-        if (const char *e = getenv("SET_AMD_WGRAD_XCD")) xcd_map = xcd_map && atoi(e) != 0;
     if (xcd_map) slices = (slices + 7) / 8 * 8 <= total ? (slices + 7) / 8 * 8 : slices / 8 * 8;
     a.chunks_per_slice = (total + slices - 1) / slices;
     slices = (total + a.chunks_per_slice - 1) / a.chunks_per_slice;

@@ -891,11 +891,10 @@ def default_persistent():
 
 
 def default_groups(B, T):
-    """Utterance groups for the reverse loop (SET_AMD_GROUPS overrides).  Measured on MI355X (profiles/): more than
+    """Utterance groups for the reverse loop (callers may pass groups= themselves).  Measured on MI355X (profiles/): more than
     one group is slower -- kernels from different streams are placed on the same CUs first, so the per-CU imbalance
     of a 416-block launch gets worse, not better -- hence 1.  Grouping never changes results."""
-    env = os.environ.get("SET_AMD_GROUPS")
-    return max(1, int(env)) if env else 1
+    return 1
 
 
 # --------------------------------------------------------------------------

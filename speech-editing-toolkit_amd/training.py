@@ -52,7 +52,7 @@ class FlatAdamW:
         # (every conv / linear here) is written directly; autograd still fires its post-accumulate hook when the backward
         # function returns (None gradient), which launches the bucket.  Parameters used several times per step keep the
         # autograd path (the hook then fires once, after the last use).
-        self.direct = os.environ.get("SET_AMD_DIRECT_GRADS", "1") == "1"
+        self.direct = True
         self.in_step, self._learned, self._uses = False, False, {}
         for p in self.params:
             p._flat_owner = self

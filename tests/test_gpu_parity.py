@@ -609,11 +609,10 @@ def test_x3_stack_tile_widths_agree_bit_for_bit(dev, monkeypatch, x3_mode):
 
 
 @pytest.mark.parametrize("x3_mode", [2, 3])
-def test_x3_stack_block_shapes_agree_bit_for_bit(dev, monkeypatch, x3_mode):
-    """Two 4-wave blocks per CU (each wave owns 64 gate + 64 filter rows; the partner block's GEMMs cover this block's
-    staging / gate / epilogue) against one 8-wave block per CU: the same images, the same products in the same order per
-    accumulator -- bit-identical, for both tile widths, ragged lengths, utterance boundaries inside a tile, several worker
-    counts (the dependency protocol must hold with two blocks per CU and with more workers than CUs)."""
+def test_x3_stack_worker_counts_agree_bit_for_bit(dev, monkeypatch, x3_mode):
+    """The persistent split-operand kernel with its default worker count against 7 workers and 512 workers (more workers than
+    CUs): the same images, the same products in the same order per accumulator -- bit-identical, for both tile widths, ragged
+    lengths and utterance boundaries inside a tile (the dependency protocol must not depend on who runs which task)."""
     from set_amd import ops
     monkeypatch.setenv("SET_AMD_X3", "2")
     monkeypatch.setenv("SET_AMD_SPLIT", "0")
@@ -622,8 +621,7 @@ def test_x3_stack_block_shapes_agree_bit_for_bit(dev, monkeypatch, x3_mode):
         x0, cp, dtab, packs, wds, wos, bd, bo = _random_stack(dev, B, T, L, B * 100 + T + 11, x3_mode)
         monkeypatch.setenv("SET_AMD_X3_TILE", tile)
         outs = []
-        for waves, grid in (("8", None), ("4", None), ("4", "7"), ("4", "512")):
-            monkeypatch.setenv("SET_AMD_X3_WAVES", waves)
+        for grid in (None, "7", "512"):
             if grid is None:
                 monkeypatch.delenv("SET_AMD_STACK_GRID", raising=False)
             else:
@@ -635,7 +633,7 @@ def test_x3_stack_block_shapes_agree_bit_for_bit(dev, monkeypatch, x3_mode):
             outs.append(((xb if L % 2 else xa).clone(), skip.clone()))
         for o in outs[1:]:
             assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]), (B, T)
-    for k in ("SET_AMD_X3_TILE", "SET_AMD_X3_WAVES", "SET_AMD_STACK_GRID"):
+    for k in ("SET_AMD_X3_TILE", "SET_AMD_STACK_GRID"):
         monkeypatch.delenv(k, raising=False)
 
 

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical: SET_AMD_BF16_REG_VARIANT / SET_AMD_BF16_T128_NSKR were round-4 measurement switches; the shipped library keeps only the chosen instantiations,
+#  the logs are profiles/r04_bf16_ab.log and profiles/r04_t128_exp.log)
 # round 4: A/B of the fused-layers kernels at B = 32, T = 800: SET_AMD_BF16_FUSE_TILE = 64 | 128 (tile width), SET_AMD_BF16_REG_VARIANT bit 0 =
 # static priority skew, bit 1 = A ring of 8 k-steps (64-frame shape) / double-buffered B fragments in GEMM 1 (128-frame shape):
 # bit-identity tests, time per group launch + phase shares

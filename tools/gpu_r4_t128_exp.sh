@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical: SET_AMD_BF16_REG_VARIANT / SET_AMD_BF16_T128_NSKR were round-4 measurement switches; the shipped library keeps only the chosen instantiations,
+#  the logs are profiles/r04_bf16_ab.log and profiles/r04_t128_exp.log)
 # round 4: where the time of the 128-frame fused-layers kernel goes -- measurement builds (tools/build_exp.sh t128eN diffnet_bf16.hip
 # -DSET_T128_EXP=N; bit 0: no weight-fragment refills, bit 1: no B-fragment reads, bit 2: no skip traffic between the layers, bit 3: plain
 # instead of streaming accesses of the private skip copy) next to the product build
