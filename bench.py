@@ -233,11 +233,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def stub_device():
+    """Test hook (tests/test_dist_gloo.py): SET_AMD_BENCH_STUB_DEVICE=cpu runs `--mode train` with NO kernels -- a toy torch-CPU
+    module stands in for the task, gloo for RCCL -- so that the self-launch, rendezvous, rank-0 broadcast, sharding, hook-launched
+    bucket all-reduce, barrier / max-over-ranks timing and the rank-0 JSON line can be driven end to end on a box without GPUs.
+    The line it prints says so ("device": "cpu-stub", "value" is not a measurement of this framework)."""
+    return os.environ.get("SET_AMD_BENCH_STUB_DEVICE", "") == "cpu"
+
+
+def _sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
 def maybe_self_launch(args):
     """`python bench.py --gpus N` from a bare shell: start N ranks (one per GPU) and hand over to them."""
     if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return
-    n_dev = torch.cuda.device_count()
+    n_dev = args.gpus if stub_device() else torch.cuda.device_count()
     if n_dev < args.gpus:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible -- refusing to report a %d-GPU number from fewer "
                          "devices" % (args.gpus, n_dev, args.gpus))
@@ -357,7 +370,7 @@ def run_infer(args, rank, world, dev):
                                "BASELINE configs[1]); on-device Philox noise",
                    "B_per_gpu": B_PER_GPU, "T": T, "T_txt": T_TXT, "denoise_steps": DIFF_STEPS,
                    "sharding": "utterances r::N, no collective"},
-        "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"],
+        "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"], "replicas_identical_after_steps": same_after,
         "per_rank_ms_per_step": [1e3 * s / args.steps for s in facts["per_rank_s"]],
         # achieved = MFMA FLOPs the dominant kernel issues per launch / its mean launch duration, against the dense peak of
         # the pipe it issues them on; algorithmic_* = the fp32 FLOPs of the layer math (conditioner
@@ -634,13 +647,60 @@ CAMPNET_B_PER_GPU = 16
 CAMPNET_TRAIN_FLOP_PER_FRAME = 3 * 2 * (15.30e6 + 5.89e6 * T_TXT / T + 6 * (2 * T + 2 * T_TXT) * 192)
 
 
-def run_train(args, rank, world, dev):
-    """--model spec_denoiser: BASELINE configs[1] (1 GPU) / configs[2] (8 GPUs, B=256 global); --model campnet: configs[4]
-    (CampNet masked-mel transformer, B=16 per GPU = egs/campnet.yaml max_sentences).  One optimisation step of the task
-    under the reference's DDP set-up (barrier, rank-0 broadcast, barrier; bucketed gradient all-reduce from autograd hooks)."""
+class _StubTask:
+    """Stands in for the task when SET_AMD_BENCH_STUB_DEVICE=cpu: two top-level modules (so that the bucketer has a module boundary
+    to respect) and one the loss never reaches (so that the exchanged prefix is shorter than the buffer)."""
+
+    def __init__(self):
+        class Net(torch.nn.Module):
+            unused_parameter_prefixes = ("dead.",)
+
+            def __init__(self):
+                super().__init__()
+                self.front = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64))
+                self.back = torch.nn.Sequential(torch.nn.Tanh(), torch.nn.Linear(64, 8))
+                self.dead = torch.nn.Linear(8, 8)
+
+            def forward(self, x):
+                return self.back(self.front(x))
+        self.model = Net()
+
+
+def _stub_step_fn(task, opt):
+    """zero_grad -> backward (bucket all-reduces launch from the autograd hooks) -> finish -> SGD on the mean gradient, in torch."""
+    class Step:
+        eager_steps, replays = 0, 0
+
+        @staticmethod
+        def usable():
+            return False
+
+        def __call__(self, sample, seed):
+            opt.zero_grad()
+            loss = (task.model(sample["x"]) - sample["y"]).pow(2).mean()
+            loss.backward()
+            world = opt.bucketer.finish()
+            opt.in_step = False
+            lr = opt.lr_at(opt.num_updates)
+            opt.num_updates += 1
+            with torch.no_grad():
+                opt.flat_p.add_(opt.flat_g, alpha=-lr / world)
+            return loss.detach(), {"mse": loss.detach()}, lr
+    return Step()
+
+
+def _train_setup(args, rank, world, dev):
+    """(task, optimizer, this rank's sample, step function, utterances per GPU) of --mode train."""
     from set_amd import hparams as HP, ops, parallel, tasks
     from set_amd.synthetic import synthetic_inputs
-    from set_amd.training import FlatAdamW
+    from set_amd.training import FlatAdamW, GraphedTrainStep
+    if stub_device():
+        torch.manual_seed(1234 + rank)
+        task = _StubTask()
+        opt = FlatAdamW(task.model, lr=1e-2, warmup_updates=0, bucket_mb=4e-3)
+        g = torch.Generator().manual_seed(7)
+        full = {"x": torch.randn(8 * world, 16, generator=g), "y": torch.randn(8 * world, 8, generator=g)}
+        return task, opt, parallel.shard_batch(full, rank, world), _stub_step_fn(task, opt), 8
     campnet = args.model == "campnet"
     bpg = CAMPNET_B_PER_GPU if campnet else B_PER_GPU
     HP.hparams.clear()
@@ -666,13 +726,6 @@ def run_train(args, rank, world, dev):
     task.model.to(dev).train()
     opt = FlatAdamW(task.model, lr=HP.hparams["lr"], betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=1.0,
                     warmup_updates=8000)
-    bcast_bytes = parallel.configure_ddp(task.model, opt)  # barrier, rank-0 broadcast, barrier
-    if world > 1:  # replicas identical now?
-        chk = opt.flat_p.double().sum().reshape(1)
-        lo, hi = chk.clone(), chk.clone()
-        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
-        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-        assert float(lo) == float(hi), "parameter broadcast left the replicas different"
     full = synthetic_inputs(bpg * world, T, T_TXT, seed=1234, pad_tail=True)
     inp = {k: v.to(dev) for k, v in parallel.shard_batch(full, rank, world).items()}
     if campnet:
@@ -683,11 +736,26 @@ def run_train(args, rank, world, dev):
                       time_mel_masks=inp["time_mel_masks"].squeeze(-1).contiguous(), spk_embed=inp["spk_embed"])
     # one captured HIP graph per batch shape (training.GraphedTrainStep: eager for the first steps, with more than one rank and
     # under SET_AMD_GRAPH_STEP=0); the timed steps below are replays when the warm-up was long enough to capture
-    from set_amd.training import GraphedTrainStep
-    step_fn = GraphedTrainStep(task, opt)
+    return task, opt, sample, GraphedTrainStep(task, opt), bpg
+
+
+def run_train(args, rank, world, dev):
+    """--model spec_denoiser: BASELINE configs[1] (1 GPU) / configs[2] (8 GPUs, B=256 global); --model campnet: configs[4]
+    (CampNet masked-mel transformer, B=16 per GPU = egs/campnet.yaml max_sentences).  One optimisation step of the task
+    under the reference's DDP set-up (barrier, rank-0 broadcast, barrier; bucketed gradient all-reduce from autograd hooks)."""
+    from set_amd import parallel
+    campnet = args.model == "campnet"
+    task, opt, sample, step_fn, bpg = _train_setup(args, rank, world, dev)
+    bcast_bytes = parallel.configure_ddp(task.model, opt)  # barrier, rank-0 broadcast, barrier
+    if world > 1:  # replicas identical now?
+        chk = opt.flat_p.double().sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        assert float(lo) == float(hi), "parameter broadcast left the replicas different"
     for w in range(max(args.warmup, step_fn.eager_steps + 2) if step_fn.usable() else args.warmup):
         step_fn(sample, seed=100 + w)
-    torch.cuda.synchronize()
+    _sync(dev)
     parallel.barrier()
     exposed, reduced, enqueue = 0.0, 0, 0.0
     replays0 = step_fn.replays
@@ -698,12 +766,20 @@ def run_train(args, rank, world, dev):
         enqueue += time.perf_counter() - t1  # host time to ENQUEUE the step (no synchronisation inside)
         exposed += opt.bucketer.exposed_s
         reduced = opt.bucketer.bytes_reduced
-    torch.cuda.synchronize()
+    _sync(dev)
     elapsed = time.perf_counter() - t0
     parallel.barrier()
     t_max = parallel.max_over_ranks(elapsed, device=dev if world > 1 else "cpu")
     facts = dist_facts(dev, world, elapsed)
     assert torch.isfinite(total).all()
+    same_after = True
+    if world > 1:  # every rank applied the same all-reduced gradient to the same weights: the replicas must still be bit-identical
+        chk = opt.flat_p.double().sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        same_after = float(lo) == float(hi)
+        assert same_after, "the replicas diverged during the timed steps"
     n_samples = bpg * world * args.steps
     flop = (CAMPNET_TRAIN_FLOP_PER_FRAME if campnet else TRAIN_FLOP_PER_FRAME) * bpg * T * args.steps  # per rank
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
@@ -718,22 +794,25 @@ def run_train(args, rank, world, dev):
         workload = ("FluentSpeech spec_denoiser training step (conditioner + one DiffNet pass + l1/ssim/dur/"
                     "pitch losses + backward + gradient all-reduce + clip + AdamW), synthetic 80-mel T=800 "
                     "batches, B=32 per GPU (BASELINE configs[1]; configs[2] at 8 GPUs = 256 global)")
+    if stub_device():
+        metric = "STUB (toy torch-CPU module over gloo: exercises bench.py's launch / exchange / timing path, measures nothing of this framework)"
+        workload = "stub"
     return {
-        "metric": metric, "value": n_samples / t_max, "unit": "samples/s",
+        "metric": metric, "value": n_samples / t_max, "unit": "samples/s", **({"device": "cpu-stub"} if stub_device() else {}),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_max / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": workload,
                    "B_per_gpu": bpg, "T": T, "T_txt": T_TXT, "sharding": "utterances r::N, gradient all-reduce (SUM, "
                    "1/N folded into AdamW) in %d buckets" % max(1, len(opt.bucketer.buckets))},
-        "frames_per_s": n_samples * T / t_max, "host_enqueue_ms_per_step": 1e3 * enqueue / args.steps,
+        "frames_per_s": None if stub_device() else n_samples * T / t_max, "host_enqueue_ms_per_step": 1e3 * enqueue / args.steps,
         "graph_replays": step_fn.replays - replays0,
-        "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"],
+        "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"], "replicas_identical_after_steps": same_after,
         "per_rank_ms_per_step": [1e3 * s / args.steps for s in facts["per_rank_s"]],
         "allreduce_bytes_per_step": reduced, "allreduce_exposed_ms_per_step": 1e3 * exposed / args.steps,
         "param_broadcast_bytes": bcast_bytes, "grad_elems": opt.n, "grad_elems_exchanged": opt.n_exchanged,
         "loss": float(total), "lr": lr, "losses": {k: float(v) for k, v in parts.items()},
-        "roofline": {"kernel": "whole training step", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                     "frac": ach / peak, "traffic": None, "flop_per_step": flop / args.steps},
+        "roofline": None if stub_device() else {"kernel": "whole training step", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                                                "frac": ach / peak, "traffic": None, "flop_per_step": flop / args.steps},
     }
 
 
@@ -755,7 +834,10 @@ def main():
                     help="train mode only: campnet = BASELINE configs[4] (B=16/GPU, T=800)")
     args = ap.parse_args()
 
-    if not torch.cuda.is_available():
+    stub = stub_device()
+    if stub and args.mode != "train":
+        raise SystemExit("SET_AMD_BENCH_STUB_DEVICE is a test hook of --mode train only")
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the set_amd hot path has no CPU fallback")
     maybe_self_launch(args)
 
@@ -765,10 +847,13 @@ def main():
     rank, world, local_rank = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit("rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     out = (run_train if args.mode == "train" else run_infer)(args, rank, world, dev)
     if rank == 0:
         print(json.dumps(out))

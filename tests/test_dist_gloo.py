@@ -254,3 +254,44 @@ def test_bucket_cut_follows_gradient_arrival_order_of_the_spec_denoiser():
     # without groups: the old behaviour (one bucket spanning both) is still what a caller without names gets
     b_old, own_old = GradBucketer.cut_buckets(numels, 64 * (1 << 20) // 4, None, total)
     assert len({groups[i] for i in range(len(names)) if own_old[i] == 0}) == 3
+
+
+def test_bench_train_mode_launches_its_own_ranks_end_to_end_on_a_stubbed_device():
+    """`python bench.py --gpus 2 --mode train` from a bare shell -- the driver's multi-GPU command minus the launcher --
+    must start its own two ranks under torch.distributed.run on 127.0.0.1, make the rank-divergent replicas identical (rank-0
+    broadcast), shard the batch, exchange the gradients in buckets launched from autograd hooks, time with barrier + max over
+    ranks and print ONE JSON line on rank 0.  No GPU here: SET_AMD_BENCH_STUB_DEVICE=cpu swaps the task for a toy torch module and
+    RCCL for gloo; everything between `main()` and the JSON line is the code the real run executes
+    (reference: mp.spawn + DDP, utils/commons/trainer.py:116-137,166-170,475-485)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SET_AMD_BENCH_STUB_DEVICE"] = "cpu"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "train", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only
+    d = json.loads(lines[0])
+    assert d["device"] == "cpu-stub" and d["metric"].startswith("STUB") and d["roofline"] is None
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["dist_backend"] == "gloo" and d["steps"] == 3 and d["warmup"] == 1
+    assert len(d["per_rank_ms_per_step"]) == 2 and d["ms_per_step"] >= max(d["per_rank_ms_per_step"]) - 1e-9   # max over ranks
+    assert d["scaling"] == "weak" and d["config"]["B_per_gpu"] == 8
+    assert d["replicas_identical_after_steps"] is True
+    # the toy module: 16*64+64 + 64*64+64 + 64*8+8 reachable parameters, 8*8+8 behind `unused_parameter_prefixes`
+    n_used, n_dead = 16 * 64 + 64 + 64 * 64 + 64 + 64 * 8 + 8, 8 * 8 + 8
+    assert d["grad_elems"] == n_used + n_dead and d["grad_elems_exchanged"] == n_used
+    assert d["allreduce_bytes_per_step"] == 4 * n_used           # every step exchanges the reachable gradients exactly once
+    assert d["param_broadcast_bytes"] == 4 * ((n_used + n_dead + 255) // 256 * 256)
+    assert "in 3 buckets" in d["config"]["sharding"]
+    # and the refusals: a launcher that started a different number of ranks, and no GPU without the test hook
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "train"],
+                        env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "launcher started 1 rank" in (r2.stderr + r2.stdout)
+    if not torch.cuda.is_available():
+        env3 = {k: v for k, v in env.items() if k != "SET_AMD_BENCH_STUB_DEVICE"}
+        r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "train"], env=env3,
+                            capture_output=True, text=True, timeout=300)
+        assert r3.returncode != 0 and "needs an MI355X" in (r3.stderr + r3.stdout)
