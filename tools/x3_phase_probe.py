@@ -38,6 +38,10 @@ for B, T in [tuple(int(v) for v in s.split("x")) for s in os.environ.get("SIZES"
     st = buf.cpu().tolist()
     tot = sum(st[:6]) + sum(st[8:13]); ntask = max(1, st[7])
     NAMES = ("claim+wait", "stage", "gemm1", "gate:tail-barrier", "gemm2", "epi+publish", "-", "-", "gate:xres+barrier", "gate:math+lds", "gate:init", "boundary:issue", "boundary:drain")
+    if tot == 0:  # the shipped library has no phase stamps (SET_X3_PROBE=0): time only
+        print("B=%d T=%d: %.1f us per 20-layer launch (no phase stamps in this build: tools/build_exp.sh probe diffnet_x3.hip -DSET_X3_PROBE=1, "
+              "then SET_AMD_LIB=build/exp/libset_amd_probe.so)" % (B, T, us))
+        continue
     print("mode %d, ticks per us: %.1f" % (wx3.mode, tot / (us * n)))
     print("B=%d T=%d: %.1f us per 20-layer launch; block 0: %d tasks/launch, %.1f us per task | share: %s" % (
         B, T, us, ntask // n, us / (ntask / n), " ".join("%s %.1f%%" % (nm, 100.0 * v / tot) for nm, v in zip(NAMES, st) if nm != "-")))
