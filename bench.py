@@ -370,7 +370,7 @@ def run_infer(args, rank, world, dev):
                                "BASELINE configs[1]); on-device Philox noise",
                    "B_per_gpu": B_PER_GPU, "T": T, "T_txt": T_TXT, "denoise_steps": DIFF_STEPS,
                    "sharding": "utterances r::N, no collective"},
-        "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"], "replicas_identical_after_steps": same_after,
+        "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"],
         "per_rank_ms_per_step": [1e3 * s / args.steps for s in facts["per_rank_s"]],
         # achieved = MFMA FLOPs the dominant kernel issues per launch / its mean launch duration, against the dense peak of
         # the pipe it issues them on; algorithmic_* = the fp32 FLOPs of the layer math (conditioner

@@ -707,20 +707,31 @@ __device__ __forceinline__ bool sx_wait(const int *f0, const int *f1, const int 
 template <int NKS, typename BF>
 __device__ __forceinline__ void sx_gemm(f32x16 &acc, u32x4_t (&A)[SX_PF][2], rsrc_t img, unsigned lane16, unsigned abase,
                                         const unsigned char *lds, unsigned piece_bytes, BF bfrag) {
+    // The schedule is pinned per k-step (round 4, as in gemm_x3):  ds_read B(k + 1) | the three MFMAs of k-step k straight from their
+    // ring slot | buffer_load refill of that slot | sched_barrier.  Rounds 2-3 had `a = A[p]; A[p] = load; mma(a)` in a fully unrolled
+    // loop: the compiler rotated the ring through v_movs and waited vmcnt(0) / vmcnt(1) in front of EVERY k-step (70 + 69 of them in
+    // the ISA) -- the ring of 8 k-steps never held more than one, which is the "GEMM 1 takes 9.4 us for 2.2 us of MFMAs" that deeper
+    // rings, L2 warmers and fence-free waits could not move.  Same products in the same order: bit-identical.
+    unsigned bo = bfrag(0);
+    u32x4_t b0 = *reinterpret_cast<const u32x4_t *>(lds + bo);
+    u32x4_t b1 = *reinterpret_cast<const u32x4_t *>(lds + piece_bytes + bo);
+#pragma unroll 1
     for (int kb = 0; kb < NKS; kb += SX_PF) {
 #pragma unroll
         for (int p = 0; p < SX_PF; ++p) {
             const int ks = kb + p;
-            const unsigned bo = bfrag(ks);
-            const u32x4_t b0 = *reinterpret_cast<const u32x4_t *>(lds + bo);
-            const u32x4_t b1 = *reinterpret_cast<const u32x4_t *>(lds + piece_bytes + bo);
-            const u32x4_t a0 = A[p][0], a1 = A[p][1];
+            const unsigned bn = bfrag(min(ks + 1, NKS - 1));
+            const u32x4_t nb0 = *reinterpret_cast<const u32x4_t *>(lds + bn);
+            const u32x4_t nb1 = *reinterpret_cast<const u32x4_t *>(lds + piece_bytes + bn);
+            acc = SplitF16x2::mma(A[p][1], b0, acc);  // the order of SplitF16x2::qa / qb
+            acc = SplitF16x2::mma(A[p][0], b1, acc);
+            acc = SplitF16x2::mma(A[p][0], b0, acc);
             const int kn = min(ks + SX_PF, NKS - 1);
             A[p][0] = buf_load_u4(img, lane16, abase + (unsigned)(kn * 4 * 1024));
             A[p][1] = buf_load_u4(img, lane16, abase + (unsigned)((kn * 4 + 1) * 1024));
-            acc = SplitF16x2::mma(a1, b0, acc);  // the order of SplitF16x2::qa / qb
-            acc = SplitF16x2::mma(a0, b1, acc);
-            acc = SplitF16x2::mma(a0, b0, acc);
+            b0 = nb0;
+            b1 = nb1;
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -789,7 +800,7 @@ __global__ void __launch_bounds__(256, 1) diffnet_stack_split_x2_kernel(SetDiffn
     unsigned short *zt = reinterpret_cast<unsigned short *>(a.z_ws) + (int64_t)i * (2 * 32 * XC);  // [piece][frame][256]
     const rsrc_t rz = make_rsrc(zt);
     const rsrc_t rsk = make_rsrc(a.skip + (int64_t)b * XC * T);
-    uint64_t *dbg = (blockIdx.x == 5 && tid == 0) ? g_x3_phase_buf : nullptr;  // debug: phase ticks of one block, see below
+    uint64_t *dbg = (SET_X3_PROBE && blockIdx.x == 5 && tid == 0) ? g_x3_phase_buf : nullptr;  // debug (probe build only): phase ticks of one block, see below
     uint64_t tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
 #define SX_PHASE(p)                                           \
     if (dbg) {                                                \
