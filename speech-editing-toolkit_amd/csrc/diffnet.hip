@@ -1605,43 +1605,61 @@ __device__ __forceinline__ f32x16 bx_mma(bx_u32x4 a, bx_u32x4 b, f32x16 c) {
 template <int NRB, typename BF>
 __device__ __forceinline__ void bx_gemm(f32x16 (&acc)[NRB][2], rsrc_t img, unsigned lane16, int rb0, int ng16, int nks,
                                         const unsigned char *lds, unsigned piece_bytes, BF bfrag) {
+    // Weight fragments straight from the packed image through a ring of PF k-steps, the k-step order pinned (round 4, as in gemm_x3 /
+    // sx_gemm):  ds_read B(k + 1) | the MFMAs of k-step k straight from their ring slot | refill of that slot | sched_barrier.  Rounds 2-3
+    // had `Ac = A[p]; A[p] = load; mma(Ac)` with a ring of 2: 150 of the kernel's 312 MFMAs sat right behind an s_waitcnt vmcnt(0 / 1).
+    // Same products in the same order per accumulator: bit-identical.
+    constexpr int PF = 4;
     auto a_load = [&](int ks, int i, int q) {
         return (bx_u32x4)__builtin_amdgcn_raw_buffer_load_b128(img, (int)lane16, (int)((((rb0 + i) * ng16 + ks) * 2 + q) * 1024), 0);
     };
-    bx_u32x4 A[2][NRB][2];
+    bx_u32x4 A[PF][NRB][2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < PF; ++p)
 #pragma unroll
         for (int i = 0; i < NRB; ++i)
 #pragma unroll
             for (int q = 0; q < 2; ++q) A[p][i][q] = a_load(min(p, nks - 1), i, q);
-    for (int kb = 0; kb < nks; kb += 2) {
+    bx_u32x4 Bv[2][2];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int ks = min(kb + p, nks - 1);
-            const bool live = kb + p < nks;  // (odd nks: the last slot repeats the final k-step and is skipped)
-            bx_u32x4 Bv[2][2], Ac[NRB][2];
+    for (int cb = 0; cb < 2; ++cb) {
+        const unsigned bo = bfrag(0, cb);
+        Bv[cb][0] = *reinterpret_cast<const bx_u32x4 *>(lds + bo);
+        Bv[cb][1] = *reinterpret_cast<const bx_u32x4 *>(lds + piece_bytes + bo);
+    }
+#pragma unroll 1
+    for (int kb = 0; kb < nks; kb += PF) {
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const unsigned bo = bfrag(ks, cb);
-                Bv[cb][0] = *reinterpret_cast<const bx_u32x4 *>(lds + bo);
-                Bv[cb][1] = *reinterpret_cast<const bx_u32x4 *>(lds + piece_bytes + bo);
-            }
+        for (int p = 0; p < PF; ++p) {
+            const int ks = kb + p;
+            if (ks < nks) {  // (nks need not be a multiple of PF: the in-projection has 5 k-steps)
+                bx_u32x4 Bn[2][2];
+                const int kq = min(ks + 1, nks - 1);
 #pragma unroll
-            for (int i = 0; i < NRB; ++i) {
-                Ac[i][0] = A[p][i][0];
-                Ac[i][1] = A[p][i][1];
-                A[p][i][0] = a_load(min(ks + 2, nks - 1), i, 0);
-                A[p][i][1] = a_load(min(ks + 2, nks - 1), i, 1);
-            }
-            if (live) {
+                for (int cb = 0; cb < 2; ++cb) {
+                    const unsigned bo = bfrag(kq, cb);
+                    Bn[cb][0] = *reinterpret_cast<const bx_u32x4 *>(lds + bo);
+                    Bn[cb][1] = *reinterpret_cast<const bx_u32x4 *>(lds + piece_bytes + bo);
+                }
 #pragma unroll
                 for (int t = 0; t < 3; ++t)  // a1 b0, a0 b1, a0 b0
 #pragma unroll
                     for (int i = 0; i < NRB; ++i)
 #pragma unroll
-                        for (int cb = 0; cb < 2; ++cb) acc[i][cb] = bx_mma(Ac[i][t == 0 ? 1 : 0], Bv[cb][t == 1 ? 1 : 0], acc[i][cb]);
+                        for (int cb = 0; cb < 2; ++cb) acc[i][cb] = bx_mma(A[p][i][t == 0 ? 1 : 0], Bv[cb][t == 1 ? 1 : 0], acc[i][cb]);
+                const int kn = min(ks + PF, nks - 1);
+#pragma unroll
+                for (int i = 0; i < NRB; ++i) {
+                    A[p][i][0] = a_load(kn, i, 0);
+                    A[p][i][1] = a_load(kn, i, 1);
+                }
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    Bv[cb][0] = Bn[cb][0];
+                    Bv[cb][1] = Bn[cb][1];
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
