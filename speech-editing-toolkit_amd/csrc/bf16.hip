@@ -111,6 +111,8 @@ __device__ __forceinline__ void conv_bf16_epilogue(const SetConv1dArgs &a, const
     const rsrc_t d_out = make_rsrc(a.out + (int64_t)b * a.out_bs);
     const rsrc_t d_res = make_rsrc(has_res ? a.res + (int64_t)b * a.res_bs : a.out + (int64_t)b * a.out_bs);
     const rsrc_t d_bias = make_rsrc(has_bias ? a.bias : a.out);
+    const bool has_mask = a.mask != nullptr;
+    const rsrc_t d_mask = make_rsrc(has_mask ? a.mask + (int64_t)b * a.T_out : a.out);
     auto tile = [&](auto ACT, const f32x16 &av, int i, int j) __attribute__((always_inline)) {
         constexpr int kAct = decltype(ACT)::value;
         const int rbase = r0 + wm * 64 + i * 32 + 4 * half;  // register r of this lane is row rbase + (r&3) + 8*(r>>2)
@@ -118,7 +120,7 @@ __device__ __forceinline__ void conv_bf16_epilogue(const SetConv1dArgs &a, const
         const bool tv = t < a.T_iter && t < a.T_out;
         const int tc = min(t, a.T_out - 1);
         float mk = 1.0f;
-        if (a.mask) mk = a.mask[(int64_t)b * a.T_out + tc];
+        if (has_mask) mk = buf_load(d_mask, (unsigned)tc * 4u, 0u);
         float bi[16], rv[16], ov[16];
         unsigned ro[16];
 #pragma unroll
@@ -147,7 +149,10 @@ __device__ __forceinline__ void conv_bf16_epilogue(const SetConv1dArgs &a, const
             else if constexpr (kAct != SET_ACT_NONE) y = dev_act(y, a.act, a.act_param);
             y = (y + rv[r]) * mk + ov[r];
             if (has_div) y = y / a.out_div;
-            if (tv && row < a.Cout) buf_store(y, d_out, (ro[r] * (unsigned)a.out_cs + (unsigned)tc) * 4u, 0u);
+            // no branch around the store: a lane outside the tensor stores at an offset beyond the descriptor's range, which the buffer
+            // unit drops.  (`if (valid) store` made every element its own exec-masked block, and the wait-count pass -- which cannot
+            // know whether the previous block ran -- put s_waitcnt vmcnt(0) in each: 64 stores per lane, each waiting for the one before.)
+            buf_store(y, d_out, (tv && row < a.Cout) ? (ro[r] * (unsigned)a.out_cs + (unsigned)tc) * 4u : BUF_OOB, 0u);
         }
     };
     auto finish = [&](auto ACT) __attribute__((always_inline)) {
@@ -415,18 +420,18 @@ __global__ void __launch_bounds__(256, 2) conv1x1_oneshot_bf16_kernel(SetConv1dA
         __syncthreads();
         if (c + 1 < nchunks) issue(c0 + CINP);  // the next chunk's loads fly under this chunk's MFMAs
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const u32x4 a0 = A[ks % RING][0], a1 = A[ks % RING][1];
+        for (int ks = 0; ks < NKS; ++ks) {  // pinned k-step order (round 4): B reads | MFMAs straight from the ring slot | refill of that slot
+            const u32x4 b0 = *reinterpret_cast<const u32x4 *>(bp + ks * 32);
+            const u32x4 b1 = *reinterpret_cast<const u32x4 *>(bp + 32 * ROWB + ks * 32);
+            acc[0][0] = mfma_bf16(A[ks % RING][0], b0, acc[0][0]);
+            acc[0][1] = mfma_bf16(A[ks % RING][0], b1, acc[0][1]);
+            acc[1][0] = mfma_bf16(A[ks % RING][1], b0, acc[1][0]);
+            acc[1][1] = mfma_bf16(A[ks % RING][1], b1, acc[1][1]);
             if (ks + RING < NKS) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) A[ks % RING][i] = __builtin_amdgcn_raw_buffer_load_b128(d_w, (int)a_off(ks0 + ks + RING, i), 0, 0);
             }
-            const u32x4 b0 = *reinterpret_cast<const u32x4 *>(bp + ks * 32);
-            const u32x4 b1 = *reinterpret_cast<const u32x4 *>(bp + 32 * ROWB + ks * 32);
-            acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
-            acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
-            acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
-            acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     conv_bf16_epilogue<WM, WN>(a, acc, b, t0, r0, wm, wn, half, l31);

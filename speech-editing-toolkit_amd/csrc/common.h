@@ -84,6 +84,8 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void *p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)0x7fffffff, (int)0x00020000);
 }
+// a per-lane offset at or beyond the descriptor's num_records (0x7fffffff): raw-buffer loads return 0 there, stores are dropped
+constexpr unsigned BUF_OOB = 0x80000000u;
 __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
