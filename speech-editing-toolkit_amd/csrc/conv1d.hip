@@ -393,8 +393,8 @@ __global__ void __launch_bounds__(256, RB == 1 ? 4 : (RB == 2 ? 3 : 2)) conv1d_m
                     f32x4 v = *reinterpret_cast<const f32x4 *>(smem + (q + 16 * i) * 64 + col);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = dev_act((v[k] + bi8[i]) * a.alpha, kAct, a.act_param);
-                    if (row0 + q < a.Cout)
-                        buf_store4((v + rv4[i]) * msk4, d_out, (unsigned)(q * a.out_cs + nc) * 4u, (unsigned)(row0 * a.out_cs) * 4u);
+                    // (rows beyond Cout: masked by range, no per-store branch -- see conv_bf16_epilogue in bf16.hip)
+                    buf_store4((v + rv4[i]) * msk4, d_out, (row0 + q < a.Cout) ? (unsigned)(q * a.out_cs + nc) * 4u : BUF_OOB, (unsigned)(row0 * a.out_cs) * 4u);
                 }
             };
             switch (a.act) {
@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256, RB == 1 ? 4 : (RB == 2 ? 3 : 2)) conv1d_m
                     float v = dev_act((smem[rr * 64 + col] + bi[i]) * a.alpha, a.act, a.act_param);
                     float y = (v + rv[i]) * msk + ov[i];
                     if (a.accumulate && a.out_div != 0.0f) y = y / a.out_div;
-                    if (co < a.Cout && tvalid) buf_store(y, d_out, (unsigned)nc * 4u, (unsigned)(co * a.out_cs) * 4u);
+                    if (co < a.Cout) buf_store(y, d_out, tvalid ? (unsigned)nc * 4u : BUF_OOB, (unsigned)(co * a.out_cs) * 4u);  // co is wave-uniform; lanes masked by range
                 }
             }
         }

@@ -227,6 +227,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
     if constexpr (PHASES) {
         // ---- transposed-conv epilogue: out[co][t u + p - P] = acc / scale + bias[co] ----
         const rsrc_t d_o = make_rsrc(a.out + (int64_t)b * a.out_bs);
+        const rsrc_t d_pb = make_rsrc(a.bias ? a.bias : a.out);
         const int n_ch = a.Cout / ph_u;
         const bool vec = (ph_u & 3) == 0 && (ph_pad & 3) == 0 && (a.out_cs & 3) == 0 && (a.T_out & 3) == 0;
 #pragma unroll
@@ -239,15 +240,14 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
                 for (int g = 0; g < 4; ++g) {
                     const int R0 = r0 + (wm * RBW + i) * 32 + 8 * g + 4 * half;  // rows R0 .. R0 + 3
                     const int co = R0 / ph_u, p0 = R0 % ph_u;
-                    const float bias = a.bias ? a.bias[min(co, n_ch - 1)] : 0.0f;
+                    const float bias = a.bias ? buf_load(d_pb, (unsigned)min(co, n_ch - 1) * 4u, 0u) : 0.0f;
                     const int n0 = t * ph_u + p0 - ph_pad;
                     if (vec) {
-                        if (t < a.T_iter && co < n_ch && n0 >= 0 && n0 + 3 < a.T_out) {
-                            f32x4 o;
+                        // (stores masked by range instead of per-store branches, see conv_bf16_epilogue in bf16.hip)
+                        f32x4 o;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] * inv_scale + bias;
-                            buf_store4(o, d_o, (unsigned)(co * (int)a.out_cs + n0) * 4u, 0u);
-                        }
+                        for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] * inv_scale + bias;
+                        buf_store4(o, d_o, (t < a.T_iter && co < n_ch && n0 >= 0 && n0 + 3 < a.T_out) ? (unsigned)(co * (int)a.out_cs + n0) * 4u : BUF_OOB, 0u);
                     } else if (ph_u == 2) {
                         // stride 2: registers 4 g + {0, 1} are the two phases of channel co at frame t -> one 8-byte store (a wave
                         // then writes 64 consecutive samples of a channel instead of every other one), {2, 3} those of co + 1
@@ -255,28 +255,27 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const int c = co + q;
-                            const float be = a.bias ? a.bias[min(c, n_ch - 1)] : 0.0f;
+                            const float be = a.bias ? buf_load(d_pb, (unsigned)min(c, n_ch - 1) * 4u, 0u) : 0.0f;
                             const float v0 = acc[i][j][4 * g + 2 * q] * inv_scale + be, v1 = acc[i][j][4 * g + 2 * q + 1] * inv_scale + be;
                             const unsigned off = (unsigned)(c * (int)a.out_cs + n0) * 4u;
-                            if (t < a.T_iter && c < n_ch) {
-                                if (n0 >= 0 && n0 + 1 < a.T_out) {
-                                    cx_u32x2 o;
-                                    o[0] = __builtin_bit_cast(unsigned, v0); o[1] = __builtin_bit_cast(unsigned, v1);
-                                    __builtin_amdgcn_raw_buffer_store_b64(o, d_o, (int)off, 0, 0);
-                                } else {
-                                    if (n0 >= 0 && n0 < a.T_out) buf_store(v0, d_o, off, 0u);
-                                    if (n0 + 1 >= 0 && n0 + 1 < a.T_out) buf_store(v1, d_o, off + 4u, 0u);
-                                }
+                            // masked by range, no branches (see conv_bf16_epilogue): the 8-byte store when both samples exist, else
+                            // the one that does (only the first / last frame of an utterance takes the 4-byte forms)
+                            const bool ok = t < a.T_iter && c < n_ch, both = n0 >= 0 && n0 + 1 < a.T_out;
+                            cx_u32x2 o;
+                            o[0] = __builtin_bit_cast(unsigned, v0); o[1] = __builtin_bit_cast(unsigned, v1);
+                            __builtin_amdgcn_raw_buffer_store_b64(o, d_o, (int)((ok && both) ? off : BUF_OOB), 0, 0);
+                            if (__builtin_amdgcn_ballot_w64(ok && !both) != 0) {  // wave-uniform: some lane sits on an utterance edge
+                                buf_store(v0, d_o, (ok && !both && n0 >= 0 && n0 < a.T_out) ? off : BUF_OOB, 0u);
+                                buf_store(v1, d_o, (ok && !both && n0 + 1 >= 0 && n0 + 1 < a.T_out) ? off + 4u : BUF_OOB, 0u);
                             }
                         }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int R = R0 + e, c = R / ph_u, n = t * ph_u + R % ph_u - ph_pad;
-                            if (t < a.T_iter && c < n_ch && n >= 0 && n < a.T_out) {
-                                const float be = a.bias ? a.bias[c] : 0.0f;
-                                buf_store(acc[i][j][4 * g + e] * inv_scale + be, d_o, (unsigned)(c * (int)a.out_cs + n) * 4u, 0u);
-                            }
+                            const bool okk = t < a.T_iter && c < n_ch && n >= 0 && n < a.T_out;
+                            const float be = a.bias ? buf_load(d_pb, (unsigned)min(c, n_ch - 1) * 4u, 0u) : 0.0f;
+                            buf_store(acc[i][j][4 * g + e] * inv_scale + be, d_o, okk ? (unsigned)(c * (int)a.out_cs + n) * 4u : BUF_OOB, 0u);
                         }
                     }
                 }
@@ -298,7 +297,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
         const bool tv = t < a.T_iter && n >= 0 && n < a.T_out;
         const int nc = min(max(n, 0), a.T_out - 1);
         float mk = 1.0f;
-        if (a.mask) mk = a.mask[(int64_t)b * a.T_out + nc];
+        if (a.mask) mk = buf_load(make_rsrc(a.mask + (int64_t)b * a.T_out), (unsigned)nc * 4u, 0u);
         float bi[16], rv[16], ov[16];
         unsigned ro[16];
 #pragma unroll
@@ -327,7 +326,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
             else if constexpr (kAct != SET_ACT_NONE) y = dev_act(y, a.act, a.act_param);
             y = (y + rv[r]) * mk + ov[r];
             if (has_div) y = y / a.out_div;
-            if (tv && row < a.Cout) buf_store(y, d_out, (ro[r] * (unsigned)a.out_cs + (unsigned)nc) * 4u, 0u);
+            buf_store(y, d_out, (tv && row < a.Cout) ? (ro[r] * (unsigned)a.out_cs + (unsigned)nc) * 4u : BUF_OOB, 0u);  // masked by range, no branch (see conv_bf16_epilogue)
         }
     };
     auto finish = [&](auto ACT) __attribute__((always_inline)) {

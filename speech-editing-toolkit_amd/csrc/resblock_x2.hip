@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_x2_kernel(SetResblockPai
                 float y = acc[i][j][r] * inv_s2 + bi[r];  // the order of conv1d_x2_kernel's epilogue (alpha = 1, no mask)
                 y = (y + rv[r]) + ov[r];
                 if (has_div) y = y / a.out_div;
-                if (tv && row < C) buf_store(y, d_out, (ro[r] * (unsigned)a.out_cs + (unsigned)fc) * 4u, 0u);
+                buf_store(y, d_out, (tv && row < C) ? (ro[r] * (unsigned)a.out_cs + (unsigned)fc) * 4u : BUF_OOB, 0u);  // masked by range, no branch (see conv_bf16_epilogue)
             }
         }
     }
