@@ -230,6 +230,26 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
         const rsrc_t d_pb = make_rsrc(a.bias ? a.bias : a.out);
         const int n_ch = a.Cout / ph_u;
         const bool vec = (ph_u & 3) == 0 && (ph_pad & 3) == 0 && (a.out_cs & 3) == 0 && (a.T_out & 3) == 0;
+        // every bias value this lane needs, fetched BEFORE the first store: vmcnt counts loads and stores in one order, so a load issued
+        // after a store cannot be waited for without waiting for that store's completion (the epilogue was load -> wait -> store -> load ...)
+        float bz[RBW][4][4];
+#pragma unroll
+        for (int i = 0; i < RBW; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = (r0 + (wm * RBW + i) * 32 + 8 * g + 4 * half + e) / ph_u;
+                    bz[i][g][e] = a.bias ? buf_load(d_pb, (unsigned)min(c, n_ch - 1) * 4u, 0u) : 0.0f;
+                }
+        // ... and waited for HERE, once, in straight-line code: left to the wait-count pass, every later block (the paths below are
+        // wave-uniform branches) re-waits vmcnt(0) because some predecessor path did not consume the values yet
+#pragma unroll
+        for (int i = 0; i < RBW; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(bz[i][g][e]));
 #pragma unroll
         for (int i = 0; i < RBW; ++i) {
             if (r0 + (wm * RBW + i) * 32 >= a.Cout) continue;
@@ -240,7 +260,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
                 for (int g = 0; g < 4; ++g) {
                     const int R0 = r0 + (wm * RBW + i) * 32 + 8 * g + 4 * half;  // rows R0 .. R0 + 3
                     const int co = R0 / ph_u, p0 = R0 % ph_u;
-                    const float bias = a.bias ? buf_load(d_pb, (unsigned)min(co, n_ch - 1) * 4u, 0u) : 0.0f;
+                    const float bias = bz[i][g][0];
                     const int n0 = t * ph_u + p0 - ph_pad;
                     if (vec) {
                         // (stores masked by range instead of per-store branches, see conv_bf16_epilogue in bf16.hip)
@@ -255,7 +275,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const int c = co + q;
-                            const float be = a.bias ? buf_load(d_pb, (unsigned)min(c, n_ch - 1) * 4u, 0u) : 0.0f;
+                            const float be = bz[i][g][2 * q];
                             const float v0 = acc[i][j][4 * g + 2 * q] * inv_scale + be, v1 = acc[i][j][4 * g + 2 * q + 1] * inv_scale + be;
                             const unsigned off = (unsigned)(c * (int)a.out_cs + n0) * 4u;
                             // masked by range, no branches (see conv_bf16_epilogue): the 8-byte store when both samples exist, else
@@ -274,7 +294,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
                         for (int e = 0; e < 4; ++e) {
                             const int R = R0 + e, c = R / ph_u, n = t * ph_u + R % ph_u - ph_pad;
                             const bool okk = t < a.T_iter && c < n_ch && n >= 0 && n < a.T_out;
-                            const float be = a.bias ? buf_load(d_pb, (unsigned)min(c, n_ch - 1) * 4u, 0u) : 0.0f;
+                            const float be = bz[i][g][e];
                             buf_store(acc[i][j][4 * g + e] * inv_scale + be, d_o, okk ? (unsigned)(c * (int)a.out_cs + n) * 4u : BUF_OOB, 0u);
                         }
                     }
