@@ -86,8 +86,9 @@ __global__ void __launch_bounds__(256) conv1d_wgrad_mfma_kernel(WgradArgs a) {
         for (int j = 0; j < 8; ++j) {
             const int cic = min(ci0 + sr0 + 8 * j, a.Cin - 1);
             xv[j] = xb[(int64_t)cic * a.T_in];
-            const float ad = addb[cic];  // unconditional (dummy address when there is no per-channel add)
-            av[j] = has_add ? ad : 0.0f;
+            av[j] = addb[cic];  // unconditional (dummy address when there is no per-channel add); the `has_add ? : 0` select sits in
+                                // commit(): done here it consumed the loaded value at once, i.e. the wave waited for the whole chunk's
+                                // loads right after issuing them -- nothing was in flight under the MFMAs (found in the ISA, round 4)
         }
     };
     auto commit = [&](int buf, int ch) {  // buf 0/1 -> integer offsets (a selected pointer would lose its LDS address space)
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(256) conv1d_wgrad_mfma_kernel(WgradArgs a) {
         for (int j = 0; j < 16; ++j) Gs[go + (sr0 + 8 * j) * WG_LD + sk] = (tv && co0 + sr0 + 8 * j < a.Cout) ? gv[j] : 0.0f;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            Xs[xo + (sr0 + 8 * j) * WG_LD + sk] = (tiv && ci0 + sr0 + 8 * j < a.Cin) ? dev_pro(xv[j] + av[j], a.pro, a.pro_param) : 0.0f;
+            Xs[xo + (sr0 + 8 * j) * WG_LD + sk] = (tiv && ci0 + sr0 + 8 * j < a.Cin) ? dev_pro(xv[j] + (has_add ? av[j] : 0.0f), a.pro, a.pro_param) : 0.0f;
     };
     // while a wave runs the MFMAs of chunk c out of buffer c & 1 the loads of chunk c + 1 are in flight; it then writes
     // them to the other buffer (last read one barrier ago) and issues the loads of chunk c + 2

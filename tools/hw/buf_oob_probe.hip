@@ -17,6 +17,20 @@ __global__ void probe(float *base, unsigned soff, int nrec, float *loaded) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)((lane & 1) ? 0x80000000u + 16u * lane : 4096u + 16u * lane), (int)soff, 0);
     loaded[lane] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(0x80000000u + 4u * lane), (int)soff, 0));
 }
+// second part: EVERY lane masked at exactly 0x80000000 (the form the epilogues use), 4- and 16-byte stores, then the WHOLE allocation is
+// searched for a non-zero word: a store that is not dropped but redirected anywhere inside the 3 GiB shows up
+__global__ void probe_all_masked(float *base, unsigned soff) {
+    const rsrc_t r = make_rsrc(base, 0x7fffffff);
+    const u32x4 v = {9u, 9u, 9u, 9u};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)0x80000000u, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(9u, r, (int)0x80000000u, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)((threadIdx.x & 16) ? 0x80000000u : 0x80000000u + 16u * threadIdx.x), (int)soff, 0);
+}
+__global__ void count_nonzero(const unsigned *p, size_t n, unsigned long long *cnt) {
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += p[i] != 0u;
+    if (c) atomicAdd(cnt, c);
+}
 int main() {
     const size_t bytes = 3ull << 30;
     float *d = nullptr, *ld = nullptr;
@@ -36,6 +50,15 @@ int main() {
         for (int i = 0; i < 64; ++i) { hit += far[i] != 100.0f + i; kept += (i & 1) == 0 ? near_[i] == 1.0f + i : near_[i] == 0.0f; ldz += l[i] == 0.0f; }
         printf("num_records 0x%08x soffset %8u: words behind base + 2 GiB changed by the masked stores: %d of 64 | in-range lanes stored, masked lanes left alone: %d of 64 | out-of-range loads returning 0: %d of 64\n",
                (unsigned)nrec, soff, hit, kept, ldz);
+    }
+    unsigned long long *cnt = nullptr;
+    hipMalloc(&cnt, 8);
+    for (unsigned soff : {0u, 614400u, 1u << 30}) {
+        hipMemset(d, 0, bytes); hipMemset(cnt, 0, 8);
+        hipLaunchKernelGGL(probe_all_masked, dim3(64), dim3(256), 0, 0, d, soff);
+        hipLaunchKernelGGL(count_nonzero, dim3(2048), dim3(256), 0, 0, (const unsigned *)d, bytes / 4, cnt);
+        unsigned long long h = 0; hipMemcpy(&h, cnt, 8, hipMemcpyDeviceToHost);
+        printf("all lanes masked at 0x80000000, soffset %10u: non-zero words anywhere in the 3 GiB allocation afterwards: %llu\n", soff, h);
     }
     return 0;
 }
