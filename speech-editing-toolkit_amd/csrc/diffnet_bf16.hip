@@ -1360,17 +1360,25 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffn
         float sd[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) sd[r] = 0.0f;
+        // The read-modify-write batches are software-pipelined: the loads of column block cb + 1 are issued BEFORE the stores of cb.
+        // vmcnt retires loads and stores in issue order, so a load issued after a batch of stores cannot be waited for without
+        // waiting for those stores (round 3's `load 16 -> store 16` per column block paid a load AND a store round trip, 8 times).
+        float rv[2][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[0][r] = buf_load(rdxo, vo4[0], (unsigned)(32 * w + urow(r)) * T4);
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
-            float rv[16];
+            if (cb + 1 < 4) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = buf_load(rdxo, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+                for (int r = 0; r < 16; ++r) rv[(cb + 1) & 1][r] = buf_load(rdxo, vo4[cb + 1], (unsigned)(32 * w + urow(r)) * T4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             if (cen[cb]) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = dxd[0][cb][r];
                     sd[r] += v;
-                    buf_store(has_dxo ? v + rv[r] * RSQRT2 : v, rdx, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+                    buf_store(has_dxo ? v + rv[cb & 1][r] * RSQRT2 : v, rdx, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
                 }
             }
         }
@@ -1380,15 +1388,20 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffn
             if (l31 == 0) a.part_dd[(int64_t)part_row * FC + 32 * w + urow(r) + 4 * half] = a0;
         }
         if (w < 6) {
+            float pv[2][16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv[0][r] = buf_load(rdc, vo4[0], (unsigned)(32 * w + urow(r)) * T4);
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
-                float pv[16];
+                if (cb + 1 < 4) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pv[r] = buf_load(rdc, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+                    for (int r = 0; r < 16; ++r) pv[(cb + 1) & 1][r] = buf_load(rdc, vo4[cb + 1], (unsigned)(32 * w + urow(r)) * T4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 if (cen[cb]) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        buf_store(a.dcond_first ? dcn[0][cb][r] : pv[r] + dcn[0][cb][r], rdc, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+                        buf_store(a.dcond_first ? dcn[0][cb][r] : pv[cb & 1][r] + dcn[0][cb][r], rdc, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
                 }
             }
         }
