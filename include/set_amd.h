@@ -400,7 +400,9 @@ typedef struct SetDiffLoopArgs {
     int32_t x3_mode;
     /* optional set_pack_conv_weight_x2 images of skip_projection (256 x 256), output_projection (M x 256) and
      * input_projection (256 x M): with x3_mode == 2 the fused step boundary then runs on the two-piece fp16 operands as well
-     * (SET_AMD_BOUNDARY_X2=0 keeps the fp32 MFMA boundary kernel) */
+     * (SET_AMD_BOUNDARY_X2=0 keeps the fp32 MFMA boundary kernel); the opt-in bf16 loop (img16_all) takes it whenever the images are
+     * given -- it can raise err_flag = 2 (an activation outside the fp16 split range), which the caller must read and answer by
+     * repeating the loop without these images */
     const void *w_skip_x2, *w_outp_x2, *w_in_x2;
     const float *w_skip_p; /* skip_projection packed */
     const float *b_skip;

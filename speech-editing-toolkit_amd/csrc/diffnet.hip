@@ -1942,6 +1942,9 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
                                     a.x3_mode, n_cu_chain);
         boundary_x2 = v == 5 || (v == 3 && !(getenv("SET_AMD_SPLIT_F32") && atoi(getenv("SET_AMD_SPLIT_F32")) != 0));
     }
+    // the bf16-operand loop takes the split-operand boundary whenever its images are given (round 4: 85 -> 37 us per step at B = 32,
+    // T = 800; it is the fp32-equivalent one, and it raises the same range word, which the caller must read)
+    if (bf16_loop && fused_boundary && a.w_skip_x2 && a.w_outp_x2 && a.w_in_x2 && a.M <= 96) boundary_x2 = true;
     if (const char *e = getenv("SET_AMD_BOUNDARY_X2")) boundary_x2 = boundary_x2 && atoi(e) != 0;
     for (int k = 0; k < a.steps && rc == SET_OK; ++k) {
         const int sid = a.steps - 1 - k;  // diffusion step id t = steps-1 .. 0 (spec_denoiser.py:181)

@@ -856,7 +856,9 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs,
     a.sync_ws = sync_ws.data_ptr()
     err = torch.zeros(1, dtype=torch.int32, device=dev)  # sticky: a dependency wait of the persistent kernel gave up
     a.err_flag = err.data_ptr()
-    if a.wx3_all and a.x3_mode == 2 and M <= 96 and os.environ.get("SET_AMD_BOUNDARY_X2", "1") != "0":
+    bf16_bx2 = bf16 is not None and split_operand_mode() == 2  # the opt-in bf16 loop: its layers are bf16, its step boundary fp32-equivalent
+    use_bx2 = ((a.wx3_all and a.x3_mode == 2) or bf16_bx2) and M <= 96 and os.environ.get("SET_AMD_BOUNDARY_X2", "1") != "0"
+    if use_bx2:
         # the fused step boundary on the same two-piece fp16 operands
         a.w_skip_x2, a.w_outp_x2, a.w_in_x2 = (w.packed_x2().data_ptr() for w in (w_skip, w_outp, w_in))
     a.w_skip_p, a.b_skip = w_skip.packed().data_ptr(), b_skip.data_ptr()
@@ -871,7 +873,7 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs,
         loop_ms = C.c_float(0.0)
         a.loop_ms = C.pointer(loop_ms)
     check(_lib.lib().set_diffusion_loop(C.byref(a), _stream()), "set_diffusion_loop")
-    if a.persistent and bf16 is None:  # (one 4-byte read-back per reverse loop; fail loudly, never return garbage)
+    if a.persistent and (bf16 is None or use_bx2):  # (one 4-byte read-back per reverse loop; fail loudly, never return garbage)
         code = int(err.item())
         if code == 2:
             raise SplitRangeError("set_diffusion_loop: an activation of magnitude >= 32768 is outside the range of the fp16 "
