@@ -503,8 +503,8 @@ int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, void *stream
  * skip sum stays in registers (64-frame tiles) or goes through L2 per layer (128-frame tiles)) and stores the tile - 2 H frames whose
  * receptive field stayed inside the tile, H = sum of the dilations 2^((l0 + m) % dilation_cycle_length), m = 1 .. nl - 1.  The tile
  * width is chosen per launch: 128 frames when B * ceil(T / (128 - 2 H)) blocks still fill 3/4 of the CUs, else 64.  Same arithmetic
- * per frame as nl set_diffnet_layer_fwd_bf16 launches (x bit-identical; the skip sum bit-identical at 64 frames, equal up to fp32
- * rounding order at 128).  Arrays are the per-layer operands of those launches laid out one layer after the other: img
+ * per frame as nl set_diffnet_layer_fwd_bf16 launches (x AND the skip sum bit-identical at both tile widths: the 128-frame shape adds
+ * the layers' skip contributions in layer order as well).  Arrays are the per-layer operands of those launches laid out one layer after the other: img
  * [nl][image_size], b_dil / b_cond / b_out [nl][512], dstep of layer l at dstep + l * d_ls (l counted from layer 0 of the network).
  * x_in != x_out.  scratch >= set_diffnet_layers_bf16_scratch_floats(B, T, l0, nl, dilation_cycle_length) floats (128-frame tiles:
  * a block's private copy of its skip rows between the layers of the group).

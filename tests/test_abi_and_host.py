@@ -396,3 +396,24 @@ def test_unreachable_parameters_sit_behind_the_exchanged_part_of_the_flat_buffer
     opt2 = FlatAdamW(m)
     opt2.load_state_dict(sd)
     assert torch.equal(opt2.m[:opt.n], opt.m[:opt.n]) and opt2.num_updates == 1
+
+
+def test_bf16_layer_group_plan_and_scratch_size():
+    """Host side of the fused bf16 layer groups (include/set_amd.h: set_diffnet_layers_bf16_plan / _scratch_floats; no GPU needed -- without
+    a device the plan assumes the MI355X's 256 CUs).  The reverse loop gives a launch as many consecutive residual layers as the plan says:
+    10 on 128-frame tiles when B * ceil(T / stored frames) blocks fill >= 3/4 of the CUs (BASELINE's B = 32, T = 800: 8 x 32 = 256), else 5
+    on 64-frame tiles; dilation cycles whose halo would eat the tile fall back to one layer per launch.  The scratch is the block-private
+    skip copy of the 128-frame shape: B x tiles x 256 rows x 128 frames floats (reference loop: diffnet.py:60-81, one layer at a time)."""
+    L = _lib.lib()
+    assert L.set_diffnet_layers_bf16_plan(32, 800, 20, 1) == 10
+    assert L.set_diffnet_layers_bf16_plan(64, 800, 20, 1) == 10
+    assert L.set_diffnet_layers_bf16_plan(4, 800, 20, 1) == 5      # 4 x 8 tiles of 128 frames would leave 7/8 of the chip idle
+    assert L.set_diffnet_layers_bf16_plan(1, 800, 20, 1) == 5
+    for dcl in (1, 2, 3, 4):
+        n = L.set_diffnet_layers_bf16_plan(32, 800, 20, dcl)
+        assert 1 <= n <= 16
+    assert L.set_diffnet_layers_bf16_plan(32, 800, 20, 4) == 1      # dilations 1, 2, 4, 8: the halo of a group leaves no stored frames
+    # 10 layers of dilation 1: halo 9 per side, 110 stored frames per 128-frame tile, balanced over T = 800 -> 8 tiles per utterance
+    assert L.set_diffnet_layers_bf16_scratch_floats(32, 800, 0, 10, 1) == 32 * 8 * 256 * 128
+    assert L.set_diffnet_layers_bf16_scratch_floats(64, 800, 0, 10, 1) == 64 * 8 * 256 * 128
+    assert L.set_diffnet_layers_bf16_scratch_floats(32, 800, 0, 5, 1) == 32 * 7 * 256 * 128   # halo 4: 120 stored frames -> 7 tiles
