@@ -404,6 +404,7 @@ def test_bf16_layer_group_plan_and_scratch_size():
     10 on 128-frame tiles when B * ceil(T / stored frames) blocks fill >= 3/4 of the CUs (BASELINE's B = 32, T = 800: 8 x 32 = 256), else 5
     on 64-frame tiles; dilation cycles whose halo would eat the tile fall back to one layer per launch.  The scratch is the block-private
     skip copy of the 128-frame shape: B x tiles x 256 rows x 128 frames floats (reference loop: diffnet.py:60-81, one layer at a time)."""
+    from set_amd import _lib
     L = _lib.lib()
     assert L.set_diffnet_layers_bf16_plan(32, 800, 20, 1) == 10
     assert L.set_diffnet_layers_bf16_plan(64, 800, 20, 1) == 10
