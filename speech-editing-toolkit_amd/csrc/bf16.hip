@@ -502,8 +502,9 @@ __device__ __forceinline__ unsigned buf_load_raw16(rsrc_t r, unsigned voff, unsi
 
 // GB16 / XB16: the operand already is bf16 in HBM (saved activations / gradients of the fused layer kernels): its bits
 // go to LDS unchanged (no prologue, no per-channel add on such an operand).
-template <bool GB16, bool XB16>
+template <bool GB16, bool XB16, bool GU = false, bool XU = false>  // GU / XU: that operand is copied in 16-byte units (host: wgrad_units_ok)
 __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args a) {
+    static_assert((!GU || GB16) && (!XU || XB16), "16-byte units need an operand that already is bf16");
     __shared__ __attribute__((aligned(16))) unsigned char Gs[128 * WGB_ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char Xs[128 * WGB_ROWB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -534,6 +535,14 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
     unsigned gv[32], xv[32];  // raw bits (fp32 or bf16): converting at issue time would wait for the load
     float av[XB16 ? 1 : 32];
     constexpr unsigned GE = GB16 ? 2u : 4u, XE = XB16 ? 2u : 4u;  // element sizes
+    // Round 4: an operand that already is bf16 in HBM is copied in 16-byte units (8 consecutive frames of a row; unit (row, ucol) of the
+    // 128 x 64 tile = thread tid + 256 q) when its rows are 16-byte aligned (T a multiple of 8; the conv input also needs shift = 0):
+    // 4 loads + 4 LDS writes per thread and chunk instead of 32 + 32 two-byte ones -- these kernels issue 16 MFMAs per chunk and were
+    // bound by the staging instructions.  Same bits in the same LDS cells as the element-wise path (which stays for ragged T).
+    // The path is a template parameter, not a run-time test: with both paths in one kernel the wait-count pass drained the next chunk's loads
+    // in front of the MFMAs at the join of the two branches.
+    constexpr bool fastg = GU, fastx = XU;
+    const int urow = tid >> 3, ucol = tid & 7;
     auto issue = [&](int ch) {
         const int b = ch / a.n_chunks_t, t0 = (ch % a.n_chunks_t) * WGB_KT;
         const unsigned vg = (unsigned)min(t0 + sk, a.T - 1) * GE;
@@ -541,16 +550,34 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
         const rsrc_t d_g = make_rsrc(reinterpret_cast<const unsigned char *>(a.g) + (int64_t)b * a.Cout * a.T * GE);
         const rsrc_t d_x = make_rsrc(reinterpret_cast<const unsigned char *>(a.x) + (int64_t)b * a.Cin * a.T_in * XE);
         const rsrc_t d_a = make_rsrc(has_add ? a.chan_add + (int64_t)b * a.Cin : reinterpret_cast<const float *>(a.x));
+        if constexpr (fastg) {  // 16 bytes = 8 frames of one row per load: 4 loads per thread instead of 32 two-byte ones
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const unsigned so = (unsigned)(min(co0 + sr0 + 4 * j, a.Cout - 1) * a.T) * GE;
-            gv[j] = GB16 ? buf_load_raw16(d_g, vg, so) : buf_load_raw(d_g, vg, so);
+            for (int q = 0; q < 4; ++q) {
+                const unsigned vo = (unsigned)(min(co0 + urow + 32 * q, a.Cout - 1) * a.T + min(t0 + 8 * ucol, a.T - 8)) * 2u;
+                const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_g, (int)vo, 0, 0);
+                gv[4 * q] = v[0]; gv[4 * q + 1] = v[1]; gv[4 * q + 2] = v[2]; gv[4 * q + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const unsigned so = (unsigned)(min(co0 + sr0 + 4 * j, a.Cout - 1) * a.T) * GE;
+                gv[j] = GB16 ? buf_load_raw16(d_g, vg, so) : buf_load_raw(d_g, vg, so);
+            }
         }
+        if constexpr (fastx) {
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const int cic = min(ci0 + sr0 + 4 * j, a.Cin - 1);
-            xv[j] = XB16 ? buf_load_raw16(d_x, vx, (unsigned)(cic * a.T_in) * XE) : buf_load_raw(d_x, vx, (unsigned)(cic * a.T_in) * XE);
-            if constexpr (!XB16) av[j] = buf_load(d_a, 0u, (unsigned)cic * 4u);
+            for (int q = 0; q < 4; ++q) {
+                const unsigned vo = (unsigned)(min(ci0 + urow + 32 * q, a.Cin - 1) * a.T_in + min(t0 + 8 * ucol, a.T_in - 8)) * 2u;
+                const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_x, (int)vo, 0, 0);
+                xv[4 * q] = v[0]; xv[4 * q + 1] = v[1]; xv[4 * q + 2] = v[2]; xv[4 * q + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int cic = min(ci0 + sr0 + 4 * j, a.Cin - 1);
+                xv[j] = XB16 ? buf_load_raw16(d_x, vx, (unsigned)(cic * a.T_in) * XE) : buf_load_raw(d_x, vx, (unsigned)(cic * a.T_in) * XE);
+                if constexpr (!XB16) av[j] = buf_load(d_a, 0u, (unsigned)cic * 4u);
+            }
         }
     };
     auto commit = [&](auto PROC, int ch) __attribute__((always_inline)) {
@@ -558,19 +585,41 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
         const int t0 = (ch % a.n_chunks_t) * WGB_KT;
         const int t = t0 + sk, ti = t + shift;
         const bool tv = t < a.T, tiv = tv && ti >= 0 && ti < a.T_in;
+        if constexpr (fastg) {
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const int row = sr0 + 4 * j;
-            unsigned short gb, xb;
-            if constexpr (GB16) gb = (unsigned short)gv[j];
-            else gb = bf16_bits(__builtin_bit_cast(float, gv[j]));
-            if constexpr (XB16) xb = (unsigned short)xv[j];
-            else {
-                const float xf = __builtin_bit_cast(float, xv[j]);
-                xb = bf16_bits(pro_c<kPro>(has_add ? xf + av[j] : xf, a.pro_param));  // unconditional, then select
+            for (int q = 0; q < 4; ++q) {
+                const int row = urow + 32 * q;
+                const bool ok = t0 + 8 * ucol < a.T && co0 + row < a.Cout;  // T % 8 == 0: a unit is entirely inside or outside
+                u32x4 v;
+                v[0] = ok ? gv[4 * q] : 0u; v[1] = ok ? gv[4 * q + 1] : 0u; v[2] = ok ? gv[4 * q + 2] : 0u; v[3] = ok ? gv[4 * q + 3] : 0u;
+                *reinterpret_cast<u32x4 *>(Gs + row * WGB_ROWB + ucol * 16) = v;
             }
-            *reinterpret_cast<unsigned short *>(Gs + row * WGB_ROWB + sk * 2) = (tv && co0 + row < a.Cout) ? gb : (unsigned short)0;
-            *reinterpret_cast<unsigned short *>(Xs + row * WGB_ROWB + sk * 2) = (tiv && ci0 + row < a.Cin) ? xb : (unsigned short)0;
+        }
+        if constexpr (fastx) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = urow + 32 * q;
+                const bool ok = t0 + 8 * ucol < a.T && t0 + 8 * ucol < a.T_in && ci0 + row < a.Cin;
+                u32x4 v;
+                v[0] = ok ? xv[4 * q] : 0u; v[1] = ok ? xv[4 * q + 1] : 0u; v[2] = ok ? xv[4 * q + 2] : 0u; v[3] = ok ? xv[4 * q + 3] : 0u;
+                *reinterpret_cast<u32x4 *>(Xs + row * WGB_ROWB + ucol * 16) = v;
+            }
+        }
+        if constexpr (!fastg || !fastx) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int row = sr0 + 4 * j;
+                unsigned short gb, xb;
+                if constexpr (GB16) gb = (unsigned short)gv[j];
+                else gb = bf16_bits(__builtin_bit_cast(float, gv[j]));
+                if constexpr (XB16) xb = (unsigned short)xv[j];
+                else {
+                    const float xf = __builtin_bit_cast(float, xv[j]);
+                    xb = bf16_bits(pro_c<kPro>(has_add ? xf + av[j] : xf, a.pro_param));  // unconditional, then select
+                }
+                if constexpr (!fastg) *reinterpret_cast<unsigned short *>(Gs + row * WGB_ROWB + sk * 2) = (tv && co0 + row < a.Cout) ? gb : (unsigned short)0;
+                if constexpr (!fastx) *reinterpret_cast<unsigned short *>(Xs + row * WGB_ROWB + sk * 2) = (tiv && ci0 + row < a.Cin) ? xb : (unsigned short)0;
+            }
         }
     };
     if (c_begin < c_end) issue(c_begin);
@@ -619,8 +668,9 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
 // Here a block owns a 128 (co) x 64 (ci) tile of dW for ALL three taps: G is staged once per 64-frame chunk, X once with
 // its 2 dil halo frames, written to three LDS copies shifted by the tap offsets (copy k, column j = frame t0 + j + k dil
 // - pad), so the MFMA fragment reads stay 16-byte aligned.  Traffic: G x Cin/64 + X x Cout/128 (208 MB for that conv).
-template <bool GB16>
+template <bool GB16, bool GU = false>
 __global__ void __launch_bounds__(256, 2) conv1d_wgrad3_bf16_kernel(WgradBf16Args a) {
+    static_assert(!GU || GB16, "16-byte units need an operand that already is bf16");
     __shared__ __attribute__((aligned(16))) unsigned char Gs[128 * WGB_ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char Xs[3 * 64 * WGB_ROWB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -648,6 +698,8 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad3_bf16_kernel(WgradBf16Arg
     const int sk = lane, sr0 = wave;
     unsigned gv[32];
     float xa[16], xb[16], av[16];
+    constexpr bool fastg = GU;
+    const int urow = tid >> 3, ucol = tid & 7;
     auto issue = [&](int ch) {
         const int b = ch / a.n_chunks_t, t0 = (ch % a.n_chunks_t) * WGB_KT;
         const unsigned vg = (unsigned)min(t0 + sk, a.T - 1) * GE;
@@ -656,10 +708,19 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad3_bf16_kernel(WgradBf16Arg
         const rsrc_t d_g = make_rsrc(reinterpret_cast<const unsigned char *>(a.g) + (int64_t)b * a.Cout * a.T * GE);
         const rsrc_t d_x = make_rsrc(reinterpret_cast<const float *>(a.x) + (int64_t)b * a.Cin * a.T_in);
         const rsrc_t d_a = make_rsrc(has_add ? a.chan_add + (int64_t)b * a.Cin : reinterpret_cast<const float *>(a.x));
+        if constexpr (fastg) {  // (see conv1d_wgrad_bf16_kernel: 16-byte units of the bf16 output gradient)
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const unsigned so = (unsigned)(min(co0 + sr0 + 4 * j, a.Cout - 1) * a.T) * GE;
-            gv[j] = GB16 ? buf_load_raw16(d_g, vg, so) : buf_load_raw(d_g, vg, so);
+            for (int q = 0; q < 4; ++q) {
+                const unsigned vo = (unsigned)(min(co0 + urow + 32 * q, a.Cout - 1) * a.T + min(t0 + 8 * ucol, a.T - 8)) * 2u;
+                const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_g, (int)vo, 0, 0);
+                gv[4 * q] = v[0]; gv[4 * q + 1] = v[1]; gv[4 * q + 2] = v[2]; gv[4 * q + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const unsigned so = (unsigned)(min(co0 + sr0 + 4 * j, a.Cout - 1) * a.T) * GE;
+                gv[j] = GB16 ? buf_load_raw16(d_g, vg, so) : buf_load_raw(d_g, vg, so);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -674,13 +735,24 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad3_bf16_kernel(WgradBf16Arg
         const bool tv = t0 + sk < a.T;
         const int fa = t0 + sh0 + sk, fb = fa + 64;  // frames of the two loaded values
         const bool va = fa >= 0 && fa < a.T_in, vb = fb >= 0 && fb < a.T_in;
+        if constexpr (fastg) {
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const int row = sr0 + 4 * j;
-            unsigned short gb;
-            if constexpr (GB16) gb = (unsigned short)gv[j];
-            else gb = bf16_bits(__builtin_bit_cast(float, gv[j]));
-            *reinterpret_cast<unsigned short *>(Gs + row * WGB_ROWB + sk * 2) = (tv && co0 + row < a.Cout) ? gb : (unsigned short)0;
+            for (int q = 0; q < 4; ++q) {
+                const int row = urow + 32 * q;
+                const bool ok = t0 + 8 * ucol < a.T && co0 + row < a.Cout;
+                u32x4 v;
+                v[0] = ok ? gv[4 * q] : 0u; v[1] = ok ? gv[4 * q + 1] : 0u; v[2] = ok ? gv[4 * q + 2] : 0u; v[3] = ok ? gv[4 * q + 3] : 0u;
+                *reinterpret_cast<u32x4 *>(Gs + row * WGB_ROWB + ucol * 16) = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int row = sr0 + 4 * j;
+                unsigned short gb;
+                if constexpr (GB16) gb = (unsigned short)gv[j];
+                else gb = bf16_bits(__builtin_bit_cast(float, gv[j]));
+                *reinterpret_cast<unsigned short *>(Gs + row * WGB_ROWB + sk * 2) = (tv && co0 + row < a.Cout) ? gb : (unsigned short)0;
+            }
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -1055,7 +1127,9 @@ static int wgrad_bf16_launch(const void *g, const void *x, const float *chan_add
         a.chunks_per_slice = (B * a.n_chunks_t + S - 1) / S;
         a.ci_tiles = (Cin + 63) / 64;
         dim3 grid(a.ci_tiles, (Cout + 127) / 128, S * groups);
+        const bool gu = (T & 7) == 0 && T >= 8;  // rows of the bf16 output gradient are 16-byte aligned: copy it in 16-byte units
         if (dtype == SET_DTYPE_BF16) hipLaunchKernelGGL((conv1d_wgrad3_bf16_kernel<false>), grid, dim3(256), 0, s, a);
+        else if (gu) hipLaunchKernelGGL((conv1d_wgrad3_bf16_kernel<true, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv1d_wgrad3_bf16_kernel<true>), grid, dim3(256), 0, s, a);
         const int rc = set_check_launch("set_conv1d_wgrad_det(bf16, 3 taps)");
         if (rc != SET_OK) return rc;
@@ -1066,9 +1140,17 @@ static int wgrad_bf16_launch(const void *g, const void *x, const float *chan_add
         a.chunks_per_slice = (total_chunks + S - 1) / S;
         a.ci_tiles = (Cin + 127) / 128;
         dim3 grid(K * a.ci_tiles, (Cout + 127) / 128, S * groups);
+        const bool gu = (T & 7) == 0 && T >= 8;                                     // (see the kernel: 16-byte units of a bf16 operand)
+        const bool xu = gu && K == 1 && pad == 0 && T_in == T;                      // the conv input too when no tap shifts it
         if (dtype == SET_DTYPE_BF16) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<false, false>), grid, dim3(256), 0, s, a);
-        else if (dtype == SET_DTYPE_BF16_G16) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, false>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, true>), grid, dim3(256), 0, s, a);
+        else if (dtype == SET_DTYPE_BF16_G16) {
+            if (gu) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, false, true, false>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, false>), grid, dim3(256), 0, s, a);
+        } else {
+            if (xu) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, true, true, true>), grid, dim3(256), 0, s, a);
+            else if (gu) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, true, true, false>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, true>), grid, dim3(256), 0, s, a);
+        }
         const int rc = set_check_launch("set_conv1d_wgrad_det(bf16)");
         if (rc != SET_OK) return rc;
     }
