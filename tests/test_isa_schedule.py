@@ -1,0 +1,40 @@
+"""Static guard on the compiled gfx950 ISA of the latency-critical kernels (no GPU: hipcc cross-compiles).
+
+DESIGN 3.5b / 3.5c: the one-block-per-CU kernels that stream weight fragments from L2 through a register ring only run as designed when
+the compiler keeps the ring pipelined -- round 4 found the row-split, step-boundary and layer-group kernels with `s_waitcnt vmcnt(0|1)` in
+front of most MFMAs (a ring drained every k-step: B = 1 latency 60 -> 45 ms once fixed).  The fix is a pinned k-step order in the source;
+this test compiles the files and fails if a later edit lets the drain come back."""
+import importlib.util
+import os
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("isa_scan", os.path.join(ROOT, "tools", "isa_scan.py"))
+isa_scan = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(isa_scan)
+
+HOT = {  # file -> kernel-name fragments whose MFMAs must not sit behind a drained ring
+    "diffnet_x3.hip": ("diffnet_stack_x3_kernel", "diffnet_stack_split_x2_kernel"),
+    "diffnet.hip": ("diffnet_boundary_x2_kernel",),
+    "diffnet_bf16.hip": ("diffnet_layers_t128_bf16_kernel", "diffnet_layers_reg_bf16_kernel", "diffnet_layer_fwd_bf16_kernel", "diffnet_layer_bwd_bf16_kernel"),
+}
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+@pytest.mark.parametrize("src", sorted(HOT))
+def test_weight_rings_stay_pipelined(src):
+    import re
+    seen = set()
+    for name, body in isa_scan.kernels(isa_scan.asm_of(os.path.join(isa_scan.CS, src))):
+        frag = next((f for f in HOT[src] if f in name), None)
+        if frag is None:
+            continue
+        seen.add(frag)
+        n_mfma = sum("v_mfma" in b for b in body)
+        drained = sum(1 for k, b in enumerate(body) if "v_mfma" in b and re.search(r"vmcnt\((0|1)\)", " ".join(body[max(0, k - 3):k])))
+        assert n_mfma >= 24, (name, n_mfma)
+        # a handful of MFMAs (the first k-step of a GEMM, a loop tail) legitimately follow a full wait; a drained ring shows up as > 40 %
+        assert drained * 10 <= n_mfma, "%s: %d of %d MFMAs sit right behind s_waitcnt vmcnt(0|1)" % (name, drained, n_mfma)
+    assert seen == set(HOT[src]), (seen, HOT[src])
