@@ -35,6 +35,7 @@ def test_weight_rings_stay_pipelined(src):
         n_mfma = sum("v_mfma" in b for b in body)
         drained = sum(1 for k, b in enumerate(body) if "v_mfma" in b and re.search(r"vmcnt\((0|1)\)", " ".join(body[max(0, k - 3):k])))
         assert n_mfma >= 24, (name, n_mfma)
-        # a handful of MFMAs (the first k-step of a GEMM, a loop tail) legitimately follow a full wait; a drained ring shows up as > 40 %
-        assert drained * 10 <= n_mfma, "%s: %d of %d MFMAs sit right behind s_waitcnt vmcnt(0|1)" % (name, drained, n_mfma)
+        # a handful of MFMAs (the first k-step of a GEMM, a loop tail: up to 12 % in the rolled loops of the layer-group kernels) legitimately
+        # follow a full wait; a drained ring showed up as 45 - 70 %
+        assert drained * 5 <= n_mfma, "%s: %d of %d MFMAs sit right behind s_waitcnt vmcnt(0|1)" % (name, drained, n_mfma)
     assert seen == set(HOT[src]), (seen, HOT[src])
