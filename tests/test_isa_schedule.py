@@ -82,3 +82,37 @@ def test_shipped_kernels_are_spill_free_except_the_listed_ones():
                     offenders.append((f, cur, int(m.group(1)), limit))
     assert n_kernels > 100, n_kernels
     assert not offenders, offenders
+
+
+STORE_GUARD = {  # file -> kernel-name fragments whose epilogue stores must not each wait for the previous store
+    "bf16.hip": ("conv1d_bf16_kernel", "conv1x1_oneshot_bf16_kernel"),
+    "conv_x2.hip": ("conv1d_x2_kernel",),
+    "resblock_x2.hip": ("resblock_pair_x2_kernel",),
+}
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+@pytest.mark.parametrize("src", sorted(STORE_GUARD))
+def test_epilogue_stores_do_not_serialise(src):
+    """`if (valid) buffer_store(...)` per accumulator element compiles to one basic block per element with `s_waitcnt vmcnt(0)` in each
+    (the wait-count pass cannot know whether the previous block ran), and vmcnt retires stores in issue order: every store then waits
+    for the one before (64 - 110 such blocks per kernel before round 4).  The epilogues mask lanes by buffer range instead."""
+    import re
+    seen = set()
+    for name, body in isa_scan.kernels(isa_scan.asm_of(os.path.join(isa_scan.CS, src))):
+        frag = next((f for f in STORE_GUARD[src] if f in name), None)
+        if frag is None:
+            continue
+        seen.add(frag)
+        blocks, cur = [], []
+        for b in body:
+            t = b.strip()
+            if t.startswith(".LBB") or t.startswith("; %bb."):
+                blocks.append(cur)
+                cur = []
+            cur.append(t)
+        blocks.append(cur)
+        ser = sum(1 for blk in blocks if 1 <= sum(x.startswith(("buffer_store", "global_store", "flat_store")) for x in blk) <= 2
+                  and any(re.search(r"vmcnt\(0\)", x) for x in blk))
+        assert ser <= 12, "%s: %d basic blocks hold a store behind s_waitcnt vmcnt(0)" % (name, ser)
+    assert seen == set(STORE_GUARD[src]), (seen, STORE_GUARD[src])
