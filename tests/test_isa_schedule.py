@@ -15,6 +15,27 @@ spec = importlib.util.spec_from_file_location("isa_scan", os.path.join(ROOT, "to
 isa_scan = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(isa_scan)
 
+@pytest.fixture(scope="module")
+def compiled():
+    """Every csrc/*.hip compiled once for gfx950 (device only, -S, resource-usage remarks), in parallel: {file: (ISA lines, remarks)}."""
+    import subprocess
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    files = sorted(f for f in os.listdir(isa_scan.CS) if f.endswith(".hip"))
+
+    def one(f):
+        out = os.path.join(tempfile.gettempdir(), "isa_test_%d_%s.s" % (os.getpid(), f))
+        r = subprocess.run(["hipcc"] + isa_scan.FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-o", out, os.path.join(isa_scan.CS, f)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = open(out).read().split("\n")
+        os.remove(out)
+        return f, (lines, r.stderr)
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        return dict(ex.map(one, files))
+
+
 HOT = {  # file -> kernel-name fragments whose MFMAs must not sit behind a drained ring
     "diffnet_x3.hip": ("diffnet_stack_x3_kernel", "diffnet_stack_split_x2_kernel"),
     "diffnet.hip": ("diffnet_boundary_x2_kernel",),
@@ -24,10 +45,10 @@ HOT = {  # file -> kernel-name fragments whose MFMAs must not sit behind a drain
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
 @pytest.mark.parametrize("src", sorted(HOT))
-def test_weight_rings_stay_pipelined(src):
+def test_weight_rings_stay_pipelined(src, compiled):
     import re
     seen = set()
-    for name, body in isa_scan.kernels(isa_scan.asm_of(os.path.join(isa_scan.CS, src))):
+    for name, body in isa_scan.kernels(compiled[src][0]):
         frag = next((f for f in HOT[src] if f in name), None)
         if frag is None:
             continue
@@ -49,24 +70,11 @@ ALLOWED_SPILLS = {  # kernels that ship with scratch; everyth
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
-def test_shipped_kernels_are_spill_free_except_the_listed_ones():
+def test_shipped_kernels_are_spill_free_except_the_listed_ones(compiled):
     """Round 3's review found experiment variants with 26 - 58 spilled registers compiled into the library; they are gone, and this keeps it so:
     every kernel of every csrc/*.hip is compiled for gfx950 and its `VGPRs Spill` remark checked."""
     import re
-    import subprocess
-    import tempfile
-    from concurrent.futures import ThreadPoolExecutor
-    files = sorted(f for f in os.listdir(isa_scan.CS) if f.endswith(".hip"))
-
-    def remarks(f):
-        out = os.path.join(tempfile.gettempdir(), "isa_spill_" + f + ".s")
-        r = subprocess.run(["hipcc"] + isa_scan.FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-o", out, os.path.join(isa_scan.CS, f)],
-                           capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-2000:]
-        return f, r.stderr
-
-    with ThreadPoolExecutor(max_workers=6) as ex:
-        results = list(ex.map(remarks, files))
+    results = [(f, v[1]) for f, v in sorted(compiled.items())]
     n_kernels, offenders = 0, []
     for f, text in results:
         cur = None
@@ -93,13 +101,13 @@ STORE_GUARD = {  # file -> kernel-name fragments whose epilogue stores must not 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
 @pytest.mark.parametrize("src", sorted(STORE_GUARD))
-def test_epilogue_stores_do_not_serialise(src):
+def test_epilogue_stores_do_not_serialise(src, compiled):
     """`if (valid) buffer_store(...)` per accumulator element compiles to one basic block per element with `s_waitcnt vmcnt(0)` in each
     (the wait-count pass cannot know whether the previous block ran), and vmcnt retires stores in issue order: every store then waits
     for the one before (64 - 110 such blocks per kernel before round 4).  The epilogues mask lanes by buffer range instead."""
     import re
     seen = set()
-    for name, body in isa_scan.kernels(isa_scan.asm_of(os.path.join(isa_scan.CS, src))):
+    for name, body in isa_scan.kernels(compiled[src][0]):
         frag = next((f for f in STORE_GUARD[src] if f in name), None)
         if frag is None:
             continue
