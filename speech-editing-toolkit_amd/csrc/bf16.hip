@@ -21,6 +21,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -504,7 +505,6 @@ __device__ __forceinline__ unsigned buf_load_raw16(rsrc_t r, unsigned voff, unsi
 // go to LDS unchanged (no prologue, no per-channel add on such an operand).
 template <bool GB16, bool XB16, bool GU = false, bool XU = false>  // GU / XU: that operand is copied in 16-byte units (host: wgrad_units_ok)
 __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args a) {
-    static_assert((!GU || GB16) && (!XU || XB16), "16-byte units need an operand that already is bf16");
     __shared__ __attribute__((aligned(16))) unsigned char Gs[128 * WGB_ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char Xs[128 * WGB_ROWB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -541,8 +541,10 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
     // bound by the staging instructions.  Same bits in the same LDS cells as the element-wise path (which stays for ragged T).
     // The path is a template parameter, not a run-time test: with both paths in one kernel the wait-count pass drained the next chunk's loads
     // in front of the MFMAs at the join of the two branches.
+    // An fp32 operand takes the same route in units of 4 frames (16 bytes; 8 units per thread, converted at the LDS write: one 8-byte write).
     constexpr bool fastg = GU, fastx = XU;
-    const int urow = tid >> 3, ucol = tid & 7;
+    const int urow = tid >> 3, ucol = tid & 7;      // bf16 units: 8 per row, 32 rows per pass
+    const int urow4 = tid >> 4, ucol4 = tid & 15;   // fp32 units: 16 per row, 16 rows per pass
     auto issue = [&](int ch) {
         const int b = ch / a.n_chunks_t, t0 = (ch % a.n_chunks_t) * WGB_KT;
         const unsigned vg = (unsigned)min(t0 + sk, a.T - 1) * GE;
@@ -550,10 +552,17 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
         const rsrc_t d_g = make_rsrc(reinterpret_cast<const unsigned char *>(a.g) + (int64_t)b * a.Cout * a.T * GE);
         const rsrc_t d_x = make_rsrc(reinterpret_cast<const unsigned char *>(a.x) + (int64_t)b * a.Cin * a.T_in * XE);
         const rsrc_t d_a = make_rsrc(has_add ? a.chan_add + (int64_t)b * a.Cin : reinterpret_cast<const float *>(a.x));
-        if constexpr (fastg) {  // 16 bytes = 8 frames of one row per load: 4 loads per thread instead of 32 two-byte ones
+        if constexpr (fastg && GB16) {  // 16 bytes = 8 frames of one row per load: 4 loads per thread instead of 32 two-byte ones
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const unsigned vo = (unsigned)(min(co0 + urow + 32 * q, a.Cout - 1) * a.T + min(t0 + 8 * ucol, a.T - 8)) * 2u;
+                const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_g, (int)vo, 0, 0);
+                gv[4 * q] = v[0]; gv[4 * q + 1] = v[1]; gv[4 * q + 2] = v[2]; gv[4 * q + 3] = v[3];
+            }
+        } else if constexpr (fastg) {  // fp32: 16 bytes = 4 frames
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned vo = (unsigned)(min(co0 + urow4 + 16 * q, a.Cout - 1) * a.T + min(t0 + 4 * ucol4, a.T - 4)) * 4u;
                 const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_g, (int)vo, 0, 0);
                 gv[4 * q] = v[0]; gv[4 * q + 1] = v[1]; gv[4 * q + 2] = v[2]; gv[4 * q + 3] = v[3];
             }
@@ -564,12 +573,21 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
                 gv[j] = GB16 ? buf_load_raw16(d_g, vg, so) : buf_load_raw(d_g, vg, so);
             }
         }
-        if constexpr (fastx) {
+        if constexpr (fastx && XB16) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const unsigned vo = (unsigned)(min(ci0 + urow + 32 * q, a.Cin - 1) * a.T_in + min(t0 + 8 * ucol, a.T_in - 8)) * 2u;
                 const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_x, (int)vo, 0, 0);
                 xv[4 * q] = v[0]; xv[4 * q + 1] = v[1]; xv[4 * q + 2] = v[2]; xv[4 * q + 3] = v[3];
+            }
+        } else if constexpr (fastx) {  // fp32: 16 bytes = 4 frames; the per-channel add of the unit's row rides along (dummy address without one)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int cic = min(ci0 + urow4 + 16 * q, a.Cin - 1);
+                const unsigned vo = (unsigned)(cic * a.T_in + min(t0 + 4 * ucol4, a.T_in - 4)) * 4u;
+                const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_x, (int)vo, 0, 0);
+                xv[4 * q] = v[0]; xv[4 * q + 1] = v[1]; xv[4 * q + 2] = v[2]; xv[4 * q + 3] = v[3];
+                av[q] = buf_load(d_a, (unsigned)cic * 4u, 0u);
             }
         } else {
 #pragma unroll
@@ -585,7 +603,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
         const int t0 = (ch % a.n_chunks_t) * WGB_KT;
         const int t = t0 + sk, ti = t + shift;
         const bool tv = t < a.T, tiv = tv && ti >= 0 && ti < a.T_in;
-        if constexpr (fastg) {
+        if constexpr (fastg && GB16) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = urow + 32 * q;
@@ -594,8 +612,21 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
                 v[0] = ok ? gv[4 * q] : 0u; v[1] = ok ? gv[4 * q + 1] : 0u; v[2] = ok ? gv[4 * q + 2] : 0u; v[3] = ok ? gv[4 * q + 3] : 0u;
                 *reinterpret_cast<u32x4 *>(Gs + row * WGB_ROWB + ucol * 16) = v;
             }
+        } else if constexpr (fastg) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = urow4 + 16 * q;
+                const bool ok = t0 + 4 * ucol4 < a.T && co0 + row < a.Cout;  // T % 4 == 0
+                unsigned short h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = bf16_bits(__builtin_bit_cast(float, gv[4 * q + e]));
+                u32x2 w;
+                w[0] = ok ? ((unsigned)h[0] | ((unsigned)h[1] << 16)) : 0u;
+                w[1] = ok ? ((unsigned)h[2] | ((unsigned)h[3] << 16)) : 0u;
+                *reinterpret_cast<u32x2 *>(Gs + row * WGB_ROWB + ucol4 * 8) = w;
+            }
         }
-        if constexpr (fastx) {
+        if constexpr (fastx && XB16) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = urow + 32 * q;
@@ -603,6 +634,22 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
                 u32x4 v;
                 v[0] = ok ? xv[4 * q] : 0u; v[1] = ok ? xv[4 * q + 1] : 0u; v[2] = ok ? xv[4 * q + 2] : 0u; v[3] = ok ? xv[4 * q + 3] : 0u;
                 *reinterpret_cast<u32x4 *>(Xs + row * WGB_ROWB + ucol * 16) = v;
+            }
+        } else if constexpr (fastx) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = urow4 + 16 * q;
+                const bool ok = t0 + 4 * ucol4 < a.T && t0 + 4 * ucol4 < a.T_in && ci0 + row < a.Cin;
+                unsigned short h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xf = __builtin_bit_cast(float, xv[4 * q + e]);
+                    h[e] = bf16_bits(pro_c<kPro>(has_add ? xf + av[q] : xf, a.pro_param));  // same arithmetic as the element-wise path
+                }
+                u32x2 w;
+                w[0] = ok ? ((unsigned)h[0] | ((unsigned)h[1] << 16)) : 0u;
+                w[1] = ok ? ((unsigned)h[2] | ((unsigned)h[3] << 16)) : 0u;
+                *reinterpret_cast<u32x2 *>(Xs + row * WGB_ROWB + ucol4 * 8) = w;
             }
         }
         if constexpr (!fastg || !fastx) {
@@ -1140,11 +1187,15 @@ static int wgrad_bf16_launch(const void *g, const void *x, const float *chan_add
         a.chunks_per_slice = (total_chunks + S - 1) / S;
         a.ci_tiles = (Cin + 127) / 128;
         dim3 grid(K * a.ci_tiles, (Cout + 127) / 128, S * groups);
-        const bool gu = (T & 7) == 0 && T >= 8;                                     // (see the kernel: 16-byte units of a bf16 operand)
+        const bool gu = (T & 7) == 0 && T >= 8;                                     // (see the kernel: 16-byte units of an operand)
         const bool xu = gu && K == 1 && pad == 0 && T_in == T;                      // the conv input too when no tap shifts it
-        if (dtype == SET_DTYPE_BF16) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<false, false>), grid, dim3(256), 0, s, a);
-        else if (dtype == SET_DTYPE_BF16_G16) {
-            if (gu) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, false, true, false>), grid, dim3(256), 0, s, a);
+        if (dtype == SET_DTYPE_BF16) {
+            if (xu) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<false, false, true, true>), grid, dim3(256), 0, s, a);
+            else if (gu) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<false, false, true, false>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<false, false>), grid, dim3(256), 0, s, a);
+        } else if (dtype == SET_DTYPE_BF16_G16) {
+            if (xu) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, false, true, true>), grid, dim3(256), 0, s, a);
+            else if (gu) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, false, true, false>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, false>), grid, dim3(256), 0, s, a);
         } else {
             if (xu) hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<true, true, true, true>), grid, dim3(256), 0, s, a);
