@@ -234,11 +234,33 @@ def _free_port():
 
 
 def stub_device():
-    """Test hook (tests/test_dist_gloo.py): SET_AMD_BENCH_STUB_DEVICE=cpu runs `--mode train` with NO kernels -- a toy torch-CPU
-    module stands in for the task, gloo for RCCL -- so that the self-launch, rendezvous, rank-0 broadcast, sharding, hook-launched
-    bucket all-reduce, barrier / max-over-ranks timing and the rank-0 JSON line can be driven end to end on a box without GPUs.
-    The line it prints says so ("device": "cpu-stub", "value" is not a measurement of this framework)."""
+    """Test hook (tests/test_dist_gloo.py): SET_AMD_BENCH_STUB_DEVICE=cpu runs either mode with NO kernels -- a toy torch-CPU
+    module stands in for the task / the model, gloo for RCCL -- so that the self-launch, rendezvous, rank-0 broadcast, sharding,
+    hook-launched bucket all-reduce (train), barrier / max-over-ranks timing, the all-gather of per-rank times and the rank-0 JSON
+    line can be driven end to end on a box without GPUs.  The line it prints says so ("device": "cpu-stub", "value" is not a
+    measurement of this framework)."""
     return os.environ.get("SET_AMD_BENCH_STUB_DEVICE", "") == "cpu"
+
+
+class _StubInferModel:
+    """Stands in for GaussianDiffusion when SET_AMD_BENCH_STUB_DEVICE=cpu (`--mode infer`): same call signature and the same keys in
+    the returned dict as the real forward(infer=True, want_layer_spans=True); the "mel" is a function of the rank's OWN shard so that
+    the test can see the utterance sharding."""
+
+    class _Dn:
+        dilation_cycle_length = 1
+
+    denoise_fn = _Dn()
+
+    def __call__(self, txt_tokens, time_mel_masks, mel2ph, spk_embed, ref_mels, f0, uv, infer=True, seed=0, want_layer_spans=False):
+        t0 = time.perf_counter()
+        mel = torch.tanh(ref_mels * (1.0 - time_mel_masks)) + 1e-3 * float(seed % 7)
+        time.sleep(0.002 * ref_mels.shape[0] / B_PER_GPU)
+        ms = 1e3 * (time.perf_counter() - t0)
+        ret = {"mel_out": mel}
+        if want_layer_spans:
+            ret.update(layer_span_ms=[ms / DIFF_STEPS] * DIFF_STEPS, loop_ms=ms, n_groups=1, persistent=1)
+        return ret
 
 
 def _sync(dev):
@@ -279,7 +301,8 @@ def run_infer(args, rank, world, dev):
     from set_amd import _lib, parallel
     from set_amd.synthetic import synthetic_inputs
     torch.set_grad_enabled(False)
-    model = build_model(dev, DIFF_STEPS)
+    stub = stub_device()
+    model = _StubInferModel() if stub else build_model(dev, DIFF_STEPS)
     # global batch = 32 per rank; every rank takes its utterances r::world of the same synthetic batch
     full = synthetic_inputs(B_PER_GPU * world, T, T_TXT, seed=1234)
     inp = {k: v.to(dev) for k, v in parallel.shard_batch(full, rank, world).items()}
@@ -290,7 +313,7 @@ def run_infer(args, rank, world, dev):
 
     for w in range(args.warmup):
         step(1000 + w)
-    torch.cuda.synchronize()
+    _sync(dev)
     parallel.barrier()
     spans, loop_ms, groups = [], [], 1
     t0 = time.perf_counter()
@@ -299,12 +322,16 @@ def run_infer(args, rank, world, dev):
         spans.extend(ret["layer_span_ms"])
         loop_ms.append(ret["loop_ms"])
         groups = ret["n_groups"]
-    torch.cuda.synchronize()
+    _sync(dev)
     elapsed = time.perf_counter() - t0
     parallel.barrier()
     t_max = parallel.max_over_ranks(elapsed, device=dev if world > 1 else "cpu")
     assert torch.isfinite(ret["mel_out"]).all()
+    assert ret["mel_out"].shape[0] == B_PER_GPU, "this rank did not get %d utterances of the global batch" % B_PER_GPU
     facts = dist_facts(dev, world, elapsed)
+    # every rank's shard is r::world of ONE global batch (speech_base.py:128-131): the first utterance ids add up accordingly
+    first_ids = parallel.sum_over_ranks(float(rank), device=dev if world > 1 else "cpu")
+    assert first_ids == world * (world - 1) / 2
 
     frames = B_PER_GPU * world * T * args.steps
     value = frames / t_max
@@ -357,8 +384,11 @@ def run_infer(args, rank, world, dev):
             traffic_note = "PMC passes of this kernel build (%s, source sha256 matches)" % tname
         else:
             traffic_note = "withheld: the kernel sources changed since the PMC passes in %s" % tname
+    extras = rank == 0 and world == 1 and not stub  # the comparison lines and sub-benchmarks of the 1-GPU default run
     out = {
-        "metric": "diffusion mel-frames/s (100-step p_sample, B=32/GPU, T=800)",
+        "metric": "diffusion mel-frames/s (100-step p_sample, B=32/GPU, T=800)" if not stub else
+                  "STUB (toy torch-CPU model over gloo: exercises bench.py's launch / sharding / timing path, measures nothing of this framework)",
+        **({"device": "cpu-stub", "stub_shard_checksum": float(ret["mel_out"].double().sum())} if stub else {}),
         "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32 (operands carried as %s, fp32 accumulate: fp32-equivalent, see roofline.note)" % (
@@ -411,18 +441,18 @@ def run_infer(args, rank, world, dev):
                               "loop on the exact 24-bit splitting")
                      if split_operands else None},
     }
-    if rank == 0 and world == 1 and not args.no_quality:
+    if extras and not args.no_quality:
         out.update(quality_vs_oracle(model))
-    if rank == 0 and world == 1 and split_operands and not args.no_native_fp32:
+    if extras and split_operands and not args.no_native_fp32:
         out["native_fp32_loop"] = native_fp32_line(model, inp, args, step(0)["mel_out"])
-    if rank == 0 and world == 1 and split_operands and variant == 5 and not args.no_bf16x3_loop:
+    if extras and split_operands and variant == 5 and not args.no_bf16x3_loop:
         out["bf16x3_operand_loop"] = bf16x3_line(model, inp, args, step(0)["mel_out"])
-    if rank == 0 and world == 1 and not args.no_bf16_loop:
+    if extras and not args.no_bf16_loop:
         out["bf16_operand_loop"] = bf16_loop_line(model, inp, args, ret_f32_seed0=step(0)["mel_out"])
-    if rank == 0 and world == 1 and args.cpu_baseline != "off":
+    if extras and args.cpu_baseline != "off":
         out["cpu_baseline"] = cpu_baseline(model, inp, args.cpu_baseline)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if extras and not args.no_secondary:
         # the other BASELINE configs, each in a process of its own (fresh hparams / allocator; this process idles meanwhile)
         del model
         torch.cuda.empty_cache()
@@ -835,8 +865,6 @@ def main():
     args = ap.parse_args()
 
     stub = stub_device()
-    if stub and args.mode != "train":
-        raise SystemExit("SET_AMD_BENCH_STUB_DEVICE is a test hook of --mode train only")
     if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the set_amd hot path has no CPU fallback")
     maybe_self_launch(args)

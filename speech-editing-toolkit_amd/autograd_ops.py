@@ -44,10 +44,27 @@ class _ZeroArena:
 
 _ARENAS = {}        # owner id -> _ZeroArena
 _ACTIVE = [None]    # the arena of the optimisation step in progress (steps do not nest)
-# Buffers replaced by a larger one are parked here instead of being freed: a captured training step holds the ADDRESS of the arena /
-# scratch buffers it was captured with, and a freed buffer is handed to other tensors by the allocator.  Growth is geometric, so the
-# parked buffers sum to a small multiple of the final size.
+# While a captured training step exists (training.GraphedTrainStep: GRAPHS_ALIVE[0] > 0) buffers replaced by a larger one are parked here
+# instead of being freed: the captured step holds the ADDRESS of the arena / scratch buffers it was captured with, and a freed buffer is
+# handed to other tensors by the allocator.  Without a captured step (plain eager training) a replaced buffer is simply dropped.  Growth is
+# geometric (x 1.5 of the current size at least), so the parked buffers sum to a small multiple of the final size.
 _RETIRED = []
+GRAPHS_ALIVE = [0]
+
+
+def _retire(buf):
+    if GRAPHS_ALIVE[0] > 0:
+        _RETIRED.append(buf)
+
+
+def graph_captured():
+    GRAPHS_ALIVE[0] += 1
+
+
+def graph_released():
+    GRAPHS_ALIVE[0] = max(0, GRAPHS_ALIVE[0] - 1)
+    if GRAPHS_ALIVE[0] == 0:
+        del _RETIRED[:]
 CAPTURED_ABORT_WORDS = []  # sync workspaces of persistent stack kernels inside captured steps ([1] != 0: a dependency wait timed out)
 
 
@@ -55,8 +72,9 @@ def zero_arena_begin(device, min_floats=0, owner=None):
     a = _ARENAS.setdefault(id(owner), _ZeroArena())
     want = max(int(min_floats), int(a.need * 1.05) + 4096)
     if a.buf is None or a.buf.device != device or a.buf.numel() < want:
-        if a.buf is not None:
-            _RETIRED.append(a.buf)
+        if a.buf is not None and a.buf.device == device:
+            _retire(a.buf)
+            want = max(want, int(a.buf.numel() * 1.5))
         a.buf = torch.empty(want, dtype=torch.float32, device=device)
     a.buf.zero_()
     a.off, a.need = 0, 0
@@ -108,7 +126,7 @@ def _det_scratch(device, n_floats):
     buf = _DET_SCRATCH.get(device)
     if buf is None or buf.numel() < n_floats:
         if buf is not None:
-            _RETIRED.append(buf)
+            _retire(buf)
         buf = torch.empty(int(n_floats * 1.25) + 4096, dtype=torch.float32, device=device)
         _DET_SCRATCH[device] = buf
     return buf
@@ -140,7 +158,7 @@ def conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro=0, pr
     buf = _WG_SCRATCH.get(g.device)
     if buf is None or buf.numel() < need:
         if buf is not None:
-            _RETIRED.append(buf)
+            _retire(buf)
         buf = torch.empty(int(need * 1.25) + 1024, dtype=torch.float32, device=g.device)
         _WG_SCRATCH[g.device] = buf
     check(L().set_conv1d_wgrad_det(_p(g), _p(x), _p(chan_add), ptr, B, Cin, Cout, K, dil, pad, T, T_in, pro,
@@ -154,7 +172,7 @@ def conv_wgrad_grouped(g, x, chan_add, dw_ptr, groups, g_gs, x_gs, add_gs, dw_gs
     buf = _WG_SCRATCH.get(g.device)
     if buf is None or buf.numel() < need:
         if buf is not None:
-            _RETIRED.append(buf)
+            _retire(buf)
         buf = torch.empty(int(need * 1.25) + 1024, dtype=torch.float32, device=g.device)
         _WG_SCRATCH[g.device] = buf
     check(L().set_conv1d_wgrad_det_grouped(_p(g), _p(x), _p(chan_add), C.c_void_p(dw_ptr), groups, g_gs, x_gs, add_gs, dw_gs, B, Cin,

@@ -1987,7 +1987,10 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
             fa.dstep = a.dstep + sid; fa.d_bs = 0; fa.d_cs = a.steps; fa.d_ls = (int64_t)DC * a.steps;
             fa.img = reinterpret_cast<const uint16_t *>(a.img16_all) + (int64_t)l * set_diffnet_layer_bf16_image_size();
             fa.b_dil = a.b_dil_all + (int64_t)l * 512; fa.b_cond = a.b_cond_all + (int64_t)l * 512; fa.b_out = a.b_out_all + (int64_t)l * 512;
-            fa.scratch = a.bf16_ws; fa.scratch_floats = a.bf16_ws_floats;  // the groups run one after the other: one buffer
+            // utterance groups (n_groups > 1) run concurrently on their own streams and the 128-frame kernel indexes its private skip
+            // rows by (blockIdx.y, blockIdx.x) of its own launch: every group gets its own slice (per-utterance floats do not depend on B)
+            const int64_t per_utt = set_diffnet_layers_bf16_scratch_floats(1, T, 0, fuse, a.dilation_cycle_length);
+            fa.scratch = a.bf16_ws + (int64_t)b0 * per_utt; fa.scratch_floats = (int64_t)Bg * per_utt;
             fa.B = Bg; fa.T = T; fa.l0 = l; fa.nl = L - l < fuse ? L - l : fuse; fa.dilation_cycle_length = a.dilation_cycle_length;
             fa.first = (l == 0);
             rc = set_diffnet_layers_fwd_bf16(&fa, s);

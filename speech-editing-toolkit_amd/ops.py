@@ -873,7 +873,9 @@ def diffusion_loop(*, x, noise, seed, condproj, dstep, coef4, w_in, b_in, packs,
         loop_ms = C.c_float(0.0)
         a.loop_ms = C.pointer(loop_ms)
     check(_lib.lib().set_diffusion_loop(C.byref(a), _stream()), "set_diffusion_loop")
-    if a.persistent and (bf16 is None or use_bx2):  # (one 4-byte read-back per reverse loop; fail loudly, never return garbage)
+    # one 4-byte read-back per reverse loop; fail loudly, never return garbage.  The range word can be raised by the persistent stack kernel
+    # AND by the split-operand step boundary, which the bf16 loop takes whether or not `persistent` is set
+    if a.persistent or use_bx2:
         code = int(err.item())
         if code == 2:
             raise SplitRangeError("set_diffusion_loop: an activation of magnitude >= 32768 is outside the range of the fp16 "

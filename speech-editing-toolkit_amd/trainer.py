@@ -12,8 +12,8 @@ What is deliberately different from the reference (and why):
 * `global_step` counts OPTIMIZER UPDATES; with `accumulate_grad_batches` = a > 1 an update consumes a batches (the
   reference counts batches and steps the optimizer on every a-th, scheduling on global_step // a): `max_updates`,
   `val_check_interval`, the warm-up and the step number in checkpoint names therefore mean a times more data here than in
-  a reference run with the same yaml; a checkpoint without the `global_step_unit` key resumed with a > 1 is read as updates
-  with a warning, or as batches / a with hparams['resume_global_step_unit'] = 'batches' (a reference-written checkpoint);
+  a reference run with the same yaml; a checkpoint without the `global_step_unit` key resumed with a > 1 takes its unit from
+  hparams['resume_global_step_unit'] = 'updates' | 'batches', else from the restored optimizer's own step count, else is refused;
 * the optimizer is the fused flat AdamW (training.FlatAdamW) whose state_dict is torch.optim.AdamW's, so checkpoints
   interchange (`optimizer_states[0]`); clip + schedule are inside its step (base_task.py:129-137).
 No tensorboard, no progress bars, no code snapshots: logging is a dict per `log_interval` updates on rank 0.
@@ -125,16 +125,29 @@ class Trainer:
         if self.global_step > 0:
             self.best_val_results = meta.get("checkpoint_callback_best")
             if self.accumulate_grad_batches > 1 and meta.get("global_step_unit") != "updates":
-                # a checkpoint without the key is either the reference trainer's (global_step counts BATCHES) or one this trainer
-                # wrote before the key existed (it already counted updates): hparams['resume_global_step_unit'] = 'updates' |
-                # 'batches' settles it; unset, the run continues on the assumption "updates" with a warning instead of refusing
+                # a checkpoint without the key is either the reference trainer's (global_step counts BATCHES) or one this trainer wrote
+                # before the key existed (it already counted updates).  hparams['resume_global_step_unit'] = 'updates' | 'batches' settles
+                # it; unset, the restored optimizer's own step count decides (updates: == global_step, batches: == global_step // a); if
+                # neither fits the run is refused -- a silent wrong guess mis-schedules warm-up, lr, validation and max_updates by a
                 unit = hparams.get("resume_global_step_unit")
+                if unit not in ("updates", "batches"):
+                    n_opt = int(getattr(self.optimizer, "num_updates", -1))
+                    a = self.accumulate_grad_batches
+                    if n_opt > 0 and n_opt == self.global_step:
+                        unit = "updates"
+                    elif n_opt > 0 and n_opt in (self.global_step // a, (self.global_step + a - 1) // a):
+                        unit = "batches"
+                    else:
+                        raise RuntimeError(
+                            "resuming a checkpoint without 'global_step_unit' under accumulate_grad_batches=%d: cannot tell whether its "
+                            "global_step=%d counts optimizer updates or batches (optimizer step count %d); set "
+                            "resume_global_step_unit=updates|batches (a reference-written checkpoint counts batches)"
+                            % (a, self.global_step, n_opt))
+                    if self.rank == 0:
+                        print("| resume: checkpoint has no 'global_step_unit'; optimizer step count %d => global_step counts %s"
+                              % (n_opt, unit), flush=True)
                 if unit == "batches":
                     self.global_step //= self.accumulate_grad_batches
-                elif unit != "updates" and self.rank == 0:
-                    print("| WARNING: resuming a checkpoint without 'global_step_unit' under accumulate_grad_batches=%d; reading its "
-                          "global_step as optimizer updates (a reference-written checkpoint counts batches: set "
-                          "resume_global_step_unit=batches)" % self.accumulate_grad_batches, flush=True)
         task.global_step = self.global_step
         # barrier, rank-0 parameter / buffer / optimizer-state broadcast, barrier (trainer.py:166-170,402,475-479)
         parallel.configure_ddp(model, self.optimizer)

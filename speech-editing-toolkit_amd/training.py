@@ -220,6 +220,10 @@ class GraphedTrainStep:
         self.hyper = self.seed_delta = self.stream = None
         self.replays = 0
 
+    def __del__(self):
+        for _ in range(getattr(self, "_n_captured", 0)):
+            A.graph_released()
+
     def usable(self):
         dev = self.opt.flat_p.device
         return (dev.type == "cuda" and os.environ.get("SET_AMD_GRAPH_STEP", "0") == "1" and not self.opt.bucketer.enabled)
@@ -273,6 +277,8 @@ class GraphedTrainStep:
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         del A.CAPTURED_ABORT_WORDS[:]
+        A.graph_captured()  # from here on replaced arena / scratch buffers are parked, not freed (the graph holds their addresses)
+        self._n_captured = getattr(self, "_n_captured", 0) + 1
         with torch.cuda.graph(g):
             total, parts, _ = _optimisation_step(self.task, e["static"], self.opt, _graph_hyper=self.hyper, **kw)
             names = sorted(parts)
@@ -305,6 +311,9 @@ class GraphedTrainStep:
             self.hyper[2:3].fill_(bc2)
             e["graph"].replay()
             self.replays += 1
+            # the replay updated the parameters: host-side packed-weight caches (packed() / packed_x2(), keyed on the weights epoch) built by
+            # eager work between replays are stale now -- FlatAdamW.step's own bump ran only once, at capture time
+            ops.bump_weights_epoch()
             out = e["out"].clone()  # the graph's output tensors are overwritten by the next replay
         cur.wait_stream(self.stream)
         out.record_stream(cur)

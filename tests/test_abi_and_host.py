@@ -418,3 +418,53 @@ def test_bf16_layer_group_plan_and_scratch_size():
     assert L.set_diffnet_layers_bf16_scratch_floats(32, 800, 0, 10, 1) == 32 * 8 * 256 * 128
     assert L.set_diffnet_layers_bf16_scratch_floats(64, 800, 0, 10, 1) == 64 * 8 * 256 * 128
     assert L.set_diffnet_layers_bf16_scratch_floats(32, 800, 0, 5, 1) == 32 * 7 * 256 * 128   # halo 4: 120 stored frames -> 7 tiles
+
+
+def _cold_build_worker(pkg_copy, q, barrier):
+    """One of N ranks calling _lib.build() at the same moment on a tree without objects or library."""
+    import importlib.util
+    import subprocess as sp
+    spec = importlib.util.spec_from_file_location("_lib_cold", os.path.join(pkg_copy, "speech-editing-toolkit_amd", "_lib.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    m.SOURCES = ["glue.hip", "attention.hip"]  # two small translation units: the test is about the locking, not about the compiler
+    n_compiles = [0]
+    real_popen = sp.Popen
+
+    def counting_popen(cmd, *a, **kw):
+        n_compiles[0] += 1
+        return real_popen(cmd, *a, **kw)
+    m.subprocess.Popen = counting_popen
+    barrier.wait()
+    path = m.build()
+    q.put((os.getpid(), path, n_compiles[0], os.path.exists(path), os.path.getsize(path)))
+
+
+def test_concurrent_cold_builds_compile_once_and_never_expose_a_partial_library(tmp_path):
+    """`torchrun --nproc-per-node N bench.py` calls _lib.build() from every rank of a fresh checkout.  Four processes
+    released by a barrier onto a COLD copy of the sources (no objects, no library): exactly one of them compiles (flock on
+    libset_amd.so.lock, staleness re-checked under the lock), the others wait and return the finished file; the library appears by an
+    atomic rename (no rank can dlopen a half-written file) and no temporary is left behind."""
+    import shutil
+    import torch.multiprocessing as mp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    copy = str(tmp_path / "tree")
+    os.makedirs(os.path.join(copy, "speech-editing-toolkit_amd"))
+    shutil.copytree(os.path.join(root, "speech-editing-toolkit_amd", "csrc"), os.path.join(copy, "speech-editing-toolkit_amd", "csrc"))
+    shutil.copy(os.path.join(root, "speech-editing-toolkit_amd", "_lib.py"), os.path.join(copy, "speech-editing-toolkit_amd", "_lib.py"))
+    shutil.copytree(os.path.join(root, "include"), os.path.join(copy, "include"))
+    ctx = mp.get_context("spawn")
+    q, barrier = ctx.Queue(), ctx.Barrier(4)
+    procs = [ctx.Process(target=_cold_build_worker, args=(copy, q, barrier)) for _ in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lib = os.path.join(copy, "speech-editing-toolkit_amd", "libset_amd.so")
+    assert all(r[1] == lib and r[3] for r in res)
+    assert len({r[4] for r in res}) == 1 and res[0][4] > 0          # every rank saw the same, complete file
+    assert sorted(r[2] for r in res) == [0, 0, 0, 3]                 # ONE builder ran 2 compiles + 1 link, three waited
+    left = [f for f in os.listdir(os.path.dirname(lib)) if ".tmp." in f]
+    assert not left, left

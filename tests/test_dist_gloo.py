@@ -295,3 +295,46 @@ def test_bench_train_mode_launches_its_own_ranks_end_to_end_on_a_stubbed_device(
         r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "train"], env=env3,
                             capture_output=True, text=True, timeout=300)
         assert r3.returncode != 0 and "needs an MI355X" in (r3.stderr + r3.stdout)
+
+
+def test_bench_infer_mode_launches_its_own_ranks_end_to_end_on_a_stubbed_device():
+    """`python bench.py --gpus 2` (default --mode infer) is the command the driver's scaling run issues; its world > 1
+    branches -- self-launch under torch.distributed.run on 127.0.0.1, shard_batch r::N of ONE global batch of 32 x N utterances, barrier,
+    max over ranks on the rank's device, the all-reduce / all-gather of dist_facts, one JSON line on rank 0 -- had never executed anywhere.
+    SET_AMD_BENCH_STUB_DEVICE=cpu swaps the model for a toy torch-CPU callable with the same call signature and return keys, RCCL for
+    gloo; everything else between main() and the printed line is the code the real run executes (no collective on the data path:
+    SURVEY.md 8(e); the reference shards the same way, tasks/tts/speech_base.py:128-131)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SET_AMD_BENCH_STUB_DEVICE"] = "cpu"
+    lines_by_n = {}
+    for n in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only
+        lines_by_n[n] = d = json.loads(lines[0])
+        assert d["device"] == "cpu-stub" and d["metric"].startswith("STUB")
+        assert d["n_gpus"] == n and d["rccl_ranks"] == n and d["steps"] == 3 and d["warmup"] == 1
+        assert d["dist_backend"] == ("gloo" if n > 1 else None)
+        assert len(d["per_rank_ms_per_step"]) == n and d["ms_per_step"] >= max(d["per_rank_ms_per_step"]) - 1e-9   # max over ranks
+        assert d["scaling"] == "weak" and d["config"]["B_per_gpu"] == 32 and d["higher_is_better"] is True
+        # whole-job aggregate: all N x 32 utterances x 800 frames x steps over the slowest rank's time
+        assert abs(d["value"] - n * 32 * 800 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
+        for k in ("roofline", "unit", "vs_baseline", "dtype", "data"):
+            assert k in d
+        assert "cpu_baseline" not in d and "train_bf16" not in d      # 1-GPU extras never run on the stub
+    # rank 0 of the 2-rank run holds utterances 0, 2, 4, ... of a 64-utterance batch: not the 1-rank run's 32
+    assert lines_by_n[1]["stub_shard_checksum"] != lines_by_n[2]["stub_shard_checksum"]
+    # the refusal: a launcher that started a different number of ranks
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "launcher started 1 rank" in (r2.stderr + r2.stdout)
+    if not torch.cuda.is_available():
+        env3 = {k: v for k, v in env.items() if k != "SET_AMD_BENCH_STUB_DEVICE"}
+        r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env3, capture_output=True, text=True, timeout=300)
+        assert r3.returncode != 0 and "needs an MI355X" in (r3.stderr + r3.stdout)

@@ -476,6 +476,37 @@ def test_bf16_inference_loop_quality_at_the_benchmark_size(dev):
     assert mcd < 0.20 and dmax < 0.05
 
 
+def test_bf16_loop_utterance_groups_do_not_share_scratch(dev, monkeypatch):
+    """with n_groups > 1 the group chains of the bf16 reverse loop run concurrently on auxiliary streams; the 128-frame layer-group
+    kernel keeps a block's private skip rows in a scratch buffer indexed by (blockIdx.y, blockIdx.x) of its OWN launch, so every group needs
+    its own slice.  Grouping must never change results: 1 / 2 / 3 groups bit-identical at a shape forced onto the 128-frame tile."""
+    from set_amd import _lib, ops
+    from set_amd.diffnet import DiffNet
+    from set_amd.spec_denoiser import GaussianDiffusion
+    from set_amd.synthetic import synthetic_inputs
+    monkeypatch.setenv("SET_AMD_BF16_FUSE_TILE", "128")
+    hp = base_hparams(timesteps=6)
+    model = GaussianDiffusion(list(range(80)), 80, DiffNet(80, hp), timesteps=6, time_scale=1, loss_type="l1", spec_min=[], spec_max=[], hp=hp)
+    model.load_state_dict(Wt.seeded_weights(Wt.load_manifest("spec_denoiser"), 11), strict=False)
+    model.to(dev).eval()
+    B, T = 6, 600
+    assert int(_lib.lib().set_diffnet_layers_bf16_plan(B // 2, T, 20, 1)) == 10
+    inp = {k: v.to(dev) for k, v in synthetic_inputs(B, T, 60, seed=99).items()}
+    ops.set_compute_dtype("bf16")
+    try:
+        outs = []
+        for G in (1, 2, 3, 2):
+            with torch.no_grad():
+                outs.append(model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"], inp["uv"],
+                                  infer=True, seed=3, n_groups=G)["mel_out"].clone())
+    finally:
+        ops.set_compute_dtype("f32")
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0]).all()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def test_batch_repack_equals_per_weight_packs(dev):
     """ops.repack_bf16_images (what FlatAdamW.step calls in bf16 mode): every registered bf16 weight image re-rounded from its
     fp32 master weight in ONE launch -- bit-equal to the per-weight pack kernel, for plain, transposed (input-gradient) and

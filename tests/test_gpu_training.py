@@ -724,6 +724,17 @@ def test_graphed_training_step_equals_the_eager_step_bit_for_bit(dev, dtype, mon
             assert torch.equal(tot_a, tot_b), it
             assert set(parts_a) == set(parts_b) and all(torch.equal(parts_a[k].reshape(()), parts_b[k].reshape(()).to(parts_a[k].dtype)) for k in parts_a), it
             assert torch.equal(oa.flat_p, ob.flat_p) and torch.equal(oa.m, ob.m) and torch.equal(oa.v, ob.v), it
+            if it in (4, 7):
+                # eager inference BETWEEN and AFTER replays must see the replayed updates: the host-side packed-weight caches are keyed on
+                # the weights epoch, which a replay has to bump like an eager optimizer step does
+                mels = []
+                for tk in (ta, tb):
+                    tk.model.eval()
+                    with torch.no_grad():
+                        mels.append(tk.model(sample["txt_tokens"], sample["time_mel_masks"][:, :, None], sample["mel2ph"], sample["spk_embed"],
+                                             sample["mels"], sample["f0"], sample["uv"], infer=True, seed=5)["mel_out"])
+                    tk.model.train()
+                assert torch.equal(mels[0], mels[1]), it
         assert gs.replays == 6 and sum(1 for e in gs.entries.values() if e["graph"] is not None) == 1
         # a second batch shape gets its own eager steps, then its own graph
         inp = Wt.synthetic_inputs(2, 64, 16, seed=5, pad_tail=True)
