@@ -497,6 +497,11 @@ int64_t set_sizeof_diffnet_layer_bf16_args(void);
 int64_t set_diffnet_layer_bf16_image_size(void);
 int set_pack_diffnet_layer_bf16(const float *wdil /*[512][256][3]*/, const float *wcond /*[512][192]*/,
                                 const float *wout /*[512][256]*/, void *img, void *stream);
+/* L layers in one launch: layer q reads wdil + q * sdil (etc., element strides between the layers' tensors) and writes image q of
+ * img [L][image_size] -- the flat optimizer lays every layer's parameters out at one stride, so the whole stack is re-rounded by ONE
+ * launch after an update instead of L. */
+int set_pack_diffnet_layers_bf16(const float *wdil, const float *wcond, const float *wout, int64_t sdil, int64_t scond, int64_t sout,
+                                 void *img, int32_t L, void *stream);
 int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, void *stream);
 /* Several consecutive residual layers per launch (bf16 operands, inference: nothing is saved): a block keeps its tile on chip for
  * `nl` (<= 16) layers l0 .. l0 + nl - 1 (x and the conditioner are read once; the fp32 residual rows stay in registers; the running
@@ -561,6 +566,11 @@ int set_diffnet_layer_bwd_bf16(const SetDiffnetLayerBf16BwdArgs *args, void *str
  * sum part_dby (over all B*tiles rows), dd[b*dd_bs + c] = sum over the tiles of utterance b of part_dd (c < 256) */
 int set_diffnet_layer_bwd_reduce(const float *part_dbo, const float *part_dby, const float *part_dd, int32_t B, int32_t tiles,
                                  float *db_out, float *db_dil, float *db_cond, float *dd, int64_t dd_bs, void *stream);
+/* the same for L layers swept with one tile count, in ONE launch: partials [L][B*tiles][512|512|256], layer q's targets at
+ * db_* + q * s_* (element strides between the layers' bias gradients) and dd + q * dd_ls */
+int set_diffnet_layers_bwd_reduce(const float *part_dbo, const float *part_dby, const float *part_dd, int32_t B, int32_t tiles, int32_t L,
+                                  float *db_out, int64_t s_out, float *db_dil, int64_t s_dil, float *db_cond, int64_t s_cond, float *dd,
+                                  int64_t dd_bs, int64_t dd_ls, void *stream);
 /* out[g][j] (+)= scale * sum_{r < rows} part[(g*rows + r)*cols + j]  in row order (deterministic reduction of per-tile partials) */
 int set_partial_rows_sum(const float *part, float *out, int32_t groups, int32_t rows, int32_t cols, int32_t accumulate,
                          float scale, void *stream);

@@ -268,6 +268,7 @@ SIGNATURES = {
     "set_sizeof_diffnet_layer_bf16_args": (_I64, []),
     "set_diffnet_layer_bf16_image_size": (_I64, []),
     "set_pack_diffnet_layer_bf16": (C.c_int, [_V, _V, _V, _V, _V]),
+    "set_pack_diffnet_layers_bf16": (C.c_int, [_V, _V, _V, _I64, _I64, _I64, _V, _I32, _V]),
     "set_diffnet_layer_fwd_bf16": (C.c_int, [C.POINTER(SetDiffnetLayerBf16Args), _V]),
     "set_sizeof_diffnet_layers_bf16_args": (_I64, []),
     "set_diffnet_layers_bf16_scratch_floats": (_I64, [_I32, _I32, _I32, _I32, _I32]),
@@ -285,6 +286,7 @@ SIGNATURES = {
     "set_step_proj_bwd_scratch_floats": (_I64, [_I32, _I32, _I32]),
     "set_step_proj_bwd": (C.c_int, [_V, _V, _V, _I64, _V, _V, _I64, _V, _I64, _V, _I32, _I32, _I32, _V]),
     "set_diffnet_layer_bwd_reduce": (C.c_int, [_V, _V, _V, _I32, _I32, _V, _V, _V, _V, _I64, _V]),
+    "set_diffnet_layers_bwd_reduce": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _V, _I64, _V, _I64, _V, _I64, _V, _I64, _I64, _V]),
     "set_channel_sum": (C.c_int, [_V, _V, _I32, _I32, _I32, _V]),
     "set_row_sum": (C.c_int, [_V, _V, _I64, _I32, _F, _V]),
     "set_conv_epilogue_bwd": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _F, _V]),

@@ -68,6 +68,84 @@ def graph_released():
 CAPTURED_ABORT_WORDS = []  # sync workspaces of persistent stack kernels inside captured steps ([1] != 0: a dependency wait timed out)
 
 
+# --------------------------------------------------------------------------------------------------
+# Leaf stream: gradient kernels nothing else in the backward pass waits for
+# --------------------------------------------------------------------------------------------------
+# A weight / bias gradient that goes straight into the flat optimizer's .grad (FlatAdamW.sink) is a LEAF of the step's dependency graph: the
+# next reader is the optimizer (or the bucket all-reduce).  On the compute stream these kernels sit in the middle of the critical chain of
+# input-gradient kernels: ~3.8 ms of the 11 ms spec_denoiser bf16 step (three grouped layer weight-gradient GEMMs 2.3 ms, ~35 conditioner
+# weight gradients, ~70 ordered bias / partial reductions), most of it while the chain itself runs 5-40 us kernels on a few dozen workgroups.
+# They are enqueued on a second HIP stream instead, ordered after the compute stream by an event at the point of the call, and the optimizer
+# step / bucket launch waits for that stream (leaf_join / leaf_fence).  Results are unchanged bit for bit: same kernels, same operands, each
+# target written by exactly one stream.  Tensors handed to a leaf kernel are record_stream()ed (their storage must not be reused by the
+# compute stream before the leaf kernel has read it); reduction scratch buffers are per stream.  SET_AMD_LEAF_STREAM=0 switches it off.
+_LEAF = {}  # device index -> {"stream", "event", "dirty"}
+
+
+def leaf_enabled():
+    return os.environ.get("SET_AMD_LEAF_STREAM", "1") != "0"
+
+
+def _leaf_state(dev):
+    st = _LEAF.get(dev.index)
+    if st is None:
+        st = _LEAF[dev.index] = {"stream": torch.cuda.Stream(device=dev), "event": torch.cuda.Event(), "dirty": False}
+    return st
+
+
+class leaf_work:
+    """with leaf_work(device, use, *tensors) as on_leaf: kernels enqueued inside run on the device's leaf stream (after everything enqueued on
+    the current stream so far) when `use` holds; `tensors` are the operands the compute stream's allocator must keep until then."""
+
+    def __init__(self, dev, use, *tensors):
+        self.on = bool(use) and dev.type == "cuda" and leaf_enabled()
+        self.dev, self.tensors = dev, tensors
+
+    def __enter__(self):
+        if not self.on:
+            return False
+        st = _leaf_state(self.dev)
+        main = torch.cuda.current_stream(self.dev)
+        st["event"].record(main)
+        st["stream"].wait_event(st["event"])
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(st["stream"])
+        self._prev = main
+        torch.cuda.set_stream(st["stream"])
+        if not st["dirty"]:
+            st["dirty"] = True
+            try:  # the stream that ran backward() waits for the leaf stream when the pass is over: callers may read .grad right away
+                torch.autograd.Variable._execution_engine.queue_callback(leaf_join)
+            except RuntimeError:
+                pass  # not inside a backward pass (a test calling a backward function by hand): FlatAdamW.step() / abort_step() join
+        return True
+
+    def __exit__(self, *exc):
+        if self.on:
+            torch.cuda.set_stream(self._prev)
+        return False
+
+
+def leaf_join():
+    """The current stream waits for everything enqueued on the leaf streams (before the optimizer reads the gradients)."""
+    for idx, st in _LEAF.items():
+        if st["dirty"]:
+            torch.cuda.current_stream(torch.device("cuda", idx)).wait_stream(st["stream"])
+            st["dirty"] = False
+
+
+def leaf_fence(dev):
+    """For a consumer that must see BOTH streams' work without stalling the compute stream (a bucket all-reduce launched from an autograd
+    hook): returns the leaf stream after making it wait for the current stream, or None when no leaf work is pending on `dev`."""
+    st = _LEAF.get(dev.index) if dev.type == "cuda" else None
+    if st is None or not st["dirty"]:
+        return None
+    st["event"].record(torch.cuda.current_stream(dev))
+    st["stream"].wait_event(st["event"])
+    return st["stream"]
+
+
 def zero_arena_begin(device, min_floats=0, owner=None):
     a = _ARENAS.setdefault(id(owner), _ZeroArena())
     want = max(int(min_floats), int(a.need * 1.05) + 4096)
@@ -119,16 +197,33 @@ def _wgrad_impl(T):
     return IMPL_MFMA if T >= 16 else IMPL_NAIVE
 
 
-_DET_SCRATCH = {}  # device -> per-block / per-slice partial results of the ordered reductions (reused: stream-ordered)
+_DET_SCRATCH = {}  # (device, stream) -> per-block / per-slice partial results of the ordered reductions (reused: stream-ordered)
+
+
+def _stream_key(device):
+    """(device, raw handle of the current stream): scratch buffers are reused in stream order, so every stream has its own."""
+    return (device, _stream().value)
 
 
 def _det_scratch(device, n_floats):
-    buf = _DET_SCRATCH.get(device)
+    key = _stream_key(device)
+    buf = _DET_SCRATCH.get(key)
     if buf is None or buf.numel() < n_floats:
         if buf is not None:
             _retire(buf)
         buf = torch.empty(int(n_floats * 1.25) + 4096, dtype=torch.float32, device=device)
-        _DET_SCRATCH[device] = buf
+        _DET_SCRATCH[key] = buf
+    return buf
+
+
+def _wg_scratch(device, need):
+    key = _stream_key(device)
+    buf = _WG_SCRATCH.get(key)
+    if buf is None or buf.numel() < need:
+        if buf is not None:
+            _retire(buf)
+        buf = torch.empty(int(need * 1.25) + 1024, dtype=torch.float32, device=device)
+        _WG_SCRATCH[key] = buf
     return buf
 
 
@@ -137,7 +232,7 @@ def channel_sum_(x, out, B, Cc, T):
     check(L().set_channel_sum_det(_p(x), _p(out), B, Cc, T, _p(_det_scratch(x.device, 2048 + Cc)), _stream()), "set_channel_sum_det")
 
 
-_WG_SCRATCH = {}  # device -> slice-partial buffer of the deterministic weight-gradient path (reused: stream-ordered)
+_WG_SCRATCH = {}  # (device, stream) -> slice-partial buffer of the deterministic weight-gradient path (reused: stream-ordered)
 DETERMINISTIC_WGRAD = True  # False: the round-1 split-K kernel with fp32 atomics (order-dependent bits)
 
 
@@ -154,13 +249,7 @@ def conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro=0, pr
         dt = dtype  # bf16 operands already in HBM (fused layer kernels)
     else:
         dt = _lib.DTYPE_BF16 if (ops.compute_dtype() == "bf16" and Cout >= 32 and Cin >= 32) else _lib.DTYPE_F32
-    need = L().set_conv1d_wgrad_scratch_floats(B, Cin, Cout, K, T, dt)
-    buf = _WG_SCRATCH.get(g.device)
-    if buf is None or buf.numel() < need:
-        if buf is not None:
-            _retire(buf)
-        buf = torch.empty(int(need * 1.25) + 1024, dtype=torch.float32, device=g.device)
-        _WG_SCRATCH[g.device] = buf
+    buf = _wg_scratch(g.device, L().set_conv1d_wgrad_scratch_floats(B, Cin, Cout, K, T, dt))
     check(L().set_conv1d_wgrad_det(_p(g), _p(x), _p(chan_add), ptr, B, Cin, Cout, K, dil, pad, T, T_in, pro,
                                    float(pro_param), dt, _p(buf), buf.numel(), _stream()), "set_conv1d_wgrad_det")
 
@@ -168,13 +257,7 @@ def conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, K, dil, pad, T, T_in, pro=0, pr
 def conv_wgrad_grouped(g, x, chan_add, dw_ptr, groups, g_gs, x_gs, add_gs, dw_gs, B, Cin, Cout, K, dil, pad, T, T_in, dtype):
     """`groups` equal bf16 weight-gradient GEMMs (the same conv of every residual layer) in one launch + one ordered reduce;
     group q reads g + q g_gs, x + q x_gs, chan_add + q add_gs and adds into dw_ptr + q dw_gs (element strides)."""
-    need = L().set_conv1d_wgrad_grouped_scratch_floats(groups, B, Cin, Cout, K, T)
-    buf = _WG_SCRATCH.get(g.device)
-    if buf is None or buf.numel() < need:
-        if buf is not None:
-            _retire(buf)
-        buf = torch.empty(int(need * 1.25) + 1024, dtype=torch.float32, device=g.device)
-        _WG_SCRATCH[g.device] = buf
+    buf = _wg_scratch(g.device, L().set_conv1d_wgrad_grouped_scratch_floats(groups, B, Cin, Cout, K, T))
     check(L().set_conv1d_wgrad_det_grouped(_p(g), _p(x), _p(chan_add), C.c_void_p(dw_ptr), groups, g_gs, x_gs, add_gs, dw_gs, B, Cin,
                                            Cout, K, dil, pad, T, T_in, dtype, _p(buf), buf.numel(), _stream()),
           "set_conv1d_wgrad_det_grouped")
@@ -241,23 +324,33 @@ class _Conv1dFn(torch.autograd.Function):
                 dadd = torch.empty(B, Cin, dtype=torch.float32, device=dy.device)
                 check(L().set_row_sum(_p(dx), _p(dadd), B * Cin, T_in, 1.0, _stream()), "set_row_sum")
         dw = db = None
-        if ctx.needs_input_grad[1]:
+        want_w, want_b = ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
+        w_sink = b_sink = None
+        if want_w:
             w = cw.raw()
             # plain [Cout,Cin,K] rows, possibly a row slice of a larger parameter (packed q/k/v projections)
             assert cw.stap == 1 and cw.sci == cw.K and cw.sco == cw.Cin * cw.K, "plain conv layout"
             whole = cw.base == 0 and w.numel() == Cout * Cin * cw.K
-            sink, owner = grad_sink(ctx.wparam) if whole else (None, None)
-            dw = sink if sink is not None else _gzeros(w.shape, dy.device)
-            conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, cw.K, dil, pad, T, T_in, PRO[pro], pro_param,
-                       dw_ptr=dw.data_ptr() + 4 * cw.base)
-            if sink is not None:
-                dw = None  # written in place; autograd still fires the parameter's post-accumulate hook (bucket launch)
-        if has_bias and ctx.needs_input_grad[2]:
-            sink, owner = grad_sink(ctx.bparam) if ctx.bparam.numel() == Cout else (None, None)
-            db = sink if sink is not None else _gzeros(Cout, dy.device)
-            channel_sum_(g, db, B, Cout, T)
-            if sink is not None:
-                db = None
+            w_sink = grad_sink(ctx.wparam)[0] if whole else None
+            dw = w_sink if w_sink is not None else _gzeros(w.shape, dy.device)
+        if want_b:
+            b_sink = grad_sink(ctx.bparam)[0] if ctx.bparam.numel() == Cout else None
+            db = b_sink if b_sink is not None else _gzeros(Cout, dy.device)
+        # gradients that go straight into .grad are leaves of this backward pass (the optimizer is their next reader): leaf stream
+        # (only when g is a tensor of this function's own: the engine's gradient buffer dy -- or g handed on as the residual's gradient --
+        # may get the next arrival accumulated into it IN PLACE, on the compute stream, while a leaf kernel still reads it)
+        on_leaf = ((not want_w or w_sink is not None) and (not want_b or b_sink is not None) and (want_w or want_b)
+                   and g is not dy and dres is not g)
+        with leaf_work(dy.device, on_leaf, g, x, chan_add):
+            if want_w:
+                conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, cw.K, dil, pad, T, T_in, PRO[pro], pro_param,
+                           dw_ptr=dw.data_ptr() + 4 * cw.base)
+            if want_b:
+                channel_sum_(g, db, B, Cout, T)
+        if w_sink is not None:
+            dw = None  # written in place; autograd still fires the parameter's post-accumulate hook (bucket launch)
+        if b_sink is not None:
+            db = None
         return (dx if ctx.needs_input_grad[0] else None, dw, db, dadd, dres, None, None, None, None, None, None, None,
                 None, None, None)
 
@@ -616,32 +709,34 @@ class _DiffNetStackFn(torch.autograd.Function):
                 return (sk, True) if sk is not None else (_zeros_like(param), False)
 
             dw_out, d1 = tgt(layer.output_projection.weight)
-            conv_wgrad(d_o, z_all[l], None, dw_out, B, C_, 2 * C_, 1, 1, 0, T, T)
             db_out, d2 = tgt(layer.output_projection.bias)
-            channel_sum_(d_o, db_out, B, 2 * C_, T)
+            dw_cond, d3 = tgt(layer.conditioner_projection.weight)
+            db, d4 = tgt(layer.conditioner_projection.bias)
+            db2, d5 = tgt(layer.dilated_conv.bias)
+            dw_dil, d6 = tgt(layer.dilated_conv.weight)
             dz = ops.conv1d(d_o, layer._w_out.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T)
             # gate
             dy = torch.empty(B, 2 * C_, T, dtype=torch.float32, device=dev)
             check(L().set_gate_bwd(_p(y_all[l]), _p(dz), _p(dy), B, C_, T, _stream()), "set_gate_bwd")
             # conditioner_projection (1x1, H -> 512): y = ... + W_cond cond + b_cond
-            dw_cond, d3 = tgt(layer.conditioner_projection.weight)
-            conv_wgrad(dy, cond, None, dw_cond, B, H, 2 * C_, 1, 1, 0, T, T)
-            db, d4 = tgt(layer.conditioner_projection.bias)
-            channel_sum_(dy, db, B, 2 * C_, T)  # = db_cond = db_dil
-            db2, d5 = tgt(layer.dilated_conv.bias)
-            channel_sum_(dy, db2, B, 2 * C_, T)
             if need_cond:
                 ops.conv1d(dy, layer._w_cond.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T, out=dcond,
                            accumulate=True)
             # dilated conv (k=3) on x_l + d_l
             dl = dmat[:, l * C_:(l + 1) * C_].contiguous()
-            dw_dil, d6 = tgt(layer.dilated_conv.weight)
-            conv_wgrad(dy, x_all[l], dl, dw_dil, B, C_, 2 * C_, 3, dil, dil, T, T)
             dxd = ops.conv1d(dy, layer._w_dil.transposed(), None, dil=-dil, pad=-dil, T_iter=T, T_out=T)
             ddl = torch.empty(B, C_, dtype=torch.float32, device=dev)
             check(L().set_row_sum(_p(dxd), _p(ddl), B * C_, T, 1.0, _stream()), "set_row_sum")
             dd[:, l * C_:(l + 1) * C_] = ddl
             dx = ops.sum_div(dxd, dxr)
+            # the layer's six parameter gradients: leaves (leaf stream when they go straight into .grad)
+            with leaf_work(dev, d1 and d2 and d3 and d4 and d5 and d6, d_o, dy, z_all, cond, x_all, dl):
+                conv_wgrad(d_o, z_all[l], None, dw_out, B, C_, 2 * C_, 1, 1, 0, T, T)
+                channel_sum_(d_o, db_out, B, 2 * C_, T)
+                conv_wgrad(dy, cond, None, dw_cond, B, H, 2 * C_, 1, 1, 0, T, T)
+                channel_sum_(dy, db, B, 2 * C_, T)  # = db_cond = db_dil
+                channel_sum_(dy, db2, B, 2 * C_, T)
+                conv_wgrad(dy, x_all[l], dl, dw_dil, B, C_, 2 * C_, 3, dil, dil, T, T)
             grads.append((None if d3 else dw_cond, None if d4 else db, None if d6 else dw_dil, None if d5 else db2,
                           None if d1 else dw_out, None if d2 else db_out))
         grads.reverse()
@@ -713,13 +808,23 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
         a.B, a.T = B, T
         grads = []
         cur = None  # gradient w.r.t. the current layer's x_out (None for the last layer: its x_out feeds nothing)
+        # grouped: the per-tile partial sums (bias / step-offset gradients) of ALL layers are kept and reduced by ONE launch after the sweep
+        # (L x ~2 MB at B = 32, T = 800) instead of one 5 us launch per layer in the middle of the chain of layer kernels
+        if grouped:
+            tiles_g = L().set_diffnet_layer_bwd_bf16_tiles(T, layers[0].dilation)
+            pdbo_all = torch.empty(L_, B * tiles_g, 2 * C_, dtype=torch.float32, device=dev)
+            pdby_all = torch.empty(L_, B * tiles_g, 2 * C_, dtype=torch.float32, device=dev)
+            pdd_all = torch.empty(L_, B * tiles_g, C_, dtype=torch.float32, device=dev)
         for l in range(L_ - 1, -1, -1):
             layer = layers[l]
             dil = layer.dilation
             tiles = L().set_diffnet_layer_bwd_bf16_tiles(T, dil)
-            pdbo_c = torch.empty(B * tiles, 2 * C_, dtype=torch.float32, device=dev)
-            pdby_c = torch.empty(B * tiles, 2 * C_, dtype=torch.float32, device=dev)
-            pdd_c = torch.empty(B * tiles, C_, dtype=torch.float32, device=dev)
+            if grouped:
+                pdbo_c, pdby_c, pdd_c = pdbo_all[l], pdby_all[l], pdd_all[l]
+            else:
+                pdbo_c = torch.empty(B * tiles, 2 * C_, dtype=torch.float32, device=dev)
+                pdby_c = torch.empty(B * tiles, 2 * C_, dtype=torch.float32, device=dev)
+                pdd_c = torch.empty(B * tiles, C_, dtype=torch.float32, device=dev)
             out = dx[l & 1]
             dy16, do16 = dy16_all[l if grouped else 0], do16_all[l if grouped else 0]
             a.dy16, a.do16 = dy16.data_ptr(), do16.data_ptr()
@@ -740,17 +845,17 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
             def wg(param, *args, **kw):
                 sink, owner = grad_sink(param)
                 tgt = sink if sink is not None else _zeros_like(param)
-                conv_wgrad(args[0], args[1], args[2], tgt, *args[3:], **kw)
+                conv_wgrad(args[0], args[1], args[2], tgt, *args[3:], **kw)  # (compute stream: the next layer's launch overwrites dy16 / do16)
                 return None if sink is not None else tgt
 
-            (t_out, db_out), (t_dil, db_dil), (t_cond, db_cond) = (btgt(layer.output_projection.bias),
-                                                                   btgt(layer.dilated_conv.bias),
-                                                                   btgt(layer.conditioner_projection.bias))
-            check(L().set_diffnet_layer_bwd_reduce(_p(pdbo_c), _p(pdby_c), _p(pdd_c), B, tiles, _p(t_out), _p(t_dil), _p(t_cond),
-                                                   dd.data_ptr() + 4 * l * C_, dd.stride(0), _stream()), "set_diffnet_layer_bwd_reduce")
             if grouped:
-                dw_out = dw_cond = dw_dil = None  # filled in below
+                dw_out = dw_cond = dw_dil = db_out = db_dil = db_cond = None  # filled in below
             else:
+                (t_out, db_out), (t_dil, db_dil), (t_cond, db_cond) = (btgt(layer.output_projection.bias),
+                                                                       btgt(layer.dilated_conv.bias),
+                                                                       btgt(layer.conditioner_projection.bias))
+                check(L().set_diffnet_layer_bwd_reduce(_p(pdbo_c), _p(pdby_c), _p(pdd_c), B, tiles, _p(t_out), _p(t_dil), _p(t_cond),
+                                                       dd.data_ptr() + 4 * l * C_, dd.stride(0), _stream()), "set_diffnet_layer_bwd_reduce")
                 dw_out = wg(layer.output_projection.weight, do16, z16[l], None, B, C_, 2 * C_, 1, 1, 0, T, T, dtype=GX16)
                 dw_cond = wg(layer.conditioner_projection.weight, dy16, cond, None, B, H, 2 * C_, 1, 1, 0, T, T, dtype=G16)
                 dl = dmat[:, l * C_:(l + 1) * C_].contiguous()
@@ -761,13 +866,25 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
         if grouped:
             dil = layers[0].dilation
             n_act = B * 2 * C_ * T
+            pb_o, sb_o, rb_o = _grouped_targets([ly.output_projection.bias for ly in layers], dev)
+            pb_d, sb_d, rb_d = _grouped_targets([ly.dilated_conv.bias for ly in layers], dev)
+            pb_c, sb_c, rb_c = _grouped_targets([ly.conditioner_projection.bias for ly in layers], dev)
+            check(L().set_diffnet_layers_bwd_reduce(_p(pdbo_all), _p(pdby_all), _p(pdd_all), B, tiles_g, L_, C.c_void_p(pb_o), sb_o,
+                                                    C.c_void_p(pb_d), sb_d, C.c_void_p(pb_c), sb_c, _p(dd), dd.stride(0), C_, _stream()),
+                  "set_diffnet_layers_bwd_reduce")
+            for l in range(L_):
+                grads[l][1], grads[l][3], grads[l][5] = rb_c[l], rb_d[l], rb_o[l]
             p_out, s_out, r_out = _grouped_targets([ly.output_projection.weight for ly in layers], dev)
-            conv_wgrad_grouped(do16_all, z16, None, p_out, L_, n_act, B * C_ * T, 0, s_out, B, C_, 2 * C_, 1, 1, 0, T, T, GX16)
             p_c, s_c, r_c = _grouped_targets([ly.conditioner_projection.weight for ly in layers], dev)
-            conv_wgrad_grouped(dy16_all, cond, None, p_c, L_, n_act, 0, 0, s_c, B, H, 2 * C_, 1, 1, 0, T, T, G16)
-            dl_all = dmat.view(B, L_, C_).transpose(0, 1).contiguous()  # [L][B][C] step offsets (the conv's input is x + d)
             p_d, s_d, r_d = _grouped_targets([ly.dilated_conv.weight for ly in layers], dev)
-            conv_wgrad_grouped(dy16_all, x_all, dl_all, p_d, L_, n_act, B * C_ * T, B * C_, s_d, B, C_, 2 * C_, 3, dil, dil, T, T, G16)
+            dl_all = dmat.view(B, L_, C_).transpose(0, 1).contiguous()  # [L][B][C] step offsets (the conv's input is x + d)
+            # written straight into .grad (every r_* entry None): leaves of the backward pass -- 2.3 ms of chip-filling GEMMs that run on the
+            # leaf stream under the conditioner's backward (hundreds of 5-40 us kernels on a few dozen workgroups each)
+            in_place = all(r is None for r in r_out + r_c + r_d)
+            with leaf_work(dev, in_place, do16_all, dy16_all, z16, cond, x_all, dl_all):
+                conv_wgrad_grouped(do16_all, z16, None, p_out, L_, n_act, B * C_ * T, 0, s_out, B, C_, 2 * C_, 1, 1, 0, T, T, GX16)
+                conv_wgrad_grouped(dy16_all, cond, None, p_c, L_, n_act, 0, 0, s_c, B, H, 2 * C_, 1, 1, 0, T, T, G16)
+                conv_wgrad_grouped(dy16_all, x_all, dl_all, p_d, L_, n_act, B * C_ * T, B * C_, s_d, B, C_, 2 * C_, 3, dil, dil, T, T, G16)
             for l in range(L_):
                 grads[l][0], grads[l][2], grads[l][4] = r_c[l], r_d[l], r_out[l]
         flat = [g for tup in grads for g in tup]

@@ -122,10 +122,13 @@ constexpr int64_t N_WT2 = 8LL * 32 * 64 * 8, N_WT1 = 8LL * 96 * 64 * 8, N_WTC = 
 constexpr int64_t OFF_W2B = N_W1B, OFF_WT2 = OFF_W2B + N_W2B, OFF_WT1 = OFF_WT2 + N_WT2, OFF_WTC = OFF_WT1 + N_WT1;
 constexpr int64_t N_IMG = OFF_WTC + N_WTC;  // bf16 elements per layer
 
+// blockIdx.y = layer: layer q reads w* + q * its element stride and writes image q (one launch re-rounds the whole stack after an update)
 __global__ void __launch_bounds__(256) pack_layer_bf16_kernel(const float *wdil, const float *wcond, const float *wout,
-                                                              unsigned short *img) {
+                                                              unsigned short *img, int64_t sdil, int64_t scond, int64_t sout) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= N_IMG) return;
+    wdil += (int64_t)blockIdx.y * sdil; wcond += (int64_t)blockIdx.y * scond; wout += (int64_t)blockIdx.y * sout;
+    img += (int64_t)blockIdx.y * N_IMG;
     float v;
     if (idx < OFF_W2B) {
         int64_t r = idx;
@@ -1426,12 +1429,18 @@ __global__ void __launch_bounds__(64 * ROWS_RG) partial_rows_sum_kernel(const fl
 // all ordered partial sums of one layer's backward in ONE launch (block = 64 columns x ROWS_RG row groups, fixed association):
 //   columns [0,512): db_out += sum over all rows of part_dbo ; [512,1024): db_dil, db_cond += ... of part_dby ;
 //   [1024,1280): dd[b][c] = sum over the tiles of utterance b of part_dd   (blockIdx.y = b there)
+// blockIdx.z = layer q of a stack swept with one tile count: partials of layer q at q * (their per-layer size), targets at q * their
+// element strides (s_out / s_dil / s_cond between the layers' bias gradients, dd_ls between the layers' step-offset columns)
 __global__ void __launch_bounds__(64 * ROWS_RG) layer_bwd_reduce_kernel(const float *pdbo, const float *pdby, const float *pdd, int B,
                                                                         int tiles, float *db_out, float *db_dil, float *db_cond,
-                                                                        float *dd, int64_t dd_bs) {
+                                                                        float *dd, int64_t dd_bs, int64_t s_out, int64_t s_dil,
+                                                                        int64_t s_cond, int64_t dd_ls) {
     __shared__ float red[ROWS_RG][64];
     const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int cbk = blockIdx.x;  // 0..7 dbo, 8..15 dby, 16..19 dd
+    const int64_t q = blockIdx.z;
+    pdbo += q * B * tiles * 2 * FC; pdby += q * B * tiles * 2 * FC; pdd += q * B * tiles * FC;
+    db_out += q * s_out; db_dil += q * s_dil; db_cond += q * s_cond; dd += q * dd_ls;
     if (cbk < 16) {
         if (blockIdx.y != 0) return;
         const float *part = cbk < 8 ? pdbo : pdby;
@@ -1455,8 +1464,16 @@ extern "C" int64_t set_diffnet_layer_bf16_image_size(void) { return N_IMG; }
 extern "C" int set_pack_diffnet_layer_bf16(const float *wdil, const float *wcond, const float *wout, void *img, void *stream) {
     SET_REQUIRE(wdil && wcond && wout && img, "set_pack_diffnet_layer_bf16");
     hipLaunchKernelGGL(pack_layer_bf16_kernel, dim3(set_blocks(N_IMG, 256)), dim3(256), 0, (hipStream_t)stream, wdil, wcond, wout,
-                       reinterpret_cast<unsigned short *>(img));
+                       reinterpret_cast<unsigned short *>(img), (int64_t)0, (int64_t)0, (int64_t)0);
     return set_check_launch("set_pack_diffnet_layer_bf16");
+}
+
+extern "C" int set_pack_diffnet_layers_bf16(const float *wdil, const float *wcond, const float *wout, int64_t sdil, int64_t scond,
+                                            int64_t sout, void *img, int32_t L, void *stream) {
+    SET_REQUIRE(wdil && wcond && wout && img && L >= 1 && L <= 65535, "set_pack_diffnet_layers_bf16");
+    hipLaunchKernelGGL(pack_layer_bf16_kernel, dim3(set_blocks(N_IMG, 256), L), dim3(256), 0, (hipStream_t)stream, wdil, wcond, wout,
+                       reinterpret_cast<unsigned short *>(img), sdil, scond, sout);
+    return set_check_launch("set_pack_diffnet_layers_bf16");
 }
 
 extern "C" int64_t set_sizeof_diffnet_layer_bf16_args(void) { return (int64_t)sizeof(SetDiffnetLayerBf16Args); }
@@ -1616,8 +1633,18 @@ extern "C" int set_diffnet_layer_bwd_reduce(const float *part_dbo, const float *
     SET_REQUIRE(part_dbo && part_dby && part_dd && db_out && db_dil && db_cond && dd && B > 0 && tiles > 0,
                 "set_diffnet_layer_bwd_reduce");
     hipLaunchKernelGGL(layer_bwd_reduce_kernel, dim3(20, B), dim3(64 * ROWS_RG), 0, (hipStream_t)stream, part_dbo, part_dby, part_dd, B,
-                       tiles, db_out, db_dil, db_cond, dd, dd_bs);
+                       tiles, db_out, db_dil, db_cond, dd, dd_bs, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0);
     return set_check_launch("set_diffnet_layer_bwd_reduce");
+}
+
+extern "C" int set_diffnet_layers_bwd_reduce(const float *part_dbo, const float *part_dby, const float *part_dd, int32_t B, int32_t tiles,
+                                             int32_t L, float *db_out, int64_t s_out, float *db_dil, int64_t s_dil, float *db_cond,
+                                             int64_t s_cond, float *dd, int64_t dd_bs, int64_t dd_ls, void *stream) {
+    SET_REQUIRE(part_dbo && part_dby && part_dd && db_out && db_dil && db_cond && dd && B > 0 && tiles > 0 && L >= 1 && L <= 65535,
+                "set_diffnet_layers_bwd_reduce");
+    hipLaunchKernelGGL(layer_bwd_reduce_kernel, dim3(20, B, L), dim3(64 * ROWS_RG), 0, (hipStream_t)stream, part_dbo, part_dby, part_dd, B,
+                       tiles, db_out, db_dil, db_cond, dd, dd_bs, s_out, s_dil, s_cond, dd_ls);
+    return set_check_launch("set_diffnet_layers_bwd_reduce");
 }
 
 // debug hook (tools/bf16_phase_probe.py): block (1, 1), thread 0 of the layer kernels stores s_memtime at its phase

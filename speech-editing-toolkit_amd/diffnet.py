@@ -139,10 +139,20 @@ class DiffNet(nn.Module):
             n = _lib.lib().set_diffnet_layer_bf16_image_size()
             dev = layers[0].dilated_conv.weight.device
             img = torch.empty(len(layers), n, dtype=torch.bfloat16, device=dev)
-            for i, l in enumerate(layers):
-                _lib.check(_lib.lib().set_pack_diffnet_layer_bf16(
-                    ops._p(l.dilated_conv.weight.detach()), ops._p(l.conditioner_projection.weight.detach()),
-                    ops._p(l.output_projection.weight.detach()), ops._p(img[i]), ops._stream()), "set_pack_diffnet_layer_bf16")
+            from .autograd_ops import _uniform_stride
+            strides = [_uniform_stride([getattr(l, name).weight.detach() for l in layers])
+                       for name in ("dilated_conv", "conditioner_projection", "output_projection")]
+            if all(st is not None for st in strides):  # (the flat optimizer's layout: every layer's tensors at one stride) one launch
+                l0 = layers[0]
+                _lib.check(_lib.lib().set_pack_diffnet_layers_bf16(
+                    ops._p(l0.dilated_conv.weight.detach()), ops._p(l0.conditioner_projection.weight.detach()),
+                    ops._p(l0.output_projection.weight.detach()), strides[0], strides[1], strides[2], ops._p(img), len(layers),
+                    ops._stream()), "set_pack_diffnet_layers_bf16")
+            else:
+                for i, l in enumerate(layers):
+                    _lib.check(_lib.lib().set_pack_diffnet_layer_bf16(
+                        ops._p(l.dilated_conv.weight.detach()), ops._p(l.conditioner_projection.weight.detach()),
+                        ops._p(l.output_projection.weight.detach()), ops._p(img[i]), ops._stream()), "set_pack_diffnet_layer_bf16")
             self._img16, self._img16_key = img, key
         return self._img16
 

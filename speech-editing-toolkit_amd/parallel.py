@@ -217,7 +217,17 @@ class GradBucketer:
 
     def _launch(self, b, why):
         s, e = self.buckets[b]
-        self._works[b] = dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True)
+        leaf = None
+        if self.flat_g.is_cuda:
+            # gradient kernels of this bucket may still be queued on the leaf stream (autograd_ops.leaf_work): the collective is enqueued
+            # behind BOTH streams -- from the leaf stream, after it has been made to wait for the compute stream -- without stalling backward
+            from . import autograd_ops as A
+            leaf = A.leaf_fence(self.flat_g.device)
+        if leaf is not None:
+            with torch.cuda.stream(leaf):
+                self._works[b] = dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            self._works[b] = dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True)
         self.launch_log.append((b, why))
         self.event_log.append(("launch", b))
         self.bytes_reduced += 4 * (e - s)

@@ -102,6 +102,7 @@ class FlatAdamW:
         """A step that failed between zero_grad() and step(): close the zero arena and leave the "in step" state, so that a
         later backward outside a zero_grad()/step() pair goes through autograd instead of writing into the flat buffer."""
         A.zero_arena_end()
+        A.leaf_join()
         self.in_step = False
 
     def step(self, graph_hyper=None):
@@ -110,6 +111,7 @@ class FlatAdamW:
         schedule (base_task.py:129-137).  graph_hyper (GraphedTrainStep, while a step is being captured): a device tensor
         [lr, bc1, bc2] the update reads instead of host values; the update counter is then advanced by the replaying caller."""
         A.zero_arena_end()
+        A.leaf_join()  # (normally done already, by the callback at the end of backward())
         self.in_step = False
         self._learned = True
         if not self._unused_checked:  # once: a parameter declared unreachable that did receive a gradient would silently diverge across ranks
