@@ -362,7 +362,7 @@ def run_infer(args, rank, world, dev):
     ach_tflops = groups * flop_per_launch / (launch_ms * 1e-3) / 1e12
     ach_wall = FLOP_PER_FRAME_LAYER * B_PER_GPU * T * L * DIFF_STEPS * len(loop_ms) / (sum(loop_ms) * 1e-3) / 1e12
     ach_gbs = groups * bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    # HBM bytes per launch of the dominant kernel from the PMC passes (tools/gpu_pmc_r03.sh: separate --pmc runs, 2 x FETCH_SIZE +
+    # HBM bytes per launch of the dominant kernel from the PMC passes (tools/sessions/gpu_pmc_r04.sh: separate --pmc runs, 2 x FETCH_SIZE +
     # WRITE_SIZE per MI355X_MICROARCH.md).  Counters cannot be collected inside this process, so the figure is the one measured
     # on the SAME kernel sources: the file carries their sha256 and the figure is withheld (null) when the sources changed since.
     traffic, traffic_note, pmc = None, None, None
@@ -636,7 +636,7 @@ def bf16_loop_line(model, inp, args, ret_f32_seed0):
     tfl = (FLOP_PER_FRAME_LAYER + 2 * 512 * 192) * B_PER_GPU * T * L / (span_ms * 1e-3) / 1e12
     from set_amd import _lib
     fuse = int(_lib.lib().set_diffnet_layers_bf16_plan(B_PER_GPU, T, L, 1))
-    # HBM bytes per group launch from the PMC passes of THESE kernel sources (tools/gpu_pmc_bf16_layers.sh; sha256-checked like the headline's)
+    # HBM bytes per group launch from the PMC passes of THESE kernel sources (tools/sessions/gpu_pmc_bf16_layers.sh; sha256-checked like the headline's)
     traffic, traffic_note, pmc = None, "no PMC file", None
     tfile = os.path.join(ROOT, "profiles", "r04_pmc_bf16_layers.json")
     if os.path.exists(tfile):

@@ -366,6 +366,10 @@ int set_randn(float *out, int64_t n, uint64_t seed, uint64_t offset, void *strea
  * replay of step k stores (seed_k - seed_captured) in the word before it launches the graph and draws exactly the numbers the eager
  * step k draws.  Process-wide; the word must stay allocated while it is set. */
 int set_rng_seed_delta(const uint64_t *dev_word);
+/* Host-side stream ordering (the training path's leaf stream, autograd_ops.leaf_work): work enqueued on `after` from now on waits for
+ * everything enqueued on `first` so far (hipEventRecord + hipStreamWaitEvent on a cached event; slot < 32 selects the event, one per
+ * direction and device).  Capturable: inside a stream capture the pair is a cross-stream edge. */
+int set_stream_order(void *first, void *after, int32_t slot);
 
 /* Whole reverse loop (spec_denoiser.py:178-184 + p_sample :103-108 + DiffNet.forward diffnet.py:110-132)
  * for residual_channels == 256.  All weights pre-packed by the caller; workspaces provided by the caller.

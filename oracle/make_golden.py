@@ -379,6 +379,13 @@ def hifigan_case(name, h, B, T, wseed, iseed, manifest=None):
         mel=mel, wav=wav)
 
 
+def hifigan_v23_cases():
+    """The V2 (C0 = 128) and V3 (ResBlock2, rates [8, 8, 4], kernels [3, 5, 7], dilations [[1, 2], [2, 6], [3, 12]]) generator shapes of
+    the HiFi-GAN paper at T = 200 (51,200 samples: many tiles per stage, every halo crosses tile borders)."""
+    hifigan_case("hifigan_v2", Wt.HIFIGAN_V2, B=1, T=200, wseed=24, iseed=205)
+    hifigan_case("hifigan_v3", Wt.HIFIGAN_V3, B=1, T=200, wseed=25, iseed=206)
+
+
 def edit_case(hp, name, seed, steps, wseed, vseed, h, **gen):
     """The reference's SpecDenoiserInfer.forward_model (inference/tts/spec_denoiser.py:63-149) on a synthetic edit
     request: constructor bypassed (it needs dictionaries, a speaker encoder and checkpoints), `input_to_batch`
@@ -468,6 +475,7 @@ def main():
     hifigan_case("hifigan_v1", Wt.HIFIGAN_V1, B=1, T=12, wseed=23, iseed=203)
     # real-length V1: 56,320 output samples, many tiles per stage, every dilation x kernel halo crosses tile borders
     hifigan_case("hifigan_v1_long", Wt.HIFIGAN_V1, B=1, T=220, wseed=23, iseed=204, manifest="hifigan_v1")
+    hifigan_v23_cases()
     edit_cases(hp)
     nopitch_cases(hp)
     normal_cases(hp)
@@ -650,6 +658,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "bbs":
         ref_import.install(timesteps=4)
         batch_by_size_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "hifigan_v23":
+        ref_import.install(timesteps=4)
+        hifigan_v23_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "hifigan_long":
         ref_import.install(timesteps=4)
         hifigan_case("hifigan_v1_long", Wt.HIFIGAN_V1, B=1, T=220, wseed=23, iseed=204, manifest="hifigan_v1")

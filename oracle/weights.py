@@ -164,6 +164,26 @@ HIFIGAN_V1 = {
     "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
 }
 
+# the other two generator shapes of the HiFi-GAN paper (the reference's real config.yaml is an external download,
+# tasks/tts/vocoder_infer/hifigan.py:14-18: generic-h is the only defence, so it is pinned on all three published shapes)
+HIFIGAN_V2 = {
+    "resblock": "1",
+    "upsample_rates": [8, 8, 2, 2],
+    "upsample_kernel_sizes": [16, 16, 4, 4],
+    "upsample_initial_channel": 128,
+    "resblock_kernel_sizes": [3, 7, 11],
+    "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+}
+
+HIFIGAN_V3 = {
+    "resblock": "2",
+    "upsample_rates": [8, 8, 4],
+    "upsample_kernel_sizes": [16, 16, 8],
+    "upsample_initial_channel": 256,
+    "resblock_kernel_sizes": [3, 5, 7],
+    "resblock_dilation_sizes": [[1, 2], [2, 6], [3, 12]],
+}
+
 HIFIGAN_TINY = {
     "resblock": "1",
     "upsample_rates": [4, 2],

@@ -234,6 +234,7 @@ SIGNATURES = {
     "set_q_sample": (C.c_int, [_V, _V, _V, _V, _V, _I32, _I32, _I32, _V]),
     "set_randn": (C.c_int, [_V, _I64, _U64, _U64, _V]),
     "set_rng_seed_delta": (C.c_int, [_V]),
+    "set_stream_order": (C.c_int, [_V, _V, _I32]),
     "set_diffusion_loop": (C.c_int, [C.POINTER(SetDiffLoopArgs), _V]),
     "set_selftest_mfma": (C.c_int, [C.POINTER(C.c_float), _V]),
     "set_sizeof_attn_args": (_I64, []),

@@ -65,6 +65,8 @@ def graph_released():
     GRAPHS_ALIVE[0] = max(0, GRAPHS_ALIVE[0] - 1)
     if GRAPHS_ALIVE[0] == 0:
         del _RETIRED[:]
+
+
 CAPTURED_ABORT_WORDS = []  # sync workspaces of persistent stack kernels inside captured steps ([1] != 0: a dependency wait timed out)
 
 
@@ -77,9 +79,10 @@ CAPTURED_ABORT_WORDS = []  # sync workspaces of persistent stack kernels inside 
 # weight gradients, ~70 ordered bias / partial reductions), most of it while the chain itself runs 5-40 us kernels on a few dozen workgroups.
 # They are enqueued on a second HIP stream instead, ordered after the compute stream by an event at the point of the call, and the optimizer
 # step / bucket launch waits for that stream (leaf_join / leaf_fence).  Results are unchanged bit for bit: same kernels, same operands, each
-# target written by exactly one stream.  Tensors handed to a leaf kernel are record_stream()ed (their storage must not be reused by the
-# compute stream before the leaf kernel has read it); reduction scratch buffers are per stream.  SET_AMD_LEAF_STREAM=0 switches it off.
-_LEAF = {}  # device index -> {"stream", "event", "dirty"}
+# target written by exactly one stream.  Tensors handed to a leaf kernel stay referenced until the join (their storage must not be reused by
+# the compute stream before the leaf kernel has read it); reduction scratch buffers are per stream.  SET_AMD_LEAF_STREAM=0 switches it off.
+# Host cost per fork: one C call (set_stream_order); torch's Event / Stream / record_stream wrappers cost ~28 us per fork (1.1 ms per step).
+_LEAF = {}  # device index -> {"stream" (torch object, kept alive), "raw" (handle), "dirty", "keep" (operands of queued leaf kernels)}
 
 
 def leaf_enabled():
@@ -87,32 +90,32 @@ def leaf_enabled():
 
 
 def _leaf_state(dev):
-    st = _LEAF.get(dev.index)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _LEAF.get(idx)
     if st is None:
-        st = _LEAF[dev.index] = {"stream": torch.cuda.Stream(device=dev), "event": torch.cuda.Event(), "dirty": False}
+        stream = torch.cuda.Stream(device=dev)
+        st = _LEAF[idx] = {"stream": stream, "raw": C.c_void_p(stream.cuda_stream), "dirty": False, "keep": [], "idx": idx}
     return st
 
 
 class leaf_work:
-    """with leaf_work(device, use, *tensors) as on_leaf: kernels enqueued inside run on the device's leaf stream (after everything enqueued on
-    the current stream so far) when `use` holds; `tensors` are the operands the compute stream's allocator must keep until then."""
+    """with leaf_work(device, use, *tensors) as on_leaf: kernels launched inside (ops._stream()) go to the device's leaf stream, ordered after
+    everything enqueued on the current stream so far, when `use` holds.  `tensors`: the operands; they are kept referenced until the
+    compute stream has been made to wait for the leaf stream (leaf_join), so the allocator cannot hand their storage to a compute-stream
+    kernel that might run before the leaf kernel has read it.  Nothing may be ALLOCATED inside (torch's current stream is unchanged)."""
 
     def __init__(self, dev, use, *tensors):
-        self.on = bool(use) and dev.type == "cuda" and leaf_enabled()
+        self.on = bool(use) and dev.type == "cuda" and leaf_enabled() and getattr(ops._STREAM_TLS, "leaf", None) is None
         self.dev, self.tensors = dev, tensors
 
     def __enter__(self):
         if not self.on:
             return False
         st = _leaf_state(self.dev)
-        main = torch.cuda.current_stream(self.dev)
-        st["event"].record(main)
-        st["stream"].wait_event(st["event"])
-        for t in self.tensors:
-            if t is not None:
-                t.record_stream(st["stream"])
-        self._prev = main
-        torch.cuda.set_stream(st["stream"])
+        check(L().set_stream_order(_stream(), st["raw"], 2 * st["idx"]), "set_stream_order")
+        st["keep"].append(self.tensors)
+        ops._STREAM_TLS.leaf = st["raw"]
+        self._st = st
         if not st["dirty"]:
             st["dirty"] = True
             try:  # the stream that ran backward() waits for the leaf stream when the pass is over: callers may read .grad right away
@@ -123,26 +126,28 @@ class leaf_work:
 
     def __exit__(self, *exc):
         if self.on:
-            torch.cuda.set_stream(self._prev)
+            ops._STREAM_TLS.leaf = None
         return False
 
 
 def leaf_join():
-    """The current stream waits for everything enqueued on the leaf streams (before the optimizer reads the gradients)."""
+    """The current stream waits for everything enqueued on the leaf streams (before the optimizer reads the gradients); the operands
+    held for the leaf kernels are released (whatever reuses their storage is ordered after this point)."""
     for idx, st in _LEAF.items():
         if st["dirty"]:
-            torch.cuda.current_stream(torch.device("cuda", idx)).wait_stream(st["stream"])
+            with torch.cuda.device(idx):
+                check(L().set_stream_order(st["raw"], _stream(), 2 * idx + 1), "set_stream_order")
             st["dirty"] = False
+            del st["keep"][:]
 
 
 def leaf_fence(dev):
     """For a consumer that must see BOTH streams' work without stalling the compute stream (a bucket all-reduce launched from an autograd
-    hook): returns the leaf stream after making it wait for the current stream, or None when no leaf work is pending on `dev`."""
-    st = _LEAF.get(dev.index) if dev.type == "cuda" else None
+    hook): returns the leaf stream (torch object) after making it wait for the current stream, or None when no leaf work is pending."""
+    st = _LEAF.get(dev.index if dev.index is not None else torch.cuda.current_device()) if dev.type == "cuda" else None
     if st is None or not st["dirty"]:
         return None
-    st["event"].record(torch.cuda.current_stream(dev))
-    st["stream"].wait_event(st["event"])
+    check(L().set_stream_order(_stream(), st["raw"], 2 * st["idx"]), "set_stream_order")
     return st["stream"]
 
 
@@ -205,12 +210,21 @@ def _stream_key(device):
     return (device, _stream().value)
 
 
+def _leaf_keep(buf):
+    """A scratch buffer replaced while the leaf stream is the launch stream: kernels queued there may still use it -- held until the join."""
+    if getattr(ops._STREAM_TLS, "leaf", None) is not None:
+        for st in _LEAF.values():
+            if st["dirty"]:
+                st["keep"].append(buf)
+
+
 def _det_scratch(device, n_floats):
     key = _stream_key(device)
     buf = _DET_SCRATCH.get(key)
     if buf is None or buf.numel() < n_floats:
         if buf is not None:
             _retire(buf)
+            _leaf_keep(buf)
         buf = torch.empty(int(n_floats * 1.25) + 4096, dtype=torch.float32, device=device)
         _DET_SCRATCH[key] = buf
     return buf
@@ -222,6 +236,7 @@ def _wg_scratch(device, need):
     if buf is None or buf.numel() < need:
         if buf is not None:
             _retire(buf)
+            _leaf_keep(buf)
         buf = torch.empty(int(need * 1.25) + 1024, dtype=torch.float32, device=device)
         _WG_SCRATCH[key] = buf
     return buf

@@ -386,3 +386,15 @@ extern "C" int set_length_regulate(const float *dur, const int64_t *txt, int64_t
                        (hipStream_t)stream, dur, txt, mel2ph, T_txt, T_out);
     return set_check_launch("set_length_regulate");
 }
+
+// Stream ordering for the host side's second ("leaf") stream: everything enqueued on `after` from now on waits for everything enqueued on
+// `first` so far.  One event per call site slot (created once, timing disabled), re-recorded at every call; inside a stream capture the pair
+// becomes a cross-stream edge of the graph.  Replaces torch's Event.record + Stream.wait_event (two Python -> C++ round trips per fork).
+extern "C" int set_stream_order(void *first, void *after, int32_t slot) {
+    static hipEvent_t ev[32] = {nullptr};
+    SET_REQUIRE(slot >= 0 && slot < 32, "set_stream_order");
+    if (!ev[slot]) SET_HIP(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming), "set_stream_order(event)");
+    SET_HIP(hipEventRecord(ev[slot], (hipStream_t)first), "set_stream_order(record)");
+    SET_HIP(hipStreamWaitEvent((hipStream_t)after, ev[slot], 0), "set_stream_order(wait)");
+    return SET_OK;
+}

@@ -87,9 +87,17 @@ def repack_bf16_images():
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+import threading  # noqa: E402
+
+_STREAM_TLS = threading.local()  # .leaf: raw handle of the leaf stream while autograd_ops.leaf_work is open IN THIS THREAD (kernels only)
+
+
 def _stream():
     """The current torch HIP stream of the current device as a raw handle.  (torch.cuda.current_stream() builds a Stream
     object through several Python layers -- ~10 us, once per kernel launch: ~3 ms of a 1,400-launch training step.)"""
+    leaf = getattr(_STREAM_TLS, "leaf", None)
+    if leaf is not None:
+        return leaf
     if _RAW_STREAM is not None:
         return C.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -999,7 +999,8 @@ def test_task_run_model_paste(dev):
 # HiFi-GAN
 # ----------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,h", [("hifigan_tiny", Wt.HIFIGAN_TINY), ("hifigan_tiny_rb2", Wt.HIFIGAN_TINY_RB2),
-                                    ("hifigan_v1", Wt.HIFIGAN_V1), ("hifigan_v1_long", Wt.HIFIGAN_V1)])
+                                    ("hifigan_v1", Wt.HIFIGAN_V1), ("hifigan_v1_long", Wt.HIFIGAN_V1),
+                                    ("hifigan_v2", Wt.HIFIGAN_V2), ("hifigan_v3", Wt.HIFIGAN_V3)])
 @pytest.mark.parametrize("impl", ["auto", "naive", "mfma"])
 def test_hifigan_matches_reference(dev, name, h, impl, monkeypatch):
     """`hifigan_v1_long` = the V1 generator at T=220 (56,320 samples): many tiles per stage, every dilation x kernel halo
@@ -1009,7 +1010,9 @@ def test_hifigan_matches_reference(dev, name, h, impl, monkeypatch):
     the fp16 range flag must stay clear (a set flag would mean the forward silently fell back to the fp32 kernels)."""
     from set_amd import ops
     from set_amd.hifigan import HifiGanGenerator
-    if impl == "naive" and name.endswith("_long"):
+    # hifigan_v2 / hifigan_v3 (VERDICT r4 #6): the paper's other two generator shapes at T = 200 -- C0 = 128 (stages of 64 / 32 / 16 / 8
+    # channels) and ResBlock2 with rates [8, 8, 4], kernels [3, 5, 7], dilations [[1, 2], [2, 6], [3, 12]] -- reference-generated
+    if impl == "naive" and (name.endswith("_long") or name in ("hifigan_v2", "hifigan_v3")):
         pytest.skip("the one-thread-per-output cross-check kernel is exercised by the short cases")
     if impl == "auto":
         assert ops._DEFAULT_IMPL == "auto"

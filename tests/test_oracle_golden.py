@@ -113,7 +113,7 @@ def test_length_regulator():
 
 
 @pytest.mark.parametrize("name,h", [("hifigan_tiny", Wt.HIFIGAN_TINY), ("hifigan_tiny_rb2", Wt.HIFIGAN_TINY_RB2),
-                                    ("hifigan_v1", Wt.HIFIGAN_V1)])
+                                    ("hifigan_v1", Wt.HIFIGAN_V1), ("hifigan_v2", Wt.HIFIGAN_V2), ("hifigan_v3", Wt.HIFIGAN_V3)])
 def test_oracle_hifigan(name, h):
     g = load_golden(name)
     W = Wt.seeded_weights(Wt.load_manifest(name), g["meta"]["wseed"])

@@ -33,6 +33,28 @@ if not campnet:
 for w in range(3):
     task.training_step(sample, opt, seed=w)
 torch.cuda.synchronize()
+# host time of the four phases of ONE step issued into an EMPTY queue (after a synchronize: no back-pressure, so this is Python + HIP
+# launch cost only), three times
+import time
+for rep in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    opt.zero_grad()
+    t1 = time.perf_counter()
+    losses, _ = task.run_model(sample, infer=False, seed=100 + rep)
+    with torch.enable_grad():
+        total = sum(losses.values())
+    t2 = time.perf_counter()
+    total.backward()
+    t3 = time.perf_counter()
+    opt.step()
+    t4 = time.perf_counter()
+    torch.cuda.synchronize()
+    t5 = time.perf_counter()
+    print("host phases (ms): zero_grad %.2f | forward %.2f | backward %.2f | optimizer %.2f | total enqueue %.2f | + drain %.2f"
+          % (1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t4 - t3), 1e3 * (t4 - t0), 1e3 * (t5 - t4)), flush=True)
+if hasattr(task, "global_step"):
+    pass
 pr = cProfile.Profile()
 pr.enable()
 N = 5

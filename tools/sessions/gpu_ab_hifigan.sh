@@ -1,5 +1,5 @@
 # A/B on ONE box (boxes differ by ~5 %): per-stage times of the HiFi-GAN V1 forward under the settings given as arguments
-# usage: tools/gpu_ab_hifigan.sh "ENV=.. ENV=.." "ENV=.." ...   (an argument "head" = the build/exp/libset_amd_head.so library)
+# usage: tools/sessions/gpu_ab_hifigan.sh "ENV=.. ENV=.." "ENV=.." ...   (an argument "head" = the build/exp/libset_amd_head.so library)
 for rep in 1 2; do
   for cfg in "$@"; do
     echo "== $cfg"

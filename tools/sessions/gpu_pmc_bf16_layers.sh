@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes (separate runs, --kernel-trace only) of the fused bf16 layer-group kernels at B = 32, T = 800 (tools/bf16_layers_probe.py):
 # MFMA busy cycles / clock / wait shares / LDS bank conflicts and HBM bytes per launch -> gpurun_out/pmc_bf16_layers_<tile>.json
-# usage: TILE=64|128 [VARIANT=0..3] [NLS=5,10] tools/gpu_pmc_bf16_layers.sh
+# usage: TILE=64|128 [VARIANT=0..3] [NLS=5,10] tools/sessions/gpu_pmc_bf16_layers.sh
 set -u
 cd "$GRAFT_REPO_ROOT"; OUT=gpurun_out/pmc_bf16; mkdir -p $OUT; export TMPDIR=/tmp; R="$GRAFT_REPO_ROOT"
 export SET_AMD_BF16_FUSE_TILE=${TILE:-128} SET_AMD_BF16_REG_VARIANT=${VARIANT:-0} NLS=${NLS:-5,10}

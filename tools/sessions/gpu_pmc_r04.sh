@@ -13,8 +13,8 @@ F=$(find $OUT/pmc_x3_fetch -name "*counter_collection.csv" | head -1); W=$(find 
 U=$(find $OUT/pmc_x3_util -name "*counter_collection.csv" | head -1)
 python tools/pmc_x3_summary.py "$F" "$W" "$U" $OUT/pmc_x3.json | tail -30
 find $OUT/pmc_x3_fetch $OUT/pmc_x3_write $OUT/pmc_x3_util -name "*.csv" -delete
-TILE=128 NLS=10 bash tools/gpu_pmc_bf16_layers.sh > $OUT/pmc_bf16_t128.log 2>&1; cp gpurun_out/pmc_bf16_layers_128.json $OUT/pmc_bf16_layers.json
-TILE=64 NLS=5 bash tools/gpu_pmc_bf16_layers.sh > $OUT/pmc_bf16_t64.log 2>&1; cp gpurun_out/pmc_bf16_layers_64.json $OUT/pmc_bf16_layers_tile64.json
+TILE=128 NLS=10 bash tools/sessions/gpu_pmc_bf16_layers.sh > $OUT/pmc_bf16_t128.log 2>&1; cp gpurun_out/pmc_bf16_layers_128.json $OUT/pmc_bf16_layers.json
+TILE=64 NLS=5 bash tools/sessions/gpu_pmc_bf16_layers.sh > $OUT/pmc_bf16_t64.log 2>&1; cp gpurun_out/pmc_bf16_layers_64.json $OUT/pmc_bf16_layers_tile64.json
 rm -rf $OUT/prof_bench
 (cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats -d "$R/$OUT/prof_bench" -o bench -- python "$R/bench.py" --no-cpu-baseline --no-native-fp32 --no-bf16x3-loop --no-secondary --no-quality --steps 3 > "$R/$OUT/rocprof_bench.log" 2>&1)
 tail -1 $OUT/rocprof_bench.log | cut -c1-300

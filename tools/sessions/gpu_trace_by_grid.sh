@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-(kernel, grid) time of a training step: rocprofv3 kernel trace of `bench.py --mode train` -> gpurun_out/trace/<model>_by_grid.csv
-# usage: tools/gpu_trace_by_grid.sh [campnet|spec_denoiser] [bf16|f32] [rows to print]
+# usage: tools/sessions/gpu_trace_by_grid.sh [campnet|spec_denoiser] [bf16|f32] [rows to print]
 set -u
 MODEL=${1:-campnet}; DT=${2:-bf16}; TOP=${3:-60}
 cd "$GRAFT_REPO_ROOT"; OUT=gpurun_out/trace; mkdir -p $OUT; export TMPDIR=/tmp; R="$GRAFT_REPO_ROOT"
