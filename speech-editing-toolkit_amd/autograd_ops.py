@@ -93,9 +93,33 @@ def _leaf_state(dev):
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _LEAF.get(idx)
     if st is None:
-        stream = torch.cuda.Stream(device=dev)
-        st = _LEAF[idx] = {"stream": stream, "raw": C.c_void_p(stream.cuda_stream), "dirty": False, "keep": [], "idx": idx}
+        # lowest priority: its chip-filling GEMMs yield workgroup slots to the compute stream's short kernels (SET_AMD_LEAF_PRIORITY=0: default)
+        if os.environ.get("SET_AMD_LEAF_PRIORITY", "low") != "0":
+            raw = C.c_void_p()
+            with torch.cuda.device(idx):
+                check(L().set_stream_create_low_priority(C.byref(raw)), "set_stream_create_low_priority")
+            stream = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
+        else:
+            stream = torch.cuda.Stream(device=dev)
+            raw = C.c_void_p(stream.cuda_stream)
+        st = _LEAF[idx] = {"stream": stream, "raw": raw, "dirty": False, "keep": [], "idx": idx}
     return st
+
+
+def _order(st, fork):
+    """fork: the leaf stream waits for the current stream; else (join) the current stream waits for the leaf stream.  Eager: one C call on a
+    cached event.  While the current stream is being captured (training.GraphedTrainStep) torch's own wait_stream with a fresh event: a graph
+    captured through the cached events crashed in its first replay (ROCm 7.2; the same capture through torch events replays fine)."""
+    if torch.cuda.is_current_stream_capturing():
+        cur = torch.cuda.current_stream()
+        if fork:
+            st["stream"].wait_stream(cur)
+        else:
+            cur.wait_stream(st["stream"])
+    elif fork:
+        check(L().set_stream_order(_stream(), st["raw"], 2 * st["idx"]), "set_stream_order")
+    else:
+        check(L().set_stream_order(st["raw"], _stream(), 2 * st["idx"] + 1), "set_stream_order")
 
 
 class leaf_work:
@@ -112,7 +136,7 @@ class leaf_work:
         if not self.on:
             return False
         st = _leaf_state(self.dev)
-        check(L().set_stream_order(_stream(), st["raw"], 2 * st["idx"]), "set_stream_order")
+        _order(st, True)
         st["keep"].append(self.tensors)
         ops._STREAM_TLS.leaf = st["raw"]
         self._st = st
@@ -136,7 +160,7 @@ def leaf_join():
     for idx, st in _LEAF.items():
         if st["dirty"]:
             with torch.cuda.device(idx):
-                check(L().set_stream_order(st["raw"], _stream(), 2 * idx + 1), "set_stream_order")
+                _order(st, False)
             st["dirty"] = False
             del st["keep"][:]
 
@@ -147,7 +171,7 @@ def leaf_fence(dev):
     st = _LEAF.get(dev.index if dev.index is not None else torch.cuda.current_device()) if dev.type == "cuda" else None
     if st is None or not st["dirty"]:
         return None
-    check(L().set_stream_order(_stream(), st["raw"], 2 * st["idx"]), "set_stream_order")
+    _order(st, True)
     return st["stream"]
 
 
@@ -218,16 +242,31 @@ def _leaf_keep(buf):
                 st["keep"].append(buf)
 
 
-def _det_scratch(device, n_floats):
+DET_HDR = 16  # floats: arrival counters of the in-launch reductions (csrc/rows_sum.h), zero between calls
+
+
+def _det_buf(device, n_floats):
+    """Per-stream scratch of the ordered reductions: [0, DET_HDR) counter words (the buffer is allocated zero-filled and every kernel
+    leaves them zero), partial results behind them."""
     key = _stream_key(device)
     buf = _DET_SCRATCH.get(key)
-    if buf is None or buf.numel() < n_floats:
+    if buf is None or buf.numel() < n_floats + DET_HDR:
         if buf is not None:
             _retire(buf)
             _leaf_keep(buf)
-        buf = torch.empty(int(n_floats * 1.25) + 4096, dtype=torch.float32, device=device)
+        buf = torch.zeros(int(n_floats * 1.25) + 4096 + DET_HDR, dtype=torch.float32, device=device)
         _DET_SCRATCH[key] = buf
     return buf
+
+
+def _det_scratch(device, n_floats):
+    """Partial-result area only (kernels followed by a separate ordered-sum launch)."""
+    return _det_buf(device, n_floats)[DET_HDR:]
+
+
+def _det_scratch_counted(device, n_floats):
+    """Header + partial-result area (set_channel_sum_det / set_weighted_sum_det / set_sumsq_det: the last block reduces in the same launch)."""
+    return _det_buf(device, n_floats)
 
 
 def _wg_scratch(device, need):
@@ -244,7 +283,7 @@ def _wg_scratch(device, need):
 
 def channel_sum_(x, out, B, Cc, T):
     """out[c] += sum_{b,t} x[b][c][t], per-slice partials combined in slice order (deterministic)."""
-    check(L().set_channel_sum_det(_p(x), _p(out), B, Cc, T, _p(_det_scratch(x.device, 2048 + Cc)), _stream()), "set_channel_sum_det")
+    check(L().set_channel_sum_det(_p(x), _p(out), B, Cc, T, _p(_det_scratch_counted(x.device, 2048 + Cc)), _stream()), "set_channel_sum_det")
 
 
 _WG_SCRATCH = {}  # (device, stream) -> slice-partial buffer of the deterministic weight-gradient path (reused: stream-ordered)
@@ -434,7 +473,7 @@ class _LayerNormChFn(torch.autograd.Function):
         sb, _ = grad_sink(ctx.bparam)
         dg = sg if sg is not None else _zeros_like(gamma)
         db = sb if sb is not None else _zeros_like(gamma)
-        part = torch.empty(L().set_layernorm_ch_bwd_scratch(B, Cc, T), dtype=torch.float32, device=x.device)
+        part = _det_scratch_counted(x.device, L().set_layernorm_ch_bwd_scratch(B, Cc, T))  # counter header + per-block partial rows
         check(L().set_layernorm_ch_bwd(_p(x), _p(gamma), _p(mask), _p(dy), _p(dx), _p(dg), _p(db), _p(part), B, Cc, T,
                                        float(ctx.eps), _stream()), "set_layernorm_ch_bwd")
         return dx, (None if sg is not None else dg), (None if sb is not None else db), None, None
@@ -1165,7 +1204,7 @@ def frame_weights(target_btm):
 
 def _sum(x, w=None, inner=1):
     out = torch.zeros(1, dtype=torch.float32, device=x.device)
-    check(L().set_weighted_sum_det(_p(x), _p(w), _p(out), x.numel(), inner, _p(_det_scratch(x.device, 1024)), _stream()),
+    check(L().set_weighted_sum_det(_p(x), _p(w), _p(out), x.numel(), inner, _p(_det_scratch_counted(x.device, 1024)), _stream()),
           "set_weighted_sum_det")
     return out
 
@@ -1318,7 +1357,7 @@ def pitch_losses(pp_bct, f0, uv, mel2ph, lam_uv, lam_f0):
 # --------------------------------------------------------------------------------------------------
 def grad_sumsq(flat_grad):
     out = torch.zeros(1, dtype=torch.float32, device=flat_grad.device)
-    check(L().set_sumsq_det(_p(flat_grad), _p(out), flat_grad.numel(), _p(_det_scratch(flat_grad.device, 2048)), _stream()),
+    check(L().set_sumsq_det(_p(flat_grad), _p(out), flat_grad.numel(), _p(_det_scratch_counted(flat_grad.device, 2048)), _stream()),
           "set_sumsq_det")
     return out
 

@@ -400,7 +400,10 @@ __global__ void __launch_bounds__(256, RB == 1 ? 4 : (RB == 2 ? 3 : 2)) conv1d_m
                     // have it -- made the fp32 training step differ between two runs of the same state (round 4,
                     // test_full_size_training_step_is_bit_stable[f32]; tools/hw/buf_oob_probe.hip shows masked 4- and 16-byte stores are
                     // dropped, with and without a scalar offset, so the cause is not understood) -- reverted rather than explained)
-#if SET_CONV_V2_MASKED_STORE  // measurement build (tools/build_exp.sh): the range-masked form of this store
+#if SET_CONV_V2_MASKED_STORE  // measurement builds (tools/build_exp.sh): 1 = the range-masked form of this store, 2 = the same behind a full wait
+#if SET_CONV_V2_MASKED_STORE == 2
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                     buf_store4((v + rv4[i]) * msk4, d_out, (row0 + q < a.Cout) ? (unsigned)(q * a.out_cs + nc) * 4u : BUF_OOB, (unsigned)(row0 * a.out_cs) * 4u);
 #else
                     if (row0 + q < a.Cout)

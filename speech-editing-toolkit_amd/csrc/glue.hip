@@ -398,3 +398,16 @@ extern "C" int set_stream_order(void *first, void *after, int32_t slot) {
     SET_HIP(hipStreamWaitEvent((hipStream_t)after, ev[slot], 0), "set_stream_order(wait)");
     return SET_OK;
 }
+
+// A non-blocking stream of the LOWEST priority the device offers: the leaf stream's chip-filling weight-gradient GEMMs must not hold
+// the workgroup slots the compute stream's short kernels are waiting for (measured with equal priorities: a 5 us ordered sum of the
+// compute stream took 110 - 170 us behind a grouped weight-gradient launch).  Never destroyed (one per process and device).
+extern "C" int set_stream_create_low_priority(void **out) {
+    SET_REQUIRE(out != nullptr, "set_stream_create_low_priority");
+    int least = 0, greatest = 0;
+    SET_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest), "set_stream_create_low_priority(range)");
+    hipStream_t s = nullptr;
+    SET_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least), "set_stream_create_low_priority");
+    *out = (void *)s;
+    return SET_OK;
+}
