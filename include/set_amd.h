@@ -616,11 +616,8 @@ int set_channel_sum(const float *x, float *out, int32_t B, int32_t C, int32_t T,
  * set_expand_states_bwd) give results whose last bits depend on the arrival order of the blocks.  The *_det variants
  * below write one partial result per block / slice into `scratch` and combine them in a fixed order: bit-identical from
  * run to run (what makes a resumed training run repeat the uninterrupted one exactly).  `scratch` may be reused by the
- * next call on the same stream.  Sizes (floats): channel_sum 16 + 2048 + C; weighted_sum 16 + 1024; sumsq 16 + 2048; dur 4 B;
- * pitch 4 ceil(B T / 256); scatter_rows B * set_scatter_rows_segments(T) * n_rows * C.
- * channel_sum / weighted_sum / sumsq reduce inside the SAME launch (the last block to arrive sums the partials in slice order):
- * their scratch[0 .. 16) holds the arrival counter -- it must be zero before the first call on a buffer, every call leaves it zero,
- * and calls that share a buffer must be ordered on one stream. */
+ * next call on the same stream.  Sizes (floats): channel_sum 2048 + C; weighted_sum 1024; sumsq 2048; dur 4 B;
+ * pitch 4 ceil(B T / 256); scatter_rows B * set_scatter_rows_segments(T) * n_rows * C. */
 int set_channel_sum_det(const float *x, float *out, int32_t B, int32_t C, int32_t T, float *scratch, void *stream);
 int set_weighted_sum_det(const float *x, const float *w, float *out, int64_t n, int64_t inner, float *scratch, void *stream);
 int set_sumsq_det(const float *g, float *out, int64_t n, float *scratch, void *stream);
@@ -650,10 +647,8 @@ int set_gate_bwd(const float *y, const float *dz, float *dy, int32_t B, int32_t 
 int set_res_skip_bwd(const float *dx_out, const float *dskip, float *dx, float *d_o, int32_t B, int32_t C, int32_t T,
                      void *stream);
 /* backward of set_layernorm_ch; dgamma/dbeta are accumulated (+=).  `partial`: scratch of
- * set_layernorm_ch_bwd_scratch(B, C, T) floats for a contention-free ordered reduction of dgamma/dbeta inside the SAME launch
- * (per-block partial rows, summed in block order by the last block to arrive): its first 16 floats are the arrival counter --
- * zero before the first call on a buffer, left zero by every call, calls sharing a buffer ordered on one stream; the rest may hold
- * anything.  NULL falls back to one atomic per (block, channel), which serialises across XCDs and is not bit-stable. */
+ * set_layernorm_ch_bwd_scratch(B, C, T) floats (contents irrelevant) for a contention-free two-pass reduction of
+ * dgamma/dbeta; NULL falls back to one atomic per (block, channel), which serialises across XCDs. */
 int64_t set_layernorm_ch_bwd_scratch(int32_t B, int32_t C, int32_t T);
 int set_layernorm_ch_bwd(const float *x, const float *gamma, const float *mask, const float *dy, float *dx,
                          float *dgamma, float *dbeta, float *partial, int32_t B, int32_t C, int32_t T, float eps,

@@ -242,31 +242,16 @@ def _leaf_keep(buf):
                 st["keep"].append(buf)
 
 
-DET_HDR = 16  # floats: arrival counters of the in-launch reductions (csrc/rows_sum.h), zero between calls
-
-
-def _det_buf(device, n_floats):
-    """Per-stream scratch of the ordered reductions: [0, DET_HDR) counter words (the buffer is allocated zero-filled and every kernel
-    leaves them zero), partial results behind them."""
+def _det_scratch(device, n_floats):
     key = _stream_key(device)
     buf = _DET_SCRATCH.get(key)
-    if buf is None or buf.numel() < n_floats + DET_HDR:
+    if buf is None or buf.numel() < n_floats:
         if buf is not None:
             _retire(buf)
             _leaf_keep(buf)
-        buf = torch.zeros(int(n_floats * 1.25) + 4096 + DET_HDR, dtype=torch.float32, device=device)
+        buf = torch.empty(int(n_floats * 1.25) + 4096, dtype=torch.float32, device=device)
         _DET_SCRATCH[key] = buf
     return buf
-
-
-def _det_scratch(device, n_floats):
-    """Partial-result area only (kernels followed by a separate ordered-sum launch)."""
-    return _det_buf(device, n_floats)[DET_HDR:]
-
-
-def _det_scratch_counted(device, n_floats):
-    """Header + partial-result area (set_channel_sum_det / set_weighted_sum_det / set_sumsq_det: the last block reduces in the same launch)."""
-    return _det_buf(device, n_floats)
 
 
 def _wg_scratch(device, need):
@@ -283,7 +268,7 @@ def _wg_scratch(device, need):
 
 def channel_sum_(x, out, B, Cc, T):
     """out[c] += sum_{b,t} x[b][c][t], per-slice partials combined in slice order (deterministic)."""
-    check(L().set_channel_sum_det(_p(x), _p(out), B, Cc, T, _p(_det_scratch_counted(x.device, 2048 + Cc)), _stream()), "set_channel_sum_det")
+    check(L().set_channel_sum_det(_p(x), _p(out), B, Cc, T, _p(_det_scratch(x.device, 2048 + Cc)), _stream()), "set_channel_sum_det")
 
 
 _WG_SCRATCH = {}  # (device, stream) -> slice-partial buffer of the deterministic weight-gradient path (reused: stream-ordered)
@@ -473,7 +458,7 @@ class _LayerNormChFn(torch.autograd.Function):
         sb, _ = grad_sink(ctx.bparam)
         dg = sg if sg is not None else _zeros_like(gamma)
         db = sb if sb is not None else _zeros_like(gamma)
-        part = _det_scratch_counted(x.device, L().set_layernorm_ch_bwd_scratch(B, Cc, T))  # counter header + per-block partial rows
+        part = _det_scratch(x.device, L().set_layernorm_ch_bwd_scratch(B, Cc, T))  # per-block partial rows (reused: stream-ordered)
         check(L().set_layernorm_ch_bwd(_p(x), _p(gamma), _p(mask), _p(dy), _p(dx), _p(dg), _p(db), _p(part), B, Cc, T,
                                        float(ctx.eps), _stream()), "set_layernorm_ch_bwd")
         return dx, (None if sg is not None else dg), (None if sb is not None else db), None, None
@@ -1204,7 +1189,7 @@ def frame_weights(target_btm):
 
 def _sum(x, w=None, inner=1):
     out = torch.zeros(1, dtype=torch.float32, device=x.device)
-    check(L().set_weighted_sum_det(_p(x), _p(w), _p(out), x.numel(), inner, _p(_det_scratch_counted(x.device, 1024)), _stream()),
+    check(L().set_weighted_sum_det(_p(x), _p(w), _p(out), x.numel(), inner, _p(_det_scratch(x.device, 1024)), _stream()),
           "set_weighted_sum_det")
     return out
 
@@ -1357,7 +1342,7 @@ def pitch_losses(pp_bct, f0, uv, mel2ph, lam_uv, lam_f0):
 # --------------------------------------------------------------------------------------------------
 def grad_sumsq(flat_grad):
     out = torch.zeros(1, dtype=torch.float32, device=flat_grad.device)
-    check(L().set_sumsq_det(_p(flat_grad), _p(out), flat_grad.numel(), _p(_det_scratch_counted(flat_grad.device, 2048)), _stream()),
+    check(L().set_sumsq_det(_p(flat_grad), _p(out), flat_grad.numel(), _p(_det_scratch(flat_grad.device, 2048)), _stream()),
           "set_sumsq_det")
     return out
 

@@ -3,8 +3,8 @@
 // Replaces every F.conv1d / nn.Linear / nn.ConvTranspose1d (polyphase) call on the hot path -- see
 // include/set_amd.h for the reference citations.
 #include "common.h"
-#ifndef SET_CONV_V2_MASKED_STORE
-#define SET_CONV_V2_MASKED_STORE 0
+#ifndef SET_CONV_V2_STORE_HAZARD
+#define SET_CONV_V2_STORE_HAZARD 0
 #endif
 #include <type_traits>
 
@@ -396,18 +396,21 @@ __global__ void __launch_bounds__(256, RB == 1 ? 4 : (RB == 2 ? 3 : 2)) conv1d_m
                     f32x4 v = *reinterpret_cast<const f32x4 *>(smem + (q + 16 * i) * 64 + col);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = dev_act((v[k] + bi8[i]) * a.alpha, kAct, a.act_param);
-                    // (kept as a branch: the range-masked form of THIS store -- `(row0 + q < Cout) ? off : BUF_OOB`, as the other epilogues
-                    // have it -- made the fp32 training step differ between two runs of the same state (round 4,
-                    // test_full_size_training_step_is_bit_stable[f32]; tools/hw/buf_oob_probe.hip shows masked 4- and 16-byte stores are
-                    // dropped, with and without a scalar offset, so the cause is not understood) -- reverted rather than explained)
-#if SET_CONV_V2_MASKED_STORE  // measurement builds (tools/build_exp.sh): 1 = the range-masked form of this store, 2 = the same behind a full wait
-#if SET_CONV_V2_MASKED_STORE == 2
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+                    // Range-masked like the other epilogues (a lane past Cout stores beyond num_records: dropped; no exec-masked block per
+                    // store, so the stores do not wait for each other), with the WHOLE offset in the VGPR (soffset 0).  Round 4 shipped a branch
+                    // here because the masked form made the fp32 training step differ from run to run; round 5 found why
+                    // (tools/grad_stability_probe.py TRACE=1): unbranched, the compiler rewrites the store's data registers in the
+                    // very next instruction (v_add_u32 v36 right behind buffer_store_dwordx4 v[34:37], ..., s10 offen -- 51 such pairs in the three
+                    // instantiations), and ROCm 7.2's hazard recognizer pads a > 64-bit buffer store against that only when its soffset is NOT an
+                    // SGPR.  On gfx950 the store then sometimes sends the overwritten dword (always component 2 of a few 16-byte stores, a few
+                    // dozen of 6.5 M elements per launch).  Measured: SGPR soffset = unstable 4 of 4 runs; + s_nop 1 behind the store, + vmcnt(0)
+                    // behind it, or soffset 0 (the compiler pads by itself) = bit-identical 5 of 5; a full wait IN FRONT of the store does not help.
+                    // (An inline-asm s_nop is not a fix: the scheduler may still put the VALU write between the store and the asm.)
+                    // tests/test_isa_schedule.py scans every kernel of the library for the pattern.
+#if SET_CONV_V2_STORE_HAZARD  // -DSET_CONV_V2_STORE_HAZARD=1 (tools/build_exp.sh): the SGPR-soffset form, for reproducing the hazard
                     buf_store4((v + rv4[i]) * msk4, d_out, (row0 + q < a.Cout) ? (unsigned)(q * a.out_cs + nc) * 4u : BUF_OOB, (unsigned)(row0 * a.out_cs) * 4u);
 #else
-                    if (row0 + q < a.Cout)
-                        buf_store4((v + rv4[i]) * msk4, d_out, (unsigned)(q * a.out_cs + nc) * 4u, (unsigned)(row0 * a.out_cs) * 4u);
+                    buf_store4((v + rv4[i]) * msk4, d_out, (row0 + q < a.Cout) ? (unsigned)((row0 + q) * a.out_cs + nc) * 4u : BUF_OOB, 0u);
 #endif
                 }
             };

@@ -6,8 +6,6 @@
 #include "common.h"
 #include "rows_sum.h"
 
-constexpr int DET_HDR = 16;  // floats at the head of a scratch buffer: arrival counters of the in-launch reductions (rows_sum.h)
-
 namespace {
 
 // -------------------------------------------------------------------------------------------------------
@@ -168,12 +166,8 @@ __global__ void __launch_bounds__(256) conv1d_wgrad_naive_kernel(WgradArgs a) {
 
 // out[c] += sum_{b,t} x[b][c][t]  (bias grads): grid (C, slices over the batch), wave-shuffle + LDS reduce, one atomic per
 // block.  (One block per channel left C <= 512 blocks to stream 50 MB: 27 us at B=32, T=800.)
-// part != NULL: the deterministic form -- per-block partials, summed in slice order by the last block to arrive (rows_sum.h); counter =
-// the first word of the scratch header
-__global__ void __launch_bounds__(256) channel_sum_kernel(const float *x, float *out, int B, int C, int T, float *part = nullptr,
-                                                          unsigned *counter = nullptr) {
-    __shared__ float red[256];
-    __shared__ unsigned flag;
+__global__ void __launch_bounds__(256) channel_sum_kernel(const float *x, float *out, int B, int C, int T, float *part = nullptr) {
+    __shared__ float red[4];
     const int c = blockIdx.x;
     float s = 0.0f;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
@@ -187,7 +181,6 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const float *x, float 
         const float v = red[0] + red[1] + red[2] + red[3];
         if (part) part[(int64_t)blockIdx.y * C + c] = v; else atomicAdd(&out[c], v);
     }
-    if (part) rows_sum_in_launch<256>(counter, gridDim.x * gridDim.y, part, out, (int)gridDim.y, C, true, 1.0f, red, &flag);
 }
 // out[b][c] = sum_t x[b][c][t] (* 1/div); one wave per (b,c)
 __global__ void __launch_bounds__(256) row_sum_kernel(const float *x, float *out, int64_t rows, int T, float scale) {
@@ -304,9 +297,10 @@ __device__ __forceinline__ void lnb_emit(float dg, float db, int c, int tl, floa
     }
 }
 
-__device__ __forceinline__ void layernorm_ch_bwd_body(const float *x, const float *gamma, const float *mask, const float *dy, float *dx,
-                                                      float *dgamma, float *dbeta, float *partial, int B, int C, int T, float eps,
-                                                      float (*red)[LNB_FT]) {
+__global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, const float *gamma, const float *mask,
+                                                               const float *dy, float *dx, float *dgamma, float *dbeta,
+                                                               float *partial, int B, int C, int T, float eps) {
+    __shared__ float red[LNB_CG][LNB_FT];
     const int tl = threadIdx.x % LNB_FT, cg = threadIdx.x / LNB_FT;
     const int b = blockIdx.y, t = blockIdx.x * LNB_FT + tl;
     const bool valid = t < T;
@@ -376,18 +370,6 @@ __device__ __forceinline__ void layernorm_ch_bwd_body(const float *x, const floa
         if (valid) op[(int64_t)c * T] = rstd * (dyc * gamma[c] - s1 - xh * s2);
         lnb_emit(dyc * xh, dyc, c, tl, dgamma, dbeta, partial, C);
     }
-}
-// partial != NULL: per-block partial rows [dgamma | dbeta], summed in block order by the last block to arrive (rows_sum.h) -- one launch
-__global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, const float *gamma, const float *mask,
-                                                               const float *dy, float *dx, float *dgamma, float *dbeta,
-                                                               float *partial, unsigned *counter, int B, int C, int T, float eps) {
-    __shared__ float red[LNB_CG][LNB_FT];
-    __shared__ unsigned flag;
-    static_assert(LNB_CG * LNB_FT >= 256, "rows_sum_in_launch needs 256 floats of LDS");
-    layernorm_ch_bwd_body(x, gamma, mask, dy, dx, dgamma, dbeta, partial, B, C, T, eps, red);
-    if (partial)
-        rows_sum_in_launch<256>(counter, gridDim.x * gridDim.y, partial, dgamma, (int)(gridDim.x * gridDim.y), 2 * C, true, 1.0f, &red[0][0],
-                                &flag, dbeta, C);
 }
 // out[j] += sum_r partial[r][j], j < n (= 2C: dgamma then dbeta); block = 64 columns x ROWS_RG row groups (rows_sum.h)
 __global__ void __launch_bounds__(64 * ROWS_RG) lnb_partial_sum_kernel(const float *partial, float *dgamma, float *dbeta, int rows,
@@ -478,7 +460,7 @@ __global__ void __launch_bounds__(256) frame_weight_kernel(const float *target, 
 }
 // sum-reduce helper: out[0] += sum x[i] (* w[i / inner])
 __global__ void __launch_bounds__(256) weighted_sum_kernel(const float *x, const float *w, float *out, int64_t n,
-                                                           int64_t inner, float *part = nullptr, unsigned *counter = nullptr) {
+                                                           int64_t inner, float *part = nullptr) {
     __shared__ float red[256];
     float s = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -490,10 +472,6 @@ __global__ void __launch_bounds__(256) weighted_sum_kernel(const float *x, const
         __syncthreads();
     }
     if (threadIdx.x == 0) { if (part) part[blockIdx.x] = red[0]; else atomicAdd(out, red[0]); }
-    if (part) {
-        __shared__ unsigned flag;
-        rows_sum_in_launch<256>(counter, gridDim.x, part, out, (int)gridDim.x, 1, true, 1.0f, red, &flag);
-    }
 }
 // |pred - target| (forward) / sign(pred - target) (backward), [n]
 __global__ void __launch_bounds__(256) l1_elem_kernel(const float *pred, const float *target, float *absd, float *sgn,
@@ -780,8 +758,7 @@ __global__ void __launch_bounds__(256) scatter_reduce_kernel(const float *part, 
 
 // ---- optimizer ---------------------------------------------------------------------------------------------------
 // sum of squares of a flat buffer -> out[0] (atomic)
-__global__ void __launch_bounds__(256) sumsq_kernel(const float *g, float *out, int64_t n, float *part = nullptr,
-                                                    unsigned *counter = nullptr) {
+__global__ void __launch_bounds__(256) sumsq_kernel(const float *g, float *out, int64_t n, float *part = nullptr) {
     __shared__ float red[256];
     float s = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = fmaf(g[i], g[i], s);
@@ -792,10 +769,6 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float *g, float *out, 
         __syncthreads();
     }
     if (threadIdx.x == 0) { if (part) part[blockIdx.x] = red[0]; else atomicAdd(out, red[0]); }
-    if (part) {
-        __shared__ unsigned flag;
-        rows_sum_in_launch<256>(counter, gridDim.x, part, out, (int)gridDim.x, 1, true, 1.0f, red, &flag);
-    }
 }
 // AdamW (torch.optim.AdamW semantics, amsgrad off) over a flat buffer; grads are first scaled by
 // clip = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))  (torch.nn.utils.clip_grad_norm_), sumsq optional.
@@ -1019,35 +992,32 @@ extern "C" int set_step_proj_bwd(const float *h, const float *g, const float *w,
     return set_check_launch("set_step_proj_bwd(dw)");
 }
 
-// Deterministic variants: per-block partial results in `scratch`, combined in a fixed order -- channel / weighted / square sums by the
-// producer kernel's last block in the SAME launch (rows_sum.h: rows_sum_in_launch; scratch[0 .. DET_HDR) is the arrival counter: zero
-// before the first call, left zero by every call, calls that share a scratch buffer ordered on one stream), the loss sums by
-// set_partial_rows_sum.
+// Deterministic variants: per-block partial results in `scratch`, combined in block order by set_partial_rows_sum.
 extern "C" int set_channel_sum_det(const float *x, float *out, int32_t B, int32_t C, int32_t T, float *scratch, void *stream) {
     SET_REQUIRE(x && out && scratch && B > 0 && C > 0 && T > 0, "set_channel_sum_det");
     int slices = (2048 + C - 1) / C;
     if (slices > B) slices = B;
     if (slices < 1) slices = 1;  // scratch: slices * C <= 2048 + C floats
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, slices), dim3(256), 0, (hipStream_t)stream, x, out, B, C, T, scratch + DET_HDR,
-                       reinterpret_cast<unsigned *>(scratch));
-    return set_check_launch("set_channel_sum_det");
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, slices), dim3(256), 0, (hipStream_t)stream, x, out, B, C, T, scratch);
+    const int rc = set_check_launch("set_channel_sum_det");
+    return rc ? rc : set_partial_rows_sum(scratch, out, 1, slices, C, 1, 1.0f, stream);
 }
 extern "C" int set_weighted_sum_det(const float *x, const float *w, float *out, int64_t n, int64_t inner, float *scratch,
                                     void *stream) {
     SET_REQUIRE(x && out && scratch && n > 0 && inner > 0, "set_weighted_sum_det");
     int64_t blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;  // scratch: <= 1024 floats
-    hipLaunchKernelGGL(weighted_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, out, n, inner,
-                       scratch + DET_HDR, reinterpret_cast<unsigned *>(scratch));
-    return set_check_launch("set_weighted_sum_det");
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, out, n, inner, scratch);
+    const int rc = set_check_launch("set_weighted_sum_det");
+    return rc ? rc : set_partial_rows_sum(scratch, out, 1, (int)blocks, 1, 1, 1.0f, stream);
 }
 extern "C" int set_sumsq_det(const float *g, float *out, int64_t n, float *scratch, void *stream) {
     SET_REQUIRE(g && out && scratch && n > 0, "set_sumsq_det");
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;  // scratch: <= 2048 floats
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, out, n, scratch + DET_HDR,
-                       reinterpret_cast<unsigned *>(scratch));
-    return set_check_launch("set_sumsq_det");
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, out, n, scratch);
+    const int rc = set_check_launch("set_sumsq_det");
+    return rc ? rc : set_partial_rows_sum(scratch, out, 1, (int)blocks, 1, 1, 1.0f, stream);
 }
 // sums-only passes of the two loss kernels with ordered partials: scratch >= 4 * B (dur) / 4 * ceil(B*T/256) (pitch) floats
 extern "C" int set_dur_loss_sums_det(const float *dur_pred, const int64_t *mel2ph, const int64_t *txt, const int64_t *word_id,
@@ -1142,7 +1112,7 @@ extern "C" int set_res_skip_bwd(const float *dx_out, const float *dskip, float *
     return set_check_launch("set_res_skip_bwd");
 }
 extern "C" int64_t set_layernorm_ch_bwd_scratch(int32_t B, int32_t C, int32_t T) {
-    return DET_HDR + (int64_t)B * ((T + LNB_FT - 1) / LNB_FT) * 2 * C;
+    return (int64_t)B * ((T + LNB_FT - 1) / LNB_FT) * 2 * C;
 }
 extern "C" int set_layernorm_ch_bwd(const float *x, const float *gamma, const float *mask, const float *dy, float *dx,
                                     float *dgamma, float *dbeta, float *partial, int32_t B, int32_t C, int32_t T,
@@ -1150,10 +1120,14 @@ extern "C" int set_layernorm_ch_bwd(const float *x, const float *gamma, const fl
     SET_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && B > 0 && C > 0 && T > 0, "set_layernorm_ch_bwd");
     SET_REQUIRE(B <= 65535, "set_layernorm_ch_bwd(B)");
     const int tiles = (T + LNB_FT - 1) / LNB_FT;
-    // partial: [0, DET_HDR) arrival counter (zero before the first call on the buffer, left zero), partial rows behind it
     hipLaunchKernelGGL(layernorm_ch_bwd_kernel, dim3(tiles, B), dim3(256), 0, (hipStream_t)stream,
-                       x, gamma, mask, dy, dx, dgamma, dbeta, partial ? partial + DET_HDR : nullptr, reinterpret_cast<unsigned *>(partial), B, C,
-                       T, eps);
+                       x, gamma, mask, dy, dx, dgamma, dbeta, partial, B, C, T, eps);
+    if (partial) {
+        const int rc = set_check_launch("set_layernorm_ch_bwd");
+        if (rc) return rc;
+        hipLaunchKernelGGL(lnb_partial_sum_kernel, dim3((2 * C + 63) / 64), dim3(64 * ROWS_RG), 0, (hipStream_t)stream,
+                           partial, dgamma, dbeta, tiles * B, C);
+    }
     return set_check_launch("set_layernorm_ch_bwd");
 }
 extern "C" int set_embedding_bwd(const int64_t *idx, const float *dout, float *dtable, int32_t B, int32_t T, int32_t C,

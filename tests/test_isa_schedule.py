@@ -124,3 +124,32 @@ def test_epilogue_stores_do_not_serialise(src, compiled):
                   and any(re.search(r"vmcnt\(0\)", x) for x in blk))
         assert ser <= 12, "%s: %d basic blocks hold a store behind s_waitcnt vmcnt(0)" % (name, ser)
     assert seen == set(STORE_GUARD[src]), (seen, STORE_GUARD[src])
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_no_wide_store_has_its_data_registers_rewritten_by_the_next_instruction(compiled):
+    """Round 5: the run-to-run differences of the fp32 training step came from
+    `buffer_store_dwordx4 v[34:37], v38, s[12:15], s10 offen` immediately followed by `v_add_u32 v36, ...`: hipcc (ROCm 7.2) pads a store of
+    more than 64 bits against a VALU write of its data registers only when the store's soffset is NOT an SGPR, and on gfx950 the unpadded
+    pair sometimes stores the new value of the register (a few dozen of 6.5 M elements per launch, always the rewritten dword).  Measured on
+    the box: that build differs in 4 of 4 repeats, `s_nop 1` behind the store / soffset 0 are bit-stable in 5 of 5.  No kernel of the library
+    may contain the pattern; the reproducer build (-DSET_CONV_V2_STORE_HAZARD=1) must, so that the scan is known to see it."""
+    import subprocess
+    import tempfile
+    n_kernels, offenders = 0, []
+    for f, (lines, _) in sorted(compiled.items()):
+        for name, body in isa_scan.kernels(lines):
+            n_kernels += 1
+            hz = isa_scan.store_data_hazards(body)
+            if hz:
+                offenders.append((f, name, len(hz), hz[0]))
+    assert n_kernels > 100, n_kernels
+    assert not offenders, offenders
+    out = os.path.join(tempfile.gettempdir(), "isa_test_%d_hazard.s" % os.getpid())
+    r = subprocess.run(["hipcc"] + isa_scan.FLAGS + ["-DSET_CONV_V2_STORE_HAZARD=1", "-o", out, os.path.join(isa_scan.CS, "conv1d.hip")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = open(out).read().split("\n")
+    os.remove(out)
+    seen = sum(len(isa_scan.store_data_hazards(body)) for name, body in isa_scan.kernels(lines) if "conv1d_mfma_v2_kernel" in name)
+    assert seen >= 3, "the reproducer build no longer shows the pattern (compiler changed?): the scan cannot be trusted blindly"

@@ -1,4 +1,4 @@
-"""Static checks on the gfx950 ISA of the kernels (no GPU needed): the two compiler pathologies of DESIGN 3.5b / 3.5c.
+"""Static checks on the gfx950 ISA of the kernels (no GPU needed): the compiler pathologies of DESIGN 3.5b / 3.5c.
 
     python tools/isa_scan.py                 # every csrc/*.hip: kernels whose MFMAs sit behind a drain, kernels whose stores wait for each other
     python tools/isa_scan.py bf16.hip conv1d_wgrad3_bf16_kernel     # one-character-per-instruction trace of the kernels matching the name
@@ -27,6 +27,30 @@ def kernels(lines):
         yield l.split(":")[0], lines[i:(starts[n + 1][0] if n + 1 < len(starts) else len(lines))]
 
 
+# (3) the store-data hazard of round 5 (DESIGN 3.5c): a buffer store of more than 64 bits whose soffset is an SGPR, followed IMMEDIATELY by a
+#     VALU instruction that writes one of its data registers.  ROCm 7.2 pads that pair with a wait state only when soffset is not a register;
+#     on gfx950 the unpadded pair sometimes stores the overwritten dword (run-to-run differences in conv1d_mfma_v2_kernel's outputs).
+WIDE_STORE = re.compile(r"(buffer_store_dwordx[34]|buffer_store_format_xyzw?|buffer_store_format_d16_xyzw) v\[(\d+):(\d+)\], "
+                        r"(?:v\d+|off|v\[\d+:\d+\]), s\[\d+:\d+\], (\S+)")
+
+
+def store_data_hazards(body):
+    """[(store, next instruction)] pairs of one kernel body that match (3)."""
+    out = []
+    ins = [b.strip() for b in body if b.strip() and not b.strip().startswith((".", ";"))]
+    for k, t in enumerate(ins[:-1]):
+        m = WIDE_STORE.match(t)
+        if not m or not re.match(r"s\d+", m.group(4)):
+            continue
+        lo, hi, n = int(m.group(2)), int(m.group(3)), ins[k + 1]
+        if not n.startswith("v_"):
+            continue
+        w, wr = re.match(r"v_\w+ v(\d+)", n), re.match(r"v_\w+ v\[(\d+):(\d+)\]", n)
+        if (w and lo <= int(w.group(1)) <= hi) or (wr and not (int(wr.group(2)) < lo or int(wr.group(1)) > hi)):
+            out.append((t, n))
+    return out
+
+
 def scan(src):
     for name, body in kernels(asm_of(src)):
         nm = sum("v_mfma" in b for b in body)
@@ -40,6 +64,10 @@ def scan(src):
         blocks.append(cur)
         ser = sum(1 for blk in blocks if 1 <= sum(x.startswith(("buffer_store", "global_store", "flat_store")) for x in blk) <= 2
                   and any(re.search(r"vmcnt\(0\)", x) for x in blk))
+        hz = store_data_hazards(body)
+        if hz:
+            print("%-18s %-90s %d wide stores with an SGPR soffset whose data registers the next VALU instruction rewrites, e.g. %s ; %s" % (
+                os.path.basename(src), name[:90], len(hz), hz[0][0][:60], hz[0][1][:40]))
         if (nm and bad * 5 >= nm) or ser >= 4:
             print("%-18s %-90s MFMAs %4d, behind vmcnt(0|1): %4d | store blocks behind vmcnt(0): %d" % (os.path.basename(src), name[:90], nm, bad, ser))
 
