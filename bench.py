@@ -513,23 +513,14 @@ def _sub_bench(argv, timeout=420):
 
 def train_line(model, dtype):
     """BASELINE configs[1] (spec_denoiser, B=32, T=800, bf16) / configs[4] per GPU (CampNet, B=16, T=800): `bench.py --mode train` in a
-    sub-process (eager steps, which are what is timed), plus the host-enqueue time of the same step replayed as a captured graph."""
+    sub-process."""
     d = _sub_bench(["--mode", "train", "--model", model, "--dtype", dtype, "--steps", "20", "--warmup", "5"])
     if "error" in d:
         return d
     out = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
            "host_enqueue_ms_per_step": d["host_enqueue_ms_per_step"], "loss": d["loss"],
            "allreduce_bytes_per_step_at_N_ranks": 4 * d.get("grad_elems_exchanged", 0),
-           "roofline": {k: d["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")}}
-    env = dict(os.environ, SET_AMD_GRAPH_STEP="1")
-    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--model", model, "--dtype", dtype, "--steps", "20", "--warmup", "5"]
-    try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420, env=env)
-        g = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-        out["graph_replay"] = {"ms_per_step": g["ms_per_step"], "host_enqueue_ms_per_step": g["host_enqueue_ms_per_step"],
-                               "replays": g.get("graph_replays"), "loss_equal_to_eager": g["loss"] == d["loss"]}
-    except Exception as e:  # noqa: BLE001
-        out["graph_replay"] = {"error": repr(e)[:200]}
+           "roofline": d["roofline"], "whole_step": d.get("whole_step"), "launches_per_step": d.get("launches_per_step")}
     return out
 
 
@@ -699,12 +690,6 @@ class _StubTask:
 def _stub_step_fn(task, opt):
     """zero_grad -> backward (bucket all-reduces launch from the autograd hooks) -> finish -> SGD on the mean gradient, in torch."""
     class Step:
-        eager_steps, replays = 0, 0
-
-        @staticmethod
-        def usable():
-            return False
-
         def __call__(self, sample, seed):
             opt.zero_grad()
             loss = (task.model(sample["x"]) - sample["y"]).pow(2).mean()
@@ -723,7 +708,7 @@ def _train_setup(args, rank, world, dev):
     """(task, optimizer, this rank's sample, step function, utterances per GPU) of --mode train."""
     from set_amd import hparams as HP, ops, parallel, tasks
     from set_amd.synthetic import synthetic_inputs
-    from set_amd.training import FlatAdamW, GraphedTrainStep
+    from set_amd.training import FlatAdamW
     if stub_device():
         torch.manual_seed(1234 + rank)
         task = _StubTask()
@@ -764,9 +749,84 @@ def _train_setup(args, rank, world, dev):
     else:
         sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"],
                       time_mel_masks=inp["time_mel_masks"].squeeze(-1).contiguous(), spk_embed=inp["spk_embed"])
-    # one captured HIP graph per batch shape (training.GraphedTrainStep: eager for the first steps, with more than one rank and
-    # under SET_AMD_GRAPH_STEP=0); the timed steps below are replays when the warm-up was long enough to capture
-    return task, opt, sample, GraphedTrainStep(task, opt), bpg
+    return task, opt, sample, _EagerStep(task, opt), bpg
+
+
+class _EagerStep:
+    """One optimisation step of the task per call: zero_grad -> forward + losses -> backward -> (bucket all-reduce) -> clip + AdamW."""
+
+    def __init__(self, task, opt):
+        self.task, self.opt = task, opt
+
+    def __call__(self, sample, seed):
+        return self.task.training_step(sample, self.opt, seed=seed)
+
+
+TRAIN_PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_train.json")
+TRAIN_KERNEL_SOURCES = ["speech-editing-toolkit_amd/csrc/diffnet_bf16.hip", "speech-editing-toolkit_amd/csrc/bf16.hip",
+                        "speech-editing-toolkit_amd/csrc/common.h", "speech-editing-toolkit_amd/csrc/rows_sum.h"]
+
+
+def _profiled(key, model, dtype):
+    """A figure that cannot be measured inside this process (rocprofv3 PMC / kernel-trace passes of `bench.py --mode train`,
+    tools/sessions/gpu_r5_final.sh -> profiles/r05_pmc_train.json), quoted only while the sha256 of the kernel sources it was taken on matches."""
+    if not os.path.exists(TRAIN_PMC_FILE):
+        return None
+    import hashlib
+    with open(TRAIN_PMC_FILE) as f:
+        tj = json.load(f)
+    h = hashlib.sha256()
+    for src in tj.get("kernel_sources", []):
+        with open(os.path.join(ROOT, src), "rb") as f:
+            h.update(f.read())
+    if h.hexdigest() != tj.get("kernel_source_sha256"):
+        return None
+    return tj.get("%s_%s" % (model, dtype), {}).get(key)
+
+
+def _train_dominant_kernel(args, step_fn, sample, dev, bpg):
+    """The kernel with the largest share of a training step's GPU time, timed with hipEvents on its launch stream over 5 extra steps.
+    spec_denoiser bf16: diffnet_layer_bwd_bf16_kernel (20 launches per step, HBM-bound: per frame and layer it reads dx' 1024 + dskip 1024
+    + y (bf16) 1024 + dcond 768 and writes dx 1024 + dy (bf16) 1024 + d_o (bf16) 1024 + dcond 768 = 7,680 B, csrc/diffnet_bf16.hip).
+    CampNet (and spec_denoiser fp32): the bf16 conv shape with the largest total time (MFMA-bound: 2 B T Cin Cout K FLOP per launch)."""
+    from set_amd import autograd_ops as A, ops
+    campnet = args.model == "campnet"
+    A.SWEEP_EVENTS, ops.CONV_EVENTS = [], []
+    try:
+        for k in range(5):
+            step_fn(sample, seed=5000 + k)
+        _sync(dev)
+        sweeps, convs = list(A.SWEEP_EVENTS), list(ops.CONV_EVENTS)
+    finally:
+        A.SWEEP_EVENTS, ops.CONV_EVENTS = None, None
+    if sweeps and not campnet:
+        per_launch_ms = sum(e0.elapsed_time(e1) / n for e0, e1, n in sweeps) / len(sweeps)
+        bytes_launch = 7680.0 * bpg * T
+        gbs = bytes_launch / (per_launch_ms * 1e-3) / 1e9
+        ent = _profiled("diffnet_layer_bwd_bf16_kernel", "spec_denoiser", args.dtype) or {}
+        return {"kernel": "diffnet_layer_bwd_bf16_kernel", "launches_per_step": L, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": ent.get("traffic_bytes"), "launch_ms": per_launch_ms,
+                "algorithmic_bytes_per_launch": bytes_launch, "share_of_step_gpu_time": L * per_launch_ms,
+                "traffic_note": "PMC passes of this kernel build (profiles/r05_pmc_train.json, source sha256 matches)" if ent else
+                                "no PMC figure for these kernel sources"}
+    if not convs:
+        return None
+    by = {}
+    for key, e0, e1 in convs:
+        d = by.setdefault(key, [0.0, 0])
+        d[0] += e0.elapsed_time(e1)
+        d[1] += 1
+    key, (ms, n) = max(by.items(), key=lambda kv: kv[1][0])
+    Cin, Cout, K, Bc, Tc = key
+    fl = 2.0 * Bc * Tc * Cin * Cout * K
+    tfl = fl / (ms / n * 1e-3) / 1e12
+    name = "conv1d_bf16_kernel %d->%d k=%d (B=%d, T=%d)" % (Cin, Cout, K, Bc, Tc)
+    ent = _profiled("conv1d_bf16_kernel", "campnet" if campnet else "spec_denoiser", args.dtype) or {}
+    return {"kernel": name, "launches_per_step": n / 5.0, "bound": "mfma", "achieved": tfl, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": tfl / PEAK_BF16_MFMA_TFLOPS, "traffic": ent.get("traffic_bytes"), "launch_ms": ms / n, "flop_per_launch": fl,
+            "share_of_step_gpu_time": ms / 5.0,
+            "traffic_note": "PMC passes, mean over ALL conv1d_bf16_kernel launches of a step (profiles/r05_pmc_train.json)" if ent else
+                            "no PMC figure for these kernel sources"}
 
 
 def run_train(args, rank, world, dev):
@@ -783,12 +843,11 @@ def run_train(args, rank, world, dev):
         torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         assert float(lo) == float(hi), "parameter broadcast left the replicas different"
-    for w in range(max(args.warmup, step_fn.eager_steps + 2) if step_fn.usable() else args.warmup):
+    for w in range(args.warmup):
         step_fn(sample, seed=100 + w)
     _sync(dev)
     parallel.barrier()
     exposed, reduced, enqueue = 0.0, 0, 0.0
-    replays0 = step_fn.replays
     t0 = time.perf_counter()
     for k in range(args.steps):
         t1 = time.perf_counter()
@@ -810,6 +869,7 @@ def run_train(args, rank, world, dev):
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         same_after = float(lo) == float(hi)
         assert same_after, "the replicas diverged during the timed steps"
+    dominant = None if stub_device() else _train_dominant_kernel(args, step_fn, sample, dev, bpg)
     n_samples = bpg * world * args.steps
     flop = (CAMPNET_TRAIN_FLOP_PER_FRAME if campnet else TRAIN_FLOP_PER_FRAME) * bpg * T * args.steps  # per rank
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
@@ -835,14 +895,18 @@ def run_train(args, rank, world, dev):
                    "B_per_gpu": bpg, "T": T, "T_txt": T_TXT, "sharding": "utterances r::N, gradient all-reduce (SUM, "
                    "1/N folded into AdamW) in %d buckets" % max(1, len(opt.bucketer.buckets))},
         "frames_per_s": None if stub_device() else n_samples * T / t_max, "host_enqueue_ms_per_step": 1e3 * enqueue / args.steps,
-        "graph_replays": step_fn.replays - replays0,
         "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"], "replicas_identical_after_steps": same_after,
         "per_rank_ms_per_step": [1e3 * s / args.steps for s in facts["per_rank_s"]],
         "allreduce_bytes_per_step": reduced, "allreduce_exposed_ms_per_step": 1e3 * exposed / args.steps,
         "param_broadcast_bytes": bcast_bytes, "grad_elems": opt.n, "grad_elems_exchanged": opt.n_exchanged,
         "loss": float(total), "lr": lr, "losses": {k: float(v) for k, v in parts.items()},
-        "roofline": None if stub_device() else {"kernel": "whole training step", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                                                "frac": ach / peak, "traffic": None, "flop_per_step": flop / args.steps},
+        # roofline = the step's dominant kernel (largest share of the GPU time; hipEvents on its launch stream over extra steps right
+        # behind the timed ones -- inside them, the ~100 event records per step would cost the step itself 0.4 ms of host time);
+        # whole_step = the algorithmic FLOPs of the step over the step time
+        "roofline": dominant,
+        "whole_step": None if stub_device() else {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                                  "flop_per_step": flop / args.steps},
+        "launches_per_step": None if stub_device() else _profiled("launches_per_step", "campnet" if campnet else "spec_denoiser", args.dtype),
     }
 
 

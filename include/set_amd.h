@@ -641,6 +641,8 @@ int set_conv_epilogue_bwd(const float *dy, const float *y, const float *mask, fl
 /* y = act(z) / dz = dy * act'(z)  for the SET_ACT_* codes */
 int set_act_fwd(const float *z, float *y, int64_t n, int32_t act, float p, void *stream);
 int set_act_bwd(const float *z, const float *dy, float *dz, int64_t n, int32_t act, float p, void *stream);
+/* dz = (dy * act'(z)) * scale: act backward followed by the producing conv's output scale alpha (set_conv1d's `alpha`), one launch */
+int set_act_bwd_scaled(const float *z, const float *dy, float *dz, int64_t n, int32_t act, float p, float scale, void *stream);
 /* backward of set_gate: y [B][2C][T] (saved pre-gate), dz [B][C][T] -> dy [B][2C][T] */
 int set_gate_bwd(const float *y, const float *dz, float *dy, int32_t B, int32_t C, int32_t T, void *stream);
 /* backward of set_res_skip: dx = dx_out/sqrt2 ; d_o[:, :C] = dx_out/sqrt2 ; d_o[:, C:] = dskip */

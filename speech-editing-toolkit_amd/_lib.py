@@ -294,6 +294,7 @@ SIGNATURES = {
     "set_conv_epilogue_bwd": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _I32, _F, _V]),
     "set_act_fwd": (C.c_int, [_V, _V, _I64, _I32, _F, _V]),
     "set_act_bwd": (C.c_int, [_V, _V, _V, _I64, _I32, _F, _V]),
+    "set_act_bwd_scaled": (C.c_int, [_V, _V, _V, _I64, _I32, _F, _F, _V]),
     "set_gate_bwd": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _V]),
     "set_res_skip_bwd": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _V]),
     "set_layernorm_ch_bwd": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _V, _I32, _I32, _I32, _F, _V]),

@@ -35,8 +35,7 @@ class _ZeroArena:
     of a few microseconds on the critical stream).  Opened by FlatAdamW.zero_grad() and closed by FlatAdamW.step():
     only then is it safe, because the optimizer owns every .grad (views of its flat buffer), so autograd ADDS these
     temporaries into .grad and nothing keeps a reference past the step.  Outside such a step `_gzeros` is torch.zeros.
-    Capacity follows the demand of the previous step.  One arena per owner (optimizer): a captured step
-    (training.GraphedTrainStep) holds the address of the arena it was captured with."""
+    Capacity follows the demand of the previous step.  One arena per owner (optimizer)."""
 
     def __init__(self):
         self.buf, self.off, self.need = None, 0, 0
@@ -44,31 +43,6 @@ class _ZeroArena:
 
 _ARENAS = {}        # owner id -> _ZeroArena
 _ACTIVE = [None]    # the arena of the optimisation step in progress (steps do not nest)
-# While a captured training step exists (training.GraphedTrainStep: GRAPHS_ALIVE[0] > 0) buffers replaced by a larger one are parked here
-# instead of being freed: the captured step holds the ADDRESS of the arena / scratch buffers it was captured with, and a freed buffer is
-# handed to other tensors by the allocator.  Without a captured step (plain eager training) a replaced buffer is simply dropped.  Growth is
-# geometric (x 1.5 of the current size at least), so the parked buffers sum to a small multiple of the final size.
-_RETIRED = []
-GRAPHS_ALIVE = [0]
-
-
-def _retire(buf):
-    if GRAPHS_ALIVE[0] > 0:
-        _RETIRED.append(buf)
-
-
-def graph_captured():
-    GRAPHS_ALIVE[0] += 1
-
-
-def graph_released():
-    GRAPHS_ALIVE[0] = max(0, GRAPHS_ALIVE[0] - 1)
-    if GRAPHS_ALIVE[0] == 0:
-        del _RETIRED[:]
-
-
-CAPTURED_ABORT_WORDS = []  # sync workspaces of persistent stack kernels inside captured steps ([1] != 0: a dependency wait timed out)
-
 
 # --------------------------------------------------------------------------------------------------
 # Leaf stream: gradient kernels nothing else in the backward pass waits for
@@ -107,16 +81,9 @@ def _leaf_state(dev):
 
 
 def _order(st, fork):
-    """fork: the leaf stream waits for the current stream; else (join) the current stream waits for the leaf stream.  Eager: one C call on a
-    cached event.  While the current stream is being captured (training.GraphedTrainStep) torch's own wait_stream with a fresh event: a graph
-    captured through the cached events crashed in its first replay (ROCm 7.2; the same capture through torch events replays fine)."""
-    if torch.cuda.is_current_stream_capturing():
-        cur = torch.cuda.current_stream()
-        if fork:
-            st["stream"].wait_stream(cur)
-        else:
-            cur.wait_stream(st["stream"])
-    elif fork:
+    """fork: the leaf stream waits for the current stream; else (join) the current stream waits for the leaf stream: one C call on a cached
+    event (torch's Event / Stream.wait_event / record_stream wrappers cost ~28 us per fork)."""
+    if fork:
         check(L().set_stream_order(_stream(), st["raw"], 2 * st["idx"]), "set_stream_order")
     else:
         check(L().set_stream_order(st["raw"], _stream(), 2 * st["idx"] + 1), "set_stream_order")
@@ -180,7 +147,6 @@ def zero_arena_begin(device, min_floats=0, owner=None):
     want = max(int(min_floats), int(a.need * 1.05) + 4096)
     if a.buf is None or a.buf.device != device or a.buf.numel() < want:
         if a.buf is not None and a.buf.device == device:
-            _retire(a.buf)
             want = max(want, int(a.buf.numel() * 1.5))
         a.buf = torch.empty(want, dtype=torch.float32, device=device)
     a.buf.zero_()
@@ -247,7 +213,6 @@ def _det_scratch(device, n_floats):
     buf = _DET_SCRATCH.get(key)
     if buf is None or buf.numel() < n_floats:
         if buf is not None:
-            _retire(buf)
             _leaf_keep(buf)
         buf = torch.empty(int(n_floats * 1.25) + 4096, dtype=torch.float32, device=device)
         _DET_SCRATCH[key] = buf
@@ -259,7 +224,6 @@ def _wg_scratch(device, need):
     buf = _WG_SCRATCH.get(key)
     if buf is None or buf.numel() < need:
         if buf is not None:
-            _retire(buf)
             _leaf_keep(buf)
         buf = torch.empty(int(need * 1.25) + 1024, dtype=torch.float32, device=device)
         _WG_SCRATCH[key] = buf
@@ -466,6 +430,91 @@ class _LayerNormChFn(torch.autograd.Function):
 
 def layernorm_ch(x, gamma, beta, mask=None, eps=1e-5, out=None):
     return _LayerNormChFn.apply(x, gamma, beta, mask, eps)
+
+
+class _PreLnFfnFn(torch.autograd.Function):
+    """One tape node for the pre-LayerNorm feed-forward sub-block both models are built from (modules/commons/conv.py:24-65 ResidualBlock
+    unit; modules/speech_editing/commons/transformer.py:76-113 + :619-652 TransformerFFNLayer inside Enc/DecSALayer):
+
+        y = (x + W2 act(alpha (W1 (*) LN(x)) + alpha b1 ...) + b2) (* mask)      -- set_conv1d semantics: alpha scales conv + bias
+
+    Forward = the four launches of the per-op tape (LN, conv k, activation on the saved pre-activation, 1x1 conv with the residual and the
+    mask in its epilogue); backward = the same kernels in hand order.  What the single node saves: four autograd nodes per sub-block in
+    each direction (17 sub-blocks per CampNet step, 8 per spec_denoiser step: the steps are bound by the host's enqueue time), the
+    alpha-scaling launch (folded into the activation backward: set_act_bwd_scaled, same two roundings) and the `.contiguous()` /
+    fan-out bookkeeping between them.  Gradients are bit-identical to the per-op tape's (tests: all-gradients goldens)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w1, b1, w2, b2, cw1, cw2, dil, pad, alpha, act, act_param, eps, mask, t_out):
+        x = x.contiguous()
+        h = ops.layernorm_ch(x, gamma, beta, None, eps)
+        z = ops.conv1d(h, cw1, b1, dil=dil, pad=pad, alpha=alpha, T_out=t_out)
+        f = torch.empty_like(z)
+        check(L().set_act_fwd(_p(z), _p(f), z.numel(), ACT[act], float(act_param), _stream()), "set_act_fwd")
+        y = ops.conv1d(f, cw2, b2, res=x, mask=mask)
+        ctx.save_for_backward(x, gamma, mask, h, z, f)
+        ctx.cws, ctx.cfg = (cw1, cw2), (dil, pad, alpha, act, act_param, eps)
+        ctx.params = (gamma, beta, w1, b1, w2, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mask, h, z, f = ctx.saved_tensors
+        cw1, cw2 = ctx.cws
+        dil, pad, alpha, act, act_param, eps = ctx.cfg
+        p_gamma, p_beta, p_w1, p_b1, p_w2, p_b2 = ctx.params
+        dy = dy.contiguous()
+        B, Cc, T = dy.shape
+        Cmid, T1, T_in = z.shape[1], z.shape[2], h.shape[2]
+        dev = dy.device
+
+        def tgt(param, cw=None):  # (accumulation target, gradient to hand to autograd or None when written in place)
+            whole = cw is None or (cw.base == 0 and param.numel() == cw.Cout * cw.Cin * cw.K)
+            sink = grad_sink(param)[0] if whole else None
+            if sink is not None:
+                return sink, None
+            tmp = _gzeros(param.shape, dev)
+            return tmp, tmp
+
+        # ---- second conv (1x1, + residual, * mask): G2 = dy * mask is also the residual's gradient
+        if mask is None:
+            g2 = dy
+        else:
+            g2 = torch.empty_like(dy)
+            check(L().set_conv_epilogue_bwd(_p(dy), None, _p(mask), _p(g2), B, Cc, T, 0, 1.0, _stream()), "set_conv_epilogue_bwd")
+        df = ops.conv1d(g2, cw2.transposed(), None, dil=-1, pad=0, T_iter=T1, T_out=T1)
+        (t_w2, r_w2), (t_b2, r_b2) = tgt(p_w2, cw2), tgt(p_b2)
+        # (leaf stream only for a tensor of this function's own: see _Conv1dFn.backward)
+        with leaf_work(dev, r_w2 is None and r_b2 is None and g2 is not dy, g2, f):
+            conv_wgrad(g2, f, None, t_w2, B, Cmid, Cc, 1, 1, 0, T, T1, dw_ptr=t_w2.data_ptr() + 4 * cw2.base)
+            channel_sum_(g2, t_b2, B, Cc, T)
+        # ---- activation backward with the first conv's alpha folded in: G1 = gradient of the raw conv + bias
+        g1 = torch.empty_like(z)
+        check(L().set_act_bwd_scaled(_p(z), _p(df), _p(g1), z.numel(), ACT[act], float(act_param), float(alpha), _stream()), "set_act_bwd_scaled")
+        dh = ops.conv1d(g1, cw1.transposed(), None, dil=-dil, pad=-pad, T_iter=T_in, T_out=T_in)
+        (t_w1, r_w1), (t_b1, r_b1) = tgt(p_w1, cw1), tgt(p_b1)
+        with leaf_work(dev, r_w1 is None and r_b1 is None, g1, h):
+            conv_wgrad(g1, h, None, t_w1, B, Cc, Cmid, cw1.K, dil, pad, T1, T_in, dw_ptr=t_w1.data_ptr() + 4 * cw1.base)
+            channel_sum_(g1, t_b1, B, Cmid, T1)
+        # ---- LayerNorm backward, then the residual branch joins (same order as the fan-out node of the per-op tape: LN branch + residual)
+        dxl = torch.empty_like(x)
+        (t_g, r_g), (t_bt, r_bt) = tgt(p_gamma), tgt(p_beta)
+        part = _det_scratch(dev, L().set_layernorm_ch_bwd_scratch(B, Cc, T_in))
+        check(L().set_layernorm_ch_bwd(_p(x), _p(gamma), None, _p(dh), _p(dxl), _p(t_g), _p(t_bt), _p(part), B, Cc, T_in, float(eps), _stream()),
+              "set_layernorm_ch_bwd")
+        dx = ops.sum_div(dxl, g2)
+        return (dx, r_g, r_bt, r_w1, r_b1, r_w2, r_b2) + (None,) * 10
+
+
+def preln_ffn(x, ln, cw1, b1, cw2, b2, *, dil=1, pad=0, alpha=1.0, act="gelu", act_param=0.0, mask=None, eps=1e-5, T_out=None):
+    """(x + conv1x1(act(alpha conv_k(LN(x))))) (* mask) as one tape node; ln = (gamma, beta).  SET_AMD_FUSED_NODES=0: the per-op tape
+    (fan-out, LayerNorm, conv, activation, conv: five nodes) -- the cross-check of tests/test_gpu_training.py and the A/B of the bench."""
+    if os.environ.get("SET_AMD_FUSED_NODES", "1") == "0":
+        x_ln, x_res = fanout(x, 2)
+        h = layernorm_ch(x_ln, ln[0], ln[1], eps=eps)
+        h = conv1d(h, cw1, b1, dil=dil, pad=pad, alpha=alpha, act=act, act_param=act_param, T_out=T_out)
+        return conv1d(h, cw2, b2, res=x_res, mask=mask)
+    return _PreLnFfnFn.apply(x, ln[0], ln[1], cw1.raw(), b1, cw2.raw(), b2, cw1, cw2, dil, pad, alpha, act, act_param, eps, mask, T_out)
 
 
 class _EmbeddingFn(torch.autograd.Function):
@@ -720,9 +769,7 @@ class _DiffNetStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dskip):
         dn = ctx.dn
-        if torch.cuda.is_current_stream_capturing():
-            CAPTURED_ABORT_WORDS.append(ctx.ws)  # no host read inside a capture: training.GraphedTrainStep polls the word between replays
-        elif int(ctx.ws[1]) != 0:  # (the forward's abort word; this read-back is the first host sync of the step)
+        if int(ctx.ws[1]) != 0:  # (the forward's abort word; this read-back is the first host sync of the step)
             raise SetAmdError("set_diffnet_stack: a tile dependency wait of the training forward timed out")
         cond, dmat, x_all, y_all, z_all = ctx.saved_tensors
         L_, C_ = dn.n_layers, dn.C
@@ -781,6 +828,9 @@ class _DiffNetStackFn(torch.autograd.Function):
         grads.reverse()
         flat = [g for tup in grads for g in tup]
         return (None, dx, dcond, dd, *flat)
+
+
+SWEEP_EVENTS = None  # bench.py sets a list: (start, end, launches) hipEvent pairs around the layer-backward sweep of every step
 
 
 class _DiffNetStackBf16Fn(torch.autograd.Function):
@@ -854,6 +904,9 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
             pdbo_all = torch.empty(L_, B * tiles_g, 2 * C_, dtype=torch.float32, device=dev)
             pdby_all = torch.empty(L_, B * tiles_g, 2 * C_, dtype=torch.float32, device=dev)
             pdd_all = torch.empty(L_, B * tiles_g, C_, dtype=torch.float32, device=dev)
+        if SWEEP_EVENTS is not None:  # measurement hook (bench.py): hipEvents around the L launches of diffnet_layer_bwd_bf16_kernel
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         for l in range(L_ - 1, -1, -1):
             layer = layers[l]
             dil = layer.dilation
@@ -901,6 +954,9 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
                 dw_dil = wg(layer.dilated_conv.weight, dy16, x_all[l], dl, B, C_, 2 * C_, 3, dil, dil, T, T, dtype=G16)
             grads.append([dw_cond, db_cond, dw_dil, db_dil, dw_out, db_out])
             cur = out
+        if SWEEP_EVENTS is not None:
+            ev1.record()
+            SWEEP_EVENTS.append((ev0, ev1, L_ if grouped else 4 * L_))  # (grouped: nothing but the L layer launches lies between the events)
         grads.reverse()
         if grouped:
             dil = layers[0].dilation
@@ -1345,19 +1401,6 @@ def grad_sumsq(flat_grad):
     check(L().set_sumsq_det(_p(flat_grad), _p(out), flat_grad.numel(), _p(_det_scratch(flat_grad.device, 2048)), _stream()),
           "set_sumsq_det")
     return out
-
-
-def adamw_step_dev(flat_p, flat_g, m, v, hyper, beta1, beta2, eps, weight_decay, sumsq=None, max_norm=0.0, grad_scale=1.0):
-    """adamw_step with [lr, bc1, bc2] in device memory (graph replay: training.GraphedTrainStep)."""
-    check(L().set_adamw_dev(_p(flat_p), _p(flat_g), _p(m), _p(v), flat_p.numel(), _p(hyper), float(beta1), float(beta2), float(eps),
-                            float(weight_decay), _p(sumsq), float(max_norm), float(grad_scale), _stream()), "set_adamw_dev")
-
-
-def adamw_hyper(beta1, beta2, step):
-    """(bc1, bc2) = 1 - beta^step in fp32, computed by the library's host code (bit-identical to set_adamw's own)."""
-    out = (C.c_float * 2)()
-    check(L().set_adamw_hyper(float(beta1), float(beta2), int(step), out), "set_adamw_hyper")
-    return float(out[0]), float(out[1])
 
 
 def adamw_step(flat_p, flat_g, m, v, lr, beta1, beta2, eps, weight_decay, step, sumsq=None, max_norm=0.0,

@@ -105,6 +105,13 @@ class TransformerFFNLayer(nn.Module):
         f = F.conv1d(h, self._w1, self._conv.bias, pad=pad, alpha=k ** -0.5, act="gelu", T_out=h.shape[2])
         return F.conv1d(f, self._w2, self.ffn_2.bias, res=res, mask=mask)
 
+    def run_preln(self, x, ln, mask=None):
+        """x + FFN(LayerNorm(x)) (* mask): the sub-block of Enc/DecSALayer as ONE tape node in training (autograd_ops._PreLnFfnFn)."""
+        k = self.kernel_size
+        pad = k // 2 if self.padding == "SAME" else k - 1
+        return _backend().preln_ffn(x, (ln.weight, ln.bias), self._w1, self._conv.bias, self._w2, self.ffn_2.bias, pad=pad, alpha=k ** -0.5,
+                                    act="gelu", mask=mask, eps=ln.eps, T_out=x.shape[2])
+
 
 class EncSALayer(nn.Module):
     def __init__(self, c, num_heads, kernel_size=9):
@@ -119,9 +126,7 @@ class EncSALayer(nn.Module):
         x_ln, x_res = F.fanout(x, 2)
         h = F.layernorm_ch(x_ln, self.layer_norm1.weight, self.layer_norm1.bias)
         x = self.self_attn.self_attn(h, x_res, key_padding, keep)
-        x_ln, x_res = F.fanout(x, 2)
-        h = F.layernorm_ch(x_ln, self.layer_norm2.weight, self.layer_norm2.bias)
-        return self.ffn.run(h, x_res, keep)
+        return self.ffn.run_preln(x, self.layer_norm2, keep)
 
 
 class DecSALayer(nn.Module):
@@ -144,9 +149,7 @@ class DecSALayer(nn.Module):
         x_ln, x_res = F.fanout(x, 2)
         h = F.layernorm_ch(x_ln, self.layer_norm2.weight, self.layer_norm2.bias)
         x, p = self.encoder_attn.cross_attn(h, enc, x_res, enc_padding, want_p)
-        x_ln, x_res = F.fanout(x, 2)
-        h = F.layernorm_ch(x_ln, self.layer_norm3.weight, self.layer_norm3.bias)
-        return self.ffn.run(h, x_res, keep), p
+        return self.ffn.run_preln(x, self.layer_norm3, keep), p
 
 
 class _Layer(nn.Module):

@@ -235,6 +235,15 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const float *z, const floa
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dz[i] = dy[i] * dev_act_grad(z[i], act, p);
 }
+// the same followed by the conv epilogue's alpha (dz = (dy act'(z)) alpha: the two roundings of act_bwd + conv_epilogue_bwd, one launch)
+__global__ void __launch_bounds__(256) act_bwd_scaled_kernel(const float *z, const float *dy, float *dz, int64_t n, int act, float p,
+                                                             float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float t = dy[i] * dev_act_grad(z[i], act, p);
+        dz[i] = t * scale;
+    }
+}
 
 // ---- gate / res-skip backward ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gate_bwd_kernel(const float *y, const float *dz, float *dy, int B, int C,
@@ -1097,6 +1106,11 @@ extern "C" int set_act_bwd(const float *z, const float *dy, float *dz, int64_t n
     SET_REQUIRE(z && dy && dz && n > 0, "set_act_bwd");
     hipLaunchKernelGGL(act_bwd_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, z, dy, dz, n, act, p);
     return set_check_launch("set_act_bwd");
+}
+extern "C" int set_act_bwd_scaled(const float *z, const float *dy, float *dz, int64_t n, int32_t act, float p, float scale, void *stream) {
+    SET_REQUIRE(z && dy && dz && n > 0, "set_act_bwd_scaled");
+    hipLaunchKernelGGL(act_bwd_scaled_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, z, dy, dz, n, act, p, scale);
+    return set_check_launch("set_act_bwd_scaled");
 }
 extern "C" int set_gate_bwd(const float *y, const float *dz, float *dy, int32_t B, int32_t C, int32_t T, void *stream) {
     SET_REQUIRE(y && dz && dy && B > 0 && C > 0 && T > 0, "set_gate_bwd");

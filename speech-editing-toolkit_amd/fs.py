@@ -61,10 +61,9 @@ class ResidualBlock(nn.Module):
         k, d = self.kernel_size, self.dilation
         nonpad = F.abs_sum_mask(x.detach())  # conv.py:58
         for b, (w1, w2) in zip(self.blocks, self._cw):
-            x_ln, x_res = F.fanout(x, 2)
-            h = F.layernorm_ch(x_ln, b[0].weight, b[0].bias, eps=self.ln_eps)
-            h = F.conv1d(h, w1, b[1].bias, dil=d, pad=(d * (k - 1)) // 2, alpha=k ** -0.5, act="gelu")
-            x = F.conv1d(h, w2, b[4].bias, res=x_res, mask=nonpad)  # (x + x_) * nonpadding
+            # LN -> conv k * k^-0.5 -> GELU -> conv 1x1, + x, * nonpadding: one tape node in training (autograd_ops._PreLnFfnFn)
+            x = F.preln_ffn(x, (b[0].weight, b[0].bias), w1, b[1].bias, w2, b[4].bias, dil=d, pad=(d * (k - 1)) // 2, alpha=k ** -0.5,
+                            act="gelu", mask=nonpad, eps=self.ln_eps)
         return x
 
 

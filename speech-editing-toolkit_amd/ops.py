@@ -355,8 +355,18 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
     a.pro_param, a.act_param, a.alpha = float(pro_param), float(act_param), float(alpha)
     a.out_div = float(out_div)
     assert not (out_div and not accumulate)
+    if CONV_EVENTS is not None and impl == "bf16":  # measurement hook (bench.py): hipEvents around every bf16 conv launch, keyed by shape
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.lib().set_conv1d(C.byref(a), _stream()), "set_conv1d")
+        e1.record()
+        CONV_EVENTS.append(((Cin, weight.Cout, weight.K, B, T_iter), e0, e1))
+        return out
     check(_lib.lib().set_conv1d(C.byref(a), _stream()), "set_conv1d")
     return out
+
+
+CONV_EVENTS = None  # bench.py sets a list: ((Cin, Cout, K, B, T), start, end) per bf16 conv launch of the timed steps
 
 
 def resblock_pair_eligible(C, K, dil, T):
@@ -444,6 +454,13 @@ def layernorm_ch(x, gamma, beta, mask=None, eps=1e-5, out=None):
     check(_lib.lib().set_layernorm_ch(_p(x), _p(gamma), _p(beta), _p(mask), _p(out), B, Cc, T, float(eps), _stream()),
           "set_layernorm_ch")
     return out
+
+
+def preln_ffn(x, ln, cw1, b1, cw2, b2, *, dil=1, pad=0, alpha=1.0, act="gelu", act_param=0.0, mask=None, eps=1e-5, T_out=None):
+    """Inference form of autograd_ops.preln_ffn: (x + conv1x1(act(alpha conv_k(LN(x))))) (* mask), the activation in the first conv's epilogue."""
+    h = layernorm_ch(x, ln[0], ln[1], eps=eps)
+    h = conv1d(h, cw1, b1, dil=dil, pad=pad, alpha=alpha, act=act, act_param=act_param, T_out=T_out)
+    return conv1d(h, cw2, b2, res=x, mask=mask)
 
 
 _VALIDATE = os.environ.get("SET_AMD_VALIDATE", "0") == "1"

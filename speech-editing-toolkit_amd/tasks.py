@@ -382,10 +382,9 @@ class CampNetTask(SpeechEditingBaseTask):
         return out
 
 
-def _optimisation_step(task, sample, optimizer, _graph_hyper=None, **kwargs):
+def _optimisation_step(task, sample, optimizer, **kwargs):
     """zero_grad -> run_model -> backward -> optimizer.step (base_task.py:101-137 for one optimizer).  A step that
-    fails half way must not leave the zero arena open (later `_gzeros` calls would hand out stale, non-zero slices).
-    _graph_hyper: training.GraphedTrainStep while it captures the step (the update reads lr / bias corrections from it)."""
+    fails half way must not leave the zero arena open (later `_gzeros` calls would hand out stale, non-zero slices)."""
     optimizer.zero_grad()
     try:
         losses, _ = task.run_model(sample, infer=False, **kwargs)
@@ -395,7 +394,7 @@ def _optimisation_step(task, sample, optimizer, _graph_hyper=None, **kwargs):
     except BaseException:
         optimizer.abort_step()
         raise
-    lr, _ = optimizer.step(graph_hyper=_graph_hyper) if _graph_hyper is not None else optimizer.step()
+    lr, _ = optimizer.step()
     return total.detach(), {k: v.detach() for k, v in losses.items()}, lr
 
 

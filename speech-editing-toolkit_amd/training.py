@@ -105,11 +105,10 @@ class FlatAdamW:
         A.leaf_join()
         self.in_step = False
 
-    def step(self, graph_hyper=None):
+    def step(self):
         """gradient all-reduce (SUM, few large buckets, launched from autograd hooks while backward was still running;
         whatever is left goes now) -> clip_grad_norm_(max_norm) + AdamW on the mean gradient, then the warm-up
-        schedule (base_task.py:129-137).  graph_hyper (GraphedTrainStep, while a step is being captured): a device tensor
-        [lr, bc1, bc2] the update reads instead of host values; the update counter is then advanced by the replaying caller."""
+        schedule (base_task.py:129-137)."""
         A.zero_arena_end()
         A.leaf_join()  # (normally done already, by the callback at the end of backward())
         self.in_step = False
@@ -121,26 +120,14 @@ class FlatAdamW:
                 raise RuntimeError("parameters declared unused received gradients: %s" % bad[:5])
         world = self.bucketer.finish()
         sumsq = A.grad_sumsq(self.flat_g) if self.clip > 0 else None
-        if graph_hyper is not None:
-            lr = None
-            A.adamw_step_dev(self.flat_p, self.flat_g, self.m, self.v, graph_hyper, self.betas[0], self.betas[1], self.eps, self.wd,
-                             sumsq, self.clip, 1.0 / world)
-        else:
-            lr = self.lr_at(self.num_updates)
-            self.num_updates += 1
-            A.adamw_step(self.flat_p, self.flat_g, self.m, self.v, lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                         self.num_updates, sumsq, self.clip, 1.0 / world)
+        lr = self.lr_at(self.num_updates)
+        self.num_updates += 1
+        A.adamw_step(self.flat_p, self.flat_g, self.m, self.v, lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                     self.num_updates, sumsq, self.clip, 1.0 / world)
         ops.bump_weights_epoch()
         if ops.compute_dtype() == "bf16":
             ops.repack_bf16_images()  # every bf16 weight image in one launch (they are all stale now)
         return lr, sumsq
-
-    def next_hyper(self):
-        """Host side of one update for a replayed graph: advances the counter, returns (lr, bc1, bc2) of that update."""
-        lr = self.lr_at(self.num_updates)
-        self.num_updates += 1
-        bc1, bc2 = A.adamw_hyper(self.betas[0], self.betas[1], self.num_updates)
-        return lr, bc1, bc2
 
     # ---- checkpoint interchange with torch.optim.AdamW (the reference's optimizer, tasks/tts/speech_base.py:163-170):
     #      `optimizer_states[0]` of a reference checkpoint (utils/commons/trainer.py:459-471) loads here and vice versa
@@ -190,137 +177,3 @@ class FlatAdamW:
         g0 = groups[0]
         self.betas, self.eps, self.wd = tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
         self.lr0 = g0.get("initial_lr", self.lr0)
-
-
-class GraphedTrainStep:
-    """One optimisation step (zero_grad -> forward + losses -> backward -> clip + AdamW -> bf16 weight images) as ONE captured HIP
-    graph per batch shape, replayed for every later update of that shape.
-
-    Why: a training step of this path is ~500 (spec_denoiser) / ~1,250 (CampNet) launches of 5 - 50 us; enqueueing them from Python
-    took 8.6 / 12.5 ms of a 12.1 / 16.1 ms step (round 3): the GPU waited for the host.  A replay costs one launch.
-    What makes the replay the SAME step as the eager one (tests/test_gpu_training.py compares them bit for bit):
-      * the batch is copied into the static input tensors the graph was captured on;
-      * every Philox kernel adds a device word to its seed argument (set_rng_seed_delta): the replay of step k stores
-        seed_k - seed_captured there, so noise / dropout are the eager step's; explicit diffusion steps `t` are a static tensor;
-      * the optimizer's lr and bias corrections come from a device tensor (set_adamw_dev) filled before each replay; the update
-        counter advances on the host as in the eager step;
-      * nothing in a step synchronises with the host or depends on host state that changes between steps (the first
-        `eager_steps` steps of a shape run eagerly: weight-image caches, the zero arena and the direct-gradient sinks reach
-        their steady state there).
-    Opt-in (SET_AMD_GRAPH_STEP=1), because it does NOT make these steps faster: measured (profiles/r04_graph.log) the eager steps were
-    never waiting for the host -- Python enqueues a step in 8.6 / 12.4 ms WHILE the GPU executes the previous one for 12.1 / 16.1 ms of
-    pure kernel time (rocprof: 670 kernels, 12.8 ms busy per step) -- and a replay adds ~0.5 ms (the batch copies, and a graph cannot
-    overlap its own previous launch): spec_denoiser bf16 12.10 ms eager / 12.62 ms graphed, CampNet 16.12 / 16.89, host enqueue
-    8.56 -> 0.27 ms and 12.36 -> 1.50 ms.  It is the right tool when the host is the bottleneck (small batches, a busy host).
-    Never graphed: more than one rank (the bucketed all-reduce runs from autograd hooks), gradient accumulation, more than
-    `max_graphs` distinct shapes (a graph holds its activations: ~2 GB at B=32, T=800)."""
-
-    def __init__(self, task, optimizer, eager_steps=3, max_graphs=4):
-        self.task, self.opt = task, optimizer
-        self.eager_steps, self.max_graphs = max(2, int(eager_steps)), int(max_graphs)
-        self.entries = {}
-        self.hyper = self.seed_delta = self.stream = None
-        self.replays = 0
-
-    def __del__(self):
-        for _ in range(getattr(self, "_n_captured", 0)):
-            A.graph_released()
-
-    def usable(self):
-        dev = self.opt.flat_p.device
-        return (dev.type == "cuda" and os.environ.get("SET_AMD_GRAPH_STEP", "0") == "1" and not self.opt.bucketer.enabled)
-
-    @staticmethod
-    def _key(sample, t):
-        return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(sample.items()) if isinstance(v, torch.Tensor)) + (t is not None,)
-
-    def eager_mode(self):
-        """Call before any eager work that draws Philox numbers once a graph exists (an eager step of another shape, a validation
-        pass): the seed-delta word of the last replay is process-wide and would shift those seeds."""
-        if self.seed_delta is not None:
-            self.seed_delta.zero_()
-
-    def _eager(self, sample, seed, t):
-        from .tasks import _optimisation_step
-        self.eager_mode()
-        kw = {"seed": seed}
-        if t is not None:
-            kw["t"] = t
-        return _optimisation_step(self.task, sample, self.opt, **kw)
-
-    def __call__(self, sample, seed, t=None):
-        if not self.usable():
-            return self._eager(sample, seed, t)
-        key = self._key(sample, t)
-        e = self.entries.setdefault(key, {"count": 0, "graph": None})
-        if e["graph"] is None:
-            n_graphs = sum(1 for v in self.entries.values() if v["graph"] is not None)
-            if e["count"] < self.eager_steps or n_graphs >= self.max_graphs:
-                e["count"] += 1
-                return self._eager(sample, seed, t)
-            self._capture(e, sample, seed, t)
-        return self._replay(e, sample, seed, t)
-
-    def _capture(self, e, sample, seed, t):
-        from . import _lib
-        from .tasks import _optimisation_step
-        dev = self.opt.flat_p.device
-        if self.hyper is None:
-            self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
-            self.seed_delta = torch.zeros(1, dtype=torch.int64, device=dev)
-            _lib.check(_lib.lib().set_rng_seed_delta(self.seed_delta.data_ptr()), "set_rng_seed_delta")
-        e["static"] = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample.items()}
-        e["t"] = t.clone() if t is not None else None
-        e["seed"] = int(seed)
-        self.seed_delta.zero_()
-        kw = {"seed": e["seed"]}
-        if t is not None:
-            kw["t"] = e["t"]
-        g = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize()
-        del A.CAPTURED_ABORT_WORDS[:]
-        A.graph_captured()  # from here on replaced arena / scratch buffers are parked, not freed (the graph holds their addresses)
-        self._n_captured = getattr(self, "_n_captured", 0) + 1
-        with torch.cuda.graph(g):
-            total, parts, _ = _optimisation_step(self.task, e["static"], self.opt, _graph_hyper=self.hyper, **kw)
-            names = sorted(parts)
-            e["out"] = torch.stack([total.reshape(())] + [parts[n].reshape(()).to(total.dtype) for n in names])
-        e["names"], e["graph"] = names, g
-        e["abort_words"] = list(A.CAPTURED_ABORT_WORDS)  # polled every 64 replays (one host read each)
-
-    def _replay(self, e, sample, seed, t):
-        # The replay runs on a stream of its own, tied to the caller's stream by events on both sides.  (Launched into the legacy
-        # default stream -- torch's current stream unless the caller changed it -- the graph ran concurrently with default-stream work
-        # enqueued right after it: an eager step of another replica shared the zero arena and the seed-delta word with the still
-        # running replay, gradients came out as garbage.  Event dependencies do not rely on the null stream's implicit ordering.)
-        cur = torch.cuda.current_stream()
-        if self.stream is None:
-            self.stream = torch.cuda.Stream()
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            for k, v in sample.items():
-                if isinstance(v, torch.Tensor):
-                    e["static"][k].copy_(v, non_blocking=True)
-                    v.record_stream(self.stream)
-            if t is not None:
-                e["t"].copy_(t, non_blocking=True)
-                t.record_stream(self.stream)
-            delta = (int(seed) - e["seed"]) % (1 << 64)
-            self.seed_delta.fill_(delta - (1 << 64) if delta >= (1 << 63) else delta)
-            lr, bc1, bc2 = self.opt.next_hyper()
-            self.hyper[0:1].fill_(lr)
-            self.hyper[1:2].fill_(bc1)
-            self.hyper[2:3].fill_(bc2)
-            e["graph"].replay()
-            self.replays += 1
-            # the replay updated the parameters: host-side packed-weight caches (packed() / packed_x2(), keyed on the weights epoch) built by
-            # eager work between replays are stale now -- FlatAdamW.step's own bump ran only once, at capture time
-            ops.bump_weights_epoch()
-            out = e["out"].clone()  # the graph's output tensors are overwritten by the next replay
-        cur.wait_stream(self.stream)
-        out.record_stream(cur)
-        if e.get("abort_words") and self.replays % 64 == 0:
-            for ws in e["abort_words"]:
-                if int(ws[1]) != 0:
-                    raise A.SetAmdError("set_diffnet_stack: a tile dependency wait of a replayed training forward timed out")
-        return out[0], {n: out[1 + i] for i, n in enumerate(e["names"])}, lr

@@ -688,70 +688,40 @@ def test_training_step_with_grouped_step_projections_equals_the_per_layer_path(d
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_graphed_training_step_equals_the_eager_step_bit_for_bit(dev, dtype, monkeypatch):
-    """training.GraphedTrainStep: the optimisation step captured once per batch shape and replayed (the step was
-    host-bound, ~500 launches enqueued from Python).  Two identical replicas, eight updates each with a different batch content,
-    explicit diffusion steps t, a different Philox seed (noise, predictor dropout) and the warm-up schedule moving the lr: replica A
-    runs every step eagerly, replica B through GraphedTrainStep (two eager steps, then capture + replays).  Losses, every parameter and
-    both Adam moments must be bit-identical after every update -- seeds reach the replay through set_rng_seed_delta, lr and the bias
-    corrections through set_adamw_dev."""
-    from set_amd import ops
-    from set_amd.training import FlatAdamW, GraphedTrainStep
-    monkeypatch.setenv("SET_AMD_GRAPH_STEP", "1")
+@pytest.mark.parametrize("shape", [(2, 192, 384, 5, 2, 70, True), (3, 192, 768, 9, 8, 100, False), (2, 64, 128, 3, 1, 33, True)])
+def test_preln_ffn_node_equals_the_per_op_tape(dev, dtype, shape, monkeypatch):
+    """autograd_ops._PreLnFfnFn (round 5): LayerNorm -> conv k (* alpha) -> GELU -> conv 1x1 (+ x, * mask) as ONE tape node against the five
+    nodes of the per-op tape on the same kernels: output and every gradient (x, LayerNorm affine, both convs) bit-identical -- 'SAME' padding
+    with a mask (ResidualBlock of the conv encoder, modules/commons/conv.py:24-65) and causal 'LEFT' padding k - 1 without one
+    (TransformerFFNLayer, modules/speech_editing/commons/transformer.py:76-113)."""
+    from set_amd import autograd_ops as A, ops
+    B, Cc, Cmid, K, pad, T, with_mask = shape
+    g = torch.Generator().manual_seed(Cc + K + T)
+    x0 = torch.randn(B, Cc, T, generator=g)
+    gy = torch.randn(B, Cc, T, generator=g)
+    mask = (torch.rand(B, T, generator=g) > 0.2).float().to(dev) if with_mask else None
+    ref = [torch.randn(Cc, generator=g), torch.randn(Cc, generator=g), torch.randn(Cmid, Cc, K, generator=g) * 0.1, torch.randn(Cmid, generator=g) * 0.1,
+           torch.randn(Cc, Cmid, 1, generator=g) * 0.1, torch.randn(Cc, generator=g) * 0.1]
     ops.set_compute_dtype(dtype)
     try:
-        reps = []
-        for _ in range(2):
-            task, W = _train_setup(dev, 8, 31)
-            task.model.train()  # dropout on
-            reps.append((task, FlatAdamW(task.model, lr=1e-3, warmup_updates=5, clip_grad_norm=1.0)))
-        (ta, oa), (tb, ob) = reps
-        assert torch.equal(oa.flat_p, ob.flat_p)
-        gs = GraphedTrainStep(tb, ob, eager_steps=2)
-        assert gs.usable()
-        base = Wt.synthetic_inputs(4, 96, 24, seed=77, pad_tail=True)
-        for it in range(8):
-            inp = Wt.synthetic_inputs(4, 96, 24, seed=77 + it, pad_tail=True)
-            sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"],
-                          time_mel_masks=inp["time_mel_masks"].squeeze(-1), spk_embed=inp["spk_embed"])
-            sample = {k: v.to(dev) for k, v in sample.items()}
-            t = torch.tensor([(1 + it) % 9, 3, (5 + 2 * it) % 9, 7], device=dev)
-            seed = 1000 + 37 * it
-            gs.eager_mode()  # (two replicas in one process: the eager one must not see the last replay's seed delta)
-            tot_a, parts_a, lr_a = ta.training_step(sample, oa, t=t, seed=seed)
-            tot_b, parts_b, lr_b = gs(sample, seed, t)
-            assert lr_a == lr_b and oa.num_updates == ob.num_updates == it + 1
-            assert torch.equal(tot_a, tot_b), it
-            assert set(parts_a) == set(parts_b) and all(torch.equal(parts_a[k].reshape(()), parts_b[k].reshape(()).to(parts_a[k].dtype)) for k in parts_a), it
-            assert torch.equal(oa.flat_p, ob.flat_p) and torch.equal(oa.m, ob.m) and torch.equal(oa.v, ob.v), it
-            if it in (4, 7):
-                # eager inference BETWEEN and AFTER replays must see the replayed updates: the host-side packed-weight caches are keyed on
-                # the weights epoch, which a replay has to bump like an eager optimizer step does (ADVICE r4)
-                mels = []
-                for tk in (ta, tb):
-                    tk.model.eval()
-                    with torch.no_grad():
-                        mels.append(tk.model(sample["txt_tokens"], sample["time_mel_masks"][:, :, None], sample["mel2ph"], sample["spk_embed"],
-                                             sample["mels"], sample["f0"], sample["uv"], infer=True, seed=5)["mel_out"])
-                    tk.model.train()
-                assert torch.equal(mels[0], mels[1]), it
-        assert gs.replays == 6 and sum(1 for e in gs.entries.values() if e["graph"] is not None) == 1
-        # a second batch shape gets its own eager steps, then its own graph
-        inp = Wt.synthetic_inputs(2, 64, 16, seed=5, pad_tail=True)
-        sample = {k: v.to(dev) for k, v in dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"],
-                                                uv=inp["uv"], time_mel_masks=inp["time_mel_masks"].squeeze(-1), spk_embed=inp["spk_embed"]).items()}
-        for it in range(4):
-            t = torch.tensor([2, (4 + it) % 9], device=dev)
-            gs.eager_mode()
-            tot_a, _, _ = ta.training_step(sample, oa, t=t, seed=7 + it)
-            tot_b, _, _ = gs(sample, 7 + it, t)
-            assert torch.equal(tot_a, tot_b) and torch.equal(oa.flat_p, ob.flat_p), it
-        assert gs.replays == 8
+        results = []
+        for fused in ("1", "0"):
+            monkeypatch.setenv("SET_AMD_FUSED_NODES", fused)
+            x = x0.clone().to(dev).requires_grad_(True)
+            ps = [t.clone().to(dev).requires_grad_(True) for t in ref]
+
+            class Holder:
+                pass
+            hold = Holder()
+            hold.w1, hold.w2 = ps[2], ps[4]
+            cw1 = ops.ConvWeight((hold, "w1"), Cmid, Cc, K)
+            cw2 = ops.ConvWeight((hold, "w2"), Cc, Cmid, 1)
+            with torch.enable_grad():
+                y = A.preln_ffn(x, (ps[0], ps[1]), cw1, ps[3], cw2, ps[5], pad=pad, alpha=K ** -0.5, act="gelu", mask=mask, T_out=T)
+                y.backward(gy.to(dev))
+            torch.cuda.synchronize()
+            results.append([y.detach(), x.grad] + [p_.grad for p_ in ps])
+        for a, b in zip(*results):
+            assert a is not None and b is not None and torch.equal(a, b)
     finally:
         ops.set_compute_dtype("f32")
-        _lib_reset_seed_delta()
-
-
-def _lib_reset_seed_delta():
-    from set_amd import _lib
-    _lib.check(_lib.lib().set_rng_seed_delta(None), "set_rng_seed_delta")

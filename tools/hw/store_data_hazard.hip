@@ -16,7 +16,8 @@
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE>  // 0: SGPR soffset, no wait state | 1: SGPR soffset + s_nop 0 | 2: SGPR soffset + s_nop 1 | 3: soffset 0 (offset in the VGPR), no wait state
+template <int MODE>  // 0: SGPR soffset, no wait state | 1: + s_nop 0 | 2: + s_nop 1 | 3: soffset 0 (offset in the VGPR), no wait state | 4 - 6: the data produced
+                     // right in front of the store by packed / packed + s_nop behind the store / plain multiplies
 __global__ void __launch_bounds__(256) probe(float *out, int iters, int rows_per_block) {
     const rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(out, (short)0, (int)0x7fffffff, (int)0x00020000);
     const unsigned lane_off = 16u * threadIdx.x;  // 256 lanes x 16 B = one 4 KiB row per store
@@ -27,6 +28,9 @@ __global__ void __launch_bounds__(256) probe(float *out, int iters, int rows_per
         if (MODE == 3) { voff += soff; soff = 0u; }
         const f32x4 v = {1.0f + it, 2.0f + it, 3.0f + it, 4.0f + it};
         const float poison = -12345.0f;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 one2 = {1.0f, 1.0f};
+        (void)one2;
         if (MODE == 3) {
             asm volatile("buffer_store_dwordx4 v[4:7], %1, %2, 0 offen\n\tv_mov_b32 v6, %3"
                          :: "{v[4:7]}"(v), "v"(voff), "s"(r), "v"(poison) : "memory", "v6");
@@ -36,9 +40,21 @@ __global__ void __launch_bounds__(256) probe(float *out, int iters, int rows_per
         } else if (MODE == 1) {
             asm volatile("buffer_store_dwordx4 v[4:7], %1, %2, %4 offen\n\ts_nop 0\n\tv_mov_b32 v6, %3"
                          :: "{v[4:7]}"(v), "v"(voff), "s"(r), "v"(poison), "s"(soff) : "memory", "v6");
-        } else {
+        } else if (MODE == 2) {
             asm volatile("buffer_store_dwordx4 v[4:7], %1, %2, %4 offen\n\ts_nop 1\n\tv_mov_b32 v6, %3"
                          :: "{v[4:7]}"(v), "v"(voff), "s"(r), "v"(poison), "s"(soff) : "memory", "v6");
+        } else if (MODE == 4) {  // what conv1d_mfma_v2_kernel's epilogue had: packed fp32 ops produce the data right in front of the store
+            asm volatile("v_pk_mul_f32 v[6:7], v[6:7], %5\n\tv_pk_mul_f32 v[4:5], v[4:5], %5\n\t"
+                         "buffer_store_dwordx4 v[4:7], %1, %2, %4 offen\n\tv_mov_b32 v6, %3"
+                         :: "{v[4:7]}"(v), "v"(voff), "s"(r), "v"(poison), "s"(soff), "v"(one2) : "memory", "v4", "v5", "v6", "v7");
+        } else if (MODE == 5) {
+            asm volatile("v_pk_mul_f32 v[6:7], v[6:7], %5\n\tv_pk_mul_f32 v[4:5], v[4:5], %5\n\t"
+                         "buffer_store_dwordx4 v[4:7], %1, %2, %4 offen\n\ts_nop 0\n\tv_mov_b32 v6, %3"
+                         :: "{v[4:7]}"(v), "v"(voff), "s"(r), "v"(poison), "s"(soff), "v"(one2) : "memory", "v4", "v5", "v6", "v7");
+        } else {  // 6: plain (unpacked) multiplies in front of the store
+            asm volatile("v_mul_f32 v6, v6, %5\n\tv_mul_f32 v4, v4, %5\n\t"
+                         "buffer_store_dwordx4 v[4:7], %1, %2, %4 offen\n\tv_mov_b32 v6, %3"
+                         :: "{v[4:7]}"(v), "v"(voff), "s"(r), "v"(poison), "s"(soff), "v"(1.0f) : "memory", "v4", "v6");
         }
     }
 }
@@ -52,15 +68,20 @@ int main() {
     const size_t bytes = (size_t)blocks * rows * 4096;
     float *d = nullptr; unsigned long long *cnt = nullptr;
     if (hipMalloc(&d, bytes) != hipSuccess || hipMalloc(&cnt, 8) != hipSuccess) { printf("alloc failed\n"); return 1; }
-    const char *names[4] = {"SGPR soffset, VALU write of data dword 2 right behind the store", "SGPR soffset, s_nop 0 (1 wait state) in between",
-                            "SGPR soffset, s_nop 1 (2 wait states) in between", "soffset 0 (offset in the VGPR), no wait state"};
+    const char *names[7] = {"SGPR soffset, VALU write of data dword 2 right behind the store", "SGPR soffset, s_nop 0 (1 wait state) in between",
+                            "SGPR soffset, s_nop 1 (2 wait states) in between", "soffset 0 (offset in the VGPR), no wait state",
+                            "v_pk_mul_f32 producing the data, SGPR soffset, VALU write right behind", "v_pk_mul_f32 ..., SGPR soffset, s_nop 0 in between",
+                            "v_mul_f32 producing the data, SGPR soffset, VALU write right behind"};
     for (int rep = 0; rep < 2; ++rep)
-        for (int mode = 0; mode < 4; ++mode) {
+        for (int mode = 0; mode < 7; ++mode) {
             hipMemset(d, 0, bytes); hipMemset(cnt, 0, 8);
             if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, d, iters, rows);
             if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(256), 0, 0, d, iters, rows);
             if (mode == 2) hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(256), 0, 0, d, iters, rows);
             if (mode == 3) hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(256), 0, 0, d, iters, rows);
+            if (mode == 4) hipLaunchKernelGGL(probe<4>, dim3(blocks), dim3(256), 0, 0, d, iters, rows);
+            if (mode == 5) hipLaunchKernelGGL(probe<5>, dim3(blocks), dim3(256), 0, 0, d, iters, rows);
+            if (mode == 6) hipLaunchKernelGGL(probe<6>, dim3(blocks), dim3(256), 0, 0, d, iters, rows);
             hipLaunchKernelGGL(count_poison, dim3(2048), dim3(256), 0, 0, (const float *)d, bytes / 4, cnt);
             unsigned long long h = 0;
             hipError_t e = hipMemcpy(&h, cnt, 8, hipMemcpyDeviceToHost);
