@@ -509,7 +509,7 @@ class _PreLnFfnFn(torch.autograd.Function):
 def preln_ffn(x, ln, cw1, b1, cw2, b2, *, dil=1, pad=0, alpha=1.0, act="gelu", act_param=0.0, mask=None, eps=1e-5, T_out=None):
     """(x + conv1x1(act(alpha conv_k(LN(x))))) (* mask) as one tape node; ln = (gamma, beta).  SET_AMD_FUSED_NODES=0: the per-op tape
     (fan-out, LayerNorm, conv, activation, conv: five nodes) -- the cross-check of tests/test_gpu_training.py and the A/B of the bench."""
-    if os.environ.get("SET_AMD_FUSED_NODES", "1") == "0":
+    if not _fused_nodes():
         x_ln, x_res = fanout(x, 2)
         h = layernorm_ch(x_ln, ln[0], ln[1], eps=eps)
         h = conv1d(h, cw1, b1, dil=dil, pad=pad, alpha=alpha, act=act, act_param=act_param, T_out=T_out)
@@ -1166,6 +1166,152 @@ def self_attention(qkv, heads, key_padding_mask=None, fill=float("-inf"), alpha=
 
 def cross_attention(q, kv, heads, key_padding_mask=None, fill=-1e8, alpha=1.0, want_p=True):
     return _CrossAttnFn.apply(q, kv, heads, key_padding_mask, fill, alpha, want_p)
+
+
+def _tape_tgt(param, dev, whole=True):
+    """(accumulation target, gradient to hand to autograd or None when the kernel writes the optimizer's .grad view in place)."""
+    sink = grad_sink(param)[0] if whole else None
+    if sink is not None:
+        return sink, None
+    tmp = _gzeros(param.shape, dev)
+    return tmp, tmp
+
+
+def _preln_tail(x, gamma, p_gamma, p_beta, dh, g2, eps):
+    """LayerNorm backward of a pre-LN sub-block, then the residual branch joins (LN branch + residual, the per-op tape's order)."""
+    B, Cc, T = x.shape
+    dxl = torch.empty_like(x)
+    (t_g, r_g), (t_b, r_b) = _tape_tgt(p_gamma, x.device), _tape_tgt(p_beta, x.device)
+    part = _det_scratch(x.device, L().set_layernorm_ch_bwd_scratch(B, Cc, T))
+    check(L().set_layernorm_ch_bwd(_p(x), _p(gamma), None, _p(dh), _p(dxl), _p(t_g), _p(t_b), _p(part), B, Cc, T, float(eps), _stream()),
+          "set_layernorm_ch_bwd")
+    return ops.sum_div(dxl, g2), r_g, r_b
+
+
+class _PreLnSelfAttnFn(torch.autograd.Function):
+    """One tape node for x + out_proj(self_attention(in_proj(LN(x)))) (* mask): the self-attention sub-block of Enc/DecSALayer
+    (modules/speech_editing/commons/transformer.py:138-189,421-422,619-652; bias-free packed projections).  Same kernels as the per-op tape
+    (LN, packed 1x1 in_proj, fused attention, 1x1 out_proj with the residual and the mask in its epilogue); fused attention kernels only."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w_in, w_out, cw_qkv, cw_out, heads, kpm, fill, alpha, mask, eps):
+        x = x.contiguous()
+        H = x.shape[1]
+        MV = ops.MatView
+        h = ops.layernorm_ch(x, gamma, beta, None, eps)
+        qkv = ops.conv1d(h, cw_qkv)
+        o, lse, _ = ops.attention_fused(MV.heads(qkv, heads, 0, H), MV.heads(qkv, heads, H, H), MV.heads(qkv, heads, 2 * H, H), heads, kpm,
+                                        fill, alpha, False)
+        y = ops.conv1d(o, cw_out, None, res=x, mask=mask)
+        ctx.save_for_backward(x, gamma, mask, kpm, h, qkv, o, lse)
+        ctx.cfg, ctx.cws, ctx.params = (heads, fill, alpha, eps), (cw_qkv, cw_out), (gamma, beta, w_in, w_out)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mask, kpm, h, qkv, o, lse = ctx.saved_tensors
+        heads, fill, alpha, eps = ctx.cfg
+        cw_qkv, cw_out = ctx.cws
+        p_gamma, p_beta, p_win, p_wout = ctx.params
+        dy = dy.contiguous()
+        B, H, T = dy.shape
+        dev, MV = dy.device, ops.MatView
+        if mask is None:
+            g2 = dy
+        else:
+            g2 = torch.empty_like(dy)
+            check(L().set_conv_epilogue_bwd(_p(dy), None, _p(mask), _p(g2), B, H, T, 0, 1.0, _stream()), "set_conv_epilogue_bwd")
+        do = ops.conv1d(g2, cw_out.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T)
+        t_wo, r_wo = _tape_tgt(p_wout, dev)
+        with leaf_work(dev, r_wo is None and g2 is not dy, g2, o):
+            conv_wgrad(g2, o, None, t_wo, B, H, H, 1, 1, 0, T, T)
+        dqkv = torch.empty_like(qkv)
+        ops.attention_fused_bwd(MV.heads(qkv, heads, 0, H), MV.heads(qkv, heads, H, H), MV.heads(qkv, heads, 2 * H, H), o, lse, do,
+                                MV.heads(dqkv, heads, 0, H), MV.heads(dqkv, heads, H, H), MV.heads(dqkv, heads, 2 * H, H), heads, kpm, fill, alpha)
+        dh = ops.conv1d(dqkv, cw_qkv.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T)
+        t_wi, r_wi = _tape_tgt(p_win, dev)
+        with leaf_work(dev, r_wi is None, dqkv, h):
+            conv_wgrad(dqkv, h, None, t_wi, B, H, 3 * H, 1, 1, 0, T, T)
+        dx, r_g, r_b = _preln_tail(x, gamma, p_gamma, p_beta, dh, g2, eps)
+        return (dx, r_g, r_b, r_wi, r_wo) + (None,) * 8
+
+
+class _PreLnCrossAttnFn(torch.autograd.Function):
+    """One tape node for x + out_proj(attention(q = in_proj_q(LN(x)), k, v = in_proj_kv(enc))): the encoder-decoder attention sub-block of
+    DecSALayer (transformer.py:283-410,531-609); returns (y, probabilities or an empty tensor).  The q rows and the k / v rows of the packed
+    in_proj weight get ONE gradient (the per-op tape returns two full-size temporaries that autograd adds); fused attention kernels only."""
+
+    @staticmethod
+    def forward(ctx, x, enc, gamma, beta, w_in, w_out, cw_q, cw_kv, cw_out, heads, kpm, fill, alpha, want_p, eps):
+        x, enc = x.contiguous(), enc.contiguous()
+        H = x.shape[1]
+        MV = ops.MatView
+        h = ops.layernorm_ch(x, gamma, beta, None, eps)
+        q = ops.conv1d(h, cw_q)
+        kv = ops.conv1d(enc, cw_kv)
+        o, lse, p = ops.attention_fused(MV.heads(q, heads), MV.heads(kv, heads, 0, H), MV.heads(kv, heads, H, H), heads, kpm, fill, alpha, want_p)
+        y = ops.conv1d(o, cw_out, None, res=x)
+        ctx.save_for_backward(x, enc, gamma, kpm, h, q, kv, o, lse)
+        ctx.cfg, ctx.cws, ctx.params = (heads, fill, alpha, eps), (cw_q, cw_kv, cw_out), (gamma, beta, w_in, w_out)
+        if p is None:
+            p = x.new_empty(0)
+        ctx.mark_non_differentiable(p)
+        return y, p
+
+    @staticmethod
+    def backward(ctx, dy, _dp):
+        x, enc, gamma, kpm, h, q, kv, o, lse = ctx.saved_tensors
+        heads, fill, alpha, eps = ctx.cfg
+        cw_q, cw_kv, cw_out = ctx.cws
+        p_gamma, p_beta, p_win, p_wout = ctx.params
+        g2 = dy.contiguous()
+        B, H, T = g2.shape
+        Tk = enc.shape[2]
+        dev, MV = g2.device, ops.MatView
+        do = ops.conv1d(g2, cw_out.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T)
+        t_wo, r_wo = _tape_tgt(p_wout, dev)
+        conv_wgrad(g2, o, None, t_wo, B, H, H, 1, 1, 0, T, T)  # (compute stream: g2 is the engine's buffer)
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        ops.attention_fused_bwd(MV.heads(q, heads), MV.heads(kv, heads, 0, H), MV.heads(kv, heads, H, H), o, lse, do,
+                                MV.heads(dq, heads), MV.heads(dkv, heads, 0, H), MV.heads(dkv, heads, H, H), heads, kpm, fill, alpha)
+        dh = ops.conv1d(dq, cw_q.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T)
+        denc = ops.conv1d(dkv, cw_kv.transposed(), None, dil=-1, pad=0, T_iter=Tk, T_out=Tk) if ctx.needs_input_grad[1] else None
+        # rows [0, H) of the packed weight from the queries, rows [H, 3H) from the keys / values: together the whole parameter, once
+        t_wi, r_wi = _tape_tgt(p_win, dev)
+        with leaf_work(dev, r_wi is None, dq, dkv, h, enc):
+            conv_wgrad(dq, h, None, t_wi, B, H, H, 1, 1, 0, T, T, dw_ptr=t_wi.data_ptr() + 4 * cw_q.base)
+            conv_wgrad(dkv, enc, None, t_wi, B, H, 2 * H, 1, 1, 0, Tk, Tk, dw_ptr=t_wi.data_ptr() + 4 * cw_kv.base)
+        dx, r_g, r_b = _preln_tail(x, gamma, p_gamma, p_beta, dh, g2, eps)
+        return (dx, denc, r_g, r_b, r_wi, r_wo) + (None,) * 9
+
+
+def _fused_nodes():
+    return os.environ.get("SET_AMD_FUSED_NODES", "1") != "0"
+
+
+def preln_self_attn(x, ln, attn, key_padding=None, mask=None, eps=1e-5):
+    """x + self-attention(LayerNorm(x)) (* mask); attn: the module holding the packed projections (campnet.MultiheadAttention)."""
+    if _fused_nodes() and ops.attention_fused_on(attn.embed_dim // attn.num_heads):
+        return _PreLnSelfAttnFn.apply(x, ln[0], ln[1], attn._w_qkv.raw(), attn._w_out.raw(), attn._w_qkv, attn._w_out, attn.num_heads,
+                                      key_padding, float("-inf"), attn.scaling, mask, eps)
+    x_ln, x_res = fanout(x, 2)
+    h = layernorm_ch(x_ln, ln[0], ln[1], eps=eps)
+    qkv = conv1d(h, attn._w_qkv)
+    o, _ = self_attention(qkv, attn.num_heads, key_padding, float("-inf"), attn.scaling)
+    return conv1d(o, attn._w_out, res=x_res, mask=mask)
+
+
+def preln_cross_attn(x, ln, attn, enc, enc_padding, want_p=True, eps=1e-5):
+    """(x + encoder-decoder attention(LayerNorm(x), enc), probabilities [B, heads, T, T_txt] or an empty tensor)."""
+    if _fused_nodes() and ops.attention_fused_on(attn.embed_dim // attn.num_heads):
+        return _PreLnCrossAttnFn.apply(x, enc, ln[0], ln[1], attn._w_q.raw(), attn._w_out.raw(), attn._w_q, attn._w_kv, attn._w_out,
+                                       attn.num_heads, enc_padding, -1e8, attn.scaling, want_p, eps)
+    x_ln, x_res = fanout(x, 2)
+    h = layernorm_ch(x_ln, ln[0], ln[1], eps=eps)
+    q = conv1d(h, attn._w_q)
+    kv = conv1d(enc, attn._w_kv)
+    o, p = cross_attention(q, kv, attn.num_heads, enc_padding, -1e8, attn.scaling, want_p=want_p)
+    return conv1d(o, attn._w_out, res=x_res), p
 
 
 class _PosAddFn(torch.autograd.Function):

@@ -123,9 +123,8 @@ class EncSALayer(nn.Module):
 
     def run(self, x, key_padding, keep):
         F = _backend()
-        x_ln, x_res = F.fanout(x, 2)
-        h = F.layernorm_ch(x_ln, self.layer_norm1.weight, self.layer_norm1.bias)
-        x = self.self_attn.self_attn(h, x_res, key_padding, keep)
+        ln = self.layer_norm1
+        x = F.preln_self_attn(x, (ln.weight, ln.bias), self.self_attn, key_padding, keep, eps=ln.eps)  # one tape node in training
         return self.ffn.run_preln(x, self.layer_norm2, keep)
 
 
@@ -143,12 +142,9 @@ class DecSALayer(nn.Module):
         """The self-attention gets NO padding mask (the reference calls the layer without self_attn_padding_mask,
         transformer.py:803); returns (x, cross-attention probabilities)."""
         F = _backend()
-        x_ln, x_res = F.fanout(x, 2)
-        h = F.layernorm_ch(x_ln, self.layer_norm1.weight, self.layer_norm1.bias)
-        x = self.self_attn.self_attn(h, x_res)
-        x_ln, x_res = F.fanout(x, 2)
-        h = F.layernorm_ch(x_ln, self.layer_norm2.weight, self.layer_norm2.bias)
-        x, p = self.encoder_attn.cross_attn(h, enc, x_res, enc_padding, want_p)
+        ln1, ln2 = self.layer_norm1, self.layer_norm2
+        x = F.preln_self_attn(x, (ln1.weight, ln1.bias), self.self_attn, eps=ln1.eps)
+        x, p = F.preln_cross_attn(x, (ln2.weight, ln2.bias), self.encoder_attn, enc, enc_padding, want_p, eps=ln2.eps)
         return self.ffn.run_preln(x, self.layer_norm3, keep), p
 
 

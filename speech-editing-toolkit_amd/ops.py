@@ -463,6 +463,23 @@ def preln_ffn(x, ln, cw1, b1, cw2, b2, *, dil=1, pad=0, alpha=1.0, act="gelu", a
     return conv1d(h, cw2, b2, res=x, mask=mask)
 
 
+def preln_self_attn(x, ln, attn, key_padding=None, mask=None, eps=1e-5):
+    """Inference form of autograd_ops.preln_self_attn."""
+    h = layernorm_ch(x, ln[0], ln[1], eps=eps)
+    qkv = conv1d(h, attn._w_qkv)
+    o, _ = self_attention(qkv, attn.num_heads, key_padding, float("-inf"), attn.scaling)
+    return conv1d(o, attn._w_out, res=x, mask=mask)
+
+
+def preln_cross_attn(x, ln, attn, enc, enc_padding, want_p=True, eps=1e-5):
+    """Inference form of autograd_ops.preln_cross_attn: (x + attention, probabilities or None)."""
+    h = layernorm_ch(x, ln[0], ln[1], eps=eps)
+    q = conv1d(h, attn._w_q)
+    kv = conv1d(enc, attn._w_kv)
+    o, p = cross_attention(q, kv, attn.num_heads, enc_padding, -1e8, attn.scaling, want_p=want_p)
+    return conv1d(o, attn._w_out, res=x), p
+
+
 _VALIDATE = os.environ.get("SET_AMD_VALIDATE", "0") == "1"
 
 

@@ -444,3 +444,50 @@ def test_attention_with_a_head_size_the_fused_kernels_do_not_cover(dev):
     assert _md(o_s, r_s.float()) < 2e-5 and _md(o_c, r_c.float()) < 2e-5
     for a, b in ((qkv.grad, qkv2.grad), (q.grad, q2.grad), (kv.grad, kv2.grad)):
         assert _md(a, b.float()) < 5e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_preln_attention_nodes_equal_the_per_op_tape(dev, dtype, monkeypatch):
+    """autograd_ops._PreLnSelfAttnFn / _PreLnCrossAttnFn (round 5): the pre-LayerNorm self-attention and encoder-decoder attention sub-blocks
+    of Enc/DecSALayer (modules/speech_editing/commons/transformer.py:531-609,619-652) as ONE tape node each against the per-op tape (fan-out,
+    LayerNorm, packed projections, fused attention, out projection + residual) on the same kernels: outputs, probabilities and every
+    gradient (x, enc, LayerNorm affine, both packed weights) bit-identical, with a key-padding mask, an output mask and a ragged T."""
+    from set_amd import autograd_ops as A, campnet, ops
+    B, H, T, Tk, heads = 3, 192, 77, 19, 2
+    g = torch.Generator().manual_seed(5)
+    x0, enc0 = torch.randn(B, H, T, generator=g), torch.randn(B, H, Tk, generator=g)
+    gy, gy2 = torch.randn(B, H, T, generator=g), torch.randn(B, H, T, generator=g)
+    keep = (torch.rand(B, T, generator=g) > 0.15).float().to(dev)
+    kpm = (1.0 - keep).contiguous()
+    enc_pad = torch.zeros(B, Tk)
+    enc_pad[1, 15:] = 1.0
+    enc_pad = enc_pad.to(dev)
+    torch.manual_seed(3)
+    mods = [campnet.MultiheadAttention(H, heads).to(dev), campnet.MultiheadAttention(H, heads).to(dev)]
+    lns = [torch.nn.LayerNorm(H).to(dev), torch.nn.LayerNorm(H).to(dev)]
+    with torch.no_grad():
+        for ln in lns:
+            ln.weight.normal_(1.0, 0.2, generator=None)
+            ln.bias.normal_(0.0, 0.2)
+    ops.set_compute_dtype(dtype)
+    try:
+        results = []
+        for fused in ("1", "0"):
+            monkeypatch.setenv("SET_AMD_FUSED_NODES", fused)
+            for p_ in list(mods[0].parameters()) + list(mods[1].parameters()) + list(lns[0].parameters()) + list(lns[1].parameters()):
+                p_.grad = None
+            x = x0.clone().to(dev).requires_grad_(True)
+            enc = enc0.clone().to(dev).requires_grad_(True)
+            with torch.enable_grad():
+                y1 = A.preln_self_attn(x, (lns[0].weight, lns[0].bias), mods[0], kpm, keep)
+                y2, p = A.preln_cross_attn(y1, (lns[1].weight, lns[1].bias), mods[1], enc, enc_pad, want_p=True)
+                (y2 * gy.to(dev)).sum().backward(retain_graph=False)
+            torch.cuda.synchronize()
+            outs = [y1.detach(), y2.detach(), p.detach(), x.grad, enc.grad]
+            outs += [q.grad.clone() for m in mods for q in m.parameters()] + [q.grad.clone() for ln in lns for q in ln.parameters()]
+            results.append(outs)
+        assert results[0][2].shape == (B, heads, T, Tk)
+        for i, (a, b) in enumerate(zip(*results)):
+            assert torch.equal(a, b), i
+    finally:
+        ops.set_compute_dtype("f32")

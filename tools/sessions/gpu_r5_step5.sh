@@ -3,7 +3,7 @@
 # the store-data hazard probe with the data produced by packed / plain multiplies right in front of the store
 set -u
 cd "$GRAFT_REPO_ROOT"; OUT=gpurun_out/r5s5; mkdir -p $OUT; export TMPDIR=/tmp; R="$GRAFT_REPO_ROOT"
-timeout 300 tools/hw/store_data_hazard 2>&1 | tee $OUT/store_data_hazard.log
+
 timeout 1200 python -X faulthandler -m pytest tests/test_gpu_training.py tests/test_gpu_campnet.py tests/test_gpu_bf16.py -q -x 2>&1 | grep -v '^  File "/usr/l' | tail -12 | tee $OUT/pytest.log
 for rep in 1 2; do
 for fused in 1 0; do
