@@ -68,7 +68,13 @@ def _leaf_state(dev):
     st = _LEAF.get(idx)
     if st is None:
         # lowest priority: its chip-filling GEMMs yield workgroup slots to the compute stream's short kernels (SET_AMD_LEAF_PRIORITY=0: default)
-        if os.environ.get("SET_AMD_LEAF_PRIORITY", "low") != "0":
+        n_cus = int(os.environ.get("SET_AMD_LEAF_CUS", "0"))
+        if n_cus > 0:  # measurement switch: the leaf stream confined to the first n_cus compute units
+            raw = C.c_void_p()
+            with torch.cuda.device(idx):
+                check(L().set_stream_create_cu_masked(C.byref(raw), n_cus), "set_stream_create_cu_masked")
+            stream = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
+        elif os.environ.get("SET_AMD_LEAF_PRIORITY", "low") != "0":
             raw = C.c_void_p()
             with torch.cuda.device(idx):
                 check(L().set_stream_create_low_priority(C.byref(raw)), "set_stream_create_low_priority")
@@ -340,10 +346,10 @@ class _Conv1dFn(torch.autograd.Function):
             b_sink = grad_sink(ctx.bparam)[0] if ctx.bparam.numel() == Cout else None
             db = b_sink if b_sink is not None else _gzeros(Cout, dy.device)
         # gradients that go straight into .grad are leaves of this backward pass (the optimizer is their next reader): leaf stream
-        # (only when g is a tensor of this function's own: the engine's gradient buffer dy -- or g handed on as the residual's gradient --
-        # may get the next arrival accumulated into it IN PLACE, on the compute stream, while a leaf kernel still reads it)
-        on_leaf = ((not want_w or w_sink is not None) and (not want_b or b_sink is not None) and (want_w or want_b)
-                   and g is not dy and dres is not g)
+        # (g may be the engine's own gradient buffer dy, or be handed on as the residual's gradient: the autograd engine accumulates a later
+        # arrival into such a buffer IN PLACE only while it holds the last reference to it (input_buffer.cpp: can_accumulate_inplace), and
+        # leaf_work keeps a reference to its operands until the streams are joined -- so nothing rewrites g under the leaf kernels)
+        on_leaf = (not want_w or w_sink is not None) and (not want_b or b_sink is not None) and (want_w or want_b)
         with leaf_work(dy.device, on_leaf, g, x, chan_add):
             if want_w:
                 conv_wgrad(g, x, chan_add, dw, B, Cin, Cout, cw.K, dil, pad, T, T_in, PRO[pro], pro_param,
@@ -484,8 +490,7 @@ class _PreLnFfnFn(torch.autograd.Function):
             check(L().set_conv_epilogue_bwd(_p(dy), None, _p(mask), _p(g2), B, Cc, T, 0, 1.0, _stream()), "set_conv_epilogue_bwd")
         df = ops.conv1d(g2, cw2.transposed(), None, dil=-1, pad=0, T_iter=T1, T_out=T1)
         (t_w2, r_w2), (t_b2, r_b2) = tgt(p_w2, cw2), tgt(p_b2)
-        # (leaf stream only for a tensor of this function's own: see _Conv1dFn.backward)
-        with leaf_work(dev, r_w2 is None and r_b2 is None and g2 is not dy, g2, f):
+        with leaf_work(dev, r_w2 is None and r_b2 is None, g2, f):  # (g2 may be dy itself: kept referenced, see _Conv1dFn.backward)
             conv_wgrad(g2, f, None, t_w2, B, Cmid, Cc, 1, 1, 0, T, T1, dw_ptr=t_w2.data_ptr() + 4 * cw2.base)
             channel_sum_(g2, t_b2, B, Cc, T)
         # ---- activation backward with the first conv's alpha folded in: G1 = gradient of the raw conv + bias
@@ -1223,7 +1228,7 @@ class _PreLnSelfAttnFn(torch.autograd.Function):
             check(L().set_conv_epilogue_bwd(_p(dy), None, _p(mask), _p(g2), B, H, T, 0, 1.0, _stream()), "set_conv_epilogue_bwd")
         do = ops.conv1d(g2, cw_out.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T)
         t_wo, r_wo = _tape_tgt(p_wout, dev)
-        with leaf_work(dev, r_wo is None and g2 is not dy, g2, o):
+        with leaf_work(dev, r_wo is None, g2, o):
             conv_wgrad(g2, o, None, t_wo, B, H, H, 1, 1, 0, T, T)
         dqkv = torch.empty_like(qkv)
         ops.attention_fused_bwd(MV.heads(qkv, heads, 0, H), MV.heads(qkv, heads, H, H), MV.heads(qkv, heads, 2 * H, H), o, lse, do,
@@ -1270,7 +1275,8 @@ class _PreLnCrossAttnFn(torch.autograd.Function):
         dev, MV = g2.device, ops.MatView
         do = ops.conv1d(g2, cw_out.transposed(), None, dil=-1, pad=0, T_iter=T, T_out=T)
         t_wo, r_wo = _tape_tgt(p_wout, dev)
-        conv_wgrad(g2, o, None, t_wo, B, H, H, 1, 1, 0, T, T)  # (compute stream: g2 is the engine's buffer)
+        with leaf_work(dev, r_wo is None, g2, o):
+            conv_wgrad(g2, o, None, t_wo, B, H, H, 1, 1, 0, T, T)
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         ops.attention_fused_bwd(MV.heads(q, heads), MV.heads(kv, heads, 0, H), MV.heads(kv, heads, H, H), o, lse, do,
                                 MV.heads(dq, heads), MV.heads(dkv, heads, 0, H), MV.heads(dkv, heads, H, H), heads, kpm, fill, alpha)
