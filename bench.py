@@ -629,7 +629,9 @@ def bf16_loop_line(model, inp, args, ret_f32_seed0):
     fuse = int(_lib.lib().set_diffnet_layers_bf16_plan(B_PER_GPU, T, L, 1))
     # HBM bytes per group launch from the PMC passes of THESE kernel sources (tools/sessions/gpu_pmc_bf16_layers.sh; sha256-checked like the headline's)
     traffic, traffic_note, pmc = None, "no PMC file", None
-    tfile = os.path.join(ROOT, "profiles", "r04_pmc_bf16_layers.json")
+    tfile = os.path.join(ROOT, "profiles", "r05_pmc_bf16_layers.json")
+    if not os.path.exists(tfile):
+        tfile = os.path.join(ROOT, "profiles", "r04_pmc_bf16_layers.json")
     if os.path.exists(tfile):
         import hashlib
         with open(tfile) as f:
@@ -642,9 +644,9 @@ def bf16_loop_line(model, inp, args, ret_f32_seed0):
         if ent is not None and h.hexdigest() == tj.get("kernel_source_sha256"):
             pmc = ent
             traffic = ent.get("hbm_bytes_per_launch")
-            traffic_note = "PMC passes of this kernel build (profiles/r04_pmc_bf16_layers.json, source sha256 matches); per launch of %d layers" % fuse
+            traffic_note = "PMC passes of this kernel build (%s, source sha256 matches); per launch of %d layers" % (os.path.relpath(tfile, ROOT), fuse)
         else:
-            traffic_note = "withheld: the kernel sources changed since the PMC passes in profiles/r04_pmc_bf16_layers.json"
+            traffic_note = "withheld: the kernel sources changed since the PMC passes in %s" % os.path.relpath(tfile, ROOT)
     return {"note": "opt-in bf16 MFMA operands in the residual layers; not the parity path, not the headline",
             "value": B_PER_GPU * T / dt, "unit": "mel-frames/s", "ms_per_step": 1e3 * dt, "dtype": "bf16 operands, f32 accumulate",
             "mcd_vs_f32_path": mcd, "max_abs_dmel_vs_f32_path": float(abs(a - b).max()),

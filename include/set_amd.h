@@ -372,8 +372,6 @@ int set_rng_seed_delta(const uint64_t *dev_word);
 int set_stream_order(void *first, void *after, int32_t slot);
 /* a non-blocking stream of the lowest priority of the current device (the leaf stream); never destroyed */
 int set_stream_create_low_priority(void **out);
-/* a stream whose kernels may only occupy the first n_cus compute units (hipExtStreamCreateWithCUMask); never destroyed */
-int set_stream_create_cu_masked(void **out, int32_t n_cus);
 
 /* Whole reverse loop (spec_denoiser.py:178-184 + p_sample :103-108 + DiffNet.forward diffnet.py:110-132)
  * for residual_channels == 256.  All weights pre-packed by the caller; workspaces provided by the caller.

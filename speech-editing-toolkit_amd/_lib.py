@@ -236,7 +236,6 @@ SIGNATURES = {
     "set_rng_seed_delta": (C.c_int, [_V]),
     "set_stream_order": (C.c_int, [_V, _V, _I32]),
     "set_stream_create_low_priority": (C.c_int, [C.POINTER(C.c_void_p)]),
-    "set_stream_create_cu_masked": (C.c_int, [C.POINTER(C.c_void_p), _I32]),
     "set_diffusion_loop": (C.c_int, [C.POINTER(SetDiffLoopArgs), _V]),
     "set_selftest_mfma": (C.c_int, [C.POINTER(C.c_float), _V]),
     "set_sizeof_attn_args": (_I64, []),

@@ -68,13 +68,7 @@ def _leaf_state(dev):
     st = _LEAF.get(idx)
     if st is None:
         # lowest priority: its chip-filling GEMMs yield workgroup slots to the compute stream's short kernels (SET_AMD_LEAF_PRIORITY=0: default)
-        n_cus = int(os.environ.get("SET_AMD_LEAF_CUS", "0"))
-        if n_cus > 0:  # measurement switch: the leaf stream confined to the first n_cus compute units
-            raw = C.c_void_p()
-            with torch.cuda.device(idx):
-                check(L().set_stream_create_cu_masked(C.byref(raw), n_cus), "set_stream_create_cu_masked")
-            stream = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
-        elif os.environ.get("SET_AMD_LEAF_PRIORITY", "low") != "0":
+        if os.environ.get("SET_AMD_LEAF_PRIORITY", "low") != "0":
             raw = C.c_void_p()
             with torch.cuda.device(idx):
                 check(L().set_stream_create_low_priority(C.byref(raw)), "set_stream_create_low_priority")

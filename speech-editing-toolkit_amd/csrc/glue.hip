@@ -402,24 +402,8 @@ extern "C" int set_stream_order(void *first, void *after, int32_t slot) {
 // A non-blocking stream of the LOWEST priority the device offers: the leaf stream's chip-filling weight-gradient GEMMs must not hold
 // the workgroup slots the compute stream's short kernels are waiting for (measured with equal priorities: a 5 us ordered sum of the
 // compute stream took 110 - 170 us behind a grouped weight-gradient launch).  Never destroyed (one per process and device).
-// The same, restricted to the first `n_cus` compute units in the runtime's CU numbering (on MI355X consecutive numbers go round the 8 XCDs,
-// so n_cus = 192 means 24 of each XCD's 32): the leaf stream's chip-filling GEMMs then never occupy the remaining CUs, and the compute
-// stream's short kernels (which may use every CU) always find free workgroup slots.
-extern "C" int set_stream_create_cu_masked(void **out, int32_t n_cus) {
-    SET_REQUIRE(out != nullptr && n_cus > 0, "set_stream_create_cu_masked");
-    int dev = 0, total = 0;
-    SET_HIP(hipGetDevice(&dev), "set_stream_create_cu_masked");
-    SET_HIP(hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev), "set_stream_create_cu_masked");
-    if (n_cus > total) n_cus = total;
-    uint32_t mask[16] = {0};
-    SET_REQUIRE(total <= 512, "set_stream_create_cu_masked");
-    for (int i = 0; i < n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
-    hipStream_t s = nullptr;
-    SET_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask), "set_stream_create_cu_masked");
-    *out = (void *)s;
-    return SET_OK;
-}
-
+// (Measured and dropped, round 5: a CU-masked leaf stream, hipExtStreamCreateWithCUMask with 128 - 224 of the 256 CUs, so that some CUs stay
+// free for the compute stream -- every launch on such a stream takes a slow path: 17 - 18 ms per spec_denoiser step instead of 9.8.)
 extern "C" int set_stream_create_low_priority(void **out) {
     SET_REQUIRE(out != nullptr, "set_stream_create_low_priority");
     int least = 0, greatest = 0;
