@@ -655,6 +655,9 @@ int64_t set_layernorm_ch_bwd_scratch(int32_t B, int32_t C, int32_t T);
 int set_layernorm_ch_bwd(const float *x, const float *gamma, const float *mask, const float *dy, float *dx,
                          float *dgamma, float *dbeta, float *partial, int32_t B, int32_t C, int32_t T, float eps,
                          void *stream);
+/* the same with dx = (LayerNorm gradient) + add [B][C][T]: the residual branch of a pre-LN sub-block joins inside the launch */
+int set_layernorm_ch_bwd_add(const float *x, const float *gamma, const float *mask, const float *dy, const float *add, float *dx,
+                             float *dgamma, float *dbeta, float *partial, int32_t B, int32_t C, int32_t T, float eps, void *stream);
 /* dtable[idx[b][t]][c] += scale * dout[b][c][t], except for row `padding_idx` (-1: none), whose gradient stays 0
  * as with nn.Embedding(padding_idx=...) (modules/commons/layers.py:45-50) */
 int set_embedding_bwd(const int64_t *idx, const float *dout, float *dtable, int32_t B, int32_t T, int32_t C,

@@ -298,6 +298,7 @@ SIGNATURES = {
     "set_gate_bwd": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _V]),
     "set_res_skip_bwd": (C.c_int, [_V, _V, _V, _V, _I32, _I32, _I32, _V]),
     "set_layernorm_ch_bwd": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _V, _I32, _I32, _I32, _F, _V]),
+    "set_layernorm_ch_bwd_add": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _I32, _I32, _I32, _F, _V]),
     "set_layernorm_ch_bwd_scratch": (C.c_int64, [_I32, _I32, _I32]),
     "set_embedding_bwd": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _I32, _F, _I32, _V]),
     "set_expand_states_bwd": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _I32, _V]),

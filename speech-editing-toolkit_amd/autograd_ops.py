@@ -499,10 +499,9 @@ class _PreLnFfnFn(torch.autograd.Function):
         dxl = torch.empty_like(x)
         (t_g, r_g), (t_bt, r_bt) = tgt(p_gamma), tgt(p_beta)
         part = _det_scratch(dev, L().set_layernorm_ch_bwd_scratch(B, Cc, T_in))
-        check(L().set_layernorm_ch_bwd(_p(x), _p(gamma), None, _p(dh), _p(dxl), _p(t_g), _p(t_bt), _p(part), B, Cc, T_in, float(eps), _stream()),
-              "set_layernorm_ch_bwd")
-        dx = ops.sum_div(dxl, g2)
-        return (dx, r_g, r_bt, r_w1, r_b1, r_w2, r_b2) + (None,) * 10
+        check(L().set_layernorm_ch_bwd_add(_p(x), _p(gamma), None, _p(dh), _p(g2), _p(dxl), _p(t_g), _p(t_bt), _p(part), B, Cc, T_in, float(eps),
+                                           _stream()), "set_layernorm_ch_bwd_add")  # dx = LN gradient + residual gradient, one launch
+        return (dxl, r_g, r_bt, r_w1, r_b1, r_w2, r_b2) + (None,) * 10
 
 
 def preln_ffn(x, ln, cw1, b1, cw2, b2, *, dil=1, pad=0, alpha=1.0, act="gelu", act_param=0.0, mask=None, eps=1e-5, T_out=None):
@@ -1182,9 +1181,9 @@ def _preln_tail(x, gamma, p_gamma, p_beta, dh, g2, eps):
     dxl = torch.empty_like(x)
     (t_g, r_g), (t_b, r_b) = _tape_tgt(p_gamma, x.device), _tape_tgt(p_beta, x.device)
     part = _det_scratch(x.device, L().set_layernorm_ch_bwd_scratch(B, Cc, T))
-    check(L().set_layernorm_ch_bwd(_p(x), _p(gamma), None, _p(dh), _p(dxl), _p(t_g), _p(t_b), _p(part), B, Cc, T, float(eps), _stream()),
-          "set_layernorm_ch_bwd")
-    return ops.sum_div(dxl, g2), r_g, r_b
+    check(L().set_layernorm_ch_bwd_add(_p(x), _p(gamma), None, _p(dh), _p(g2), _p(dxl), _p(t_g), _p(t_b), _p(part), B, Cc, T, float(eps),
+                                       _stream()), "set_layernorm_ch_bwd_add")  # dx = LN gradient + residual gradient, one launch
+    return dxl, r_g, r_b
 
 
 class _PreLnSelfAttnFn(torch.autograd.Function):

@@ -306,9 +306,10 @@ __device__ __forceinline__ void lnb_emit(float dg, float db, int c, int tl, floa
     }
 }
 
+// add != NULL: dx = (LayerNorm gradient) + add -- the residual branch of a pre-LN sub-block joins here instead of in a separate launch
 __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, const float *gamma, const float *mask,
                                                                const float *dy, float *dx, float *dgamma, float *dbeta,
-                                                               float *partial, int B, int C, int T, float eps) {
+                                                               float *partial, int B, int C, int T, float eps, const float *add) {
     __shared__ float red[LNB_CG][LNB_FT];
     const int tl = threadIdx.x % LNB_FT, cg = threadIdx.x / LNB_FT;
     const int b = blockIdx.y, t = blockIdx.x * LNB_FT + tl;
@@ -318,6 +319,7 @@ __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, c
     const float *xp = x + (int64_t)b * C * T + tc;
     const float *dp = dy + (int64_t)b * C * T + tc;
     float *op = dx + (int64_t)b * C * T + tc;
+    const float *ap = add ? add + (int64_t)b * C * T + tc : nullptr;
     const float m = !valid ? 0.0f : (mask ? mask[(int64_t)b * T + t] : 1.0f);  // m == 0 on the frames beyond T
     if (cq <= LNB_RC) {  // block-uniform
         float xv[LNB_RC], gv[LNB_RC], gm[LNB_RC];
@@ -352,7 +354,10 @@ __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, c
 #pragma unroll
         for (int i = 0; i < LNB_RC; ++i) {
             if (c0 + i < c1) {  // uniform per channel group
-                if (valid) op[(int64_t)(c0 + i) * T] = rstd * (gv[i] * gm[i] - s1 - xv[i] * s2);
+                if (valid) {
+                    const float gx = rstd * (gv[i] * gm[i] - s1 - xv[i] * s2);
+                    op[(int64_t)(c0 + i) * T] = ap ? gx + ap[(int64_t)(c0 + i) * T] : gx;
+                }
                 lnb_emit(gv[i] * xv[i], gv[i], c0 + i, tl, dgamma, dbeta, partial, C);
             }
         }
@@ -376,7 +381,10 @@ __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, c
     for (int c = c0; c < c1; ++c) {
         const float xh = (xp[(int64_t)c * T] - mean) * rstd;
         const float dyc = dp[(int64_t)c * T] * m;
-        if (valid) op[(int64_t)c * T] = rstd * (dyc * gamma[c] - s1 - xh * s2);
+        if (valid) {
+            const float gx = rstd * (dyc * gamma[c] - s1 - xh * s2);
+            op[(int64_t)c * T] = ap ? gx + ap[(int64_t)c * T] : gx;
+        }
         lnb_emit(dyc * xh, dyc, c, tl, dgamma, dbeta, partial, C);
     }
 }
@@ -1128,14 +1136,26 @@ extern "C" int set_res_skip_bwd(const float *dx_out, const float *dskip, float *
 extern "C" int64_t set_layernorm_ch_bwd_scratch(int32_t B, int32_t C, int32_t T) {
     return (int64_t)B * ((T + LNB_FT - 1) / LNB_FT) * 2 * C;
 }
+static int layernorm_ch_bwd_launch(const float *x, const float *gamma, const float *mask, const float *dy, float *dx, float *dgamma,
+                                   float *dbeta, float *partial, int32_t B, int32_t C, int32_t T, float eps, const float *add, void *stream);
 extern "C" int set_layernorm_ch_bwd(const float *x, const float *gamma, const float *mask, const float *dy, float *dx,
                                     float *dgamma, float *dbeta, float *partial, int32_t B, int32_t C, int32_t T,
                                     float eps, void *stream) {
+    return layernorm_ch_bwd_launch(x, gamma, mask, dy, dx, dgamma, dbeta, partial, B, C, T, eps, nullptr, stream);
+}
+extern "C" int set_layernorm_ch_bwd_add(const float *x, const float *gamma, const float *mask, const float *dy, const float *add, float *dx,
+                                        float *dgamma, float *dbeta, float *partial, int32_t B, int32_t C, int32_t T, float eps,
+                                        void *stream) {
+    SET_REQUIRE(add != nullptr, "set_layernorm_ch_bwd_add");
+    return layernorm_ch_bwd_launch(x, gamma, mask, dy, dx, dgamma, dbeta, partial, B, C, T, eps, add, stream);
+}
+static int layernorm_ch_bwd_launch(const float *x, const float *gamma, const float *mask, const float *dy, float *dx, float *dgamma,
+                                   float *dbeta, float *partial, int32_t B, int32_t C, int32_t T, float eps, const float *add, void *stream) {
     SET_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && B > 0 && C > 0 && T > 0, "set_layernorm_ch_bwd");
     SET_REQUIRE(B <= 65535, "set_layernorm_ch_bwd(B)");
     const int tiles = (T + LNB_FT - 1) / LNB_FT;
     hipLaunchKernelGGL(layernorm_ch_bwd_kernel, dim3(tiles, B), dim3(256), 0, (hipStream_t)stream,
-                       x, gamma, mask, dy, dx, dgamma, dbeta, partial, B, C, T, eps);
+                       x, gamma, mask, dy, dx, dgamma, dbeta, partial, B, C, T, eps, add);
     if (partial) {
         const int rc = set_check_launch("set_layernorm_ch_bwd");
         if (rc) return rc;
