@@ -766,7 +766,8 @@ class _EagerStep:
 
 TRAIN_PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_train.json")
 TRAIN_KERNEL_SOURCES = ["speech-editing-toolkit_amd/csrc/diffnet_bf16.hip", "speech-editing-toolkit_amd/csrc/bf16.hip",
-                        "speech-editing-toolkit_amd/csrc/common.h", "speech-editing-toolkit_amd/csrc/rows_sum.h"]
+                        "speech-editing-toolkit_amd/csrc/common.h", "speech-editing-toolkit_amd/csrc/rows_sum.h",
+                  "speech-editing-toolkit_amd/csrc/train.hip", "speech-editing-toolkit_amd/autograd_ops.py"]
 
 
 def _profiled(key, model, dtype):

@@ -11,7 +11,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ["speech-editing-toolkit_amd/csrc/diffnet_bf16.hip", "speech-editing-toolkit_amd/csrc/bf16.hip",
-                  "speech-editing-toolkit_amd/csrc/common.h", "speech-editing-toolkit_amd/csrc/rows_sum.h"]
+                  "speech-editing-toolkit_amd/csrc/common.h", "speech-editing-toolkit_amd/csrc/rows_sum.h",
+                  "speech-editing-toolkit_amd/csrc/train.hip", "speech-editing-toolkit_amd/autograd_ops.py"]
 FAMILIES = ["diffnet_layer_bwd_bf16_kernel", "diffnet_layer_fwd_bf16_kernel", "conv1d_wgrad3_bf16_kernel", "conv1d_wgrad_bf16_kernel",
             "conv1d_bf16_kernel", "conv1x1_oneshot_bf16_kernel", "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn_fwd_kernel"]
 
