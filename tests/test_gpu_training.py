@@ -725,3 +725,47 @@ def test_preln_ffn_node_equals_the_per_op_tape(dev, dtype, shape, monkeypatch):
             assert a is not None and b is not None and torch.equal(a, b)
     finally:
         ops.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("dtype,size", [("f32", "tiny"), ("bf16", "tiny"), ("bf16", "full")])
+def test_leaf_stream_updates_equal_the_single_stream_updates_bit_for_bit(dev, dtype, size, monkeypatch):
+    """Round 5: weight / bias gradients that go straight into the flat optimizer's .grad run on a second HIP stream beside the
+    chain of input-gradient kernels (autograd_ops.leaf_work), joined at the end of backward().  Same kernels, same operands, every target
+    written by one stream: two identical replicas -- one with the leaf stream, one with SET_AMD_LEAF_STREAM=0 -- must hold bit-identical
+    losses, parameters and Adam moments after every one of six updates (dropout on, different batches and seeds, warm-up moving the lr).
+    `full` is the benchmark shape (B = 32, T = 800, 20 layers: the grouped layer weight gradients really do overlap the conditioner's
+    backward there); a race between the streams, or an operand freed under a leaf kernel, would show up as a difference."""
+    from set_amd import autograd_ops as A, ops
+    from set_amd.synthetic import synthetic_inputs
+    from set_amd.training import FlatAdamW
+    ops.set_compute_dtype(dtype)
+    try:
+        reps = []
+        for _ in range(2):
+            task, W = _train_setup(dev, 8, 31) if size == "tiny" else _train_setup(dev, 8, 18)
+            task.model.train()
+            reps.append((task, FlatAdamW(task.model, lr=1e-3, warmup_updates=4, clip_grad_norm=1.0)))
+        (ta, oa), (tb, ob) = reps
+        assert torch.equal(oa.flat_p, ob.flat_p)
+        for it in range(6):
+            if size == "tiny":
+                inp = Wt.synthetic_inputs(4, 96, 24, seed=77 + it, pad_tail=True)
+                t = torch.tensor([(1 + it) % 9, 3, (5 + 2 * it) % 9, 7], device=dev)
+            else:
+                inp = synthetic_inputs(32, 800, 100, seed=1234 + it, pad_tail=True)
+                t = torch.randint(0, 9, (32,), generator=torch.Generator().manual_seed(it)).to(dev)
+            sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"],
+                          time_mel_masks=inp["time_mel_masks"].squeeze(-1).contiguous(), spk_embed=inp["spk_embed"])
+            sample = {k: v.to(dev) for k, v in sample.items()}
+            monkeypatch.setenv("SET_AMD_LEAF_STREAM", "1")
+            tot_a, parts_a, _ = ta.training_step(sample, oa, t=t, seed=500 + 13 * it)
+            used_leaf = any(st["stream"] is not None for st in A._LEAF.values())
+            monkeypatch.setenv("SET_AMD_LEAF_STREAM", "0")
+            tot_b, parts_b, _ = tb.training_step(sample, ob, t=t, seed=500 + 13 * it)
+            torch.cuda.synchronize()
+            assert torch.equal(tot_a, tot_b), it
+            assert all(torch.equal(parts_a[k], parts_b[k]) for k in parts_a), it
+            assert torch.equal(oa.flat_p, ob.flat_p) and torch.equal(oa.m, ob.m) and torch.equal(oa.v, ob.v), it
+        assert used_leaf  # (from the second update on the gradients take the direct sinks, i.e. the leaf stream)
+    finally:
+        ops.set_compute_dtype("f32")
