@@ -27,6 +27,7 @@ python tools/pmc_train_summary.py $OUT/pmc_train.json spec_denoiser_bf16 "$FS" "
 find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 cp $OUT/pmc_train.json profiles/r05_pmc_train.json   # so that the bench line below quotes it
 TILE=128 NLS=10 bash tools/sessions/gpu_pmc_bf16_layers.sh > $OUT/pmc_bf16_t128.log 2>&1; cp gpurun_out/pmc_bf16_layers_128.json $OUT/pmc_bf16_layers.json; cp $OUT/pmc_bf16_layers.json profiles/r05_pmc_bf16_layers.json
+for cfg in "spec_denoiser bf16 60" "spec_denoiser f32 20" "campnet bf16 60"; do set -- $cfg; MODEL=$1 DTYPE=$2 STEPS=$3 timeout 600 python tools/leaf_soak_probe.py 2>&1 | grep -v amdgpu.ids | tail -2; done | tee $OUT/leaf_soak.log
 T0=$(date +%s); timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -6 > $OUT/pytest_gpu.log; echo "wall $(( $(date +%s) - T0 )) s" >> $OUT/pytest_gpu.log; cat $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 > $OUT/smoke.log; cat $OUT/smoke.log
 T0=$(date +%s); timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench wall $(( $(date +%s) - T0 )) s" | tee $OUT/bench_wall.log
