@@ -1222,13 +1222,19 @@ __device__ __forceinline__ float half_sum(float v) {  // sum over the 32 lanes o
     return v;
 }
 
-__global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffnetLayerBf16BwdArgs a) {
+// NT = frames per tile: 128 (one block per CU, 133 KB of LDS) or 64 (two blocks per CU, 68 KB each, <= 128 registers: while one block waits
+// for its loads or stores the other one runs its GEMMs -- the 128-frame block alone is a chain of dependent phases at 0.27 of the HBM peak)
+template <int NT>
+__global__ void __launch_bounds__(512, NT == 128 ? 1 : 2) diffnet_layer_bwd_bf16_kernel(SetDiffnetLayerBf16BwdArgs a) {
+    constexpr int NCB = NT / 32;       // 32-frame column blocks
+    constexpr int NCG = 512 / NT;      // channel groups of the staging pass (thread = frame x channel group)
+    constexpr int CPG = 2 * FC / NCG;  // channels of d_o per staging thread
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y, T = a.T, d = a.dil;
-    const int NTc = FNT - 2 * d;
+    const int NTc = NT - 2 * d;
     const int ts = blockIdx.x * NTc - d;
     const int part_row = b * gridDim.x + blockIdx.x;
     const unsigned T4 = 4u * (unsigned)T, T2 = 2u * (unsigned)T;
@@ -1247,53 +1253,54 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffn
 
     // ---- stage d_o = [dx_out / sqrt2 ; dskip] as [frame][512] bf16 (+ its bf16 copy in HBM for the weight gradient)
     {
-        const int f = tid & 127, cg = __builtin_amdgcn_readfirstlane(tid >> 7);
+        const int f = tid % NT, cg = __builtin_amdgcn_readfirstlane(tid / NT);
         const int t = ts + f;
         const bool tv = t >= 0 && t < T;
-        const bool central = tv && f >= d && f < FNT - d;
+        const bool central = tv && f >= d && f < NT - d;
         const unsigned tc = (unsigned)min(max(t, 0), T - 1);
-        const rsrc_t rs = cg < 2 ? rdxo : rdsk;
-        const float sc = cg < 2 ? (has_dxo ? RSQRT2 : 0.0f) : 1.0f;
-        const int cs0 = 128 * (cg & 1);  // channel inside the source tensor
-        // all 128 loads of the thread in flight at once (nothing else is live yet): one memory round trip
-        float v[128];
+        const bool from_dx = cg < NCG / 2;  // the first 256 channels of d_o come from dx_out / sqrt2, the other 256 from dskip
+        const rsrc_t rs = from_dx ? rdxo : rdsk;
+        const float sc = from_dx ? (has_dxo ? RSQRT2 : 0.0f) : 1.0f;
+        const int cs0 = CPG * (cg % (NCG / 2));  // channel inside the source tensor
+        // all loads of the thread in flight at once (nothing else is live yet): one memory round trip
+        float v[CPG];
 #pragma unroll
-        for (int k = 0; k < 128; ++k) v[k] = buf_load(rs, 4u * tc, (unsigned)(cs0 + k) * T4) * sc;
+        for (int k = 0; k < CPG; ++k) v[k] = buf_load(rs, 4u * tc, (unsigned)(cs0 + k) * T4) * sc;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < CPG / 8; ++q) {
             u32x4_t u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) u[e] = tv ? pack2(v[8 * q + 2 * e], v[8 * q + 2 * e + 1]) : 0u;
-            *reinterpret_cast<u32x4_t *>(lds + (f + d) * DR + (128 * cg + 8 * q) * 2) = u;
+            *reinterpret_cast<u32x4_t *>(lds + (f + d) * DR + (CPG * cg + 8 * q) * 2) = u;
         }
         if (central) {
 #pragma unroll
-            for (int k = 0; k < 128; ++k) buf_store_u16(f2bf(v[k]), rdo, 2u * tc, (unsigned)(128 * cg + k) * T2);
+            for (int k = 0; k < CPG; ++k) buf_store_u16(f2bf(v[k]), rdo, 2u * tc, (unsigned)(CPG * cg + k) * T2);
         }
     }
     __syncthreads();
     // ---- bias gradient of the output projection: column sums of the central rows of the d_o tile (thread = channel)
     {
         float s = 0.0f;
-        for (int j = d; j < FNT - d; ++j) s += bf2f(*reinterpret_cast<const unsigned short *>(lds + (j + d) * DR + tid * 2));
+        for (int j = d; j < NT - d; ++j) s += bf2f(*reinterpret_cast<const unsigned short *>(lds + (j + d) * DR + tid * 2));
         a.part_dbo[(int64_t)part_row * 2 * FC + tid] = s;  // rows outside [0, T) were staged as zeros
     }
 
     // ---- GEMM A: dz[256 x 128] = Wout^T d_o
-    f32x16 dz[1][4];
+    f32x16 dz[1][NCB];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) dz[0][cb] = (f32x16){0};
-    gemm_bf16<1, 4>(dz, rwt2, lane16, 0, 32, lds, [&](int ks, int cb) {
+    for (int cb = 0; cb < NCB; ++cb) dz[0][cb] = (f32x16){0};
+    gemm_bf16<1, NCB>(dz, rwt2, lane16, 0, 32, lds, [&](int ks, int cb) {
         return (unsigned)((cb * 32 + l31 + d) * DR + (ks * 16 + half * 8) * 2);
     });
 
     // ---- gate derivative (lane-local), dy over the tile, dy to HBM, bias partial sums
-    bool cen[4];
-    unsigned vo4[4], vo2[4];
+    bool cen[NCB];
+    unsigned vo4[NCB], vo2[NCB];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
         const int j = cb * 32 + l31, t = ts + j;
-        cen[cb] = t >= 0 && t < T && j >= d && j < FNT - d;
+        cen[cb] = t >= 0 && t < T && j >= d && j < NT - d;
         const int tc = min(max(t, 0), T - 1);
         vo4[cb] = 4u * (unsigned)(4 * half * T + tc);
         vo2[cb] = 2u * (unsigned)(4 * half * T + tc);
@@ -1304,9 +1311,9 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffn
 #pragma unroll
         for (int r = 0; r < 16; ++r) sg[r] = sf[r] = 0.0f;
         // the saved pre-gate values of all four column blocks are fetched up front (one round trip, not four)
-        unsigned short yg[4][16], yf[4][16];
+        unsigned short yg[NCB][16], yf[NCB][16];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned ur = (unsigned)(32 * w + urow(r));
@@ -1314,7 +1321,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffn
                 yf[cb][r] = buf_load_u16(ry, vo2[cb], (ur + FC) * T2);
             }
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
+        for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned ur = (unsigned)(32 * w + urow(r));
@@ -1346,15 +1353,15 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffn
     __syncthreads();
 
     // ---- GEMM B: dxd[256 x 128] = sum_tap Wdil[tap]^T dy shifted by (1 - tap) dil ;  GEMM C (waves 0..5): dcond = Wcond^T dy
-    f32x16 dxd[1][4], dcn[1][4];
+    f32x16 dxd[1][NCB], dcn[1][NCB];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) { dxd[0][cb] = (f32x16){0}; dcn[0][cb] = (f32x16){0}; }
-    gemm_bf16<1, 4>(dxd, rwt1, lane16, 0, 96, lds, [&](int ks, int cb) {
+    for (int cb = 0; cb < NCB; ++cb) { dxd[0][cb] = (f32x16){0}; dcn[0][cb] = (f32x16){0}; }
+    gemm_bf16<1, NCB>(dxd, rwt1, lane16, 0, 96, lds, [&](int ks, int cb) {
         const int tap = ks >> 5, c0 = (ks & 31) * 16;
         return (unsigned)((cb * 32 + l31 + (2 - tap) * d) * DR + (c0 + half * 8) * 2);
     });
     if (w < 6)
-        gemm_bf16<1, 4>(dcn, rwtc, lane16, 0, 32, lds, [&](int ks, int cb) {
+        gemm_bf16<1, NCB>(dcn, rwtc, lane16, 0, 32, lds, [&](int ks, int cb) {
             return (unsigned)((cb * 32 + l31 + d) * DR + (ks * 16 + half * 8) * 2);
         });
 
@@ -1370,8 +1377,8 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffn
 #pragma unroll
         for (int r = 0; r < 16; ++r) rv[0][r] = buf_load(rdxo, vo4[0], (unsigned)(32 * w + urow(r)) * T4);
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            if (cb + 1 < 4) {
+        for (int cb = 0; cb < NCB; ++cb) {
+            if (cb + 1 < NCB) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) rv[(cb + 1) & 1][r] = buf_load(rdxo, vo4[cb + 1], (unsigned)(32 * w + urow(r)) * T4);
             }
@@ -1395,8 +1402,8 @@ __global__ void __launch_bounds__(512, 1) diffnet_layer_bwd_bf16_kernel(SetDiffn
 #pragma unroll
             for (int r = 0; r < 16; ++r) pv[0][r] = buf_load(rdc, vo4[0], (unsigned)(32 * w + urow(r)) * T4);
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                if (cb + 1 < 4) {
+            for (int cb = 0; cb < NCB; ++cb) {
+                if (cb + 1 < NCB) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) pv[(cb + 1) & 1][r] = buf_load(rdc, vo4[cb + 1], (unsigned)(32 * w + urow(r)) * T4);
                 }
@@ -1598,7 +1605,13 @@ extern "C" int set_diffnet_layers_fwd_bf16(const SetDiffnetLayersBf16Args *args,
 
 extern "C" int64_t set_sizeof_diffnet_layer_bf16_bwd_args(void) { return (int64_t)sizeof(SetDiffnetLayerBf16BwdArgs); }
 
-extern "C" int32_t set_diffnet_layer_bwd_bf16_tiles(int32_t T, int32_t dil) { return (T + (FNT - 2 * dil) - 1) / (FNT - 2 * dil); }
+// tile width of the layer backward: 128 frames (one block per CU) by default; SET_AMD_BWD_TILE=64: two blocks per CU (measurement switch,
+// read at every call -- the tile count below and the launch must agree)
+static int layer_bwd_tile() { const char *e = getenv("SET_AMD_BWD_TILE"); return (e && atoi(e) == 64) ? 64 : FNT; }
+extern "C" int32_t set_diffnet_layer_bwd_bf16_tiles(int32_t T, int32_t dil) {
+    const int nt = layer_bwd_tile();
+    return (T + (nt - 2 * dil) - 1) / (nt - 2 * dil);
+}
 
 extern "C" int set_diffnet_layer_bwd_bf16(const SetDiffnetLayerBf16BwdArgs *args, void *stream) {
     SET_REQUIRE(args != nullptr, "set_diffnet_layer_bwd_bf16");
@@ -1607,15 +1620,20 @@ extern "C" int set_diffnet_layer_bwd_bf16(const SetDiffnetLayerBf16BwdArgs *args
                 "set_diffnet_layer_bwd_bf16");
     SET_REQUIRE(a.B > 0 && a.T > 0 && a.dil >= 1 && a.dil <= 8, "set_diffnet_layer_bwd_bf16");
     SET_REQUIRE((int64_t)2 * FC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_layer_bwd_bf16 (T too large)");
-    const size_t ldsz = (size_t)(FNT + 2 * a.dil) * DR;
+    const int nt = layer_bwd_tile();
+    SET_REQUIRE(nt - 2 * a.dil >= 32, "set_diffnet_layer_bwd_bf16 (dilation too large for the tile)");
+    const size_t ldsz = (size_t)(nt + 2 * a.dil) * DR;
     static bool attr_set = false;
     if (!attr_set) {
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_bwd_bf16_kernel),
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_bwd_bf16_kernel<128>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layer bwd bf16 attr");
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_bwd_bf16_kernel<64>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "layer bwd bf16 attr");
         attr_set = true;
     }
     dim3 grid(set_diffnet_layer_bwd_bf16_tiles(a.T, a.dil), a.B);
-    hipLaunchKernelGGL(diffnet_layer_bwd_bf16_kernel, grid, dim3(512), ldsz, (hipStream_t)stream, a);
+    if (nt == 64) hipLaunchKernelGGL(diffnet_layer_bwd_bf16_kernel<64>, grid, dim3(512), ldsz, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(diffnet_layer_bwd_bf16_kernel<128>, grid, dim3(512), ldsz, (hipStream_t)stream, a);
     return set_check_launch("set_diffnet_layer_bwd_bf16");
 }
 

@@ -48,10 +48,13 @@ for it in range(steps):
                   time_mel_masks=inp["time_mel_masks"].squeeze(-1).contiguous())
     if not campnet:
         sample.update(mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"])
+    kw = {"seed": 900 + 7 * it}
+    if not campnet:  # the diffusion step ids are drawn from torch's global generator unless given: both replicas must see the same ones
+        kw["t"] = torch.randint(0, HP.hparams["timesteps"] + 1, (B,), generator=torch.Generator().manual_seed(it)).to(dev)
     os.environ["SET_AMD_LEAF_STREAM"] = "1"
-    la, pa, _ = ta.training_step(sample, oa, seed=900 + 7 * it)
+    la, pa, _ = ta.training_step(sample, oa, **kw)
     os.environ["SET_AMD_LEAF_STREAM"] = "0"
-    lb, pb, _ = tb.training_step(sample, ob, seed=900 + 7 * it)
+    lb, pb, _ = tb.training_step(sample, ob, **kw)
     torch.cuda.synchronize()
     same = torch.equal(la, lb) and all(torch.equal(pa[k], pb[k]) for k in pa) and torch.equal(oa.flat_p, ob.flat_p) and \
         torch.equal(oa.m, ob.m) and torch.equal(oa.v, ob.v)
