@@ -1222,8 +1222,10 @@ __device__ __forceinline__ float half_sum(float v) {  // sum over the 32 lanes o
     return v;
 }
 
-// NT = frames per tile: 128 (one block per CU, 133 KB of LDS) or 64 (two blocks per CU, 68 KB each, <= 128 registers: while one block waits
-// for its loads or stores the other one runs its GEMMs -- the 128-frame block alone is a chain of dependent phases at 0.27 of the HBM peak)
+// NT = frames per tile: 128 is what ships (one block per CU, 133 KB of LDS).  Measured in round 5 and not instantiated (profiles/r05_layer_bwd_probe.log):
+// NT = 64 as two blocks per CU (68 KB of LDS each, 120 registers, no spills) runs the same 86 - 88 us per launch -- the kernel is not
+// waiting for its own phases; builds without its 2-byte memory instructions (the bf16 d_o / dy stores, the y loads: 384 per lane) run 65 us,
+// and even that moves the training step by 0.15 ms only.
 template <int NT>
 __global__ void __launch_bounds__(512, NT == 128 ? 1 : 2) diffnet_layer_bwd_bf16_kernel(SetDiffnetLayerBf16BwdArgs a) {
     constexpr int NCB = NT / 32;       // 32-frame column blocks
@@ -1605,9 +1607,7 @@ extern "C" int set_diffnet_layers_fwd_bf16(const SetDiffnetLayersBf16Args *args,
 
 extern "C" int64_t set_sizeof_diffnet_layer_bf16_bwd_args(void) { return (int64_t)sizeof(SetDiffnetLayerBf16BwdArgs); }
 
-// tile width of the layer backward: 128 frames (one block per CU) by default; SET_AMD_BWD_TILE=64: two blocks per CU (measurement switch,
-// read at every call -- the tile count below and the launch must agree)
-static int layer_bwd_tile() { const char *e = getenv("SET_AMD_BWD_TILE"); return (e && atoi(e) == 64) ? 64 : FNT; }
+static int layer_bwd_tile() { return FNT; }
 extern "C" int32_t set_diffnet_layer_bwd_bf16_tiles(int32_t T, int32_t dil) {
     const int nt = layer_bwd_tile();
     return (T + (nt - 2 * dil) - 1) / (nt - 2 * dil);
@@ -1627,13 +1627,10 @@ extern "C" int set_diffnet_layer_bwd_bf16(const SetDiffnetLayerBf16BwdArgs *args
     if (!attr_set) {
         SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_bwd_bf16_kernel<128>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layer bwd bf16 attr");
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_layer_bwd_bf16_kernel<64>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "layer bwd bf16 attr");
         attr_set = true;
     }
     dim3 grid(set_diffnet_layer_bwd_bf16_tiles(a.T, a.dil), a.B);
-    if (nt == 64) hipLaunchKernelGGL(diffnet_layer_bwd_bf16_kernel<64>, grid, dim3(512), ldsz, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(diffnet_layer_bwd_bf16_kernel<128>, grid, dim3(512), ldsz, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(diffnet_layer_bwd_bf16_kernel<128>, grid, dim3(512), ldsz, (hipStream_t)stream, a);
     return set_check_launch("set_diffnet_layer_bwd_bf16");
 }
 
