@@ -825,8 +825,10 @@ def _train_dominant_kernel(args, step_fn, sample, dev, bpg):
     by_l = 4.0 * Bc * Tc * (Cin + Cout)  # fp32 activations in and out (weights are L2-resident)
     tfl = fl / (ms / n * 1e-3) / 1e12
     gbs = by_l / (ms / n * 1e-3) / 1e9
-    name = "conv1d_bf16_kernel %d->%d k=%d (B=%d, T=%d)" % (Cin, Cout, K, Bc, Tc)
-    ent = _profiled("conv1d_bf16_kernel", "campnet" if campnet else "spec_denoiser", args.dtype) or {}
+    # (csrc/bf16.hip: 1x1 convs with Cin > 32 and Cout > 64 run in conv1x1_oneshot_bf16_kernel<Cin rounded up>, the rest in conv1d_bf16_kernel)
+    family = "conv1x1_oneshot_bf16_kernel" if (K == 1 and Cin > 32 and Cout > 64) else "conv1d_bf16_kernel"
+    name = "%s %d->%d k=%d (B=%d, T=%d)" % (family, Cin, Cout, K, Bc, Tc)
+    ent = _profiled(family, "campnet" if campnet else "spec_denoiser", args.dtype) or {}
     # the bound follows the shape's arithmetic intensity against the ridge of the bf16 pipe (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B)
     hbm_bound = fl / by_l < PEAK_BF16_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
     return {"kernel": name, "launches_per_step": n / 5.0, "bound": "hbm" if hbm_bound else "mfma",
@@ -834,7 +836,7 @@ def _train_dominant_kernel(args, step_fn, sample, dev, bpg):
             "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": gbs / PEAK_HBM_GBS if hbm_bound else tfl / PEAK_BF16_MFMA_TFLOPS,
             "traffic": ent.get("traffic_bytes"), "launch_ms": ms / n, "flop_per_launch": fl, "algorithmic_bytes_per_launch": by_l,
             "mfma_TFLOPs": tfl, "hbm_GBps": gbs, "share_of_step_gpu_time": ms / 5.0,
-            "traffic_note": "PMC passes, mean over ALL conv1d_bf16_kernel launches of a step (profiles/r05_pmc_train.json)" if ent else
+            "traffic_note": "PMC passes, mean over ALL launches of this kernel family in a step, i.e. over its shapes (profiles/r05_pmc_train.json)" if ent else
                             "no PMC figure for these kernel sources"}
 
 
