@@ -67,15 +67,12 @@ def _leaf_state(dev):
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _LEAF.get(idx)
     if st is None:
-        # lowest priority: its chip-filling GEMMs yield workgroup slots to the compute stream's short kernels (SET_AMD_LEAF_PRIORITY=0: default)
-        if os.environ.get("SET_AMD_LEAF_PRIORITY", "low") != "0":
-            raw = C.c_void_p()
-            with torch.cuda.device(idx):
-                check(L().set_stream_create_low_priority(C.byref(raw)), "set_stream_create_low_priority")
-            stream = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
-        else:
-            stream = torch.cuda.Stream(device=dev)
-            raw = C.c_void_p(stream.cuda_stream)
+        # lowest priority: its chip-filling GEMMs yield workgroup slots to the compute stream's short kernels (a default-priority stream
+        # measured the same step time, profiles/r05_training_ab.log; one form kept)
+        raw = C.c_void_p()
+        with torch.cuda.device(idx):
+            check(L().set_stream_create_low_priority(C.byref(raw)), "set_stream_create_low_priority")
+        stream = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
         st = _LEAF[idx] = {"stream": stream, "raw": raw, "dirty": False, "keep": [], "idx": idx}
     return st
 
@@ -1329,7 +1326,7 @@ class _PosAddFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             pe = ops.embedding_bct(pos, table)
             prod = ops.blend_mask(torch.zeros_like(pe), pe, d.contiguous(), 1)  # pe * d elementwise
-            dalpha = _sum(prod).reshape(1)
+            dalpha = _sum(prod, arena=False).reshape(1)
         return d, dalpha, None, None
 
 
@@ -1388,8 +1385,10 @@ def frame_weights(target_btm):
     return w
 
 
-def _sum(x, w=None, inner=1):
-    out = torch.zeros(1, dtype=torch.float32, device=x.device)
+def _sum(x, w=None, inner=1, arena=True):
+    # arena: the accumulator is a slice of the step's zero arena inside an optimisation step (no fill launch) -- for values consumed within the
+    # step; a result handed to autograd as a gradient (which may keep it as .grad) owns its storage instead
+    out = _gzeros(1, x.device) if arena else torch.zeros(1, dtype=torch.float32, device=x.device)
     check(L().set_weighted_sum_det(_p(x), _p(w), _p(out), x.numel(), inner, _p(_det_scratch(x.device, 1024)), _stream()),
           "set_weighted_sum_det")
     return out
@@ -1473,7 +1472,7 @@ class _DurLossFn(torch.autograd.Function):
         dur_pred = dur_pred.contiguous()
         B, T_txt = dur_pred.shape
         T = mel2ph.shape[1]
-        sums = torch.zeros(4, dtype=torch.float32, device=dur_pred.device)
+        sums = _gzeros(4, dur_pred.device)
         check(L().set_dur_loss_sums_det(_p(dur_pred), _p(mel2ph), _p(txt), _p(word_id), _p(sums), B, T, T_txt, n_words,
                                         _p(_det_scratch(dur_pred.device, 4 * B)), _stream()), "set_dur_loss_sums_det")
         ctx.save_for_backward(dur_pred, mel2ph, txt, word_id, sums)
@@ -1511,7 +1510,7 @@ class _PitchLossFn(torch.autograd.Function):
     def forward(ctx, pp, f0, uv, mel2ph, lam_uv, lam_f0):
         pp = pp.contiguous()
         B, _, T = pp.shape
-        sums = torch.zeros(4, dtype=torch.float32, device=pp.device)
+        sums = _gzeros(4, pp.device)
         check(L().set_pitch_loss_sums_det(_p(pp), _p(f0), _p(uv), _p(mel2ph), _p(sums), B, T,
                                           _p(_det_scratch(pp.device, 4 * ((B * T + 255) // 256))), _stream()),
               "set_pitch_loss_sums_det")

@@ -7,6 +7,7 @@ import csv
 import hashlib
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,7 +40,7 @@ if __name__ == "__main__":
     out_path = sys.argv[1]
     out = {"_note": "per launch, mean over the launches of a kernel family in a few training steps at the bench shape; traffic_bytes = "
                     "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (KB counters; gfx950 reports half of wide coalesced reads); launches_per_step = "
-                    "all kernels of a rocprofv3 --kernel-trace run / its optimizer steps",
+                    "the kernels of one steady-state step of a rocprofv3 --kernel-trace run (launches_per_step_incl_setup: all kernels / optimizer steps)",
            "kernel_sources": KERNEL_SOURCES, "kernel_source_sha256": source_sha()}
     rest = sys.argv[2:]
     while rest:
@@ -54,8 +55,15 @@ if __name__ == "__main__":
         rows = list(csv.DictReader(open(stats_csv)))
         steps = next((int(r["Calls"]) for r in rows if "adamw_kernel" in r["Name"]), 0)
         if steps:
-            ent["launches_per_step"] = sum(int(r["Calls"]) for r in rows) / steps
+            ent["launches_per_step_incl_setup"] = sum(int(r["Calls"]) for r in rows) / steps  # (first-step flattening / packing launches included)
+            ent["launches_per_step"] = ent["launches_per_step_incl_setup"]
             ent["kernel_time_us_per_step"] = sum(float(r["TotalDurationUs"]) for r in rows) / steps
+        # steady state: the kernels between two optimizer launches late in the run, counted by tools/rocpd_timeline.py ("step 9: 549 kernels")
+        tl = stats_csv.replace("_kernel_stats.csv", "_timeline.log")
+        if os.path.exists(tl):
+            m = re.search(r"step \d+: (\d+) kernels", open(tl).read())
+            if m:
+                ent["launches_per_step"] = int(m.group(1))
         out[tag] = ent
     json.dump(out, open(out_path, "w"), indent=1)
     print(json.dumps(out, indent=1)[:3000])
