@@ -280,6 +280,11 @@ int64_t set_diffnet_w1p_size(void);
 int64_t set_diffnet_w2p_size(void);
 /* pack dilated_conv.weight [512][256][3] and output_projection.weight [512][256][1] (diffnet.py:63,66) */
 int set_pack_diffnet_layer(const float *w_dil, const float *w_out, float *w1p, float *w2p, void *stream);
+/* every layer of a stack in one launch per image family: layer q's weights at w_dil + q wd_ls / w_out + q wo_ls (element strides),
+ * w1p / w2p = [L][set_diffnet_w1p_size()] / [L][set_diffnet_w2p_size()]; w1w / w2w (both or neither) = the Winograd images
+ * [L][set_diffnet_w1w_size()] / [L][512 * 256] of set_pack_diffnet_layer_wino */
+int set_pack_diffnet_layers(const float *w_dil, const float *w_out, int64_t wd_ls, int64_t wo_ls, float *w1p, float *w2p,
+                            float *w1w, float *w2w, int32_t L, void *stream);
 
 /* All L residual layers of one DiffNet pass in ONE persistent launch (residual_channels == 256).
  * Up to 2 x #CU resident blocks pull (layer, tile) tasks in layer-major order from an atomic queue; a task
@@ -608,6 +613,19 @@ typedef struct SetPackBf16Desc {
 } SetPackBf16Desc;
 int64_t set_sizeof_pack_bf16_desc(void);
 int set_pack_conv_weights_bf16_batch(const SetPackBf16Desc *descs_dev, int32_t n, int64_t total, void *stream);
+/* The same for the fp32 images (training in the reference's default precision, egs/spec_denoiser.yaml:4): every image of
+ * set_pack_conv_weight (kind 0) / set_pack_conv_weight_v2 (kind 1) a step used, re-packed in ONE launch after the optimizer step.
+ * The caller sets w, wp, w_base .. w_stap, Cout, Cin, K and `start`; set_fill_pack_f32_desc (host) fills kind and the layout
+ * fields and returns the image's element count (-1: bad arguments).  The table lives on the device. */
+typedef struct SetPackF32Desc {
+    const float *w;
+    float *wp;
+    int64_t w_base, w_sco, w_sci, w_stap, start;
+    int32_t Cout, Cin, K, CinP, kind, RB, ch_max, pad_;
+} SetPackF32Desc;
+int64_t set_sizeof_pack_f32_desc(void);
+int64_t set_fill_pack_f32_desc(SetPackF32Desc *d, int32_t kind, int32_t dil);
+int set_pack_conv_weights_f32_batch(const SetPackF32Desc *descs_dev, int32_t n, int64_t total, void *stream);
 /* out[c] += sum_{b,t} x[b][c][t]   (bias gradients) */
 int set_channel_sum(const float *x, float *out, int32_t B, int32_t C, int32_t T, void *stream);
 

@@ -147,6 +147,15 @@ class SetPackBf16Desc(C.Structure):
     ]
 
 
+class SetPackF32Desc(C.Structure):
+    _fields_ = [
+        ("w", C.c_void_p), ("wp", C.c_void_p),
+        ("w_base", C.c_int64), ("w_sco", C.c_int64), ("w_sci", C.c_int64), ("w_stap", C.c_int64), ("start", C.c_int64),
+        ("Cout", C.c_int32), ("Cin", C.c_int32), ("K", C.c_int32), ("CinP", C.c_int32), ("kind", C.c_int32), ("RB", C.c_int32),
+        ("ch_max", C.c_int32), ("pad_", C.c_int32),
+    ]
+
+
 class SetBmmArgs(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
@@ -214,6 +223,7 @@ SIGNATURES = {
     "set_diffnet_w1p_size": (_I64, []),
     "set_diffnet_w2p_size": (_I64, []),
     "set_pack_diffnet_layer": (C.c_int, [_V, _V, _V, _V, _V]),
+    "set_pack_diffnet_layers": (C.c_int, [_V, _V, _I64, _I64, _V, _V, _V, _V, _I32, _V]),
     "set_diffnet_stack_variant": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "set_packed_conv_weight_x2_size": (C.c_int64, [_I32, _I32, _I32]),
     "set_pack_conv_weight_x2": (C.c_int, [_V, _V, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I32, _V]),
@@ -260,6 +270,9 @@ SIGNATURES = {
     "set_pack_conv_weight_bf16": (C.c_int, [_V, _V, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _V]),
     "set_sizeof_pack_bf16_desc": (_I64, []),
     "set_pack_conv_weights_bf16_batch": (C.c_int, [_V, _I32, _I64, _V]),
+    "set_sizeof_pack_f32_desc": (_I64, []),
+    "set_fill_pack_f32_desc": (_I64, [C.POINTER(SetPackF32Desc), _I32, _I32]),
+    "set_pack_conv_weights_f32_batch": (C.c_int, [_V, _I32, _I64, _V]),
     "set_channel_sum_det": (C.c_int, [_V, _V, _I32, _I32, _I32, _V, _V]),
     "set_weighted_sum_det": (C.c_int, [_V, _V, _V, _I64, _I64, _V, _V]),
     "set_sumsq_det": (C.c_int, [_V, _V, _I64, _V, _V]),
@@ -408,6 +421,7 @@ def lib():
     assert L.set_sizeof_resblock_pair_args() == C.sizeof(SetResblockPairArgs), "SetResblockPairArgs ABI mismatch"
     assert L.set_sizeof_attn_args() == C.sizeof(SetAttnArgs), "SetAttnArgs ABI mismatch"
     assert L.set_sizeof_pack_bf16_desc() == C.sizeof(SetPackBf16Desc), "SetPackBf16Desc ABI mismatch"
+    assert L.set_sizeof_pack_f32_desc() == C.sizeof(SetPackF32Desc), "SetPackF32Desc ABI mismatch"
     assert L.set_sizeof_attn_bwd_args() == C.sizeof(SetAttnBwdArgs), "SetAttnBwdArgs ABI mismatch"
     assert L.set_sizeof_diffnet_layer_bf16_args() == C.sizeof(SetDiffnetLayerBf16Args), "SetDiffnetLayerBf16Args ABI mismatch"
     assert L.set_sizeof_diffnet_layers_bf16_args() == C.sizeof(SetDiffnetLayersBf16Args), "SetDiffnetLayersBf16Args ABI mismatch"

@@ -38,6 +38,9 @@ static __global__ void __launch_bounds__(256) set_zero_words_kernel(unsigned *p,
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < words) p[i] = 0u;
 }
+static inline bool set_aligned16(const void *a, const void *b, const void *c) {  // 16-byte vector accesses are legal on all three
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
 static inline hipError_t set_zero_async(void *p, size_t bytes, hipStream_t s) {
     const int64_t words = (int64_t)((bytes + 3) / 4);
     hipLaunchKernelGGL(set_zero_words_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, reinterpret_cast<unsigned *>(p), words);

@@ -577,6 +577,79 @@ extern "C" int set_pack_conv_weight(const float *w, float *wp, int32_t Cout, int
     return set_check_launch("set_pack_conv_weight");
 }
 
+// every fp32 weight image a training step uses in ONE launch (after the optimizer step: ~150 pack launches of ~5 us per fp32 training
+// step otherwise -- 1.1 ms of a 32 ms step on the compute stream): element gidx of the concatenated image space -> its descriptor by
+// binary search over `start`; kind 0 = the layout of pack_conv_weight_kernel, kind 1 = pack_conv_weight_v2_kernel.  Same values, same places.
+__global__ void __launch_bounds__(256) pack_conv_weights_f32_batch_kernel(const SetPackF32Desc *d, int n, int64_t total) {
+    const int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gidx >= total) return;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (d[mid].start <= gidx) lo = mid; else hi = mid - 1;
+    }
+    const SetPackF32Desc e = d[lo];
+    const int64_t idx = gidx - e.start;
+    int co, ci, tap;
+    if (e.kind == 0) {
+        const int lane = (int)(idx & 63);
+        int64_t r = idx >> 6;
+        const int cp_total = e.CinP / 2;
+        const int cp = (int)(r % cp_total);
+        r /= cp_total;
+        tap = (int)(r % e.K);
+        const int rb = (int)(r / e.K);
+        co = rb * 32 + (lane & 31);
+        ci = 2 * cp + (lane >> 5);
+    } else {
+        const int rb = (int)(idx % e.RB);
+        const int lane = (int)((idx / e.RB) & 63);
+        int64_t r = idx / e.RB / 64;
+        const int64_t ks_total = (int64_t)e.K * (e.CinP / 2);
+        int64_t ks = r % ks_total;
+        r /= ks_total;
+        const int wv = (int)(r & 3), g = (int)(r >> 2);
+        int c0 = 0;
+        for (;;) {  // ks -> (chunk, tap, channel pair), the kernel's consumption order
+            const int CH = e.CinP - c0 < e.ch_max ? e.CinP - c0 : e.ch_max;
+            const int64_t per_chunk = (int64_t)e.K * (CH / 2);
+            if (ks < per_chunk) {
+                tap = (int)(ks / (CH / 2));
+                ci = c0 + 2 * (int)(ks % (CH / 2)) + (lane >> 5);
+                break;
+            }
+            ks -= per_chunk;
+            c0 += CH;
+        }
+        co = g * 128 * e.RB + wv * 32 * e.RB + rb * 32 + (lane & 31);
+    }
+    float v = 0.0f;
+    if (co < e.Cout && ci < e.Cin) v = e.w[e.w_base + (int64_t)co * e.w_sco + (int64_t)ci * e.w_sci + (int64_t)tap * e.w_stap];
+    e.wp[idx] = v;
+}
+extern "C" int64_t set_sizeof_pack_f32_desc(void) { return (int64_t)sizeof(SetPackF32Desc); }
+// host side: the layout parameters of an image (CinP, RB, ch_max) and its element count from Cout / Cin / K (and |dil| for kind 1)
+extern "C" int64_t set_fill_pack_f32_desc(SetPackF32Desc *d, int32_t kind, int32_t dil) {
+    if (d == nullptr || (kind != 0 && kind != 1) || d->Cout <= 0 || d->Cin <= 0 || d->K <= 0) return -1;
+    d->kind = kind;
+    if (kind == 0) {
+        d->CinP = round_up(d->Cin, KC);
+        d->RB = 1;
+        d->ch_max = 0;
+        return set_packed_conv_weight_size(d->Cout, d->Cin, d->K);
+    }
+    d->CinP = round_up(d->Cin, 16);
+    d->RB = v2_rb(d->Cout);
+    d->ch_max = v2_ch_max((d->K - 1) * (dil < 0 ? -dil : dil));
+    return set_packed_conv_weight_v2_size(d->Cout, d->Cin, d->K);
+}
+extern "C" int set_pack_conv_weights_f32_batch(const SetPackF32Desc *descs_dev, int32_t n, int64_t total, void *stream) {
+    SET_REQUIRE(descs_dev && n > 0 && total > 0, "set_pack_conv_weights_f32_batch");
+    hipLaunchKernelGGL(pack_conv_weights_f32_batch_kernel, dim3(set_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, descs_dev, n,
+                       total);
+    return set_check_launch("set_pack_conv_weights_f32_batch");
+}
+
 int set_conv1d_bf16_dispatch(const SetConv1dArgs &a, hipStream_t s);  // bf16.hip
 int set_conv1d_x2_dispatch(const SetConv1dArgs &a, hipStream_t s);    // csrc/conv_x2.hip
 

@@ -985,10 +985,15 @@ __global__ void __launch_bounds__(512, 2) diffnet_stack_wino_kernel(SetDiffnetSt
     }
 }
 
+// blockIdx.y = layer q of a stack: weights at w_dil + q wd_ls / w_out + q wo_ls (element strides), images at q * (their per-layer size)
 __global__ void __launch_bounds__(256) pack_diffnet_layer_kernel(const float *w_dil, const float *w_out, float *w1p,
-                                                                 float *w2p) {
+                                                                 float *w2p, int64_t wd_ls = 0, int64_t wo_ls = 0) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t n1 = (int64_t)4 * KS1 * 64 * 4, n2 = (int64_t)4 * KS2 * 64 * 4;
+    w_dil += (int64_t)blockIdx.y * wd_ls;
+    w_out += (int64_t)blockIdx.y * wo_ls;
+    w1p += (int64_t)blockIdx.y * n1;
+    w2p += (int64_t)blockIdx.y * n2;
     if (idx < n1) {
         const int rb = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
         const int ks = (int)((idx >> 8) % KS1), w = (int)((idx >> 8) / KS1);
@@ -1007,9 +1012,13 @@ __global__ void __launch_bounds__(256) pack_diffnet_layer_kernel(const float *w_
 // Winograd images: w1w[w][ks][lane][rf*4 + p] = G_p(Wdil[rf*256 + 32w + (lane&31)][2ks + (lane>>5)][0..2]),
 //                  w2w[w][ks][lane][rb]       = Wout[rb*256 + 32w + (lane&31)][2ks + (lane>>5)]          (8 waves)
 __global__ void __launch_bounds__(256) pack_diffnet_wino_kernel(const float *w_dil, const float *w_out, float *w1w,
-                                                                float *w2w) {
+                                                                float *w2w, int64_t wd_ls = 0, int64_t wo_ls = 0) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t n1 = (int64_t)8 * WN_KS * 64 * 8, n2 = (int64_t)8 * WN_KS * 64 * 2;
+    w_dil += (int64_t)blockIdx.y * wd_ls;  // (blockIdx.y = layer, as in pack_diffnet_layer_kernel)
+    w_out += (int64_t)blockIdx.y * wo_ls;
+    w1w += (int64_t)blockIdx.y * n1;
+    w2w += (int64_t)blockIdx.y * n2;
     if (idx < n1) {
         const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
         const int ks = (int)((idx >> 9) % WN_KS), w = (int)((idx >> 9) / WN_KS);
@@ -1042,6 +1051,26 @@ extern "C" int set_pack_diffnet_layer_wino(const float *w_dil, const float *w_ou
 extern "C" int64_t set_diffnet_w1p_size(void) { return (int64_t)512 * 768; }
 extern "C" int64_t set_diffnet_w2p_size(void) { return (int64_t)512 * 256; }
 
+// every layer of a stack in one launch per image family (the training forward re-packs all of them after each optimizer step: 2 x L
+// launches of ~5 us otherwise).  Layer q's weights at w_dil + q wd_ls / w_out + q wo_ls (the flat optimizer's layout: one stride between
+// the layers' tensors); w1p / w2p are [L][set_diffnet_w1p_size()] / [L][set_diffnet_w2p_size()], w1w / w2w (optional, both or neither) the
+// Winograd images [L][set_diffnet_w1w_size()] / [L][512 * 256].
+extern "C" int set_pack_diffnet_layers(const float *w_dil, const float *w_out, int64_t wd_ls, int64_t wo_ls, float *w1p, float *w2p,
+                                       float *w1w, float *w2w, int32_t L, void *stream) {
+    SET_REQUIRE(w_dil && w_out && w1p && w2p && L > 0 && L <= 65535 && (w1w == nullptr) == (w2w == nullptr), "set_pack_diffnet_layers");
+    SET_REQUIRE((int64_t)8 * WN_KS * 64 * 8 == set_diffnet_w1w_size() && (int64_t)8 * WN_KS * 64 * 2 == (int64_t)512 * 256 &&
+                    (int64_t)4 * KS1 * 64 * 4 == set_diffnet_w1p_size() && (int64_t)4 * KS2 * 64 * 4 == set_diffnet_w2p_size(),
+                "set_pack_diffnet_layers(image sizes)");
+    const int64_t total = set_diffnet_w1p_size() + set_diffnet_w2p_size();
+    hipLaunchKernelGGL(pack_diffnet_layer_kernel, dim3(set_blocks(total, 256), L), dim3(256), 0, (hipStream_t)stream, w_dil, w_out, w1p,
+                       w2p, wd_ls, wo_ls);
+    int rc = set_check_launch("set_pack_diffnet_layers");
+    if (rc != SET_OK || w1w == nullptr) return rc;
+    const int64_t totw = set_diffnet_w1w_size() + (int64_t)512 * 256;
+    hipLaunchKernelGGL(pack_diffnet_wino_kernel, dim3(set_blocks(totw, 256), L), dim3(256), 0, (hipStream_t)stream, w_dil, w_out, w1w,
+                       w2w, wd_ls, wo_ls);
+    return set_check_launch("set_pack_diffnet_layers(wino)");
+}
 extern "C" int set_pack_diffnet_layer(const float *w_dil, const float *w_out, float *w1p, float *w2p, void *stream) {
     SET_REQUIRE(w_dil && w_out && w1p && w2p, "set_pack_diffnet_layer");
     const int64_t total = set_diffnet_w1p_size() + set_diffnet_w2p_size();

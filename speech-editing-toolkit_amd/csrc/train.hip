@@ -260,6 +260,27 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const float *y, const flo
 }
 // forward: x_out = (x + o[:C]) / sqrt2 ; skip_out = skip_in + o[C:]
 // backward: dx = dx_out / sqrt2 ; do[:C] = dx_out / sqrt2 ; do[C:] = dskip_out
+// four consecutive elements per thread (16-byte accesses; C * T a multiple of 4, 16-byte aligned operands): the one-element form above moves
+// 131 MB in 62 us at B = 32, T = 800 (2.1 TB/s) -- 20 launches per fp32 training step.  Same arithmetic per element: same bits.
+__global__ void __launch_bounds__(256) gate_bwd_vec4_kernel(const float *y, const float *dz, float *dy, int64_t n4, int64_t ct4_per_b,
+                                                            int64_t CT) {
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= n4) return;
+    const int64_t b = i4 / ct4_per_b, ct = (i4 - b * ct4_per_b) * 4;
+    const float *yb = y + b * 2 * CT + ct;
+    float *dyb = dy + b * 2 * CT + ct;
+    const f32x4 yg = *reinterpret_cast<const f32x4 *>(yb), yf = *reinterpret_cast<const f32x4 *>(yb + CT);
+    const f32x4 d = *reinterpret_cast<const f32x4 *>(dz + i4 * 4);
+    f32x4 og, of;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float s = dev_sigmoid(yg[e]), th = tanhf(yf[e]);
+        og[e] = d[e] * th * s * (1.0f - s);
+        of[e] = d[e] * s * (1.0f - th * th);
+    }
+    *reinterpret_cast<f32x4 *>(dyb) = og;
+    *reinterpret_cast<f32x4 *>(dyb + CT) = of;
+}
 __global__ void __launch_bounds__(256) res_skip_bwd_kernel(const float *dx_out, const float *dskip, float *dx, float *d_o,
                                                            int B, int C, int T) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -270,6 +291,20 @@ __global__ void __launch_bounds__(256) res_skip_bwd_kernel(const float *dx_out, 
     float *ob = d_o + b * 2 * C * T;
     ob[ct] = v;
     ob[(int64_t)C * T + ct] = dskip[i];
+}
+__global__ void __launch_bounds__(256) res_skip_bwd_vec4_kernel(const float *dx_out, const float *dskip, float *dx, float *d_o, int64_t n4,
+                                                                int64_t ct4_per_b, int64_t CT) {
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= n4) return;
+    const int64_t b = i4 / ct4_per_b, ct = (i4 - b * ct4_per_b) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4 *>(dx_out + i4 * 4);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = g[e] / 1.41421356237309504880f;
+    *reinterpret_cast<f32x4 *>(dx + i4 * 4) = v;
+    float *ob = d_o + b * 2 * CT + ct;
+    *reinterpret_cast<f32x4 *>(ob) = v;
+    *reinterpret_cast<f32x4 *>(ob + CT) = *reinterpret_cast<const f32x4 *>(dskip + i4 * 4);
 }
 
 // ---- LayerNorm over channels, backward: block = 32 frames x 8 channel groups (as the forward kernel), column sums
@@ -1122,14 +1157,24 @@ extern "C" int set_act_bwd_scaled(const float *z, const float *dy, float *dz, in
 }
 extern "C" int set_gate_bwd(const float *y, const float *dz, float *dy, int32_t B, int32_t C, int32_t T, void *stream) {
     SET_REQUIRE(y && dz && dy && B > 0 && C > 0 && T > 0, "set_gate_bwd");
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0, (hipStream_t)stream, y,
-                       dz, dy, B, C, T);
+    const int64_t CT = (int64_t)C * T;
+    if (CT % 4 == 0 && set_aligned16(y, dz, dy))
+        hipLaunchKernelGGL(gate_bwd_vec4_kernel, dim3(set_blocks(B * CT / 4, 256)), dim3(256), 0, (hipStream_t)stream, y, dz, dy, B * CT / 4,
+                           CT / 4, CT);
+    else
+        hipLaunchKernelGGL(gate_bwd_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0, (hipStream_t)stream, y,
+                           dz, dy, B, C, T);
     return set_check_launch("set_gate_bwd");
 }
 extern "C" int set_res_skip_bwd(const float *dx_out, const float *dskip, float *dx, float *d_o, int32_t B, int32_t C,
                                 int32_t T, void *stream) {
     SET_REQUIRE(dx_out && dskip && dx && d_o && B > 0 && C > 0 && T > 0, "set_res_skip_bwd");
-    hipLaunchKernelGGL(res_skip_bwd_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0, (hipStream_t)stream,
+    const int64_t CT = (int64_t)C * T;
+    if (CT % 4 == 0 && set_aligned16(dx_out, dskip, dx) && set_aligned16(d_o, d_o, d_o))
+        hipLaunchKernelGGL(res_skip_bwd_vec4_kernel, dim3(set_blocks(B * CT / 4, 256)), dim3(256), 0, (hipStream_t)stream, dx_out, dskip, dx,
+                           d_o, B * CT / 4, CT / 4, CT);
+    else
+        hipLaunchKernelGGL(res_skip_bwd_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0, (hipStream_t)stream,
                        dx_out, dskip, dx, d_o, B, C, T);
     return set_check_launch("set_res_skip_bwd");
 }

@@ -101,17 +101,23 @@ class DiffNet(nn.Module):
         if self._packs is None or key != self._packs_key:
             w1 = torch.empty(L, 512 * 768, dtype=torch.float32, device=dev)
             w2 = torch.empty(L, 512 * 256, dtype=torch.float32, device=dev)
-            for i, l in enumerate(layers):
-                ops.pack_diffnet_layer(l.dilated_conv.weight, l.output_projection.weight, w1[i], w2[i])
+            wino = self.dilation_cycle_length <= 4  # Winograd F(2,3) images for the persistent stack kernel (d <= 8)
+            w1w = torch.empty(L, 512 * 256 * 4, dtype=torch.float32, device=dev) if wino else None
+            w2w = torch.empty(L, 512 * 256, dtype=torch.float32, device=dev) if wino else None
+            from .autograd_ops import _uniform_stride
+            wds, wos = [l.dilated_conv.weight.detach() for l in layers], [l.output_projection.weight.detach() for l in layers]
+            sd, so = _uniform_stride(wds), _uniform_stride(wos)
+            if sd is not None and so is not None and wds[0].is_cuda:  # (the flat optimizer's layout) every layer in one launch per image family
+                from . import _lib
+                _lib.check(_lib.lib().set_pack_diffnet_layers(ops._p(wds[0]), ops._p(wos[0]), sd, so, ops._p(w1), ops._p(w2), ops._p(w1w),
+                                                              ops._p(w2w), L, ops._stream()), "set_pack_diffnet_layers")
+            else:
+                for i, l in enumerate(layers):
+                    ops.pack_diffnet_layer(l.dilated_conv.weight, l.output_projection.weight, w1[i], w2[i])
+                    if wino:
+                        ops.pack_diffnet_layer_wino(wds[i], wos[i], w1w[i], w2w[i])
             bd = torch.stack([l.dilated_conv.bias for l in layers]).contiguous()
             bo = torch.stack([l.output_projection.bias for l in layers]).contiguous()
-            w1w = w2w = None
-            if self.dilation_cycle_length <= 4:  # Winograd F(2,3) images for the persistent stack kernel (d <= 8)
-                w1w = torch.empty(L, 512 * 256 * 4, dtype=torch.float32, device=dev)
-                w2w = torch.empty(L, 512 * 256, dtype=torch.float32, device=dev)
-                for i, l in enumerate(layers):
-                    ops.pack_diffnet_layer_wino(l.dilated_conv.weight.detach(), l.output_projection.weight.detach(),
-                                                w1w[i], w2w[i])
             self._packs, self._packs_key = (w1, w2, bd, bo, w1w, w2w), key
             self._packs_extra_key = None
         if not inference:

@@ -127,6 +127,7 @@ class FlatAdamW:
         ops.bump_weights_epoch()
         if ops.compute_dtype() == "bf16":
             ops.repack_bf16_images()  # every bf16 weight image in one launch (they are all stale now)
+        ops.repack_f32_images()  # and every fp32 image the step used
         return lr, sumsq
 
     # ---- checkpoint interchange with torch.optim.AdamW (the reference's optimizer, tasks/tts/speech_base.py:163-170):

@@ -769,3 +769,106 @@ def test_leaf_stream_updates_equal_the_single_stream_updates_bit_for_bit(dev, dt
         assert used_leaf  # (from the second update on the gradients take the direct sinks, i.e. the leaf stream)
     finally:
         ops.set_compute_dtype("f32")
+
+
+def test_gate_and_res_skip_backward_vector_and_scalar_forms(dev):
+    """set_gate_bwd / set_res_skip_bwd (diffnet.py:74-81 backward, fp32 per-op tape): the 16-byte form (C * T a multiple of 4, aligned operands)
+    and the one-element form (odd sizes, or an operand that starts 4 bytes off) against the closed-form gradients -- and against each other bit
+    for bit on the same data."""
+    from set_amd import _lib
+    from set_amd.ops import _p, _stream
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(31)
+    for B, C, T in ((2, 4, 8), (2, 5, 7), (3, 256, 100)):
+        y = torch.randn(B, 2 * C, T, generator=g).to(dev)
+        dz = torch.randn(B, C, T, generator=g).to(dev)
+        dxo, dsk = torch.randn(B, C, T, generator=g).to(dev), torch.randn(B, C, T, generator=g).to(dev)
+        outs = []
+        for off in (0, 1):  # off = 1: every operand starts one float into its allocation -> the one-element form
+            def shifted(t):
+                buf = torch.empty(t.numel() + 4, device=dev)
+                v = buf[off:off + t.numel()].view(t.shape)
+                v.copy_(t)
+                return v
+            yy, dd, a, b = shifted(y), shifted(dz), shifted(dxo), shifted(dsk)
+            dy, dx, do = shifted(torch.zeros_like(y)), shifted(torch.zeros_like(dz)), shifted(torch.zeros_like(y))
+            _lib.check(L.set_gate_bwd(_p(yy), _p(dd), _p(dy), B, C, T, _stream()), "set_gate_bwd")
+            _lib.check(L.set_res_skip_bwd(_p(a), _p(b), _p(dx), _p(do), B, C, T, _stream()), "set_res_skip_bwd")
+            torch.cuda.synchronize()
+            outs.append((dy.clone(), dx.clone(), do.clone()))
+        for u, v in zip(*outs):
+            assert torch.equal(u, v), (B, C, T)
+        s_, th = torch.sigmoid(y[:, :C].double()), torch.tanh(y[:, C:].double())
+        want = torch.cat([dz.double() * th * s_ * (1 - s_), dz.double() * s_ * (1 - th * th)], 1)
+        assert _rel(outs[0][0], want) < 2e-6
+        assert _rel(outs[0][1], dxo.double() / math.sqrt(2.0)) < 1e-7
+        assert _rel(outs[0][2], torch.cat([dxo.double() / math.sqrt(2.0), dsk.double()], 1)) < 1e-7
+
+
+@pytest.mark.parametrize("stack", ["per_op", "fused_stack"])
+def test_batched_fp32_image_repack_equals_the_per_image_packs(dev, monkeypatch, stack):
+    """ops.repack_f32_images / set_pack_conv_weights_f32_batch and set_pack_diffnet_layers (round 5): after an fp32 optimizer step every weight
+    image the step used has been re-packed by ONE launch (two for the DiffNet stack).  Each must equal, bit for bit, the image the
+    one-launch-per-weight entry points (set_pack_conv_weight, set_pack_conv_weight_v2, set_pack_diffnet_layer(_wino)) make of the
+    updated weight, and the next step must not pack anything again lazily."""
+    from set_amd import _lib, ops
+    from set_amd.ops import _p, _stream
+    from set_amd.training import FlatAdamW
+    if stack == "fused_stack":
+        monkeypatch.setenv("SET_AMD_WINO", "2")
+    else:
+        monkeypatch.setenv("SET_AMD_TRAIN_STACK", "0")
+    task, W = _train_setup(dev, 8, 31)
+    task.model.train()
+    opt = FlatAdamW(task.model, lr=1e-3, warmup_updates=2)
+    inp = Wt.synthetic_inputs(4, 96, 24, seed=5, pad_tail=True)
+    sample = dict(txt_tokens=inp["txt_tokens"], mels=inp["ref_mels"], mel2ph=inp["mel2ph"], f0=inp["f0"], uv=inp["uv"],
+                  time_mel_masks=inp["time_mel_masks"].squeeze(-1).contiguous(), spk_embed=inp["spk_embed"])
+    sample = {k: v.to(dev) for k, v in sample.items()}
+    for it in range(2):
+        task.training_step(sample, opt, seed=it)
+    L = _lib.lib()
+    n0 = n2 = 0
+    for cw in list(ops._F32_IMAGES):
+        w = cw.raw()
+        if w.device != dev:
+            continue
+        key = (w.data_ptr(), w._version, w.device, ops.weights_epoch())
+        if cw._packed is not None and cw._key == key:  # current for this epoch without having been asked for: the batch launch did it
+            ref = torch.empty_like(cw._packed)
+            _lib.check(L.set_pack_conv_weight(_p(w), _p(ref), cw.Cout, cw.Cin, cw.K, cw.base, cw.sco, cw.sci, cw.stap, _stream()), "pack")
+            assert torch.equal(ref, cw._packed), (cw.Cout, cw.Cin, cw.K)
+            n0 += 1
+        for slot, ent in cw._packed2.items():
+            if ent[0] == key:
+                ref = torch.empty_like(ent[1])
+                _lib.check(L.set_pack_conv_weight_v2(_p(w), _p(ref), cw.Cout, cw.Cin, cw.K, ent[2], cw.base, cw.sco, cw.sci, cw.stap,
+                                                     _stream()), "pack v2")
+                assert torch.equal(ref, ent[1]), (cw.Cout, cw.Cin, cw.K, slot)
+                n2 += 1
+    print("images current after the step: %d plain, %d big-tile" % (n0, n2))
+    assert n0 >= 20
+    # the DiffNet stack images: one launch per family against the per-layer entry points
+    net = task.model.denoise_fn if hasattr(task.model, "denoise_fn") else task.model.decoder.denoise_fn
+    packs = net.fused_packs(inference=False)
+    for i, l in enumerate(net.residual_layers):
+        w1, w2 = ops.pack_diffnet_layer(l.dilated_conv.weight.detach(), l.output_projection.weight.detach())
+        assert torch.equal(packs[0][i], w1) and torch.equal(packs[1][i], w2), i
+        if packs[4] is not None:
+            a, b = torch.empty_like(packs[4][i]), torch.empty_like(packs[5][i])
+            ops.pack_diffnet_layer_wino(l.dilated_conv.weight.detach(), l.output_projection.weight.detach(), a, b)
+            assert torch.equal(packs[4][i], a) and torch.equal(packs[5][i], b), i
+    # nothing left for the lazy path: a third step asks for the same images and finds them current
+    calls = []
+    real = L.set_pack_conv_weight
+
+    class Spy:
+        def __getattr__(self, name):
+            if name in ("set_pack_conv_weight", "set_pack_conv_weight_v2"):
+                calls.append(name)
+            return getattr(L, name)
+    monkeypatch.setattr(_lib, "lib", lambda: Spy())
+    task.training_step(sample, opt, seed=9)
+    monkeypatch.undo()
+    assert not calls, calls[:5]
+    assert real is L.set_pack_conv_weight
