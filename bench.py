@@ -459,6 +459,7 @@ def run_infer(args, rank, world, dev):
         out["e2e_b64_vocoder"] = e2e_line()
         out["train_bf16"] = train_line("spec_denoiser", "bf16")
         out["campnet_train_bf16"] = train_line("campnet", "bf16")
+        out["train_f32"] = train_line("spec_denoiser", "f32")  # the reference's default precision (egs/spec_denoiser.yaml:4), same shape as configs[1]
     return out
 
 
@@ -820,20 +821,23 @@ def _train_dominant_kernel(args, step_fn, sample, dev, bpg):
         d[0] += e0.elapsed_time(e1)
         d[1] += 1
     key, (ms, n) = max(by.items(), key=lambda kv: kv[1][0])
-    Cin, Cout, K, Bc, Tc = key
+    Cin, Cout, K, Bc, Tc, impl = key
     fl = 2.0 * Bc * Tc * Cin * Cout * K
     by_l = 4.0 * Bc * Tc * (Cin + Cout)  # fp32 activations in and out (weights are L2-resident)
     tfl = fl / (ms / n * 1e-3) / 1e12
     gbs = by_l / (ms / n * 1e-3) / 1e9
-    # (csrc/bf16.hip: 1x1 convs with Cin > 32 and Cout > 64 run in conv1x1_oneshot_bf16_kernel<Cin rounded up>, the rest in conv1d_bf16_kernel)
-    family = "conv1x1_oneshot_bf16_kernel" if (K == 1 and Cin > 32 and Cout > 64) else "conv1d_bf16_kernel"
+    if impl == "bf16":
+        # (csrc/bf16.hip: 1x1 convs with Cin > 32 and Cout > 64 run in conv1x1_oneshot_bf16_kernel<Cin rounded up>, the rest in conv1d_bf16_kernel)
+        family, peak = ("conv1x1_oneshot_bf16_kernel" if (K == 1 and Cin > 32 and Cout > 64) else "conv1d_bf16_kernel"), PEAK_BF16_MFMA_TFLOPS
+    else:  # fp32 operands on v_mfma_f32_32x32x2_f32 (csrc/conv1d.hip): the 64-row kernel or the big-tile one
+        family, peak = ("conv1d_mfma_v2_kernel" if impl == "mfma2" else "conv1d_mfma_kernel"), PEAK_F32_MFMA_TFLOPS
     name = "%s %d->%d k=%d (B=%d, T=%d)" % (family, Cin, Cout, K, Bc, Tc)
     ent = _profiled(family, "campnet" if campnet else "spec_denoiser", args.dtype) or {}
-    # the bound follows the shape's arithmetic intensity against the ridge of the bf16 pipe (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B)
-    hbm_bound = fl / by_l < PEAK_BF16_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    # the bound follows the shape's arithmetic intensity against the ridge of the pipe (bf16: 2.5 PFLOP/s / 8 TB/s = 312 FLOP/B; fp32: 19.7)
+    hbm_bound = fl / by_l < peak * 1e12 / (PEAK_HBM_GBS * 1e9)
     return {"kernel": name, "launches_per_step": n / 5.0, "bound": "hbm" if hbm_bound else "mfma",
-            "achieved": gbs if hbm_bound else tfl, "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_MFMA_TFLOPS,
-            "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": gbs / PEAK_HBM_GBS if hbm_bound else tfl / PEAK_BF16_MFMA_TFLOPS,
+            "achieved": gbs if hbm_bound else tfl, "peak": PEAK_HBM_GBS if hbm_bound else peak,
+            "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": gbs / PEAK_HBM_GBS if hbm_bound else tfl / peak,
             "traffic": ent.get("traffic_bytes"), "launch_ms": ms / n, "flop_per_launch": fl, "algorithmic_bytes_per_launch": by_l,
             "mfma_TFLOPs": tfl, "hbm_GBps": gbs, "share_of_step_gpu_time": ms / 5.0,
             "traffic_note": "PMC passes, mean over ALL launches of this kernel family in a step, i.e. over its shapes (profiles/r05_pmc_train.json)" if ent else

@@ -596,6 +596,12 @@ int set_step_proj_fwd(const float *h, const float *w, int64_t w_ls, const float 
 int64_t set_step_proj_bwd_scratch_floats(int32_t L, int32_t C, int32_t N);
 int set_step_proj_bwd(const float *h, const float *g, const float *w, int64_t w_ls, float *dh, float *dw, int64_t dw_ls, float *db,
                       int64_t db_ls, float *scratch, int32_t L, int32_t C, int32_t N, void *stream);
+/* its two halves on their own (set_step_proj_bwd = _dh then _dw): dh feeds the backward chain, dW / db are parameter gradients
+ * the host side may launch on its second stream */
+int set_step_proj_bwd_dh(const float *g, const float *w, int64_t w_ls, float *dh, float *scratch, int32_t L, int32_t C, int32_t N,
+                         void *stream);
+int set_step_proj_bwd_dw(const float *h, const float *g, float *dw, int64_t dw_ls, float *db, int64_t db_ls, int32_t L, int32_t C,
+                         int32_t N, void *stream);
 
 /* bf16 weight image for SET_IMPL_BF16: wp[tap][chunk][row][32] bf16, row < Cout rounded up to 128, chunk < ceil(Cin/32),
  * zero padded; ..._size returns the number of bf16 ELEMENTS (2 bytes each). */

@@ -300,6 +300,8 @@ SIGNATURES = {
     "set_step_proj_fwd": (C.c_int, [_V, _V, _I64, _V, _I64, _V, _I32, _I32, _I32, _V]),
     "set_step_proj_bwd_scratch_floats": (_I64, [_I32, _I32, _I32]),
     "set_step_proj_bwd": (C.c_int, [_V, _V, _V, _I64, _V, _V, _I64, _V, _I64, _V, _I32, _I32, _I32, _V]),
+    "set_step_proj_bwd_dh": (C.c_int, [_V, _V, _I64, _V, _V, _I32, _I32, _I32, _V]),
+    "set_step_proj_bwd_dw": (C.c_int, [_V, _V, _V, _I64, _V, _I64, _I32, _I32, _I32, _V]),
     "set_diffnet_layer_bwd_reduce": (C.c_int, [_V, _V, _V, _I32, _I32, _V, _V, _V, _V, _I64, _V]),
     "set_diffnet_layers_bwd_reduce": (C.c_int, [_V, _V, _V, _I32, _I32, _I32, _V, _I64, _V, _I64, _V, _I64, _V, _I64, _I64, _V]),
     "set_channel_sum": (C.c_int, [_V, _V, _I32, _I32, _I32, _V]),

@@ -524,6 +524,7 @@ class _EmbeddingFn(torch.autograd.Function):
             out = ops.embedding_bct(idx, table, scale=scale, out=base.detach().clone(), accumulate=True)
         ctx.save_for_backward(idx)
         ctx.cfg = (tuple(table.shape), scale, base is not None)
+        ctx.tparam = table
         return out
 
     @staticmethod
@@ -532,13 +533,15 @@ class _EmbeddingFn(torch.autograd.Function):
         (n_rows, Cc), scale, has_base = ctx.cfg
         dout = dout.contiguous()
         B, T = idx.shape
-        dtab = _gzeros((n_rows, Cc), dout.device)
+        sink, _ = grad_sink(ctx.tparam)  # (a table that is a parameter used once: its gradient goes straight into .grad, on the leaf stream)
+        dtab = sink if sink is not None else _gzeros((n_rows, Cc), dout.device)
         # ordered scatter (no atomics): gradient rows transposed to [B][T][C], per-(utterance, segment) partial tables
         doutT = ops.bct_to_btc(dout)
         S = L().set_scatter_rows_segments(T)
-        check(L().set_scatter_rows_det(_p(idx), _p(doutT), _p(dtab), B, T, Cc, n_rows, float(scale), ctx.padding_idx, 0,
-                                       _p(_det_scratch(dout.device, B * S * n_rows * Cc)), _stream()), "set_scatter_rows_det")
-        return None, dtab, (dout if has_base else None), None, None
+        with leaf_work(dout.device, sink is not None, dout, doutT, idx):
+            check(L().set_scatter_rows_det(_p(idx), _p(doutT), _p(dtab), B, T, Cc, n_rows, float(scale), ctx.padding_idx, 0,
+                                           _p(_det_scratch(dout.device, B * S * n_rows * Cc)), _stream()), "set_scatter_rows_det")
+        return None, (None if sink is not None else dtab), (dout if has_base else None), None, None
 
 
 def embedding_bct(idx, table, scale=1.0, out=None, accumulate=False, padding_idx=None):
@@ -1021,8 +1024,11 @@ class _StepProjFn(torch.autograd.Function):
         p_b, s_b, r_b = _grouped_targets(list(bs), dev)
         dh = torch.empty_like(h)
         scratch = _det_scratch(dev, L().set_step_proj_bwd_scratch_floats(L_, Cc, N))
-        check(L().set_step_proj_bwd(_p(h), _p(g), _p(ws[0]), ctx.w_ls, _p(dh), C.c_void_p(p_w), s_w, C.c_void_p(p_b), s_b, _p(scratch),
-                                    L_, Cc, N, _stream()), "set_step_proj_bwd")
+        check(L().set_step_proj_bwd_dh(_p(g), _p(ws[0]), ctx.w_ls, _p(dh), _p(scratch), L_, Cc, N, _stream()), "set_step_proj_bwd_dh")
+        sinks = all(r is None for r in r_w) and all(r is None for r in r_b)  # every dW / db goes straight into the flat gradient buffer
+        with leaf_work(dev, sinks, h, g):
+            check(L().set_step_proj_bwd_dw(_p(h), _p(g), C.c_void_p(p_w), s_w, C.c_void_p(p_b), s_b, L_, Cc, N, _stream()),
+                  "set_step_proj_bwd_dw")
         return (dh, None, None, *r_w, *r_b)
 
 

@@ -1029,19 +1029,30 @@ extern "C" int set_step_proj_fwd(const float *h, const float *w, int64_t w_ls, c
 
 extern "C" int64_t set_step_proj_bwd_scratch_floats(int32_t L, int32_t C, int32_t N) { return (int64_t)L * (C / 64) * C * N; }
 
+// the two halves of set_step_proj_bwd as entry points of their own: the input gradient feeds the chain of backward kernels, the weight /
+// bias gradients are parameter gradients nothing reads before the optimizer -- the host side launches them on its second stream
+extern "C" int set_step_proj_bwd_dh(const float *g, const float *w, int64_t w_ls, float *dh, float *scratch, int32_t L, int32_t C, int32_t N,
+                                    void *stream) {
+    SET_REQUIRE(g && w && dh && scratch && L > 0 && C > 0 && N > 0, "set_step_proj_bwd_dh");
+    if (C % 64 != 0 || N > SP_NMAX) return set_fail(SET_E_UNSUPPORTED, "set_step_proj_bwd_dh", "needs C % 64 == 0, N <= 64");
+    hipLaunchKernelGGL(step_proj_bwd_dh_kernel, dim3(C / 64, L, C / 64), dim3(256), 0, (hipStream_t)stream, g, w, w_ls, scratch, L, C, N);
+    const int rc = set_check_launch("set_step_proj_bwd_dh");
+    return rc ? rc : set_partial_rows_sum(scratch, dh, 1, L * (C / 64), C * N, 0, 1.0f, stream);  // dh = sum of the partials, in (l, quarter) order
+}
+extern "C" int set_step_proj_bwd_dw(const float *h, const float *g, float *dw, int64_t dw_ls, float *db, int64_t db_ls, int32_t L, int32_t C,
+                                    int32_t N, void *stream) {
+    SET_REQUIRE(h && g && dw && db && L > 0 && C > 0 && N > 0, "set_step_proj_bwd_dw");
+    if (C % 64 != 0 || N > SP_NMAX) return set_fail(SET_E_UNSUPPORTED, "set_step_proj_bwd_dw", "needs C % 64 == 0, N <= 64");
+    hipStream_t s = (hipStream_t)stream;
+    if (N <= 32) hipLaunchKernelGGL(step_proj_bwd_dw_kernel<32>, dim3(L, C / 16), dim3(256), 0, s, h, g, dw, dw_ls, db, db_ls, L, C, N);
+    else hipLaunchKernelGGL(step_proj_bwd_dw_kernel<64>, dim3(L, C / 16), dim3(256), 0, s, h, g, dw, dw_ls, db, db_ls, L, C, N);
+    return set_check_launch("set_step_proj_bwd_dw");
+}
 extern "C" int set_step_proj_bwd(const float *h, const float *g, const float *w, int64_t w_ls, float *dh, float *dw, int64_t dw_ls,
                                  float *db, int64_t db_ls, float *scratch, int32_t L, int32_t C, int32_t N, void *stream) {
     SET_REQUIRE(h && g && w && dh && dw && db && scratch && L > 0 && C > 0 && N > 0, "set_step_proj_bwd");
-    if (C % 64 != 0 || N > SP_NMAX) return set_fail(SET_E_UNSUPPORTED, "set_step_proj_bwd", "needs C % 64 == 0, N <= 64");
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(step_proj_bwd_dh_kernel, dim3(C / 64, L, C / 64), dim3(256), 0, s, g, w, w_ls, scratch, L, C, N);
-    int rc = set_check_launch("set_step_proj_bwd(dh)");
-    if (rc) return rc;
-    rc = set_partial_rows_sum(scratch, dh, 1, L * (C / 64), C * N, 0, 1.0f, stream);  // dh = sum of the partials, in (l, quarter) order
-    if (rc) return rc;
-    if (N <= 32) hipLaunchKernelGGL(step_proj_bwd_dw_kernel<32>, dim3(L, C / 16), dim3(256), 0, s, h, g, dw, dw_ls, db, db_ls, L, C, N);
-    else hipLaunchKernelGGL(step_proj_bwd_dw_kernel<64>, dim3(L, C / 16), dim3(256), 0, s, h, g, dw, dw_ls, db, db_ls, L, C, N);
-    return set_check_launch("set_step_proj_bwd(dw)");
+    const int rc = set_step_proj_bwd_dh(g, w, w_ls, dh, scratch, L, C, N, stream);
+    return rc ? rc : set_step_proj_bwd_dw(h, g, dw, dw_ls, db, db_ls, L, C, N, stream);
 }
 
 // Deterministic variants: per-block partial results in `scratch`, combined in block order by set_partial_rows_sum.

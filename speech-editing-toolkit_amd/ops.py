@@ -413,18 +413,18 @@ def conv1d(x, weight, bias=None, *, dil=1, pad=0, pro="none", pro_param=0.0, act
     a.pro_param, a.act_param, a.alpha = float(pro_param), float(act_param), float(alpha)
     a.out_div = float(out_div)
     assert not (out_div and not accumulate)
-    if CONV_EVENTS is not None and impl == "bf16":  # measurement hook (bench.py): hipEvents around every bf16 conv launch, keyed by shape
+    if CONV_EVENTS is not None and impl in ("bf16", "mfma", "mfma2"):  # measurement hook (bench.py): hipEvents around every MFMA conv launch, keyed by shape
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(_lib.lib().set_conv1d(C.byref(a), _stream()), "set_conv1d")
         e1.record()
-        CONV_EVENTS.append(((Cin, weight.Cout, weight.K, B, T_iter), e0, e1))
+        CONV_EVENTS.append(((Cin, weight.Cout, weight.K, B, T_iter, impl), e0, e1))
         return out
     check(_lib.lib().set_conv1d(C.byref(a), _stream()), "set_conv1d")
     return out
 
 
-CONV_EVENTS = None  # bench.py sets a list: ((Cin, Cout, K, B, T), start, end) per bf16 conv launch of the timed steps
+CONV_EVENTS = None  # bench.py sets a list: ((Cin, Cout, K, B, T, impl), start, end) per bf16 / fp32 MFMA conv launch of the timed steps
 
 
 def resblock_pair_eligible(C, K, dil, T):
