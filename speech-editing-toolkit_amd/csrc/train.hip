@@ -314,21 +314,29 @@ __global__ void __launch_bounds__(256) res_skip_bwd_vec4_kernel(const float *dx_
 //      or, without scratch, one atomic per (block, channel): every block hits the same 2C addresses, and same-address
 //      device-scope atomics from different XCDs serialise at ~0.7 us each (measured: 416 blocks -> 280 us for 80 MB
 //      of traffic), hence the scratch path.
-constexpr int LNB_FT = 32, LNB_CG = 8, LNB_RC = 32;
-__device__ __forceinline__ float lnb_block_sum(float v, float (*red)[LNB_FT], int cg, int tl) {
+// Two block shapes (template): 32 frames x 8 channel groups (<= 32 channels per thread in registers, 256 VGPRs) for C > 256, and -- round 5 --
+// 16 frames x 16 channel groups (<= 16 per thread, 148 VGPRs, three blocks per SIMD) for C <= 256: twice the blocks (CampNet B = 16, T = 800:
+// 400 wide blocks on 256 CUs = two rounds, the second 56 % full; the conditioner's text-level LayerNorms: 128 blocks), and the residual
+// gradient `add` fetched with x and dy instead of in the store loop (a second exposed memory round trip per block).  Alone on the GPU
+// (tools/ln_bwd_probe.py, profiles/r05_ln_bwd_probe.log; both launches of a call): B=16 C=256 T=800 32.6 -> 31.0 us, B=32 C=192 T=100
+// 19.8 -> 11.7 us, B=32 C=192 T=800 48.7 -> 39.4 us.  Still 2 TB/s: 64-byte row segments per lane group; an LDS-staged tile is the next step.
+constexpr int LNB_FT = 32;  // frames per block of the wide shape (the scratch size and the fallback loop are written for it)
+template <int FT, int CG>
+__device__ __forceinline__ float lnb_block_sum(float v, float (*red)[FT], int cg, int tl) {
     __syncthreads();
     red[cg][tl] = v;
     __syncthreads();
     float s = 0.0f;
 #pragma unroll
-    for (int g = 0; g < LNB_CG; ++g) s += red[g][tl];
+    for (int g = 0; g < CG; ++g) s += red[g][tl];
     return s;
 }
+template <int FT>
 __device__ __forceinline__ void lnb_emit(float dg, float db, int c, int tl, float *dgamma, float *dbeta, float *partial,
                                          int C) {
-    // sum over the 32 frames of this channel group (half a wave: xor offsets stay inside the half)
+    // sum over the FT frames of this channel group (FT consecutive lanes: xor offsets stay inside the group)
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) { dg += __shfl_xor(dg, off); db += __shfl_xor(db, off); }
+    for (int off = FT / 2; off > 0; off >>= 1) { dg += __shfl_xor(dg, off); db += __shfl_xor(db, off); }
     if (tl == 0) {
         if (partial) {
             float *row = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
@@ -342,68 +350,76 @@ __device__ __forceinline__ void lnb_emit(float dg, float db, int c, int tl, floa
 }
 
 // add != NULL: dx = (LayerNorm gradient) + add -- the residual branch of a pre-LN sub-block joins here instead of in a separate launch
+template <int FT, int CG, int RC>
 __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, const float *gamma, const float *mask,
                                                                const float *dy, float *dx, float *dgamma, float *dbeta,
                                                                float *partial, int B, int C, int T, float eps, const float *add) {
-    __shared__ float red[LNB_CG][LNB_FT];
-    const int tl = threadIdx.x % LNB_FT, cg = threadIdx.x / LNB_FT;
-    const int b = blockIdx.y, t = blockIdx.x * LNB_FT + tl;
+    static_assert(FT * CG == 256, "one thread per (frame, channel group)");
+    __shared__ float red[CG][FT];
+    const int tl = threadIdx.x % FT, cg = threadIdx.x / FT;
+    const int b = blockIdx.y, t = blockIdx.x * FT + tl;
     const bool valid = t < T;
     const int tc = valid ? t : T - 1;
-    const int cq = (C + LNB_CG - 1) / LNB_CG, c0 = cg * cq, c1 = min(C, c0 + cq);
+    const int cq = (C + CG - 1) / CG, c0 = cg * cq, c1 = min(C, c0 + cq);
     const float *xp = x + (int64_t)b * C * T + tc;
     const float *dp = dy + (int64_t)b * C * T + tc;
     float *op = dx + (int64_t)b * C * T + tc;
     const float *ap = add ? add + (int64_t)b * C * T + tc : nullptr;
     const float m = !valid ? 0.0f : (mask ? mask[(int64_t)b * T + t] : 1.0f);  // m == 0 on the frames beyond T
-    if (cq <= LNB_RC) {  // block-uniform
-        float xv[LNB_RC], gv[LNB_RC], gm[LNB_RC];
+    if (cq <= RC) {  // block-uniform
+        constexpr bool PREF = RC <= 16;  // the residual gradient rides with x and dy when the registers allow (32 more made the wide shape slower)
+        float xv[RC], gv[RC], gm[RC], av[PREF ? RC : 1];
 #pragma unroll
-        for (int i = 0; i < LNB_RC; ++i) xv[i] = xp[(int64_t)min(c0 + i, C - 1) * T];
+        for (int i = 0; i < RC; ++i) xv[i] = xp[(int64_t)min(c0 + i, C - 1) * T];
 #pragma unroll
-        for (int i = 0; i < LNB_RC; ++i) gv[i] = dp[(int64_t)min(c0 + i, C - 1) * T];
+        for (int i = 0; i < RC; ++i) gv[i] = dp[(int64_t)min(c0 + i, C - 1) * T];
+        if constexpr (PREF) {
 #pragma unroll
-        for (int i = 0; i < LNB_RC; ++i) gm[i] = gamma[min(c0 + i, C - 1)];
+            for (int i = 0; i < RC; ++i) av[i] = ap ? ap[(int64_t)min(c0 + i, C - 1) * T] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < RC; ++i) gm[i] = gamma[min(c0 + i, C - 1)];
         float s = 0.0f;
 #pragma unroll
-        for (int i = 0; i < LNB_RC; ++i) s += c0 + i < c1 ? xv[i] : 0.0f;
-        const float mean = lnb_block_sum(s, red, cg, tl) / (float)C;
+        for (int i = 0; i < RC; ++i) s += c0 + i < c1 ? xv[i] : 0.0f;
+        const float mean = lnb_block_sum<FT, CG>(s, red, cg, tl) / (float)C;
         float q = 0.0f;
 #pragma unroll
-        for (int i = 0; i < LNB_RC; ++i) {
+        for (int i = 0; i < RC; ++i) {
             const float d = c0 + i < c1 ? xv[i] - mean : 0.0f;
             q = fmaf(d, d, q);
         }
-        const float rstd = 1.0f / sqrtf(lnb_block_sum(q, red, cg, tl) / (float)C + eps);
+        const float rstd = 1.0f / sqrtf(lnb_block_sum<FT, CG>(q, red, cg, tl) / (float)C + eps);
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < LNB_RC; ++i) {
+        for (int i = 0; i < RC; ++i) {
             xv[i] = (xv[i] - mean) * rstd;                 // x-hat
             gv[i] = c0 + i < c1 ? gv[i] * m : 0.0f;        // masked dy (0 for the channels this thread does not own)
             const float g = gv[i] * gm[i];
             s1 += g;
             s2 = fmaf(g, xv[i], s2);
         }
-        s1 = lnb_block_sum(s1, red, cg, tl) / (float)C;
-        s2 = lnb_block_sum(s2, red, cg, tl) / (float)C;
+        s1 = lnb_block_sum<FT, CG>(s1, red, cg, tl) / (float)C;
+        s2 = lnb_block_sum<FT, CG>(s2, red, cg, tl) / (float)C;
 #pragma unroll
-        for (int i = 0; i < LNB_RC; ++i) {
+        for (int i = 0; i < RC; ++i) {
             if (c0 + i < c1) {  // uniform per channel group
                 if (valid) {
                     const float gx = rstd * (gv[i] * gm[i] - s1 - xv[i] * s2);
-                    op[(int64_t)(c0 + i) * T] = ap ? gx + ap[(int64_t)(c0 + i) * T] : gx;
+                    if constexpr (PREF) op[(int64_t)(c0 + i) * T] = ap ? gx + av[i] : gx;
+                    else op[(int64_t)(c0 + i) * T] = ap ? gx + ap[(int64_t)(c0 + i) * T] : gx;
                 }
-                lnb_emit(gv[i] * xv[i], gv[i], c0 + i, tl, dgamma, dbeta, partial, C);
+                lnb_emit<FT>(gv[i] * xv[i], gv[i], c0 + i, tl, dgamma, dbeta, partial, C);
             }
         }
         return;
     }
     float s = 0.0f;
     for (int c = c0; c < c1; ++c) s += xp[(int64_t)c * T];
-    const float mean = lnb_block_sum(s, red, cg, tl) / (float)C;
+    const float mean = lnb_block_sum<FT, CG>(s, red, cg, tl) / (float)C;
     float q = 0.0f;
     for (int c = c0; c < c1; ++c) { const float d = xp[(int64_t)c * T] - mean; q = fmaf(d, d, q); }
-    const float rstd = 1.0f / sqrtf(lnb_block_sum(q, red, cg, tl) / (float)C + eps);
+    const float rstd = 1.0f / sqrtf(lnb_block_sum<FT, CG>(q, red, cg, tl) / (float)C + eps);
     float s1 = 0.0f, s2 = 0.0f;
     for (int c = c0; c < c1; ++c) {
         const float xh = (xp[(int64_t)c * T] - mean) * rstd;
@@ -411,8 +427,8 @@ __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, c
         s1 += g;
         s2 = fmaf(g, xh, s2);
     }
-    s1 = lnb_block_sum(s1, red, cg, tl) / (float)C;
-    s2 = lnb_block_sum(s2, red, cg, tl) / (float)C;
+    s1 = lnb_block_sum<FT, CG>(s1, red, cg, tl) / (float)C;
+    s2 = lnb_block_sum<FT, CG>(s2, red, cg, tl) / (float)C;
     for (int c = c0; c < c1; ++c) {
         const float xh = (xp[(int64_t)c * T] - mean) * rstd;
         const float dyc = dp[(int64_t)c * T] * m;
@@ -420,7 +436,7 @@ __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, c
             const float gx = rstd * (dyc * gamma[c] - s1 - xh * s2);
             op[(int64_t)c * T] = ap ? gx + ap[(int64_t)c * T] : gx;
         }
-        lnb_emit(dyc * xh, dyc, c, tl, dgamma, dbeta, partial, C);
+        lnb_emit<FT>(dyc * xh, dyc, c, tl, dgamma, dbeta, partial, C);
     }
 }
 // out[j] += sum_r partial[r][j], j < n (= 2C: dgamma then dbeta); block = 64 columns x ROWS_RG row groups (rows_sum.h)
@@ -1190,7 +1206,7 @@ extern "C" int set_res_skip_bwd(const float *dx_out, const float *dskip, float *
     return set_check_launch("set_res_skip_bwd");
 }
 extern "C" int64_t set_layernorm_ch_bwd_scratch(int32_t B, int32_t C, int32_t T) {
-    return (int64_t)B * ((T + LNB_FT - 1) / LNB_FT) * 2 * C;
+    return (int64_t)B * ((T + 15) / 16) * 2 * C;  // one row of 2 C partial sums per block; the 16-frame block shape has the most blocks
 }
 static int layernorm_ch_bwd_launch(const float *x, const float *gamma, const float *mask, const float *dy, float *dx, float *dgamma,
                                    float *dbeta, float *partial, int32_t B, int32_t C, int32_t T, float eps, const float *add, void *stream);
@@ -1209,9 +1225,15 @@ static int layernorm_ch_bwd_launch(const float *x, const float *gamma, const flo
                                    float *dbeta, float *partial, int32_t B, int32_t C, int32_t T, float eps, const float *add, void *stream) {
     SET_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && B > 0 && C > 0 && T > 0, "set_layernorm_ch_bwd");
     SET_REQUIRE(B <= 65535, "set_layernorm_ch_bwd(B)");
-    const int tiles = (T + LNB_FT - 1) / LNB_FT;
-    hipLaunchKernelGGL(layernorm_ch_bwd_kernel, dim3(tiles, B), dim3(256), 0, (hipStream_t)stream,
-                       x, gamma, mask, dy, dx, dgamma, dbeta, partial, B, C, T, eps, add);
+    // narrow blocks (16 frames x 16 channel groups) whenever the channels fit their registers: faster at every shape measured
+    const bool narrow = C <= 256;
+    const int tiles = narrow ? (T + 15) / 16 : (T + LNB_FT - 1) / LNB_FT;
+    if (narrow)
+        hipLaunchKernelGGL((layernorm_ch_bwd_kernel<16, 16, 16>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream,
+                           x, gamma, mask, dy, dx, dgamma, dbeta, partial, B, C, T, eps, add);
+    else
+        hipLaunchKernelGGL((layernorm_ch_bwd_kernel<32, 8, 32>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream,
+                           x, gamma, mask, dy, dx, dgamma, dbeta, partial, B, C, T, eps, add);
     if (partial) {
         const int rc = set_check_launch("set_layernorm_ch_bwd");
         if (rc) return rc;
