@@ -11,9 +11,9 @@ pmc() {  # tag model counter
   (cd /tmp && timeout 300 rocprofv3 --pmc $3 --kernel-trace --output-format csv -d "$R/$OUT/pmc_$1_$3" -o pmc -- python "$R/bench.py" --mode train --model $2 --dtype bf16 --steps 3 --warmup 2 > "$R/$OUT/pmc_$1_$3.log" 2>&1)
   find $OUT/pmc_$1_$3 -name "*counter_collection.csv" | head -1
 }
-stats() {  # tag model
+stats() {  # tag model [dtype]
   rm -rf $OUT/prof
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$R/$OUT/prof" -o t -- python "$R/bench.py" --mode train --model $2 --dtype bf16 --steps 10 --warmup 3 > "$R/$OUT/rocprof_$1.log" 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$R/$OUT/prof" -o t -- python "$R/bench.py" --mode train --model $2 --dtype ${3:-bf16} --steps 10 --warmup 3 > "$R/$OUT/rocprof_$1.log" 2>&1)
   local db=$(find $OUT/prof -name "*.db" | head -1)
   python tools/rocpd_summary.py $db $OUT/$1_kernel_stats.csv > /dev/null 2>&1
   python tools/rocpd_timeline.py $db $OUT/$1_timeline.csv 2>&1 | grep -v "kernels columns" | tee $OUT/$1_timeline.log
@@ -21,6 +21,7 @@ stats() {  # tag model
 }
 stats train_bf16 spec_denoiser
 stats campnet_bf16 campnet
+stats train_f32 spec_denoiser f32
 FS=$(pmc spec spec_denoiser FETCH_SIZE); WS=$(pmc spec spec_denoiser WRITE_SIZE)
 FC=$(pmc camp campnet FETCH_SIZE); WC=$(pmc camp campnet WRITE_SIZE)
 python tools/pmc_train_summary.py $OUT/pmc_train.json spec_denoiser_bf16 "$FS" "$WS" $OUT/train_bf16_kernel_stats.csv campnet_bf16 "$FC" "$WC" $OUT/campnet_bf16_kernel_stats.csv | head -60
@@ -37,7 +38,7 @@ d = json.loads([l for l in open("gpurun_out/r05/bench.json") if l.startswith("{"
 print("headline %.0f frames/s, %.2f ms/step, launch %.3f ms, frac %.3f (alg %.3f), traffic %s" % (d["value"], d["ms_per_step"], d["roofline"]["launch_ms"], d["roofline"]["frac"], d["roofline"]["frac_algorithmic"], d["roofline"]["traffic"]))
 for k in ("bf16_operand_loop", "native_fp32_loop", "bf16x3_operand_loop"):
     if k in d: print(k, d[k]["value"], d[k].get("roofline", {}).get("frac"))
-for k in ("train_bf16", "campnet_train_bf16"):
+for k in ("train_bf16", "campnet_train_bf16", "train_f32"):
     print(k, json.dumps(d.get(k))[:700])
 print("e2e", d.get("e2e_b64_vocoder"))
 print("cpu", d["cpu_baseline"]["value"], d["speedup_vs_cpu_baseline"])
