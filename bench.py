@@ -366,9 +366,9 @@ def run_infer(args, rank, world, dev):
     # WRITE_SIZE per MI355X_MICROARCH.md).  Counters cannot be collected inside this process, so the figure is the one measured
     # on the SAME kernel sources: the file carries their sha256 and the figure is withheld (null) when the sources changed since.
     traffic, traffic_note, pmc = None, None, None
-    tfile = os.path.join(ROOT, "profiles", "r04_pmc_x3.json")
+    tfile = os.path.join(ROOT, "profiles", "r05_pmc_x3.json")
     if not os.path.exists(tfile):
-        tfile = os.path.join(ROOT, "profiles", "r03_pmc_x3.json")
+        tfile = os.path.join(ROOT, "profiles", "r04_pmc_x3.json")
     tname = os.path.relpath(tfile, ROOT)
     if os.path.exists(tfile) and persistent and variant in (4, 5):
         import hashlib
