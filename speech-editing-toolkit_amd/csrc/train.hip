@@ -314,12 +314,11 @@ __global__ void __launch_bounds__(256) res_skip_bwd_vec4_kernel(const float *dx_
 //      or, without scratch, one atomic per (block, channel): every block hits the same 2C addresses, and same-address
 //      device-scope atomics from different XCDs serialise at ~0.7 us each (measured: 416 blocks -> 280 us for 80 MB
 //      of traffic), hence the scratch path.
-// Two block shapes (template): 32 frames x 8 channel groups (<= 32 channels per thread in registers, 256 VGPRs) for C > 256, and -- round 5 --
-// 16 frames x 16 channel groups (<= 16 per thread, 148 VGPRs, three blocks per SIMD) for C <= 256: twice the blocks (CampNet B = 16, T = 800:
-// 400 wide blocks on 256 CUs = two rounds, the second 56 % full; the conditioner's text-level LayerNorms: 128 blocks), and the residual
-// gradient `add` fetched with x and dy instead of in the store loop (a second exposed memory round trip per block).  Alone on the GPU
-// (tools/ln_bwd_probe.py, profiles/r05_ln_bwd_probe.log; both launches of a call): B=16 C=256 T=800 32.6 -> 31.0 us, B=32 C=192 T=100
-// 19.8 -> 11.7 us, B=32 C=192 T=800 48.7 -> 39.4 us.  Still 2 TB/s: 64-byte row segments per lane group; an LDS-staged tile is the next step.
+// Three block shapes (template FT frames x CG channel groups, RC channels per thread in registers): 32 x 8 (C > 256), 16 x 16 in 256 threads
+// and 32 x 16 in 512 threads (C <= 256; the launch function picks by grid size).  Round 5: the 16-group shapes (twice the blocks of the
+// 32 x 8 one, which left CampNet's B = 16, T = 800 at 400 blocks = two rounds on 256 CUs), the residual gradient `add` fetched with x and dy
+// instead of in the store loop (a second exposed memory round trip per block), raw-buffer addressing (one per-lane offset + wave-uniform row
+// offsets: 148 -> 96 registers, the 64-bit address per load was the rest).  Still ~2.4 TB/s at the large shapes.
 constexpr int LNB_FT = 32;  // frames per block of the wide shape (the scratch size and the fallback loop are written for it)
 template <int FT, int CG>
 __device__ __forceinline__ float lnb_block_sum(float v, float (*red)[FT], int cg, int tl) {
@@ -351,10 +350,10 @@ __device__ __forceinline__ void lnb_emit(float dg, float db, int c, int tl, floa
 
 // add != NULL: dx = (LayerNorm gradient) + add -- the residual branch of a pre-LN sub-block joins here instead of in a separate launch
 template <int FT, int CG, int RC>
-__global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, const float *gamma, const float *mask,
+__global__ void __launch_bounds__(FT * CG) layernorm_ch_bwd_kernel(const float *x, const float *gamma, const float *mask,
                                                                const float *dy, float *dx, float *dgamma, float *dbeta,
                                                                float *partial, int B, int C, int T, float eps, const float *add) {
-    static_assert(FT * CG == 256, "one thread per (frame, channel group)");
+    static_assert(FT * CG == 256 || FT * CG == 512, "one thread per (frame, channel group)");
     __shared__ float red[CG][FT];
     const int tl = threadIdx.x % FT, cg = threadIdx.x / FT;
     const int b = blockIdx.y, t = blockIdx.x * FT + tl;
@@ -368,14 +367,19 @@ __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, c
     const float m = !valid ? 0.0f : (mask ? mask[(int64_t)b * T + t] : 1.0f);  // m == 0 on the frames beyond T
     if (cq <= RC) {  // block-uniform
         constexpr bool PREF = RC <= 16;  // the residual gradient rides with x and dy when the registers allow (32 more made the wide shape slower)
+        // raw-buffer addressing: one per-lane byte offset (first owned channel row, frame) + a wave-uniform row offset per channel; rows
+        // beyond C are not fetched (per-lane offset out of range: the buffer unit returns 0) -- no 64-bit address per load
+        const rsrc_t rx = make_rsrc(x + (int64_t)b * C * T), rdy = make_rsrc(dy + (int64_t)b * C * T);
+        const rsrc_t radd = make_rsrc(add ? add + (int64_t)b * C * T : x), rdx = make_rsrc(dx + (int64_t)b * C * T);
+        const unsigned vb = (unsigned)(c0 * T + tc) * 4u, T4 = (unsigned)T * 4u;
         float xv[RC], gv[RC], gm[RC], av[PREF ? RC : 1];
 #pragma unroll
-        for (int i = 0; i < RC; ++i) xv[i] = xp[(int64_t)min(c0 + i, C - 1) * T];
+        for (int i = 0; i < RC; ++i) xv[i] = buf_load(rx, c0 + i < C ? vb : BUF_OOB, (unsigned)i * T4);
 #pragma unroll
-        for (int i = 0; i < RC; ++i) gv[i] = dp[(int64_t)min(c0 + i, C - 1) * T];
+        for (int i = 0; i < RC; ++i) gv[i] = buf_load(rdy, c0 + i < C ? vb : BUF_OOB, (unsigned)i * T4);
         if constexpr (PREF) {
 #pragma unroll
-            for (int i = 0; i < RC; ++i) av[i] = ap ? ap[(int64_t)min(c0 + i, C - 1) * T] : 0.0f;
+            for (int i = 0; i < RC; ++i) av[i] = buf_load(radd, (add && c0 + i < C) ? vb : BUF_OOB, (unsigned)i * T4);
         }
 #pragma unroll
         for (int i = 0; i < RC; ++i) gm[i] = gamma[min(c0 + i, C - 1)];
@@ -404,11 +408,11 @@ __global__ void __launch_bounds__(256) layernorm_ch_bwd_kernel(const float *x, c
 #pragma unroll
         for (int i = 0; i < RC; ++i) {
             if (c0 + i < c1) {  // uniform per channel group
-                if (valid) {
-                    const float gx = rstd * (gv[i] * gm[i] - s1 - xv[i] * s2);
-                    if constexpr (PREF) op[(int64_t)(c0 + i) * T] = ap ? gx + av[i] : gx;
-                    else op[(int64_t)(c0 + i) * T] = ap ? gx + ap[(int64_t)(c0 + i) * T] : gx;
-                }
+                const float gx = rstd * (gv[i] * gm[i] - s1 - xv[i] * s2);
+                float o;
+                if constexpr (PREF) o = add ? gx + av[i] : gx;
+                else o = add ? gx + buf_load(radd, valid ? vb : BUF_OOB, (unsigned)i * T4) : gx;
+                buf_store(o, rdx, valid ? vb : BUF_OOB, (unsigned)i * T4);  // frames beyond T: offset out of range, dropped
                 lnb_emit<FT>(gv[i] * xv[i], gv[i], c0 + i, tl, dgamma, dbeta, partial, C);
             }
         }
@@ -1225,10 +1229,23 @@ static int layernorm_ch_bwd_launch(const float *x, const float *gamma, const flo
                                    float *dbeta, float *partial, int32_t B, int32_t C, int32_t T, float eps, const float *add, void *stream) {
     SET_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && B > 0 && C > 0 && T > 0, "set_layernorm_ch_bwd");
     SET_REQUIRE(B <= 65535, "set_layernorm_ch_bwd(B)");
-    // narrow blocks (16 frames x 16 channel groups) whenever the channels fit their registers: faster at every shape measured
-    const bool narrow = C <= 256;
-    const int tiles = narrow ? (T + 15) / 16 : (T + LNB_FT - 1) / LNB_FT;
-    if (narrow)
+    SET_REQUIRE((int64_t)(C + 32) * T * 4 < ((int64_t)1 << 31), "set_layernorm_ch_bwd (one utterance exceeds the 2 GiB of a buffer offset)");
+    // C <= 256: 16 channel groups (<= 16 channels per thread in registers).  32-frame tiles in 512-thread blocks (128-byte row segments, two
+    // blocks per CU) once they fill the chip; 16-frame tiles in 256-thread blocks for the small launches (the conditioner's text level:
+    // 128 -> 224 blocks).  C > 256: 8 groups of <= 32 channels.  Alone on the GPU, both launches of a call (profiles/r05_ln_bwd_probe.log):
+    // B=16 C=256 T=800 32.6 -> 22.1 us, B=32 C=192 T=800 48.7 -> 31.0 us, B=32 C=192 T=100 19.8 -> 11.0 us.
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    const int t32 = (T + LNB_FT - 1) / LNB_FT;
+    const bool groups16 = C <= 256, big = groups16 && (int64_t)B * t32 >= n_cu;
+    const int tiles = (groups16 && !big) ? (T + 15) / 16 : t32;
+    if (big)
+        hipLaunchKernelGGL((layernorm_ch_bwd_kernel<32, 16, 16>), dim3(tiles, B), dim3(512), 0, (hipStream_t)stream,
+                           x, gamma, mask, dy, dx, dgamma, dbeta, partial, B, C, T, eps, add);
+    else if (groups16)
         hipLaunchKernelGGL((layernorm_ch_bwd_kernel<16, 16, 16>), dim3(tiles, B), dim3(256), 0, (hipStream_t)stream,
                            x, gamma, mask, dy, dx, dgamma, dbeta, partial, B, C, T, eps, add);
     else
