@@ -573,24 +573,39 @@ struct SsimArgs {
     int B, H, W;
 };
 __constant__ float c_gauss[11];
+// Round 5: 16 x 16 output pixels per block from a 26 x 26 LDS tile of (pixel + bias) values (0 outside the image) instead of 121 x 2 global
+// loads per pixel (150 us per launch at B = 32, T = 800, M = 80: two launches per loss on the compute stream).  Same taps in the same order, the
+// same skipped (out-of-image) taps, the same fmaf chain per accumulator: bit-identical to the per-pixel gather it replaces.
+constexpr int SS_T = 16, SS_H = 5, SS_R = SS_T + 2 * SS_H, SS_LD = SS_R + 1;  // tile, halo, tile rows incl. halo, padded LDS row
 __global__ void __launch_bounds__(256) ssim_filter_kernel(SsimArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)a.B * a.H * a.W) return;
-    const int x = (int)(i % a.W), y = (int)((i / a.W) % a.H), b = (int)(i / ((int64_t)a.W * a.H));
+    __shared__ float us[SS_R][SS_LD], vs[SS_R][SS_LD];
+    const int b = blockIdx.z, x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     const float *p1 = a.img1 + (int64_t)b * a.H * a.W, *p2 = a.img2 + (int64_t)b * a.H * a.W;
+    for (int k = threadIdx.x; k < SS_R * SS_R; k += 256) {
+        const int ly = k / SS_R, lx = k - ly * SS_R;
+        const int yy = y0 - SS_H + ly, xx = x0 - SS_H + lx;
+        const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        us[ly][lx] = in ? p1[(int64_t)yy * a.W + xx] + a.bias : 0.0f;
+        vs[ly][lx] = in ? p2[(int64_t)yy * a.W + xx] + a.bias : 0.0f;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & (SS_T - 1), ty = threadIdx.x >> 4;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= a.W || y >= a.H) return;
+    // no range tests on the taps: an out-of-image cell of the tile holds +0, and fmaf(w, +0, acc) returns acc bit for bit (the accumulators
+    // start at +0 and (+0) + (+-0) = +0 in round-to-nearest, so not even the sign of a zero can differ from skipping the tap)
     float m1 = 0, m2 = 0, q11 = 0, q22 = 0, q12 = 0;
+#pragma unroll
     for (int dy = -5; dy <= 5; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= a.H) continue;
+#pragma unroll
         for (int dx = -5; dx <= 5; ++dx) {
-            const int xx = x + dx;
-            if (xx < 0 || xx >= a.W) continue;
             const float wgt = c_gauss[dy + 5] * c_gauss[dx + 5];
-            const float u = p1[(int64_t)yy * a.W + xx] + a.bias, v = p2[(int64_t)yy * a.W + xx] + a.bias;
+            const float u = us[ty + dy + SS_H][tx + dx + SS_H], v = vs[ty + dy + SS_H][tx + dx + SS_H];
             m1 = fmaf(wgt, u, m1); m2 = fmaf(wgt, v, m2);
             q11 = fmaf(wgt, u * u, q11); q22 = fmaf(wgt, v * v, q22); q12 = fmaf(wgt, u * v, q12);
         }
     }
+    const int64_t i = ((int64_t)b * a.H + y) * a.W + x;
     a.mu1[i] = m1; a.mu2[i] = m2; a.s11[i] = q11; a.s22[i] = q22; a.s12[i] = q12;
 }
 // per pixel: ssim value (-> one_minus) and the partials of ssim w.r.t. (mu1, E[x^2], E[xy])
@@ -618,22 +633,34 @@ __global__ void __launch_bounds__(256) ssim_map_kernel(const float *mu1, const f
 __global__ void __launch_bounds__(256) ssim_bwd_kernel(const float *img1, const float *img2, const float *gm,
                                                        const float *g11, const float *g12, float *dimg1, int B, int H,
                                                        int W, float bias) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)B * H * W) return;
-    const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((int64_t)W * H));
+    __shared__ float t0[SS_R][SS_LD], t1[SS_R][SS_LD], t2[SS_R][SS_LD];  // tiles of the three upstream maps (as ssim_filter_kernel)
+    const int b = blockIdx.z, x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     const int64_t base = (int64_t)b * H * W;
+    for (int k = threadIdx.x; k < SS_R * SS_R; k += 256) {
+        const int ly = k / SS_R, lx = k - ly * SS_R;
+        const int yy = y0 - SS_H + ly, xx = x0 - SS_H + lx;
+        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const int64_t j = base + (int64_t)(in ? yy : 0) * W + (in ? xx : 0);
+        t0[ly][lx] = in ? gm[j] : 0.0f;
+        t1[ly][lx] = in ? g11[j] : 0.0f;
+        t2[ly][lx] = in ? g12[j] : 0.0f;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & (SS_T - 1), ty = threadIdx.x >> 4;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= W || y >= H) return;
     float a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
     for (int dy = -5; dy <= 5; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= H) continue;
-        for (int dx = -5; dx <= 5; ++dx) {
-            const int xx = x + dx;
-            if (xx < 0 || xx >= W) continue;
+#pragma unroll
+        for (int dx = -5; dx <= 5; ++dx) {  // (no range tests: see ssim_filter_kernel)
             const float wgt = c_gauss[dy + 5] * c_gauss[dx + 5];
-            const int64_t j = base + (int64_t)yy * W + xx;
-            a0 = fmaf(wgt, gm[j], a0); a1 = fmaf(wgt, g11[j], a1); a2 = fmaf(wgt, g12[j], a2);
+            a0 = fmaf(wgt, t0[ty + dy + SS_H][tx + dx + SS_H], a0);
+            a1 = fmaf(wgt, t1[ty + dy + SS_H][tx + dx + SS_H], a1);
+            a2 = fmaf(wgt, t2[ty + dy + SS_H][tx + dx + SS_H], a2);
         }
     }
+    const int64_t i = base + (int64_t)y * W + x;
     dimg1[i] = a0 + 2.0f * (img1[i] + bias) * a1 + (img2[i] + bias) * a2;
 }
 
@@ -1321,7 +1348,8 @@ extern "C" int set_ssim_filter(const float *img1, const float *img2, float bias,
     int rc = ssim_upload_window();
     if (rc != SET_OK) return rc;
     SsimArgs a = {img1, img2, bias, mu1, mu2, s11, s22, s12, B, H, W};
-    hipLaunchKernelGGL(ssim_filter_kernel, dim3(set_blocks((int64_t)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    SET_REQUIRE(B <= 65535 && (H + SS_T - 1) / SS_T <= 65535, "set_ssim_filter(grid)");
+    hipLaunchKernelGGL(ssim_filter_kernel, dim3((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, B), dim3(256), 0, (hipStream_t)stream, a);
     return set_check_launch("set_ssim_filter");
 }
 extern "C" int set_ssim_map(const float *mu1, const float *mu2, const float *s11, const float *s22, const float *s12,
@@ -1336,7 +1364,8 @@ extern "C" int set_ssim_bwd(const float *img1, const float *img2, float bias, co
     SET_REQUIRE(img1 && img2 && gm && g11 && g12 && dimg1 && B > 0 && H > 0 && W > 0, "set_ssim_bwd");
     int rc = ssim_upload_window();
     if (rc != SET_OK) return rc;
-    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(set_blocks((int64_t)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, img1,
+    SET_REQUIRE(B <= 65535 && (H + SS_T - 1) / SS_T <= 65535, "set_ssim_bwd(grid)");
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, B), dim3(256), 0, (hipStream_t)stream, img1,
                        img2, gm, g11, g12, dimg1, B, H, W, bias);
     return set_check_launch("set_ssim_bwd");
 }
