@@ -468,3 +468,45 @@ def test_concurrent_cold_builds_compile_once_and_never_expose_a_partial_library(
     assert sorted(r[2] for r in res) == [0, 0, 0, 3]                 # ONE builder ran 2 compiles + 1 link, three waited
     left = [f for f in os.listdir(os.path.dirname(lib)) if ".tmp." in f]
     assert not left, left
+
+
+def test_conv_weight_lookup_follows_the_owner_through_module_tables_and_plain_attributes():
+    """ops.ConvWeight resolves (owner, "a.b.weight") at every use (so that a deepcopy of the model computes with its own parameters); round 5
+    walks the owning modules' `_modules` / `_parameters` tables instead of nn.Module.__getattr__ -- same object as getattr in every case:
+    nested modules, a parameter replaced after construction, a parametrized (weight-norm) weight that is a property, a plain object, and a
+    deep copy."""
+    import copy
+    import torch
+    from set_amd import ops
+
+    class Inner(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Conv1d(3, 5, 3)
+
+    class Owner(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.inner = Inner()
+            self.lin = torch.nn.Linear(4, 2)
+            self.cw = ops.ConvWeight((self, "inner.conv.weight"), 5, 3, 3)
+
+    o = Owner()
+    assert o.cw._resolve() is o.inner.conv.weight
+    o.inner.conv.weight = torch.nn.Parameter(torch.zeros(5, 3, 3))  # a new Parameter object under the same name
+    assert o.cw._resolve() is o.inner.conv.weight
+    o2 = copy.deepcopy(o)
+    assert o2.cw._resolve() is o2.inner.conv.weight and o2.cw._resolve() is not o.inner.conv.weight
+    wn = torch.nn.utils.parametrizations.weight_norm(torch.nn.Conv1d(3, 5, 3))
+    holder = torch.nn.Module()
+    holder.c = wn
+    got = ops.ConvWeight((holder, "c.weight"), 5, 3, 3)._resolve()  # `weight` is a parametrization property here, not an entry of _parameters
+    assert torch.equal(got, wn.weight)
+
+    class Plain:
+        pass
+    q = Plain()
+    q.w = torch.zeros(2)
+    assert ops.ConvWeight((q, "w"), 1, 1, 1)._resolve() is q.w
+    t = torch.ones(3)
+    assert ops.ConvWeight(t, 1, 1, 1)._resolve() is t and ops.ConvWeight(lambda: t, 1, 1, 1)._resolve() is t
