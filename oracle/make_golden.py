@@ -476,9 +476,18 @@ def main():
     # real-length V1: 56,320 output samples, many tiles per stage, every dilation x kernel halo crosses tile borders
     hifigan_case("hifigan_v1_long", Wt.HIFIGAN_V1, B=1, T=220, wseed=23, iseed=204, manifest="hifigan_v1")
     hifigan_v23_cases()
+    ragged_cases(hp)
     edit_cases(hp)
     nopitch_cases(hp)
     normal_cases(hp)
+
+
+def ragged_cases(hp):
+    """Round 5: a whole-model case whose sizes are multiples of nothing -- T = 77 frames, T_txt = 19 tokens, three utterances with padded tails
+    of different lengths, the full 20-layer stack: every other full-model fixture has T in {48, 64, 80, 96}."""
+    base = dict(residual_layers=20, residual_channels=256, dilation_cycle_length=1)
+    hp.update(base)
+    infer_case(hp, "infer_ragged", B=3, T=77, T_txt=19, steps=3, wseed=19, iseed=109, pad_tail=True, overrides=base, keep_steps=(0, 2))
 
 
 def nopitch_cases(hp):
