@@ -322,6 +322,7 @@ def test_fused_layer_matches_golden_layer_trace(dev):
 # ----------------------------------------------------------------------------------------------------
 FULL = [("infer_tiny", "spec_denoiser", {}), ("infer_pad", "spec_denoiser", {}),
         ("infer_ragged", "spec_denoiser", {}),  # round 5: T = 77, T_txt = 19, three padded tails -- sizes that are multiples of nothing
+        ("infer_short", "spec_denoiser", {}),   # round 5: T = 7, T_txt = 3 -- shorter than every tile, halo and MFMA threshold
         ("infer_predpitch", "spec_denoiser", {}), ("infer_drift100", "spec_denoiser", {}),
         ("infer_dil", "spec_denoiser_dil", {}), ("infer_c64", "spec_denoiser_c64", {}),
         ("infer_nopitch", "spec_denoiser_nopitch", {}),  # egs/spec_denoiser_libritts.yaml: use_pitch_embed false
@@ -639,7 +640,7 @@ def test_x3_stack_worker_counts_agree_bit_for_bit(dev, monkeypatch, x3_mode):
 
 
 @pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
-@pytest.mark.parametrize("case", ["infer_tiny", "infer_pad", "infer_ragged", "infer_drift100", "infer_dil"])
+@pytest.mark.parametrize("case", ["infer_tiny", "infer_pad", "infer_ragged", "infer_short", "infer_drift100", "infer_dil"])
 def test_full_inference_matches_reference_with_split_operand_kernel_forced(dev, monkeypatch, case, split):
     """The parity bar (|dmel| < 1e-4 against the reference's output, 100-step drift case included) with every DiffNet
     stack pass on the split-operand kernel (these small batches would otherwise take the row-split fp32 kernel)."""
@@ -858,7 +859,7 @@ def test_winograd_stack_soak_is_bit_stable(dev, monkeypatch):
     assert n_runs == 88
 
 
-@pytest.mark.parametrize("case", ["infer_tiny", "infer_pad", "infer_ragged", "infer_drift100", "infer_dil"])
+@pytest.mark.parametrize("case", ["infer_tiny", "infer_pad", "infer_ragged", "infer_short", "infer_drift100", "infer_dil"])
 def test_full_inference_matches_reference_with_winograd_forced(dev, monkeypatch, case):
     """The parity bar (|dmel| < 1e-4 against the reference's output) with every DiffNet stack pass on the Winograd
     kernel (small batches would otherwise use the direct kernel)."""

@@ -11,7 +11,7 @@ from oracle import weights as Wt
 torch.set_grad_enabled(False)
 TOL = 2e-5
 
-INFER = [("infer_tiny", "spec_denoiser"), ("infer_pad", "spec_denoiser"), ("infer_ragged", "spec_denoiser"), ("infer_predpitch", "spec_denoiser"),
+INFER = [("infer_tiny", "spec_denoiser"), ("infer_pad", "spec_denoiser"), ("infer_ragged", "spec_denoiser"), ("infer_short", "spec_denoiser"), ("infer_predpitch", "spec_denoiser"),
          ("infer_dil", "spec_denoiser_dil"), ("infer_c64", "spec_denoiser_c64"), ("infer_drift100", "spec_denoiser"),
          ("infer_nopitch", "spec_denoiser_nopitch"),  # egs/spec_denoiser_libritts.yaml: use_pitch_embed false
          ("infer_normal", "spec_denoiser_normal")]    # egs/spec_denoiser_wo_masked_predictor.yaml
