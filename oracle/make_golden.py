@@ -490,6 +490,8 @@ def ragged_cases(hp):
     infer_case(hp, "infer_ragged", B=3, T=77, T_txt=19, steps=3, wseed=19, iseed=109, pad_tail=True, overrides=base, keep_steps=(0, 2))
     # and one shorter than every tile, halo and the 16-frame threshold of the MFMA convs: 7 frames, 3 tokens
     infer_case(hp, "infer_short", B=2, T=7, T_txt=3, steps=2, wseed=20, iseed=110, pad_tail=True, overrides=base, keep_steps=(0, 1))
+    # training at the ragged sizes: losses + every gradient (weight gradients whose frame rows are not 16-byte aligned, LayerNorm / SSIM tile edges)
+    train_loss_case(hp, "train_losses_ragged", B=3, T=77, T_txt=19, steps=8, wseed=24, iseed=112)
 
 
 def nopitch_cases(hp):

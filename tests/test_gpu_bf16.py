@@ -236,11 +236,11 @@ def test_deterministic_wgrad_is_bit_stable_and_matches_the_atomic_kernel(dev, dt
     assert _rel(outs[0], ref) < tol
 
 
-def _run_training_golden(dev, dtype, monkeypatch, fused=False):
+def _run_training_golden(dev, dtype, monkeypatch, fused=False, fixture="train_losses"):
     from set_amd import hparams as H, ops, tasks
     # fused=False: one differentiable kernel per op for both operand types; True: the fused bf16 layer kernels
     monkeypatch.setenv("SET_AMD_TRAIN_STACK", "1" if fused else "0")
-    g = load_golden("train_losses")
+    g = load_golden(fixture)
     m = g["meta"]
     H.hparams.clear()
     H.hparams.update(base_hparams(timesteps=m["steps"]))
@@ -266,14 +266,15 @@ def _run_training_golden(dev, dtype, monkeypatch, fused=False):
     return g, {k: float(v) for k, v in losses.items()}, out["mel_out_bct"].detach().transpose(1, 2).cpu(), grads
 
 
+@pytest.mark.parametrize("fixture", ["train_losses", "train_losses_ragged"])
 @pytest.mark.parametrize("layers", ["per_op", "fused_layers"])
-def test_training_golden_within_the_bf16_tolerance(dev, monkeypatch, layers):
+def test_training_golden_within_the_bf16_tolerance(dev, monkeypatch, layers, fixture):
     """The reference-generated training golden under bf16 operands: every loss within BF16_LOSS_REL of the reference's
     value, mel_out within BF16_MEL_MCD (mel-level MCD) of the fp32 path's, every parameter gradient within
     BF16_GRAD_REL / BF16_GRAD_COS of the fp32 path's.  `fused_layers`: the DiffNet layers through the fused bf16 forward /
     backward kernels (what a training run uses); `per_op`: one kernel per op."""
-    g, l32, mel32, g32 = _run_training_golden(dev, "f32", monkeypatch)
-    _, l16, mel16, g16 = _run_training_golden(dev, "bf16", monkeypatch, fused=(layers == "fused_layers"))
+    g, l32, mel32, g32 = _run_training_golden(dev, "f32", monkeypatch, fixture=fixture)
+    _, l16, mel16, g16 = _run_training_golden(dev, "bf16", monkeypatch, fused=(layers == "fused_layers"), fixture=fixture)
     for k in ("l1_coarse", "ssim_coarse", "pdur", "wdur", "uv", "f0"):
         ref = float(g["loss_" + k])
         assert abs(l32[k] - ref) < 2e-5 * max(1.0, abs(ref))                    # the fp32 leg is the parity path

@@ -250,16 +250,18 @@ def _train_setup(dev, steps, wseed, over=None, manifest="spec_denoiser", task_cl
     return task, W
 
 
+@pytest.mark.parametrize("fixture", ["train_losses", "train_losses_ragged"])
 @pytest.mark.parametrize("stack", ["per_op", "fused_stack"])
-def test_training_losses_and_all_gradients_match_reference(dev, monkeypatch, stack):
+def test_training_losses_and_all_gradients_match_reference(dev, monkeypatch, stack, fixture):
     """tests/golden/train_losses.npz: the reference's own model + loss functions + autograd (oracle/make_golden.py).
     `fused_stack`: the DiffNet layers run as one persistent Winograd launch with saved activations and the
-    hand-ordered backward (what large batches use); `per_op`: one differentiable kernel per op."""
+    hand-ordered backward (what large batches use); `per_op`: one differentiable kernel per op.
+    `train_losses_ragged` (round 5): B = 3, T = 77, T_txt = 19 with padded tails -- sizes that are multiples of nothing."""
     if stack == "fused_stack":
         monkeypatch.setenv("SET_AMD_WINO", "2")       # tiny batch: force the kernel choice the big batches get
     else:
         monkeypatch.setenv("SET_AMD_TRAIN_STACK", "0")
-    g = load_golden("train_losses")
+    g = load_golden(fixture)
     m = g["meta"]
     task, W = _train_setup(dev, m["steps"], m["wseed"])
     inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=True)

@@ -60,7 +60,7 @@ def test_oracle_train_branch():
     assert np.abs(ret["mel_out"].numpy() - g["mel_out"]).max() < TOL
 
 
-@pytest.mark.parametrize("case,manifest", [("train_losses", "spec_denoiser"),
+@pytest.mark.parametrize("case,manifest", [("train_losses", "spec_denoiser"), ("train_losses_ragged", "spec_denoiser"),
                                            ("train_losses_nopitch", "spec_denoiser_nopitch"),
                                            ("train_losses_normal", "spec_denoiser_normal")])
 def test_oracle_training_losses_and_grads(case, manifest):
