@@ -94,9 +94,42 @@ def _cpu_steps(O, W, tab, cond, n_timed, seed=0, gpu_model=None):
     return sum(times[1:]) / n_timed, parity
 
 
-def _cpu_mp_worker(rank, W, cond, threads, barrier, q):
-    """One of P concurrent CPU processes (all host cores busy): 1 warm-up + 2 timed steps on its own 4 utterances."""
+def host_cores():
+    """What this process may really use: the affinity set (cpuset) and, when the container runs under a CFS quota, the quota in cores --
+    os.cpu_count() sees neither (round-5 review: 256 "cpus" whose 32-process leg ran 5 x slower than one 16-thread process)."""
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = list(range(os.cpu_count() or 1))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            a, b = f.read().split()
+            quota = None if a == "max" else float(a) / float(b)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                a, b = float(f.read()), float(g.read())
+                quota = None if a <= 0 else a / b
+        except (OSError, ValueError):
+            pass
+    usable = len(aff) if quota is None else max(1, min(len(aff), int(quota)))
+    return {"os_cpu_count": os.cpu_count() or 1, "affinity": aff, "cgroup_quota_cores": quota, "usable": usable}
+
+
+def _cpu_mp_worker(rank, W, cond, threads, barrier, q, cores):
+    """One of P concurrent CPU processes (all usable host cores busy), pinned to its own disjoint core range: 1 warm-up + 2 timed steps on
+    its own 4 utterances."""
+    if cores:
+        try:
+            os.sched_setaffinity(0, cores)  # threads the OpenMP pool creates later inherit the mask
+        except OSError:
+            pass
     torch.set_num_threads(threads)
+    try:
+        torch.set_num_interop_threads(1)
+    except RuntimeError:
+        pass
     torch.set_grad_enabled(False)
     from oracle import oracle as O
     tab, _ = O.diffusion_tables(DIFF_STEPS)
@@ -115,21 +148,33 @@ def _cpu_mp_worker(rank, W, cond, threads, barrier, q):
     q.put((rank, times[1:]))
 
 
-def cpu_all_cores(W, cond, threads, ncpu):
-    """Throughput with EVERY host core busy: P = host_cpus // threads processes, `threads` threads each, 4 utterances per
-    process (what a CPU deployment of the reference would do for throughput; one PyTorch process does not scale past a
-    few tens of threads on this workload)."""
+def cpu_all_cores(W, cond, threads, hc):
+    """Throughput with EVERY usable host core busy: P = usable // threads processes, `threads` threads each, each process pinned to its own
+    core range of the affinity set (OMP_NUM_THREADS set before the spawn), 4 utterances per process -- what a CPU deployment of the
+    reference would do for throughput; one PyTorch process does not scale past a few tens of threads on this workload."""
     import torch.multiprocessing as mp
-    P = max(1, min(ncpu // threads, 32))
+    usable = hc["usable"]
+    P = max(1, min(usable // threads, 32))
+    pin = hc["cgroup_quota_cores"] is None or len(hc["affinity"]) <= usable  # under a CFS quota the cores are shared: do not pin
+    ranges = [hc["affinity"][r * threads:(r + 1) * threads] if pin else None for r in range(P)]
     ctx = mp.get_context("spawn")
     q, barrier = ctx.Queue(), ctx.Barrier(P)
     Wd = {k: v for k, v in W.items() if k.startswith("denoise_fn.")}
     for v in Wd.values():
         v.share_memory_()
     c4 = cond[:4].contiguous().share_memory_()
-    procs = [ctx.Process(target=_cpu_mp_worker, args=(r, Wd, c4, threads, barrier, q)) for r in range(P)]
-    for p in procs:
-        p.start()
+    old = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    os.environ["OMP_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = str(threads)
+    try:
+        procs = [ctx.Process(target=_cpu_mp_worker, args=(r, Wd, c4, threads, barrier, q, ranges[r])) for r in range(P)]
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     res, deadline = [], time.time() + 300
     import queue as _queue
     while len(res) < P:
@@ -145,9 +190,10 @@ def cpu_all_cores(W, cond, threads, ncpu):
         p.join(timeout=60)
     step = max(sum(t) / len(t) for _, t in res)  # the slowest process bounds the aggregate
     return {"value": P * 4 * T / (DIFF_STEPS * step), "unit": "mel-frames/s", "cores": P * threads, "processes": P,
-            "threads_per_process": threads,
-            "sample": "%d processes x %d threads, 4 utterances each, 2 timed DiffNet+posterior steps after a common "
-                      "barrier, scaled to %d steps; slowest process s/step=%.3f" % (P, threads, DIFF_STEPS, step)}
+            "threads_per_process": threads, "pinned": bool(pin),
+            "sample": "%d processes x %d threads%s, 4 utterances each, 2 timed DiffNet+posterior steps after a common "
+                      "barrier, scaled to %d steps; slowest process s/step=%.3f"
+                      % (P, threads, " pinned to disjoint core ranges" if pin else "", DIFF_STEPS, step)}
 
 
 def cpu_baseline(model, inp, protocol="full"):
@@ -159,7 +205,9 @@ def cpu_baseline(model, inp, protocol="full"):
     W = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     cpu_in = {k: v.cpu() for k, v in inp.items()}
     tab, _ = O.diffusion_tables(DIFF_STEPS)
-    ncpu = os.cpu_count() or 1
+    hc = host_cores()
+    ncpu = hc["usable"]  # affinity set / cgroup quota, not os.cpu_count()
+    torch.set_num_threads(min(ncpu, 32))
     t0 = time.perf_counter()
     ret, cond = O.conditioner(W, cpu_in["txt_tokens"], cpu_in["time_mel_masks"], cpu_in["mel2ph"],
                               cpu_in["spk_embed"], cpu_in["ref_mels"], cpu_in["f0"], cpu_in["uv"])
@@ -175,7 +223,9 @@ def cpu_baseline(model, inp, protocol="full"):
     torch.set_num_threads(best)
     t_step, parity = _cpu_steps(O, W, tab, cond, 3, gpu_model=model)
     total = t_cond + DIFF_STEPS * t_step
-    out = {"value": B * T / total, "unit": "mel-frames/s", "cores": best, "host_cpus": ncpu, "kind": "port",
+    out = {"value": B * T / total, "unit": "mel-frames/s", "cores": best, "host_cpus": hc["os_cpu_count"],
+           "host_cpus_affinity": len(hc["affinity"]), "host_cgroup_quota_cores": hc["cgroup_quota_cores"], "host_cpus_usable": ncpu,
+           "kind": "port",
            "parity_max_abs_dx0_one_pass": parity,
            "thread_sweep_frames_per_s_B8": {str(k): v for k, v in sweep.items()},
            "sample": "conditioner once + 3 timed DiffNet+posterior steps (after 1 warm-up) at B=%d,T=%d with %d threads "
@@ -210,7 +260,7 @@ def cpu_baseline(model, inp, protocol="full"):
         out["hifigan_v1_B4"] = {"value": 4 * T / th, "unit": "mel-frames/s", "cores": best, "seconds": th}
         # every host core busy: P processes x `best` threads
         try:
-            out["all_cores_multiprocess"] = cpu_all_cores(W, cond, min(best, 8), ncpu)
+            out["all_cores_multiprocess"] = cpu_all_cores(W, cond, min(best, 8), hc)
         except Exception as e:  # a reported baseline must not take the benchmark down
             out["all_cores_multiprocess"] = {"error": repr(e)}
         # `value` is the CPU's best over everything measured above
@@ -220,9 +270,15 @@ def cpu_baseline(model, inp, protocol="full"):
             cands.append(("all cores, %d processes" % out["all_cores_multiprocess"]["processes"],
                           out["all_cores_multiprocess"]["value"], out["all_cores_multiprocess"]["cores"]))
         name, val, cores = max(cands, key=lambda c: c[1])
+        am = out["all_cores_multiprocess"]
+        if "value" in am and am["value"] < max(c[1] for c in cands[:2]):
+            # every usable core busy must not lose to one process; when it does, say what the box looked like
+            am["note"] = ("aggregate below the one-process figure: %d processes x %d threads on %d usable cores (affinity %d, cgroup quota %s, "
+                          "os.cpu_count %d) -- the cores are shared or throttled; `value` stays the best measured figure"
+                          % (am["processes"], am["threads_per_process"], ncpu, len(hc["affinity"]), hc["cgroup_quota_cores"], hc["os_cpu_count"]))
         out["one_process_B32"] = {"value": out["value"], "cores": best}
         out["value"], out["cores"], out["best_of"] = val, cores, name
-    torch.set_num_threads(ncpu)
+    torch.set_num_threads(min(ncpu, 64))
     return out
 
 
@@ -464,42 +520,36 @@ def run_infer(args, rank, world, dev):
 
 
 def quality_vs_oracle(model):
-    """BASELINE's "MCD vs ref" on the headline path: 4 synthetic utterances at T = 800 through TWO reverse steps of the shipped kernels
-    (timesteps = 2, explicit noise) against the CPU oracle (the port of the reference's torch path, pinned on the reference-generated
-    goldens in tests/) on the same weights, inputs and noise: mel-level MCD (utils/eval/mcd.py:89-95 restated in oracle.mel_mcd) and
-    max |dmel|.  Two steps keep the oracle's CPU time at seconds; the 100-step drift is covered by tests/golden/infer_drift100."""
+    """BASELINE's "MCD vs ref" on the headline path, over the FULL loop (round 6): the metric's own configuration -- B = 32, T = 800, all 100
+    reverse steps of the shipped kernels with explicit noise -- and four of its utterances (rows 0, 9, 20, 31) through the CPU oracle (the port
+    of the reference's torch path, pinned on the reference-generated goldens in tests/, the T = 800 x 100-step one included) on the same weights,
+    inputs and noise: mel-level MCD (utils/eval/mcd.py:89-95 restated in oracle.mel_mcd) and max |dmel| (spec_denoiser.py:178-184)."""
     from oracle import oracle as O
-    from set_amd.diffnet import DiffNet
-    from set_amd.spec_denoiser import GaussianDiffusion
     from set_amd.synthetic import synthetic_inputs
     dev = next(model.parameters()).device
-    hp = load_hparams()
-    hp["timesteps"] = 2
-    m2 = GaussianDiffusion(list(range(80)), M, DiffNet(M, hp), timesteps=2, time_scale=1, loss_type="l1", spec_min=[], spec_max=[], hp=hp)
-    sd = {k: v for k, v in model.state_dict().items() if k in m2.state_dict() and m2.state_dict()[k].shape == v.shape and not O_is_table(k)}
-    m2.load_state_dict(sd, strict=False)
-    m2.to(dev).eval()
-    Bq = 4
-    inp = synthetic_inputs(Bq, T, T_TXT, seed=4321)
+    rows = [0, 9, 20, 31]
+    inp = synthetic_inputs(B_PER_GPU, T, T_TXT, seed=4321)
     g = torch.Generator().manual_seed(99)
-    noises = [torch.randn(Bq, 1, M, T, generator=g) for _ in range(3)]
+    nz_rows = [torch.randn(len(rows), 1, M, T, generator=g) for _ in range(DIFF_STEPS + 1)]
+    gd = torch.Generator(device=dev).manual_seed(98)
+    noises = torch.randn(DIFF_STEPS + 1, B_PER_GPU, 1, M, T, device=dev, generator=gd)
+    noises[:, rows] = torch.stack(nz_rows).to(dev)
     d = {k: v.to(dev) for k, v in inp.items()}
     with torch.no_grad():
-        ret = m2(d["txt_tokens"], d["time_mel_masks"], d["mel2ph"], d["spk_embed"], d["ref_mels"], d["f0"], d["uv"], infer=True,
-                 noises=torch.stack(noises).to(dev))
-    W = {k: v.detach().float().cpu() for k, v in m2.state_dict().items()}
+        ret = model(d["txt_tokens"], d["time_mel_masks"], d["mel2ph"], d["spk_embed"], d["ref_mels"], d["f0"], d["uv"], infer=True,
+                    noises=noises)
+    del noises
+    W = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    sub = {k: v[rows].contiguous() for k, v in inp.items()}
     t0 = time.perf_counter()
-    oret = O.gaussian_diffusion_infer(W, 2, inp, noises)
+    oret = O.gaussian_diffusion_infer(W, DIFF_STEPS, sub, nz_rows)
     dt = time.perf_counter() - t0
-    a, b = ret["mel_out"].float().cpu().numpy(), oret["mel_out"].float().numpy()
-    return {"mcd_vs_oracle": max(O.mel_mcd(a[i], b[i]) for i in range(Bq)), "max_abs_dmel_vs_oracle": float(abs(a - b).max()),
-            "quality_sample": "4 utterances x T=800 x 2 explicit-noise reverse steps, shipped kernels vs the CPU oracle (%.1f s of CPU)" % dt,
-            "integers_equal_vs_oracle": bool(torch.equal(ret["pitch"].cpu(), oret["pitch"]) and torch.equal(ret["masked_dur"].cpu(), oret["masked_dur"]))}
-
-
-def O_is_table(key):
-    """diffusion schedule buffers (they depend on `timesteps`; the 2-step model computes its own)"""
-    return "." not in key
+    a, b = ret["mel_out"][rows].float().cpu().numpy(), oret["mel_out"].float().numpy()
+    return {"mcd_vs_oracle": max(O.mel_mcd(a[i], b[i]) for i in range(len(rows))), "max_abs_dmel_vs_oracle": float(abs(a - b).max()),
+            "quality_sample": "B=%d x T=%d x %d explicit-noise reverse steps on the shipped kernels (the metric's configuration); rows %s "
+                              "against the CPU oracle's complete %d-step loop (%.1f s of CPU)" % (B_PER_GPU, T, DIFF_STEPS, rows, DIFF_STEPS, dt),
+            "integers_equal_vs_oracle": bool(torch.equal(ret["pitch"][rows].cpu(), oret["pitch"]) and
+                                             torch.equal(ret["masked_dur"][rows].cpu(), oret["masked_dur"]))}
 
 
 def _sub_bench(argv, timeout=420):

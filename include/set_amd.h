@@ -373,8 +373,15 @@ int set_randn(float *out, int64_t n, uint64_t seed, uint64_t offset, void *strea
 int set_rng_seed_delta(const uint64_t *dev_word);
 /* Host-side stream ordering (the training path's leaf stream, autograd_ops.leaf_work): work enqueued on `after` from now on waits for
  * everything enqueued on `first` so far (hipEventRecord + hipStreamWaitEvent on a cached event; slot < 32 selects the event, one per
- * direction and device).  Capturable: inside a stream capture the pair is a cross-stream edge. */
+ * direction and device: slot s belongs to device s / 2 and its event is created there, whatever the calling thread's current device is).
+ * Capturable: inside a stream capture the pair is a cross-stream edge. */
 int set_stream_order(void *first, void *after, int32_t slot);
+/* Progress markers of a stream (round 6; the leaf stream's operand bookkeeping, autograd_ops.leaf_work -- the reference's autograd engine
+ * frees a backward operand as soon as its node has run, utils/commons/trainer.py:340-350 `loss.backward()`): set_stream_mark records marker
+ * `slot` (0 .. 63, an event of device `dev`, created on first use) on `stream`; set_stream_mark_done(slot) returns 1 once everything enqueued on
+ * that stream before the mark has finished, 0 while it has not, < 0 on error (never blocks). */
+int set_stream_mark(void *stream, int32_t slot, int32_t dev);
+int set_stream_mark_done(int32_t slot);
 /* a non-blocking stream of the lowest priority of the current device (the leaf stream); never destroyed */
 int set_stream_create_low_priority(void **out);
 

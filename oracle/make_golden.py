@@ -93,7 +93,9 @@ def maxdiff(a, b):
 
 
 def infer_case(hp, name, B, T, T_txt, steps, wseed, iseed, pad_tail=False, overrides=None,
-               trace_layers=(), flags=None, keep_steps=None):
+               trace_layers=(), flags=None, keep_steps=None, light_stride=0):
+    """light_stride > 0 (the metric-shaped case, T = 800): the fixture keeps mel_out, the integer tensors and every
+    `light_stride`-th frame of the kept x0 / x traces -- not decoder_inp / the float pitch tensors (1.6 MB at T = 800)."""
     flags = flags or {}
     model = build_ref_model(hp, steps, overrides)
     W = load_seeded(model, wseed)
@@ -170,18 +172,26 @@ def infer_case(hp, name, B, T, T_txt, steps, wseed, iseed, pad_tail=False, overr
     out = dict(
         meta=np.array(json.dumps(dict(B=B, T=T, T_txt=T_txt, steps=steps, wseed=wseed, iseed=iseed,
                                       pad_tail=pad_tail, overrides=overrides or {}, flags=flags,
-                                      trace_layers=list(trace_layers), variant=VARIANT))),
+                                      trace_layers=list(trace_layers), variant=VARIANT, light_stride=light_stride))),
         mel_out=ret["mel_out"], decoder_inp=ret["decoder_inp"], dur=ret["dur"], mel2ph=ret["mel2ph"],
     )
+    if light_stride:
+        del out["decoder_inp"]
     if VARIANT == "masked":
         out["masked_dur"] = ref_int["masked_dur"]
     if use_pitch:
         out.update(pitch_pred=ret["pitch_pred"], f0_denorm=ret["f0_denorm"], f0_denorm_pred=ret["f0_denorm_pred"],
                    pitch=ref_int["pitch"])
+        if light_stride:
+            del out["f0_denorm"], out["f0_denorm_pred"]
         if VARIANT == "masked":
             out["masked_pitch"] = ref_int["masked_pitch"]
     ks = range(steps) if keep_steps is None else keep_steps
     for k in ks:
+        if light_stride:  # [B, 1, M, T] -> every light_stride-th frame
+            out["x0_step%d" % k] = rec["x0"][k][..., ::light_stride]
+            out["x_step%d" % k] = rec["x"][k][..., ::light_stride]
+            continue
         out["x0_step%d" % k] = rec["x0"][k]
         out["x_step%d" % k] = rec["x"][k]
     for li, (xl, sl) in rec["layers"].items():
@@ -477,6 +487,7 @@ def main():
     hifigan_case("hifigan_v1_long", Wt.HIFIGAN_V1, B=1, T=220, wseed=23, iseed=204, manifest="hifigan_v1")
     hifigan_v23_cases()
     ragged_cases(hp)
+    full800_case(hp)
     edit_cases(hp)
     nopitch_cases(hp)
     normal_cases(hp)
@@ -492,6 +503,16 @@ def ragged_cases(hp):
     infer_case(hp, "infer_short", B=2, T=7, T_txt=3, steps=2, wseed=20, iseed=110, pad_tail=True, overrides=base, keep_steps=(0, 1))
     # training at the ragged sizes: losses + every gradient (weight gradients whose frame rows are not 16-byte aligned, LayerNorm / SSIM tile edges)
     train_loss_case(hp, "train_losses_ragged", B=3, T=77, T_txt=19, steps=8, wseed=24, iseed=112)
+
+
+def full800_case(hp):
+    """Round 6: the shape BASELINE.json's metric is quoted on, run by the reference itself -- T = 800 frames (13 tiles of 64 per utterance, so
+    the inter-tile halo hand-off of the stack kernels is exercised over all 100 steps of spec_denoiser.py:178-184), T_txt = 100, 100 steps,
+    B = 2 with one padded tail.  The GPU tests also embed the two utterances in a B = 32 batch (the throughput tiles) and run B = 1."""
+    base = dict(residual_layers=20, residual_channels=256, dilation_cycle_length=1)
+    hp.update(base)
+    infer_case(hp, "infer_full800", B=2, T=800, T_txt=100, steps=100, wseed=25, iseed=113, pad_tail=True, overrides=base,
+               keep_steps=(0, 50, 99), light_stride=8)
 
 
 def nopitch_cases(hp):

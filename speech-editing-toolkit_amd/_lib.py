@@ -245,6 +245,8 @@ SIGNATURES = {
     "set_randn": (C.c_int, [_V, _I64, _U64, _U64, _V]),
     "set_rng_seed_delta": (C.c_int, [_V]),
     "set_stream_order": (C.c_int, [_V, _V, _I32]),
+    "set_stream_mark": (C.c_int, [_V, _I32, _I32]),
+    "set_stream_mark_done": (C.c_int, [_I32]),
     "set_stream_create_low_priority": (C.c_int, [C.POINTER(C.c_void_p)]),
     "set_diffusion_loop": (C.c_int, [C.POINTER(SetDiffLoopArgs), _V]),
     "set_selftest_mfma": (C.c_int, [C.POINTER(C.c_float), _V]),

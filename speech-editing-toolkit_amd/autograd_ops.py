@@ -4,6 +4,7 @@ torch.autograd is used as the tape only: every forward AND backward below is a k
 (include/set_amd.h, "Training" section).  Ops without gradients (masks, integer bookkeeping) are re-exported
 from ops.py unchanged.
 """
+import collections
 import ctypes as C
 import os
 
@@ -56,7 +57,78 @@ _ACTIVE = [None]    # the arena of the optimisation step in progress (steps do n
 # target written by exactly one stream.  Tensors handed to a leaf kernel stay referenced until the join (their storage must not be reused by
 # the compute stream before the leaf kernel has read it); reduction scratch buffers are per stream.  SET_AMD_LEAF_STREAM=0 switches it off.
 # Host cost per fork: one C call (set_stream_order); torch's Event / Stream / record_stream wrappers cost ~28 us per fork (1.1 ms per step).
-_LEAF = {}  # device index -> {"stream" (torch object, kept alive), "raw" (handle), "dirty", "keep" (operands of queued leaf kernels)}
+# Operand lifetime (round 6, advisor item): the operands are no longer all held until the end of backward() -- the fp32 DiffNet stack alone kept
+# d_o and dy of 20 layers (2.1 GB at B = 32, T = 800) alive that way, growing with depth.  After every ~SET_AMD_LEAF_MARK_MB (128) MB of newly
+# held operands a marker event is recorded on the leaf stream (set_stream_mark); at the next fork the markers that have completed
+# (set_stream_mark_done, a non-blocking query) release everything held before them: those kernels have RUN, so whoever gets the storage
+# next cannot race them.  Above SET_AMD_LEAF_KEEP_MB (2048) MB of held operands the compute stream is made to wait for the leaf stream
+# (an early leaf_join) -- a bound, not the normal path.
+_LEAF = {}  # device index -> {"stream" (torch object, kept alive), "raw" (handle), "dirty", "keep" (operands of queued leaf kernels), ...}
+_LEAF_STATS = {"max_keep_bytes": 0, "released_by_marker": 0, "early_joins": 0}
+
+
+def _mb_env(name, default):
+    try:
+        return max(1, int(os.environ.get(name, default))) << 20
+    except ValueError:
+        return int(default) << 20
+
+
+def _nbytes(obj):
+    if isinstance(obj, torch.Tensor):
+        return obj.numel() * obj.element_size()
+    if isinstance(obj, (tuple, list)):
+        return sum(_nbytes(o) for o in obj)
+    return 0
+
+
+def _leaf_hold(st, obj):
+    n = _nbytes(obj)
+    st["keep"].append((obj, n))
+    st["count"] += 1
+    st["bytes"] += n
+    st["unmarked"] += n
+    if st["bytes"] > _LEAF_STATS["max_keep_bytes"]:
+        _LEAF_STATS["max_keep_bytes"] = st["bytes"]
+
+
+def _leaf_release_all(st):
+    st["keep"].clear()
+    st["marks"].clear()
+    st["base"], st["bytes"], st["unmarked"] = st["count"], 0, 0
+
+
+def _leaf_poll(st):
+    """Release the operands whose leaf kernels have finished (markers that completed); non-blocking."""
+    marks = st["marks"]
+    while marks and L().set_stream_mark_done(marks[0][0]) == 1:
+        _, upto = marks.popleft()
+        keep = st["keep"]
+        while st["base"] < upto:
+            _, n = keep.popleft()
+            st["bytes"] -= n
+            st["base"] += 1
+            _LEAF_STATS["released_by_marker"] += 1
+
+
+def _leaf_mark(st):
+    """After the kernels of a fork have been enqueued: a marker once enough new operands are held and a slot of the device's ring is free."""
+    if st["unmarked"] < st["mark_bytes"] or len(st["marks"]) >= 8:
+        return
+    busy = {m[0] for m in st["marks"]}
+    slot = next(s for s in range(8 * (st["idx"] % 8), 8 * (st["idx"] % 8) + 8) if s not in busy)
+    check(L().set_stream_mark(st["raw"], slot, st["idx"]), "set_stream_mark")
+    st["marks"].append((slot, st["count"]))
+    st["unmarked"] = 0
+
+
+def leaf_stats(reset=False):
+    """{"max_keep_bytes", "released_by_marker", "early_joins"} since the last reset (tests / probes)."""
+    out = dict(_LEAF_STATS)
+    if reset:
+        for k in _LEAF_STATS:
+            _LEAF_STATS[k] = 0
+    return out
 
 
 def leaf_enabled():
@@ -73,7 +145,9 @@ def _leaf_state(dev):
         with torch.cuda.device(idx):
             check(L().set_stream_create_low_priority(C.byref(raw)), "set_stream_create_low_priority")
         stream = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
-        st = _LEAF[idx] = {"stream": stream, "raw": raw, "dirty": False, "keep": [], "idx": idx}
+        st = _LEAF[idx] = {"stream": stream, "raw": raw, "dirty": False, "keep": collections.deque(), "idx": idx,
+                           "marks": collections.deque(), "count": 0, "base": 0, "bytes": 0, "unmarked": 0,
+                           "mark_bytes": _mb_env("SET_AMD_LEAF_MARK_MB", 128), "cap_bytes": _mb_env("SET_AMD_LEAF_KEEP_MB", 2048)}
     return st
 
 
@@ -100,8 +174,14 @@ class leaf_work:
         if not self.on:
             return False
         st = _leaf_state(self.dev)
+        if st["marks"]:
+            _leaf_poll(st)
+        if st["bytes"] > st["cap_bytes"]:  # the bound: the compute stream waits for the leaf stream, everything held so far is released
+            _order(st, False)
+            _leaf_release_all(st)
+            _LEAF_STATS["early_joins"] += 1
         _order(st, True)
-        st["keep"].append(self.tensors)
+        _leaf_hold(st, self.tensors)
         ops._STREAM_TLS.leaf = st["raw"]
         self._st = st
         if not st["dirty"]:
@@ -115,6 +195,8 @@ class leaf_work:
     def __exit__(self, *exc):
         if self.on:
             ops._STREAM_TLS.leaf = None
+            if exc[0] is None:
+                _leaf_mark(self._st)
         return False
 
 
@@ -126,7 +208,7 @@ def leaf_join():
             with torch.cuda.device(idx):
                 _order(st, False)
             st["dirty"] = False
-            del st["keep"][:]
+            _leaf_release_all(st)
 
 
 def leaf_fence(dev):
@@ -202,7 +284,7 @@ def _leaf_keep(buf):
     if getattr(ops._STREAM_TLS, "leaf", None) is not None:
         for st in _LEAF.values():
             if st["dirty"]:
-                st["keep"].append(buf)
+                _leaf_hold(st, buf)
 
 
 def _det_scratch(device, n_floats):

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "boundary_x2.h"
 
 namespace {
 
@@ -1276,35 +1277,7 @@ __global__ void __launch_bounds__(256) sinusoid_kernel(const float *t, float *ou
     out[i] = j < half ? sinf(ang) : cosf(ang);
 }
 
-// ---- Philox4x32-10 (counter based) + Box-Muller ------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
-__device__ __forceinline__ void randn4(uint64_t seed, uint64_t ctr, float out[4]) {
-    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
-    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    // (0,1] uniforms, Box-Muller
-    const float u0 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
-    const float u1 = ((float)(c[1] >> 8) + 1.0f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(c[2] >> 8) + 1.0f) * (1.0f / 16777216.0f);
-    const float u3 = ((float)(c[3] >> 8) + 1.0f) * (1.0f / 16777216.0f);
-    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
-    float s0, c0, s1, c1;
-    sincosf(6.28318530717958647692f * u1, &s0, &c0);
-    sincosf(6.28318530717958647692f * u3, &s1, &c1);
-    out[0] = r0 * c0; out[1] = r0 * s0; out[2] = r1 * c1; out[3] = r1 * s1;
-}
+// (Philox4x32-10 + Box-Muller: csrc/boundary_x2.h, shared with the whole-loop kernel of csrc/diffnet_x3.hip)
 
 // seed_delta (set_rng_seed_delta, may be NULL): a device word ADDED to the seed argument -- a captured graph carries the seed of the
 // step it was captured at; the replay of step k stores (seed_k - seed_captured) there and draws exactly the eager step's numbers
@@ -1608,90 +1581,12 @@ __global__ void __launch_bounds__(256, 2) diffnet_boundary_kernel(BoundaryArgs a
 // the operand tiles live in LDS as [piece][frame][channel] fp16 (rows padded by 16 B), the weights come from the images of
 // set_pack_conv_weight_x2 (A-fragment order, straight from global memory), x0 / x' pass through an fp32 tile for the
 // posterior update exactly as above.  Used by the reverse loop whenever the layer stack runs on two-piece fp16 operands.
-typedef _Float16 bx_f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned bx_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned bx_u32x2 __attribute__((ext_vector_type(2)));
-constexpr int BX_XR = DC * 2 + 16;     // bytes per row of the s / h tiles [frame][256]
-constexpr int BX_PR = 96 * 2 + 16;     // ... of the x' tile [frame][96]
-constexpr int BX_PIECE = 64 * BX_XR;   // one piece of a [64][256] tile
-
+// (operand types, bx_split / bx_mma / bx_gemm and the tile constants: csrc/boundary_x2.h)
 struct BoundaryX2Args {
     BoundaryArgs g;
     const unsigned short *w_skip_x2, *w_outp_x2, *w_in_x2;
     int32_t *err_flag;
 };
-
-__device__ __forceinline__ void bx_split(float v, unsigned short &p0, unsigned short &p1) {
-    const _Float16 h0 = (_Float16)v;
-    p0 = __builtin_bit_cast(unsigned short, h0);
-    p1 = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h0));
-}
-__device__ __forceinline__ f32x16 bx_mma(bx_u32x4 a, bx_u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bx_f16x8, a), __builtin_bit_cast(bx_f16x8, b), c, 0, 0, 0);
-}
-// acc[NRB][2] += W[32 (rb0 + i) .. ][16 ks ..] * B over nks k-steps; image [rb32][ng16][piece][lane][8] (K = 1 tap);
-// B piece q of (ks, cb) at lds + q * piece_bytes + bfrag(ks, cb)
-template <int NRB, typename BF>
-__device__ __forceinline__ void bx_gemm(f32x16 (&acc)[NRB][2], rsrc_t img, unsigned lane16, int rb0, int ng16, int nks,
-                                        const unsigned char *lds, unsigned piece_bytes, BF bfrag) {
-    // Weight fragments straight from the packed image through a ring of PF k-steps, the k-step order pinned (round 4, as in gemm_x3 /
-    // sx_gemm):  ds_read B(k + 1) | the MFMAs of k-step k straight from their ring slot | refill of that slot | sched_barrier.  Rounds 2-3
-    // had `Ac = A[p]; A[p] = load; mma(Ac)` with a ring of 2: 150 of the kernel's 312 MFMAs sat right behind an s_waitcnt vmcnt(0 / 1).
-    // Same products in the same order per accumulator: bit-identical.
-    constexpr int PF = 4;
-    auto a_load = [&](int ks, int i, int q) {
-        return (bx_u32x4)__builtin_amdgcn_raw_buffer_load_b128(img, (int)lane16, (int)((((rb0 + i) * ng16 + ks) * 2 + q) * 1024), 0);
-    };
-    bx_u32x4 A[PF][NRB][2];
-#pragma unroll
-    for (int p = 0; p < PF; ++p)
-#pragma unroll
-        for (int i = 0; i < NRB; ++i)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) A[p][i][q] = a_load(min(p, nks - 1), i, q);
-    bx_u32x4 Bv[2][2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const unsigned bo = bfrag(0, cb);
-        Bv[cb][0] = *reinterpret_cast<const bx_u32x4 *>(lds + bo);
-        Bv[cb][1] = *reinterpret_cast<const bx_u32x4 *>(lds + piece_bytes + bo);
-    }
-#pragma unroll 1
-    for (int kb = 0; kb < nks; kb += PF) {
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const int ks = kb + p;
-            if (ks < nks) {  // (nks need not be a multiple of PF: the in-projection has 5 k-steps)
-                bx_u32x4 Bn[2][2];
-                const int kq = min(ks + 1, nks - 1);
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    const unsigned bo = bfrag(kq, cb);
-                    Bn[cb][0] = *reinterpret_cast<const bx_u32x4 *>(lds + bo);
-                    Bn[cb][1] = *reinterpret_cast<const bx_u32x4 *>(lds + piece_bytes + bo);
-                }
-#pragma unroll
-                for (int t = 0; t < 3; ++t)  // a1 b0, a0 b1, a0 b0
-#pragma unroll
-                    for (int i = 0; i < NRB; ++i)
-#pragma unroll
-                        for (int cb = 0; cb < 2; ++cb) acc[i][cb] = bx_mma(A[p][i][t == 0 ? 1 : 0], Bv[cb][t == 1 ? 1 : 0], acc[i][cb]);
-                const int kn = min(ks + PF, nks - 1);
-#pragma unroll
-                for (int i = 0; i < NRB; ++i) {
-                    A[p][i][0] = a_load(kn, i, 0);
-                    A[p][i][1] = a_load(kn, i, 1);
-                }
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    Bv[cb][0] = Bn[cb][0];
-                    Bv[cb][1] = Bn[cb][1];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
 
 __global__ void __launch_bounds__(256, 2) diffnet_boundary_x2_kernel(BoundaryX2Args ax) {
     const BoundaryArgs &a = ax.g;
@@ -1941,8 +1836,16 @@ static int aux_stream(int i, hipStream_t *out) {
     return SET_OK;
 }
 
-// enqueue the chain of one utterance group [b0, b0+Bg) on stream s
-static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipStream_t s, hipEvent_t *ev) {
+// csrc/diffnet_x3.hip: the whole reverse loop of a group as ONE launch (step boundaries as tasks of the persistent queue)
+struct SetLoopX3Boundary {
+    float *x; const float *eps; int64_t eps_ks; const float *coef4; const void *w_skip_x2, *w_outp_x2, *w_in_x2;
+    const float *b_skip, *b_outp, *b_in; float div; uint64_t seed, quads_total, quads_before; int32_t M, steps;
+};
+bool set_loop_x3_usable(const SetDiffnetStackArgs &a, int n_cu);
+int set_launch_diffnet_loop_x3(const SetDiffnetStackArgs &a, const SetLoopX3Boundary &lb, int n_cu, hipStream_t s);
+
+// enqueue the chain of one utterance group [b0, b0+Bg) on stream s; *whole_loop = the group ran as one launch (ev[0], ev[1] bracket it)
+static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipStream_t s, hipEvent_t *ev, bool *whole_loop) {
     const int T = a.T, M = a.M, L = a.L;
     const int64_t per_batch = (int64_t)M * T;
     float *x = a.x + (int64_t)b0 * per_batch;
@@ -1965,16 +1868,45 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
         SET_HIP(hipDeviceGetAttribute(&n_cu_chain, hipDeviceAttributeMultiprocessorCount, dev), "set_diffusion_loop");
     }
     bool boundary_x2 = false;
+    int v = -1;
     if (a.persistent && !bf16_loop && fused_boundary && a.w_skip_x2 && a.w_outp_x2 && a.w_in_x2 && a.wx3_all && a.x3_mode == 2 &&
         a.M <= 96) {
-        const int v = stack_variant(Bg, T, a.dilation_cycle_length, a.w1w_all && a.w2w_all, a.w1s_all && a.w2s_all && a.z_ws,
-                                    a.x3_mode, n_cu_chain);
+        v = stack_variant(Bg, T, a.dilation_cycle_length, a.w1w_all && a.w2w_all, a.w1s_all && a.w2s_all && a.z_ws,
+                          a.x3_mode, n_cu_chain);
         boundary_x2 = v == 5 || (v == 3 && !(getenv("SET_AMD_SPLIT_F32") && atoi(getenv("SET_AMD_SPLIT_F32")) != 0));
     }
     // the bf16-operand loop takes the split-operand boundary whenever its images are given (round 4: 85 -> 37 us per step at B = 32,
     // T = 800; it is the fp32-equivalent one, and it raises the same range word, which the caller must read)
     if (bf16_loop && fused_boundary && a.w_skip_x2 && a.w_outp_x2 && a.w_in_x2 && a.M <= 96) boundary_x2 = true;
     if (const char *e = getenv("SET_AMD_BOUNDARY_X2")) boundary_x2 = boundary_x2 && atoi(e) != 0;
+    if (whole_loop) *whole_loop = false;
+    // ---- the whole loop as ONE launch (round 6): the throughput kernel on 64-frame tiles with the split-operand boundary as a task of its
+    //      queue; bit-identical to the per-step launches below (SET_AMD_LOOP_LAUNCH=0 keeps those)
+    if (v == 5 && boundary_x2 && !bf16_loop && a.persistent) {
+        SetDiffnetStackArgs sa = {};
+        sa.xa = ws_x0; sa.xb = ws_x1; sa.skip = ws_skip;
+        sa.condproj = condproj; sa.cp_bs = (int64_t)L * 512 * T; sa.cp_ls = (int64_t)512 * T;
+        sa.dstep = a.dstep; sa.d_bs = 0; sa.d_cs = a.steps; sa.d_ls = (int64_t)DC * a.steps;
+        sa.b_dil_all = a.b_dil_all; sa.b_out_all = a.b_out_all; sa.wx3_all = a.wx3_all; sa.x3_mode = a.x3_mode;
+        sa.err_flag = a.err_flag; sa.sync_ws = sync_ws;
+        sa.B = Bg; sa.T = T; sa.L = L; sa.dilation_cycle_length = a.dilation_cycle_length;
+        if (set_loop_x3_usable(sa, n_cu_chain)) {
+            SetConv1dArgs cin = conv1x1_args(x, a.w_in_p, a.b_in, ws_x0, Bg, M, DC, T);  // step 0's input projection (diffnet.py:118-120)
+            cin.act = SET_ACT_RELU;
+            rc = set_conv1d(&cin, s);
+            if (rc != SET_OK) return rc;
+            SetLoopX3Boundary lb = {};
+            lb.x = x; lb.eps = a.noise ? a.noise + (int64_t)b0 * per_batch : nullptr; lb.eps_ks = (int64_t)a.B * per_batch;
+            lb.coef4 = a.coef4; lb.w_skip_x2 = a.w_skip_x2; lb.w_outp_x2 = a.w_outp_x2; lb.w_in_x2 = a.w_in_x2;
+            lb.b_skip = a.b_skip; lb.b_outp = a.b_outp; lb.b_in = a.b_in; lb.div = sqrtf((float)L);
+            lb.seed = a.seed; lb.quads_total = quads_total; lb.quads_before = quads_before; lb.M = M; lb.steps = a.steps;
+            if (ev) (void)hipEventRecord(ev[0], s);
+            rc = set_launch_diffnet_loop_x3(sa, lb, n_cu_chain, s);
+            if (ev) (void)hipEventRecord(ev[1], s);
+            if (whole_loop) *whole_loop = true;
+            return rc;
+        }
+    }
     for (int k = 0; k < a.steps && rc == SET_OK; ++k) {
         const int sid = a.steps - 1 - k;  // diffusion step id t = steps-1 .. 0 (spec_denoiser.py:181)
         // input projection + ReLU (diffnet.py:118-120); with the fused boundary it is part of the previous step's
@@ -2108,8 +2040,9 @@ extern "C" int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream) {
         (void)hipEventRecord(loop_ev[0], s);
     }
     int rc = SET_OK;
+    bool whole[8] = {false, false, false, false, false, false, false, false};
     if (G == 1) {
-        rc = diffusion_chain(a, 0, 0, a.B, s, ev);
+        rc = diffusion_chain(a, 0, 0, a.B, s, ev, &whole[0]);
     } else {
         hipEvent_t fork = nullptr, join[8] = {nullptr};
         SET_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming), "set_diffusion_loop(fork)");
@@ -2120,7 +2053,7 @@ extern "C" int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream) {
             rc = aux_stream(g, &sg);
             if (rc != SET_OK) break;
             SET_HIP(hipStreamWaitEvent(sg, fork, 0), "set_diffusion_loop(fork wait)");
-            rc = diffusion_chain(a, g, b0, b1 - b0, sg, ev ? ev + (size_t)2 * a.steps * g : nullptr);
+            rc = diffusion_chain(a, g, b0, b1 - b0, sg, ev ? ev + (size_t)2 * a.steps * g : nullptr, &whole[g]);
             SET_HIP(hipEventCreateWithFlags(&join[g], hipEventDisableTiming), "set_diffusion_loop(join)");
             SET_HIP(hipEventRecord(join[g], sg), "set_diffusion_loop(join)");
             SET_HIP(hipStreamWaitEvent(s, join[g], 0), "set_diffusion_loop(join wait)");
@@ -2140,7 +2073,12 @@ extern "C" int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream) {
                 float acc_ms = 0.0f;
                 for (int g = 0; g < G; ++g) {
                     float ms = 0.0f;
-                    (void)hipEventElapsedTime(&ms, ev[(size_t)2 * a.steps * g + 2 * k], ev[(size_t)2 * a.steps * g + 2 * k + 1]);
+                    if (whole[g]) {  // one launch for the whole loop: every step gets its share (the step boundaries are part of it)
+                        (void)hipEventElapsedTime(&ms, ev[(size_t)2 * a.steps * g], ev[(size_t)2 * a.steps * g + 1]);
+                        ms /= (float)a.steps;
+                    } else {
+                        (void)hipEventElapsedTime(&ms, ev[(size_t)2 * a.steps * g + 2 * k], ev[(size_t)2 * a.steps * g + 2 * k + 1]);
+                    }
                     acc_ms += ms;
                 }
                 a.layer_span_ms[k] = acc_ms / (float)G;

@@ -35,6 +35,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "boundary_x2.h"
 
 // measurement builds only (tools/build_exp.sh): bit 0 = the A fragments are loaded once per GEMM (no L2 operand stream), bit 1 =
 // every k-step reads the B fragment of k-step 0 (the compiler hoists it: no LDS stream), bit 2 = no s_setprio.  WRONG RESULTS.
@@ -222,6 +223,7 @@ constexpr size_t x3_lds_bytes(int max_dil) {
 struct X3Tile {
     const float *xin;       // BATCH bases ([B][256][T])
     float *xout, *skp;
+    float *xin_next;        // whole-loop kernel, boundary tasks only: the next step's layer-0 input (= xa)
     const float *cp;        // conditioner projection of this layer, utterance 0; utterance stride cp_bs
     const float *dstep;     // step offsets of this layer, utterance 0; utterance stride d_bs, channel stride d_cs
     int64_t cp_bs, d_bs, d_cs;
@@ -555,6 +557,7 @@ __global__ void __launch_bounds__(512 / NU, NU) diffnet_stack_x3_kernel(SetDiffn
         lt.xin = (l & 1) ? a.xb : a.xa;
         lt.xout = (l & 1) ? a.xa : a.xb;
         lt.skp = a.skip;
+        lt.xin_next = nullptr;
         lt.cp = a.condproj + (int64_t)l * a.cp_ls; lt.cp_bs = a.cp_bs;
         lt.dstep = a.dstep + (int64_t)l * a.d_ls; lt.d_bs = a.d_bs; lt.d_cs = a.d_cs;
         lt.img = reinterpret_cast<const unsigned short *>(a.wx3_all) + (int64_t)l * x_nimg<S>();
@@ -654,6 +657,315 @@ int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_
     hipLaunchKernelGGL((diffnet_stack_x3_kernel<S, NU, NCB>), dim3(grid), dim3(512 / NU), ldsz, s, a, tiles_per_utt, ntiles, (int)ntasks64,
                        piece_bytes, fault_tile);
     return set_check_launch("set_diffnet_stack");
+}
+
+// =====================================================================================================================
+// The WHOLE reverse loop as one launch (round 6; spec_denoiser.py:178-184).  The queue of diffnet_stack_x3_kernel gets one more
+// "layer" per denoise step: task (step s, pseudo-layer l, tile i), l < L a residual layer, l == L the STEP BOUNDARY of that tile --
+// skip sum / sqrt(L) -> skip projection -> ReLU -> output head -> posterior update of the mel state (explicit eps or Philox) -> the next
+// step's input projection (diffnet_boundary_x2_kernel's five phases, csrc/diffnet.hip, on the same two-piece fp16 operands and the same
+// images; all three are 1 x 1 convs: the boundary of tile i needs tile i of layer L - 1 only).  Flags count monotonically over the
+// loop: done[i] = s (L + 1) + l + 1; a task waits for done[i - 1 .. i + 1] >= s (L + 1) + l, which for l == 0, s > 0 is the previous
+// step's boundary.  What this removes from every one of the 100 steps: the boundary launch (36 us at B = 32, T = 800) with its ramp, two
+// launch gaps and the flag reset (13 us), and the drain of the stack launch (the last tasks of a launch leave most CUs idle) -- the layers
+// of step s + 1 start on the tiles whose boundary is done while other tiles are still in step s.
+// Buffer hazards (dynamic schedule): boundary (s, i) overwrites xa[i] (the next step's input) -- its last readers, layer L - 2 of tiles
+// i - 1 .. i + 1, finished before layer L - 1 of i - 1 .. i + 1 could start, which the boundary waits for; layer 0 of step s + 1 overwrites
+// xb[i] / skip[i] -- last read by layer L - 1 of i - 1 .. i + 1 / boundary (s, i), both implied by the boundary flags of i - 1 .. i + 1.
+// Results: every accumulator sees the products of the per-step launches in the same order -- bit-identical to them
+// (tests/test_gpu_parity.py::test_whole_loop_launch_equals_per_step_launches).
+// =====================================================================================================================
+struct X3LoopBoundary {
+    float *x;                     // [B][M][T] mel state: in x_T, out x_0
+    const float *eps;             // optional explicit noise of executed step k at eps + k * eps_ks ([B][M][T] each); NULL: Philox
+    int64_t eps_ks;
+    const float *coef4;           // [steps][4] {c1, c2, logvar, nonzero} by step id
+    const unsigned short *w_skip_x2, *w_outp_x2, *w_in_x2;  // set_pack_conv_weight_x2 images
+    const float *b_skip, *b_outp, *b_in;
+    float div;                    // sqrt(L)
+    uint64_t seed, quads_total, quads_before;  // Philox quad of element e at executed step k: (k + 1) quads_total + quads_before + e / 4
+    int32_t M, steps;
+};
+
+// the step boundary of one 64-frame tile (two 32-frame column blocks, each with its own utterance) by an 8-wave block; bl: >= 2 BX_PIECE
+// bytes of LDS.  Arithmetic = diffnet_boundary_x2_kernel's (same images, same k-step order per accumulator, same posterior formula and
+// Philox quads), frames addressed through the column blocks; everything another CU will read is stored agent-scope (write-through).
+__device__ __forceinline__ void x3_boundary(const X3Tile &a, const X3LoopBoundary &p, int k, unsigned char *bl) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int T = a.T, M = p.M;
+    const unsigned lane16 = 16u * (unsigned)lane;
+    const unsigned T4 = 4u * (unsigned)T;
+    const int sid = p.steps - 1 - k;
+    const bool last = k + 1 >= p.steps;
+    float amax = 0.0f;
+    // ---- phase 1: skip tile / sqrt(L), split -> LDS [piece][row = 32 cb + frame][256]: wave w stages column block w & 1, lane (frame,
+    //      channel group of 32)
+    {
+        const int cbs = w & 1, fr = l31, cg = (w >> 1) * 2 + half;
+        const X3Col c = x3_col(a, cbs);
+        const rsrc_t rs = make_rsrc(a.skp + (int64_t)c.b * XC * T);
+        const int t = c.t0 + fr;
+        const bool tv = c.ok && t < T;
+        const unsigned vo = 4u * (unsigned)min(t, T - 1) + (unsigned)(32 * cg) * T4;
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = buf_load(rs, vo, (unsigned)u * T4);
+#pragma unroll
+        for (int q8 = 0; q8 < 4; ++q8) {
+            bx_u32x4 u0, u1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned short p0[2], p1[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float sv = v[8 * q8 + 2 * e + j] / p.div;
+                    const float x = tv ? sv : 0.0f;
+                    amax = fmaxf(amax, fabsf(x));
+                    bx_split(x, p0[j], p1[j]);
+                }
+                u0[e] = (unsigned)p0[0] | ((unsigned)p0[1] << 16);
+                u1[e] = (unsigned)p1[0] | ((unsigned)p1[1] << 16);
+            }
+            *reinterpret_cast<bx_u32x4 *>(bl + (cbs * 32 + fr) * BX_XR + (32 * cg + 8 * q8) * 2) = u0;
+            *reinterpret_cast<bx_u32x4 *>(bl + BX_PIECE + (cbs * 32 + fr) * BX_XR + (32 * cg + 8 * q8) * 2) = u1;
+        }
+    }
+    __syncthreads();
+    auto bfrag256 = [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * BX_XR + (ks * 16 + half * 8) * 2); };
+    // ---- phase 2: h = ReLU(W_skip s + b): wave w owns rows [32 w, 32 w + 32)
+    {
+        const float inv = reinterpret_cast<const float *>(p.w_skip_x2 + (XC / 32) * (XC / 16) * 1024)[1];
+        f32x16 acc[1][2];
+        acc[0][0] = (f32x16){0};
+        acc[0][1] = (f32x16){0};
+        bx_gemm<1>(acc, make_rsrc(p.w_skip_x2), lane16, w, XC / 16, XC / 16, bl, BX_PIECE, bfrag256);
+        __syncthreads();  // every wave is done reading the s tile
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned short p0[4], p1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = 32 * w + 8 * g + 4 * half + e;
+                    const float h = fmaxf(acc[0][cb][4 * g + e] * inv + p.b_skip[row], 0.0f);
+                    amax = fmaxf(amax, h);
+                    bx_split(h, p0[e], p1[e]);
+                }
+                const unsigned off = (unsigned)((cb * 32 + l31) * BX_XR + (32 * w + 8 * g + 4 * half) * 2);
+                bx_u32x2 u;
+                u[0] = (unsigned)p0[0] | ((unsigned)p0[1] << 16); u[1] = (unsigned)p0[2] | ((unsigned)p0[3] << 16);
+                *reinterpret_cast<bx_u32x2 *>(bl + off) = u;
+                u[0] = (unsigned)p1[0] | ((unsigned)p1[1] << 16); u[1] = (unsigned)p1[2] | ((unsigned)p1[3] << 16);
+                *reinterpret_cast<bx_u32x2 *>(bl + BX_PIECE + off) = u;
+            }
+    }
+    __syncthreads();
+    // ---- phase 3: x0 = W_out h + b: row blocks 0 .. ceil(M / 32) - 1 on waves 0 .. 2; x0 -> fp32 tile xs[96][64] (over piece 0)
+    float *xs = reinterpret_cast<float *>(bl);
+    {
+        const int rbn = (M + 31) / 32;
+        f32x16 xo[1][2];
+        xo[0][0] = (f32x16){0};
+        xo[0][1] = (f32x16){0};
+        const float inv = reinterpret_cast<const float *>(p.w_outp_x2 + ((M + 31) / 32) * (XC / 16) * 1024)[1];
+        if (w < rbn) bx_gemm<1>(xo, make_rsrc(p.w_outp_x2), lane16, w, XC / 16, XC / 16, bl, BX_PIECE, bfrag256);
+        __syncthreads();  // h tile consumed
+        if (w < 3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * w + mfma32_row(r, lane);
+                const float bias = p.b_outp[min(row, M - 1)];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) xs[row * 64 + 32 * cb + l31] = (w < rbn && row < M) ? xo[0][cb][r] * inv + bias : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 4: posterior update on quads of 4 consecutive frames (T % 4 == 0; a quad never leaves its 32-frame column block)
+    {
+        const float *cf = p.coef4 + 4 * sid;
+        const float c1 = cf[0], c2 = cf[1], sig = cf[3] * expf(0.5f * cf[2]);
+        const uint64_t qoff = (uint64_t)(k + 1) * p.quads_total + p.quads_before;
+        for (int qi = tid; qi < 96 * 16; qi += 512) {
+            const int m = qi >> 4, tq = qi & 15;
+            const X3Col c = x3_col(a, tq >> 3);
+            const int t = c.t0 + 4 * (tq & 7);
+            float *cell = xs + m * 64 + 4 * tq;
+            if (m < M && c.ok && t < T) {
+                const int64_t ub = (int64_t)c.b * M * T, i = (int64_t)m * T + t;
+                const rsrc_t rx = make_rsrc(p.x + ub);
+                const f32x4 xt = buf_load4(rx, 4u * (unsigned)i, 0u);
+                float z[4];
+                if (p.eps) {
+                    const f32x4 e4 = *reinterpret_cast<const f32x4 *>(p.eps + (int64_t)k * p.eps_ks + ub + i);
+                    z[0] = e4[0]; z[1] = e4[1]; z[2] = e4[2]; z[3] = e4[3];
+                } else {
+                    randn4(p.seed, qoff + (uint64_t)((ub + i) >> 2), z);
+                }
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float mean = c1 * cell[j] + c2 * xt[j];
+                    o[j] = mean + sig * z[j];
+                }
+                buf_store4_stream(o, rx, 4u * (unsigned)i, 0u);  // sc1: the next step's boundary of this tile may run on another XCD
+                *reinterpret_cast<f32x4 *>(cell) = o;
+            } else {
+                *reinterpret_cast<f32x4 *>(cell) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};  // K padding rows / frames >= T
+            }
+        }
+    }
+    if (last) {
+        if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    __syncthreads();
+    // ---- x' (fp32 [96][64]) -> two fp16 pieces [frame][96] in the piece-1 region: waves 0 .. 3, thread (frame f, 24 channels cg)
+    unsigned char *xp = bl + BX_PIECE;
+    constexpr unsigned XP_PIECE = 64 * BX_PR;
+    if (w < 4) {
+        const int f = lane, cg = w;
+#pragma unroll
+        for (int q8 = 0; q8 < 3; ++q8) {
+            bx_u32x4 u0, u1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned short p0[2], p1[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float x = xs[(24 * cg + 8 * q8 + 2 * e + j) * 64 + f];
+                    amax = fmaxf(amax, fabsf(x));
+                    bx_split(x, p0[j], p1[j]);
+                }
+                u0[e] = (unsigned)p0[0] | ((unsigned)p0[1] << 16);
+                u1[e] = (unsigned)p1[0] | ((unsigned)p1[1] << 16);
+            }
+            *reinterpret_cast<bx_u32x4 *>(xp + f * BX_PR + (24 * cg + 8 * q8) * 2) = u0;
+            *reinterpret_cast<bx_u32x4 *>(xp + XP_PIECE + f * BX_PR + (24 * cg + 8 * q8) * 2) = u1;
+        }
+    }
+    if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // ---- phase 5: next step's input projection xin = ReLU(W_in x' + b_in), K = M rounded up to 32 (zero padded): wave w rows [32 w ..)
+    {
+        const int ngin = ((M + 31) / 32) * 2;
+        const float inv = reinterpret_cast<const float *>(p.w_in_x2 + (XC / 32) * ngin * 1024)[1];
+        f32x16 acc[1][2];
+        acc[0][0] = (f32x16){0};
+        acc[0][1] = (f32x16){0};
+        bx_gemm<1>(acc, make_rsrc(p.w_in_x2), lane16, w, ngin, ngin, xp, XP_PIECE,
+                   [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * BX_PR + (ks * 16 + half * 8) * 2); });
+        float bin[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bin[r] = (p.b_in + 32 * w + urow(r))[4 * half];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const X3Col c = x3_col(a, cb);
+            if (c.ok && c.t0 + l31 < T) {
+                const rsrc_t ro = make_rsrc(a.xin_next + (int64_t)c.b * XC * T);
+                const unsigned so = 4u * (unsigned)(4 * half * T + c.t0 + l31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    buf_store_agent(fmaxf(acc[0][cb][r] * inv + bin[r], 0.0f), ro, so, (unsigned)(32 * w + urow(r)) * T4);
+            }
+        }
+    }
+}
+
+// the boundary's arguments live in device memory (behind the flags of sync_ws), not in the kernel argument segment: as kernel arguments
+// they were all kept in SGPRs across the task loop (160 spilled SGPRs, which pushed 25 VGPRs of the layer path into scratch)
+__global__ void store_loop_boundary_kernel(X3LoopBoundary bd, X3LoopBoundary *dst) {
+    if (threadIdx.x == 0) *dst = bd;
+}
+
+template <typename S>
+__global__ void __launch_bounds__(512, 1) diffnet_loop_x3_kernel(SetDiffnetStackArgs a, const X3LoopBoundary *bdp, int steps, int ntiles,
+                                                                  int ntasks, unsigned piece_bytes) {
+    constexpr int NU = 1, NCB = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int *s_task = reinterpret_cast<int *>(lds + S::NP * piece_bytes + NCB * XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
+    int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
+    const int tid = threadIdx.x;
+    const int L1 = a.L + 1, per_step = L1 * ntiles;
+    uint64_t tprev = 0;
+    if (tid == 0) s_task[0] = atomicAdd(counter, 1);
+    __syncthreads();
+    int n = __builtin_amdgcn_readfirstlane(s_task[0]);
+    int i_done = -1, v_done = 0;  // finished but not yet published tile of this block, and the flag value that publishes it
+    while (n < ntasks) {
+        const int k = n / per_step, r = n - k * per_step;  // executed step k (step id steps - 1 - k)
+        const int l = r / ntiles, i = r - l * ntiles;
+        const int want = k * L1 + l;
+        const bool boundary = l == a.L;
+        X3Tile lt;
+        lt.xin = (l & 1) ? a.xb : a.xa;
+        lt.xout = (l & 1) ? a.xa : a.xb;
+        lt.skp = a.skip;
+        lt.xin_next = a.xa;
+        const int lw = boundary ? 0 : l;  // (a boundary task reads none of the per-layer operands)
+        lt.cp = a.condproj + (int64_t)lw * a.cp_ls; lt.cp_bs = a.cp_bs;
+        lt.dstep = a.dstep + (int64_t)lw * a.d_ls + (steps - 1 - k); lt.d_bs = a.d_bs; lt.d_cs = a.d_cs;
+        lt.img = reinterpret_cast<const unsigned short *>(a.wx3_all) + (int64_t)lw * x_nimg<S>();
+        lt.b_dil = a.b_dil_all + (int64_t)lw * 512;
+        lt.b_out = a.b_out_all + (int64_t)lw * 512;
+        lt.err_flag = a.err_flag;
+        lt.T = a.T; lt.dil = 1 << (lw % a.dilation_cycle_length); lt.first = (l == 0);
+        lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * NCB;
+        f32x16 acc[NU][2][NCB];
+        if (!boundary) x3_init<NU, NCB>(lt, acc);  // issued before the previous tile's store drain / publish and before the dependency wait
+        __builtin_amdgcn_sched_barrier(0);
+        const int *f0 = done + i, *fl = done + (i > 0 ? i - 1 : i), *fr = done + (i < ntiles - 1 ? i + 1 : i);
+        int peek = want, claimed = 0;
+        if (tid == 0) {
+            if (want > 0) peek = min(ld_agent(f0), min(ld_agent(fl), ld_agent(fr)));
+            claimed = atomicAdd(counter, 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: the finished tile is visible to every XCD
+        if (tid == 0) {
+            if (peek >= want) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_task[0] = claimed;
+            s_task[1] = peek >= want ? 1 : 2;
+        }
+        __syncthreads();  // (also: the LDS tile is free)
+        if (tid == 0 && i_done >= 0) __hip_atomic_store(done + i_done, v_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        i_done = -1;
+        if (__builtin_amdgcn_readfirstlane(s_task[1]) == 2) {  // producers not finished at the peek: wait for them now
+            if (tid == 0) {
+                int ok = 1;
+                unsigned spins = 0;
+                for (;;) {
+                    const int v0 = ld_agent(f0), v1 = ld_agent(fl), v2 = ld_agent(fr);
+                    if (min(v0, min(v1, v2)) >= want) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > X_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
+                        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (a.err_flag) __hip_atomic_store(a.err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                s_task[2] = ok;
+            }
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(s_task[2]) == 0) break;
+        }
+        const int n_next = __builtin_amdgcn_readfirstlane(s_task[0]);
+        if (boundary)
+            x3_boundary(lt, *bdp, k, lds);
+        else
+            x3_main<S, NU, NCB>(lt, acc, lds, piece_bytes, nullptr, tprev);
+        i_done = i;
+        v_done = want + 1;
+        n = n_next;
+    }
+    // the last finished tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && i_done >= 0) __hip_atomic_store(done + i_done, v_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // =====================================================================================================================
@@ -1007,6 +1319,62 @@ int set_launch_diffnet_stack_split_x2(const SetDiffnetStackArgs &a, int fault_ti
     const int nofence = 1;
     hipLaunchKernelGGL(diffnet_stack_split_x2_kernel, dim3(4 * nt + extra), dim3(256), ldsz, s, a, tiles, nt, piece_bytes, fault_tile, nofence);
     return set_check_launch("set_diffnet_stack");
+}
+
+// The whole reverse loop in one launch (diffnet_loop_x3_kernel): called by set_diffusion_loop (csrc/diffnet.hip) for batches that take the
+// 64-frame-tile split-operand kernel with the split-operand step boundary.  `a`: the stack arguments of the loop (dstep = column 0 of
+// the [L * 256][steps] table, d_cs = steps); `lb`: csrc/diffnet.hip fills it through set_loop_x3_boundary().
+struct SetLoopX3Boundary {  // plain mirror of X3LoopBoundary for the other translation unit
+    float *x; const float *eps; int64_t eps_ks; const float *coef4; const void *w_skip_x2, *w_outp_x2, *w_in_x2;
+    const float *b_skip, *b_outp, *b_in; float div; uint64_t seed, quads_total, quads_before; int32_t M, steps;
+};
+bool set_loop_x3_usable(const SetDiffnetStackArgs &a, int n_cu) {
+    const char *e_on = getenv("SET_AMD_LOOP_LAUNCH");  // opt-in until it has been measured on the GPU
+    if (!e_on || atoi(e_on) == 0) return false;
+    if (a.x3_mode != 2) return false;  // the split-operand step boundary exists for the two-piece fp16 splitting only
+    const int64_t tiles64 = (int64_t)a.B * ((a.T + 63) / 64);
+    bool narrow = 5 * tiles64 < 3 * (int64_t)n_cu;  // the rule of set_launch_diffnet_stack_x3
+    if (const char *e = getenv("SET_AMD_X3_TILE")) narrow = atoi(e) == 32;
+    return !narrow && a.T % 4 == 0;
+}
+int set_launch_diffnet_loop_x3(const SetDiffnetStackArgs &a, const SetLoopX3Boundary &lb, int n_cu, hipStream_t s) {
+    SET_REQUIRE(a.x3_mode == 2, "set_diffusion_loop(whole-loop kernel: x3_mode)");
+    SET_REQUIRE(lb.M >= 2 && lb.M <= 96 && lb.steps >= 1 && a.T % 4 == 0, "set_diffusion_loop(whole-loop kernel: shape)");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_loop_x3_kernel<SplitF16x2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "set_diffusion_loop(loop x3 attr)");
+        attr_set = true;
+    }
+    constexpr int NCB = 2;
+    const int Q = a.B * ((a.T + 31) / 32);
+    const int ntiles = (Q + NCB - 1) / NCB;
+    const int64_t ntasks64 = (int64_t)ntiles * (a.L + 1) * lb.steps;
+    SET_REQUIRE(ntasks64 < (1ll << 30), "set_diffusion_loop(whole-loop kernel: task count)");
+    SET_REQUIRE((int64_t)2 * XC * a.T * 4 < ((int64_t)1 << 31), "set_diffusion_loop(whole-loop kernel: T too large)");
+    const int max_dil = 1 << (a.dilation_cycle_length - 1);
+    const unsigned piece_bytes = (unsigned)(NCB * (32 + 2 * max_dil) * XR);
+    SET_REQUIRE((size_t)piece_bytes >= (size_t)BX_PIECE, "set_diffusion_loop(whole-loop kernel: LDS)");
+    SET_HIP(set_zero_async(a.sync_ws, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffusion_loop(memset)");
+    int grid = n_cu;
+    if (grid > ntiles * 4 / 5) grid = ntiles * 4 / 5;
+    if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
+    if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
+    if (grid < 1) grid = 1;
+    X3LoopBoundary bd;
+    bd.x = lb.x; bd.eps = lb.eps; bd.eps_ks = lb.eps_ks; bd.coef4 = lb.coef4;
+    bd.w_skip_x2 = reinterpret_cast<const unsigned short *>(lb.w_skip_x2);
+    bd.w_outp_x2 = reinterpret_cast<const unsigned short *>(lb.w_outp_x2);
+    bd.w_in_x2 = reinterpret_cast<const unsigned short *>(lb.w_in_x2);
+    bd.b_skip = lb.b_skip; bd.b_outp = lb.b_outp; bd.b_in = lb.b_in; bd.div = lb.div;
+    bd.seed = lb.seed; bd.quads_total = lb.quads_total; bd.quads_before = lb.quads_before; bd.M = lb.M; bd.steps = lb.steps;
+    const size_t ldsz = x3_lds_bytes<SplitF16x2, NCB>(max_dil);
+    // (sync_ws holds >= 16 + 2 B ceil(T / 32) words per utterance group; the flags take 4 + ntiles of them)
+    SET_REQUIRE((int64_t)(4 + ntiles + 2) * 4 + (int64_t)sizeof(X3LoopBoundary) <= (int64_t)(16 + 2 * Q) * 4, "set_diffusion_loop(whole-loop kernel: sync_ws)");
+    X3LoopBoundary *bdp = reinterpret_cast<X3LoopBoundary *>(a.sync_ws + ((4 + ntiles + 1) & ~1));
+    hipLaunchKernelGGL(store_loop_boundary_kernel, dim3(1), dim3(64), 0, s, bd, bdp);
+    hipLaunchKernelGGL((diffnet_loop_x3_kernel<SplitF16x2>), dim3(grid), dim3(512), ldsz, s, a, bdp, lb.steps, ntiles, (int)ntasks64, piece_bytes);
+    return set_check_launch("set_diffusion_loop(whole-loop kernel)");
 }
 
 extern "C" int set_debug_x3_phase_buffer(uint64_t *buf) {

@@ -2,6 +2,8 @@
 // integer duration / pitch-bin bookkeeping, transposes.  All are tiny, HBM/latency-bound and
 // coalesced along T (the contiguous axis of the [B][C][T] layout).  Reference citations are in
 // include/set_amd.h next to each prototype.
+#include <mutex>
+
 #include "common.h"
 #include "pitch_edges.h"
 
@@ -390,12 +392,58 @@ extern "C" int set_length_regulate(const float *dur, const int64_t *txt, int64_t
 // Stream ordering for the host side's second ("leaf") stream: everything enqueued on `after` from now on waits for everything enqueued on
 // `first` so far.  One event per call site slot (created once, timing disabled), re-recorded at every call; inside a stream capture the pair
 // becomes a cross-stream edge of the graph.  Replaces torch's Event.record + Stream.wait_event (two Python -> C++ round trips per fork).
+// Events are created once per slot, on the device the slot belongs to (slot s <-> device s / 2: the host side numbers its slots 2 idx and
+// 2 idx + 1), under a mutex: the first call may come from the autograd engine's worker thread while the main thread makes its own first
+// call, and from a thread whose current device is not the stream's (round-5 advisor item).
+static hipEvent_t set_cached_event(hipEvent_t *table, int32_t slot, int32_t dev, const char *what) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    if (table[slot]) return table[slot];
+    int cur = 0, n = 0;
+    if (hipGetDevice(&cur) != hipSuccess || hipGetDeviceCount(&n) != hipSuccess) return nullptr;
+    const bool sw = dev >= 0 && dev < n && dev != cur;
+    if (sw && hipSetDevice(dev) != hipSuccess) return nullptr;
+    hipEvent_t e = nullptr;
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (sw) (void)hipSetDevice(cur);
+    if (rc != hipSuccess) {
+        (void)set_fail(SET_E_LAUNCH, what, hipGetErrorString(rc));
+        return nullptr;
+    }
+    table[slot] = e;
+    return e;
+}
+
 extern "C" int set_stream_order(void *first, void *after, int32_t slot) {
     static hipEvent_t ev[32] = {nullptr};
     SET_REQUIRE(slot >= 0 && slot < 32, "set_stream_order");
-    if (!ev[slot]) SET_HIP(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming), "set_stream_order(event)");
-    SET_HIP(hipEventRecord(ev[slot], (hipStream_t)first), "set_stream_order(record)");
-    SET_HIP(hipStreamWaitEvent((hipStream_t)after, ev[slot], 0), "set_stream_order(wait)");
+    const hipEvent_t e = ev[slot] ? ev[slot] : set_cached_event(ev, slot, slot / 2, "set_stream_order(event)");
+    SET_REQUIRE(e != nullptr, "set_stream_order(event)");
+    SET_HIP(hipEventRecord(e, (hipStream_t)first), "set_stream_order(record)");
+    SET_HIP(hipStreamWaitEvent((hipStream_t)after, e, 0), "set_stream_order(wait)");
+    return SET_OK;
+}
+
+// Progress markers of a stream (round 6): set_stream_mark records marker `slot` (0 .. 63; device `dev`) on `stream`, set_stream_mark_done
+// returns 1 once everything enqueued before that mark has finished, 0 while it has not, < 0 on error.  The leaf stream's host side uses
+// them to let go of the operands of leaf kernels that have already run instead of holding every operand of a backward pass until its end.
+static hipEvent_t g_marks[64] = {nullptr};
+extern "C" int set_stream_mark(void *stream, int32_t slot, int32_t dev) {
+    SET_REQUIRE(slot >= 0 && slot < 64, "set_stream_mark");
+    const hipEvent_t e = g_marks[slot] ? g_marks[slot] : set_cached_event(g_marks, slot, dev, "set_stream_mark(event)");
+    SET_REQUIRE(e != nullptr, "set_stream_mark(event)");
+    SET_HIP(hipEventRecord(e, (hipStream_t)stream), "set_stream_mark(record)");
+    return SET_OK;
+}
+extern "C" int set_stream_mark_done(int32_t slot) {
+    SET_REQUIRE(slot >= 0 && slot < 64 && g_marks[slot] != nullptr, "set_stream_mark_done");
+    const hipError_t rc = hipEventQuery(g_marks[slot]);
+    if (rc == hipSuccess) return 1;
+    if (rc == hipErrorNotReady) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    SET_HIP(rc, "set_stream_mark_done");
     return SET_OK;
 }
 

@@ -1261,11 +1261,10 @@ static int layernorm_ch_bwd_launch(const float *x, const float *gamma, const flo
     // blocks per CU) once they fill the chip; 16-frame tiles in 256-thread blocks for the small launches (the conditioner's text level:
     // 128 -> 224 blocks).  C > 256: 8 groups of <= 32 channels.  Alone on the GPU, both launches of a call (profiles/r05_ln_bwd_probe.log):
     // B=16 C=256 T=800 32.6 -> 22.1 us, B=32 C=192 T=800 48.7 -> 31.0 us, B=32 C=192 T=100 19.8 -> 11.0 us.
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    }
+    // The block shape (and with it the partial rows and the summation order of dgamma / dbeta) is a function of B, C and T ALONE -- 256 = the CU
+    // count of the part this is written for, as a constant: a cached per-process device query made the gradients depend on which device was
+    // current at the first call (round-5 advisor item).
+    constexpr int n_cu = 256;
     const int t32 = (T + LNB_FT - 1) / LNB_FT;
     const bool groups16 = C <= 256, big = groups16 && (int64_t)B * t32 >= n_cu;
     const int tiles = (groups16 && !big) ? (T + 15) / 16 : t32;

@@ -5,6 +5,7 @@ only; every arithmetic op below is a kernel in libset_amd.so.  All tensors must
 be fp32 (or int64 for indices), contiguous, on a HIP device.  Nothing here has a
 CPU implementation: calling an op without the library / without a GPU raises.
 """
+import collections
 import ctypes as C
 import math
 import os
@@ -85,7 +86,7 @@ def repack_bf16_images():
 
 
 _F32_IMAGES = weakref.WeakSet()    # ConvWeights that hold an fp32 image (set_pack_conv_weight / _v2)
-_F32_BATCH = [None, None, 0]       # (signature, device descriptor table, total elements) of the last batch re-pack
+_F32_TABLES = collections.OrderedDict()  # signature -> (device descriptor table, total elements, pinned host copy): the last few batch re-packs
 
 
 def repack_f32_images():
@@ -109,9 +110,16 @@ def repack_f32_images():
     ws = [it[0].raw() for it in items]
     dev = ws[0].device
     keep = [i for i, w in enumerate(ws) if w.device == dev and items[i][3].device == dev]
-    items, ws = [items[i] for i in keep], [ws[i] for i in keep]
+    # a deterministic order (the WeakSet's iteration order changes with the set of live images) and a small cache of tables: bucketed
+    # ragged batches alternate between a few sets of used images (packed() vs packed_v2() by T) -- each set's table is built and uploaded
+    # once, from pinned memory without a host sync (round-5 advisor item)
+    order = sorted(range(len(keep)), key=lambda j: (items[keep[j]][3].data_ptr(), items[keep[j]][1], str(items[keep[j]][2])))
+    items, ws = [items[keep[j]] for j in order], [ws[keep[j]] for j in order]
     sig = tuple((id(it[0]), it[1], it[2], w.data_ptr(), it[3].data_ptr()) for it, w in zip(items, ws))
-    if _F32_BATCH[0] != sig:
+    ent = _F32_TABLES.get(sig)
+    if ent is not None:
+        _F32_TABLES.move_to_end(sig)
+    else:
         arr = (_lib.SetPackF32Desc * len(items))()
         start = 0
         for d, (cw, kind, slot, wp, dil), w in zip(arr, items, ws):
@@ -121,9 +129,13 @@ def repack_f32_images():
             n = _lib.lib().set_fill_pack_f32_desc(C.byref(d), kind, int(dil))
             assert n == wp.numel(), (n, wp.numel(), kind)
             start += n
-        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-        _F32_BATCH[0], _F32_BATCH[1], _F32_BATCH[2] = sig, raw, start
-    check(_lib.lib().set_pack_conv_weights_f32_batch(C.c_void_p(_F32_BATCH[1].data_ptr()), len(items), _F32_BATCH[2], _stream()),
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        if dev.type == "cuda":
+            host = host.pin_memory()
+        ent = _F32_TABLES[sig] = (host.to(dev, non_blocking=True), start, host)
+        while len(_F32_TABLES) > 8:
+            _F32_TABLES.popitem(last=False)
+    check(_lib.lib().set_pack_conv_weights_f32_batch(C.c_void_p(ent[0].data_ptr()), len(items), ent[1], _stream()),
           "set_pack_conv_weights_f32_batch")
     for (cw, kind, slot, wp, dil), w in zip(items, ws):
         key = (w.data_ptr(), w._version, w.device, _WEIGHTS_EPOCH)

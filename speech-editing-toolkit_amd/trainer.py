@@ -133,9 +133,13 @@ class Trainer:
                 if unit not in ("updates", "batches"):
                     n_opt = int(getattr(self.optimizer, "num_updates", -1))
                     a = self.accumulate_grad_batches
-                    if n_opt > 0 and n_opt == self.global_step:
+                    # the reference steps its optimizer exactly floor(N / a) times for N batches (utils/commons/trainer.py:366): only that
+                    # count means "batches"; when BOTH readings fit (tiny global_step) the run is refused like any other ambiguous one
+                    fits_updates = n_opt > 0 and n_opt == self.global_step
+                    fits_batches = n_opt > 0 and n_opt == self.global_step // a
+                    if fits_updates and not fits_batches:
                         unit = "updates"
-                    elif n_opt > 0 and n_opt in (self.global_step // a, (self.global_step + a - 1) // a):
+                    elif fits_batches and not fits_updates:
                         unit = "batches"
                     else:
                         raise RuntimeError(

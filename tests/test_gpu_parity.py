@@ -1212,6 +1212,91 @@ def test_full_size_100_steps_split_operand_vs_fp32_pipe(dev, monkeypatch):
 
 
 # ----------------------------------------------------------------------------------------------------
+# round 6: the metric's own shape against the REFERENCE (tests/golden/infer_full800.npz: T = 800, T_txt = 100, 100 steps, B = 2 with one
+# padded tail, generated by oracle/make_golden.full800_case from /root/reference; spec_denoiser.py:178-184)
+# ----------------------------------------------------------------------------------------------------
+FULL800_PATHS = {
+    "default": {},                                                                                   # B = 2: row-split f16x2 kernel
+    "f16x2": {"SET_AMD_X3": "2", "SET_AMD_SPLIT": "0", "SET_AMD_SPLIT_OPERAND": "f16x2"},            # throughput kernel, 64-frame tiles
+    "bf16x3": {"SET_AMD_X3": "2", "SET_AMD_SPLIT": "0", "SET_AMD_SPLIT_OPERAND": "bf16x3"},
+    "winograd": {"SET_AMD_WINO": "2"},                                                               # fp32 MFMA pipe
+}
+
+
+def _full800(dev):
+    g = load_golden("infer_full800")
+    m = g["meta"]
+    assert (m["B"], m["T"], m["steps"]) == (2, 800, 100)
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"], **m["overrides"])
+    inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=True)
+    noises = torch.stack(Wt.synthetic_noises(m["B"], m["T"], m["steps"], seed=m["iseed"] + 1))
+    return g, model, inp, noises
+
+
+def _run800(model, inp, noises, dev, **kw):
+    d = {k: v.to(dev) for k, v in inp.items()}
+    ret = model(d["txt_tokens"], d["time_mel_masks"], d["mel2ph"], d["spk_embed"], d["ref_mels"], d["f0"], d["uv"], infer=True,
+                noises=noises.to(dev), **kw)
+    torch.cuda.synchronize()
+    return ret
+
+
+@pytest.mark.parametrize("path", sorted(FULL800_PATHS))
+def test_full800_100_steps_matches_reference(dev, monkeypatch, path):
+    """13 tiles of 64 frames per utterance, the halo hand-off between them exercised over all 100 steps, on every stack kernel family:
+    |dmel| < 1e-4 against the reference's own output, integer tensors bit-exact."""
+    for k, v in FULL800_PATHS[path].items():
+        monkeypatch.setenv(k, v)
+    g, model, inp, noises = _full800(dev)
+    ret = _run800(model, inp, noises, dev, **({} if path == "default" else {"persistent": True}))
+    for k in ("mel2ph", "masked_dur", "pitch", "masked_pitch"):
+        assert torch.equal(ret[k].cpu(), torch.from_numpy(g[k])), k
+    d = _maxdiff(ret["mel_out"], g["mel_out"])
+    mcd = O.mel_mcd(ret["mel_out"].cpu().numpy(), g["mel_out"])
+    print("infer_full800 [%s]: max|dmel| = %.3e  mel-MCD = %.3e" % (path, d, mcd))
+    assert d < 1e-4 and mcd < 1e-3
+
+
+def test_full800_inside_a_batch_of_32_matches_reference(dev):
+    """The same two utterances as rows 5 and 18 of a B = 32 batch -- the metric's configuration: the throughput kernel on 64-frame tiles cut
+    from the batch's block list (400 tiles, several of them straddling two utterances), 100 steps.  The rows must still match the
+    reference's output for those utterances (< 1e-4), and the other 30 rows must not matter."""
+    from set_amd import ops
+    g, model, inp2, noises2 = _full800(dev)
+    B, T, Tt, steps = 32, 800, 100, 100
+    rows = [5, 18]
+    inp = Wt.synthetic_inputs(B, T, Tt, seed=9001, pad_tail=True)
+    for k in inp:
+        inp[k][rows] = inp2[k]
+    gen = torch.Generator(device=dev).manual_seed(9002)
+    noises = torch.randn(steps + 1, B, 1, 80, T, device=dev, generator=gen)
+    noises[:, rows] = noises2.to(dev)
+    assert ops.stack_variant(B, T, 1) == 5
+    ret = _run800(model, inp, noises, dev)
+    for k in ("mel2ph", "masked_dur", "pitch", "masked_pitch"):
+        assert torch.equal(ret[k][rows].cpu(), torch.from_numpy(g[k])), k
+    d = _maxdiff(ret["mel_out"][rows], g["mel_out"])
+    mcd = O.mel_mcd(ret["mel_out"][rows].cpu().numpy(), g["mel_out"])
+    print("infer_full800 inside B=32: max|dmel| = %.3e  mel-MCD = %.3e" % (d, mcd))
+    assert d < 1e-4 and mcd < 1e-3
+    assert torch.isfinite(ret["mel_out"]).all()
+
+
+@pytest.mark.parametrize("row", [0, 1])
+def test_full800_single_utterance_matches_reference(dev, row):
+    """BASELINE configs[0]'s shape on the GPU: ONE utterance, T = 800, 100 steps, through the kernel a batch of one selects (row-split)."""
+    from set_amd import ops
+    g, model, inp, noises = _full800(dev)
+    assert ops.stack_variant(1, 800, 1) != 5
+    one = {k: v[row:row + 1].contiguous() for k, v in inp.items()}
+    ret = _run800(model, one, noises[:, row:row + 1].contiguous(), dev)
+    assert torch.equal(ret["mel2ph"].cpu(), torch.from_numpy(g["mel2ph"][row:row + 1]))
+    d = _maxdiff(ret["mel_out"], g["mel_out"][row:row + 1])
+    print("infer_full800 row %d alone: max|dmel| = %.3e" % (row, d))
+    assert d < 1e-4
+
+
+# ----------------------------------------------------------------------------------------------------
 # ragged / extreme shapes vs the oracle (no golden: the oracle itself is pinned by tests/test_oracle_golden.py)
 # ----------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,T,Tt,steps,pad", [(1, 5, 2, 3, False), (2, 31, 7, 2, True), (1, 33, 9, 2, False),

@@ -51,6 +51,25 @@ def test_oracle_infer_matches_reference(case, manifest):
     assert np.array_equal(ret["pitch"].numpy(), g["pitch"])
 
 
+def test_oracle_full800_100_steps_matches_reference():
+    """The metric's own shape run by the reference (round 6): T = 800, T_txt = 100, 100 steps, B = 2 with one padded tail.  The light fixture
+    keeps mel_out, the integer tensors and every 8th frame of the x traces of steps 0 / 50 / 99 (spec_denoiser.py:178-184)."""
+    g = load_golden("infer_full800")
+    m = g["meta"]
+    assert (m["B"], m["T"], m["T_txt"], m["steps"], m["light_stride"]) == (2, 800, 100, 100, 8)
+    W = Wt.seeded_weights(Wt.load_manifest("spec_denoiser"), m["wseed"])
+    inp = Wt.synthetic_inputs(m["B"], m["T"], m["T_txt"], seed=m["iseed"], pad_tail=True)
+    noises = Wt.synthetic_noises(m["B"], m["T"], m["steps"], seed=m["iseed"] + 1)
+    trace = []
+    ret = O.gaussian_diffusion_infer(W, m["steps"], inp, noises, trace=trace)
+    assert np.abs(ret["mel_out"].numpy() - g["mel_out"]).max() < TOL
+    for k in ("mel2ph", "masked_dur", "pitch", "masked_pitch"):
+        assert np.array_equal(ret[k].numpy(), g[k]), k
+    for k in (0, 50, 99):
+        assert np.abs(trace[k][0].numpy()[..., ::8] - g["x0_step%d" % k]).max() < TOL
+        assert np.abs(trace[k][1].numpy()[..., ::8] - g["x_step%d" % k]).max() < TOL
+
+
 def test_oracle_train_branch():
     g = load_golden("train_tiny")
     m = g["meta"]
