@@ -61,8 +61,10 @@ _ACTIVE = [None]    # the arena of the optimisation step in progress (steps do n
 # d_o and dy of 20 layers (2.1 GB at B = 32, T = 800) alive that way, growing with depth.  After every ~SET_AMD_LEAF_MARK_MB (128) MB of newly
 # held operands a marker event is recorded on the leaf stream (set_stream_mark); at the next fork the markers that have completed
 # (set_stream_mark_done, a non-blocking query) release everything held before them: those kernels have RUN, so whoever gets the storage
-# next cannot race them.  Above SET_AMD_LEAF_KEEP_MB (2048) MB of held operands the compute stream is made to wait for the leaf stream
-# (an early leaf_join) -- a bound, not the normal path.
+# next cannot race them.  Above SET_AMD_LEAF_KEEP_MB (4096) MB of held operands the compute stream is made to wait for the leaf stream
+# (an early leaf_join) -- the bound; not the normal path at the benchmark shapes (fp32 step at B = 32, T = 800: 2.5 GB at the peak, no early
+# join).  Measured (profiles/r06_leaf_operands.log): the lowest-priority leaf stream runs late, so markers rarely complete inside a
+# backward pass -- it is the cap that bounds the memory; with a 64 MB cap the step joins 26 times and stays bit-identical.
 _LEAF = {}  # device index -> {"stream" (torch object, kept alive), "raw" (handle), "dirty", "keep" (operands of queued leaf kernels), ...}
 _LEAF_STATS = {"max_keep_bytes": 0, "released_by_marker": 0, "early_joins": 0}
 
@@ -147,7 +149,7 @@ def _leaf_state(dev):
         stream = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
         st = _LEAF[idx] = {"stream": stream, "raw": raw, "dirty": False, "keep": collections.deque(), "idx": idx,
                            "marks": collections.deque(), "count": 0, "base": 0, "bytes": 0, "unmarked": 0,
-                           "mark_bytes": _mb_env("SET_AMD_LEAF_MARK_MB", 128), "cap_bytes": _mb_env("SET_AMD_LEAF_KEEP_MB", 2048)}
+                           "mark_bytes": _mb_env("SET_AMD_LEAF_MARK_MB", 128), "cap_bytes": _mb_env("SET_AMD_LEAF_KEEP_MB", 4096)}
     return st
 
 

@@ -690,7 +690,15 @@ struct X3LoopBoundary {
 // the step boundary of one 64-frame tile (two 32-frame column blocks, each with its own utterance) by an 8-wave block; bl: >= 2 BX_PIECE
 // bytes of LDS.  Arithmetic = diffnet_boundary_x2_kernel's (same images, same k-step order per accumulator, same posterior formula and
 // Philox quads), frames addressed through the column blocks; everything another CU will read is stored agent-scope (write-through).
-__device__ __forceinline__ void x3_boundary(const X3Tile &a, const X3LoopBoundary &p, int k, unsigned char *bl) {
+// NOT inlined: inlined into the task loop, its address arithmetic was hoisted in front of the loop and pushed the layer path (235 VGPRs in
+// diffnet_stack_x3_kernel) over the 256 registers of a two-waves-per-SIMD block -- 21 - 25 spilled VGPRs with reloads inside the layer task.
+// As a call, the layer path keeps its allocation and only the boundary path (1 task in L + 1) pays for saved registers.  Scalars by value:
+// a struct by reference would be written to scratch in front of every task.
+__device__ __noinline__ void x3_boundary(const float *skp, float *xin_next, int32_t *err_flag, int T_, int q0, int nbu, int Q,
+                                         const X3LoopBoundary *pp, int k, unsigned char *bl) {
+    X3Tile a;
+    a.skp = const_cast<float *>(skp); a.xin_next = xin_next; a.err_flag = err_flag; a.T = T_; a.q0 = q0; a.nbu = nbu; a.Q = Q;
+    const X3LoopBoundary &p = *pp;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -955,7 +963,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_loop_x3_kernel(SetDiffnetStack
         }
         const int n_next = __builtin_amdgcn_readfirstlane(s_task[0]);
         if (boundary)
-            x3_boundary(lt, *bdp, k, lds);
+            x3_boundary(lt.skp, lt.xin_next, lt.err_flag, lt.T, lt.q0, lt.nbu, lt.Q, bdp, k, lds);
         else
             x3_main<S, NU, NCB>(lt, acc, lds, piece_bytes, nullptr, tprev);
         i_done = i;

@@ -1296,6 +1296,60 @@ def test_full800_single_utterance_matches_reference(dev, row):
     assert d < 1e-4
 
 
+@pytest.mark.parametrize("noise", ["explicit", "philox"])
+def test_whole_loop_launch_equals_per_step_launches(dev, monkeypatch, noise):
+    """Round 6: the reverse loop as ONE launch (step boundaries as tasks of the persistent queue, csrc/diffnet_x3.hip diffnet_loop_x3_kernel)
+    against the per-step launches (stack + boundary kernel per step) at the metric's batch shape, 7 steps, explicit and Philox noise: the same
+    images, the same products in the same order per accumulator, the same posterior arithmetic and Philox quads -> bit-identical mels; twice
+    the same -> deterministic; and against the CPU oracle on two utterances (explicit noise)."""
+    from set_amd import ops
+    B, T, Tt, steps = 32, 800, 100, 7
+    model, W = _build_model(dev, "spec_denoiser", 61, steps)
+    inp = Wt.synthetic_inputs(B, T, Tt, seed=5151, pad_tail=True)
+    di = {k: v.to(dev) for k, v in inp.items()}
+    noises = torch.stack(Wt.synthetic_noises(B, T, steps, seed=5152)).to(dev) if noise == "explicit" else None
+    assert ops.stack_variant(B, T, 1) == 5
+
+    def run():
+        ret = model(di["txt_tokens"], di["time_mel_masks"], di["mel2ph"], di["spk_embed"], di["ref_mels"], di["f0"], di["uv"], infer=True,
+                    noises=noises, seed=11, want_layer_spans=True)
+        torch.cuda.synchronize()
+        return ret
+
+    monkeypatch.setenv("SET_AMD_LOOP_LAUNCH", "0")
+    per_step = run()
+    monkeypatch.setenv("SET_AMD_LOOP_LAUNCH", "1")
+    whole, again = run(), run()
+    assert torch.isfinite(whole["mel_out"]).all()
+    assert torch.equal(whole["mel_out"], again["mel_out"])
+    assert torch.equal(whole["mel_out"], per_step["mel_out"])
+    # the whole-loop launch reports one launch's share per step: equal spans, and fewer milliseconds than the per-step path's spans + boundaries
+    assert len(whole["layer_span_ms"]) == steps and max(whole["layer_span_ms"]) - min(whole["layer_span_ms"]) < 1e-6
+    if noise == "explicit":
+        rows = [3, 31]
+        sub = {k: v[rows] for k, v in inp.items()}
+        oret = O.gaussian_diffusion_infer(W, steps, sub, [n[rows].cpu() for n in noises])
+        assert _maxdiff(whole["mel_out"][rows], oret["mel_out"]) < 1e-4
+
+
+def test_whole_loop_launch_full800_reference_rows(dev, monkeypatch):
+    """infer_full800 (the reference's own T = 800 x 100-step output) as rows 5 and 18 of a B = 32 batch through the whole-loop launch."""
+    monkeypatch.setenv("SET_AMD_LOOP_LAUNCH", "1")
+    g, model, inp2, noises2 = _full800(dev)
+    rows = [5, 18]
+    inp = Wt.synthetic_inputs(32, 800, 100, seed=9001, pad_tail=True)
+    for k in inp:
+        inp[k][rows] = inp2[k]
+    gen = torch.Generator(device=dev).manual_seed(9002)
+    noises = torch.randn(101, 32, 1, 80, 800, device=dev, generator=gen)
+    noises[:, rows] = noises2.to(dev)
+    ret = _run800(model, inp, noises, dev, want_layer_spans=True)
+    assert max(ret["layer_span_ms"]) - min(ret["layer_span_ms"]) < 1e-6  # (one launch: every step reports its share)
+    d = _maxdiff(ret["mel_out"][rows], g["mel_out"])
+    print("infer_full800 inside B=32, whole-loop launch: max|dmel| = %.3e" % d)
+    assert d < 1e-4
+
+
 # ----------------------------------------------------------------------------------------------------
 # ragged / extreme shapes vs the oracle (no golden: the oracle itself is pinned by tests/test_oracle_golden.py)
 # ----------------------------------------------------------------------------------------------------

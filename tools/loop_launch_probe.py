@@ -1,0 +1,59 @@
+"""Round 6 A/B: the reverse loop of the metric's configuration (B = 32, T = 800, 100 steps, Philox noise) as ONE launch (SET_AMD_LOOP_LAUNCH=1:
+step boundaries as tasks of the persistent queue, csrc/diffnet_x3.hip) against the per-step launches (stack + boundary + flag reset per step),
+with socket power / shader clock sampled over each sustained run (hwmon, tools/power_probe.py) and a bit-for-bit comparison of the mels.
+usage: python tools/loop_launch_probe.py [seconds per variant (default 6)] [extra variants: grid=<n> ...]"""
+import json, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench  # noqa: E402
+from power_probe import Sampler, hwmon_files  # noqa: E402
+from set_amd.synthetic import synthetic_inputs  # noqa: E402
+
+torch.set_grad_enabled(False)
+dev = torch.device("cuda:0")
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 6.0
+model = bench.build_model(dev, bench.DIFF_STEPS)
+inp = {k: v.to(dev) for k, v in synthetic_inputs(bench.B_PER_GPU, bench.T, bench.T_TXT, seed=1234).items()}
+
+
+def step(seed, spans=False):
+    return model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"], inp["uv"], infer=True,
+                 seed=seed, want_layer_spans=spans)
+
+
+files = hwmon_files()
+variants = [("per_step_launches", {"SET_AMD_LOOP_LAUNCH": "0"}), ("whole_loop_launch", {"SET_AMD_LOOP_LAUNCH": "1"})]
+for a in sys.argv[2:]:
+    if a.startswith("grid="):
+        variants.append(("whole_loop_launch_grid%s" % a[5:], {"SET_AMD_LOOP_LAUNCH": "1", "SET_AMD_STACK_GRID": a[5:]}))
+mels = {}
+for name, env in variants:
+    for k in ("SET_AMD_LOOP_LAUNCH", "SET_AMD_STACK_GRID"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    for w in range(2):
+        mels[name] = step(7)["mel_out"].clone()
+    torch.cuda.synchronize()
+    smp = Sampler(files)
+    smp.start()
+    t0, n, loop_ms = time.perf_counter(), 0, []
+    while time.perf_counter() - t0 < secs:
+        ret = step(100 + n, spans=True)
+        loop_ms.append(ret["loop_ms"])
+        n += 1
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    smp.stop_flag = True
+    smp.join()
+    rows = smp.rows[len(smp.rows) // 4:]  # drop the ramp
+    pw = [r.get("power1_average", r.get("power1_input", 0.0)) / 1e6 for r in rows]
+    fq = [r.get("freq1_input", 0.0) / 1e6 for r in rows]
+    out = {"variant": name, "loops": n, "ms_per_100_steps_wall": 1e3 * wall / n, "loop_ms_events_mean": sum(loop_ms) / len(loop_ms),
+           "frames_per_s_wall": bench.B_PER_GPU * bench.T * n / wall, "power_w_mean": sum(pw) / max(1, len(pw)), "power_w_max": max(pw or [0]),
+           "sclk_mhz_mean": sum(fq) / max(1, len(fq)), "span_ms_mean": sum(ret["layer_span_ms"]) / len(ret["layer_span_ms"])}
+    print(json.dumps(out), flush=True)
+base = mels["per_step_launches"]
+for name, m in mels.items():
+    print("%-28s bit-identical to the per-step launches: %s  (max |d| %.3e)" % (name, bool(torch.equal(m, base)), float((m - base).abs().max())))
