@@ -410,6 +410,10 @@ def run_infer(args, rank, world, dev):
         executed_ratio, pipe_peak, pipe = 6.0, PEAK_BF16_MFMA_TFLOPS, "v_mfma_f32_32x32x16_bf16"
     elif persistent and variant == 5:
         executed_ratio, pipe_peak, pipe = 3.0, PEAK_BF16_MFMA_TFLOPS, "v_mfma_f32_32x32x16_f16"
+    x3w = bool(persistent and variant == 5 and ops.stack_x3_winograd(B_PER_GPU // groups, T, model.denoise_fn.dilation_cycle_length))
+    if x3w:  # round 6: GEMM 1 of the two-piece fp16 kernel in its Winograd F(2,3) form: 3/4 of the layer's MFMAs are issued
+        stack_kernel = "diffnet_stack_x3w_kernel (SplitF16x2, Winograd F(2,3) form of GEMM 1)"
+        executed_ratio = 3.0 * (512 * 512 + 512 * 256) / (512 * 768 + 512 * 256)
     split_operands = persistent and variant in (4, 5)
     layers_per_launch = L if persistent else 1
     launch_ms = sum(spans) / len(spans) / (L // layers_per_launch)
@@ -422,9 +426,9 @@ def run_infer(args, rank, world, dev):
     # WRITE_SIZE per MI355X_MICROARCH.md).  Counters cannot be collected inside this process, so the figure is the one measured
     # on the SAME kernel sources: the file carries their sha256 and the figure is withheld (null) when the sources changed since.
     traffic, traffic_note, pmc = None, None, None
-    tfile = os.path.join(ROOT, "profiles", "r05_pmc_x3.json")
+    tfile = os.path.join(ROOT, "profiles", "r06_pmc_x3.json")
     if not os.path.exists(tfile):
-        tfile = os.path.join(ROOT, "profiles", "r04_pmc_x3.json")
+        tfile = os.path.join(ROOT, "profiles", "r05_pmc_x3.json")
     tname = os.path.relpath(tfile, ROOT)
     if os.path.exists(tfile) and persistent and variant in (4, 5):
         import hashlib
@@ -434,7 +438,7 @@ def run_infer(args, rank, world, dev):
         for src in tj.get("kernel_sources", []):
             with open(os.path.join(ROOT, src), "rb") as f:
                 h.update(f.read())
-        ent = tj.get("diffnet_stack_x3_kernel<%s>" % ("SplitF16x2" if variant == 5 else "SplitBf16x3"))
+        ent = tj.get("diffnet_stack_x3w_kernel" if x3w else "diffnet_stack_x3_kernel<%s>" % ("SplitF16x2" if variant == 5 else "SplitBf16x3"))
         if ent is not None and h.hexdigest() == tj.get("kernel_source_sha256"):
             traffic, pmc = ent["traffic_bytes"], ent
             traffic_note = "PMC passes of this kernel build (%s, source sha256 matches)" % tname
@@ -483,13 +487,18 @@ def run_infer(args, rank, world, dev):
                               "(2.4 GHz max; profiles/r04_power.log); a bare v_mfma_f32_32x32x16_f16 loop on the same box reaches "
                               "1,836 TFLOP/s at 1.29 kW, 1,356 TFLOP/s with this kernel's weight-fragment stream from L2 "
                               "(profiles/r04_mfma_ceiling.log); removing the kernel's ring stalls (round 4) lowered the clock from "
-                              "2.00 to 1.86 GHz and the time by 1.4 %",
+                              "2.00 to 1.86 GHz and the time by 1.4 %; round 6 (profiles/r06_*_ab.log, power and clock per variant): the whole "
+                              "loop as one launch -2.3 %, XCD-aware task claiming -2.7 %, next-task prefetch -1.1 % -- only fewer matrix "
+                              "instructions moved it: the Winograd form of GEMM 1 (3/4 of the MFMAs) +2.8 % at 20-30 W less",
                      "note": (("fp32-equivalent results from 16-bit MFMAs.  f16x2: every fp32 operand is carried as TWO fp16 pieces "
                                "(11 + 11 = 22 significand bits, 2 fewer than fp32's 24) and a product is a0 b0 + a0 b1 + a1 b0 -- "
                                "the a1 b1 term (~2^-22 |ab|) is dropped; fp32 accumulation.  " if variant == 5 else
                                "fp32-equivalent results from 16-bit MFMAs.  bf16x3: every fp32 operand is the sum of THREE bf16 "
                                "pieces (8 + 8 + 8 = 24 significand bits) and a product is the six cross terms down to 2^-16; fp32 "
                                "accumulation.  ") +
+                              + ("GEMM 1 (the k = 3 dilated conv) runs in its Winograd F(2,3) form over output pairs on the same two-piece "
+                                 "operands (tests ::test_x3w_*: error against fp64 within 2 x the fp32 chain's, the T = 800 x 100-step reference "
+                                 "golden at 1.7e-6).  " if x3w else "") +
                               "Asserted: error of a layer stack against fp64 <= 1.5 x the native fp32-MFMA chain's "
                               "(tests/test_gpu_parity.py::test_x3_stack_matches_fp32_stack_and_fp64), the reference goldens incl. "
                               "the 100-step drift case at |dmel| ~1.2e-6 through this kernel (::test_full_inference_*split_operand*). "

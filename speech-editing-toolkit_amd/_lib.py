@@ -225,6 +225,7 @@ SIGNATURES = {
     "set_pack_diffnet_layer": (C.c_int, [_V, _V, _V, _V, _V]),
     "set_pack_diffnet_layers": (C.c_int, [_V, _V, _I64, _I64, _V, _V, _V, _V, _I32, _V]),
     "set_diffnet_stack_variant": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "set_diffnet_stack_x3_winograd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "set_packed_conv_weight_x2_size": (C.c_int64, [_I32, _I32, _I32]),
     "set_pack_conv_weight_x2": (C.c_int, [_V, _V, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I32, _V]),
     "set_conv_x2_range_flag": (C.c_int, [C.POINTER(C.c_int32), _I32]),

@@ -1150,6 +1150,14 @@ extern "C" int set_diffnet_stack_variant(int B, int T, int dilation_cycle_length
 }
 
 int set_launch_diffnet_stack_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s);  // csrc/diffnet_x3.hip
+bool set_x3_winograd_selected(int x3_mode, int B, int T, int dilation_cycle_length, int n_cu);               // csrc/diffnet_x3.hip
+extern "C" int set_diffnet_stack_x3_winograd(int B, int T, int dilation_cycle_length, int images) {
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int x3_mode = (images & 4) ? 3 : ((images & 8) ? 2 : 0);
+    if (stack_variant(B, T, dilation_cycle_length, (images & 1) != 0, (images & 2) != 0, x3_mode, n_cu) != 5) return 0;
+    return set_x3_winograd_selected(x3_mode, B, T, dilation_cycle_length, n_cu) ? 1 : 0;
+}
 int set_launch_diffnet_stack_split_x2(const SetDiffnetStackArgs &a, int fault_tile, hipStream_t s);      // csrc/diffnet_x3.hip
 
 extern "C" int set_diffnet_stack(const SetDiffnetStackArgs *args, void *stream) {
@@ -1836,16 +1844,8 @@ static int aux_stream(int i, hipStream_t *out) {
     return SET_OK;
 }
 
-// csrc/diffnet_x3.hip: the whole reverse loop of a group as ONE launch (step boundaries as tasks of the persistent queue)
-struct SetLoopX3Boundary {
-    float *x; const float *eps; int64_t eps_ks; const float *coef4; const void *w_skip_x2, *w_outp_x2, *w_in_x2;
-    const float *b_skip, *b_outp, *b_in; float div; uint64_t seed, quads_total, quads_before; int32_t M, steps;
-};
-bool set_loop_x3_usable(const SetDiffnetStackArgs &a, int n_cu);
-int set_launch_diffnet_loop_x3(const SetDiffnetStackArgs &a, const SetLoopX3Boundary &lb, int n_cu, hipStream_t s);
-
-// enqueue the chain of one utterance group [b0, b0+Bg) on stream s; *whole_loop = the group ran as one launch (ev[0], ev[1] bracket it)
-static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipStream_t s, hipEvent_t *ev, bool *whole_loop) {
+// enqueue the chain of one utterance group [b0, b0+Bg) on stream s
+static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipStream_t s, hipEvent_t *ev) {
     const int T = a.T, M = a.M, L = a.L;
     const int64_t per_batch = (int64_t)M * T;
     float *x = a.x + (int64_t)b0 * per_batch;
@@ -1868,45 +1868,16 @@ static int diffusion_chain(const SetDiffLoopArgs &a, int g, int b0, int Bg, hipS
         SET_HIP(hipDeviceGetAttribute(&n_cu_chain, hipDeviceAttributeMultiprocessorCount, dev), "set_diffusion_loop");
     }
     bool boundary_x2 = false;
-    int v = -1;
     if (a.persistent && !bf16_loop && fused_boundary && a.w_skip_x2 && a.w_outp_x2 && a.w_in_x2 && a.wx3_all && a.x3_mode == 2 &&
         a.M <= 96) {
-        v = stack_variant(Bg, T, a.dilation_cycle_length, a.w1w_all && a.w2w_all, a.w1s_all && a.w2s_all && a.z_ws,
-                          a.x3_mode, n_cu_chain);
+        const int v = stack_variant(Bg, T, a.dilation_cycle_length, a.w1w_all && a.w2w_all, a.w1s_all && a.w2s_all && a.z_ws,
+                                    a.x3_mode, n_cu_chain);
         boundary_x2 = v == 5 || (v == 3 && !(getenv("SET_AMD_SPLIT_F32") && atoi(getenv("SET_AMD_SPLIT_F32")) != 0));
     }
     // the bf16-operand loop takes the split-operand boundary whenever its images are given (round 4: 85 -> 37 us per step at B = 32,
     // T = 800; it is the fp32-equivalent one, and it raises the same range word, which the caller must read)
     if (bf16_loop && fused_boundary && a.w_skip_x2 && a.w_outp_x2 && a.w_in_x2 && a.M <= 96) boundary_x2 = true;
     if (const char *e = getenv("SET_AMD_BOUNDARY_X2")) boundary_x2 = boundary_x2 && atoi(e) != 0;
-    if (whole_loop) *whole_loop = false;
-    // ---- the whole loop as ONE launch (round 6): the throughput kernel on 64-frame tiles with the split-operand boundary as a task of its
-    //      queue; bit-identical to the per-step launches below (SET_AMD_LOOP_LAUNCH=0 keeps those)
-    if (v == 5 && boundary_x2 && !bf16_loop && a.persistent) {
-        SetDiffnetStackArgs sa = {};
-        sa.xa = ws_x0; sa.xb = ws_x1; sa.skip = ws_skip;
-        sa.condproj = condproj; sa.cp_bs = (int64_t)L * 512 * T; sa.cp_ls = (int64_t)512 * T;
-        sa.dstep = a.dstep; sa.d_bs = 0; sa.d_cs = a.steps; sa.d_ls = (int64_t)DC * a.steps;
-        sa.b_dil_all = a.b_dil_all; sa.b_out_all = a.b_out_all; sa.wx3_all = a.wx3_all; sa.x3_mode = a.x3_mode;
-        sa.err_flag = a.err_flag; sa.sync_ws = sync_ws;
-        sa.B = Bg; sa.T = T; sa.L = L; sa.dilation_cycle_length = a.dilation_cycle_length;
-        if (set_loop_x3_usable(sa, n_cu_chain)) {
-            SetConv1dArgs cin = conv1x1_args(x, a.w_in_p, a.b_in, ws_x0, Bg, M, DC, T);  // step 0's input projection (diffnet.py:118-120)
-            cin.act = SET_ACT_RELU;
-            rc = set_conv1d(&cin, s);
-            if (rc != SET_OK) return rc;
-            SetLoopX3Boundary lb = {};
-            lb.x = x; lb.eps = a.noise ? a.noise + (int64_t)b0 * per_batch : nullptr; lb.eps_ks = (int64_t)a.B * per_batch;
-            lb.coef4 = a.coef4; lb.w_skip_x2 = a.w_skip_x2; lb.w_outp_x2 = a.w_outp_x2; lb.w_in_x2 = a.w_in_x2;
-            lb.b_skip = a.b_skip; lb.b_outp = a.b_outp; lb.b_in = a.b_in; lb.div = sqrtf((float)L);
-            lb.seed = a.seed; lb.quads_total = quads_total; lb.quads_before = quads_before; lb.M = M; lb.steps = a.steps;
-            if (ev) (void)hipEventRecord(ev[0], s);
-            rc = set_launch_diffnet_loop_x3(sa, lb, n_cu_chain, s);
-            if (ev) (void)hipEventRecord(ev[1], s);
-            if (whole_loop) *whole_loop = true;
-            return rc;
-        }
-    }
     for (int k = 0; k < a.steps && rc == SET_OK; ++k) {
         const int sid = a.steps - 1 - k;  // diffusion step id t = steps-1 .. 0 (spec_denoiser.py:181)
         // input projection + ReLU (diffnet.py:118-120); with the fused boundary it is part of the previous step's
@@ -2040,9 +2011,8 @@ extern "C" int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream) {
         (void)hipEventRecord(loop_ev[0], s);
     }
     int rc = SET_OK;
-    bool whole[8] = {false, false, false, false, false, false, false, false};
     if (G == 1) {
-        rc = diffusion_chain(a, 0, 0, a.B, s, ev, &whole[0]);
+        rc = diffusion_chain(a, 0, 0, a.B, s, ev);
     } else {
         hipEvent_t fork = nullptr, join[8] = {nullptr};
         SET_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming), "set_diffusion_loop(fork)");
@@ -2053,7 +2023,7 @@ extern "C" int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream) {
             rc = aux_stream(g, &sg);
             if (rc != SET_OK) break;
             SET_HIP(hipStreamWaitEvent(sg, fork, 0), "set_diffusion_loop(fork wait)");
-            rc = diffusion_chain(a, g, b0, b1 - b0, sg, ev ? ev + (size_t)2 * a.steps * g : nullptr, &whole[g]);
+            rc = diffusion_chain(a, g, b0, b1 - b0, sg, ev ? ev + (size_t)2 * a.steps * g : nullptr);
             SET_HIP(hipEventCreateWithFlags(&join[g], hipEventDisableTiming), "set_diffusion_loop(join)");
             SET_HIP(hipEventRecord(join[g], sg), "set_diffusion_loop(join)");
             SET_HIP(hipStreamWaitEvent(s, join[g], 0), "set_diffusion_loop(join wait)");
@@ -2073,12 +2043,7 @@ extern "C" int set_diffusion_loop(const SetDiffLoopArgs *args, void *stream) {
                 float acc_ms = 0.0f;
                 for (int g = 0; g < G; ++g) {
                     float ms = 0.0f;
-                    if (whole[g]) {  // one launch for the whole loop: every step gets its share (the step boundaries are part of it)
-                        (void)hipEventElapsedTime(&ms, ev[(size_t)2 * a.steps * g], ev[(size_t)2 * a.steps * g + 1]);
-                        ms /= (float)a.steps;
-                    } else {
-                        (void)hipEventElapsedTime(&ms, ev[(size_t)2 * a.steps * g + 2 * k], ev[(size_t)2 * a.steps * g + 2 * k + 1]);
-                    }
+                    (void)hipEventElapsedTime(&ms, ev[(size_t)2 * a.steps * g + 2 * k], ev[(size_t)2 * a.steps * g + 2 * k + 1]);
                     acc_ms += ms;
                 }
                 a.layer_span_ms[k] = acc_ms / (float)G;

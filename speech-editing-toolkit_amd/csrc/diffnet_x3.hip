@@ -35,7 +35,6 @@
 #include <stdlib.h>
 
 #include "common.h"
-#include "boundary_x2.h"
 
 // measurement builds only (tools/build_exp.sh): bit 0 = the A fragments are loaded once per GEMM (no L2 operand stream), bit 1 =
 // every k-step reads the B fragment of k-step 0 (the compiler hoists it: no LDS stream), bit 2 = no s_setprio.  WRONG RESULTS.
@@ -111,7 +110,11 @@ struct SplitF16x2 {
 // scales the weights of the two GEMMs were multiplied by before splitting)
 template <typename S> constexpr int64_t x_n1() { return 8LL * X_KS1 * 2 * S::NP * 512; }
 template <typename S> constexpr int64_t x_n2() { return 8LL * X_KS2 * 2 * S::NP * 512; }
-template <typename S> constexpr int64_t x_nimg() { return x_n1<S>() + x_n2<S>() + 8; }
+// Winograd F(2,3) image of GEMM 1 (round 6; two-piece fp16 only): 64 k-steps = the four transformed weight planes U0, -U3, U1, U2 in the
+// order the kernel consumes them, [wave][k-step][row block][piece][lane][8], then {s1w, 1 / s1w} + padding (4 floats)
+constexpr int X_KSW = 64;
+template <typename S> constexpr int64_t x_nw() { return S::MODE == 2 ? 8LL * X_KSW * 2 * S::NP * 512 + 8 : 0; }
+template <typename S> constexpr int64_t x_nimg() { return x_n1<S>() + x_n2<S>() + 8 + x_nw<S>(); }
 __device__ __forceinline__ u32x4_t buf_load_u4(rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
 }
@@ -128,23 +131,41 @@ template <typename S>
 __global__ void __launch_bounds__(256) pack_layer_x3_kernel(const float *wdil, const float *wout, unsigned short *img, float s1, float s2) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (fragment element, all pieces)
     constexpr int64_t n1 = x_n1<S>() / S::NP, n2 = x_n2<S>() / S::NP;
+    constexpr int64_t nw = x_nw<S>() > 0 ? (x_nw<S>() - 8) / S::NP : 0;
     if (idx == 0) {
         float *tail = reinterpret_cast<float *>(img + x_n1<S>() + x_n2<S>());
         tail[0] = s1; tail[1] = 1.0f / s1; tail[2] = s2; tail[3] = 1.0f / s2;
+        if (nw > 0) {  // |U| <= 1.5 max |w|: half the scale of the direct image keeps the top piece in the same binade range
+            float *tw = reinterpret_cast<float *>(img + x_nimg<S>() - 8);
+            tw[0] = 0.5f * s1; tw[1] = 1.0f / (0.5f * s1); tw[2] = 0.0f; tw[3] = 0.0f;
+        }
     }
-    if (idx >= n1 + n2) return;
-    const bool g2 = idx >= n1;
-    int64_t r = g2 ? idx - n1 : idx;
+    if (idx >= n1 + n2 + nw) return;
+    const bool gw = idx >= n1 + n2;  // Winograd planes of GEMM 1
+    const bool g2 = !gw && idx >= n1;
+    int64_t r = gw ? idx - n1 - n2 : (g2 ? idx - n1 : idx);
     const int e = r & 7; r >>= 3;
     const int l = r & 63; r >>= 6;
     const int rb = r & 1; r >>= 1;
-    const int nks = g2 ? X_KS2 : X_KS1;
+    const int nks = gw ? X_KSW : (g2 ? X_KS2 : X_KS1);
     const int ks = (int)(r % nks), w = (int)(r / nks);
     const int row = (rb ? XC : 0) + 32 * w + (l & 31), k = 8 * (l >> 5) + e;
-    const float v = g2 ? s2 * wout[(int64_t)row * XC + 16 * ks + k] : s1 * wdil[((int64_t)row * XC + 16 * (ks % 16) + k) * 3 + ks / 16];
+    float v;
+    if (gw) {
+        // y[2p] = m0 + m1 + m2, y[2p+1] = m1 - m2 - m3 with m_j = U_j . V_j over the channels (diffnet.py:70 dilated_conv, dilation 1):
+        // U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2; stored plane order: U0, -U3 (accumulates straight into the odd
+        // output), U1, U2.  Formed in fp64, rounded to fp32 once.
+        const int plane = ks >> 4, c = 16 * (ks & 15) + k;
+        const float *g = wdil + ((int64_t)row * XC + c) * 3;
+        const double g0 = g[0], g1 = g[1], gg2 = g[2];
+        const double u = plane == 0 ? g0 : (plane == 1 ? -gg2 : (plane == 2 ? 0.5 * (g0 + g1 + gg2) : 0.5 * (g0 - g1 + gg2)));
+        v = (0.5f * s1) * (float)u;
+    } else {
+        v = g2 ? s2 * wout[(int64_t)row * XC + 16 * ks + k] : s1 * wdil[((int64_t)row * XC + 16 * (ks % 16) + k) * 3 + ks / 16];
+    }
     unsigned short p[S::NP];
     S::split(v, p);
-    unsigned short *base = img + (g2 ? x_n1<S>() : 0) + ((((int64_t)w * nks + ks) * 2 + rb) * S::NP) * 512 + l * 8 + e;
+    unsigned short *base = img + (gw ? x_n1<S>() + x_n2<S>() + 8 : (g2 ? x_n1<S>() : 0)) + ((((int64_t)w * nks + ks) * 2 + rb) * S::NP) * 512 + l * 8 + e;
 #pragma unroll
     for (int q = 0; q < S::NP; ++q) base[q * 512] = p[q];
 }
@@ -223,7 +244,6 @@ constexpr size_t x3_lds_bytes(int max_dil) {
 struct X3Tile {
     const float *xin;       // BATCH bases ([B][256][T])
     float *xout, *skp;
-    float *xin_next;        // whole-loop kernel, boundary tasks only: the next step's layer-0 input (= xa)
     const float *cp;        // conditioner projection of this layer, utterance 0; utterance stride cp_bs
     const float *dstep;     // step offsets of this layer, utterance 0; utterance stride d_bs, channel stride d_cs
     int64_t cp_bs, d_bs, d_cs;
@@ -557,7 +577,6 @@ __global__ void __launch_bounds__(512 / NU, NU) diffnet_stack_x3_kernel(SetDiffn
         lt.xin = (l & 1) ? a.xb : a.xa;
         lt.xout = (l & 1) ? a.xa : a.xb;
         lt.skp = a.skip;
-        lt.xin_next = nullptr;
         lt.cp = a.condproj + (int64_t)l * a.cp_ls; lt.cp_bs = a.cp_bs;
         lt.dstep = a.dstep + (int64_t)l * a.d_ls; lt.d_bs = a.d_bs; lt.d_cs = a.d_cs;
         lt.img = reinterpret_cast<const unsigned short *>(a.wx3_all) + (int64_t)l * x_nimg<S>();
@@ -660,293 +679,385 @@ int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_
 }
 
 // =====================================================================================================================
-// The WHOLE reverse loop as one launch (round 6; spec_denoiser.py:178-184).  The queue of diffnet_stack_x3_kernel gets one more
-// "layer" per denoise step: task (step s, pseudo-layer l, tile i), l < L a residual layer, l == L the STEP BOUNDARY of that tile --
-// skip sum / sqrt(L) -> skip projection -> ReLU -> output head -> posterior update of the mel state (explicit eps or Philox) -> the next
-// step's input projection (diffnet_boundary_x2_kernel's five phases, csrc/diffnet.hip, on the same two-piece fp16 operands and the same
-// images; all three are 1 x 1 convs: the boundary of tile i needs tile i of layer L - 1 only).  Flags count monotonically over the
-// loop: done[i] = s (L + 1) + l + 1; a task waits for done[i - 1 .. i + 1] >= s (L + 1) + l, which for l == 0, s > 0 is the previous
-// step's boundary.  What this removes from every one of the 100 steps: the boundary launch (36 us at B = 32, T = 800) with its ramp, two
-// launch gaps and the flag reset (13 us), and the drain of the stack launch (the last tasks of a launch leave most CUs idle) -- the layers
-// of step s + 1 start on the tiles whose boundary is done while other tiles are still in step s.
-// Buffer hazards (dynamic schedule): boundary (s, i) overwrites xa[i] (the next step's input) -- its last readers, layer L - 2 of tiles
-// i - 1 .. i + 1, finished before layer L - 1 of i - 1 .. i + 1 could start, which the boundary waits for; layer 0 of step s + 1 overwrites
-// xb[i] / skip[i] -- last read by layer L - 1 of i - 1 .. i + 1 / boundary (s, i), both implied by the boundary flags of i - 1 .. i + 1.
-// Results: every accumulator sees the products of the per-step launches in the same order -- bit-identical to them
-// (tests/test_gpu_parity.py::test_whole_loop_launch_equals_per_step_launches).
+// Winograd F(2,3) for GEMM 1 on the two-piece fp16 operands (round 6).  The kernel is limited by the package power, not by time
+// (profiles/r04_power.log, r06_loop_launch_ab.log), and 57 % of its energy is the fp16 MFMA work itself -- so the lever is FEWER matrix
+// instructions: the k = 3 conv over an output PAIR (frames 2p, 2p + 1) is four channel GEMMs instead of six,
+//     V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3          (d0 .. d3 = x + step offset at frames 2p - 1 .. 2p + 2; fp32, then split)
+//     y[2p] = U0 V0 + U1 V1 + U2 V2,   y[2p + 1] = U1 V1 - U2 V2 - U3 V3   (U: pack_layer_x3_kernel)
+// i.e. 2/3 of GEMM 1's MFMAs, 3/4 of the layer's.  Price: every weight fragment now feeds ONE triple of MFMAs (32 pair-columns per
+// plane) instead of two, so the L2 -> CU fragment stream per MFMA doubles (2 MiB per task for GEMM 1 instead of 1.5), and the split /
+// transform work of the staging pass doubles.  64-frame tiles only, dilation 1, even T, both column blocks of the tile in ONE utterance;
+// any other tile of the launch takes x3_main (direct form) inside the same kernel -- the direct image is part of the layer image.
+// Same accumulation precision (fp32) and piece products; the sums are formed in a different order than the direct form: results agree
+// with it to fp32 rounding (like the fp32-pipe Winograd kernel of csrc/diffnet.hip), not bit for bit.
+// LDS: V tile [plane 4][piece 2][pair 32][XR] (132 KB; the z tile [piece][64][XR] overlays it), step offsets, task slots.
 // =====================================================================================================================
-struct X3LoopBoundary {
-    float *x;                     // [B][M][T] mel state: in x_T, out x_0
-    const float *eps;             // optional explicit noise of executed step k at eps + k * eps_ks ([B][M][T] each); NULL: Philox
-    int64_t eps_ks;
-    const float *coef4;           // [steps][4] {c1, c2, logvar, nonzero} by step id
-    const unsigned short *w_skip_x2, *w_outp_x2, *w_in_x2;  // set_pack_conv_weight_x2 images
-    const float *b_skip, *b_outp, *b_in;
-    float div;                    // sqrt(L)
-    uint64_t seed, quads_total, quads_before;  // Philox quad of element e at executed step k: (k + 1) quads_total + quads_before + e / 4
-    int32_t M, steps;
-};
+constexpr unsigned XW_PIECE = 32 * XR;          // one piece of one plane of the V tile
+constexpr unsigned XW_PLANE = 2 * XW_PIECE;
+constexpr unsigned XW_TILE = 4 * XW_PLANE;      // 135,168 bytes
+constexpr unsigned XW_ZPIECE = 64 * XR;         // one piece of the z tile
+typedef unsigned u32x2w_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 buf_load2(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+// lane i <- lane i - 1 / lane i + 1 of the wave (DPP wave_shr:1 / wave_shl:1; the ends get `old`)
+__device__ __forceinline__ float wave_prev(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_next(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
 
-// the step boundary of one 64-frame tile (two 32-frame column blocks, each with its own utterance) by an 8-wave block; bl: >= 2 BX_PIECE
-// bytes of LDS.  Arithmetic = diffnet_boundary_x2_kernel's (same images, same k-step order per accumulator, same posterior formula and
-// Philox quads), frames addressed through the column blocks; everything another CU will read is stored agent-scope (write-through).
-// NOT inlined: inlined into the task loop, its address arithmetic was hoisted in front of the loop and pushed the layer path (235 VGPRs in
-// diffnet_stack_x3_kernel) over the 256 registers of a two-waves-per-SIMD block -- 21 - 25 spilled VGPRs with reloads inside the layer task.
-// As a call, the layer path keeps its allocation and only the boundary path (1 task in L + 1) pays for saved registers.  Scalars by value:
-// a struct by reference would be written to scratch in front of every task.
-__device__ __noinline__ void x3_boundary(const float *skp, float *xin_next, int32_t *err_flag, int T_, int q0, int nbu, int Q,
-                                         const X3LoopBoundary *pp, int k, unsigned char *bl) {
-    X3Tile a;
-    a.skp = const_cast<float *>(skp); a.xin_next = xin_next; a.err_flag = err_flag; a.T = T_; a.q0 = q0; a.nbu = nbu; a.Q = Q;
-    const X3LoopBoundary &p = *pp;
-    const int tid = threadIdx.x, lane = tid & 63;
+// a tile the Winograd form covers: both column blocks exist, lie in one utterance (then they are adjacent) and T is even
+__device__ __forceinline__ bool x3w_tile_ok(const X3Tile &a) {
+    const int q1 = a.q0 + 1;
+    return q1 < a.Q && (a.q0 / a.nbu) == (q1 / a.nbu) && (a.T & 1) == 0 && a.dil == 1;
+}
+
+// accumulator start: EO[0][rb] (even frames) / EO[1][rb] (odd frames) = b_dil + conditioner projection; lane l31 = pair
+__device__ __forceinline__ void x3w_init(const X3Tile &a, f32x16 (&EO)[2][2]) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // (see x3w_main)
+    const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int T = a.T, M = p.M;
-    const unsigned lane16 = 16u * (unsigned)lane;
+    const int T = a.T;
     const unsigned T4 = 4u * (unsigned)T;
-    const int sid = p.steps - 1 - k;
-    const bool last = k + 1 >= p.steps;
-    float amax = 0.0f;
-    // ---- phase 1: skip tile / sqrt(L), split -> LDS [piece][row = 32 cb + frame][256]: wave w stages column block w & 1, lane (frame,
-    //      channel group of 32)
-    {
-        const int cbs = w & 1, fr = l31, cg = (w >> 1) * 2 + half;
-        const X3Col c = x3_col(a, cbs);
-        const rsrc_t rs = make_rsrc(a.skp + (int64_t)c.b * XC * T);
-        const int t = c.t0 + fr;
-        const bool tv = c.ok && t < T;
-        const unsigned vo = 4u * (unsigned)min(t, T - 1) + (unsigned)(32 * cg) * T4;
-        float v[32];
+    const X3Col c = x3_col(a, 0);
+    const rsrc_t rcp = make_rsrc(a.cp + (int64_t)c.b * a.cp_bs);
+    const unsigned vo = 4u * (unsigned)(4 * half * T + min(c.t0 + 2 * l31, T - 2));
 #pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = buf_load(rs, vo, (unsigned)u * T4);
+    for (int rb = 0; rb < 2; ++rb) {
+        const float *bd = a.b_dil + (rb ? XC : 0) + 32 * w;
 #pragma unroll
-        for (int q8 = 0; q8 < 4; ++q8) {
-            bx_u32x4 u0, u1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned short p0[2], p1[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float sv = v[8 * q8 + 2 * e + j] / p.div;
-                    const float x = tv ? sv : 0.0f;
-                    amax = fmaxf(amax, fabsf(x));
-                    bx_split(x, p0[j], p1[j]);
-                }
-                u0[e] = (unsigned)p0[0] | ((unsigned)p0[1] << 16);
-                u1[e] = (unsigned)p1[0] | ((unsigned)p1[1] << 16);
-            }
-            *reinterpret_cast<bx_u32x4 *>(bl + (cbs * 32 + fr) * BX_XR + (32 * cg + 8 * q8) * 2) = u0;
-            *reinterpret_cast<bx_u32x4 *>(bl + BX_PIECE + (cbs * 32 + fr) * BX_XR + (32 * cg + 8 * q8) * 2) = u1;
+        for (int r = 0; r < 16; ++r) {
+            const unsigned ur = (unsigned)((rb ? XC : 0) + 32 * w + urow(r));
+            const float blo = bd[urow(r)], bhi = bd[urow(r) + 4];
+            const f32x2 v = buf_load2(rcp, vo, ur * T4);
+            EO[0][rb][r] = (half ? bhi : blo) + v[0];
+            EO[1][rb][r] = (half ? bhi : blo) + v[1];
         }
     }
-    __syncthreads();
-    auto bfrag256 = [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * BX_XR + (ks * 16 + half * 8) * 2); };
-    // ---- phase 2: h = ReLU(W_skip s + b): wave w owns rows [32 w, 32 w + 32)
+}
+
+// 16 k-steps (one plane) of the Winograd GEMM 1 into acc[rb]; the fragment ring A runs through all 64 k-steps of the GEMM
+template <int PFW>
+__device__ __forceinline__ void x3w_plane(f32x16 (&acc)[2], u32x4_t (&A)[PFW][2][2], rsrc_t img, unsigned lane16, unsigned abase, int seg,
+                                          const unsigned char *bplane, unsigned boff) {
+    typedef SplitF16x2 S;
+    for (int kb = 0; kb < 16; kb += PFW) {
+#pragma unroll
+        for (int p = 0; p < PFW; ++p) {
+            const int kc = kb + p, ks = 16 * seg + kc;
+            u32x4_t Bv[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) Bv[q] = *reinterpret_cast<const u32x4_t *>(bplane + q * XW_PIECE + boff + (unsigned)kc * 32u);
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef SET_X3W_NOPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+            for (int t = 0; t < S::NPROD; ++t)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) acc[rb] = S::mma(A[p][rb][S::qa(t)], Bv[S::qb(t)], acc[rb]);
+#ifndef SET_X3W_NOPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            const int kn = min(ks + PFW, X_KSW - 1);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) A[p][rb][q] = buf_load_u4(img, lane16, abase + (unsigned)(((kn * 2 + rb) * 2 + q) * 1024));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+#ifndef SET_X3W_PF
+#define SET_X3W_PF 4  // fragment ring depth of the Winograd GEMM 1 in k-steps (measurement builds: tools/build_exp.sh ... -DSET_X3W_PF=8)
+#endif
+// Measured and not kept (round 6, profiles/r06_x3w_prefetch_ab.log): touching the NEXT task's conditioner-projection rows under GEMM 2 so that
+// the accumulator-start loads of the next task hit the L2 -- 1.669 ms per launch with it, 1.650 ms without.
+__device__ __forceinline__ void x3w_main(const X3Tile &a, f32x16 (&EO)[2][2], unsigned char *lds, uint64_t *dbg, uint64_t &tprev) {
+#define X3W_PHASE(p)                                          \
+    if (dbg) {                                                \
+        const uint64_t tn = __builtin_amdgcn_s_memtime();     \
+        dbg[p] += tn - tprev;                                 \
+        tprev = tn;                                           \
+    }
+    X3W_PHASE(0)
+    typedef SplitF16x2 S;
+    constexpr int PFW = SET_X3W_PF;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // opaque per task: the lane arithmetic below is not hoisted in front of the task loop (where it would sit
+                                   // in registers next to the direct path's own loop invariants and push both paths into scratch)
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int T = a.T;
+    const unsigned T4 = 4u * (unsigned)T;
+    const unsigned lane16 = 16u * (unsigned)lane;
+    float *dsh = reinterpret_cast<float *>(lds + XW_TILE);  // [256] step offsets of the tile's utterance
+    const X3Col c0 = x3_col(a, 0);
+    const int b = c0.b, t0 = c0.t0;  // 64 frames t0 .. t0 + 63 of utterance b
+    const int64_t ub = (int64_t)b * XC * T;
+    const rsrc_t rw = make_rsrc(a.img);
+    const float *sc = reinterpret_cast<const float *>(a.img + x_n1<S>() + x_n2<S>());
+    const float s2 = sc[2], is2 = sc[3];
+    const float *scw = reinterpret_cast<const float *>(a.img + x_nimg<S>() - 8);
+    const float s1w = scw[0], is1w = scw[1];
+    bool tv[2];
+    unsigned vo4[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int t = t0 + 32 * cb + l31;
+        tv[cb] = t < T;
+        vo4[cb] = 4u * (unsigned)(4 * half * T + min(t, T - 1));
+    }
+    // ---- stage: lane = (pair p = l31, channel group cg = 2 w + half of 16 channels): d1, d2 by one 8-byte load per channel, d0 / d3 from
+    //      the neighbouring lanes (the ends of the tile from two halo loads), transform, split, 16-byte writes per (plane, piece)
     {
-        const float inv = reinterpret_cast<const float *>(p.w_skip_x2 + (XC / 32) * (XC / 16) * 1024)[1];
-        f32x16 acc[1][2];
-        acc[0][0] = (f32x16){0};
-        acc[0][1] = (f32x16){0};
-        bx_gemm<1>(acc, make_rsrc(p.w_skip_x2), lane16, w, XC / 16, XC / 16, bl, BX_PIECE, bfrag256);
-        __syncthreads();  // every wave is done reading the s tile
+        if (tid < XC) dsh[tid] = a.dstep[(int64_t)b * a.d_bs + (int64_t)tid * a.d_cs];
+        const int cg = 2 * w + half, ch0 = 16 * cg;
+        const rsrc_t rx = make_rsrc(a.xin + ub);
+        const int t = t0 + 2 * l31;                       // frames t, t + 1 (T even: both inside or both outside)
+        const bool v12 = t < T;
+        const int th = l31 == 0 ? t0 - 1 : t0 + 64;       // halo frame of the end lanes
+        const bool edge = l31 == 0 || l31 == 31, vh = edge && th >= 0 && th < T;
+        const unsigned cgo = (unsigned)ch0 * T4;
+        const unsigned vox = 4u * (unsigned)min(t, T - 2) + cgo, voh = 4u * (unsigned)min(max(th, 0), T - 1) + cgo;
+        f32x2 x12[16];
+        float xh[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x12[k] = buf_load2(rx, vox, (unsigned)k * T4);
+        if (edge) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xh[k] = buf_load(rx, voh, (unsigned)k * T4);
+        }
+        __syncthreads();  // dsh
+        float amax = 0.0f;
+#pragma unroll
+        for (int q8 = 0; q8 < 2; ++q8) {
+            unsigned short pc[4][8][2];  // [plane][channel][piece]
+            const f32x4 dA = *reinterpret_cast<const f32x4 *>(dsh + ch0 + 8 * q8);
+            const f32x4 dB = *reinterpret_cast<const f32x4 *>(dsh + ch0 + 8 * q8 + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * q8 + e;
+                const float ds = e < 4 ? dA[e & 3] : dB[e & 3];
+                const float d1 = v12 ? x12[k][0] + ds : 0.0f, d2 = v12 ? x12[k][1] + ds : 0.0f;
+                float d0 = wave_prev(d2), d3 = wave_next(d1);
+                const float hv = vh ? xh[k] + ds : 0.0f;
+                d0 = l31 == 0 ? hv : d0;
+                d3 = l31 == 31 ? hv : d3;
+                const float V[4] = {d0 - d2, d1 - d3, d1 + d2, d2 - d1};  // plane order of the image: U0, -U3, U1, U2
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    amax = fmaxf(amax, fabsf(V[j]));
+                    S::split(V[j], pc[j][e]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x4_t u[2];
+                pack8<2>(pc[j], u);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    *reinterpret_cast<u32x4_t *>(lds + j * XW_PLANE + q * XW_PIECE + l31 * XR + (ch0 + 8 * q8) * 2) = u[q];
+            }
+        }
+        if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int eo = 0; eo < 2; ++eo)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) EO[eo][rb][r] *= s1w;
+    __syncthreads();
+    X3W_PHASE(1)
+
+    // ---- GEMM 1: planes in image order: U0 V0 -> even, (-U3) V3 -> odd, U1 V1 -> both (+, +), U2 V2 -> both (+, -)
+    {
+        const unsigned abase = (unsigned)(x_n1<S>() * 2 + x_n2<S>() * 2 + 16) + (unsigned)(w * X_KSW * 2 * 2 * 1024);
+        const unsigned boff = (unsigned)(l31 * XR + half * 16);
+        u32x4_t A[PFW][2][2];
+#pragma unroll
+        for (int p = 0; p < PFW; ++p)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) A[p][rb][q] = buf_load_u4(rw, lane16, abase + (unsigned)(((p * 2 + rb) * 2 + q) * 1024));
+        x3w_plane<PFW>(EO[0], A, rw, lane16, abase, 0, lds + 0 * XW_PLANE, boff);
+        x3w_plane<PFW>(EO[1], A, rw, lane16, abase, 1, lds + 1 * XW_PLANE, boff);
+        f32x16 Tm[2];
+        Tm[0] = (f32x16){0};
+        Tm[1] = (f32x16){0};
+        x3w_plane<PFW>(Tm, A, rw, lane16, abase, 2, lds + 2 * XW_PLANE, boff);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                EO[0][rb][r] += Tm[rb][r];
+                EO[1][rb][r] += Tm[rb][r];
+                Tm[rb][r] = 0.0f;
+            }
+        x3w_plane<PFW>(Tm, A, rw, lane16, abase, 3, lds + 3 * XW_PLANE, boff);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                EO[0][rb][r] += Tm[rb][r];
+                EO[1][rb][r] -= Tm[rb][r];
+            }
+    }
+    X3W_PHASE(2)
+    // ---- residual rows of x for GEMM 2's accumulator start (issued here, consumed after the gate)
+    float xres[2][16];
+    {
+        const rsrc_t rx = make_rsrc(a.xin + ub);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
+            for (int r = 0; r < 16; ++r) xres[cb][r] = buf_load(rx, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+    }
+    __syncthreads();  // every wave is done reading the V tile: the z tile overlays it (row = frame of the tile)
+    // ---- gate: lane l31 holds frames 2 l31 (even accumulators) and 2 l31 + 1 (odd): z rows 2 l31 / 2 l31 + 1
+    {
+        const bool tvp = t0 + 2 * l31 < T;
+#pragma unroll
+        for (int eo = 0; eo < 2; ++eo)
+#pragma unroll
             for (int g = 0; g < 4; ++g) {
-                unsigned short p0[4], p1[4];
+                unsigned short p[4][2];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int row = 32 * w + 8 * g + 4 * half + e;
-                    const float h = fmaxf(acc[0][cb][4 * g + e] * inv + p.b_skip[row], 0.0f);
-                    amax = fmaxf(amax, h);
-                    bx_split(h, p0[e], p1[e]);
+                    const int r = 4 * g + e;
+                    const float zz = fsig(EO[eo][0][r] * is1w) * ftanh(EO[eo][1][r] * is1w);
+                    S::split(tvp ? zz : 0.0f, p[e]);
                 }
-                const unsigned off = (unsigned)((cb * 32 + l31) * BX_XR + (32 * w + 8 * g + 4 * half) * 2);
-                bx_u32x2 u;
-                u[0] = (unsigned)p0[0] | ((unsigned)p0[1] << 16); u[1] = (unsigned)p0[2] | ((unsigned)p0[3] << 16);
-                *reinterpret_cast<bx_u32x2 *>(bl + off) = u;
-                u[0] = (unsigned)p1[0] | ((unsigned)p1[1] << 16); u[1] = (unsigned)p1[2] | ((unsigned)p1[3] << 16);
-                *reinterpret_cast<bx_u32x2 *>(bl + BX_PIECE + off) = u;
+                const unsigned off = (unsigned)((2 * l31 + eo) * XR + (32 * w + 8 * g + 4 * half) * 2);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    u32x2w_t uu;
+                    uu[0] = (unsigned)p[0][q] | ((unsigned)p[1][q] << 16);
+                    uu[1] = (unsigned)p[2][q] | ((unsigned)p[3][q] << 16);
+                    *reinterpret_cast<u32x2w_t *>(lds + q * XW_ZPIECE + off) = uu;
+                }
             }
     }
-    __syncthreads();
-    // ---- phase 3: x0 = W_out h + b: row blocks 0 .. ceil(M / 32) - 1 on waves 0 .. 2; x0 -> fp32 tile xs[96][64] (over piece 0)
-    float *xs = reinterpret_cast<float *>(bl);
-    {
-        const int rbn = (M + 31) / 32;
-        f32x16 xo[1][2];
-        xo[0][0] = (f32x16){0};
-        xo[0][1] = (f32x16){0};
-        const float inv = reinterpret_cast<const float *>(p.w_outp_x2 + ((M + 31) / 32) * (XC / 16) * 1024)[1];
-        if (w < rbn) bx_gemm<1>(xo, make_rsrc(p.w_outp_x2), lane16, w, XC / 16, XC / 16, bl, BX_PIECE, bfrag256);
-        __syncthreads();  // h tile consumed
-        if (w < 3) {
+    // ---- GEMM 2 accumulators: residual rows start at s2 (b_out + x), skip rows at s2 b_out; then exactly x3_main's second half
+    f32x16 acc[1][2][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * w + mfma32_row(r, lane);
-                const float bias = p.b_outp[min(row, M - 1)];
+    for (int rb = 0; rb < 2; ++rb) {
+        const float *bo = a.b_out + (rb ? XC : 0) + 32 * w;
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) xs[row * 64 + 32 * cb + l31] = (w < rbn && row < M) ? xo[0][cb][r] * inv + bias : 0.0f;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const float blo = bo[urow(r)], bhi = bo[urow(r) + 4];
+            const float bias = half ? bhi : blo;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[0][rb][cb][r] = (rb == 0 ? bias + xres[cb][r] : bias) * s2;
         }
     }
-    __syncthreads();
-    // ---- phase 4: posterior update on quads of 4 consecutive frames (T % 4 == 0; a quad never leaves its 32-frame column block)
+    float sk[2][16];
     {
-        const float *cf = p.coef4 + 4 * sid;
-        const float c1 = cf[0], c2 = cf[1], sig = cf[3] * expf(0.5f * cf[2]);
-        const uint64_t qoff = (uint64_t)(k + 1) * p.quads_total + p.quads_before;
-        for (int qi = tid; qi < 96 * 16; qi += 512) {
-            const int m = qi >> 4, tq = qi & 15;
-            const X3Col c = x3_col(a, tq >> 3);
-            const int t = c.t0 + 4 * (tq & 7);
-            float *cell = xs + m * 64 + 4 * tq;
-            if (m < M && c.ok && t < T) {
-                const int64_t ub = (int64_t)c.b * M * T, i = (int64_t)m * T + t;
-                const rsrc_t rx = make_rsrc(p.x + ub);
-                const f32x4 xt = buf_load4(rx, 4u * (unsigned)i, 0u);
-                float z[4];
-                if (p.eps) {
-                    const f32x4 e4 = *reinterpret_cast<const f32x4 *>(p.eps + (int64_t)k * p.eps_ks + ub + i);
-                    z[0] = e4[0]; z[1] = e4[1]; z[2] = e4[2]; z[3] = e4[3];
-                } else {
-                    randn4(p.seed, qoff + (uint64_t)((ub + i) >> 2), z);
-                }
-                f32x4 o;
+        const rsrc_t rsk = make_rsrc(a.skp + ub);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float mean = c1 * cell[j] + c2 * xt[j];
-                    o[j] = mean + sig * z[j];
-                }
-                buf_store4_stream(o, rx, 4u * (unsigned)i, 0u);  // sc1: the next step's boundary of this tile may run on another XCD
-                *reinterpret_cast<f32x4 *>(cell) = o;
-            } else {
-                *reinterpret_cast<f32x4 *>(cell) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};  // K padding rows / frames >= T
-            }
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+    }
+    __syncthreads();
+    X3W_PHASE(3)
+    gemm_x3<S, X_KS2, 1, 2, S::PF>(acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + w * X_KS2 * 2 * 2 * 1024), (unsigned)(X_KS2 * 2 * 2 * 1024), lds,
+                                   XW_ZPIECE, [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2); });
+    X3W_PHASE(4)
+    // ---- epilogue
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        if (tv[cb]) {
+            const rsrc_t rxo = make_rsrc(a.xout + ub);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) buf_store_agent((acc[0][0][cb][r] * is2) * RSQRT2, rxo, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
         }
     }
-    if (last) {
-        if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    __syncthreads();
-    // ---- x' (fp32 [96][64]) -> two fp16 pieces [frame][96] in the piece-1 region: waves 0 .. 3, thread (frame f, 24 channels cg)
-    unsigned char *xp = bl + BX_PIECE;
-    constexpr unsigned XP_PIECE = 64 * BX_PR;
-    if (w < 4) {
-        const int f = lane, cg = w;
+    const bool first = a.first != 0;
 #pragma unroll
-        for (int q8 = 0; q8 < 3; ++q8) {
-            bx_u32x4 u0, u1;
+    for (int cb = 0; cb < 2; ++cb) {
+        if (tv[cb]) {
+            const rsrc_t rsk = make_rsrc(a.skp + ub);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned short p0[2], p1[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float x = xs[(24 * cg + 8 * q8 + 2 * e + j) * 64 + f];
-                    amax = fmaxf(amax, fabsf(x));
-                    bx_split(x, p0[j], p1[j]);
-                }
-                u0[e] = (unsigned)p0[0] | ((unsigned)p0[1] << 16);
-                u1[e] = (unsigned)p1[0] | ((unsigned)p1[1] << 16);
-            }
-            *reinterpret_cast<bx_u32x4 *>(xp + f * BX_PR + (24 * cg + 8 * q8) * 2) = u0;
-            *reinterpret_cast<bx_u32x4 *>(xp + XP_PIECE + f * BX_PR + (24 * cg + 8 * q8) * 2) = u1;
-        }
-    }
-    if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    // ---- phase 5: next step's input projection xin = ReLU(W_in x' + b_in), K = M rounded up to 32 (zero padded): wave w rows [32 w ..)
-    {
-        const int ngin = ((M + 31) / 32) * 2;
-        const float inv = reinterpret_cast<const float *>(p.w_in_x2 + (XC / 32) * ngin * 1024)[1];
-        f32x16 acc[1][2];
-        acc[0][0] = (f32x16){0};
-        acc[0][1] = (f32x16){0};
-        bx_gemm<1>(acc, make_rsrc(p.w_in_x2), lane16, w, ngin, ngin, xp, XP_PIECE,
-                   [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * BX_PR + (ks * 16 + half * 8) * 2); });
-        float bin[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bin[r] = (p.b_in + 32 * w + urow(r))[4 * half];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const X3Col c = x3_col(a, cb);
-            if (c.ok && c.t0 + l31 < T) {
-                const rsrc_t ro = make_rsrc(a.xin_next + (int64_t)c.b * XC * T);
-                const unsigned so = 4u * (unsigned)(4 * half * T + c.t0 + l31);
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    buf_store_agent(fmaxf(acc[0][cb][r] * inv + bin[r], 0.0f), ro, so, (unsigned)(32 * w + urow(r)) * T4);
-            }
+            for (int r = 0; r < 16; ++r)
+                buf_store_agent(first ? acc[0][1][cb][r] * is2 : acc[0][1][cb][r] * is2 + sk[cb][r], rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
         }
     }
 }
 
-// the boundary's arguments live in device memory (behind the flags of sync_ws), not in the kernel argument segment: as kernel arguments
-// they were all kept in SGPRs across the task loop (160 spilled SGPRs, which pushed 25 VGPRs of the layer path into scratch)
-__global__ void store_loop_boundary_kernel(X3LoopBoundary bd, X3LoopBoundary *dst) {
-    if (threadIdx.x == 0) *dst = bd;
-}
+#undef X3W_PHASE
 
-template <typename S>
-__global__ void __launch_bounds__(512, 1) diffnet_loop_x3_kernel(SetDiffnetStackArgs a, const X3LoopBoundary *bdp, int steps, int ntiles,
-                                                                  int ntasks, unsigned piece_bytes) {
-    constexpr int NU = 1, NCB = 2;
+// the persistent (layer, tile) queue of diffnet_stack_x3_kernel with the Winograd form of GEMM 1 on every tile it covers
+// Measured and not kept (round 6, profiles/r06_x3w_xcd_chunks_ab.log): XCD-aware claiming -- the blocks of one XCD (blockIdx.x % 8) taking chunks
+// of 32 consecutive tasks from a counter of their own, so that the 32 CUs sharing an L2 stream the same layer image: 1.718 ms per launch
+// against 1.672 ms with the one global counter (1,287 W against 1,319 W: the groups drift apart and their tasks wait for each other's
+// tiles).  Any free block taking the next task matters more than which L2 the image sits in.
+__global__ void __launch_bounds__(512, 1) diffnet_stack_x3w_kernel(SetDiffnetStackArgs a, int ntiles, int ntasks, unsigned piece_bytes, int fault_tile) {
+    typedef SplitF16x2 S;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int *s_task = reinterpret_cast<int *>(lds + S::NP * piece_bytes + NCB * XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
+    int *s_task = reinterpret_cast<int *>(lds + XW_TILE + 2 * XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
     int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
     const int tid = threadIdx.x;
-    const int L1 = a.L + 1, per_step = L1 * ntiles;
-    uint64_t tprev = 0;
+    uint64_t *dbg = (SET_X3_PROBE && blockIdx.x == 0 && tid == 0) ? g_x3_phase_buf : nullptr;
+    uint64_t tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
     if (tid == 0) s_task[0] = atomicAdd(counter, 1);
     __syncthreads();
     int n = __builtin_amdgcn_readfirstlane(s_task[0]);
-    int i_done = -1, v_done = 0;  // finished but not yet published tile of this block, and the flag value that publishes it
+    int i_done = -1, l_done = 0;
     while (n < ntasks) {
-        const int k = n / per_step, r = n - k * per_step;  // executed step k (step id steps - 1 - k)
-        const int l = r / ntiles, i = r - l * ntiles;
-        const int want = k * L1 + l;
-        const bool boundary = l == a.L;
+        const int l = n / ntiles, i = n - l * ntiles;
         X3Tile lt;
         lt.xin = (l & 1) ? a.xb : a.xa;
         lt.xout = (l & 1) ? a.xa : a.xb;
         lt.skp = a.skip;
-        lt.xin_next = a.xa;
-        const int lw = boundary ? 0 : l;  // (a boundary task reads none of the per-layer operands)
-        lt.cp = a.condproj + (int64_t)lw * a.cp_ls; lt.cp_bs = a.cp_bs;
-        lt.dstep = a.dstep + (int64_t)lw * a.d_ls + (steps - 1 - k); lt.d_bs = a.d_bs; lt.d_cs = a.d_cs;
-        lt.img = reinterpret_cast<const unsigned short *>(a.wx3_all) + (int64_t)lw * x_nimg<S>();
-        lt.b_dil = a.b_dil_all + (int64_t)lw * 512;
-        lt.b_out = a.b_out_all + (int64_t)lw * 512;
+        lt.cp = a.condproj + (int64_t)l * a.cp_ls; lt.cp_bs = a.cp_bs;
+        lt.dstep = a.dstep + (int64_t)l * a.d_ls; lt.d_bs = a.d_bs; lt.d_cs = a.d_cs;
+        lt.img = reinterpret_cast<const unsigned short *>(a.wx3_all) + (int64_t)l * x_nimg<S>();
+        lt.b_dil = a.b_dil_all + (int64_t)l * 512;
+        lt.b_out = a.b_out_all + (int64_t)l * 512;
         lt.err_flag = a.err_flag;
-        lt.T = a.T; lt.dil = 1 << (lw % a.dilation_cycle_length); lt.first = (l == 0);
-        lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * NCB;
-        f32x16 acc[NU][2][NCB];
-        if (!boundary) x3_init<NU, NCB>(lt, acc);  // issued before the previous tile's store drain / publish and before the dependency wait
+        lt.T = a.T; lt.dil = 1; lt.first = (l == 0);
+        lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * 2;
+        const bool wino = x3w_tile_ok(lt);  // block-uniform
+        f32x16 acc[1][2][2];  // direct form: [rb][cb]; Winograd form: [even / odd][rb] (the same 64 registers)
+        f32x16 (&EO)[2][2] = acc[0];
+        if (wino)
+            x3w_init(lt, EO);
+        else
+            x3_init<1, 2>(lt, acc);
         __builtin_amdgcn_sched_barrier(0);
         const int *f0 = done + i, *fl = done + (i > 0 ? i - 1 : i), *fr = done + (i < ntiles - 1 ? i + 1 : i);
-        int peek = want, claimed = 0;
+        int peek = l, claimed = 0;
         if (tid == 0) {
-            if (want > 0) peek = min(ld_agent(f0), min(ld_agent(fl), ld_agent(fr)));
+            if (l > 0) peek = min(ld_agent(f0), min(ld_agent(fl), ld_agent(fr)));
             claimed = atomicAdd(counter, 1);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: the finished tile is visible to every XCD
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) {
-            if (peek >= want) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (peek >= l) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             s_task[0] = claimed;
-            s_task[1] = peek >= want ? 1 : 2;
+            s_task[1] = peek >= l ? 1 : 2;
         }
-        __syncthreads();  // (also: the LDS tile is free)
-        if (tid == 0 && i_done >= 0) __hip_atomic_store(done + i_done, v_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tid == 0 && i_done >= 0 && !(l_done == 0 && i_done == fault_tile))
+            __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         i_done = -1;
-        if (__builtin_amdgcn_readfirstlane(s_task[1]) == 2) {  // producers not finished at the peek: wait for them now
+        if (__builtin_amdgcn_readfirstlane(s_task[1]) == 2) {
             if (tid == 0) {
                 int ok = 1;
                 unsigned spins = 0;
                 for (;;) {
                     const int v0 = ld_agent(f0), v1 = ld_agent(fl), v2 = ld_agent(fr);
-                    if (min(v0, min(v1, v2)) >= want) break;
+                    if (min(v0, min(v1, v2)) >= l) break;
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > X_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
                         __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -962,19 +1073,56 @@ __global__ void __launch_bounds__(512, 1) diffnet_loop_x3_kernel(SetDiffnetStack
             if (__builtin_amdgcn_readfirstlane(s_task[2]) == 0) break;
         }
         const int n_next = __builtin_amdgcn_readfirstlane(s_task[0]);
-        if (boundary)
-            x3_boundary(lt.skp, lt.xin_next, lt.err_flag, lt.T, lt.q0, lt.nbu, lt.Q, bdp, k, lds);
+        if (wino)
+            x3w_main(lt, EO, lds, dbg, tprev);
         else
-            x3_main<S, NU, NCB>(lt, acc, lds, piece_bytes, nullptr, tprev);
+            x3_main<S, 1, 2>(lt, acc, lds, piece_bytes, nullptr, tprev);
         i_done = i;
-        v_done = want + 1;
+        l_done = l;
         n = n_next;
+        if (dbg) {
+            const uint64_t tn = __builtin_amdgcn_s_memtime();
+            dbg[5] += tn - tprev;
+            dbg[7] += 1;
+            tprev = tn;
+        }
     }
-    // the last finished tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0 && i_done >= 0) __hip_atomic_store(done + i_done, v_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && i_done >= 0 && !(l_done == 0 && i_done == fault_tile))
+        __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+int launch_x3w(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_x3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                "set_diffnet_stack(x3w attr)");
+        attr_set = true;
+    }
+    const int Q = a.B * ((a.T + 31) / 32);
+    const int ntiles = (Q + 1) / 2;
+    const int64_t ntasks64 = (int64_t)ntiles * a.L;
+    SET_REQUIRE(ntasks64 < (1ll << 30), "set_diffnet_stack(task count)");
+    SET_REQUIRE((int64_t)2 * XC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_stack(split-operand kernel: T too large)");
+    SET_REQUIRE(a.dilation_cycle_length == 1, "set_diffnet_stack(x3w: dilation 1 only)");
+    const unsigned piece_bytes = (unsigned)(2 * (32 + 2) * XR);  // the direct-form tiles of the launch (x3_main)
+    const size_t ldsz = (size_t)XW_TILE + 2 * XC * sizeof(float) + 16;
+    SET_HIP(set_zero_async(a.sync_ws, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
+    int grid = n_cu;
+    if (grid > ntiles * 4 / 5) grid = ntiles * 4 / 5;
+    if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
+    if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(diffnet_stack_x3w_kernel, dim3(grid), dim3(512), ldsz, s, a, ntiles, (int)ntasks64, piece_bytes, fault_tile);
+    return set_check_launch("set_diffnet_stack");
+}
+
+// Measured and not kept (round 6; the code is in commit 9e25393 "... whole-loop kernel", profiles/r06_loop_launch_ab.log): the WHOLE reverse loop
+// as one launch -- the step boundary (skip projection -> output head -> posterior -> next step's input projection) as one more task type of
+// this queue, flags counting over all 100 steps.  Bit-identical to the per-step launches, and 2.3 % SLOWER at B = 32, T = 800 (179.2 against
+// 175.2 ms per 100 steps; 1,364 W / 1.95 GHz against 1,351 W / 1.99 GHz): the launch gaps and the drain of every stack launch are not lost time
+// under the package power limit -- the clock recovers in them.
 
 // =====================================================================================================================
 // Small batches: the row-split scheme of diffnet_stack_split_kernel (csrc/diffnet.hip: every 32-frame tile computed by FOUR
@@ -1329,62 +1477,6 @@ int set_launch_diffnet_stack_split_x2(const SetDiffnetStackArgs &a, int fault_ti
     return set_check_launch("set_diffnet_stack");
 }
 
-// The whole reverse loop in one launch (diffnet_loop_x3_kernel): called by set_diffusion_loop (csrc/diffnet.hip) for batches that take the
-// 64-frame-tile split-operand kernel with the split-operand step boundary.  `a`: the stack arguments of the loop (dstep = column 0 of
-// the [L * 256][steps] table, d_cs = steps); `lb`: csrc/diffnet.hip fills it through set_loop_x3_boundary().
-struct SetLoopX3Boundary {  // plain mirror of X3LoopBoundary for the other translation unit
-    float *x; const float *eps; int64_t eps_ks; const float *coef4; const void *w_skip_x2, *w_outp_x2, *w_in_x2;
-    const float *b_skip, *b_outp, *b_in; float div; uint64_t seed, quads_total, quads_before; int32_t M, steps;
-};
-bool set_loop_x3_usable(const SetDiffnetStackArgs &a, int n_cu) {
-    const char *e_on = getenv("SET_AMD_LOOP_LAUNCH");  // opt-in until it has been measured on the GPU
-    if (!e_on || atoi(e_on) == 0) return false;
-    if (a.x3_mode != 2) return false;  // the split-operand step boundary exists for the two-piece fp16 splitting only
-    const int64_t tiles64 = (int64_t)a.B * ((a.T + 63) / 64);
-    bool narrow = 5 * tiles64 < 3 * (int64_t)n_cu;  // the rule of set_launch_diffnet_stack_x3
-    if (const char *e = getenv("SET_AMD_X3_TILE")) narrow = atoi(e) == 32;
-    return !narrow && a.T % 4 == 0;
-}
-int set_launch_diffnet_loop_x3(const SetDiffnetStackArgs &a, const SetLoopX3Boundary &lb, int n_cu, hipStream_t s) {
-    SET_REQUIRE(a.x3_mode == 2, "set_diffusion_loop(whole-loop kernel: x3_mode)");
-    SET_REQUIRE(lb.M >= 2 && lb.M <= 96 && lb.steps >= 1 && a.T % 4 == 0, "set_diffusion_loop(whole-loop kernel: shape)");
-    static bool attr_set = false;
-    if (!attr_set) {
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_loop_x3_kernel<SplitF16x2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "set_diffusion_loop(loop x3 attr)");
-        attr_set = true;
-    }
-    constexpr int NCB = 2;
-    const int Q = a.B * ((a.T + 31) / 32);
-    const int ntiles = (Q + NCB - 1) / NCB;
-    const int64_t ntasks64 = (int64_t)ntiles * (a.L + 1) * lb.steps;
-    SET_REQUIRE(ntasks64 < (1ll << 30), "set_diffusion_loop(whole-loop kernel: task count)");
-    SET_REQUIRE((int64_t)2 * XC * a.T * 4 < ((int64_t)1 << 31), "set_diffusion_loop(whole-loop kernel: T too large)");
-    const int max_dil = 1 << (a.dilation_cycle_length - 1);
-    const unsigned piece_bytes = (unsigned)(NCB * (32 + 2 * max_dil) * XR);
-    SET_REQUIRE((size_t)piece_bytes >= (size_t)BX_PIECE, "set_diffusion_loop(whole-loop kernel: LDS)");
-    SET_HIP(set_zero_async(a.sync_ws, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffusion_loop(memset)");
-    int grid = n_cu;
-    if (grid > ntiles * 4 / 5) grid = ntiles * 4 / 5;
-    if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
-    if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
-    if (grid < 1) grid = 1;
-    X3LoopBoundary bd;
-    bd.x = lb.x; bd.eps = lb.eps; bd.eps_ks = lb.eps_ks; bd.coef4 = lb.coef4;
-    bd.w_skip_x2 = reinterpret_cast<const unsigned short *>(lb.w_skip_x2);
-    bd.w_outp_x2 = reinterpret_cast<const unsigned short *>(lb.w_outp_x2);
-    bd.w_in_x2 = reinterpret_cast<const unsigned short *>(lb.w_in_x2);
-    bd.b_skip = lb.b_skip; bd.b_outp = lb.b_outp; bd.b_in = lb.b_in; bd.div = lb.div;
-    bd.seed = lb.seed; bd.quads_total = lb.quads_total; bd.quads_before = lb.quads_before; bd.M = lb.M; bd.steps = lb.steps;
-    const size_t ldsz = x3_lds_bytes<SplitF16x2, NCB>(max_dil);
-    // (sync_ws holds >= 16 + 2 B ceil(T / 32) words per utterance group; the flags take 4 + ntiles of them)
-    SET_REQUIRE((int64_t)(4 + ntiles + 2) * 4 + (int64_t)sizeof(X3LoopBoundary) <= (int64_t)(16 + 2 * Q) * 4, "set_diffusion_loop(whole-loop kernel: sync_ws)");
-    X3LoopBoundary *bdp = reinterpret_cast<X3LoopBoundary *>(a.sync_ws + ((4 + ntiles + 1) & ~1));
-    hipLaunchKernelGGL(store_loop_boundary_kernel, dim3(1), dim3(64), 0, s, bd, bdp);
-    hipLaunchKernelGGL((diffnet_loop_x3_kernel<SplitF16x2>), dim3(grid), dim3(512), ldsz, s, a, bdp, lb.steps, ntiles, (int)ntasks64, piece_bytes);
-    return set_check_launch("set_diffusion_loop(whole-loop kernel)");
-}
-
 extern "C" int set_debug_x3_phase_buffer(uint64_t *buf) {
     SET_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_x3_phase_buf), &buf, sizeof(buf)), "set_debug_x3_phase_buffer");
     return SET_OK;
@@ -1401,12 +1493,23 @@ extern "C" int set_pack_diffnet_layer_x3(const float *w_dil, const float *w_out,
     const float s1 = ldexpf(1.0f, k1), s2 = ldexpf(1.0f, k2);
     unsigned short *im = reinterpret_cast<unsigned short *>(img);
     if (mode == 2)
-        hipLaunchKernelGGL(pack_layer_x3_kernel<SplitF16x2>, dim3(set_blocks((x_nimg<SplitF16x2>() - 8) / 2, 256)), dim3(256), 0,
+        hipLaunchKernelGGL(pack_layer_x3_kernel<SplitF16x2>, dim3(set_blocks((x_nimg<SplitF16x2>() - 16) / 2, 256)), dim3(256), 0,
                            (hipStream_t)stream, w_dil, w_out, im, s1, s2);
     else
         hipLaunchKernelGGL(pack_layer_x3_kernel<SplitBf16x3>, dim3(set_blocks((x_nimg<SplitBf16x3>() - 8) / 3, 256)), dim3(256), 0,
                            (hipStream_t)stream, w_dil, w_out, im, s1, s2);
     return set_check_launch("set_pack_diffnet_layer_x3");
+}
+
+// does set_launch_diffnet_stack_x3 take the Winograd form (diffnet_stack_x3w_kernel) for this shape?
+bool set_x3_winograd_selected(int x3_mode, int B, int T, int dilation_cycle_length, int n_cu) {
+    if (x3_mode != 2 || dilation_cycle_length != 1 || T % 2 != 0) return false;
+    const int64_t tiles64 = (int64_t)B * ((T + 63) / 64);
+    bool narrow = 5 * tiles64 < 3 * (int64_t)n_cu;
+    if (const char *e = getenv("SET_AMD_X3_TILE")) narrow = atoi(e) == 32;
+    if (narrow) return false;
+    if (const char *e = getenv("SET_AMD_X3_WINO")) return atoi(e) != 0;
+    return true;
 }
 
 // called by set_diffnet_stack (csrc/diffnet.hip) once it has picked this kernel
@@ -1422,6 +1525,9 @@ int set_launch_diffnet_stack_x3(const SetDiffnetStackArgs &a, int n_cu, int faul
     // to 1.63 GHz; profiles/r03_x3_pair_probe.log -- but its 64-frame instantiation spilled registers, which confounded the
     // comparison; round 4 measured the power limit directly instead (profiles/r04_power.log, r04_mfma_ceiling.log) and removed the
     // variant from the library.  The NU template parameter of the kernel stays for tools/build_exp.sh experiments.)
+    // round 6: Winograd F(2,3) form of GEMM 1 on the 64-frame tiles (dilation 1, even T; SET_AMD_X3_WINO=0 keeps the direct form) --
+    // see diffnet_stack_x3w_kernel
+    if (set_x3_winograd_selected(a.x3_mode, a.B, a.T, a.dilation_cycle_length, n_cu)) return launch_x3w(a, n_cu, fault_tile, s);
     if (a.x3_mode == 2)
         return narrow ? launch_x3<SplitF16x2, 1, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitF16x2, 1, 2>(a, n_cu, fault_tile, s);
     return narrow ? launch_x3<SplitBf16x3, 1, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitBf16x3, 1, 2>(a, n_cu, fault_tile, s);

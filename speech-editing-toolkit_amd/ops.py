@@ -793,6 +793,14 @@ def stack_variant(B, T, dilation_cycle_length, have_wino=True, have_split=True, 
     return int(_lib.lib().set_diffnet_stack_variant(int(B), int(T), int(dilation_cycle_length), bits))
 
 
+def stack_x3_winograd(B, T, dilation_cycle_length, have_wino=True, have_split=True, x3_mode=None):
+    """True when variant 5 (two-piece fp16 split-operand kernel) runs GEMM 1 in its Winograd F(2,3) form for this shape
+    (diffnet_stack_x3w_kernel, round 6)."""
+    m = split_operand_mode() if x3_mode is None else int(x3_mode)
+    bits = int(bool(have_wino)) | (2 if have_split else 0) | (4 if m == 3 else 0) | (8 if m == 2 else 0)
+    return bool(_lib.lib().set_diffnet_stack_x3_winograd(int(B), int(T), int(dilation_cycle_length), bits))
+
+
 STACK_VARIANT_NAMES = {0: "diffnet_stack_kernel<2,4,2>", 1: "diffnet_stack_kernel<1,8,2>", 2: "diffnet_stack_wino_kernel",
                        3: "diffnet_stack_split_kernel", 4: "diffnet_stack_x3_kernel<SplitBf16x3>",
                        5: "diffnet_stack_x3_kernel<SplitF16x2>"}

@@ -596,6 +596,7 @@ def test_x3_stack_tile_widths_agree_bit_for_bit(dev, monkeypatch, x3_mode):
     from set_amd import ops
     monkeypatch.setenv("SET_AMD_X3", "2")
     monkeypatch.setenv("SET_AMD_SPLIT", "0")
+    monkeypatch.setenv("SET_AMD_X3_WINO", "0")  # the direct form on both widths (round 6: 64-frame tiles default to the Winograd form of GEMM 1)
     for (B, T, L, dcl) in ((8, 800, 20, 1), (3, 203, 5, 3), (1, 1, 2, 1), (5, 66, 8, 4), (2, 1548, 2, 2)):
         x0, cp, dtab, packs, wds, wos, bd, bo = _random_stack(dev, B, T, L, B * 100 + T + 9, x3_mode)
         outs = []
@@ -1296,57 +1297,76 @@ def test_full800_single_utterance_matches_reference(dev, row):
     assert d < 1e-4
 
 
-@pytest.mark.parametrize("noise", ["explicit", "philox"])
-def test_whole_loop_launch_equals_per_step_launches(dev, monkeypatch, noise):
-    """Round 6: the reverse loop as ONE launch (step boundaries as tasks of the persistent queue, csrc/diffnet_x3.hip diffnet_loop_x3_kernel)
-    against the per-step launches (stack + boundary kernel per step) at the metric's batch shape, 7 steps, explicit and Philox noise: the same
-    images, the same products in the same order per accumulator, the same posterior arithmetic and Philox quads -> bit-identical mels; twice
-    the same -> deterministic; and against the CPU oracle on two utterances (explicit noise)."""
+def test_x3w_winograd_split_operand_stack(dev, monkeypatch):
+    """Round 6: the Winograd F(2,3) form of GEMM 1 on the two-piece fp16 operands (diffnet_stack_x3w_kernel, SET_AMD_X3_WINO=1: 3/4 of the
+    layer's MFMAs) against the direct split-operand kernel and the fp32-pipe kernel on the same weights -- equal to fp32 rounding; run to run
+    and for 7 / 512 workers bit-identical; against an fp64 evaluation of the same layers its error stays within 2 x the fp32 kernel's.
+    Shapes: the metric's batch, tiles that straddle two utterances or end in a partial block (those take the direct form inside the same
+    launch), T = 66 (a tile whose second block holds two frames)."""
     from set_amd import ops
-    B, T, Tt, steps = 32, 800, 100, 7
-    model, W = _build_model(dev, "spec_denoiser", 61, steps)
-    inp = Wt.synthetic_inputs(B, T, Tt, seed=5151, pad_tail=True)
-    di = {k: v.to(dev) for k, v in inp.items()}
-    noises = torch.stack(Wt.synthetic_noises(B, T, steps, seed=5152)).to(dev) if noise == "explicit" else None
-    assert ops.stack_variant(B, T, 1) == 5
+    import torch.nn.functional as F
+    monkeypatch.setenv("SET_AMD_SPLIT", "0")
+    monkeypatch.setenv("SET_AMD_X3_TILE", "64")
+    for (B, T, L, reps) in ((32, 800, 20, 2), (3, 204, 5, 2), (2, 66, 3, 2), (5, 70, 4, 1), (1, 2, 2, 1), (2, 800, 20, 1)):
+        x0, cp, dtab, packs, wds, wos, bd, bo = _random_stack(dev, B, T, L, B * 1000 + T + 17, 2)
 
-    def run():
-        ret = model(di["txt_tokens"], di["time_mel_masks"], di["mel2ph"], di["spk_embed"], di["ref_mels"], di["f0"], di["uv"], infer=True,
-                    noises=noises, seed=11, want_layer_spans=True)
-        torch.cuda.synchronize()
-        return ret
+        def run(x3, wino, grid=None):
+            monkeypatch.setenv("SET_AMD_X3", x3)
+            monkeypatch.setenv("SET_AMD_X3_WINO", wino)
+            if grid is None:
+                monkeypatch.delenv("SET_AMD_STACK_GRID", raising=False)
+            else:
+                monkeypatch.setenv("SET_AMD_STACK_GRID", grid)
+            xa, xb, skip = x0.clone(), torch.full_like(x0, float("nan")), torch.full_like(x0, float("nan"))
+            ws = ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4, 0, 3, 256 * 3, packs, 1)
+            torch.cuda.synchronize()
+            assert int(ws[1]) == 0, "dependency wait timed out"
+            return (xb if L % 2 else xa).clone(), skip.clone()
 
-    monkeypatch.setenv("SET_AMD_LOOP_LAUNCH", "0")
-    per_step = run()
-    monkeypatch.setenv("SET_AMD_LOOP_LAUNCH", "1")
-    whole, again = run(), run()
-    assert torch.isfinite(whole["mel_out"]).all()
-    assert torch.equal(whole["mel_out"], again["mel_out"])
-    assert torch.equal(whole["mel_out"], per_step["mel_out"])
-    # the whole-loop launch reports one launch's share per step: equal spans, and fewer milliseconds than the per-step path's spans + boundaries
-    assert len(whole["layer_span_ms"]) == steps and max(whole["layer_span_ms"]) - min(whole["layer_span_ms"]) < 1e-6
-    if noise == "explicit":
-        rows = [3, 31]
-        sub = {k: v[rows] for k, v in inp.items()}
-        oret = O.gaussian_diffusion_infer(W, steps, sub, [n[rows].cpu() for n in noises])
-        assert _maxdiff(whole["mel_out"][rows], oret["mel_out"]) < 1e-4
+        x32, s32 = run("0", "0")
+        xd2, sd2 = run("2", "0")
+        xw, sw = run("2", "1")
+        tol = 1e-5 * max(1.0, float(x32.abs().max()))
+        assert _maxdiff(xw, x32) < tol and _maxdiff(sw, s32) < 1e-5 * max(1.0, float(s32.abs().max())), (B, T)
+        assert _maxdiff(xw, xd2) < tol, (B, T)
+        for rep in range(reps - 1):
+            x, sk = run("2", "1")
+            assert torch.equal(x, xw) and torch.equal(sk, sw), (B, T, rep)
+        for grid in ("7", "512"):
+            x, sk = run("2", "1", grid)
+            assert torch.equal(x, xw) and torch.equal(sk, sw), (B, T, grid)
+        if B * T <= 2048:
+            xd, skd = x0.double(), torch.zeros_like(x0, dtype=torch.float64)
+            for l in range(L):
+                dv = dtab[l * 256:(l + 1) * 256, 1].double()[None, :, None]
+                y = F.conv1d(xd + dv, wds[l].double(), bd[l].double(), padding=1) + cp[:, l * 512:(l + 1) * 512].double()
+                z = torch.sigmoid(y[:, :256]) * torch.tanh(y[:, 256:])
+                o = F.conv1d(z, wos[l].double(), bo[l].double())
+                xd, skd = (xd + o[:, :256]) / 2 ** 0.5, skd + o[:, 256:]
+            e32 = max(float((x32.double() - xd).abs().max()), float((s32.double() - skd).abs().max()))
+            ed = max(float((xd2.double() - xd).abs().max()), float((sd2.double() - skd).abs().max()))
+            ew = max(float((xw.double() - xd).abs().max()), float((sw.double() - skd).abs().max()))
+            print("stack (%d, %d, L=%d): max err vs fp64: fp32 kernel %.3e, split-operand direct %.3e, split-operand Winograd %.3e" % (B, T, L, e32, ed, ew))
+            assert ew < 2.0 * e32 + 1e-7, (B, T, ew, e32)
 
 
-def test_whole_loop_launch_full800_reference_rows(dev, monkeypatch):
-    """infer_full800 (the reference's own T = 800 x 100-step output) as rows 5 and 18 of a B = 32 batch through the whole-loop launch."""
-    monkeypatch.setenv("SET_AMD_LOOP_LAUNCH", "1")
-    g, model, inp2, noises2 = _full800(dev)
-    rows = [5, 18]
-    inp = Wt.synthetic_inputs(32, 800, 100, seed=9001, pad_tail=True)
-    for k in inp:
-        inp[k][rows] = inp2[k]
-    gen = torch.Generator(device=dev).manual_seed(9002)
-    noises = torch.randn(101, 32, 1, 80, 800, device=dev, generator=gen)
-    noises[:, rows] = noises2.to(dev)
-    ret = _run800(model, inp, noises, dev, want_layer_spans=True)
-    assert max(ret["layer_span_ms"]) - min(ret["layer_span_ms"]) < 1e-6  # (one launch: every step reports its share)
-    d = _maxdiff(ret["mel_out"][rows], g["mel_out"])
-    print("infer_full800 inside B=32, whole-loop launch: max|dmel| = %.3e" % d)
+@pytest.mark.parametrize("case", ["infer_full800", "infer_tiny", "infer_pad", "infer_ragged", "infer_drift100"])
+def test_full_inference_matches_reference_with_x3w_forced(dev, monkeypatch, case):
+    """The parity bar (|dmel| < 1e-4 against the reference's own output; the T = 800 x 100-step and the 100-step drift cases included) with
+    every DiffNet stack pass on the split-operand kernel's Winograd form (odd T: the launch falls back to the direct form)."""
+    monkeypatch.setenv("SET_AMD_X3", "2")
+    monkeypatch.setenv("SET_AMD_SPLIT", "0")
+    monkeypatch.setenv("SET_AMD_X3_TILE", "64")
+    monkeypatch.setenv("SET_AMD_X3_WINO", "1")
+    g = load_golden(case)
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"], **m["overrides"])
+    inp, noises = _case_inputs(g, dev)
+    ret = model(inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"],
+                inp["f0"], inp["uv"], infer=True, noises=noises, persistent=True, **m["flags"])
+    torch.cuda.synchronize()
+    d = _maxdiff(ret["mel_out"], g["mel_out"])
+    print("%s (split-operand Winograd): max|dmel| = %.3e" % (case, d))
     assert d < 1e-4
 
 

@@ -1,7 +1,7 @@
-"""Round 6 A/B: the reverse loop of the metric's configuration (B = 32, T = 800, 100 steps, Philox noise) as ONE launch (SET_AMD_LOOP_LAUNCH=1:
-step boundaries as tasks of the persistent queue, csrc/diffnet_x3.hip) against the per-step launches (stack + boundary + flag reset per step),
-with socket power / shader clock sampled over each sustained run (hwmon, tools/power_probe.py) and a bit-for-bit comparison of the mels.
-usage: python tools/loop_launch_probe.py [seconds per variant (default 6)] [extra variants: grid=<n> ...]"""
+"""Round 6 A/B harness: the reverse loop of the metric's configuration (B = 32, T = 800, 100 steps, Philox noise) under several environment
+variants of the same library build (or, with SET_AMD_LIB, of an experiment build), socket power / shader clock sampled over each sustained run
+(hwmon, tools/power_probe.py), the mels of every variant compared with the first one.  Logs: profiles/r06_*_ab.log.
+usage: python tools/loop_ab_probe.py [seconds per variant (default 6)] [only-extra] [env:<name>:K=V,K=V ...]"""
 import json, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,13 +24,17 @@ def step(seed, spans=False):
 
 
 files = hwmon_files()
-variants = [("per_step_launches", {"SET_AMD_LOOP_LAUNCH": "0"}), ("whole_loop_launch", {"SET_AMD_LOOP_LAUNCH": "1"})]
+variants = [("per_step_launches", {"SET_AMD_X3_WINO": "0"}), ("x3_winograd_default", {})]
 for a in sys.argv[2:]:
-    if a.startswith("grid="):
-        variants.append(("whole_loop_launch_grid%s" % a[5:], {"SET_AMD_LOOP_LAUNCH": "1", "SET_AMD_STACK_GRID": a[5:]}))
+    if a.startswith("env:"):  # env:NAME:K=V,K=V -- any other variant of the same loop
+        _, name, kv = a.split(":", 2)
+        variants.append((name, dict(x.split("=", 1) for x in kv.split(","))))
+    elif a == "only-extra":
+        variants = variants[:1] + variants[2:]
+# (round-6 history: SET_AMD_LOOP_LAUNCH selected the whole-loop kernel of commit 9e25393; per_step_launches now = the direct split-operand form)
 mels = {}
 for name, env in variants:
-    for k in ("SET_AMD_LOOP_LAUNCH", "SET_AMD_STACK_GRID"):
+    for k in ("SET_AMD_LOOP_LAUNCH", "SET_AMD_STACK_GRID", "SET_AMD_X3_WINO"):
         os.environ.pop(k, None)
     os.environ.update(env)
     for w in range(2):

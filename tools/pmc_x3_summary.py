@@ -10,7 +10,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["speech-editing-toolkit_amd/csrc/diffnet_x3.hip", "speech-editing-toolkit_amd/csrc/common.h"]
+KERNEL_SOURCES = ["speech-editing-toolkit_amd/csrc/diffnet_x3.hip", "speech-editing-toolkit_amd/csrc/boundary_x2.h", "speech-editing-toolkit_amd/csrc/common.h"]
 
 
 def source_sha():
@@ -24,7 +24,9 @@ def collect(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         n = r["Kernel_Name"]
-        if "diffnet_stack_x3_kernel" in n and "pack_" not in n:
+        if "diffnet_stack_x3w_kernel" in n:  # round 6: the Winograd form of the two-piece fp16 kernel
+            acc["diffnet_stack_x3w_kernel"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        elif "diffnet_stack_x3_kernel" in n and "pack_" not in n:
             key = "diffnet_stack_x3_kernel<%s>" % ("SplitF16x2" if "SplitF16x2" in n else "SplitBf16x3")
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in acc.items()}

@@ -12,5 +12,5 @@ timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -s -k "full800 or wh
 grep -h "infer_full800\|max|dmel|" $OUT/step1_new_tests.log | tail -12
 timeout 600 python -m pytest tests/test_integration_doc.py tests/test_gpu_training.py -q -x -s -k "section_b or operands_are_released" > $OUT/step1_misc_tests.log 2>&1; echo "misc rc=$?" | tee -a $OUT/step1_misc_tests.log
 grep -h "INTEGRATION\|leaf operand" $OUT/step1_misc_tests.log | tail -4
-timeout 600 python tools/loop_launch_probe.py 6 grid=240 grid=288 > $OUT/loop_launch_ab.log 2>&1; cat $OUT/loop_launch_ab.log | tail -12
+timeout 600 python tools/loop_ab_probe.py 6 grid=240 grid=288 > $OUT/loop_launch_ab.log 2>&1; cat $OUT/loop_launch_ab.log | tail -12
 timeout 1500 python -m pytest tests -m gpu -q -x > $OUT/pytest_gpu_step1.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu_step1.log; tail -3 $OUT/pytest_gpu_step1.log
