@@ -496,7 +496,7 @@ def run_infer(args, rank, world, dev):
                                "fp32-equivalent results from 16-bit MFMAs.  bf16x3: every fp32 operand is the sum of THREE bf16 "
                                "pieces (8 + 8 + 8 = 24 significand bits) and a product is the six cross terms down to 2^-16; fp32 "
                                "accumulation.  ") +
-                              + ("GEMM 1 (the k = 3 dilated conv) runs in its Winograd F(2,3) form over output pairs on the same two-piece "
+                              ("GEMM 1 (the k = 3 dilated conv) runs in its Winograd F(2,3) form over output pairs on the same two-piece "
                                  "operands (tests ::test_x3w_*: error against fp64 within 2 x the fp32 chain's, the T = 800 x 100-step reference "
                                  "golden at 1.7e-6).  " if x3w else "") +
                               "Asserted: error of a layer stack against fp64 <= 1.5 x the native fp32-MFMA chain's "

@@ -121,6 +121,13 @@ __device__ __forceinline__ u32x4_t buf_load_u4(rsrc_t r, unsigned voff, unsigned
 __device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 __device__ __forceinline__ int urow(int r) { return (r & 3) + 8 * (r >> 2); }  // + 4 * (lane >> 5)
+// read-once streams (the conditioner projection, the running skip sum): nt = evict-first at the L2, which the layer images live in
+#ifndef SET_X3W_NT
+#define SET_X3W_NT 1  // measured (round 6, profiles/r06_x3w_nt_ab.log): 1.664 against 1.688 ms per launch; 0 = plain loads
+#endif
+__device__ __forceinline__ float buf_load_nt(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, SET_X3W_NT ? 2 : 0));
+}
 __device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ---- weight images --------------------------------------------------------------------------------------------------
@@ -311,7 +318,7 @@ __device__ __forceinline__ void x3_init(const X3Tile &a, f32x16 (&acc)[NU][2][NC
                 for (int r = 0; r < 16; ++r) {
                     const unsigned ur = (unsigned)((rb ? XC : 0) + 32 * (NU * w + u) + urow(r));
                     const float blo = bd[urow(r)], bhi = bd[urow(r) + 4];
-                    acc[u][rb][cb][r] = (half ? bhi : blo) + buf_load(rcp, vo4, ur * T4);
+                    acc[u][rb][cb][r] = (half ? bhi : blo) + buf_load_nt(rcp, vo4, ur * T4);
                 }
             }
     }
@@ -506,7 +513,7 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[NU][2][NC
 #pragma unroll
             for (int u = 0; u < NU; ++u)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sk[u][cb][r] = buf_load(rsk, vo4[cb], (unsigned)(32 * (NU * w + u) + urow(r)) * T4);
+                for (int r = 0; r < 16; ++r) sk[u][cb][r] = buf_load_nt(rsk, vo4[cb], (unsigned)(32 * (NU * w + u) + urow(r)) * T4);
         }
     };
     if constexpr (NU == 1) load_sk();
@@ -701,6 +708,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 buf_load2(rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
 }
+// (measured and not kept: the epilogue's write-through stores as nt stores too -- 1.719 against 1.659 ms per launch, profiles/r06_x3w_nt_ab.log)
+__device__ __forceinline__ f32x2 buf_load2_nt(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, SET_X3W_NT ? 2 : 0));
+}
 // lane i <- lane i - 1 / lane i + 1 of the wave (DPP wave_shr:1 / wave_shl:1; the ends get `old`)
 __device__ __forceinline__ float wave_prev(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
@@ -734,7 +745,7 @@ __device__ __forceinline__ void x3w_init(const X3Tile &a, f32x16 (&EO)[2][2]) {
         for (int r = 0; r < 16; ++r) {
             const unsigned ur = (unsigned)((rb ? XC : 0) + 32 * w + urow(r));
             const float blo = bd[urow(r)], bhi = bd[urow(r) + 4];
-            const f32x2 v = buf_load2(rcp, vo, ur * T4);
+            const f32x2 v = buf_load2_nt(rcp, vo, ur * T4);
             EO[0][rb][r] = (half ? bhi : blo) + v[0];
             EO[1][rb][r] = (half ? bhi : blo) + v[1];
         }
@@ -966,7 +977,7 @@ __device__ __forceinline__ void x3w_main(const X3Tile &a, f32x16 (&EO)[2][2], un
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+            for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load_nt(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
     }
     __syncthreads();
     X3W_PHASE(3)
