@@ -343,14 +343,41 @@ def dist_facts(dev, world, elapsed):
     """Proof that the ranks really talk: world size as the process group sees it, an all-reduce that every rank must
     join (sum of rank+1), and every rank's own elapsed time."""
     import torch.distributed as dist
+    me = device_identity(dev)
     if world == 1:
-        return {"rccl_ranks": 1, "backend": None, "per_rank_s": [elapsed]}
+        return {"rccl_ranks": 1, "backend": None, "per_rank_s": [elapsed], "devices": [me]}
     one = torch.tensor([float(dist.get_rank() + 1)], device=dev)
     dist.all_reduce(one)
     assert int(one.item()) == world * (world + 1) // 2, "all-reduce did not reach every rank"
     per = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
     dist.all_gather(per, torch.tensor([elapsed], dtype=torch.float64, device=dev))
-    return {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "per_rank_s": [float(p.item()) for p in per]}
+    # which physical device every rank ran on (a first multi-GPU run must show N DIFFERENT devices, not N ranks on one)
+    devs = [None] * world
+    dist.all_gather_object(devs, me)
+    ids = [d.get("uuid") or d.get("pci") for d in devs]
+    return {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "per_rank_s": [float(p.item()) for p in per],
+            "devices": devs, "distinct_devices": len(set(ids)) if all(ids) else None}
+
+
+def overlap_frac(bucketer):
+    if not getattr(bucketer, "enabled", False) or not bucketer.buckets:
+        return None
+    tot = sum(e - s0 for s0, e in bucketer.buckets)
+    hook = sum(bucketer.buckets[b][1] - bucketer.buckets[b][0] for b, how in getattr(bucketer, "launch_log", []) if how == "hook")
+    return hook / tot if tot else None
+
+
+def device_identity(dev):
+    """{"rank", "local_device", "name", "uuid", "pci", "hip_visible_devices"} of the device this rank runs on."""
+    out = {"rank": int(os.environ.get("RANK", 0)), "local_device": str(dev), "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES")}
+    if dev.type == "cuda":
+        pr = torch.cuda.get_device_properties(dev)
+        out["name"] = pr.name
+        u = getattr(pr, "uuid", None)
+        out["uuid"] = str(u) if u is not None else None
+        out["pci"] = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+        out["n_cu"] = pr.multi_processor_count
+    return out
 
 
 def run_infer(args, rank, world, dev):
@@ -462,6 +489,8 @@ def run_infer(args, rank, world, dev):
                    "sharding": "utterances r::N, no collective"},
         "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"],
         "per_rank_ms_per_step": [1e3 * s / args.steps for s in facts["per_rank_s"]],
+        "devices": facts.get("devices"), "distinct_devices": facts.get("distinct_devices"),
+        "collective_bytes_per_step": 0,  # inference shards by utterance: no data-path collective
         # achieved = MFMA FLOPs the dominant kernel issues per launch / its mean launch duration, against the dense peak of
         # the pipe it issues them on; algorithmic_* = the fp32 FLOPs of the layer math (conditioner
         # projection hoisted) over the same time, for comparison with rounds that ran on the fp32 pipe
@@ -971,7 +1000,11 @@ def run_train(args, rank, world, dev):
         "frames_per_s": None if stub_device() else n_samples * T / t_max, "host_enqueue_ms_per_step": 1e3 * enqueue / args.steps,
         "rccl_ranks": facts["rccl_ranks"], "dist_backend": facts["backend"], "replicas_identical_after_steps": same_after,
         "per_rank_ms_per_step": [1e3 * s / args.steps for s in facts["per_rank_s"]],
+        "devices": facts.get("devices"), "distinct_devices": facts.get("distinct_devices"),
         "allreduce_bytes_per_step": reduced, "allreduce_exposed_ms_per_step": 1e3 * exposed / args.steps,
+        # of the bytes exchanged in the last step: the share whose all-reduce was LAUNCHED from a gradient hook, i.e. under the rest of
+        # backward (the remainder was launched by finish() after backward); with exposed_ms this says how much of the exchange was hidden
+        "allreduce_launched_under_backward_frac": overlap_frac(opt.bucketer),
         "param_broadcast_bytes": bcast_bytes, "grad_elems": opt.n, "grad_elems_exchanged": opt.n_exchanged,
         "loss": float(total), "lr": lr, "losses": {k: float(v) for k, v in parts.items()},
         # roofline = the step's dominant kernel (largest share of the GPU time; hipEvents on its launch stream over extra steps right
