@@ -1008,10 +1008,12 @@ __device__ __forceinline__ void x3w_main(const X3Tile &a, f32x16 (&EO)[2][2], un
 #undef X3W_PHASE
 
 // the persistent (layer, tile) queue of diffnet_stack_x3_kernel with the Winograd form of GEMM 1 on every tile it covers
-// Measured and not kept (round 6, profiles/r06_x3w_xcd_chunks_ab.log): XCD-aware claiming -- the blocks of one XCD (blockIdx.x % 8) taking chunks
-// of 32 consecutive tasks from a counter of their own, so that the 32 CUs sharing an L2 stream the same layer image: 1.718 ms per launch
-// against 1.672 ms with the one global counter (1,287 W against 1,319 W: the groups drift apart and their tasks wait for each other's
-// tiles).  Any free block taking the next task matters more than which L2 the image sits in.
+// Measured and not kept (round 6, profiles/r06_x3w_xcd_chunks_ab.log): XCD-aware task claiming -- the blocks of one XCD (blockIdx.x % 8) taking
+// their tasks from a chunk of 16 / 32 / 64 consecutive tiles of ONE layer, so that the 32 CUs sharing an L2 stream the same layer image.
+// Static chunk ownership (group g owns chunks g, g + 8, ..): 1.718 against 1.672 ms per launch at 1,287 W (groups drift apart and wait for each
+// other's tiles).  Chunks handed out dynamically (no block ever waits for work): 2.69 - 3.08 ms at 1,050 - 1,180 W and the maximum clock -- the
+// CUs of an XCD then run in lockstep and ask the L2 for the SAME weight fragments at the same moment.  The one global counter, which spreads
+// the CUs of an XCD over the phases of a task, is the better schedule; the 1.7 x algorithmic HBM bytes are its price.
 __global__ void __launch_bounds__(512, 1) diffnet_stack_x3w_kernel(SetDiffnetStackArgs a, int ntiles, int ntasks, unsigned piece_bytes, int fault_tile) {
     typedef SplitF16x2 S;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
