@@ -718,9 +718,9 @@ def bf16_loop_line(model, inp, args, ret_f32_seed0):
     fuse = int(_lib.lib().set_diffnet_layers_bf16_plan(B_PER_GPU, T, L, 1))
     # HBM bytes per group launch from the PMC passes of THESE kernel sources (tools/sessions/gpu_pmc_bf16_layers.sh; sha256-checked like the headline's)
     traffic, traffic_note, pmc = None, "no PMC file", None
-    tfile = os.path.join(ROOT, "profiles", "r05_pmc_bf16_layers.json")
+    tfile = os.path.join(ROOT, "profiles", "r06_pmc_bf16_layers.json")
     if not os.path.exists(tfile):
-        tfile = os.path.join(ROOT, "profiles", "r04_pmc_bf16_layers.json")
+        tfile = os.path.join(ROOT, "profiles", "r05_pmc_bf16_layers.json")
     if os.path.exists(tfile):
         import hashlib
         with open(tfile) as f:
@@ -853,7 +853,9 @@ class _EagerStep:
         return self.task.training_step(sample, self.opt, seed=seed)
 
 
-TRAIN_PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_train.json")
+TRAIN_PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_train.json")
+if not os.path.exists(TRAIN_PMC_FILE):
+    TRAIN_PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_train.json")
 TRAIN_KERNEL_SOURCES = ["speech-editing-toolkit_amd/csrc/diffnet_bf16.hip", "speech-editing-toolkit_amd/csrc/bf16.hip",
                         "speech-editing-toolkit_amd/csrc/common.h", "speech-editing-toolkit_amd/csrc/rows_sum.h",
                   "speech-editing-toolkit_amd/csrc/train.hip", "speech-editing-toolkit_amd/autograd_ops.py"]
@@ -861,7 +863,7 @@ TRAIN_KERNEL_SOURCES = ["speech-editing-toolkit_amd/csrc/diffnet_bf16.hip", "spe
 
 def _profiled(key, model, dtype):
     """A figure that cannot be measured inside this process (rocprofv3 PMC / kernel-trace passes of `bench.py --mode train`,
-    tools/sessions/gpu_r5_final.sh -> profiles/r05_pmc_train.json), quoted only while the sha256 of the kernel sources it was taken on matches."""
+    tools/sessions/gpu_r6_final.sh -> profiles/r06_pmc_train.json), quoted only while the sha256 of the kernel sources it was taken on matches."""
     if not os.path.exists(TRAIN_PMC_FILE):
         return None
     import hashlib
@@ -899,7 +901,7 @@ def _train_dominant_kernel(args, step_fn, sample, dev, bpg):
         return {"kernel": "diffnet_layer_bwd_bf16_kernel", "launches_per_step": L, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
                 "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": ent.get("traffic_bytes"), "launch_ms": per_launch_ms,
                 "algorithmic_bytes_per_launch": bytes_launch, "share_of_step_gpu_time": L * per_launch_ms,
-                "traffic_note": "PMC passes of this kernel build (profiles/r05_pmc_train.json, source sha256 matches)" if ent else
+                "traffic_note": "PMC passes of this kernel build (%s, source sha256 matches)" % os.path.relpath(TRAIN_PMC_FILE, ROOT) if ent else
                                 "no PMC figure for these kernel sources"}
     if not convs:
         return None
@@ -928,7 +930,7 @@ def _train_dominant_kernel(args, step_fn, sample, dev, bpg):
             "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": gbs / PEAK_HBM_GBS if hbm_bound else tfl / peak,
             "traffic": ent.get("traffic_bytes"), "launch_ms": ms / n, "flop_per_launch": fl, "algorithmic_bytes_per_launch": by_l,
             "mfma_TFLOPs": tfl, "hbm_GBps": gbs, "share_of_step_gpu_time": ms / 5.0,
-            "traffic_note": "PMC passes, mean over ALL launches of this kernel family in a step, i.e. over its shapes (profiles/r05_pmc_train.json)" if ent else
+            "traffic_note": "PMC passes, mean over ALL launches of this kernel family in a step, i.e. over its shapes (%s)" % os.path.relpath(TRAIN_PMC_FILE, ROOT) if ent else
                             "no PMC figure for these kernel sources"}
 
 

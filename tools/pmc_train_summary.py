@@ -1,4 +1,4 @@
-"""rocprofv3 passes over `bench.py --mode train` -> profiles/r05_pmc_train.json: per kernel family the HBM bytes per launch
+"""rocprofv3 passes over `bench.py --mode train` -> profiles/r06_pmc_train.json: per kernel family the HBM bytes per launch
 (2 x FETCH_SIZE + WRITE_SIZE KB, the gfx950 half-count correction of MI355X_MICROARCH.md's HBM section; separate --pmc passes) and, from a
 plain kernel trace, the launches per step; stamped with the sha256 of the kernel sources (bench.py quotes the figures only while it matches).
 usage: python tools/pmc_train_summary.py <out.json> <model>_<dtype> <fetch.csv> <write.csv> <kernel_stats.csv> [more triples of the other model]"""
@@ -13,9 +13,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ["speech-editing-toolkit_amd/csrc/diffnet_bf16.hip", "speech-editing-toolkit_amd/csrc/bf16.hip",
                   "speech-editing-toolkit_amd/csrc/common.h", "speech-editing-toolkit_amd/csrc/rows_sum.h",
-                  "speech-editing-toolkit_amd/csrc/train.hip", "speech-editing-toolkit_amd/autograd_ops.py"]
+                  "speech-editing-toolkit_amd/csrc/train.hip", "speech-editing-toolkit_amd/csrc/conv1d.hip",
+                  "speech-editing-toolkit_amd/autograd_ops.py"]
 FAMILIES = ["diffnet_layer_bwd_bf16_kernel", "diffnet_layer_fwd_bf16_kernel", "conv1d_wgrad3_bf16_kernel", "conv1d_wgrad_bf16_kernel",
-            "conv1d_bf16_kernel", "conv1x1_oneshot_bf16_kernel", "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn_fwd_kernel"]
+            "conv1d_bf16_kernel", "conv1x1_oneshot_bf16_kernel", "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn_fwd_kernel",
+            # fp32 step (round 6: the reference's default precision had no PMC figure): the two generic fp32 MFMA conv kernels, the Winograd stack
+            "conv1d_mfma_v2_kernel", "conv1d_mfma_kernel", "diffnet_stack_wino_kernel"]
 
 
 def source_sha():
