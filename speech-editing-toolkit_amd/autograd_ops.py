@@ -61,17 +61,18 @@ _ACTIVE = [None]    # the arena of the optimisation step in progress (steps do n
 # d_o and dy of 20 layers (2.1 GB at B = 32, T = 800) alive that way, growing with depth.  After every ~SET_AMD_LEAF_MARK_MB (128) MB of newly
 # held operands a marker event is recorded on the leaf stream (set_stream_mark); at the next fork the markers that have completed
 # (set_stream_mark_done, a non-blocking query) release everything held before them: those kernels have RUN, so whoever gets the storage
-# next cannot race them.  Above SET_AMD_LEAF_KEEP_MB (4096) MB of held operands the compute stream is made to wait for the leaf stream
-# (an early leaf_join) -- the bound; not the normal path at the benchmark shapes (fp32 step at B = 32, T = 800: 2.5 GB at the peak, no early
-# join).  Measured (profiles/r06_leaf_operands.log): the lowest-priority leaf stream runs late, so markers rarely complete inside a
-# backward pass -- it is the cap that bounds the memory; with a 64 MB cap the step joins 26 times and stays bit-identical.
+# next cannot race them.  Above SET_AMD_LEAF_KEEP_MB (16384; 0 = no accounting) MB of held operands the compute stream is made to wait for the
+# leaf stream (an early leaf_join) -- the bound, sized for a 288 GB part; not the normal path at the benchmark shapes: every early join
+# gives up overlap (fp32 step at B = 32, T = 800 with a 4 GB cap: 31.9 against 30.9 ms, profiles/r06_leaf_accounting_ab.log; the bf16 steps
+# hold less and do not move).  Measured (profiles/r06_leaf_operands.log): the lowest-priority leaf stream runs late, so markers rarely
+# complete inside a backward pass -- it is the cap that bounds the memory; with a 64 MB cap the step joins 26 times and stays bit-identical.
 _LEAF = {}  # device index -> {"stream" (torch object, kept alive), "raw" (handle), "dirty", "keep" (operands of queued leaf kernels), ...}
 _LEAF_STATS = {"max_keep_bytes": 0, "released_by_marker": 0, "early_joins": 0}
 
 
 def _mb_env(name, default):
     try:
-        return max(1, int(os.environ.get(name, default))) << 20
+        return max(0, int(os.environ.get(name, default))) << 20
     except ValueError:
         return int(default) << 20
 
@@ -85,7 +86,7 @@ def _nbytes(obj):
 
 
 def _leaf_hold(st, obj):
-    n = _nbytes(obj)
+    n = _nbytes(obj) if st["cap_bytes"] else 0  # SET_AMD_LEAF_KEEP_MB=0: no accounting (operands held until the join, as in round 5)
     st["keep"].append((obj, n))
     st["count"] += 1
     st["bytes"] += n
@@ -149,7 +150,7 @@ def _leaf_state(dev):
         stream = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
         st = _LEAF[idx] = {"stream": stream, "raw": raw, "dirty": False, "keep": collections.deque(), "idx": idx,
                            "marks": collections.deque(), "count": 0, "base": 0, "bytes": 0, "unmarked": 0,
-                           "mark_bytes": _mb_env("SET_AMD_LEAF_MARK_MB", 128), "cap_bytes": _mb_env("SET_AMD_LEAF_KEEP_MB", 4096)}
+                           "mark_bytes": _mb_env("SET_AMD_LEAF_MARK_MB", 128), "cap_bytes": _mb_env("SET_AMD_LEAF_KEEP_MB", 16384)}
     return st
 
 
@@ -178,7 +179,7 @@ class leaf_work:
         st = _leaf_state(self.dev)
         if st["marks"]:
             _leaf_poll(st)
-        if st["bytes"] > st["cap_bytes"]:  # the bound: the compute stream waits for the leaf stream, everything held so far is released
+        if st["cap_bytes"] and st["bytes"] > st["cap_bytes"]:  # the bound: the compute stream waits for the leaf stream, everything held so far is released
             _order(st, False)
             _leaf_release_all(st)
             _LEAF_STATS["early_joins"] += 1

@@ -776,10 +776,12 @@ __device__ __forceinline__ void x3w_plane(f32x16 (&acc)[2], u32x4_t (&A)[PFW][2]
             __builtin_amdgcn_s_setprio(0);
 #endif
             const int kn = min(ks + PFW, X_KSW - 1);
+#if !(SET_X3_EXP & 8)  // (measurement builds, bit 3: no weight-fragment stream in the Winograd GEMM -- WRONG RESULTS)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) A[p][rb][q] = buf_load_u4(img, lane16, abase + (unsigned)(((kn * 2 + rb) * 2 + q) * 1024));
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }

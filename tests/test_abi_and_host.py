@@ -329,6 +329,18 @@ def test_stack_kernel_selection_rules(built_lib, monkeypatch):
     assert ops.stack_variant(8, 800, 1, have_split=False, x3_mode=0) == 1               # fp32 pipe: direct, 32-frame tiles
     assert ops.stack_variant(4, 800, 1, x3_mode=0) == 3                                 # fp32 row-split: up to 2 blocks per CU
     assert ops.stack_variant(32, 800, 5) == 0 or ops.stack_variant(32, 800, 5) == 1     # dilation 16: direct kernels only
+    # round 6: the two-piece fp16 kernel runs GEMM 1 in its Winograd form on 64-frame tiles, dilation 1, even T -- and nowhere else
+    for k in ("SET_AMD_X3_WINO", "SET_AMD_X3_TILE"):
+        monkeypatch.delenv(k, raising=False)
+    assert ops.stack_x3_winograd(32, 800, 1) and ops.stack_x3_winograd(64, 800, 1) and ops.stack_x3_winograd(32, 802, 1)
+    assert not ops.stack_x3_winograd(32, 801, 1)           # odd T: the direct form
+    assert not ops.stack_x3_winograd(32, 800, 2)           # dilation cycles: the direct form
+    assert not ops.stack_x3_winograd(8, 800, 1)            # part-filled chip: 32-frame tiles of the direct form
+    assert not ops.stack_x3_winograd(2, 800, 1)            # row-split kernel (variant 3)
+    assert not ops.stack_x3_winograd(32, 800, 1, x3_mode=3) and not ops.stack_x3_winograd(32, 800, 1, x3_mode=0)
+    monkeypatch.setenv("SET_AMD_X3_WINO", "0")
+    assert not ops.stack_x3_winograd(32, 800, 1)
+    monkeypatch.delenv("SET_AMD_X3_WINO")
     monkeypatch.setenv("SET_AMD_X3", "0")
     assert ops.stack_variant(32, 800, 1) == 2
     monkeypatch.setenv("SET_AMD_X3", "2")
