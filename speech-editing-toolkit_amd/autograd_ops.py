@@ -61,10 +61,10 @@ _ACTIVE = [None]    # the arena of the optimisation step in progress (steps do n
 # d_o and dy of 20 layers (2.1 GB at B = 32, T = 800) alive that way, growing with depth.  After every ~SET_AMD_LEAF_MARK_MB (128) MB of newly
 # held operands a marker event is recorded on the leaf stream (set_stream_mark); at the next fork the markers that have completed
 # (set_stream_mark_done, a non-blocking query) release everything held before them: those kernels have RUN, so whoever gets the storage
-# next cannot race them.  Above SET_AMD_LEAF_KEEP_MB (16384; 0 = no accounting) MB of held operands the compute stream is made to wait for the
-# leaf stream (an early leaf_join) -- the bound, sized for a 288 GB part; not the normal path at the benchmark shapes: every early join
-# gives up overlap (fp32 step at B = 32, T = 800 with a 4 GB cap: 31.9 against 30.9 ms, profiles/r06_leaf_accounting_ab.log; the bf16 steps
-# hold less and do not move).  Measured (profiles/r06_leaf_operands.log): the lowest-priority leaf stream runs late, so markers rarely
+# next cannot race them.  Above SET_AMD_LEAF_KEEP_MB (8192; 0 = no accounting) MB of held operand STORAGE (views of one saved buffer count
+# once) the compute stream is made to wait for the leaf stream (an early leaf_join) -- the bound, sized for a 288 GB part; not the normal
+# path at the benchmark shapes: every early join gives up overlap (a first accounting that counted every view -- 18 GB "held" in the fp32
+# step -- joined early and cost it 0.9 ms: 31.9 against 30.9 ms, profiles/r06_leaf_accounting_ab.log).  Measured (profiles/r06_leaf_operands.log): the lowest-priority leaf stream runs late, so markers rarely
 # complete inside a backward pass -- it is the cap that bounds the memory; with a 64 MB cap the step joins 26 times and stays bit-identical.
 _LEAF = {}  # device index -> {"stream" (torch object, kept alive), "raw" (handle), "dirty", "keep" (operands of queued leaf kernels), ...}
 _LEAF_STATS = {"max_keep_bytes": 0, "released_by_marker": 0, "early_joins": 0}
@@ -77,27 +77,53 @@ def _mb_env(name, default):
         return int(default) << 20
 
 
-def _nbytes(obj):
+def _storages(obj, out):
+    """(storage address, storage bytes) of every tensor in obj (tuples / lists nested): operands are often VIEWS of one saved buffer
+    (every layer's slice of the [L, B, 512, T] tensors of the fused stack) -- counting numel per view made the fp32 step look like
+    18 GB of held operands and join early for nothing (profiles/r06_leaf_accounting_ab.log)."""
     if isinstance(obj, torch.Tensor):
-        return obj.numel() * obj.element_size()
-    if isinstance(obj, (tuple, list)):
-        return sum(_nbytes(o) for o in obj)
-    return 0
+        s_ = obj.untyped_storage()
+        out.append((s_.data_ptr(), s_.nbytes()))
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            _storages(o, out)
 
 
 def _leaf_hold(st, obj):
-    n = _nbytes(obj) if st["cap_bytes"] else 0  # SET_AMD_LEAF_KEEP_MB=0: no accounting (operands held until the join, as in round 5)
-    st["keep"].append((obj, n))
+    keys = None
+    if st["cap_bytes"]:  # SET_AMD_LEAF_KEEP_MB=0: no accounting (operands held until the join, as in round 5)
+        keys, stor = [], st["stor"]
+        _storages(obj, keys)
+        for k, n in keys:
+            ent = stor.get(k)
+            if ent is None:
+                stor[k] = [1, n]
+                st["bytes"] += n
+                st["unmarked"] += n
+            else:
+                ent[0] += 1
+    st["keep"].append((obj, keys))
     st["count"] += 1
-    st["bytes"] += n
-    st["unmarked"] += n
     if st["bytes"] > _LEAF_STATS["max_keep_bytes"]:
         _LEAF_STATS["max_keep_bytes"] = st["bytes"]
+
+
+def _leaf_drop(st, keys):
+    if keys:
+        stor = st["stor"]
+        for k, n in keys:
+            ent = stor.get(k)
+            if ent is not None:
+                ent[0] -= 1
+                if ent[0] <= 0:
+                    del stor[k]
+                    st["bytes"] -= n
 
 
 def _leaf_release_all(st):
     st["keep"].clear()
     st["marks"].clear()
+    st["stor"].clear()
     st["base"], st["bytes"], st["unmarked"] = st["count"], 0, 0
 
 
@@ -108,8 +134,8 @@ def _leaf_poll(st):
         _, upto = marks.popleft()
         keep = st["keep"]
         while st["base"] < upto:
-            _, n = keep.popleft()
-            st["bytes"] -= n
+            _, keys = keep.popleft()
+            _leaf_drop(st, keys)
             st["base"] += 1
             _LEAF_STATS["released_by_marker"] += 1
 
@@ -149,8 +175,8 @@ def _leaf_state(dev):
             check(L().set_stream_create_low_priority(C.byref(raw)), "set_stream_create_low_priority")
         stream = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
         st = _LEAF[idx] = {"stream": stream, "raw": raw, "dirty": False, "keep": collections.deque(), "idx": idx,
-                           "marks": collections.deque(), "count": 0, "base": 0, "bytes": 0, "unmarked": 0,
-                           "mark_bytes": _mb_env("SET_AMD_LEAF_MARK_MB", 128), "cap_bytes": _mb_env("SET_AMD_LEAF_KEEP_MB", 16384)}
+                           "marks": collections.deque(), "stor": {}, "count": 0, "base": 0, "bytes": 0, "unmarked": 0,
+                           "mark_bytes": _mb_env("SET_AMD_LEAF_MARK_MB", 128), "cap_bytes": _mb_env("SET_AMD_LEAF_KEEP_MB", 8192)}
     return st
 
 

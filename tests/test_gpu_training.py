@@ -778,7 +778,7 @@ def test_leaf_stream_updates_equal_the_single_stream_updates_bit_for_bit(dev, dt
 def test_leaf_stream_operands_are_released_as_their_kernels_finish(dev):
     """Round 6 (advisor): the operands of leaf kernels used to be held until the end of backward() -- the fp32 DiffNet stack kept d_o and dy of all
     20 layers alive (2.1 GB at B = 32, T = 800), without a bound.  Now a marker event every ~128 MB of held operands releases what has already
-    run, and a byte cap (16 GB by default) makes the compute stream wait for the leaf stream.  Full-size fp32 step: (a) default budgets -- the peak of
+    run, and a byte cap (8 GB of operand storage by default) makes the compute stream wait for the leaf stream.  Full-size fp32 step: (a) default budgets -- the peak of
     held bytes stays under the cap without an early join; (b) budgets of 1 MB / 64 MB -- early joins happen and the peak drops to the cap plus
     the largest single set of operands (the fused stack's, ~1.1 GB); (c) a replica without the leaf stream: losses, parameters and Adam
     moments bit-identical after each of three updates in all three."""
@@ -803,7 +803,7 @@ def test_leaf_stream_operands_are_released_as_their_kernels_finish(dev):
             for name, (task, opt) in zip(("default", "tight", "single"), reps):
                 os.environ["SET_AMD_LEAF_STREAM"] = "0" if name == "single" else "1"
                 for st in A._LEAF.values():
-                    st["mark_bytes"], st["cap_bytes"] = ((1 << 20, 64 << 20) if name == "tight" else (128 << 20, 16384 << 20))
+                    st["mark_bytes"], st["cap_bytes"] = ((1 << 20, 64 << 20) if name == "tight" else (128 << 20, 8192 << 20))
                 A.leaf_stats(reset=True)
                 tot, parts, _ = task.training_step(sample, opt, t=t, seed=900 + it)
                 torch.cuda.synchronize()
@@ -814,12 +814,12 @@ def test_leaf_stream_operands_are_released_as_their_kernels_finish(dev):
                 assert torch.equal(opt.flat_p, outs[0][1].flat_p) and torch.equal(opt.m, outs[0][1].m) and torch.equal(opt.v, outs[0][1].v), it
         print("leaf operand bookkeeping (fp32, B=32, T=800), last step:", stats)
         assert stats["single"]["max_keep_bytes"] == 0
-        assert 0 < stats["default"]["max_keep_bytes"] <= (16384 << 20) and stats["default"]["early_joins"] == 0
+        assert 0 < stats["default"]["max_keep_bytes"] <= (8192 << 20) and stats["default"]["early_joins"] == 0
         assert stats["tight"]["early_joins"] > 0 and stats["tight"]["max_keep_bytes"] < stats["default"]["max_keep_bytes"]
         assert stats["tight"]["max_keep_bytes"] <= (64 << 20) + (1280 << 20)
     finally:
         for st in A._LEAF.values():
-            st["mark_bytes"], st["cap_bytes"] = 128 << 20, 16384 << 20
+            st["mark_bytes"], st["cap_bytes"] = 128 << 20, 8192 << 20
         if old_env is None:
             os.environ.pop("SET_AMD_LEAF_STREAM", None)
         else:
