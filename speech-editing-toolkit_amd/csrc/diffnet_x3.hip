@@ -693,8 +693,8 @@ int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_
 //     y[2p] = U0 V0 + U1 V1 + U2 V2,   y[2p + 1] = U1 V1 - U2 V2 - U3 V3   (U: pack_layer_x3_kernel)
 // i.e. 2/3 of GEMM 1's MFMAs, 3/4 of the layer's.  Price: every weight fragment now feeds ONE triple of MFMAs (32 pair-columns per
 // plane) instead of two, so the L2 -> CU fragment stream per MFMA doubles (2 MiB per task for GEMM 1 instead of 1.5), and the split /
-// transform work of the staging pass doubles.  64-frame tiles only, dilation 1, even T, both column blocks of the tile in ONE utterance;
-// any other tile of the launch takes x3_main (direct form) inside the same kernel -- the direct image is part of the layer image.
+// transform work of the staging pass doubles.  64-frame tiles only, dilation 1, even T; every tile of such a launch takes this form (the two
+// column blocks of a tile may lie in different utterances: x3w_lane below).
 // Same accumulation precision (fp32) and piece products; the sums are formed in a different order than the direct form: results agree
 // with it to fp32 rounding (like the fp32-pipe Winograd kernel of csrc/diffnet.hip), not bit for bit.
 // LDS: V tile [plane 4][piece 2][pair 32][XR] (132 KB; the z tile [piece][64][XR] overlays it), step offsets, task slots.
@@ -720,10 +720,23 @@ __device__ __forceinline__ float wave_next(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
-// a tile the Winograd form covers: both column blocks exist, lie in one utterance (then they are adjacent) and T is even
-__device__ __forceinline__ bool x3w_tile_ok(const X3Tile &a) {
-    const int q1 = a.q0 + 1;
-    return q1 < a.Q && (a.q0 / a.nbu) == (q1 / a.nbu) && (a.T & 1) == 0 && a.dil == 1;
+// Tile geometry of the Winograd form (round 6, second half): a tile is TWO 32-frame column blocks = 2 x 16 output pairs, and -- as in the direct
+// form -- every column block carries its own utterance, first frame and halo frames: lane l31 of a staging / accumulator-start fragment is pair
+// (l31 & 15) of column block (l31 >> 4).  T even: a pair never straddles an utterance end.  The first version ran the tiles whose two blocks lie in
+// different utterances (16 of 400 at B = 32, T = 800) through the direct form inside the same launch: each of them streamed the layer's 3 MiB
+// DIRECT image past the L2 for one tile (16 x 20 x 3 MiB = 1.0 GB of the 5.0 GB a launch fetched) and ran ~2 x as long as its neighbours wait for.
+struct X3wLane {
+    int b, t0;   // utterance and first frame of this lane's column block
+    bool ok;     // the block exists (the last tile of an odd block count has one)
+};
+__device__ __forceinline__ X3wLane x3w_lane(const X3Tile &a, int l31) {
+    const X3Col c0 = x3_col(a, 0), c1 = x3_col(a, 1);
+    const bool hi = l31 >= 16;
+    X3wLane r;
+    r.b = hi ? c1.b : c0.b;
+    r.t0 = hi ? c1.t0 : c0.t0;
+    r.ok = hi ? c1.ok : c0.ok;
+    return r;
 }
 
 // accumulator start: EO[0][rb] (even frames) / EO[1][rb] (odd frames) = b_dil + conditioner projection; lane l31 = pair
@@ -735,9 +748,9 @@ __device__ __forceinline__ void x3w_init(const X3Tile &a, f32x16 (&EO)[2][2]) {
     const int half = lane >> 5, l31 = lane & 31;
     const int T = a.T;
     const unsigned T4 = 4u * (unsigned)T;
-    const X3Col c = x3_col(a, 0);
-    const rsrc_t rcp = make_rsrc(a.cp + (int64_t)c.b * a.cp_bs);
-    const unsigned vo = 4u * (unsigned)(4 * half * T + min(c.t0 + 2 * l31, T - 2));
+    const X3wLane c = x3w_lane(a, l31);
+    const rsrc_t rcp = make_rsrc(a.cp);  // BATCH base: the utterance is part of the lane offset
+    const unsigned vo = 4u * ((unsigned)c.b * (unsigned)a.cp_bs + (unsigned)(4 * half * T + min(c.t0 + 2 * (l31 & 15), T - 2)));
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const float *bd = a.b_dil + (rb ? XC : 0) + 32 * w;
@@ -811,35 +824,40 @@ __device__ __forceinline__ void x3w_main(const X3Tile &a, f32x16 (&EO)[2][2], un
     const int T = a.T;
     const unsigned T4 = 4u * (unsigned)T;
     const unsigned lane16 = 16u * (unsigned)lane;
-    float *dsh = reinterpret_cast<float *>(lds + XW_TILE);  // [256] step offsets of the tile's utterance
-    const X3Col c0 = x3_col(a, 0);
-    const int b = c0.b, t0 = c0.t0;  // 64 frames t0 .. t0 + 63 of utterance b
-    const int64_t ub = (int64_t)b * XC * T;
+    float *dsh = reinterpret_cast<float *>(lds + XW_TILE);  // [2][256] step offsets of the two column blocks' utterances
+    const X3Col c0 = x3_col(a, 0), c1 = x3_col(a, 1);
+    const X3wLane cl = x3w_lane(a, l31);  // staging / gate layout: lane = pair (l31 & 15) of column block (l31 >> 4)
     const rsrc_t rw = make_rsrc(a.img);
     const float *sc = reinterpret_cast<const float *>(a.img + x_n1<S>() + x_n2<S>());
     const float s2 = sc[2], is2 = sc[3];
     const float *scw = reinterpret_cast<const float *>(a.img + x_nimg<S>() - 8);
     const float s1w = scw[0], is1w = scw[1];
+    // GEMM 2 / epilogue layout: column block cb, lane = frame l31 of it
     bool tv[2];
     unsigned vo4[2];
+    int64_t ub[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-        const int t = t0 + 32 * cb + l31;
-        tv[cb] = t < T;
+        const X3Col c = cb ? c1 : c0;
+        const int t = c.t0 + l31;
+        tv[cb] = c.ok && t < T;
         vo4[cb] = 4u * (unsigned)(4 * half * T + min(t, T - 1));
+        ub[cb] = (int64_t)c.b * XC * T;
     }
-    // ---- stage: lane = (pair p = l31, channel group cg = 2 w + half of 16 channels): d1, d2 by one 8-byte load per channel, d0 / d3 from
-    //      the neighbouring lanes (the ends of the tile from two halo loads), transform, split, 16-byte writes per (plane, piece)
+    // ---- stage: lane = (pair, channel group cg = 2 w + half of 16 channels): d1, d2 by one 8-byte load per channel, d0 / d3 from
+    //      the neighbouring lanes (the ends of a column block from two halo loads), transform, split, 16-byte writes per (plane, piece)
     {
-        if (tid < XC) dsh[tid] = a.dstep[(int64_t)b * a.d_bs + (int64_t)tid * a.d_cs];
+        dsh[tid] = a.dstep[(int64_t)((tid >> 8) ? c1.b : c0.b) * a.d_bs + (int64_t)(tid & (XC - 1)) * a.d_cs];  // 512 threads = 2 x 256
         const int cg = 2 * w + half, ch0 = 16 * cg;
-        const rsrc_t rx = make_rsrc(a.xin + ub);
-        const int t = t0 + 2 * l31;                       // frames t, t + 1 (T even: both inside or both outside)
-        const bool v12 = t < T;
-        const int th = l31 == 0 ? t0 - 1 : t0 + 64;       // halo frame of the end lanes
-        const bool edge = l31 == 0 || l31 == 31, vh = edge && th >= 0 && th < T;
-        const unsigned cgo = (unsigned)ch0 * T4;
+        const int pl = l31 & 15;
+        const rsrc_t rx = make_rsrc(a.xin);               // BATCH base: the utterance is part of the lane offset
+        const int t = cl.t0 + 2 * pl;                     // frames t, t + 1 (T even: both inside or both outside)
+        const bool v12 = cl.ok && t < T;
+        const int th = pl == 0 ? cl.t0 - 1 : cl.t0 + 32;  // halo frame of the block's end lanes
+        const bool edge = pl == 0 || pl == 15, vh = cl.ok && edge && th >= 0 && th < T;
+        const unsigned cgo = (unsigned)ch0 * T4 + 4u * (unsigned)(cl.b * XC * T);
         const unsigned vox = 4u * (unsigned)min(t, T - 2) + cgo, voh = 4u * (unsigned)min(max(th, 0), T - 1) + cgo;
+        const float *dshl = dsh + (l31 >> 4) * XC;
         f32x2 x12[16];
         float xh[16];
 #pragma unroll
@@ -853,8 +871,8 @@ __device__ __forceinline__ void x3w_main(const X3Tile &a, f32x16 (&EO)[2][2], un
 #pragma unroll
         for (int q8 = 0; q8 < 2; ++q8) {
             unsigned short pc[4][8][2];  // [plane][channel][piece]
-            const f32x4 dA = *reinterpret_cast<const f32x4 *>(dsh + ch0 + 8 * q8);
-            const f32x4 dB = *reinterpret_cast<const f32x4 *>(dsh + ch0 + 8 * q8 + 4);
+            const f32x4 dA = *reinterpret_cast<const f32x4 *>(dshl + ch0 + 8 * q8);
+            const f32x4 dB = *reinterpret_cast<const f32x4 *>(dshl + ch0 + 8 * q8 + 4);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = 8 * q8 + e;
@@ -862,8 +880,8 @@ __device__ __forceinline__ void x3w_main(const X3Tile &a, f32x16 (&EO)[2][2], un
                 const float d1 = v12 ? x12[k][0] + ds : 0.0f, d2 = v12 ? x12[k][1] + ds : 0.0f;
                 float d0 = wave_prev(d2), d3 = wave_next(d1);
                 const float hv = vh ? xh[k] + ds : 0.0f;
-                d0 = l31 == 0 ? hv : d0;
-                d3 = l31 == 31 ? hv : d3;
+                d0 = pl == 0 ? hv : d0;
+                d3 = pl == 15 ? hv : d3;
                 const float V[4] = {d0 - d2, d1 - d3, d1 + d2, d2 - d1};  // plane order of the image: U0, -U3, U1, U2
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -929,16 +947,17 @@ __device__ __forceinline__ void x3w_main(const X3Tile &a, f32x16 (&EO)[2][2], un
     // ---- residual rows of x for GEMM 2's accumulator start (issued here, consumed after the gate)
     float xres[2][16];
     {
-        const rsrc_t rx = make_rsrc(a.xin + ub);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < 2; ++cb) {
+            const rsrc_t rx = make_rsrc(a.xin + ub[cb]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) xres[cb][r] = buf_load(rx, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+        }
     }
     __syncthreads();  // every wave is done reading the V tile: the z tile overlays it (row = frame of the tile)
     // ---- gate: lane l31 holds frames 2 l31 (even accumulators) and 2 l31 + 1 (odd): z rows 2 l31 / 2 l31 + 1
     {
-        const bool tvp = t0 + 2 * l31 < T;
+        const bool tvp = cl.ok && cl.t0 + 2 * (l31 & 15) < T;
 #pragma unroll
         for (int eo = 0; eo < 2; ++eo)
 #pragma unroll
@@ -975,11 +994,12 @@ __device__ __forceinline__ void x3w_main(const X3Tile &a, f32x16 (&EO)[2][2], un
     }
     float sk[2][16];
     {
-        const rsrc_t rsk = make_rsrc(a.skp + ub);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < 2; ++cb) {
+            const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load_nt(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+        }
     }
     __syncthreads();
     X3W_PHASE(3)
@@ -990,7 +1010,7 @@ __device__ __forceinline__ void x3w_main(const X3Tile &a, f32x16 (&EO)[2][2], un
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         if (tv[cb]) {
-            const rsrc_t rxo = make_rsrc(a.xout + ub);
+            const rsrc_t rxo = make_rsrc(a.xout + ub[cb]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) buf_store_agent((acc[0][0][cb][r] * is2) * RSQRT2, rxo, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
         }
@@ -999,7 +1019,7 @@ __device__ __forceinline__ void x3w_main(const X3Tile &a, f32x16 (&EO)[2][2], un
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         if (tv[cb]) {
-            const rsrc_t rsk = make_rsrc(a.skp + ub);
+            const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 buf_store_agent(first ? acc[0][1][cb][r] * is2 : acc[0][1][cb][r] * is2 + sk[cb][r], rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
@@ -1016,7 +1036,7 @@ __device__ __forceinline__ void x3w_main(const X3Tile &a, f32x16 (&EO)[2][2], un
 // other's tiles).  Chunks handed out dynamically (no block ever waits for work): 2.69 - 3.08 ms at 1,050 - 1,180 W and the maximum clock -- the
 // CUs of an XCD then run in lockstep and ask the L2 for the SAME weight fragments at the same moment.  The one global counter, which spreads
 // the CUs of an XCD over the phases of a task, is the better schedule; the 1.7 x algorithmic HBM bytes are its price.
-__global__ void __launch_bounds__(512, 1) diffnet_stack_x3w_kernel(SetDiffnetStackArgs a, int ntiles, int ntasks, unsigned piece_bytes, int fault_tile) {
+__global__ void __launch_bounds__(512, 1) diffnet_stack_x3w_kernel(SetDiffnetStackArgs a, int ntiles, int ntasks, int fault_tile) {
     typedef SplitF16x2 S;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     int *s_task = reinterpret_cast<int *>(lds + XW_TILE + 2 * XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
@@ -1042,13 +1062,8 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3w_kernel(SetDiffnetSta
         lt.err_flag = a.err_flag;
         lt.T = a.T; lt.dil = 1; lt.first = (l == 0);
         lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * 2;
-        const bool wino = x3w_tile_ok(lt);  // block-uniform
-        f32x16 acc[1][2][2];  // direct form: [rb][cb]; Winograd form: [even / odd][rb] (the same 64 registers)
-        f32x16 (&EO)[2][2] = acc[0];
-        if (wino)
-            x3w_init(lt, EO);
-        else
-            x3_init<1, 2>(lt, acc);
+        f32x16 EO[2][2];  // [even / odd frame of a pair][rb]
+        x3w_init(lt, EO);
         __builtin_amdgcn_sched_barrier(0);
         const int *f0 = done + i, *fl = done + (i > 0 ? i - 1 : i), *fr = done + (i < ntiles - 1 ? i + 1 : i);
         int peek = l, claimed = 0;
@@ -1088,10 +1103,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3w_kernel(SetDiffnetSta
             if (__builtin_amdgcn_readfirstlane(s_task[2]) == 0) break;
         }
         const int n_next = __builtin_amdgcn_readfirstlane(s_task[0]);
-        if (wino)
-            x3w_main(lt, EO, lds, dbg, tprev);
-        else
-            x3_main<S, 1, 2>(lt, acc, lds, piece_bytes, nullptr, tprev);
+        x3w_main(lt, EO, lds, dbg, tprev);
         i_done = i;
         l_done = l;
         n = n_next;
@@ -1120,8 +1132,10 @@ int launch_x3w(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream
     const int64_t ntasks64 = (int64_t)ntiles * a.L;
     SET_REQUIRE(ntasks64 < (1ll << 30), "set_diffnet_stack(task count)");
     SET_REQUIRE((int64_t)2 * XC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_stack(split-operand kernel: T too large)");
-    SET_REQUIRE(a.dilation_cycle_length == 1, "set_diffnet_stack(x3w: dilation 1 only)");
-    const unsigned piece_bytes = (unsigned)(2 * (32 + 2) * XR);  // the direct-form tiles of the launch (x3_main)
+    SET_REQUIRE(a.dilation_cycle_length == 1 && a.T % 2 == 0, "set_diffnet_stack(x3w: dilation 1 and even T only)");
+    // the utterance is part of the 32-bit lane offsets of the x and conditioner-projection loads (descriptor range 2^31 - 1 bytes)
+    SET_REQUIRE(((int64_t)a.B + 1) * XC * a.T * 4 < ((int64_t)1 << 31) && ((int64_t)a.B * a.cp_bs + (int64_t)2 * XC * a.T) * 4 < ((int64_t)1 << 31),
+                "set_diffnet_stack(x3w: batch too large for 32-bit lane offsets)");
     const size_t ldsz = (size_t)XW_TILE + 2 * XC * sizeof(float) + 16;
     SET_HIP(set_zero_async(a.sync_ws, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
     int grid = n_cu;
@@ -1129,7 +1143,7 @@ int launch_x3w(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream
     if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
     if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(diffnet_stack_x3w_kernel, dim3(grid), dim3(512), ldsz, s, a, ntiles, (int)ntasks64, piece_bytes, fault_tile);
+    hipLaunchKernelGGL(diffnet_stack_x3w_kernel, dim3(grid), dim3(512), ldsz, s, a, ntiles, (int)ntasks64, fault_tile);
     return set_check_launch("set_diffnet_stack");
 }
 
@@ -1542,7 +1556,12 @@ int set_launch_diffnet_stack_x3(const SetDiffnetStackArgs &a, int n_cu, int faul
     // variant from the library.  The NU template parameter of the kernel stays for tools/build_exp.sh experiments.)
     // round 6: Winograd F(2,3) form of GEMM 1 on the 64-frame tiles (dilation 1, even T; SET_AMD_X3_WINO=0 keeps the direct form) --
     // see diffnet_stack_x3w_kernel
-    if (set_x3_winograd_selected(a.x3_mode, a.B, a.T, a.dilation_cycle_length, n_cu)) return launch_x3w(a, n_cu, fault_tile, s);
+    // (its 8-byte loads of frame pairs need 8-byte aligned tensors and even strides; anything else takes the direct form)
+    // (and the utterance offset rides in their 32-bit lane offsets)
+    const bool al8 = ((reinterpret_cast<uintptr_t>(a.condproj) | reinterpret_cast<uintptr_t>(a.xa) | reinterpret_cast<uintptr_t>(a.xb)) & 7) == 0 &&
+                     ((a.cp_bs | a.cp_ls) & 1) == 0 && ((int64_t)a.B + 1) * XC * a.T * 4 < ((int64_t)1 << 31) &&
+                     ((int64_t)a.B * a.cp_bs + (int64_t)2 * XC * a.T) * 4 < ((int64_t)1 << 31);
+    if (al8 && set_x3_winograd_selected(a.x3_mode, a.B, a.T, a.dilation_cycle_length, n_cu)) return launch_x3w(a, n_cu, fault_tile, s);
     if (a.x3_mode == 2)
         return narrow ? launch_x3<SplitF16x2, 1, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitF16x2, 1, 2>(a, n_cu, fault_tile, s);
     return narrow ? launch_x3<SplitBf16x3, 1, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitBf16x3, 1, 2>(a, n_cu, fault_tile, s);
