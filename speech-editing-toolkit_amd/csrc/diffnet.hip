@@ -1150,13 +1150,13 @@ extern "C" int set_diffnet_stack_variant(int B, int T, int dilation_cycle_length
 }
 
 int set_launch_diffnet_stack_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s);  // csrc/diffnet_x3.hip
-bool set_x3_winograd_selected(int x3_mode, int B, int T, int dilation_cycle_length, int n_cu);               // csrc/diffnet_x3.hip
+int set_x3_winograd_selected(int x3_mode, int B, int T, int dilation_cycle_length, int n_cu);                // csrc/diffnet_x3.hip (0 / 1 / 2)
 extern "C" int set_diffnet_stack_x3_winograd(int B, int T, int dilation_cycle_length, int images) {
     int dev = 0, n_cu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     const int x3_mode = (images & 4) ? 3 : ((images & 8) ? 2 : 0);
     if (stack_variant(B, T, dilation_cycle_length, (images & 1) != 0, (images & 2) != 0, x3_mode, n_cu) != 5) return 0;
-    return set_x3_winograd_selected(x3_mode, B, T, dilation_cycle_length, n_cu) ? 1 : 0;
+    return set_x3_winograd_selected(x3_mode, B, T, dilation_cycle_length, n_cu);
 }
 int set_launch_diffnet_stack_split_x2(const SetDiffnetStackArgs &a, int fault_tile, hipStream_t s);      // csrc/diffnet_x3.hip
 

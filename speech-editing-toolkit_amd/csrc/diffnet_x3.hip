@@ -114,7 +114,12 @@ template <typename S> constexpr int64_t x_n2() { return 8LL * X_KS2 * 2 * S::NP 
 // order the kernel consumes them, [wave][k-step][row block][piece][lane][8], then {s1w, 1 / s1w} + padding (4 floats)
 constexpr int X_KSW = 64;
 template <typename S> constexpr int64_t x_nw() { return S::MODE == 2 ? 8LL * X_KSW * 2 * S::NP * 512 + 8 : 0; }
-template <typename S> constexpr int64_t x_nimg() { return x_n1<S>() + x_n2<S>() + 8 + x_nw<S>(); }
+// The same four planes for the 16-wide matrix instruction (v_mfma_f32_16x16x32_f16; diffnet_stack_x3v_kernel): 32 k-steps of 32 channels in
+// the order U1, U2, U0, -U3, [wave][k-step][row block 4: gate 0-15, gate 16-31, filter 0-15, filter 16-31][piece][lane][8].  It sits between
+// the body of the 32-wide Winograd image and the {s1w, 1 / s1w} tail, which both forms share (the tail stays the last 8 elements of the image).
+constexpr int X_KSV = 32;
+template <typename S> constexpr int64_t x_nv() { return S::MODE == 2 ? 8LL * X_KSV * 4 * S::NP * 512 : 0; }
+template <typename S> constexpr int64_t x_nimg() { return x_n1<S>() + x_n2<S>() + 8 + x_nw<S>() + x_nv<S>(); }
 __device__ __forceinline__ u32x4_t buf_load_u4(rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
 }
@@ -147,7 +152,26 @@ __global__ void __launch_bounds__(256) pack_layer_x3_kernel(const float *wdil, c
             tw[0] = 0.5f * s1; tw[1] = 1.0f / (0.5f * s1); tw[2] = 0.0f; tw[3] = 0.0f;
         }
     }
-    if (idx >= n1 + n2 + nw) return;
+    constexpr int64_t nv = x_nv<S>() / S::NP;
+    if (idx >= n1 + n2 + nw + nv) return;
+    if (idx >= n1 + n2 + nw) {  // Winograd planes of GEMM 1 for the 16-wide matrix instruction
+        int64_t r = idx - n1 - n2 - nw;
+        const int e = r & 7; r >>= 3;
+        const int l = r & 63; r >>= 6;
+        const int mb = r & 3; r >>= 2;
+        const int ks = (int)(r % X_KSV), w = (int)(r / X_KSV);
+        const int row = (mb >= 2 ? XC : 0) + 32 * w + 16 * (mb & 1) + (l & 15), k = 8 * (l >> 4) + e;
+        const int plane = ks >> 3, c = 32 * (ks & 7) + k;  // plane order U1, U2, U0, -U3 (see pack of the 32-wide planes below for the U's)
+        const float *g = wdil + ((int64_t)row * XC + c) * 3;
+        const double g0 = g[0], g1 = g[1], gg2 = g[2];
+        const double u = plane == 0 ? 0.5 * (g0 + g1 + gg2) : (plane == 1 ? 0.5 * (g0 - g1 + gg2) : (plane == 2 ? g0 : -gg2));
+        unsigned short p[S::NP];
+        S::split((0.5f * s1) * (float)u, p);
+        unsigned short *base = img + x_n1<S>() + x_n2<S>() + 8 + (x_nw<S>() - 8) + ((((int64_t)w * X_KSV + ks) * 4 + mb) * S::NP) * 512 + l * 8 + e;
+#pragma unroll
+        for (int q = 0; q < S::NP; ++q) base[q * 512] = p[q];
+        return;
+    }
     const bool gw = idx >= n1 + n2;  // Winograd planes of GEMM 1
     const bool g2 = !gw && idx >= n1;
     int64_t r = gw ? idx - n1 - n2 : (g2 ? idx - n1 : idx);
@@ -1147,6 +1171,440 @@ int launch_x3w(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream
     return set_check_launch("set_diffnet_stack");
 }
 
+// =====================================================================================================================
+// 96-frame tiles on the 16-wide matrix instruction (round 6, second half).  What bounds the 64-frame Winograd form is the weight-fragment
+// stream of GEMM 1: 2 MiB per task from the L2 at ~50 B/clk/CU (profiles/r06_x3w_no_a_stream_bound.log), and the only lever on it is the
+// number of columns every fragment meets.  128-frame tiles leave 56 CUs without a tile chain at B = 32, T = 800 (200 chains) and need
+// 192 accumulator registers; 96 frames = 48 output pairs are 1.5 column blocks of the 32-wide instruction -- but exactly THREE of the 16-wide
+// one.  Operand-stream models of the three GEMM loops under the power cap (tools/hw/mfma_ceiling_w.hip, profiles/r06_ceiling_w.log): shipped
+// 64-frame loop 1,139 TFLOP/s executed, 128-frame loop 1,373, 96-frame loop on v_mfma_f32_16x16x32_f16 1,434 (the bare 16-wide instruction
+// itself sustains 2,140 against the 32-wide one's 1,875 at the same package power).
+//   tile   = 3 column blocks of 32 frames (16 pairs each; every block with its own utterance, first frame and halo frames): 267 chains
+//   wave   = 64 rows (gate rows 32 w .. + 31, filter rows 256 + 32 w ..) x 48 pairs = 4 x 3 accumulator blocks of 16 x 16
+//   k-step = 32 channels of one plane: 8 weight fragments (1 KiB each) + 6 LDS fragment reads -> 36 MFMAs (64-frame form: 8 + 4 -> 12 of twice the size)
+//   planes two at a time (LDS: [plane 2][piece 2][pair 48][XR] = 99 KB; the z tile [piece][96][XR] overlays it exactly):
+//            P = (e + o) / 2 + U1 (d1 + d2),  Q = (e - o) / 2 + U2 (d2 - d1)      (e / o = bias + conditioner projection at the even / odd frame)
+//            E = P + Q + U0 (d0 - d2),        O = P - Q + (-U3) (d1 - d3)
+//          -- two accumulator sets (96 registers) instead of the 64-frame form's three; the second pair of planes is staged (x re-read
+//          from the L2, neighbours by DPP row shifts, block ends by halo loads) after the first pair's GEMMs.
+//   GEMM 2 = the 32-wide loop of the other forms on three column blocks (gemm_x3<.., NCB = 3>), same image.
+// Results: same piece products and fp32 accumulation; sums in another order than the 64-frame form (equal to fp32 rounding).
+// =====================================================================================================================
+constexpr int XV_NB = 3;                          // column blocks per tile
+constexpr unsigned XV_PIECE = 16 * XV_NB * XR;    // one piece of one plane of the V tile (48 pair rows)
+constexpr unsigned XV_PLANE = 2 * XV_PIECE;
+constexpr unsigned XV_TILE = 2 * XV_PLANE;        // 101,376 bytes
+constexpr unsigned XV_ZPIECE = 32 * XV_NB * XR;   // one piece of the z tile (96 frame rows) = XV_PLANE
+#ifndef SET_X3V_DEFAULT
+#define SET_X3V_DEFAULT 1                         // what a chip-filling shape takes without SET_AMD_X3_WINO: 1 = 64-frame tiles, 2 = 96-frame tiles
+#endif
+#ifndef SET_X3V_PF
+#define SET_X3V_PF 2                              // fragment ring depth of GEMM 1 in k-steps of 32 (8 fragments = 32 registers each)
+#endif
+#ifndef SET_X3V_PF2
+#define SET_X3V_PF2 2                             // fragment ring depth of GEMM 2 in k-steps of 16
+#endif
+
+__device__ __forceinline__ f32x4 mma16(u32x4_t a, u32x4_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+// lane i <- lane i - 1 / i + 1 of its 16-lane row (DPP row_shr:1 / row_shl:1; the row ends get `old`)
+__device__ __forceinline__ float row_prev(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_next(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
+}
+
+// accumulator start: PQ[0] = s1w (e + o) / 2, PQ[1] = s1w (e - o) / 2; lane (l15, kg): pair l15 of column block nb, rows 4 kg .. 4 kg + 3 of block mb
+__device__ __forceinline__ void x3v_init(const X3Tile &a, f32x4 (&PQ)[2][4][XV_NB]) {
+    typedef SplitF16x2 S;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int T = a.T;
+    const unsigned T4 = 4u * (unsigned)T;
+    const float hs = 0.5f * reinterpret_cast<const float *>(a.img + x_nimg<S>() - 8)[0];
+    f32x4 bias[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) bias[mb] = *reinterpret_cast<const f32x4 *>(a.b_dil + (mb >= 2 ? XC : 0) + 32 * w + 16 * (mb & 1) + 4 * kg);
+#pragma unroll
+    for (int nb = 0; nb < XV_NB; ++nb) {
+        const X3Col c = x3_col(a, nb);
+        const rsrc_t rcp = make_rsrc(a.cp + (int64_t)c.b * a.cp_bs);
+        const unsigned vo = 4u * (unsigned)(4 * kg * T + min(c.t0 + 2 * l15, T - 2));
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const unsigned row0 = (unsigned)((mb >= 2 ? XC : 0) + 32 * w + 16 * (mb & 1));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x2 v = buf_load2_nt(rcp, vo, (row0 + (unsigned)i) * T4);
+                const float e = bias[mb][i] + v[0], o = bias[mb][i] + v[1];
+                PQ[0][mb][nb][i] = hs * (e + o);
+                PQ[1][mb][nb][i] = hs * (e - o);
+            }
+        }
+    }
+}
+
+// one pair of planes of the V tile: PH = 0: d1 + d2 | d2 - d1 (U1, U2);  PH = 1: d0 - d2 | d1 - d3 (U0, -U3).  lane (l15, cs): pair l15 of every
+// column block, 8 channels 32 w + 8 cs ..; returns the largest magnitude staged (range check of the fp16 pieces)
+template <int PH>
+__device__ __forceinline__ float x3v_stage(const X3Tile &a, unsigned char *lds, const float *dsh, int w, int lane) {
+    typedef SplitF16x2 S;
+    const int l15 = lane & 15, cs = lane >> 4;
+    const int ch0 = 32 * w + 8 * cs;
+    const int T = a.T;
+    const unsigned T4 = 4u * (unsigned)T;
+    const bool edge = l15 == 0 || l15 == 15;
+    f32x2 x12[XV_NB][8];
+    float xh[XV_NB][8];
+#pragma unroll
+    for (int nb = 0; nb < XV_NB; ++nb) {
+        const X3Col c = x3_col(a, nb);
+        const rsrc_t rx = make_rsrc(a.xin + (int64_t)c.b * XC * T);
+        const int t = c.t0 + 2 * l15;  // frames t, t + 1 (T even: both inside or both outside)
+        const unsigned vox = 4u * (unsigned)min(t, T - 2) + (unsigned)ch0 * T4;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x12[nb][k] = buf_load2(rx, vox, (unsigned)k * T4);
+        if (PH == 1) {
+            const int th = l15 == 0 ? c.t0 - 1 : c.t0 + 32;  // halo frame of the block's end lanes
+            const unsigned voh = 4u * (unsigned)min(max(th, 0), T - 1) + (unsigned)ch0 * T4;
+            if (edge) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xh[nb][k] = buf_load(rx, voh, (unsigned)k * T4);
+            }
+        }
+    }
+    float amax = 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < XV_NB; ++nb) {
+        const X3Col c = x3_col(a, nb);
+        const int t = c.t0 + 2 * l15, th = l15 == 0 ? c.t0 - 1 : c.t0 + 32;
+        const bool v12 = c.ok && t < T, vh = c.ok && edge && th >= 0 && th < T;
+        const f32x4 dA = *reinterpret_cast<const f32x4 *>(dsh + nb * XC + ch0);
+        const f32x4 dB = *reinterpret_cast<const f32x4 *>(dsh + nb * XC + ch0 + 4);
+        unsigned short pc[2][8][2];  // [plane of the pair][channel][piece]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ds = e < 4 ? dA[e & 3] : dB[e & 3];
+            const float d1 = v12 ? x12[nb][e][0] + ds : 0.0f, d2 = v12 ? x12[nb][e][1] + ds : 0.0f;
+            float V[2];
+            if (PH == 0) {
+                V[0] = d1 + d2;
+                V[1] = d2 - d1;
+            } else {
+                float d0 = row_prev(d2), d3 = row_next(d1);
+                const float hv = vh ? xh[nb][e] + ds : 0.0f;
+                d0 = l15 == 0 ? hv : d0;
+                d3 = l15 == 15 ? hv : d3;
+                V[0] = d0 - d2;
+                V[1] = d1 - d3;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                amax = fmaxf(amax, fabsf(V[j]));
+                S::split(V[j], pc[j][e]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x4_t u[2];
+            pack8<2>(pc[j], u);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4_t *>(lds + j * XV_PLANE + q * XV_PIECE + (16 * nb + l15) * XR + ch0 * 2) = u[q];
+        }
+    }
+    return amax;
+}
+
+// 8 k-steps (one plane) of GEMM 1 into acc; the fragment ring runs through the 16 k-steps of a plane PAIR (k-steps 16 pair .. 16 pair + 15)
+template <int PFV>
+__device__ __forceinline__ void x3v_plane(f32x4 (&acc)[4][XV_NB], u32x4_t (&A)[PFV][4][2], rsrc_t img, unsigned lane16, unsigned abase, int seg,
+                                          const unsigned char *bplane, unsigned boff) {
+    typedef SplitF16x2 S;
+    const int ks_last = 16 * (seg >> 1) + 15;
+    for (int kb = 0; kb < 8; kb += PFV) {
+#pragma unroll
+        for (int p = 0; p < PFV; ++p) {
+            const int kc = kb + p, ks = 8 * seg + kc;
+            u32x4_t Bv[XV_NB][2];
+#pragma unroll
+            for (int nb = 0; nb < XV_NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) Bv[nb][q] = *reinterpret_cast<const u32x4_t *>(bplane + q * XV_PIECE + boff + (unsigned)(nb * 16 * XR) + (unsigned)kc * 64u);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int t = 0; t < S::NPROD; ++t)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < XV_NB; ++nb) acc[mb][nb] = mma16(A[p][mb][S::qa(t)], Bv[nb][S::qb(t)], acc[mb][nb]);
+            __builtin_amdgcn_s_setprio(0);
+            const int kn = min(ks + PFV, ks_last);  // tail: harmless re-load of the pair's last k-step
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) A[p][mb][q] = buf_load_u4(img, lane16, abase + (unsigned)(((kn * 4 + mb) * 2 + q) * 1024));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+__device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_NB], unsigned char *lds) {
+    typedef SplitF16x2 S;
+    constexpr int PFV = SET_X3V_PF;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;    // 16-wide fragments (GEMM 1, gate)
+    const int half = lane >> 5, l31 = lane & 31;  // 32-wide fragments (GEMM 2, epilogue)
+    const int T = a.T;
+    const unsigned T4 = 4u * (unsigned)T;
+    const unsigned lane16 = 16u * (unsigned)lane;
+    float *dsh = reinterpret_cast<float *>(lds + XV_TILE);  // [3][256] step offsets of the column blocks' utterances
+    const rsrc_t rw = make_rsrc(a.img);
+    const float *sc = reinterpret_cast<const float *>(a.img + x_n1<S>() + x_n2<S>());
+    const float s2 = sc[2], is2 = sc[3];
+    const float is1w = reinterpret_cast<const float *>(a.img + x_nimg<S>() - 8)[1];
+    {
+        const X3Col c0 = x3_col(a, 0), c1 = x3_col(a, 1), c2 = x3_col(a, 2);
+        dsh[tid] = a.dstep[(int64_t)((tid >> 8) ? c1.b : c0.b) * a.d_bs + (int64_t)(tid & (XC - 1)) * a.d_cs];
+        if (tid < XC) dsh[2 * XC + tid] = a.dstep[(int64_t)c2.b * a.d_bs + (int64_t)tid * a.d_cs];
+    }
+    __syncthreads();  // dsh
+    // ---- GEMM 1, first pair of planes
+    const unsigned abase = (unsigned)((x_n1<S>() + x_n2<S>() + x_nw<S>()) * 2) + (unsigned)(w * X_KSV * 4 * 2 * 1024);
+    const unsigned boff = (unsigned)(l15 * XR + kg * 16);
+    u32x4_t A[PFV][4][2];
+    float amax = x3v_stage<0>(a, lds, dsh, w, lane);
+#pragma unroll
+    for (int p = 0; p < PFV; ++p)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) A[p][mb][q] = buf_load_u4(rw, lane16, abase + (unsigned)(((p * 4 + mb) * 2 + q) * 1024));
+    __syncthreads();
+    x3v_plane<PFV>(PQ[0], A, rw, lane16, abase, 0, lds, boff);
+    x3v_plane<PFV>(PQ[1], A, rw, lane16, abase, 1, lds + XV_PLANE, boff);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < XV_NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float pp = PQ[0][mb][nb][i], qq = PQ[1][mb][nb][i];
+                PQ[0][mb][nb][i] = pp + qq;  // even frame of the pair
+                PQ[1][mb][nb][i] = pp - qq;  // odd frame
+            }
+    __syncthreads();  // every wave is done reading the first pair of planes
+    // ---- second pair
+    amax = fmaxf(amax, x3v_stage<1>(a, lds, dsh, w, lane));
+    if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int p = 0; p < PFV; ++p)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) A[p][mb][q] = buf_load_u4(rw, lane16, abase + (unsigned)((((16 + p) * 4 + mb) * 2 + q) * 1024));
+    __syncthreads();
+    x3v_plane<PFV>(PQ[0], A, rw, lane16, abase, 2, lds, boff);
+    x3v_plane<PFV>(PQ[1], A, rw, lane16, abase, 3, lds + XV_PLANE, boff);
+    // ---- residual rows of x for GEMM 2's accumulator start (issued here, consumed after the gate)
+    bool tv[XV_NB];
+    unsigned vo4[XV_NB];
+    int64_t ub[XV_NB];
+#pragma unroll
+    for (int cb = 0; cb < XV_NB; ++cb) {
+        const X3Col c = x3_col(a, cb);
+        const int t = c.t0 + l31;
+        tv[cb] = c.ok && t < T;
+        vo4[cb] = 4u * (unsigned)(4 * half * T + min(t, T - 1));
+        ub[cb] = (int64_t)c.b * XC * T;
+    }
+    float xres[XV_NB][16];
+#pragma unroll
+    for (int cb = 0; cb < XV_NB; ++cb) {
+        const rsrc_t rx = make_rsrc(a.xin + ub[cb]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xres[cb][r] = buf_load(rx, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+    }
+    __syncthreads();  // every wave is done reading the V tile: the z tile overlays it (row = frame of the tile)
+    // ---- gate: lane (l15, kg) holds the pair's frames 2 l15 (PQ[0]) and 2 l15 + 1 (PQ[1]) of column block nb, channels 32 w + 16 m + 4 kg ..
+#pragma unroll
+    for (int nb = 0; nb < XV_NB; ++nb) {
+        const X3Col c = x3_col(a, nb);
+        const bool tvp = c.ok && c.t0 + 2 * l15 < T;
+#pragma unroll
+        for (int eo = 0; eo < 2; ++eo)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                unsigned short p[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float zz = fsig(PQ[eo][m][nb][i] * is1w) * ftanh(PQ[eo][m + 2][nb][i] * is1w);
+                    S::split(tvp ? zz : 0.0f, p[i]);
+                }
+                const unsigned off = (unsigned)((32 * nb + 2 * l15 + eo) * XR + (32 * w + 16 * m + 4 * kg) * 2);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    u32x2w_t uu;
+                    uu[0] = (unsigned)p[0][q] | ((unsigned)p[1][q] << 16);
+                    uu[1] = (unsigned)p[2][q] | ((unsigned)p[3][q] << 16);
+                    *reinterpret_cast<u32x2w_t *>(lds + q * XV_ZPIECE + off) = uu;
+                }
+            }
+    }
+    // ---- GEMM 2 accumulators: residual rows start at s2 (b_out + x), skip rows at s2 b_out
+    f32x16 acc[1][2][XV_NB];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const float *bo = a.b_out + (rb ? XC : 0) + 32 * w;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float blo = bo[urow(r)], bhi = bo[urow(r) + 4];
+            const float bias = half ? bhi : blo;
+#pragma unroll
+            for (int cb = 0; cb < XV_NB; ++cb) acc[0][rb][cb][r] = (rb == 0 ? bias + xres[cb][r] : bias) * s2;
+        }
+    }
+    __syncthreads();
+    gemm_x3<S, X_KS2, 1, XV_NB, SET_X3V_PF2>(acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + w * X_KS2 * 2 * 2 * 1024), (unsigned)(X_KS2 * 2 * 2 * 1024), lds,
+                                             XV_ZPIECE, [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2); });
+    // ---- epilogue
+    const bool first = a.first != 0;
+    float sk[XV_NB][16];
+    if (!first) {
+#pragma unroll
+        for (int cb = 0; cb < XV_NB; ++cb) {
+            const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load_nt(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < XV_NB; ++cb) {
+        if (tv[cb]) {
+            const rsrc_t rxo = make_rsrc(a.xout + ub[cb]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) buf_store_agent((acc[0][0][cb][r] * is2) * RSQRT2, rxo, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < XV_NB; ++cb) {
+        if (tv[cb]) {
+            const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                buf_store_agent(first ? acc[0][1][cb][r] * is2 : acc[0][1][cb][r] * is2 + sk[cb][r], rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+        }
+    }
+}
+
+// the persistent (layer, tile) queue of diffnet_stack_x3w_kernel on 96-frame tiles
+__global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetStackArgs a, int ntiles, int ntasks, int fault_tile) {
+    typedef SplitF16x2 S;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int *s_task = reinterpret_cast<int *>(lds + XV_TILE + XV_NB * XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
+    int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_task[0] = atomicAdd(counter, 1);
+    __syncthreads();
+    int n = __builtin_amdgcn_readfirstlane(s_task[0]);
+    int i_done = -1, l_done = 0;
+    while (n < ntasks) {
+        const int l = n / ntiles, i = n - l * ntiles;
+        X3Tile lt;
+        lt.xin = (l & 1) ? a.xb : a.xa;
+        lt.xout = (l & 1) ? a.xa : a.xb;
+        lt.skp = a.skip;
+        lt.cp = a.condproj + (int64_t)l * a.cp_ls; lt.cp_bs = a.cp_bs;
+        lt.dstep = a.dstep + (int64_t)l * a.d_ls; lt.d_bs = a.d_bs; lt.d_cs = a.d_cs;
+        lt.img = reinterpret_cast<const unsigned short *>(a.wx3_all) + (int64_t)l * x_nimg<S>();
+        lt.b_dil = a.b_dil_all + (int64_t)l * 512;
+        lt.b_out = a.b_out_all + (int64_t)l * 512;
+        lt.err_flag = a.err_flag;
+        lt.T = a.T; lt.dil = 1; lt.first = (l == 0);
+        lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * XV_NB;
+        f32x4 PQ[2][4][XV_NB];
+        x3v_init(lt, PQ);
+        __builtin_amdgcn_sched_barrier(0);
+        const int *f0 = done + i, *fl = done + (i > 0 ? i - 1 : i), *fr = done + (i < ntiles - 1 ? i + 1 : i);
+        int peek = l, claimed = 0;
+        if (tid == 0) {
+            if (l > 0) peek = min(ld_agent(f0), min(ld_agent(fl), ld_agent(fr)));
+            claimed = atomicAdd(counter, 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            if (peek >= l) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_task[0] = claimed;
+            s_task[1] = peek >= l ? 1 : 2;
+        }
+        __syncthreads();
+        if (tid == 0 && i_done >= 0 && !(l_done == 0 && i_done == fault_tile))
+            __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        i_done = -1;
+        if (__builtin_amdgcn_readfirstlane(s_task[1]) == 2) {
+            if (tid == 0) {
+                int ok = 1;
+                unsigned spins = 0;
+                for (;;) {
+                    const int v0 = ld_agent(f0), v1 = ld_agent(fl), v2 = ld_agent(fr);
+                    if (min(v0, min(v1, v2)) >= l) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > X_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
+                        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (a.err_flag) __hip_atomic_store(a.err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                s_task[2] = ok;
+            }
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(s_task[2]) == 0) break;
+        }
+        const int n_next = __builtin_amdgcn_readfirstlane(s_task[0]);
+        x3v_main(lt, PQ, lds);
+        i_done = i;
+        l_done = l;
+        n = n_next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && i_done >= 0 && !(l_done == 0 && i_done == fault_tile))
+        __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int launch_x3v(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_x3v_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                "set_diffnet_stack(x3v attr)");
+        attr_set = true;
+    }
+    const int Q = a.B * ((a.T + 31) / 32);
+    const int ntiles = (Q + XV_NB - 1) / XV_NB;
+    const int64_t ntasks64 = (int64_t)ntiles * a.L;
+    SET_REQUIRE(ntasks64 < (1ll << 30), "set_diffnet_stack(task count)");
+    SET_REQUIRE((int64_t)2 * XC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_stack(split-operand kernel: T too large)");
+    SET_REQUIRE(a.dilation_cycle_length == 1 && a.T % 2 == 0, "set_diffnet_stack(x3v: dilation 1 and even T only)");
+    const size_t ldsz = (size_t)XV_TILE + XV_NB * XC * sizeof(float) + 16;
+    SET_HIP(set_zero_async(a.sync_ws, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
+    int grid = n_cu;
+    if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
+    if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(diffnet_stack_x3v_kernel, dim3(grid), dim3(512), ldsz, s, a, ntiles, (int)ntasks64, fault_tile);
+    return set_check_launch("set_diffnet_stack");
+}
+
 // Measured and not kept (round 6; the code is in commit 9e25393 "... whole-loop kernel", profiles/r06_loop_launch_ab.log): the WHOLE reverse loop
 // as one launch -- the step boundary (skip projection -> output head -> posterior -> next step's input projection) as one more task type of
 // this queue, flags counting over all 100 steps.  Bit-identical to the per-step launches, and 2.3 % SLOWER at B = 32, T = 800 (179.2 against
@@ -1531,14 +1989,17 @@ extern "C" int set_pack_diffnet_layer_x3(const float *w_dil, const float *w_out,
 }
 
 // does set_launch_diffnet_stack_x3 take the Winograd form (diffnet_stack_x3w_kernel) for this shape?
-bool set_x3_winograd_selected(int x3_mode, int B, int T, int dilation_cycle_length, int n_cu) {
-    if (x3_mode != 2 || dilation_cycle_length != 1 || T % 2 != 0) return false;
+// 0 = direct form, 1 = 64-frame Winograd tiles (diffnet_stack_x3w_kernel), 2 = 96-frame tiles on the 16-wide instruction (diffnet_stack_x3v_kernel)
+int set_x3_winograd_selected(int x3_mode, int B, int T, int dilation_cycle_length, int n_cu) {
+    if (x3_mode != 2 || dilation_cycle_length != 1 || T % 2 != 0) return 0;
     const int64_t tiles64 = (int64_t)B * ((T + 63) / 64);
     bool narrow = 5 * tiles64 < 3 * (int64_t)n_cu;
     if (const char *e = getenv("SET_AMD_X3_TILE")) narrow = atoi(e) == 32;
-    if (narrow) return false;
-    if (const char *e = getenv("SET_AMD_X3_WINO")) return atoi(e) != 0;
-    return true;
+    if (narrow) return 0;
+    if (const char *e = getenv("SET_AMD_X3_WINO")) return atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
+    // 96-frame tiles once every CU has a tile chain of them (B = 32, T = 800: 267 chains for 256 CUs)
+    const int64_t tiles96 = ((int64_t)B * ((T + 31) / 32) + 2) / 3;
+    return tiles96 >= (int64_t)n_cu ? SET_X3V_DEFAULT : 1;
 }
 
 // called by set_diffnet_stack (csrc/diffnet.hip) once it has picked this kernel
@@ -1561,7 +2022,9 @@ int set_launch_diffnet_stack_x3(const SetDiffnetStackArgs &a, int n_cu, int faul
     const bool al8 = ((reinterpret_cast<uintptr_t>(a.condproj) | reinterpret_cast<uintptr_t>(a.xa) | reinterpret_cast<uintptr_t>(a.xb)) & 7) == 0 &&
                      ((a.cp_bs | a.cp_ls) & 1) == 0 && ((int64_t)a.B + 1) * XC * a.T * 4 < ((int64_t)1 << 31) &&
                      ((int64_t)a.B * a.cp_bs + (int64_t)2 * XC * a.T) * 4 < ((int64_t)1 << 31);
-    if (al8 && set_x3_winograd_selected(a.x3_mode, a.B, a.T, a.dilation_cycle_length, n_cu)) return launch_x3w(a, n_cu, fault_tile, s);
+    const int wino = al8 ? set_x3_winograd_selected(a.x3_mode, a.B, a.T, a.dilation_cycle_length, n_cu) : 0;
+    if (wino == 2) return launch_x3v(a, n_cu, fault_tile, s);
+    if (wino == 1) return launch_x3w(a, n_cu, fault_tile, s);
     if (a.x3_mode == 2)
         return narrow ? launch_x3<SplitF16x2, 1, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitF16x2, 1, 2>(a, n_cu, fault_tile, s);
     return narrow ? launch_x3<SplitBf16x3, 1, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitBf16x3, 1, 2>(a, n_cu, fault_tile, s);

@@ -1297,12 +1297,14 @@ def test_full800_single_utterance_matches_reference(dev, row):
     assert d < 1e-4
 
 
-def test_x3w_winograd_split_operand_stack(dev, monkeypatch):
-    """Round 6: the Winograd F(2,3) form of GEMM 1 on the two-piece fp16 operands (diffnet_stack_x3w_kernel, SET_AMD_X3_WINO=1: 3/4 of the
-    layer's MFMAs) against the direct split-operand kernel and the fp32-pipe kernel on the same weights -- equal to fp32 rounding; run to run
-    and for 7 / 512 workers bit-identical; against an fp64 evaluation of the same layers its error stays within 2 x the fp32 kernel's.
-    Shapes: the metric's batch, tiles that straddle two utterances or end in a partial block (those take the direct form inside the same
-    launch), T = 66 (a tile whose second block holds two frames)."""
+@pytest.mark.parametrize("form", ["1", "2"])
+def test_x3w_winograd_split_operand_stack(dev, monkeypatch, form):
+    """Round 6: the Winograd F(2,3) form of GEMM 1 on the two-piece fp16 operands (SET_AMD_X3_WINO=1: diffnet_stack_x3w_kernel, 64-frame tiles;
+    =2: diffnet_stack_x3v_kernel, 96-frame tiles on the 16-wide matrix instruction; 3/4 of the layer's MFMAs) against the direct split-operand
+    kernel and the fp32-pipe kernel on the same weights -- equal to fp32 rounding; run to run and for 7 / 512 workers bit-identical; against an
+    fp64 evaluation of the same layers its error stays within 2 x the fp32 kernel's.
+    Shapes: the metric's batch, tiles whose column blocks lie in different utterances or end in a partial block (every column block of a tile
+    carries its own utterance and halo frames), T = 66 (a block that holds two frames), T = 2."""
     from set_amd import ops
     import torch.nn.functional as F
     monkeypatch.setenv("SET_AMD_SPLIT", "0")
@@ -1325,15 +1327,15 @@ def test_x3w_winograd_split_operand_stack(dev, monkeypatch):
 
         x32, s32 = run("0", "0")
         xd2, sd2 = run("2", "0")
-        xw, sw = run("2", "1")
+        xw, sw = run("2", form)
         tol = 1e-5 * max(1.0, float(x32.abs().max()))
         assert _maxdiff(xw, x32) < tol and _maxdiff(sw, s32) < 1e-5 * max(1.0, float(s32.abs().max())), (B, T)
         assert _maxdiff(xw, xd2) < tol, (B, T)
         for rep in range(reps - 1):
-            x, sk = run("2", "1")
+            x, sk = run("2", form)
             assert torch.equal(x, xw) and torch.equal(sk, sw), (B, T, rep)
         for grid in ("7", "512"):
-            x, sk = run("2", "1", grid)
+            x, sk = run("2", form, grid)
             assert torch.equal(x, xw) and torch.equal(sk, sw), (B, T, grid)
         if B * T <= 2048:
             xd, skd = x0.double(), torch.zeros_like(x0, dtype=torch.float64)
@@ -1350,14 +1352,15 @@ def test_x3w_winograd_split_operand_stack(dev, monkeypatch):
             assert ew < 2.0 * e32 + 1e-7, (B, T, ew, e32)
 
 
+@pytest.mark.parametrize("form", ["1", "2"])
 @pytest.mark.parametrize("case", ["infer_full800", "infer_tiny", "infer_pad", "infer_ragged", "infer_drift100"])
-def test_full_inference_matches_reference_with_x3w_forced(dev, monkeypatch, case):
+def test_full_inference_matches_reference_with_x3w_forced(dev, monkeypatch, case, form):
     """The parity bar (|dmel| < 1e-4 against the reference's own output; the T = 800 x 100-step and the 100-step drift cases included) with
     every DiffNet stack pass on the split-operand kernel's Winograd form (odd T: the launch falls back to the direct form)."""
     monkeypatch.setenv("SET_AMD_X3", "2")
     monkeypatch.setenv("SET_AMD_SPLIT", "0")
     monkeypatch.setenv("SET_AMD_X3_TILE", "64")
-    monkeypatch.setenv("SET_AMD_X3_WINO", "1")
+    monkeypatch.setenv("SET_AMD_X3_WINO", form)
     g = load_golden(case)
     m = g["meta"]
     model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"], **m["overrides"])
@@ -1366,7 +1369,7 @@ def test_full_inference_matches_reference_with_x3w_forced(dev, monkeypatch, case
                 inp["f0"], inp["uv"], infer=True, noises=noises, persistent=True, **m["flags"])
     torch.cuda.synchronize()
     d = _maxdiff(ret["mel_out"], g["mel_out"])
-    print("%s (split-operand Winograd): max|dmel| = %.3e" % (case, d))
+    print("%s (split-operand Winograd, form %s): max|dmel| = %.3e" % (case, form, d))
     assert d < 1e-4
 
 
