@@ -437,10 +437,14 @@ def run_infer(args, rank, world, dev):
         executed_ratio, pipe_peak, pipe = 6.0, PEAK_BF16_MFMA_TFLOPS, "v_mfma_f32_32x32x16_bf16"
     elif persistent and variant == 5:
         executed_ratio, pipe_peak, pipe = 3.0, PEAK_BF16_MFMA_TFLOPS, "v_mfma_f32_32x32x16_f16"
-    x3w = bool(persistent and variant == 5 and ops.stack_x3_winograd(B_PER_GPU // groups, T, model.denoise_fn.dilation_cycle_length))
+    x3w = int(ops.stack_x3_winograd(B_PER_GPU // groups, T, model.denoise_fn.dilation_cycle_length)) if persistent and variant == 5 else 0
+    x3w_name = {1: "diffnet_stack_x3w_kernel", 2: "diffnet_stack_x3v_kernel"}.get(x3w)
     if x3w:  # round 6: GEMM 1 of the two-piece fp16 kernel in its Winograd F(2,3) form: 3/4 of the layer's MFMAs are issued
-        stack_kernel = "diffnet_stack_x3w_kernel (SplitF16x2, Winograd F(2,3) form of GEMM 1)"
+        stack_kernel = ("diffnet_stack_x3w_kernel (SplitF16x2, Winograd F(2,3) form of GEMM 1, 64-frame tiles)" if x3w == 1 else
+                        "diffnet_stack_x3v_kernel (SplitF16x2, Winograd F(2,3) form of GEMM 1, 96-frame tiles on v_mfma_f32_16x16x32_f16)")
         executed_ratio = 3.0 * (512 * 512 + 512 * 256) / (512 * 768 + 512 * 256)
+        if x3w == 2:
+            pipe = "v_mfma_f32_16x16x32_f16 (GEMM 1) + v_mfma_f32_32x32x16_f16 (GEMM 2)"
     split_operands = persistent and variant in (4, 5)
     layers_per_launch = L if persistent else 1
     launch_ms = sum(spans) / len(spans) / (L // layers_per_launch)
@@ -465,7 +469,7 @@ def run_infer(args, rank, world, dev):
         for src in tj.get("kernel_sources", []):
             with open(os.path.join(ROOT, src), "rb") as f:
                 h.update(f.read())
-        ent = tj.get("diffnet_stack_x3w_kernel" if x3w else "diffnet_stack_x3_kernel<%s>" % ("SplitF16x2" if variant == 5 else "SplitBf16x3"))
+        ent = tj.get(x3w_name if x3w else "diffnet_stack_x3_kernel<%s>" % ("SplitF16x2" if variant == 5 else "SplitBf16x3"))
         if ent is not None and h.hexdigest() == tj.get("kernel_source_sha256"):
             traffic, pmc = ent["traffic_bytes"], ent
             traffic_note = "PMC passes of this kernel build (%s, source sha256 matches)" % tname
@@ -518,7 +522,10 @@ def run_infer(args, rank, world, dev):
                               "(profiles/r04_mfma_ceiling.log); removing the kernel's ring stalls (round 4) lowered the clock from "
                               "2.00 to 1.86 GHz and the time by 1.4 %; round 6 (profiles/r06_*_ab.log, power and clock per variant): the whole "
                               "loop as one launch -2.3 %, XCD-aware task claiming -2.7 %, next-task prefetch -1.1 % -- only fewer matrix "
-                              "instructions moved it: the Winograd form of GEMM 1 (3/4 of the MFMAs) +2.8 % at 20-30 W less",
+                              "instructions and fewer operand bytes moved it: the Winograd form of GEMM 1 (3/4 of the MFMAs) +2.8 % at 20-30 W less, then 96-frame "
+                              "tiles on the 16-wide instruction (2/3 of the weight-fragment stream per frame, two accumulator sets): 1.43 against 1.61 ms "
+                              "per launch on the same box (profiles/r06_x3v_ab.log; operand-stream ceilings of the three GEMM loops in "
+                              "profiles/r06_ceiling_w.log: 1,139 / 1,434 / 1,373 TFLOP/s executed for 64- / 96- / 128-frame tiles)",
                      "note": (("fp32-equivalent results from 16-bit MFMAs.  f16x2: every fp32 operand is carried as TWO fp16 pieces "
                                "(11 + 11 = 22 significand bits, 2 fewer than fp32's 24) and a product is a0 b0 + a0 b1 + a1 b0 -- "
                                "the a1 b1 term (~2^-22 |ab|) is dropped; fp32 accumulation.  " if variant == 5 else

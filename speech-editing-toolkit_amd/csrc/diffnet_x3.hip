@@ -1196,13 +1196,16 @@ constexpr unsigned XV_PLANE = 2 * XV_PIECE;
 constexpr unsigned XV_TILE = 2 * XV_PLANE;        // 101,376 bytes
 constexpr unsigned XV_ZPIECE = 32 * XV_NB * XR;   // one piece of the z tile (96 frame rows) = XV_PLANE
 #ifndef SET_X3V_DEFAULT
-#define SET_X3V_DEFAULT 1                         // what a chip-filling shape takes without SET_AMD_X3_WINO: 1 = 64-frame tiles, 2 = 96-frame tiles
+#define SET_X3V_DEFAULT 2                         // what a chip-filling shape takes without SET_AMD_X3_WINO: 1 = 64-frame tiles, 2 = 96-frame tiles
 #endif
 #ifndef SET_X3V_PF
 #define SET_X3V_PF 2                              // fragment ring depth of GEMM 1 in k-steps of 32 (8 fragments = 32 registers each)
 #endif
 #ifndef SET_X3V_PF2
 #define SET_X3V_PF2 2                             // fragment ring depth of GEMM 2 in k-steps of 16
+#endif
+#ifndef SET_X3V_SK_EARLY
+#define SET_X3V_SK_EARLY 0                        // 1 = the running skip rows are fetched before GEMM 2 (48 more live registers through it)
 #endif
 
 __device__ __forceinline__ f32x4 mma16(u32x4_t a, u32x4_t b, f32x4 c) {
@@ -1354,7 +1357,16 @@ __device__ __forceinline__ void x3v_plane(f32x4 (&acc)[4][XV_NB], u32x4_t (&A)[P
     }
 }
 
-__device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_NB], unsigned char *lds) {
+// (SET_X3_PROBE builds: lane 0 of block 0 adds its s_memtime ticks per phase to g_x3_phase_buf -- 0 claim + accumulator start + wait, 1 first
+// plane pair staged, 2 its GEMMs, 3 E / O + second pair staged, 4 its GEMMs, 8 residual loads + gate, 9 GEMM 2, 10 epilogue issue, 5 publish)
+__device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_NB], unsigned char *lds, uint64_t *dbg, uint64_t &tprev) {
+#define X3V_PHASE(p)                                          \
+    if (dbg) {                                                \
+        const uint64_t tn = __builtin_amdgcn_s_memtime();     \
+        dbg[p] += tn - tprev;                                 \
+        tprev = tn;                                           \
+    }
+    X3V_PHASE(0)
     typedef SplitF16x2 S;
     constexpr int PFV = SET_X3V_PF;
     int tid = threadIdx.x;
@@ -1389,8 +1401,10 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
 #pragma unroll
             for (int q = 0; q < 2; ++q) A[p][mb][q] = buf_load_u4(rw, lane16, abase + (unsigned)(((p * 4 + mb) * 2 + q) * 1024));
     __syncthreads();
+    X3V_PHASE(1)
     x3v_plane<PFV>(PQ[0], A, rw, lane16, abase, 0, lds, boff);
     x3v_plane<PFV>(PQ[1], A, rw, lane16, abase, 1, lds + XV_PLANE, boff);
+    X3V_PHASE(2)
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -1412,8 +1426,10 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
 #pragma unroll
             for (int q = 0; q < 2; ++q) A[p][mb][q] = buf_load_u4(rw, lane16, abase + (unsigned)((((16 + p) * 4 + mb) * 2 + q) * 1024));
     __syncthreads();
+    X3V_PHASE(3)
     x3v_plane<PFV>(PQ[0], A, rw, lane16, abase, 2, lds, boff);
     x3v_plane<PFV>(PQ[1], A, rw, lane16, abase, 3, lds + XV_PLANE, boff);
+    X3V_PHASE(4)
     // ---- residual rows of x for GEMM 2's accumulator start (issued here, consumed after the gate)
     bool tv[XV_NB];
     unsigned vo4[XV_NB];
@@ -1472,11 +1488,23 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
             for (int cb = 0; cb < XV_NB; ++cb) acc[0][rb][cb][r] = (rb == 0 ? bias + xres[cb][r] : bias) * s2;
         }
     }
+#if SET_X3V_SK_EARLY
+    float sk[XV_NB][16];
+#pragma unroll
+    for (int cb = 0; cb < XV_NB; ++cb) {
+        const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load_nt(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
+    }
+#endif
     __syncthreads();
+    X3V_PHASE(8)
     gemm_x3<S, X_KS2, 1, XV_NB, SET_X3V_PF2>(acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + w * X_KS2 * 2 * 2 * 1024), (unsigned)(X_KS2 * 2 * 2 * 1024), lds,
                                              XV_ZPIECE, [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2); });
+    X3V_PHASE(9)
     // ---- epilogue
     const bool first = a.first != 0;
+#if !SET_X3V_SK_EARLY
     float sk[XV_NB][16];
     if (!first) {
 #pragma unroll
@@ -1486,6 +1514,7 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
             for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load_nt(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
         }
     }
+#endif
 #pragma unroll
     for (int cb = 0; cb < XV_NB; ++cb) {
         if (tv[cb]) {
@@ -1503,7 +1532,9 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
                 buf_store_agent(first ? acc[0][1][cb][r] * is2 : acc[0][1][cb][r] * is2 + sk[cb][r], rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
         }
     }
+    X3V_PHASE(10)
 }
+#undef X3V_PHASE
 
 // the persistent (layer, tile) queue of diffnet_stack_x3w_kernel on 96-frame tiles
 __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetStackArgs a, int ntiles, int ntasks, int fault_tile) {
@@ -1512,6 +1543,8 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
     int *s_task = reinterpret_cast<int *>(lds + XV_TILE + XV_NB * XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
     int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
     const int tid = threadIdx.x;
+    uint64_t *dbg = (SET_X3_PROBE && blockIdx.x == 0 && tid == 0) ? g_x3_phase_buf : nullptr;
+    uint64_t tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
     if (tid == 0) s_task[0] = atomicAdd(counter, 1);
     __syncthreads();
     int n = __builtin_amdgcn_readfirstlane(s_task[0]);
@@ -1529,7 +1562,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
         lt.b_out = a.b_out_all + (int64_t)l * 512;
         lt.err_flag = a.err_flag;
         lt.T = a.T; lt.dil = 1; lt.first = (l == 0);
-        lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * XV_NB;
+        lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * XV_NB;  // (x3v)
         f32x4 PQ[2][4][XV_NB];
         x3v_init(lt, PQ);
         __builtin_amdgcn_sched_barrier(0);
@@ -1571,10 +1604,16 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
             if (__builtin_amdgcn_readfirstlane(s_task[2]) == 0) break;
         }
         const int n_next = __builtin_amdgcn_readfirstlane(s_task[0]);
-        x3v_main(lt, PQ, lds);
+        x3v_main(lt, PQ, lds, dbg, tprev);
         i_done = i;
         l_done = l;
         n = n_next;
+        if (dbg) {
+            const uint64_t tn = __builtin_amdgcn_s_memtime();
+            dbg[5] += tn - tprev;
+            dbg[7] += 1;
+            tprev = tn;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

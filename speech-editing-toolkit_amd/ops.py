@@ -794,11 +794,12 @@ def stack_variant(B, T, dilation_cycle_length, have_wino=True, have_split=True, 
 
 
 def stack_x3_winograd(B, T, dilation_cycle_length, have_wino=True, have_split=True, x3_mode=None):
-    """True when variant 5 (two-piece fp16 split-operand kernel) runs GEMM 1 in its Winograd F(2,3) form for this shape
-    (diffnet_stack_x3w_kernel, round 6)."""
+    """Non-zero when variant 5 (two-piece fp16 split-operand kernel) runs GEMM 1 in its Winograd F(2,3) form for this shape (round 6):
+    1 = 64-frame tiles (diffnet_stack_x3w_kernel), 2 = 96-frame tiles on the 16-wide matrix instruction (diffnet_stack_x3v_kernel: shapes
+    with a tile chain for every CU); 0 = the direct form."""
     m = split_operand_mode() if x3_mode is None else int(x3_mode)
     bits = int(bool(have_wino)) | (2 if have_split else 0) | (4 if m == 3 else 0) | (8 if m == 2 else 0)
-    return bool(_lib.lib().set_diffnet_stack_x3_winograd(int(B), int(T), int(dilation_cycle_length), bits))
+    return int(_lib.lib().set_diffnet_stack_x3_winograd(int(B), int(T), int(dilation_cycle_length), bits))
 
 
 STACK_VARIANT_NAMES = {0: "diffnet_stack_kernel<2,4,2>", 1: "diffnet_stack_kernel<1,8,2>", 2: "diffnet_stack_wino_kernel",

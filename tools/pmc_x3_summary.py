@@ -24,7 +24,9 @@ def collect(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         n = r["Kernel_Name"]
-        if "diffnet_stack_x3w_kernel" in n:  # round 6: the Winograd form of the two-piece fp16 kernel
+        if "diffnet_stack_x3v_kernel" in n:  # round 6: Winograd form on 96-frame tiles, GEMM 1 on the 16-wide instruction
+            acc["diffnet_stack_x3v_kernel"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        elif "diffnet_stack_x3w_kernel" in n:  # round 6: the Winograd form of the two-piece fp16 kernel, 64-frame tiles
             acc["diffnet_stack_x3w_kernel"][r["Counter_Name"]].append(float(r["Counter_Value"]))
         elif "diffnet_stack_x3_kernel" in n and "pack_" not in n:
             key = "diffnet_stack_x3_kernel<%s>" % ("SplitF16x2" if "SplitF16x2" in n else "SplitBf16x3")
@@ -46,6 +48,7 @@ if __name__ == "__main__":
         out[k] = {"traffic_bytes": 2.0 * f * 1024.0 + w * 1024.0, "fetch_KB_raw": f, "write_KB_raw": w, "launches": [nf, nw],
                   "counters": m, "cycles_per_launch": cyc,
                   "mfma_busy_frac_of_simd_cycles": m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc) if cyc else None,
-                  "mfma_instructions_per_launch": m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 32.0}
+                  # (32 busy cycles per 32x32x16 instruction; the x3v kernel's GEMM 1 issues 16x16x32 ones of 16 cycles: not derivable there)
+                  "mfma_instructions_per_launch": None if "x3v" in k else m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 32.0}
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     print(json.dumps(out, indent=1))

@@ -38,6 +38,8 @@ for B, T in [tuple(int(v) for v in s.split("x")) for s in os.environ.get("SIZES"
     st = buf.cpu().tolist()
     tot = sum(st[:6]) + sum(st[8:13]); ntask = max(1, st[7])
     NAMES = ("claim+wait", "stage", "gemm1", "gate:tail-barrier", "gemm2", "epi+publish", "-", "-", "gate:xres+barrier", "gate:math+lds", "gate:init", "boundary:issue", "boundary:drain")
+    if os.environ.get("X3_NAMES"):  # other kernels of the family stamp other phases (x3v: see x3v_main)
+        NAMES = tuple(os.environ["X3_NAMES"].split(","))
     if tot == 0:  # the shipped library has no phase stamps (SET_X3_PROBE=0): time only
         print("B=%d T=%d: %.1f us per 20-layer launch (no phase stamps in this build: tools/build_exp.sh probe diffnet_x3.hip -DSET_X3_PROBE=1, "
               "then SET_AMD_LIB=build/exp/libset_amd_probe.so)" % (B, T, us))
