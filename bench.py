@@ -438,13 +438,11 @@ def run_infer(args, rank, world, dev):
     elif persistent and variant == 5:
         executed_ratio, pipe_peak, pipe = 3.0, PEAK_BF16_MFMA_TFLOPS, "v_mfma_f32_32x32x16_f16"
     x3w = int(ops.stack_x3_winograd(B_PER_GPU // groups, T, model.denoise_fn.dilation_cycle_length)) if persistent and variant == 5 else 0
-    x3w_name = {1: "diffnet_stack_x3w_kernel", 2: "diffnet_stack_x3v_kernel"}.get(x3w)
+    x3w_name = "diffnet_stack_x3v_kernel<%d>" % x3w if x3w else None  # x3w = column blocks (32 frames) per tile: 2 or 3
     if x3w:  # round 6: GEMM 1 of the two-piece fp16 kernel in its Winograd F(2,3) form: 3/4 of the layer's MFMAs are issued
-        stack_kernel = ("diffnet_stack_x3w_kernel (SplitF16x2, Winograd F(2,3) form of GEMM 1, 64-frame tiles)" if x3w == 1 else
-                        "diffnet_stack_x3v_kernel (SplitF16x2, Winograd F(2,3) form of GEMM 1, 96-frame tiles on v_mfma_f32_16x16x32_f16)")
+        stack_kernel = "diffnet_stack_x3v_kernel<%d> (SplitF16x2, Winograd F(2,3) form of GEMM 1, %d-frame tiles on v_mfma_f32_16x16x32_f16)" % (x3w, 32 * x3w)
         executed_ratio = 3.0 * (512 * 512 + 512 * 256) / (512 * 768 + 512 * 256)
-        if x3w == 2:
-            pipe = "v_mfma_f32_16x16x32_f16 (GEMM 1) + v_mfma_f32_32x32x16_f16 (GEMM 2)"
+        pipe = "v_mfma_f32_16x16x32_f16 (GEMM 1) + v_mfma_f32_32x32x16_f16 (GEMM 2)"
     split_operands = persistent and variant in (4, 5)
     layers_per_launch = L if persistent else 1
     launch_ms = sum(spans) / len(spans) / (L // layers_per_launch)
@@ -533,7 +531,7 @@ def run_infer(args, rank, world, dev):
                                "pieces (8 + 8 + 8 = 24 significand bits) and a product is the six cross terms down to 2^-16; fp32 "
                                "accumulation.  ") +
                               ("GEMM 1 (the k = 3 dilated conv) runs in its Winograd F(2,3) form over output pairs on the same two-piece "
-                                 "operands (tests ::test_x3w_*: error against fp64 within 2 x the fp32 chain's, the T = 800 x 100-step reference "
+                                 "operands (tests ::test_x3v_*: error against fp64 within 2 x the fp32 chain's, the T = 800 x 100-step reference "
                                  "golden at 1.7e-6).  " if x3w else "") +
                               "Asserted: error of a layer stack against fp64 <= 1.5 x the native fp32-MFMA chain's "
                               "(tests/test_gpu_parity.py::test_x3_stack_matches_fp32_stack_and_fp64), the reference goldens incl. "

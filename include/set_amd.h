@@ -352,9 +352,10 @@ int64_t set_diffnet_layer_x3_image_size(int32_t mode); /* 16-bit elements per la
 int set_pack_diffnet_layer_x3(const float *w_dil /*[512][256][3]*/, const float *w_out /*[512][256]*/, void *img, int32_t mode,
                               int32_t k1, int32_t k2, void *stream);
 int set_diffnet_stack_variant(int B, int T, int dilation_cycle_length, int images);
-/* 1 when the split-operand kernel of variant 5 runs GEMM 1 in its Winograd F(2,3) form for this shape (diffnet_stack_x3w_kernel: the k = 3
- * dilated conv of diffnet.py:70 over output pairs, 3/4 of the layer's matrix instructions; 64-frame tiles, dilation 1, even T;
- * SET_AMD_X3_WINO=0 keeps the direct form), else 0.  `images` as for set_diffnet_stack_variant. */
+/* Non-zero when the split-operand kernel of variant 5 runs GEMM 1 in its Winograd F(2,3) form for this shape (diffnet_stack_x3v_kernel: the
+ * k = 3 dilated conv of diffnet.py:70 over output pairs, 3/4 of the layer's matrix instructions; dilation 1, even T): the number of 32-frame
+ * column blocks per tile -- 3 (96-frame tiles: shapes with a tile chain for every CU) or 2 (64-frame tiles); 0 = the direct form
+ * (SET_AMD_X3_WINO=0 pins it, =2 / =3 pin the tile width).  `images` as for set_diffnet_stack_variant. */
 int set_diffnet_stack_x3_winograd(int B, int T, int dilation_cycle_length, int images);
 int64_t set_diffnet_w1w_size(void);
 int set_pack_diffnet_layer_wino(const float *w_dil, const float *w_out, float *w1w, float *w2w, void *stream);

@@ -110,16 +110,13 @@ struct SplitF16x2 {
 // scales the weights of the two GEMMs were multiplied by before splitting)
 template <typename S> constexpr int64_t x_n1() { return 8LL * X_KS1 * 2 * S::NP * 512; }
 template <typename S> constexpr int64_t x_n2() { return 8LL * X_KS2 * 2 * S::NP * 512; }
-// Winograd F(2,3) image of GEMM 1 (round 6; two-piece fp16 only): 64 k-steps = the four transformed weight planes U0, -U3, U1, U2 in the
-// order the kernel consumes them, [wave][k-step][row block][piece][lane][8], then {s1w, 1 / s1w} + padding (4 floats)
-constexpr int X_KSW = 64;
-template <typename S> constexpr int64_t x_nw() { return S::MODE == 2 ? 8LL * X_KSW * 2 * S::NP * 512 + 8 : 0; }
-// The same four planes for the 16-wide matrix instruction (v_mfma_f32_16x16x32_f16; diffnet_stack_x3v_kernel): 32 k-steps of 32 channels in
-// the order U1, U2, U0, -U3, [wave][k-step][row block 4: gate 0-15, gate 16-31, filter 0-15, filter 16-31][piece][lane][8].  It sits between
-// the body of the 32-wide Winograd image and the {s1w, 1 / s1w} tail, which both forms share (the tail stays the last 8 elements of the image).
+// Winograd F(2,3) image of GEMM 1 (round 6; two-piece fp16 only) for the 16-wide matrix instruction (v_mfma_f32_16x16x32_f16;
+// diffnet_stack_x3v_kernel): the four transformed weight planes as 32 k-steps of 32 channels in the order the kernel consumes them -- U1, U2, U0,
+// -U3 -- [wave][k-step][row block 4: gate 0-15, gate 16-31, filter 0-15, filter 16-31][piece][lane][8], then {s1w, 1 / s1w} + padding (4 floats:
+// the last 8 elements of the layer image)
 constexpr int X_KSV = 32;
-template <typename S> constexpr int64_t x_nv() { return S::MODE == 2 ? 8LL * X_KSV * 4 * S::NP * 512 : 0; }
-template <typename S> constexpr int64_t x_nimg() { return x_n1<S>() + x_n2<S>() + 8 + x_nw<S>() + x_nv<S>(); }
+template <typename S> constexpr int64_t x_nv() { return S::MODE == 2 ? 8LL * X_KSV * 4 * S::NP * 512 + 8 : 0; }
+template <typename S> constexpr int64_t x_nimg() { return x_n1<S>() + x_n2<S>() + 8 + x_nv<S>(); }
 __device__ __forceinline__ u32x4_t buf_load_u4(rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
 }
@@ -143,60 +140,49 @@ template <typename S>
 __global__ void __launch_bounds__(256) pack_layer_x3_kernel(const float *wdil, const float *wout, unsigned short *img, float s1, float s2) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (fragment element, all pieces)
     constexpr int64_t n1 = x_n1<S>() / S::NP, n2 = x_n2<S>() / S::NP;
-    constexpr int64_t nw = x_nw<S>() > 0 ? (x_nw<S>() - 8) / S::NP : 0;
+    constexpr int64_t nv = x_nv<S>() > 0 ? (x_nv<S>() - 8) / S::NP : 0;
     if (idx == 0) {
         float *tail = reinterpret_cast<float *>(img + x_n1<S>() + x_n2<S>());
         tail[0] = s1; tail[1] = 1.0f / s1; tail[2] = s2; tail[3] = 1.0f / s2;
-        if (nw > 0) {  // |U| <= 1.5 max |w|: half the scale of the direct image keeps the top piece in the same binade range
+        if (nv > 0) {  // |U| <= 1.5 max |w|: half the scale of the direct image keeps the top piece in the same binade range
             float *tw = reinterpret_cast<float *>(img + x_nimg<S>() - 8);
             tw[0] = 0.5f * s1; tw[1] = 1.0f / (0.5f * s1); tw[2] = 0.0f; tw[3] = 0.0f;
         }
     }
-    constexpr int64_t nv = x_nv<S>() / S::NP;
-    if (idx >= n1 + n2 + nw + nv) return;
-    if (idx >= n1 + n2 + nw) {  // Winograd planes of GEMM 1 for the 16-wide matrix instruction
-        int64_t r = idx - n1 - n2 - nw;
+    if (idx >= n1 + n2 + nv) return;
+    if (idx >= n1 + n2) {  // Winograd planes of GEMM 1 (fragments of the 16-wide matrix instruction: lane l holds row (l & 15), k = 8 (l >> 4) + e)
+        // y[2p] = m0 + m1 + m2, y[2p+1] = m1 - m2 - m3 with m_j = U_j . V_j over the channels (diffnet.py:70 dilated_conv, dilation 1):
+        // U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2; stored plane order: U1, U2 (the first pair of planes the kernel
+        // stages), U0, -U3 (accumulates straight into the odd output).  Formed in fp64, rounded to fp32 once.
+        int64_t r = idx - n1 - n2;
         const int e = r & 7; r >>= 3;
         const int l = r & 63; r >>= 6;
         const int mb = r & 3; r >>= 2;
         const int ks = (int)(r % X_KSV), w = (int)(r / X_KSV);
         const int row = (mb >= 2 ? XC : 0) + 32 * w + 16 * (mb & 1) + (l & 15), k = 8 * (l >> 4) + e;
-        const int plane = ks >> 3, c = 32 * (ks & 7) + k;  // plane order U1, U2, U0, -U3 (see pack of the 32-wide planes below for the U's)
+        const int plane = ks >> 3, c = 32 * (ks & 7) + k;
         const float *g = wdil + ((int64_t)row * XC + c) * 3;
         const double g0 = g[0], g1 = g[1], gg2 = g[2];
         const double u = plane == 0 ? 0.5 * (g0 + g1 + gg2) : (plane == 1 ? 0.5 * (g0 - g1 + gg2) : (plane == 2 ? g0 : -gg2));
         unsigned short p[S::NP];
         S::split((0.5f * s1) * (float)u, p);
-        unsigned short *base = img + x_n1<S>() + x_n2<S>() + 8 + (x_nw<S>() - 8) + ((((int64_t)w * X_KSV + ks) * 4 + mb) * S::NP) * 512 + l * 8 + e;
+        unsigned short *base = img + x_n1<S>() + x_n2<S>() + 8 + ((((int64_t)w * X_KSV + ks) * 4 + mb) * S::NP) * 512 + l * 8 + e;
 #pragma unroll
         for (int q = 0; q < S::NP; ++q) base[q * 512] = p[q];
         return;
     }
-    const bool gw = idx >= n1 + n2;  // Winograd planes of GEMM 1
-    const bool g2 = !gw && idx >= n1;
-    int64_t r = gw ? idx - n1 - n2 : (g2 ? idx - n1 : idx);
+    const bool g2 = idx >= n1;
+    int64_t r = g2 ? idx - n1 : idx;
     const int e = r & 7; r >>= 3;
     const int l = r & 63; r >>= 6;
     const int rb = r & 1; r >>= 1;
-    const int nks = gw ? X_KSW : (g2 ? X_KS2 : X_KS1);
+    const int nks = g2 ? X_KS2 : X_KS1;
     const int ks = (int)(r % nks), w = (int)(r / nks);
     const int row = (rb ? XC : 0) + 32 * w + (l & 31), k = 8 * (l >> 5) + e;
-    float v;
-    if (gw) {
-        // y[2p] = m0 + m1 + m2, y[2p+1] = m1 - m2 - m3 with m_j = U_j . V_j over the channels (diffnet.py:70 dilated_conv, dilation 1):
-        // U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2; stored plane order: U0, -U3 (accumulates straight into the odd
-        // output), U1, U2.  Formed in fp64, rounded to fp32 once.
-        const int plane = ks >> 4, c = 16 * (ks & 15) + k;
-        const float *g = wdil + ((int64_t)row * XC + c) * 3;
-        const double g0 = g[0], g1 = g[1], gg2 = g[2];
-        const double u = plane == 0 ? g0 : (plane == 1 ? -gg2 : (plane == 2 ? 0.5 * (g0 + g1 + gg2) : 0.5 * (g0 - g1 + gg2)));
-        v = (0.5f * s1) * (float)u;
-    } else {
-        v = g2 ? s2 * wout[(int64_t)row * XC + 16 * ks + k] : s1 * wdil[((int64_t)row * XC + 16 * (ks % 16) + k) * 3 + ks / 16];
-    }
+    const float v = g2 ? s2 * wout[(int64_t)row * XC + 16 * ks + k] : s1 * wdil[((int64_t)row * XC + 16 * (ks % 16) + k) * 3 + ks / 16];
     unsigned short p[S::NP];
     S::split(v, p);
-    unsigned short *base = img + (gw ? x_n1<S>() + x_n2<S>() + 8 : (g2 ? x_n1<S>() : 0)) + ((((int64_t)w * nks + ks) * 2 + rb) * S::NP) * 512 + l * 8 + e;
+    unsigned short *base = img + (g2 ? x_n1<S>() : 0) + ((((int64_t)w * nks + ks) * 2 + rb) * S::NP) * 512 + l * 8 + e;
 #pragma unroll
     for (int q = 0; q < S::NP; ++q) base[q * 512] = p[q];
 }
@@ -711,22 +697,19 @@ int launch_x3(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_
 
 // =====================================================================================================================
 // Winograd F(2,3) for GEMM 1 on the two-piece fp16 operands (round 6).  The kernel is limited by the package power, not by time
-// (profiles/r04_power.log, r06_loop_launch_ab.log), and 57 % of its energy is the fp16 MFMA work itself -- so the lever is FEWER matrix
-// instructions: the k = 3 conv over an output PAIR (frames 2p, 2p + 1) is four channel GEMMs instead of six,
+// (profiles/r04_power.log, r06_loop_launch_ab.log), and the fp16 MFMA work is the largest part of its energy -- so the first lever is FEWER
+// matrix instructions: the k = 3 conv over an output PAIR (frames 2p, 2p + 1) is four channel GEMMs instead of six,
 //     V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3          (d0 .. d3 = x + step offset at frames 2p - 1 .. 2p + 2; fp32, then split)
 //     y[2p] = U0 V0 + U1 V1 + U2 V2,   y[2p + 1] = U1 V1 - U2 V2 - U3 V3   (U: pack_layer_x3_kernel)
-// i.e. 2/3 of GEMM 1's MFMAs, 3/4 of the layer's.  Price: every weight fragment now feeds ONE triple of MFMAs (32 pair-columns per
-// plane) instead of two, so the L2 -> CU fragment stream per MFMA doubles (2 MiB per task for GEMM 1 instead of 1.5), and the split /
-// transform work of the staging pass doubles.  64-frame tiles only, dilation 1, even T; every tile of such a launch takes this form (the two
-// column blocks of a tile may lie in different utterances: x3w_lane below).
+// i.e. 2/3 of GEMM 1's MFMAs, 3/4 of the layer's.  Dilation 1 and even T only (a pair never straddles an utterance end).
 // Same accumulation precision (fp32) and piece products; the sums are formed in a different order than the direct form: results agree
 // with it to fp32 rounding (like the fp32-pipe Winograd kernel of csrc/diffnet.hip), not bit for bit.
-// LDS: V tile [plane 4][piece 2][pair 32][XR] (132 KB; the z tile [piece][64][XR] overlays it), step offsets, task slots.
+// History: the first form (diffnet_stack_x3w_kernel, commits 4f9a309 .. 1cd6a4e) ran 64-frame tiles on the 32-wide instruction with three
+// accumulator sets (even, odd, one temporary) and the whole four-plane V tile in LDS: 1.61 - 1.70 ms per 20-layer launch against the direct
+// form's 1.69 - 1.75, bound by its weight-fragment stream (every fragment met ONE 32-pair column block: 2 MiB per task at ~50 B/clk/CU,
+// profiles/r06_x3w_no_a_stream_bound.log).  The kernel below replaced it on every shape (same box: B = 32 1.43 against 1.61 ms on 96-frame
+// tiles; 64-frame tiles B = 24 / 16 / 12: +5.3 / +3.7 / +3.1 % frames/s, profiles/r06_x3v_ab.log, r06_x3v_nb2_ab.log).
 // =====================================================================================================================
-constexpr unsigned XW_PIECE = 32 * XR;          // one piece of one plane of the V tile
-constexpr unsigned XW_PLANE = 2 * XW_PIECE;
-constexpr unsigned XW_TILE = 4 * XW_PLANE;      // 135,168 bytes
-constexpr unsigned XW_ZPIECE = 64 * XR;         // one piece of the z tile
 typedef unsigned u32x2w_t __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 buf_load2(rsrc_t r, unsigned voff, unsigned soff) {
@@ -736,440 +719,12 @@ __device__ __forceinline__ f32x2 buf_load2(rsrc_t r, unsigned voff, unsigned sof
 __device__ __forceinline__ f32x2 buf_load2_nt(rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, SET_X3W_NT ? 2 : 0));
 }
-// lane i <- lane i - 1 / lane i + 1 of the wave (DPP wave_shr:1 / wave_shl:1; the ends get `old`)
-__device__ __forceinline__ float wave_prev(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float wave_next(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
-}
-
-// Tile geometry of the Winograd form (round 6, second half): a tile is TWO 32-frame column blocks = 2 x 16 output pairs, and -- as in the direct
-// form -- every column block carries its own utterance, first frame and halo frames: lane l31 of a staging / accumulator-start fragment is pair
-// (l31 & 15) of column block (l31 >> 4).  T even: a pair never straddles an utterance end.  The first version ran the tiles whose two blocks lie in
-// different utterances (16 of 400 at B = 32, T = 800) through the direct form inside the same launch: each of them streamed the layer's 3 MiB
-// DIRECT image past the L2 for one tile (16 x 20 x 3 MiB = 1.0 GB of the 5.0 GB a launch fetched) and ran ~2 x as long as its neighbours wait for.
-struct X3wLane {
-    int b, t0;   // utterance and first frame of this lane's column block
-    bool ok;     // the block exists (the last tile of an odd block count has one)
-};
-__device__ __forceinline__ X3wLane x3w_lane(const X3Tile &a, int l31) {
-    const X3Col c0 = x3_col(a, 0), c1 = x3_col(a, 1);
-    const bool hi = l31 >= 16;
-    X3wLane r;
-    r.b = hi ? c1.b : c0.b;
-    r.t0 = hi ? c1.t0 : c0.t0;
-    r.ok = hi ? c1.ok : c0.ok;
-    return r;
-}
-
-// accumulator start: EO[0][rb] (even frames) / EO[1][rb] (odd frames) = b_dil + conditioner projection; lane l31 = pair
-__device__ __forceinline__ void x3w_init(const X3Tile &a, f32x16 (&EO)[2][2]) {
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));  // (see x3w_main)
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, l31 = lane & 31;
-    const int T = a.T;
-    const unsigned T4 = 4u * (unsigned)T;
-    const X3wLane c = x3w_lane(a, l31);
-    const rsrc_t rcp = make_rsrc(a.cp);  // BATCH base: the utterance is part of the lane offset
-    const unsigned vo = 4u * ((unsigned)c.b * (unsigned)a.cp_bs + (unsigned)(4 * half * T + min(c.t0 + 2 * (l31 & 15), T - 2)));
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const float *bd = a.b_dil + (rb ? XC : 0) + 32 * w;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned ur = (unsigned)((rb ? XC : 0) + 32 * w + urow(r));
-            const float blo = bd[urow(r)], bhi = bd[urow(r) + 4];
-            const f32x2 v = buf_load2_nt(rcp, vo, ur * T4);
-            EO[0][rb][r] = (half ? bhi : blo) + v[0];
-            EO[1][rb][r] = (half ? bhi : blo) + v[1];
-        }
-    }
-}
-
-// 16 k-steps (one plane) of the Winograd GEMM 1 into acc[rb]; the fragment ring A runs through all 64 k-steps of the GEMM
-template <int PFW>
-__device__ __forceinline__ void x3w_plane(f32x16 (&acc)[2], u32x4_t (&A)[PFW][2][2], rsrc_t img, unsigned lane16, unsigned abase, int seg,
-                                          const unsigned char *bplane, unsigned boff) {
-    typedef SplitF16x2 S;
-    for (int kb = 0; kb < 16; kb += PFW) {
-#pragma unroll
-        for (int p = 0; p < PFW; ++p) {
-            const int kc = kb + p, ks = 16 * seg + kc;
-            u32x4_t Bv[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) Bv[q] = *reinterpret_cast<const u32x4_t *>(bplane + q * XW_PIECE + boff + (unsigned)kc * 32u);
-            __builtin_amdgcn_sched_barrier(0);
-#ifndef SET_X3W_NOPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-            for (int t = 0; t < S::NPROD; ++t)
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) acc[rb] = S::mma(A[p][rb][S::qa(t)], Bv[S::qb(t)], acc[rb]);
-#ifndef SET_X3W_NOPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            const int kn = min(ks + PFW, X_KSW - 1);
-#if !(SET_X3_EXP & 8)  // (measurement builds, bit 3: no weight-fragment stream in the Winograd GEMM -- WRONG RESULTS)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) A[p][rb][q] = buf_load_u4(img, lane16, abase + (unsigned)(((kn * 2 + rb) * 2 + q) * 1024));
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-#ifndef SET_X3W_PF
-#define SET_X3W_PF 4  // fragment ring depth of the Winograd GEMM 1 in k-steps (measurement builds: tools/build_exp.sh ... -DSET_X3W_PF=8)
-#endif
-// Measured and not kept (round 6, profiles/r06_x3w_prefetch_ab.log): touching the NEXT task's conditioner-projection rows under GEMM 2 so that
-// the accumulator-start loads of the next task hit the L2 -- 1.669 ms per launch with it, 1.650 ms without.
-__device__ __forceinline__ void x3w_main(const X3Tile &a, f32x16 (&EO)[2][2], unsigned char *lds, uint64_t *dbg, uint64_t &tprev) {
-#define X3W_PHASE(p)                                          \
-    if (dbg) {                                                \
-        const uint64_t tn = __builtin_amdgcn_s_memtime();     \
-        dbg[p] += tn - tprev;                                 \
-        tprev = tn;                                           \
-    }
-    X3W_PHASE(0)
-    typedef SplitF16x2 S;
-    constexpr int PFW = SET_X3W_PF;
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));  // opaque per task: the lane arithmetic below is not hoisted in front of the task loop (where it would sit
-                                   // in registers next to the direct path's own loop invariants and push both paths into scratch)
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, l31 = lane & 31;
-    const int T = a.T;
-    const unsigned T4 = 4u * (unsigned)T;
-    const unsigned lane16 = 16u * (unsigned)lane;
-    float *dsh = reinterpret_cast<float *>(lds + XW_TILE);  // [2][256] step offsets of the two column blocks' utterances
-    const X3Col c0 = x3_col(a, 0), c1 = x3_col(a, 1);
-    const X3wLane cl = x3w_lane(a, l31);  // staging / gate layout: lane = pair (l31 & 15) of column block (l31 >> 4)
-    const rsrc_t rw = make_rsrc(a.img);
-    const float *sc = reinterpret_cast<const float *>(a.img + x_n1<S>() + x_n2<S>());
-    const float s2 = sc[2], is2 = sc[3];
-    const float *scw = reinterpret_cast<const float *>(a.img + x_nimg<S>() - 8);
-    const float s1w = scw[0], is1w = scw[1];
-    // GEMM 2 / epilogue layout: column block cb, lane = frame l31 of it
-    bool tv[2];
-    unsigned vo4[2];
-    int64_t ub[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const X3Col c = cb ? c1 : c0;
-        const int t = c.t0 + l31;
-        tv[cb] = c.ok && t < T;
-        vo4[cb] = 4u * (unsigned)(4 * half * T + min(t, T - 1));
-        ub[cb] = (int64_t)c.b * XC * T;
-    }
-    // ---- stage: lane = (pair, channel group cg = 2 w + half of 16 channels): d1, d2 by one 8-byte load per channel, d0 / d3 from
-    //      the neighbouring lanes (the ends of a column block from two halo loads), transform, split, 16-byte writes per (plane, piece)
-    {
-        dsh[tid] = a.dstep[(int64_t)((tid >> 8) ? c1.b : c0.b) * a.d_bs + (int64_t)(tid & (XC - 1)) * a.d_cs];  // 512 threads = 2 x 256
-        const int cg = 2 * w + half, ch0 = 16 * cg;
-        const int pl = l31 & 15;
-        const rsrc_t rx = make_rsrc(a.xin);               // BATCH base: the utterance is part of the lane offset
-        const int t = cl.t0 + 2 * pl;                     // frames t, t + 1 (T even: both inside or both outside)
-        const bool v12 = cl.ok && t < T;
-        const int th = pl == 0 ? cl.t0 - 1 : cl.t0 + 32;  // halo frame of the block's end lanes
-        const bool edge = pl == 0 || pl == 15, vh = cl.ok && edge && th >= 0 && th < T;
-        const unsigned cgo = (unsigned)ch0 * T4 + 4u * (unsigned)(cl.b * XC * T);
-        const unsigned vox = 4u * (unsigned)min(t, T - 2) + cgo, voh = 4u * (unsigned)min(max(th, 0), T - 1) + cgo;
-        const float *dshl = dsh + (l31 >> 4) * XC;
-        f32x2 x12[16];
-        float xh[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) x12[k] = buf_load2(rx, vox, (unsigned)k * T4);
-        if (edge) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) xh[k] = buf_load(rx, voh, (unsigned)k * T4);
-        }
-        __syncthreads();  // dsh
-        float amax = 0.0f;
-#pragma unroll
-        for (int q8 = 0; q8 < 2; ++q8) {
-            unsigned short pc[4][8][2];  // [plane][channel][piece]
-            const f32x4 dA = *reinterpret_cast<const f32x4 *>(dshl + ch0 + 8 * q8);
-            const f32x4 dB = *reinterpret_cast<const f32x4 *>(dshl + ch0 + 8 * q8 + 4);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = 8 * q8 + e;
-                const float ds = e < 4 ? dA[e & 3] : dB[e & 3];
-                const float d1 = v12 ? x12[k][0] + ds : 0.0f, d2 = v12 ? x12[k][1] + ds : 0.0f;
-                float d0 = wave_prev(d2), d3 = wave_next(d1);
-                const float hv = vh ? xh[k] + ds : 0.0f;
-                d0 = pl == 0 ? hv : d0;
-                d3 = pl == 15 ? hv : d3;
-                const float V[4] = {d0 - d2, d1 - d3, d1 + d2, d2 - d1};  // plane order of the image: U0, -U3, U1, U2
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    amax = fmaxf(amax, fabsf(V[j]));
-                    S::split(V[j], pc[j][e]);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                u32x4_t u[2];
-                pack8<2>(pc[j], u);
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    *reinterpret_cast<u32x4_t *>(lds + j * XW_PLANE + q * XW_PIECE + l31 * XR + (ch0 + 8 * q8) * 2) = u[q];
-            }
-        }
-        if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int eo = 0; eo < 2; ++eo)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) EO[eo][rb][r] *= s1w;
-    __syncthreads();
-    X3W_PHASE(1)
-
-    // ---- GEMM 1: planes in image order: U0 V0 -> even, (-U3) V3 -> odd, U1 V1 -> both (+, +), U2 V2 -> both (+, -)
-    {
-        const unsigned abase = (unsigned)(x_n1<S>() * 2 + x_n2<S>() * 2 + 16) + (unsigned)(w * X_KSW * 2 * 2 * 1024);
-        const unsigned boff = (unsigned)(l31 * XR + half * 16);
-        u32x4_t A[PFW][2][2];
-#pragma unroll
-        for (int p = 0; p < PFW; ++p)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) A[p][rb][q] = buf_load_u4(rw, lane16, abase + (unsigned)(((p * 2 + rb) * 2 + q) * 1024));
-        x3w_plane<PFW>(EO[0], A, rw, lane16, abase, 0, lds + 0 * XW_PLANE, boff);
-        x3w_plane<PFW>(EO[1], A, rw, lane16, abase, 1, lds + 1 * XW_PLANE, boff);
-        f32x16 Tm[2];
-        Tm[0] = (f32x16){0};
-        Tm[1] = (f32x16){0};
-        x3w_plane<PFW>(Tm, A, rw, lane16, abase, 2, lds + 2 * XW_PLANE, boff);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                EO[0][rb][r] += Tm[rb][r];
-                EO[1][rb][r] += Tm[rb][r];
-                Tm[rb][r] = 0.0f;
-            }
-        x3w_plane<PFW>(Tm, A, rw, lane16, abase, 3, lds + 3 * XW_PLANE, boff);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                EO[0][rb][r] += Tm[rb][r];
-                EO[1][rb][r] -= Tm[rb][r];
-            }
-    }
-    X3W_PHASE(2)
-    // ---- residual rows of x for GEMM 2's accumulator start (issued here, consumed after the gate)
-    float xres[2][16];
-    {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const rsrc_t rx = make_rsrc(a.xin + ub[cb]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xres[cb][r] = buf_load(rx, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
-        }
-    }
-    __syncthreads();  // every wave is done reading the V tile: the z tile overlays it (row = frame of the tile)
-    // ---- gate: lane l31 holds frames 2 l31 (even accumulators) and 2 l31 + 1 (odd): z rows 2 l31 / 2 l31 + 1
-    {
-        const bool tvp = cl.ok && cl.t0 + 2 * (l31 & 15) < T;
-#pragma unroll
-        for (int eo = 0; eo < 2; ++eo)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                unsigned short p[4][2];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    const float zz = fsig(EO[eo][0][r] * is1w) * ftanh(EO[eo][1][r] * is1w);
-                    S::split(tvp ? zz : 0.0f, p[e]);
-                }
-                const unsigned off = (unsigned)((2 * l31 + eo) * XR + (32 * w + 8 * g + 4 * half) * 2);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    u32x2w_t uu;
-                    uu[0] = (unsigned)p[0][q] | ((unsigned)p[1][q] << 16);
-                    uu[1] = (unsigned)p[2][q] | ((unsigned)p[3][q] << 16);
-                    *reinterpret_cast<u32x2w_t *>(lds + q * XW_ZPIECE + off) = uu;
-                }
-            }
-    }
-    // ---- GEMM 2 accumulators: residual rows start at s2 (b_out + x), skip rows at s2 b_out; then exactly x3_main's second half
-    f32x16 acc[1][2][2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const float *bo = a.b_out + (rb ? XC : 0) + 32 * w;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float blo = bo[urow(r)], bhi = bo[urow(r) + 4];
-            const float bias = half ? bhi : blo;
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[0][rb][cb][r] = (rb == 0 ? bias + xres[cb][r] : bias) * s2;
-        }
-    }
-    float sk[2][16];
-    {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load_nt(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
-        }
-    }
-    __syncthreads();
-    X3W_PHASE(3)
-    gemm_x3<S, X_KS2, 1, 2, S::PF>(acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + w * X_KS2 * 2 * 2 * 1024), (unsigned)(X_KS2 * 2 * 2 * 1024), lds,
-                                   XW_ZPIECE, [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2); });
-    X3W_PHASE(4)
-    // ---- epilogue
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        if (tv[cb]) {
-            const rsrc_t rxo = make_rsrc(a.xout + ub[cb]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) buf_store_agent((acc[0][0][cb][r] * is2) * RSQRT2, rxo, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
-        }
-    }
-    const bool first = a.first != 0;
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        if (tv[cb]) {
-            const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                buf_store_agent(first ? acc[0][1][cb][r] * is2 : acc[0][1][cb][r] * is2 + sk[cb][r], rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
-        }
-    }
-}
-
-#undef X3W_PHASE
-
-// the persistent (layer, tile) queue of diffnet_stack_x3_kernel with the Winograd form of GEMM 1 on every tile it covers
-// Measured and not kept (round 6, profiles/r06_x3w_xcd_chunks_ab.log): XCD-aware task claiming -- the blocks of one XCD (blockIdx.x % 8) taking
-// their tasks from a chunk of 16 / 32 / 64 consecutive tiles of ONE layer, so that the 32 CUs sharing an L2 stream the same layer image.
-// Static chunk ownership (group g owns chunks g, g + 8, ..): 1.718 against 1.672 ms per launch at 1,287 W (groups drift apart and wait for each
-// other's tiles).  Chunks handed out dynamically (no block ever waits for work): 2.69 - 3.08 ms at 1,050 - 1,180 W and the maximum clock -- the
-// CUs of an XCD then run in lockstep and ask the L2 for the SAME weight fragments at the same moment.  The one global counter, which spreads
-// the CUs of an XCD over the phases of a task, is the better schedule; the 1.7 x algorithmic HBM bytes are its price.
-__global__ void __launch_bounds__(512, 1) diffnet_stack_x3w_kernel(SetDiffnetStackArgs a, int ntiles, int ntasks, int fault_tile) {
-    typedef SplitF16x2 S;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int *s_task = reinterpret_cast<int *>(lds + XW_TILE + 2 * XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
-    int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
-    const int tid = threadIdx.x;
-    uint64_t *dbg = (SET_X3_PROBE && blockIdx.x == 0 && tid == 0) ? g_x3_phase_buf : nullptr;
-    uint64_t tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
-    if (tid == 0) s_task[0] = atomicAdd(counter, 1);
-    __syncthreads();
-    int n = __builtin_amdgcn_readfirstlane(s_task[0]);
-    int i_done = -1, l_done = 0;
-    while (n < ntasks) {
-        const int l = n / ntiles, i = n - l * ntiles;
-        X3Tile lt;
-        lt.xin = (l & 1) ? a.xb : a.xa;
-        lt.xout = (l & 1) ? a.xa : a.xb;
-        lt.skp = a.skip;
-        lt.cp = a.condproj + (int64_t)l * a.cp_ls; lt.cp_bs = a.cp_bs;
-        lt.dstep = a.dstep + (int64_t)l * a.d_ls; lt.d_bs = a.d_bs; lt.d_cs = a.d_cs;
-        lt.img = reinterpret_cast<const unsigned short *>(a.wx3_all) + (int64_t)l * x_nimg<S>();
-        lt.b_dil = a.b_dil_all + (int64_t)l * 512;
-        lt.b_out = a.b_out_all + (int64_t)l * 512;
-        lt.err_flag = a.err_flag;
-        lt.T = a.T; lt.dil = 1; lt.first = (l == 0);
-        lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * 2;
-        f32x16 EO[2][2];  // [even / odd frame of a pair][rb]
-        x3w_init(lt, EO);
-        __builtin_amdgcn_sched_barrier(0);
-        const int *f0 = done + i, *fl = done + (i > 0 ? i - 1 : i), *fr = done + (i < ntiles - 1 ? i + 1 : i);
-        int peek = l, claimed = 0;
-        if (tid == 0) {
-            if (l > 0) peek = min(ld_agent(f0), min(ld_agent(fl), ld_agent(fr)));
-            claimed = atomicAdd(counter, 1);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) {
-            if (peek >= l) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            s_task[0] = claimed;
-            s_task[1] = peek >= l ? 1 : 2;
-        }
-        __syncthreads();
-        if (tid == 0 && i_done >= 0 && !(l_done == 0 && i_done == fault_tile))
-            __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        i_done = -1;
-        if (__builtin_amdgcn_readfirstlane(s_task[1]) == 2) {
-            if (tid == 0) {
-                int ok = 1;
-                unsigned spins = 0;
-                for (;;) {
-                    const int v0 = ld_agent(f0), v1 = ld_agent(fl), v2 = ld_agent(fr);
-                    if (min(v0, min(v1, v2)) >= l) break;
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > X_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
-                        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (a.err_flag) __hip_atomic_store(a.err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = 0;
-                        break;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                s_task[2] = ok;
-            }
-            __syncthreads();
-            if (__builtin_amdgcn_readfirstlane(s_task[2]) == 0) break;
-        }
-        const int n_next = __builtin_amdgcn_readfirstlane(s_task[0]);
-        x3w_main(lt, EO, lds, dbg, tprev);
-        i_done = i;
-        l_done = l;
-        n = n_next;
-        if (dbg) {
-            const uint64_t tn = __builtin_amdgcn_s_memtime();
-            dbg[5] += tn - tprev;
-            dbg[7] += 1;
-            tprev = tn;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0 && i_done >= 0 && !(l_done == 0 && i_done == fault_tile))
-        __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-int launch_x3w(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_x3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                "set_diffnet_stack(x3w attr)");
-        attr_set = true;
-    }
-    const int Q = a.B * ((a.T + 31) / 32);
-    const int ntiles = (Q + 1) / 2;
-    const int64_t ntasks64 = (int64_t)ntiles * a.L;
-    SET_REQUIRE(ntasks64 < (1ll << 30), "set_diffnet_stack(task count)");
-    SET_REQUIRE((int64_t)2 * XC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_stack(split-operand kernel: T too large)");
-    SET_REQUIRE(a.dilation_cycle_length == 1 && a.T % 2 == 0, "set_diffnet_stack(x3w: dilation 1 and even T only)");
-    // the utterance is part of the 32-bit lane offsets of the x and conditioner-projection loads (descriptor range 2^31 - 1 bytes)
-    SET_REQUIRE(((int64_t)a.B + 1) * XC * a.T * 4 < ((int64_t)1 << 31) && ((int64_t)a.B * a.cp_bs + (int64_t)2 * XC * a.T) * 4 < ((int64_t)1 << 31),
-                "set_diffnet_stack(x3w: batch too large for 32-bit lane offsets)");
-    const size_t ldsz = (size_t)XW_TILE + 2 * XC * sizeof(float) + 16;
-    SET_HIP(set_zero_async(a.sync_ws, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
-    int grid = n_cu;
-    if (grid > ntiles * 4 / 5) grid = ntiles * 4 / 5;
-    if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
-    if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(diffnet_stack_x3w_kernel, dim3(grid), dim3(512), ldsz, s, a, ntiles, (int)ntasks64, fault_tile);
-    return set_check_launch("set_diffnet_stack");
-}
+// Measured on the first form and not kept (round 6): touching the NEXT task's conditioner-projection rows under GEMM 2 (1.669 against 1.650 ms,
+// profiles/r06_x3w_prefetch_ab.log); XCD-aware task claiming -- the blocks of one XCD (blockIdx.x % 8) taking their tasks from a chunk of
+// 16 / 32 / 64 consecutive tiles of ONE layer so that the 32 CUs sharing an L2 stream the same layer image: static chunk ownership 1.718 against
+// 1.672 ms (groups drift apart and wait for each other's tiles), chunks handed out dynamically 2.69 - 3.08 ms at 1,050 - 1,180 W and the maximum
+// clock -- the CUs of an XCD then run in lockstep and ask the L2 for the SAME weight fragments at the same moment
+// (profiles/r06_x3w_xcd_chunks_ab.log).  The one global counter, which spreads the CUs of an XCD over the phases of a task, is the better schedule.
 
 // =====================================================================================================================
 // 96-frame tiles on the 16-wide matrix instruction (round 6, second half).  What bounds the 64-frame Winograd form is the weight-fragment
@@ -1190,14 +745,11 @@ int launch_x3w(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream
 //   GEMM 2 = the 32-wide loop of the other forms on three column blocks (gemm_x3<.., NCB = 3>), same image.
 // Results: same piece products and fp32 accumulation; sums in another order than the 64-frame form (equal to fp32 rounding).
 // =====================================================================================================================
-constexpr int XV_NB = 3;                          // column blocks per tile
-constexpr unsigned XV_PIECE = 16 * XV_NB * XR;    // one piece of one plane of the V tile (48 pair rows)
-constexpr unsigned XV_PLANE = 2 * XV_PIECE;
-constexpr unsigned XV_TILE = 2 * XV_PLANE;        // 101,376 bytes
-constexpr unsigned XV_ZPIECE = 32 * XV_NB * XR;   // one piece of the z tile (96 frame rows) = XV_PLANE
-#ifndef SET_X3V_DEFAULT
-#define SET_X3V_DEFAULT 2                         // what a chip-filling shape takes without SET_AMD_X3_WINO: 1 = 64-frame tiles, 2 = 96-frame tiles
-#endif
+// NB = column blocks per tile: 3 (96 frames; shapes with a tile chain for every CU) or 2 (64 frames)
+template <int NB> constexpr unsigned xv_piece() { return 16 * NB * XR; }      // one piece of one plane of the V tile (16 NB pair rows)
+template <int NB> constexpr unsigned xv_plane() { return 2 * xv_piece<NB>(); }
+template <int NB> constexpr unsigned xv_tile() { return 2 * xv_plane<NB>(); }   // NB = 3: 101,376 bytes
+template <int NB> constexpr unsigned xv_zpiece() { return 32 * NB * XR; }     // one piece of the z tile (32 NB frame rows) = xv_plane
 #ifndef SET_X3V_PF
 #define SET_X3V_PF 2                              // fragment ring depth of GEMM 1 in k-steps of 32 (8 fragments = 32 registers each)
 #endif
@@ -1220,7 +772,8 @@ __device__ __forceinline__ float row_next(float v) {
 }
 
 // accumulator start: PQ[0] = s1w (e + o) / 2, PQ[1] = s1w (e - o) / 2; lane (l15, kg): pair l15 of column block nb, rows 4 kg .. 4 kg + 3 of block mb
-__device__ __forceinline__ void x3v_init(const X3Tile &a, f32x4 (&PQ)[2][4][XV_NB]) {
+template <int NB>
+__device__ __forceinline__ void x3v_init(const X3Tile &a, f32x4 (&PQ)[2][4][NB]) {
     typedef SplitF16x2 S;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -1234,7 +787,7 @@ __device__ __forceinline__ void x3v_init(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) bias[mb] = *reinterpret_cast<const f32x4 *>(a.b_dil + (mb >= 2 ? XC : 0) + 32 * w + 16 * (mb & 1) + 4 * kg);
 #pragma unroll
-    for (int nb = 0; nb < XV_NB; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         const X3Col c = x3_col(a, nb);
         const rsrc_t rcp = make_rsrc(a.cp + (int64_t)c.b * a.cp_bs);
         const unsigned vo = 4u * (unsigned)(4 * kg * T + min(c.t0 + 2 * l15, T - 2));
@@ -1254,7 +807,7 @@ __device__ __forceinline__ void x3v_init(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
 
 // one pair of planes of the V tile: PH = 0: d1 + d2 | d2 - d1 (U1, U2);  PH = 1: d0 - d2 | d1 - d3 (U0, -U3).  lane (l15, cs): pair l15 of every
 // column block, 8 channels 32 w + 8 cs ..; returns the largest magnitude staged (range check of the fp16 pieces)
-template <int PH>
+template <int NB, int PH>
 __device__ __forceinline__ float x3v_stage(const X3Tile &a, unsigned char *lds, const float *dsh, int w, int lane) {
     typedef SplitF16x2 S;
     const int l15 = lane & 15, cs = lane >> 4;
@@ -1262,10 +815,10 @@ __device__ __forceinline__ float x3v_stage(const X3Tile &a, unsigned char *lds, 
     const int T = a.T;
     const unsigned T4 = 4u * (unsigned)T;
     const bool edge = l15 == 0 || l15 == 15;
-    f32x2 x12[XV_NB][8];
-    float xh[XV_NB][8];
+    f32x2 x12[NB][8];
+    float xh[NB][8];
 #pragma unroll
-    for (int nb = 0; nb < XV_NB; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         const X3Col c = x3_col(a, nb);
         const rsrc_t rx = make_rsrc(a.xin + (int64_t)c.b * XC * T);
         const int t = c.t0 + 2 * l15;  // frames t, t + 1 (T even: both inside or both outside)
@@ -1283,7 +836,7 @@ __device__ __forceinline__ float x3v_stage(const X3Tile &a, unsigned char *lds, 
     }
     float amax = 0.0f;
 #pragma unroll
-    for (int nb = 0; nb < XV_NB; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         const X3Col c = x3_col(a, nb);
         const int t = c.t0 + 2 * l15, th = l15 == 0 ? c.t0 - 1 : c.t0 + 32;
         const bool v12 = c.ok && t < T, vh = c.ok && edge && th >= 0 && th < T;
@@ -1317,15 +870,15 @@ __device__ __forceinline__ float x3v_stage(const X3Tile &a, unsigned char *lds, 
             u32x4_t u[2];
             pack8<2>(pc[j], u);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4_t *>(lds + j * XV_PLANE + q * XV_PIECE + (16 * nb + l15) * XR + ch0 * 2) = u[q];
+            for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4_t *>(lds + j * xv_plane<NB>() + q * xv_piece<NB>() + (16 * nb + l15) * XR + ch0 * 2) = u[q];
         }
     }
     return amax;
 }
 
 // 8 k-steps (one plane) of GEMM 1 into acc; the fragment ring runs through the 16 k-steps of a plane PAIR (k-steps 16 pair .. 16 pair + 15)
-template <int PFV>
-__device__ __forceinline__ void x3v_plane(f32x4 (&acc)[4][XV_NB], u32x4_t (&A)[PFV][4][2], rsrc_t img, unsigned lane16, unsigned abase, int seg,
+template <int NB, int PFV>
+__device__ __forceinline__ void x3v_plane(f32x4 (&acc)[4][NB], u32x4_t (&A)[PFV][4][2], rsrc_t img, unsigned lane16, unsigned abase, int seg,
                                           const unsigned char *bplane, unsigned boff) {
     typedef SplitF16x2 S;
     const int ks_last = 16 * (seg >> 1) + 15;
@@ -1333,11 +886,11 @@ __device__ __forceinline__ void x3v_plane(f32x4 (&acc)[4][XV_NB], u32x4_t (&A)[P
 #pragma unroll
         for (int p = 0; p < PFV; ++p) {
             const int kc = kb + p, ks = 8 * seg + kc;
-            u32x4_t Bv[XV_NB][2];
+            u32x4_t Bv[NB][2];
 #pragma unroll
-            for (int nb = 0; nb < XV_NB; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) Bv[nb][q] = *reinterpret_cast<const u32x4_t *>(bplane + q * XV_PIECE + boff + (unsigned)(nb * 16 * XR) + (unsigned)kc * 64u);
+                for (int q = 0; q < 2; ++q) Bv[nb][q] = *reinterpret_cast<const u32x4_t *>(bplane + q * xv_piece<NB>() + boff + (unsigned)(nb * 16 * XR) + (unsigned)kc * 64u);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1345,7 +898,7 @@ __device__ __forceinline__ void x3v_plane(f32x4 (&acc)[4][XV_NB], u32x4_t (&A)[P
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                    for (int nb = 0; nb < XV_NB; ++nb) acc[mb][nb] = mma16(A[p][mb][S::qa(t)], Bv[nb][S::qb(t)], acc[mb][nb]);
+                    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = mma16(A[p][mb][S::qa(t)], Bv[nb][S::qb(t)], acc[mb][nb]);
             __builtin_amdgcn_s_setprio(0);
             const int kn = min(ks + PFV, ks_last);  // tail: harmless re-load of the pair's last k-step
 #pragma unroll
@@ -1359,7 +912,8 @@ __device__ __forceinline__ void x3v_plane(f32x4 (&acc)[4][XV_NB], u32x4_t (&A)[P
 
 // (SET_X3_PROBE builds: lane 0 of block 0 adds its s_memtime ticks per phase to g_x3_phase_buf -- 0 claim + accumulator start + wait, 1 first
 // plane pair staged, 2 its GEMMs, 3 E / O + second pair staged, 4 its GEMMs, 8 residual loads + gate, 9 GEMM 2, 10 epilogue issue, 5 publish)
-__device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_NB], unsigned char *lds, uint64_t *dbg, uint64_t &tprev) {
+template <int NB>
+__device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB], unsigned char *lds, uint64_t *dbg, uint64_t &tprev) {
 #define X3V_PHASE(p)                                          \
     if (dbg) {                                                \
         const uint64_t tn = __builtin_amdgcn_s_memtime();     \
@@ -1378,22 +932,19 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
     const int T = a.T;
     const unsigned T4 = 4u * (unsigned)T;
     const unsigned lane16 = 16u * (unsigned)lane;
-    float *dsh = reinterpret_cast<float *>(lds + XV_TILE);  // [3][256] step offsets of the column blocks' utterances
+    float *dsh = reinterpret_cast<float *>(lds + xv_tile<NB>());  // [NB][256] step offsets of the column blocks' utterances
     const rsrc_t rw = make_rsrc(a.img);
     const float *sc = reinterpret_cast<const float *>(a.img + x_n1<S>() + x_n2<S>());
     const float s2 = sc[2], is2 = sc[3];
     const float is1w = reinterpret_cast<const float *>(a.img + x_nimg<S>() - 8)[1];
-    {
-        const X3Col c0 = x3_col(a, 0), c1 = x3_col(a, 1), c2 = x3_col(a, 2);
-        dsh[tid] = a.dstep[(int64_t)((tid >> 8) ? c1.b : c0.b) * a.d_bs + (int64_t)(tid & (XC - 1)) * a.d_cs];
-        if (tid < XC) dsh[2 * XC + tid] = a.dstep[(int64_t)c2.b * a.d_bs + (int64_t)tid * a.d_cs];
-    }
+    for (int idx = tid; idx < NB * XC; idx += 512)
+        dsh[idx] = a.dstep[(int64_t)x3_col(a, idx >> 8).b * a.d_bs + (int64_t)(idx & (XC - 1)) * a.d_cs];
     __syncthreads();  // dsh
     // ---- GEMM 1, first pair of planes
-    const unsigned abase = (unsigned)((x_n1<S>() + x_n2<S>() + x_nw<S>()) * 2) + (unsigned)(w * X_KSV * 4 * 2 * 1024);
+    const unsigned abase = (unsigned)((x_n1<S>() + x_n2<S>() + 8) * 2) + (unsigned)(w * X_KSV * 4 * 2 * 1024);
     const unsigned boff = (unsigned)(l15 * XR + kg * 16);
     u32x4_t A[PFV][4][2];
-    float amax = x3v_stage<0>(a, lds, dsh, w, lane);
+    float amax = x3v_stage<NB, 0>(a, lds, dsh, w, lane);
 #pragma unroll
     for (int p = 0; p < PFV; ++p)
 #pragma unroll
@@ -1402,13 +953,13 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
             for (int q = 0; q < 2; ++q) A[p][mb][q] = buf_load_u4(rw, lane16, abase + (unsigned)(((p * 4 + mb) * 2 + q) * 1024));
     __syncthreads();
     X3V_PHASE(1)
-    x3v_plane<PFV>(PQ[0], A, rw, lane16, abase, 0, lds, boff);
-    x3v_plane<PFV>(PQ[1], A, rw, lane16, abase, 1, lds + XV_PLANE, boff);
+    x3v_plane<NB, PFV>(PQ[0], A, rw, lane16, abase, 0, lds, boff);
+    x3v_plane<NB, PFV>(PQ[1], A, rw, lane16, abase, 1, lds + xv_plane<NB>(), boff);
     X3V_PHASE(2)
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < XV_NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float pp = PQ[0][mb][nb][i], qq = PQ[1][mb][nb][i];
@@ -1417,7 +968,7 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
             }
     __syncthreads();  // every wave is done reading the first pair of planes
     // ---- second pair
-    amax = fmaxf(amax, x3v_stage<1>(a, lds, dsh, w, lane));
+    amax = fmaxf(amax, x3v_stage<NB, 1>(a, lds, dsh, w, lane));
     if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int p = 0; p < PFV; ++p)
@@ -1427,24 +978,24 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
             for (int q = 0; q < 2; ++q) A[p][mb][q] = buf_load_u4(rw, lane16, abase + (unsigned)((((16 + p) * 4 + mb) * 2 + q) * 1024));
     __syncthreads();
     X3V_PHASE(3)
-    x3v_plane<PFV>(PQ[0], A, rw, lane16, abase, 2, lds, boff);
-    x3v_plane<PFV>(PQ[1], A, rw, lane16, abase, 3, lds + XV_PLANE, boff);
+    x3v_plane<NB, PFV>(PQ[0], A, rw, lane16, abase, 2, lds, boff);
+    x3v_plane<NB, PFV>(PQ[1], A, rw, lane16, abase, 3, lds + xv_plane<NB>(), boff);
     X3V_PHASE(4)
     // ---- residual rows of x for GEMM 2's accumulator start (issued here, consumed after the gate)
-    bool tv[XV_NB];
-    unsigned vo4[XV_NB];
-    int64_t ub[XV_NB];
+    bool tv[NB];
+    unsigned vo4[NB];
+    int64_t ub[NB];
 #pragma unroll
-    for (int cb = 0; cb < XV_NB; ++cb) {
+    for (int cb = 0; cb < NB; ++cb) {
         const X3Col c = x3_col(a, cb);
         const int t = c.t0 + l31;
         tv[cb] = c.ok && t < T;
         vo4[cb] = 4u * (unsigned)(4 * half * T + min(t, T - 1));
         ub[cb] = (int64_t)c.b * XC * T;
     }
-    float xres[XV_NB][16];
+    float xres[NB][16];
 #pragma unroll
-    for (int cb = 0; cb < XV_NB; ++cb) {
+    for (int cb = 0; cb < NB; ++cb) {
         const rsrc_t rx = make_rsrc(a.xin + ub[cb]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) xres[cb][r] = buf_load(rx, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
@@ -1452,7 +1003,7 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
     __syncthreads();  // every wave is done reading the V tile: the z tile overlays it (row = frame of the tile)
     // ---- gate: lane (l15, kg) holds the pair's frames 2 l15 (PQ[0]) and 2 l15 + 1 (PQ[1]) of column block nb, channels 32 w + 16 m + 4 kg ..
 #pragma unroll
-    for (int nb = 0; nb < XV_NB; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         const X3Col c = x3_col(a, nb);
         const bool tvp = c.ok && c.t0 + 2 * l15 < T;
 #pragma unroll
@@ -1471,12 +1022,12 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
                     u32x2w_t uu;
                     uu[0] = (unsigned)p[0][q] | ((unsigned)p[1][q] << 16);
                     uu[1] = (unsigned)p[2][q] | ((unsigned)p[3][q] << 16);
-                    *reinterpret_cast<u32x2w_t *>(lds + q * XV_ZPIECE + off) = uu;
+                    *reinterpret_cast<u32x2w_t *>(lds + q * xv_zpiece<NB>() + off) = uu;
                 }
             }
     }
     // ---- GEMM 2 accumulators: residual rows start at s2 (b_out + x), skip rows at s2 b_out
-    f32x16 acc[1][2][XV_NB];
+    f32x16 acc[1][2][NB];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const float *bo = a.b_out + (rb ? XC : 0) + 32 * w;
@@ -1485,13 +1036,13 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
             const float blo = bo[urow(r)], bhi = bo[urow(r) + 4];
             const float bias = half ? bhi : blo;
 #pragma unroll
-            for (int cb = 0; cb < XV_NB; ++cb) acc[0][rb][cb][r] = (rb == 0 ? bias + xres[cb][r] : bias) * s2;
+            for (int cb = 0; cb < NB; ++cb) acc[0][rb][cb][r] = (rb == 0 ? bias + xres[cb][r] : bias) * s2;
         }
     }
 #if SET_X3V_SK_EARLY
-    float sk[XV_NB][16];
+    float sk[NB][16];
 #pragma unroll
-    for (int cb = 0; cb < XV_NB; ++cb) {
+    for (int cb = 0; cb < NB; ++cb) {
         const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load_nt(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
@@ -1499,16 +1050,16 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
 #endif
     __syncthreads();
     X3V_PHASE(8)
-    gemm_x3<S, X_KS2, 1, XV_NB, SET_X3V_PF2>(acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + w * X_KS2 * 2 * 2 * 1024), (unsigned)(X_KS2 * 2 * 2 * 1024), lds,
-                                             XV_ZPIECE, [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2); });
+    gemm_x3<S, X_KS2, 1, NB, SET_X3V_PF2>(acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + w * X_KS2 * 2 * 2 * 1024), (unsigned)(X_KS2 * 2 * 2 * 1024), lds,
+                                             xv_zpiece<NB>(), [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2); });
     X3V_PHASE(9)
     // ---- epilogue
     const bool first = a.first != 0;
 #if !SET_X3V_SK_EARLY
-    float sk[XV_NB][16];
+    float sk[NB][16];
     if (!first) {
 #pragma unroll
-        for (int cb = 0; cb < XV_NB; ++cb) {
+        for (int cb = 0; cb < NB; ++cb) {
             const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load_nt(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
@@ -1516,7 +1067,7 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
     }
 #endif
 #pragma unroll
-    for (int cb = 0; cb < XV_NB; ++cb) {
+    for (int cb = 0; cb < NB; ++cb) {
         if (tv[cb]) {
             const rsrc_t rxo = make_rsrc(a.xout + ub[cb]);
 #pragma unroll
@@ -1524,7 +1075,7 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
         }
     }
 #pragma unroll
-    for (int cb = 0; cb < XV_NB; ++cb) {
+    for (int cb = 0; cb < NB; ++cb) {
         if (tv[cb]) {
             const rsrc_t rsk = make_rsrc(a.skp + ub[cb]);
 #pragma unroll
@@ -1536,11 +1087,12 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][XV_N
 }
 #undef X3V_PHASE
 
-// the persistent (layer, tile) queue of diffnet_stack_x3w_kernel on 96-frame tiles
+// the persistent (layer, tile) queue of diffnet_stack_x3_kernel (same flags, same publish protocol) on tiles of NB column blocks
+template <int NB>
 __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetStackArgs a, int ntiles, int ntasks, int fault_tile) {
     typedef SplitF16x2 S;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int *s_task = reinterpret_cast<int *>(lds + XV_TILE + XV_NB * XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
+    int *s_task = reinterpret_cast<int *>(lds + xv_tile<NB>() + NB * XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
     int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
     const int tid = threadIdx.x;
     uint64_t *dbg = (SET_X3_PROBE && blockIdx.x == 0 && tid == 0) ? g_x3_phase_buf : nullptr;
@@ -1562,9 +1114,9 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
         lt.b_out = a.b_out_all + (int64_t)l * 512;
         lt.err_flag = a.err_flag;
         lt.T = a.T; lt.dil = 1; lt.first = (l == 0);
-        lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * XV_NB;  // (x3v)
-        f32x4 PQ[2][4][XV_NB];
-        x3v_init(lt, PQ);
+        lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * NB;  // (x3v)
+        f32x4 PQ[2][4][NB];
+        x3v_init<NB>(lt, PQ);
         __builtin_amdgcn_sched_barrier(0);
         const int *f0 = done + i, *fl = done + (i > 0 ? i - 1 : i), *fr = done + (i < ntiles - 1 ? i + 1 : i);
         int peek = l, claimed = 0;
@@ -1604,7 +1156,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
             if (__builtin_amdgcn_readfirstlane(s_task[2]) == 0) break;
         }
         const int n_next = __builtin_amdgcn_readfirstlane(s_task[0]);
-        x3v_main(lt, PQ, lds, dbg, tprev);
+        x3v_main<NB>(lt, PQ, lds, dbg, tprev);
         i_done = i;
         l_done = l;
         n = n_next;
@@ -1621,26 +1173,28 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
         __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <int NB>
 int launch_x3v(const SetDiffnetStackArgs &a, int n_cu, int fault_tile, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_x3v_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diffnet_stack_x3v_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                 "set_diffnet_stack(x3v attr)");
         attr_set = true;
     }
     const int Q = a.B * ((a.T + 31) / 32);
-    const int ntiles = (Q + XV_NB - 1) / XV_NB;
+    const int ntiles = (Q + NB - 1) / NB;
     const int64_t ntasks64 = (int64_t)ntiles * a.L;
     SET_REQUIRE(ntasks64 < (1ll << 30), "set_diffnet_stack(task count)");
     SET_REQUIRE((int64_t)2 * XC * a.T * 4 < ((int64_t)1 << 31), "set_diffnet_stack(split-operand kernel: T too large)");
     SET_REQUIRE(a.dilation_cycle_length == 1 && a.T % 2 == 0, "set_diffnet_stack(x3v: dilation 1 and even T only)");
-    const size_t ldsz = (size_t)XV_TILE + XV_NB * XC * sizeof(float) + 16;
+    const size_t ldsz = (size_t)xv_tile<NB>() + NB * XC * sizeof(float) + 16;
     SET_HIP(set_zero_async(a.sync_ws, (size_t)(4 + ntiles) * sizeof(int32_t), s), "set_diffnet_stack(memset)");
     int grid = n_cu;
+    if (NB == 2 && grid > ntiles * 4 / 5) grid = ntiles * 4 / 5;  // (the 64-frame rule of the earlier forms: workers beyond 0.8 tile chains mostly wait)
     if (const char *e = getenv("SET_AMD_STACK_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
     if ((int64_t)grid > ntasks64) grid = (int)ntasks64;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(diffnet_stack_x3v_kernel, dim3(grid), dim3(512), ldsz, s, a, ntiles, (int)ntasks64, fault_tile);
+    hipLaunchKernelGGL(diffnet_stack_x3v_kernel<NB>, dim3(grid), dim3(512), ldsz, s, a, ntiles, (int)ntasks64, fault_tile);
     return set_check_launch("set_diffnet_stack");
 }
 
@@ -2027,18 +1581,23 @@ extern "C" int set_pack_diffnet_layer_x3(const float *w_dil, const float *w_out,
     return set_check_launch("set_pack_diffnet_layer_x3");
 }
 
-// does set_launch_diffnet_stack_x3 take the Winograd form (diffnet_stack_x3w_kernel) for this shape?
-// 0 = direct form, 1 = 64-frame Winograd tiles (diffnet_stack_x3w_kernel), 2 = 96-frame tiles on the 16-wide instruction (diffnet_stack_x3v_kernel)
+// does set_launch_diffnet_stack_x3 take the Winograd form (diffnet_stack_x3v_kernel) for this shape?  Returns the column blocks per tile:
+// 0 = direct form, 2 = 64-frame tiles, 3 = 96-frame tiles.  SET_AMD_X3_WINO=0 pins the direct form, =2 / =3 the tile width.
 int set_x3_winograd_selected(int x3_mode, int B, int T, int dilation_cycle_length, int n_cu) {
     if (x3_mode != 2 || dilation_cycle_length != 1 || T % 2 != 0) return 0;
     const int64_t tiles64 = (int64_t)B * ((T + 63) / 64);
     bool narrow = 5 * tiles64 < 3 * (int64_t)n_cu;
     if (const char *e = getenv("SET_AMD_X3_TILE")) narrow = atoi(e) == 32;
     if (narrow) return 0;
-    if (const char *e = getenv("SET_AMD_X3_WINO")) return atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
-    // 96-frame tiles once every CU has a tile chain of them (B = 32, T = 800: 267 chains for 256 CUs)
+    if (const char *e = getenv("SET_AMD_X3_WINO")) {
+        const int v = atoi(e);
+        if (v <= 0) return 0;
+        if (v == 2 || v == 3) return v;
+    }
+    // 96-frame tiles once every CU has a tile chain of them (B = 32, T = 800: 267 chains for 256 CUs; below that the workers wait for each
+    // other: B = 24 123 k frames/s on 96-frame tiles against 149 k on 64-frame ones, profiles/r06_x3v_nb2_ab.log)
     const int64_t tiles96 = ((int64_t)B * ((T + 31) / 32) + 2) / 3;
-    return tiles96 >= (int64_t)n_cu ? SET_X3V_DEFAULT : 1;
+    return tiles96 >= (int64_t)n_cu ? 3 : 2;
 }
 
 // called by set_diffnet_stack (csrc/diffnet.hip) once it has picked this kernel
@@ -2054,16 +1613,13 @@ int set_launch_diffnet_stack_x3(const SetDiffnetStackArgs &a, int n_cu, int faul
     // to 1.63 GHz; profiles/r03_x3_pair_probe.log -- but its 64-frame instantiation spilled registers, which confounded the
     // comparison; round 4 measured the power limit directly instead (profiles/r04_power.log, r04_mfma_ceiling.log) and removed the
     // variant from the library.  The NU template parameter of the kernel stays for tools/build_exp.sh experiments.)
-    // round 6: Winograd F(2,3) form of GEMM 1 on the 64-frame tiles (dilation 1, even T; SET_AMD_X3_WINO=0 keeps the direct form) --
-    // see diffnet_stack_x3w_kernel
-    // (its 8-byte loads of frame pairs need 8-byte aligned tensors and even strides; anything else takes the direct form)
-    // (and the utterance offset rides in their 32-bit lane offsets)
+    // round 6: Winograd F(2,3) form of GEMM 1 on 64- / 96-frame tiles (dilation 1, even T; SET_AMD_X3_WINO=0 keeps the direct form) -- see
+    // diffnet_stack_x3v_kernel (its 8-byte loads of frame pairs need 8-byte aligned tensors and even strides; anything else takes the direct form)
     const bool al8 = ((reinterpret_cast<uintptr_t>(a.condproj) | reinterpret_cast<uintptr_t>(a.xa) | reinterpret_cast<uintptr_t>(a.xb)) & 7) == 0 &&
-                     ((a.cp_bs | a.cp_ls) & 1) == 0 && ((int64_t)a.B + 1) * XC * a.T * 4 < ((int64_t)1 << 31) &&
-                     ((int64_t)a.B * a.cp_bs + (int64_t)2 * XC * a.T) * 4 < ((int64_t)1 << 31);
+                     ((a.cp_bs | a.cp_ls) & 1) == 0;
     const int wino = al8 ? set_x3_winograd_selected(a.x3_mode, a.B, a.T, a.dilation_cycle_length, n_cu) : 0;
-    if (wino == 2) return launch_x3v(a, n_cu, fault_tile, s);
-    if (wino == 1) return launch_x3w(a, n_cu, fault_tile, s);
+    if (wino == 3) return launch_x3v<3>(a, n_cu, fault_tile, s);
+    if (wino == 2) return launch_x3v<2>(a, n_cu, fault_tile, s);
     if (a.x3_mode == 2)
         return narrow ? launch_x3<SplitF16x2, 1, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitF16x2, 1, 2>(a, n_cu, fault_tile, s);
     return narrow ? launch_x3<SplitBf16x3, 1, 1>(a, n_cu, fault_tile, s) : launch_x3<SplitBf16x3, 1, 2>(a, n_cu, fault_tile, s);

@@ -794,9 +794,9 @@ def stack_variant(B, T, dilation_cycle_length, have_wino=True, have_split=True, 
 
 
 def stack_x3_winograd(B, T, dilation_cycle_length, have_wino=True, have_split=True, x3_mode=None):
-    """Non-zero when variant 5 (two-piece fp16 split-operand kernel) runs GEMM 1 in its Winograd F(2,3) form for this shape (round 6):
-    1 = 64-frame tiles (diffnet_stack_x3w_kernel), 2 = 96-frame tiles on the 16-wide matrix instruction (diffnet_stack_x3v_kernel: shapes
-    with a tile chain for every CU); 0 = the direct form."""
+    """Non-zero when variant 5 (two-piece fp16 split-operand kernel) runs GEMM 1 in its Winograd F(2,3) form for this shape (round 6,
+    diffnet_stack_x3v_kernel): the number of 32-frame column blocks per tile -- 3 = 96-frame tiles (shapes with a tile chain for every CU),
+    2 = 64-frame tiles; 0 = the direct form."""
     m = split_operand_mode() if x3_mode is None else int(x3_mode)
     bits = int(bool(have_wino)) | (2 if have_split else 0) | (4 if m == 3 else 0) | (8 if m == 2 else 0)
     return int(_lib.lib().set_diffnet_stack_x3_winograd(int(B), int(T), int(dilation_cycle_length), bits))

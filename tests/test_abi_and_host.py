@@ -334,10 +334,10 @@ def test_stack_kernel_selection_rules(built_lib, monkeypatch):
         monkeypatch.delenv(k, raising=False)
     assert ops.stack_x3_winograd(32, 800, 1) and ops.stack_x3_winograd(64, 800, 1) and ops.stack_x3_winograd(32, 802, 1)
     # ... on 96-frame tiles (the 16-wide instruction) once every CU has a chain of them (256 CUs: 267 chains at B = 32, T = 800), else 64
-    assert ops.stack_x3_winograd(32, 800, 1) == 2 and ops.stack_x3_winograd(64, 800, 1) == 2
-    assert ops.stack_x3_winograd(30, 800, 1) == 1 and ops.stack_x3_winograd(20, 800, 1) == 1
-    monkeypatch.setenv("SET_AMD_X3_WINO", "1")
-    assert ops.stack_x3_winograd(32, 800, 1) == 1
+    assert ops.stack_x3_winograd(32, 800, 1) == 3 and ops.stack_x3_winograd(64, 800, 1) == 3
+    assert ops.stack_x3_winograd(30, 800, 1) == 2 and ops.stack_x3_winograd(20, 800, 1) == 2
+    monkeypatch.setenv("SET_AMD_X3_WINO", "2")
+    assert ops.stack_x3_winograd(32, 800, 1) == 2
     monkeypatch.delenv("SET_AMD_X3_WINO")
     assert not ops.stack_x3_winograd(32, 801, 1)           # odd T: the direct form
     assert not ops.stack_x3_winograd(32, 800, 2)           # dilation cycles: the direct form

@@ -1297,10 +1297,10 @@ def test_full800_single_utterance_matches_reference(dev, row):
     assert d < 1e-4
 
 
-@pytest.mark.parametrize("form", ["1", "2"])
-def test_x3w_winograd_split_operand_stack(dev, monkeypatch, form):
-    """Round 6: the Winograd F(2,3) form of GEMM 1 on the two-piece fp16 operands (SET_AMD_X3_WINO=1: diffnet_stack_x3w_kernel, 64-frame tiles;
-    =2: diffnet_stack_x3v_kernel, 96-frame tiles on the 16-wide matrix instruction; 3/4 of the layer's MFMAs) against the direct split-operand
+@pytest.mark.parametrize("form", ["2", "3"])
+def test_x3v_winograd_split_operand_stack(dev, monkeypatch, form):
+    """Round 6: the Winograd F(2,3) form of GEMM 1 on the two-piece fp16 operands (diffnet_stack_x3v_kernel; SET_AMD_X3_WINO=2 / =3: 64- / 96-frame
+    tiles = 2 / 3 column blocks, GEMM 1 on the 16-wide matrix instruction; 3/4 of the layer's MFMAs) against the direct split-operand
     kernel and the fp32-pipe kernel on the same weights -- equal to fp32 rounding; run to run and for 7 / 512 workers bit-identical; against an
     fp64 evaluation of the same layers its error stays within 2 x the fp32 kernel's.
     Shapes: the metric's batch, tiles whose column blocks lie in different utterances or end in a partial block (every column block of a tile
@@ -1352,9 +1352,9 @@ def test_x3w_winograd_split_operand_stack(dev, monkeypatch, form):
             assert ew < 2.0 * e32 + 1e-7, (B, T, ew, e32)
 
 
-@pytest.mark.parametrize("form", ["1", "2"])
+@pytest.mark.parametrize("form", ["2", "3"])
 @pytest.mark.parametrize("case", ["infer_full800", "infer_tiny", "infer_pad", "infer_ragged", "infer_drift100"])
-def test_full_inference_matches_reference_with_x3w_forced(dev, monkeypatch, case, form):
+def test_full_inference_matches_reference_with_x3v_forced(dev, monkeypatch, case, form):
     """The parity bar (|dmel| < 1e-4 against the reference's own output; the T = 800 x 100-step and the 100-step drift cases included) with
     every DiffNet stack pass on the split-operand kernel's Winograd form (odd T: the launch falls back to the direct form)."""
     monkeypatch.setenv("SET_AMD_X3", "2")

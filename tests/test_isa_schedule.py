@@ -37,7 +37,7 @@ def compiled():
 
 
 HOT = {  # file -> kernel-name fragments whose MFMAs must not sit behind a drained ring
-    "diffnet_x3.hip": ("diffnet_stack_x3_kernel", "diffnet_stack_x3w_kernel", "diffnet_stack_split_x2_kernel"),
+    "diffnet_x3.hip": ("diffnet_stack_x3_kernel", "diffnet_stack_x3v_kernel", "diffnet_stack_split_x2_kernel"),
     "diffnet.hip": ("diffnet_boundary_x2_kernel",),
     "diffnet_bf16.hip": ("diffnet_layers_t128_bf16_kernel", "diffnet_layers_reg_bf16_kernel", "diffnet_layer_fwd_bf16_kernel", "diffnet_layer_bwd_bf16_kernel"),
 }
@@ -66,8 +66,6 @@ ALLOWED_SPILLS = {  # kernels that ship with scratch; everyth
     "diffnet_layers_t128_bf16_kernel": 16,   # 128-frame layer groups: 10 registers, outside the GEMM loops
     "diffnet_layer_kernel": 4,               # fp32 one-launch-per-layer fallback
     "diffnet_stack_kernelILi2ELi4ELi2E": 40, # direct fp32 stack for dilation cycles the Winograd kernel does not cover
-    "diffnet_stack_x3w_kernel": 4,           # round 6, Winograd form of the split-operand kernel + its direct-form fallback in one task loop: 3 loop
-                                             # invariants, stored once, reloaded once per task outside the GEMM loops
 }
 
 

@@ -14,6 +14,8 @@ from set_amd.synthetic import synthetic_inputs  # noqa: E402
 torch.set_grad_enabled(False)
 dev = torch.device("cuda:0")
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 6.0
+if os.environ.get("AB_B"):  # another batch size than the metric's (tile-form comparisons at part-filled shapes)
+    bench.B_PER_GPU = int(os.environ["AB_B"])
 model = bench.build_model(dev, bench.DIFF_STEPS)
 inp = {k: v.to(dev) for k, v in synthetic_inputs(bench.B_PER_GPU, bench.T, bench.T_TXT, seed=1234).items()}
 
@@ -24,14 +26,14 @@ def step(seed, spans=False):
 
 
 files = hwmon_files()
-variants = [("per_step_launches", {"SET_AMD_X3_WINO": "0"}), ("x3_winograd_default", {})]
+variants = [("direct_form", {"SET_AMD_X3_WINO": "0"}), ("x3_winograd_default", {})]
 for a in sys.argv[2:]:
     if a.startswith("env:"):  # env:NAME:K=V,K=V -- any other variant of the same loop
         _, name, kv = a.split(":", 2)
         variants.append((name, dict(x.split("=", 1) for x in kv.split(","))))
     elif a == "only-extra":
         variants = variants[:1] + variants[2:]
-# (round-6 history: SET_AMD_LOOP_LAUNCH selected the whole-loop kernel of commit 9e25393; per_step_launches now = the direct split-operand form)
+# (round-6 history: SET_AMD_LOOP_LAUNCH selected the whole-loop kernel of commit 9e25393; the first variant's name was per_step_launches then)
 mels = {}
 for name, env in variants:
     for k in ("SET_AMD_LOOP_LAUNCH", "SET_AMD_STACK_GRID", "SET_AMD_X3_WINO"):
@@ -58,6 +60,6 @@ for name, env in variants:
            "frames_per_s_wall": bench.B_PER_GPU * bench.T * n / wall, "power_w_mean": sum(pw) / max(1, len(pw)), "power_w_max": max(pw or [0]),
            "sclk_mhz_mean": sum(fq) / max(1, len(fq)), "span_ms_mean": sum(ret["layer_span_ms"]) / len(ret["layer_span_ms"])}
     print(json.dumps(out), flush=True)
-base = mels["per_step_launches"]
+base = mels["direct_form"]
 for name, m in mels.items():
     print("%-28s bit-identical to the per-step launches: %s  (max |d| %.3e)" % (name, bool(torch.equal(m, base)), float((m - base).abs().max())))

@@ -24,10 +24,8 @@ def collect(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         n = r["Kernel_Name"]
-        if "diffnet_stack_x3v_kernel" in n:  # round 6: Winograd form on 96-frame tiles, GEMM 1 on the 16-wide instruction
-            acc["diffnet_stack_x3v_kernel"][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        elif "diffnet_stack_x3w_kernel" in n:  # round 6: the Winograd form of the two-piece fp16 kernel, 64-frame tiles
-            acc["diffnet_stack_x3w_kernel"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "diffnet_stack_x3v_kernel" in n:  # round 6: Winograd form on 64- / 96-frame tiles (<2> / <3>), GEMM 1 on the 16-wide instruction
+            acc["diffnet_stack_x3v_kernel<%s>" % ("3" if "<3>" in n else "2")][r["Counter_Name"]].append(float(r["Counter_Value"]))
         elif "diffnet_stack_x3_kernel" in n and "pack_" not in n:
             key = "diffnet_stack_x3_kernel<%s>" % ("SplitF16x2" if "SplitF16x2" in n else "SplitBf16x3")
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
