@@ -171,7 +171,7 @@ class GaussianDiffusion(nn.Module):
             eps = None
         ids = torch.arange(steps, device=dev)
         coef4 = self.posterior_coef(ids)
-        dtab = dn.step_table(ids.to(torch.float32))  # [L*C, steps]
+        dtab = dn.step_table_all(steps, dev)  # [L*C, steps]; cached while the weights it depends on are unchanged
         # opt-in bf16-operand loop (ops.set_compute_dtype("bf16")): NOT the parity path -- see DESIGN.md section 3.5
         bf16 = None
         if ops.compute_dtype() == "bf16" and dn.use_fused() and dn.encoder_hidden == 192 and T >= 32:

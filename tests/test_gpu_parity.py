@@ -1297,6 +1297,40 @@ def test_full800_single_utterance_matches_reference(dev, row):
     assert d < 1e-4
 
 
+def test_step_table_is_kept_across_loops_and_follows_the_weights(dev):
+    """Round 6: the reverse loop keeps its table of step offsets (DiffNet.step_table_all: a function of the step MLP and the layers' diffusion
+    projections only) across calls.  A second loop reuses it (same object, same mel); an in-place change of ONE of the 44 tensors (version
+    counter), a load_state_dict and an optimizer-style epoch bump each rebuild it, and the loop then equals a freshly built model's."""
+    from set_amd import ops
+    g = load_golden("infer_tiny")
+    m = g["meta"]
+    model, W = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"], **m["overrides"])
+    inp, noises = _case_inputs(g, dev)
+    args = (inp["txt_tokens"], inp["time_mel_masks"], inp["mel2ph"], inp["spk_embed"], inp["ref_mels"], inp["f0"], inp["uv"])
+    a = model(*args, infer=True, noises=noises, **m["flags"])["mel_out"].clone()
+    dn = model.denoise_fn
+    t0 = dn._dtab
+    b = model(*args, infer=True, noises=noises, **m["flags"])["mel_out"].clone()
+    assert dn._dtab is t0 and torch.equal(a, b)
+    assert _maxdiff(a, g["mel_out"]) < 1e-4
+    with torch.no_grad():
+        dn.residual_layers[3].diffusion_projection.bias.add_(0.25)   # in place: version counter
+    c = model(*args, infer=True, noises=noises, **m["flags"])["mel_out"].clone()
+    assert dn._dtab is not t0 and not torch.equal(a, c)
+    fresh, _ = _build_model(dev, "spec_denoiser", m["wseed"], m["steps"], **m["overrides"])
+    with torch.no_grad():
+        fresh.denoise_fn.residual_layers[3].diffusion_projection.bias.add_(0.25)
+    assert torch.equal(c, fresh(*args, infer=True, noises=noises, **m["flags"])["mel_out"])
+    t1 = dn._dtab
+    model.load_state_dict({k: v.to(dev) for k, v in W.items()}, strict=False)   # back to the golden's weights (copy_: version counters)
+    d = model(*args, infer=True, noises=noises, **m["flags"])["mel_out"].clone()
+    assert dn._dtab is not t1 and torch.equal(d, a)
+    t2 = dn._dtab
+    ops.bump_weights_epoch()                                                     # what FlatAdamW.step does after its in-place kernel
+    e = model(*args, infer=True, noises=noises, **m["flags"])["mel_out"]
+    assert dn._dtab is not t2 and torch.equal(e, a)
+
+
 @pytest.mark.parametrize("form", ["2", "3"])
 def test_x3v_winograd_split_operand_stack(dev, monkeypatch, form):
     """Round 6: the Winograd F(2,3) form of GEMM 1 on the two-piece fp16 operands (diffnet_stack_x3v_kernel; SET_AMD_X3_WINO=2 / =3: 64- / 96-frame
