@@ -195,6 +195,19 @@ class DiffNet(nn.Module):
         B, H, T = cond.shape
         C, L = self.C, self.n_layers
         out = torch.empty(B, L * 2 * C, T, dtype=torch.float32, device=cond.device)
+        if not torch.is_grad_enabled():
+            # one launch on the layers' weights stacked along the output channels (bit-identical to the per-layer launches: same kernel, same
+            # k order per output; 1.17 against 1.4 - 1.55 ms at B = 32, T = 800, profiles/r06_condproj_probe.log); the stacked copy follows the
+            # layers' tensors by storage, version counter and the optimizer's weights epoch
+            ps = [t for layer in self.residual_layers for t in (layer.conditioner_projection.weight, layer.conditioner_projection.bias)]
+            key = (str(cond.device), ops.weights_epoch()) + tuple((p.data_ptr(), p._version) for p in ps)
+            if getattr(self, "_wc_all_key", None) != key:
+                self._wc_all = torch.cat([p.detach() for p in ps[0::2]], 0).contiguous()
+                self._bc_all = torch.cat([p.detach() for p in ps[1::2]], 0).contiguous()
+                self._wc_all_cw = ops.ConvWeight((self, "_wc_all"), L * 2 * C, H, 1)
+                self._wc_all_key = key
+            ops.conv1d(cond, self._wc_all_cw, self._bc_all, out=out)
+            return out
         for l, layer in enumerate(self.residual_layers):
             ops.conv1d(cond, layer._w_cond, layer.conditioner_projection.bias,
                        out=out[:, l * 2 * C:(l + 1) * 2 * C, :])

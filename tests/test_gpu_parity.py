@@ -1329,6 +1329,20 @@ def test_step_table_is_kept_across_loops_and_follows_the_weights(dev):
     ops.bump_weights_epoch()                                                     # what FlatAdamW.step does after its in-place kernel
     e = model(*args, infer=True, noises=noises, **m["flags"])["mel_out"]
     assert dn._dtab is not t2 and torch.equal(e, a)
+    # the stacked conditioner projection of the loop (DiffNet.cond_projections: one launch for all layers) follows its layers the same way and
+    # equals the per-layer launches bit for bit
+    cond = torch.randn(2, dn.encoder_hidden, 64, device=dev)
+    one = dn.cond_projections(cond).clone()
+    with torch.enable_grad():
+        per_layer = dn.cond_projections(cond)
+    assert torch.equal(one, per_layer)
+    w_all = dn._wc_all
+    with torch.no_grad():
+        dn.residual_layers[7].conditioner_projection.weight.mul_(1.5)
+    two = dn.cond_projections(cond)
+    with torch.enable_grad():
+        per_layer = dn.cond_projections(cond)
+    assert dn._wc_all is not w_all and torch.equal(two, per_layer) and not torch.equal(one, two)
 
 
 @pytest.mark.parametrize("form", ["2", "3"])
