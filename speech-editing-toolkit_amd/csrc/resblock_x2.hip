@@ -415,7 +415,10 @@ extern "C" int set_resblock_pair_x2(const SetResblockPairArgs *args, void *strea
         return set_fail(SET_E_UNSUPPORTED, "set_resblock_pair_x2", "one batch slice of x / out exceeds 2 GiB");
     hipStream_t s = (hipStream_t)stream;
     if (a.C > 128) return launch_pair<4, 1, 2, 2>(a, s);  // 256 rows x  64 frames
-    if (a.C > 64) return launch_pair<2, 2, 2, 2>(a, s);   // 128 rows x 128 frames
-    if (a.C > 32) return launch_pair<1, 4, 2, 2>(a, s);   //  64 rows x 256 frames
+    // round 6: 128-frame WAVE tiles for 33 .. 128 channels -- every weight fragment meets four column blocks of one wave instead of two column
+    // blocks of two waves (half the fragment loads per MFMA; same k order per output: bit-identical).  V1, B = 64: 103.1 -> 101.5 ms per forward,
+    // the C = 128 / C = 64 stages +2 .. 5 % (profiles/r06_rp_wide_ab.log); before: <2, 2, 2, 2> and <1, 4, 2, 2>.
+    if (a.C > 64) return launch_pair<4, 1, 1, 4>(a, s);   // 128 rows x 128 frames, wave tile 32 x 128
+    if (a.C > 32) return launch_pair<2, 2, 1, 4>(a, s);   //  64 rows x 256 frames, wave tile 32 x 128
     return launch_pair<1, 4, 1, 2>(a, s);                 //  32 rows x 256 frames
 }

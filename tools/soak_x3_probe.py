@@ -11,6 +11,8 @@ dev = torch.device("cuda:0")
 N = int(os.environ.get("SOAK_N", 300))
 # B, T, L, dcl, x3 mode, env
 SHAPES = ((32, 800, 20, 1, 2, dict(SET_AMD_X3="2", SET_AMD_SPLIT="0")), (24, 797, 20, 1, 2, dict(SET_AMD_X3="2", SET_AMD_SPLIT="0")),
+          # round 6: the Winograd form on 64-frame tiles (no 96-frame chain per CU) and on 96-frame tiles whose last block is partial
+          (24, 800, 20, 1, 2, dict(SET_AMD_X3="2", SET_AMD_SPLIT="0")), (33, 802, 20, 1, 2, dict(SET_AMD_X3="2", SET_AMD_SPLIT="0")),
           (32, 800, 8, 4, 3, dict(SET_AMD_X3="2", SET_AMD_SPLIT="0")), (8, 800, 20, 1, 2, dict(SET_AMD_X3="2", SET_AMD_SPLIT="0")),
           (7, 1548, 20, 1, 2, dict(SET_AMD_X3="2", SET_AMD_SPLIT="0", SET_AMD_X3_TILE="32")),
           (1, 800, 20, 1, 2, dict(SET_AMD_SPLIT="2")), (2, 800, 20, 1, 2, dict(SET_AMD_SPLIT="2")),
