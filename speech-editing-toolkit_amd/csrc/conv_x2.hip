@@ -433,8 +433,9 @@ extern "C" int set_conv_transpose1d_x2(const float *in, const void *wp, const fl
         return set_fail(SET_E_UNSUPPORTED, "set_conv_transpose1d_x2", "one batch slice of in / out exceeds 2 GiB");
     const int lo = -(J - 1), halo = J - 1;
     hipStream_t s = (hipStream_t)stream;
-    if (a.Cout > 64) return launch_conv_x2<2, 2, 2, 2, true>(a, lo, halo, s, u, P);
-    return launch_conv_x2<1, 4, 2, 2, true>(a, lo, halo, s, u, P);
+    // (round 6: 128-frame wave tiles, see set_conv1d_x2_ below; before: <2, 2, 2, 2> / <1, 4, 2, 2>)
+    if (a.Cout > 64) return launch_conv_x2<4, 1, 1, 4, true>(a, lo, halo, s, u, P);
+    return launch_conv_x2<2, 2, 1, 4, true>(a, lo, halo, s, u, P);
 }
 
 /* *flag = the sticky "an activation left the fp16 range of the splitting" word (synchronises the device); reset != 0 clears it */
@@ -465,7 +466,10 @@ int set_conv1d_x2_dispatch(const SetConv1dArgs &a, hipStream_t s) {
         return set_fail(SET_E_UNSUPPORTED, "set_conv1d(f16x2)", "one batch slice of in / out / res exceeds 2 GiB");
     // wave tile 64 rows x 64 frames (4 accumulators): with 8 (2 x 4 blocks) the staging registers of the next chunk no
     // longer fit beside them
-    if (a.Cout > 64) return launch_conv_x2<2, 2, 2, 2>(a, lo, halo, s);   // 128 rows x 128 frames
-    if (a.Cout > 32) return launch_conv_x2<1, 4, 2, 2>(a, lo, halo, s);   //  64 rows x 256 frames
+    // round 6: 128-frame WAVE tiles -- every weight fragment meets four column blocks of one wave instead of two column blocks of two waves
+    // (half the fragment loads per MFMA; same k order per output: bit-identical).  With the same change in the ResBlock-pair kernel HiFi-GAN V1 at
+    // B = 64 went 103.1 -> 101.5 -> 100.8 ms per forward on one box (profiles/r06_rp_wide_ab.log, r06_cx_wide_ab.log); before: <2, 2, 2, 2> / <1, 4, 2, 2>
+    if (a.Cout > 64) return launch_conv_x2<4, 1, 1, 4>(a, lo, halo, s);   // 128 rows x 128 frames, wave tile 32 x 128
+    if (a.Cout > 32) return launch_conv_x2<2, 2, 1, 4>(a, lo, halo, s);   //  64 rows x 256 frames, wave tile 32 x 128
     return launch_conv_x2<1, 4, 1, 2>(a, lo, halo, s);                    //  32 rows x 256 frames
 }
