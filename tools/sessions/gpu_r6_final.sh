@@ -45,3 +45,5 @@ rm -rf $OUT/trace_infer
 T0=$(date +%s); timeout 1800 python -m pytest tests -q -m gpu 2>&1 | tail -6 > $OUT/pytest_gpu.log; echo "wall $(( $(date +%s) - T0 )) s" >> $OUT/pytest_gpu.log; cat $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 > $OUT/smoke.log; cat $OUT/smoke.log
 bash tools/sessions/gpu_r6_bench.sh
+# soak of the persistent kernels (every launch compared bit for bit with the first; incl. the Winograd form on 64- / 96-frame tiles)
+SOAK_N=200 timeout 900 python tools/soak_x3_probe.py 2>&1 | grep -v amdgpu.ids | tee $OUT/soak.log | cut -c1-200
