@@ -1401,6 +1401,32 @@ def test_x3v_winograd_split_operand_stack(dev, monkeypatch, form):
 
 
 @pytest.mark.parametrize("form", ["2", "3"])
+def test_x3v_shape_sweep_against_the_direct_form(dev, monkeypatch, form):
+    """The Winograd kernel on shapes around its tile geometry: T below one column block, at / one pair past the 32-, 64- and 96-frame
+    boundaries, the reference's max_frames (1548), batches whose column-block count is not a multiple of the tile's 2 / 3 blocks -- against
+    the direct split-operand kernel on the same images (fp32 rounding apart), NaN-filled outputs so that an unwritten element shows."""
+    from set_amd import ops
+    monkeypatch.setenv("SET_AMD_SPLIT", "0")
+    monkeypatch.setenv("SET_AMD_X3_TILE", "64")
+    monkeypatch.setenv("SET_AMD_X3", "2")
+    L = 3
+    for (B, T) in ((1, 30), (1, 32), (2, 34), (3, 62), (1, 64), (2, 94), (1, 96), (3, 98), (2, 130), (5, 190), (1, 1548), (7, 258), (4, 4)):
+        x0, cp, dtab, packs, wds, wos, bd, bo = _random_stack(dev, B, T, L, 31 * B + T, 2)
+        outs = {}
+        for wino in ("0", form):
+            monkeypatch.setenv("SET_AMD_X3_WINO", wino)
+            xa, xb, skip = x0.clone(), torch.full_like(x0, float("nan")), torch.full_like(x0, float("nan"))
+            ws = ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4, 0, 3, 256 * 3, packs, 1)
+            torch.cuda.synchronize()
+            assert int(ws[1]) == 0, "dependency wait timed out"
+            outs[wino] = ((xb if L % 2 else xa).clone(), skip.clone())
+        (xd, sd), (xw, sw) = outs["0"], outs[form]
+        assert bool(torch.isfinite(xw).all()) and bool(torch.isfinite(sw).all()), (B, T)
+        assert _maxdiff(xw, xd) < 1e-5 * max(1.0, float(xd.abs().max())), (B, T, _maxdiff(xw, xd))
+        assert _maxdiff(sw, sd) < 1e-5 * max(1.0, float(sd.abs().max())), (B, T, _maxdiff(sw, sd))
+
+
+@pytest.mark.parametrize("form", ["2", "3"])
 @pytest.mark.parametrize("case", ["infer_full800", "infer_tiny", "infer_pad", "infer_ragged", "infer_drift100"])
 def test_full_inference_matches_reference_with_x3v_forced(dev, monkeypatch, case, form):
     """The parity bar (|dmel| < 1e-4 against the reference's own output; the T = 800 x 100-step and the 100-step drift cases included) with
