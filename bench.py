@@ -510,6 +510,14 @@ def run_infer(args, rank, world, dev):
                      "achieved_wall_lower_bound": executed_ratio * ach_wall,
                      "frac_wall_lower_bound": executed_ratio * ach_wall / pipe_peak,
                      "hbm_algorithmic_GBps": ach_gbs, "hbm_frac": ach_gbs / PEAK_HBM_GBS,
+                     # the same launch priced with the bytes the PMC passes counted (L2 misses: HBM + MALL), for what the memory system actually moves
+                     "hbm_measured_GBps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
+                     # what the bare matrix instructions of this kernel's mix sustain at the package power cap on the same chip (registers only, no
+                     # operand streams; tools/hw/mfma_ceiling_w.hip, profiles/r06_ceiling_w.log: 16-wide 2,140 / 32-wide 1,875 TFLOP/s): GEMM 1 is 2/3
+                     # of the executed FLOPs (16-wide), GEMM 2 1/3 (32-wide) in the Winograd kernel
+                     "power_capped_mfma_ceiling_TFLOPs": (1.0 / (2.0 / 3.0 / 2140.0 + 1.0 / 3.0 / 1875.0)) if x3w else (1875.0 if variant == 5 else None),
+                     "frac_of_power_capped_mfma_ceiling": (executed_ratio * ach_tflops / (1.0 / (2.0 / 3.0 / 2140.0 + 1.0 / 3.0 / 1875.0))) if x3w else
+                                                          (executed_ratio * ach_tflops / 1875.0 if variant == 5 else None),
                      "traffic_note": traffic_note,
                      "traffic_over_algorithmic_bytes": traffic / bytes_per_launch if traffic else None,
                      "pmc_mfma_busy_frac_of_simd_cycles": pmc["mfma_busy_frac_of_simd_cycles"] if pmc else None,
