@@ -9,7 +9,7 @@ from power_probe import Sampler, hwmon_files  # noqa: E402
 secs = sys.argv[1] if len(sys.argv) > 1 else "6"
 exe = os.path.join(ROOT, "build", "exp", "mfma_ceiling_w")
 files = hwmon_files()
-for mode in ("0", "1", "2", "3", "4", "2", "3"):
+for mode in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("0", "1", "2", "3", "4", "2", "3")):
     smp = Sampler(files)
     smp.start()
     r = subprocess.run([exe, secs, mode], capture_output=True, text=True, timeout=120)

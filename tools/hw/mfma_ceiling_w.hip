@@ -6,6 +6,7 @@
 //   mode 2  shipped tile: per 16-k step 4 x 1 KiB weight fragments from an L2-resident image + 2 ds_read_b128 -> 6 MFMAs 32x32x16 (wave tile 64 rows x 32 pairs)
 //   mode 3  96-frame tile: per 32-k step 8 x 1 KiB weight fragments + 6 ds_read_b128 -> 36 MFMAs 16x16x32 (wave tile 64 rows x 48 pairs)
 //   mode 4  128-frame tile: per 16-k step 4 x 1 KiB weight fragments + 4 ds_read_b128 -> 12 MFMAs 32x32x16 (wave tile 64 rows x 64 pairs)
+//   modes 5 / 6  HiFi-GAN conv loop (4-wave blocks, two per CU, wave tile 32 rows x 128 frames) on the 32-wide / the 16-wide instruction
 // prints executed TFLOP/s; socket power / clock are sampled by the caller (tools/power_probe.py).
 //   hipcc --offload-arch=gfx950 -O3 -o build/exp/mfma_ceiling_w tools/hw/mfma_ceiling_w.hip
 #include <hip/hip_runtime.h>
@@ -132,6 +133,127 @@ __global__ void __launch_bounds__(512, 1) ceiling_kernel(const u32x4 *img, float
     out[(size_t)blockIdx.x * 512 + tid] = s;
 }
 
+// HiFi-GAN conv / ResBlock-pair loop models (wave tile 32 rows x 128 frames, two-piece operands): mode 5 = shipped, per k-step of 16 channels
+// 2 weight fragments + 8 ds_read_b128 -> 12 MFMAs 32x32x16; mode 6 = the same tile on 16x16x32: per k-step of 32 channels 4 + 16 -> 48 MFMAs
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) conv_ceiling_kernel(const u32x4 *img, float *out, int iters, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < 256 * 96 / 4; i += 256) {
+        unsigned h = (unsigned)(i * 2654435761u + blockIdx.x * 40503u);
+        reinterpret_cast<unsigned *>(lds)[i] = (h & 0x83ff83ffu) | 0x38003800u;
+    }
+    __syncthreads();
+    const u32x4 *ap = img + lane;
+    int blk = w;
+    float s = 0.0f;
+    if (MODE == 5) {
+        f32x16 acc[4];
+        for (int n = 0; n < 4; ++n)
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+        u32x4 A[2][2], B[4][2];
+        for (int u = 0; u < 2; ++u)
+            for (int q = 0; q < 2; ++q) A[u][q] = rnd4((unsigned)((lane + 64 * (q + 2 * u) + 7) * 2246822519u));
+        const unsigned boff = (unsigned)((lane & 31) * 80 + (lane >> 5) * 16);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) B[n][q] = *reinterpret_cast<const u32x4 *>(lds + boff + (n * 32 + (u & 3)) * 80 + q * 128 * 80 + 32 * (u & 1));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[u & 1][p == 0]), __builtin_bit_cast(f16x8, B[n][p == 1]), acc[n], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    A[u & 1][q] = ap[(size_t)blk * 64];
+                    blk += 4;
+                    if (blk >= nblk) blk -= nblk;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if ((it & 63) == 63)
+                for (int n = 0; n < 4; ++n)
+                    for (int r = 0; r < 16; ++r) acc[n][r] *= 1e-3f;
+        }
+        for (int n = 0; n < 4; ++n)
+            for (int r = 0; r < 16; ++r) s += acc[n][r];
+    } else {
+        f32x4 acc[2][8];
+        for (int m = 0; m < 2; ++m)
+            for (int n = 0; n < 8; ++n)
+                for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.0f;
+        u32x4 A[2][2][2], B[8][2];
+        for (int u = 0; u < 2; ++u)
+            for (int m = 0; m < 2; ++m)
+                for (int q = 0; q < 2; ++q) A[u][m][q] = rnd4((unsigned)((lane + 64 * (q + 2 * m + 4 * u) + 7) * 2246822519u));
+        const unsigned boff = (unsigned)((lane & 15) * 96 + (lane >> 4) * 16);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) B[n][q] = *reinterpret_cast<const u32x4 *>(lds + boff + (n * 16 + u) * 96 + q * 128 * 96);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 8; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[u & 1][m][p == 0]), __builtin_bit_cast(f16x8, B[n][p == 1]), acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        A[u & 1][m][q] = ap[(size_t)blk * 64];
+                        blk += 4;
+                        if (blk >= nblk) blk -= nblk;
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if ((it & 63) == 63)
+                for (int m = 0; m < 2; ++m)
+                    for (int n = 0; n < 8; ++n)
+                        for (int r = 0; r < 4; ++r) acc[m][n][r] *= 1e-3f;
+        }
+        for (int m = 0; m < 2; ++m)
+            for (int n = 0; n < 8; ++n)
+                for (int r = 0; r < 4; ++r) s += acc[m][n][r];
+    }
+    out[(size_t)blockIdx.x * 256 + tid] = s;
+}
+
+template <int MODE>
+int run_conv(const u32x4 *img, float *out, int nblk, double seconds) {
+    // executed flops per iteration and wave: mode 5: 8 x 12 x 32768; mode 6: 4 x 48 x 16384 (the same)
+    const double flop_it = 8 * 12 * 32768.0;
+    const int iters = 1000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(conv_ceiling_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 96);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(conv_ceiling_kernel<MODE>, dim3(512), dim3(256), 256 * 96, 0, img, out, iters, nblk);
+    hipDeviceSynchronize();
+    const int n = (int)(seconds / 3.2e-3) + 2;
+    for (int i = 0; i < n / 2; ++i) hipLaunchKernelGGL(conv_ceiling_kernel<MODE>, dim3(512), dim3(256), 256 * 96, 0, img, out, iters, nblk);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < n / 2; ++i) hipLaunchKernelGGL(conv_ceiling_kernel<MODE>, dim3(512), dim3(256), 256 * 96, 0, img, out, iters, nblk);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)(n / 2) * 512 * 4 * (double)iters * flop_it;
+    printf("mode %d: %.1f TFLOP/s executed (%.3f ms per launch, %d launches); conv loop model, wave tile 32 rows x 128 frames, %s\n", MODE,
+           flop / (ms * 1e-3) / 1e12, ms / (n / 2), n / 2, MODE == 5 ? "v_mfma_f32_32x32x16_f16" : "v_mfma_f32_16x16x32_f16");
+    fflush(stdout);
+    return 0;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 template <int MODE>
@@ -176,5 +298,7 @@ int main(int argc, char **argv) {
     if ((only < 0 || only == 2) && run<2>(img, out, nblk, seconds)) return 1;
     if ((only < 0 || only == 3) && run<3>(img, out, nblk, seconds)) return 1;
     if ((only < 0 || only == 4) && run<4>(img, out, nblk, seconds)) return 1;
+    if ((only < 0 || only == 5) && run_conv<5>(img, out, nblk, seconds)) return 1;
+    if ((only < 0 || only == 6) && run_conv<6>(img, out, nblk, seconds)) return 1;
     return 0;
 }
