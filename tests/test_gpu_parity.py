@@ -1400,6 +1400,71 @@ def test_x3v_winograd_split_operand_stack(dev, monkeypatch, form):
             assert ew < 2.0 * e32 + 1e-7, (B, T, ew, e32)
 
 
+@pytest.mark.parametrize("form", ["0", "2", "3"])
+def test_split_operand_stack_on_heavy_tailed_weights_and_activations(dev, monkeypatch, form):
+    """Every fixture of this suite draws Gaussian weights -- the benign case for the two-piece fp16 splitting (real checkpoints are external
+    downloads).  Here the layers get what trained conv stacks show: heavy-tailed weights (Student-t, 3 degrees of freedom: a few entries
+    20 - 50 x the typical one, so the per-layer power-of-two scale leaves most weights' low pieces near the subnormal range), per-channel gains over
+    two decades, and activations with isolated outliers of a few hundred.  Criterion as for the Gaussian stacks: the error of the split-operand
+    kernel (direct form, Winograd form on 64- / 96-frame tiles) against an fp64 evaluation stays within 2 x the native fp32-MFMA kernel's."""
+    from set_amd import ops
+    import torch.nn.functional as F
+    monkeypatch.setenv("SET_AMD_SPLIT", "0")
+    monkeypatch.setenv("SET_AMD_X3_TILE", "64")
+    B, T, L = 2, 192, 4
+    g = torch.Generator().manual_seed(909)
+
+    def student_t(*shape):
+        z = torch.randn(*shape, generator=g)
+        chi = (torch.randn(3, *shape, generator=g) ** 2).sum(0) / 3.0
+        return z / chi.sqrt()
+
+    x0 = torch.randn(B, 256, T, generator=g)
+    x0[torch.rand(B, 256, T, generator=g) < 2e-3] *= 300.0
+    x0 = x0.to(dev)
+    cp = (torch.randn(B, L * 512, T, generator=g) * 0.5).to(dev)
+    dtab = torch.randn(L * 256, 3, generator=g).to(dev)
+    w1 = torch.empty(L, 512 * 768, device=dev)
+    w2 = torch.empty(L, 512 * 256, device=dev)
+    wx3 = ops.SplitOperandImages(L, 2, dev)
+    bd = (torch.randn(L, 512, generator=g) * 0.1).to(dev)
+    bo = (torch.randn(L, 512, generator=g) * 0.1).to(dev)
+    wds, wos = [], []
+    for l in range(L):
+        gain = torch.exp(torch.randn(512, 1, 1, generator=g) * 1.2)           # per-output-channel gains over ~two decades
+        wd = (student_t(512, 256, 3) * gain / 60.0).to(dev)
+        wo = (student_t(512, 256, 1) * torch.exp(torch.randn(512, 1, 1, generator=g)) / 40.0).to(dev)
+        ops.pack_diffnet_layer(wd, wo, w1[l], w2[l])
+        wx3.pack(l, wd, wo)
+        wds.append(wd), wos.append(wo)
+    packs = (w1, w2, bd, bo, None, None) + ops.split_images(w1, w2) + (wx3,)
+
+    def run(x3, wino):
+        monkeypatch.setenv("SET_AMD_X3", x3)
+        monkeypatch.setenv("SET_AMD_X3_WINO", wino)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        xa, xb, skip = x0.clone(), torch.full_like(x0, float("nan")), torch.full_like(x0, float("nan"))
+        ws = ops.diffnet_stack(xa, xb, skip, cp, dtab.data_ptr() + 4, 0, 3, 256 * 3, packs, 1, err_flag=err)
+        torch.cuda.synchronize()
+        assert int(ws[1]) == 0 and int(err) == 0, (int(ws[1]), int(err))   # no time-out, no activation beyond the fp16 range
+        return (xb if L % 2 else xa).clone(), skip.clone()
+
+    x32, s32 = run("0", "0")
+    xs, ss = run("2", form)
+    xd, skd = x0.double(), torch.zeros_like(x0, dtype=torch.float64)
+    for l in range(L):
+        dv = dtab[l * 256:(l + 1) * 256, 1].double()[None, :, None]
+        y = F.conv1d(xd + dv, wds[l].double(), bd[l].double(), padding=1) + cp[:, l * 512:(l + 1) * 512].double()
+        z = torch.sigmoid(y[:, :256]) * torch.tanh(y[:, 256:])
+        o = F.conv1d(z, wos[l].double(), bo[l].double())
+        xd, skd = (xd + o[:, :256]) / 2 ** 0.5, skd + o[:, 256:]
+    scale = max(float(xd.abs().max()), float(skd.abs().max()))
+    e32 = max(float((x32.double() - xd).abs().max()), float((s32.double() - skd).abs().max()))
+    es = max(float((xs.double() - xd).abs().max()), float((ss.double() - skd).abs().max()))
+    print("heavy-tailed stack, form %s: max |value| %.1f, max err vs fp64: fp32 kernel %.3e, split-operand %.3e" % (form, scale, e32, es))
+    assert es < 2.0 * e32 + 1e-7 * scale, (form, es, e32)
+
+
 @pytest.mark.parametrize("form", ["2", "3"])
 def test_x3v_shape_sweep_against_the_direct_form(dev, monkeypatch, form):
     """The Winograd kernel on shapes around its tile geometry: T below one column block, at / one pair past the 32-, 64- and 96-frame
