@@ -122,6 +122,19 @@ __device__ __forceinline__ void buf_store_agent(float v, rsrc_t r, unsigned voff
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 16);
 }
 
+// two fp32 values -> their two-piece fp16 splittings (a0 + a1 = a to 22 significand bits), each piece pair packed into one dword with the
+// first value in the low half: v_cvt_pk_f16_f32, two back-conversions, v_pk_add_f32, v_cvt_pk_f16_f32 -- five instructions where two
+// scalar splittings and their packing take ten.  Same roundings (to nearest even, twice) as `h0 = (f16)a; h1 = (f16)(a - (float)h0)`.
+__device__ __forceinline__ void split2_f16(float a, float b, unsigned &p0, unsigned &p1) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t v = {a, b};
+    const h2_t h0 = __builtin_convertvector(v, h2_t);
+    const h2_t h1 = __builtin_convertvector(v - __builtin_convertvector(h0, f2_t), h2_t);
+    p0 = __builtin_bit_cast(unsigned, h0);
+    p1 = __builtin_bit_cast(unsigned, h1);
+}
+
 // ---- shared fp32 MFMA GEMM inner loop -----------------------------------------------------------------------
 // acc[RB][NCB] (32x32 blocks) += A * B over `ng` groups of GS k-steps (2 k values each).
 //   A operand: packed image, one vector of RB floats per lane per k-step:  wp[u * 64] for k-step u of the group

@@ -135,14 +135,18 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
                 const int row = p * 128 + sf;
                 const int ti = t0 + lo + row;
                 const bool tv = ti >= 0 && ti < a.T_in;
-                unsigned short h0[16], h1[16];
+                unsigned h0[8], h1[8];  // channel pairs (2 j, 2 j + 1), packed
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    float v = cx_pro<kPro>(pv[p][k], a.pro_param);             // unconditional, straight-line
-                    v = (tv && c0 + scg * 16 + k < a.Cin) ? v : 0.0f;          // select, no branch
-                    amax = fmaxf(amax, fabsf(v));
-                    h0[k] = cx_f2h(v);
-                    h1[k] = cx_f2h(v - cx_h2f(h0[k]));
+                for (int j = 0; j < 8; ++j) {
+                    float v[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int k = 2 * j + h;
+                        v[h] = cx_pro<kPro>(pv[p][k], a.pro_param);                  // unconditional, straight-line
+                        v[h] = (tv && c0 + scg * 16 + k < a.Cin) ? v[h] : 0.0f;      // select, no branch
+                    }
+                    amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
+                    split2_f16(v[0], v[1], h0[j], h1[j]);
                 }
                 if (row < R) {
 #pragma unroll
@@ -150,8 +154,8 @@ __global__ void __launch_bounds__(256, 2) conv1d_x2_kernel(SetConv1dArgs a, int 
                         cx_u32x4 u0, u1;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            u0[e] = (unsigned)h0[8 * q + 2 * e] | ((unsigned)h0[8 * q + 2 * e + 1] << 16);
-                            u1[e] = (unsigned)h1[8 * q + 2 * e] | ((unsigned)h1[8 * q + 2 * e + 1] << 16);
+                            u0[e] = h0[4 * q + e];
+                            u1[e] = h1[4 * q + e];
                         }
                         *reinterpret_cast<cx_u32x4 *>(Bs + row * CX_ROWB + (scg * 16 + 8 * q) * 2) = u0;
                         *reinterpret_cast<cx_u32x4 *>(Bs + piece_bytes + row * CX_ROWB + (scg * 16 + 8 * q) * 2) = u1;

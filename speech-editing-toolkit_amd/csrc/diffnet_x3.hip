@@ -102,6 +102,8 @@ struct SplitF16x2 {
         p[0] = f2h(a);
         p[1] = f2h(a - h2f(p[0]));
     }
+    // two values at once, pieces packed (a in the low half; common.h)
+    static __device__ __forceinline__ void split2(float a, float b, unsigned (&p)[2]) { split2_f16(a, b, p[0], p[1]); }
     static __device__ __forceinline__ f32x16 mma(u32x4_t a, u32x4_t b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
@@ -192,7 +194,7 @@ __global__ void __launch_bounds__(256) pack_layer_x3_kernel(const float *wdil, c
 //   A: image block of (w8, ks, rb, piece) at byte offset abase + u * ustride + ((ks * 2 + rb) * NP + piece) * 1024 (+ lane * 16)
 //   B: piece q of this lane's fragment for (ks, cb) at lds + q * piece_bytes + bfrag(ks, cb)
 //   PF: A prefetch distance in k-steps.  Every accumulator sees its products in the same order whatever NU is.
-template <typename S, int NKS, int NU, int NCB, int PF, typename BF>
+template <typename S, int NKS, int NU, int NCB, int PF, int SLP = 0, typename BF>
 __device__ __forceinline__ void gemm_x3(f32x16 (&acc)[NU][2][NCB], rsrc_t img, unsigned lane16, unsigned abase, unsigned ustride,
                                         const unsigned char *lds, unsigned piece_bytes, BF bfrag) {
     constexpr int NP = S::NP;
@@ -222,6 +224,7 @@ __device__ __forceinline__ void gemm_x3(f32x16 (&acc)[NU][2][NCB], rsrc_t img, u
             // (Copying the slot to temporaries and refilling it BEFORE the MFMAs -- the earlier form -- made the compiler rotate the ring
             // through v_mov chains behind s_waitcnt vmcnt(0) at the end of every PF k-steps: the ring drained once per loop iteration.)
             __builtin_amdgcn_sched_barrier(0);
+            if (SLP) __builtin_amdgcn_s_sleep(SLP);  // (x3v: the wave's own rate cap, see SET_X3V_SLEEP)
             if (!(SET_X3_EXP & 4)) __builtin_amdgcn_s_setprio(1);
             // the accumulators interleave, so consecutive MFMAs never depend on each other
 #pragma unroll
@@ -449,7 +452,7 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[NU][2][NC
     X3_PHASE(1)
 
     // ---- GEMM 1: y = Wdil (*) (x + d); k-step ks -> tap ks / 16 (a row shift of tap * d), channels 16 (ks % 16) ..
-    gemm_x3<S, X_KS1, NU, NCB, (NU == 1 ? S::PF : S::PF2)>(
+    gemm_x3<S, X_KS1, NU, NCB, (NU == 1 ? S::PF : S::PF2), 0>(
         acc, rw, lane16, (unsigned)(NU * w * X_KS1 * 2 * NP * 1024), (unsigned)(X_KS1 * 2 * NP * 1024), lds, piece_bytes, [&](int ks, int cb) {
             return (unsigned)((cb * RB + l31 + (ks >> 4) * d) * XR + ((ks & 15) * 16 + half * 8) * 2);
         });
@@ -532,7 +535,7 @@ __device__ __forceinline__ void x3_main(const X3Tile &a, f32x16 (&acc)[NU][2][NC
     X3_PHASE(3)
 
     // ---- GEMM 2: o = Wout z
-    gemm_x3<S, X_KS2, NU, NCB, (NU == 1 ? S::PF : S::PF2)>(
+    gemm_x3<S, X_KS2, NU, NCB, (NU == 1 ? S::PF : S::PF2), 0>(
         acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + NU * w * X_KS2 * 2 * NP * 1024), (unsigned)(X_KS2 * 2 * NP * 1024), lds, piece_bytes,
         [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2); });
     X3_PHASE(4)
@@ -769,6 +772,12 @@ template <int NB> constexpr unsigned xv_tile() { return 2 * xv_plane<NB>() > 2 *
 #ifndef SET_X3V_PF2
 #define SET_X3V_PF2 2                             // fragment ring depth of GEMM 2 in k-steps of 16
 #endif
+#ifndef SET_X3V_SLEEP
+#define SET_X3V_SLEEP 0                           // s_sleep argument (x 64 clocks) in front of every k-step's MFMA burst of GEMM 1 (36 MFMAs = 576 clocks)
+#endif
+#ifndef SET_X3V_SLEEP2
+#define SET_X3V_SLEEP2 0                          // same for GEMM 2 (18 MFMAs of 32 clocks)
+#endif
 #ifndef SET_X3V_SK_EARLY
 #define SET_X3V_SK_EARLY 0                        // 1 = the running skip rows are fetched before GEMM 2 (48 more live registers through it)
 #endif
@@ -855,36 +864,40 @@ __device__ __forceinline__ float x3v_stage(const X3Tile &a, unsigned char *lds, 
         const bool v12 = c.ok && t < T, vh = c.ok && edge && th >= 0 && th < T;
         const f32x4 dA = *reinterpret_cast<const f32x4 *>(dsh + nb * XC + ch0);
         const f32x4 dB = *reinterpret_cast<const f32x4 *>(dsh + nb * XC + ch0 + 4);
-        unsigned short pc[2][8][2];  // [plane of the pair][channel][piece]
+        u32x4_t u[2][2];  // [plane of the pair][piece]: 8 channels, two to a word
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float ds = e < 4 ? dA[e & 3] : dB[e & 3];
-            const float d1 = v12 ? x12[nb][e][0] + ds : 0.0f, d2 = v12 ? x12[nb][e][1] + ds : 0.0f;
-            float V[2];
-            if (PH == 0) {
-                V[0] = d1 + d2;
-                V[1] = d2 - d1;
-            } else {
-                float d0 = row_prev(d2), d3 = row_next(d1);
-                const float hv = vh ? xh[nb][e] + ds : 0.0f;
-                d0 = l15 == 0 ? hv : d0;
-                d3 = l15 == 15 ? hv : d3;
-                V[0] = d0 - d2;
-                V[1] = d1 - d3;
+        for (int e2 = 0; e2 < 4; ++e2) {
+            float V[2][2];  // [plane][channel of the word]
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 2 * e2 + h;
+                const float ds = e < 4 ? dA[e & 3] : dB[e & 3];
+                const float d1 = v12 ? x12[nb][e][0] + ds : 0.0f, d2 = v12 ? x12[nb][e][1] + ds : 0.0f;
+                if (PH == 0) {
+                    V[0][h] = d1 + d2;
+                    V[1][h] = d2 - d1;
+                } else {
+                    float d0 = row_prev(d2), d3 = row_next(d1);
+                    const float hv = vh ? xh[nb][e] + ds : 0.0f;
+                    d0 = l15 == 0 ? hv : d0;
+                    d3 = l15 == 15 ? hv : d3;
+                    V[0][h] = d0 - d2;
+                    V[1][h] = d1 - d3;
+                }
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                amax = fmaxf(amax, fabsf(V[j]));
-                S::split(V[j], pc[j][e]);
+                amax = fmaxf(fmaxf(amax, fabsf(V[j][0])), fabsf(V[j][1]));
+                unsigned pw[2];
+                S::split2(V[j][0], V[j][1], pw);
+                u[j][0][e2] = pw[0];
+                u[j][1][e2] = pw[1];
             }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            u32x4_t u[2];
-            pack8<2>(pc[j], u);
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4_t *>(lds + j * xv_plane<NB>() + q * xv_piece<NB>() + (16 * nb + l15) * XRV + ch0 * 2) = u[q];
-        }
+            for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4_t *>(lds + j * xv_plane<NB>() + q * xv_piece<NB>() + (16 * nb + l15) * XRV + ch0 * 2) = u[j][q];
     }
     return amax;
 }
@@ -905,6 +918,7 @@ __device__ __forceinline__ void x3v_plane(f32x4 (&acc)[4][NB], u32x4_t (&A)[PFV]
 #pragma unroll
                 for (int q = 0; q < 2; ++q) Bv[nb][q] = *reinterpret_cast<const u32x4_t *>(bplane + q * xv_piece<NB>() + boff + (unsigned)(nb * 16 * XRV) + (unsigned)kc * 64u);
             __builtin_amdgcn_sched_barrier(0);
+            if (SET_X3V_SLEEP) __builtin_amdgcn_s_sleep(SET_X3V_SLEEP);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < S::NPROD; ++t)
@@ -926,13 +940,27 @@ __device__ __forceinline__ void x3v_plane(f32x4 (&acc)[4][NB], u32x4_t (&A)[PFV]
 // (SET_X3_PROBE builds: lane 0 of block 0 adds its s_memtime ticks per phase to g_x3_phase_buf -- 0 claim + accumulator start + wait, 1 first
 // plane pair staged, 2 its GEMMs, 3 E / O + second pair staged, 4 its GEMMs, 8 residual loads + gate, 9 GEMM 2, 10 epilogue issue, 5 publish)
 template <int NB>
-__device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB], unsigned char *lds, uint64_t *dbg, uint64_t &tprev) {
+__device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB], unsigned char *lds, uint64_t *dbg, uint64_t &tprev, uint64_t (&ts)[32]) {
+#if SET_X3_PROBE == 2  // timeline build: every wave keeps the s_memtime stamps of its task in SGPRs (ts[8 + p]), no memory access here
+#define X3V_PHASE(p)                                  \
+    {                                                 \
+        __builtin_amdgcn_sched_barrier(0);            \
+        ts[8 + (p)] = __builtin_amdgcn_s_memtime();   \
+        __builtin_amdgcn_sched_barrier(0);            \
+    }
+#else
 #define X3V_PHASE(p)                                          \
     if (dbg) {                                                \
         const uint64_t tn = __builtin_amdgcn_s_memtime();     \
         dbg[p] += tn - tprev;                                 \
         tprev = tn;                                           \
     }
+#endif
+#if SET_X3_PROBE == 2
+#define X3V_TS(p) X3V_PHASE(p)  // stamps of the timeline build only
+#else
+#define X3V_TS(p)
+#endif
     X3V_PHASE(0)
     typedef SplitF16x2 S;
     constexpr int PFV = SET_X3V_PF;
@@ -950,9 +978,7 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB],
     const float *sc = reinterpret_cast<const float *>(a.img + x_n1<S>() + x_n2<S>());
     const float s2 = sc[2], is2 = sc[3];
     const float is1w = reinterpret_cast<const float *>(a.img + x_nimg<S>() - 8)[1];
-    for (int idx = tid; idx < NB * XC; idx += 512)
-        dsh[idx] = a.dstep[(int64_t)x3_col(a, idx >> 8).b * a.d_bs + (int64_t)(idx & (XC - 1)) * a.d_cs];
-    __syncthreads();  // dsh
+    // (dsh: staged by the kernel's task loop in front of the dependency wait -- the offsets depend on nothing the layer below wrote)
     // ---- GEMM 1, first pair of planes
     const unsigned abase = (unsigned)((x_n1<S>() + x_n2<S>() + 8) * 2) + (unsigned)(w * X_KSV * 4 * 2 * 1024);
     const unsigned boff = (unsigned)(l15 * XRV + kg * 16);
@@ -964,6 +990,7 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB],
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int q = 0; q < 2; ++q) A[p][mb][q] = buf_load_u4(rw, lane16, abase + (unsigned)(((p * 4 + mb) * 2 + q) * 1024));
+    X3V_TS(12)
     __syncthreads();
     X3V_PHASE(1)
     x3v_plane<NB, PFV>(PQ[0], A, rw, lane16, abase, 0, lds, boff);
@@ -980,6 +1007,7 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB],
                 PQ[1][mb][nb][i] = pp - qq;  // odd frame
             }
     __syncthreads();  // every wave is done reading the first pair of planes
+    X3V_TS(13)
     // ---- second pair
     amax = fmaxf(amax, x3v_stage<NB, 1>(a, lds, dsh, w, lane));
     if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -989,6 +1017,7 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB],
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int q = 0; q < 2; ++q) A[p][mb][q] = buf_load_u4(rw, lane16, abase + (unsigned)((((16 + p) * 4 + mb) * 2 + q) * 1024));
+    X3V_TS(14)
     __syncthreads();
     X3V_PHASE(3)
     x3v_plane<NB, PFV>(PQ[0], A, rw, lane16, abase, 2, lds, boff);
@@ -1014,6 +1043,7 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB],
         for (int r = 0; r < 16; ++r) xres[cb][r] = buf_load(rx, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
     }
     __syncthreads();  // every wave is done reading the V tile: the z tile overlays it (row = frame of the tile)
+    X3V_TS(15)
     // ---- gate: lane (l15, kg) holds the pair's frames 2 l15 (PQ[0]) and 2 l15 + 1 (PQ[1]) of column block nb, channels 32 w + 16 m + 4 kg ..
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -1023,18 +1053,21 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB],
         for (int eo = 0; eo < 2; ++eo)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                unsigned short p[4][2];
+                float zz[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float zz = fsig(PQ[eo][m][nb][i] * is1w) * ftanh(PQ[eo][m + 2][nb][i] * is1w);
-                    S::split(tvp ? zz : 0.0f, p[i]);
+                    const float g = fsig(PQ[eo][m][nb][i] * is1w) * ftanh(PQ[eo][m + 2][nb][i] * is1w);
+                    zz[i] = tvp ? g : 0.0f;
                 }
+                unsigned plo[2], phi[2];
+                S::split2(zz[0], zz[1], plo);
+                S::split2(zz[2], zz[3], phi);
                 const unsigned off = (unsigned)((32 * nb + 2 * l15 + eo) * XR + (32 * w + 16 * m + 4 * kg) * 2);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     u32x2w_t uu;
-                    uu[0] = (unsigned)p[0][q] | ((unsigned)p[1][q] << 16);
-                    uu[1] = (unsigned)p[2][q] | ((unsigned)p[3][q] << 16);
+                    uu[0] = plo[q];
+                    uu[1] = phi[q];
                     *reinterpret_cast<u32x2w_t *>(lds + q * xv_zpiece<NB>() + off) = uu;
                 }
             }
@@ -1061,9 +1094,10 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB],
         for (int r = 0; r < 16; ++r) sk[cb][r] = buf_load_nt(rsk, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
     }
 #endif
+    X3V_TS(16)
     __syncthreads();
     X3V_PHASE(8)
-    gemm_x3<S, X_KS2, 1, NB, SET_X3V_PF2>(acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + w * X_KS2 * 2 * 2 * 1024), (unsigned)(X_KS2 * 2 * 2 * 1024), lds,
+    gemm_x3<S, X_KS2, 1, NB, SET_X3V_PF2, SET_X3V_SLEEP2>(acc, rw, lane16, (unsigned)(x_n1<S>() * 2 + w * X_KS2 * 2 * 2 * 1024), (unsigned)(X_KS2 * 2 * 2 * 1024), lds,
                                              xv_zpiece<NB>(), [&](int ks, int cb) { return (unsigned)((cb * 32 + l31) * XR + (ks * 16 + half * 8) * 2); });
     X3V_PHASE(9)
     // ---- epilogue
@@ -1087,6 +1121,7 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB],
             for (int r = 0; r < 16; ++r) buf_store_agent((acc[0][0][cb][r] * is2) * RSQRT2, rxo, vo4[cb], (unsigned)(32 * w + urow(r)) * T4);
         }
     }
+    X3V_TS(17)
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
         if (tv[cb]) {
@@ -1099,8 +1134,22 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB],
     X3V_PHASE(10)
 }
 #undef X3V_PHASE
+#undef X3V_TS
 
 // the persistent (layer, tile) queue of diffnet_stack_x3_kernel (same flags, same publish protocol) on tiles of NB column blocks
+#if SET_X3_PROBE == 2
+#ifndef X3V_TL_TASK
+#define X3V_TL_TASK 10
+#endif
+#define X3V_KTS(p)                                \
+    {                                             \
+        __builtin_amdgcn_sched_barrier(0);        \
+        ts[p] = __builtin_amdgcn_s_memtime();     \
+        __builtin_amdgcn_sched_barrier(0);        \
+    }
+#else
+#define X3V_KTS(p)
+#endif
 template <int NB>
 __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetStackArgs a, int ntiles, int ntasks, int fault_tile) {
     typedef SplitF16x2 S;
@@ -1108,12 +1157,15 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
     int *s_task = reinterpret_cast<int *>(lds + xv_tile<NB>() + NB * XC * sizeof(float));  // [0] next task, [1] peek result, [2] wait result
     int *counter = a.sync_ws, *abort_flag = a.sync_ws + 1, *done = a.sync_ws + 4;
     const int tid = threadIdx.x;
-    uint64_t *dbg = (SET_X3_PROBE && blockIdx.x == 0 && tid == 0) ? g_x3_phase_buf : nullptr;
+    uint64_t *dbg = (SET_X3_PROBE == 1 && blockIdx.x == 0 && tid == 0) ? g_x3_phase_buf : nullptr;
     uint64_t tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
     if (tid == 0) s_task[0] = atomicAdd(counter, 1);
     __syncthreads();
     int n = __builtin_amdgcn_readfirstlane(s_task[0]);
     int i_done = -1, l_done = 0;
+    uint64_t ts[32] = {};
+    int n_mine = 0;
+    (void)n_mine;
     while (n < ntasks) {
         const int l = n / ntiles, i = n - l * ntiles;
         X3Tile lt;
@@ -1129,6 +1181,15 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
         lt.T = a.T; lt.dil = 1; lt.first = (l == 0);
         lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * NB;  // (x3v)
         f32x4 PQ[2][4][NB];
+        X3V_KTS(0)
+        // step offsets of the column blocks' utterances: loaded first, stored to LDS behind the wait below, published by the task-slot barrier
+        // (the previous task read its offsets for the last time in its second staging pass, several barriers ago)
+        float dsv[(NB * XC + 511) / 512];
+#pragma unroll
+        for (int j = 0; j < (NB * XC + 511) / 512; ++j) {
+            const int idx = min(tid + 512 * j, NB * XC - 1);
+            dsv[j] = lt.dstep[(int64_t)x3_col(lt, idx >> 8).b * lt.d_bs + (int64_t)(idx & (XC - 1)) * lt.d_cs];
+        }
         x3v_init<NB>(lt, PQ);
         __builtin_amdgcn_sched_barrier(0);
         const int *f0 = done + i, *fl = done + (i > 0 ? i - 1 : i), *fr = done + (i < ntiles - 1 ? i + 1 : i);
@@ -1137,13 +1198,22 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
             if (l > 0) peek = min(ld_agent(f0), min(ld_agent(fl), ld_agent(fr)));
             claimed = atomicAdd(counter, 1);
         }
+        X3V_KTS(1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        X3V_KTS(2)
+        {
+            float *dsh = reinterpret_cast<float *>(lds + xv_tile<NB>());
+#pragma unroll
+            for (int j = 0; j < (NB * XC + 511) / 512; ++j)
+                if (tid + 512 * j < NB * XC) dsh[tid + 512 * j] = dsv[j];
+        }
         if (tid == 0) {
             if (peek >= l) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             s_task[0] = claimed;
             s_task[1] = peek >= l ? 1 : 2;
         }
         __syncthreads();
+        X3V_KTS(3)
         if (tid == 0 && i_done >= 0 && !(l_done == 0 && i_done == fault_tile))
             __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         i_done = -1;
@@ -1169,7 +1239,23 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
             if (__builtin_amdgcn_readfirstlane(s_task[2]) == 0) break;
         }
         const int n_next = __builtin_amdgcn_readfirstlane(s_task[0]);
-        x3v_main<NB>(lt, PQ, lds, dbg, tprev);
+        X3V_KTS(4)
+        x3v_main<NB>(lt, PQ, lds, dbg, tprev, ts);
+#if SET_X3_PROBE == 2
+        // timeline of this block's X3V_TL_TASK-th task, waves 0 and 7: row (2 block + wave / 7) of 32 dwords = ticks since the task's first stamp
+        // (slot 5: the task number, 6: 1 if the dependency wait had to spin)
+        if (++n_mine == X3V_TL_TASK && (tid == 0 || tid == 448) && g_x3_phase_buf) {
+            const rsrc_t rt = make_rsrc(g_x3_phase_buf);
+            const unsigned row = (unsigned)(2 * blockIdx.x + (tid ? 1 : 0)) * 128u;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(ts[k] - ts[0]), rt, (int)(row + 4 * k), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)n, rt, (int)(row + 20), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)s_task[1], rt, (int)(row + 24), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)ts[0], rt, (int)(row + 28), 0, 0);
+        } else if (n_mine == X3V_TL_TASK + 1 && (tid == 0 || tid == 448) && g_x3_phase_buf) {  // slot 31: the NEXT task's first stamp (absolute, as slot 7)
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)ts[0], make_rsrc(g_x3_phase_buf), (int)((unsigned)(2 * blockIdx.x + (tid ? 1 : 0)) * 128u + 124u), 0, 0);
+        }
+#endif
         i_done = i;
         l_done = l;
         n = n_next;

@@ -135,15 +135,19 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_x2_kernel(SetResblockPai
                 const int row = p * 128 + sf;
                 const int ti = f0 - h1 + row;
                 const bool tv = ti >= 0 && ti < T;
-                unsigned short q0[16], q1[16];
+                unsigned q0[8], q1[8];  // channel pairs (2 j, 2 j + 1), packed
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    float v = pv[p][k];
-                    v = v > 0.0f ? v : v * a.slope;                     // unconditional, straight-line
-                    v = (tv && c0 + scg * 16 + k < C) ? v : 0.0f;        // select, no branch
-                    amax = fmaxf(amax, fabsf(v));
-                    q0[k] = rp_f2h(v);
-                    q1[k] = rp_f2h(v - rp_h2f(q0[k]));
+                for (int j = 0; j < 8; ++j) {
+                    float v[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int k = 2 * j + h;
+                        v[h] = pv[p][k];
+                        v[h] = v[h] > 0.0f ? v[h] : v[h] * a.slope;                   // unconditional, straight-line
+                        v[h] = (tv && c0 + scg * 16 + k < C) ? v[h] : 0.0f;           // select, no branch
+                    }
+                    amax = fmaxf(fmaxf(amax, fabsf(v[0])), fabsf(v[1]));
+                    split2_f16(v[0], v[1], q0[j], q1[j]);
                 }
                 if (row < R1) {
 #pragma unroll
@@ -151,8 +155,8 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_x2_kernel(SetResblockPai
                         rp_u32x4 u0, u1;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            u0[e] = (unsigned)q0[8 * q + 2 * e] | ((unsigned)q0[8 * q + 2 * e + 1] << 16);
-                            u1[e] = (unsigned)q1[8 * q + 2 * e] | ((unsigned)q1[8 * q + 2 * e + 1] << 16);
+                            u0[e] = q0[4 * q + e];
+                            u1[e] = q1[4 * q + e];
                         }
                         *reinterpret_cast<rp_u32x4 *>(Bs + row * RP_ROWB + (scg * 16 + 8 * q) * 2) = u0;
                         *reinterpret_cast<rp_u32x4 *>(Bs + piece1 + row * RP_ROWB + (scg * 16 + 8 * q) * 2) = u1;
@@ -245,20 +249,19 @@ __global__ void __launch_bounds__(256, 2) resblock_pair_x2_kernel(SetResblockPai
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int chb = ch0 + 8 * g + 4 * half;  // channels chb .. chb + 3 (register 4 g + e)
-                unsigned short q0[4], q1[4];
+                float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = acc[i][j][4 * g + e] * inv_s1 + b1v[4 * g + e];
-                    v = v > 0.0f ? v : v * a.slope;
-                    v = (fv && chb + e < C) ? v : 0.0f;
-                    amax = fmaxf(amax, fabsf(v));
-                    q0[e] = rp_f2h(v);
-                    q1[e] = rp_f2h(v - rp_h2f(q0[e]));
+                    v[e] = acc[i][j][4 * g + e] * inv_s1 + b1v[4 * g + e];
+                    v[e] = v[e] > 0.0f ? v[e] : v[e] * a.slope;
+                    v[e] = (fv && chb + e < C) ? v[e] : 0.0f;
+                    amax = fmaxf(amax, fabsf(v[e]));
                 }
                 const unsigned off = (unsigned)((col + h2) * TROW + chb * 2);
-                rp_u32x2 u0, u1;
-                u0[0] = (unsigned)q0[0] | ((unsigned)q0[1] << 16); u0[1] = (unsigned)q0[2] | ((unsigned)q0[3] << 16);
-                u1[0] = (unsigned)q1[0] | ((unsigned)q1[1] << 16); u1[1] = (unsigned)q1[2] | ((unsigned)q1[3] << 16);
+                unsigned lo0, lo1, hi0, hi1;
+                split2_f16(v[0], v[1], lo0, lo1);
+                split2_f16(v[2], v[3], hi0, hi1);
+                const rp_u32x2 u0 = {lo0, hi0}, u1 = {lo1, hi1};
                 *reinterpret_cast<rp_u32x2 *>(Bs + off) = u0;
                 *reinterpret_cast<rp_u32x2 *>(Bs + piece2 + off) = u1;
             }

@@ -61,5 +61,8 @@ for name, env in variants:
            "sclk_mhz_mean": sum(fq) / max(1, len(fq)), "span_ms_mean": sum(ret["layer_span_ms"]) / len(ret["layer_span_ms"])}
     print(json.dumps(out), flush=True)
 base = mels["direct_form"]
+import hashlib  # (mels of runs under different library builds -- SET_AMD_LIB -- are compared through these)
+for name, m in mels.items():
+    print("%-28s sha256 of the mel: %s" % (name, hashlib.sha256(m.cpu().numpy().tobytes()).hexdigest()[:16]))
 for name, m in mels.items():
     print("%-28s bit-identical to the per-step launches: %s  (max |d| %.3e)" % (name, bool(torch.equal(m, base)), float((m - base).abs().max())))
