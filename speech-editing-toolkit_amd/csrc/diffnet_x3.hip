@@ -772,6 +772,10 @@ template <int NB> constexpr unsigned xv_tile() { return 2 * xv_plane<NB>() > 2 *
 #ifndef SET_X3V_PF2
 #define SET_X3V_PF2 2                             // fragment ring depth of GEMM 2 in k-steps of 16
 #endif
+#ifndef SET_X3V_WAVE_PUBLISH
+#define SET_X3V_WAVE_PUBLISH 1                    // 1 = every wave publishes its part of a finished tile (flag = waves done, 8 per layer); 0 = one store per block behind a barrier
+#endif
+#define X3V_FLAG_UNIT (SET_X3V_WAVE_PUBLISH ? 8 : 1)
 #ifndef SET_X3V_SLEEP
 #define SET_X3V_SLEEP 0                           // s_sleep argument (x 64 clocks) in front of every k-step's MFMA burst of GEMM 1 (36 MFMAs = 576 clocks)
 #endif
@@ -1182,6 +1186,18 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
         lt.nbu = (a.T + 31) / 32; lt.Q = a.B * lt.nbu; lt.q0 = i * NB;  // (x3v)
         f32x4 PQ[2][4][NB];
         X3V_KTS(0)
+#if SET_X3V_WAVE_PUBLISH
+        // the finished tile is published by every wave on its own, as soon as ITS stores are complete (agent-scope write-through stores: complete =
+        // visible to every XCD): the tile's flag counts waves, 8 per layer.  (The block-wide form -- drain, barrier, one store -- published ~5 us
+        // after the last wave's stores were issued, behind the next task's accumulator-start loads; profiles/r06_x3v_timeline.log.)
+        if (i_done >= 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((tid & 63) == 0 && !(l_done == 0 && i_done == fault_tile))
+                (void)__hip_atomic_fetch_add(done + i_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            i_done = -1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // step offsets of the column blocks' utterances: loaded first, stored to LDS behind the wait below, published by the task-slot barrier
         // (the previous task read its offsets for the last time in its second staging pass, several barriers ago)
         float dsv[(NB * XC + 511) / 512];
@@ -1195,7 +1211,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
         const int *f0 = done + i, *fl = done + (i > 0 ? i - 1 : i), *fr = done + (i < ntiles - 1 ? i + 1 : i);
         int peek = l, claimed = 0;
         if (tid == 0) {
-            if (l > 0) peek = min(ld_agent(f0), min(ld_agent(fl), ld_agent(fr)));
+            if (l > 0) peek = min(ld_agent(f0), min(ld_agent(fl), ld_agent(fr))) / X3V_FLAG_UNIT;
             claimed = atomicAdd(counter, 1);
         }
         X3V_KTS(1)
@@ -1214,16 +1230,18 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
         }
         __syncthreads();
         X3V_KTS(3)
+#if !SET_X3V_WAVE_PUBLISH
         if (tid == 0 && i_done >= 0 && !(l_done == 0 && i_done == fault_tile))
             __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         i_done = -1;
+#endif
         if (__builtin_amdgcn_readfirstlane(s_task[1]) == 2) {
             if (tid == 0) {
                 int ok = 1;
                 unsigned spins = 0;
                 for (;;) {
                     const int v0 = ld_agent(f0), v1 = ld_agent(fl), v2 = ld_agent(fr);
-                    if (min(v0, min(v1, v2)) >= l) break;
+                    if (min(v0, min(v1, v2)) >= l * X3V_FLAG_UNIT) break;
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > X_SPIN_LIMIT || ld_agent(abort_flag) != 0) {
                         __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1267,9 +1285,14 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if SET_X3V_WAVE_PUBLISH
+    if ((tid & 63) == 0 && i_done >= 0 && !(l_done == 0 && i_done == fault_tile))
+        (void)__hip_atomic_fetch_add(done + i_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
     __syncthreads();
     if (tid == 0 && i_done >= 0 && !(l_done == 0 && i_done == fault_tile))
         __hip_atomic_store(done + i_done, l_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 template <int NB>
