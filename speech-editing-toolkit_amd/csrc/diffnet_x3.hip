@@ -750,6 +750,15 @@ __device__ __forceinline__ f32x2 buf_load2_nt(rsrc_t r, unsigned voff, unsigned 
 // (profiles/r06_x3v_nb4_ab.log) -- beyond 96 frames the weight-fragment stream is no longer what the time follows; GEMM 2 on the 16-wide
 // instruction in its transposed form (lane = one output row at four consecutive frames): -19 % with 8-byte, -3 % with 16-byte epilogue accesses
 // (half-line accesses; profiles/r06_x3v_gemm2_16wide_ab.log); skip rows fetched before GEMM 2 / a 4-deep GEMM 2 ring: +-0.3 %.
+// Per-task timeline (tools/x3_timeline_probe.py, profiles/r06_x3v_timeline.log; 68 us per task at B = 32, T = 800): the two waves of a SIMD do not share
+// the matrix pipe evenly -- the older one (waves 0-3) finishes every GEMM pass ~4 us before the younger one and runs ~10 us ahead at the task boundary,
+// so its epilogue and next accumulator-start loads run under the younger waves' GEMM 2 (17 us against 9.4 us of MFMA issue: the younger wave alone is
+// latency-bound on its fragment ring while the CU's memory pipe moves ~490 KB of stores and read-once loads).  Kept from that reading: step offsets
+// staged in front of the dependency wait, tiles published per wave.  Measured and not kept: a per-wave rate cap (s_sleep in front of every k-step's
+// MFMA burst: both waves finish together, GEMM 2 10 us -- and the epilogue then takes the 7 us it had been hidden for; 1.47-1.50 against 1.42-1.43 ms,
+// profiles/r06_x3v_dsh_sleep_ab.log); bias + conditioner projection added in the gate from chunks fetched one ahead, accumulators starting at zero
+// (the task boundary shrinks from 5.8 to 1.7 us, but the gate grows by 1.7 us of exposed HBM latency, every GEMM pass by ~1 us at 254 registers and
+// the dependency wait by 4 us: 1.57 against 1.41 ms, profiles/r06_x3v_late_cp_ab.log).
 // Results: same piece products and fp32 accumulation; sums in another order than the 64-frame form (equal to fp32 rounding).
 // =====================================================================================================================
 // NB = column blocks per tile: 3 (96 frames; shapes with a tile chain for every CU) or 2 (64 frames)
