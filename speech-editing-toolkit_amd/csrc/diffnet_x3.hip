@@ -785,6 +785,13 @@ template <int NB> constexpr unsigned xv_tile() { return 2 * xv_plane<NB>() > 2 *
 #define SET_X3V_WAVE_PUBLISH 1                    // 1 = every wave publishes its part of a finished tile (flag = waves done, 8 per layer); 0 = one store per block behind a barrier
 #endif
 #define X3V_FLAG_UNIT (SET_X3V_WAVE_PUBLISH ? 8 : 1)
+#ifndef X3V_LEAD
+#define X3V_LEAD 0                                // the thread that claims the next task and looks at the dependency flags.  Lane 0 of wave 7 (448) -- one of the
+#endif                                            // waves that reach the task boundary last, so its look is the freshest (spins in 51 of 256 tasks instead of 242)
+                                                  // -- waits for its claim behind its own 48 accumulator-start loads: +2.3 us per task (profiles/r06_x3v_e_ab.log)
+#ifndef SET_X3V_GATE2
+#define SET_X3V_GATE2 1                           // gate as one quotient (3 transcendentals per value) instead of sigmoid x tanh (4)
+#endif
 #ifndef SET_X3V_SLEEP
 #define SET_X3V_SLEEP 0                           // s_sleep argument (x 64 clocks) in front of every k-step's MFMA burst of GEMM 1 (36 MFMAs = 576 clocks)
 #endif
@@ -842,16 +849,14 @@ __device__ __forceinline__ void x3v_init(const X3Tile &a, f32x4 (&PQ)[2][4][NB])
 
 // one pair of planes of the V tile: PH = 0: d1 + d2 | d2 - d1 (U1, U2);  PH = 1: d0 - d2 | d1 - d3 (U0, -U3).  lane (l15, cs): pair l15 of every
 // column block, 8 channels 32 w + 8 cs ..; returns the largest magnitude staged (range check of the fp16 pieces)
+// (two halves, so that the second pass's loads can be issued in front of the barrier that retires the first pair of planes)
 template <int NB, int PH>
-__device__ __forceinline__ float x3v_stage(const X3Tile &a, unsigned char *lds, const float *dsh, int w, int lane) {
-    typedef SplitF16x2 S;
+__device__ __forceinline__ void x3v_stage_load(const X3Tile &a, int w, int lane, f32x2 (&x12)[NB][8], float (&xh)[NB][8]) {
     const int l15 = lane & 15, cs = lane >> 4;
     const int ch0 = 32 * w + 8 * cs;
     const int T = a.T;
     const unsigned T4 = 4u * (unsigned)T;
     const bool edge = l15 == 0 || l15 == 15;
-    f32x2 x12[NB][8];
-    float xh[NB][8];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const X3Col c = x3_col(a, nb);
@@ -869,6 +874,15 @@ __device__ __forceinline__ float x3v_stage(const X3Tile &a, unsigned char *lds, 
             }
         }
     }
+}
+template <int NB, int PH>
+__device__ __forceinline__ float x3v_stage_store(const X3Tile &a, unsigned char *lds, const float *dsh, int w, int lane, const f32x2 (&x12)[NB][8],
+                                                 const float (&xh)[NB][8]) {
+    typedef SplitF16x2 S;
+    const int l15 = lane & 15, cs = lane >> 4;
+    const int ch0 = 32 * w + 8 * cs;
+    const int T = a.T;
+    const bool edge = l15 == 0 || l15 == 15;
     float amax = 0.0f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -991,12 +1005,17 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB],
     const float *sc = reinterpret_cast<const float *>(a.img + x_n1<S>() + x_n2<S>());
     const float s2 = sc[2], is2 = sc[3];
     const float is1w = reinterpret_cast<const float *>(a.img + x_nimg<S>() - 8)[1];
+    const float cg2 = is1w * -1.4426950408889634f, cf2 = is1w * 2.8853900817779268f;  // (is1w: a power of two)
+    (void)cg2; (void)cf2;
     // (dsh: staged by the kernel's task loop in front of the dependency wait -- the offsets depend on nothing the layer below wrote)
     // ---- GEMM 1, first pair of planes
     const unsigned abase = (unsigned)((x_n1<S>() + x_n2<S>() + 8) * 2) + (unsigned)(w * X_KSV * 4 * 2 * 1024);
     const unsigned boff = (unsigned)(l15 * XRV + kg * 16);
     u32x4_t A[PFV][4][2];
-    float amax = x3v_stage<NB, 0>(a, lds, dsh, w, lane);
+    f32x2 x12[NB][8];
+    float xh[NB][8];
+    x3v_stage_load<NB, 0>(a, w, lane, x12, xh);
+    float amax = x3v_stage_store<NB, 0>(a, lds, dsh, w, lane, x12, xh);
 #pragma unroll
     for (int p = 0; p < PFV; ++p)
 #pragma unroll
@@ -1009,6 +1028,8 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB],
     x3v_plane<NB, PFV>(PQ[0], A, rw, lane16, abase, 0, lds, boff);
     x3v_plane<NB, PFV>(PQ[1], A, rw, lane16, abase, 1, lds + xv_plane<NB>(), boff);
     X3V_PHASE(2)
+    x3v_stage_load<NB, 1>(a, w, lane, x12, xh);  // second pair's x: in flight through the E / O combine and the barrier
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -1022,7 +1043,7 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB],
     __syncthreads();  // every wave is done reading the first pair of planes
     X3V_TS(13)
     // ---- second pair
-    amax = fmaxf(amax, x3v_stage<NB, 1>(a, lds, dsh, w, lane));
+    amax = fmaxf(amax, x3v_stage_store<NB, 1>(a, lds, dsh, w, lane, x12, xh));
     if (!(amax < 32768.0f) && a.err_flag) __hip_atomic_store(a.err_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int p = 0; p < PFV; ++p)
@@ -1069,7 +1090,15 @@ __device__ __forceinline__ void x3v_main(const X3Tile &a, f32x4 (&PQ)[2][4][NB],
                 float zz[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+#if SET_X3V_GATE2
+                    // sigmoid(a) tanh(b) = (v - 1) / ((1 + u) (1 + v)), u = e^-a, v = e^2b: three transcendentals instead of four.  v is capped at 2^64
+                    // (tanh = 1 to fp32 from 2^25 on; inf - 1 times 1 / inf would be NaN); u may overflow: the quotient then is the limit, 0.
+                    const float u = __builtin_amdgcn_exp2f(PQ[eo][m][nb][i] * cg2);
+                    const float v = __builtin_amdgcn_exp2f(fminf(PQ[eo][m + 2][nb][i] * cf2, 64.0f));
+                    const float g = (v - 1.0f) * __builtin_amdgcn_rcpf((1.0f + u) * (1.0f + v));
+#else
                     const float g = fsig(PQ[eo][m][nb][i] * is1w) * ftanh(PQ[eo][m + 2][nb][i] * is1w);
+#endif
                     zz[i] = tvp ? g : 0.0f;
                 }
                 unsigned plo[2], phi[2];
@@ -1219,7 +1248,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
         __builtin_amdgcn_sched_barrier(0);
         const int *f0 = done + i, *fl = done + (i > 0 ? i - 1 : i), *fr = done + (i < ntiles - 1 ? i + 1 : i);
         int peek = l, claimed = 0;
-        if (tid == 0) {
+        if (tid == X3V_LEAD) {
             if (l > 0) peek = min(ld_agent(f0), min(ld_agent(fl), ld_agent(fr))) / X3V_FLAG_UNIT;
             claimed = atomicAdd(counter, 1);
         }
@@ -1232,7 +1261,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
             for (int j = 0; j < (NB * XC + 511) / 512; ++j)
                 if (tid + 512 * j < NB * XC) dsh[tid + 512 * j] = dsv[j];
         }
-        if (tid == 0) {
+        if (tid == X3V_LEAD) {
             if (peek >= l) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             s_task[0] = claimed;
             s_task[1] = peek >= l ? 1 : 2;
@@ -1245,7 +1274,7 @@ __global__ void __launch_bounds__(512, 1) diffnet_stack_x3v_kernel(SetDiffnetSta
         i_done = -1;
 #endif
         if (__builtin_amdgcn_readfirstlane(s_task[1]) == 2) {
-            if (tid == 0) {
+            if (tid == X3V_LEAD) {
                 int ok = 1;
                 unsigned spins = 0;
                 for (;;) {
