@@ -758,7 +758,8 @@ __device__ __forceinline__ f32x2 buf_load2_nt(rsrc_t r, unsigned voff, unsigned 
 // MFMA burst: both waves finish together, GEMM 2 10 us -- and the epilogue then takes the 7 us it had been hidden for; 1.47-1.50 against 1.42-1.43 ms,
 // profiles/r06_x3v_dsh_sleep_ab.log); bias + conditioner projection added in the gate from chunks fetched one ahead, accumulators starting at zero
 // (the task boundary shrinks from 5.8 to 1.7 us, but the gate grows by 1.7 us of exposed HBM latency, every GEMM pass by ~1 us at 254 registers and
-// the dependency wait by 4 us: 1.57 against 1.41 ms, profiles/r06_x3v_late_cp_ab.log).
+// the dependency wait by 4 us: 1.57 against 1.41 ms, profiles/r06_x3v_late_cp_ab.log); GEMM 1's ring slots refilled row block by row block inside the
+// k-step's MFMA burst (up to 27 MFMAs earlier; bit-identical, no difference: profiles/r06_x3v_early_refill_ab.log).
 // Results: same piece products and fp32 accumulation; sums in another order than the 64-frame form (equal to fp32 rounding).
 // =====================================================================================================================
 // NB = column blocks per tile: 3 (96 frames; shapes with a tile chain for every CU) or 2 (64 frames)
