@@ -989,6 +989,137 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_taps_bf16_kernel(WgradBf1
     }
 }
 
+// ---- 3-tap weight gradient, one X copy (round 6) -------------------------------------------------------------------------------------
+// conv1d_wgrad3_bf16_kernel stages the fp32 conv input one frame per load (32 four-byte loads per thread and chunk) and writes it to
+// THREE shifted LDS copies with two-byte writes (96 per thread and chunk) for 24 MFMAs per wave: the vector-memory and LDS-write issue,
+// not the matrix pipe, set its time (327 TFLOP/s on the DiffNet dilated conv).  Here, for the "same" convs (pad = dil in {1, 2, 4, 8},
+// T a multiple of 8, bf16 output gradient): X is loaded in 16-byte units (4 frames: 5 loads per thread and chunk), converted once and
+// written to ONE copy with an 8-frame halo on either side (5 eight-byte LDS writes); a lane reads the three aligned 8-frame groups
+// around its k-group and cuts the tap windows out of those 12 registers, as conv1d_wgrad_taps_bf16_kernel does.  Same bf16 operand
+// values, same chunk / k-step / tap order per accumulator as conv1d_wgrad3_bf16_kernel: the partial tiles are bit-identical.
+template <int DIL>
+__global__ void __launch_bounds__(256, 2) conv1d_wgrad3u_bf16_kernel(WgradBf16Args a) {
+    static_assert(DIL == 1 || DIL == 2 || DIL == 4 || DIL == 8, "tap shifts must stay inside the 8-frame halo");
+    __shared__ __attribute__((aligned(16))) unsigned char Gs[128 * WGB_ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[64 * WGT_XROWB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 128;
+    const int total_chunks = a.B * a.n_chunks_t;
+    const int grp = blockIdx.z / a.S;
+    const int c_begin = (blockIdx.z - grp * a.S) * a.chunks_per_slice;
+    const int c_end = min(c_begin + a.chunks_per_slice, total_chunks);
+    const bool has_add = a.chan_add != nullptr;
+    a.g = reinterpret_cast<const unsigned char *>(a.g) + grp * a.g_gs;
+    a.x = reinterpret_cast<const unsigned char *>(a.x) + grp * a.x_gs;
+    if (has_add) a.chan_add += grp * a.add_gs;
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[k][i] = (f32x16){0};
+
+    // G: unit (row urow + 32 q, frames 8 ucol ..) as in conv1d_wgrad3_bf16_kernel; X: 64 rows x 20 units of 4 frames (frames t0 - 8 ..
+    // t0 + 71), unit tid + 256 q = (row xr[q], unit column xc[q])
+    constexpr int XU_ROW = WGT_XF / 4, XQ = 64 * XU_ROW / 256;  // 20 units per row, 5 per thread
+    static_assert(64 * XU_ROW % 256 == 0, "whole units per thread");
+    const int urow = tid >> 3, ucol = tid & 7;
+    int xr[XQ], xc[XQ];
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) { const int u = tid + 256 * q; xr[q] = u / XU_ROW; xc[q] = u - xr[q] * XU_ROW; }
+    u32x4 gv[4], xv[XQ];
+    float av[XQ];
+    auto issue = [&](int ch) {
+        const int b = ch / a.n_chunks_t, t0 = (ch % a.n_chunks_t) * WGB_KT;
+        const rsrc_t d_g = make_rsrc(reinterpret_cast<const unsigned char *>(a.g) + (int64_t)b * a.Cout * a.T * 2u);
+        const rsrc_t d_x = make_rsrc(reinterpret_cast<const float *>(a.x) + (int64_t)b * a.Cin * a.T_in);
+        const rsrc_t d_a = make_rsrc(has_add ? a.chan_add + (int64_t)b * a.Cin : reinterpret_cast<const float *>(a.x));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned vo = (unsigned)(min(co0 + urow + 32 * q, a.Cout - 1) * a.T + min(t0 + 8 * ucol, a.T - 8)) * 2u;
+            gv[q] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_g, (int)vo, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int cic = min(ci0 + xr[q], a.Cin - 1);
+            const unsigned vo = (unsigned)(cic * a.T_in + min(max(t0 - 8 + 4 * xc[q], 0), a.T_in - 4)) * 4u;
+            xv[q] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_x, (int)vo, 0, 0);
+            av[q] = buf_load(d_a, (unsigned)cic * 4u, 0u);
+        }
+    };
+    auto commit = [&](int ch) {
+        const int t0 = (ch % a.n_chunks_t) * WGB_KT;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = urow + 32 * q;
+            const bool ok = t0 + 8 * ucol < a.T && co0 + row < a.Cout;  // T % 8 == 0: a unit is entirely inside or outside
+            u32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? gv[q][e] : 0u;
+            *reinterpret_cast<u32x4 *>(Gs + row * WGB_ROWB + ucol * 16) = v;
+        }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int f0 = t0 - 8 + 4 * xc[q];
+            const bool ok = f0 >= 0 && f0 < a.T_in && ci0 + xr[q] < a.Cin;  // T_in % 4 == 0
+            const float ad = has_add ? av[q] : 0.0f;
+            unsigned short h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned bits = xv[q][e];  // (a scalar copy first: __builtin_bit_cast of a vector-element lvalue reads element 0)
+                h[e] = bf16_bits(__builtin_bit_cast(float, bits) + ad);  // the 3-copy kernel's arithmetic
+            }
+            u32x2 w;
+            w[0] = ok ? ((unsigned)h[0] | ((unsigned)h[1] << 16)) : 0u;
+            w[1] = ok ? ((unsigned)h[2] | ((unsigned)h[3] << 16)) : 0u;
+            *reinterpret_cast<u32x2 *>(Xs + xr[q] * WGT_XROWB + xc[q] * 8) = w;
+        }
+    };
+    if (c_begin < c_end) issue(c_begin);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        __syncthreads();
+        commit(ch);
+        __syncthreads();
+        if (ch + 1 < c_end) issue(ch + 1);
+        // X row element e <-> frame t0 - 8 + e; the lane's k-group of G covers frames t0 + 16 ks + 8 half + (0 .. 7), tap k pairs them
+        // with X frames shifted by (k - 1) DIL: elements 16 ks + 8 half + 8 + (k - 1) DIL + (0 .. 7) -> offset 8 + (k - 1) DIL in W
+        const unsigned char *ap = Gs + (wm * 64 + l31) * WGB_ROWB + half * 16;
+        const unsigned char *bp = Xs + (wn * 32 + l31) * WGT_XROWB + half * 16;
+#pragma unroll
+        for (int ks = 0; ks < WGB_KT / 16; ++ks) {
+            const u32x4 a0 = *reinterpret_cast<const u32x4 *>(ap + ks * 32);
+            const u32x4 a1 = *reinterpret_cast<const u32x4 *>(ap + 32 * WGB_ROWB + ks * 32);
+            u32x4 W[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) W[g] = *reinterpret_cast<const u32x4 *>(bp + ks * 32 + g * 16);
+            const u32x4 b0 = wgt_window<8 - DIL>(W), b1 = W[1], b2 = wgt_window<8 + DIL>(W);
+            acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
+            acc[0][1] = mfma_bf16(a1, b0, acc[0][1]);
+            acc[1][0] = mfma_bf16(a0, b1, acc[1][0]);
+            acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+            acc[2][0] = mfma_bf16(a0, b2, acc[2][0]);
+            acc[2][1] = mfma_bf16(a1, b2, acc[2][1]);
+        }
+    }
+    float *pz = a.partial + (int64_t)blockIdx.z * a.Cout * a.Cin * 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 64 + i * 32 + mfma32_row(r, lane);
+            const int ci = ci0 + wn * 32 + l31;
+            if (co < a.Cout && ci < a.Cin) {
+                float *p = pz + ((int64_t)co * a.Cin + ci) * 3;
+                p[0] = acc[0][i][r];
+                p[1] = acc[1][i][r];
+                p[2] = acc[2][i][r];
+            }
+        }
+}
+
 // dw[i] += sum_{s < S} partial[s][i]   (one fixed association: four interleaved chains over the slices, combined pairwise -- four
 // loads in flight per thread instead of one dependent add per memory round trip)
 // (grid.y = group: partial[(group * S + z) * n + i], dw + group * dw_gs)
@@ -1175,7 +1306,15 @@ static int wgrad_bf16_launch(const void *g, const void *x, const float *chan_add
         a.ci_tiles = (Cin + 63) / 64;
         dim3 grid(a.ci_tiles, (Cout + 127) / 128, S * groups);
         const bool gu = (T & 7) == 0 && T >= 8;  // rows of the bf16 output gradient are 16-byte aligned: copy it in 16-byte units
-        if (dtype == SET_DTYPE_BF16) hipLaunchKernelGGL((conv1d_wgrad3_bf16_kernel<false>), grid, dim3(256), 0, s, a);
+        // one-copy form (16-byte units of X): "same" convs with the tap shifts inside the 8-frame halo; SET_AMD_WGRAD3_UNITS=0 keeps the
+        // three-copy kernel (the bit-identity test's reference)
+        const bool units_env = !(getenv("SET_AMD_WGRAD3_UNITS") && atoi(getenv("SET_AMD_WGRAD3_UNITS")) == 0);
+        const bool xu = units_env && dtype == SET_DTYPE_BF16_G16 && gu && pad == dil && T_in == T && (dil == 1 || dil == 2 || dil == 4 || dil == 8);
+        if (xu && dil == 1) hipLaunchKernelGGL((conv1d_wgrad3u_bf16_kernel<1>), grid, dim3(256), 0, s, a);
+        else if (xu && dil == 2) hipLaunchKernelGGL((conv1d_wgrad3u_bf16_kernel<2>), grid, dim3(256), 0, s, a);
+        else if (xu && dil == 4) hipLaunchKernelGGL((conv1d_wgrad3u_bf16_kernel<4>), grid, dim3(256), 0, s, a);
+        else if (xu) hipLaunchKernelGGL((conv1d_wgrad3u_bf16_kernel<8>), grid, dim3(256), 0, s, a);
+        else if (dtype == SET_DTYPE_BF16) hipLaunchKernelGGL((conv1d_wgrad3_bf16_kernel<false>), grid, dim3(256), 0, s, a);
         else if (gu) hipLaunchKernelGGL((conv1d_wgrad3_bf16_kernel<true, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv1d_wgrad3_bf16_kernel<true>), grid, dim3(256), 0, s, a);
         const int rc = set_check_launch("set_conv1d_wgrad_det(bf16, 3 taps)");

@@ -207,6 +207,45 @@ def test_wgrad_all_taps_kernel_equals_rounded_operand_products(dev, case, monkey
     assert _rel(outs[1], 2 * want) < 2e-5
 
 
+WGRAD3_UNIT_CASES = [
+    # B, Cin, Cout, dil, T, per-channel add: the one-copy 3-tap weight-gradient kernel (bf16 output gradient, fp32 conv input in 16-byte units)
+    (4, 256, 512, 1, 800, True),    # the DiffNet dilated conv of the training step
+    (2, 256, 512, 2, 800, True),
+    (2, 256, 512, 4, 800, False),
+    (2, 256, 512, 8, 800, True),
+    (3, 100, 200, 1, 136, True),    # partial row tiles, a last chunk of 8 frames
+    (2, 64, 128, 8, 64, False),     # exactly one chunk: every halo frame is padding
+    (5, 72, 130, 2, 72, True),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD3_UNIT_CASES)
+def test_wgrad3_one_copy_kernel_equals_the_three_copy_kernel_bit_for_bit(dev, case, monkeypatch):
+    """conv1d_wgrad3u_bf16_kernel (one staged X copy, tap windows cut from three aligned groups) against conv1d_wgrad3_bf16_kernel
+    (three shifted copies): the same operand values in the same order per accumulator, hence torch.equal; and against the rounded
+    operand products."""
+    from set_amd import _lib, autograd_ops as A
+    B, Cin, Cout, dil, T, with_add = case
+    g = torch.Generator().manual_seed(Cin + Cout + dil + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    gy = torch.randn(B, Cout, T, generator=g)
+    add = torch.randn(B, Cin, generator=g) if with_add else None
+    xin = x if add is None else x + add[:, :, None]
+    xp = F.pad(_r(xin), (dil, dil))
+    want = torch.stack([torch.einsum("bot,bit->oi", _r(gy), xp[:, :, k * dil:k * dil + T]) for k in range(3)], dim=-1)
+    xd, gd = x.to(dev), gy.to(dev).to(torch.bfloat16)
+    ad = None if add is None else add.to(dev)
+    outs = {}
+    for units in ("0", "1"):
+        monkeypatch.setenv("SET_AMD_WGRAD3_UNITS", units)
+        dw = torch.zeros(Cout, Cin, 3, device=dev)
+        A.conv_wgrad(gd, xd, ad, dw, B, Cin, Cout, 3, dil, dil, T, T, dtype=_lib.DTYPE_BF16_G16)
+        torch.cuda.synchronize()
+        outs[units] = dw
+    assert torch.equal(outs["0"], outs["1"])
+    assert _rel(outs["1"], want) < 2e-5
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_deterministic_wgrad_is_bit_stable_and_matches_the_atomic_kernel(dev, dtype):
     from set_amd import _lib, autograd_ops as A, ops
