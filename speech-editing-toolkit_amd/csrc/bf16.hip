@@ -183,8 +183,12 @@ __device__ __forceinline__ void conv_bf16_epilogue(const SetConv1dArgs &a, const
 // Two shapes of stage: KCH = 32 with up to TGM = 4 taps (A tile <= 4 * 128 * 80 B = 40 KiB; every K, per-channel add
 // supported) and KCH = 64 with one tap for the 1x1 convs (twice the MFMAs per pair of barriers; no halo rows, no
 // per-channel add -- the staging registers of a 64-channel stage leave no room for them).
-template <int WM, int WN, int KCH, int TGM, bool HALO, bool ADD>
+// VEC (round 6): the input tile is loaded in 16-byte units (4 frames of one channel; a thread owns 4 frames x 4 channels per unit = 4
+// loads, four 8-byte LDS writes) instead of one frame per load (NPASS * KCH / 2 four-byte loads per thread and chunk): the same values
+// in the same LDS cells.  Host: T_in, the strides and Cin multiples of 4, 16-byte aligned bases, halo <= 16 (launch_conv_bf16).
+template <int WM, int WN, int KCH, int TGM, bool HALO, bool ADD, bool VEC = false>
 __global__ void __launch_bounds__(256, 2) conv1d_bf16_kernel(SetConv1dArgs a, int lo, int halo, int CinP, int CoutP) {
+    static_assert(!VEC || KCH == 32, "16-byte input units: 32-channel stages");
     constexpr int BF_TG_MAX = TGM;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int MB = 64 * WM, NB = 64 * WN;
@@ -216,8 +220,13 @@ __global__ void __launch_bounds__(256, 2) conv1d_bf16_kernel(SetConv1dArgs a, in
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
 
     // ---- staging registers (one stage ahead) ----
-    float pv[NPASS][CPT], pa[ADD ? CPT : 1];
+    float pv[NPASS][CPT], pa[ADD ? CPT : 1];  // (dead under VEC)
     u32x4 au[AU_MAX];
+    // VEC: unit u = tid + 256 j -> frame quad u >> 3 (frames F0 + 4 (u >> 3) .., F0 = t0 + lo rounded down to a multiple of 4), channel
+    // quad u & 7 of the 32-channel chunk; NQ quads cover the R rows of the tile
+    constexpr int VQMAX = (64 * WN + 16 + 3) / 4 + 1, VJ = (VQMAX * 8 + 255) / 256;
+    f32x4 vx[VEC ? VJ : 1][VEC ? 4 : 1], va[(VEC && ADD) ? VJ : 1];
+    const int vF0 = (t0 + lo) & ~3, vsh = (t0 + lo) - vF0, vNQ = (R + vsh + 3) >> 2;
     const int sf = tid & 127, scg = tid >> 7;  // B staging: frame row sf (+128*pass), channel group scg
 
     // raw-buffer addressing (common.h): one VGPR byte offset per frame pass + a scalar byte offset per channel (the
@@ -226,6 +235,18 @@ __global__ void __launch_bounds__(256, 2) conv1d_bf16_kernel(SetConv1dArgs a, in
     const rsrc_t d_add = make_rsrc(addp);
     const int scg_u = __builtin_amdgcn_readfirstlane(scg);
     auto issue_b = [&](int c0) {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int j = 0; j < VJ; ++j) {
+                const int u = tid + 256 * j, q = min(u >> 3, vNQ - 1), cq = u & 7;
+                const unsigned vo = (unsigned)min(max(vF0 + 4 * q, 0), a.T_in - 4) * 4u;
+                const int cc = min(c0 + 4 * cq, a.Cin - 4);
+                if constexpr (ADD) va[j] = buf_load4(d_add, (unsigned)cc * 4u, 0u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vx[j][i] = buf_load4(d_in, vo + (unsigned)((cc + i) * (int)a.in_cs) * 4u, 0u);
+            }
+            return;
+        }
         if constexpr (ADD) {
 #pragma unroll
             for (int k = 0; k < CPT; ++k) pa[k] = buf_load(d_add, 0u, (unsigned)min(c0 + scg_u * CPT + k, a.Cin - 1) * 4u);
@@ -243,6 +264,32 @@ __global__ void __launch_bounds__(256, 2) conv1d_bf16_kernel(SetConv1dArgs a, in
     };
     auto commit_b = [&](auto PROC, int c0) __attribute__((always_inline)) {
         constexpr int kPro = decltype(PROC)::value;
+        if constexpr (VEC) {
+#pragma unroll
+            for (int j = 0; j < VJ; ++j) {
+                const int u = tid + 256 * j, q = u >> 3, cq = u & 7;
+                const int f = vF0 + 4 * q;  // T_in % 4 == 0: the quad is entirely inside or outside; Cin % 4 == 0: so is the channel quad
+                const bool ok = q < vNQ && f >= 0 && f < a.T_in && c0 + 4 * cq < a.Cin;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {  // frame f + e -> tile row 4 q + e - vsh
+                    float x[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = vx[j][i][e];
+                        if constexpr (ADD) v = has_add ? v + va[j][i] : v;
+                        v = pro_c<kPro>(v, a.pro_param);
+                        x[i] = ok ? v : 0.0f;
+                    }
+                    const int row = 4 * q + e - vsh;
+                    if (q < vNQ && row >= 0 && row < R) {
+                        u32x2 w;
+                        w[0] = pack_bf16(x[0], x[1]); w[1] = pack_bf16(x[2], x[3]);
+                        *reinterpret_cast<u32x2 *>(Bs + row * ROWB + cq * 8) = w;
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             const int row = p * 128 + sf;
@@ -453,20 +500,26 @@ static int launch_conv1x1_oneshot(const SetConv1dArgs &a, hipStream_t s) {
     return set_check_launch("set_conv1d(bf16, 1x1)");
 }
 
-template <int WM, int WN, int KCH, int TGM, bool HALO, bool ADD>
+template <int WM, int WN, int KCH, int TGM, bool HALO, bool ADD, bool VEC = false>
 static int launch_conv_bf16(const SetConv1dArgs &a, int lo, int halo, hipStream_t s) {
+    if constexpr (KCH == 32 && !VEC) {  // 16-byte input units where the layout allows (SET_AMD_CONV_BF16_UNITS=0: one frame per load)
+        const bool env = !(getenv("SET_AMD_CONV_BF16_UNITS") && atoi(getenv("SET_AMD_CONV_BF16_UNITS")) == 0);
+        const bool al = ((uintptr_t)a.in & 15) == 0 && a.T_in % 4 == 0 && a.T_in >= 4 && a.in_cs % 4 == 0 && a.in_bs % 4 == 0 && a.Cin % 4 == 0 &&
+                        (!a.in_chan_add || ((uintptr_t)a.in_chan_add & 15) == 0);
+        if (env && al && halo <= 16) return launch_conv_bf16<WM, WN, KCH, TGM, HALO, ADD, true>(a, lo, halo, s);
+    }
     constexpr int MB = 64 * WM, NB = 64 * WN, ROWB = KCH * 2 + 16, BF_TG_MAX = TGM;
     const int CinP = round_up_i(a.Cin, 32), CoutP = round_up_i(a.Cout, 128);
     const size_t lds = (size_t)BF_TG_MAX * MB * ROWB + (size_t)(NB + halo) * ROWB;
     static bool attr_set = false;
     if (!attr_set) {
-        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1d_bf16_kernel<WM, WN, KCH, TGM, HALO, ADD>),
+        SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1d_bf16_kernel<WM, WN, KCH, TGM, HALO, ADD, VEC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "conv bf16 attr");
         attr_set = true;
     }
     if (lds > 96 * 1024) return set_fail(SET_E_UNSUPPORTED, "set_conv1d(bf16)", "tile does not fit LDS");
     dim3 grid((a.T_iter + NB - 1) / NB, (a.Cout + MB - 1) / MB, a.B), block(256);
-    hipLaunchKernelGGL((conv1d_bf16_kernel<WM, WN, KCH, TGM, HALO, ADD>), grid, block, lds, s, a, lo, halo, CinP, CoutP);
+    hipLaunchKernelGGL((conv1d_bf16_kernel<WM, WN, KCH, TGM, HALO, ADD, VEC>), grid, block, lds, s, a, lo, halo, CinP, CoutP);
     return set_check_launch("set_conv1d(bf16)");
 }
 

@@ -117,6 +117,46 @@ def test_conv1d_bf16_equals_fp32_conv_of_rounded_operands(dev, case):
     assert _rel(out, (prev + want) / 3.0) < 1e-5
 
 
+UNIT_CASES = [
+    # B, Cin, Cout, K, dil, pad, T, extras: the 16-byte-unit input staging of conv1d_bf16_kernel (T % 4 == 0, Cin % 4 == 0, halo <= 16)
+    (2, 192, 768, 9, 1, 4, 800, dict()),                                   # CampNet FFN conv
+    (2, 768, 192, 9, 1, 8, 800, dict(act="relu")),                         # ... causal ("LEFT") padding
+    (2, 192, 384, 5, 1, 2, 800, dict(alpha=5 ** -0.5, act="gelu")),        # encoder conv: tile starts 2 frames off a quad
+    (2, 256, 512, 3, 1, 1, 300, dict(chan_add=True, res=True)),            # DiffNet dilated conv, per-channel add
+    (2, 256, 512, 3, 4, 4, 132, dict(chan_add=True)),
+    (3, 100, 72, 3, 1, 1, 260, dict(pro="lrelu", pro_param=0.1)),          # partial channel chunk (100 of 128), a 4-frame second tile
+    (2, 128, 128, 7, 2, 6, 200, dict(pro="div", pro_param=3.0, mask=True)),
+    (1, 36, 200, 5, 1, 2, 4, dict()),                                      # T = one quad
+]
+
+
+@pytest.mark.parametrize("case", UNIT_CASES)
+def test_conv1d_bf16_unit_staging_equals_the_per_frame_staging_bit_for_bit(dev, case, monkeypatch):
+    """conv1d_bf16_kernel<..., VEC = true> (input in 16-byte units: 4 frames of a channel per load) writes the same bf16 values to the
+    same LDS cells as the one-frame-per-load form: torch.equal; and both equal the conv of the rounded operands."""
+    from set_amd import ops
+    B, Cin, Cout, K, dil, pad, T, ex = case
+    g = torch.Generator().manual_seed(Cin + Cout + K + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / math.sqrt(Cin * K)
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(B, Cout, T, generator=g) if ex.get("res") else None
+    mask = (torch.rand(B, T, generator=g) > 0.3).float() if ex.get("mask") else None
+    add = torch.randn(B, Cin, generator=g) if ex.get("chan_add") else None
+    wd = w.to(dev)
+    cw = ops.ConvWeight(lambda: wd, Cout, Cin, K)
+    kw = {k: ex[k] for k in ("pro", "pro_param", "act", "alpha") if k in ex}
+    outs = {}
+    for units in ("0", "1"):
+        monkeypatch.setenv("SET_AMD_CONV_BF16_UNITS", units)
+        outs[units] = ops.conv1d(x.to(dev), cw, b.to(dev), dil=dil, pad=pad, in_chan_add=None if add is None else add.to(dev),
+                                 res=None if res is None else res.to(dev), mask=None if mask is None else mask.to(dev), impl="bf16", **kw)
+        torch.cuda.synchronize()
+    assert torch.equal(outs["0"], outs["1"])
+    if pad == dil * (K - 1) // 2:
+        assert _rel(outs["1"], _ref_conv(x, w, b, add, res, mask, K, dil, ex)) < 1e-5
+
+
 @pytest.mark.parametrize("case", CASES[:9])
 def test_conv1d_bf16_backward_equals_rounded_operand_gradients(dev, case, bf16):
     """dgrad = conv of the (bf16-rounded) output gradient with the (bf16-rounded) transposed weights; wgrad = products of
