@@ -514,7 +514,7 @@ static int launch_conv_bf16(const SetConv1dArgs &a, int lo, int halo, hipStream_
     static bool attr_set = false;
     if (!attr_set) {
         SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1d_bf16_kernel<WM, WN, KCH, TGM, HALO, ADD, VEC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "conv bf16 attr");
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), "conv bf16 attr");  // (two blocks per CU)
         attr_set = true;
     }
     if (lds > 96 * 1024) return set_fail(SET_E_UNSUPPORTED, "set_conv1d(bf16)", "tile does not fit LDS");
@@ -1246,7 +1246,8 @@ int set_conv1d_bf16_dispatch(const SetConv1dArgs &a, hipStream_t s) {
                       : launch_conv_bf16<2, 2, 64, 1, false, false>(a, lo, halo, s);
     }
     // taps per stage: 5 and 9 taps (the predictor / FFN convs) are 1 and 2 stages per 32-channel chunk with 5 taps per stage, 2 and 3
-    // with 4 -- these convs wait on their stage round trips, not on MFMAs (tools/small_conv_probe.py)
+    // with 4 -- these convs wait on their stage round trips, not on MFMAs (tools/small_conv_probe.py); all 9 taps in one stage of the
+    // 64-row blocks (46 KB of weights per stage): 118 vs 125 us on 768 -> 192 at 12,800 frames, not kept (profiles/r06_conv_tg9_ab.log)
     if (a.K == 5 || a.K > 8)
         return narrow ? launch_conv_bf16<1, 4, 32, 5, true, true>(a, lo, halo, s) : launch_conv_bf16<2, 2, 32, 5, true, true>(a, lo, halo, s);
     return narrow ? launch_conv_bf16<1, 4, 32, 4, true, true>(a, lo, halo, s)
