@@ -15,7 +15,7 @@ KERNEL_SOURCES = ["speech-editing-toolkit_amd/csrc/diffnet_bf16.hip", "speech-ed
                   "speech-editing-toolkit_amd/csrc/common.h", "speech-editing-toolkit_amd/csrc/rows_sum.h",
                   "speech-editing-toolkit_amd/csrc/train.hip", "speech-editing-toolkit_amd/csrc/conv1d.hip",
                   "speech-editing-toolkit_amd/autograd_ops.py"]
-FAMILIES = ["diffnet_layer_bwd_bf16_kernel", "diffnet_layer_fwd_bf16_kernel", "conv1d_wgrad3_bf16_kernel", "conv1d_wgrad_bf16_kernel",
+FAMILIES = ["diffnet_layer_bwd_bf16_kernel", "diffnet_layer_fwd_bf16_kernel", "conv1d_wgrad3u_bf16_kernel", "conv1d_wgrad3_bf16_kernel", "conv1d_wgrad_bf16_kernel",
             "conv1d_bf16_kernel", "conv1x1_oneshot_bf16_kernel", "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn_fwd_kernel",
             # fp32 step (round 6: the reference's default precision had no PMC figure): the two generic fp32 MFMA conv kernels, the Winograd stack
             "conv1d_mfma_v2_kernel", "conv1d_mfma_kernel", "diffnet_stack_wino_kernel"]
