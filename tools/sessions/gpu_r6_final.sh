@@ -6,7 +6,7 @@
 #   3. PMC passes of the headline kernel -> pmc_x3.json; of the bf16 layer groups -> pmc_bf16_layers.json; kernel stats of the inference loop
 #   4. full -m gpu suite, smoke(), the driver's default bench command with its wall time (quoting the PMC files of this very run)
 set -u
-cd "$GRAFT_REPO_ROOT"; OUT=gpurun_out/r06; mkdir -p $OUT; export TMPDIR=/tmp; R="$GRAFT_REPO_ROOT"
+cd "$GRAFT_REPO_ROOT"; OUT=gpurun_out/r06; mkdir -p $OUT gpurun_out; export TMPDIR=/tmp; R="$GRAFT_REPO_ROOT"
 pmc() {  # tag model counter dtype
   rm -rf $OUT/pmc_$1_$3
   (cd /tmp && timeout 300 rocprofv3 --pmc $3 --kernel-trace --output-format csv -d "$R/$OUT/pmc_$1_$3" -o pmc -- python "$R/bench.py" --mode train --model $2 --dtype ${4:-bf16} --steps 3 --warmup 2 > "$R/$OUT/pmc_$1_$3.log" 2>&1)
@@ -30,7 +30,7 @@ python tools/pmc_train_summary.py $OUT/pmc_train.json spec_denoiser_bf16 "$FS" "
     spec_denoiser_f32 "$FF" "$WF" $OUT/train_f32_kernel_stats.csv | head -40
 find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 cp $OUT/pmc_train.json profiles/r06_pmc_train.json   # so that the bench line below quotes it
-TILE=128 NLS=10 bash tools/sessions/gpu_pmc_bf16_layers.sh > $OUT/pmc_bf16_t128.log 2>&1; cp gpurun_out/pmc_bf16_layers_128.json $OUT/pmc_bf16_layers.json
+TILE=128 NLS=10 bash tools/sessions/gpu_pmc_bf16_layers.sh > $OUT/pmc_bf16_t128.log 2>&1; cp gpurun_out/pmc_bf16_layers_128.json $OUT/pmc_bf16_layers.json; cp $OUT/pmc_bf16_layers.json profiles/r06_pmc_bf16_layers.json   # quoted by the bench line below
 # headline kernel PMC + kernel stats of the inference loop
 rm -rf $OUT/pmc_x3_* $OUT/trace_infer
 for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/$OUT/pmc_x3_$c" -o pmc -- python "$R/tools/x3_phase_probe.py" > "$R/$OUT/pmc_x3_$c.log" 2>&1); done
