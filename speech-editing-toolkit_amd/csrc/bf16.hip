@@ -554,6 +554,19 @@ __device__ __forceinline__ unsigned buf_load_raw16(rsrc_t r, unsigned voff, unsi
     return (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 0);
 }
 
+// A bf16 operand in HBM (GB16 / XB16, the tensors the fused DiffNet layer kernels hand over) is CHANNEL-QUAD INTERLEAVED: element (c, t) of a
+// batch slice at byte ((c >> 2) T + t) 8 + (c & 3) 2 (diffnet_bf16.hip).  q4_row / q4_frame: scalar / per-lane parts of that offset.
+__device__ __forceinline__ unsigned q4_row(int c, int T) { return (unsigned)((c >> 2) * T) * 8u + (unsigned)(c & 3) * 2u; }
+// 8 frames x 4 channels (four 16-byte units of 2 frames x 4 channels, consecutive in memory) -> channel c's 8 frames as one 16-byte row piece
+template <int N>
+__device__ __forceinline__ u32x4 q4_channel(const unsigned (&u)[N], int c) {
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)  // unit k: dwords {f0: c0 c1 | c2 c3, f1: c0 c1 | c2 c3}
+        o[k] = __builtin_amdgcn_perm(u[4 * k + 2 + (c >> 1)], u[4 * k + (c >> 1)], (c & 1) ? 0x07060302u : 0x05040100u);
+    return o;
+}
+
 // GB16 / XB16: the operand already is bf16 in HBM (saved activations / gradients of the fused layer kernels): its bits
 // go to LDS unchanged (no prologue, no per-channel add on such an operand).
 template <bool GB16, bool XB16, bool GU = false, bool XU = false>  // GU / XU: that operand is copied in 16-byte units (host: wgrad_units_ok)
@@ -600,16 +613,16 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
     const int urow4 = tid >> 4, ucol4 = tid & 15;   // fp32 units: 16 per row, 16 rows per pass
     auto issue = [&](int ch) {
         const int b = ch / a.n_chunks_t, t0 = (ch % a.n_chunks_t) * WGB_KT;
-        const unsigned vg = (unsigned)min(t0 + sk, a.T - 1) * GE;
-        const unsigned vx = (unsigned)min(max(t0 + sk + shift, 0), a.T_in - 1) * XE;
+        const unsigned vg = (unsigned)min(t0 + sk, a.T - 1) * (GB16 ? 8u : 4u);  // (bf16: quad-interleaved, 8 bytes per frame of a channel quad)
+        const unsigned vx = (unsigned)min(max(t0 + sk + shift, 0), a.T_in - 1) * (XB16 ? 8u : 4u);
         const rsrc_t d_g = make_rsrc(reinterpret_cast<const unsigned char *>(a.g) + (int64_t)b * a.Cout * a.T * GE);
         const rsrc_t d_x = make_rsrc(reinterpret_cast<const unsigned char *>(a.x) + (int64_t)b * a.Cin * a.T_in * XE);
         const rsrc_t d_a = make_rsrc(has_add ? a.chan_add + (int64_t)b * a.Cin : reinterpret_cast<const float *>(a.x));
-        if constexpr (fastg && GB16) {  // 16 bytes = 8 frames of one row per load: 4 loads per thread instead of 32 two-byte ones
+        if constexpr (fastg && GB16) {  // thread = (channel quad urow, 8 frames ucol): four consecutive 16-byte units (2 frames x 4 channels each)
+            const unsigned vo = (unsigned)(min((co0 >> 2) + urow, (a.Cout >> 2) - 1) * a.T + min(t0 + 8 * ucol, a.T - 8)) * 8u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const unsigned vo = (unsigned)(min(co0 + urow + 32 * q, a.Cout - 1) * a.T + min(t0 + 8 * ucol, a.T - 8)) * 2u;
-                const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_g, (int)vo, 0, 0);
+                const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_g, (int)(vo + 16u * q), 0, 0);
                 gv[4 * q] = v[0]; gv[4 * q + 1] = v[1]; gv[4 * q + 2] = v[2]; gv[4 * q + 3] = v[3];
             }
         } else if constexpr (fastg) {  // fp32: 16 bytes = 4 frames
@@ -622,15 +635,15 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
         } else {
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
-                const unsigned so = (unsigned)(min(co0 + sr0 + 4 * j, a.Cout - 1) * a.T) * GE;
-                gv[j] = GB16 ? buf_load_raw16(d_g, vg, so) : buf_load_raw(d_g, vg, so);
+                const int gr = min(co0 + sr0 + 4 * j, a.Cout - 1);
+                gv[j] = GB16 ? buf_load_raw16(d_g, vg, q4_row(gr, a.T)) : buf_load_raw(d_g, vg, (unsigned)(gr * a.T) * 4u);
             }
         }
         if constexpr (fastx && XB16) {
+            const unsigned vo = (unsigned)(min((ci0 >> 2) + urow, (a.Cin >> 2) - 1) * a.T_in + min(t0 + 8 * ucol, a.T_in - 8)) * 8u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const unsigned vo = (unsigned)(min(ci0 + urow + 32 * q, a.Cin - 1) * a.T_in + min(t0 + 8 * ucol, a.T_in - 8)) * 2u;
-                const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_x, (int)vo, 0, 0);
+                const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_x, (int)(vo + 16u * q), 0, 0);
                 xv[4 * q] = v[0]; xv[4 * q + 1] = v[1]; xv[4 * q + 2] = v[2]; xv[4 * q + 3] = v[3];
             }
         } else if constexpr (fastx) {  // fp32: 16 bytes = 4 frames; the per-channel add of the unit's row rides along (dummy address without one)
@@ -646,7 +659,7 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 const int cic = min(ci0 + sr0 + 4 * j, a.Cin - 1);
-                xv[j] = XB16 ? buf_load_raw16(d_x, vx, (unsigned)(cic * a.T_in) * XE) : buf_load_raw(d_x, vx, (unsigned)(cic * a.T_in) * XE);
+                xv[j] = XB16 ? buf_load_raw16(d_x, vx, q4_row(cic, a.T_in)) : buf_load_raw(d_x, vx, (unsigned)(cic * a.T_in) * 4u);
                 if constexpr (!XB16) av[j] = buf_load(d_a, 0u, (unsigned)cic * 4u);
             }
         }
@@ -658,11 +671,12 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
         const bool tv = t < a.T, tiv = tv && ti >= 0 && ti < a.T_in;
         if constexpr (fastg && GB16) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = urow + 32 * q;
-                const bool ok = t0 + 8 * ucol < a.T && co0 + row < a.Cout;  // T % 8 == 0: a unit is entirely inside or outside
+            for (int c = 0; c < 4; ++c) {  // the 8 frames of channel 4 urow + c, cut out of the thread's 8 frames x 4 channels
+                const int row = 4 * urow + c;
+                const bool ok = t0 + 8 * ucol < a.T && co0 + row < a.Cout;  // T % 8 == 0, Cout % 4 == 0: entirely inside or outside
+                const u32x4 w = q4_channel(gv, c);
                 u32x4 v;
-                v[0] = ok ? gv[4 * q] : 0u; v[1] = ok ? gv[4 * q + 1] : 0u; v[2] = ok ? gv[4 * q + 2] : 0u; v[3] = ok ? gv[4 * q + 3] : 0u;
+                v[0] = ok ? w[0] : 0u; v[1] = ok ? w[1] : 0u; v[2] = ok ? w[2] : 0u; v[3] = ok ? w[3] : 0u;
                 *reinterpret_cast<u32x4 *>(Gs + row * WGB_ROWB + ucol * 16) = v;
             }
         } else if constexpr (fastg) {
@@ -681,11 +695,12 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad_bf16_kernel(WgradBf16Args
         }
         if constexpr (fastx && XB16) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = urow + 32 * q;
+            for (int c = 0; c < 4; ++c) {
+                const int row = 4 * urow + c;
                 const bool ok = t0 + 8 * ucol < a.T && t0 + 8 * ucol < a.T_in && ci0 + row < a.Cin;
+                const u32x4 w = q4_channel(xv, c);
                 u32x4 v;
-                v[0] = ok ? xv[4 * q] : 0u; v[1] = ok ? xv[4 * q + 1] : 0u; v[2] = ok ? xv[4 * q + 2] : 0u; v[3] = ok ? xv[4 * q + 3] : 0u;
+                v[0] = ok ? w[0] : 0u; v[1] = ok ? w[1] : 0u; v[2] = ok ? w[2] : 0u; v[3] = ok ? w[3] : 0u;
                 *reinterpret_cast<u32x4 *>(Xs + row * WGB_ROWB + ucol * 16) = v;
             }
         } else if constexpr (fastx) {
@@ -802,24 +817,24 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad3_bf16_kernel(WgradBf16Arg
     const int urow = tid >> 3, ucol = tid & 7;
     auto issue = [&](int ch) {
         const int b = ch / a.n_chunks_t, t0 = (ch % a.n_chunks_t) * WGB_KT;
-        const unsigned vg = (unsigned)min(t0 + sk, a.T - 1) * GE;
+        const unsigned vg = (unsigned)min(t0 + sk, a.T - 1) * (GB16 ? 8u : 4u);  // (bf16: quad-interleaved)
         const unsigned va = (unsigned)min(max(t0 + sh0 + sk, 0), a.T_in - 1) * 4u;
         const unsigned vb = (unsigned)min(max(t0 + sh0 + 64 + sk, 0), a.T_in - 1) * 4u;
         const rsrc_t d_g = make_rsrc(reinterpret_cast<const unsigned char *>(a.g) + (int64_t)b * a.Cout * a.T * GE);
         const rsrc_t d_x = make_rsrc(reinterpret_cast<const float *>(a.x) + (int64_t)b * a.Cin * a.T_in);
         const rsrc_t d_a = make_rsrc(has_add ? a.chan_add + (int64_t)b * a.Cin : reinterpret_cast<const float *>(a.x));
         if constexpr (fastg) {  // (see conv1d_wgrad_bf16_kernel: 16-byte units of the bf16 output gradient)
+            const unsigned vo = (unsigned)(min((co0 >> 2) + urow, (a.Cout >> 2) - 1) * a.T + min(t0 + 8 * ucol, a.T - 8)) * 8u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const unsigned vo = (unsigned)(min(co0 + urow + 32 * q, a.Cout - 1) * a.T + min(t0 + 8 * ucol, a.T - 8)) * 2u;
-                const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_g, (int)vo, 0, 0);
+                const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_g, (int)(vo + 16u * q), 0, 0);
                 gv[4 * q] = v[0]; gv[4 * q + 1] = v[1]; gv[4 * q + 2] = v[2]; gv[4 * q + 3] = v[3];
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
-                const unsigned so = (unsigned)(min(co0 + sr0 + 4 * j, a.Cout - 1) * a.T) * GE;
-                gv[j] = GB16 ? buf_load_raw16(d_g, vg, so) : buf_load_raw(d_g, vg, so);
+                const int gr = min(co0 + sr0 + 4 * j, a.Cout - 1);
+                gv[j] = GB16 ? buf_load_raw16(d_g, vg, q4_row(gr, a.T)) : buf_load_raw(d_g, vg, (unsigned)(gr * a.T) * 4u);
             }
         }
 #pragma unroll
@@ -837,11 +852,12 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad3_bf16_kernel(WgradBf16Arg
         const bool va = fa >= 0 && fa < a.T_in, vb = fb >= 0 && fb < a.T_in;
         if constexpr (fastg) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = urow + 32 * q;
+            for (int c = 0; c < 4; ++c) {
+                const int row = 4 * urow + c;
                 const bool ok = t0 + 8 * ucol < a.T && co0 + row < a.Cout;
+                const u32x4 w = q4_channel(gv, c);
                 u32x4 v;
-                v[0] = ok ? gv[4 * q] : 0u; v[1] = ok ? gv[4 * q + 1] : 0u; v[2] = ok ? gv[4 * q + 2] : 0u; v[3] = ok ? gv[4 * q + 3] : 0u;
+                v[0] = ok ? w[0] : 0u; v[1] = ok ? w[1] : 0u; v[2] = ok ? w[2] : 0u; v[3] = ok ? w[3] : 0u;
                 *reinterpret_cast<u32x4 *>(Gs + row * WGB_ROWB + ucol * 16) = v;
             }
         } else {
@@ -1083,17 +1099,19 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad3u_bf16_kernel(WgradBf16Ar
     int xr[XQ], xc[XQ];
 #pragma unroll
     for (int q = 0; q < XQ; ++q) { const int u = tid + 256 * q; xr[q] = u / XU_ROW; xc[q] = u - xr[q] * XU_ROW; }
-    u32x4 gv[4], xv[XQ];
+    unsigned gv[16];
+    u32x4 xv[XQ];
     float av[XQ];
     auto issue = [&](int ch) {
         const int b = ch / a.n_chunks_t, t0 = (ch % a.n_chunks_t) * WGB_KT;
         const rsrc_t d_g = make_rsrc(reinterpret_cast<const unsigned char *>(a.g) + (int64_t)b * a.Cout * a.T * 2u);
         const rsrc_t d_x = make_rsrc(reinterpret_cast<const float *>(a.x) + (int64_t)b * a.Cin * a.T_in);
         const rsrc_t d_a = make_rsrc(has_add ? a.chan_add + (int64_t)b * a.Cin : reinterpret_cast<const float *>(a.x));
+        const unsigned vog = (unsigned)(min((co0 >> 2) + urow, (a.Cout >> 2) - 1) * a.T + min(t0 + 8 * ucol, a.T - 8)) * 8u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned vo = (unsigned)(min(co0 + urow + 32 * q, a.Cout - 1) * a.T + min(t0 + 8 * ucol, a.T - 8)) * 2u;
-            gv[q] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_g, (int)vo, 0, 0);
+        for (int q = 0; q < 4; ++q) {  // (quad-interleaved G: channel quad urow, 8 frames ucol = four consecutive 16-byte units)
+            const u32x4 v = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(d_g, (int)(vog + 16u * q), 0, 0);
+            gv[4 * q] = v[0]; gv[4 * q + 1] = v[1]; gv[4 * q + 2] = v[2]; gv[4 * q + 3] = v[3];
         }
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
@@ -1106,12 +1124,13 @@ __global__ void __launch_bounds__(256, 2) conv1d_wgrad3u_bf16_kernel(WgradBf16Ar
     auto commit = [&](int ch) {
         const int t0 = (ch % a.n_chunks_t) * WGB_KT;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = urow + 32 * q;
-            const bool ok = t0 + 8 * ucol < a.T && co0 + row < a.Cout;  // T % 8 == 0: a unit is entirely inside or outside
+        for (int c = 0; c < 4; ++c) {
+            const int row = 4 * urow + c;
+            const bool ok = t0 + 8 * ucol < a.T && co0 + row < a.Cout;  // T % 8 == 0, Cout % 4 == 0: entirely inside or outside
+            const u32x4 w = q4_channel(gv, c);
             u32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ok ? gv[q][e] : 0u;
+            for (int e = 0; e < 4; ++e) v[e] = ok ? w[e] : 0u;
             *reinterpret_cast<u32x4 *>(Gs + row * WGB_ROWB + ucol * 16) = v;
         }
 #pragma unroll
@@ -1331,6 +1350,8 @@ static int wgrad_bf16_launch(const void *g, const void *x, const float *chan_add
                              int64_t x_gs, int64_t add_gs, int64_t dw_gs, int S_plain, int S_taps3, hipStream_t s) {
     const int64_t n = (int64_t)Cout * Cin * K;
     const bool g16 = dtype != SET_DTYPE_BF16, x16 = dtype == SET_DTYPE_BF16_G16_X16;
+    if ((g16 && Cout % 4) || (x16 && Cin % 4))  // bf16 operands are channel-quad interleaved (see q4_row)
+        return set_fail(SET_E_UNSUPPORTED, "set_conv1d_wgrad_det(bf16 operand)", "channel count of a bf16 operand must be a multiple of 4");
     WgradBf16Args a;
     a.g = g; a.x = x; a.chan_add = chan_add; a.partial = scratch;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.K = K; a.dil = dil; a.pad = pad; a.T = T; a.T_in = T_in; a.pro = pro;

@@ -247,6 +247,43 @@ def test_wgrad_all_taps_kernel_equals_rounded_operand_products(dev, case, monkey
     assert _rel(outs[1], 2 * want) < 2e-5
 
 
+def _q4(t):
+    """[B, C, T] -> the channel-quad-interleaved storage [B][C / 4][T][4] the bf16 operands of the weight-gradient kernels use
+    (csrc/diffnet_bf16.hip: what the fused layer kernels write); same shape label, other memory order."""
+    B, C, T = t.shape
+    return t.reshape(B, C // 4, 4, T).transpose(2, 3).contiguous().view(B, C, T)
+
+
+Q4_WGRAD_CASES = [
+    # B, Cin, Cout, K, dil, T, bf16 X too: every loader of a bf16 operand (16-byte units / element-wise, 1 tap / 3 taps in three copies / one copy)
+    (2, 256, 512, 1, 1, 800, True),    # output projection: G and X bf16, 16-byte units
+    (3, 192, 512, 1, 1, 77, False),    # conditioner projection, ragged T: element-wise G
+    (2, 100, 200, 1, 1, 136, True),    # partial row tiles
+    (3, 256, 512, 1, 1, 77, True),     # ragged T, both operands element-wise
+    (2, 256, 512, 3, 1, 77, False),    # 3 taps, ragged T: three-copy kernel, element-wise G
+    (2, 64, 132, 3, 3, 72, False),     # 3 taps, dilation 3: three-copy kernel, G in units
+    (2, 256, 512, 3, 2, 264, False),   # one-copy kernel
+]
+
+
+@pytest.mark.parametrize("case", Q4_WGRAD_CASES)
+def test_wgrad_reads_bf16_operands_in_the_quad_interleaved_layout(dev, case):
+    from set_amd import _lib, autograd_ops as A
+    B, Cin, Cout, K, dil, T, x16 = case
+    g = torch.Generator().manual_seed(Cin + Cout + K + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    gy = torch.randn(B, Cout, T, generator=g)
+    pad = dil * (K - 1) // 2
+    xp = F.pad(_r(x), (pad, pad))
+    want = torch.stack([torch.einsum("bot,bit->oi", _r(gy), xp[:, :, k * dil:k * dil + T]) for k in range(K)], dim=-1)
+    gd = _q4(gy.to(dev).to(torch.bfloat16))
+    xd = _q4(x.to(dev).to(torch.bfloat16)) if x16 else x.to(dev)
+    dw = torch.zeros(Cout, Cin, K, device=dev)
+    A.conv_wgrad(gd, xd, None, dw, B, Cin, Cout, K, dil, pad, T, T, dtype=_lib.DTYPE_BF16_G16_X16 if x16 else _lib.DTYPE_BF16_G16)
+    torch.cuda.synchronize()
+    assert _rel(dw, want) < 2e-5
+
+
 WGRAD3_UNIT_CASES = [
     # B, Cin, Cout, dil, T, per-channel add: the one-copy 3-tap weight-gradient kernel (bf16 output gradient, fp32 conv input in 16-byte units)
     (4, 256, 512, 1, 800, True),    # the DiffNet dilated conv of the training step
@@ -255,7 +292,7 @@ WGRAD3_UNIT_CASES = [
     (2, 256, 512, 8, 800, True),
     (3, 100, 200, 1, 136, True),    # partial row tiles, a last chunk of 8 frames
     (2, 64, 128, 8, 64, False),     # exactly one chunk: every halo frame is padding
-    (5, 72, 130, 2, 72, True),
+    (5, 72, 132, 2, 72, True),
 ]
 
 
@@ -273,7 +310,7 @@ def test_wgrad3_one_copy_kernel_equals_the_three_copy_kernel_bit_for_bit(dev, ca
     xin = x if add is None else x + add[:, :, None]
     xp = F.pad(_r(xin), (dil, dil))
     want = torch.stack([torch.einsum("bot,bit->oi", _r(gy), xp[:, :, k * dil:k * dil + T]) for k in range(3)], dim=-1)
-    xd, gd = x.to(dev), gy.to(dev).to(torch.bfloat16)
+    xd, gd = x.to(dev), _q4(gy.to(dev).to(torch.bfloat16))
     ad = None if add is None else add.to(dev)
     outs = {}
     for units in ("0", "1"):

@@ -26,9 +26,14 @@ def timed(fn, n=20):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-dy16 = torch.randn(L_, B, 2 * C_, T, generator=g).to(dev).to(torch.bfloat16)
-do16 = torch.randn(L_, B, 2 * C_, T, generator=g).to(dev).to(torch.bfloat16)
-z16 = torch.randn(L_, B, C_, T, generator=g).to(dev).to(torch.bfloat16)
+def q4(t):  # bf16 operands are channel-quad interleaved in memory: [..][C / 4][T][4] (csrc/diffnet_bf16.hip)
+    s = t.shape
+    return t.reshape(*s[:-2], s[-2] // 4, 4, s[-1]).transpose(-1, -2).contiguous().view(s)
+
+
+dy16 = q4(torch.randn(L_, B, 2 * C_, T, generator=g).to(dev).to(torch.bfloat16))
+do16 = q4(torch.randn(L_, B, 2 * C_, T, generator=g).to(dev).to(torch.bfloat16))
+z16 = q4(torch.randn(L_, B, C_, T, generator=g).to(dev).to(torch.bfloat16))
 x_all = torch.randn(L_, B, C_, T, generator=g).to(dev)
 dl_all = torch.randn(L_, B, C_, generator=g).to(dev)
 cond = torch.randn(B, H, T, generator=g).to(dev)
