@@ -206,6 +206,32 @@ __global__ void __launch_bounds__(256) conv_epilogue_bwd_kernel(const float *dy,
     g[i] = v * alpha;
 }
 
+// four consecutive frames per thread (T % 4 == 0, 16-byte aligned operands): the same arithmetic per element, 16-byte accesses and one
+// index division per four elements (round 6: the one-element forms of these elementwise kernels ran at 2 - 4 TB/s)
+__global__ void __launch_bounds__(256) conv_epilogue_bwd_vec4_kernel(const float *dy, const float *y, const float *mask, float *g,
+                                                                     int64_t n4, int64_t CT, int T, int act, float alpha) {
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= n4) return;
+    const int64_t i = i4 * 4;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(dy + i);
+    if (mask) {
+        const int64_t b = i / CT;
+        const int t = (int)(i % T);
+        const f32x4 m = *reinterpret_cast<const f32x4 *>(mask + b * T + t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= m[e];
+    }
+    if (act == SET_ACT_RELU) {
+        const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (!(yv[e] > 0.0f)) v[e] = 0.0f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] * alpha;
+    *reinterpret_cast<f32x4 *>(g + i) = v;
+}
+
 // ---- activations with saved pre-activation z ----------------------------------------------------------------
 __device__ __forceinline__ float dev_act_grad(float z, int act, float p) {
     switch (act) {
@@ -243,6 +269,30 @@ __global__ void __launch_bounds__(256) act_bwd_scaled_kernel(const float *z, con
         const float t = dy[i] * dev_act_grad(z[i], act, p);
         dz[i] = t * scale;
     }
+}
+
+__global__ void __launch_bounds__(256) act_fwd_vec4_kernel(const float *z, float *y, int64_t n4, int act, float p) {
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= n4) return;
+    const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + i4 * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = dev_act(zv[e], act, p);
+    *reinterpret_cast<f32x4 *>(y + i4 * 4) = o;
+}
+// scaled != 0: dz = (dy act'(z)) scale (act_bwd_scaled_kernel's two roundings), else dz = dy act'(z)
+__global__ void __launch_bounds__(256) act_bwd_vec4_kernel(const float *z, const float *dy, float *dz, int64_t n4, int act, float p,
+                                                           int scaled, float scale) {
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= n4) return;
+    const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + i4 * 4), dv = *reinterpret_cast<const f32x4 *>(dy + i4 * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = dv[e] * dev_act_grad(zv[e], act, p);
+        o[e] = scaled ? t * scale : t;
+    }
+    *reinterpret_cast<f32x4 *>(dz + i4 * 4) = o;
 }
 
 // ---- gate / res-skip backward ---------------------------------------------------------------------------------
@@ -504,7 +554,7 @@ __device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_
     }
 }
 __global__ void __launch_bounds__(256) dropout_kernel(const float *x, float *y, int64_t n, float p, uint64_t seed,
-                                                      uint64_t offset, const uint64_t *seed_delta) {
+                                                      uint64_t offset, const uint64_t *seed_delta, int vec) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q * 4 >= n) return;
     if (seed_delta) seed += *seed_delta;  // set_rng_seed_delta: see randn_kernel
@@ -512,6 +562,17 @@ __global__ void __launch_bounds__(256) dropout_kernel(const float *x, float *y, 
     uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0x5eedu, 0u};
     philox_round(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     const float inv = 1.0f / (1.0f - p);
+    if (vec && q * 4 + 3 < n) {  // 16-byte aligned operands: one load, one store (same values)
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + q * 4);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float u = (float)(c[k] >> 8) * (1.0f / 16777216.0f);
+            o[k] = u >= p ? xv[k] * inv : 0.0f;
+        }
+        *reinterpret_cast<f32x4 *>(y + q * 4) = o;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int64_t i = q * 4 + k;
@@ -1194,23 +1255,36 @@ extern "C" int set_conv_epilogue_bwd(const float *dy, const float *y, const floa
                                      int32_t T, int32_t act, float alpha, void *stream) {
     SET_REQUIRE(dy && g && B > 0 && C > 0 && T > 0 && (act == SET_ACT_NONE || (act == SET_ACT_RELU && y)),
                 "set_conv_epilogue_bwd");
-    hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0,
-                       (hipStream_t)stream, dy, y, mask, g, B, C, T, act, alpha);
+    if (T % 4 == 0 && set_aligned16(dy, y, mask) && set_aligned16(g, g, g))
+        hipLaunchKernelGGL(conv_epilogue_bwd_vec4_kernel, dim3(set_blocks((int64_t)B * C * T / 4, 256)), dim3(256), 0, (hipStream_t)stream, dy, y,
+                           mask, g, (int64_t)B * C * T / 4, (int64_t)C * T, T, act, alpha);
+    else
+        hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3(set_blocks((int64_t)B * C * T, 256)), dim3(256), 0,
+                           (hipStream_t)stream, dy, y, mask, g, B, C, T, act, alpha);
     return set_check_launch("set_conv_epilogue_bwd");
 }
 extern "C" int set_act_fwd(const float *z, float *y, int64_t n, int32_t act, float p, void *stream) {
     SET_REQUIRE(z && y && n > 0, "set_act_fwd");
-    hipLaunchKernelGGL(act_fwd_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, z, y, n, act, p);
+    if (n % 4 == 0 && set_aligned16(z, y, y))
+        hipLaunchKernelGGL(act_fwd_vec4_kernel, dim3(set_blocks(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, z, y, n / 4, act, p);
+    else
+        hipLaunchKernelGGL(act_fwd_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, z, y, n, act, p);
     return set_check_launch("set_act_fwd");
 }
 extern "C" int set_act_bwd(const float *z, const float *dy, float *dz, int64_t n, int32_t act, float p, void *stream) {
     SET_REQUIRE(z && dy && dz && n > 0, "set_act_bwd");
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, z, dy, dz, n, act, p);
+    if (n % 4 == 0 && set_aligned16(z, dy, dz))
+        hipLaunchKernelGGL(act_bwd_vec4_kernel, dim3(set_blocks(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, z, dy, dz, n / 4, act, p, 0, 1.0f);
+    else
+        hipLaunchKernelGGL(act_bwd_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, z, dy, dz, n, act, p);
     return set_check_launch("set_act_bwd");
 }
 extern "C" int set_act_bwd_scaled(const float *z, const float *dy, float *dz, int64_t n, int32_t act, float p, float scale, void *stream) {
     SET_REQUIRE(z && dy && dz && n > 0, "set_act_bwd_scaled");
-    hipLaunchKernelGGL(act_bwd_scaled_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, z, dy, dz, n, act, p, scale);
+    if (n % 4 == 0 && set_aligned16(z, dy, dz))
+        hipLaunchKernelGGL(act_bwd_vec4_kernel, dim3(set_blocks(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, z, dy, dz, n / 4, act, p, 1, scale);
+    else
+        hipLaunchKernelGGL(act_bwd_scaled_kernel, dim3(set_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, z, dy, dz, n, act, p, scale);
     return set_check_launch("set_act_bwd_scaled");
 }
 extern "C" int set_gate_bwd(const float *y, const float *dz, float *dy, int32_t B, int32_t C, int32_t T, void *stream) {
@@ -1302,7 +1376,7 @@ extern "C" int set_expand_states_bwd(const int64_t *mel2ph, const float *dout, f
 extern "C" int set_dropout(const float *x, float *y, int64_t n, float p, uint64_t seed, uint64_t offset, void *stream) {
     SET_REQUIRE(x && y && n > 0 && p >= 0.0f && p < 1.0f, "set_dropout");
     hipLaunchKernelGGL(dropout_kernel, dim3(set_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, p,
-                       seed, offset, set_seed_delta_ptr());
+                       seed, offset, set_seed_delta_ptr(), set_aligned16(x, y, y) ? 1 : 0);
     return set_check_launch("set_dropout");
 }
 extern "C" int set_frame_weight(const float *target, float *w, int64_t frames, int32_t M, void *stream) {
