@@ -22,6 +22,9 @@ a = _lib.SetDiffnetLayerBf16Args()
 a.x_in, a.x_out, a.skip, a.cond, a.dstep, a.img = x.data_ptr(), xo.data_ptr(), sk.data_ptr(), cond.data_ptr(), dst.data_ptr(), img.data_ptr()
 a.b_dil, a.b_cond, a.b_out = (b.data_ptr() for b in bias)
 a.d_bs, a.d_cs, a.B, a.T, a.dil, a.first = Cc, 1, B, T, 1, 0
+if os.environ.get("TRAIN"):  # the training form: y / z saved in bf16 (quad-interleaved)
+    y16, z16 = torch.empty(B, 2 * Cc, T, dtype=torch.bfloat16, device=dev), torch.empty(B, Cc, T, dtype=torch.bfloat16, device=dev)
+    a.y16, a.z16 = y16.data_ptr(), z16.data_ptr()
 for it in range(3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
