@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(NT * 4, 1) diffnet_layer_fwd_bf16_kernel(SetDi
     unsigned char *xs = lds;                   // [XROWS][XR]   x + d, row j <-> frame t0 - d + j   (z overlays it: row j <-> t0 + j)
     unsigned char *cs = lds + XROWS * XR;      // [NT][CR]      cond,  row j <-> frame t0 + j
     float *dsh = reinterpret_cast<float *>(lds + XROWS * XR + NT * CR);  // [256] per-utterance step offsets
+    float *bsh = dsh + FC;                                                // [512] b_dil + b_cond | [512] b_out
     const unsigned T4 = 4u * (unsigned)T, T2 = 2u * (unsigned)T;
     const rsrc_t rx = make_rsrc(a.x_in + (int64_t)b * FC * T), rxo = make_rsrc(a.x_out + (int64_t)b * FC * T);
     const rsrc_t rsk = make_rsrc(a.skip + (int64_t)b * FC * T), rcd = make_rsrc(a.cond + (int64_t)b * FH * T);
@@ -262,6 +263,9 @@ __global__ void __launch_bounds__(NT * 4, 1) diffnet_layer_fwd_bf16_kernel(SetDi
     {
         const int f = tid % NT, cg = __builtin_amdgcn_readfirstlane(tid / NT);  // cg 0..3
         if (tid < FC) dsh[tid] = buf_load(rd, 0u, (unsigned)tid * 4u * (unsigned)a.d_cs);
+        // biases through LDS too (round 6): the accumulator starts read them as 16-byte LDS reads instead of 96 dependent 4-byte loads per lane
+        bsh[tid] = buf_load(rbd, 4u * (unsigned)tid, 0u) + buf_load(rbc, 4u * (unsigned)tid, 0u);
+        bsh[2 * FC + tid] = buf_load(rbo, 4u * (unsigned)tid, 0u);
         const int t = t0 - d + f;           // x row j = f
         const bool tvx = t >= 0 && t < T;
         const unsigned vox = 4u * (unsigned)min(max(t, 0), T - 1);
@@ -316,11 +320,12 @@ __global__ void __launch_bounds__(NT * 4, 1) diffnet_layer_fwd_bf16_kernel(SetDi
 #pragma unroll
     for (int rb = 0; rb < 2 * RBW; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned ur = (unsigned)(row0(rb) + urow(r));
-            const float bias = buf_load(rbd, lb, 4u * ur) + buf_load(rbc, lb, 4u * ur);
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bsh + row0(rb) + 8 * g4 + 4 * half);
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = bias;
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][4 * g4 + e] = bv[e];
         }
     __syncthreads();
     BF16_PHASE(1)
@@ -388,10 +393,12 @@ __global__ void __launch_bounds__(NT * 4, 1) diffnet_layer_fwd_bf16_kernel(SetDi
 #pragma unroll
     for (int rb = 0; rb < 2 * RBW; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float bias = buf_load(rbo, lb, 4u * (unsigned)(row0(rb) + urow(r)));
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bsh + 2 * FC + row0(rb) + 8 * g4 + 4 * half);
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][r] = rb < RBW ? bias + xres[rb % RBW][cb][r] : bias;
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb][4 * g4 + e] = rb < RBW ? bv[e] + xres[rb % RBW][cb][4 * g4 + e] : bv[e];
         }
     __syncthreads();
     BF16_PHASE(3)
@@ -1542,7 +1549,7 @@ extern "C" int set_diffnet_layer_fwd_bf16(const SetDiffnetLayerBf16Args *args, v
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "layer fwd bf16 attr");
         attr_set = true;
     }
-    const size_t ldsz = (size_t)(tile + 2 * a.dil) * XR + (size_t)tile * CR + FC * sizeof(float);
+    const size_t ldsz = (size_t)(tile + 2 * a.dil) * XR + (size_t)tile * CR + 5 * FC * sizeof(float);  // tiles, step offsets, the two bias vectors
     dim3 grid((a.T + tile - 1) / tile, a.B);
     hipStream_t st = (hipStream_t)stream;
     if (a.y16) hipLaunchKernelGGL((diffnet_layer_fwd_bf16_kernel<true, 128>), grid, dim3(512), ldsz, st, a);
