@@ -939,6 +939,18 @@ class _DiffNetStackFn(torch.autograd.Function):
         return (None, dx, dcond, dd, *flat)
 
 
+def _bf16_layer_pointers(dn, layers, imgs):
+    """[(image, b_dil, b_cond, b_out, dilation)] of the residual layers as integers, cached on the DiffNet while the tensors stay where they are
+    (parameters are views of the optimizer's flat buffer; the images are rebuilt in place)."""
+    key = (imgs[0].data_ptr(), imgs[-1].data_ptr(), layers[0].dilated_conv.bias.data_ptr(), layers[-1].output_projection.bias.data_ptr(), len(layers))
+    ent = getattr(dn, "_bf16_ptrs", None)
+    if ent is None or ent[0] != key:
+        ent = (key, [(imgs[l].data_ptr(), ly.dilated_conv.bias.data_ptr(), ly.conditioner_projection.bias.data_ptr(),
+                      ly.output_projection.bias.data_ptr(), int(ly.dilation)) for l, ly in enumerate(layers)])
+        dn._bf16_ptrs = ent
+    return ent[1]
+
+
 SWEEP_EVENTS = None  # bench.py sets a list: (start, end, launches) hipEvent pairs around the layer-backward sweep of every step
 
 
@@ -965,15 +977,19 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
         a.skip, a.cond = skip.data_ptr(), cond.data_ptr()
         a.d_bs, a.d_cs = dmat.stride(0), 1
         a.B, a.T = B, T
-        for l, layer in enumerate(layers):
-            a.x_in, a.x_out = x_all[l].data_ptr(), x_all[l + 1].data_ptr()
-            a.dstep = dmat.data_ptr() + 4 * l * C_
-            a.img = imgs[l].data_ptr()
-            a.b_dil, a.b_cond, a.b_out = (layer.dilated_conv.bias.data_ptr(), layer.conditioner_projection.bias.data_ptr(),
-                                          layer.output_projection.bias.data_ptr())
-            a.y16, a.z16 = y16[l].data_ptr(), z16[l].data_ptr()
-            a.dil, a.first = layer.dilation, int(l == 0)
-            check(L().set_diffnet_layer_fwd_bf16(C.byref(a), _stream()), "set_diffnet_layer_fwd_bf16")
+        # per-layer addresses as integers (a tensor index or an nn.Module attribute per operand and layer cost ~0.4 ms of host time per step
+        # in this loop and the backward sweep: the step is bound by the host's enqueue time)
+        x0, sx = x_all.data_ptr(), 4 * B * C_ * T
+        y0, z0, d0 = y16.data_ptr(), z16.data_ptr(), dmat.data_ptr()
+        per = _bf16_layer_pointers(dn, layers, imgs)
+        fn, st, ref = L().set_diffnet_layer_fwd_bf16, _stream(), C.byref(a)
+        for l in range(L_):
+            a.x_in, a.x_out = x0 + l * sx, x0 + (l + 1) * sx
+            a.dstep = d0 + 4 * l * C_
+            a.img, a.b_dil, a.b_cond, a.b_out, a.dil = per[l]
+            a.y16, a.z16 = y0 + l * sx, z0 + l * (sx // 2)  # bf16 [B][2C][T] and [B][C][T]
+            a.first = int(l == 0)
+            check(fn(ref, st), "set_diffnet_layer_fwd_bf16")
         ctx.dn, ctx.imgs = dn, imgs
         ctx.save_for_backward(cond, dmat, x_all, y16, z16)
         return skip
@@ -1016,7 +1032,24 @@ class _DiffNetStackBf16Fn(torch.autograd.Function):
         if SWEEP_EVENTS is not None:  # measurement hook (bench.py): hipEvents around the L launches of diffnet_layer_bwd_bf16_kernel
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        for l in range(L_ - 1, -1, -1):
+        if grouped:  # the sweep as 20 launches on integer addresses (see forward); everything else of this form happens after the loop
+            per = _bf16_layer_pointers(dn, layers, imgs)
+            dy0, do0, y0, s16 = dy16_all.data_ptr(), do16_all.data_ptr(), y16.data_ptr(), 2 * B * 2 * C_ * T
+            pb0, py0, pd0, sp = pdbo_all.data_ptr(), pdby_all.data_ptr(), pdd_all.data_ptr(), 4 * B * tiles_g * C_
+            dxp = (dx[0].data_ptr(), dx[1].data_ptr())
+            fn, st, ref = L().set_diffnet_layer_bwd_bf16, _stream(), C.byref(a)
+            a.dil = layers[0].dilation
+            curp = None
+            for l in range(L_ - 1, -1, -1):
+                a.dy16, a.do16, a.y16 = dy0 + l * s16, do0 + l * s16, y0 + l * s16
+                a.dx_out, a.img, a.dx = curp, per[l][0], dxp[l & 1]
+                a.part_dbo, a.part_dby, a.part_dd = pb0 + l * 2 * sp, py0 + l * 2 * sp, pd0 + l * sp
+                a.dcond_first = int(l == L_ - 1)
+                check(fn(ref, st), "set_diffnet_layer_bwd_bf16")
+                grads.append([None] * 6)
+                curp = dxp[l & 1]
+            cur = dx[0]
+        for l in (range(L_ - 1, -1, -1) if not grouped else ()):
             layer = layers[l]
             dil = layer.dilation
             tiles = L().set_diffnet_layer_bwd_bf16_tiles(T, dil)
