@@ -186,8 +186,26 @@ __device__ __forceinline__ void conv_bf16_epilogue(const SetConv1dArgs &a, const
 // VEC (round 6): the input tile is loaded in 16-byte units (4 frames of one channel; a thread owns 4 frames x 4 channels per unit = 4
 // loads, four 8-byte LDS writes) instead of one frame per load (NPASS * KCH / 2 four-byte loads per thread and chunk): the same values
 // in the same LDS cells.  Host: T_in, the strides and Cin multiples of 4, 16-byte aligned bases, halo <= 16 (launch_conv_bf16).
+// measurement build only (tools/build_exp.sh convprobe bf16.hip -DSET_CONV_PROBE=1; tools/conv_phase_probe.py): per-stage phase times of one
+// block of conv1d_bf16_kernel (s_memtime, 100 MHz) summed in registers, written once at the end.  Not in the shipped library.
+#ifndef SET_CONV_PROBE
+#define SET_CONV_PROBE 0
+#endif
+#if SET_CONV_PROBE
+__device__ uint64_t *g_conv_phase_buf = nullptr;
+extern "C" int set_debug_conv_phase_buffer(uint64_t *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_conv_phase_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#define CONV_PHASE(i) if (cprobe) { const uint64_t tn = __builtin_amdgcn_s_memtime(); cph[i] += tn - cprev; cprev = tn; }
+#else
+#define CONV_PHASE(i)
+#endif
 template <int WM, int WN, int KCH, int TGM, bool HALO, bool ADD, bool VEC = false>
 __global__ void __launch_bounds__(256, 2) conv1d_bf16_kernel(SetConv1dArgs a, int lo, int halo, int CinP, int CoutP) {
+#if SET_CONV_PROBE
+    const bool cprobe = g_conv_phase_buf && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 1 && threadIdx.x == 0;
+    uint64_t cph[6] = {0, 0, 0, 0, 0, 0}, cprev = __builtin_amdgcn_s_memtime();
+#endif
     static_assert(!VEC || KCH == 32, "16-byte input units: 32-channel stages");
     constexpr int BF_TG_MAX = TGM;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -280,12 +298,13 @@ __global__ void __launch_bounds__(256, 2) conv1d_bf16_kernel(SetConv1dArgs a, in
                         v = pro_c<kPro>(v, a.pro_param);
                         x[i] = ok ? v : 0.0f;
                     }
+                    // (no branch around the write: rows outside the tile go to a spare row behind it -- twelve exec-masked blocks, each with its
+                    // own wait, made the commit phase a third of a stage, profiles/r06_conv_phase_probe.log)
                     const int row = 4 * q + e - vsh;
-                    if (q < vNQ && row >= 0 && row < R) {
-                        u32x2 w;
-                        w[0] = pack_bf16(x[0], x[1]); w[1] = pack_bf16(x[2], x[3]);
-                        *reinterpret_cast<u32x2 *>(Bs + row * ROWB + cq * 8) = w;
-                    }
+                    const int rw = (q < vNQ && row >= 0 && row < R) ? row : R;
+                    u32x2 w;
+                    w[0] = pack_bf16(x[0], x[1]); w[1] = pack_bf16(x[2], x[3]);
+                    *reinterpret_cast<u32x2 *>(Bs + rw * ROWB + cq * 8) = w;
                 }
             }
             return;
@@ -351,9 +370,11 @@ __global__ void __launch_bounds__(256, 2) conv1d_bf16_kernel(SetConv1dArgs a, in
     stage_of(0, c0, tg0, tgn);
     issue_b(c0);
     issue_a(c0, tg0, tgn);
+    CONV_PHASE(0)  // prologue: first loads issued
     for (int s = 0; s < nstages; ++s) {
         stage_of(s, c0, tg0, tgn);
         __syncthreads();  // MFMAs of the previous stage are done with the tiles
+        CONV_PHASE(1)  // barrier 1
         if (tg0 == 0) {
             switch (a.pro) {
                 case SET_PRO_LRELU: commit_b(ic<SET_PRO_LRELU>{}, c0); break;
@@ -362,14 +383,10 @@ __global__ void __launch_bounds__(256, 2) conv1d_bf16_kernel(SetConv1dArgs a, in
             }
         }
         commit_a(c0, tgn);
+        CONV_PHASE(2)  // wait for the stage's loads + LDS writes
         __syncthreads();
-        if (s + 1 < nstages) {
-            int c1, tg1, tgn1;
-            stage_of(s + 1, c1, tg1, tgn1);
-            if (tg1 == 0) issue_b(c1);
-            issue_a(c1, tg1, tgn1);
-        }
-        for (int tl = 0; tl < tgn; ++tl) {  // (rolled: unrolled over the taps of a stage it ran 8 - 16 % slower, profiles/r06_conv_unroll_ab.log)
+        CONV_PHASE(3)  // barrier 2
+        auto mfma_tap = [&](int tl) {
             const int off = (tg0 + tl) * a.dil - a.pad - lo;  // >= 0: frame-row shift of this tap inside the B tile
             const unsigned char *ap = As + (tl * MB + wm * 64 + l31) * ROWB + half * 16;
             const unsigned char *bp = Bs + (wn * 64 + l31 + off) * ROWB + half * 16;
@@ -384,9 +401,24 @@ __global__ void __launch_bounds__(256, 2) conv1d_bf16_kernel(SetConv1dArgs a, in
                 acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
                 acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
             }
+        };
+        if (s + 1 < nstages) {
+            int c1, tg1, tgn1;
+            stage_of(s + 1, c1, tg1, tgn1);
+            if (tg1 == 0) issue_b(c1);
+            issue_a(c1, tg1, tgn1);
         }
+        CONV_PHASE(4)  // issue of the next stage's loads
+        // (rolled: unrolled over the taps of a stage it ran 8 - 16 % slower, profiles/r06_conv_unroll_ab.log; the next stage's loads issued in
+        // slices between the taps' MFMA groups instead of one burst behind the barrier: 5 - 10 % slower, profiles/r06_conv_sliced_issue_ab.log)
+        for (int tl = 0; tl < tgn; ++tl) mfma_tap(tl);
+        CONV_PHASE(5)  // fragment reads + MFMAs of the stage
     }
 
+#if SET_CONV_PROBE
+    CONV_PHASE(5)  // (the last stage's MFMAs land here; per stage they are accounted below)
+    if (cprobe) { for (int i = 0; i < 6; ++i) g_conv_phase_buf[i] = cph[i]; g_conv_phase_buf[6] = (uint64_t)nstages; }
+#endif
     conv_bf16_epilogue<WM, WN>(a, acc, b, t0, r0, wm, wn, half, l31);
 }
 
@@ -510,7 +542,7 @@ static int launch_conv_bf16(const SetConv1dArgs &a, int lo, int halo, hipStream_
     }
     constexpr int MB = 64 * WM, NB = 64 * WN, ROWB = KCH * 2 + 16, BF_TG_MAX = TGM;
     const int CinP = round_up_i(a.Cin, 32), CoutP = round_up_i(a.Cout, 128);
-    const size_t lds = (size_t)BF_TG_MAX * MB * ROWB + (size_t)(NB + halo) * ROWB;
+    const size_t lds = (size_t)BF_TG_MAX * MB * ROWB + (size_t)(NB + halo + (VEC ? 1 : 0)) * ROWB;  // (VEC: one spare row for the masked-out writes)
     static bool attr_set = false;
     if (!attr_set) {
         SET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1d_bf16_kernel<WM, WN, KCH, TGM, HALO, ADD, VEC>),
