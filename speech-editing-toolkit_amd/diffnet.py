@@ -137,8 +137,12 @@ class DiffNet(nn.Module):
         """Per-layer packed bf16 weight images of the fused training kernels (forward GEMM 1 / 2 and the three transposed
         images of the backward), re-rounded from the fp32 master weights whenever they change."""
         layers = list(self.residual_layers)
-        key = tuple((p.data_ptr(), p._version) for l in layers for p in
-                    (l.dilated_conv.weight, l.conditioner_projection.weight, l.output_projection.weight))
+        # the 60 weight tensors as a flat list, looked up once (module attribute chains cost ~1 us each: this key is computed every step)
+        ps = getattr(self, "_img16_params", None)
+        if ps is None or len(ps) != 3 * len(layers) or ps[0] is not layers[0].dilated_conv.weight or ps[-1] is not layers[-1].output_projection.weight:
+            ps = self._img16_params = [p for l in layers for p in (l.dilated_conv.weight, l.conditioner_projection.weight, l.output_projection.weight)]
+            self._img16_strides = None
+        key = tuple((p.data_ptr(), p._version) for p in ps)
         key = key + (ops.weights_epoch(),)
         if getattr(self, "_img16", None) is None or self._img16_key != key:
             from . import _lib
@@ -146,8 +150,11 @@ class DiffNet(nn.Module):
             dev = layers[0].dilated_conv.weight.device
             img = torch.empty(len(layers), n, dtype=torch.bfloat16, device=dev)
             from .autograd_ops import _uniform_stride
-            strides = [_uniform_stride([getattr(l, name).weight.detach() for l in layers])
-                       for name in ("dilated_conv", "conditioner_projection", "output_projection")]
+            # the layers' strides are a property of where the tensors live: recomputed when any address changes
+            addr = tuple(k[0] for k in key[:-1])
+            if self._img16_strides is None or self._img16_strides[0] != addr:
+                self._img16_strides = (addr, [_uniform_stride([p.detach() for p in ps[j::3]]) for j in range(3)])
+            strides = self._img16_strides[1]
             if all(st is not None for st in strides):  # (the flat optimizer's layout: every layer's tensors at one stride) one launch
                 l0 = layers[0]
                 _lib.check(_lib.lib().set_pack_diffnet_layers_bf16(

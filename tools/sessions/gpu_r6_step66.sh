@@ -1,0 +1,10 @@
+# bf16_layer_images: parameter list / strides cached (host time of the per-step image key): signature, tests, step
+mkdir -p gpurun_out
+python tools/train_grad_sha.py 2>&1 | grep -v amdgpu.ids
+python -m pytest tests/test_gpu_bf16.py tests/test_gpu_training.py -q -m gpu 2>&1 | tail -2
+for i in 1 2 3 4; do
+  python bench.py --mode train --dtype bf16 --steps 40 --warmup 5 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train', {k:round(d.get(k),3) for k in ('ms_per_step','host_enqueue_ms_per_step','loss')})"
+done
+python tools/host_profile.py 2>&1 | grep "host phases" | head -3
