@@ -939,6 +939,23 @@ class _DiffNetStackFn(torch.autograd.Function):
         return (None, dx, dcond, dd, *flat)
 
 
+class _SumLossesFn(torch.autograd.Function):
+    """total = sum of the 0-d loss terms as ONE stack + ONE reduction (Python's sum() is an add launch per term, starting from 0, and an
+    add / mul node per term on the way back); every term's gradient is the incoming one."""
+
+    @staticmethod
+    def forward(ctx, *vals):
+        return torch.stack([v.reshape(()) for v in vals]).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g for _ in ctx.needs_input_grad)
+
+
+def sum_losses(vals):
+    return _SumLossesFn.apply(*vals)
+
+
 def _bf16_layer_pointers(dn, layers, imgs):
     """[(image, b_dil, b_cond, b_out, dilation)] of the residual layers as integers, cached on the DiffNet while the tensors stay where they are
     (parameters are views of the optimizer's flat buffer; the images are rebuilt in place)."""
